@@ -1,0 +1,160 @@
+/*
+ * markovflow_amd - C ABI of the MI355X (gfx950) Kalman / block-tridiagonal hot path.
+ *
+ * This is the drop-in boundary.  In the reference the arithmetic of this path is reached through
+ * eight Python imports from the third-party TensorFlow-op library banded_matrices
+ * (/root/reference/markovflow/block_tri_diag.py:22-31) plus batched TensorFlow small-matrix ops
+ * (markovflow/state_space_model.py:431-483, markovflow/kalman_filter.py:86-271).  Each entry point
+ * below names the reference call it replaces.
+ *
+ * Conventions
+ *   - every pointer is a caller-owned DEVICE pointer, contiguous row-major, layout exactly the
+ *     reference's: matrices [B, T, d, d], vectors [B, T, d]; `sub` has T-1 blocks per series and
+ *     block k couples block k+1 (row) with block k (column);
+ *   - suffix _f32 / _f64 selects the scalar type; both are first class;
+ *   - nothing is allocated inside: scratch comes from the caller (`*_workspace_bytes` + `ws`);
+ *   - `stream` is a hipStream_t (passed as void*); all work is enqueued, nothing synchronises;
+ *   - `info` (nullable) is a device int the kernels raise to 1 on a non-positive pivot
+ *     (LAPACK info>0 style; results are then NaN);
+ *   - return value: 0 ok; -k = argument k (1-based) invalid; -100 = state dimension not
+ *     instantiated (1..9 in this build); -1000 = launch failure;
+ *   - re-entrant, no global state.
+ */
+#ifndef MARKOVFLOW_AMD_H
+#define MARKOVFLOW_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Library / build identification. */
+int mf_version(void);
+int mf_max_state_dim(void);
+
+/*
+ * KalmanFilter.log_likelihood, per series, fully fused
+ *   replaces markovflow/kalman_filter.py:184-255 and everything it calls:
+ *   _k_inv_post (:86-101), StateSpaceModel._build_precision (state_space_model.py:431-483),
+ *   SymmetricBlockTriDiagonal.cholesky (block_tri_diag.py:423-436 -> banded cholesky_band),
+ *   marginal_means (state_space_model.py:232-251), LowerTriangularBlockTriDiagonal.solve
+ *   (block_tri_diag.py:339-351 -> banded solve_triang_mat), abs_log_det (:353-366),
+ *   log_det_precision (state_space_model.py:343-373).
+ * Inputs: mu0 [B,d], cholP0 [B,d,d], A [B,T-1,d,d], b [B,T-1,d], cholQ [B,T-1,d,d],
+ *         H [B,T,m,d], y [B,T,m], Rinv [m,m] (rinv_per_step=0, KalmanFilter) or [B,T,m,m]
+ *         (rinv_per_step=1, KalmanFilterWithSites / WithSparseSites), 1 <= m <= 4.
+ * Output: out[s] = add_const + term1 + term2 + 1/2 log|K^-1| - log|L|  (kalman_filter.py:233-253), i.e. the
+ *         per-series log-likelihood; the terms that do not depend on the chain,
+ *         -1/2 m T log(2 pi) + 1/2 log|Sigma^-1|  (kalman_filter.py:229-231,249-253), are passed in add_const.
+ * chunks: number of time partitions per series (0 = choose automatically).
+ * prof_start / prof_stop: optional hipEvent_t (NULL = off) recorded on `stream` immediately before and after
+ *         the dominant (level-0) kernel, so a caller can time that kernel alone.
+ */
+size_t mf_kf_loglik_workspace_bytes(int64_t B, int64_t T, int d, int elem_size, int64_t chunks);
+int mf_kf_loglik_f64(int64_t B, int64_t T, int d, int m, const double* mu0, const double* cholP0,
+                     const double* A, const double* b, const double* cholQ, const double* H, const double* y,
+                     const double* Rinv, int rinv_per_step, double add_const, double* out, void* ws,
+                     size_t ws_bytes, int* info, int64_t chunks, void* prof_start, void* prof_stop, void* stream);
+int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const float* cholP0,
+                     const float* A, const float* b, const float* cholQ, const float* H, const float* y,
+                     const float* Rinv, int rinv_per_step, float add_const, float* out, void* ws,
+                     size_t ws_bytes, int* info, int64_t chunks, void* prof_start, void* prof_stop, void* stream);
+
+/*
+ * SymmetricBlockTriDiagonal.cholesky  (block_tri_diag.py:423-436; banded cholesky_band +
+ * block_to_band/band_to_block layout shuffles, which do not exist here).  Natural order:
+ * L_0 = chol(D_0), W_{k-1} = S_{k-1} L_{k-1}^-T, L_k = chol(D_k - W_{k-1} W_{k-1}^T).
+ * sub / lsub may be NULL (block-diagonal matrix).  Only the lower triangle of diag is read.
+ */
+int mf_btd_cholesky_f64(int64_t B, int64_t T, int d, const double* diag, const double* sub, double* ldiag,
+                        double* lsub, int* info, void* stream);
+int mf_btd_cholesky_f32(int64_t B, int64_t T, int d, const float* diag, const float* sub, float* ldiag,
+                        float* lsub, int* info, void* stream);
+
+/*
+ * LowerTriangularBlockTriDiagonal.solve  (block_tri_diag.py:339-351; banded solve_triang_mat):
+ * out = L^-1 rhs (transpose=0) or L^-T rhs (transpose=1).  rhs/out are [Br,T,d]; rhs series r uses the
+ * factor of series r % Bl (Br a multiple of Bl: extra leading dims, state_space_model.py:307-322).
+ */
+int mf_btd_solve_f64(int64_t Bl, int64_t Br, int64_t T, int d, const double* ldiag, const double* lsub,
+                     const double* rhs, double* out, int transpose, void* stream);
+int mf_btd_solve_f32(int64_t Bl, int64_t Br, int64_t T, int d, const float* ldiag, const float* lsub,
+                     const float* rhs, float* out, int transpose, void* stream);
+
+/*
+ * BlockTriDiagonal.dense_mult  (block_tri_diag.py:175-199; banded product_band_mat).
+ * mode 0: M x for lower-triangular M; 1: M^T x; 2: symmetric M x (lower triangle mirrored).
+ */
+int mf_btd_matvec_f64(int64_t Bl, int64_t Br, int64_t T, int d, const double* diag, const double* sub,
+                      const double* x, double* out, int mode, void* stream);
+int mf_btd_matvec_f32(int64_t Bl, int64_t Br, int64_t T, int d, const float* diag, const float* sub,
+                      const float* x, float* out, int mode, void* stream);
+
+/* LowerTriangularBlockTriDiagonal.abs_log_det  (block_tri_diag.py:353-366): out [B]. */
+int mf_btd_logdet_f64(int64_t B, int64_t T, int d, const double* ldiag, double* out, void* stream);
+int mf_btd_logdet_f32(int64_t B, int64_t T, int d, const float* ldiag, float* out, void* stream);
+
+/*
+ * Fused scalar form of cholesky + solve + abs_log_det on an explicit (diag, sub, rhs):
+ * out[s] = 1/2 |L^-1 rhs|^2 - log|L|, computed by partitioned (block cyclic reduction style)
+ * elimination in time; this is what the log-likelihood of the sites variants reduces to.
+ */
+size_t mf_btd_logdet_quad_workspace_bytes(int64_t B, int64_t T, int d, int elem_size);
+int mf_btd_logdet_quad_f64(int64_t B, int64_t T, int d, const double* diag, const double* sub, const double* rhs,
+                           double* out, void* ws, size_t ws_bytes, int* info, void* stream);
+int mf_btd_logdet_quad_f32(int64_t B, int64_t T, int d, const float* diag, const float* sub, const float* rhs,
+                           float* out, void* ws, size_t ws_bytes, int* info, void* stream);
+
+/*
+ * LowerTriangularBlockTriDiagonal.block_diagonal_of_inverse  (block_tri_diag.py:318-337; banded
+ * inverse_from_cholesky_band): diagonal blocks of (L L^T)^-1 into odiag [B,T,d,d]; if osub != NULL also
+ * the sub-diagonal blocks [B,T-1,d,d] (what ssm_gaussian_transformations.py:453-458 reads).
+ */
+int mf_btd_diag_of_inverse_f64(int64_t B, int64_t T, int d, const double* ldiag, const double* lsub,
+                               double* odiag, double* osub, void* stream);
+int mf_btd_diag_of_inverse_f32(int64_t B, int64_t T, int d, const float* ldiag, const float* lsub, float* odiag,
+                               float* osub, void* stream);
+
+/*
+ * SymmetricBlockTriDiagonal.upper_diagonal_lower  (block_tri_diag.py:438-545, the tf.while_loop):
+ * ut [B,T-1,d,d] = U_k^T, chol_d [B,T,d,d] = chol(Delta_k).
+ * With eta != NULL ([B,T,d]) it additionally runs the rest of
+ * BaseKalmanFilter.posterior_state_space_model (kalman_filter.py:159-174) in the same sweep:
+ * m_post [B,T,d] = [mu0', b'_1...] and chol_dinv [B,T,d,d] = chol(Delta_k^-1) = [cholP0', cholQ'_1...].
+ */
+int mf_btd_udl_f64(int64_t B, int64_t T, int d, const double* diag, const double* sub, double* ut, double* chol_d,
+                   const double* eta, double* m_post, double* chol_dinv, int* info, void* stream);
+int mf_btd_udl_f32(int64_t B, int64_t T, int d, const float* diag, const float* sub, float* ut, float* chol_d,
+                   const float* eta, float* m_post, float* chol_dinv, int* info, void* stream);
+
+/*
+ * StateSpaceModel._build_precision (state_space_model.py:431-483), optionally + H^T R^-1 H
+ * (kalman_filter.py:86-101) and the posterior information vector
+ * eta = G^T Sigma^-1 y + K^-1 mu (kalman_filter.py:153-156).
+ * H == NULL: prior precision only.  y == NULL: no observation term in eta.  eta == NULL: not computed
+ * (mu0, b may then be NULL).  diag [B,T,d,d], sub [B,T-1,d,d], eta [B,T,d].
+ */
+int mf_ssm_precision_f64(int64_t B, int64_t T, int d, int m, const double* mu0, const double* cholP0,
+                         const double* A, const double* b, const double* cholQ, const double* H, const double* y,
+                         const double* Rinv, int rinv_per_step, double* diag, double* sub, double* eta,
+                         void* stream);
+int mf_ssm_precision_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const float* cholP0, const float* A,
+                         const float* b, const float* cholQ, const float* H, const float* y, const float* Rinv,
+                         int rinv_per_step, float* diag, float* sub, float* eta, void* stream);
+
+/*
+ * StateSpaceModel.marginal_means / sample  (state_space_model.py:232-251,298-324): solves
+ * (A^-1 block) x = offs, i.e. x_0 = offs_0, x_k = A_k x_{k-1} + offs_k.  offs/out [Br,T,d]; series r uses
+ * the transitions of series r % Bl.
+ */
+int mf_ssm_marginal_means_f64(int64_t Bl, int64_t Br, int64_t T, int d, const double* A, const double* offs,
+                              double* out, void* stream);
+int mf_ssm_marginal_means_f32(int64_t Bl, int64_t Br, int64_t T, int d, const float* A, const float* offs,
+                              float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MARKOVFLOW_AMD_H */

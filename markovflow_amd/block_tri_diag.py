@@ -1,0 +1,247 @@
+"""
+Block-tridiagonal operators on the MI355X.
+
+Mirror of ``markovflow/block_tri_diag.py`` (reference): same class names, constructor arguments,
+method names and meaning, but tensors are ``torch`` HIP tensors and every method dispatches to a
+hand-written HIP kernel through the C ABI (``include/markovflow_amd.h``).  The reference's band
+layout and its block<->band conversions (block_tri_diag.py:206-237,549-592) do not exist here:
+the native layout IS ``[..., outer_dim, inner_dim, inner_dim]``.
+"""
+import abc
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+
+def _flat(t: torch.Tensor, tail: int) -> torch.Tensor:
+    """Collapse leading batch dims: [..., <tail dims>] -> [B, <tail dims>] contiguous."""
+    return t.reshape((-1,) + tuple(t.shape[-tail:])).contiguous()
+
+
+class BlockTriDiagonal(abc.ABC):
+    """Abstract block tridiagonal matrix (reference: block_tri_diag.py:37-288)."""
+
+    def __init__(self, diagonal: torch.Tensor, symmetric: bool, sub_diagonal: Optional[torch.Tensor] = None) -> None:
+        """
+        :param diagonal: ``[... outer_dim, inner_dim, inner_dim]``.
+        :param symmetric: whether the matrix is symmetric.
+        :param sub_diagonal: ``[... outer_dim - 1, inner_dim, inner_dim]`` or None.
+        """
+        if diagonal.dim() < 3:
+            raise ValueError(f"diagonal must be at least 3D but has shape {tuple(diagonal.shape)}")
+        if diagonal.shape[-1] != diagonal.shape[-2]:
+            raise ValueError("Last two dimensions of the block diagonal must match.")  # block_tri_diag.py:55-59
+        self._diag = diagonal
+        if sub_diagonal is not None:
+            if self.outer_dim <= 1:
+                raise ValueError("There is no sub-diagonal with outer dimension of one.")  # :68-74
+            shape = tuple(self.batch_shape) + (self.outer_dim - 1, self.inner_dim, self.inner_dim)
+            if tuple(sub_diagonal.shape) != shape:
+                raise ValueError(f"Sub_diagonal has shape {tuple(sub_diagonal.shape)} but must have shape: {shape}")
+            if sub_diagonal.dtype != diagonal.dtype or sub_diagonal.device != diagonal.device:
+                raise ValueError("diagonal and sub_diagonal must share dtype and device")
+        self._sub_diag = sub_diagonal
+        self._symmetric = symmetric
+
+    # -- shape properties (block_tri_diag.py:100-148) ------------------------------------------------
+    @property
+    def bandwidth(self) -> int:
+        bandwidth = self.inner_dim - 1
+        if self._sub_diag is not None:
+            bandwidth += self.inner_dim
+        return bandwidth
+
+    @property
+    def batch_shape(self) -> torch.Size:
+        return self._diag.shape[:-3]
+
+    @property
+    def inner_dim(self) -> int:
+        return self._diag.shape[-2]
+
+    @property
+    def outer_dim(self) -> int:
+        return self._diag.shape[-3]
+
+    @property
+    def block_diagonal(self) -> torch.Tensor:
+        return self._diag
+
+    @property
+    def block_sub_diagonal(self) -> Optional[torch.Tensor]:
+        return self._sub_diag
+
+    @property
+    def _batch_numel(self) -> int:
+        n = 1
+        for s in self.batch_shape:
+            n *= s
+        return n
+
+    # -- dense view, for tests (block_tri_diag.py:150-173) --------------------------------------------
+    def to_dense(self) -> torch.Tensor:
+        n, d = self.outer_dim, self.inner_dim
+        dense = self._diag.new_zeros(tuple(self.batch_shape) + (n * d, n * d))
+        lower_blocks = torch.tril(self._diag)
+        for i in range(n):
+            dense[..., i * d:(i + 1) * d, i * d:(i + 1) * d] = lower_blocks[..., i, :, :]
+            if self._sub_diag is not None and i < n - 1:
+                dense[..., (i + 1) * d:(i + 2) * d, i * d:(i + 1) * d] = self._sub_diag[..., i, :, :]
+        if self._symmetric:
+            dg = torch.diagonal(dense, dim1=-2, dim2=-1)
+            dense = dense + dense.transpose(-1, -2) - torch.diag_embed(dg)
+        return dense
+
+    # -- products (block_tri_diag.py:175-199) ----------------------------------------------------------
+    def dense_mult(self, right: torch.Tensor, transpose_left: bool = False) -> torch.Tensor:
+        """``L x`` (or ``Lᵀ x``; symmetric objects ignore nothing: transposing them is a no-op)."""
+        right_b, out_shape = self._broadcast_right(right)
+        mode = 2 if self._symmetric else (1 if transpose_left else 0)
+        out = torch.empty_like(right_b)
+        sub = None if self._sub_diag is None else _flat(self._sub_diag, 3)
+        _lib.call("mf_btd_matvec", self._diag.dtype, self._batch_numel, right_b.shape[0], self.outer_dim,
+                  self.inner_dim, _lib.ptr(_flat(self._diag, 3)), _lib.ptr(sub), _lib.ptr(right_b), _lib.ptr(out),
+                  mode, _lib.stream_ptr(self._diag.device))
+        return out.reshape(out_shape)
+
+    @abc.abstractmethod
+    def __add__(self, other):
+        raise NotImplementedError
+
+    def _add_parts(self, other: "BlockTriDiagonal") -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        # block_tri_diag.py:368-380,412-421
+        if self._sub_diag is not None:
+            sub_diag = self._sub_diag
+            if other.block_sub_diagonal is not None:
+                sub_diag = sub_diag + other.block_sub_diagonal
+        else:
+            sub_diag = other.block_sub_diagonal
+        return self._diag + other.block_diagonal, sub_diag
+
+    # -- right-hand sides (block_tri_diag.py:239-287) ---------------------------------------------------
+    def _assert_compatible_right_shape(self, right: torch.Tensor) -> None:
+        if right.dim() < 2 or tuple(right.shape[-2:]) != (self.outer_dim, self.inner_dim):
+            raise ValueError(
+                f"right has shape {tuple(right.shape)} but its last two dims must be "
+                f"({self.outer_dim}, {self.inner_dim})"
+            )
+        if right.dim() > 2:
+            nb = len(self.batch_shape)
+            rb = tuple(right.shape[-(2 + nb):-2]) if right.dim() >= 2 + nb else tuple(right.shape[:-2])
+            mine = tuple(self.batch_shape)[len(self.batch_shape) - len(rb):]
+            for a, b in zip(rb, mine):
+                if not (a == b or a == 1 or b == 1):
+                    raise ValueError(f"right batch shape {rb} is not compatible with {tuple(self.batch_shape)}")
+        if right.dtype != self._diag.dtype or right.device != self._diag.device:
+            raise ValueError("right must share dtype and device with the operator")
+
+    def _broadcast_right(self, right: torch.Tensor):
+        """Return ``right`` as [Br, T, d] with Br a multiple of the operator's flattened batch, + output shape."""
+        self._assert_compatible_right_shape(right)
+        batch = tuple(self.batch_shape)
+        lead = tuple(right.shape[:-2])
+        full = tuple(torch.broadcast_shapes(lead, batch))
+        # the operator must not be broadcast (that would need copies of the factor): only leading extra dims
+        if tuple(full[len(full) - len(batch):]) != batch:
+            raise ValueError(
+                f"right batch shape {lead} would broadcast the operator batch {batch}; expand the operator instead"
+            )
+        right_b = right.expand(full + tuple(right.shape[-2:])).reshape(-1, self.outer_dim, self.inner_dim).contiguous()
+        return right_b, full + (self.outer_dim, self.inner_dim)
+
+
+class LowerTriangularBlockTriDiagonal(BlockTriDiagonal):
+    """Lower triangular block tridiagonal matrix (reference: block_tri_diag.py:291-380)."""
+
+    def __init__(self, diagonal: torch.Tensor, sub_diagonal: Optional[torch.Tensor] = None) -> None:
+        super().__init__(diagonal, symmetric=False, sub_diagonal=sub_diagonal)
+
+    def block_diagonal_of_inverse(self) -> torch.Tensor:
+        """Diagonal blocks of ``(L Lᵀ)⁻¹`` (block_tri_diag.py:318-337)."""
+        return self._diag_and_sub_of_inverse(want_sub=False)[0]
+
+    def _diag_and_sub_of_inverse(self, want_sub: bool):
+        diag = _flat(self._diag, 3)
+        sub = None if self._sub_diag is None else _flat(self._sub_diag, 3)
+        odiag = torch.empty_like(diag)
+        osub = torch.empty_like(sub) if (want_sub and sub is not None) else None
+        _lib.call("mf_btd_diag_of_inverse", diag.dtype, diag.shape[0], self.outer_dim, self.inner_dim,
+                  _lib.ptr(diag), _lib.ptr(sub), _lib.ptr(odiag), _lib.ptr(osub), _lib.stream_ptr(diag.device))
+        odiag = odiag.reshape(self._diag.shape)
+        if osub is not None:
+            osub = osub.reshape(self._sub_diag.shape)
+        return odiag, osub
+
+    def solve(self, right: torch.Tensor, transpose_left: bool = False) -> torch.Tensor:
+        """``L⁻¹ x`` or ``L⁻ᵀ x`` (block_tri_diag.py:339-351)."""
+        right_b, out_shape = self._broadcast_right(right)
+        diag = _flat(self._diag, 3)
+        sub = None if self._sub_diag is None else _flat(self._sub_diag, 3)
+        out = torch.empty_like(right_b)
+        _lib.call("mf_btd_solve", diag.dtype, diag.shape[0], right_b.shape[0], self.outer_dim, self.inner_dim,
+                  _lib.ptr(diag), _lib.ptr(sub), _lib.ptr(right_b), _lib.ptr(out), int(transpose_left),
+                  _lib.stream_ptr(diag.device))
+        return out.reshape(out_shape)
+
+    def abs_log_det(self) -> torch.Tensor:
+        """``log |det L|`` with shape ``batch_shape`` (block_tri_diag.py:353-366)."""
+        diag = _flat(self._diag, 3)
+        out = torch.empty(diag.shape[0], dtype=diag.dtype, device=diag.device)
+        _lib.call("mf_btd_logdet", diag.dtype, diag.shape[0], self.outer_dim, self.inner_dim, _lib.ptr(diag),
+                  _lib.ptr(out), _lib.stream_ptr(diag.device))
+        return out.reshape(tuple(self.batch_shape))
+
+    def __add__(self, other: "LowerTriangularBlockTriDiagonal") -> "LowerTriangularBlockTriDiagonal":
+        return LowerTriangularBlockTriDiagonal(*self._add_parts(other))
+
+
+class SymmetricBlockTriDiagonal(BlockTriDiagonal):
+    """Symmetric block tridiagonal matrix - the form of every precision (block_tri_diag.py:384-545)."""
+
+    def __init__(self, diagonal: torch.Tensor, sub_diagonal: Optional[torch.Tensor] = None) -> None:
+        super().__init__(diagonal, symmetric=True, sub_diagonal=sub_diagonal)
+
+    def __add__(self, other: "SymmetricBlockTriDiagonal") -> "SymmetricBlockTriDiagonal":
+        return SymmetricBlockTriDiagonal(*self._add_parts(other))
+
+    @property
+    def cholesky(self) -> LowerTriangularBlockTriDiagonal:
+        """Natural-order Cholesky factor (block_tri_diag.py:423-436)."""
+        diag = _flat(self._diag, 3)
+        sub = None if self._sub_diag is None else _flat(self._sub_diag, 3)
+        ldiag = torch.empty_like(diag)
+        lsub = None if sub is None else torch.empty_like(sub)
+        info = _lib.new_info(diag.device)
+        _lib.call("mf_btd_cholesky", diag.dtype, diag.shape[0], self.outer_dim, self.inner_dim, _lib.ptr(diag),
+                  _lib.ptr(sub), _lib.ptr(ldiag), _lib.ptr(lsub), _lib.ptr(info), _lib.stream_ptr(diag.device))
+        _lib.raise_on_info(info, "SymmetricBlockTriDiagonal.cholesky")
+        return LowerTriangularBlockTriDiagonal(
+            ldiag.reshape(self._diag.shape), None if lsub is None else lsub.reshape(self._sub_diag.shape)
+        )
+
+    def upper_diagonal_lower(self) -> Tuple[LowerTriangularBlockTriDiagonal, LowerTriangularBlockTriDiagonal]:
+        """``U D Uᵀ`` factorisation; returns ``(Uᵀ, chol_D)`` (block_tri_diag.py:438-545)."""
+        assert self._sub_diag is not None  # block_tri_diag.py:486
+        u_t, chol_d, _, _ = self._udl(None)
+        identities = torch.eye(self.inner_dim, dtype=self._diag.dtype, device=self._diag.device).expand(
+            self._diag.shape).contiguous()
+        return LowerTriangularBlockTriDiagonal(identities, u_t), LowerTriangularBlockTriDiagonal(chol_d)
+
+    def _udl(self, eta: Optional[torch.Tensor]):
+        diag, sub = _flat(self._diag, 3), _flat(self._sub_diag, 3)
+        u_t, chol_d = torch.empty_like(sub), torch.empty_like(diag)
+        m_post = chol_dinv = eta_f = None
+        if eta is not None:
+            eta_f = _flat(eta, 2)
+            m_post, chol_dinv = torch.empty_like(eta_f), torch.empty_like(diag)
+        info = _lib.new_info(diag.device)
+        _lib.call("mf_btd_udl", diag.dtype, diag.shape[0], self.outer_dim, self.inner_dim, _lib.ptr(diag),
+                  _lib.ptr(sub), _lib.ptr(u_t), _lib.ptr(chol_d), _lib.ptr(eta_f), _lib.ptr(m_post),
+                  _lib.ptr(chol_dinv), _lib.ptr(info), _lib.stream_ptr(diag.device))
+        _lib.raise_on_info(info, "SymmetricBlockTriDiagonal.upper_diagonal_lower")
+        u_t, chol_d = u_t.reshape(self._sub_diag.shape), chol_d.reshape(self._diag.shape)
+        if eta is not None:
+            m_post, chol_dinv = m_post.reshape(eta.shape), chol_dinv.reshape(self._diag.shape)
+        return u_t, chol_d, m_post, chol_dinv

@@ -1,0 +1,179 @@
+// extern "C" entry points of include/markovflow_amd.h: argument checks + dispatch on the state dimension.
+#include "../../include/markovflow_amd.h"
+#include "mf_launch.hpp"
+
+namespace {
+
+template <typename T> const mf::OpsTable<T>* table_for(int d);
+#define MF_CASE(D) case D: return mf::ops_f32_d##D();
+template <> const mf::OpsTable<float>* table_for<float>(int d) {
+    switch (d) {
+        MF_CASE(1) MF_CASE(2) MF_CASE(3) MF_CASE(4) MF_CASE(5) MF_CASE(6) MF_CASE(7) MF_CASE(8) MF_CASE(9)
+        default: return nullptr;
+    }
+}
+#undef MF_CASE
+#define MF_CASE(D) case D: return mf::ops_f64_d##D();
+template <> const mf::OpsTable<double>* table_for<double>(int d) {
+    switch (d) {
+        MF_CASE(1) MF_CASE(2) MF_CASE(3) MF_CASE(4) MF_CASE(5) MF_CASE(6) MF_CASE(7) MF_CASE(8) MF_CASE(9)
+        default: return nullptr;
+    }
+}
+#undef MF_CASE
+
+inline hipStream_t S(void* s) { return static_cast<hipStream_t>(s); }
+
+template <typename T>
+int kf_loglik(int64_t B, int64_t Tn, int d, int m, const T* mu0, const T* cholP0, const T* A, const T* b,
+              const T* cholQ, const T* H, const T* y, const T* Rinv, int rinv_per_step, T add_const, T* out, void* ws,
+              size_t ws_bytes, int* info, int64_t chunks, void* ev0, void* ev1, void* stream) {
+    if (B < 0) return -1;
+    if (Tn < 1) return -2;
+    const auto* t = table_for<T>(d);
+    if (!t) return d < 1 ? -3 : -100;
+    if (m < 1 || m > 4) return -4;
+    if (B == 0) return 0;
+    if (!mu0) return -5;
+    if (!cholP0) return -6;
+    if (Tn > 1 && (!A || !b || !cholQ)) return -7;
+    if (!H) return -10;
+    if (!y) return -11;
+    if (!Rinv) return -12;
+    if (!out) return -15;
+    return t->kf_loglik(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, add_const, out, ws, ws_bytes,
+                        info, chunks, static_cast<hipEvent_t>(ev0), static_cast<hipEvent_t>(ev1), S(stream));
+}
+
+}  // namespace
+
+extern "C" {
+
+int mf_version(void) { return 1; }
+int mf_max_state_dim(void) { return mf::MF_MAX_D; }
+
+size_t mf_kf_loglik_workspace_bytes(int64_t B, int64_t T, int d, int elem_size, int64_t chunks) {
+    if (elem_size == 4) { const auto* t = table_for<float>(d); return t ? t->kf_loglik_ws(B, T, chunks) : 0; }
+    const auto* t = table_for<double>(d);
+    return t ? t->kf_loglik_ws(B, T, chunks) : 0;
+}
+
+int mf_kf_loglik_f64(int64_t B, int64_t T, int d, int m, const double* mu0, const double* cholP0, const double* A,
+                     const double* b, const double* cholQ, const double* H, const double* y, const double* Rinv,
+                     int rinv_per_step, double add_const, double* out, void* ws, size_t ws_bytes, int* info,
+                     int64_t chunks, void* prof_start, void* prof_stop, void* stream) {
+    return kf_loglik<double>(B, T, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, add_const, out, ws,
+                             ws_bytes, info, chunks, prof_start, prof_stop, stream);
+}
+int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const float* cholP0, const float* A,
+                     const float* b, const float* cholQ, const float* H, const float* y, const float* Rinv,
+                     int rinv_per_step, float add_const, float* out, void* ws, size_t ws_bytes, int* info,
+                     int64_t chunks, void* prof_start, void* prof_stop, void* stream) {
+    return kf_loglik<float>(B, T, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, add_const, out, ws,
+                            ws_bytes, info, chunks, prof_start, prof_stop, stream);
+}
+
+#define MF_HEAD(T, B, Tn, d)                       \
+    if ((B) < 0) return -1;                        \
+    if ((Tn) < 1) return -2;                       \
+    const auto* t = table_for<T>(d);               \
+    if (!t) return (d) < 1 ? -3 : -100;            \
+    if ((B) == 0) return 0;
+
+#define MF_DEFINE(SUF, T)                                                                                              \
+    int mf_btd_cholesky_##SUF(int64_t B, int64_t Tn, int d, const T* diag, const T* sub, T* ldiag, T* lsub, int* info, \
+                              void* stream) {                                                                          \
+        MF_HEAD(T, B, Tn, d)                                                                                           \
+        if (!diag) return -4;                                                                                          \
+        if (!ldiag) return -6;                                                                                         \
+        if (sub && !lsub) return -7;                                                                                   \
+        if (Tn == 1) sub = nullptr;                                                                                    \
+        return t->btd_cholesky(B, Tn, diag, sub, ldiag, lsub, info, S(stream));                                        \
+    }                                                                                                                  \
+    int mf_btd_solve_##SUF(int64_t Bl, int64_t Br, int64_t Tn, int d, const T* ldiag, const T* lsub, const T* rhs,     \
+                           T* out, int transpose, void* stream) {                                                      \
+        MF_HEAD(T, Br, Tn, d)                                                                                          \
+        if (Bl < 1 || Br % Bl != 0) return -1;                                                                         \
+        if (!ldiag) return -5;                                                                                         \
+        if (!rhs) return -7;                                                                                           \
+        if (!out) return -8;                                                                                           \
+        if (Tn == 1) lsub = nullptr;                                                                                   \
+        return t->btd_solve(Bl, Br, Tn, ldiag, lsub, rhs, out, transpose, S(stream));                                  \
+    }                                                                                                                  \
+    int mf_btd_matvec_##SUF(int64_t Bl, int64_t Br, int64_t Tn, int d, const T* diag, const T* sub, const T* x,        \
+                            T* out, int mode, void* stream) {                                                          \
+        MF_HEAD(T, Br, Tn, d)                                                                                          \
+        if (Bl < 1 || Br % Bl != 0) return -1;                                                                         \
+        if (!diag) return -5;                                                                                          \
+        if (!x) return -7;                                                                                             \
+        if (!out) return -8;                                                                                           \
+        if (mode < 0 || mode > 2) return -9;                                                                           \
+        if (Tn == 1) sub = nullptr;                                                                                    \
+        return t->btd_matvec(Bl, Br, Tn, diag, sub, x, out, mode, S(stream));                                          \
+    }                                                                                                                  \
+    int mf_btd_logdet_##SUF(int64_t B, int64_t Tn, int d, const T* ldiag, T* out, void* stream) {                      \
+        MF_HEAD(T, B, Tn, d)                                                                                           \
+        if (!ldiag) return -4;                                                                                         \
+        if (!out) return -5;                                                                                           \
+        return t->btd_logdet(B, Tn, ldiag, out, S(stream));                                                            \
+    }                                                                                                                  \
+    int mf_btd_logdet_quad_##SUF(int64_t B, int64_t Tn, int d, const T* diag, const T* sub, const T* rhs, T* out,      \
+                                 void* ws, size_t ws_bytes, int* info, void* stream) {                                 \
+        MF_HEAD(T, B, Tn, d)                                                                                           \
+        if (!diag) return -4;                                                                                          \
+        if (Tn > 1 && !sub) return -5;                                                                                 \
+        if (!rhs) return -6;                                                                                           \
+        if (!out) return -7;                                                                                           \
+        return t->btd_logdet_quad(B, Tn, diag, sub, rhs, out, ws, ws_bytes, info, 0, S(stream));                       \
+    }                                                                                                                  \
+    int mf_btd_diag_of_inverse_##SUF(int64_t B, int64_t Tn, int d, const T* ldiag, const T* lsub, T* odiag, T* osub,   \
+                                     void* stream) {                                                                   \
+        MF_HEAD(T, B, Tn, d)                                                                                           \
+        if (!ldiag) return -4;                                                                                         \
+        if (!odiag) return -6;                                                                                         \
+        if (Tn == 1) lsub = nullptr;                                                                                   \
+        if (!lsub) osub = nullptr;                                                                                     \
+        return t->btd_diag_of_inverse(B, Tn, ldiag, lsub, odiag, osub, S(stream));                                     \
+    }                                                                                                                  \
+    int mf_btd_udl_##SUF(int64_t B, int64_t Tn, int d, const T* diag, const T* sub, T* ut, T* chol_d, const T* eta,    \
+                         T* m_post, T* chol_dinv, int* info, void* stream) {                                           \
+        MF_HEAD(T, B, Tn, d)                                                                                           \
+        if (!diag) return -4;                                                                                          \
+        if (Tn > 1 && (!sub || !ut)) return -5;                                                                        \
+        if (!chol_d) return -7;                                                                                        \
+        if (eta && (!m_post || !chol_dinv)) return -9;                                                                 \
+        return t->btd_udl(B, Tn, diag, sub, ut, chol_d, eta, m_post, chol_dinv, info, S(stream));                      \
+    }                                                                                                                  \
+    int mf_ssm_precision_##SUF(int64_t B, int64_t Tn, int d, int m, const T* mu0, const T* cholP0, const T* A,         \
+                               const T* b, const T* cholQ, const T* H, const T* y, const T* Rinv, int rinv_per_step,   \
+                               T* diag, T* sub, T* eta, void* stream) {                                                \
+        MF_HEAD(T, B, Tn, d)                                                                                           \
+        if (!cholP0) return -6;                                                                                        \
+        if (Tn > 1 && (!A || !cholQ || !sub)) return -7;                                                               \
+        if (H && !Rinv) return -12;                                                                                    \
+        if (H && (m < 1 || m > 4)) return -4;                                                                          \
+        if (!diag) return -14;                                                                                         \
+        if (eta && (!mu0 || (Tn > 1 && !b))) return -5;                                                                \
+        return t->ssm_precision(B, Tn, H ? m : 1, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, diag, sub, eta, \
+                                S(stream));                                                                            \
+    }                                                                                                                  \
+    int mf_ssm_marginal_means_##SUF(int64_t Bl, int64_t Br, int64_t Tn, int d, const T* A, const T* offs, T* out,      \
+                                    void* stream) {                                                                    \
+        MF_HEAD(T, Br, Tn, d)                                                                                          \
+        if (Bl < 1 || Br % Bl != 0) return -1;                                                                         \
+        if (Tn > 1 && !A) return -5;                                                                                   \
+        if (!offs) return -6;                                                                                          \
+        if (!out) return -7;                                                                                           \
+        return t->ssm_means(Bl, Br, Tn, A, offs, out, S(stream));                                                      \
+    }
+
+MF_DEFINE(f64, double)
+MF_DEFINE(f32, float)
+
+size_t mf_btd_logdet_quad_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {
+    if (elem_size == 4) { const auto* t = table_for<float>(d); return t ? t->btd_logdet_quad_ws(B, T, 0) : 0; }
+    const auto* t = table_for<double>(d);
+    return t ? t->btd_logdet_quad_ws(B, T, 0) : 0;
+}
+
+}  // extern "C"

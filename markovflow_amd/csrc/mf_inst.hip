@@ -1,0 +1,216 @@
+// Instantiates every kernel for ONE state dimension (compile with -DMF_D=<d>) and both scalar types,
+// and exports the launch tables declared in mf_launch.hpp.
+#ifndef MF_D
+#error "compile with -DMF_D=<state dimension>"
+#endif
+#include "mf_kernels.hpp"
+#include "mf_launch.hpp"
+
+#include <cstdlib>
+
+namespace mf {
+namespace {
+
+constexpr int D = MF_D;
+constexpr long RED_CHUNK = 8;    // chunk length of the intermediate reduction levels
+constexpr long RED_FINAL = 8;    // the last level is walked serially once at most this many blocks remain
+
+inline long cdiv(long a, long b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
+
+// elements per reduced block: Dv, GU, F (D*D each), tv, gU (D each), sc (1)
+constexpr long RED_ELEMS = 3 * D * D + 2 * D + 1;
+
+template <typename T> size_t red_bytes(long B, long n) { return align_up(size_t(B) * n * RED_ELEMS * sizeof(T)); }
+
+template <typename T> RedSys<T> carve(char*& p, long B, long n) {
+    RedSys<T> r;
+    T* base = reinterpret_cast<T*>(p);
+    const long nb = B * n;
+    r.Dv = base;
+    r.GU = r.Dv + nb * D * D;
+    r.F = r.GU + nb * D * D;
+    r.tv = r.F + nb * D * D;
+    r.gU = r.tv + nb * D;
+    r.sc = r.gU + nb * D;
+    r.n = n;
+    r.f_stride = n;
+    r.f_off = 0;
+    p += red_bytes<T>(B, n);
+    return r;
+}
+
+// Number of level-0 chunks per series: enough sub-problems to put one wavefront on every SIMD
+// (256 CUs x 4 SIMDs x 64 lanes), but never chunks shorter than 4 blocks.
+inline long auto_chunks(long B, long n) {
+    static const long target = [] {
+        const char* e = std::getenv("MF_TARGET_LANES");
+        return e ? std::atol(e) : 65536L;
+    }();
+    long P = cdiv(target, B);
+    const long maxP = n / 4 > 0 ? n / 4 : 1;
+    if (P > maxP) P = maxP;
+    if (P < 1) P = 1;
+    return P;
+}
+
+template <typename T> size_t levels_ws(long B, long P) {
+    size_t total = red_bytes<T>(B, P);
+    long n = P;
+    while (n > RED_FINAL) {
+        n = cdiv(n, RED_CHUNK);
+        total += red_bytes<T>(B, n);
+    }
+    return total;
+}
+
+// Reduce `cur` (already in workspace or user memory) down to a scalar per series.
+template <typename T>
+int reduce_levels(RedSys<T> cur, long B, char* p, T add_const, T* out, int* info, hipStream_t st) {
+    while (cur.n > RED_FINAL) {
+        const long P = cdiv(cur.n, RED_CHUNK);
+        RedSys<T> nxt = carve<T>(p, B, P);
+        const long lanes = B * P;
+        hipLaunchKernelGGL((red_chunk_kernel<T, D, true>), dim3((unsigned)cdiv(lanes, 64)), dim3(64), 0, st, cur, nxt, B,
+                           P, info);
+        cur = nxt;
+    }
+    hipLaunchKernelGGL((red_final_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, cur, B, add_const, out,
+                       info);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+template <typename T> size_t kf_loglik_ws(long B, long Tn, long chunks) {
+    const long P = chunks > 0 ? (chunks > Tn ? Tn : chunks) : auto_chunks(B, Tn);
+    return levels_ws<T>(B, P);
+}
+
+template <typename T>
+int kf_loglik(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ,
+              const T* H, const T* y, const T* Rinv, int rinv_per_step, T add_const, T* out, void* ws,
+              size_t ws_bytes, int* info, long chunks, hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
+    if (m < 1 || m > MF_MAXM) return -4;
+    const long P = chunks > 0 ? (chunks > Tn ? Tn : chunks) : auto_chunks(B, Tn);
+    if (ws_bytes < levels_ws<T>(B, P) || ws == nullptr) return -15;
+    KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, info};
+    char* p = static_cast<char*>(ws);
+    RedSys<T> lvl0 = carve<T>(p, B, P);
+    const long lanes = B * P;
+    const dim3 grid((unsigned)cdiv(lanes, 64)), block(64);
+    if (ev0) (void)hipEventRecord(ev0, st);
+    if (P > 1) {
+        if (m == 1) hipLaunchKernelGGL((kf_chunk_kernel<T, D, 1, true>), grid, block, 0, st, a, lvl0);
+        else hipLaunchKernelGGL((kf_chunk_kernel<T, D, 0, true>), grid, block, 0, st, a, lvl0);
+    } else {
+        if (m == 1) hipLaunchKernelGGL((kf_chunk_kernel<T, D, 1, false>), grid, block, 0, st, a, lvl0);
+        else hipLaunchKernelGGL((kf_chunk_kernel<T, D, 0, false>), grid, block, 0, st, a, lvl0);
+    }
+    if (ev1) (void)hipEventRecord(ev1, st);
+    return reduce_levels<T>(lvl0, B, p, add_const, out, info, st);
+}
+
+template <typename T> size_t btd_logdet_quad_ws(long B, long n, long chunks) {
+    (void)chunks;
+    long nn = n;
+    size_t total = 256;
+    while (nn > RED_FINAL) {
+        nn = cdiv(nn, RED_CHUNK);
+        total += red_bytes<T>(B, nn);
+    }
+    return total;
+}
+
+// out[s] = 0.5 |L^-1 rhs|^2 - log|L|  for the natural-order Cholesky L of (diag, sub); any order gives
+// the same number, so the partitioned elimination is used.
+template <typename T>
+int btd_logdet_quad(long B, long n, const T* diag, const T* sub, const T* rhs, T* out, void* ws, size_t ws_bytes,
+                    int* info, long chunks, hipStream_t st) {
+    if (ws_bytes < btd_logdet_quad_ws<T>(B, n, chunks) || ws == nullptr) return -9;
+    RedSys<T> in;
+    in.Dv = const_cast<T*>(diag);
+    in.GU = nullptr;
+    in.gU = nullptr;
+    in.F = const_cast<T*>(sub);
+    in.tv = const_cast<T*>(rhs);
+    in.sc = nullptr;
+    in.n = n;
+    in.f_stride = n - 1;
+    in.f_off = -1;
+    return reduce_levels<T>(in, B, static_cast<char*>(ws), T(0), out, info, st);
+}
+
+template <typename T>
+int btd_cholesky(long B, long n, const T* diag, const T* sub, T* ldiag, T* lsub, int* info, hipStream_t st) {
+    hipLaunchKernelGGL((btd_cholesky_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, diag, sub, ldiag,
+                       lsub, info);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+template <typename T>
+int btd_solve(long Bl, long Br, long n, const T* ldiag, const T* lsub, const T* rhs, T* out, int transpose,
+              hipStream_t st) {
+    hipLaunchKernelGGL((btd_solve_kernel<T, D>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Bl, Br, n, ldiag, lsub,
+                       rhs, out, transpose);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+template <typename T>
+int btd_matvec(long Bl, long Br, long n, const T* diag, const T* sub, const T* x, T* out, int mode, hipStream_t st) {
+    hipLaunchKernelGGL((btd_matvec_kernel<T, D>), dim3((unsigned)cdiv(Br * n, 256)), dim3(256), 0, st, Bl, Br, n, diag,
+                       sub, x, out, mode);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+template <typename T> int btd_logdet(long B, long n, const T* ldiag, T* out, hipStream_t st) {
+    hipLaunchKernelGGL((btd_logdet_kernel<T, D>), dim3((unsigned)B), dim3(64), 0, st, B, n, ldiag, out);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+template <typename T>
+int btd_diag_of_inverse(long B, long n, const T* ldiag, const T* lsub, T* odiag, T* osub, hipStream_t st) {
+    hipLaunchKernelGGL((btd_diag_of_inverse_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, ldiag,
+                       lsub, odiag, osub);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+template <typename T>
+int btd_udl(long B, long n, const T* diag, const T* sub, T* ut, T* chol_d, const T* eta, T* m_post, T* chol_dinv,
+            int* info, hipStream_t st) {
+    hipLaunchKernelGGL((btd_udl_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, diag, sub, ut, chol_d,
+                       eta, m_post, chol_dinv, info);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+template <typename T>
+int ssm_precision(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ,
+                  const T* H, const T* y, const T* Rinv, int rinv_per_step, T* diag, T* sub, T* eta, hipStream_t st) {
+    if (H && (m < 1 || m > MF_MAXM)) return -3;
+    KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, 1, nullptr};
+    const dim3 grid((unsigned)cdiv(B * Tn, 256)), block(256);
+    if (m == 1) hipLaunchKernelGGL((ssm_precision_kernel<T, D, 1>), grid, block, 0, st, a, diag, sub, eta);
+    else hipLaunchKernelGGL((ssm_precision_kernel<T, D, 0>), grid, block, 0, st, a, diag, sub, eta);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+template <typename T> int ssm_means(long Bl, long Br, long Tn, const T* A, const T* offs, T* out, hipStream_t st) {
+    hipLaunchKernelGGL((ssm_means_kernel<T, D>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Bl, Br, Tn, A, offs, out);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+template <typename T> const OpsTable<T>* table() {
+    static const OpsTable<T> t = {
+        &kf_loglik_ws<T>, &kf_loglik<T>, &btd_logdet_quad_ws<T>, &btd_logdet_quad<T>, &btd_cholesky<T>,
+        &btd_solve<T>,    &btd_matvec<T>, &btd_logdet<T>,        &btd_diag_of_inverse<T>, &btd_udl<T>,
+        &ssm_precision<T>, &ssm_means<T>,
+    };
+    return &t;
+}
+
+}  // namespace
+
+#define MF_CAT2(a, b) a##b
+#define MF_CAT(a, b) MF_CAT2(a, b)
+const OpsTable<float>* MF_CAT(ops_f32_d, MF_D)() { return table<float>(); }
+const OpsTable<double>* MF_CAT(ops_f64_d, MF_D)() { return table<double>(); }
+
+}  // namespace mf

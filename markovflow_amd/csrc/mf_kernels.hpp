@@ -1,0 +1,618 @@
+// HIP kernels of the Kalman / block-tridiagonal hot path, templated on scalar type T and state dim D.
+//
+// Execution model (MI355X / gfx950): ONE LANE = ONE sub-problem, everything register resident
+// (mf_small.hpp), 64 independent sub-problems per wavefront, no cross-lane traffic.  The sequential
+// scan over time is parallelised by PARTITIONED block elimination ("one level of block cyclic
+// reduction with chunk size c"): a chain of n blocks is cut into chunks; every chunk eliminates its
+// interior blocks in natural order while carrying the fill-in ("spike") towards the separator on its
+// left, and hands a reduced block-tridiagonal system of one block per chunk to the next level.
+// log|M| and r^T M^-1 r are invariant under the elimination order, so the log-likelihood comes out
+// exact (to rounding) from any partition.  Notation follows SURVEY.md Appendix B.
+#pragma once
+#include "mf_small.hpp"
+
+namespace mf {
+
+// Reduced block-tridiagonal system with n blocks per series ("RedSys").  For block j:
+//   pivot   D'_j   = Dv[j] + GU[j+1]   (GU[j+1] absent for the last block)
+//   rhs     eta'_j = tv[j] + gU[j+1]
+//   coupling M'_{j,j-1} = F[j]          (F[0] unused)
+//   sc[j]   additive scalar already earned by the blocks folded into j
+// GU / gU may be null (plain user-supplied systems).
+template <typename T> struct RedSys {
+    T* Dv; T* GU; T* F; T* tv; T* gU; T* sc;
+    long n;          // blocks per series
+    long f_stride;   // blocks per series in F's allocation (n, or n-1 with f_off = -1 for a user `sub`)
+    long f_off;      // F block index for coupling j is (j + f_off)
+};
+
+// Elimination state of one chunk.
+template <typename T, int D, bool SPIKE> struct Elim {
+    T Phi[D][D];   // lower: partial pivot of the current block, then its Cholesky factor
+    T Li[D];
+    T t[D];        // partial rhs of the current block, then z = L^-1 t
+    T X[D][D];     // coupling current block <-> left separator, then V = L^-1 X
+    T GU[D][D];    // lower: accumulated contribution to the left separator's pivot
+    T gU[D];       // accumulated contribution to the left separator's rhs
+    T quad;        // sum |z|^2
+    LogAcc<T> laL; // prod diag(L)
+    bool bad;
+
+    MF_DEV void init() {
+        MF_UNROLL for (int i = 0; i < D; ++i) {
+            t[i] = T(0); gU[i] = T(0); Li[i] = T(0);
+            MF_UNROLL for (int j = 0; j < D; ++j) { Phi[i][j] = T(0); X[i][j] = T(0); GU[i][j] = T(0); }
+        }
+        quad = T(0);
+        laL.init();
+        bad = false;
+    }
+    // Factor the (complete) pivot in Phi, solve for z and the spike V, fold V into the separator.
+    MF_DEV void eliminate() {
+        chol_lower<T, D>(Phi, Li, laL, bad);
+        laL.renorm();
+        trsv_lower<T, D>(Phi, Li, t);
+        quad += dot_self<T, D>(t);
+        if (SPIKE) {
+            trsm_left_lower<T, D, D>(Phi, Li, X);
+            syrk_tn_lower<T, D, D>(X, GU, T(-1));
+            T vz[D];
+            gemv_t<T, D, D>(X, t, vz);
+            MF_UNROLL for (int i = 0; i < D; ++i) gU[i] -= vz[i];
+        }
+    }
+    // After eliminate(): move to the next block whose coupling to the eliminated one is W L^T
+    // (W = S L^-T already formed by the caller); Dn / rn are the next block's own pivot / rhs parts.
+    MF_DEV void advance(const T (&W)[D][D], const T (&Dn)[D][D], const T (&rn)[D]) {
+        T wz[D];
+        gemv_n<T, D, D>(W, t, wz);
+        MF_UNROLL for (int i = 0; i < D; ++i) {
+            t[i] = rn[i] - wz[i];
+            MF_UNROLL for (int j = 0; j <= i; ++j) Phi[i][j] = Dn[i][j];
+        }
+        syrk_nt_lower<T, D, D>(W, Phi, T(-1));
+        if (SPIKE) neg_mul_inplace<T, D>(W, X);
+    }
+};
+
+template <typename T, int D, bool SPIKE>
+MF_DEV void store_chunk(const RedSys<T>& out, long idx, const Elim<T, D, SPIKE>& E, T scalar) {
+    store_sym<T, D>(out.Dv + idx * D * D, E.Phi);
+    store_vec<T, D>(out.tv + idx * D, E.t);
+    store_sym<T, D>(out.GU + idx * D * D, E.GU);
+    store_vec<T, D>(out.gU + idx * D, E.gU);
+    store_mat<T, D, D>(out.F + idx * D * D, E.X);
+    out.sc[idx] = scalar;
+}
+
+// -------------------------------------------------------------------------------------------------
+// K0 level 0: state-space model + observations -> reduced system of P blocks per series.
+// Replaces, fused and without materialising anything:  StateSpaceModel._build_precision
+// (state_space_model.py:431-483), _k_inv_post (kalman_filter.py:86-101), the natural-order banded
+// Cholesky (block_tri_diag.py:423-436), the forward solve (:339-351) and the log-dets
+// (kalman_filter.py:229-253).  The prior mean enters through the information vector
+// eta = G^T S^-1 y + K^-1 mu  (kalman_filter.py:129-145) instead of the marginal-mean recursion, so a
+// chunk needs nothing from its predecessors.
+// -------------------------------------------------------------------------------------------------
+template <typename T> struct KfArgs {
+    long B, Tn;          // series, time points
+    int m;               // output dim (runtime, <= MAXM)
+    const T* mu0; const T* cholP0; const T* A; const T* b; const T* cholQ;   // [B,d] [B,d,d] [B,T-1,d,d] [B,T-1,d] [B,T-1,d,d]
+    const T* H; const T* y;                                                 // [B,T,m,d] [B,T,m]
+    const T* Rinv; int rinv_per_step;                                       // [m,m] or [B,T,m,m]
+    long P;              // chunks per series
+    int* info;
+};
+
+constexpr int MF_MAXM = 4;
+
+template <typename T, int D, int M> struct Obs {
+    // adds H^T R^-1 H to Phi (lower), H^T R^-1 y to t and returns y^T R^-1 y
+    static MF_DEV T apply(const T* __restrict__ Hk, const T* __restrict__ yk, const T* __restrict__ Ri, int m,
+                          T (&Phi)[D][D], T (&t)[D]) {
+        constexpr int MM = (M > 0) ? M : MF_MAXM;
+        T h[MM][D], yv[MM], rh[MM][D], ry[MM];
+        MF_UNROLL for (int o = 0; o < MM; ++o) {
+            const bool on = (M > 0) || (o < m);
+            yv[o] = on ? yk[o] : T(0);
+            MF_UNROLL for (int i = 0; i < D; ++i) h[o][i] = on ? Hk[o * D + i] : T(0);
+        }
+        MF_UNROLL for (int o = 0; o < MM; ++o) {
+            ry[o] = T(0);
+            MF_UNROLL for (int i = 0; i < D; ++i) rh[o][i] = T(0);
+            MF_UNROLL for (int p = 0; p < MM; ++p) {
+                const bool on = (M > 0) || (o < m && p < m);
+                const T r = on ? Ri[o * ((M > 0) ? M : m) + p] : T(0);
+                ry[o] += r * yv[p];
+                MF_UNROLL for (int i = 0; i < D; ++i) rh[o][i] += r * h[p][i];
+            }
+        }
+        T yry = T(0);
+        MF_UNROLL for (int o = 0; o < MM; ++o) {
+            yry += yv[o] * ry[o];
+            MF_UNROLL for (int i = 0; i < D; ++i) {
+                t[i] += h[o][i] * ry[o];
+                MF_UNROLL for (int j = 0; j <= i; ++j) Phi[i][j] += h[o][i] * rh[o][j];
+            }
+        }
+        return yry;
+    }
+};
+
+template <typename T, int D, int M, bool SPIKE>
+__global__ void __launch_bounds__(64) kf_chunk_kernel(KfArgs<T> a, RedSys<T> out) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= a.B * a.P) return;
+    const long s = id / a.P, c = id % a.P;
+    const long k0 = (c * a.Tn) / a.P, k1 = ((c + 1) * a.Tn) / a.P;   // blocks [k0, k1)
+    const int m = a.m;
+    const T* As = a.A + s * (a.Tn - 1) * D * D;
+    const T* Qs = a.cholQ + s * (a.Tn - 1) * D * D;
+    const T* bs = a.b + s * (a.Tn - 1) * D;
+    const T* Hs = a.H + s * a.Tn * m * D;
+    const T* ys = a.y + s * a.Tn * m;
+
+    Elim<T, D, SPIKE> E;
+    E.init();
+    LogAcc<T> laC;
+    laC.init();
+    T acc_yry = T(0), acc_ww = T(0);
+
+    for (long k = k0; k < k1; ++k) {
+        T C[D][D], Ci[D][D], mvec[D], w[D];
+        if (k == 0) {
+            load_lower<T, D>(a.cholP0 + s * D * D, C);
+            load_vec<T, D>(a.mu0 + s * D, mvec);
+        } else {
+            load_lower<T, D>(Qs + (k - 1) * D * D, C);
+            load_vec<T, D>(bs + (k - 1) * D, mvec);
+        }
+        tri_inv_lower<T, D>(C, Ci, laC, E.bad);
+        laC.renorm();
+        trimul_lower_vec<T, D>(Ci, mvec, w);
+        acc_ww += dot_self<T, D>(w);
+
+        T Dn[D][D], rn[D];
+        trimulT_self_lower<T, D>(Ci, Dn);          // Q_k^-1
+        trimulT_lower_vec<T, D>(Ci, w, rn);        // Q_k^-1 m_k
+        const T* Ri = a.rinv_per_step ? a.Rinv + (s * a.Tn + k) * m * m : a.Rinv;
+        acc_yry += Obs<T, D, M>::apply(Hs + k * m * D, ys + k * m, Ri, m, Dn, rn);
+
+        if (k == 0) {
+            MF_UNROLL for (int i = 0; i < D; ++i) {
+                E.t[i] = rn[i];
+                MF_UNROLL for (int j = 0; j <= i; ++j) E.Phi[i][j] = Dn[i][j];
+            }
+            continue;
+        }
+        T Bm[D][D];
+        {
+            T Am[D][D];
+            load_mat<T, D, D>(As + (k - 1) * D * D, Am);
+            trimul_lower<T, D, D>(Ci, Am, Bm);     // B = C^-1 A
+        }
+        T btw[D], W[D][D];
+        gemv_t<T, D, D>(Bm, w, btw);               // A^T Q^-1 m
+        if (k == k0) {
+            // block k-1 is the separator on the left: it is not eliminated here.
+            syrk_tn_lower<T, D, D>(Bm, E.GU, T(1));
+            MF_UNROLL for (int i = 0; i < D; ++i) E.gU[i] = -btw[i];
+            trimulT_lower<T, D, D>(Ci, Bm, W);
+            MF_UNROLL for (int i = 0; i < D; ++i) {
+                E.t[i] = rn[i];
+                MF_UNROLL for (int j = 0; j < D; ++j) { E.X[i][j] = -W[i][j]; }
+                MF_UNROLL for (int j = 0; j <= i; ++j) E.Phi[i][j] = Dn[i][j];
+            }
+        } else {
+            syrk_tn_lower<T, D, D>(Bm, E.Phi, T(1));    // D_{k-1} complete
+            MF_UNROLL for (int i = 0; i < D; ++i) E.t[i] -= btw[i];
+            E.eliminate();
+            trsm_right_lower_t<T, D, D>(E.Phi, E.Li, Bm);   // Y = B L^-T
+            trimulT_lower<T, D, D>(Ci, Bm, W);              // -W = C^-T Y
+            MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) W[i][j] = -W[i][j];
+            E.advance(W, Dn, rn);
+        }
+    }
+    const T scalar = T(-0.5) * (acc_yry + acc_ww) + T(0.5) * E.quad - laC.value() - E.laL.value();
+    store_chunk<T, D, SPIKE>(out, id, E, scalar);
+    if (E.bad && a.info) atomicMax(a.info, 1);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Generic level: RedSys(n) -> RedSys(P), same elimination on explicit blocks.
+// -------------------------------------------------------------------------------------------------
+template <typename T, int D>
+MF_DEV void load_red_block(const RedSys<T>& in, long s, long j, T (&Dn)[D][D], T (&rn)[D], T& sc) {
+    const long idx = s * in.n + j;
+    load_lower<T, D>(in.Dv + idx * D * D, Dn);
+    load_vec<T, D>(in.tv + idx * D, rn);
+    sc = in.sc ? in.sc[idx] : T(0);
+    if (in.GU && j + 1 < in.n) {
+        T g[D][D], gv[D];
+        load_lower<T, D>(in.GU + (idx + 1) * D * D, g);
+        load_vec<T, D>(in.gU + (idx + 1) * D, gv);
+        MF_UNROLL for (int i = 0; i < D; ++i) {
+            rn[i] += gv[i];
+            MF_UNROLL for (int jj = 0; jj <= i; ++jj) Dn[i][jj] += g[i][jj];
+        }
+    }
+}
+
+template <typename T, int D, bool SPIKE>
+__global__ void __launch_bounds__(64) red_chunk_kernel(RedSys<T> in, RedSys<T> out, long B, long P, int* info) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= B * P) return;
+    const long s = id / P, c = id % P;
+    const long k0 = (c * in.n) / P, k1 = ((c + 1) * in.n) / P;
+    Elim<T, D, SPIKE> E;
+    E.init();
+    T acc_sc = T(0);
+    for (long k = k0; k < k1; ++k) {
+        T Dn[D][D], rn[D], sc;
+        load_red_block<T, D>(in, s, k, Dn, rn, sc);
+        acc_sc += sc;
+        if (k == 0) {
+            MF_UNROLL for (int i = 0; i < D; ++i) {
+                E.t[i] = rn[i];
+                MF_UNROLL for (int j = 0; j <= i; ++j) E.Phi[i][j] = Dn[i][j];
+            }
+            continue;
+        }
+        T W[D][D];
+        load_mat<T, D, D>(in.F + (s * in.f_stride + k + in.f_off) * D * D, W);
+        if (k == k0) {
+            MF_UNROLL for (int i = 0; i < D; ++i) {
+                E.t[i] = rn[i];
+                MF_UNROLL for (int j = 0; j < D; ++j) E.X[i][j] = W[i][j];
+                MF_UNROLL for (int j = 0; j <= i; ++j) E.Phi[i][j] = Dn[i][j];
+            }
+        } else {
+            E.eliminate();
+            trsm_right_lower_t<T, D, D>(E.Phi, E.Li, W);    // W = S L^-T
+            E.advance(W, Dn, rn);
+        }
+    }
+    const T scalar = acc_sc + T(0.5) * E.quad - E.laL.value();
+    store_chunk<T, D, SPIKE>(out, id, E, scalar);
+    if (E.bad && info) atomicMax(info, 1);
+}
+
+// Final level: one lane per series walks the remaining n blocks; out[s] = add_const + sum of scalars.
+template <typename T, int D>
+__global__ void __launch_bounds__(64) red_final_kernel(RedSys<T> in, long B, T add_const, T* __restrict__ out, int* info) {
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= B) return;
+    Elim<T, D, false> E;
+    E.init();
+    T acc_sc = T(0);
+    for (long k = 0; k < in.n; ++k) {
+        T Dn[D][D], rn[D], sc;
+        load_red_block<T, D>(in, s, k, Dn, rn, sc);
+        acc_sc += sc;
+        if (k == 0) {
+            MF_UNROLL for (int i = 0; i < D; ++i) {
+                E.t[i] = rn[i];
+                MF_UNROLL for (int j = 0; j <= i; ++j) E.Phi[i][j] = Dn[i][j];
+            }
+        } else {
+            T W[D][D];
+            load_mat<T, D, D>(in.F + (s * in.f_stride + k + in.f_off) * D * D, W);
+            E.eliminate();
+            trsm_right_lower_t<T, D, D>(E.Phi, E.Li, W);
+            E.advance(W, Dn, rn);
+        }
+    }
+    E.eliminate();
+    out[s] = add_const + acc_sc + T(0.5) * E.quad - E.laL.value();
+    if (E.bad && info) atomicMax(info, 1);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Operator kernels (natural order, one lane per series) - the API-parity forms of
+// cholesky / solve / dense_mult / abs_log_det / block_diagonal_of_inverse / upper_diagonal_lower.
+// -------------------------------------------------------------------------------------------------
+
+// K1  SymmetricBlockTriDiagonal.cholesky (block_tri_diag.py:423-436)
+template <typename T, int D>
+__global__ void __launch_bounds__(64) btd_cholesky_kernel(long B, long n, const T* __restrict__ diag,
+                                                          const T* __restrict__ sub, T* __restrict__ ldiag,
+                                                          T* __restrict__ lsub, int* info) {
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= B) return;
+    T L[D][D], Li[D];
+    LogAcc<T> la;
+    la.init();
+    bool bad = false;
+    for (long k = 0; k < n; ++k) {
+        T S[D][D];
+        load_lower<T, D>(diag + (s * n + k) * D * D, S);
+        if (sub && k > 0) {
+            T W[D][D];
+            load_mat<T, D, D>(sub + (s * (n - 1) + k - 1) * D * D, W);
+            trsm_right_lower_t<T, D, D>(L, Li, W);
+            store_mat<T, D, D>(lsub + (s * (n - 1) + k - 1) * D * D, W);
+            syrk_nt_lower<T, D, D>(W, S, T(-1));
+        }
+        chol_lower<T, D>(S, Li, la, bad);
+        la.init();
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) L[i][j] = S[i][j];
+        store_lower<T, D>(ldiag + (s * n + k) * D * D, L);
+    }
+    if (bad && info) atomicMax(info, 1);
+}
+
+// K2  LowerTriangularBlockTriDiagonal.solve (block_tri_diag.py:339-351); rhs series r uses factor r % Bl
+template <typename T, int D>
+__global__ void __launch_bounds__(64) btd_solve_kernel(long Bl, long Br, long n, const T* __restrict__ ldiag,
+                                                       const T* __restrict__ lsub, const T* __restrict__ rhs,
+                                                       T* __restrict__ out, int transpose) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= Br) return;
+    const long s = r % Bl;
+    T z[D];
+    MF_UNROLL for (int i = 0; i < D; ++i) z[i] = T(0);
+    for (long kk = 0; kk < n; ++kk) {
+        const long k = transpose ? n - 1 - kk : kk;
+        T L[D][D], Li[D], x[D];
+        load_lower<T, D>(ldiag + (s * n + k) * D * D, L);
+        MF_UNROLL for (int i = 0; i < D; ++i) Li[i] = T(1) / L[i][i];
+        load_vec<T, D>(rhs + (r * n + k) * D, x);
+        if (lsub && kk > 0) {
+            T W[D][D], wz[D];
+            if (!transpose) {
+                load_mat<T, D, D>(lsub + (s * (n - 1) + k - 1) * D * D, W);
+                gemv_n<T, D, D>(W, z, wz);
+            } else {
+                load_mat<T, D, D>(lsub + (s * (n - 1) + k) * D * D, W);
+                gemv_t<T, D, D>(W, z, wz);
+            }
+            MF_UNROLL for (int i = 0; i < D; ++i) x[i] -= wz[i];
+        }
+        if (!transpose) trsv_lower<T, D>(L, Li, x); else trsv_lower_t<T, D>(L, Li, x);
+        MF_UNROLL for (int i = 0; i < D; ++i) z[i] = x[i];
+        store_vec<T, D>(out + (r * n + k) * D, z);
+    }
+}
+
+// K3  BlockTriDiagonal.dense_mult (block_tri_diag.py:175-199): one lane per (series, block)
+//     mode 0: lower-triangular M x; 1: M^T x; 2: symmetric M x (lower triangle of diag mirrored)
+template <typename T, int D>
+__global__ void __launch_bounds__(256) btd_matvec_kernel(long Bl, long Br, long n, const T* __restrict__ diag,
+                                                         const T* __restrict__ sub, const T* __restrict__ x,
+                                                         T* __restrict__ out, int mode) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= Br * n) return;
+    const long r = id / n, k = id % n, s = r % Bl;
+    T Dk[D][D], xv[D], acc[D];
+    load_lower<T, D>(diag + (s * n + k) * D * D, Dk);
+    load_vec<T, D>(x + (r * n + k) * D, xv);
+    MF_UNROLL for (int i = 0; i < D; ++i) {
+        T a = T(0);
+        MF_UNROLL for (int j = 0; j < D; ++j) {
+            T e;
+            if (mode == 0) e = (j <= i) ? Dk[i][j] : T(0);
+            else if (mode == 1) e = (j >= i) ? Dk[j][i] : T(0);
+            else e = (j <= i) ? Dk[i][j] : Dk[j][i];
+            a += e * xv[j];
+        }
+        acc[i] = a;
+    }
+    if (sub) {
+        if ((mode == 0 || mode == 2) && k > 0) {
+            T S[D][D], xp[D], t[D];
+            load_mat<T, D, D>(sub + (s * (n - 1) + k - 1) * D * D, S);
+            load_vec<T, D>(x + (r * n + k - 1) * D, xp);
+            gemv_n<T, D, D>(S, xp, t);
+            MF_UNROLL for (int i = 0; i < D; ++i) acc[i] += t[i];
+        }
+        if ((mode == 1 || mode == 2) && k + 1 < n) {
+            T S[D][D], xn[D], t[D];
+            load_mat<T, D, D>(sub + (s * (n - 1) + k) * D * D, S);
+            load_vec<T, D>(x + (r * n + k + 1) * D, xn);
+            gemv_t<T, D, D>(S, xn, t);
+            MF_UNROLL for (int i = 0; i < D; ++i) acc[i] += t[i];
+        }
+    }
+    store_vec<T, D>(out + (r * n + k) * D, acc);
+}
+
+// abs_log_det (block_tri_diag.py:353-366): one wavefront per series
+template <typename T, int D>
+__global__ void __launch_bounds__(64) btd_logdet_kernel(long B, long n, const T* __restrict__ ldiag, T* __restrict__ out) {
+    const long s = blockIdx.x;
+    T acc = T(0);
+    for (long e = threadIdx.x; e < n * D; e += 64) {
+        const long k = e / D;
+        const int i = (int)(e % D);
+        const T v = ldiag[(s * n + k) * D * D + i * D + i];
+        acc += T(0.5) * log(v * v);
+    }
+    MF_UNROLL for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if (threadIdx.x == 0) out[s] = acc;
+}
+
+// K4  block_diagonal_of_inverse (block_tri_diag.py:318-337), block Takahashi, backward
+template <typename T, int D>
+__global__ void __launch_bounds__(64) btd_diag_of_inverse_kernel(long B, long n, const T* __restrict__ ldiag,
+                                                                 const T* __restrict__ lsub, T* __restrict__ odiag,
+                                                                 T* __restrict__ osub) {
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= B) return;
+    T Sig[D][D];   // full symmetric Sigma_{k+1,k+1}
+    for (long k = n - 1; k >= 0; --k) {
+        T L[D][D], Li[D], Linv[D][D];
+        load_lower<T, D>(ldiag + (s * n + k) * D * D, L);
+        LogAcc<T> la;
+        la.init();
+        bool bad = false;
+        tri_inv_lower<T, D>(L, Linv, la, bad);
+        (void)Li;
+        T Out[D][D];
+        trimulT_self_lower<T, D>(Linv, Out);        // L^-T L^-1 (lower)
+        if (lsub && k + 1 < n) {
+            T W[D][D], G[D][D], SG[D][D];
+            load_mat<T, D, D>(lsub + (s * (n - 1) + k) * D * D, W);
+            // G = W L^-1
+            MF_UNROLL for (int i = 0; i < D; ++i)
+                MF_UNROLL for (int j = 0; j < D; ++j) {
+                    T a = T(0);
+                    MF_UNROLL for (int l = j; l < D; ++l) a += W[i][l] * Linv[l][j];
+                    G[i][j] = a;
+                }
+            // SG = Sigma_{k+1} G
+            MF_UNROLL for (int i = 0; i < D; ++i)
+                MF_UNROLL for (int j = 0; j < D; ++j) {
+                    T a = T(0);
+                    MF_UNROLL for (int l = 0; l < D; ++l) a += Sig[i][l] * G[l][j];
+                    SG[i][j] = a;
+                }
+            if (osub) {
+                T neg[D][D];
+                MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) neg[i][j] = -SG[i][j];
+                store_mat<T, D, D>(osub + (s * (n - 1) + k) * D * D, neg);
+            }
+            MF_UNROLL for (int i = 0; i < D; ++i)
+                MF_UNROLL for (int j = 0; j <= i; ++j) {
+                    T a = T(0);
+                    MF_UNROLL for (int l = 0; l < D; ++l) a += G[l][i] * SG[l][j];
+                    Out[i][j] += a;
+                }
+        }
+        MF_UNROLL for (int i = 0; i < D; ++i)
+            MF_UNROLL for (int j = 0; j < D; ++j) Sig[i][j] = (i >= j) ? Out[i][j] : Out[j][i];
+        store_mat<T, D, D>(odiag + (s * n + k) * D * D, Sig);
+    }
+}
+
+// K5  upper_diagonal_lower (block_tri_diag.py:438-545): backward UDU^T; writes U_k^T and chol(Delta_k).
+//     With eta != null it also produces the posterior chain of posterior_state_space_model
+//     (kalman_filter.py:149-182): m_post, chol(Delta_k^-1).
+template <typename T, int D>
+__global__ void __launch_bounds__(64) btd_udl_kernel(long B, long n, const T* __restrict__ diag,
+                                                     const T* __restrict__ sub, T* __restrict__ ut,
+                                                     T* __restrict__ chol_d, const T* __restrict__ eta,
+                                                     T* __restrict__ m_post, T* __restrict__ chol_dinv, int* info) {
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= B) return;
+    T Lp[D][D], Lpi[D], xp[D];   // chol(Delta_{k+1}), its inverse diagonal, x_{k+1}
+    bool bad = false;
+    for (long k = n - 1; k >= 0; --k) {
+        T Dl[D][D], x[D];
+        load_lower<T, D>(diag + (s * n + k) * D * D, Dl);
+        if (eta) load_vec<T, D>(eta + (s * n + k) * D, x);
+        if (k + 1 < n) {
+            T S[D][D], U[D][D];
+            load_mat<T, D, D>(sub + (s * (n - 1) + k) * D * D, S);
+            MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) U[i][j] = S[i][j];
+            trsm_left_lower<T, D, D>(Lp, Lpi, U);          // L^-1 S
+            syrk_tn_lower<T, D, D>(U, Dl, T(-1));          // Delta_k = D_k - S^T Delta_{k+1}^-1 S
+            trsm_left_lower_t<T, D, D>(Lp, Lpi, U);        // U_k^T = Delta_{k+1}^-1 S
+            store_mat<T, D, D>(ut + (s * (n - 1) + k) * D * D, U);
+            if (eta) {
+                T ux[D];
+                gemv_t<T, D, D>(U, xp, ux);                // U_k x_{k+1}
+                MF_UNROLL for (int i = 0; i < D; ++i) x[i] -= ux[i];
+            }
+        }
+        LogAcc<T> la;
+        la.init();
+        chol_lower<T, D>(Dl, Lpi, la, bad);
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Lp[i][j] = Dl[i][j];
+        store_lower<T, D>(chol_d + (s * n + k) * D * D, Lp);
+        if (eta) {
+            MF_UNROLL for (int i = 0; i < D; ++i) xp[i] = x[i];
+            trsv_lower<T, D>(Lp, Lpi, x);
+            trsv_lower_t<T, D>(Lp, Lpi, x);                // m_k = Delta_k^-1 x_k
+            store_vec<T, D>(m_post + (s * n + k) * D, x);
+            // chol(Delta_k^-1) = chol(L^-T L^-1)
+            T Linv[D][D], Q[D][D], Qi[D];
+            LogAcc<T> lb;
+            lb.init();
+            tri_inv_lower<T, D>(Lp, Linv, lb, bad);
+            trimulT_self_lower<T, D>(Linv, Q);
+            chol_lower<T, D>(Q, Qi, lb, bad);
+            store_lower<T, D>(chol_dinv + (s * n + k) * D * D, Q);
+        }
+    }
+    if (bad && info) atomicMax(info, 1);
+}
+
+// Posterior precision + information vector, one lane per (series, block):
+//   diag_k = Q_k^-1 + A_{k+1}^T Q_{k+1}^-1 A_{k+1} (+ H^T R^-1 H),  sub_k = -Q_{k+1}^-1 A_{k+1},
+//   eta_k  = Q_k^-1 m_k - A_{k+1}^T Q_{k+1}^-1 m_{k+1} (+ H^T R^-1 y)
+// (state_space_model.py:431-483, kalman_filter.py:86-101,153-156).  H == null gives the prior precision.
+template <typename T, int D, int M>
+__global__ void __launch_bounds__(256) ssm_precision_kernel(KfArgs<T> a, T* __restrict__ diag, T* __restrict__ sub,
+                                                            T* __restrict__ eta) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= a.B * a.Tn) return;
+    const long s = id / a.Tn, k = id % a.Tn;
+    const int m = a.m;
+    T C[D][D], Ci[D][D], Dn[D][D], rn[D], mvec[D], w[D];
+    LogAcc<T> la;
+    la.init();
+    bool bad = false;
+    load_lower<T, D>(k == 0 ? a.cholP0 + s * D * D : a.cholQ + (s * (a.Tn - 1) + k - 1) * D * D, C);
+    tri_inv_lower<T, D>(C, Ci, la, bad);
+    trimulT_self_lower<T, D>(Ci, Dn);
+    MF_UNROLL for (int i = 0; i < D; ++i) rn[i] = T(0);
+    if (eta) {
+        load_vec<T, D>(k == 0 ? a.mu0 + s * D : a.b + (s * (a.Tn - 1) + k - 1) * D, mvec);
+        trimul_lower_vec<T, D>(Ci, mvec, w);
+        trimulT_lower_vec<T, D>(Ci, w, rn);
+    }
+    if (a.H) {
+        const T* Ri = a.rinv_per_step ? a.Rinv + (s * a.Tn + k) * m * m : a.Rinv;
+        T dummy[D];
+        MF_UNROLL for (int i = 0; i < D; ++i) dummy[i] = T(0);
+        if (a.y) Obs<T, D, M>::apply(a.H + (s * a.Tn + k) * m * D, a.y + (s * a.Tn + k) * m, Ri, m, Dn, rn);
+        else {
+            // precision only: feed zeros for y
+            T zero[MF_MAXM] = {T(0), T(0), T(0), T(0)};
+            Obs<T, D, M>::apply(a.H + (s * a.Tn + k) * m * D, zero, Ri, m, Dn, dummy);
+        }
+    }
+    if (k + 1 < a.Tn) {
+        T C2[D][D], Ci2[D][D], Am[D][D], Bm[D][D], W[D][D];
+        load_lower<T, D>(a.cholQ + (s * (a.Tn - 1) + k) * D * D, C2);
+        tri_inv_lower<T, D>(C2, Ci2, la, bad);
+        load_mat<T, D, D>(a.A + (s * (a.Tn - 1) + k) * D * D, Am);
+        trimul_lower<T, D, D>(Ci2, Am, Bm);
+        syrk_tn_lower<T, D, D>(Bm, Dn, T(1));
+        trimulT_lower<T, D, D>(Ci2, Bm, W);
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) W[i][j] = -W[i][j];
+        store_mat<T, D, D>(sub + (s * (a.Tn - 1) + k) * D * D, W);
+        if (eta) {
+            T m2[D], w2[D], btw[D];
+            load_vec<T, D>(a.b + (s * (a.Tn - 1) + k) * D, m2);
+            trimul_lower_vec<T, D>(Ci2, m2, w2);
+            gemv_t<T, D, D>(Bm, w2, btw);
+            MF_UNROLL for (int i = 0; i < D; ++i) rn[i] -= btw[i];
+        }
+    }
+    store_sym<T, D>(diag + id * D * D, Dn);
+    if (eta) store_vec<T, D>(eta + id * D, rn);
+}
+
+// StateSpaceModel.marginal_means (state_space_model.py:232-251): mu_{k+1} = A_k mu_k + b_k.
+// rhs series r uses transitions of series r % Bl (sample() passes sample_shape + batch_shape).
+template <typename T, int D>
+__global__ void __launch_bounds__(64) ssm_means_kernel(long Bl, long Br, long Tn, const T* __restrict__ A,
+                                                       const T* __restrict__ offs, T* __restrict__ out) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= Br) return;
+    const long s = r % Bl;
+    T mu[D];
+    load_vec<T, D>(offs + r * Tn * D, mu);
+    store_vec<T, D>(out + r * Tn * D, mu);
+    for (long k = 1; k < Tn; ++k) {
+        T Am[D][D], bv[D], nx[D];
+        load_mat<T, D, D>(A + (s * (Tn - 1) + k - 1) * D * D, Am);
+        load_vec<T, D>(offs + (r * Tn + k) * D, bv);
+        gemv_n<T, D, D>(Am, mu, nx);
+        MF_UNROLL for (int i = 0; i < D; ++i) mu[i] = nx[i] + bv[i];
+        store_vec<T, D>(out + (r * Tn + k) * D, mu);
+    }
+}
+
+}  // namespace mf

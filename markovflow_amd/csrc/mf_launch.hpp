@@ -1,0 +1,42 @@
+// Per-state-dimension launch tables.  One translation unit (mf_inst.hip, compiled with -DMF_D=<d>)
+// instantiates every kernel for that d and both scalar types and exports its table; mf_api.hip
+// dispatches the extern "C" entry points of include/markovflow_amd.h through these tables.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace mf {
+
+template <typename T> struct OpsTable {
+    size_t (*kf_loglik_ws)(long B, long Tn, long chunks);
+    int (*kf_loglik)(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ,
+                     const T* H, const T* y, const T* Rinv, int rinv_per_step, T add_const, T* out, void* ws,
+                     size_t ws_bytes, int* info, long chunks, hipEvent_t ev0, hipEvent_t ev1, hipStream_t st);
+    size_t (*btd_logdet_quad_ws)(long B, long n, long chunks);
+    int (*btd_logdet_quad)(long B, long n, const T* diag, const T* sub, const T* rhs, T* out, void* ws,
+                           size_t ws_bytes, int* info, long chunks, hipStream_t st);
+    int (*btd_cholesky)(long B, long n, const T* diag, const T* sub, T* ldiag, T* lsub, int* info, hipStream_t st);
+    int (*btd_solve)(long Bl, long Br, long n, const T* ldiag, const T* lsub, const T* rhs, T* out, int transpose,
+                     hipStream_t st);
+    int (*btd_matvec)(long Bl, long Br, long n, const T* diag, const T* sub, const T* x, T* out, int mode,
+                      hipStream_t st);
+    int (*btd_logdet)(long B, long n, const T* ldiag, T* out, hipStream_t st);
+    int (*btd_diag_of_inverse)(long B, long n, const T* ldiag, const T* lsub, T* odiag, T* osub, hipStream_t st);
+    int (*btd_udl)(long B, long n, const T* diag, const T* sub, T* ut, T* chol_d, const T* eta, T* m_post,
+                   T* chol_dinv, int* info, hipStream_t st);
+    int (*ssm_precision)(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b,
+                         const T* cholQ, const T* H, const T* y, const T* Rinv, int rinv_per_step, T* diag, T* sub,
+                         T* eta, hipStream_t st);
+    int (*ssm_means)(long Bl, long Br, long Tn, const T* A, const T* offs, T* out, hipStream_t st);
+};
+
+constexpr int MF_MAX_D = 9;   // largest state dimension with a register-resident instantiation
+
+#define MF_DECLARE_TABLES(D)                          \
+    const OpsTable<float>* ops_f32_d##D();            \
+    const OpsTable<double>* ops_f64_d##D();
+MF_DECLARE_TABLES(1) MF_DECLARE_TABLES(2) MF_DECLARE_TABLES(3) MF_DECLARE_TABLES(4) MF_DECLARE_TABLES(5)
+MF_DECLARE_TABLES(6) MF_DECLARE_TABLES(7) MF_DECLARE_TABLES(8) MF_DECLARE_TABLES(9)
+#undef MF_DECLARE_TABLES
+
+}  // namespace mf

@@ -1,0 +1,277 @@
+// Register-resident small-matrix primitives for one lane = one (series, time-chunk) sub-problem.
+//
+// Everything here is fully unrolled over the compile-time state dimension D so that every matrix
+// lives in VGPRs with static indexing (runtime-indexed arrays would go to scratch on gfx950).
+// Symmetric matrices are kept in full D x D arrays but only the LOWER triangle (i >= j) is ever
+// computed or read, so the compiler drops the upper half.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define MF_DEV __device__ __forceinline__
+#define MF_UNROLL _Pragma("unroll")
+
+namespace mf {
+
+template <typename T> MF_DEV T t_sqrt(T x);
+template <> MF_DEV float t_sqrt<float>(float x) { return __builtin_sqrtf(x); }
+template <> MF_DEV double t_sqrt<double>(double x) { return __builtin_sqrt(x); }
+
+// Running log-determinant accumulator (sum of log|x_i|).
+// double: kept as (mantissa product, exponent sum) so the per-step cost is a few multiplies and one
+//         frexp instead of 2*D software log evaluations; one log at the very end.
+// float : v_log_f32 is a single instruction, so simply sum log2|x|.
+template <typename T> struct LogAcc;
+template <> struct LogAcc<double> {
+    double mant;
+    int expo;
+    MF_DEV void init() { mant = 1.0; expo = 0; }
+    MF_DEV void mul(double x) { mant *= x; }
+    MF_DEV void renorm() {
+        int e;
+        mant = frexp(mant, &e);
+        expo += e;
+    }
+    MF_DEV double value() const {
+        const double m = mant < 0.0 ? -mant : mant;
+        return log(m) + double(expo) * 0.6931471805599453094;
+    }
+};
+template <> struct LogAcc<float> {
+    float acc;
+    MF_DEV void init() { acc = 0.f; }
+    MF_DEV void mul(float x) { acc += __log2f(__builtin_fabsf(x)); }
+    MF_DEV void renorm() {}
+    MF_DEV float value() const { return acc * 0.6931471805599453094f; }
+};
+
+// ---- loads / stores of contiguous blocks -------------------------------------------------------
+template <typename T, int N> MF_DEV void load_vec(const T* __restrict__ p, T (&v)[N]) {
+    MF_UNROLL for (int i = 0; i < N; ++i) v[i] = p[i];
+}
+template <typename T, int N> MF_DEV void store_vec(T* __restrict__ p, const T (&v)[N]) {
+    MF_UNROLL for (int i = 0; i < N; ++i) p[i] = v[i];
+}
+template <typename T, int R, int C> MF_DEV void load_mat(const T* __restrict__ p, T (&m)[R][C]) {
+    MF_UNROLL for (int i = 0; i < R; ++i) MF_UNROLL for (int j = 0; j < C; ++j) m[i][j] = p[i * C + j];
+}
+template <typename T, int D> MF_DEV void load_lower(const T* __restrict__ p, T (&m)[D][D]) {
+    MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) m[i][j] = p[i * D + j];
+}
+template <typename T, int R, int C> MF_DEV void store_mat(T* __restrict__ p, const T (&m)[R][C]) {
+    MF_UNROLL for (int i = 0; i < R; ++i) MF_UNROLL for (int j = 0; j < C; ++j) p[i * C + j] = m[i][j];
+}
+// store a symmetric matrix held in its lower triangle as a full dense block
+template <typename T, int D> MF_DEV void store_sym(T* __restrict__ p, const T (&m)[D][D]) {
+    MF_UNROLL for (int i = 0; i < D; ++i)
+        MF_UNROLL for (int j = 0; j < D; ++j) p[i * D + j] = (i >= j) ? m[i][j] : m[j][i];
+}
+// store a lower-triangular matrix as a dense block with an explicit zero upper triangle
+template <typename T, int D> MF_DEV void store_lower(T* __restrict__ p, const T (&m)[D][D]) {
+    MF_UNROLL for (int i = 0; i < D; ++i)
+        MF_UNROLL for (int j = 0; j < D; ++j) p[i * D + j] = (i >= j) ? m[i][j] : T(0);
+}
+
+// ---- triangular / symmetric kernels --------------------------------------------------------------
+
+// Ci = C^-1 for lower-triangular C (only the lower triangle of C is read).  `la` picks up prod diag(C).
+template <typename T, int D>
+MF_DEV void tri_inv_lower(const T (&C)[D][D], T (&Ci)[D][D], LogAcc<T>& la, bool& bad) {
+    MF_UNROLL for (int i = 0; i < D; ++i) {
+        const T c = C[i][i];
+        bad |= !(c != T(0));
+        la.mul(c);
+        Ci[i][i] = T(1) / c;
+    }
+    MF_UNROLL for (int j = 0; j < D; ++j)
+        MF_UNROLL for (int i = j + 1; i < D; ++i) {
+            T s = T(0);
+            MF_UNROLL for (int k = j; k < i; ++k) s += C[i][k] * Ci[k][j];
+            Ci[i][j] = -s * Ci[i][i];
+        }
+}
+
+// out = Lo * A   (Lo lower triangular)
+template <typename T, int D, int N>
+MF_DEV void trimul_lower(const T (&Lo)[D][D], const T (&A)[D][N], T (&out)[D][N]) {
+    MF_UNROLL for (int i = 0; i < D; ++i)
+        MF_UNROLL for (int j = 0; j < N; ++j) {
+            T s = T(0);
+            MF_UNROLL for (int k = 0; k <= i; ++k) s += Lo[i][k] * A[k][j];
+            out[i][j] = s;
+        }
+}
+template <typename T, int D>
+MF_DEV void trimul_lower_vec(const T (&Lo)[D][D], const T (&a)[D], T (&out)[D]) {
+    MF_UNROLL for (int i = 0; i < D; ++i) {
+        T s = T(0);
+        MF_UNROLL for (int k = 0; k <= i; ++k) s += Lo[i][k] * a[k];
+        out[i] = s;
+    }
+}
+// out = Lo^T * A
+template <typename T, int D, int N>
+MF_DEV void trimulT_lower(const T (&Lo)[D][D], const T (&A)[D][N], T (&out)[D][N]) {
+    MF_UNROLL for (int i = 0; i < D; ++i)
+        MF_UNROLL for (int j = 0; j < N; ++j) {
+            T s = T(0);
+            MF_UNROLL for (int k = i; k < D; ++k) s += Lo[k][i] * A[k][j];
+            out[i][j] = s;
+        }
+}
+template <typename T, int D>
+MF_DEV void trimulT_lower_vec(const T (&Lo)[D][D], const T (&a)[D], T (&out)[D]) {
+    MF_UNROLL for (int i = 0; i < D; ++i) {
+        T s = T(0);
+        MF_UNROLL for (int k = i; k < D; ++k) s += Lo[k][i] * a[k];
+        out[i] = s;
+    }
+}
+// S(lower) = Lo^T Lo
+template <typename T, int D> MF_DEV void trimulT_self_lower(const T (&Lo)[D][D], T (&S)[D][D]) {
+    MF_UNROLL for (int i = 0; i < D; ++i)
+        MF_UNROLL for (int j = 0; j <= i; ++j) {
+            T s = T(0);
+            MF_UNROLL for (int k = i; k < D; ++k) s += Lo[k][i] * Lo[k][j];
+            S[i][j] = s;
+        }
+}
+// S(lower) += sign * B^T B
+template <typename T, int D, int N>
+MF_DEV void syrk_tn_lower(const T (&B)[N][D], T (&S)[D][D], T sign) {
+    MF_UNROLL for (int i = 0; i < D; ++i)
+        MF_UNROLL for (int j = 0; j <= i; ++j) {
+            T s = T(0);
+            MF_UNROLL for (int k = 0; k < N; ++k) s += B[k][i] * B[k][j];
+            S[i][j] += sign * s;
+        }
+}
+// S(lower) += sign * W W^T
+template <typename T, int D, int N>
+MF_DEV void syrk_nt_lower(const T (&W)[D][N], T (&S)[D][D], T sign) {
+    MF_UNROLL for (int i = 0; i < D; ++i)
+        MF_UNROLL for (int j = 0; j <= i; ++j) {
+            T s = T(0);
+            MF_UNROLL for (int k = 0; k < N; ++k) s += W[i][k] * W[j][k];
+            S[i][j] += sign * s;
+        }
+}
+// out = B^T v
+template <typename T, int D, int N>
+MF_DEV void gemv_t(const T (&B)[N][D], const T (&v)[N], T (&out)[D]) {
+    MF_UNROLL for (int i = 0; i < D; ++i) {
+        T s = T(0);
+        MF_UNROLL for (int k = 0; k < N; ++k) s += B[k][i] * v[k];
+        out[i] = s;
+    }
+}
+// out = W v
+template <typename T, int D, int N>
+MF_DEV void gemv_n(const T (&W)[D][N], const T (&v)[N], T (&out)[D]) {
+    MF_UNROLL for (int i = 0; i < D; ++i) {
+        T s = T(0);
+        MF_UNROLL for (int k = 0; k < N; ++k) s += W[i][k] * v[k];
+        out[i] = s;
+    }
+}
+
+// In-place lower Cholesky of the symmetric matrix held in the lower triangle of S.  On exit the lower
+// triangle holds L and Li[i] = 1 / L[i][i].  `la` picks up prod diag(L); `bad` is set on a
+// non-positive pivot (the result is then NaN, LAPACK info > 0 style).
+template <typename T, int D>
+MF_DEV void chol_lower(T (&S)[D][D], T (&Li)[D], LogAcc<T>& la, bool& bad) {
+    MF_UNROLL for (int j = 0; j < D; ++j) {
+        T s = S[j][j];
+        MF_UNROLL for (int k = 0; k < j; ++k) s -= S[j][k] * S[j][k];
+        bad |= !(s > T(0));
+        const T l = t_sqrt<T>(s);
+        const T inv = T(1) / l;
+        S[j][j] = l;
+        Li[j] = inv;
+        la.mul(l);
+        MF_UNROLL for (int i = j + 1; i < D; ++i) {
+            T t = S[i][j];
+            MF_UNROLL for (int k = 0; k < j; ++k) t -= S[i][k] * S[j][k];
+            S[i][j] = t * inv;
+        }
+    }
+}
+
+// z <- L^-1 z
+template <typename T, int D>
+MF_DEV void trsv_lower(const T (&L)[D][D], const T (&Li)[D], T (&z)[D]) {
+    MF_UNROLL for (int i = 0; i < D; ++i) {
+        T t = z[i];
+        MF_UNROLL for (int k = 0; k < i; ++k) t -= L[i][k] * z[k];
+        z[i] = t * Li[i];
+    }
+}
+// z <- L^-T z
+template <typename T, int D>
+MF_DEV void trsv_lower_t(const T (&L)[D][D], const T (&Li)[D], T (&z)[D]) {
+    MF_UNROLL for (int i = D - 1; i >= 0; --i) {
+        T t = z[i];
+        MF_UNROLL for (int k = i + 1; k < D; ++k) t -= L[k][i] * z[k];
+        z[i] = t * Li[i];
+    }
+}
+// X <- L^-1 X   (N columns)
+template <typename T, int D, int N>
+MF_DEV void trsm_left_lower(const T (&L)[D][D], const T (&Li)[D], T (&X)[D][N]) {
+    MF_UNROLL for (int i = 0; i < D; ++i)
+        MF_UNROLL for (int c = 0; c < N; ++c) {
+            T t = X[i][c];
+            MF_UNROLL for (int k = 0; k < i; ++k) t -= L[i][k] * X[k][c];
+            X[i][c] = t * Li[i];
+        }
+}
+// X <- L^-T X
+template <typename T, int D, int N>
+MF_DEV void trsm_left_lower_t(const T (&L)[D][D], const T (&Li)[D], T (&X)[D][N]) {
+    MF_UNROLL for (int i = D - 1; i >= 0; --i)
+        MF_UNROLL for (int c = 0; c < N; ++c) {
+            T t = X[i][c];
+            MF_UNROLL for (int k = i + 1; k < D; ++k) t -= L[k][i] * X[k][c];
+            X[i][c] = t * Li[i];
+        }
+}
+// Y <- Y L^-T   (each of the R rows y solves  L y^T = b^T)
+template <typename T, int D, int R>
+MF_DEV void trsm_right_lower_t(const T (&L)[D][D], const T (&Li)[D], T (&Y)[R][D]) {
+    MF_UNROLL for (int r = 0; r < R; ++r)
+        MF_UNROLL for (int j = 0; j < D; ++j) {
+            T t = Y[r][j];
+            MF_UNROLL for (int k = 0; k < j; ++k) t -= Y[r][k] * L[j][k];
+            Y[r][j] = t * Li[j];
+        }
+}
+// Y <- Y L^-1   (each row y solves  L^T y^T = b^T)
+template <typename T, int D, int R>
+MF_DEV void trsm_right_lower(const T (&L)[D][D], const T (&Li)[D], T (&Y)[R][D]) {
+    MF_UNROLL for (int r = 0; r < R; ++r)
+        MF_UNROLL for (int j = D - 1; j >= 0; --j) {
+            T t = Y[r][j];
+            MF_UNROLL for (int k = j + 1; k < D; ++k) t -= Y[r][k] * L[k][j];
+            Y[r][j] = t * Li[j];
+        }
+}
+// X <- -(W X), column by column in place
+template <typename T, int D>
+MF_DEV void neg_mul_inplace(const T (&W)[D][D], T (&X)[D][D]) {
+    MF_UNROLL for (int c = 0; c < D; ++c) {
+        T col[D];
+        MF_UNROLL for (int i = 0; i < D; ++i) {
+            T s = T(0);
+            MF_UNROLL for (int k = 0; k < D; ++k) s += W[i][k] * X[k][c];
+            col[i] = s;
+        }
+        MF_UNROLL for (int i = 0; i < D; ++i) X[i][c] = -col[i];
+    }
+}
+
+template <typename T, int D> MF_DEV T dot_self(const T (&z)[D]) {
+    T s = T(0);
+    MF_UNROLL for (int i = 0; i < D; ++i) s += z[i] * z[i];
+    return s;
+}
+
+}  // namespace mf

@@ -1,0 +1,299 @@
+"""
+Kalman filter (SpInGP precision formulation) on the MI355X.
+
+Mirror of ``markovflow/kalman_filter.py`` (reference): ``BaseKalmanFilter``, ``KalmanFilter``,
+``GaussianSites``, ``UnivariateGaussianSitesNat``, ``KalmanFilterWithSites`` and
+``KalmanFilterWithSparseSites`` with the same constructors, attributes and methods.
+
+``log_likelihood`` is ONE fused HIP pipeline (``mf_kf_loglik_*``): precision assembly, posterior
+Cholesky, forward solve and the log-determinants never touch HBM as intermediates, and the scan
+over time is partitioned so that every SIMD of the chip has work.
+``posterior_state_space_model`` is two kernels: a parallel assembly of the posterior precision and
+information vector, and one backward UDUᵀ sweep that emits the posterior chain.
+"""
+import abc
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .block_tri_diag import SymmetricBlockTriDiagonal, _flat
+from .emission_model import EmissionModel
+from .state_space_model import StateSpaceModel
+
+
+class BaseKalmanFilter(abc.ABC):
+    """Kalman filter over a ``StateSpaceModel`` and an ``EmissionModel`` (kalman_filter.py:32-271)."""
+
+    def __init__(self, state_space_model: StateSpaceModel, emission_model: EmissionModel) -> None:
+        self.prior_ssm = state_space_model
+        self.emission = emission_model
+
+    # tuning / measurement hooks (not part of the reference API): time partitions per series (0 = automatic) and
+    # an optional pair of hipEvent_t handles recorded around the dominant kernel (used by bench.py)
+    _chunks = 0
+    _prof_events = (None, None)
+
+    @property
+    @abc.abstractmethod
+    def _r_inv(self) -> torch.Tensor:
+        """Precision of the observation model: ``[m, m]`` or ``[..., T, m, m]``."""
+
+    @property
+    @abc.abstractmethod
+    def observations(self) -> torch.Tensor:
+        """Observation vector ``batch_shape + [T, m]``."""
+
+    @property
+    def _r_inv_per_step(self) -> bool:
+        return self._r_inv.dim() > 2
+
+    @property
+    def _k_inv_prior(self) -> SymmetricBlockTriDiagonal:
+        return self.prior_ssm.precision
+
+    def _expanded(self):
+        """Emission matrix / observations / per-step precisions expanded to the chain's batch shape."""
+        batch = tuple(self.prior_ssm.batch_shape)
+        n, m, d = self.prior_ssm.num_transitions + 1, self.emission.output_dim, self.prior_ssm.state_dim
+        h = self.emission.emission_matrix
+        if tuple(h.shape[-3:]) != (n, m, d):
+            raise ValueError(f"emission matrix has shape {tuple(h.shape)}, expected [..., {n}, {m}, {d}]")
+        h = _flat(h.expand(batch + (n, m, d)), 3)
+        y = _flat(self.observations.expand(batch + (n, m)), 2)
+        r_inv = self._r_inv
+        if self._r_inv_per_step:
+            r_inv = _flat(r_inv.expand(batch + (n, m, m)), 3)
+        else:
+            r_inv = r_inv.contiguous()
+        return h, y, r_inv
+
+    @property
+    def _k_inv_post(self) -> SymmetricBlockTriDiagonal:
+        """Posterior precision ``K⁻¹ + GᵀΣ⁻¹G`` (kalman_filter.py:86-101)."""
+        h, _, r_inv = self._expanded()
+        diag, sub, _ = self.prior_ssm._precision_and_eta(h, None, r_inv, self._r_inv_per_step, want_eta=False)
+        return SymmetricBlockTriDiagonal(diag, sub)
+
+    @property
+    def _log_det_observation_precision(self) -> torch.Tensor:
+        """``T · log|R⁻¹|`` (kalman_filter.py:103-107)."""
+        num_data = self.prior_ssm.num_transitions + 1
+        return num_data * torch.linalg.slogdet(self._r_inv)[1]
+
+    def posterior_state_space_model(self) -> StateSpaceModel:
+        """Posterior as a state space model (kalman_filter.py:109-182)."""
+        h, y, r_inv = self._expanded()
+        # posterior precision and  GᵀΣ⁻¹y + K⁻¹μ  (kalman_filter.py:149-156) in one parallel kernel
+        diag, sub, eta = self.prior_ssm._precision_and_eta(h, y, r_inv, self._r_inv_per_step, want_eta=True)
+        # backward UDUᵀ sweep, m_post and chol(Δ⁻¹) fused (kalman_filter.py:159-174)
+        u_t, _, m_post, chol_dinv = SymmetricBlockTriDiagonal(diag, sub)._udl(eta)
+        return StateSpaceModel(
+            initial_mean=m_post[..., 0, :],
+            chol_initial_covariance=chol_dinv[..., 0, :, :],
+            state_transitions=-u_t,
+            state_offsets=m_post[..., 1:, :],
+            chol_process_covariances=chol_dinv[..., 1:, :, :],
+        )
+
+    def _constant_terms(self, num_points: int) -> torch.Tensor:
+        """``cst + ½ log|Σ⁻¹|`` (kalman_filter.py:229-231,249-253), shape [] or batch_shape."""
+        cst = -0.5 * math.log(2 * math.pi) * (self.emission.output_dim * num_points)
+        return cst + 0.5 * self._log_det_observation_precision
+
+    def _log_likelihood_per_series(self) -> torch.Tensor:
+        """Per-series log-likelihood WITHOUT the chain-independent constant terms, shape [B]."""
+        mu0, cp0, a_s, b_s, cq = self.prior_ssm._flat_params()
+        h, y, r_inv = self._expanded()
+        bsz, n, d, m = a_s.shape[0], self.prior_ssm.num_transitions + 1, self.prior_ssm.state_dim, h.shape[-2]
+        lib = _lib.load()
+        esz = a_s.element_size()
+        ws_bytes = int(lib.mf_kf_loglik_workspace_bytes(bsz, n, d, esz, self._chunks))
+        if ws_bytes == 0:
+            _lib.check(-100, "mf_kf_loglik")
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a_s.device)
+        out = torch.empty(bsz, dtype=a_s.dtype, device=a_s.device)
+        info = _lib.new_info(a_s.device)
+        _lib.call("mf_kf_loglik", a_s.dtype, bsz, n, d, m, _lib.ptr(mu0), _lib.ptr(cp0), _lib.ptr(a_s),
+                  _lib.ptr(b_s), _lib.ptr(cq), _lib.ptr(h), _lib.ptr(y), _lib.ptr(r_inv), int(self._r_inv_per_step),
+                  0.0, _lib.ptr(out), _lib.ptr(ws), ws_bytes, _lib.ptr(info), self._chunks, self._prof_events[0],
+                  self._prof_events[1], _lib.stream_ptr(a_s.device))
+        _lib.raise_on_info(info, "KalmanFilter.log_likelihood")
+        return out
+
+    def log_likelihood(self) -> torch.Tensor:
+        """Log marginal likelihood, summed over ``batch_shape`` (kalman_filter.py:184-255)."""
+        per_series = self._log_likelihood_per_series().reshape(tuple(self.prior_ssm.batch_shape))
+        num_data = self.prior_ssm.num_transitions + 1
+        return torch.sum(per_series + self._constant_terms(num_data))
+
+    def _back_project_y_to_state(self, observations: torch.Tensor) -> torch.Tensor:
+        """``(GᵀΣ⁻¹) y`` (kalman_filter.py:257-271)."""
+        back = torch.einsum("...ij,...ki->...kj", self.emission.emission_matrix, self._r_inv)
+        return torch.einsum("...ij,...i->...j", back, observations)
+
+
+class KalmanFilter(BaseKalmanFilter):
+    """Kalman filter with one observation covariance shared by all time points (kalman_filter.py:275-353)."""
+
+    def __init__(
+        self,
+        state_space_model: StateSpaceModel,
+        emission_model: EmissionModel,
+        observations: torch.Tensor,
+        chol_obs_covariance: torch.Tensor,
+    ) -> None:
+        """
+        :param observations: ``batch_shape + [num_transitions + 1, output_dim]``.
+        :param chol_obs_covariance: ``[output_dim, output_dim]`` Cholesky of the observation covariance.
+        """
+        super().__init__(state_space_model, emission_model)
+        assert isinstance(observations, torch.Tensor)   # kalman_filter.py:318 (tensor, not ndarray)
+        m = emission_model.output_dim
+        if tuple(chol_obs_covariance.shape) != (m, m):
+            raise ValueError("The shape of the observation covariance matrix and the emission matrix are not compatible")
+        shape = tuple(state_space_model.batch_shape) + (state_space_model.num_transitions + 1, m)
+        if tuple(observations.shape) != shape:
+            raise ValueError("The shape of the observations and the state-space-model parameters are not compatible")
+        self._chol_obs_covariance = chol_obs_covariance
+        self._observations = observations
+
+    @property
+    def _r_inv(self) -> torch.Tensor:
+        eye = torch.eye(self.emission.output_dim, dtype=self._chol_obs_covariance.dtype,
+                        device=self._chol_obs_covariance.device)
+        return torch.cholesky_solve(eye, self._chol_obs_covariance)
+
+    @property
+    def observations(self) -> torch.Tensor:
+        return self._observations
+
+
+class GaussianSites(abc.ABC):
+    """Parameters of independent Gaussian sites (kalman_filter.py:356-379)."""
+
+    @property
+    def means(self):
+        raise NotImplementedError
+
+    @property
+    def precisions(self):
+        raise NotImplementedError
+
+    @property
+    def log_det_precisions(self):
+        raise NotImplementedError
+
+
+class UnivariateGaussianSitesNat(GaussianSites):
+    """Univariate Gaussian sites in natural parameters (kalman_filter.py:382-433)."""
+
+    def __init__(self, nat1: torch.Tensor, nat2: torch.Tensor, log_norm: Optional[torch.Tensor] = None):
+        """:param nat1: ``[N, 1]``; :param nat2: ``[N, 1, 1]``; :param log_norm: ``[N, 1]`` or None."""
+        if nat1.dim() != 2 or nat1.shape[-1] != 1:
+            raise ValueError(f"nat1 must have shape [N, 1], got {tuple(nat1.shape)}")
+        if tuple(nat2.shape) != (nat1.shape[0], 1, 1):
+            raise ValueError(f"nat2 must have shape [N, 1, 1], got {tuple(nat2.shape)}")
+        if log_norm is not None and tuple(log_norm.shape) != (nat1.shape[0], 1):
+            raise ValueError(f"log_norm must have shape [N, 1], got {tuple(log_norm.shape)}")
+        self.num_data, self.output_dim = nat1.shape
+        self.nat1 = nat1
+        self.nat2 = nat2
+        self.log_norm = log_norm
+
+    @property
+    def means(self):
+        return -0.5 * self.nat1 / self.nat2[..., 0]
+
+    @property
+    def precisions(self):
+        return -2 * self.nat2
+
+    @property
+    def log_det_precisions(self):
+        return torch.log(-2 * self.nat2)
+
+
+class KalmanFilterWithSites(BaseKalmanFilter):
+    """Kalman filter with time-dependent Gaussian sites (kalman_filter.py:437-497)."""
+
+    def __init__(self, state_space_model: StateSpaceModel, emission_model: EmissionModel, sites: GaussianSites) -> None:
+        if sites.output_dim != emission_model.output_dim:
+            raise ValueError("The shape of the site matrices and the emission matrix are not compatible")
+        self.sites = sites
+        super().__init__(state_space_model, emission_model)
+
+    @property
+    def _r_inv(self):
+        return self.sites.precisions
+
+    @property
+    def _log_det_observation_precision(self):
+        return torch.sum(torch.linalg.slogdet(self._r_inv)[1], dim=-1)
+
+    @property
+    def observations(self):
+        return self.sites.means
+
+
+class KalmanFilterWithSparseSites(BaseKalmanFilter):
+    """Kalman filter with Gaussian sites observed on a subset of a time grid (kalman_filter.py:501-626)."""
+
+    def __init__(self, state_space_model: StateSpaceModel, emission_model: EmissionModel, sites: GaussianSites,
+                 num_grid_points: int, observations_index: torch.Tensor, observations: torch.Tensor):
+        """
+        :param num_grid_points: number of grid points.
+        :param observations_index: ``[N, 1]`` int64 positions of the observations in the grid.
+        :param observations: ``[n_batch] + [N, output_dim]`` sparse observations.
+        """
+        self.sites = sites
+        self.observations_index = observations_index
+        self.sparse_observations = self._drop_batch_shape(observations)
+        self.grid_shape = (num_grid_points, 1)
+        super().__init__(state_space_model, emission_model)
+
+    @property
+    def _r_inv(self):
+        return self.sparse_to_dense(self.sites.precisions, output_shape=self.grid_shape + (1,))
+
+    def _drop_batch_shape(self, tensor: torch.Tensor):
+        """Check the batch, if present, is 1 and drop it (kalman_filter.py:531-539)."""
+        if tensor.dim() < 3:
+            return tensor
+        if tensor.shape[0] != 1:
+            raise Exception("KalmanFilterWithSparseSites doesn't support batches")
+        return tensor.squeeze(0)
+
+    @property
+    def _log_det_observation_precision(self):
+        return torch.sum(torch.linalg.slogdet(self._r_inv_data)[1], dim=-1)
+
+    @property
+    def observations(self):
+        return self.sparse_to_dense(self.sparse_observations, self.grid_shape)
+
+    @property
+    def _r_inv_data(self):
+        return self.sites.precisions
+
+    def sparse_to_dense(self, tensor: torch.Tensor, output_shape) -> torch.Tensor:
+        """Scatter onto the grid (the tf.scatter_nd of kalman_filter.py:561-565; duplicates add)."""
+        out = torch.zeros(tuple(output_shape), dtype=tensor.dtype, device=tensor.device)
+        idx = self.observations_index.reshape(-1).to(device=tensor.device, dtype=torch.long)
+        return out.index_add_(0, idx, tensor.reshape((idx.shape[0],) + tuple(output_shape[1:])))
+
+    def dense_to_sparse(self, tensor: torch.Tensor) -> torch.Tensor:
+        """Gather from the grid (kalman_filter.py:567-577)."""
+        expand_dims = tensor.dim() == 3
+        idx = self.observations_index.reshape(-1).to(device=tensor.device, dtype=torch.long)
+        out = tensor.reshape(-1, 1)[idx]
+        if expand_dims:
+            out = out[..., None]
+        return out
+
+    def log_likelihood(self) -> torch.Tensor:
+        """Log marginal likelihood; only observed points count in the constants (kalman_filter.py:579-626)."""
+        per_series = self._log_likelihood_per_series()
+        num_data = self.observations_index.shape[0]
+        return torch.sum(per_series + self._constant_terms(num_data))

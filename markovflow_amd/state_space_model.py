@@ -1,0 +1,282 @@
+"""
+State space model ``x_{k+1} = A_k x_k + b_k + q_k`` on the MI355X.
+
+Mirror of ``markovflow/state_space_model.py`` (reference): same constructor, properties and
+methods.  The sequential pieces (precision assembly, mean recursion, Cholesky, Takahashi
+diagonal-of-inverse) are HIP kernels behind the C ABI; the remaining glue is element-wise torch
+on the device, as it is element-wise TensorFlow in the reference.
+"""
+import math
+from typing import Tuple
+
+import torch
+
+from . import _lib
+from .block_tri_diag import LowerTriangularBlockTriDiagonal, SymmetricBlockTriDiagonal, _flat
+from .gauss_markov import GaussMarkovDistribution, SampleShape, check_compatible
+
+
+class StateSpaceModel(GaussMarkovDistribution):
+    """State space model (state_space_model.py:35-609)."""
+
+    def __init__(
+        self,
+        initial_mean: torch.Tensor,
+        chol_initial_covariance: torch.Tensor,
+        state_transitions: torch.Tensor,
+        state_offsets: torch.Tensor,
+        chol_process_covariances: torch.Tensor,
+    ) -> None:
+        """
+        :param initial_mean: ``batch_shape + [state_dim]``.
+        :param chol_initial_covariance: ``batch_shape + [state_dim, state_dim]``.
+        :param state_transitions: ``batch_shape + [num_transitions, state_dim, state_dim]``.
+        :param state_offsets: ``batch_shape + [num_transitions, state_dim]``.
+        :param chol_process_covariances: ``batch_shape + [num_transitions, state_dim, state_dim]``.
+        """
+        # shape checks of state_space_model.py:101-116 (InvalidArgumentError there, ValueError here)
+        if initial_mean.dim() < 1 or chol_initial_covariance.dim() < 2 or state_transitions.dim() < 3 \
+                or state_offsets.dim() < 2 or chol_process_covariances.dim() < 3:
+            raise ValueError("StateSpaceModel: parameter ranks are too small")
+        d = initial_mean.shape[-1]
+        n = state_transitions.shape[-3]
+        if d < 1:
+            raise ValueError("StateSpaceModel: state_dim must be at least 1")
+        if n < 1:
+            raise ValueError("StateSpaceModel: num_transitions must be at least 1")   # test_state_space_model.py:58-60
+        batch = tuple(initial_mean.shape[:-1])
+        expect = {
+            "chol_initial_covariance": (chol_initial_covariance, batch + (d, d)),
+            "state_transitions": (state_transitions, batch + (n, d, d)),
+            "state_offsets": (state_offsets, batch + (n, d)),
+            "chol_process_covariances": (chol_process_covariances, batch + (n, d, d)),
+        }
+        for name, (t, shape) in expect.items():
+            if tuple(t.shape) != shape:
+                raise ValueError(f"StateSpaceModel: {name} has shape {tuple(t.shape)}, expected {shape}")
+            if t.dtype != initial_mean.dtype or t.device != initial_mean.device:
+                raise ValueError(f"StateSpaceModel: {name} must share dtype and device with initial_mean")
+        self._mu_0 = initial_mean
+        self._A_s = state_transitions
+        self._chol_P_0 = chol_initial_covariance
+        self._chol_Q_s = chol_process_covariances
+        self._b_s = state_offsets
+
+    # -- shapes / accessors (state_space_model.py:126-229) ------------------------------------------------
+    @property
+    def event_shape(self) -> Tuple[int, int]:
+        return (self.num_transitions + 1, self.state_dim)
+
+    @property
+    def batch_shape(self) -> torch.Size:
+        return self._A_s.shape[:-3]
+
+    @property
+    def state_dim(self) -> int:
+        return self._A_s.shape[-2]
+
+    @property
+    def num_transitions(self) -> int:
+        return self._A_s.shape[-3]
+
+    @property
+    def cholesky_process_covariances(self) -> torch.Tensor:
+        return self._chol_Q_s
+
+    @property
+    def cholesky_initial_covariance(self) -> torch.Tensor:
+        return self._chol_P_0
+
+    @property
+    def initial_covariance(self) -> torch.Tensor:
+        return self._chol_P_0 @ self._chol_P_0.transpose(-1, -2)
+
+    @property
+    def concatenated_cholesky_process_covariance(self) -> torch.Tensor:
+        return torch.cat([self._chol_P_0[..., None, :, :], self._chol_Q_s], dim=-3)
+
+    @property
+    def state_offsets(self) -> torch.Tensor:
+        return self._b_s
+
+    @property
+    def initial_mean(self) -> torch.Tensor:
+        return self._mu_0
+
+    @property
+    def concatenated_state_offsets(self) -> torch.Tensor:
+        return torch.cat([self._mu_0[..., None, :], self._b_s], dim=-2)
+
+    @property
+    def state_transitions(self) -> torch.Tensor:
+        return self._A_s
+
+    # -- C-ABI plumbing ---------------------------------------------------------------------------------
+    def _flat_params(self):
+        return (_flat(self._mu_0, 1), _flat(self._chol_P_0, 2), _flat(self._A_s, 3), _flat(self._b_s, 2),
+                _flat(self._chol_Q_s, 3))
+
+    def _propagate(self, offsets: torch.Tensor) -> torch.Tensor:
+        """Solve ``A⁻¹ x = offsets`` (the a_inv_block.solve of state_space_model.py:251,322)."""
+        lead = tuple(offsets.shape[:-2])
+        a_f = _flat(self._A_s, 3)
+        offs = _flat(offsets, 2)
+        out = torch.empty_like(offs)
+        _lib.call("mf_ssm_marginal_means", offs.dtype, a_f.shape[0], offs.shape[0], self.num_transitions + 1,
+                  self.state_dim, _lib.ptr(a_f), _lib.ptr(offs), _lib.ptr(out), _lib.stream_ptr(offs.device))
+        return out.reshape(lead + (self.num_transitions + 1, self.state_dim))
+
+    # -- marginals ----------------------------------------------------------------------------------------
+    @property
+    def marginal_means(self) -> torch.Tensor:
+        """``μ_{k+1} = A_k μ_k + b_k`` (state_space_model.py:232-251)."""
+        return self._propagate(self.concatenated_state_offsets)
+
+    @property
+    def marginal_covariances(self) -> torch.Tensor:
+        """Diagonal blocks of the covariance (state_space_model.py:254-262)."""
+        return self.precision.cholesky.block_diagonal_of_inverse()
+
+    def covariance_blocks(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        covs = self.marginal_covariances
+        return covs, self.subsequent_covariances(covs)
+
+    @property
+    def a_inv_block(self) -> LowerTriangularBlockTriDiagonal:
+        """``A⁻¹`` as unit lower block-bidiagonal (state_space_model.py:277-296)."""
+        identities = torch.eye(self.state_dim, dtype=self._A_s.dtype, device=self._A_s.device).expand(
+            tuple(self.batch_shape) + (self.num_transitions + 1, self.state_dim, self.state_dim)).contiguous()
+        return LowerTriangularBlockTriDiagonal(identities, -self._A_s)
+
+    def sample(self, sample_shape: SampleShape) -> torch.Tensor:
+        """Sample trajectories, ``sample_shape + batch_shape + event_shape`` (state_space_model.py:298-324)."""
+        if isinstance(sample_shape, int):
+            sample_shape = (sample_shape,)
+        full = tuple(sample_shape) + tuple(self.batch_shape) + self.event_shape
+        eps = torch.randn(full + (1,), dtype=self._A_s.dtype, device=self._A_s.device)
+        z = torch.matmul(self.concatenated_cholesky_process_covariance, eps)[..., 0]
+        cond = self.concatenated_state_offsets + z
+        if cond.numel() == 0:
+            return cond
+        return self._propagate(cond)
+
+    def subsequent_covariances(self, marginal_covariances: torch.Tensor) -> torch.Tensor:
+        """``Cov(x_{k+1}, x_k) = A_k P_k`` (state_space_model.py:326-341)."""
+        return self._A_s @ marginal_covariances[..., :-1, :, :]
+
+    def log_det_precision(self) -> torch.Tensor:
+        """``-2 (log|chol P0| + Σ log|chol Q_k|)`` (state_space_model.py:343-373)."""
+        d0 = torch.diagonal(self._chol_P_0, dim1=-2, dim2=-1)
+        dq = torch.diagonal(self._chol_Q_s, dim1=-2, dim2=-1)
+        return -(torch.sum(torch.log(torch.square(d0)), dim=-1) + torch.sum(torch.log(torch.square(dq)), dim=(-1, -2)))
+
+    def create_non_trainable_copy(self) -> "StateSpaceModel":
+        """Detached copy (state_space_model.py:375-394)."""
+        return StateSpaceModel(self._mu_0.detach(), self._chol_P_0.detach(), self._A_s.detach(), self._b_s.detach(),
+                               self._chol_Q_s.detach())
+
+    def create_trainable_copy(self) -> "StateSpaceModel":
+        """Copy with leaf parameters that require grad (state_space_model.py:396-429).
+
+        The reference wraps the Choleskys in a FillTriangular bijector; here the lower-triangular
+        structure is kept by construction (``tril`` of a leaf tensor).
+        """
+        def leaf(t):
+            return t.detach().clone().requires_grad_(True)
+
+        ssm = StateSpaceModel(leaf(self._mu_0), torch.tril(leaf(self._chol_P_0)), leaf(self._A_s), leaf(self._b_s),
+                              torch.tril(leaf(self._chol_Q_s)))
+        check_compatible(ssm, self)
+        return ssm
+
+    def _build_precision(self) -> SymmetricBlockTriDiagonal:
+        """``K⁻¹ = A⁻ᵀ Q⁻¹ A⁻¹`` in block form (state_space_model.py:431-483)."""
+        diag, sub, _ = self._precision_and_eta(None, None, None, False, want_eta=False)
+        return SymmetricBlockTriDiagonal(diag, sub)
+
+    def _precision_and_eta(self, h, y, r_inv, per_step: bool, want_eta: bool):
+        mu0, cp0, a_s, b_s, cq = self._flat_params()
+        bsz, n, d = a_s.shape[0], self.num_transitions + 1, self.state_dim
+        diag = torch.empty((bsz, n, d, d), dtype=a_s.dtype, device=a_s.device)
+        sub = torch.empty((bsz, n - 1, d, d), dtype=a_s.dtype, device=a_s.device)
+        eta = torch.empty((bsz, n, d), dtype=a_s.dtype, device=a_s.device) if want_eta else None
+        m = 1 if h is None else h.shape[-2]
+        _lib.call("mf_ssm_precision", a_s.dtype, bsz, n, d, m, _lib.ptr(mu0), _lib.ptr(cp0), _lib.ptr(a_s),
+                  _lib.ptr(b_s), _lib.ptr(cq), _lib.ptr(h), _lib.ptr(y), _lib.ptr(r_inv), int(per_step),
+                  _lib.ptr(diag), _lib.ptr(sub), _lib.ptr(eta), _lib.stream_ptr(a_s.device))
+        batch = tuple(self.batch_shape)
+        diag, sub = diag.reshape(batch + (n, d, d)), sub.reshape(batch + (n - 1, d, d))
+        if eta is not None:
+            eta = eta.reshape(batch + (n, d))
+        return diag, sub, eta
+
+    def _log_pdf_factors(self, states: torch.Tensor) -> torch.Tensor:
+        """``[log p(x₀), log p(x₁|x₀), ...]`` (state_space_model.py:485-513)."""
+        if tuple(states.shape[-2:]) != self.event_shape:
+            raise ValueError(f"states has shape {tuple(states.shape)}, event shape is {self.event_shape}")
+        d = self.state_dim
+
+        def mvn_tril(loc, tril, x):
+            diff = (x - loc)[..., None]
+            tril_b = tril.expand(diff.shape[:-2] + tril.shape[-2:])
+            z = torch.linalg.solve_triangular(tril_b, diff, upper=False)[..., 0]
+            logdet = torch.sum(torch.log(torch.abs(torch.diagonal(tril, dim1=-2, dim2=-1))), dim=-1)
+            return -0.5 * torch.sum(z * z, dim=-1) - logdet - 0.5 * d * math.log(2 * math.pi)
+
+        init = mvn_tril(self._mu_0, self._chol_P_0, states[..., 0, :])
+        cond = torch.matmul(self._A_s, states[..., :-1, :, None])[..., 0] + self._b_s
+        rest = mvn_tril(cond, self._chol_Q_s, states[..., 1:, :])
+        return torch.cat([init[..., None], rest], dim=-1)
+
+    def log_pdf(self, states) -> torch.Tensor:
+        """``log p(x)`` (state_space_model.py:515-526)."""
+        return torch.sum(self._log_pdf_factors(states), dim=-1)
+
+    def kl_divergence(self, dist: GaussMarkovDistribution) -> torch.Tensor:
+        """``KL(self ∥ dist)`` with shape ``batch_shape`` (state_space_model.py:528-593)."""
+        check_compatible(self, dist)
+        marginal_covs_1 = self.marginal_covariances
+        precision_2 = dist.precision
+        subsequent_covs_1 = self.subsequent_covariances(marginal_covs_1)
+        trace = torch.sum(precision_2.block_diagonal * marginal_covs_1, dim=(-3, -2, -1)) + 2.0 * torch.sum(
+            precision_2.block_sub_diagonal * subsequent_covs_1, dim=(-3, -2, -1))
+        mean_diff = dist.marginal_means - self.marginal_means
+        l_mean_diff = precision_2.cholesky.dense_mult(mean_diff, transpose_left=True)
+        mahalanobis = torch.sum(l_mean_diff * l_mean_diff, dim=(-2, -1))
+        dim = (self.num_transitions + 1) * self.state_dim
+        return 0.5 * (trace + mahalanobis - dim - dist.log_det_precision() + self.log_det_precision())
+
+    def normalizer(self):
+        """Normaliser of the chain (state_space_model.py:595-609)."""
+        dim = (self.num_transitions + 1) * self.state_dim
+        cst = dim * math.log(2.0 * math.pi)
+        log_det = -self.log_det_precision()
+        l_mean = self.precision.cholesky.dense_mult(self.marginals[0], transpose_left=True)
+        mahalanobis = torch.sum(l_mean * l_mean, dim=(-2, -1))
+        return 0.5 * (cst + log_det + mahalanobis)
+
+
+def state_space_model_from_covariances(
+    initial_mean: torch.Tensor,
+    initial_covariance: torch.Tensor,
+    state_transitions: torch.Tensor,
+    state_offsets: torch.Tensor,
+    process_covariances: torch.Tensor,
+) -> StateSpaceModel:
+    """Build from full covariances; all-zero matrices pass through as zero (state_space_model.py:613-664)."""
+
+    def cholesky_or_zero(covariance: torch.Tensor) -> torch.Tensor:
+        if covariance.numel() < 1:
+            raise ValueError("covariance must have at least one element")
+        mask = torch.all(covariance == 0, dim=-1).all(dim=-1)[..., None, None]
+        eye = torch.eye(covariance.shape[-1], dtype=covariance.dtype, device=covariance.device)
+        fix = torch.where(mask, eye, torch.zeros_like(covariance))
+        return torch.where(mask, torch.zeros_like(covariance), torch.linalg.cholesky(covariance + fix))
+
+    return StateSpaceModel(
+        initial_mean=initial_mean,
+        chol_initial_covariance=cholesky_or_zero(initial_covariance),
+        state_transitions=state_transitions,
+        state_offsets=state_offsets,
+        chol_process_covariances=cholesky_or_zero(process_covariances),
+    )

@@ -1,0 +1,277 @@
+/*
+ * CPU restatement (plain C, fp64) of the reference's Kalman log-likelihood / block-tridiagonal path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE: only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it.  It is the timed "CPU port" of the reference algorithm
+ * (TensorFlow + banded_matrices cannot be installed here or on the GPU box) and a second,
+ * independent implementation for differential testing of the numpy oracle.
+ *
+ * The steps follow the reference one by one - they are NOT the fused formulation of the HIP kernels:
+ *   precision assembly      markovflow/state_space_model.py:431-483  (cholesky_solve x2 + matmul)
+ *   + H^T R^-1 H            markovflow/kalman_filter.py:86-101
+ *   natural-order Cholesky  markovflow/block_tri_diag.py:423-436     (banded_matrices.cholesky_band)
+ *   marginal means          markovflow/state_space_model.py:232-251
+ *   forward solve           markovflow/block_tri_diag.py:339-351     (banded_matrices.solve_triang_mat)
+ *   log-dets, terms         markovflow/kalman_filter.py:229-255, state_space_model.py:343-373,
+ *                           block_tri_diag.py:353-366
+ * Layout: row-major [B,T,d,d] / [B,T,d] exactly like the reference tensors.  OpenMP over series.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MAXD 64
+
+/* lower Cholesky in place (only lower triangle referenced/written); returns 0 or 1+index of bad pivot */
+static int chol_lower(double *a, int d) {
+    for (int j = 0; j < d; ++j) {
+        double s = a[j * d + j];
+        for (int k = 0; k < j; ++k) s -= a[j * d + k] * a[j * d + k];
+        if (!(s > 0.0)) return j + 1;
+        double l = sqrt(s);
+        a[j * d + j] = l;
+        for (int i = j + 1; i < d; ++i) {
+            double t = a[i * d + j];
+            for (int k = 0; k < j; ++k) t -= a[i * d + k] * a[j * d + k];
+            a[i * d + j] = t / l;
+        }
+        for (int k = j + 1; k < d; ++k) a[j * d + k] = 0.0;
+    }
+    return 0;
+}
+
+/* x <- L^-1 x (n right-hand sides stored as columns of a row-major d x n matrix) */
+static void trsm_lower(const double *l, double *x, int d, int n) {
+    for (int i = 0; i < d; ++i)
+        for (int c = 0; c < n; ++c) {
+            double t = x[i * n + c];
+            for (int k = 0; k < i; ++k) t -= l[i * d + k] * x[k * n + c];
+            x[i * n + c] = t / l[i * d + i];
+        }
+}
+
+/* x <- L^-T x */
+static void trsm_lower_t(const double *l, double *x, int d, int n) {
+    for (int i = d - 1; i >= 0; --i)
+        for (int c = 0; c < n; ++c) {
+            double t = x[i * n + c];
+            for (int k = i + 1; k < d; ++k) t -= l[k * d + i] * x[k * n + c];
+            x[i * n + c] = t / l[i * d + i];
+        }
+}
+
+/* (chol chol^T)^-1 rhs, the meaning of tf.linalg.cholesky_solve */
+static void chol_solve(const double *chol, double *rhs, int d, int n) {
+    trsm_lower(chol, rhs, d, n);
+    trsm_lower_t(chol, rhs, d, n);
+}
+
+/* per-series precision blocks: diag[T,d,d], sub[T-1,d,d]  (state_space_model.py:431-483) */
+static void build_precision(int T, int d, const double *cholP0, const double *A, const double *cholQ,
+                            double *diag, double *sub) {
+    double tmp[MAXD * MAXD];
+    for (int k = 0; k < T; ++k) {
+        const double *c = k == 0 ? cholP0 : cholQ + (size_t)(k - 1) * d * d;
+        double *dk = diag + (size_t)k * d * d;
+        memset(dk, 0, sizeof(double) * d * d);
+        for (int i = 0; i < d; ++i) dk[i * d + i] = 1.0;
+        chol_solve(c, dk, d, d);                       /* [P0^-1, Q^-1 ...] */
+    }
+    for (int k = 0; k < T - 1; ++k) {
+        const double *a = A + (size_t)k * d * d;
+        memcpy(tmp, a, sizeof(double) * d * d);
+        chol_solve(cholQ + (size_t)k * d * d, tmp, d, d);   /* Q^-1 A */
+        double *dk = diag + (size_t)k * d * d;
+        double *sk = sub + (size_t)k * d * d;
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j < d; ++j) {
+                double s = 0.0;
+                for (int l = 0; l < d; ++l) s += a[l * d + i] * tmp[l * d + j];   /* A^T Q^-1 A */
+                dk[i * d + j] += s;
+                sk[i * d + j] = -tmp[i * d + j];
+            }
+    }
+}
+
+/* natural-order block Cholesky in place: diag -> L blocks, sub -> W blocks  (Appendix B.1) */
+static int btd_cholesky_inplace(int T, int d, double *diag, double *sub) {
+    double wt[MAXD * MAXD];
+    for (int k = 0; k < T; ++k) {
+        double *dk = diag + (size_t)k * d * d;
+        if (k > 0 && sub) {
+            double *s = sub + (size_t)(k - 1) * d * d;
+            const double *lp = diag + (size_t)(k - 1) * d * d;
+            for (int i = 0; i < d; ++i) for (int j = 0; j < d; ++j) wt[j * d + i] = s[i * d + j];
+            trsm_lower(lp, wt, d, d);                  /* W^T = L^-1 S^T */
+            for (int i = 0; i < d; ++i) for (int j = 0; j < d; ++j) s[i * d + j] = wt[j * d + i];
+            for (int i = 0; i < d; ++i)
+                for (int j = 0; j <= i; ++j) {
+                    double acc = 0.0;
+                    for (int l = 0; l < d; ++l) acc += s[i * d + l] * s[j * d + l];
+                    dk[i * d + j] -= acc;
+                }
+        }
+        int info = chol_lower(dk, d);
+        if (info) return k * d + info;
+    }
+    return 0;
+}
+
+int mf_oracle_btd_cholesky_f64(int64_t B, int64_t T, int d, const double *diag, const double *sub,
+                               double *ldiag, double *lsub) {
+    if (d > MAXD) return -3;
+    int bad = 0;
+#pragma omp parallel for schedule(static)
+    for (int64_t s = 0; s < B; ++s) {
+        double *ld = ldiag + (size_t)s * T * d * d;
+        double *ls = sub ? lsub + (size_t)s * (T - 1) * d * d : NULL;
+        memcpy(ld, diag + (size_t)s * T * d * d, sizeof(double) * T * d * d);
+        if (sub) memcpy(ls, sub + (size_t)s * (T - 1) * d * d, sizeof(double) * (T - 1) * d * d);
+        if (btd_cholesky_inplace((int)T, d, ld, ls)) bad = 1;
+    }
+    return bad;
+}
+
+int mf_oracle_btd_solve_f64(int64_t B, int64_t T, int d, const double *ldiag, const double *lsub,
+                            const double *rhs, double *out, int transpose) {
+    if (d > MAXD) return -3;
+#pragma omp parallel for schedule(static)
+    for (int64_t s = 0; s < B; ++s) {
+        const double *ld = ldiag + (size_t)s * T * d * d;
+        const double *ls = lsub ? lsub + (size_t)s * (T - 1) * d * d : NULL;
+        const double *r = rhs + (size_t)s * T * d;
+        double *o = out + (size_t)s * T * d;
+        memcpy(o, r, sizeof(double) * T * d);
+        if (!transpose) {
+            for (int64_t k = 0; k < T; ++k) {
+                if (k > 0 && ls)
+                    for (int i = 0; i < d; ++i) {
+                        double acc = 0.0;
+                        for (int j = 0; j < d; ++j) acc += ls[(k - 1) * d * d + i * d + j] * o[(k - 1) * d + j];
+                        o[k * d + i] -= acc;
+                    }
+                trsm_lower(ld + k * d * d, o + k * d, d, 1);
+            }
+        } else {
+            for (int64_t k = T - 1; k >= 0; --k) {
+                if (k < T - 1 && ls)
+                    for (int i = 0; i < d; ++i) {
+                        double acc = 0.0;
+                        for (int j = 0; j < d; ++j) acc += ls[k * d * d + j * d + i] * o[(k + 1) * d + j];
+                        o[k * d + i] -= acc;
+                    }
+                trsm_lower_t(ld + k * d * d, o + k * d, d, 1);
+            }
+        }
+    }
+    return 0;
+}
+
+/*
+ * KalmanFilter.log_likelihood per series (kalman_filter.py:184-255).
+ * rinv_per_step == 0: Rinv is [m,m] shared (KalmanFilter); 1: [B,T,m,m] (sites variants).
+ * The term 0.5*log|Sigma^-1| and the 2*pi constant are included for the shared case; for the
+ * per-step case the caller adds 0.5*sum_k logdet(R_k^-1) itself (kalman_filter.py:489-492) and
+ * this function includes only the 2*pi constant over all T steps.
+ */
+int mf_oracle_kf_loglik_f64(int64_t B, int64_t T, int d, int m, const double *mu0, const double *cholP0,
+                            const double *A, const double *b, const double *cholQ, const double *H,
+                            const double *y, const double *Rinv, int rinv_per_step, double *out) {
+    if (d > MAXD || m > 8) return -3;
+    int bad = 0;
+    double logdet_rinv = 0.0;
+    if (!rinv_per_step) {
+        double tmp[64];
+        memcpy(tmp, Rinv, sizeof(double) * m * m);
+        if (chol_lower(tmp, m)) return -12;
+        for (int i = 0; i < m; ++i) logdet_rinv += 2.0 * log(tmp[i * m + i]);
+    }
+#pragma omp parallel
+    {
+        double *diag = (double *)malloc(sizeof(double) * T * d * d);
+        double *sub = (double *)malloc(sizeof(double) * (T > 1 ? T - 1 : 1) * d * d);
+        double *rhs = (double *)malloc(sizeof(double) * T * d);
+#pragma omp for schedule(static)
+        for (int64_t s = 0; s < B; ++s) {
+            const double *As = A + (size_t)s * (T - 1) * d * d;
+            const double *Qs = cholQ + (size_t)s * (T - 1) * d * d;
+            const double *bs = b + (size_t)s * (T - 1) * d;
+            const double *Hs = H + (size_t)s * T * m * d;
+            const double *ys = y + (size_t)s * T * m;
+            const double *P0 = cholP0 + (size_t)s * d * d;
+            build_precision((int)T, d, P0, As, Qs, diag, sub);
+            double mu[MAXD], nxt[MAXD], disp[8], rv[8];
+            memcpy(mu, mu0 + (size_t)s * d, sizeof(double) * d);
+            double term1 = 0.0;
+            for (int64_t k = 0; k < T; ++k) {
+                const double *ri = rinv_per_step ? Rinv + ((size_t)s * T + k) * m * m : Rinv;
+                const double *h = Hs + (size_t)k * m * d;
+                double *dk = diag + (size_t)k * d * d;
+                for (int i = 0; i < d; ++i)                       /* + H^T R^-1 H */
+                    for (int j = 0; j < d; ++j) {
+                        double acc = 0.0;
+                        for (int o = 0; o < m; ++o)
+                            for (int p = 0; p < m; ++p) acc += h[o * d + i] * ri[o * m + p] * h[p * d + j];
+                        dk[i * d + j] += acc;
+                    }
+                for (int o = 0; o < m; ++o) {                     /* disp = y - H mu */
+                    double acc = 0.0;
+                    for (int j = 0; j < d; ++j) acc += h[o * d + j] * mu[j];
+                    disp[o] = ys[k * m + o] - acc;
+                }
+                for (int o = 0; o < m; ++o) {
+                    double acc = 0.0;
+                    for (int p = 0; p < m; ++p) acc += ri[o * m + p] * disp[p];
+                    rv[o] = acc;
+                    term1 += disp[o] * acc;
+                }
+                for (int j = 0; j < d; ++j) {                     /* (G^T Sigma^-1) disp */
+                    double acc = 0.0;
+                    for (int o = 0; o < m; ++o) acc += h[o * d + j] * rv[o];
+                    rhs[k * d + j] = acc;
+                }
+                if (k < T - 1) {                                  /* mu_{k+1} = A mu_k + b */
+                    for (int i = 0; i < d; ++i) {
+                        double acc = bs[k * d + i];
+                        for (int j = 0; j < d; ++j) acc += As[k * d * d + i * d + j] * mu[j];
+                        nxt[i] = acc;
+                    }
+                    memcpy(mu, nxt, sizeof(double) * d);
+                }
+            }
+            if (btd_cholesky_inplace((int)T, d, diag, T > 1 ? sub : NULL)) bad = 1;
+            double term2 = 0.0, logdet_l = 0.0, logdet_prior = 0.0;
+            for (int64_t k = 0; k < T; ++k) {
+                if (k > 0)
+                    for (int i = 0; i < d; ++i) {
+                        double acc = 0.0;
+                        for (int j = 0; j < d; ++j) acc += sub[(k - 1) * d * d + i * d + j] * rhs[(k - 1) * d + j];
+                        rhs[k * d + i] -= acc;
+                    }
+                trsm_lower(diag + k * d * d, rhs + k * d, d, 1);
+                for (int i = 0; i < d; ++i) {
+                    term2 += rhs[k * d + i] * rhs[k * d + i];
+                    double l = diag[k * d * d + i * d + i];
+                    logdet_l += 0.5 * log(l * l);
+                    double c = k == 0 ? P0[i * d + i] : Qs[(k - 1) * d * d + i * d + i];
+                    logdet_prior -= log(c * c);
+                }
+            }
+            double cst = -0.5 * log(2.0 * M_PI) * (double)(m * T);
+            out[s] = cst - 0.5 * term1 + 0.5 * term2 + 0.5 * logdet_prior - logdet_l
+                     + (rinv_per_step ? 0.0 : 0.5 * (double)T * logdet_rinv);
+        }
+        free(diag); free(sub); free(rhs);
+    }
+    return bad;
+}
+
+int mf_oracle_num_threads(void) {
+#ifdef _OPENMP
+    extern int omp_get_max_threads(void);
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

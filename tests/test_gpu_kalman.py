@@ -1,0 +1,264 @@
+"""
+GPU parity tests of KalmanFilter / StateSpaceModel (through the C ABI) against the golden vectors produced by
+the reference's numpy Kalman filter and against the numpy oracle.  They re-express
+/root/reference/tests/integration/test_kalman_filter.py:105-139, test_kalman_filter_with_sites.py,
+test_kalman_filter_with_sparse_sites.py:69-104, tests/unit/test_state_space_model.py and the GPR identity of
+tests/integration/models/test_gaussian_process_regression.py:99-105.
+Tolerances (written per test): fp64 log-likelihood rtol 1e-9 vs the oracle on identical inputs; fp32 rtol 5e-4.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import markovflow_amd as mfa
+from markovflow_amd import _lib
+from oracle import numpy_oracle as O
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def tt(x, dtype=torch.float64):
+    return None if x is None else torch.tensor(np.ascontiguousarray(x), dtype=dtype, device=DEV)
+
+
+def nn(x):
+    return x.detach().cpu().numpy().astype(np.float64)
+
+
+def random_ssm(rng, batch, t, d, m, stable=True):
+    scale = 0.5 / np.sqrt(d) if stable else 1.0
+    return dict(
+        mu0=rng.normal(size=batch + (d,)),
+        chol_p0=np.tril(0.3 * rng.normal(size=batch + (d, d))) + np.eye(d),
+        a_s=scale * rng.normal(size=batch + (t - 1, d, d)),
+        b_s=0.3 * rng.normal(size=batch + (t - 1, d)),
+        chol_q=np.tril(0.3 * rng.normal(size=batch + (t - 1, d, d))) + np.eye(d),
+        h=rng.normal(size=batch + (t, m, d)),
+        y=rng.normal(size=batch + (t, m)),
+    )
+
+
+def build_kf(kw, chol_r, dtype=torch.float64):
+    ssm = mfa.StateSpaceModel(tt(kw["mu0"], dtype), tt(kw["chol_p0"], dtype), tt(kw["a_s"], dtype),
+                              tt(kw["b_s"], dtype), tt(kw["chol_q"], dtype))
+    return mfa.KalmanFilter(ssm, mfa.EmissionModel(tt(kw["h"], dtype)), tt(kw["y"], dtype), tt(chol_r, dtype))
+
+
+def loglik_with_chunks(kw, r_inv, chunks, dtype=torch.float64, per_step=False):
+    """Call the C ABI directly with an explicit number of time partitions; returns per-series values."""
+    mu0, cp0, a, b, cq, h, y = (tt(kw[k], dtype) for k in ("mu0", "chol_p0", "a_s", "b_s", "chol_q", "h", "y"))
+    bsz, t, m, d = h.shape
+    lib = _lib.load()
+    esz = 8 if dtype == torch.float64 else 4
+    wsb = int(lib.mf_kf_loglik_workspace_bytes(bsz, t, d, esz, chunks))
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=DEV)
+    out = torch.empty(bsz, dtype=dtype, device=DEV)
+    info = _lib.new_info(torch.device(DEV))
+    ri = tt(r_inv, dtype)
+    _lib.call("mf_kf_loglik", dtype, bsz, t, d, m, _lib.ptr(mu0), _lib.ptr(cp0), _lib.ptr(a), _lib.ptr(b), _lib.ptr(cq),
+              _lib.ptr(h), _lib.ptr(y), _lib.ptr(ri), int(per_step), 0.0, _lib.ptr(out), _lib.ptr(ws), wsb,
+              _lib.ptr(info), chunks, None, None, _lib.stream_ptr(torch.device(DEV)))
+    assert int(info.item()) == 0
+    return nn(out)
+
+
+# ------------------------------------------------------------------------------------------------ golden vectors
+@pytest.mark.parametrize("tag", ["0", "3", "2x1"])
+def test_golden_log_likelihood_and_posterior(tag):
+    g = golden(f"kf_T8_d3_m2_b{tag}.npz")
+    y = g["y"]
+    batch, n = y.shape[:-2], y.shape[-2] - 1
+    bc = lambda x, extra: np.broadcast_to(x, batch + extra + x.shape).copy()  # noqa: E731
+    kw = dict(mu0=bc(g["mu0"], ()), chol_p0=bc(g["cholP0"], ()), a_s=bc(g["A"], (n,)), b_s=bc(g["b"], (n,)),
+              chol_q=bc(g["cholQ"], (n,)), h=bc(g["H"], (n + 1,)), y=y)
+    kf = build_kf(kw, g["cholR"])
+    # test_kalman_filter.py:131-139 (default rtol 1e-7 there)
+    np.testing.assert_allclose(float(kf.log_likelihood().cpu()), np.sum(g["log_liks"]), rtol=1e-8)
+    post = kf.posterior_state_space_model()
+    # test_kalman_filter.py:105-128
+    np.testing.assert_allclose(nn(post.marginal_means), g["smooth_means"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(*np.broadcast_arrays(nn(post.marginal_covariances), g["smooth_covs"]), rtol=1e-7, atol=1e-10)
+
+
+def test_golden_sites():
+    g = golden("kf_sites_T7_d2_m1.npz")
+    n = g["site_means"].shape[0] - 1
+    ssm = mfa.StateSpaceModel(tt(g["mu0"]), tt(g["cholP0"]), tt(np.tile(g["A"], (n, 1, 1))),
+                              tt(np.tile(g["b"], (n, 1))), tt(np.tile(g["cholQ"], (n, 1, 1))))
+    sites = mfa.UnivariateGaussianSitesNat(nat1=tt(g["nat1"]), nat2=tt(g["nat2"]))
+    kf = mfa.KalmanFilterWithSites(ssm, mfa.EmissionModel(tt(np.tile(g["H"], (n + 1, 1, 1)))), sites)
+    np.testing.assert_allclose(float(kf.log_likelihood().cpu()), np.sum(g["log_liks"]), rtol=1e-9)
+    post = kf.posterior_state_space_model()
+    np.testing.assert_allclose(nn(post.marginal_means), g["smooth_means"], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(nn(post.marginal_covariances), g["smooth_covs"], rtol=1e-7, atol=1e-12)
+
+
+@pytest.mark.parametrize("n", [15, 500])
+def test_golden_gpr_matern32(n):
+    # BASELINE config 1: GPR Matern-3/2 log marginal likelihood vs the dense GP
+    g = golden(f"gpr_matern32_N{n}.npz")
+    ssm = mfa.state_space_model_from_covariances(tt(np.zeros(2)), tt(g["P0"]), tt(g["A"]), tt(np.zeros((n - 1, 2))),
+                                                 tt(g["Q"]))
+    kf = mfa.KalmanFilter(ssm, mfa.EmissionModel(tt(np.tile(g["H"], (n, 1, 1)))), tt(g["y"]),
+                          tt(np.sqrt(g["noise"]) * np.eye(1)))
+    np.testing.assert_allclose(float(kf.log_likelihood().cpu()), g["log_marginal_likelihood"], rtol=1e-6)
+    post = kf.posterior_state_space_model()
+    f_mean = nn(kf.emission.project_state_to_f(post.marginal_means))[:, 0]
+    f_var = nn(kf.emission.project_state_covariance_to_f(post.marginal_covariances))[:, 0]
+    np.testing.assert_allclose(f_mean, g["post_mean"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(f_var, g["post_var"], rtol=1e-4, atol=1e-7)
+
+
+def test_golden_matern52_sum_d6():
+    g = golden("matern52_sum_d6_T64.npz")
+    y = g["y"]; bsz, n = y.shape[0], y.shape[1] - 1
+    kw = dict(mu0=np.zeros((bsz, 6)), chol_p0=np.tile(np.linalg.cholesky(g["P0"]), (bsz, 1, 1)),
+              a_s=np.tile(g["A"], (bsz, n, 1, 1)), b_s=np.zeros((bsz, n, 6)),
+              chol_q=np.tile(np.linalg.cholesky(g["Q"]), (bsz, n, 1, 1)), h=np.tile(g["H"], (bsz, n + 1, 1, 1)), y=y)
+    kf = build_kf(kw, np.sqrt(g["R"]))
+    np.testing.assert_allclose(float(kf.log_likelihood().cpu()), np.sum(g["log_liks"]), rtol=1e-8)
+    for chunks in (1, 2, 5, 16):
+        per = loglik_with_chunks(kw, np.linalg.inv(g["R"]), chunks)
+        cst = -0.5 * np.log(2 * np.pi) * (n + 1) + 0.5 * (n + 1) * np.log(1.0 / g["R"][0, 0])
+        np.testing.assert_allclose(per + cst, np.sum(g["log_liks"], axis=-1), rtol=1e-8)
+
+
+# ------------------------------------------------------------------------------------------------ oracle parity
+@pytest.mark.parametrize("d,m,t", [(1, 1, 1), (1, 1, 2), (2, 1, 5), (3, 2, 8), (4, 1, 37), (5, 3, 12), (6, 1, 130),
+                                   (7, 2, 9), (8, 4, 20), (9, 3, 33)])
+@pytest.mark.parametrize("batch", [(3,), (), (2, 1)])
+def test_log_likelihood_matches_oracle_fp64(rng, d, m, t, batch):
+    if t == 1:
+        pytest.skip("StateSpaceModel needs at least one transition (test_state_space_model.py:58-60)")
+    kw = random_ssm(rng, batch, t, d, m)
+    r = rng.normal(size=(m, m)); cov = r @ r.T + np.eye(m)
+    kf = build_kf(kw, np.linalg.cholesky(cov))
+    ref = O.kf_log_likelihood(**kw, r_inv=np.linalg.inv(cov))
+    np.testing.assert_allclose(float(kf.log_likelihood().cpu()), ref, rtol=1e-9)
+
+
+@pytest.mark.parametrize("chunks", [1, 2, 3, 7, 16, 61, 130])
+def test_time_partition_invariance_fp64(rng, chunks):
+    """The result must not depend on how the chain is partitioned (ragged chunks included)."""
+    kw = random_ssm(rng, (6,), 130, 6, 1)
+    r_inv = np.array([[2.5]])
+    ref = O.kf_log_likelihood(**kw, r_inv=r_inv, per_series=True)
+    cst = -0.5 * np.log(2 * np.pi) * 130 + 0.5 * 130 * np.log(2.5)
+    np.testing.assert_allclose(loglik_with_chunks(kw, r_inv, chunks) + cst, ref, rtol=1e-10)
+
+
+def test_unstable_transitions_like_reference_fixture(rng):
+    """Random non-stable A (the reference fixture draws A ~ N(0,1)); means grow, conditioning is poor."""
+    kw = random_ssm(rng, (4,), 8, 3, 2, stable=False)
+    cov = np.array([[1.3, 0.2], [0.2, 0.7]])
+    kf = build_kf(kw, np.linalg.cholesky(cov))
+    ref = O.kf_log_likelihood(**kw, r_inv=np.linalg.inv(cov))
+    np.testing.assert_allclose(float(kf.log_likelihood().cpu()), ref, rtol=1e-8)
+
+
+@pytest.mark.parametrize("d,m,t", [(2, 1, 50), (6, 1, 200), (9, 3, 40)])
+def test_log_likelihood_fp32(rng, d, m, t):
+    kw = random_ssm(rng, (8,), t, d, m)
+    cov = 0.5 * np.eye(m)
+    kf = build_kf(kw, np.linalg.cholesky(cov), dtype=torch.float32)
+    ref = O.kf_log_likelihood(**kw, r_inv=np.linalg.inv(cov))
+    np.testing.assert_allclose(float(kf.log_likelihood().cpu()), ref, rtol=5e-4)
+
+
+def test_per_step_precisions_and_sparse_sites(rng):
+    # KalmanFilterWithSparseSites on a grid with 1-in-3 observed (test_kalman_filter_with_sparse_sites.py:69-104)
+    n, d = 31, 2
+    kw = random_ssm(rng, (), n, d, 1)
+    kw["h"] = np.tile(rng.normal(size=(1, d)), (n, 1, 1))
+    idx = np.arange(0, n, 3)
+    prec = rng.uniform(0.5, 2.0, size=(idx.size, 1, 1)); yobs = rng.normal(size=(idx.size, 1))
+    ssm = mfa.StateSpaceModel(tt(kw["mu0"]), tt(kw["chol_p0"]), tt(kw["a_s"]), tt(kw["b_s"]), tt(kw["chol_q"]))
+    sites = mfa.UnivariateGaussianSitesNat(nat1=tt(yobs * prec[..., 0]), nat2=tt(-0.5 * prec))
+    kf = mfa.KalmanFilterWithSparseSites(ssm, mfa.EmissionModel(tt(kw["h"])), sites, n,
+                                         torch.tensor(idx[:, None], device=DEV), tt(yobs))
+    ref = O.kf_sparse_sites_log_likelihood(kw["mu0"], kw["chol_p0"], kw["a_s"], kw["b_s"], kw["chol_q"], kw["h"],
+                                           idx, yobs, prec)
+    np.testing.assert_allclose(float(kf.log_likelihood().cpu()), ref, rtol=1e-9)
+    # sparse <-> dense bookkeeping (kalman_filter.py:561-577)
+    dense = kf.sparse_to_dense(tt(yobs), kf.grid_shape)
+    np.testing.assert_allclose(nn(kf.dense_to_sparse(dense)), yobs)
+    # the dense-sites filter on the same grid gives the same posterior marginals
+    post = kf.posterior_state_space_model()
+    r_inv = np.zeros((n, 1, 1)); r_inv[idx] = prec
+    obs = np.zeros((n, 1)); obs[idx] = yobs
+    pm = O.kf_posterior_ssm(kw["mu0"], kw["chol_p0"], kw["a_s"], kw["b_s"], kw["chol_q"], kw["h"], obs, r_inv)
+    np.testing.assert_allclose(nn(post.marginal_means), O.ssm_marginal_means(pm[0], pm[2], pm[3]), rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize("d,m,t", [(3, 2, 8), (6, 1, 60), (9, 3, 21)])
+def test_posterior_ssm_matches_oracle(rng, d, m, t):
+    kw = random_ssm(rng, (3,), t, d, m)
+    cov = 0.3 * np.eye(m)
+    post = build_kf(kw, np.linalg.cholesky(cov)).posterior_state_space_model()
+    mu0, cp0, a, b, cq = O.kf_posterior_ssm(**kw, r_inv=np.linalg.inv(cov))
+    tol = dict(rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(nn(post.initial_mean), mu0, **tol)
+    np.testing.assert_allclose(nn(post.cholesky_initial_covariance), cp0, **tol)
+    np.testing.assert_allclose(nn(post.state_transitions), a, **tol)
+    np.testing.assert_allclose(nn(post.state_offsets), b, **tol)
+    np.testing.assert_allclose(nn(post.cholesky_process_covariances), cq, **tol)
+
+
+# ------------------------------------------------------------------------------------------------ StateSpaceModel
+def test_state_space_model_vs_dense_joint():
+    # tests/unit/test_state_space_model.py:40-235 on the committed fixture
+    g = golden("ssm_T5_d3.npz")
+    mk = lambda p: mfa.StateSpaceModel(*(tt(g[f"{p}_{k}"]) for k in ("mu0", "cholP0", "A", "b", "cholQ")))  # noqa: E731
+    s1, s2 = mk("s1"), mk("s2")
+    d = 3
+    np.testing.assert_allclose(nn(s1.marginal_means), g["means1"], rtol=1e-10)
+    covs = nn(s1.marginal_covariances)
+    n = covs.shape[-3]
+    np.testing.assert_allclose(covs, np.stack([g["cov1"][..., i * d:(i + 1) * d, i * d:(i + 1) * d] for i in range(n)], -3),
+                               rtol=1e-8, atol=1e-10)
+    diag_c, sub_c = s1.covariance_blocks()
+    np.testing.assert_allclose(nn(sub_c), np.stack([g["cov1"][..., (i + 1) * d:(i + 2) * d, i * d:(i + 1) * d]
+                                                    for i in range(n - 1)], -3), rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(nn(s1.precision.to_dense()), g["precision1"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(nn(s1.log_det_precision()), g["logdet_precision1"], rtol=1e-10)
+    np.testing.assert_allclose(nn(s1.kl_divergence(s2)), g["kl_12"], rtol=1e-8)
+    np.testing.assert_allclose(nn(s1.kl_divergence(s1)), 0.0, atol=1e-8)          # test_state_space_model.py:179-184
+    np.testing.assert_allclose(nn(s1.log_pdf(tt(g["states"]))), g["log_pdf1"], rtol=1e-9)
+    assert s1.event_shape == (6, 3) and tuple(s1.batch_shape) == (3,)
+    # sampling: sample mean / covariance of many trajectories (tests/tools/check_distributions.py style)
+    torch.manual_seed(0)
+    samples = nn(s1.sample((4000,)))
+    assert samples.shape == (4000, 3, 6, 3)
+    np.testing.assert_allclose(samples.mean(0), g["means1"], atol=0.25)
+    tr = s1.create_trainable_copy()
+    assert tr.state_transitions.requires_grad and not s1.create_non_trainable_copy().state_transitions.requires_grad
+
+
+# ------------------------------------------------------------------------------------------------ full-size properties
+def test_full_size_partition_invariance_and_linearity():
+    """
+    BASELINE-size check (B=1024, T=10000, d=6, fp64) through properties that need no CPU oracle:
+    (1) the log-likelihood does not depend on the time partition (1 chunk/series vs the automatic choice),
+    (2) a subset of the series evaluated alone gives the same per-series numbers,
+    (3) the subset agrees with the numpy oracle on 2 full-length series.
+    """
+    from markovflow_amd import synthetic
+    inp = synthetic.make_ssm(1024, 10000, (5, 5), dtype=torch.float64, device=DEV)
+    kf = synthetic.kalman_filter_from(inp)
+    per_auto = nn(kf._log_likelihood_per_series())
+    assert np.all(np.isfinite(per_auto))
+    kw = {k2: nn(inp[k1][:64]) for k1, k2 in (("mu0", "mu0"), ("cholP0", "chol_p0"), ("A", "a_s"), ("b", "b_s"),
+                                               ("cholQ", "chol_q"), ("H", "h"), ("y", "y"))}
+    r_inv = np.array([[1.0 / 0.1]])
+    per_serial = loglik_with_chunks(kw, r_inv, 1)
+    np.testing.assert_allclose(per_auto[:64], per_serial, rtol=1e-9)
+    kw2 = {k: v[:2] for k, v in kw.items()}
+    ref = O.kf_log_likelihood(**kw2, r_inv=r_inv, per_series=True)
+    cst = -0.5 * np.log(2 * np.pi) * 10000 + 0.5 * 10000 * np.log(10.0)
+    np.testing.assert_allclose(per_auto[:2] + cst, ref, rtol=1e-9)
+    total = float(kf.log_likelihood().cpu())
+    np.testing.assert_allclose(total, np.sum(per_auto + cst), rtol=1e-12)

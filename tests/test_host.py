@@ -1,0 +1,104 @@
+"""CPU-only tests: the C ABI library loads and exports every declared symbol; host-side logic and error behaviour."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import markovflow_amd as mfa
+from markovflow_amd import _lib
+from conftest import ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "markovflow_amd.h")).read()
+    declared = set(re.findall(r"\b(mf_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.exported_symbols())
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.mf_version() >= 1 and lib.mf_max_state_dim() == 9
+
+
+def test_argument_errors_without_touching_the_gpu():
+    lib = _lib.load()
+    # invalid sizes / NULL pointers are rejected before any launch
+    assert lib.mf_btd_cholesky_f64(1, 0, 3, None, None, None, None, None, None) == -2
+    assert lib.mf_btd_cholesky_f64(1, 4, 0, None, None, None, None, None, None) == -3
+    assert lib.mf_btd_cholesky_f64(1, 4, 12, None, None, None, None, None, None) == -100
+    assert lib.mf_btd_cholesky_f64(1, 4, 3, None, None, None, None, None, None) == -4
+    assert lib.mf_btd_solve_f32(2, 3, 4, 3, None, None, None, None, 0, None) == -1
+    assert lib.mf_kf_loglik_workspace_bytes(1024, 10000, 6, 8, 0) > 0
+    assert lib.mf_kf_loglik_workspace_bytes(1024, 10000, 12, 8, 0) == 0
+    assert lib.mf_btd_cholesky_f64(0, 4, 3, None, None, None, None, None, None) == 0   # empty batch is a no-op
+
+
+def test_cpu_tensors_fail_loudly():
+    d = torch.eye(3, dtype=torch.float64).expand(2, 4, 3, 3).contiguous()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mfa.SymmetricBlockTriDiagonal(d).cholesky
+
+
+def test_constructor_shape_checks():
+    z = torch.zeros
+    with pytest.raises(ValueError):
+        mfa.EmissionModel(z(3, 2))                                         # emission_model.py:46-49
+    with pytest.raises(ValueError):
+        mfa.SymmetricBlockTriDiagonal(z(4, 3, 2))
+    with pytest.raises(ValueError):
+        mfa.SymmetricBlockTriDiagonal(z(1, 3, 3), z(0, 3, 3))              # no sub-diagonal with outer dim 1
+    with pytest.raises(ValueError):
+        mfa.SymmetricBlockTriDiagonal(z(4, 3, 3), z(4, 3, 3))
+    with pytest.raises(ValueError):                                        # zero transitions, test_state_space_model.py:58-60
+        mfa.StateSpaceModel(z(3), z(3, 3), z(0, 3, 3), z(0, 3), z(0, 3, 3))
+    with pytest.raises(ValueError):                                        # batch shapes must match exactly (:111-116)
+        mfa.StateSpaceModel(z(2, 3), z(2, 3, 3), z(1, 5, 3, 3), z(2, 5, 3), z(2, 5, 3, 3))
+    ssm = mfa.StateSpaceModel(z(2, 3), z(2, 3, 3), z(2, 5, 3, 3), z(2, 5, 3), z(2, 5, 3, 3))
+    assert ssm.event_shape == (6, 3) and ssm.num_transitions == 5 and ssm.state_dim == 3
+    assert tuple(ssm.concatenated_state_offsets.shape) == (2, 6, 3)
+    em = mfa.EmissionModel(z(2, 6, 1, 3))
+    with pytest.raises(ValueError):
+        mfa.KalmanFilter(ssm, em, z(2, 5, 1), torch.eye(1))               # kalman_filter.py:326-336
+    with pytest.raises(ValueError):
+        mfa.KalmanFilter(ssm, em, z(2, 6, 1), torch.eye(2))               # kalman_filter.py:320-324
+    with pytest.raises(ValueError):
+        mfa.UnivariateGaussianSitesNat(z(6, 2), z(6, 1, 1))               # kalman_filter.py:403-409
+    kf = mfa.KalmanFilter(ssm, em, z(2, 6, 1), torch.eye(1))
+    assert kf.prior_ssm is ssm and kf.emission is em
+
+
+def test_sparse_sites_bookkeeping_on_cpu():
+    ssm = mfa.StateSpaceModel(torch.zeros(2), torch.eye(2), torch.zeros(9, 2, 2), torch.zeros(9, 2), torch.eye(2).expand(9, 2, 2))
+    em = mfa.EmissionModel(torch.ones(10, 1, 2))
+    idx = torch.tensor([[1], [4], [7]])
+    sites = mfa.UnivariateGaussianSitesNat(nat1=torch.tensor([[1.0], [2.0], [3.0]]), nat2=-0.5 * torch.ones(3, 1, 1))
+    kf = mfa.KalmanFilterWithSparseSites(ssm, em, sites, 10, idx, torch.tensor([[[1.0], [2.0], [3.0]]]))
+    assert tuple(kf.observations.shape) == (10, 1) and float(kf.observations[4, 0]) == 2.0
+    assert tuple(kf._r_inv.shape) == (10, 1, 1) and float(kf._r_inv[7, 0, 0]) == 1.0 and float(kf._r_inv[0, 0, 0]) == 0.0
+    np.testing.assert_allclose(kf.dense_to_sparse(kf.observations).numpy(), [[1.0], [2.0], [3.0]])
+    np.testing.assert_allclose(sites.means.numpy(), [[1.0], [2.0], [3.0]])
+    with pytest.raises(Exception):
+        mfa.KalmanFilterWithSparseSites(ssm, em, sites, 10, idx, torch.zeros(2, 3, 1))   # batches unsupported (:531-539)
+
+
+def test_synthetic_closed_forms_match_reference_expm_kernels():
+    """Closed-form Matérn transitions == the reference's scipy-expm test kernels (fixtures hold their output)."""
+    from conftest import golden
+    from markovflow_amd import synthetic
+    g = golden("gpr_matern32_N15.npz")
+    dt = torch.tensor(np.diff(g["t"]))[None]
+    f64 = torch.float64
+    lam = torch.tensor([np.sqrt(3.0) / float(g["length_scale"])], dtype=f64)
+    a, pinf = synthetic._matern_block(3, lam, torch.tensor([float(g["variance"])], dtype=f64), dt)
+    np.testing.assert_allclose(a[0].numpy(), g["A"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(pinf[0].numpy(), g["P0"], rtol=1e-12)
+    g5 = golden("matern52_sum_d6_T64.npz")
+    a5, p5 = synthetic._matern_block(5, torch.tensor([np.sqrt(5.0) / 0.7], dtype=f64), torch.tensor([1.3], dtype=f64),
+                                       torch.tensor([[0.13]], dtype=f64))
+    np.testing.assert_allclose(a5[0, 0].numpy(), g5["A"][:3, :3], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(p5[0].numpy(), g5["P0"][:3, :3], rtol=1e-12)
+    inp = synthetic.make_ssm(3, 12, (5, 5), device="cpu")
+    assert tuple(inp["A"].shape) == (3, 11, 6, 6) and tuple(inp["H"].shape) == (3, 12, 1, 6)
+    inp9 = synthetic.make_ssm(2, 5, (5, 5, 5), output_dim=3, device="cpu")
+    assert tuple(inp9["H"].shape) == (2, 5, 3, 9) and tuple(inp9["cholR"].shape) == (3, 3)
