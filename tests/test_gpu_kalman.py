@@ -29,8 +29,19 @@ def nn(x):
     return x.detach().cpu().numpy().astype(np.float64)
 
 
-def random_ssm(rng, batch, t, d, m, stable=True):
+def random_ssm(rng, batch, t, d, m, stable=True, well=False):
+    """Random chain.  ``well`` keeps |diag(chol)| >= 1 (fp32 runs: a draw of tril(0.3 N) + I can put a
+    diagonal entry near zero, i.e. a process precision ~1e8, which no fp32 implementation survives)."""
     scale = 0.5 / np.sqrt(d) if stable else 1.0
+    out = _random_ssm(rng, batch, t, d, m, scale)
+    if well:
+        idx = np.arange(d)
+        for key in ("chol_p0", "chol_q"):
+            out[key][..., idx, idx] = 1.0 + np.abs(out[key][..., idx, idx] - 1.0)
+    return out
+
+
+def _random_ssm(rng, batch, t, d, m, scale):
     return dict(
         mu0=rng.normal(size=batch + (d,)),
         chol_p0=np.tril(0.3 * rng.normal(size=batch + (d, d))) + np.eye(d),
@@ -162,7 +173,7 @@ def test_unstable_transitions_like_reference_fixture(rng):
 
 @pytest.mark.parametrize("d,m,t", [(2, 1, 50), (6, 1, 200), (9, 3, 40)])
 def test_log_likelihood_fp32(rng, d, m, t):
-    kw = random_ssm(rng, (8,), t, d, m)
+    kw = random_ssm(rng, (8,), t, d, m, well=True)
     cov = 0.5 * np.eye(m)
     kf = build_kf(kw, np.linalg.cholesky(cov), dtype=torch.float32)
     ref = O.kf_log_likelihood(**kw, r_inv=np.linalg.inv(cov))
