@@ -4,9 +4,11 @@
 #error "compile with -DMF_D=<state dimension>"
 #endif
 #include "mf_kernels.hpp"
+#include "mf_kf_lds.hpp"
 #include "mf_launch.hpp"
 
 #include <cstdlib>
+#include <string>
 
 namespace mf {
 namespace {
@@ -80,9 +82,35 @@ int reduce_levels(RedSys<T> cur, long B, char* p, T add_const, T* out, int* info
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
+// The LDS-DMA streaming kernel covers the common case: one output, a shared observation precision,
+// matrix rows that are a whole number of 16-B units, 16-B aligned tensors, at least one transition.
+template <typename T> bool use_lds_kernel(long Tn, int m, const void* A, const void* cholQ, int rinv_per_step) {
+    static const bool force_direct = [] {
+        const char* e = std::getenv("MF_KF_IMPL");
+        return e && std::string(e) == "direct";
+    }();
+    if (force_direct) return false;
+    if (m != 1 || rinv_per_step || Tn < 2) return false;
+    if ((D * D * sizeof(T)) % 16 != 0) return false;
+    if ((reinterpret_cast<size_t>(A) | reinterpret_cast<size_t>(cholQ)) & 15) return false;
+    return KfLdsCfg<T, D, 1>::LDS_TOTAL <= 64 * 1024;
+}
+
+// chunks per series and transitions per chunk of the LDS kernel
+inline void lds_partition(long B, long Tn, long chunks, long& P, long& L) {
+    const long nt = Tn - 1;
+    long want = chunks > 0 ? chunks : auto_chunks(B, nt);
+    if (want > nt) want = nt;
+    if (want < 1) want = 1;
+    L = cdiv(nt, want);
+    P = cdiv(nt, L);
+}
+
 template <typename T> size_t kf_loglik_ws(long B, long Tn, long chunks) {
     const long P = chunks > 0 ? (chunks > Tn ? Tn : chunks) : auto_chunks(B, Tn);
-    return levels_ws<T>(B, P);
+    long P2 = 1, L2 = 1;
+    if (Tn >= 2) lds_partition(B, Tn, chunks, P2, L2);
+    return levels_ws<T>(B, P > P2 ? P : P2);
 }
 
 template <typename T>
@@ -90,8 +118,22 @@ int kf_loglik(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A,
               const T* H, const T* y, const T* Rinv, int rinv_per_step, T add_const, T* out, void* ws,
               size_t ws_bytes, int* info, long chunks, hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
     if (m < 1 || m > MF_MAXM) return -4;
+    if (ws_bytes < kf_loglik_ws<T>(B, Tn, chunks) || ws == nullptr) return -15;
+    if (use_lds_kernel<T>(Tn, m, A, cholQ, rinv_per_step)) {
+        long P, L;
+        lds_partition(B, Tn, chunks, P, L);
+        KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, info};
+        char* p = static_cast<char*>(ws);
+        RedSys<T> lvl0 = carve<T>(p, B, P);
+        const dim3 grid((unsigned)cdiv(B * P, 64)), block(64);
+        constexpr int lds = KfLdsCfg<T, D, 1>::LDS_TOTAL;
+        if (ev0) (void)hipEventRecord(ev0, st);
+        if (P > 1) hipLaunchKernelGGL((kf_chunk_lds_kernel<T, D, 1, true>), grid, block, lds, st, a, L, lvl0);
+        else hipLaunchKernelGGL((kf_chunk_lds_kernel<T, D, 1, false>), grid, block, lds, st, a, L, lvl0);
+        if (ev1) (void)hipEventRecord(ev1, st);
+        return reduce_levels<T>(lvl0, B, p, add_const, out, info, st);
+    }
     const long P = chunks > 0 ? (chunks > Tn ? Tn : chunks) : auto_chunks(B, Tn);
-    if (ws_bytes < levels_ws<T>(B, P) || ws == nullptr) return -15;
     KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, info};
     char* p = static_cast<char*>(ws);
     RedSys<T> lvl0 = carve<T>(p, B, P);

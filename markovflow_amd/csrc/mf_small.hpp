@@ -16,6 +16,33 @@ template <typename T> MF_DEV T t_sqrt(T x);
 template <> MF_DEV float t_sqrt<float>(float x) { return __builtin_sqrtf(x); }
 template <> MF_DEV double t_sqrt<double>(double x) { return __builtin_sqrt(x); }
 
+// 1/x and 1/sqrt(x) from the hardware seed (v_rcp / v_rsq) plus one Newton step: ~1 ulp, a handful of
+// dependent instructions.  The IEEE-exact expansions of `1/x` and `sqrt` are ~3x longer and sit on the
+// critical path of every Cholesky pivot.
+template <typename T> MF_DEV T t_rcp(T x);
+template <> MF_DEV float t_rcp<float>(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(r, __builtin_fmaf(-x, r, 1.0f), r);
+}
+template <> MF_DEV double t_rcp<double>(double x) {
+    const double r = __builtin_amdgcn_rcp(x);
+    const double r1 = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+    return __builtin_fma(r1, __builtin_fma(-x, r1, 1.0), r1);
+}
+template <typename T> MF_DEV T t_rsqrt(T x);
+template <> MF_DEV float t_rsqrt<float>(float x) {
+    const float r = __builtin_amdgcn_rsqf(x);
+    const float h = 0.5f * r;
+    return __builtin_fmaf(h, __builtin_fmaf(-x * r, r, 1.0f), r);
+}
+template <> MF_DEV double t_rsqrt<double>(double x) {
+    const double r = __builtin_amdgcn_rsq(x);
+    const double e = __builtin_fma(-x * r, r, 1.0);
+    const double r1 = __builtin_fma(0.5 * r, e, r);
+    const double e1 = __builtin_fma(-x * r1, r1, 1.0);
+    return __builtin_fma(0.5 * r1, e1, r1);
+}
+
 // Running log-determinant accumulator (sum of log|x_i|).
 // double: kept as (mantissa product, exponent sum) so the per-step cost is a few multiplies and one
 //         frexp instead of 2*D software log evaluations; one log at the very end.
@@ -80,7 +107,7 @@ MF_DEV void tri_inv_lower(const T (&C)[D][D], T (&Ci)[D][D], LogAcc<T>& la, bool
         const T c = C[i][i];
         bad |= !(c != T(0));
         la.mul(c);
-        Ci[i][i] = T(1) / c;
+        Ci[i][i] = t_rcp<T>(c);
     }
     MF_UNROLL for (int j = 0; j < D; ++j)
         MF_UNROLL for (int i = j + 1; i < D; ++i) {
@@ -125,6 +152,16 @@ MF_DEV void trimulT_lower_vec(const T (&Lo)[D][D], const T (&a)[D], T (&out)[D])
         MF_UNROLL for (int k = i; k < D; ++k) s += Lo[k][i] * a[k];
         out[i] = s;
     }
+}
+// Y <- -(Lo^T Y), in place (row i of the result only needs rows k >= i of Y)
+template <typename T, int D, int N>
+MF_DEV void neg_trimulT_lower_inplace(const T (&Lo)[D][D], T (&Y)[D][N]) {
+    MF_UNROLL for (int i = 0; i < D; ++i)
+        MF_UNROLL for (int j = 0; j < N; ++j) {
+            T s = T(0);
+            MF_UNROLL for (int k = i; k < D; ++k) s += Lo[k][i] * Y[k][j];
+            Y[i][j] = -s;
+        }
 }
 // S(lower) = Lo^T Lo
 template <typename T, int D> MF_DEV void trimulT_self_lower(const T (&Lo)[D][D], T (&S)[D][D]) {
@@ -183,8 +220,8 @@ MF_DEV void chol_lower(T (&S)[D][D], T (&Li)[D], LogAcc<T>& la, bool& bad) {
         T s = S[j][j];
         MF_UNROLL for (int k = 0; k < j; ++k) s -= S[j][k] * S[j][k];
         bad |= !(s > T(0));
-        const T l = t_sqrt<T>(s);
-        const T inv = T(1) / l;
+        const T inv = t_rsqrt<T>(s);
+        const T l = s * inv;
         S[j][j] = l;
         Li[j] = inv;
         la.mul(l);
