@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmarkovflow_amd.so")
+LIB_PATH = os.environ.get("MF_LIB_PATH", os.path.join(_HERE, "libmarkovflow_amd.so"))   # override: A/B builds
 
 _i64, _int, _vp, _sz = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
 

@@ -91,9 +91,8 @@ template <typename T> bool use_lds_kernel(long Tn, int m, const void* A, const v
     }();
     if (force_direct) return false;
     if (m != 1 || rinv_per_step || Tn < 2) return false;
-    if ((D * D * sizeof(T)) % 16 != 0) return false;
     if ((reinterpret_cast<size_t>(A) | reinterpret_cast<size_t>(cholQ)) & 15) return false;
-    return KfLdsCfg<T, D, 1>::LDS_TOTAL <= 64 * 1024;
+    return KfLdsCfg<T, D, 1>::SUPPORTED;
 }
 
 // chunks per series and transitions per chunk of the LDS kernel
@@ -119,10 +118,11 @@ int kf_loglik(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A,
               size_t ws_bytes, int* info, long chunks, hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
     if (m < 1 || m > MF_MAXM) return -4;
     if (ws_bytes < kf_loglik_ws<T>(B, Tn, chunks) || ws == nullptr) return -15;
-    if (use_lds_kernel<T>(Tn, m, A, cholQ, rinv_per_step)) {
+    if constexpr (KfLdsCfg<T, D, 1>::SUPPORTED) if (use_lds_kernel<T>(Tn, m, A, cholQ, rinv_per_step)) {
         long P, L;
         lds_partition(B, Tn, chunks, P, L);
-        KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, info};
+        static const int dbg = [] { const char* e = std::getenv("MF_KF_DEBUG"); return e ? std::atoi(e) : 0; }();
+        KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, info, dbg};
         char* p = static_cast<char*>(ws);
         RedSys<T> lvl0 = carve<T>(p, B, P);
         const dim3 grid((unsigned)cdiv(B * P, 64)), block(64);
@@ -134,7 +134,7 @@ int kf_loglik(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A,
         return reduce_levels<T>(lvl0, B, p, add_const, out, info, st);
     }
     const long P = chunks > 0 ? (chunks > Tn ? Tn : chunks) : auto_chunks(B, Tn);
-    KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, info};
+    KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, info, 0};
     char* p = static_cast<char*>(ws);
     RedSys<T> lvl0 = carve<T>(p, B, P);
     const long lanes = B * P;
@@ -227,7 +227,7 @@ template <typename T>
 int ssm_precision(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ,
                   const T* H, const T* y, const T* Rinv, int rinv_per_step, T* diag, T* sub, T* eta, hipStream_t st) {
     if (H && (m < 1 || m > MF_MAXM)) return -3;
-    KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, 1, nullptr};
+    KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, 1, nullptr, 0};
     const dim3 grid((unsigned)cdiv(B * Tn, 256)), block(256);
     if (m == 1) hipLaunchKernelGGL((ssm_precision_kernel<T, D, 1>), grid, block, 0, st, a, diag, sub, eta);
     else hipLaunchKernelGGL((ssm_precision_kernel<T, D, 0>), grid, block, 0, st, a, diag, sub, eta);

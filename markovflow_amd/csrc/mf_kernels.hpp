@@ -49,10 +49,16 @@ template <typename T, int D, bool SPIKE> struct Elim {
     }
     // Factor the (complete) pivot in Phi, solve for z and the spike V, fold V into the separator.
     MF_DEV void eliminate() {
+        eliminate_main();
+        eliminate_spike();
+    }
+    MF_DEV void eliminate_main() {
         chol_lower<T, D>(Phi, Li, laL, bad);
         laL.renorm();
         trsv_lower<T, D>(Phi, Li, t);
         quad += dot_self<T, D>(t);
+    }
+    MF_DEV void eliminate_spike() {
         if (SPIKE) {
             trsm_left_lower<T, D, D>(Phi, Li, X);
             syrk_tn_lower<T, D, D>(X, GU, T(-1));
@@ -102,6 +108,7 @@ template <typename T> struct KfArgs {
     const T* Rinv; int rinv_per_step;                                       // [m,m] or [B,T,m,m]
     long P;              // chunks per series
     int* info;
+    int debug;           // timing experiments only: bit 0 = DMA descriptors with zero records (no memory traffic)
 };
 
 constexpr int MF_MAXM = 4;

@@ -22,19 +22,26 @@
 // chunk leaves behind is the block its last transition leads to.
 #pragma once
 #include "mf_kernels.hpp"
+#ifndef MF_PUMPMASK
+#define MF_PUMPMASK 63   // bit k: DMA batch k of the next step is issued between arithmetic phases (else up front)
+#endif
 
 namespace mf {
 
 typedef int mf_v4i __attribute__((ext_vector_type(4)));
 
+// NOTE the leading `s_nop 4`: hipcc pads no hazards inside an asm string.  When the descriptor (or the LDS
+// address) has just been produced by a VALU instruction - v_readfirstlane, or a v_readlane restoring a spilled
+// SGPR - a VMEM instruction reading it needs 5 wait states; without them the DMA ran with a stale descriptor
+// and silently fetched another stream's rows.
 MF_DEV void dma_b128(mf_v4i srd, unsigned lds_addr, unsigned voff) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(srd), "s"(lds_addr) : "memory");
 }
 MF_DEV void dma_b32(mf_v4i srd, unsigned lds_addr, unsigned voff) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(srd), "s"(lds_addr) : "memory");
 }
 
@@ -89,14 +96,12 @@ constexpr unsigned long long MF_DMA_MAXREC = 0xE0000000ull;
 // registers (a register table per instruction was spilled to scratch, and every scratch reload waits
 // `vmcnt(0)`, i.e. for every DMA in flight).
 template <typename St> struct DmaStream {
-    int q0, c0;                    // lane / U, lane % U
-    MF_DEV void init(int lane) { q0 = lane / St::U; c0 = lane - q0 * St::U; }
+    unsigned vo[St::NI];           // this lane's source byte offset for DMA instruction i (registers / AGPRs)
     // rel_tab: LDS byte address of this stream's row-offset table; gtab: LDS byte address of the
     // compact-unit -> global byte offset table (only read when the stream drops units)
-    MF_DEV void issue(const char* smem, mf_v4i srd, unsigned lds_base, int rel_tab, int gtab) const {
-        unsigned vo[St::NI];
+    MF_DEV void init(const char* smem, int lane, int rel_tab, int gtab) {
+        const int q0 = lane / St::U, c0 = lane - q0 * St::U;
         MF_UNROLL for (int i = 0; i < St::NI; ++i) {
-            constexpr int dummy = 0; (void)dummy;
             const int a = (64 * i) / St::U, b = (64 * i) % St::U;
             int cu = c0 + b;
             const int carry = cu >= St::U ? 1 : 0;
@@ -108,9 +113,14 @@ template <typename St> struct DmaStream {
             else off = *reinterpret_cast<const unsigned*>(smem + gtab + cu * 4);
             vo[i] = rel + off;
         }
-        MF_UNROLL for (int i = 0; i < St::NI; ++i) {
-            if (St::UNIT == 16) dma_b128(srd, lds_base + i * 1024, vo[i]);
-            else dma_b32(srd, lds_base + i * 256, vo[i]);
+    }
+    // issue DMA instructions [i0, i1) of this stream
+    template <int I0, int I1> MF_DEV void issue(mf_v4i srd, unsigned lds_base) const {
+        MF_UNROLL for (int i = I0; i < I1; ++i) {
+            if (i < St::NI) {
+                if (St::UNIT == 16) dma_b128(srd, lds_base + i * 1024, vo[i]);
+                else dma_b32(srd, lds_base + i * 256, vo[i]);
+            }
         }
     }
 };
@@ -123,8 +133,9 @@ MF_DEV unsigned long long uniform64(unsigned long long x) {
 }
 
 // wave-uniform buffer descriptor over [base, end)
-MF_DEV mf_v4i make_srd(unsigned long long base, unsigned long long end) {
+MF_DEV mf_v4i make_srd(unsigned long long base, unsigned long long end, int debug = 0) {
     unsigned long long rem = end > base ? end - base : 0ull;
+    if (debug & 1) rem = 0;
     if (rem > MF_DMA_MAXREC) rem = MF_DMA_MAXREC;
     mf_v4i srd;
     srd.x = __builtin_amdgcn_readfirstlane((int)(unsigned)base);
@@ -165,44 +176,122 @@ template <typename T, int D, int M> struct KfLdsCfg {
     static constexpr int OFF_rely = OFF_relH + 256;
     static constexpr int OFF_gtabC = OFF_rely + 256;
     static constexpr int LDS_TOTAL = OFF_gtabC + ((StC::U * 4 + 15) / 16) * 16;
+    // the streaming kernel is instantiated only where matrix rows are whole 16-B units, the per-step DMA count
+    // fits the 6-bit vm counter and the image fits 64 KB of LDS
+    static constexpr bool SUPPORTED = (D * D * S) % 16 == 0 && (StA::NI + StC::NI + Stb::NI + StH::NI + Sty::NI) < 64 &&
+                                      LDS_TOTAL <= 64 * 1024;
+};
+
+// DMA batches of one step.  All of a step's data is pulled into registers at the top of the step behind ONE
+// `s_waitcnt vmcnt(0)`; the batches of the next step are then issued between the arithmetic phases.
+// (Counted waits - "all but the youngest n have landed" - were tried and are NOT safe here: with dword and
+// dwordx4 LDS-DMA mixed in one stream of requests the landing order did not follow the issue order.)
+template <typename Cfg> struct KfPump {
+    static constexpr int N_SMALL = Cfg::StC::NI + Cfg::Stb::NI + Cfg::StH::NI + Cfg::Sty::NI;
+    static constexpr int N_BIG = Cfg::StA::NI;
+    const DmaStream<typename Cfg::StA>& dA; const DmaStream<typename Cfg::StC>& dC;
+    const DmaStream<typename Cfg::Stb>& db; const DmaStream<typename Cfg::StH>& dH;
+    const DmaStream<typename Cfg::Sty>& dy;
+    mf_v4i sA, sC, sb, sH, sy;
+    unsigned lds0;
+    bool more;
+    template <int K> MF_DEV void small() const {
+        if (!((MF_PUMPMASK >> K) & 1)) return;
+        small_do<K>();
+    }
+    template <int K> MF_DEV void small_do() const {
+        if (!more) return;
+        constexpr int HC = (Cfg::StC::NI + 1) / 2;
+        if (K == 0) dC.template issue<0, HC>(sC, lds0 + Cfg::OFF_C);
+        else {
+            dC.template issue<HC, 64>(sC, lds0 + Cfg::OFF_C);
+            db.template issue<0, 64>(sb, lds0 + Cfg::OFF_b);
+            dH.template issue<0, 64>(sH, lds0 + Cfg::OFF_H);
+            dy.template issue<0, 64>(sy, lds0 + Cfg::OFF_y);
+        }
+    }
+    template <int K> MF_DEV void all() const {
+        dC.template issue<0, 64>(sC, lds0 + Cfg::OFF_C);
+        db.template issue<0, 64>(sb, lds0 + Cfg::OFF_b);
+        dH.template issue<0, 64>(sH, lds0 + Cfg::OFF_H);
+        dy.template issue<0, 64>(sy, lds0 + Cfg::OFF_y);
+        dA.template issue<0, 64>(sA, lds0 + Cfg::OFF_A);
+    }
+    template <int K> MF_DEV void big() const {
+        if (!((MF_PUMPMASK >> (K + 2)) & 1)) return;
+        big_do<K>();
+    }
+    // the batches that are NOT pumped between the arithmetic phases are issued up front
+    MF_DEV void unpumped() const {
+        if (!((MF_PUMPMASK >> 0) & 1)) small_do<0>();
+        if (!((MF_PUMPMASK >> 1) & 1)) small_do<1>();
+        if (!((MF_PUMPMASK >> 2) & 1)) big_do<0>();
+        if (!((MF_PUMPMASK >> 3) & 1)) big_do<1>();
+        if (!((MF_PUMPMASK >> 4) & 1)) big_do<2>();
+        if (!((MF_PUMPMASK >> 5) & 1)) big_do<3>();
+    }
+    template <int K> MF_DEV void big_do() const {
+        if (!more) return;
+        constexpr int Q = (Cfg::StA::NI + 3) / 4;
+        dA.template issue<K * Q, (K + 1) * Q>(sA, lds0 + Cfg::OFF_A);
+    }
 };
 
 // One transition of the chain for this lane.  FIRST_SEP: the block on the left is this chunk's separator
 // (it is not eliminated here; its coupling seeds the spike).  Register discipline: the only large live
 // temporaries are Ci (lower), and ONE D x D array that is A -> B = C^-1 A -> Y = B L^-T -> W in turn;
 // Q_k^-1 + H^T R^-1 H is formed after the elimination, when B is no longer needed.
-template <typename T, int D, int M, bool SPIKE, bool FIRST_SEP>
+// `pump` issues the LDS-DMA of the NEXT step in small batches between the arithmetic phases: a burst of
+// ~40 wave-instructions back to back fills the CU's address queue and stalls the (only) wave of the SIMD
+// at issue, while one batch every few hundred VALU instructions is absorbed for free.
+template <typename T, int D, int M, bool SPIKE, bool FIRST, typename Pump>
 MF_DEV void kf_lds_step(Elim<T, D, SPIKE>& E, LogAcc<T>& laC, T& acc_yry, T& acc_ww, const T (&C)[D][D],
-                        T (&Bm)[D][D], const T (&mvec)[D], const T (&hk)[M * D], const T (&yk)[M],
-                        const T (&Rsh)[M * M]) {
-    T Ci[D][D], w[D];
-    tri_inv_lower<T, D>(C, Ci, laC, E.bad);
-    laC.renorm();
-    trimul_lower_vec<T, D>(Ci, mvec, w);
-    acc_ww += dot_self<T, D>(w);
-    {
-        // B = C^-1 A in place (row i only needs rows k <= i: go bottom-up)
-        MF_UNROLL for (int i = D - 1; i >= 0; --i)
-            MF_UNROLL for (int j = 0; j < D; ++j) {
-                T sacc = T(0);
-                MF_UNROLL for (int k = 0; k <= i; ++k) sacc += Ci[i][k] * Bm[k][j];
-                Bm[i][j] = sacc;
-            }
+                        const T (&mvec)[D], const T (&hk)[M * D], const T (&yk)[M], const T (&Rsh)[M * M],
+                        T (&Bm)[D][D], const Pump& pump, bool active, bool sep_lane) {
+    // FIRST (step 0 of a chunk): lanes of chunks c > 0 take the separator form, lanes of chunk 0 the ordinary
+    // one - both inside the SAME call, because the DMA batches must be issued once, by all lanes, in order.
+    const bool sep = FIRST && sep_lane, ord = active && !sep;
+    // Every arithmetic phase is predicated on `active` (a chunk shorter than the wave's trip count idles),
+    // the DMA batches in between are issued by ALL lanes: an LDS-DMA lane carries another row's data.
+    T Ci[D][D], w[D], btw[D];
+    if (active) {
+        tri_inv_lower<T, D>(C, Ci, laC, E.bad);
+        laC.renorm();
     }
-    T btw[D];
-    gemv_t<T, D, D>(Bm, w, btw);
-    if (FIRST_SEP) {
+    pump.template small<0>();
+    if (active) {
+        trimul_lower_vec<T, D>(Ci, mvec, w);
+        acc_ww += dot_self<T, D>(w);
+    }
+    pump.template small<1>();
+    pump.template big<0>();
+    if (active) {
+        trimul_lower_inplace<T, D, D>(Ci, Bm);            // B = C^-1 A
+        gemv_t<T, D, D>(Bm, w, btw);
+    }
+    pump.template big<1>();
+    if (FIRST && active && sep) {
         syrk_tn_lower<T, D, D>(Bm, E.GU, T(1));
         MF_UNROLL for (int i = 0; i < D; ++i) E.gU[i] = -btw[i];
+    }
+    if (ord) {
+        syrk_tn_lower<T, D, D>(Bm, E.Phi, T(1));
+        MF_UNROLL for (int i = 0; i < D; ++i) E.t[i] -= btw[i];
+    }
+    pump.template big<2>();
+    if (FIRST && active && sep) {
         neg_trimulT_lower_inplace<T, D, D>(Ci, Bm);       // S = -C^-T B
         MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) E.X[i][j] = Bm[i][j];
+    }
+    if (ord) E.eliminate_main();
+    pump.template big<3>();
+    if (FIRST && active && sep) {
         trimulT_self_lower<T, D>(Ci, E.Phi);
         trimulT_lower_vec<T, D>(Ci, w, E.t);
         acc_yry += Obs<T, D, M>::apply(hk, yk, Rsh, M, E.Phi, E.t);
-    } else {
-        syrk_tn_lower<T, D, D>(Bm, E.Phi, T(1));
-        MF_UNROLL for (int i = 0; i < D; ++i) E.t[i] -= btw[i];
-        E.eliminate();
+    }
+    if (ord) {
+        E.eliminate_spike();
         trsm_right_lower_t<T, D, D>(E.Phi, E.Li, Bm);     // Y = B L^-T
         neg_trimulT_lower_inplace<T, D, D>(Ci, Bm);       // W = -C^-T Y
         T Dn[D][D], rn[D];
@@ -256,7 +345,6 @@ __global__ void __launch_bounds__(64) kf_chunk_lds_kernel(KfArgs<T> a, long L, R
     DmaStream<typename Cfg::Stb> db;
     DmaStream<typename Cfg::StH> dH;
     DmaStream<typename Cfg::Sty> dy;
-    dA.init(lane); dC.init(lane); db.init(lane); dH.init(lane); dy.init(lane);
     unsigned long long pA = (unsigned long long)a.A + offA0, pC = (unsigned long long)a.cholQ + offA0;
     unsigned long long pb = (unsigned long long)a.b + offb0, pH = (unsigned long long)a.H + offH0;
     unsigned long long py = (unsigned long long)a.y + offy0;
@@ -298,6 +386,11 @@ __global__ void __launch_bounds__(64) kf_chunk_lds_kernel(KfArgs<T> a, long L, R
     // the LDS tables must be visible to every lane before the first DMA address is formed (one wave: a
     // wait on the LDS counter is enough) and the plain loads above must be done before DMAs are counted
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    dA.init(smem, lane, Cfg::OFF_relA, 0);
+    dC.init(smem, lane, Cfg::OFF_relA, Cfg::OFF_gtabC);
+    db.init(smem, lane, Cfg::OFF_relb, 0);
+    dH.init(smem, lane, Cfg::OFF_relH, 0);
+    dy.init(smem, lane, Cfg::OFF_rely, 0);
 
     const RowReader<T, typename Cfg::StA> rA(smem, Cfg::OFF_A, lane);
     const RowReader<T, typename Cfg::StC> rC(smem, Cfg::OFF_C, lane);
@@ -305,26 +398,40 @@ __global__ void __launch_bounds__(64) kf_chunk_lds_kernel(KfArgs<T> a, long L, R
     const RowReader<T, typename Cfg::StH> rH(smem, Cfg::OFF_H, lane);
     const RowReader<T, typename Cfg::Sty> ry(smem, Cfg::OFF_y, lane);
 
-    auto issue_small = [&]() {
-        dC.issue(smem, make_srd(pC, eC), lds0 + Cfg::OFF_C, Cfg::OFF_relA, Cfg::OFF_gtabC);
-        db.issue(smem, make_srd(pb, eb), lds0 + Cfg::OFF_b, Cfg::OFF_relb, 0);
-        dH.issue(smem, make_srd(pH, eH), lds0 + Cfg::OFF_H, Cfg::OFF_relH, 0);
-        dy.issue(smem, make_srd(py, ey), lds0 + Cfg::OFF_y, Cfg::OFF_rely, 0);
-    };
-    auto issue_A = [&]() { dA.issue(smem, make_srd(pA, eA), lds0 + Cfg::OFF_A, Cfg::OFF_relA, 0); };
+    using Pump = KfPump<Cfg>;
 
-    if (nsteps > 0) {
-        issue_small();
-        issue_A();
+    if (nsteps > 0) {   // prologue: fetch step 0
+        Pump p0{dA, dC, db, dH, dy, make_srd(pA, eA, a.debug), make_srd(pC, eC, a.debug | ((a.debug >> 2) & 1)),
+                make_srd(pb, eb, a.debug | ((a.debug >> 1) & 1)), make_srd(pH, eH, a.debug | ((a.debug >> 1) & 1)),
+                make_srd(py, ey, a.debug | ((a.debug >> 1) & 1)), lds0, true};
+        p0.template all<0>();
     }
 
-    // One streamed step: wait for the data of step j, move it to registers, refill the LDS regions for
-    // step j+1 as soon as they have been read, then do the arithmetic.  FIRST distinguishes step 0 (whose
-    // left block is the separator for every chunk but the first) so that the steady-state loop body holds
-    // a single code path.
+    // One streamed step: wait for this step's cholQ/b/H/y (A may still be in flight), move them to registers,
+    // then run the arithmetic with the next step's DMA pumped in between.  FIRST distinguishes step 0 (whose
+    // left block is the separator for every chunk but the first) so that the steady-state loop body holds a
+    // single code path.
+#ifdef MF_STAMP
+#define MF_STAMP_AT(var) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); var = t_; }
+    unsigned long long st_wait = 0, st_io = 0, st_comp = 0, ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+#define MF_STAMP_ACC { asm volatile("" :: "v"(E.quad), "v"(E.Phi[0][0]) : "memory"); MF_STAMP_AT(ts3) st_wait += ts1 - ts0; st_io += ts2 - ts1; st_comp += ts3 - ts2; }
+#else
+#define MF_STAMP_AT(var)
+#define MF_STAMP_ACC
+#endif
+#ifdef MF_CHECKSUM
+    T cs_A = 0, cs_C = 0, cs_b = 0, cs_H = 0, cs_y = 0;
+#define MF_CHECKSUM_ACC if (j < len) { MF_UNROLL for (int i = 0; i < D; ++i) { cs_b += mvec[i]; MF_UNROLL for (int jj = 0; jj < D; ++jj) { cs_A += Bm[i][jj] * T(1 + i * D + jj); if (jj <= i) cs_C += C[i][jj] * T(1 + i * D + jj); } } \
+        MF_UNROLL for (int i = 0; i < M * D; ++i) cs_H += hk[i] * T(1 + i); MF_UNROLL for (int i = 0; i < M; ++i) cs_y += yk[i]; }
+#else
+#define MF_CHECKSUM_ACC
+#endif
+#define MF_NOPUMP_ISSUE pump.unpumped();
 #define MF_KF_LDS_STEP(FIRST)                                                                                         \
     {                                                                                                                 \
+        MF_STAMP_AT(ts0)                                                                                              \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                              \
+        MF_STAMP_AT(ts1)                                                                                              \
         const bool more = (j + 1 < nsteps);                                                                           \
         pA += D * D * S; pC += D * D * S; pb += D * S; pH += M * D * S; py += M * S;                                  \
         T C[D][D], mvec[D], hk[M * D], yk[M];                                                                         \
@@ -332,18 +439,20 @@ __global__ void __launch_bounds__(64) kf_chunk_lds_kernel(KfArgs<T> a, long L, R
         MF_UNROLL for (int i = 0; i < D; ++i) mvec[i] = rb.at(i);                                                     \
         MF_UNROLL for (int i = 0; i < M * D; ++i) hk[i] = rH.at(i);                                                   \
         MF_UNROLL for (int i = 0; i < M; ++i) yk[i] = ry.at(i);                                                       \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                            \
-        if (more) issue_small();                                                                                      \
         T Bm[D][D];                                                                                                   \
         MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int jj = 0; jj < D; ++jj) Bm[i][jj] = rA.at(i * D + jj); \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                            \
-        if (more) issue_A();                                                                                          \
-        if (j < len) {                                                                                                \
-            if (FIRST && c > 0)                                                                                       \
-                kf_lds_step<T, D, M, SPIKE, true>(E, laC, acc_yry, acc_ww, C, Bm, mvec, hk, yk, Rsh);                 \
-            else                                                                                                      \
-                kf_lds_step<T, D, M, SPIKE, false>(E, laC, acc_yry, acc_ww, C, Bm, mvec, hk, yk, Rsh);                \
-        }                                                                                                             \
+        MF_CHECKSUM_ACC                                                                                               \
+        MF_STAMP_AT(ts2)                                                                                              \
+        const Pump pump{dA, dC, db, dH, dy, make_srd(pA, eA, a.debug),                                                \
+                        make_srd(pC, eC, a.debug | ((a.debug >> 2) & 1)),                                             \
+                        make_srd(pb, eb, a.debug | ((a.debug >> 1) & 1)),                                             \
+                        make_srd(pH, eH, a.debug | ((a.debug >> 1) & 1)),                                             \
+                        make_srd(py, ey, a.debug | ((a.debug >> 1) & 1)), lds0, more};                                \
+        MF_NOPUMP_ISSUE                                                                                               \
+        const bool active = j < len;                                                                                  \
+        kf_lds_step<T, D, M, SPIKE, FIRST>(E, laC, acc_yry, acc_ww, C, mvec, hk, yk, Rsh, Bm, pump, active, c > 0);    \
+        MF_STAMP_ACC                                                                                                  \
     }
     long j = 0;
     if (nsteps > 0) MF_KF_LDS_STEP(true)
@@ -354,6 +463,15 @@ __global__ void __launch_bounds__(64) kf_chunk_lds_kernel(KfArgs<T> a, long L, R
         const T scalar = T(-0.5) * (acc_yry + acc_ww) + T(0.5) * E.quad - laC.value() - E.laL.value();
         store_chunk<T, D, SPIKE>(out, id, E, scalar);
         if (E.bad && a.info) atomicMax(a.info, 1);
+#ifdef MF_CHECKSUM
+        out.GU[id * D * D + 0] = cs_A; out.GU[id * D * D + 1] = cs_C; out.GU[id * D * D + 2] = cs_b;
+        out.gU[id * D + 0] = cs_H; out.gU[id * D + 1] = cs_y;
+#endif
+#ifdef MF_STAMP
+        if (lane == 0) {   // diagnostic build only: overwrite this chunk's GU block with the stamp sums
+            out.GU[id * D * D + 0] = (T)st_wait; out.GU[id * D * D + 1] = (T)st_io; out.GU[id * D * D + 2] = (T)st_comp;
+        }
+#endif
     }
 }
 

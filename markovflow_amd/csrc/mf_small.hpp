@@ -99,6 +99,10 @@ template <typename T, int D> MF_DEV void store_lower(T* __restrict__ p, const T 
 }
 
 // ---- triangular / symmetric kernels --------------------------------------------------------------
+// Loop order convention: the INNERMOST loop always runs over independent outputs (outer-product /
+// right-looking forms), never along a dot product.  With one wavefront per SIMD there is no other wave
+// to hide the latency of a dependent fp64 FMA, so instruction-level parallelism has to be in program
+// order (under register pressure the scheduler stays close to it).
 
 // Ci = C^-1 for lower-triangular C (only the lower triangle of C is read).  `la` picks up prod diag(C).
 template <typename T, int D>
@@ -109,198 +113,182 @@ MF_DEV void tri_inv_lower(const T (&C)[D][D], T (&Ci)[D][D], LogAcc<T>& la, bool
         la.mul(c);
         Ci[i][i] = t_rcp<T>(c);
     }
-    MF_UNROLL for (int j = 0; j < D; ++j)
-        MF_UNROLL for (int i = j + 1; i < D; ++i) {
-            T s = T(0);
-            MF_UNROLL for (int k = j; k < i; ++k) s += C[i][k] * Ci[k][j];
-            Ci[i][j] = -s * Ci[i][i];
-        }
+    // row i of C^-1:  Ci[i][j] = -Ci[i][i] * sum_{k=j}^{i-1} C[i][k] Ci[k][j]
+    MF_UNROLL for (int i = 1; i < D; ++i) {
+        T acc[D];
+        MF_UNROLL for (int j = 0; j < i; ++j) acc[j] = T(0);
+        MF_UNROLL for (int k = 0; k < i; ++k)
+            MF_UNROLL for (int j = 0; j <= k; ++j) acc[j] += C[i][k] * Ci[k][j];
+        MF_UNROLL for (int j = 0; j < i; ++j) Ci[i][j] = -acc[j] * Ci[i][i];
+    }
 }
 
 // out = Lo * A   (Lo lower triangular)
 template <typename T, int D, int N>
 MF_DEV void trimul_lower(const T (&Lo)[D][D], const T (&A)[D][N], T (&out)[D][N]) {
-    MF_UNROLL for (int i = 0; i < D; ++i)
-        MF_UNROLL for (int j = 0; j < N; ++j) {
-            T s = T(0);
-            MF_UNROLL for (int k = 0; k <= i; ++k) s += Lo[i][k] * A[k][j];
-            out[i][j] = s;
-        }
+    MF_UNROLL for (int i = 0; i < D; ++i) {
+        MF_UNROLL for (int j = 0; j < N; ++j) out[i][j] = Lo[i][0] * A[0][j];
+        MF_UNROLL for (int k = 1; k <= i; ++k)
+            MF_UNROLL for (int j = 0; j < N; ++j) out[i][j] += Lo[i][k] * A[k][j];
+    }
+}
+// A <- Lo * A in place (row i only needs rows k <= i: bottom-up)
+template <typename T, int D, int N>
+MF_DEV void trimul_lower_inplace(const T (&Lo)[D][D], T (&A)[D][N]) {
+    MF_UNROLL for (int i = D - 1; i >= 0; --i) {
+        MF_UNROLL for (int j = 0; j < N; ++j) A[i][j] *= Lo[i][i];
+        MF_UNROLL for (int k = 0; k < i; ++k)
+            MF_UNROLL for (int j = 0; j < N; ++j) A[i][j] += Lo[i][k] * A[k][j];
+    }
 }
 template <typename T, int D>
 MF_DEV void trimul_lower_vec(const T (&Lo)[D][D], const T (&a)[D], T (&out)[D]) {
-    MF_UNROLL for (int i = 0; i < D; ++i) {
-        T s = T(0);
-        MF_UNROLL for (int k = 0; k <= i; ++k) s += Lo[i][k] * a[k];
-        out[i] = s;
-    }
+    MF_UNROLL for (int i = 0; i < D; ++i) out[i] = Lo[i][0] * a[0];
+    MF_UNROLL for (int k = 1; k < D; ++k)
+        MF_UNROLL for (int i = k; i < D; ++i) out[i] += Lo[i][k] * a[k];
 }
 // out = Lo^T * A
 template <typename T, int D, int N>
 MF_DEV void trimulT_lower(const T (&Lo)[D][D], const T (&A)[D][N], T (&out)[D][N]) {
-    MF_UNROLL for (int i = 0; i < D; ++i)
-        MF_UNROLL for (int j = 0; j < N; ++j) {
-            T s = T(0);
-            MF_UNROLL for (int k = i; k < D; ++k) s += Lo[k][i] * A[k][j];
-            out[i][j] = s;
-        }
+    MF_UNROLL for (int i = 0; i < D; ++i) {
+        MF_UNROLL for (int j = 0; j < N; ++j) out[i][j] = Lo[i][i] * A[i][j];
+        MF_UNROLL for (int k = i + 1; k < D; ++k)
+            MF_UNROLL for (int j = 0; j < N; ++j) out[i][j] += Lo[k][i] * A[k][j];
+    }
 }
 template <typename T, int D>
 MF_DEV void trimulT_lower_vec(const T (&Lo)[D][D], const T (&a)[D], T (&out)[D]) {
-    MF_UNROLL for (int i = 0; i < D; ++i) {
-        T s = T(0);
-        MF_UNROLL for (int k = i; k < D; ++k) s += Lo[k][i] * a[k];
-        out[i] = s;
-    }
+    MF_UNROLL for (int i = 0; i < D; ++i) out[i] = Lo[i][i] * a[i];
+    MF_UNROLL for (int k = 1; k < D; ++k)
+        MF_UNROLL for (int i = 0; i < k; ++i) out[i] += Lo[k][i] * a[k];
 }
 // Y <- -(Lo^T Y), in place (row i of the result only needs rows k >= i of Y)
 template <typename T, int D, int N>
 MF_DEV void neg_trimulT_lower_inplace(const T (&Lo)[D][D], T (&Y)[D][N]) {
-    MF_UNROLL for (int i = 0; i < D; ++i)
-        MF_UNROLL for (int j = 0; j < N; ++j) {
-            T s = T(0);
-            MF_UNROLL for (int k = i; k < D; ++k) s += Lo[k][i] * Y[k][j];
-            Y[i][j] = -s;
-        }
+    MF_UNROLL for (int i = 0; i < D; ++i) {
+        MF_UNROLL for (int j = 0; j < N; ++j) Y[i][j] *= -Lo[i][i];
+        MF_UNROLL for (int k = i + 1; k < D; ++k)
+            MF_UNROLL for (int j = 0; j < N; ++j) Y[i][j] -= Lo[k][i] * Y[k][j];
+    }
 }
 // S(lower) = Lo^T Lo
 template <typename T, int D> MF_DEV void trimulT_self_lower(const T (&Lo)[D][D], T (&S)[D][D]) {
-    MF_UNROLL for (int i = 0; i < D; ++i)
-        MF_UNROLL for (int j = 0; j <= i; ++j) {
-            T s = T(0);
-            MF_UNROLL for (int k = i; k < D; ++k) s += Lo[k][i] * Lo[k][j];
-            S[i][j] = s;
-        }
+    MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) S[i][j] = Lo[D - 1][i] * Lo[D - 1][j];
+    MF_UNROLL for (int k = D - 2; k >= 0; --k)
+        MF_UNROLL for (int i = 0; i <= k; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) S[i][j] += Lo[k][i] * Lo[k][j];
 }
 // S(lower) += sign * B^T B
 template <typename T, int D, int N>
 MF_DEV void syrk_tn_lower(const T (&B)[N][D], T (&S)[D][D], T sign) {
-    MF_UNROLL for (int i = 0; i < D; ++i)
-        MF_UNROLL for (int j = 0; j <= i; ++j) {
-            T s = T(0);
-            MF_UNROLL for (int k = 0; k < N; ++k) s += B[k][i] * B[k][j];
-            S[i][j] += sign * s;
+    MF_UNROLL for (int k = 0; k < N; ++k)
+        MF_UNROLL for (int i = 0; i < D; ++i) {
+            const T bi = sign * B[k][i];
+            MF_UNROLL for (int j = 0; j <= i; ++j) S[i][j] += bi * B[k][j];
         }
 }
 // S(lower) += sign * W W^T
 template <typename T, int D, int N>
 MF_DEV void syrk_nt_lower(const T (&W)[D][N], T (&S)[D][D], T sign) {
-    MF_UNROLL for (int i = 0; i < D; ++i)
-        MF_UNROLL for (int j = 0; j <= i; ++j) {
-            T s = T(0);
-            MF_UNROLL for (int k = 0; k < N; ++k) s += W[i][k] * W[j][k];
-            S[i][j] += sign * s;
+    MF_UNROLL for (int k = 0; k < N; ++k)
+        MF_UNROLL for (int i = 0; i < D; ++i) {
+            const T wi = sign * W[i][k];
+            MF_UNROLL for (int j = 0; j <= i; ++j) S[i][j] += wi * W[j][k];
         }
 }
 // out = B^T v
 template <typename T, int D, int N>
 MF_DEV void gemv_t(const T (&B)[N][D], const T (&v)[N], T (&out)[D]) {
-    MF_UNROLL for (int i = 0; i < D; ++i) {
-        T s = T(0);
-        MF_UNROLL for (int k = 0; k < N; ++k) s += B[k][i] * v[k];
-        out[i] = s;
-    }
+    MF_UNROLL for (int i = 0; i < D; ++i) out[i] = B[0][i] * v[0];
+    MF_UNROLL for (int k = 1; k < N; ++k)
+        MF_UNROLL for (int i = 0; i < D; ++i) out[i] += B[k][i] * v[k];
 }
 // out = W v
 template <typename T, int D, int N>
 MF_DEV void gemv_n(const T (&W)[D][N], const T (&v)[N], T (&out)[D]) {
-    MF_UNROLL for (int i = 0; i < D; ++i) {
-        T s = T(0);
-        MF_UNROLL for (int k = 0; k < N; ++k) s += W[i][k] * v[k];
-        out[i] = s;
-    }
+    MF_UNROLL for (int i = 0; i < D; ++i) out[i] = W[i][0] * v[0];
+    MF_UNROLL for (int k = 1; k < N; ++k)
+        MF_UNROLL for (int i = 0; i < D; ++i) out[i] += W[i][k] * v[k];
 }
 
-// In-place lower Cholesky of the symmetric matrix held in the lower triangle of S.  On exit the lower
-// triangle holds L and Li[i] = 1 / L[i][i].  `la` picks up prod diag(L); `bad` is set on a
+// In-place lower Cholesky (right-looking) of the symmetric matrix held in the lower triangle of S.  On exit
+// the lower triangle holds L and Li[i] = 1 / L[i][i].  `la` picks up prod diag(L); `bad` is set on a
 // non-positive pivot (the result is then NaN, LAPACK info > 0 style).
 template <typename T, int D>
 MF_DEV void chol_lower(T (&S)[D][D], T (&Li)[D], LogAcc<T>& la, bool& bad) {
     MF_UNROLL for (int j = 0; j < D; ++j) {
-        T s = S[j][j];
-        MF_UNROLL for (int k = 0; k < j; ++k) s -= S[j][k] * S[j][k];
+        const T s = S[j][j];
         bad |= !(s > T(0));
         const T inv = t_rsqrt<T>(s);
         const T l = s * inv;
         S[j][j] = l;
         Li[j] = inv;
         la.mul(l);
-        MF_UNROLL for (int i = j + 1; i < D; ++i) {
-            T t = S[i][j];
-            MF_UNROLL for (int k = 0; k < j; ++k) t -= S[i][k] * S[j][k];
-            S[i][j] = t * inv;
-        }
+        MF_UNROLL for (int i = j + 1; i < D; ++i) S[i][j] *= inv;
+        MF_UNROLL for (int i = j + 1; i < D; ++i)
+            MF_UNROLL for (int k = j + 1; k <= i; ++k) S[i][k] -= S[i][j] * S[k][j];
     }
 }
 
 // z <- L^-1 z
 template <typename T, int D>
 MF_DEV void trsv_lower(const T (&L)[D][D], const T (&Li)[D], T (&z)[D]) {
-    MF_UNROLL for (int i = 0; i < D; ++i) {
-        T t = z[i];
-        MF_UNROLL for (int k = 0; k < i; ++k) t -= L[i][k] * z[k];
-        z[i] = t * Li[i];
+    MF_UNROLL for (int k = 0; k < D; ++k) {
+        z[k] *= Li[k];
+        MF_UNROLL for (int i = k + 1; i < D; ++i) z[i] -= L[i][k] * z[k];
     }
 }
 // z <- L^-T z
 template <typename T, int D>
 MF_DEV void trsv_lower_t(const T (&L)[D][D], const T (&Li)[D], T (&z)[D]) {
-    MF_UNROLL for (int i = D - 1; i >= 0; --i) {
-        T t = z[i];
-        MF_UNROLL for (int k = i + 1; k < D; ++k) t -= L[k][i] * z[k];
-        z[i] = t * Li[i];
+    MF_UNROLL for (int k = D - 1; k >= 0; --k) {
+        z[k] *= Li[k];
+        MF_UNROLL for (int i = 0; i < k; ++i) z[i] -= L[k][i] * z[k];
     }
 }
 // X <- L^-1 X   (N columns)
 template <typename T, int D, int N>
 MF_DEV void trsm_left_lower(const T (&L)[D][D], const T (&Li)[D], T (&X)[D][N]) {
-    MF_UNROLL for (int i = 0; i < D; ++i)
-        MF_UNROLL for (int c = 0; c < N; ++c) {
-            T t = X[i][c];
-            MF_UNROLL for (int k = 0; k < i; ++k) t -= L[i][k] * X[k][c];
-            X[i][c] = t * Li[i];
-        }
+    MF_UNROLL for (int k = 0; k < D; ++k) {
+        MF_UNROLL for (int c = 0; c < N; ++c) X[k][c] *= Li[k];
+        MF_UNROLL for (int i = k + 1; i < D; ++i)
+            MF_UNROLL for (int c = 0; c < N; ++c) X[i][c] -= L[i][k] * X[k][c];
+    }
 }
 // X <- L^-T X
 template <typename T, int D, int N>
 MF_DEV void trsm_left_lower_t(const T (&L)[D][D], const T (&Li)[D], T (&X)[D][N]) {
-    MF_UNROLL for (int i = D - 1; i >= 0; --i)
-        MF_UNROLL for (int c = 0; c < N; ++c) {
-            T t = X[i][c];
-            MF_UNROLL for (int k = i + 1; k < D; ++k) t -= L[k][i] * X[k][c];
-            X[i][c] = t * Li[i];
-        }
+    MF_UNROLL for (int k = D - 1; k >= 0; --k) {
+        MF_UNROLL for (int c = 0; c < N; ++c) X[k][c] *= Li[k];
+        MF_UNROLL for (int i = 0; i < k; ++i)
+            MF_UNROLL for (int c = 0; c < N; ++c) X[i][c] -= L[k][i] * X[k][c];
+    }
 }
 // Y <- Y L^-T   (each of the R rows y solves  L y^T = b^T)
 template <typename T, int D, int R>
 MF_DEV void trsm_right_lower_t(const T (&L)[D][D], const T (&Li)[D], T (&Y)[R][D]) {
-    MF_UNROLL for (int r = 0; r < R; ++r)
-        MF_UNROLL for (int j = 0; j < D; ++j) {
-            T t = Y[r][j];
-            MF_UNROLL for (int k = 0; k < j; ++k) t -= Y[r][k] * L[j][k];
-            Y[r][j] = t * Li[j];
-        }
+    MF_UNROLL for (int k = 0; k < D; ++k) {
+        MF_UNROLL for (int r = 0; r < R; ++r) Y[r][k] *= Li[k];
+        MF_UNROLL for (int j = k + 1; j < D; ++j)
+            MF_UNROLL for (int r = 0; r < R; ++r) Y[r][j] -= Y[r][k] * L[j][k];
+    }
 }
 // Y <- Y L^-1   (each row y solves  L^T y^T = b^T)
 template <typename T, int D, int R>
 MF_DEV void trsm_right_lower(const T (&L)[D][D], const T (&Li)[D], T (&Y)[R][D]) {
-    MF_UNROLL for (int r = 0; r < R; ++r)
-        MF_UNROLL for (int j = D - 1; j >= 0; --j) {
-            T t = Y[r][j];
-            MF_UNROLL for (int k = j + 1; k < D; ++k) t -= Y[r][k] * L[k][j];
-            Y[r][j] = t * Li[j];
-        }
+    MF_UNROLL for (int k = D - 1; k >= 0; --k) {
+        MF_UNROLL for (int r = 0; r < R; ++r) Y[r][k] *= Li[k];
+        MF_UNROLL for (int j = 0; j < k; ++j)
+            MF_UNROLL for (int r = 0; r < R; ++r) Y[r][j] -= Y[r][k] * L[k][j];
+    }
 }
 // X <- -(W X), column by column in place
 template <typename T, int D>
 MF_DEV void neg_mul_inplace(const T (&W)[D][D], T (&X)[D][D]) {
     MF_UNROLL for (int c = 0; c < D; ++c) {
         T col[D];
-        MF_UNROLL for (int i = 0; i < D; ++i) {
-            T s = T(0);
-            MF_UNROLL for (int k = 0; k < D; ++k) s += W[i][k] * X[k][c];
-            col[i] = s;
-        }
+        MF_UNROLL for (int i = 0; i < D; ++i) col[i] = W[i][0] * X[0][c];
+        MF_UNROLL for (int k = 1; k < D; ++k)
+            MF_UNROLL for (int i = 0; i < D; ++i) col[i] += W[i][k] * X[k][c];
         MF_UNROLL for (int i = 0; i < D; ++i) X[i][c] = -col[i];
     }
 }
