@@ -1,0 +1,46 @@
+"""
+Batch sharding of independent series over the GPUs of one node (one process per GPU).
+
+The reference is single-process: its only "parallel" axis is the leading batch shape, and
+``log_likelihood`` / ``kl_divergence`` end in a sum over it (``markovflow/kalman_filter.py:255``).  That sum is
+the single exchange step of the sharded path: every rank evaluates its own contiguous slice of series with
+the HIP kernels and ONE all-reduce of a scalar (RCCL over xGMI with backend ``"nccl"``; ``gloo`` on CPU in the
+tests) yields the total.  No tensor of the path is ever replicated or moved between ranks.
+"""
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(num_series: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Contiguous slice ``[lo, hi)`` of the batch axis owned by ``rank``; sizes differ by at most one."""
+    if world_size < 1 or not 0 <= rank < world_size:
+        raise ValueError(f"invalid rank {rank} for world size {world_size}")
+    if num_series < 0:
+        raise ValueError("num_series must be non-negative")
+    base, extra = divmod(num_series, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_batch(tensor: torch.Tensor, rank: int, world_size: int) -> torch.Tensor:
+    """This rank's slice of a tensor whose leading axis is the series axis (a view, nothing is copied)."""
+    lo, hi = shard_bounds(tensor.shape[0], rank, world_size)
+    return tensor[lo:hi]
+
+
+def all_reduce_sum(value: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """Sum a (scalar) tensor over the ranks in place; a no-op when torch.distributed is not initialised."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(value, op=dist.ReduceOp.SUM, group=group)
+    return value
+
+
+def sharded_log_likelihood(kalman_filter, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """
+    Total log marginal likelihood of a batch that is sharded over the ranks: ``kalman_filter`` holds THIS
+    rank's series only; the result is identical on every rank.  An empty local shard contributes zero.
+    """
+    local = kalman_filter.log_likelihood()
+    return all_reduce_sum(local.reshape(()).clone(), group)

@@ -1,0 +1,96 @@
+"""
+Multi-process (world_size 2, gloo, CPU) test of the batch-sharded path of markovflow_amd.distributed.
+
+The HIP kernels cannot run here, so every rank's LOCAL log-likelihood comes from the numpy oracle (the
+checker); what is under test is the host logic of the sharded path: contiguous, non-overlapping, exhaustive
+shards (including uneven and empty ones) and the single scalar all-reduce that every rank must agree on.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from markovflow_amd import distributed as mfd
+from oracle import numpy_oracle as O
+
+
+def _inputs(bsz, t=9, d=3, m=1, seed=5):
+    rng = np.random.default_rng(seed)
+    return dict(
+        mu0=rng.normal(size=(bsz, d)),
+        chol_p0=np.tril(0.1 * rng.normal(size=(bsz, d, d))) + np.eye(d),
+        a_s=0.8 * np.eye(d) + 0.05 * rng.normal(size=(bsz, t - 1, d, d)),
+        b_s=0.1 * rng.normal(size=(bsz, t - 1, d)),
+        chol_q=np.tril(0.1 * rng.normal(size=(bsz, t - 1, d, d))) + 0.5 * np.eye(d),
+        h=rng.normal(size=(bsz, t, m, d)),
+        y=rng.normal(size=(bsz, t, m)),
+    )
+
+
+class _OracleBackedFilter:
+    """Stands in for a KalmanFilter that holds one rank's series: log_likelihood() of the local shard."""
+
+    def __init__(self, arrays):
+        self.arrays = arrays
+
+    def log_likelihood(self):
+        if self.arrays["mu0"].shape[0] == 0:
+            return torch.zeros((), dtype=torch.float64)
+        return torch.tensor(O.kf_log_likelihood(r_inv=np.array([[4.0]]), **self.arrays), dtype=torch.float64)
+
+
+def _worker(rank, world, port, bsz, results):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        full = _inputs(bsz)
+        lo, hi = mfd.shard_bounds(bsz, rank, world)
+        local = {k: v[lo:hi] for k, v in full.items()}
+        assert torch.equal(mfd.shard_batch(torch.arange(bsz), rank, world), torch.arange(lo, hi))
+        total = mfd.sharded_log_likelihood(_OracleBackedFilter(local))
+        results[rank] = (lo, hi, float(total))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("bsz", [6, 5, 1])
+def test_sharded_log_likelihood_world2_gloo(bsz):
+    world = 2
+    with mp.Manager() as manager:
+        results = manager.dict()
+        mp.spawn(_worker, args=(world, _free_port(), bsz, results), nprocs=world, join=True)
+        results = dict(results)
+    expect = float(O.kf_log_likelihood(r_inv=np.array([[4.0]]), **_inputs(bsz)))
+    bounds = sorted((lo, hi) for lo, hi, _ in results.values())
+    assert bounds[0][0] == 0 and bounds[-1][1] == bsz and bounds[0][1] == bounds[1][0]
+    for rank in range(world):
+        assert results[rank][2] == pytest.approx(expect, rel=1e-12)
+    assert results[0][2] == results[1][2]          # bit-identical on every rank
+
+
+@pytest.mark.parametrize("n,world", [(0, 1), (1, 8), (7, 8), (8, 8), (1024, 8), (4099, 8), (5, 2)])
+def test_shard_bounds_partition_the_batch(n, world):
+    cover = []
+    for r in range(world):
+        lo, hi = mfd.shard_bounds(n, r, world)
+        assert 0 <= lo <= hi <= n and hi - lo in (n // world, n // world + 1)
+        cover += list(range(lo, hi))
+    assert cover == list(range(n))
+    with pytest.raises(ValueError):
+        mfd.shard_bounds(n, world, world)
+
+
+def test_all_reduce_is_identity_without_process_group():
+    x = torch.tensor(3.5, dtype=torch.float64)
+    assert mfd.all_reduce_sum(x) is x and float(x) == 3.5
