@@ -113,6 +113,7 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
+    from markovflow_amd import distributed as mfd
     from markovflow_amd import synthetic
 
     dtype = torch.float64 if args.dtype == "f64" else torch.float32
@@ -125,10 +126,8 @@ def main():
     kf._prof_events = (ev.start, ev.stop)
 
     def step():
-        ll = kf.log_likelihood()
-        if dist is not None:
-            dist.all_reduce(ll, op=dist.ReduceOp.SUM)      # the path's only exchange: one scalar
-        return ll
+        # this rank's series + the path's only exchange: one all-reduce of the scalar (a no-op at N=1)
+        return mfd.sharded_log_likelihood(kf)
 
     for _ in range(args.warmup):
         ll = step()
@@ -161,6 +160,17 @@ def main():
     achieved_gbs = units_per_launch * bytes_per_step / (kern_avg_ms * 1e-3) / 1e9
     value = world * bsz * tn * args.steps / elapsed
 
+    # HBM-side bytes per launch measured with rocprofv3 PMC passes (cannot be collected from inside this
+    # process): quoted from profiles/hbm_traffic.json when it holds this exact workload, else null
+    traffic, traffic_src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fh:
+            entry = json.load(fh).get(f"kf_loglik B={bsz} T={tn} d={d} m={m} {args.dtype}")
+        if entry and args.chunks == 0:
+            traffic, traffic_src = entry["traffic_bytes"], entry["source"]
+    except OSError:
+        pass
+
     result = {
         "metric": "Kalman log-lik steps/sec (BxT) at d=6",
         "value": value,
@@ -182,8 +192,8 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-            "kernel": "kf_chunk_kernel", "kernel_ms": kern_avg_ms,
+            "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": "mf::kf_chunk_lds_kernel (level 0 of the partitioned elimination)", "kernel_ms": kern_avg_ms,
             "algorithmic_bytes_per_launch": units_per_launch * bytes_per_step,
         },
         "log_likelihood": float(ll.item()),

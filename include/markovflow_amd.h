@@ -67,21 +67,29 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
  * block_to_band/band_to_block layout shuffles, which do not exist here).  Natural order:
  * L_0 = chol(D_0), W_{k-1} = S_{k-1} L_{k-1}^-T, L_k = chol(D_k - W_{k-1} W_{k-1}^T).
  * sub / lsub may be NULL (block-diagonal matrix).  Only the lower triangle of diag is read.
+ * With many series one lane walks each chain.  With few, long chains (BASELINE config 3: B=1, T=100000) the
+ * factorisation is parallelised in time by a multi-level partitioned elimination that still returns the
+ * natural-order factor (csrc/mf_btd_par.hpp); that path needs scratch: ws_bytes >=
+ * mf_btd_cholesky_workspace_bytes(...) (0 = the serial kernel will be used; ws may then be NULL).
  */
+size_t mf_btd_cholesky_workspace_bytes(int64_t B, int64_t T, int d, int elem_size);
 int mf_btd_cholesky_f64(int64_t B, int64_t T, int d, const double* diag, const double* sub, double* ldiag,
-                        double* lsub, int* info, void* stream);
+                        double* lsub, void* ws, size_t ws_bytes, int* info, void* stream);
 int mf_btd_cholesky_f32(int64_t B, int64_t T, int d, const float* diag, const float* sub, float* ldiag,
-                        float* lsub, int* info, void* stream);
+                        float* lsub, void* ws, size_t ws_bytes, int* info, void* stream);
 
 /*
  * LowerTriangularBlockTriDiagonal.solve  (block_tri_diag.py:339-351; banded solve_triang_mat):
  * out = L^-1 rhs (transpose=0) or L^-T rhs (transpose=1).  rhs/out are [Br,T,d]; rhs series r uses the
  * factor of series r % Bl (Br a multiple of Bl: extra leading dims, state_space_model.py:307-322).
+ * Few, long chains are solved in parallel in time (the substitution is an affine recursion, composed per chunk
+ * and scanned over the chunks); scratch as for the Cholesky: mf_btd_solve_workspace_bytes (0 = serial kernel).
  */
+size_t mf_btd_solve_workspace_bytes(int64_t Bl, int64_t Br, int64_t T, int d, int elem_size);
 int mf_btd_solve_f64(int64_t Bl, int64_t Br, int64_t T, int d, const double* ldiag, const double* lsub,
-                     const double* rhs, double* out, int transpose, void* stream);
+                     const double* rhs, double* out, int transpose, void* ws, size_t ws_bytes, void* stream);
 int mf_btd_solve_f32(int64_t Bl, int64_t Br, int64_t T, int d, const float* ldiag, const float* lsub,
-                     const float* rhs, float* out, int transpose, void* stream);
+                     const float* rhs, float* out, int transpose, void* ws, size_t ws_bytes, void* stream);
 
 /*
  * BlockTriDiagonal.dense_mult  (block_tri_diag.py:175-199; banded product_band_mat).

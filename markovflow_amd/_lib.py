@@ -19,8 +19,8 @@ _i64, _int, _vp, _sz = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_s
 _SIGS = {
     "mf_kf_loglik": (_int, [_i64, _i64, _int, _int, "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", _int, "T",
                             "Tp", _vp, _sz, _vp, _i64, _vp, _vp, _vp]),
-    "mf_btd_cholesky": (_int, [_i64, _i64, _int, "Tp", "Tp", "Tp", "Tp", _vp, _vp]),
-    "mf_btd_solve": (_int, [_i64, _i64, _i64, _int, "Tp", "Tp", "Tp", "Tp", _int, _vp]),
+    "mf_btd_cholesky": (_int, [_i64, _i64, _int, "Tp", "Tp", "Tp", "Tp", _vp, _sz, _vp, _vp]),
+    "mf_btd_solve": (_int, [_i64, _i64, _i64, _int, "Tp", "Tp", "Tp", "Tp", _int, _vp, _sz, _vp]),
     "mf_btd_matvec": (_int, [_i64, _i64, _i64, _int, "Tp", "Tp", "Tp", "Tp", _int, _vp]),
     "mf_btd_logdet": (_int, [_i64, _i64, _int, "Tp", "Tp", _vp]),
     "mf_btd_logdet_quad": (_int, [_i64, _i64, _int, "Tp", "Tp", "Tp", "Tp", _vp, _sz, _vp, _vp]),
@@ -35,6 +35,8 @@ _PLAIN = {
     "mf_max_state_dim": (_int, []),
     "mf_kf_loglik_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _i64]),
     "mf_btd_logdet_quad_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
+    "mf_btd_cholesky_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
+    "mf_btd_solve_workspace_bytes": (_sz, [_i64, _i64, _i64, _int, _int]),
 }
 
 _lib = None
@@ -116,6 +118,11 @@ def check(rc: int, what: str):
 def call(base: str, dtype: torch.dtype, *args):
     fn = getattr(load(), base + suffix(dtype))
     check(fn(*args), base)
+
+
+def workspace(nbytes: int, device) -> Optional[torch.Tensor]:
+    """Caller-owned scratch for the C ABI (None when the entry point asked for none)."""
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device) if nbytes else None
 
 
 def new_info(device) -> torch.Tensor:

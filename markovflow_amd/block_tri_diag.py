@@ -180,9 +180,12 @@ class LowerTriangularBlockTriDiagonal(BlockTriDiagonal):
         diag = _flat(self._diag, 3)
         sub = None if self._sub_diag is None else _flat(self._sub_diag, 3)
         out = torch.empty_like(right_b)
+        ws_bytes = int(_lib.load().mf_btd_solve_workspace_bytes(diag.shape[0], right_b.shape[0], self.outer_dim,
+                                                                 self.inner_dim, diag.element_size()))
+        ws = _lib.workspace(ws_bytes, diag.device)
         _lib.call("mf_btd_solve", diag.dtype, diag.shape[0], right_b.shape[0], self.outer_dim, self.inner_dim,
                   _lib.ptr(diag), _lib.ptr(sub), _lib.ptr(right_b), _lib.ptr(out), int(transpose_left),
-                  _lib.stream_ptr(diag.device))
+                  _lib.ptr(ws), ws_bytes, _lib.stream_ptr(diag.device))
         return out.reshape(out_shape)
 
     def abs_log_det(self) -> torch.Tensor:
@@ -214,8 +217,12 @@ class SymmetricBlockTriDiagonal(BlockTriDiagonal):
         ldiag = torch.empty_like(diag)
         lsub = None if sub is None else torch.empty_like(sub)
         info = _lib.new_info(diag.device)
+        ws_bytes = int(_lib.load().mf_btd_cholesky_workspace_bytes(diag.shape[0], self.outer_dim, self.inner_dim,
+                                                                    diag.element_size()))
+        ws = _lib.workspace(ws_bytes, diag.device)
         _lib.call("mf_btd_cholesky", diag.dtype, diag.shape[0], self.outer_dim, self.inner_dim, _lib.ptr(diag),
-                  _lib.ptr(sub), _lib.ptr(ldiag), _lib.ptr(lsub), _lib.ptr(info), _lib.stream_ptr(diag.device))
+                  _lib.ptr(sub), _lib.ptr(ldiag), _lib.ptr(lsub), _lib.ptr(ws), ws_bytes, _lib.ptr(info),
+                  _lib.stream_ptr(diag.device))
         _lib.raise_on_info(info, "SymmetricBlockTriDiagonal.cholesky")
         return LowerTriangularBlockTriDiagonal(
             ldiag.reshape(self._diag.shape), None if lsub is None else lsub.reshape(self._sub_diag.shape)

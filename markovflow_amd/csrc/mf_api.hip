@@ -81,24 +81,24 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
     if ((B) == 0) return 0;
 
 #define MF_DEFINE(SUF, T)                                                                                              \
-    int mf_btd_cholesky_##SUF(int64_t B, int64_t Tn, int d, const T* diag, const T* sub, T* ldiag, T* lsub, int* info, \
-                              void* stream) {                                                                          \
+    int mf_btd_cholesky_##SUF(int64_t B, int64_t Tn, int d, const T* diag, const T* sub, T* ldiag, T* lsub, void* ws,  \
+                              size_t ws_bytes, int* info, void* stream) {                                              \
         MF_HEAD(T, B, Tn, d)                                                                                           \
         if (!diag) return -4;                                                                                          \
         if (!ldiag) return -6;                                                                                         \
         if (sub && !lsub) return -7;                                                                                   \
         if (Tn == 1) sub = nullptr;                                                                                    \
-        return t->btd_cholesky(B, Tn, diag, sub, ldiag, lsub, info, S(stream));                                        \
+        return t->btd_cholesky(B, Tn, diag, sub, ldiag, lsub, ws, ws_bytes, info, S(stream));                          \
     }                                                                                                                  \
     int mf_btd_solve_##SUF(int64_t Bl, int64_t Br, int64_t Tn, int d, const T* ldiag, const T* lsub, const T* rhs,     \
-                           T* out, int transpose, void* stream) {                                                      \
+                           T* out, int transpose, void* ws, size_t ws_bytes, void* stream) {                           \
         MF_HEAD(T, Br, Tn, d)                                                                                          \
         if (Bl < 1 || Br % Bl != 0) return -1;                                                                         \
         if (!ldiag) return -5;                                                                                         \
         if (!rhs) return -7;                                                                                           \
         if (!out) return -8;                                                                                           \
         if (Tn == 1) lsub = nullptr;                                                                                   \
-        return t->btd_solve(Bl, Br, Tn, ldiag, lsub, rhs, out, transpose, S(stream));                                  \
+        return t->btd_solve(Bl, Br, Tn, ldiag, lsub, rhs, out, transpose, ws, ws_bytes, S(stream));                    \
     }                                                                                                                  \
     int mf_btd_matvec_##SUF(int64_t Bl, int64_t Br, int64_t Tn, int d, const T* diag, const T* sub, const T* x,        \
                             T* out, int mode, void* stream) {                                                          \
@@ -169,6 +169,19 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
 
 MF_DEFINE(f64, double)
 MF_DEFINE(f32, float)
+
+size_t mf_btd_cholesky_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {
+    if (B < 1 || T < 1) return 0;
+    if (elem_size == 4) { const auto* t = table_for<float>(d); return t ? t->btd_cholesky_ws(B, T) : 0; }
+    const auto* t = table_for<double>(d);
+    return t ? t->btd_cholesky_ws(B, T) : 0;
+}
+size_t mf_btd_solve_workspace_bytes(int64_t Bl, int64_t Br, int64_t T, int d, int elem_size) {
+    if (Bl < 1 || Br < 1 || T < 1) return 0;
+    if (elem_size == 4) { const auto* t = table_for<float>(d); return t ? t->btd_solve_ws(Bl, Br, T) : 0; }
+    const auto* t = table_for<double>(d);
+    return t ? t->btd_solve_ws(Bl, Br, T) : 0;
+}
 
 size_t mf_btd_logdet_quad_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {
     if (elem_size == 4) { const auto* t = table_for<float>(d); return t ? t->btd_logdet_quad_ws(B, T, 0) : 0; }

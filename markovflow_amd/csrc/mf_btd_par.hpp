@@ -1,0 +1,344 @@
+// Parallel-in-time forms of SymmetricBlockTriDiagonal.cholesky and LowerTriangularBlockTriDiagonal.solve
+// (block_tri_diag.py:423-436, :339-351) for FEW, LONG chains (BASELINE config 3: B=1, T=100000, d=6).
+//
+// The API contract is the NATURAL-ORDER factor (tests/unit/test_block_tri_diag.py:104-107 of the reference), which a
+// plain odd-even cyclic reduction does not produce.  What is used instead is a multi-level partitioned
+// elimination that keeps natural-order information:
+//
+//   up-sweep    every chunk of `len` consecutive blocks eliminates its interior in natural order (carrying the
+//               fill-in towards the block on its left, exactly as the log-likelihood reduction does) and leaves
+//               its LAST block as one block of the next, `len` times shorter, level.  Contributions that come
+//               from blocks located AFTER a block in natural order (the interior of the next chunk) are kept
+//               apart from it ("future" part: Gf + GU) instead of being folded into its pivot.
+//   down-sweep  the natural-order pivot Sigma_j = L_j L_j^T of a block is the Schur complement of everything
+//               BEFORE it, and it obeys, on every level,
+//                   Sigma_j = Dv_j - F_j (Sigma_{j-1} + future_{j-1})^-1 F_j^T ,
+//               so from the pivots at the chunk boundaries (known from the coarser level) every chunk recovers the
+//               pivots of its own blocks independently; at level 0 the "future" parts vanish and the recursion
+//               is the textbook one, which emits L_k and W_k.
+//
+// Sequential depth: 2 * len * (number of levels) block steps instead of T; every level is one launch of
+// independent lanes (one lane = one chunk, register resident, mf_small.hpp).  The solve is the same idea on
+// the affine recursion z_k = M_k z_{k-1} + c_k,  M_k = -L_k^-1 W_{k-1},  c_k = L_k^-1 r_k.
+#pragma once
+#include "mf_small.hpp"
+
+namespace mf {
+
+// One level of the factorisation hierarchy, n blocks per series.
+template <typename T> struct ParLevel {
+    const T* Dv;   // [B, n, D, D]  pivot part that stems from the block itself and from blocks before it
+    const T* Gf;   // [B, n, D, D]  future part inherited from the levels below (null on level 0)
+    const T* GU;   // [B, n, D, D]  GU[j]: what eliminating the interior of (lower-level) chunk j adds to block j-1
+    const T* F;    // coupling of block j with block j-1 (block index j + f_off, f_stride blocks per series)
+    long n, f_stride, f_off;
+};
+
+template <typename T, int D> MF_DEV void load_sym_lower(const T* __restrict__ p, T (&m)[D][D]) { load_lower<T, D>(p, m); }
+
+// future part of block j on a level: Gf[j] + GU[j+1]   (lower triangle), returns false if identically zero
+template <typename T, int D> MF_DEV bool par_future(const ParLevel<T>& lv, long s, long j, T (&fut)[D][D]) {
+    bool any = false;
+    MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int jj = 0; jj <= i; ++jj) fut[i][jj] = T(0);
+    if (lv.Gf) {
+        T g[D][D];
+        load_lower<T, D>(lv.Gf + (s * lv.n + j) * D * D, g);
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int jj = 0; jj <= i; ++jj) fut[i][jj] += g[i][jj];
+        any = true;
+    }
+    if (lv.GU && j + 1 < lv.n) {
+        T g[D][D];
+        load_lower<T, D>(lv.GU + (s * lv.n + j + 1) * D * D, g);
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int jj = 0; jj <= i; ++jj) fut[i][jj] += g[i][jj];
+        any = true;
+    }
+    return any;
+}
+
+// ---- Cholesky: up-sweep -----------------------------------------------------------------------------------------
+// chunk c of series s covers blocks [c len, min(n, (c+1) len)) of `in` and becomes block c of the next level:
+//   oDv = pivot of its last block after the chunk's interior is gone (future part excluded), oGf = that block's
+//   future part, oGU = what the interior adds to the block left of the chunk, oF = coupling last block <-> that block.
+template <typename T, int D>
+__global__ void __launch_bounds__(64) par_chol_up_kernel(ParLevel<T> in, long B, long len, long P, T* __restrict__ oDv,
+                                                         T* __restrict__ oGf, T* __restrict__ oGU, T* __restrict__ oF,
+                                                         int* info) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= B * P) return;
+    const long s = id / P, c = id % P;
+    const long k0 = c * len;
+    long k1 = k0 + len;
+    if (k1 > in.n) k1 = in.n;
+    T Phi[D][D], Li[D], X[D][D], GU[D][D];
+    MF_UNROLL for (int i = 0; i < D; ++i) {
+        Li[i] = T(0);
+        MF_UNROLL for (int j = 0; j < D; ++j) { Phi[i][j] = T(0); X[i][j] = T(0); GU[i][j] = T(0); }
+    }
+    LogAcc<T> la;
+    la.init();
+    bool bad = false;
+    for (long k = k0; k < k1; ++k) {
+        const bool last = (k + 1 == k1);
+        T Dn[D][D], fut[D][D];
+        load_lower<T, D>(in.Dv + (s * in.n + k) * D * D, Dn);
+        par_future<T, D>(in, s, k, fut);
+        if (last) {
+            // the future part of the chunk's last block travels separately
+            store_sym<T, D>(oGf + id * D * D, fut);
+        } else {
+            MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Dn[i][j] += fut[i][j];
+        }
+        if (k == k0) {
+            if (k > 0) load_mat<T, D, D>(in.F + (s * in.f_stride + k + in.f_off) * D * D, X);
+            MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Phi[i][j] = Dn[i][j];
+            continue;
+        }
+        // eliminate block k-1 (pivot complete in Phi): factor, spike towards the block left of the chunk
+        chol_lower<T, D>(Phi, Li, la, bad);
+        la.init();
+        if (k0 > 0) {
+            trsm_left_lower<T, D, D>(Phi, Li, X);            // V = L^-1 X
+            syrk_tn_lower<T, D, D>(X, GU, T(-1));            // GU -= V^T V
+        }
+        T W[D][D];
+        load_mat<T, D, D>(in.F + (s * in.f_stride + k + in.f_off) * D * D, W);
+        trsm_right_lower_t<T, D, D>(Phi, Li, W);             // W = F_k L^-T
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Phi[i][j] = Dn[i][j];
+        syrk_nt_lower<T, D, D>(W, Phi, T(-1));               // next pivot: Dn - W W^T
+        if (k0 > 0) neg_mul_inplace<T, D>(W, X);             // next coupling to the left block: -W V
+    }
+    store_sym<T, D>(oDv + id * D * D, Phi);
+    store_sym<T, D>(oGU + id * D * D, GU);
+    store_mat<T, D, D>(oF + id * D * D, X);
+    if (bad && info) atomicMax(info, 1);
+}
+
+// ---- Cholesky: down-sweep on a level >= 1 (also the serial walk of the coarsest level: len >= n, up = null) --------
+// writes the natural-order pivots Pn[j] of every block of `lv`; `up` holds the pivots of the next coarser level,
+// whose block c is the last block of chunk c here.
+template <typename T, int D>
+__global__ void __launch_bounds__(64) par_chol_down_kernel(ParLevel<T> lv, long B, long len, long P,
+                                                           const T* __restrict__ up, T* __restrict__ Pn, int* info) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= B * P) return;
+    const long s = id / P, c = id % P;
+    const long k0 = c * len;
+    long k1 = k0 + len;
+    if (k1 > lv.n) k1 = lv.n;
+    T Sig[D][D], Li[D];
+    LogAcc<T> la;
+    la.init();
+    bool bad = false;
+    if (c > 0) load_lower<T, D>(up + (s * P + c - 1) * D * D, Sig);
+    for (long k = k0; k < k1; ++k) {
+        T Dn[D][D];
+        load_lower<T, D>(lv.Dv + (s * lv.n + k) * D * D, Dn);
+        if (k > 0) {
+            // pivot of block k-1 at the moment block k is reached: natural pivot + its future part
+            T fut[D][D], W[D][D];
+            par_future<T, D>(lv, s, k - 1, fut);
+            MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Sig[i][j] += fut[i][j];
+            chol_lower<T, D>(Sig, Li, la, bad);
+            la.init();
+            load_mat<T, D, D>(lv.F + (s * lv.f_stride + k + lv.f_off) * D * D, W);
+            trsm_right_lower_t<T, D, D>(Sig, Li, W);
+            syrk_nt_lower<T, D, D>(W, Dn, T(-1));
+        }
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Sig[i][j] = Dn[i][j];
+        store_sym<T, D>(Pn + (s * lv.n + k) * D * D, Sig);
+    }
+    if (bad && info) atomicMax(info, 1);
+}
+
+// ---- Cholesky: level 0, emits the factor ----------------------------------------------------------------------
+// chunk c restarts the natural-order recursion from the pivot of block c len - 1 (`up`, block c-1 of level 1).
+template <typename T, int D>
+__global__ void __launch_bounds__(64) par_chol_emit_kernel(long B, long n, long len, long P, const T* __restrict__ diag,
+                                                           const T* __restrict__ sub, const T* __restrict__ up,
+                                                           T* __restrict__ ldiag, T* __restrict__ lsub, int* info) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= B * P) return;
+    const long s = id / P, c = id % P;
+    const long k0 = c * len;
+    long k1 = k0 + len;
+    if (k1 > n) k1 = n;
+    T L[D][D], Li[D];
+    LogAcc<T> la;
+    la.init();
+    bool bad = false;
+    if (c > 0) {
+        load_lower<T, D>(up + (s * P + c - 1) * D * D, L);
+        chol_lower<T, D>(L, Li, la, bad);
+        la.init();
+    }
+    for (long k = k0; k < k1; ++k) {
+        T S[D][D];
+        load_lower<T, D>(diag + (s * n + k) * D * D, S);
+        if (k > 0) {
+            T W[D][D];
+            load_mat<T, D, D>(sub + (s * (n - 1) + k - 1) * D * D, W);
+            trsm_right_lower_t<T, D, D>(L, Li, W);
+            store_mat<T, D, D>(lsub + (s * (n - 1) + k - 1) * D * D, W);
+            syrk_nt_lower<T, D, D>(W, S, T(-1));
+        }
+        chol_lower<T, D>(S, Li, la, bad);
+        la.init();
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) L[i][j] = S[i][j];
+        store_lower<T, D>(ldiag + (s * n + k) * D * D, L);
+    }
+    if (bad && info) atomicMax(info, 1);
+}
+
+// ---- Solve: affine recursion z_p = M_p z_{p-1} + c_p over positions p (p = k, or n-1-k for the transposed solve) -----
+// level 0 -> level 1: composite map of every chunk from the factor and the right-hand side
+template <typename T, int D>
+__global__ void __launch_bounds__(64) par_solve_up0_kernel(long Bl, long Br, long n, long len, long P,
+                                                           const T* __restrict__ ldiag, const T* __restrict__ lsub,
+                                                           const T* __restrict__ rhs, int transpose, T* __restrict__ oM,
+                                                           T* __restrict__ oc) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= Br * P) return;
+    const long r = id / P, c = id % P, s = r % Bl;
+    const long p0 = c * len;
+    long p1 = p0 + len;
+    if (p1 > n) p1 = n;
+    T Pm[D][D], q[D];
+    MF_UNROLL for (int i = 0; i < D; ++i) { q[i] = T(0); MF_UNROLL for (int j = 0; j < D; ++j) Pm[i][j] = T(0); }
+    for (long p = p0; p < p1; ++p) {
+        const long k = transpose ? n - 1 - p : p;
+        T L[D][D], Li[D], x[D];
+        load_lower<T, D>(ldiag + (s * n + k) * D * D, L);
+        MF_UNROLL for (int i = 0; i < D; ++i) Li[i] = t_rcp<T>(L[i][i]);
+        load_vec<T, D>(rhs + (r * n + k) * D, x);
+        if (lsub && p > 0) {
+            T W[D][D], wq[D], WP[D][D];
+            if (!transpose) {
+                load_mat<T, D, D>(lsub + (s * (n - 1) + k - 1) * D * D, W);
+            } else {
+                T Wt[D][D];
+                load_mat<T, D, D>(lsub + (s * (n - 1) + k) * D * D, Wt);
+                MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) W[i][j] = Wt[j][i];
+            }
+            gemv_n<T, D, D>(W, q, wq);
+            MF_UNROLL for (int i = 0; i < D; ++i) x[i] -= wq[i];
+            if (p == p0) {
+                MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) WP[i][j] = -W[i][j];
+            } else {
+                MF_UNROLL for (int i = 0; i < D; ++i)
+                    MF_UNROLL for (int j = 0; j < D; ++j) {
+                        T a = T(0);
+                        MF_UNROLL for (int l = 0; l < D; ++l) a += W[i][l] * Pm[l][j];
+                        WP[i][j] = -a;
+                    }
+            }
+            if (!transpose) trsm_left_lower<T, D, D>(L, Li, WP); else trsm_left_lower_t<T, D, D>(L, Li, WP);
+            MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Pm[i][j] = WP[i][j];
+        }
+        if (!transpose) trsv_lower<T, D>(L, Li, x); else trsv_lower_t<T, D>(L, Li, x);
+        MF_UNROLL for (int i = 0; i < D; ++i) q[i] = x[i];
+    }
+    store_mat<T, D, D>(oM + id * D * D, Pm);
+    store_vec<T, D>(oc + id * D, q);
+}
+
+// level l -> level l+1 (l >= 1): compose explicit maps
+template <typename T, int D>
+__global__ void __launch_bounds__(64) par_affine_up_kernel(long Br, long n, long len, long P, const T* __restrict__ M,
+                                                           const T* __restrict__ cv, T* __restrict__ oM,
+                                                           T* __restrict__ oc) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= Br * P) return;
+    const long r = id / P, c = id % P;
+    const long p0 = c * len;
+    long p1 = p0 + len;
+    if (p1 > n) p1 = n;
+    T Pm[D][D], q[D];
+    load_mat<T, D, D>(M + (r * n + p0) * D * D, Pm);
+    load_vec<T, D>(cv + (r * n + p0) * D, q);
+    for (long p = p0 + 1; p < p1; ++p) {
+        T Mp[D][D], cp[D], nq[D], nP[D][D];
+        load_mat<T, D, D>(M + (r * n + p) * D * D, Mp);
+        load_vec<T, D>(cv + (r * n + p) * D, cp);
+        gemv_n<T, D, D>(Mp, q, nq);
+        MF_UNROLL for (int i = 0; i < D; ++i) q[i] = nq[i] + cp[i];
+        MF_UNROLL for (int i = 0; i < D; ++i)
+            MF_UNROLL for (int j = 0; j < D; ++j) {
+                T a = T(0);
+                MF_UNROLL for (int l = 0; l < D; ++l) a += Mp[i][l] * Pm[l][j];
+                nP[i][j] = a;
+            }
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Pm[i][j] = nP[i][j];
+    }
+    store_mat<T, D, D>(oM + id * D * D, Pm);
+    store_vec<T, D>(oc + id * D, q);
+}
+
+// down-sweep on a level >= 1 (and, with len >= n and up = null, the serial walk of the coarsest level):
+// Z[p] for every position of the level; `up` = Z of the next coarser level.
+template <typename T, int D>
+__global__ void __launch_bounds__(64) par_affine_down_kernel(long Br, long n, long len, long P, const T* __restrict__ M,
+                                                             const T* __restrict__ cv, const T* __restrict__ up,
+                                                             T* __restrict__ Z) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= Br * P) return;
+    const long r = id / P, c = id % P;
+    const long p0 = c * len;
+    long p1 = p0 + len;
+    if (p1 > n) p1 = n;
+    T z[D];
+    MF_UNROLL for (int i = 0; i < D; ++i) z[i] = T(0);
+    if (c > 0) load_vec<T, D>(up + (r * P + c - 1) * D, z);
+    for (long p = p0; p < p1; ++p) {
+        T cp[D];
+        load_vec<T, D>(cv + (r * n + p) * D, cp);
+        if (p > 0) {
+            T Mp[D][D], nz[D];
+            load_mat<T, D, D>(M + (r * n + p) * D * D, Mp);
+            gemv_n<T, D, D>(Mp, z, nz);
+            MF_UNROLL for (int i = 0; i < D; ++i) z[i] = nz[i] + cp[i];
+        } else {
+            MF_UNROLL for (int i = 0; i < D; ++i) z[i] = cp[i];
+        }
+        store_vec<T, D>(Z + (r * n + p) * D, z);
+    }
+}
+
+// level 0: every chunk redoes its substitution from the known incoming vector and writes the solution
+template <typename T, int D>
+__global__ void __launch_bounds__(64) par_solve_emit_kernel(long Bl, long Br, long n, long len, long P,
+                                                            const T* __restrict__ ldiag, const T* __restrict__ lsub,
+                                                            const T* __restrict__ rhs, const T* __restrict__ up,
+                                                            int transpose, T* __restrict__ out) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= Br * P) return;
+    const long r = id / P, c = id % P, s = r % Bl;
+    const long p0 = c * len;
+    long p1 = p0 + len;
+    if (p1 > n) p1 = n;
+    T z[D];
+    MF_UNROLL for (int i = 0; i < D; ++i) z[i] = T(0);
+    if (c > 0) load_vec<T, D>(up + (r * P + c - 1) * D, z);
+    for (long p = p0; p < p1; ++p) {
+        const long k = transpose ? n - 1 - p : p;
+        T L[D][D], Li[D], x[D];
+        load_lower<T, D>(ldiag + (s * n + k) * D * D, L);
+        MF_UNROLL for (int i = 0; i < D; ++i) Li[i] = t_rcp<T>(L[i][i]);
+        load_vec<T, D>(rhs + (r * n + k) * D, x);
+        if (lsub && p > 0) {
+            T W[D][D], wz[D];
+            if (!transpose) {
+                load_mat<T, D, D>(lsub + (s * (n - 1) + k - 1) * D * D, W);
+                gemv_n<T, D, D>(W, z, wz);
+            } else {
+                load_mat<T, D, D>(lsub + (s * (n - 1) + k) * D * D, W);
+                gemv_t<T, D, D>(W, z, wz);
+            }
+            MF_UNROLL for (int i = 0; i < D; ++i) x[i] -= wz[i];
+        }
+        if (!transpose) trsv_lower<T, D>(L, Li, x); else trsv_lower_t<T, D>(L, Li, x);
+        MF_UNROLL for (int i = 0; i < D; ++i) z[i] = x[i];
+        store_vec<T, D>(out + (r * n + k) * D, z);
+    }
+}
+
+}  // namespace mf

@@ -5,6 +5,7 @@
 #endif
 #include "mf_kernels.hpp"
 #include "mf_kf_lds.hpp"
+#include "mf_btd_par.hpp"
 #include "mf_launch.hpp"
 
 #include <cstdlib>
@@ -181,18 +182,139 @@ int btd_logdet_quad(long B, long n, const T* diag, const T* sub, const T* rhs, T
     return reduce_levels<T>(in, B, static_cast<char*>(ws), T(0), out, info, st);
 }
 
-template <typename T>
-int btd_cholesky(long B, long n, const T* diag, const T* sub, T* ldiag, T* lsub, int* info, hipStream_t st) {
-    hipLaunchKernelGGL((btd_cholesky_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, diag, sub, ldiag,
-                       lsub, info);
-    return hipGetLastError() == hipSuccess ? 0 : -1000;
+// ---- parallel-in-time cholesky / solve (mf_btd_par.hpp): chosen when there are too few series to fill the chip ----
+constexpr long PAR_MIN_BLOCKS = 64;      // never partition chains shorter than this
+constexpr long PAR_MAX_SERIES = 4096;    // with this many series one lane per series already fills the chip
+
+// level-0 chunk length (0 = use the serial one-lane-per-series kernel)
+inline long par_len0(long B, long n) {
+    static const long force = [] { const char* e = std::getenv("MF_BTD_PAR_LEN"); return e ? std::atol(e) : -1L; }();
+    if (force >= 0) return (force > 0 && n >= 2 * force) ? force : 0;
+    if (B >= PAR_MAX_SERIES || n < PAR_MIN_BLOCKS) return 0;
+    long len = cdiv(B * n, 65536);           // aim at one wavefront per SIMD ...
+    if (len < RED_CHUNK) len = RED_CHUNK;     // ... but keep the reduced system at most 1/8 of the input
+    return n >= 2 * len ? len : 0;
+}
+
+struct ParPlan {
+    int levels;          // number of reduced levels (>= 1)
+    long n[24];          // n[0] = T, n[l] = blocks per series on level l
+    long len[24];        // chunk length used on level l to form level l+1
+};
+inline ParPlan par_plan(long n0, long len0) {
+    ParPlan pl;
+    pl.n[0] = n0;
+    pl.len[0] = len0;
+    int l = 0;
+    do {
+        pl.n[l + 1] = cdiv(pl.n[l], pl.len[l]);
+        ++l;
+        pl.len[l] = RED_CHUNK;
+    } while (pl.n[l] > RED_FINAL && l < 22);
+    pl.levels = l;
+    return pl;
+}
+
+template <typename T> size_t btd_cholesky_ws(long B, long n) {
+    const long len0 = par_len0(B, n);
+    if (len0 == 0) return 0;
+    const ParPlan pl = par_plan(n, len0);
+    size_t total = 0;
+    for (int l = 1; l <= pl.levels; ++l) total += 5 * align_up(size_t(B) * pl.n[l] * D * D * sizeof(T));
+    return total;
 }
 
 template <typename T>
-int btd_solve(long Bl, long Br, long n, const T* ldiag, const T* lsub, const T* rhs, T* out, int transpose,
-              hipStream_t st) {
-    hipLaunchKernelGGL((btd_solve_kernel<T, D>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Bl, Br, n, ldiag, lsub,
-                       rhs, out, transpose);
+int btd_cholesky(long B, long n, const T* diag, const T* sub, T* ldiag, T* lsub, void* ws, size_t ws_bytes, int* info,
+                 hipStream_t st) {
+    const long len0 = sub ? par_len0(B, n) : 0;
+    if (len0 == 0 || ws == nullptr || ws_bytes < btd_cholesky_ws<T>(B, n)) {
+        hipLaunchKernelGGL((btd_cholesky_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, diag, sub,
+                           ldiag, lsub, info);
+        return hipGetLastError() == hipSuccess ? 0 : -1000;
+    }
+    const ParPlan pl = par_plan(n, len0);
+    struct Arr { T *Dv, *Gf, *GU, *F, *Pn; } arr[24];
+    char* p = static_cast<char*>(ws);
+    for (int l = 1; l <= pl.levels; ++l) {
+        const size_t sz = align_up(size_t(B) * pl.n[l] * D * D * sizeof(T));
+        T** f[5] = {&arr[l].Dv, &arr[l].Gf, &arr[l].GU, &arr[l].F, &arr[l].Pn};
+        for (auto* q : f) { *q = reinterpret_cast<T*>(p); p += sz; }
+    }
+    auto level = [&](int l) {
+        if (l == 0) return ParLevel<T>{diag, nullptr, nullptr, sub, n, n - 1, -1};
+        return ParLevel<T>{arr[l].Dv, arr[l].Gf, arr[l].GU, arr[l].F, pl.n[l], pl.n[l], 0};
+    };
+    for (int l = 0; l < pl.levels; ++l) {
+        const long P = pl.n[l + 1];
+        hipLaunchKernelGGL((par_chol_up_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, level(l), B,
+                           pl.len[l], P, arr[l + 1].Dv, arr[l + 1].Gf, arr[l + 1].GU, arr[l + 1].F, info);
+    }
+    {   // coarsest level: one lane per series walks it
+        const int l = pl.levels;
+        hipLaunchKernelGGL((par_chol_down_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, level(l), B,
+                           pl.n[l], 1L, static_cast<const T*>(nullptr), arr[l].Pn, info);
+    }
+    for (int l = pl.levels - 1; l >= 1; --l) {
+        const long P = pl.n[l + 1];
+        hipLaunchKernelGGL((par_chol_down_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, level(l), B,
+                           pl.len[l], P, static_cast<const T*>(arr[l + 1].Pn), arr[l].Pn, info);
+    }
+    hipLaunchKernelGGL((par_chol_emit_kernel<T, D>), dim3((unsigned)cdiv(B * pl.n[1], 64)), dim3(64), 0, st, B, n, len0,
+                       pl.n[1], diag, sub, static_cast<const T*>(arr[1].Pn), ldiag, lsub, info);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+template <typename T> size_t btd_solve_ws(long Bl, long Br, long n) {
+    (void)Bl;
+    const long len0 = par_len0(Br, n);
+    if (len0 == 0) return 0;
+    const ParPlan pl = par_plan(n, len0);
+    size_t total = 0;
+    for (int l = 1; l <= pl.levels; ++l)
+        total += align_up(size_t(Br) * pl.n[l] * D * D * sizeof(T)) + 2 * align_up(size_t(Br) * pl.n[l] * D * sizeof(T));
+    return total;
+}
+
+template <typename T>
+int btd_solve(long Bl, long Br, long n, const T* ldiag, const T* lsub, const T* rhs, T* out, int transpose, void* ws,
+              size_t ws_bytes, hipStream_t st) {
+    const long len0 = lsub ? par_len0(Br, n) : 0;
+    if (len0 == 0 || ws == nullptr || ws_bytes < btd_solve_ws<T>(Bl, Br, n)) {
+        hipLaunchKernelGGL((btd_solve_kernel<T, D>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Bl, Br, n, ldiag,
+                           lsub, rhs, out, transpose);
+        return hipGetLastError() == hipSuccess ? 0 : -1000;
+    }
+    const ParPlan pl = par_plan(n, len0);
+    struct Arr { T *M, *c, *Z; } arr[24];
+    char* p = static_cast<char*>(ws);
+    for (int l = 1; l <= pl.levels; ++l) {
+        arr[l].M = reinterpret_cast<T*>(p); p += align_up(size_t(Br) * pl.n[l] * D * D * sizeof(T));
+        arr[l].c = reinterpret_cast<T*>(p); p += align_up(size_t(Br) * pl.n[l] * D * sizeof(T));
+        arr[l].Z = reinterpret_cast<T*>(p); p += align_up(size_t(Br) * pl.n[l] * D * sizeof(T));
+    }
+    hipLaunchKernelGGL((par_solve_up0_kernel<T, D>), dim3((unsigned)cdiv(Br * pl.n[1], 64)), dim3(64), 0, st, Bl, Br, n,
+                       len0, pl.n[1], ldiag, lsub, rhs, transpose, arr[1].M, arr[1].c);
+    for (int l = 1; l < pl.levels; ++l) {
+        const long P = pl.n[l + 1];
+        hipLaunchKernelGGL((par_affine_up_kernel<T, D>), dim3((unsigned)cdiv(Br * P, 64)), dim3(64), 0, st, Br, pl.n[l],
+                           pl.len[l], P, static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c), arr[l + 1].M,
+                           arr[l + 1].c);
+    }
+    {
+        const int l = pl.levels;
+        hipLaunchKernelGGL((par_affine_down_kernel<T, D>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Br, pl.n[l],
+                           pl.n[l], 1L, static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c),
+                           static_cast<const T*>(nullptr), arr[l].Z);
+    }
+    for (int l = pl.levels - 1; l >= 1; --l) {
+        const long P = pl.n[l + 1];
+        hipLaunchKernelGGL((par_affine_down_kernel<T, D>), dim3((unsigned)cdiv(Br * P, 64)), dim3(64), 0, st, Br, pl.n[l],
+                           pl.len[l], P, static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c),
+                           static_cast<const T*>(arr[l + 1].Z), arr[l].Z);
+    }
+    hipLaunchKernelGGL((par_solve_emit_kernel<T, D>), dim3((unsigned)cdiv(Br * pl.n[1], 64)), dim3(64), 0, st, Bl, Br, n,
+                       len0, pl.n[1], ldiag, lsub, rhs, static_cast<const T*>(arr[1].Z), transpose, out);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
@@ -241,8 +363,8 @@ template <typename T> int ssm_means(long Bl, long Br, long Tn, const T* A, const
 
 template <typename T> const OpsTable<T>* table() {
     static const OpsTable<T> t = {
-        &kf_loglik_ws<T>, &kf_loglik<T>, &btd_logdet_quad_ws<T>, &btd_logdet_quad<T>, &btd_cholesky<T>,
-        &btd_solve<T>,    &btd_matvec<T>, &btd_logdet<T>,        &btd_diag_of_inverse<T>, &btd_udl<T>,
+        &kf_loglik_ws<T>, &kf_loglik<T>, &btd_logdet_quad_ws<T>, &btd_logdet_quad<T>, &btd_cholesky_ws<T>, &btd_cholesky<T>,
+        &btd_solve_ws<T>, &btd_solve<T>,    &btd_matvec<T>, &btd_logdet<T>,        &btd_diag_of_inverse<T>, &btd_udl<T>,
         &ssm_precision<T>, &ssm_means<T>,
     };
     return &t;

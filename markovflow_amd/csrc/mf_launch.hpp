@@ -15,9 +15,12 @@ template <typename T> struct OpsTable {
     size_t (*btd_logdet_quad_ws)(long B, long n, long chunks);
     int (*btd_logdet_quad)(long B, long n, const T* diag, const T* sub, const T* rhs, T* out, void* ws,
                            size_t ws_bytes, int* info, long chunks, hipStream_t st);
-    int (*btd_cholesky)(long B, long n, const T* diag, const T* sub, T* ldiag, T* lsub, int* info, hipStream_t st);
+    size_t (*btd_cholesky_ws)(long B, long n);
+    int (*btd_cholesky)(long B, long n, const T* diag, const T* sub, T* ldiag, T* lsub, void* ws, size_t ws_bytes,
+                        int* info, hipStream_t st);
+    size_t (*btd_solve_ws)(long Bl, long Br, long n);
     int (*btd_solve)(long Bl, long Br, long n, const T* ldiag, const T* lsub, const T* rhs, T* out, int transpose,
-                     hipStream_t st);
+                     void* ws, size_t ws_bytes, hipStream_t st);
     int (*btd_matvec)(long Bl, long Br, long n, const T* diag, const T* sub, const T* x, T* out, int mode,
                       hipStream_t st);
     int (*btd_logdet)(long B, long n, const T* ldiag, T* out, hipStream_t st);

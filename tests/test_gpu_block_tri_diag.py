@@ -166,8 +166,8 @@ def test_non_positive_definite_sets_info(rng):
     dg = tt(diag)
     ld = torch.empty_like(dg)
     info = _lib.new_info(torch.device(DEV))
-    _lib.call("mf_btd_cholesky", torch.float64, 2, 4, 3, _lib.ptr(dg), None, _lib.ptr(ld), None, _lib.ptr(info),
-              _lib.stream_ptr(torch.device(DEV)))
+    _lib.call("mf_btd_cholesky", torch.float64, 2, 4, 3, _lib.ptr(dg), None, _lib.ptr(ld), None, None, 0,
+              _lib.ptr(info), _lib.stream_ptr(torch.device(DEV)))
     assert int(info.item()) == 1
 
 

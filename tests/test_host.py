@@ -24,14 +24,14 @@ def test_library_exports_every_declared_symbol():
 def test_argument_errors_without_touching_the_gpu():
     lib = _lib.load()
     # invalid sizes / NULL pointers are rejected before any launch
-    assert lib.mf_btd_cholesky_f64(1, 0, 3, None, None, None, None, None, None) == -2
-    assert lib.mf_btd_cholesky_f64(1, 4, 0, None, None, None, None, None, None) == -3
-    assert lib.mf_btd_cholesky_f64(1, 4, 12, None, None, None, None, None, None) == -100
-    assert lib.mf_btd_cholesky_f64(1, 4, 3, None, None, None, None, None, None) == -4
-    assert lib.mf_btd_solve_f32(2, 3, 4, 3, None, None, None, None, 0, None) == -1
+    assert lib.mf_btd_cholesky_f64(1, 0, 3, None, None, None, None, None, 0, None, None) == -2
+    assert lib.mf_btd_cholesky_f64(1, 4, 0, None, None, None, None, None, 0, None, None) == -3
+    assert lib.mf_btd_cholesky_f64(1, 4, 12, None, None, None, None, None, 0, None, None) == -100
+    assert lib.mf_btd_cholesky_f64(1, 4, 3, None, None, None, None, None, 0, None, None) == -4
+    assert lib.mf_btd_solve_f32(2, 3, 4, 3, None, None, None, None, 0, None, 0, None) == -1
     assert lib.mf_kf_loglik_workspace_bytes(1024, 10000, 6, 8, 0) > 0
     assert lib.mf_kf_loglik_workspace_bytes(1024, 10000, 12, 8, 0) == 0
-    assert lib.mf_btd_cholesky_f64(0, 4, 3, None, None, None, None, None, None) == 0   # empty batch is a no-op
+    assert lib.mf_btd_cholesky_f64(0, 4, 3, None, None, None, None, None, 0, None, None) == 0   # empty batch is a no-op
 
 
 def test_cpu_tensors_fail_loudly():
