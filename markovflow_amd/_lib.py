@@ -33,6 +33,7 @@ _SIGS = {
 _PLAIN = {
     "mf_version": (_int, []),
     "mf_max_state_dim": (_int, []),
+    "mf_max_state_dim_f32_loglik": (_int, []),
     "mf_kf_loglik_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _i64]),
     "mf_btd_logdet_quad_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
     "mf_btd_cholesky_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
@@ -108,7 +109,8 @@ def check(rc: int, what: str):
         return
     if rc == -100:
         raise NotImplementedError(
-            f"{what}: state dimension not instantiated in this build (supported: 1..{load().mf_max_state_dim()})"
+            f"{what}: state dimension not instantiated in this build (supported: 1..{load().mf_max_state_dim()}; "
+            f"float32 log_likelihood up to {load().mf_max_state_dim_f32_loglik()})"
         )
     if rc == -1000:
         raise MarkovflowAmdError(f"{what}: kernel launch failed")

@@ -33,7 +33,15 @@ template <typename T> struct OpsTable {
     int (*ssm_means)(long Bl, long Br, long Tn, const T* A, const T* offs, T* out, hipStream_t st);
 };
 
-constexpr int MF_MAX_D = 9;   // largest state dimension with a register-resident instantiation
+constexpr int MF_MAX_D = 9;        // largest state dimension with a register-resident instantiation
+constexpr int MF_MAX_D_BIG = 64;   // largest state dimension of the LDS-tiled MFMA path (fp32, log-likelihood only)
+
+// mf_big_inst.hip
+size_t big_kf_loglik_ws(long B, long Tn, int d, long chunks);
+int big_kf_loglik_f32(long B, long Tn, int d, int m, const float* mu0, const float* cholP0, const float* A, const float* b,
+                      const float* cholQ, const float* H, const float* y, const float* Rinv, int rinv_per_step,
+                      float add_const, float* out, void* ws, size_t ws_bytes, int* info, long chunks, hipEvent_t ev0,
+                      hipEvent_t ev1, hipStream_t st);
 
 #define MF_DECLARE_TABLES(D)                          \
     const OpsTable<float>* ops_f32_d##D();            \

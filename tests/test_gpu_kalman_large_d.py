@@ -1,0 +1,89 @@
+"""
+GPU parity tests of the large-state-dimension log-likelihood (csrc/mf_big.hpp: one workgroup per (series, chunk),
+LDS-resident d x d tiles, f32 MFMA) - the path BASELINE config 5 (state_dim = 64, fp32) takes.  Same contract as the
+small-d tests: KalmanFilter.log_likelihood of /root/reference/markovflow/kalman_filter.py:184-255, compared with the
+fp64 numpy oracle on identical (fp32-rounded) inputs.  Tolerance: fp32 arithmetic, rtol 3e-4 on the scalar.
+"""
+import numpy as np
+import pytest
+import torch
+
+import markovflow_amd as mfa
+from markovflow_amd import _lib
+from oracle import numpy_oracle as O
+from test_gpu_kalman import DEV, build_kf, loglik_with_chunks, nn, random_ssm, tt
+
+pytestmark = pytest.mark.gpu
+F32 = torch.float32
+RTOL = 3e-4
+
+
+def rounded(kw):
+    """The values the fp32 kernel actually sees."""
+    return {k: v.astype(np.float32).astype(np.float64) for k, v in kw.items()}
+
+
+@pytest.mark.parametrize("d,m,t,batch", [(10, 1, 7, (2,)), (16, 2, 12, (3,)), (17, 1, 9, ()), (32, 4, 20, (2,)),
+                                         (40, 3, 6, (1,)), (48, 1, 33, (2,)), (64, 1, 2, (2,)), (64, 2, 3, (1,)),
+                                         (64, 32, 24, (2,)), (64, 5, 40, (3,))])
+def test_large_d_log_likelihood_vs_oracle(rng, d, m, t, batch):
+    kw = rounded(random_ssm(rng, batch, t, d, m, well=True))
+    cov = 0.5 * np.eye(m) + 0.1 * np.ones((m, m))
+    chol_r = np.linalg.cholesky(cov).astype(np.float32).astype(np.float64)
+    kf = build_kf(kw, chol_r, dtype=F32)
+    ref = O.kf_log_likelihood(**kw, r_inv=np.linalg.inv(chol_r @ chol_r.T))
+    np.testing.assert_allclose(float(kf.log_likelihood().cpu()), ref, rtol=RTOL)
+
+
+@pytest.mark.parametrize("chunks", [1, 2, 3, 5, 16, 24, 70])
+def test_large_d_time_partition_invariance(rng, chunks):
+    """Any partition of the time axis (including >1 reduction level: 70 chunks -> 9 -> 2) gives the same scalar."""
+    d, m, t = 24, 2, 281
+    kw = rounded(random_ssm(rng, (2,), t, d, m, well=True))
+    r_inv = np.array([[2.0, 0.3], [0.3, 1.5]])
+    ref = O.kf_log_likelihood(**kw, r_inv=r_inv, per_series=True)
+    cst = -0.5 * np.log(2 * np.pi) * m * t + 0.5 * t * np.linalg.slogdet(r_inv)[1]
+    got = loglik_with_chunks(kw, r_inv, chunks, dtype=F32)
+    np.testing.assert_allclose(got + cst, ref, rtol=RTOL)
+
+
+def test_large_d_per_step_precisions(rng):
+    """KalmanFilterWithSites (per-step R^-1, m = 1) through the large-d kernel (kalman_filter.py:437-497)."""
+    d, t = 20, 30
+    kw = rounded(random_ssm(rng, (), t, d, 1, well=True))
+    prec = (0.5 + rng.random(size=(t, 1, 1))).astype(np.float32).astype(np.float64)
+    means = kw["y"]
+    ssm = mfa.StateSpaceModel(*(tt(kw[k], F32) for k in ("mu0", "chol_p0", "a_s", "b_s", "chol_q")))
+    sites = mfa.UnivariateGaussianSitesNat(nat1=tt(means * prec[..., 0], F32), nat2=tt(-0.5 * prec, F32))
+    kf = mfa.KalmanFilterWithSites(ssm, mfa.EmissionModel(tt(kw["h"], F32)), sites)
+    ref = O.kf_log_likelihood(**kw, r_inv=prec, log_det_obs_precision=np.sum(np.log(prec)))
+    np.testing.assert_allclose(float(kf.log_likelihood().cpu()), ref, rtol=RTOL)
+
+
+def test_config5_shape_state_dim_64(rng):
+    """BASELINE config 5 shape (d = 64, fp32, m = 32 spatial outputs), time axis cut to what the oracle does in seconds,
+    plus the size-independent property at the full T = 2048: the scalar does not depend on the time partition."""
+    d, m = 64, 32
+    kw = rounded(random_ssm(rng, (1,), 48, d, m, well=True))
+    chol_r = np.sqrt(0.1) * np.eye(m)
+    chol_r = chol_r.astype(np.float32).astype(np.float64)
+    kf = build_kf(kw, chol_r, dtype=F32)
+    ref = O.kf_log_likelihood(**kw, r_inv=np.linalg.inv(chol_r @ chol_r.T))
+    np.testing.assert_allclose(float(kf.log_likelihood().cpu()), ref, rtol=RTOL)
+    big = rounded(random_ssm(rng, (1,), 2048, d, 4, well=True))
+    r_inv = 2.0 * np.eye(4)
+    a = loglik_with_chunks(big, r_inv, 0, dtype=F32)
+    b = loglik_with_chunks(big, r_inv, 37, dtype=F32)
+    np.testing.assert_allclose(a, b, rtol=RTOL)
+
+
+def test_large_d_unsupported_cases_fail_loudly(rng):
+    kw = random_ssm(rng, (1,), 4, 12, 1, well=True)
+    with pytest.raises(NotImplementedError):          # fp64 beyond the register-resident sizes
+        build_kf(kw, np.eye(1)).log_likelihood()
+    kw = random_ssm(rng, (1,), 4, 65, 1, well=True)
+    with pytest.raises(NotImplementedError):          # beyond the LDS-tiled sizes
+        build_kf(kw, np.eye(1), dtype=F32).log_likelihood()
+    kw = random_ssm(rng, (1,), 4, 16, 1, well=True)
+    with pytest.raises(NotImplementedError):          # operators other than the log-likelihood: small d only
+        build_kf(kw, np.eye(1), dtype=F32).posterior_state_space_model()
