@@ -47,14 +47,27 @@ __device__ __forceinline__ void gemm(const float* __restrict__ A, const float* _
         if (KM == K_B_LOWER) k0 = tj;
         if (KM == K_B_UPPER) k1 = min(k1, tj + 1);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // the sum over k may run in any order as long as A and B agree: lane (r, q) takes k = 16 kt + 4 q + kk in MFMA
+        // kk, so an operand that is contiguous in k is ONE 16-byte LDS read per K-tile
         for (int kt = k0; kt < k1; ++kt) {
+            const int kb = 16 * kt + 4 * q;
+            float av[4], bv[4];
+            if (TA) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int k = 16 * kt + 4 * kk + q;
-                const float a = TA ? A[k * LD + 16 * ti + r] : A[(16 * ti + r) * LD + k];
-                const float b = TB ? B[(16 * tj + r) * LD + k] : B[k * LD + 16 * tj + r];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+                for (int kk = 0; kk < 4; ++kk) av[kk] = A[(kb + kk) * LD + 16 * ti + r];
+            } else {
+                const f32x4 t4 = *reinterpret_cast<const f32x4*>(A + (16 * ti + r) * LD + kb);
+                av[0] = t4[0]; av[1] = t4[1]; av[2] = t4[2]; av[3] = t4[3];
             }
+            if (TB) {
+                const f32x4 t4 = *reinterpret_cast<const f32x4*>(B + (16 * tj + r) * LD + kb);
+                bv[0] = t4[0]; bv[1] = t4[1]; bv[2] = t4[2]; bv[3] = t4[3];
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) bv[kk] = B[(kb + kk) * LD + 16 * tj + r];
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bv[kk], acc, 0, 0, 0);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -124,7 +137,8 @@ __device__ __forceinline__ float diag_tile(float* __restrict__ S, float* __restr
 // (!CHOL) Inv <- S^-1 for lower-triangular S.  Returns log|det L| in wave 0 (valid on every lane of wave 0).
 // All threads must call; ends with a barrier.
 template <int DP, bool CHOL>
-__device__ __forceinline__ float factor_invert(float* __restrict__ S, float* __restrict__ Inv, bool& bad) {
+__device__ __forceinline__ float factor_invert(float* __restrict__ S, float* __restrict__ Inv, bool& bad,
+                                               float* __restrict__ red) {
     constexpr int LD = Geo<DP>::LD, NT = Geo<DP>::NT;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     float logdet = 0.f;
@@ -133,7 +147,19 @@ __device__ __forceinline__ float factor_invert(float* __restrict__ S, float* __r
         const int row = e / DP, col = e % DP;
         if ((col >> 4) > (row >> 4)) Inv[row * LD + col] = 0.f;
     }
-    for (int jb = 0; jb < NT; ++jb) {
+    if (!CHOL) {
+        // the diagonal tiles of a triangular matrix invert independently: one per wave; the per-wave
+        // log-determinants and pivot flags meet through eight words of `red`
+        float mine = 0.f;
+        bool mybad = false;
+        for (int jb = wave; jb < NT; jb += NTHR / 64)
+            mine += diag_tile<LD, false>(S + 16 * jb * LD + 16 * jb, Inv + 16 * jb * LD + 16 * jb, mybad);
+        if (lane == 0) { red[wave] = mine; red[4 + wave] = mybad ? 1.f : 0.f; }
+        __syncthreads();
+        logdet = red[0] + red[1] + red[2] + red[3];
+        bad |= (red[4] + red[5] + red[6] + red[7]) != 0.f;
+    }
+    for (int jb = 0; CHOL && jb < NT; ++jb) {
         if (wave == 0) logdet += diag_tile<LD, CHOL>(S + 16 * jb * LD + 16 * jb, Inv + 16 * jb * LD + 16 * jb, bad);
         __syncthreads();
         if (CHOL) {
@@ -342,7 +368,7 @@ __device__ __forceinline__ float obs_terms(const Smem<DP>& sm, float* __restrict
 // Eliminate the block whose complete pivot is in Phi: Linv -> U2, z -> V_Z, spike V -> U4 folded into GU / gU.
 template <int DP>
 __device__ __forceinline__ void eliminate(const Smem<DP>& sm, bool spike, double& logL, double& quad, bool& bad) {
-    logL += (double)factor_invert<DP, true>(sm.tile(T_PHI), sm.tile(T_U2), bad);
+    logL += (double)factor_invert<DP, true>(sm.tile(T_PHI), sm.tile(T_U2), bad, sm.scratch());
     matvec<DP, 0>(sm.tile(T_U2), sm.vec(V_T), sm.vec(V_Z), 1.f, 0.f, sm.scratch());
     quad += (double)sumsq<DP>(sm.vec(V_Z));
     if (spike) {
@@ -414,7 +440,7 @@ template <int DP> __global__ void __launch_bounds__(NTHR) big_kf_chunk_kernel(Bi
         load_tile<DP>(U1, a.cholP0 + s * d * d, nullptr, d, true, true);
         load_vec_lds<DP>(sm.vec(V_M), a.mu0 + s * d, nullptr, d);
         __syncthreads();
-        logC += (double)factor_invert<DP, false>(U1, Ci, bad);
+        logC += (double)factor_invert<DP, false>(U1, Ci, bad, sm.scratch());
         matvec<DP, 0>(Ci, sm.vec(V_M), sm.vec(V_W), 1.f, 0.f, sm.scratch());
         acc_ww += (double)sumsq<DP>(sm.vec(V_W));
         own_terms(0, sm.vec(V_T));
@@ -425,7 +451,7 @@ template <int DP> __global__ void __launch_bounds__(NTHR) big_kf_chunk_kernel(Bi
         load_tile<DP>(U2, a.A + (s * nt + tau) * d * d, nullptr, d, false, false);
         load_vec_lds<DP>(sm.vec(V_M), a.b + (s * nt + tau) * d, nullptr, d);
         __syncthreads();
-        logC += (double)factor_invert<DP, false>(U1, Ci, bad);
+        logC += (double)factor_invert<DP, false>(U1, Ci, bad, sm.scratch());
         matvec<DP, 0>(Ci, sm.vec(V_M), sm.vec(V_W), 1.f, 0.f, sm.scratch());
         acc_ww += (double)sumsq<DP>(sm.vec(V_W));
         gemm<DP, 0, 0, 0, K_A_LOWER, O_FULL>(Ci, U2, U1, 1.f);                                    // Bm = Ci A

@@ -34,14 +34,34 @@ typedef int mf_v4i __attribute__((ext_vector_type(4)));
 // address) has just been produced by a VALU instruction - v_readfirstlane, or a v_readlane restoring a spilled
 // SGPR - a VMEM instruction reading it needs 5 wait states; without them the DMA ran with a stale descriptor
 // and silently fetched another stream's rows.
-MF_DEV void dma_b128(mf_v4i srd, unsigned lds_addr, unsigned voff) {
+// Cache policy of the wide (A, cholQ) and narrow (b, H, y) streams: experiment knobs, "" = default policy.
+#define MF_POLICY_STR_0 ""
+#define MF_POLICY_STR_1 " nt"
+#define MF_POLICY_STR_2 " sc1"
+#define MF_POLICY_STR_3 " sc0 sc1"
+#define MF_POLICY_STR_4 " sc0"
+#define MF_POLICY_CAT(n) MF_POLICY_STR_##n
+#define MF_POLICY_OF(n) MF_POLICY_CAT(n)
+#ifndef MF_POLW
+#define MF_POLW 1   // A, cholQ: nt - streamed past the L2 so that it keeps the partially used b, H, y lines (measured -6 %)
+#endif
+#ifndef MF_POLN
+#define MF_POLN 0
+#endif
+#define MF_POLICY_WIDE MF_POLICY_OF(MF_POLW)
+#define MF_POLICY_NARROW MF_POLICY_OF(MF_POLN)
+template <bool WIDE> MF_DEV void dma_b128(mf_v4i srd, unsigned lds_addr, unsigned voff) {
     unsigned keep;
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(srd), "s"(lds_addr) : "memory");
+    if (WIDE)
+        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen" MF_POLICY_WIDE " lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(srd), "s"(lds_addr) : "memory");
+    else
+        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen" MF_POLICY_NARROW " lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(srd), "s"(lds_addr) : "memory");
 }
 MF_DEV void dma_b32(mf_v4i srd, unsigned lds_addr, unsigned voff) {
     unsigned keep;
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen" MF_POLICY_NARROW " lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(srd), "s"(lds_addr) : "memory");
 }
 
@@ -118,7 +138,7 @@ template <typename St> struct DmaStream {
     template <int I0, int I1> MF_DEV void issue(mf_v4i srd, unsigned lds_base) const {
         MF_UNROLL for (int i = I0; i < I1; ++i) {
             if (i < St::NI) {
-                if (St::UNIT == 16) dma_b128(srd, lds_base + i * 1024, vo[i]);
+                if (St::UNIT == 16) dma_b128<(St::UG >= 8)>(srd, lds_base + i * 1024, vo[i]);
                 else dma_b32(srd, lds_base + i * 256, vo[i]);
             }
         }
