@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--chunks", type=int, default=0, help="time partitions per series (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the brief timing of BASELINE configs 2-5")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
 
@@ -93,6 +94,87 @@ def cpu_baseline(inputs, seconds: float):
         "sample": f"{take} series x {t} time points (d={arrs['A'].shape[-1]}, fp64), best of {reps} passes; "
                   "C restatement of the reference algorithm (oracle/c/mf_oracle.c), OpenMP over series",
     }, out
+
+
+def _time_gpu(fn, iters=10, warm=2):
+    import torch
+
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def other_configs(dev):
+    """The remaining BASELINE.json configs, timed briefly on rank 0 (parity for them lives in tests/): reported beside
+    the headline, never as `value`."""
+    import torch
+
+    from markovflow_amd import _lib, synthetic
+    import markovflow_amd as mfa
+
+    out = {}
+    # config 2: KalmanFilter.log_likelihood B=256 T=4096 d=4 fp64
+    inp = synthetic.make_ssm(256, 4096, (3, 3), dtype=torch.float64, device=dev)
+    kf = synthetic.kalman_filter_from(inp)
+    ms = _time_gpu(kf.log_likelihood)
+    out["config2_loglik_B256_T4096_d4_f64"] = {
+        "ms": ms, "steps_per_s": 256 * 4096 / ms * 1e3,
+        "algorithmic_GBps": 256 * 4096 * synthetic.loglik_bytes_per_step(4, 1, 8) / ms / 1e6}
+    # config 3: SymmetricBlockTriDiagonal.cholesky + solve, T=100000 d=6 fp32, one chain (parallel-in-time path)
+    n, d = 100000, 6
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    ld = torch.tril(0.3 * torch.randn(1, n, d, d, dtype=torch.float64, device=dev, generator=g))
+    ld = ld - torch.diag_embed(torch.diagonal(ld, dim1=-2, dim2=-1)) + torch.diag_embed(
+        1 + torch.rand(1, n, d, dtype=torch.float64, device=dev, generator=g))
+    ls = 0.3 * torch.randn(1, n - 1, d, d, dtype=torch.float64, device=dev, generator=g)
+    diag = ld @ ld.transpose(-1, -2)
+    diag[:, 1:] += ls @ ls.transpose(-1, -2)
+    sub = ls @ ld[:, :-1].transpose(-1, -2)
+    sym = mfa.SymmetricBlockTriDiagonal(diag.float().contiguous(), sub.float().contiguous())
+    rhs = torch.randn(1, n, d, dtype=torch.float32, device=dev, generator=g)
+    chol = sym.cholesky
+    t_c = _time_gpu(lambda: sym.cholesky)
+    t_s = _time_gpu(lambda: chol.solve(rhs))
+    out["config3_btd_T100000_d6_f32_B1"] = {
+        "cholesky_us": t_c * 1e3, "solve_us": t_s * 1e3,
+        "cholesky_algorithmic_GBps": n * 4 * d * d * 4 / t_c / 1e6, "solve_algorithmic_GBps": n * (2 * d * d + 2 * d) * 4 / t_s / 1e6,
+        "frac_of_hbm_peak_cholesky": n * 4 * d * d * 4 / t_c / 1e6 / HBM_PEAK_GBS,
+        "note": "one chain: bound by the dependent block steps of the multi-level elimination (5 levels x 2 x 8), not bytes; "
+                "includes the Python-side allocation of outputs and workspace",
+        "max_abs_err_vs_exact_factor": float((chol.block_diagonal.double() - ld).abs().max())}
+    # config 4 shape: d=9 (3 x Matern-5/2, 3 outputs), 512 series per GPU (4096 over 8 GPUs), fp64
+    inp = synthetic.make_ssm(512, 1000, (5, 5, 5), output_dim=3, dtype=torch.float64, device=dev)
+    kf = synthetic.kalman_filter_from(inp)
+    ms = _time_gpu(kf.log_likelihood, iters=5)
+    post = kf.posterior_state_space_model()
+    ms_kl = _time_gpu(lambda: post.kl_divergence(kf.prior_ssm), iters=3, warm=1)
+    out["config4_d9_m3_B512_T1000_f64"] = {"loglik_ms": ms, "loglik_steps_per_s": 512 * 1000 / ms * 1e3,
+                                          "kl_divergence_ms": ms_kl}
+    # config 5: state_dim 64, T=2048, fp32, 32 spatial outputs, 8 series (LDS-tiled MFMA path)
+    bsz, tn, d, m = 8, 2048, 64, 32
+    eye = torch.eye(d, dtype=torch.float32, device=dev)
+    a_s = 0.9 * eye + (0.3 / d ** 0.5) * torch.randn(bsz, tn - 1, d, d, dtype=torch.float32, device=dev, generator=g)
+    cq = torch.tril((0.3 / d ** 0.5) * torch.randn(bsz, tn - 1, d, d, dtype=torch.float32, device=dev, generator=g)) + 0.5 * eye
+    cp0 = torch.tril(0.1 * torch.randn(bsz, d, d, dtype=torch.float32, device=dev, generator=g)) + eye
+    ssm = mfa.StateSpaceModel(torch.randn(bsz, d, dtype=torch.float32, device=dev, generator=g), cp0, a_s,
+                              0.1 * torch.randn(bsz, tn - 1, d, dtype=torch.float32, device=dev, generator=g), cq)
+    kf = mfa.KalmanFilter(ssm, mfa.EmissionModel(torch.randn(bsz, tn, m, d, dtype=torch.float32, device=dev, generator=g) / d ** 0.5),
+                          torch.randn(bsz, tn, m, dtype=torch.float32, device=dev, generator=g),
+                          0.3 * torch.eye(m, dtype=torch.float32, device=dev))
+    ms = _time_gpu(kf.log_likelihood, iters=5)
+    flop_step = 2 * 64 ** 3 * 7.5
+    out["config5_loglik_d64_T2048_m32_B8_f32"] = {
+        "ms": ms, "steps_per_s": bsz * tn / ms * 1e3, "mfma_TFLOPs": bsz * tn * flop_step / ms / 1e9,
+        "frac_of_f32_mfma_peak": bsz * tn * flop_step / ms / 1e9 / 157.3,
+        "note": "flop model 15 d^3 per step (products + factor/inverse tiles incl. the spike); MFMA busy counters: profiles/"}
+    return out
 
 
 def main():
@@ -208,6 +290,11 @@ def main():
         cst = -0.5 * np.log(2 * np.pi) * tn + 0.5 * tn * np.log(1.0 / 0.1)
         rel = float(np.max(np.abs(per + cst - cpu_out) / np.abs(cpu_out)))
         result["cpu_baseline"]["max_rel_diff_vs_gpu"] = rel
+    if rank == 0 and world == 1 and not args.no_other_configs:
+        try:
+            result["other_configs"] = other_configs(dev)
+        except Exception as exc:   # the headline line must still be printed
+            result["other_configs"] = {"error": repr(exc)}
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:

@@ -122,12 +122,15 @@ int mf_btd_logdet_quad_f32(int64_t B, int64_t T, int d, const float* diag, const
 /*
  * LowerTriangularBlockTriDiagonal.block_diagonal_of_inverse  (block_tri_diag.py:318-337; banded
  * inverse_from_cholesky_band): diagonal blocks of (L L^T)^-1 into odiag [B,T,d,d]; if osub != NULL also
- * the sub-diagonal blocks [B,T-1,d,d] (what ssm_gaussian_transformations.py:453-458 reads).
+ * the sub-diagonal blocks [B,T-1,d,d] (what ssm_gaussian_transformations.py:453-458 reads).  The backward
+ * (Takahashi) recursion is a congruence recursion Sigma_k = N_k + G_k^T Sigma_{k+1} G_k; for few series it is
+ * composed per time-chunk and scanned (csrc/mf_btd_par.hpp), with scratch from the caller.
  */
+size_t mf_btd_diag_of_inverse_workspace_bytes(int64_t B, int64_t T, int d, int elem_size);   /* 0 = serial kernel */
 int mf_btd_diag_of_inverse_f64(int64_t B, int64_t T, int d, const double* ldiag, const double* lsub,
-                               double* odiag, double* osub, void* stream);
+                               double* odiag, double* osub, void* ws, size_t ws_bytes, void* stream);
 int mf_btd_diag_of_inverse_f32(int64_t B, int64_t T, int d, const float* ldiag, const float* lsub, float* odiag,
-                               float* osub, void* stream);
+                               float* osub, void* ws, size_t ws_bytes, void* stream);
 
 /*
  * SymmetricBlockTriDiagonal.upper_diagonal_lower  (block_tri_diag.py:438-545, the tf.while_loop):
@@ -159,12 +162,23 @@ int mf_ssm_precision_f32(int64_t B, int64_t T, int d, int m, const float* mu0, c
 /*
  * StateSpaceModel.marginal_means / sample  (state_space_model.py:232-251,298-324): solves
  * (A^-1 block) x = offs, i.e. x_0 = offs_0, x_k = A_k x_{k-1} + offs_k.  offs/out [Br,T,d]; series r uses
- * the transitions of series r % Bl.
+ * the transitions of series r % Bl.  Scratch (parallel-in-time scan for few series): the size
+ * mf_btd_solve_workspace_bytes(Bl, Br, T, d, elem_size) returns (0 / NULL = serial kernel).
  */
 int mf_ssm_marginal_means_f64(int64_t Bl, int64_t Br, int64_t T, int d, const double* A, const double* offs,
-                              double* out, void* stream);
+                              double* out, void* ws, size_t ws_bytes, void* stream);
 int mf_ssm_marginal_means_f32(int64_t Bl, int64_t Br, int64_t T, int d, const float* A, const float* offs,
-                              float* out, void* stream);
+                              float* out, void* ws, size_t ws_bytes, void* stream);
+
+/*
+ * Block-wise d x d products out[s,k] = X[s,k] Y[s,k] over [B, n] blocks; x_stride / y_stride = blocks per series in
+ * the allocations of X / Y (>= n: a leading slice of a longer chain needs no copy).  Replaces the batched tf.matmul of
+ * StateSpaceModel.subsequent_covariances (state_space_model.py:326-341), Cov(x_{k+1}, x_k) = A_k P_k.
+ */
+int mf_block_matmul_f64(int64_t B, int64_t n, int d, const double* X, int64_t x_stride, const double* Y,
+                        int64_t y_stride, double* out, void* stream);
+int mf_block_matmul_f32(int64_t B, int64_t n, int d, const float* X, int64_t x_stride, const float* Y,
+                        int64_t y_stride, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -24,11 +24,12 @@ _SIGS = {
     "mf_btd_matvec": (_int, [_i64, _i64, _i64, _int, "Tp", "Tp", "Tp", "Tp", _int, _vp]),
     "mf_btd_logdet": (_int, [_i64, _i64, _int, "Tp", "Tp", _vp]),
     "mf_btd_logdet_quad": (_int, [_i64, _i64, _int, "Tp", "Tp", "Tp", "Tp", _vp, _sz, _vp, _vp]),
-    "mf_btd_diag_of_inverse": (_int, [_i64, _i64, _int, "Tp", "Tp", "Tp", "Tp", _vp]),
+    "mf_btd_diag_of_inverse": (_int, [_i64, _i64, _int, "Tp", "Tp", "Tp", "Tp", _vp, _sz, _vp]),
     "mf_btd_udl": (_int, [_i64, _i64, _int, "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", _vp, _vp]),
     "mf_ssm_precision": (_int, [_i64, _i64, _int, _int, "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", _int,
                                 "Tp", "Tp", "Tp", _vp]),
-    "mf_ssm_marginal_means": (_int, [_i64, _i64, _i64, _int, "Tp", "Tp", "Tp", _vp]),
+    "mf_ssm_marginal_means": (_int, [_i64, _i64, _i64, _int, "Tp", "Tp", "Tp", _vp, _sz, _vp]),
+    "mf_block_matmul": (_int, [_i64, _i64, _int, "Tp", _i64, "Tp", _i64, "Tp", _vp]),
 }
 _PLAIN = {
     "mf_version": (_int, []),
@@ -38,6 +39,7 @@ _PLAIN = {
     "mf_btd_logdet_quad_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
     "mf_btd_cholesky_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
     "mf_btd_solve_workspace_bytes": (_sz, [_i64, _i64, _i64, _int, _int]),
+    "mf_btd_diag_of_inverse_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
 }
 
 _lib = None

@@ -167,8 +167,12 @@ class LowerTriangularBlockTriDiagonal(BlockTriDiagonal):
         sub = None if self._sub_diag is None else _flat(self._sub_diag, 3)
         odiag = torch.empty_like(diag)
         osub = torch.empty_like(sub) if (want_sub and sub is not None) else None
+        ws_bytes = int(_lib.load().mf_btd_diag_of_inverse_workspace_bytes(diag.shape[0], self.outer_dim, self.inner_dim,
+                                                                           diag.element_size()))
+        ws = _lib.workspace(ws_bytes, diag.device)
         _lib.call("mf_btd_diag_of_inverse", diag.dtype, diag.shape[0], self.outer_dim, self.inner_dim,
-                  _lib.ptr(diag), _lib.ptr(sub), _lib.ptr(odiag), _lib.ptr(osub), _lib.stream_ptr(diag.device))
+                  _lib.ptr(diag), _lib.ptr(sub), _lib.ptr(odiag), _lib.ptr(osub), _lib.ptr(ws), ws_bytes,
+                  _lib.stream_ptr(diag.device))
         odiag = odiag.reshape(self._diag.shape)
         if osub is not None:
             osub = osub.reshape(self._sub_diag.shape)

@@ -140,13 +140,13 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         return t->btd_logdet_quad(B, Tn, diag, sub, rhs, out, ws, ws_bytes, info, 0, S(stream));                       \
     }                                                                                                                  \
     int mf_btd_diag_of_inverse_##SUF(int64_t B, int64_t Tn, int d, const T* ldiag, const T* lsub, T* odiag, T* osub,   \
-                                     void* stream) {                                                                   \
+                                     void* ws, size_t ws_bytes, void* stream) {                                        \
         MF_HEAD(T, B, Tn, d)                                                                                           \
         if (!ldiag) return -4;                                                                                         \
         if (!odiag) return -6;                                                                                         \
         if (Tn == 1) lsub = nullptr;                                                                                   \
         if (!lsub) osub = nullptr;                                                                                     \
-        return t->btd_diag_of_inverse(B, Tn, ldiag, lsub, odiag, osub, S(stream));                                     \
+        return t->btd_diag_of_inverse(B, Tn, ldiag, lsub, odiag, osub, ws, ws_bytes, S(stream));                       \
     }                                                                                                                  \
     int mf_btd_udl_##SUF(int64_t B, int64_t Tn, int d, const T* diag, const T* sub, T* ut, T* chol_d, const T* eta,    \
                          T* m_post, T* chol_dinv, int* info, void* stream) {                                           \
@@ -171,17 +171,31 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
                                 S(stream));                                                                            \
     }                                                                                                                  \
     int mf_ssm_marginal_means_##SUF(int64_t Bl, int64_t Br, int64_t Tn, int d, const T* A, const T* offs, T* out,      \
-                                    void* stream) {                                                                    \
+                                    void* ws, size_t ws_bytes, void* stream) {                                         \
         MF_HEAD(T, Br, Tn, d)                                                                                          \
         if (Bl < 1 || Br % Bl != 0) return -1;                                                                         \
         if (Tn > 1 && !A) return -5;                                                                                   \
         if (!offs) return -6;                                                                                          \
         if (!out) return -7;                                                                                           \
-        return t->ssm_means(Bl, Br, Tn, A, offs, out, S(stream));                                                      \
+        return t->ssm_means(Bl, Br, Tn, A, offs, out, ws, ws_bytes, S(stream));                                        \
+    }
+
+#define MF_DEFINE2(SUF, T)                                                                                             \
+    int mf_block_matmul_##SUF(int64_t B, int64_t n, int d, const T* X, int64_t x_stride, const T* Y, int64_t y_stride,  \
+                              T* out, void* stream) {                                                                  \
+        MF_HEAD(T, B, n, d)                                                                                            \
+        if (!X) return -4;                                                                                             \
+        if (x_stride < n) return -5;                                                                                   \
+        if (!Y) return -6;                                                                                             \
+        if (y_stride < n) return -7;                                                                                   \
+        if (!out) return -8;                                                                                           \
+        return t->block_matmul(B, n, X, x_stride, Y, y_stride, out, S(stream));                                        \
     }
 
 MF_DEFINE(f64, double)
 MF_DEFINE(f32, float)
+MF_DEFINE2(f64, double)
+MF_DEFINE2(f32, float)
 
 size_t mf_btd_cholesky_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {
     if (B < 1 || T < 1) return 0;
@@ -194,6 +208,13 @@ size_t mf_btd_solve_workspace_bytes(int64_t Bl, int64_t Br, int64_t T, int d, in
     if (elem_size == 4) { const auto* t = table_for<float>(d); return t ? t->btd_solve_ws(Bl, Br, T) : 0; }
     const auto* t = table_for<double>(d);
     return t ? t->btd_solve_ws(Bl, Br, T) : 0;
+}
+
+size_t mf_btd_diag_of_inverse_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {
+    if (B < 1 || T < 1) return 0;
+    if (elem_size == 4) { const auto* t = table_for<float>(d); return t ? t->btd_diag_of_inverse_ws(B, T) : 0; }
+    const auto* t = table_for<double>(d);
+    return t ? t->btd_diag_of_inverse_ws(B, T) : 0;
 }
 
 size_t mf_btd_logdet_quad_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {

@@ -341,4 +341,242 @@ __global__ void __launch_bounds__(64) par_solve_emit_kernel(long Bl, long Br, lo
     }
 }
 
+
+// ---- StateSpaceModel.marginal_means in parallel in time: x_p = A_{p-1} x_{p-1} + o_p is already an affine recursion ------
+template <typename T, int D>
+__global__ void __launch_bounds__(64) par_means_up0_kernel(long Bl, long Br, long n, long len, long P,
+                                                           const T* __restrict__ A, const T* __restrict__ offs,
+                                                           T* __restrict__ oM, T* __restrict__ oc) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= Br * P) return;
+    const long r = id / P, c = id % P, s = r % Bl;
+    const long p0 = c * len;
+    long p1 = p0 + len;
+    if (p1 > n) p1 = n;
+    T Pm[D][D], q[D];
+    MF_UNROLL for (int i = 0; i < D; ++i) { q[i] = T(0); MF_UNROLL for (int j = 0; j < D; ++j) Pm[i][j] = T(0); }
+    for (long p = p0; p < p1; ++p) {
+        T o[D];
+        load_vec<T, D>(offs + (r * n + p) * D, o);
+        if (p > 0) {
+            T Am[D][D], nq[D];
+            load_mat<T, D, D>(A + (s * (n - 1) + p - 1) * D * D, Am);
+            gemv_n<T, D, D>(Am, q, nq);
+            MF_UNROLL for (int i = 0; i < D; ++i) q[i] = nq[i] + o[i];
+            if (p == p0) {
+                MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Pm[i][j] = Am[i][j];
+            } else {
+                T nP[D][D];
+                MF_UNROLL for (int i = 0; i < D; ++i)
+                    MF_UNROLL for (int j = 0; j < D; ++j) {
+                        T a = T(0);
+                        MF_UNROLL for (int l = 0; l < D; ++l) a += Am[i][l] * Pm[l][j];
+                        nP[i][j] = a;
+                    }
+                MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Pm[i][j] = nP[i][j];
+            }
+        } else {
+            MF_UNROLL for (int i = 0; i < D; ++i) q[i] = o[i];
+        }
+    }
+    store_mat<T, D, D>(oM + id * D * D, Pm);
+    store_vec<T, D>(oc + id * D, q);
+}
+
+template <typename T, int D>
+__global__ void __launch_bounds__(64) par_means_emit_kernel(long Bl, long Br, long n, long len, long P,
+                                                            const T* __restrict__ A, const T* __restrict__ offs,
+                                                            const T* __restrict__ up, T* __restrict__ out) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= Br * P) return;
+    const long r = id / P, c = id % P, s = r % Bl;
+    const long p0 = c * len;
+    long p1 = p0 + len;
+    if (p1 > n) p1 = n;
+    T x[D];
+    MF_UNROLL for (int i = 0; i < D; ++i) x[i] = T(0);
+    if (c > 0) load_vec<T, D>(up + (r * P + c - 1) * D, x);
+    for (long p = p0; p < p1; ++p) {
+        T o[D];
+        load_vec<T, D>(offs + (r * n + p) * D, o);
+        if (p > 0) {
+            T Am[D][D], nx[D];
+            load_mat<T, D, D>(A + (s * (n - 1) + p - 1) * D * D, Am);
+            gemv_n<T, D, D>(Am, x, nx);
+            MF_UNROLL for (int i = 0; i < D; ++i) x[i] = nx[i] + o[i];
+        } else {
+            MF_UNROLL for (int i = 0; i < D; ++i) x[i] = o[i];
+        }
+        store_vec<T, D>(out + (r * n + p) * D, x);
+    }
+}
+
+// ---- block_diagonal_of_inverse (block Takahashi) in parallel in time ------------------------------------------------------------
+// Backward congruence recursion over positions p = n-1-k:  Sigma(p) = N_p + G_p^T Sigma(p-1) G_p,  Sigma(0) = N_0, with
+// N = L_k^-T L_k^-1 and G = W_k L_k^-1.  A run of positions composes into one (Gc, Nc):
+//   Gc <- Gc G_p,   Nc <- N_p + G_p^T Nc G_p.
+template <typename T, int D> MF_DEV void congruence_step(const T (&G)[D][D], const T (&N)[D][D], T (&Sig)[D][D]) {
+    // Sig(full symmetric) <- N(lower) + G^T Sig G
+    T SG[D][D];
+    MF_UNROLL for (int i = 0; i < D; ++i)
+        MF_UNROLL for (int j = 0; j < D; ++j) {
+            T a = T(0);
+            MF_UNROLL for (int l = 0; l < D; ++l) a += Sig[i][l] * G[l][j];
+            SG[i][j] = a;
+        }
+    T Out[D][D];
+    MF_UNROLL for (int i = 0; i < D; ++i)
+        MF_UNROLL for (int j = 0; j <= i; ++j) {
+            T a = N[i][j];
+            MF_UNROLL for (int l = 0; l < D; ++l) a += G[l][i] * SG[l][j];
+            Out[i][j] = a;
+        }
+    MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Sig[i][j] = (i >= j) ? Out[i][j] : Out[j][i];
+}
+// N (lower) and G of block k from the factor
+template <typename T, int D>
+MF_DEV void takahashi_terms(const T* __restrict__ ldiag, const T* __restrict__ lsub, long s, long n, long k, bool has_g,
+                            T (&N)[D][D], T (&G)[D][D]) {
+    T L[D][D], Linv[D][D];
+    load_lower<T, D>(ldiag + (s * n + k) * D * D, L);
+    LogAcc<T> la;
+    la.init();
+    bool bad = false;
+    tri_inv_lower<T, D>(L, Linv, la, bad);
+    trimulT_self_lower<T, D>(Linv, N);
+    if (has_g) {
+        T W[D][D];
+        load_mat<T, D, D>(lsub + (s * (n - 1) + k) * D * D, W);
+        MF_UNROLL for (int i = 0; i < D; ++i)
+            MF_UNROLL for (int j = 0; j < D; ++j) {
+                T a = T(0);
+                MF_UNROLL for (int l = j; l < D; ++l) a += W[i][l] * Linv[l][j];
+                G[i][j] = a;
+            }
+    }
+}
+
+template <typename T, int D>
+__global__ void __launch_bounds__(64) par_tak_up0_kernel(long B, long n, long len, long P, const T* __restrict__ ldiag,
+                                                         const T* __restrict__ lsub, T* __restrict__ oG, T* __restrict__ oN) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= B * P) return;
+    const long s = id / P, c = id % P;
+    const long p0 = c * len;
+    long p1 = p0 + len;
+    if (p1 > n) p1 = n;
+    T Gc[D][D], Nc[D][D];
+    for (long p = p0; p < p1; ++p) {
+        const long k = n - 1 - p;
+        T N[D][D], G[D][D];
+        takahashi_terms<T, D>(ldiag, lsub, s, n, k, p > 0, N, G);
+        if (p == p0) {
+            MF_UNROLL for (int i = 0; i < D; ++i)
+                MF_UNROLL for (int j = 0; j < D; ++j) { Nc[i][j] = (i >= j) ? N[i][j] : N[j][i]; Gc[i][j] = (p > 0) ? G[i][j] : T(0); }
+        } else {
+            congruence_step<T, D>(G, N, Nc);
+            T nG[D][D];
+            MF_UNROLL for (int i = 0; i < D; ++i)
+                MF_UNROLL for (int j = 0; j < D; ++j) {
+                    T a = T(0);
+                    MF_UNROLL for (int l = 0; l < D; ++l) a += Gc[i][l] * G[l][j];
+                    nG[i][j] = a;
+                }
+            MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Gc[i][j] = nG[i][j];
+        }
+    }
+    store_mat<T, D, D>(oG + id * D * D, Gc);
+    store_mat<T, D, D>(oN + id * D * D, Nc);
+}
+
+template <typename T, int D>
+__global__ void __launch_bounds__(64) par_tak_up_kernel(long B, long n, long len, long P, const T* __restrict__ Gs,
+                                                        const T* __restrict__ Ns, T* __restrict__ oG, T* __restrict__ oN) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= B * P) return;
+    const long s = id / P, c = id % P;
+    const long p0 = c * len;
+    long p1 = p0 + len;
+    if (p1 > n) p1 = n;
+    T Gc[D][D], Nc[D][D];
+    load_mat<T, D, D>(Gs + (s * n + p0) * D * D, Gc);
+    load_mat<T, D, D>(Ns + (s * n + p0) * D * D, Nc);
+    for (long p = p0 + 1; p < p1; ++p) {
+        T G[D][D], N[D][D], nG[D][D];
+        load_mat<T, D, D>(Gs + (s * n + p) * D * D, G);
+        load_lower<T, D>(Ns + (s * n + p) * D * D, N);
+        congruence_step<T, D>(G, N, Nc);
+        MF_UNROLL for (int i = 0; i < D; ++i)
+            MF_UNROLL for (int j = 0; j < D; ++j) {
+                T a = T(0);
+                MF_UNROLL for (int l = 0; l < D; ++l) a += Gc[i][l] * G[l][j];
+                nG[i][j] = a;
+            }
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Gc[i][j] = nG[i][j];
+    }
+    store_mat<T, D, D>(oG + id * D * D, Gc);
+    store_mat<T, D, D>(oN + id * D * D, Nc);
+}
+
+// Sigma at every position of a level >= 1 (coarsest level: len >= n, up = null)
+template <typename T, int D>
+__global__ void __launch_bounds__(64) par_tak_down_kernel(long B, long n, long len, long P, const T* __restrict__ Gs,
+                                                          const T* __restrict__ Ns, const T* __restrict__ up,
+                                                          T* __restrict__ Z) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= B * P) return;
+    const long s = id / P, c = id % P;
+    const long p0 = c * len;
+    long p1 = p0 + len;
+    if (p1 > n) p1 = n;
+    T Sig[D][D];
+    if (c > 0) load_mat<T, D, D>(up + (s * P + c - 1) * D * D, Sig);
+    for (long p = p0; p < p1; ++p) {
+        if (p > 0) {
+            T G[D][D], N[D][D];
+            load_mat<T, D, D>(Gs + (s * n + p) * D * D, G);
+            load_lower<T, D>(Ns + (s * n + p) * D * D, N);
+            congruence_step<T, D>(G, N, Sig);
+        } else {
+            load_mat<T, D, D>(Ns + (s * n) * D * D, Sig);
+        }
+        store_mat<T, D, D>(Z + (s * n + p) * D * D, Sig);
+    }
+}
+
+template <typename T, int D>
+__global__ void __launch_bounds__(64) par_tak_emit_kernel(long B, long n, long len, long P, const T* __restrict__ ldiag,
+                                                          const T* __restrict__ lsub, const T* __restrict__ up,
+                                                          T* __restrict__ odiag, T* __restrict__ osub) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= B * P) return;
+    const long s = id / P, c = id % P;
+    const long p0 = c * len;
+    long p1 = p0 + len;
+    if (p1 > n) p1 = n;
+    T Sig[D][D];
+    if (c > 0) load_mat<T, D, D>(up + (s * P + c - 1) * D * D, Sig);
+    for (long p = p0; p < p1; ++p) {
+        const long k = n - 1 - p;
+        T N[D][D], G[D][D];
+        takahashi_terms<T, D>(ldiag, lsub, s, n, k, p > 0, N, G);
+        if (p > 0) {
+            if (osub) {
+                T neg[D][D];
+                MF_UNROLL for (int i = 0; i < D; ++i)
+                    MF_UNROLL for (int j = 0; j < D; ++j) {
+                        T a = T(0);
+                        MF_UNROLL for (int l = 0; l < D; ++l) a += Sig[i][l] * G[l][j];
+                        neg[i][j] = -a;
+                    }
+                store_mat<T, D, D>(osub + (s * (n - 1) + k) * D * D, neg);
+            }
+            congruence_step<T, D>(G, N, Sig);
+        } else {
+            MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Sig[i][j] = (i >= j) ? N[i][j] : N[j][i];
+        }
+        store_mat<T, D, D>(odiag + (s * n + k) * D * D, Sig);
+    }
+}
+
 }  // namespace mf

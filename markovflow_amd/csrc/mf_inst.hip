@@ -330,10 +330,55 @@ template <typename T> int btd_logdet(long B, long n, const T* ldiag, T* out, hip
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
+template <typename T> size_t btd_diag_of_inverse_ws(long B, long n) {
+    const long len0 = par_len0(B, n);
+    if (len0 == 0) return 0;
+    const ParPlan pl = par_plan(n, len0);
+    size_t total = 0;
+    for (int l = 1; l <= pl.levels; ++l) total += 3 * align_up(size_t(B) * pl.n[l] * D * D * sizeof(T));
+    return total;
+}
+
 template <typename T>
-int btd_diag_of_inverse(long B, long n, const T* ldiag, const T* lsub, T* odiag, T* osub, hipStream_t st) {
-    hipLaunchKernelGGL((btd_diag_of_inverse_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, ldiag,
-                       lsub, odiag, osub);
+int btd_diag_of_inverse(long B, long n, const T* ldiag, const T* lsub, T* odiag, T* osub, void* ws, size_t ws_bytes,
+                        hipStream_t st) {
+    const long len0 = lsub ? par_len0(B, n) : 0;
+    if (len0 == 0 || ws == nullptr || ws_bytes < btd_diag_of_inverse_ws<T>(B, n)) {
+        hipLaunchKernelGGL((btd_diag_of_inverse_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, ldiag,
+                           lsub, odiag, osub);
+        return hipGetLastError() == hipSuccess ? 0 : -1000;
+    }
+    const ParPlan pl = par_plan(n, len0);
+    struct Arr { T *G, *N, *Z; } arr[24];
+    char* p = static_cast<char*>(ws);
+    for (int l = 1; l <= pl.levels; ++l) {
+        const size_t sz = align_up(size_t(B) * pl.n[l] * D * D * sizeof(T));
+        arr[l].G = reinterpret_cast<T*>(p); p += sz;
+        arr[l].N = reinterpret_cast<T*>(p); p += sz;
+        arr[l].Z = reinterpret_cast<T*>(p); p += sz;
+    }
+    hipLaunchKernelGGL((par_tak_up0_kernel<T, D>), dim3((unsigned)cdiv(B * pl.n[1], 64)), dim3(64), 0, st, B, n, len0,
+                       pl.n[1], ldiag, lsub, arr[1].G, arr[1].N);
+    for (int l = 1; l < pl.levels; ++l) {
+        const long P = pl.n[l + 1];
+        hipLaunchKernelGGL((par_tak_up_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, B, pl.n[l],
+                           pl.len[l], P, static_cast<const T*>(arr[l].G), static_cast<const T*>(arr[l].N), arr[l + 1].G,
+                           arr[l + 1].N);
+    }
+    {
+        const int l = pl.levels;
+        hipLaunchKernelGGL((par_tak_down_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, pl.n[l], pl.n[l],
+                           1L, static_cast<const T*>(arr[l].G), static_cast<const T*>(arr[l].N),
+                           static_cast<const T*>(nullptr), arr[l].Z);
+    }
+    for (int l = pl.levels - 1; l >= 1; --l) {
+        const long P = pl.n[l + 1];
+        hipLaunchKernelGGL((par_tak_down_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, B, pl.n[l],
+                           pl.len[l], P, static_cast<const T*>(arr[l].G), static_cast<const T*>(arr[l].N),
+                           static_cast<const T*>(arr[l + 1].Z), arr[l].Z);
+    }
+    hipLaunchKernelGGL((par_tak_emit_kernel<T, D>), dim3((unsigned)cdiv(B * pl.n[1], 64)), dim3(64), 0, st, B, n, len0,
+                       pl.n[1], ldiag, lsub, static_cast<const T*>(arr[1].Z), odiag, osub);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
@@ -356,16 +401,61 @@ int ssm_precision(long B, long Tn, int m, const T* mu0, const T* cholP0, const T
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
-template <typename T> int ssm_means(long Bl, long Br, long Tn, const T* A, const T* offs, T* out, hipStream_t st) {
-    hipLaunchKernelGGL((ssm_means_kernel<T, D>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Bl, Br, Tn, A, offs, out);
+template <typename T>
+int ssm_means(long Bl, long Br, long Tn, const T* A, const T* offs, T* out, void* ws, size_t ws_bytes, hipStream_t st) {
+    const long n = Tn;
+    const long len0 = par_len0(Br, n);
+    if (len0 == 0 || ws == nullptr || ws_bytes < btd_solve_ws<T>(Bl, Br, n)) {
+        hipLaunchKernelGGL((ssm_means_kernel<T, D>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Bl, Br, Tn, A, offs,
+                           out);
+        return hipGetLastError() == hipSuccess ? 0 : -1000;
+    }
+    // the mean recursion is the affine scan of the triangular solve with M_p = A_{p-1}, c_p = offs_p (same workspace)
+    const ParPlan pl = par_plan(n, len0);
+    struct Arr { T *M, *c, *Z; } arr[24];
+    char* p = static_cast<char*>(ws);
+    for (int l = 1; l <= pl.levels; ++l) {
+        arr[l].M = reinterpret_cast<T*>(p); p += align_up(size_t(Br) * pl.n[l] * D * D * sizeof(T));
+        arr[l].c = reinterpret_cast<T*>(p); p += align_up(size_t(Br) * pl.n[l] * D * sizeof(T));
+        arr[l].Z = reinterpret_cast<T*>(p); p += align_up(size_t(Br) * pl.n[l] * D * sizeof(T));
+    }
+    hipLaunchKernelGGL((par_means_up0_kernel<T, D>), dim3((unsigned)cdiv(Br * pl.n[1], 64)), dim3(64), 0, st, Bl, Br, n,
+                       len0, pl.n[1], A, offs, arr[1].M, arr[1].c);
+    for (int l = 1; l < pl.levels; ++l) {
+        const long P = pl.n[l + 1];
+        hipLaunchKernelGGL((par_affine_up_kernel<T, D>), dim3((unsigned)cdiv(Br * P, 64)), dim3(64), 0, st, Br, pl.n[l],
+                           pl.len[l], P, static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c), arr[l + 1].M,
+                           arr[l + 1].c);
+    }
+    {
+        const int l = pl.levels;
+        hipLaunchKernelGGL((par_affine_down_kernel<T, D>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Br, pl.n[l],
+                           pl.n[l], 1L, static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c),
+                           static_cast<const T*>(nullptr), arr[l].Z);
+    }
+    for (int l = pl.levels - 1; l >= 1; --l) {
+        const long P = pl.n[l + 1];
+        hipLaunchKernelGGL((par_affine_down_kernel<T, D>), dim3((unsigned)cdiv(Br * P, 64)), dim3(64), 0, st, Br, pl.n[l],
+                           pl.len[l], P, static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c),
+                           static_cast<const T*>(arr[l + 1].Z), arr[l].Z);
+    }
+    hipLaunchKernelGGL((par_means_emit_kernel<T, D>), dim3((unsigned)cdiv(Br * pl.n[1], 64)), dim3(64), 0, st, Bl, Br, n,
+                       len0, pl.n[1], A, offs, static_cast<const T*>(arr[1].Z), out);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+template <typename T>
+int block_matmul(long B, long n, const T* X, long xs, const T* Y, long ys, T* out, hipStream_t st) {
+    hipLaunchKernelGGL((block_matmul_kernel<T, D>), dim3((unsigned)cdiv(B * n, 256)), dim3(256), 0, st, B, n, X, xs, Y, ys,
+                       out);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
 template <typename T> const OpsTable<T>* table() {
     static const OpsTable<T> t = {
         &kf_loglik_ws<T>, &kf_loglik<T>, &btd_logdet_quad_ws<T>, &btd_logdet_quad<T>, &btd_cholesky_ws<T>, &btd_cholesky<T>,
-        &btd_solve_ws<T>, &btd_solve<T>,    &btd_matvec<T>, &btd_logdet<T>,        &btd_diag_of_inverse<T>, &btd_udl<T>,
-        &ssm_precision<T>, &ssm_means<T>,
+        &btd_solve_ws<T>, &btd_solve<T>,    &btd_matvec<T>, &btd_logdet<T>,        &btd_diag_of_inverse_ws<T>, &btd_diag_of_inverse<T>, &btd_udl<T>,
+        &ssm_precision<T>, &ssm_means<T>, &block_matmul<T>,
     };
     return &t;
 }

@@ -601,6 +601,26 @@ __global__ void __launch_bounds__(256) ssm_precision_kernel(KfArgs<T> a, T* __re
     if (eta) store_vec<T, D>(eta + id * D, rn);
 }
 
+// Block-wise product out[s, k] = X[s, k] Y[s, k] of two [B, n, d, d] block arrays whose series may be strided
+// (StateSpaceModel.subsequent_covariances, state_space_model.py:326-341: A_k P_k with P = covs[..., :-1, :, :]).
+// One lane per block; a batched d x d GEMM through a BLAS library costs a launch-bound eternity at d <= 9.
+template <typename T, int D>
+__global__ void __launch_bounds__(256) block_matmul_kernel(long B, long n, const T* __restrict__ X, long xs,
+                                                           const T* __restrict__ Y, long ys, T* __restrict__ out) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= B * n) return;
+    const long s = id / n, k = id % n;
+    T Xm[D][D], Ym[D][D], Om[D][D];
+    load_mat<T, D, D>(X + (s * xs + k) * D * D, Xm);
+    load_mat<T, D, D>(Y + (s * ys + k) * D * D, Ym);
+    MF_UNROLL for (int i = 0; i < D; ++i) {
+        MF_UNROLL for (int j = 0; j < D; ++j) Om[i][j] = Xm[i][0] * Ym[0][j];
+        MF_UNROLL for (int l = 1; l < D; ++l)
+            MF_UNROLL for (int j = 0; j < D; ++j) Om[i][j] += Xm[i][l] * Ym[l][j];
+    }
+    store_mat<T, D, D>(out + id * D * D, Om);
+}
+
 // StateSpaceModel.marginal_means (state_space_model.py:232-251): mu_{k+1} = A_k mu_k + b_k.
 // rhs series r uses transitions of series r % Bl (sample() passes sample_shape + batch_shape).
 template <typename T, int D>

@@ -24,13 +24,17 @@ template <typename T> struct OpsTable {
     int (*btd_matvec)(long Bl, long Br, long n, const T* diag, const T* sub, const T* x, T* out, int mode,
                       hipStream_t st);
     int (*btd_logdet)(long B, long n, const T* ldiag, T* out, hipStream_t st);
-    int (*btd_diag_of_inverse)(long B, long n, const T* ldiag, const T* lsub, T* odiag, T* osub, hipStream_t st);
+    size_t (*btd_diag_of_inverse_ws)(long B, long n);
+    int (*btd_diag_of_inverse)(long B, long n, const T* ldiag, const T* lsub, T* odiag, T* osub, void* ws, size_t ws_bytes,
+                               hipStream_t st);
     int (*btd_udl)(long B, long n, const T* diag, const T* sub, T* ut, T* chol_d, const T* eta, T* m_post,
                    T* chol_dinv, int* info, hipStream_t st);
     int (*ssm_precision)(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b,
                          const T* cholQ, const T* H, const T* y, const T* Rinv, int rinv_per_step, T* diag, T* sub,
                          T* eta, hipStream_t st);
-    int (*ssm_means)(long Bl, long Br, long Tn, const T* A, const T* offs, T* out, hipStream_t st);
+    int (*ssm_means)(long Bl, long Br, long Tn, const T* A, const T* offs, T* out, void* ws, size_t ws_bytes,
+                     hipStream_t st);
+    int (*block_matmul)(long B, long n, const T* X, long xs, const T* Y, long ys, T* out, hipStream_t st);
 };
 
 constexpr int MF_MAX_D = 9;        // largest state dimension with a register-resident instantiation

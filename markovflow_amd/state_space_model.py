@@ -122,8 +122,12 @@ class StateSpaceModel(GaussMarkovDistribution):
         a_f = _flat(self._A_s, 3)
         offs = _flat(offsets, 2)
         out = torch.empty_like(offs)
+        ws_bytes = int(_lib.load().mf_btd_solve_workspace_bytes(a_f.shape[0], offs.shape[0], self.num_transitions + 1,
+                                                                 self.state_dim, offs.element_size()))
+        ws = _lib.workspace(ws_bytes, offs.device)
         _lib.call("mf_ssm_marginal_means", offs.dtype, a_f.shape[0], offs.shape[0], self.num_transitions + 1,
-                  self.state_dim, _lib.ptr(a_f), _lib.ptr(offs), _lib.ptr(out), _lib.stream_ptr(offs.device))
+                  self.state_dim, _lib.ptr(a_f), _lib.ptr(offs), _lib.ptr(out), _lib.ptr(ws), ws_bytes,
+                  _lib.stream_ptr(offs.device))
         return out.reshape(lead + (self.num_transitions + 1, self.state_dim))
 
     # -- marginals ----------------------------------------------------------------------------------------
@@ -162,7 +166,15 @@ class StateSpaceModel(GaussMarkovDistribution):
 
     def subsequent_covariances(self, marginal_covariances: torch.Tensor) -> torch.Tensor:
         """``Cov(x_{k+1}, x_k) = A_k P_k`` (state_space_model.py:326-341)."""
-        return self._A_s @ marginal_covariances[..., :-1, :, :]
+        n, d = self.num_transitions, self.state_dim
+        if tuple(marginal_covariances.shape) != tuple(self.batch_shape) + (n + 1, d, d):
+            raise ValueError(f"marginal_covariances has shape {tuple(marginal_covariances.shape)}")
+        a_f, cov_f = _flat(self._A_s, 3), _flat(marginal_covariances, 3)
+        out = torch.empty_like(a_f)
+        # blocks 0..n-1 of the [n+1]-long covariance chain are read in place (series stride n+1): no slice copy
+        _lib.call("mf_block_matmul", a_f.dtype, a_f.shape[0], n, d, _lib.ptr(a_f), n, _lib.ptr(cov_f), n + 1,
+                  _lib.ptr(out), _lib.stream_ptr(a_f.device))
+        return out.reshape(self._A_s.shape)
 
     def log_det_precision(self) -> torch.Tensor:
         """``-2 (log|chol P0| + Σ log|chol Q_k|)`` (state_space_model.py:343-373)."""

@@ -10,7 +10,7 @@ python3 -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc
 tail -3 $OUT/pytest_gpu.log
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+BENCH="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs"
 rm -rf /tmp/prof_stats
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- $BENCH > $OUT/bench_prof.log 2>&1
 f=$(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1)

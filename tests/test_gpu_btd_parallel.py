@@ -130,3 +130,46 @@ def test_config3_full_size_fp32_recombination_and_round_trip(rng):
         np.testing.assert_allclose(nn(back), nn(rhs), rtol=2e-3, atol=2e-4)
     # log-determinant through the factor equals the one through the partitioned scalar reduction
     assert torch.isfinite(chol.abs_log_det()).all()
+
+
+# ---- parallel-in-time Takahashi (block_diagonal_of_inverse) and marginal means --------------------------------------------------
+@pytest.mark.parametrize("d,n,batch", [(1, 64, ()), (3, 100, (2,)), (2, 777, (3,)), (6, 1000, (1,)), (9, 513, (2, 1))])
+def test_parallel_block_diagonal_of_inverse_vs_oracle(rng, d, n, batch):
+    bsz = int(np.prod(batch)) if batch else 1
+    assert _lib.load().mf_btd_diag_of_inverse_workspace_bytes(bsz, n, d, 8) > 0
+    ldiag, lsub, _, _ = factor_and_matrix(rng, batch, n, d)
+    low = mfa.LowerTriangularBlockTriDiagonal(tt(ldiag), tt(lsub))
+    inv_d, inv_s = O.btd_block_diagonal_of_inverse(ldiag, lsub, return_sub=True)
+    got_d, got_s = low._diag_and_sub_of_inverse(want_sub=True)
+    np.testing.assert_allclose(nn(got_d), inv_d, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(nn(got_s), inv_s, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(nn(low.block_diagonal_of_inverse()), inv_d, rtol=1e-8, atol=1e-10)
+
+
+def test_parallel_block_diagonal_of_inverse_long_chain_identity(rng):
+    """Size-independent property at T = 20000: block row k of  M Sigma = I  restricted to the tridiagonal pattern,
+    S_{k-1} Sigma_{k-1,k} + D_k Sigma_{kk} + S_k^T Sigma_{k+1,k} = I."""
+    d, n = 6, 20000
+    ldiag, lsub, diag, sub = factor_and_matrix(rng, (), n, d)
+    low = mfa.LowerTriangularBlockTriDiagonal(tt(ldiag), tt(lsub))
+    sig_d, sig_s = low._diag_and_sub_of_inverse(want_sub=True)
+    dg, sb = tt(diag), tt(sub)
+    row = dg @ sig_d
+    row[1:] += sb @ sig_s.transpose(-1, -2)
+    row[:-1] += sb.transpose(-1, -2) @ sig_s
+    eye = torch.eye(d, dtype=torch.float64, device=DEV).expand(n, d, d)
+    np.testing.assert_allclose(nn(row), nn(eye), rtol=0, atol=1e-8)
+
+
+@pytest.mark.parametrize("d,n,batch", [(2, 64, ()), (6, 1000, (2,)), (4, 4099, ()), (9, 300, (3,))])
+def test_parallel_marginal_means_and_sample_propagation(rng, d, n, batch):
+    a = 0.9 * np.eye(d) + 0.1 * rng.normal(size=batch + (n - 1, d, d)) / np.sqrt(d)
+    mu0, b = rng.normal(size=batch + (d,)), rng.normal(size=batch + (n - 1, d))
+    chol = np.tile(np.eye(d), batch + (n - 1, 1, 1))
+    ssm = mfa.StateSpaceModel(tt(mu0), tt(np.tile(np.eye(d), batch + (1, 1))), tt(a), tt(b), tt(chol))
+    np.testing.assert_allclose(nn(ssm.marginal_means), O.ssm_marginal_means(mu0, a, b), rtol=1e-9, atol=1e-10)
+    # extra leading dims (sample_shape + batch_shape, state_space_model.py:307-322): one set of transitions, 3 offsets
+    offs = rng.normal(size=(3,) + batch + (n, d))
+    got = nn(ssm._propagate(tt(offs)))
+    want = np.stack([O.ssm_marginal_means(offs[i][..., 0, :], a, offs[i][..., 1:, :]) for i in range(3)])
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-10)
