@@ -248,9 +248,12 @@ class SymmetricBlockTriDiagonal(BlockTriDiagonal):
             eta_f = _flat(eta, 2)
             m_post, chol_dinv = torch.empty_like(eta_f), torch.empty_like(diag)
         info = _lib.new_info(diag.device)
+        ws_bytes = int(_lib.load().mf_btd_udl_workspace_bytes(diag.shape[0], self.outer_dim, self.inner_dim,
+                                                               diag.element_size()))
+        ws = _lib.workspace(ws_bytes, diag.device)
         _lib.call("mf_btd_udl", diag.dtype, diag.shape[0], self.outer_dim, self.inner_dim, _lib.ptr(diag),
                   _lib.ptr(sub), _lib.ptr(u_t), _lib.ptr(chol_d), _lib.ptr(eta_f), _lib.ptr(m_post),
-                  _lib.ptr(chol_dinv), _lib.ptr(info), _lib.stream_ptr(diag.device))
+                  _lib.ptr(chol_dinv), _lib.ptr(ws), ws_bytes, _lib.ptr(info), _lib.stream_ptr(diag.device))
         _lib.raise_on_info(info, "SymmetricBlockTriDiagonal.upper_diagonal_lower")
         u_t, chol_d = u_t.reshape(self._sub_diag.shape), chol_d.reshape(self._diag.shape)
         if eta is not None:

@@ -149,13 +149,13 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         return t->btd_diag_of_inverse(B, Tn, ldiag, lsub, odiag, osub, ws, ws_bytes, S(stream));                       \
     }                                                                                                                  \
     int mf_btd_udl_##SUF(int64_t B, int64_t Tn, int d, const T* diag, const T* sub, T* ut, T* chol_d, const T* eta,    \
-                         T* m_post, T* chol_dinv, int* info, void* stream) {                                           \
+                         T* m_post, T* chol_dinv, void* ws, size_t ws_bytes, int* info, void* stream) {                \
         MF_HEAD(T, B, Tn, d)                                                                                           \
         if (!diag) return -4;                                                                                          \
         if (Tn > 1 && (!sub || !ut)) return -5;                                                                        \
         if (!chol_d) return -7;                                                                                        \
         if (eta && (!m_post || !chol_dinv)) return -9;                                                                 \
-        return t->btd_udl(B, Tn, diag, sub, ut, chol_d, eta, m_post, chol_dinv, info, S(stream));                      \
+        return t->btd_udl(B, Tn, diag, sub, ut, chol_d, eta, m_post, chol_dinv, ws, ws_bytes, info, S(stream));        \
     }                                                                                                                  \
     int mf_ssm_precision_##SUF(int64_t B, int64_t Tn, int d, int m, const T* mu0, const T* cholP0, const T* A,         \
                                const T* b, const T* cholQ, const T* H, const T* y, const T* Rinv, int rinv_per_step,   \
@@ -215,6 +215,13 @@ size_t mf_btd_diag_of_inverse_workspace_bytes(int64_t B, int64_t T, int d, int e
     if (elem_size == 4) { const auto* t = table_for<float>(d); return t ? t->btd_diag_of_inverse_ws(B, T) : 0; }
     const auto* t = table_for<double>(d);
     return t ? t->btd_diag_of_inverse_ws(B, T) : 0;
+}
+
+size_t mf_btd_udl_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {
+    if (B < 1 || T < 1) return 0;
+    if (elem_size == 4) { const auto* t = table_for<float>(d); return t ? t->btd_udl_ws(B, T) : 0; }
+    const auto* t = table_for<double>(d);
+    return t ? t->btd_udl_ws(B, T) : 0;
 }
 
 size_t mf_btd_logdet_quad_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {

@@ -32,7 +32,24 @@ template <typename T> struct ParLevel {
     const T* GU;   // [B, n, D, D]  GU[j]: what eliminating the interior of (lower-level) chunk j adds to block j-1
     const T* F;    // coupling of block j with block j-1 (block index j + f_off, f_stride blocks per series)
     long n, f_stride, f_off;
+    int rev;       // level 0 only: positions run backwards over the user's blocks (p -> block n-1-p, coupling transposed):
+                   // the natural-order pivots of the REVERSED matrix are the Delta_k of the U D U^T factorisation
 };
+
+template <typename T, int D> MF_DEV void par_load_dv(const ParLevel<T>& lv, long s, long p, T (&Dn)[D][D]) {
+    const long k = lv.rev ? lv.n - 1 - p : p;
+    load_lower<T, D>(lv.Dv + (s * lv.n + k) * D * D, Dn);
+}
+// coupling of position p with position p-1 (rows: p)
+template <typename T, int D> MF_DEV void par_load_f(const ParLevel<T>& lv, long s, long p, T (&W)[D][D]) {
+    if (!lv.rev) {
+        load_mat<T, D, D>(lv.F + (s * lv.f_stride + p + lv.f_off) * D * D, W);
+    } else {
+        T St[D][D];
+        load_mat<T, D, D>(lv.F + (s * (lv.n - 1) + lv.n - 1 - p) * D * D, St);   // sub[k], k = n-1-p: rows k+1, cols k
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) W[i][j] = St[j][i];
+    }
+}
 
 template <typename T, int D> MF_DEV void load_sym_lower(const T* __restrict__ p, T (&m)[D][D]) { load_lower<T, D>(p, m); }
 
@@ -80,7 +97,7 @@ __global__ void __launch_bounds__(64) par_chol_up_kernel(ParLevel<T> in, long B,
     for (long k = k0; k < k1; ++k) {
         const bool last = (k + 1 == k1);
         T Dn[D][D], fut[D][D];
-        load_lower<T, D>(in.Dv + (s * in.n + k) * D * D, Dn);
+        par_load_dv<T, D>(in, s, k, Dn);
         par_future<T, D>(in, s, k, fut);
         if (last) {
             // the future part of the chunk's last block travels separately
@@ -89,7 +106,7 @@ __global__ void __launch_bounds__(64) par_chol_up_kernel(ParLevel<T> in, long B,
             MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Dn[i][j] += fut[i][j];
         }
         if (k == k0) {
-            if (k > 0) load_mat<T, D, D>(in.F + (s * in.f_stride + k + in.f_off) * D * D, X);
+            if (k > 0) par_load_f<T, D>(in, s, k, X);
             MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Phi[i][j] = Dn[i][j];
             continue;
         }
@@ -101,7 +118,7 @@ __global__ void __launch_bounds__(64) par_chol_up_kernel(ParLevel<T> in, long B,
             syrk_tn_lower<T, D, D>(X, GU, T(-1));            // GU -= V^T V
         }
         T W[D][D];
-        load_mat<T, D, D>(in.F + (s * in.f_stride + k + in.f_off) * D * D, W);
+        par_load_f<T, D>(in, s, k, W);
         trsm_right_lower_t<T, D, D>(Phi, Li, W);             // W = F_k L^-T
         MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Phi[i][j] = Dn[i][j];
         syrk_nt_lower<T, D, D>(W, Phi, T(-1));               // next pivot: Dn - W W^T
@@ -132,7 +149,7 @@ __global__ void __launch_bounds__(64) par_chol_down_kernel(ParLevel<T> lv, long 
     if (c > 0) load_lower<T, D>(up + (s * P + c - 1) * D * D, Sig);
     for (long k = k0; k < k1; ++k) {
         T Dn[D][D];
-        load_lower<T, D>(lv.Dv + (s * lv.n + k) * D * D, Dn);
+        par_load_dv<T, D>(lv, s, k, Dn);
         if (k > 0) {
             // pivot of block k-1 at the moment block k is reached: natural pivot + its future part
             T fut[D][D], W[D][D];
@@ -140,7 +157,7 @@ __global__ void __launch_bounds__(64) par_chol_down_kernel(ParLevel<T> lv, long 
             MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Sig[i][j] += fut[i][j];
             chol_lower<T, D>(Sig, Li, la, bad);
             la.init();
-            load_mat<T, D, D>(lv.F + (s * lv.f_stride + k + lv.f_off) * D * D, W);
+            par_load_f<T, D>(lv, s, k, W);
             trsm_right_lower_t<T, D, D>(Sig, Li, W);
             syrk_nt_lower<T, D, D>(W, Dn, T(-1));
         }
@@ -577,6 +594,134 @@ __global__ void __launch_bounds__(64) par_tak_emit_kernel(long B, long n, long l
         }
         store_mat<T, D, D>(odiag + (s * n + k) * D * D, Sig);
     }
+}
+
+
+// ---- upper_diagonal_lower (U D U^T) and the posterior chain in parallel in time -------------------------------------------------
+// Level-0 emit of the reversed factorisation: chunk c covers positions [c len, ...) (position p = block n-1-p) and restarts
+// the backward recursion  Delta_k = D_k - S_k^T Delta_{k+1}^-1 S_k  from the pivot at position c len - 1 (`up`).
+template <typename T, int D>
+__global__ void __launch_bounds__(64) par_udl_emit_kernel(long B, long n, long len, long P, const T* __restrict__ diag,
+                                                          const T* __restrict__ sub, const T* __restrict__ up,
+                                                          T* __restrict__ ut, T* __restrict__ chol_d, int* info) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= B * P) return;
+    const long s = id / P, c = id % P;
+    const long p0 = c * len;
+    long p1 = p0 + len;
+    if (p1 > n) p1 = n;
+    T Lp[D][D], Lpi[D];
+    LogAcc<T> la;
+    la.init();
+    bool bad = false;
+    if (c > 0) {
+        load_lower<T, D>(up + (s * P + c - 1) * D * D, Lp);
+        chol_lower<T, D>(Lp, Lpi, la, bad);
+        la.init();
+    }
+    for (long p = p0; p < p1; ++p) {
+        const long k = n - 1 - p;
+        T Dl[D][D];
+        load_lower<T, D>(diag + (s * n + k) * D * D, Dl);
+        if (p > 0) {
+            T U[D][D];
+            load_mat<T, D, D>(sub + (s * (n - 1) + k) * D * D, U);
+            trsm_left_lower<T, D, D>(Lp, Lpi, U);          // L^-1 S
+            syrk_tn_lower<T, D, D>(U, Dl, T(-1));          // Delta_k = D_k - S^T Delta_{k+1}^-1 S
+            trsm_left_lower_t<T, D, D>(Lp, Lpi, U);        // U_k^T = Delta_{k+1}^-1 S
+            store_mat<T, D, D>(ut + (s * (n - 1) + k) * D * D, U);
+        }
+        chol_lower<T, D>(Dl, Lpi, la, bad);
+        la.init();
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Lp[i][j] = Dl[i][j];
+        store_lower<T, D>(chol_d + (s * n + k) * D * D, Lp);
+    }
+    if (bad && info) atomicMax(info, 1);
+}
+
+// posterior chain, backward affine recursion over positions:  x(p) = eta_k - U_k x(p-1),  U_k = (ut[k])^T, k = n-1-p
+template <typename T, int D>
+__global__ void __launch_bounds__(64) par_post_up0_kernel(long B, long n, long len, long P, const T* __restrict__ ut,
+                                                          const T* __restrict__ eta, T* __restrict__ oM, T* __restrict__ oc) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= B * P) return;
+    const long s = id / P, c = id % P;
+    const long p0 = c * len;
+    long p1 = p0 + len;
+    if (p1 > n) p1 = n;
+    T Pm[D][D], q[D];
+    MF_UNROLL for (int i = 0; i < D; ++i) { q[i] = T(0); MF_UNROLL for (int j = 0; j < D; ++j) Pm[i][j] = T(0); }
+    for (long p = p0; p < p1; ++p) {
+        const long k = n - 1 - p;
+        T e[D];
+        load_vec<T, D>(eta + (s * n + k) * D, e);
+        if (p > 0) {
+            T Ut[D][D], uq[D];
+            load_mat<T, D, D>(ut + (s * (n - 1) + k) * D * D, Ut);
+            gemv_t<T, D, D>(Ut, q, uq);                    // U_k q
+            MF_UNROLL for (int i = 0; i < D; ++i) q[i] = e[i] - uq[i];
+            T nP[D][D];
+            if (p == p0) {
+                MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) nP[i][j] = -Ut[j][i];
+            } else {
+                MF_UNROLL for (int i = 0; i < D; ++i)
+                    MF_UNROLL for (int j = 0; j < D; ++j) {
+                        T a = T(0);
+                        MF_UNROLL for (int l = 0; l < D; ++l) a += Ut[l][i] * Pm[l][j];
+                        nP[i][j] = -a;
+                    }
+            }
+            MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Pm[i][j] = nP[i][j];
+        } else {
+            MF_UNROLL for (int i = 0; i < D; ++i) q[i] = e[i];
+        }
+    }
+    store_mat<T, D, D>(oM + id * D * D, Pm);
+    store_vec<T, D>(oc + id * D, q);
+}
+
+// level 0: x_k, then m_k = Delta_k^-1 x_k and chol(Delta_k^-1) (kalman_filter.py:159-174)
+template <typename T, int D>
+__global__ void __launch_bounds__(64) par_post_emit_kernel(long B, long n, long len, long P, const T* __restrict__ ut,
+                                                           const T* __restrict__ chol_d, const T* __restrict__ eta,
+                                                           const T* __restrict__ up, T* __restrict__ m_post,
+                                                           T* __restrict__ chol_dinv, int* info) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= B * P) return;
+    const long s = id / P, c = id % P;
+    const long p0 = c * len;
+    long p1 = p0 + len;
+    if (p1 > n) p1 = n;
+    T xp[D];
+    MF_UNROLL for (int i = 0; i < D; ++i) xp[i] = T(0);
+    if (c > 0) load_vec<T, D>(up + (s * P + c - 1) * D, xp);
+    bool bad = false;
+    for (long p = p0; p < p1; ++p) {
+        const long k = n - 1 - p;
+        T x[D];
+        load_vec<T, D>(eta + (s * n + k) * D, x);
+        if (p > 0) {
+            T Ut[D][D], ux[D];
+            load_mat<T, D, D>(ut + (s * (n - 1) + k) * D * D, Ut);
+            gemv_t<T, D, D>(Ut, xp, ux);
+            MF_UNROLL for (int i = 0; i < D; ++i) x[i] -= ux[i];
+        }
+        MF_UNROLL for (int i = 0; i < D; ++i) xp[i] = x[i];
+        T Lp[D][D], Lpi[D], Linv[D][D], Q[D][D], Qi[D];
+        load_lower<T, D>(chol_d + (s * n + k) * D * D, Lp);
+        LogAcc<T> lb;
+        lb.init();
+        tri_inv_lower<T, D>(Lp, Linv, lb, bad);
+        MF_UNROLL for (int i = 0; i < D; ++i) Lpi[i] = Linv[i][i];
+        trsv_lower<T, D>(Lp, Lpi, x);
+        trsv_lower_t<T, D>(Lp, Lpi, x);                    // m_k = Delta_k^-1 x_k
+        store_vec<T, D>(m_post + (s * n + k) * D, x);
+        trimulT_self_lower<T, D>(Linv, Q);
+        lb.init();
+        chol_lower<T, D>(Q, Qi, lb, bad);
+        store_lower<T, D>(chol_dinv + (s * n + k) * D * D, Q);
+    }
+    if (bad && info) atomicMax(info, 1);
 }
 
 }  // namespace mf

@@ -242,8 +242,8 @@ int btd_cholesky(long B, long n, const T* diag, const T* sub, T* ldiag, T* lsub,
         for (auto* q : f) { *q = reinterpret_cast<T*>(p); p += sz; }
     }
     auto level = [&](int l) {
-        if (l == 0) return ParLevel<T>{diag, nullptr, nullptr, sub, n, n - 1, -1};
-        return ParLevel<T>{arr[l].Dv, arr[l].Gf, arr[l].GU, arr[l].F, pl.n[l], pl.n[l], 0};
+        if (l == 0) return ParLevel<T>{diag, nullptr, nullptr, sub, n, n - 1, -1, 0};
+        return ParLevel<T>{arr[l].Dv, arr[l].Gf, arr[l].GU, arr[l].F, pl.n[l], pl.n[l], 0, 0};
     };
     for (int l = 0; l < pl.levels; ++l) {
         const long P = pl.n[l + 1];
@@ -382,11 +382,83 @@ int btd_diag_of_inverse(long B, long n, const T* ldiag, const T* lsub, T* odiag,
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
+template <typename T> size_t btd_udl_ws(long B, long n) {
+    const long len0 = par_len0(B, n);
+    if (len0 == 0) return 0;
+    const ParPlan pl = par_plan(n, len0);
+    size_t total = 0;
+    for (int l = 1; l <= pl.levels; ++l)
+        total += 6 * align_up(size_t(B) * pl.n[l] * D * D * sizeof(T)) + 2 * align_up(size_t(B) * pl.n[l] * D * sizeof(T));
+    return total;
+}
+
 template <typename T>
 int btd_udl(long B, long n, const T* diag, const T* sub, T* ut, T* chol_d, const T* eta, T* m_post, T* chol_dinv,
-            int* info, hipStream_t st) {
-    hipLaunchKernelGGL((btd_udl_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, diag, sub, ut, chol_d,
-                       eta, m_post, chol_dinv, info);
+            void* ws, size_t ws_bytes, int* info, hipStream_t st) {
+    const long len0 = sub ? par_len0(B, n) : 0;
+    if (len0 == 0 || ws == nullptr || ws_bytes < btd_udl_ws<T>(B, n)) {
+        hipLaunchKernelGGL((btd_udl_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, diag, sub, ut,
+                           chol_d, eta, m_post, chol_dinv, info);
+        return hipGetLastError() == hipSuccess ? 0 : -1000;
+    }
+    // Delta_k = natural-order pivots of the REVERSED matrix: the Cholesky hierarchy with rev = 1 on level 0
+    const ParPlan pl = par_plan(n, len0);
+    struct Arr { T *Dv, *Gf, *GU, *F, *Pn, *M, *c, *Z; } arr[24];
+    char* p = static_cast<char*>(ws);
+    for (int l = 1; l <= pl.levels; ++l) {
+        const size_t sz = align_up(size_t(B) * pl.n[l] * D * D * sizeof(T)), sv = align_up(size_t(B) * pl.n[l] * D * sizeof(T));
+        T** f[6] = {&arr[l].Dv, &arr[l].Gf, &arr[l].GU, &arr[l].F, &arr[l].Pn, &arr[l].M};
+        for (auto* q : f) { *q = reinterpret_cast<T*>(p); p += sz; }
+        arr[l].c = reinterpret_cast<T*>(p); p += sv;
+        arr[l].Z = reinterpret_cast<T*>(p); p += sv;
+    }
+    auto level = [&](int l) {
+        if (l == 0) return ParLevel<T>{diag, nullptr, nullptr, sub, n, n - 1, -1, 1};
+        return ParLevel<T>{arr[l].Dv, arr[l].Gf, arr[l].GU, arr[l].F, pl.n[l], pl.n[l], 0, 0};
+    };
+    for (int l = 0; l < pl.levels; ++l) {
+        const long P = pl.n[l + 1];
+        hipLaunchKernelGGL((par_chol_up_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, level(l), B,
+                           pl.len[l], P, arr[l + 1].Dv, arr[l + 1].Gf, arr[l + 1].GU, arr[l + 1].F, info);
+    }
+    {
+        const int l = pl.levels;
+        hipLaunchKernelGGL((par_chol_down_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, level(l), B,
+                           pl.n[l], 1L, static_cast<const T*>(nullptr), arr[l].Pn, info);
+    }
+    for (int l = pl.levels - 1; l >= 1; --l) {
+        const long P = pl.n[l + 1];
+        hipLaunchKernelGGL((par_chol_down_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, level(l), B,
+                           pl.len[l], P, static_cast<const T*>(arr[l + 1].Pn), arr[l].Pn, info);
+    }
+    const dim3 g0((unsigned)cdiv(B * pl.n[1], 64));
+    hipLaunchKernelGGL((par_udl_emit_kernel<T, D>), g0, dim3(64), 0, st, B, n, len0, pl.n[1], diag, sub,
+                       static_cast<const T*>(arr[1].Pn), ut, chol_d, info);
+    if (eta) {
+        // x_k = eta_k - U_k x_{k+1}: affine scan over the reversed positions, then the per-block finish
+        hipLaunchKernelGGL((par_post_up0_kernel<T, D>), g0, dim3(64), 0, st, B, n, len0, pl.n[1], static_cast<const T*>(ut),
+                           eta, arr[1].M, arr[1].c);
+        for (int l = 1; l < pl.levels; ++l) {
+            const long P = pl.n[l + 1];
+            hipLaunchKernelGGL((par_affine_up_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, B, pl.n[l],
+                               pl.len[l], P, static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c),
+                               arr[l + 1].M, arr[l + 1].c);
+        }
+        {
+            const int l = pl.levels;
+            hipLaunchKernelGGL((par_affine_down_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, pl.n[l],
+                               pl.n[l], 1L, static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c),
+                               static_cast<const T*>(nullptr), arr[l].Z);
+        }
+        for (int l = pl.levels - 1; l >= 1; --l) {
+            const long P = pl.n[l + 1];
+            hipLaunchKernelGGL((par_affine_down_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, B, pl.n[l],
+                               pl.len[l], P, static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c),
+                               static_cast<const T*>(arr[l + 1].Z), arr[l].Z);
+        }
+        hipLaunchKernelGGL((par_post_emit_kernel<T, D>), g0, dim3(64), 0, st, B, n, len0, pl.n[1], static_cast<const T*>(ut),
+                           static_cast<const T*>(chol_d), eta, static_cast<const T*>(arr[1].Z), m_post, chol_dinv, info);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
@@ -454,7 +526,7 @@ int block_matmul(long B, long n, const T* X, long xs, const T* Y, long ys, T* ou
 template <typename T> const OpsTable<T>* table() {
     static const OpsTable<T> t = {
         &kf_loglik_ws<T>, &kf_loglik<T>, &btd_logdet_quad_ws<T>, &btd_logdet_quad<T>, &btd_cholesky_ws<T>, &btd_cholesky<T>,
-        &btd_solve_ws<T>, &btd_solve<T>,    &btd_matvec<T>, &btd_logdet<T>,        &btd_diag_of_inverse_ws<T>, &btd_diag_of_inverse<T>, &btd_udl<T>,
+        &btd_solve_ws<T>, &btd_solve<T>,    &btd_matvec<T>, &btd_logdet<T>,        &btd_diag_of_inverse_ws<T>, &btd_diag_of_inverse<T>, &btd_udl_ws<T>, &btd_udl<T>,
         &ssm_precision<T>, &ssm_means<T>, &block_matmul<T>,
     };
     return &t;

@@ -173,3 +173,50 @@ def test_parallel_marginal_means_and_sample_propagation(rng, d, n, batch):
     got = nn(ssm._propagate(tt(offs)))
     want = np.stack([O.ssm_marginal_means(offs[i][..., 0, :], a, offs[i][..., 1:, :]) for i in range(3)])
     np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-10)
+
+
+# ---- parallel-in-time U D U^T and posterior chain ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("d,n,batch", [(1, 64, ()), (3, 100, (2,)), (2, 777, (3,)), (6, 1000, (1,)), (9, 300, (2, 1))])
+def test_parallel_upper_diagonal_lower_vs_oracle(rng, d, n, batch):
+    bsz = int(np.prod(batch)) if batch else 1
+    assert _lib.load().mf_btd_udl_workspace_bytes(bsz, n, d, 8) > 0
+    _, _, diag, sub = factor_and_matrix(rng, batch, n, d)
+    u_t, chol_d = mfa.SymmetricBlockTriDiagonal(tt(diag), tt(sub)).upper_diagonal_lower()
+    want_u, want_c = O.btd_upper_diagonal_lower(diag, sub)
+    np.testing.assert_allclose(nn(u_t.block_sub_diagonal), want_u, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(nn(chol_d.block_diagonal), np.tril(want_c), rtol=1e-8, atol=1e-10)
+
+
+def test_parallel_udl_long_chain_recombines(rng):
+    """U D U^T = M block by block at T = 20000 (test_block_tri_diag.py:205-225 of the reference, size-independent form):
+    D_k = Delta_k + U_k Delta_{k+1} U_k^T,  S_k = Delta_{k+1} U_k^T."""
+    d, n = 6, 20000
+    _, _, diag, sub = factor_and_matrix(rng, (), n, d)
+    u_t, chol_d = mfa.SymmetricBlockTriDiagonal(tt(diag), tt(sub)).upper_diagonal_lower()
+    ut, cd = u_t.block_sub_diagonal, chol_d.block_diagonal
+    delta = cd @ cd.transpose(-1, -2)
+    rec_sub = delta[1:] @ ut
+    rec_diag = delta.clone()
+    rec_diag[:-1] += ut.transpose(-1, -2) @ delta[1:] @ ut
+    np.testing.assert_allclose(nn(rec_sub), sub, rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(nn(rec_diag), diag, rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize("d,m,n", [(2, 1, 300), (6, 1, 500), (4, 2, 129)])
+def test_parallel_posterior_state_space_model_vs_oracle(rng, d, m, n):
+    """KalmanFilter.posterior_state_space_model (kalman_filter.py:109-182) on the parallel-in-time path (few series)."""
+    from test_gpu_kalman import build_kf, random_ssm
+    kw = random_ssm(rng, (2,), n, d, m)
+    cov = 0.4 * np.eye(m)
+    kf = build_kf(kw, np.linalg.cholesky(cov))
+    post = kf.posterior_state_space_model()
+    want = O.kf_posterior_ssm(**kw, r_inv=np.linalg.inv(cov))
+    got = (post.initial_mean, post.cholesky_initial_covariance, post.state_transitions, post.state_offsets,
+           post.cholesky_process_covariances)
+    for g, w in zip(got, want):
+        np.testing.assert_allclose(nn(g), w, rtol=1e-7, atol=1e-9)
+    # smoothed marginals against the oracle's (means: affine scan; covariances: Cholesky + Takahashi, all parallel in time)
+    means = O.ssm_marginal_means(want[0], want[2], want[3])
+    np.testing.assert_allclose(nn(post.marginal_means), means, rtol=1e-7, atol=1e-9)
+    covs = O.ssm_marginal_covariances(want[1], want[2], want[4])
+    np.testing.assert_allclose(nn(post.marginal_covariances), covs, rtol=1e-6, atol=1e-9)
