@@ -184,16 +184,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # under torch.distributed.run
+    if world > 1 or launched:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl")          # RCCL on ROCm
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # RCCL on ROCm
     else:
         dist = None
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if dist is not None else 0)
 
     from markovflow_amd import distributed as mfd
     from markovflow_amd import synthetic

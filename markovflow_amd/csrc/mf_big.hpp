@@ -38,6 +38,61 @@ __device__ __forceinline__ void gemm(const float* __restrict__ A, const float* _
                                      float alpha, int kt_end = Geo<DP>::NT) {
     constexpr int LD = Geo<DP>::LD, NT = Geo<DP>::NT;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    if constexpr (NT >= 3) {
+        // one COLUMN of output tiles per wave: the B fragment of a K-tile is read once for all of them and the NT
+        // accumulators give the matrix pipe independent chains (a single 16x16x4 chain is latency-bound)
+        const int tj = wave;
+        if (tj >= NT) return;
+        f32x4 acc[NT];
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) acc[ti] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < kt_end; ++kt) {
+            if (KM == K_B_LOWER && kt < tj) continue;
+            if (KM == K_B_UPPER && kt > tj) continue;
+            const int kb = 16 * kt + 4 * q;
+            float bv[4], av[NT][4];
+            if (TB) {
+                const f32x4 t4 = *reinterpret_cast<const f32x4*>(B + (16 * tj + r) * LD + kb);
+                bv[0] = t4[0]; bv[1] = t4[1]; bv[2] = t4[2]; bv[3] = t4[3];
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) bv[kk] = B[(kb + kk) * LD + 16 * tj + r];
+            }
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti) {
+                const bool on = !(OM == O_LOWER && tj > ti) && !(KM == K_A_LOWER && kt > ti) && !(KM == K_A_UPPER && kt < ti);
+                if (on) {
+                    if (TA) {
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) av[ti][kk] = A[(kb + kk) * LD + 16 * ti + r];
+                    } else {
+                        const f32x4 t4 = *reinterpret_cast<const f32x4*>(A + (16 * ti + r) * LD + kb);
+                        av[ti][0] = t4[0]; av[ti][1] = t4[1]; av[ti][2] = t4[2]; av[ti][3] = t4[3];
+                    }
+                } else {
+                    av[ti][0] = av[ti][1] = av[ti][2] = av[ti][3] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti) {
+                    const bool on = !(OM == O_LOWER && tj > ti) && !(KM == K_A_LOWER && kt > ti) && !(KM == K_A_UPPER && kt < ti);
+                    if (on) acc[ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ti][kk], bv[kk], acc[ti], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+            if (OM == O_LOWER && tj > ti) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float* p = C + (16 * ti + 4 * q + e) * LD + 16 * tj + r;
+                if (ACC) *p += alpha * acc[ti][e]; else *p = alpha * acc[ti][e];
+            }
+        }
+        return;
+    }
     for (int idx = wave; idx < NT * NT; idx += NTHR / 64) {
         const int ti = idx / NT, tj = idx % NT;
         if (OM == O_LOWER && tj > ti) continue;
@@ -288,6 +343,31 @@ __device__ __forceinline__ void load_tile(float* __restrict__ tile, const float*
         tile[row * LD + col] = v;
     }
 }
+// The next transition's d x d block held in registers (NE floats per thread) between its global load, issued one
+// step ahead, and its landing in an LDS tile: HBM latency is covered by a whole step of arithmetic.
+template <int DP> struct TilePrefetch {
+    static constexpr int NE = DP * DP / NTHR;
+    float v[NE];
+    __device__ __forceinline__ void load(const float* __restrict__ g, int d, bool lower, bool idpad) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = threadIdx.x + i * NTHR, row = e / DP, col = e % DP;
+            float x = 0.f;
+            if (row < d && col < d && (!lower || col <= row)) x = g[row * d + col];
+            else if (idpad && row == col && row >= d) x = 1.f;
+            v[i] = x;
+        }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ tile) const {
+        constexpr int LD = Geo<DP>::LD;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = threadIdx.x + i * NTHR;
+            tile[(e / DP) * LD + (e % DP)] = v[i];
+        }
+    }
+};
+
 template <int DP> __device__ __forceinline__ void zero_tile(float* __restrict__ tile) {
     constexpr int LD = Geo<DP>::LD;
     for (int e = threadIdx.x; e < DP * LD; e += NTHR) tile[e] = 0.f;
@@ -445,12 +525,21 @@ template <int DP> __global__ void __launch_bounds__(NTHR) big_kf_chunk_kernel(Bi
         acc_ww += (double)sumsq<DP>(sm.vec(V_W));
         own_terms(0, sm.vec(V_T));
     }
+    TilePrefetch<DP> pfC, pfA;
+    float pfb = 0.f;
+    auto prefetch = [&](long tau) {
+        pfC.load(a.cholQ + (s * nt + tau) * d * d, d, true, true);
+        pfA.load(a.A + (s * nt + tau) * d * d, d, false, false);
+        pfb = (threadIdx.x < d) ? a.b[(s * nt + tau) * d + threadIdx.x] : 0.f;
+    };
+    if (len > 0) prefetch(tau0);
     for (long j = 0; j < len; ++j) {
         const long tau = tau0 + j;
-        load_tile<DP>(U1, a.cholQ + (s * nt + tau) * d * d, nullptr, d, true, true);
-        load_tile<DP>(U2, a.A + (s * nt + tau) * d * d, nullptr, d, false, false);
-        load_vec_lds<DP>(sm.vec(V_M), a.b + (s * nt + tau) * d, nullptr, d);
+        pfC.store(U1);
+        pfA.store(U2);
+        if (threadIdx.x < DP) sm.vec(V_M)[threadIdx.x] = pfb;
         __syncthreads();
+        if (j + 1 < len) prefetch(tau + 1);      // in flight during the whole step
         logC += (double)factor_invert<DP, false>(U1, Ci, bad, sm.scratch());
         matvec<DP, 0>(Ci, sm.vec(V_M), sm.vec(V_W), 1.f, 0.f, sm.scratch());
         acc_ww += (double)sumsq<DP>(sm.vec(V_W));
