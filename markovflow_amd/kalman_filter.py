@@ -161,9 +161,20 @@ class KalmanFilter(BaseKalmanFilter):
 
     @property
     def _r_inv(self) -> torch.Tensor:
-        eye = torch.eye(self.emission.output_dim, dtype=self._chol_obs_covariance.dtype,
-                        device=self._chol_obs_covariance.device)
-        return torch.cholesky_solve(eye, self._chol_obs_covariance)
+        """``R⁻¹ = (chol cholᵀ)⁻¹`` (kalman_filter.py:341-348)."""
+        chol = self._chol_obs_covariance
+        if chol.shape[-1] == 1:
+            return 1.0 / (chol * chol)            # one tiny kernel pair instead of a potrs call chain
+        eye = torch.eye(self.emission.output_dim, dtype=chol.dtype, device=chol.device)
+        return torch.cholesky_solve(eye, chol)
+
+    @property
+    def _log_det_observation_precision(self) -> torch.Tensor:
+        """``T · log|R⁻¹| = −2 T Σ log diag(chol R)`` (kalman_filter.py:103-107): read off the Cholesky factor that is
+        already given instead of an LU-based slogdet of the inverse (a dozen launch-bound kernels per call)."""
+        num_data = self.prior_ssm.num_transitions + 1
+        diag = torch.diagonal(self._chol_obs_covariance, dim1=-2, dim2=-1)
+        return (-2.0 * num_data) * torch.sum(torch.log(torch.abs(diag)))
 
     @property
     def observations(self) -> torch.Tensor:
