@@ -17,7 +17,7 @@
  *   - `info` (nullable) is a device int the kernels raise to 1 on a non-positive pivot
  *     (LAPACK info>0 style; results are then NaN);
  *   - return value: 0 ok; -k = argument k (1-based) invalid; -100 = state dimension not
- *     instantiated (1..9 in this build; mf_kf_loglik_f32 up to 64); -1000 = launch failure;
+ *     instantiated (1..9 in this build; mf_kf_loglik up to 64 in fp32, 32 in fp64); -1000 = launch failure;
  *   - re-entrant, no global state.
  */
 #ifndef MARKOVFLOW_AMD_H
@@ -34,6 +34,7 @@ extern "C" {
 int mf_version(void);
 int mf_max_state_dim(void);              /* every entry point, fp32 and fp64: register-resident kernels (9)       */
 int mf_max_state_dim_f32_loglik(void);   /* mf_kf_loglik_f32 only: LDS-tiled MFMA kernels for 10 <= d <= 64       */
+int mf_max_state_dim_f64_loglik(void);   /* mf_kf_loglik_f64 only: the same on f64 MFMA for 10 <= d <= 32         */
 
 /*
  * KalmanFilter.log_likelihood, per series, fully fused
@@ -46,9 +47,9 @@ int mf_max_state_dim_f32_loglik(void);   /* mf_kf_loglik_f32 only: LDS-tiled MFM
  * Inputs: mu0 [B,d], cholP0 [B,d,d], A [B,T-1,d,d], b [B,T-1,d], cholQ [B,T-1,d,d],
  *         H [B,T,m,d], y [B,T,m], Rinv [m,m] (rinv_per_step=0, KalmanFilter) or [B,T,m,m]
  *         (rinv_per_step=1, KalmanFilterWithSites / WithSparseSites), 1 <= m <= 4.
- * State dimension: 1..9 in fp32 and fp64 (one lane per (series, time-chunk), registers); mf_kf_loglik_f32 also
- *         takes 10 <= d <= 64 with 1 <= m <= 32 (one workgroup per (series, time-chunk), LDS tiles, f32 MFMA:
- *         csrc/mf_big.hpp - BASELINE config 5, state_dim = 64).
+ * State dimension: 1..9 in fp32 and fp64 (one lane per (series, time-chunk), registers); 10 <= d <= 64 (fp32) or
+ *         10 <= d <= 32 (fp64) with 1 <= m <= 32 run one workgroup per (series, time-chunk) on LDS tiles and
+ *         f32 / f64 MFMA (csrc/mf_big.hpp - BASELINE config 5, state_dim = 64).
  * Output: out[s] = add_const + term1 + term2 + 1/2 log|K^-1| - log|L|  (kalman_filter.py:233-253), i.e. the
  *         per-series log-likelihood; the terms that do not depend on the chain,
  *         -1/2 m T log(2 pi) + 1/2 log|Sigma^-1|  (kalman_filter.py:229-231,249-253), are passed in add_const.

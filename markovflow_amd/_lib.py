@@ -35,6 +35,7 @@ _PLAIN = {
     "mf_version": (_int, []),
     "mf_max_state_dim": (_int, []),
     "mf_max_state_dim_f32_loglik": (_int, []),
+    "mf_max_state_dim_f64_loglik": (_int, []),
     "mf_kf_loglik_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _i64]),
     "mf_btd_logdet_quad_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
     "mf_btd_cholesky_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
@@ -113,7 +114,8 @@ def check(rc: int, what: str):
     if rc == -100:
         raise NotImplementedError(
             f"{what}: state dimension not instantiated in this build (supported: 1..{load().mf_max_state_dim()}; "
-            f"float32 log_likelihood up to {load().mf_max_state_dim_f32_loglik()})"
+            f"log_likelihood up to {load().mf_max_state_dim_f32_loglik()} in float32, "
+            f"{load().mf_max_state_dim_f64_loglik()} in float64)"
         )
     if rc == -1000:
         raise MarkovflowAmdError(f"{what}: kernel launch failed")

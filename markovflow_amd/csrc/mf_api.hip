@@ -32,7 +32,7 @@ int kf_loglik(int64_t B, int64_t Tn, int d, int m, const T* mu0, const T* cholP0
     if (Tn < 1) return -2;
     if (d < 1) return -3;
     const auto* t = table_for<T>(d);
-    const bool big = !t && sizeof(T) == 4 && d <= mf::MF_MAX_D_BIG;
+    const bool big = !t && d <= (sizeof(T) == 4 ? mf::MF_MAX_D_BIG : mf::MF_MAX_D_BIG_F64);
     if (!t && !big) return -100;
     if (m < 1 || m > (big ? 32 : 4)) return -4;
     if (B == 0) return 0;
@@ -43,9 +43,13 @@ int kf_loglik(int64_t B, int64_t Tn, int d, int m, const T* mu0, const T* cholP0
     if (!y) return -11;
     if (!Rinv) return -12;
     if (!out) return -15;
-    if constexpr (sizeof(T) == 4) {
-        if (big)
+    if (big) {
+        if constexpr (sizeof(T) == 4)
             return mf::big_kf_loglik_f32(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, add_const, out,
+                                         ws, ws_bytes, info, chunks, static_cast<hipEvent_t>(ev0),
+                                         static_cast<hipEvent_t>(ev1), S(stream));
+        else
+            return mf::big_kf_loglik_f64(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, add_const, out,
                                          ws, ws_bytes, info, chunks, static_cast<hipEvent_t>(ev0),
                                          static_cast<hipEvent_t>(ev1), S(stream));
     }
@@ -64,12 +68,14 @@ size_t mf_kf_loglik_workspace_bytes(int64_t B, int64_t T, int d, int elem_size, 
     if (elem_size == 4) {
         const auto* t = table_for<float>(d);
         if (t) return t->kf_loglik_ws(B, T, chunks);
-        return (d >= 1 && d <= mf::MF_MAX_D_BIG && B >= 1 && T >= 1) ? mf::big_kf_loglik_ws(B, T, d, chunks) : 0;
+        return (d >= 1 && d <= mf::MF_MAX_D_BIG && B >= 1 && T >= 1) ? mf::big_kf_loglik_ws(B, T, d, chunks, 4) : 0;
     }
     const auto* t = table_for<double>(d);
-    return t ? t->kf_loglik_ws(B, T, chunks) : 0;
+    if (t) return t->kf_loglik_ws(B, T, chunks);
+    return (d >= 1 && d <= mf::MF_MAX_D_BIG_F64 && B >= 1 && T >= 1) ? mf::big_kf_loglik_ws(B, T, d, chunks, 8) : 0;
 }
 int mf_max_state_dim_f32_loglik(void) { return mf::MF_MAX_D_BIG; }
+int mf_max_state_dim_f64_loglik(void) { return mf::MF_MAX_D_BIG_F64; }
 
 int mf_kf_loglik_f64(int64_t B, int64_t T, int d, int m, const double* mu0, const double* cholP0, const double* A,
                      const double* b, const double* cholQ, const double* H, const double* y, const double* Rinv,

@@ -1,0 +1,713 @@
+// Body of mf_big.hpp, included once per scalar type (MF_BIG_T = float / double, MF_BIG_NS = big / bigd).
+namespace mf {
+namespace MF_BIG_NS {
+
+typedef MF_BIG_T real;
+
+typedef real real4 __attribute__((ext_vector_type(4)));
+constexpr int NTHR = 256;
+constexpr int MAXM_BIG = 32;   // observation dimension supported by the large-d path
+
+template <int DP> struct Geo {
+    static constexpr int LD = DP + 4;
+    static constexpr int NT = DP / 16;
+    static constexpr int TILE = DP * LD;          // floats
+};
+
+using namespace bigcommon;
+__device__ __forceinline__ constexpr int acc_row(int q, int e) { return sizeof(real) == 4 ? 4 * q + e : q + 4 * e; }
+
+enum KMode { K_FULL = 0, K_A_LOWER = 1, K_A_UPPER = 2, K_B_LOWER = 3, K_B_UPPER = 4 };
+enum OMode { O_FULL = 0, O_LOWER = 1 };
+
+// C (=, +=) alpha * opA(A) * opB(B) on DP x DP LDS images.  TA/TB = 1 use the transpose.  KM names a triangular
+// operand (in its op() form) so that all-zero 16 x 16 K-tiles are skipped; kt_end limits the K tiles (for K < DP).
+// Every wave owns whole output tiles; no barrier inside.
+template <int DP, int TA, int TB, int ACC, int KM, int OM>
+__device__ __forceinline__ void gemm(const real* __restrict__ A, const real* __restrict__ B, real* __restrict__ C,
+                                     real alpha, int kt_end = Geo<DP>::NT) {
+    constexpr int LD = Geo<DP>::LD, NT = Geo<DP>::NT;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    if constexpr (NT >= 3) {
+        // one COLUMN of output tiles per wave: the B fragment of a K-tile is read once for all of them and the NT
+        // accumulators give the matrix pipe independent chains (a single 16x16x4 chain is latency-bound)
+        const int tj = wave;
+        if (tj >= NT) return;
+        real4 acc[NT];
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) acc[ti] = real4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < kt_end; ++kt) {
+            if (KM == K_B_LOWER && kt < tj) continue;
+            if (KM == K_B_UPPER && kt > tj) continue;
+            const int kb = 16 * kt + 4 * q;
+            real bv[4], av[NT][4];
+            if (TB) {
+                const real4 t4 = *reinterpret_cast<const real4*>(B + (16 * tj + r) * LD + kb);
+                bv[0] = t4[0]; bv[1] = t4[1]; bv[2] = t4[2]; bv[3] = t4[3];
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) bv[kk] = B[(kb + kk) * LD + 16 * tj + r];
+            }
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti) {
+                const bool on = !(OM == O_LOWER && tj > ti) && !(KM == K_A_LOWER && kt > ti) && !(KM == K_A_UPPER && kt < ti);
+                if (on) {
+                    if (TA) {
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) av[ti][kk] = A[(kb + kk) * LD + 16 * ti + r];
+                    } else {
+                        const real4 t4 = *reinterpret_cast<const real4*>(A + (16 * ti + r) * LD + kb);
+                        av[ti][0] = t4[0]; av[ti][1] = t4[1]; av[ti][2] = t4[2]; av[ti][3] = t4[3];
+                    }
+                } else {
+                    av[ti][0] = av[ti][1] = av[ti][2] = av[ti][3] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti) {
+                    const bool on = !(OM == O_LOWER && tj > ti) && !(KM == K_A_LOWER && kt > ti) && !(KM == K_A_UPPER && kt < ti);
+                    if (on) acc[ti] = mfma(av[ti][kk], bv[kk], acc[ti]);
+                }
+            }
+        }
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+            if (OM == O_LOWER && tj > ti) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                real* p = C + (16 * ti + acc_row(q, e)) * LD + 16 * tj + r;
+                if (ACC) *p += alpha * acc[ti][e]; else *p = alpha * acc[ti][e];
+            }
+        }
+        return;
+    }
+    for (int idx = wave; idx < NT * NT; idx += NTHR / 64) {
+        const int ti = idx / NT, tj = idx % NT;
+        if (OM == O_LOWER && tj > ti) continue;
+        int k0 = 0, k1 = kt_end;
+        if (KM == K_A_LOWER) k1 = min(k1, ti + 1);
+        if (KM == K_A_UPPER) k0 = ti;
+        if (KM == K_B_LOWER) k0 = tj;
+        if (KM == K_B_UPPER) k1 = min(k1, tj + 1);
+        real4 acc = {0.f, 0.f, 0.f, 0.f};
+        // the sum over k may run in any order as long as A and B agree: lane (r, q) takes k = 16 kt + 4 q + kk in MFMA
+        // kk, so an operand that is contiguous in k is ONE 16-byte LDS read per K-tile
+        for (int kt = k0; kt < k1; ++kt) {
+            const int kb = 16 * kt + 4 * q;
+            real av[4], bv[4];
+            if (TA) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) av[kk] = A[(kb + kk) * LD + 16 * ti + r];
+            } else {
+                const real4 t4 = *reinterpret_cast<const real4*>(A + (16 * ti + r) * LD + kb);
+                av[0] = t4[0]; av[1] = t4[1]; av[2] = t4[2]; av[3] = t4[3];
+            }
+            if (TB) {
+                const real4 t4 = *reinterpret_cast<const real4*>(B + (16 * tj + r) * LD + kb);
+                bv[0] = t4[0]; bv[1] = t4[1]; bv[2] = t4[2]; bv[3] = t4[3];
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) bv[kk] = B[(kb + kk) * LD + 16 * tj + r];
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc = mfma(av[kk], bv[kk], acc);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            real* p = C + (16 * ti + acc_row(q, e)) * LD + 16 * tj + r;
+            if (ACC) *p += alpha * acc[e]; else *p = alpha * acc[e];
+        }
+    }
+}
+
+// One 16 x 16 diagonal tile, handled by ONE wavefront (all 64 lanes run it, lanes 16..63 shadow lanes 0..15).
+// CHOL: S holds a symmetric positive definite tile (lower triangle read): on exit S = L (lower, zeros above) and
+//       Inv = L^-1.   !CHOL: S holds a lower-triangular tile, Inv = S^-1.
+// Returns sum_i log(diag_i) of the triangular factor (uniform across lanes); `bad` on a non-positive pivot.
+template <int LD, bool CHOL>
+__device__ __forceinline__ real diag_tile(real* __restrict__ S, real* __restrict__ Inv, bool& bad) {
+    const int lane = threadIdx.x & 63, i = lane & 15;
+    real a[16], rd[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] = S[i * LD + k];
+    real logsum = 0.f;
+    if (CHOL) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const real p = bcast(a[j], j);
+            bad |= !(p > 0.f);
+            const real ri = t_rsqrt<real>(p);
+            rd[j] = ri;
+            logsum += 0.5f * mf_log(p);
+            const real lij = a[j] * ri;
+            a[j] = lij;
+#pragma unroll
+            for (int k = j + 1; k < 16; ++k) a[k] -= lij * bcast(lij, k);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (lane < 16) S[i * LD + k] = (k <= i) ? a[k] : 0.f;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const real p = bcast(a[j], j);
+            bad |= !(p != 0.f);
+            rd[j] = t_rcp<real>(p);
+            logsum += mf_log((p < 0 ? -p : p));
+        }
+    }
+    // column `i` of the inverse by forward substitution; L[row][k] is lane `row`'s a[k]
+    real x[16];
+#pragma unroll
+    for (int row = 0; row < 16; ++row) {
+        real s = (row == i) ? 1.f : 0.f;
+#pragma unroll
+        for (int k = 0; k < row; ++k) s -= bcast(a[k], row) * x[k];
+        x[row] = s * rd[row];
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int row = 0; row < 16; ++row) Inv[row * LD + i] = x[row];
+    }
+    return logsum;
+}
+
+// (CHOL) S <- chol(S) lower with zeros above inside the diagonal tiles, Inv <- L^-1 (full lower, upper tiles zeroed);
+// (!CHOL) Inv <- S^-1 for lower-triangular S.  Returns log|det L| in wave 0 (valid on every lane of wave 0).
+// All threads must call; ends with a barrier.
+template <int DP, bool CHOL>
+__device__ __forceinline__ real factor_invert(real* __restrict__ S, real* __restrict__ Inv, bool& bad,
+                                               real* __restrict__ red) {
+    constexpr int LD = Geo<DP>::LD, NT = Geo<DP>::NT;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    real logdet = 0.f;
+    // zero the strictly-upper tiles of Inv
+    for (int e = threadIdx.x; e < DP * DP; e += NTHR) {
+        const int row = e / DP, col = e % DP;
+        if ((col >> 4) > (row >> 4)) Inv[row * LD + col] = 0.f;
+    }
+    if (!CHOL) {
+        // the diagonal tiles of a triangular matrix invert independently: one per wave; the per-wave
+        // log-determinants and pivot flags meet through eight words of `red`
+        real mine = 0.f;
+        bool mybad = false;
+        for (int jb = wave; jb < NT; jb += NTHR / 64)
+            mine += diag_tile<LD, false>(S + 16 * jb * LD + 16 * jb, Inv + 16 * jb * LD + 16 * jb, mybad);
+        if (lane == 0) { red[wave] = mine; red[4 + wave] = mybad ? 1.f : 0.f; }
+        __syncthreads();
+        logdet = red[0] + red[1] + red[2] + red[3];
+        bad |= (red[4] + red[5] + red[6] + red[7]) != 0.f;
+    }
+    for (int jb = 0; CHOL && jb < NT; ++jb) {
+        if (wave == 0) logdet += diag_tile<LD, CHOL>(S + 16 * jb * LD + 16 * jb, Inv + 16 * jb * LD + 16 * jb, bad);
+        __syncthreads();
+        if (CHOL) {
+            // panel: L_ij = S_ij Inv_jj^T   (one 16-deep product per tile, in place)
+            for (int ti = jb + 1 + wave; ti < NT; ti += NTHR / 64) {
+                real4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int k = 16 * jb + 4 * kk + q;
+                    const real a = S[(16 * ti + r) * LD + k];
+                    const real b = Inv[(16 * jb + r) * LD + k];          // Inv_jj[r][k] = (Inv_jj^T)[k][r]
+                    acc = mfma(a, b, acc);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) S[(16 * ti + acc_row(q, e)) * LD + 16 * jb + r] = acc[e];
+            }
+            __syncthreads();
+            // trailing update: S_ik -= L_ij L_kj^T for i >= k > jb
+            int cnt = 0;
+            for (int ti = jb + 1; ti < NT; ++ti)
+                for (int tk = jb + 1; tk <= ti; ++tk, ++cnt) {
+                    if ((cnt & 3) != wave) continue;
+                    real4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int k = 16 * jb + 4 * kk + q;
+                        const real a = S[(16 * ti + r) * LD + k];
+                        const real b = S[(16 * tk + r) * LD + k];
+                        acc = mfma(a, b, acc);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) S[(16 * ti + acc_row(q, e)) * LD + 16 * tk + r] -= acc[e];
+                }
+            __syncthreads();
+        }
+    }
+    // off-diagonal blocks of the inverse, block row by block row:  Inv_ij = -Inv_ii sum_{k=j}^{i-1} L_ik Inv_kj
+    for (int ti = 1; ti < NT; ++ti) {
+        for (int tj = wave; tj < ti; tj += NTHR / 64) {
+            real4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int kt = tj; kt < ti; ++kt) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int k = 16 * kt + 4 * kk + q;
+                    acc = mfma(S[(16 * ti + r) * LD + k], Inv[k * LD + 16 * tj + r], acc);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Inv[(16 * ti + acc_row(q, e)) * LD + 16 * tj + r] = acc[e];   // T_ij, temporarily
+        }
+        __syncthreads();
+        for (int tj = wave; tj < ti; tj += NTHR / 64) {
+            real4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int k = 4 * kk + q;
+                acc = mfma(Inv[(16 * ti + r) * LD + 16 * ti + k],
+                                                           Inv[(16 * ti + k) * LD + 16 * tj + r], acc);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Inv[(16 * ti + acc_row(q, e)) * LD + 16 * tj + r] = -acc[e];
+        }
+        __syncthreads();
+    }
+    return logdet;
+}
+
+
+// ---- vectors ---------------------------------------------------------------------------------------------------
+// out[r] = beta out[r] + alpha sum_k op(M)[r][k] v[k];  out must not alias v.  `scratch`: 4*64 floats (TRANS only).
+// Ends with a barrier.
+template <int DP, int TRANS>
+__device__ __forceinline__ void matvec(const real* __restrict__ M, const real* __restrict__ v, real* __restrict__ out,
+                                       real alpha, real beta, real* __restrict__ scratch) {
+    constexpr int LD = Geo<DP>::LD;
+    if (!TRANS) {
+        const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+        real p = 0.f;
+        if (r < DP)
+            for (int k = q; k < DP; k += 4) p += M[r * LD + k] * v[k];
+        p += __shfl_xor(p, 1);
+        p += __shfl_xor(p, 2);
+        if (q == 0 && r < DP) out[r] = (beta == 0.f ? 0.f : beta * out[r]) + alpha * p;
+        __syncthreads();
+    } else {
+        const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+        real p = 0.f;
+        if (c < DP)
+            for (int k = q; k < DP; k += 4) p += M[k * LD + c] * v[k];
+        scratch[q * 64 + c] = p;
+        __syncthreads();
+        if (threadIdx.x < DP) {
+            const int t = threadIdx.x;
+            const real sum = scratch[t] + scratch[64 + t] + scratch[128 + t] + scratch[192 + t];
+            out[t] = (beta == 0.f ? 0.f : beta * out[t]) + alpha * sum;
+        }
+        __syncthreads();
+    }
+}
+
+// sum_i v[i]^2 (i < DP), the same value on every thread
+template <int DP> __device__ __forceinline__ real sumsq(const real* __restrict__ v) {
+    const int lane = threadIdx.x & 63;
+    real x = lane < DP ? v[lane] : 0.f;
+    x *= x;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+    return x;
+}
+
+// ---- global <-> LDS ----------------------------------------------------------------------------------------------
+// tile <- g [d x d] (+ g2), zero padded; lower: the upper triangle is zeroed; idpad: identity on the padded diagonal
+template <int DP>
+__device__ __forceinline__ void load_tile(real* __restrict__ tile, const real* __restrict__ g, const real* __restrict__ g2,
+                                          int d, bool lower, bool idpad) {
+    constexpr int LD = Geo<DP>::LD;
+    for (int e = threadIdx.x; e < DP * DP; e += NTHR) {
+        const int row = e / DP, col = e % DP;
+        real v = 0.f;
+        if (row < d && col < d && (!lower || col <= row)) {
+            v = g[row * d + col];
+            if (g2) v += g2[row * d + col];
+        } else if (idpad && row == col && row >= d) {
+            v = 1.f;
+        }
+        tile[row * LD + col] = v;
+    }
+}
+// The next transition's d x d block held in registers (NE floats per thread) between its global load, issued one
+// step ahead, and its landing in an LDS tile: HBM latency is covered by a whole step of arithmetic.
+template <int DP> struct TilePrefetch {
+    static constexpr int NE = DP * DP / NTHR;
+    real v[NE];
+    __device__ __forceinline__ void load(const real* __restrict__ g, int d, bool lower, bool idpad) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = threadIdx.x + i * NTHR, row = e / DP, col = e % DP;
+            real x = 0.f;
+            if (row < d && col < d && (!lower || col <= row)) x = g[row * d + col];
+            else if (idpad && row == col && row >= d) x = 1.f;
+            v[i] = x;
+        }
+    }
+    __device__ __forceinline__ void store(real* __restrict__ tile) const {
+        constexpr int LD = Geo<DP>::LD;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = threadIdx.x + i * NTHR;
+            tile[(e / DP) * LD + (e % DP)] = v[i];
+        }
+    }
+};
+
+template <int DP> __device__ __forceinline__ void zero_tile(real* __restrict__ tile) {
+    constexpr int LD = Geo<DP>::LD;
+    for (int e = threadIdx.x; e < DP * LD; e += NTHR) tile[e] = 0.f;
+}
+template <int DP> __device__ __forceinline__ void store_tile(real* __restrict__ g, const real* __restrict__ tile, int d) {
+    constexpr int LD = Geo<DP>::LD;
+    for (int e = threadIdx.x; e < d * d; e += NTHR) g[e] = tile[(e / d) * LD + (e % d)];
+}
+template <int DP>
+__device__ __forceinline__ void load_vec_lds(real* __restrict__ v, const real* __restrict__ g, const real* __restrict__ g2, int d) {
+    if (threadIdx.x < DP) {
+        real x = 0.f;
+        if (threadIdx.x < d) { x = g[threadIdx.x]; if (g2) x += g2[threadIdx.x]; }
+        v[threadIdx.x] = x;
+    }
+}
+
+// LDS carve of one workgroup
+template <int DP> struct Smem {
+    static constexpr int TILE = Geo<DP>::TILE, LD = Geo<DP>::LD;
+    static constexpr int OBS_ROWS = MAXM_BIG;
+    static constexpr int N_TILES = 7;
+    static constexpr int FLOATS = N_TILES * TILE + 2 * OBS_ROWS * LD + MAXM_BIG * MAXM_BIG + 10 * 64 + 256 + 2 * MAXM_BIG;
+    static constexpr int BYTES = FLOATS * (int)sizeof(real);
+    real* base;
+    __device__ real* tile(int i) const { return base + i * TILE; }
+    __device__ real* Hs() const { return base + N_TILES * TILE; }
+    __device__ real* Gs() const { return Hs() + OBS_ROWS * LD; }
+    __device__ real* Rs() const { return Gs() + OBS_ROWS * LD; }
+    __device__ real* vec(int i) const { return Rs() + MAXM_BIG * MAXM_BIG + i * 64; }
+    __device__ real* scratch() const { return vec(10); }
+    __device__ real* ys() const { return scratch() + 256; }
+    __device__ real* rys() const { return ys() + MAXM_BIG; }
+};
+enum { T_PHI = 0, T_X = 1, T_GU = 2, T_U1 = 3, T_U2 = 4, T_U3 = 5, T_U4 = 6 };
+enum { V_M = 0, V_W = 1, V_BTW = 2, V_T = 3, V_Z = 4, V_GU = 5, V_RN = 6, V_TMP = 7 };
+
+// Observation terms of one block: Phi += H^T R^-1 H, tvec += H^T R^-1 y, returns y^T R^-1 y (uniform).
+// Rs already holds R^-1 when it is shared; per-step precisions are loaded here.  Ends with a barrier.
+template <int DP>
+__device__ __forceinline__ real obs_terms(const Smem<DP>& sm, real* __restrict__ Phi, real* __restrict__ tvec,
+                                           const real* __restrict__ Hk, const real* __restrict__ yk,
+                                           const real* __restrict__ Rk, int d, int m) {
+    constexpr int LD = Geo<DP>::LD;
+    const int mp = (m + 15) & ~15;
+    real *Hs = sm.Hs(), *Gs = sm.Gs(), *Rs = sm.Rs(), *ys = sm.ys(), *rys = sm.rys();
+    for (int e = threadIdx.x; e < mp * DP; e += NTHR) {
+        const int o = e / DP, i = e % DP;
+        Hs[o * LD + i] = (o < m && i < d) ? Hk[o * d + i] : 0.f;
+    }
+    if (Rk) for (int e = threadIdx.x; e < m * m; e += NTHR) Rs[e] = Rk[e];
+    if (threadIdx.x < m) ys[threadIdx.x] = yk[threadIdx.x];
+    __syncthreads();
+    for (int e = threadIdx.x; e < mp * DP; e += NTHR) {
+        const int o = e / DP, i = e % DP;
+        real g = 0.f;
+        if (o < m) for (int p = 0; p < m; ++p) g += Rs[o * m + p] * Hs[p * LD + i];
+        Gs[o * LD + i] = g;
+    }
+    if (threadIdx.x < m) {
+        real a = 0.f;
+        for (int p = 0; p < m; ++p) a += Rs[threadIdx.x * m + p] * ys[p];
+        rys[threadIdx.x] = a;
+    }
+    __syncthreads();
+    gemm<DP, 1, 0, 1, K_FULL, O_FULL>(Hs, Gs, Phi, 1.f, mp / 16);
+    if (threadIdx.x < DP) {
+        real a = 0.f;
+        for (int o = 0; o < m; ++o) a += Hs[o * LD + threadIdx.x] * rys[o];
+        tvec[threadIdx.x] += a;
+    }
+    real yry = 0.f;
+    for (int o = 0; o < m; ++o) yry += ys[o] * rys[o];
+    __syncthreads();
+    return yry;
+}
+
+// Eliminate the block whose complete pivot is in Phi: Linv -> U2, z -> V_Z, spike V -> U4 folded into GU / gU.
+template <int DP>
+__device__ __forceinline__ void eliminate(const Smem<DP>& sm, bool spike, double& logL, double& quad, bool& bad) {
+    logL += (double)factor_invert<DP, true>(sm.tile(T_PHI), sm.tile(T_U2), bad, sm.scratch());
+    matvec<DP, 0>(sm.tile(T_U2), sm.vec(V_T), sm.vec(V_Z), 1.f, 0.f, sm.scratch());
+    quad += (double)sumsq<DP>(sm.vec(V_Z));
+    if (spike) {
+        gemm<DP, 0, 0, 0, K_A_LOWER, O_FULL>(sm.tile(T_U2), sm.tile(T_X), sm.tile(T_U4), 1.f);      // V = Linv X
+        __syncthreads();
+        gemm<DP, 1, 0, 1, K_FULL, O_FULL>(sm.tile(T_U4), sm.tile(T_U4), sm.tile(T_GU), -1.f);       // GU -= V^T V
+        matvec<DP, 1>(sm.tile(T_U4), sm.vec(V_Z), sm.vec(V_GU), -1.f, 1.f, sm.scratch());           // gU -= V^T z
+    }
+}
+// After eliminate(): W is in U1, the next block's own pivot part in Phi and rhs part in V_RN.
+template <int DP> __device__ __forceinline__ void advance(const Smem<DP>& sm, bool spike) {
+    gemm<DP, 0, 1, 1, K_FULL, O_FULL>(sm.tile(T_U1), sm.tile(T_U1), sm.tile(T_PHI), -1.f);          // Phi -= W W^T
+    if (threadIdx.x < DP) sm.vec(V_T)[threadIdx.x] = sm.vec(V_RN)[threadIdx.x];
+    __syncthreads();
+    matvec<DP, 0>(sm.tile(T_U1), sm.vec(V_Z), sm.vec(V_T), -1.f, 1.f, sm.scratch());                // t = rn - W z
+    if (spike) gemm<DP, 0, 0, 0, K_FULL, O_FULL>(sm.tile(T_U1), sm.tile(T_U4), sm.tile(T_X), -1.f); // X = -W V
+    __syncthreads();
+}
+
+template <int DP>
+__device__ __forceinline__ void store_chunk_big(const Smem<DP>& sm, const RedSys<real>& out, long idx, int d, real scalar) {
+    store_tile<DP>(out.Dv + idx * d * d, sm.tile(T_PHI), d);
+    store_tile<DP>(out.GU + idx * d * d, sm.tile(T_GU), d);
+    store_tile<DP>(out.F + idx * d * d, sm.tile(T_X), d);
+    if (threadIdx.x < d) {
+        out.tv[idx * d + threadIdx.x] = sm.vec(V_T)[threadIdx.x];
+        out.gU[idx * d + threadIdx.x] = sm.vec(V_GU)[threadIdx.x];
+    }
+    if (threadIdx.x == 0) out.sc[idx] = scalar;
+}
+
+struct BigArgs {
+    long B, Tn;
+    int d, m;
+    const real *mu0, *cholP0, *A, *b, *cholQ, *H, *y, *Rinv;
+    int rinv_per_step;
+    long P, L;          // chunks per series, transitions per chunk
+    int* info;
+};
+
+// Level 0: workgroup (s, c) eliminates the transitions [c L, min((c+1) L, T-1)) of series s.
+template <int DP> __global__ void __launch_bounds__(NTHR) big_kf_chunk_kernel(BigArgs a, RedSys<real> out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const Smem<DP> sm{reinterpret_cast<real*>(smem_raw)};
+    const long id = blockIdx.x, s = id / a.P, c = id % a.P;
+    const int d = a.d, m = a.m;
+    const long nt = a.Tn - 1, tau0 = c * a.L;
+    long len = nt - tau0;
+    if (len > a.L) len = a.L;
+    if (len < 0) len = 0;
+    const bool spike = c > 0;
+    double logC = 0.0, logL = 0.0, quad = 0.0, acc_ww = 0.0, acc_yry = 0.0;
+    bool bad = false;
+    for (int i = 0; i < 3; ++i) zero_tile<DP>(sm.tile(i));
+    if (threadIdx.x < 64) { sm.vec(V_T)[threadIdx.x] = 0.f; sm.vec(V_GU)[threadIdx.x] = 0.f; }
+    if (!a.rinv_per_step) for (int e = threadIdx.x; e < m * m; e += NTHR) sm.Rs()[e] = a.Rinv[e];
+    __syncthreads();
+    real *Phi = sm.tile(T_PHI), *U1 = sm.tile(T_U1), *U2 = sm.tile(T_U2), *Ci = sm.tile(T_U3);
+
+    // pivot part Q^-1 (+ observation) and rhs part of the block a Cholesky factor C (already inverted into Ci) leads to
+    auto own_terms = [&](long blk, real* tvec) {
+        gemm<DP, 1, 0, 0, K_A_UPPER, O_FULL>(Ci, Ci, Phi, 1.f);                                   // Phi = Ci^T Ci
+        matvec<DP, 1>(Ci, sm.vec(V_W), tvec, 1.f, 0.f, sm.scratch());                             // Ci^T w
+        const real* Rk = a.rinv_per_step ? a.Rinv + (s * a.Tn + blk) * m * m : nullptr;
+        acc_yry += (double)obs_terms<DP>(sm, Phi, tvec, a.H + (s * a.Tn + blk) * m * d, a.y + (s * a.Tn + blk) * m, Rk, d, m);
+    };
+
+    if (c == 0) {   // block 0: the prior
+        load_tile<DP>(U1, a.cholP0 + s * d * d, nullptr, d, true, true);
+        load_vec_lds<DP>(sm.vec(V_M), a.mu0 + s * d, nullptr, d);
+        __syncthreads();
+        logC += (double)factor_invert<DP, false>(U1, Ci, bad, sm.scratch());
+        matvec<DP, 0>(Ci, sm.vec(V_M), sm.vec(V_W), 1.f, 0.f, sm.scratch());
+        acc_ww += (double)sumsq<DP>(sm.vec(V_W));
+        own_terms(0, sm.vec(V_T));
+    }
+    TilePrefetch<DP> pfC, pfA;
+    real pfb = 0.f;
+    auto prefetch = [&](long tau) {
+        pfC.load(a.cholQ + (s * nt + tau) * d * d, d, true, true);
+        pfA.load(a.A + (s * nt + tau) * d * d, d, false, false);
+        pfb = (threadIdx.x < d) ? a.b[(s * nt + tau) * d + threadIdx.x] : 0.f;
+    };
+    if (len > 0) prefetch(tau0);
+    for (long j = 0; j < len; ++j) {
+        const long tau = tau0 + j;
+        pfC.store(U1);
+        pfA.store(U2);
+        if (threadIdx.x < DP) sm.vec(V_M)[threadIdx.x] = pfb;
+        __syncthreads();
+        if (j + 1 < len) prefetch(tau + 1);      // in flight during the whole step
+        logC += (double)factor_invert<DP, false>(U1, Ci, bad, sm.scratch());
+        matvec<DP, 0>(Ci, sm.vec(V_M), sm.vec(V_W), 1.f, 0.f, sm.scratch());
+        acc_ww += (double)sumsq<DP>(sm.vec(V_W));
+        gemm<DP, 0, 0, 0, K_A_LOWER, O_FULL>(Ci, U2, U1, 1.f);                                    // Bm = Ci A
+        __syncthreads();
+        matvec<DP, 1>(U1, sm.vec(V_W), sm.vec(V_BTW), 1.f, 0.f, sm.scratch());                    // Bm^T w
+        if (j == 0 && spike) {
+            // the block on the left is the chunk's separator: its coupling seeds the spike
+            gemm<DP, 1, 0, 0, K_FULL, O_FULL>(U1, U1, sm.tile(T_GU), 1.f);                         // GU = Bm^T Bm
+            gemm<DP, 1, 0, 0, K_A_UPPER, O_FULL>(Ci, U1, sm.tile(T_X), -1.f);                      // X = -Ci^T Bm
+            if (threadIdx.x < DP) sm.vec(V_GU)[threadIdx.x] = -sm.vec(V_BTW)[threadIdx.x];
+            __syncthreads();
+            own_terms(tau + 1, sm.vec(V_T));
+        } else {
+            gemm<DP, 1, 0, 1, K_FULL, O_FULL>(U1, U1, Phi, 1.f);                                  // Phi += Bm^T Bm
+            if (threadIdx.x < DP) sm.vec(V_T)[threadIdx.x] -= sm.vec(V_BTW)[threadIdx.x];
+            __syncthreads();
+            eliminate<DP>(sm, spike, logL, quad, bad);
+            gemm<DP, 0, 1, 0, K_B_UPPER, O_FULL>(U1, U2, sm.tile(T_X), 1.f);                       // Y = Bm Linv^T
+            __syncthreads();
+            gemm<DP, 1, 0, 0, K_A_UPPER, O_FULL>(Ci, sm.tile(T_X), U1, -1.f);                      // W = -Ci^T Y
+            __syncthreads();
+            own_terms(tau + 1, sm.vec(V_RN));
+            advance<DP>(sm, spike);
+        }
+    }
+    store_chunk_big<DP>(sm, out, id, d, (real)(-0.5 * (acc_yry + acc_ww) + 0.5 * quad - logC - logL));
+    if (threadIdx.x == 0 && bad && a.info) atomicMax(a.info, 1);
+}
+
+// Reduction level: RedSys(n) -> RedSys(P) (FINAL: P = 1, the last block is eliminated too and out_scalar written).
+template <int DP, bool FINAL>
+__global__ void __launch_bounds__(NTHR) big_red_kernel(RedSys<real> in, RedSys<real> out, long B, long P, int d,
+                                                      real add_const, real* __restrict__ out_scalar, int* info) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const Smem<DP> sm{reinterpret_cast<real*>(smem_raw)};
+    const long id = blockIdx.x, s = id / P, c = id % P;
+    const long k0 = (c * in.n) / P, k1 = ((c + 1) * in.n) / P;
+    const bool spike = !FINAL && k0 > 0;
+    double logL = 0.0, quad = 0.0, acc_sc = 0.0;
+    bool bad = false;
+    for (int i = 0; i < 3; ++i) zero_tile<DP>(sm.tile(i));
+    if (threadIdx.x < 64) { sm.vec(V_T)[threadIdx.x] = 0.f; sm.vec(V_GU)[threadIdx.x] = 0.f; }
+    __syncthreads();
+    for (long k = k0; k < k1; ++k) {
+        const long idx = s * in.n + k;
+        const bool has_next = in.GU && (k + 1 < in.n);
+        acc_sc += in.sc ? (double)in.sc[idx] : 0.0;
+        if (k > k0) {
+            eliminate<DP>(sm, spike, logL, quad, bad);
+            load_tile<DP>(sm.tile(T_U3), in.F + (s * in.f_stride + k + in.f_off) * d * d, nullptr, d, false, false);
+            __syncthreads();
+            gemm<DP, 0, 1, 0, K_B_UPPER, O_FULL>(sm.tile(T_U3), sm.tile(T_U2), sm.tile(T_U1), 1.f);   // W = F Linv^T
+        } else if (k > 0) {
+            load_tile<DP>(sm.tile(T_X), in.F + (s * in.f_stride + k + in.f_off) * d * d, nullptr, d, false, false);
+        }
+        // the block's own pivot / rhs parts (padded diagonal = 1 keeps the padded states harmless)
+        load_tile<DP>(sm.tile(T_PHI), in.Dv + idx * d * d, has_next ? in.GU + (idx + 1) * d * d : nullptr, d, false, true);
+        load_vec_lds<DP>(sm.vec(V_RN), in.tv + idx * d, has_next ? in.gU + (idx + 1) * d : nullptr, d);
+        __syncthreads();
+        if (k > k0) {
+            advance<DP>(sm, spike);
+        } else {
+            if (threadIdx.x < DP) sm.vec(V_T)[threadIdx.x] = sm.vec(V_RN)[threadIdx.x];
+            __syncthreads();
+        }
+    }
+    if (FINAL) {
+        eliminate<DP>(sm, false, logL, quad, bad);
+        if (threadIdx.x == 0) out_scalar[s] = (real)((double)add_const + acc_sc + 0.5 * quad - logL);
+    } else {
+        store_chunk_big<DP>(sm, out, id, d, (real)(acc_sc + 0.5 * quad - logL));
+    }
+    if (threadIdx.x == 0 && bad && info) atomicMax(info, 1);
+}
+
+
+// ---- host side: workspace carving, partition choice, launches ---------------------------------------------------------------
+
+
+constexpr long BIG_RED_CHUNK = 8, BIG_RED_FINAL = 8;
+inline long cdivl(long a, long b) { return (a + b - 1) / b; }
+inline size_t align_up_big(size_t x) { return (x + 255) & ~size_t(255); }
+inline long red_elems(int d) { return 3L * d * d + 2L * d + 1; }
+inline size_t red_bytes_big(long B, long n, int d) { return align_up_big(size_t(B) * n * red_elems(d) * sizeof(real)); }
+
+inline RedSys<real> carve_big(char*& p, long B, long n, int d) {
+    RedSys<real> r;
+    real* base = reinterpret_cast<real*>(p);
+    const long nb = B * n, dd = long(d) * d;
+    r.Dv = base;
+    r.GU = r.Dv + nb * dd;
+    r.F = r.GU + nb * dd;
+    r.tv = r.F + nb * dd;
+    r.gU = r.tv + nb * d;
+    r.sc = r.gU + nb * d;
+    r.n = n;
+    r.f_stride = n;
+    r.f_off = 0;
+    p += red_bytes_big(B, n, d);
+    return r;
+}
+
+// chunks per series: enough workgroups for two rounds over the 256 CUs, chunks of at least 4 transitions
+inline void big_partition(long B, long Tn, long chunks, long& P, long& L) {
+    static const long target = [] { const char* e = std::getenv("MF_BIG_TARGET_WGS"); return e ? std::atol(e) : 512L; }();
+    const long nt = Tn - 1;
+    if (nt < 1) { P = 1; L = 1; return; }
+    long want = chunks > 0 ? chunks : cdivl(target, B);
+    const long maxP = nt / 4 > 0 ? nt / 4 : 1;
+    if (want > maxP) want = maxP;
+    if (want < 1) want = 1;
+    L = cdivl(nt, want);
+    P = cdivl(nt, L);
+}
+
+template <int DP> int launch_big(long B, long Tn, int d, int m, const real* mu0, const real* cholP0, const real* A,
+                                 const real* b, const real* cholQ, const real* H, const real* y, const real* Rinv,
+                                 int rinv_per_step, real add_const, real* out, void* ws, int* info, long P, long L,
+                                 hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
+    using SM = Smem<DP>;
+    static const bool attr_ok = [] {
+        bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&big_kf_chunk_kernel<DP>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, SM::BYTES) == hipSuccess;
+        ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&big_red_kernel<DP, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, SM::BYTES) == hipSuccess;
+        ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&big_red_kernel<DP, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, SM::BYTES) == hipSuccess;
+        return ok;
+    }();
+    if (!attr_ok) return -1000;
+    char* p = static_cast<char*>(ws);
+    RedSys<real> cur = carve_big(p, B, P, d);
+    BigArgs a{B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, L, info};
+    if (ev0) (void)hipEventRecord(ev0, st);
+    hipLaunchKernelGGL((big_kf_chunk_kernel<DP>), dim3((unsigned)(B * P)), dim3(NTHR), SM::BYTES, st, a, cur);
+    if (ev1) (void)hipEventRecord(ev1, st);
+    while (cur.n > BIG_RED_FINAL) {
+        const long Pn = cdivl(cur.n, BIG_RED_CHUNK);
+        RedSys<real> nxt = carve_big(p, B, Pn, d);
+        hipLaunchKernelGGL((big_red_kernel<DP, false>), dim3((unsigned)(B * Pn)), dim3(NTHR), SM::BYTES, st, cur,
+                           nxt, B, Pn, d, 0.f, static_cast<real*>(nullptr), info);
+        cur = nxt;
+    }
+    hipLaunchKernelGGL((big_red_kernel<DP, true>), dim3((unsigned)B), dim3(NTHR), SM::BYTES, st, cur, cur, B, 1L,
+                       d, add_const, out, info);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+
+inline size_t kf_loglik_ws(long B, long Tn, int d, long chunks) {
+    long P, L;
+    big_partition(B, Tn, chunks, P, L);
+    size_t total = red_bytes_big(B, P, d);
+    long n = P;
+    while (n > BIG_RED_FINAL) {
+        n = cdivl(n, BIG_RED_CHUNK);
+        total += red_bytes_big(B, n, d);
+    }
+    return total;
+}
+
+inline int kf_loglik(long B, long Tn, int d, int m, const real* mu0, const real* cholP0, const real* A, const real* b,
+                     const real* cholQ, const real* H, const real* y, const real* Rinv, int rinv_per_step, real add_const,
+                     real* out, void* ws, size_t ws_bytes, int* info, long chunks, hipEvent_t ev0, hipEvent_t ev1,
+                     hipStream_t st) {
+    if (m < 1 || m > MAXM_BIG) return -4;
+    if (ws == nullptr || ws_bytes < kf_loglik_ws(B, Tn, d, chunks)) return -15;
+    long P, L;
+    big_partition(B, Tn, chunks, P, L);
+#define MF_BIG_CASE(DP)                                                                                               \
+    return launch_big<DP>(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, add_const, out, ws, info, \
+                          P, L, ev0, ev1, st);
+    if (d <= 16) { MF_BIG_CASE(16) }
+    if (d <= 32) { MF_BIG_CASE(32) }
+    if constexpr (sizeof(real) == 4) {
+        if (d <= 48) { MF_BIG_CASE(48) }
+        if (d <= 64) { MF_BIG_CASE(64) }
+    }
+#undef MF_BIG_CASE
+    return -100;
+}
+
+}  // namespace MF_BIG_NS
+}  // namespace mf

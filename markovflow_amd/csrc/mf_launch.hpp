@@ -39,10 +39,15 @@ template <typename T> struct OpsTable {
 };
 
 constexpr int MF_MAX_D = 9;        // largest state dimension with a register-resident instantiation
-constexpr int MF_MAX_D_BIG = 64;   // largest state dimension of the LDS-tiled MFMA path (fp32, log-likelihood only)
+constexpr int MF_MAX_D_BIG = 64;      // largest state dimension of the LDS-tiled MFMA path, fp32 (log-likelihood only)
+constexpr int MF_MAX_D_BIG_F64 = 32;  // the same in fp64 (seven d x d tiles must fit the 160 KB of LDS)
 
 // mf_big_inst.hip
-size_t big_kf_loglik_ws(long B, long Tn, int d, long chunks);
+size_t big_kf_loglik_ws(long B, long Tn, int d, long chunks, int elem_size);
+int big_kf_loglik_f64(long B, long Tn, int d, int m, const double* mu0, const double* cholP0, const double* A,
+                      const double* b, const double* cholQ, const double* H, const double* y, const double* Rinv,
+                      int rinv_per_step, double add_const, double* out, void* ws, size_t ws_bytes, int* info, long chunks,
+                      hipEvent_t ev0, hipEvent_t ev1, hipStream_t st);
 int big_kf_loglik_f32(long B, long Tn, int d, int m, const float* mu0, const float* cholP0, const float* A, const float* b,
                       const float* cholQ, const float* H, const float* y, const float* Rinv, int rinv_per_step,
                       float add_const, float* out, void* ws, size_t ws_bytes, int* info, long chunks, hipEvent_t ev0,

@@ -77,9 +77,30 @@ def test_config5_shape_state_dim_64(rng):
     np.testing.assert_allclose(a, b, rtol=RTOL)
 
 
+@pytest.mark.parametrize("d,m,t,batch", [(10, 1, 7, (2,)), (14, 2, 30, (3,)), (16, 3, 12, ()), (24, 1, 50, (2,)),
+                                         (32, 32, 9, (1,)), (32, 2, 64, (2,))])
+def test_large_d_fp64_log_likelihood_vs_oracle(rng, d, m, t, batch):
+    """fp64 on f64 MFMA (d <= 32): same tolerance as the register-resident fp64 kernels, rtol 1e-9."""
+    kw = random_ssm(rng, batch, t, d, m, well=True)
+    cov = 0.5 * np.eye(m) + 0.1 * np.ones((m, m))
+    kf = build_kf(kw, np.linalg.cholesky(cov))
+    ref = O.kf_log_likelihood(**kw, r_inv=np.linalg.inv(cov))
+    np.testing.assert_allclose(float(kf.log_likelihood().cpu()), ref, rtol=1e-9)
+
+
+@pytest.mark.parametrize("chunks", [1, 3, 16, 70])
+def test_large_d_fp64_time_partition_invariance(rng, chunks):
+    d, m, t = 14, 1, 281       # e.g. a periodic kernel's state dimension
+    kw = random_ssm(rng, (2,), t, d, m, well=True)
+    r_inv = np.array([[2.0]])
+    ref = O.kf_log_likelihood(**kw, r_inv=r_inv, per_series=True)
+    cst = -0.5 * np.log(2 * np.pi) * m * t + 0.5 * t * np.linalg.slogdet(r_inv)[1]
+    np.testing.assert_allclose(loglik_with_chunks(kw, r_inv, chunks) + cst, ref, rtol=1e-9)
+
+
 def test_large_d_unsupported_cases_fail_loudly(rng):
-    kw = random_ssm(rng, (1,), 4, 12, 1, well=True)
-    with pytest.raises(NotImplementedError):          # fp64 beyond the register-resident sizes
+    kw = random_ssm(rng, (1,), 4, 33, 1, well=True)
+    with pytest.raises(NotImplementedError):          # fp64 beyond the sizes whose seven tiles fit the LDS
         build_kf(kw, np.eye(1)).log_likelihood()
     kw = random_ssm(rng, (1,), 4, 65, 1, well=True)
     with pytest.raises(NotImplementedError):          # beyond the LDS-tiled sizes

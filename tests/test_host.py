@@ -30,7 +30,9 @@ def test_argument_errors_without_touching_the_gpu():
     assert lib.mf_btd_cholesky_f64(1, 4, 3, None, None, None, None, None, 0, None, None) == -4
     assert lib.mf_btd_solve_f32(2, 3, 4, 3, None, None, None, None, 0, None, 0, None) == -1
     assert lib.mf_kf_loglik_workspace_bytes(1024, 10000, 6, 8, 0) > 0
-    assert lib.mf_kf_loglik_workspace_bytes(1024, 10000, 12, 8, 0) == 0
+    assert lib.mf_kf_loglik_workspace_bytes(1024, 10000, 12, 8, 0) > 0      # LDS-tiled f64 MFMA path (d <= 32)
+    assert lib.mf_kf_loglik_workspace_bytes(1024, 10000, 40, 8, 0) == 0
+    assert lib.mf_kf_loglik_workspace_bytes(1024, 10000, 64, 4, 0) > 0 and lib.mf_kf_loglik_workspace_bytes(8, 100, 65, 4, 0) == 0
     assert lib.mf_btd_cholesky_f64(0, 4, 3, None, None, None, None, None, 0, None, None) == 0   # empty batch is a no-op
 
 
