@@ -92,11 +92,14 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
                             ws_bytes, info, chunks, prof_start, prof_stop, stream);
 }
 
-#define MF_HEAD(T, B, Tn, d)                       \
-    if ((B) < 0) return -1;                        \
-    if ((Tn) < 1) return -2;                       \
-    const auto* t = table_for<T>(d);               \
-    if (!t) return (d) < 1 ? -3 : -100;            \
+// `t` = register-resident table (d <= 9) or NULL; `big` = the LDS-tile / MFMA kernels take this (d, type)
+#define MF_HEAD(T, B, Tn, d)                                                                        \
+    if ((B) < 0) return -1;                                                                         \
+    if ((Tn) < 1) return -2;                                                                        \
+    if ((d) < 1) return -3;                                                                         \
+    const auto* t = table_for<T>(d);                                                                \
+    const bool big = !t && (d) <= (sizeof(T) == 4 ? mf::MF_MAX_D_BIG : mf::MF_MAX_D_BIG_F64);       \
+    if (!t && !big) return -100;                                                                    \
     if ((B) == 0) return 0;
 
 #define MF_DEFINE(SUF, T)                                                                                              \
@@ -107,6 +110,7 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (!ldiag) return -6;                                                                                         \
         if (sub && !lsub) return -7;                                                                                   \
         if (Tn == 1) sub = nullptr;                                                                                    \
+        if (big) return mf::big_cholesky_##SUF(B, Tn, d, diag, sub, ldiag, lsub, info, S(stream));                     \
         return t->btd_cholesky(B, Tn, diag, sub, ldiag, lsub, ws, ws_bytes, info, S(stream));                          \
     }                                                                                                                  \
     int mf_btd_solve_##SUF(int64_t Bl, int64_t Br, int64_t Tn, int d, const T* ldiag, const T* lsub, const T* rhs,     \
@@ -117,6 +121,7 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (!rhs) return -7;                                                                                           \
         if (!out) return -8;                                                                                           \
         if (Tn == 1) lsub = nullptr;                                                                                   \
+        if (big) return mf::big_solve_##SUF(Bl, Br, Tn, d, ldiag, lsub, rhs, out, transpose, S(stream));               \
         return t->btd_solve(Bl, Br, Tn, ldiag, lsub, rhs, out, transpose, ws, ws_bytes, S(stream));                    \
     }                                                                                                                  \
     int mf_btd_matvec_##SUF(int64_t Bl, int64_t Br, int64_t Tn, int d, const T* diag, const T* sub, const T* x,        \
@@ -128,12 +133,14 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (!out) return -8;                                                                                           \
         if (mode < 0 || mode > 2) return -9;                                                                           \
         if (Tn == 1) sub = nullptr;                                                                                    \
+        if (big) return mf::big_matvec_##SUF(Bl, Br, Tn, d, diag, sub, x, out, mode, S(stream));                       \
         return t->btd_matvec(Bl, Br, Tn, diag, sub, x, out, mode, S(stream));                                          \
     }                                                                                                                  \
     int mf_btd_logdet_##SUF(int64_t B, int64_t Tn, int d, const T* ldiag, T* out, void* stream) {                      \
         MF_HEAD(T, B, Tn, d)                                                                                           \
         if (!ldiag) return -4;                                                                                         \
         if (!out) return -5;                                                                                           \
+        if (big) return mf::big_logdet_##SUF(B, Tn, d, ldiag, out, S(stream));                                         \
         return t->btd_logdet(B, Tn, ldiag, out, S(stream));                                                            \
     }                                                                                                                  \
     int mf_btd_logdet_quad_##SUF(int64_t B, int64_t Tn, int d, const T* diag, const T* sub, const T* rhs, T* out,      \
@@ -143,6 +150,7 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (Tn > 1 && !sub) return -5;                                                                                 \
         if (!rhs) return -6;                                                                                           \
         if (!out) return -7;                                                                                           \
+        if (big) return -100;                                                                                          \
         return t->btd_logdet_quad(B, Tn, diag, sub, rhs, out, ws, ws_bytes, info, 0, S(stream));                       \
     }                                                                                                                  \
     int mf_btd_diag_of_inverse_##SUF(int64_t B, int64_t Tn, int d, const T* ldiag, const T* lsub, T* odiag, T* osub,   \
@@ -152,6 +160,7 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (!odiag) return -6;                                                                                         \
         if (Tn == 1) lsub = nullptr;                                                                                   \
         if (!lsub) osub = nullptr;                                                                                     \
+        if (big) return mf::big_diag_of_inverse_##SUF(B, Tn, d, ldiag, lsub, odiag, osub, S(stream));                  \
         return t->btd_diag_of_inverse(B, Tn, ldiag, lsub, odiag, osub, ws, ws_bytes, S(stream));                       \
     }                                                                                                                  \
     int mf_btd_udl_##SUF(int64_t B, int64_t Tn, int d, const T* diag, const T* sub, T* ut, T* chol_d, const T* eta,    \
@@ -161,6 +170,7 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (Tn > 1 && (!sub || !ut)) return -5;                                                                        \
         if (!chol_d) return -7;                                                                                        \
         if (eta && (!m_post || !chol_dinv)) return -9;                                                                 \
+        if (big) return mf::big_udl_##SUF(B, Tn, d, diag, sub, ut, chol_d, eta, m_post, chol_dinv, info, S(stream));   \
         return t->btd_udl(B, Tn, diag, sub, ut, chol_d, eta, m_post, chol_dinv, ws, ws_bytes, info, S(stream));        \
     }                                                                                                                  \
     int mf_ssm_precision_##SUF(int64_t B, int64_t Tn, int d, int m, const T* mu0, const T* cholP0, const T* A,         \
@@ -170,9 +180,12 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (!cholP0) return -6;                                                                                        \
         if (Tn > 1 && (!A || !cholQ || !sub)) return -7;                                                               \
         if (H && !Rinv) return -12;                                                                                    \
-        if (H && (m < 1 || m > 4)) return -4;                                                                          \
+        if (H && (m < 1 || m > (big ? 32 : 4))) return -4;                                                             \
         if (!diag) return -14;                                                                                         \
         if (eta && (!mu0 || (Tn > 1 && !b))) return -5;                                                                \
+        if (big)                                                                                                       \
+            return mf::big_ssm_precision_##SUF(B, Tn, d, H ? m : 1, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step,   \
+                                               diag, sub, eta, S(stream));                                             \
         return t->ssm_precision(B, Tn, H ? m : 1, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, diag, sub, eta, \
                                 S(stream));                                                                            \
     }                                                                                                                  \
@@ -183,6 +196,7 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (Tn > 1 && !A) return -5;                                                                                   \
         if (!offs) return -6;                                                                                          \
         if (!out) return -7;                                                                                           \
+        if (big) return mf::big_means_##SUF(Bl, Br, Tn, d, A, offs, out, S(stream));                                   \
         return t->ssm_means(Bl, Br, Tn, A, offs, out, ws, ws_bytes, S(stream));                                        \
     }
 
@@ -195,6 +209,7 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (!Y) return -6;                                                                                             \
         if (y_stride < n) return -7;                                                                                   \
         if (!out) return -8;                                                                                           \
+        if (big) return mf::big_block_matmul_##SUF(B, n, d, X, x_stride, Y, y_stride, out, S(stream));                 \
         return t->block_matmul(B, n, X, x_stride, Y, y_stride, out, S(stream));                                        \
     }
 

@@ -405,7 +405,7 @@ __device__ __forceinline__ real obs_terms(const Smem<DP>& sm, real* __restrict__
         Hs[o * LD + i] = (o < m && i < d) ? Hk[o * d + i] : 0.f;
     }
     if (Rk) for (int e = threadIdx.x; e < m * m; e += NTHR) Rs[e] = Rk[e];
-    if (threadIdx.x < m) ys[threadIdx.x] = yk[threadIdx.x];
+    if (threadIdx.x < m) ys[threadIdx.x] = yk ? yk[threadIdx.x] : real(0);      // yk == NULL: precision only
     __syncthreads();
     for (int e = threadIdx.x; e < mp * DP; e += NTHR) {
         const int o = e / DP, i = e % DP;

@@ -25,4 +25,42 @@ int big_kf_loglik_f64(long B, long Tn, int d, int m, const double* mu0, const do
                            info, chunks, ev0, ev1, st);
 }
 
+
+#define MF_BIG_EXPORT(SUF, T, NS)                                                                                            \
+    int big_cholesky_##SUF(long B, long n, int d, const T* diag, const T* sub, T* ldiag, T* lsub, int* info, hipStream_t st) { \
+        return NS::op_cholesky(B, n, d, diag, sub, ldiag, lsub, info, st);                                                   \
+    }                                                                                                                        \
+    int big_solve_##SUF(long Bl, long Br, long n, int d, const T* ldiag, const T* lsub, const T* rhs, T* out, int transpose,  \
+                        hipStream_t st) {                                                                                    \
+        return NS::op_solve(Bl, Br, n, d, ldiag, lsub, rhs, out, transpose, st);                                             \
+    }                                                                                                                        \
+    int big_matvec_##SUF(long Bl, long Br, long n, int d, const T* diag, const T* sub, const T* x, T* out, int mode,          \
+                         hipStream_t st) {                                                                                   \
+        return NS::op_matvec(Bl, Br, n, d, diag, sub, x, out, mode, st);                                                     \
+    }                                                                                                                        \
+    int big_logdet_##SUF(long B, long n, int d, const T* ldiag, T* out, hipStream_t st) {                                    \
+        return NS::op_logdet(B, n, d, ldiag, out, st);                                                                       \
+    }                                                                                                                        \
+    int big_diag_of_inverse_##SUF(long B, long n, int d, const T* ldiag, const T* lsub, T* odiag, T* osub, hipStream_t st) {  \
+        return NS::op_diag_of_inverse(B, n, d, ldiag, lsub, odiag, osub, st);                                                \
+    }                                                                                                                        \
+    int big_udl_##SUF(long B, long n, int d, const T* diag, const T* sub, T* ut, T* chol_d, const T* eta, T* m_post,          \
+                      T* chol_dinv, int* info, hipStream_t st) {                                                             \
+        return NS::op_udl(B, n, d, diag, sub, ut, chol_d, eta, m_post, chol_dinv, info, st);                                 \
+    }                                                                                                                        \
+    int big_ssm_precision_##SUF(long B, long Tn, int d, int m, const T* mu0, const T* cholP0, const T* A, const T* b,         \
+                                const T* cholQ, const T* H, const T* y, const T* Rinv, int rinv_per_step, T* diag, T* sub,    \
+                                T* eta, hipStream_t st) {                                                                    \
+        return NS::op_ssm_precision(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, diag, sub, eta, st);   \
+    }                                                                                                                        \
+    int big_means_##SUF(long Bl, long Br, long Tn, int d, const T* A, const T* offs, T* out, hipStream_t st) {               \
+        return NS::op_means(Bl, Br, Tn, d, A, offs, out, st);                                                                \
+    }                                                                                                                        \
+    int big_block_matmul_##SUF(long B, long n, int d, const T* X, long xs, const T* Y, long ys, T* out, hipStream_t st) {     \
+        return NS::op_block_matmul(B, n, d, X, xs, Y, ys, out, st);                                                          \
+    }
+MF_BIG_EXPORT(f32, float, big)
+MF_BIG_EXPORT(f64, double, bigd)
+#undef MF_BIG_EXPORT
+
 }  // namespace mf
