@@ -172,6 +172,9 @@ def test_non_positive_definite_sets_info(rng):
 
 
 def test_unsupported_state_dim_fails_loudly(rng):
-    diag = np.tile(np.eye(12), (1, 3, 1, 1))
+    diag = np.tile(np.eye(40), (1, 3, 1, 1))        # fp64: register kernels to d = 9, LDS-tile kernels to d = 32
     with pytest.raises(NotImplementedError):
         mfa.SymmetricBlockTriDiagonal(tt(diag)).cholesky
+    diag = np.tile(np.eye(65), (1, 3, 1, 1))        # fp32: to d = 64
+    with pytest.raises(NotImplementedError):
+        mfa.SymmetricBlockTriDiagonal(tt(diag, torch.float32)).cholesky
