@@ -10,6 +10,7 @@
 
 #include <cstdlib>
 #include <string>
+#include <type_traits>
 
 namespace mf {
 namespace {
@@ -83,23 +84,44 @@ int reduce_levels(RedSys<T> cur, long B, char* p, T add_const, T* out, int* info
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
-// The LDS-DMA streaming kernel covers the common case: one output, a shared observation precision,
-// matrix rows that are a whole number of 16-B units, 16-B aligned tensors, at least one transition.
+// The LDS-DMA streaming kernel (mf_kf_lds.hpp) covers: up to 3 outputs with a shared observation precision,
+// or one output with per-step precisions (sites); matrix rows that are a whole number of 16-B units; 16-B aligned
+// tensors; at least one transition.  Everything else takes kf_chunk_kernel (direct loads).
+template <typename T, int M, bool RSTEP> constexpr bool lds_supported() { return KfLdsCfg<T, D, M, RSTEP>::SUPPORTED; }
 template <typename T> bool use_lds_kernel(long Tn, int m, const void* A, const void* cholQ, int rinv_per_step) {
     static const bool force_direct = [] {
         const char* e = std::getenv("MF_KF_IMPL");
         return e && std::string(e) == "direct";
     }();
-    if (force_direct) return false;
-    if (m != 1 || rinv_per_step || Tn < 2) return false;
+    if (force_direct || Tn < 2) return false;
     if ((reinterpret_cast<size_t>(A) | reinterpret_cast<size_t>(cholQ)) & 15) return false;
-    return KfLdsCfg<T, D, 1>::SUPPORTED;
+    if (rinv_per_step) return m == 1 && lds_supported<T, 1, true>();
+    switch (m) {
+        case 1: return lds_supported<T, 1, false>();
+        case 2: return lds_supported<T, 2, false>();
+        case 3: return lds_supported<T, 3, false>();
+        default: return false;
+    }
+}
+// lanes that fill the chip with this variant: one wavefront per SIMD unless the LDS image allows fewer per CU
+template <typename T> long lds_target_lanes(int m, int rinv_per_step) {
+    auto waves = [](int lds_bytes) { const int w = (160 * 1024) / lds_bytes; return w > 4 ? 4 : (w < 1 ? 1 : w); };
+    int w = 4;
+    if (rinv_per_step) w = waves(KfLdsCfg<T, D, 1, true>::LDS_TOTAL);
+    else if (m == 2) w = waves(KfLdsCfg<T, D, 2, false>::LDS_TOTAL);
+    else if (m == 3) w = waves(KfLdsCfg<T, D, 3, false>::LDS_TOTAL);
+    return 256L * 64 * w;
 }
 
 // chunks per series and transitions per chunk of the LDS kernel
-inline void lds_partition(long B, long Tn, long chunks, long& P, long& L) {
+inline void lds_partition(long B, long Tn, long chunks, long& P, long& L, long target_lanes = 65536) {
     const long nt = Tn - 1;
     long want = chunks > 0 ? chunks : auto_chunks(B, nt);
+    if (chunks <= 0 && target_lanes < 65536) {          // fewer resident waves per CU: fewer, longer chunks
+        want = cdiv(target_lanes, B);
+        const long maxP = nt / 4 > 0 ? nt / 4 : 1;
+        if (want > maxP) want = maxP;
+    }
     if (want > nt) want = nt;
     if (want < 1) want = 1;
     L = cdiv(nt, want);
@@ -109,7 +131,7 @@ inline void lds_partition(long B, long Tn, long chunks, long& P, long& L) {
 template <typename T> size_t kf_loglik_ws(long B, long Tn, long chunks) {
     const long P = chunks > 0 ? (chunks > Tn ? Tn : chunks) : auto_chunks(B, Tn);
     long P2 = 1, L2 = 1;
-    if (Tn >= 2) lds_partition(B, Tn, chunks, P2, L2);
+    if (Tn >= 2) lds_partition(B, Tn, chunks, P2, L2);      // the 4-waves-per-CU partition is the largest one
     return levels_ws<T>(B, P > P2 ? P : P2);
 }
 
@@ -119,18 +141,29 @@ int kf_loglik(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A,
               size_t ws_bytes, int* info, long chunks, hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
     if (m < 1 || m > MF_MAXM) return -4;
     if (ws_bytes < kf_loglik_ws<T>(B, Tn, chunks) || ws == nullptr) return -15;
-    if constexpr (KfLdsCfg<T, D, 1>::SUPPORTED) if (use_lds_kernel<T>(Tn, m, A, cholQ, rinv_per_step)) {
+    if (use_lds_kernel<T>(Tn, m, A, cholQ, rinv_per_step)) {
         long P, L;
-        lds_partition(B, Tn, chunks, P, L);
+        lds_partition(B, Tn, chunks, P, L, lds_target_lanes<T>(m, rinv_per_step));
         static const int dbg = [] { const char* e = std::getenv("MF_KF_DEBUG"); return e ? std::atoi(e) : 0; }();
         KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, info, dbg};
         char* p = static_cast<char*>(ws);
         RedSys<T> lvl0 = carve<T>(p, B, P);
         const dim3 grid((unsigned)cdiv(B * P, 64)), block(64);
-        constexpr int lds = KfLdsCfg<T, D, 1>::LDS_TOTAL;
         if (ev0) (void)hipEventRecord(ev0, st);
-        if (P > 1) hipLaunchKernelGGL((kf_chunk_lds_kernel<T, D, 1, true>), grid, block, lds, st, a, L, lvl0);
-        else hipLaunchKernelGGL((kf_chunk_lds_kernel<T, D, 1, false>), grid, block, lds, st, a, L, lvl0);
+        auto launch = [&](auto mtag, auto rtag) {
+            constexpr int M = decltype(mtag)::value;
+            constexpr bool RS = decltype(rtag)::value;
+            if constexpr (KfLdsCfg<T, D, M, RS>::SUPPORTED) {
+                constexpr int lds = KfLdsCfg<T, D, M, RS>::LDS_TOTAL;
+                if (P > 1) hipLaunchKernelGGL((kf_chunk_lds_kernel<T, D, M, true, RS>), grid, block, lds, st, a, L, lvl0);
+                else hipLaunchKernelGGL((kf_chunk_lds_kernel<T, D, M, false, RS>), grid, block, lds, st, a, L, lvl0);
+            }
+        };
+        using std::integral_constant;
+        if (rinv_per_step) launch(integral_constant<int, 1>{}, integral_constant<bool, true>{});
+        else if (m == 1) launch(integral_constant<int, 1>{}, integral_constant<bool, false>{});
+        else if (m == 2) launch(integral_constant<int, 2>{}, integral_constant<bool, false>{});
+        else launch(integral_constant<int, 3>{}, integral_constant<bool, false>{});
         if (ev1) (void)hipEventRecord(ev1, st);
         return reduce_levels<T>(lvl0, B, p, add_const, out, info, st);
     }

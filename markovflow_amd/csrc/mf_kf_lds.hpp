@@ -178,27 +178,34 @@ template <typename T, typename St> struct RowReader {
     }
 };
 
-template <typename T, int D, int M> struct KfLdsCfg {
+// RSTEP: the observation precision is a per-step stream [B, T, M, M] (KalmanFilterWithSites / WithSparseSites) instead of
+// one shared [M, M] matrix held in registers.
+template <typename T, int D, int M, bool RSTEP = false> struct KfLdsCfg {
     static constexpr int S = sizeof(T);
     using StA = Stream<D * D * S, KeepAll>;
     using StC = Stream<D * D * S, KeepLower<D, S>>;
     using Stb = Stream<D * S, KeepAll>;
     using StH = Stream<M * D * S, KeepAll>;
     using Sty = Stream<M * S, KeepAll>;
+    using StR = Stream<M * M * S, KeepAll>;
+    static constexpr bool RS = RSTEP;
     static constexpr int OFF_A = 0;
     static constexpr int OFF_C = OFF_A + StA::LDS_BYTES;
     static constexpr int OFF_b = OFF_C + StC::LDS_BYTES;
     static constexpr int OFF_H = OFF_b + Stb::LDS_BYTES;
     static constexpr int OFF_y = OFF_H + StH::LDS_BYTES;
-    static constexpr int OFF_relA = OFF_y + ((Sty::LDS_BYTES + 15) / 16) * 16;   // row offsets of A and cholQ
+    static constexpr int OFF_R = OFF_y + ((Sty::LDS_BYTES + 15) / 16) * 16;
+    static constexpr int OFF_relA = OFF_R + (RSTEP ? ((StR::LDS_BYTES + 15) / 16) * 16 : 0);   // row offsets of A and cholQ
     static constexpr int OFF_relb = OFF_relA + 256;
     static constexpr int OFF_relH = OFF_relb + 256;
     static constexpr int OFF_rely = OFF_relH + 256;
-    static constexpr int OFF_gtabC = OFF_rely + 256;
+    static constexpr int OFF_relR = OFF_rely + 256;
+    static constexpr int OFF_gtabC = OFF_relR + 256;
     static constexpr int LDS_TOTAL = OFF_gtabC + ((StC::U * 4 + 15) / 16) * 16;
     // the streaming kernel is instantiated only where matrix rows are whole 16-B units, the per-step DMA count
     // fits the 6-bit vm counter and the image fits 64 KB of LDS
-    static constexpr bool SUPPORTED = (D * D * S) % 16 == 0 && (StA::NI + StC::NI + Stb::NI + StH::NI + Sty::NI) < 64 &&
+    static constexpr bool SUPPORTED = (D * D * S) % 16 == 0 &&
+                                      (StA::NI + StC::NI + Stb::NI + StH::NI + Sty::NI + (RSTEP ? StR::NI : 0)) < 64 &&
                                       LDS_TOTAL <= 64 * 1024;
 };
 
@@ -207,12 +214,12 @@ template <typename T, int D, int M> struct KfLdsCfg {
 // (Counted waits - "all but the youngest n have landed" - were tried and are NOT safe here: with dword and
 // dwordx4 LDS-DMA mixed in one stream of requests the landing order did not follow the issue order.)
 template <typename Cfg> struct KfPump {
-    static constexpr int N_SMALL = Cfg::StC::NI + Cfg::Stb::NI + Cfg::StH::NI + Cfg::Sty::NI;
+    static constexpr int N_SMALL = Cfg::StC::NI + Cfg::Stb::NI + Cfg::StH::NI + Cfg::Sty::NI + (Cfg::RS ? Cfg::StR::NI : 0);
     static constexpr int N_BIG = Cfg::StA::NI;
     const DmaStream<typename Cfg::StA>& dA; const DmaStream<typename Cfg::StC>& dC;
     const DmaStream<typename Cfg::Stb>& db; const DmaStream<typename Cfg::StH>& dH;
-    const DmaStream<typename Cfg::Sty>& dy;
-    mf_v4i sA, sC, sb, sH, sy;
+    const DmaStream<typename Cfg::Sty>& dy; const DmaStream<typename Cfg::StR>& dR;
+    mf_v4i sA, sC, sb, sH, sy, sR;
     unsigned lds0;
     bool more;
     template <int K> MF_DEV void small() const {
@@ -228,6 +235,7 @@ template <typename Cfg> struct KfPump {
             db.template issue<0, 64>(sb, lds0 + Cfg::OFF_b);
             dH.template issue<0, 64>(sH, lds0 + Cfg::OFF_H);
             dy.template issue<0, 64>(sy, lds0 + Cfg::OFF_y);
+            if (Cfg::RS) dR.template issue<0, 64>(sR, lds0 + Cfg::OFF_R);
         }
     }
     template <int K> MF_DEV void all() const {
@@ -235,6 +243,7 @@ template <typename Cfg> struct KfPump {
         db.template issue<0, 64>(sb, lds0 + Cfg::OFF_b);
         dH.template issue<0, 64>(sH, lds0 + Cfg::OFF_H);
         dy.template issue<0, 64>(sy, lds0 + Cfg::OFF_y);
+        if (Cfg::RS) dR.template issue<0, 64>(sR, lds0 + Cfg::OFF_R);
         dA.template issue<0, 64>(sA, lds0 + Cfg::OFF_A);
     }
     template <int K> MF_DEV void big() const {
@@ -323,9 +332,9 @@ MF_DEV void kf_lds_step(Elim<T, D, SPIKE>& E, LogAcc<T>& laC, T& acc_yry, T& acc
 }
 
 // KfArgs::P = chunks per series, L = transitions per chunk.
-template <typename T, int D, int M, bool SPIKE>
+template <typename T, int D, int M, bool SPIKE, bool RSTEP = false>
 __global__ void __launch_bounds__(64) kf_chunk_lds_kernel(KfArgs<T> a, long L, RedSys<T> out) {
-    using Cfg = KfLdsCfg<T, D, M>;
+    using Cfg = KfLdsCfg<T, D, M, RSTEP>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const long total = a.B * a.P;
@@ -345,8 +354,9 @@ __global__ void __launch_bounds__(64) kf_chunk_lds_kernel(KfArgs<T> a, long L, R
     const unsigned long long offb = (unsigned long long)(s * nt + tau0) * (D * S);
     const unsigned long long offH = (unsigned long long)(s * a.Tn + tau0 + 1) * (M * D * S);
     const unsigned long long offy = (unsigned long long)(s * a.Tn + tau0 + 1) * (M * S);
+    const unsigned long long offR = (unsigned long long)(s * a.Tn + tau0 + 1) * (M * M * S);
     const unsigned long long offA0 = uniform64(offA), offb0 = uniform64(offb);
-    const unsigned long long offH0 = uniform64(offH), offy0 = uniform64(offy);
+    const unsigned long long offH0 = uniform64(offH), offy0 = uniform64(offy), offR0 = uniform64(offR);
     const bool rowok = valid && len > 0;
     {
         unsigned* tab = reinterpret_cast<unsigned*>(smem);
@@ -354,6 +364,7 @@ __global__ void __launch_bounds__(64) kf_chunk_lds_kernel(KfArgs<T> a, long L, R
         tab[Cfg::OFF_relb / 4 + lane] = rowok ? (unsigned)(offb - offb0) : MF_DMA_INVALID;
         tab[Cfg::OFF_relH / 4 + lane] = rowok ? (unsigned)(offH - offH0) : MF_DMA_INVALID;
         tab[Cfg::OFF_rely / 4 + lane] = rowok ? (unsigned)(offy - offy0) : MF_DMA_INVALID;
+        tab[Cfg::OFF_relR / 4 + lane] = rowok ? (unsigned)(offR - offR0) : MF_DMA_INVALID;
         if (lane < Cfg::StC::U) {
             unsigned g = 0;
             MF_UNROLL for (int cc = 0; cc < Cfg::StC::U; ++cc) if (lane == cc) g = (unsigned)Cfg::StC::global_unit(cc);
@@ -365,14 +376,17 @@ __global__ void __launch_bounds__(64) kf_chunk_lds_kernel(KfArgs<T> a, long L, R
     DmaStream<typename Cfg::Stb> db;
     DmaStream<typename Cfg::StH> dH;
     DmaStream<typename Cfg::Sty> dy;
+    DmaStream<typename Cfg::StR> dR;
     unsigned long long pA = (unsigned long long)a.A + offA0, pC = (unsigned long long)a.cholQ + offA0;
     unsigned long long pb = (unsigned long long)a.b + offb0, pH = (unsigned long long)a.H + offH0;
     unsigned long long py = (unsigned long long)a.y + offy0;
+    unsigned long long pR = (unsigned long long)a.Rinv + (RSTEP ? offR0 : 0ull);
     const unsigned long long eA = (unsigned long long)a.A + (unsigned long long)a.B * nt * (D * D * S);
     const unsigned long long eC = (unsigned long long)a.cholQ + (unsigned long long)a.B * nt * (D * D * S);
     const unsigned long long eb = (unsigned long long)a.b + (unsigned long long)a.B * nt * (D * S);
     const unsigned long long eH = (unsigned long long)a.H + (unsigned long long)a.B * a.Tn * (M * D * S);
     const unsigned long long ey = (unsigned long long)a.y + (unsigned long long)a.B * a.Tn * (M * S);
+    const unsigned long long eR = (unsigned long long)a.Rinv + (RSTEP ? (unsigned long long)a.B * a.Tn * (M * M * S) : 0ull);
     const unsigned lds0 = (unsigned)(size_t)smem;
 
     // ---- block 0 of chunk 0: the prior (plain loads; no DMA in flight yet) ------------------------------
@@ -381,8 +395,8 @@ __global__ void __launch_bounds__(64) kf_chunk_lds_kernel(KfArgs<T> a, long L, R
     LogAcc<T> laC;
     laC.init();
     T acc_yry = T(0), acc_ww = T(0);
-    T Rsh[M * M];                                  // shared observation precision, kept in registers
-    MF_UNROLL for (int i = 0; i < M * M; ++i) Rsh[i] = a.Rinv[i];
+    T Rsh[M * M];                                  // observation precision: shared (kept in registers) or this step's
+    MF_UNROLL for (int i = 0; i < M * M; ++i) Rsh[i] = RSTEP ? (valid ? a.Rinv[(s * a.Tn) * M * M + i] : T(0)) : a.Rinv[i];
     if (valid && c == 0) {
         T C[D][D], Ci[D][D], mvec[D], w[D];
         load_lower<T, D>(a.cholP0 + s * D * D, C);
@@ -411,19 +425,21 @@ __global__ void __launch_bounds__(64) kf_chunk_lds_kernel(KfArgs<T> a, long L, R
     db.init(smem, lane, Cfg::OFF_relb, 0);
     dH.init(smem, lane, Cfg::OFF_relH, 0);
     dy.init(smem, lane, Cfg::OFF_rely, 0);
+    if (RSTEP) dR.init(smem, lane, Cfg::OFF_relR, 0);
 
     const RowReader<T, typename Cfg::StA> rA(smem, Cfg::OFF_A, lane);
     const RowReader<T, typename Cfg::StC> rC(smem, Cfg::OFF_C, lane);
     const RowReader<T, typename Cfg::Stb> rb(smem, Cfg::OFF_b, lane);
     const RowReader<T, typename Cfg::StH> rH(smem, Cfg::OFF_H, lane);
     const RowReader<T, typename Cfg::Sty> ry(smem, Cfg::OFF_y, lane);
+    const RowReader<T, typename Cfg::StR> rR(smem, Cfg::OFF_R, lane);
 
     using Pump = KfPump<Cfg>;
 
     if (nsteps > 0) {   // prologue: fetch step 0
-        Pump p0{dA, dC, db, dH, dy, make_srd(pA, eA, a.debug), make_srd(pC, eC, a.debug | ((a.debug >> 2) & 1)),
+        Pump p0{dA, dC, db, dH, dy, dR, make_srd(pA, eA, a.debug), make_srd(pC, eC, a.debug | ((a.debug >> 2) & 1)),
                 make_srd(pb, eb, a.debug | ((a.debug >> 1) & 1)), make_srd(pH, eH, a.debug | ((a.debug >> 1) & 1)),
-                make_srd(py, ey, a.debug | ((a.debug >> 1) & 1)), lds0, true};
+                make_srd(py, ey, a.debug | ((a.debug >> 1) & 1)), make_srd(pR, eR, a.debug | ((a.debug >> 1) & 1)), lds0, true};
         p0.template all<0>();
     }
 
@@ -453,22 +469,24 @@ __global__ void __launch_bounds__(64) kf_chunk_lds_kernel(KfArgs<T> a, long L, R
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                              \
         MF_STAMP_AT(ts1)                                                                                              \
         const bool more = (j + 1 < nsteps);                                                                           \
-        pA += D * D * S; pC += D * D * S; pb += D * S; pH += M * D * S; py += M * S;                                  \
+        pA += D * D * S; pC += D * D * S; pb += D * S; pH += M * D * S; py += M * S; if (RSTEP) pR += M * M * S;     \
         T C[D][D], mvec[D], hk[M * D], yk[M];                                                                         \
         MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int jj = 0; jj <= i; ++jj) C[i][jj] = rC.at(i * D + jj); \
         MF_UNROLL for (int i = 0; i < D; ++i) mvec[i] = rb.at(i);                                                     \
         MF_UNROLL for (int i = 0; i < M * D; ++i) hk[i] = rH.at(i);                                                   \
         MF_UNROLL for (int i = 0; i < M; ++i) yk[i] = ry.at(i);                                                       \
+        if (RSTEP) { MF_UNROLL for (int i = 0; i < M * M; ++i) Rsh[i] = rR.at(i); }                                    \
         T Bm[D][D];                                                                                                   \
         MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int jj = 0; jj < D; ++jj) Bm[i][jj] = rA.at(i * D + jj); \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                            \
         MF_CHECKSUM_ACC                                                                                               \
         MF_STAMP_AT(ts2)                                                                                              \
-        const Pump pump{dA, dC, db, dH, dy, make_srd(pA, eA, a.debug),                                                \
+        const Pump pump{dA, dC, db, dH, dy, dR, make_srd(pA, eA, a.debug),                                            \
                         make_srd(pC, eC, a.debug | ((a.debug >> 2) & 1)),                                             \
                         make_srd(pb, eb, a.debug | ((a.debug >> 1) & 1)),                                             \
                         make_srd(pH, eH, a.debug | ((a.debug >> 1) & 1)),                                             \
-                        make_srd(py, ey, a.debug | ((a.debug >> 1) & 1)), lds0, more};                                \
+                        make_srd(py, ey, a.debug | ((a.debug >> 1) & 1)),                                             \
+                        make_srd(pR, eR, a.debug | ((a.debug >> 1) & 1)), lds0, more};                                \
         MF_NOPUMP_ISSUE                                                                                               \
         const bool active = j < len;                                                                                  \
         kf_lds_step<T, D, M, SPIKE, FIRST>(E, laC, acc_yry, acc_ww, C, mvec, hk, yk, Rsh, Bm, pump, active, c > 0);    \

@@ -277,3 +277,36 @@ def test_full_size_partition_invariance_and_linearity():
     np.testing.assert_allclose(per_auto[:2] + cst, ref, rtol=1e-9)
     total = float(kf.log_likelihood().cpu())
     np.testing.assert_allclose(total, np.sum(per_auto + cst), rtol=1e-12)
+
+
+# ---- the LDS-DMA streaming kernel beyond m = 1 / shared R (even d: rows are whole 16-B units) -----------------------------------
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("d,m,t", [(2, 2, 33), (4, 2, 50), (6, 3, 64), (8, 2, 20), (6, 2, 300), (4, 3, 129)])
+def test_streaming_kernel_multi_output(rng, dtype, d, m, t):
+    kw = random_ssm(rng, (5,), t, d, m, well=True)
+    if dtype == torch.float32:
+        kw = {k: v.astype(np.float32).astype(np.float64) for k, v in kw.items()}
+    cov = 0.5 * np.eye(m) + 0.1 * np.ones((m, m))
+    r_inv = np.linalg.inv(cov)
+    ref = O.kf_log_likelihood(**kw, r_inv=r_inv, per_series=True)
+    cst = -0.5 * np.log(2 * np.pi) * m * t + 0.5 * t * np.linalg.slogdet(r_inv)[1]
+    for chunks in (0, 1, 5):
+        got = loglik_with_chunks(kw, r_inv, chunks, dtype=dtype)
+        np.testing.assert_allclose(got + cst, ref, rtol=1e-9 if dtype == torch.float64 else 5e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("d,t", [(2, 40), (6, 257), (4, 64)])
+def test_streaming_kernel_per_step_precisions(rng, dtype, d, t):
+    """KalmanFilterWithSites-shaped call (m = 1, R^-1 per step) on the streaming kernel, several time partitions."""
+    kw = random_ssm(rng, (3,), t, d, 1, well=True)
+    if dtype == torch.float32:
+        kw = {k: v.astype(np.float32).astype(np.float64) for k, v in kw.items()}
+    prec = 0.5 + rng.random(size=(3, t, 1, 1))
+    if dtype == torch.float32:
+        prec = prec.astype(np.float32).astype(np.float64)
+    ref = O.kf_log_likelihood(**kw, r_inv=prec, log_det_obs_precision=np.sum(np.log(prec), axis=(-1, -2, -3)), per_series=True)
+    cst = -0.5 * np.log(2 * np.pi) * t + 0.5 * np.sum(np.log(prec), axis=(-1, -2, -3))
+    for chunks in (0, 1, 7):
+        got = loglik_with_chunks(kw, prec, chunks, dtype=dtype, per_step=True)
+        np.testing.assert_allclose(got + cst, ref, rtol=1e-9 if dtype == torch.float64 else 5e-4)
