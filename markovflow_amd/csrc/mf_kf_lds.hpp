@@ -186,7 +186,10 @@ template <typename T, int D, int M, bool RSTEP = false> struct KfLdsCfg {
     using StC = Stream<D * D * S, KeepLower<D, S>>;
     using Stb = Stream<D * S, KeepAll>;
     using StH = Stream<M * D * S, KeepAll>;
-    using Sty = Stream<M * S, KeepAll>;
+    // y rows are tiny (M S bytes): with one output they are fetched YG steps at a time, so a 128-B line of y is
+    // touched every YG-th step instead of every step (the memory side moves whole lines whatever part is used)
+    static constexpr int YG = (M == 1) ? 4 : 1;
+    using Sty = Stream<YG * M * S, KeepAll>;
     using StR = Stream<M * M * S, KeepAll>;
     static constexpr bool RS = RSTEP;
     static constexpr int OFF_A = 0;
@@ -222,6 +225,7 @@ template <typename Cfg> struct KfPump {
     mf_v4i sA, sC, sb, sH, sy, sR;
     unsigned lds0;
     bool more;
+    bool yfetch = true;     // this step's batch includes the next group of y rows
     template <int K> MF_DEV void small() const {
         if (!((MF_PUMPMASK >> K) & 1)) return;
         small_do<K>();
@@ -234,7 +238,7 @@ template <typename Cfg> struct KfPump {
             dC.template issue<HC, 64>(sC, lds0 + Cfg::OFF_C);
             db.template issue<0, 64>(sb, lds0 + Cfg::OFF_b);
             dH.template issue<0, 64>(sH, lds0 + Cfg::OFF_H);
-            dy.template issue<0, 64>(sy, lds0 + Cfg::OFF_y);
+            if (yfetch) dy.template issue<0, 64>(sy, lds0 + Cfg::OFF_y);
             if (Cfg::RS) dR.template issue<0, 64>(sR, lds0 + Cfg::OFF_R);
         }
     }
@@ -469,12 +473,15 @@ __global__ void __launch_bounds__(64) kf_chunk_lds_kernel(KfArgs<T> a, long L, R
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                              \
         MF_STAMP_AT(ts1)                                                                                              \
         const bool more = (j + 1 < nsteps);                                                                           \
-        pA += D * D * S; pC += D * D * S; pb += D * S; pH += M * D * S; py += M * S; if (RSTEP) pR += M * M * S;     \
+        const bool yfetch = ((j + 1) % Cfg::YG) == 0;                                                                 \
+        pA += D * D * S; pC += D * D * S; pb += D * S; pH += M * D * S; if (RSTEP) pR += M * M * S;                   \
+        if (yfetch) py += Cfg::YG * M * S;                                                                            \
         T C[D][D], mvec[D], hk[M * D], yk[M];                                                                         \
         MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int jj = 0; jj <= i; ++jj) C[i][jj] = rC.at(i * D + jj); \
         MF_UNROLL for (int i = 0; i < D; ++i) mvec[i] = rb.at(i);                                                     \
         MF_UNROLL for (int i = 0; i < M * D; ++i) hk[i] = rH.at(i);                                                   \
-        MF_UNROLL for (int i = 0; i < M; ++i) yk[i] = ry.at(i);                                                       \
+        MF_UNROLL for (int i = 0; i < M; ++i)                                                                         \
+            yk[i] = *reinterpret_cast<const T*>(ry.row + ((int)(j % Cfg::YG) * M + i) * (int)sizeof(T));              \
         if (RSTEP) { MF_UNROLL for (int i = 0; i < M * M; ++i) Rsh[i] = rR.at(i); }                                    \
         T Bm[D][D];                                                                                                   \
         MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int jj = 0; jj < D; ++jj) Bm[i][jj] = rA.at(i * D + jj); \
@@ -486,7 +493,7 @@ __global__ void __launch_bounds__(64) kf_chunk_lds_kernel(KfArgs<T> a, long L, R
                         make_srd(pb, eb, a.debug | ((a.debug >> 1) & 1)),                                             \
                         make_srd(pH, eH, a.debug | ((a.debug >> 1) & 1)),                                             \
                         make_srd(py, ey, a.debug | ((a.debug >> 1) & 1)),                                             \
-                        make_srd(pR, eR, a.debug | ((a.debug >> 1) & 1)), lds0, more};                                \
+                        make_srd(pR, eR, a.debug | ((a.debug >> 1) & 1)), lds0, more, yfetch};                        \
         MF_NOPUMP_ISSUE                                                                                               \
         const bool active = j < len;                                                                                  \
         kf_lds_step<T, D, M, SPIKE, FIRST>(E, laC, acc_yry, acc_ww, C, mvec, hk, yk, Rsh, Bm, pump, active, c > 0);    \
