@@ -74,6 +74,34 @@ class BlockTriDiagonal(abc.ABC):
         return self._sub_diag
 
     @property
+    def as_band(self) -> torch.Tensor:
+        """
+        The lower band of the represented N x N matrix, ``batch_shape + [bandwidth + 1, N]`` with row k holding the
+        k-th sub-diagonal aligned on columns (``band[k, j] = M[j + k, j]``, zero past the end) - the layout of the
+        reference's ``BandedMatrixTensor`` (block_tri_diag.py:84-98,206-237).  Nothing here consumes it: the kernels work
+        on the blocks; it exists for API parity and for interchange with band-oriented code.
+        """
+        return self._convert_to_band()
+
+    def _convert_to_band(self) -> torch.Tensor:
+        d, t = self.inner_dim, self.outer_dim
+        n, width = d * t, self.bandwidth + 1
+        dev = self._diag.device
+        k = torch.arange(width, device=dev)[:, None]
+        j = torch.arange(n, device=dev)[None, :]
+        i = j + k                                          # row of the entry
+        c, q = j // d, j % d
+        r, p = torch.clamp(i // d, max=t - 1), i % d
+        in_diag = (i < n) & (i // d == c)
+        band = torch.where(in_diag, self._diag[..., c.expand_as(i), p, q.expand_as(i)], torch.zeros((), dtype=self._diag.dtype, device=dev))
+        if self._sub_diag is not None:
+            in_sub = (i < n) & (i // d == c + 1)
+            cs = torch.clamp(c, max=max(t - 2, 0)).expand_as(i)
+            band = torch.where(in_sub, self._sub_diag[..., cs, p, q.expand_as(i)], band)
+        del r
+        return band
+
+    @property
     def _batch_numel(self) -> int:
         n = 1
         for s in self.batch_shape:
@@ -259,3 +287,27 @@ class SymmetricBlockTriDiagonal(BlockTriDiagonal):
         if eta is not None:
             m_post, chol_dinv = m_post.reshape(eta.shape), chol_dinv.reshape(self._diag.shape)
         return u_t, chol_d, m_post, chol_dinv
+
+
+def _banded_to_block_tri(banded: torch.Tensor, block_size: int) -> LowerTriangularBlockTriDiagonal:
+    """
+    Lower band ``[..., K, N]`` (K = d or 2 d rows, layout of :meth:`BlockTriDiagonal.as_band`) -> lower-triangular block
+    tridiagonal (block_tri_diag.py:549-592 of the reference).
+    """
+    d = block_size
+    width, n = banded.shape[-2], banded.shape[-1]
+    if n % d != 0 or width not in (d, 2 * d):
+        raise ValueError(f"band of shape {tuple(banded.shape)} is not block tridiagonal with block size {d}")
+    t, dev = n // d, banded.device
+    c = torch.arange(t, device=dev)[:, None, None]
+    p = torch.arange(d, device=dev)[None, :, None]
+    q = torch.arange(d, device=dev)[None, None, :]
+    col = (c * d + q).expand(t, d, d)
+    kd = (p - q).expand(t, d, d)
+    zero = torch.zeros((), dtype=banded.dtype, device=dev)
+    diag = torch.where(kd >= 0, banded[..., torch.clamp(kd, min=0), col], zero)
+    sub = None
+    if width == 2 * d:
+        ks = (d + p - q).expand(t, d, d)
+        sub = torch.where(ks < width, banded[..., torch.clamp(ks, max=width - 1), col], zero)[..., :-1, :, :]
+    return LowerTriangularBlockTriDiagonal(diag, sub)

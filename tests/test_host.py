@@ -26,7 +26,8 @@ def test_argument_errors_without_touching_the_gpu():
     # invalid sizes / NULL pointers are rejected before any launch
     assert lib.mf_btd_cholesky_f64(1, 0, 3, None, None, None, None, None, 0, None, None) == -2
     assert lib.mf_btd_cholesky_f64(1, 4, 0, None, None, None, None, None, 0, None, None) == -3
-    assert lib.mf_btd_cholesky_f64(1, 4, 12, None, None, None, None, None, 0, None, None) == -100
+    assert lib.mf_btd_cholesky_f64(1, 4, 40, None, None, None, None, None, 0, None, None) == -100   # fp64: d <= 32
+    assert lib.mf_btd_cholesky_f32(1, 4, 65, None, None, None, None, None, 0, None, None) == -100   # fp32: d <= 64
     assert lib.mf_btd_cholesky_f64(1, 4, 3, None, None, None, None, None, 0, None, None) == -4
     assert lib.mf_btd_solve_f32(2, 3, 4, 3, None, None, None, None, 0, None, 0, None) == -1
     assert lib.mf_kf_loglik_workspace_bytes(1024, 10000, 6, 8, 0) > 0
@@ -104,3 +105,31 @@ def test_synthetic_closed_forms_match_reference_expm_kernels():
     assert tuple(inp["A"].shape) == (3, 11, 6, 6) and tuple(inp["H"].shape) == (3, 12, 1, 6)
     inp9 = synthetic.make_ssm(2, 5, (5, 5, 5), output_dim=3, device="cpu")
     assert tuple(inp9["H"].shape) == (2, 5, 3, 9) and tuple(inp9["cholR"].shape) == (3, 3)
+
+
+@pytest.mark.parametrize("d,t,has_sub,batch", [(1, 1, False, ()), (3, 4, True, ()), (3, 4, False, (2,)), (2, 5, True, (2, 1))])
+def test_as_band_layout_and_round_trip(d, t, has_sub, batch):
+    """band[k, j] = M[j + k, j] (the BandedMatrixTensor layout, block_tri_diag.py:84-98) and its inverse - host-side torch."""
+    from markovflow_amd.block_tri_diag import _banded_to_block_tri
+    rng = np.random.default_rng(3)
+    diag = torch.tensor(np.tril(rng.normal(size=batch + (t, d, d))))
+    sub = torch.tensor(rng.normal(size=batch + (t - 1, d, d))) if has_sub else None
+    low = mfa.LowerTriangularBlockTriDiagonal(diag, sub)
+    band = low.as_band
+    n = d * t
+    assert tuple(band.shape) == batch + (low.bandwidth + 1, n)
+    dense = np.zeros(batch + (n, n))
+    for k in range(t):
+        dense[..., k * d:(k + 1) * d, k * d:(k + 1) * d] = diag[..., k, :, :].numpy()
+        if has_sub and k + 1 < t:
+            dense[..., (k + 1) * d:(k + 2) * d, k * d:(k + 1) * d] = sub[..., k, :, :].numpy()
+    for kk in range(low.bandwidth + 1):
+        for j in range(n):
+            want = dense[..., j + kk, j] if j + kk < n else np.zeros(batch)
+            np.testing.assert_allclose(band[..., kk, j].numpy(), want)
+    back = _banded_to_block_tri(band, d)
+    np.testing.assert_allclose(back.block_diagonal.numpy(), diag.numpy())
+    if has_sub:
+        np.testing.assert_allclose(back.block_sub_diagonal.numpy(), sub.numpy())
+    else:
+        assert back.block_sub_diagonal is None
