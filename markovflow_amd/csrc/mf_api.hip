@@ -2,6 +2,8 @@
 #include "../../include/markovflow_amd.h"
 #include "mf_launch.hpp"
 
+#include <cstdlib>
+
 namespace {
 
 template <typename T> const mf::OpsTable<T>* table_for(int d);
@@ -32,7 +34,10 @@ int kf_loglik(int64_t B, int64_t Tn, int d, int m, const T* mu0, const T* cholP0
     if (Tn < 1) return -2;
     if (d < 1) return -3;
     const auto* t = table_for<T>(d);
-    const bool big = !t && d <= (sizeof(T) == 4 ? mf::MF_MAX_D_BIG : mf::MF_MAX_D_BIG_F64);
+    // experiment knob: state dimensions >= MF_BIG_FROM take the LDS-tile / MFMA path even where a register-resident
+    // instantiation exists
+    static const int big_from = [] { const char* e = std::getenv("MF_BIG_FROM"); return e ? std::atoi(e) : 1000; }();
+    const bool big = (!t || d >= big_from) && d <= (sizeof(T) == 4 ? mf::MF_MAX_D_BIG : mf::MF_MAX_D_BIG_F64);
     if (!t && !big) return -100;
     if (m < 1 || m > (big ? 32 : 4)) return -4;
     if (B == 0) return 0;
@@ -67,12 +72,14 @@ int mf_max_state_dim(void) { return mf::MF_MAX_D; }
 size_t mf_kf_loglik_workspace_bytes(int64_t B, int64_t T, int d, int elem_size, int64_t chunks) {
     if (elem_size == 4) {
         const auto* t = table_for<float>(d);
-        if (t) return t->kf_loglik_ws(B, T, chunks);
-        return (d >= 1 && d <= mf::MF_MAX_D_BIG && B >= 1 && T >= 1) ? mf::big_kf_loglik_ws(B, T, d, chunks, 4) : 0;
+        const size_t small = t ? t->kf_loglik_ws(B, T, chunks) : 0;
+        const size_t large = (d >= 1 && d <= mf::MF_MAX_D_BIG && B >= 1 && T >= 1) ? mf::big_kf_loglik_ws(B, T, d, chunks, 4) : 0;
+        return small > large ? small : large;
     }
     const auto* t = table_for<double>(d);
-    if (t) return t->kf_loglik_ws(B, T, chunks);
-    return (d >= 1 && d <= mf::MF_MAX_D_BIG_F64 && B >= 1 && T >= 1) ? mf::big_kf_loglik_ws(B, T, d, chunks, 8) : 0;
+    const size_t small = t ? t->kf_loglik_ws(B, T, chunks) : 0;
+    const size_t large = (d >= 1 && d <= mf::MF_MAX_D_BIG_F64 && B >= 1 && T >= 1) ? mf::big_kf_loglik_ws(B, T, d, chunks, 8) : 0;
+    return small > large ? small : large;
 }
 int mf_max_state_dim_f32_loglik(void) { return mf::MF_MAX_D_BIG; }
 int mf_max_state_dim_f64_loglik(void) { return mf::MF_MAX_D_BIG_F64; }
