@@ -73,8 +73,12 @@ MF_DEV void dma_b32(mf_v4i srd, unsigned lds_addr, unsigned voff) {
 // the kernel reads ~600 B per lane per step, nowhere near LDS bandwidth, while padding would push the
 // fp64 d=6 image over a quarter of the CU's 160 KB and cost a wave of occupancy.)
 template <int ROWB, typename Keep> struct Stream {
-    static constexpr int UNIT = (ROWB % 16 == 0) ? 16 : 4;
-    static constexpr int UG = ROWB / UNIT;                       // units per row in global memory
+    // 16-B granules whenever a row holds at least one; a row that is not a whole number of them (odd d) is fetched up
+    // to the next 16-B boundary: the extra 4..12 bytes belong to the next row (or lie past the end of the tensor, where
+    // the buffer range check returns zeros) and are never read.  Rows then start 4- or 8-byte aligned, which the DMA
+    // (dword-aligned dwordx4) accepts.
+    static constexpr int UNIT = (ROWB >= 16) ? 16 : 4;
+    static constexpr int UG = (ROWB + UNIT - 1) / UNIT;          // units per row in global memory
     static constexpr int count_kept() { int n = 0; for (int u = 0; u < UG; ++u) n += Keep::keep(u, UNIT) ? 1 : 0; return n; }
     static constexpr int U = count_kept();                        // units per row kept in LDS
     static constexpr int NI = U;                                  // DMA wave-instructions per step
@@ -207,7 +211,7 @@ template <typename T, int D, int M, bool RSTEP = false> struct KfLdsCfg {
     static constexpr int LDS_TOTAL = OFF_gtabC + ((StC::U * 4 + 15) / 16) * 16;
     // the streaming kernel is instantiated only where matrix rows are whole 16-B units, the per-step DMA count
     // fits the 6-bit vm counter and the image fits 64 KB of LDS
-    static constexpr bool SUPPORTED = (D * D * S) % 16 == 0 &&
+    static constexpr bool SUPPORTED =
                                       (StA::NI + StC::NI + Stb::NI + StH::NI + Sty::NI + (RSTEP ? StR::NI : 0)) < 64 &&
                                       LDS_TOTAL <= 64 * 1024;
 };
