@@ -26,6 +26,9 @@ enum OMode { O_FULL = 0, O_LOWER = 1 };
 template <int DP, int TA, int TB, int ACC, int KM, int OM>
 __device__ __forceinline__ void gemm(const real* __restrict__ A, const real* __restrict__ B, real* __restrict__ C,
                                      real alpha, int kt_end = Geo<DP>::NT) {
+#ifdef MF_BIG_SKIP_GEMM
+    return;
+#endif
     constexpr int LD = Geo<DP>::LD, NT = Geo<DP>::NT;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     if constexpr (NT >= 3) {
@@ -128,6 +131,9 @@ __device__ __forceinline__ void gemm(const real* __restrict__ A, const real* __r
 // Returns sum_i log(diag_i) of the triangular factor (uniform across lanes); `bad` on a non-positive pivot.
 template <int LD, bool CHOL>
 __device__ __forceinline__ real diag_tile(real* __restrict__ S, real* __restrict__ Inv, bool& bad) {
+#ifdef MF_BIG_SKIP_DIAG
+    return real(0);
+#endif
     const int lane = threadIdx.x & 63, i = lane & 15;
     real a[16], rd[16];
 #pragma unroll
@@ -275,6 +281,9 @@ __device__ __forceinline__ real factor_invert(real* __restrict__ S, real* __rest
 template <int DP, int TRANS>
 __device__ __forceinline__ void matvec(const real* __restrict__ M, const real* __restrict__ v, real* __restrict__ out,
                                        real alpha, real beta, real* __restrict__ scratch) {
+#ifdef MF_BIG_SKIP_MATVEC
+    return;
+#endif
     constexpr int LD = Geo<DP>::LD;
     if (!TRANS) {
         const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
@@ -407,11 +416,23 @@ __device__ __forceinline__ real obs_terms(const Smem<DP>& sm, real* __restrict__
     if (Rk) for (int e = threadIdx.x; e < m * m; e += NTHR) Rs[e] = Rk[e];
     if (threadIdx.x < m) ys[threadIdx.x] = yk ? yk[threadIdx.x] : real(0);      // yk == NULL: precision only
     __syncthreads();
-    for (int e = threadIdx.x; e < mp * DP; e += NTHR) {
-        const int o = e / DP, i = e % DP;
-        real g = 0.f;
-        if (o < m) for (int p = 0; p < m; ++p) g += Rs[o * m + p] * Hs[p * LD + i];
-        Gs[o * LD + i] = g;
+    {   // G = R^-1 H on the matrix cores: (mp/16) x NT output tiles of 16 x 16, K = mp
+        constexpr int NT = Geo<DP>::NT;
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+        for (int idx = wave; idx < (mp / 16) * NT; idx += NTHR / 64) {
+            const int ti = idx / NT, tj = idx % NT, o = 16 * ti + r;
+            real4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int kt = 0; kt < mp / 16; ++kt) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int p = 16 * kt + 4 * q + kk;
+                    const real av = (o < m && p < m) ? Rs[o * m + p] : real(0);
+                    acc = mfma(av, Hs[p * LD + 16 * tj + r], acc);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Gs[(16 * ti + acc_row(q, e)) * LD + 16 * tj + r] = acc[e];
+        }
     }
     if (threadIdx.x < m) {
         real a = 0.f;
