@@ -70,6 +70,7 @@ int mf_version(void) { return 1; }
 int mf_max_state_dim(void) { return mf::MF_MAX_D; }
 
 size_t mf_kf_loglik_workspace_bytes(int64_t B, int64_t T, int d, int elem_size, int64_t chunks) {
+    if (B < 1 || T < 1 || d < 1) return 0;
     if (elem_size == 4) {
         const auto* t = table_for<float>(d);
         const size_t small = t ? t->kf_loglik_ws(B, T, chunks) : 0;
@@ -253,6 +254,7 @@ size_t mf_btd_udl_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {
 }
 
 size_t mf_btd_logdet_quad_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {
+    if (B < 1 || T < 1 || d < 1) return 0;
     if (elem_size == 4) { const auto* t = table_for<float>(d); return t ? t->btd_logdet_quad_ws(B, T, 0) : 0; }
     const auto* t = table_for<double>(d);
     return t ? t->btd_logdet_quad_ws(B, T, 0) : 0;

@@ -109,6 +109,8 @@ class BaseKalmanFilter(abc.ABC):
         bsz, n, d, m = a_s.shape[0], self.prior_ssm.num_transitions + 1, self.prior_ssm.state_dim, h.shape[-2]
         lib = _lib.load()
         esz = a_s.element_size()
+        if bsz == 0:                                   # empty batch: nothing to launch
+            return torch.empty(0, dtype=a_s.dtype, device=a_s.device)
         ws_bytes = int(lib.mf_kf_loglik_workspace_bytes(bsz, n, d, esz, self._chunks))
         if ws_bytes == 0:
             _lib.check(-100, "mf_kf_loglik")

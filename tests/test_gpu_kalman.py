@@ -310,3 +310,16 @@ def test_streaming_kernel_per_step_precisions(rng, dtype, d, t):
     for chunks in (0, 1, 7):
         got = loglik_with_chunks(kw, prec, chunks, dtype=dtype, per_step=True)
         np.testing.assert_allclose(got + cst, ref, rtol=1e-9 if dtype == torch.float64 else 5e-4)
+
+
+def test_empty_batch_is_a_no_op(rng):
+    """batch_shape (0,): every entry point returns empty / zero results without launching anything."""
+    t, d, m = 5, 3, 1
+    z = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=DEV)  # noqa: E731
+    ssm = mfa.StateSpaceModel(z(0, d), z(0, d, d), z(0, t - 1, d, d), z(0, t - 1, d), z(0, t - 1, d, d))
+    kf = mfa.KalmanFilter(ssm, mfa.EmissionModel(z(0, t, m, d)), z(0, t, m), torch.eye(m, dtype=torch.float64, device=DEV))
+    assert float(kf.log_likelihood()) == 0.0
+    assert tuple(ssm.marginal_means.shape) == (0, t, d)
+    assert tuple(ssm.precision.cholesky.block_diagonal.shape) == (0, t, d, d)
+    assert tuple(kf.posterior_state_space_model().marginal_covariances.shape) == (0, t, d, d)
+    assert tuple(ssm.sample(3).shape) == (3, 0, t, d)

@@ -37,6 +37,18 @@ def test_argument_errors_without_touching_the_gpu():
     assert lib.mf_btd_cholesky_f64(0, 4, 3, None, None, None, None, None, 0, None, None) == 0   # empty batch is a no-op
 
 
+def test_workspace_queries_accept_degenerate_sizes():
+    lib = _lib.load()
+    for b, t in ((0, 10), (4, 0), (0, 0), (-1, 5)):
+        assert lib.mf_kf_loglik_workspace_bytes(b, t, 6, 8, 0) == 0
+        assert lib.mf_btd_cholesky_workspace_bytes(b, t, 6, 8) == 0
+        assert lib.mf_btd_solve_workspace_bytes(max(b, 0), b, t, 6, 8) == 0
+        assert lib.mf_btd_diag_of_inverse_workspace_bytes(b, t, 6, 8) == 0
+        assert lib.mf_btd_udl_workspace_bytes(b, t, 6, 8) == 0
+        assert lib.mf_btd_logdet_quad_workspace_bytes(b, t, 6, 8) == 0
+    assert lib.mf_kf_loglik_workspace_bytes(3, 1, 6, 8, 0) > 0          # a chain of one block is legal
+
+
 def test_cpu_tensors_fail_loudly():
     d = torch.eye(3, dtype=torch.float64).expand(2, 4, 3, 3).contiguous()
     with pytest.raises(RuntimeError, match="no CPU fallback"):
