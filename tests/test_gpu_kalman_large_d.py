@@ -108,3 +108,31 @@ def test_large_d_unsupported_cases_fail_loudly(rng):
     kw = random_ssm(rng, (1,), 4, 40, 1, well=True)
     with pytest.raises(NotImplementedError):          # the operators too are limited to d <= 32 in fp64
         build_kf(kw, np.eye(1)).posterior_state_space_model()
+
+
+@pytest.mark.parametrize("dtype", [F32, torch.float64])
+def test_large_d_edge_shapes(rng, dtype):
+    """A chain of ONE block (T = 1, C ABI level: the Python classes need a transition) and more outputs than padded state
+    columns (m = 32 with d = 10)."""
+    tol = RTOL if dtype == F32 else 1e-9
+    kw = random_ssm(rng, (3,), 2, 16, 2, well=True)
+    one = {k: (v[:, :0] if k in ("a_s", "b_s", "chol_q") else (v[:, :1] if k in ("h", "y") else v)) for k, v in kw.items()}
+    if dtype == F32:
+        one = rounded(one)
+    r_inv = np.array([[2.0, 0.5], [0.5, 1.0]])
+    # oracle for T = 1: Gaussian evidence of y0 = H x0 + e
+    ref = []
+    for s in range(3):
+        p0 = one["chol_p0"][s] @ one["chol_p0"][s].T
+        h, y = one["h"][s, 0], one["y"][s, 0]
+        cov = h @ p0 @ h.T + np.linalg.inv(r_inv)
+        res = y - h @ one["mu0"][s]
+        ref.append(-0.5 * (res @ np.linalg.solve(cov, res) + np.linalg.slogdet(cov)[1] + 2 * np.log(2 * np.pi)))
+    cst = -0.5 * np.log(2 * np.pi) * 2 + 0.5 * np.linalg.slogdet(r_inv)[1]
+    np.testing.assert_allclose(loglik_with_chunks(one, r_inv, 0, dtype=dtype) + cst, ref, rtol=tol)
+    kw = random_ssm(rng, (2,), 6, 10, 32, well=True)
+    if dtype == F32:
+        kw = rounded(kw)
+    cov = 0.5 * np.eye(32)
+    ref = O.kf_log_likelihood(**kw, r_inv=np.linalg.inv(cov))
+    np.testing.assert_allclose(float(build_kf(kw, np.linalg.cholesky(cov), dtype=dtype).log_likelihood().cpu()), ref, rtol=tol)
