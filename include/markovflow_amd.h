@@ -187,6 +187,23 @@ int mf_block_matmul_f64(int64_t B, int64_t n, int d, const double* X, int64_t x_
 int mf_block_matmul_f32(int64_t B, int64_t n, int d, const float* X, int64_t x_stride, const float* Y,
                         int64_t y_stride, float* out, void* stream);
 
+/*
+ * SDE kernel -> state space model tensors on the device (the step right before the path).
+ * For a concatenation (block-diagonal state: Sum / IndependentMultiOutput / a single kernel) of `ncomp` Matern components
+ * of order orders[c] in {1, 3, 5} (Matern-1/2, 3/2, 5/2; state sizes 1, 2, 3) with lam = sqrt(order) / lengthscale and
+ * variance var:  A[s,k] = exp(F dt[s,k]) in closed form (markovflow/kernels/matern.py:66-86,299-324,434-460, block diagonal
+ * as kernels/sde_kernel.py:592-610), Q = Pinf - A Pinf A^T + jitter I (sde_kernel.py:421-446) and cholQ = its lower Cholesky
+ * factor with an exactly zero Q passed through as zero (state_space_model.py:634-656).
+ * orders is a HOST array of ncomp ints; lam / var are device arrays [ncomp] (per_series = 0) or [B, ncomp] (per_series = 1);
+ * dt [B, n]; outputs A, cholQ (nullable), Q (nullable): [B, n, d, d] with d = sum of the component sizes.
+ */
+int mf_sde_matern_transitions_f64(int64_t B, int64_t n, int ncomp, const int* orders, const double* lam, const double* var,
+                                  int per_series, const double* dt, double jitter, double* A, double* cholQ, double* Q,
+                                  void* stream);
+int mf_sde_matern_transitions_f32(int64_t B, int64_t n, int ncomp, const int* orders, const float* lam, const float* var,
+                                  int per_series, const float* dt, float jitter, float* A, float* cholQ, float* Q,
+                                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

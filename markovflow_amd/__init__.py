@@ -17,10 +17,14 @@ from .kalman_filter import (
     UnivariateGaussianSitesNat,
 )
 from .state_space_model import StateSpaceModel, state_space_model_from_covariances
+from . import kernels, models
+from .kernels import IndependentMultiOutput, Matern12, Matern32, Matern52, SDEKernel, StationaryKernel, Sum
+from .models import GaussianProcessRegression
 
 __all__ = [
     "BlockTriDiagonal", "LowerTriangularBlockTriDiagonal", "SymmetricBlockTriDiagonal", "EmissionModel",
     "GaussMarkovDistribution", "check_compatible", "BaseKalmanFilter", "GaussianSites", "KalmanFilter",
     "KalmanFilterWithSites", "KalmanFilterWithSparseSites", "UnivariateGaussianSitesNat", "StateSpaceModel",
-    "state_space_model_from_covariances",
+    "state_space_model_from_covariances", "kernels", "models", "SDEKernel", "StationaryKernel", "Matern12", "Matern32",
+    "Matern52", "Sum", "IndependentMultiOutput", "GaussianProcessRegression",
 ]

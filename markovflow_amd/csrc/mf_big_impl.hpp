@@ -165,13 +165,16 @@ __device__ __forceinline__ real diag_tile(real* __restrict__ S, real* __restrict
         }
     }
     // column `i` of the inverse by forward substitution; L[row][k] is lane `row`'s a[k]
+    // (column-oriented: once x[k] is final every later row takes its contribution - independent updates instead of one
+    // dependent accumulation chain per row)
     real x[16];
 #pragma unroll
-    for (int row = 0; row < 16; ++row) {
-        real s = (row == i) ? 1.f : 0.f;
+    for (int row = 0; row < 16; ++row) x[row] = (row == i) ? 1.f : 0.f;
 #pragma unroll
-        for (int k = 0; k < row; ++k) s -= bcast(a[k], row) * x[k];
-        x[row] = s * rd[row];
+    for (int k = 0; k < 16; ++k) {
+        x[k] *= rd[k];
+#pragma unroll
+        for (int row = k + 1; row < 16; ++row) x[row] -= bcast(a[k], row) * x[k];
     }
     if (lane < 16) {
 #pragma unroll

@@ -1,0 +1,191 @@
+// SDE kernel -> state space model on the device: for a concatenation (block-diagonal state) of
+// Matern-1/2, 3/2, 5/2 components, the transition matrices A_k = exp(F dt_k) in closed form and the Cholesky factors of
+// the process covariances Q_k = Pinf - A_k Pinf A_k^T (+ jitter I), written straight into the [B, T-1, d, d] tensors
+// StateSpaceModel takes.  Replaces, for these kernels, the TensorFlow graph of
+//   markovflow/kernels/matern.py:66-86 (Matern12), :299-324,:343-356 (Matern32), :434-460,:485-501 (Matern52),
+//   markovflow/kernels/sde_kernel.py:421-446 (transition_statistics: Q = Pinf - A Pinf A^T + jitter),
+//   markovflow/kernels/sde_kernel.py:592-610,644-658 (ConcatKernel: block-diagonal A and Pinf),
+//   markovflow/state_space_model.py:634-656 (cholesky_or_zero: an all-zero covariance passes through as zero).
+// One lane per (series, transition); every component is at most 3 x 3, so everything is register resident.
+#include "../../include/markovflow_amd.h"
+
+// No fused-multiply-add contraction in this file: Q = Pinf - A Pinf A^T must come out EXACTLY zero for a zero time gap
+// (the all-zero pass-through of cholesky_or_zero), which a contracted `P - fma(...)` breaks by one rounding error.
+#pragma STDC FP_CONTRACT OFF
+
+#include <hip/hip_runtime.h>
+
+namespace {
+
+constexpr int MAXC = 16;   // components per kernel
+struct Spec {
+    int ncomp, d;
+    int order[MAXC];       // 1, 3 or 5  (Matern-order/2)
+    int off[MAXC];         // first state index of the component
+};
+
+template <typename T> __device__ __forceinline__ T t_exp(T x);
+template <> __device__ __forceinline__ float t_exp<float>(float x) { return expf(x); }
+template <> __device__ __forceinline__ double t_exp<double>(double x) { return exp(x); }
+template <typename T> __device__ __forceinline__ T t_sqrt_(T x);
+template <> __device__ __forceinline__ float t_sqrt_<float>(float x) { return sqrtf(x); }
+template <> __device__ __forceinline__ double t_sqrt_<double>(double x) { return sqrt(x); }
+
+// A (K x K) and Pinf (K x K) of one Matern component; lam = sqrt(order) / lengthscale
+template <typename T, int K> struct Comp {
+    T A[K][K], P[K][K];
+    __device__ __forceinline__ void build(T lam, T var, T dt) {
+        const T e = t_exp<T>(-lam * dt);
+        for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) P[i][j] = T(0);
+        if (K == 1) {
+            A[0][0] = e;
+            P[0][0] = var;
+        } else if (K == 2) {
+            // F = [[0, 1], [-lam^2, -2 lam]],  A = e^{-lam dt} (I + (F + lam I) dt)        (matern.py:316-320)
+            A[0][0] = e * (T(1) + lam * dt);
+            A[0][1] = e * dt;
+            A[1][0] = -e * lam * lam * dt;
+            A[1][1] = e * (T(1) - lam * dt);
+            P[0][0] = var;
+            P[1][1] = var * lam * lam;
+        } else {
+            // F = [[0,1,0],[0,0,1],[-lam^3,-3 lam^2,-3 lam]],  N = F + lam I is nilpotent: A = e^{-lam dt}(I + N dt + N^2 dt^2/2)
+            const T l2 = lam * lam, l3 = l2 * lam;
+            const T N[3][3] = {{lam, T(1), T(0)}, {T(0), lam, T(1)}, {-l3, -T(3) * l2, -T(2) * lam}};
+            T N2[3][3];
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) {
+                    T a = T(0);
+                    for (int l = 0; l < 3; ++l) a += N[i][l] * N[l][j];
+                    N2[i][j] = a;
+                }
+            const T h = T(0.5) * dt * dt;
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) A[i][j] = e * ((i == j ? T(1) : T(0)) + N[i][j] * dt + N2[i][j] * h);
+            const T l23 = l2 / T(3);                                                        // matern.py:494-500
+            P[0][0] = var;
+            P[0][2] = -var * l23;
+            P[2][0] = -var * l23;
+            P[1][1] = var * l23;
+            P[2][2] = var * l2 * l2;
+        }
+    }
+};
+
+// writes the component's blocks of A and chol(Q) (lower; an exactly zero Q passes through as zero)
+template <typename T, int K>
+__device__ __forceinline__ void emit(const Comp<T, K>& c, T jitter, int d, int off, T* __restrict__ Ablk, T* __restrict__ Cblk,
+                                     T* __restrict__ Qblk) {
+    T AP[K][K], Q[K][K];
+    for (int i = 0; i < K; ++i)
+        for (int j = 0; j < K; ++j) {
+            T a = T(0);
+            for (int l = 0; l < K; ++l) a += c.A[i][l] * c.P[l][j];
+            AP[i][j] = a;
+        }
+    bool zero = true;
+    for (int i = 0; i < K; ++i)
+        for (int j = 0; j < K; ++j) {
+            T a = T(0);
+            for (int l = 0; l < K; ++l) a += AP[i][l] * c.A[j][l];
+            Q[i][j] = c.P[i][j] - a + (i == j ? jitter : T(0));
+        }
+    for (int i = 0; i < K; ++i)
+        for (int j = 0; j < i; ++j) { const T m = T(0.5) * (Q[i][j] + Q[j][i]); Q[i][j] = m; Q[j][i] = m; }
+    for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) zero &= (Q[i][j] == T(0));
+    T L[K][K];
+    for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) L[i][j] = T(0);
+    if (!zero) {
+        for (int j = 0; j < K; ++j) {
+            T s = Q[j][j];
+            for (int l = 0; l < j; ++l) s -= L[j][l] * L[j][l];
+            const T ljj = t_sqrt_<T>(s);
+            L[j][j] = ljj;
+            for (int i = j + 1; i < K; ++i) {
+                T v = Q[i][j];
+                for (int l = 0; l < j; ++l) v -= L[i][l] * L[j][l];
+                L[i][j] = v / ljj;
+            }
+        }
+    }
+    for (int i = 0; i < K; ++i)
+        for (int j = 0; j < K; ++j) {
+            const long idx = (long)(off + i) * d + off + j;
+            Ablk[idx] = c.A[i][j];
+            if (Cblk) Cblk[idx] = L[i][j];
+            if (Qblk) Qblk[idx] = Q[i][j];
+        }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) matern_transitions_kernel(long B, long n, Spec sp, const T* __restrict__ lam,
+                                                                 const T* __restrict__ var, long hstride,
+                                                                 const T* __restrict__ dt, T jitter, T* __restrict__ A,
+                                                                 T* __restrict__ cholQ, T* __restrict__ Q) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= B * n) return;
+    const long s = id / n;
+    const int d = sp.d;
+    const long dd = (long)d * d;
+    T* Ablk = A + id * dd;
+    T* Cblk = cholQ ? cholQ + id * dd : nullptr;
+    T* Qblk = Q ? Q + id * dd : nullptr;
+    for (long e = 0; e < dd; ++e) {
+        Ablk[e] = T(0);
+        if (Cblk) Cblk[e] = T(0);
+        if (Qblk) Qblk[e] = T(0);
+    }
+    const T delta = dt[id];
+    for (int c = 0; c < sp.ncomp; ++c) {
+        const T l = lam[s * hstride + c], v = var[s * hstride + c];
+        if (sp.order[c] == 1) { Comp<T, 1> k; k.build(l, v, delta); emit<T, 1>(k, jitter, d, sp.off[c], Ablk, Cblk, Qblk); }
+        else if (sp.order[c] == 3) { Comp<T, 2> k; k.build(l, v, delta); emit<T, 2>(k, jitter, d, sp.off[c], Ablk, Cblk, Qblk); }
+        else { Comp<T, 3> k; k.build(l, v, delta); emit<T, 3>(k, jitter, d, sp.off[c], Ablk, Cblk, Qblk); }
+    }
+}
+
+template <typename T>
+int run(int64_t B, int64_t n, int ncomp, const int* orders, const T* lam, const T* var, int per_series, const T* dt, T jitter,
+        T* A, T* cholQ, T* Q, void* stream) {
+    if (B < 0) return -1;
+    if (n < 0) return -2;
+    if (ncomp < 1 || ncomp > MAXC) return -3;
+    if (!orders) return -4;
+    Spec sp;
+    sp.ncomp = ncomp;
+    int off = 0;
+    for (int c = 0; c < ncomp; ++c) {
+        if (orders[c] != 1 && orders[c] != 3 && orders[c] != 5) return -4;
+        sp.order[c] = orders[c];
+        sp.off[c] = off;
+        off += (orders[c] + 1) / 2;
+    }
+    sp.d = off;
+    if (B == 0 || n == 0) return 0;
+    if (!lam) return -5;
+    if (!var) return -6;
+    if (!dt) return -8;
+    if (!A) return -10;
+    const long total = B * n;
+    hipLaunchKernelGGL((matern_transitions_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), (long)B, (long)n, sp, lam, var, per_series ? (long)ncomp : 0L, dt,
+                       jitter, A, cholQ, Q);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mf_sde_matern_transitions_f64(int64_t B, int64_t n, int ncomp, const int* orders, const double* lam, const double* var,
+                                  int per_series, const double* dt, double jitter, double* A, double* cholQ, double* Q,
+                                  void* stream) {
+    return run<double>(B, n, ncomp, orders, lam, var, per_series, dt, jitter, A, cholQ, Q, stream);
+}
+int mf_sde_matern_transitions_f32(int64_t B, int64_t n, int ncomp, const int* orders, const float* lam, const float* var,
+                                  int per_series, const float* dt, float jitter, float* A, float* cholQ, float* Q,
+                                  void* stream) {
+    return run<float>(B, n, ncomp, orders, lam, var, per_series, dt, jitter, A, cholQ, Q, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,345 @@
+"""
+SDE kernels -> state space models on the MI355X: the step immediately before the Kalman path.
+
+Mirror of the part of ``markovflow/kernels`` (reference) that generates the BASELINE configurations:
+``SDEKernel`` / ``StationaryKernel`` (``kernels/sde_kernel.py:43-497``), ``Matern12`` / ``Matern32`` / ``Matern52``
+(``kernels/matern.py``), ``ConcatKernel`` / ``Sum`` / ``IndependentMultiOutput`` (``sde_kernel.py:540-690,826-878``), with
+the same method names and shapes.  The transition matrices ``A_k = exp(F Δt_k)`` and the Cholesky factors of
+``Q_k = P∞ − A_k P∞ A_kᵀ`` are produced by one HIP kernel (``mf_sde_matern_transitions_*``) directly in the
+``[batch, T−1, d, d]`` layout ``StateSpaceModel`` takes; nothing else of the reference's kernels package (Product, Stack,
+Periodic, piecewise, latent-exp kernels) is mirrored.
+
+Hyper-parameters are plain tensors / floats (the reference wraps them in ``gpflow.Parameter``); a hyper-parameter may also
+carry ``batch_shape`` (one value per series), which the reference expresses with ``StackKernel``.
+"""
+import abc
+import ctypes
+import math
+from typing import List, Sequence, Tuple, Union
+
+import torch
+
+from . import _lib
+from .emission_model import EmissionModel
+from .gauss_markov import GaussMarkovDistribution
+from .state_space_model import StateSpaceModel
+
+Hyper = Union[float, torch.Tensor]
+
+
+def to_delta_time(time_points: torch.Tensor) -> torch.Tensor:
+    """``Δt_k = t_{k+1} − t_k`` (markovflow/utils.py ``to_delta_time``)."""
+    return time_points[..., 1:] - time_points[..., :-1]
+
+
+def _block_diag(blocks: Sequence[torch.Tensor]) -> torch.Tensor:
+    """Block-diagonal of matrices that share their leading dims (markovflow/utils.py ``block_diag``)."""
+    lead = torch.broadcast_shapes(*[tuple(b.shape[:-2]) for b in blocks])
+    d = sum(b.shape[-1] for b in blocks)
+    out = torch.zeros(tuple(lead) + (d, d), dtype=blocks[0].dtype, device=blocks[0].device)
+    off = 0
+    for b in blocks:
+        k = b.shape[-1]
+        out[..., off:off + k, off:off + k] = b
+        off += k
+    return out
+
+
+class SDEKernel(abc.ABC):
+    """Kernel defined by a linear SDE ``dx = F x dt + L dβ`` (sde_kernel.py:43-351)."""
+
+    def __init__(self, output_dim: int = 1, jitter: float = 0.0) -> None:
+        assert output_dim > 0, "The output dimension must be positive"     # sde_kernel.py:127-129
+        assert jitter >= 0.0, "jitter must be a non-negative float number."
+        self._output_dim = output_dim
+        self._jitter = float(jitter)
+
+    @property
+    def output_dim(self) -> int:
+        return self._output_dim
+
+    @property
+    @abc.abstractmethod
+    def state_dim(self) -> int:
+        """Dimension of the state."""
+
+    # -- what a concrete kernel provides -----------------------------------------------------------------------------
+    @abc.abstractmethod
+    def _components(self) -> List["_MaternBase"]:
+        """The Matérn components whose block-diagonal concatenation is this kernel's state."""
+
+    @abc.abstractmethod
+    def initial_mean(self, batch_shape) -> torch.Tensor:
+        """``batch_shape + [state_dim]``."""
+
+    @abc.abstractmethod
+    def initial_covariance(self, initial_time_point: torch.Tensor) -> torch.Tensor:
+        """``batch_shape + [state_dim, state_dim]``."""
+
+    # -- generic machinery ---------------------------------------------------------------------------------------------
+    @property
+    def jitter_matrix(self) -> torch.Tensor:
+        """``jitter · I`` (sde_kernel.py:332-340)."""
+        ref = self._components()[0]._variance_t
+        return self._jitter * torch.eye(self.state_dim, dtype=ref.dtype, device=ref.device)
+
+    def _device_transitions(self, time_deltas: torch.Tensor, want_chol: bool, want_cov: bool):
+        """(A, chol Q, Q) for ``time_deltas`` of shape ``batch_shape + [n]`` through the HIP kernel."""
+        comps = self._components()
+        batch = tuple(time_deltas.shape[:-1])
+        n, d = time_deltas.shape[-1], self.state_dim
+        dt = time_deltas.reshape(-1, n).contiguous()
+        bsz = dt.shape[0]
+        lam = [c._lambda.to(dtype=dt.dtype, device=dt.device) for c in comps]
+        var = [c._variance_t.to(dtype=dt.dtype, device=dt.device) for c in comps]
+        per_series = any(x.dim() > 0 for x in lam + var)
+        if per_series:
+            lam_t = torch.stack([x.expand(batch).reshape(-1) for x in lam], dim=-1).contiguous()
+            var_t = torch.stack([x.expand(batch).reshape(-1) for x in var], dim=-1).contiguous()
+        else:
+            lam_t, var_t = torch.stack(lam).contiguous(), torch.stack(var).contiguous()
+        orders = (ctypes.c_int * len(comps))(*[c.order for c in comps])
+        a_s = torch.empty((bsz, n, d, d), dtype=dt.dtype, device=dt.device)
+        chol = torch.empty_like(a_s) if want_chol else None
+        cov = torch.empty_like(a_s) if want_cov else None
+        _lib.call("mf_sde_matern_transitions", dt.dtype, bsz, n, len(comps), orders, _lib.ptr(lam_t), _lib.ptr(var_t),
+                  int(per_series), _lib.ptr(dt), self._jitter, _lib.ptr(a_s), _lib.ptr(chol), _lib.ptr(cov),
+                  _lib.stream_ptr(dt.device))
+        shape = batch + (n, d, d)
+        return (a_s.reshape(shape), None if chol is None else chol.reshape(shape),
+                None if cov is None else cov.reshape(shape))
+
+    def state_transitions(self, transition_times: torch.Tensor, time_deltas: torch.Tensor) -> torch.Tensor:
+        """``A_k = exp(F Δt_k)``, ``batch_shape + [num_transitions, state_dim, state_dim]`` (sde_kernel.py:299-310)."""
+        return self._device_transitions(time_deltas, False, False)[0]
+
+    def process_covariances(self, transition_times: torch.Tensor, time_deltas: torch.Tensor) -> torch.Tensor:
+        """``Q_k`` (sde_kernel.py:312-330)."""
+        return self._device_transitions(time_deltas, False, True)[2]
+
+    def transition_statistics(self, transition_times: torch.Tensor, time_deltas: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """``(A_k, Q_k)`` with ``Q_k = P∞ − A_k P∞ A_kᵀ + jitter`` (sde_kernel.py:421-446)."""
+        a_s, _, q_s = self._device_transitions(time_deltas, False, True)
+        return a_s, q_s
+
+    def transition_statistics_from_time_points(self, time_points: torch.Tensor):
+        """sde_kernel.py:253-265."""
+        return self.transition_statistics(time_points[..., :-1], to_delta_time(time_points))
+
+    def state_offsets(self, transition_times: torch.Tensor, time_deltas: torch.Tensor) -> torch.Tensor:
+        """``b_k = (I − A_k) m`` for a state mean ``m`` (sde_kernel.py:460-475); zero for a zero mean."""
+        mean = self.initial_mean(tuple(time_deltas.shape[:-1]))
+        if not bool(torch.any(mean != 0)):
+            return torch.zeros(tuple(time_deltas.shape) + (self.state_dim,), dtype=time_deltas.dtype, device=time_deltas.device)
+        a_s = self.state_transitions(transition_times, time_deltas)
+        m = mean[..., None, :].to(dtype=a_s.dtype, device=a_s.device)
+        return m - torch.matmul(a_s, m[..., None])[..., 0]
+
+    def state_space_model(self, time_points: torch.Tensor) -> StateSpaceModel:
+        """The chain this kernel induces on ``time_points`` (``batch_shape + [num_data]``, strictly increasing)
+        (sde_kernel.py:153-171).  The Cholesky factors come straight from the device kernel (zero covariances pass
+        through as zero, as in ``state_space_model_from_covariances``)."""
+        batch = tuple(time_points.shape[:-1])
+        deltas = to_delta_time(time_points)
+        a_s, chol_q, _ = self._device_transitions(deltas, True, False)
+        p0 = self.initial_covariance(time_points[..., 0:1]).to(dtype=a_s.dtype, device=a_s.device)
+        p0 = p0.expand(batch + tuple(p0.shape[-2:])).contiguous()
+        return StateSpaceModel(
+            initial_mean=self.initial_mean(batch).to(dtype=a_s.dtype, device=a_s.device).expand(batch + (self.state_dim,)).contiguous(),
+            chol_initial_covariance=torch.linalg.cholesky(p0),
+            state_transitions=a_s,
+            state_offsets=self.state_offsets(time_points[..., :-1], deltas).to(dtype=a_s.dtype),
+            chol_process_covariances=chol_q,
+        )
+
+    def build_finite_distribution(self, time_points: torch.Tensor) -> GaussMarkovDistribution:
+        """sde_kernel.py:140-151."""
+        return self.state_space_model(time_points)
+
+    def generate_emission_model(self, time_points: torch.Tensor) -> EmissionModel:
+        """``H = [1, 0, 0, …]`` tiled over the time points (sde_kernel.py:173-211)."""
+        h = torch.zeros((self.output_dim, self.state_dim), dtype=time_points.dtype, device=time_points.device)
+        h[:, 0] = 1.0
+        return EmissionModel(h.expand(tuple(time_points.shape) + h.shape).contiguous())
+
+    def __add__(self, other: "SDEKernel") -> "Sum":
+        assert self.output_dim == other.output_dim                         # sde_kernel.py:342-345
+        return Sum([self, other])
+
+
+class StationaryKernel(SDEKernel, abc.ABC):
+    """Stationary SDE kernel: constant feedback matrix ``F`` and steady state covariance ``P∞`` (sde_kernel.py:353-497)."""
+
+    @property
+    @abc.abstractmethod
+    def feedback_matrix(self) -> torch.Tensor:
+        """``F``, ``[state_dim, state_dim]`` (leading batch dims if a hyper-parameter has them)."""
+
+    @property
+    @abc.abstractmethod
+    def steady_state_covariance(self) -> torch.Tensor:
+        """``P∞``."""
+
+    def initial_mean(self, batch_shape) -> torch.Tensor:
+        ref = self._components()[0]._variance_t
+        return torch.zeros(tuple(batch_shape) + (self.state_dim,), dtype=ref.dtype, device=ref.device)
+
+    def initial_covariance(self, initial_time_point: torch.Tensor) -> torch.Tensor:
+        """``P∞ + jitter`` (sde_kernel.py:402-419)."""
+        assert initial_time_point.shape[-1] == 1
+        p = self.steady_state_covariance
+        batch = tuple(initial_time_point.shape[:-1])
+        return p.expand(torch.broadcast_shapes(batch + p.shape[-2:], p.shape)) + self.jitter_matrix
+
+
+class _MaternBase(StationaryKernel):
+    order = 0   # Matérn-order/2
+
+    def __init__(self, lengthscale: Hyper, variance: Hyper, output_dim: int = 1, jitter: float = 0.0, device=None,
+                 dtype=torch.float64) -> None:
+        super().__init__(output_dim, jitter)
+        dev = device if device is not None else (lengthscale.device if isinstance(lengthscale, torch.Tensor) else "cpu")
+        self._lengthscale_t = torch.as_tensor(lengthscale, dtype=dtype, device=dev)
+        self._variance_t = torch.as_tensor(variance, dtype=dtype, device=dev)
+        if bool(torch.any(self._lengthscale_t <= 0)) or bool(torch.any(self._variance_t <= 0)):
+            raise ValueError("lengthscale and variance must be positive.")   # matern.py:52-56
+
+    @property
+    def state_dim(self) -> int:
+        return (self.order + 1) // 2
+
+    @property
+    def lengthscale(self) -> torch.Tensor:
+        return self._lengthscale_t
+
+    @property
+    def variance(self) -> torch.Tensor:
+        return self._variance_t
+
+    @property
+    def _lambda(self) -> torch.Tensor:
+        return math.sqrt(self.order) / self._lengthscale_t
+
+    def _components(self):
+        return [self]
+
+
+class Matern12(_MaternBase):
+    """Matérn-1/2 (exponential / Ornstein–Uhlenbeck) kernel (matern.py:27-127): ``F = −1/ℓ``, ``P∞ = σ²``."""
+    order = 1
+
+    @property
+    def feedback_matrix(self) -> torch.Tensor:
+        return (-1.0 / self._lengthscale_t)[..., None, None]
+
+    @property
+    def steady_state_covariance(self) -> torch.Tensor:
+        return self._variance_t[..., None, None].clone()
+
+
+class Matern32(_MaternBase):
+    """Matérn-3/2 kernel (matern.py:237-373): ``F = [[0, 1], [−λ², −2λ]]``, ``P∞ = σ² diag(1, λ²)``, ``λ = √3/ℓ``."""
+    order = 3
+
+    @property
+    def feedback_matrix(self) -> torch.Tensor:
+        lam = self._lambda
+        f = torch.zeros(tuple(lam.shape) + (2, 2), dtype=lam.dtype, device=lam.device)
+        f[..., 0, 1] = 1.0
+        f[..., 1, 0] = -lam ** 2
+        f[..., 1, 1] = -2 * lam
+        return f
+
+    @property
+    def steady_state_covariance(self) -> torch.Tensor:
+        lam, var = self._lambda, self._variance_t
+        p = torch.zeros(tuple(torch.broadcast_shapes(lam.shape, var.shape)) + (2, 2), dtype=lam.dtype, device=lam.device)
+        p[..., 0, 0] = var
+        p[..., 1, 1] = var * lam ** 2
+        return p
+
+
+class Matern52(_MaternBase):
+    """Matérn-5/2 kernel (matern.py:376-518): ``F = [[0,1,0],[0,0,1],[−λ³,−3λ²,−3λ]]``, ``λ = √5/ℓ``."""
+    order = 5
+
+    @property
+    def feedback_matrix(self) -> torch.Tensor:
+        lam = self._lambda
+        f = torch.zeros(tuple(lam.shape) + (3, 3), dtype=lam.dtype, device=lam.device)
+        f[..., 0, 1] = 1.0
+        f[..., 1, 2] = 1.0
+        f[..., 2, 0] = -lam ** 3
+        f[..., 2, 1] = -3 * lam ** 2
+        f[..., 2, 2] = -3 * lam
+        return f
+
+    @property
+    def steady_state_covariance(self) -> torch.Tensor:
+        lam, var = self._lambda, self._variance_t
+        l23 = lam ** 2 / 3.0
+        p = torch.zeros(tuple(torch.broadcast_shapes(lam.shape, var.shape)) + (3, 3), dtype=lam.dtype, device=lam.device)
+        p[..., 0, 0] = var
+        p[..., 0, 2] = -var * l23
+        p[..., 2, 0] = -var * l23
+        p[..., 1, 1] = var * l23
+        p[..., 2, 2] = var * lam ** 4
+        return p
+
+
+class ConcatKernel(StationaryKernel, abc.ABC):
+    """State = concatenation of the child states; ``A``, ``F``, ``P∞`` block diagonal (sde_kernel.py:540-658)."""
+
+    def __init__(self, kernels: List[SDEKernel], jitter: float = 0.0):
+        assert kernels, "There must be at least one child kernel."           # sde_kernel.py:566-571
+        assert all(k.output_dim == kernels[0].output_dim for k in kernels), "All kernels must have the same output dimension"
+        self._kernels = list(kernels)
+        super().__init__(self._kernels[0].output_dim, jitter)
+
+    @property
+    def kernels(self) -> List[SDEKernel]:
+        return self._kernels
+
+    @property
+    def state_dim(self) -> int:
+        return sum(k.state_dim for k in self._kernels)
+
+    def _components(self):
+        return [c for k in self._kernels for c in k._components()]
+
+    def initial_mean(self, batch_shape) -> torch.Tensor:
+        return torch.cat([k.initial_mean(batch_shape) for k in self._kernels], dim=-1)
+
+    @property
+    def feedback_matrix(self) -> torch.Tensor:
+        return _block_diag([k.feedback_matrix for k in self._kernels])
+
+    @property
+    def steady_state_covariance(self) -> torch.Tensor:
+        return _block_diag([k.steady_state_covariance for k in self._kernels])
+
+
+class Sum(ConcatKernel):
+    """Sum of kernels: ``H = [H₁, H₂, …]`` (sde_kernel.py:660-688)."""
+
+    def generate_emission_model(self, time_points: torch.Tensor) -> EmissionModel:
+        return EmissionModel(torch.cat([k.generate_emission_model(time_points).emission_matrix for k in self._kernels], dim=-1))
+
+
+class IndependentMultiOutput(ConcatKernel):
+    """Independent outputs, one child kernel each: ``H = H₁ ⊕ H₂ ⊕ …`` (sde_kernel.py:826-878)."""
+
+    def __init__(self, kernels: List[SDEKernel], jitter: float = 0.0):
+        super().__init__(kernels, jitter)
+        self._output_dim = sum(k.output_dim for k in kernels)                # sde_kernel.py:843-845
+
+    def generate_emission_model(self, time_points: torch.Tensor) -> EmissionModel:
+        mats = [k.generate_emission_model(time_points).emission_matrix for k in self._kernels]
+        lead = tuple(time_points.shape)
+        out = torch.zeros(lead + (self.output_dim, self.state_dim), dtype=mats[0].dtype, device=mats[0].device)
+        r = c = 0
+        for m in mats:
+            out[..., r:r + m.shape[-2], c:c + m.shape[-1]] = m
+            r += m.shape[-2]
+            c += m.shape[-1]
+        return EmissionModel(out)

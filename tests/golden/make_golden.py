@@ -19,6 +19,9 @@ Fixtures:
                            time-invariant step so the numpy filter applies.
   btd_d{d}_T{T}_sub{0,1}.npz  random SPD block-tridiagonal matrices built like
                            tests/unit/test_block_tri_diag.py:274-295 + dense numpy.linalg answers.
+  kernels_matern_T24.npz   Matern12/32/52Test (closed form / scipy expm) of the reference's test tools on random, irregular
+                           time points (batch (2,)): A_k, Q_k = Pinf - A Pinf A^T, Pinf per kernel; hyper-parameters of
+                           tests/unit/kernels (variance, length scale drawn once).
   ssm_T5_d3.npz            random SSM pair + dense joint-Gaussian answers (means, covs, logdet, KL, log_pdf)
                            following tests/unit/test_state_space_model.py:40-235.
 """
@@ -281,6 +284,23 @@ def make_ssm_fixture():
     )
 
 
+def make_kernels_fixture():
+    np.random.seed(DEFAULT_SEED + 7)
+    batch, n = (2,), 24
+    t = gro.generate_random_time_points(expected_range=6.0, shape=batch + (n,))
+    dts = np.diff(t, axis=-1)
+    out = {"t": t}
+    for name, cls in (("m12", rkern.Matern12Test), ("m32", rkern.Matern32Test), ("m52", rkern.Matern52Test)):
+        variance, length_scale = float(np.random.uniform(0.5, 2.0)), float(np.random.uniform(0.5, 2.0))
+        kern = cls(variance, length_scale, rkern.DataShape(batch, n))
+        out[f"{name}_variance"], out[f"{name}_length_scale"] = variance, length_scale
+        out[f"{name}_A"] = kern.state_transitions(t[..., :-1], dts)
+        out[f"{name}_Q"] = kern.process_covariances(t[..., :-1], dts)
+        out[f"{name}_Pinf"] = kern.steady_state_covariance()
+        out[f"{name}_P0"] = kern.initial_covariance()
+    np.savez(os.path.join(OUT, "kernels_matern_T24.npz"), **out)
+
+
 if __name__ == "__main__":
     for shape, tag in (((), "0"), ((3,), "3"), ((2, 1), "2x1")):
         make_kf_fixture(shape, tag)
@@ -292,4 +312,5 @@ if __name__ == "__main__":
                     (6, 64, True), (9, 64, True)):
         make_btd_fixture(d, n, s)
     make_ssm_fixture()
+    make_kernels_fixture()
     print("golden fixtures written to", OUT)
