@@ -204,6 +204,25 @@ int mf_sde_matern_transitions_f32(int64_t B, int64_t n, int ncomp, const int* or
                                   int per_series, const float* dt, float jitter, float* A, float* cholQ, float* Q,
                                   void* stream);
 
+/*
+ * GaussianProcessRegression.log_likelihood (markovflow/models/gaussian_process_regression.py:150-160) for a Matern kernel or
+ * a Sum of two, with the kernel -> state-space-model step FUSED into the Kalman sweep: A_k and chol(Q_k) are generated in
+ * registers from dt_k = t_{k+1} - t_k, so a step reads 16 bytes (t, y) instead of the materialised tensors.  One output,
+ * zero mean function, H = [1 0 .. | 1 0 ..].  Arguments as mf_sde_matern_transitions (orders: HOST array, ncomp <= 2) plus
+ * time points t [B,T] (strictly increasing), observations y [B,T], rinv [1] (device: 1 / noise variance); out[s] as
+ * mf_kf_loglik (add_const carries -T/2 log 2 pi + T/2 log rinv).  Workspace: mf_kf_loglik_workspace_bytes(B, T, d, ...).
+ * Returns -101 when the component signature is not instantiated (supported: (1), (3), (5), (3,3), (5,3), (3,5), (5,5));
+ * the caller then materialises the model (mf_sde_matern_transitions + mf_kf_loglik).
+ */
+int mf_gpr_matern_loglik_f64(int64_t B, int64_t T, int ncomp, const int* orders, const double* lam, const double* var,
+                             int per_series, const double* t, const double* y, const double* rinv, double jitter,
+                             double add_const, double* out, void* ws, size_t ws_bytes, int* info, int64_t chunks,
+                             void* prof_start, void* prof_stop, void* stream);
+int mf_gpr_matern_loglik_f32(int64_t B, int64_t T, int ncomp, const int* orders, const float* lam, const float* var,
+                             int per_series, const float* t, const float* y, const float* rinv, float jitter,
+                             float add_const, float* out, void* ws, size_t ws_bytes, int* info, int64_t chunks,
+                             void* prof_start, void* prof_stop, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

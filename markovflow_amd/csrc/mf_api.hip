@@ -221,10 +221,39 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         return t->block_matmul(B, n, X, x_stride, Y, y_stride, out, S(stream));                                        \
     }
 
+#define MF_DEFINE3(SUF, T)                                                                                             \
+    int mf_gpr_matern_loglik_##SUF(int64_t B, int64_t Tn, int ncomp, const int* orders, const T* lam, const T* var,    \
+                                   int per_series, const T* t_pts, const T* y, const T* rinv, T jitter, T add_const,   \
+                                   T* out, void* ws, size_t ws_bytes, int* info, int64_t chunks, void* prof_start,     \
+                                   void* prof_stop, void* stream) {                                                    \
+        if (B < 0) return -1;                                                                                          \
+        if (Tn < 1) return -2;                                                                                         \
+        if (ncomp < 1 || !orders) return -3;                                                                           \
+        int d = 0;                                                                                                     \
+        for (int c = 0; c < ncomp; ++c) {                                                                              \
+            if (orders[c] != 1 && orders[c] != 3 && orders[c] != 5) return -4;                                         \
+            d += (orders[c] + 1) / 2;                                                                                  \
+        }                                                                                                              \
+        const auto* t = table_for<T>(d);                                                                               \
+        if (!t || ncomp > 2) return -101;                                                                              \
+        if (B == 0) return 0;                                                                                          \
+        if (!lam) return -5;                                                                                           \
+        if (!var) return -6;                                                                                           \
+        if (!t_pts) return -8;                                                                                         \
+        if (!y) return -9;                                                                                             \
+        if (!rinv) return -10;                                                                                         \
+        if (!out) return -13;                                                                                          \
+        return t->gpr_loglik(B, Tn, ncomp, orders, lam, var, per_series, t_pts, y, rinv, jitter, add_const, out, ws,   \
+                             ws_bytes, info, chunks, static_cast<hipEvent_t>(prof_start),                              \
+                             static_cast<hipEvent_t>(prof_stop), S(stream));                                           \
+    }
+
 MF_DEFINE(f64, double)
 MF_DEFINE(f32, float)
 MF_DEFINE2(f64, double)
 MF_DEFINE2(f32, float)
+MF_DEFINE3(f64, double)
+MF_DEFINE3(f32, float)
 
 size_t mf_btd_cholesky_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {
     if (B < 1 || T < 1) return 0;

@@ -6,6 +6,7 @@
 #include "mf_kernels.hpp"
 #include "mf_kf_lds.hpp"
 #include "mf_btd_par.hpp"
+#include "mf_gpr_fused.hpp"
 #include "mf_launch.hpp"
 
 #include <cstdlib>
@@ -556,11 +557,49 @@ int block_matmul(long B, long n, const T* X, long xs, const T* Y, long ys, T* ou
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
+// GPR log-likelihood with the Matern kernel -> SSM generation fused into the sweep (mf_gpr_fused.hpp).  This translation
+// unit (state dimension D) holds the component signatures whose sizes add up to D; others return -101 and the caller
+// materialises the state space model instead.
+template <typename T, int O0, int O1>
+int gpr_launch(const GprArgs<T>& a, RedSys<T> lvl0, hipStream_t st) {
+    const dim3 grid((unsigned)cdiv(a.B * a.P, 64)), block(64);
+    if (a.P > 1) hipLaunchKernelGGL((gpr_chunk_kernel<T, O0, O1, true>), grid, block, 0, st, a, lvl0);
+    else hipLaunchKernelGGL((gpr_chunk_kernel<T, O0, O1, false>), grid, block, 0, st, a, lvl0);
+    return 0;
+}
+template <typename T>
+int gpr_loglik(long B, long Tn, int ncomp, const int* orders, const T* lam, const T* var, int per_series, const T* t,
+               const T* y, const T* rinv, T jitter, T add_const, T* out, void* ws, size_t ws_bytes, int* info, long chunks,
+               hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
+    const int o0 = orders[0], o1 = ncomp > 1 ? orders[1] : 0;
+    if (ncomp > 2) return -101;
+    if (ws_bytes < kf_loglik_ws<T>(B, Tn, chunks) || ws == nullptr) return -15;
+    long P = 1, L = 1;
+    if (Tn >= 2) lds_partition(B, Tn, chunks, P, L);
+    GprArgs<T> a{B, Tn, lam, var, per_series ? (long)ncomp : 0L, t, y, rinv, jitter, P, L, info};
+    char* p = static_cast<char*>(ws);
+    RedSys<T> lvl0 = carve<T>(p, B, P);
+    if (ev0) (void)hipEventRecord(ev0, st);
+    int rc = -101;
+    if constexpr (D == 1) { if (o0 == 1 && o1 == 0) rc = gpr_launch<T, 1, 0>(a, lvl0, st); }
+    if constexpr (D == 2) { if (o0 == 3 && o1 == 0) rc = gpr_launch<T, 3, 0>(a, lvl0, st); }
+    if constexpr (D == 3) { if (o0 == 5 && o1 == 0) rc = gpr_launch<T, 5, 0>(a, lvl0, st); }
+    if constexpr (D == 4) { if (o0 == 3 && o1 == 3) rc = gpr_launch<T, 3, 3>(a, lvl0, st); }
+    if constexpr (D == 5) {
+        if (o0 == 5 && o1 == 3) rc = gpr_launch<T, 5, 3>(a, lvl0, st);
+        else if (o0 == 3 && o1 == 5) rc = gpr_launch<T, 3, 5>(a, lvl0, st);
+    }
+    if constexpr (D == 6) { if (o0 == 5 && o1 == 5) rc = gpr_launch<T, 5, 5>(a, lvl0, st); }
+    if (rc != 0) return rc;
+    if (ev1) (void)hipEventRecord(ev1, st);
+    return reduce_levels<T>(lvl0, B, p, add_const, out, info, st);
+}
+
 template <typename T> const OpsTable<T>* table() {
     static const OpsTable<T> t = {
         &kf_loglik_ws<T>, &kf_loglik<T>, &btd_logdet_quad_ws<T>, &btd_logdet_quad<T>, &btd_cholesky_ws<T>, &btd_cholesky<T>,
         &btd_solve_ws<T>, &btd_solve<T>,    &btd_matvec<T>, &btd_logdet<T>,        &btd_diag_of_inverse_ws<T>, &btd_diag_of_inverse<T>, &btd_udl_ws<T>, &btd_udl<T>,
-        &ssm_precision<T>, &ssm_means<T>, &block_matmul<T>,
+        &ssm_precision<T>, &ssm_means<T>, &block_matmul<T>, &gpr_loglik<T>,
     };
     return &t;
 }

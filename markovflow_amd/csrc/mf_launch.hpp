@@ -36,6 +36,9 @@ template <typename T> struct OpsTable {
     int (*ssm_means)(long Bl, long Br, long Tn, const T* A, const T* offs, T* out, void* ws, size_t ws_bytes,
                      hipStream_t st);
     int (*block_matmul)(long B, long n, const T* X, long xs, const T* Y, long ys, T* out, hipStream_t st);
+    int (*gpr_loglik)(long B, long Tn, int ncomp, const int* orders, const T* lam, const T* var, int per_series, const T* t,
+                      const T* y, const T* rinv, T jitter, T add_const, T* out, void* ws, size_t ws_bytes, int* info,
+                      long chunks, hipEvent_t ev0, hipEvent_t ev1, hipStream_t st);
 };
 
 constexpr int MF_MAX_D = 9;        // largest state dimension with a register-resident instantiation

@@ -7,10 +7,14 @@ Only what drives the hot path is mirrored: construction from ``(time_points, obs
 """
 from typing import Optional, Tuple
 
+import ctypes
+import math
+
 import torch
 
+from . import _lib
 from .kalman_filter import KalmanFilter
-from .kernels import SDEKernel
+from .kernels import IndependentMultiOutput, SDEKernel
 from .state_space_model import StateSpaceModel
 
 
@@ -59,8 +63,60 @@ class GaussianProcessRegression:
             chol_obs_covariance=self._chol_obs_covariance,
         )
 
+    # time partitions per series of the fused kernel (0 = automatic) and optional hipEvent_t pair around its level-0 kernel
+    _chunks = 0
+    _prof_events = (None, None)
+    fused = True    # set False to force the materialised route (kernel tensors -> KalmanFilter)
+
+    def _fused_log_likelihood_per_series(self) -> Optional[torch.Tensor]:
+        """Per-series log-likelihood through ``mf_gpr_matern_loglik_*`` (kernel -> SSM generation fused into the Kalman
+        sweep: 16 bytes per step instead of the materialised tensors); ``None`` when the kernel / shapes are not covered."""
+        comps = self._kernel._components()
+        if (not self.fused or isinstance(self._kernel, IndependentMultiOutput) or len(comps) > 2
+                or self._observations.shape[-1] != 1 or not self._observations.is_cuda):
+            return None
+        batch = tuple(self._time_points.shape[:-1])
+        n, dtype, dev = self._time_points.shape[-1], self._observations.dtype, self._observations.device
+        t = self._time_points.reshape(-1, n).to(dtype).contiguous()
+        y = self._observations.reshape(-1, n).contiguous()
+        bsz = t.shape[0]
+        if bsz == 0 or n < 1:
+            return None
+        lam = [c._lambda.to(dtype=dtype, device=dev) for c in comps]
+        var = [c._variance_t.to(dtype=dtype, device=dev) for c in comps]
+        per_series = any(x.dim() > 0 for x in lam + var)
+        if per_series:
+            lam_t = torch.stack([x.expand(batch).reshape(-1) for x in lam], dim=-1).contiguous()
+            var_t = torch.stack([x.expand(batch).reshape(-1) for x in var], dim=-1).contiguous()
+        else:
+            lam_t, var_t = torch.stack(lam).contiguous(), torch.stack(var).contiguous()
+        chol = self._chol_obs_covariance.to(dtype=dtype, device=dev)
+        rinv = (1.0 / (chol * chol)).reshape(1).contiguous()
+        d = self._kernel.state_dim
+        lib = _lib.load()
+        ws_bytes = int(lib.mf_kf_loglik_workspace_bytes(bsz, n, d, t.element_size(), self._chunks))
+        if ws_bytes == 0:
+            return None
+        ws = _lib.workspace(ws_bytes, dev)
+        out = torch.empty(bsz, dtype=dtype, device=dev)
+        info = _lib.new_info(dev)
+        orders = (ctypes.c_int * len(comps))(*[c.order for c in comps])
+        fn = getattr(lib, "mf_gpr_matern_loglik" + _lib.suffix(dtype))
+        rc = fn(bsz, n, len(comps), orders, _lib.ptr(lam_t), _lib.ptr(var_t), int(per_series), _lib.ptr(t), _lib.ptr(y),
+                _lib.ptr(rinv), self._kernel._jitter, 0.0, _lib.ptr(out), _lib.ptr(ws), ws_bytes, _lib.ptr(info),
+                self._chunks, self._prof_events[0], self._prof_events[1], _lib.stream_ptr(dev))
+        if rc == -101:
+            return None                     # component signature not instantiated: materialise instead
+        _lib.check(rc, "mf_gpr_matern_loglik")
+        _lib.raise_on_info(info, "GaussianProcessRegression.log_likelihood")
+        const = -0.5 * math.log(2 * math.pi) * n + 0.5 * n * torch.log(rinv[0])
+        return (out + const).reshape(batch)
+
     def log_likelihood(self) -> torch.Tensor:
         """``log p(y | ϑ)`` summed over the batch (gaussian_process_regression.py:150-160)."""
+        per_series = self._fused_log_likelihood_per_series()
+        if per_series is not None:
+            return torch.sum(per_series)
         return self._kalman.log_likelihood()
 
     def loss(self) -> torch.Tensor:

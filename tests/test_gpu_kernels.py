@@ -119,3 +119,44 @@ def test_gpr_sum_kernel_batch_vs_dense_gp(rng):
     for s in range(bsz):
         kd = K.dense_kernel_matrix(orders, ls, var, t[s])
         np.testing.assert_allclose(f_mean[s], kd @ np.linalg.solve(kd + noise * np.eye(n), y[s, :, 0]), rtol=1e-6, atol=1e-8)
+
+
+# ---- fused route: kernel -> SSM generation inside the Kalman sweep -----------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("sig", [(1,), (3,), (5,), (3, 3), (5, 3), (3, 5), (5, 5)])
+def test_fused_gpr_log_likelihood_equals_materialised_route(rng, dtype, sig):
+    """mf_gpr_matern_loglik (generation fused) against the materialised route (mf_sde_matern_transitions + mf_kf_loglik) and,
+    through it, the oracle; several time partitions; per-series hyper-parameters."""
+    cls = {1: mfa.Matern12, 3: mfa.Matern32, 5: mfa.Matern52}
+    bsz, n = 4, 150
+    # fp32: Q = Pinf - A Pinf A^T loses its digits at small gaps (SURVEY.md section 7, "fp32 conditioning"): wider gaps + jitter
+    f64 = dtype == torch.float64
+    t = np.cumsum((0.05 if f64 else 0.4) + rng.exponential(0.1 if f64 else 0.3, size=(bsz, n)), axis=-1)
+    y = rng.normal(size=(bsz, n, 1))
+    ls = [tt(0.5 + rng.random(bsz), dtype) for _ in sig]
+    var = [tt(0.5 + rng.random(bsz), dtype) for _ in sig]
+    jit = 1e-9 if f64 else 1e-4
+    parts = [cls[o](l, v, jitter=jit) for o, l, v in zip(sig, ls, var)]
+    kern = parts[0] if len(parts) == 1 else mfa.Sum(parts, jitter=jit)
+    chol_r = tt(np.sqrt(0.1) * np.eye(1), dtype)
+    gpr = mfa.GaussianProcessRegression((tt(t, dtype), tt(y, dtype)), kern, chol_obs_covariance=chol_r)
+    fused = gpr._fused_log_likelihood_per_series()
+    assert fused is not None, "this signature is meant to be covered by the fused kernel"
+    ref = gpr._kalman._log_likelihood_per_series() + gpr._kalman._constant_terms(n)
+    tol = 1e-9 if dtype == torch.float64 else 2e-3
+    np.testing.assert_allclose(nn(fused), nn(ref), rtol=tol)
+    for chunks in (1, 3, 16):
+        gpr._chunks = chunks
+        np.testing.assert_allclose(nn(gpr._fused_log_likelihood_per_series()), nn(ref), rtol=tol)
+    gpr._chunks = 0
+    assert torch.isfinite(ref).all()
+    assert float(gpr.log_likelihood().cpu()) == pytest.approx(float(ref.sum().cpu()), rel=tol)
+
+
+def test_fused_gpr_falls_back_when_not_covered(rng):
+    """Three components / several outputs are not fused: log_likelihood takes the materialised route (still all HIP)."""
+    t = np.cumsum(0.1 + rng.random(size=(2, 30)), axis=-1)
+    kern = mfa.Sum([mfa.Matern12(1.0, 1.0, device=DEV), mfa.Matern32(1.0, 1.0, device=DEV), mfa.Matern52(1.0, 1.0, device=DEV)])
+    gpr = mfa.GaussianProcessRegression((tt(t), tt(rng.normal(size=(2, 30, 1)))), kern, chol_obs_covariance=tt(0.3 * np.eye(1)))
+    assert gpr._fused_log_likelihood_per_series() is None
+    assert torch.isfinite(gpr.log_likelihood())
