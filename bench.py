@@ -157,6 +157,21 @@ def other_configs(dev):
     ms_kl = _time_gpu(lambda: post.kl_divergence(kf.prior_ssm), iters=3, warm=1)
     out["config4_d9_m3_B512_T1000_f64"] = {"loglik_ms": ms, "loglik_steps_per_s": 512 * 1000 / ms * 1e3,
                                           "kl_divergence_ms": ms_kl}
+    # GPR log-likelihood with the kernel -> SSM generation fused into the sweep, at the headline shape
+    # (B=1024, T=10000, Sum of two Matern-5/2 = d 6, fp64); input is (t, y, hyper-parameters): 16 B per step
+    bsz, tn = 1024, 10000
+    t_pts = torch.cumsum(0.05 + 0.05 * torch.empty(bsz, tn, dtype=torch.float64, device=dev).exponential_(1.0, generator=g), dim=-1)
+    y_obs = torch.randn(bsz, tn, 1, dtype=torch.float64, device=dev, generator=g)
+    parts = [mfa.Matern52(0.5 + 1.5 * torch.rand(bsz, dtype=torch.float64, device=dev, generator=g),
+                          0.5 + 1.5 * torch.rand(bsz, dtype=torch.float64, device=dev, generator=g)) for _ in range(2)]
+    gpr = mfa.GaussianProcessRegression((t_pts, y_obs), mfa.Sum(parts, jitter=1e-9),
+                                        chol_obs_covariance=(0.1 ** 0.5) * torch.eye(1, dtype=torch.float64, device=dev))
+    ms = _time_gpu(gpr.log_likelihood, iters=10)
+    out["gpr_fused_matern52x2_B1024_T10000_d6_f64"] = {
+        "ms": ms, "steps_per_s": bsz * tn / ms * 1e3,
+        "note": "GaussianProcessRegression.log_likelihood through mf_gpr_matern_loglik (A_k, chol Q_k generated in registers); "
+                "NOT the headline metric: the boundary differs (time points + hyper-parameters instead of SSM tensors)"}
+    del t_pts, y_obs, gpr
     # config 5: state_dim 64, T=2048, fp32, 32 spatial outputs, 8 series (LDS-tiled MFMA path)
     bsz, tn, d, m = 8, 2048, 64, 32
     eye = torch.eye(d, dtype=torch.float32, device=dev)
