@@ -208,9 +208,9 @@ int mf_sde_matern_transitions_f32(int64_t B, int64_t n, int ncomp, const int* or
  * GaussianProcessRegression.log_likelihood (markovflow/models/gaussian_process_regression.py:150-160) for a Matern kernel or
  * a Sum of two, with the kernel -> state-space-model step FUSED into the Kalman sweep: A_k and chol(Q_k) are generated in
  * registers from dt_k = t_{k+1} - t_k, so a step reads 16 bytes (t, y) instead of the materialised tensors.  One output,
- * zero mean function, H = [1 0 .. | 1 0 ..].  Arguments as mf_sde_matern_transitions (orders: HOST array, ncomp <= 2) plus
+ * zero mean function, H = [1 0 .. | 1 0 ..].  Arguments as for mf_sde_matern_transitions_* - orders: HOST array, ncomp <= 2 - plus
  * time points t [B,T] (strictly increasing), observations y [B,T], rinv [1] (device: 1 / noise variance); out[s] as
- * mf_kf_loglik (add_const carries -T/2 log 2 pi + T/2 log rinv).  Workspace: mf_kf_loglik_workspace_bytes(B, T, d, ...).
+ * mf_kf_loglik_*: add_const carries -T/2 log 2 pi + T/2 log rinv.  Workspace: the size mf_kf_loglik_workspace_bytes returns.
  * Returns -101 when the component signature is not instantiated (supported: (1), (3), (5), (3,3), (5,3), (3,5), (5,5));
  * the caller then materialises the model (mf_sde_matern_transitions + mf_kf_loglik).
  */
@@ -222,6 +222,25 @@ int mf_gpr_matern_loglik_f32(int64_t B, int64_t T, int ncomp, const int* orders,
                              int per_series, const float* t, const float* y, const float* rinv, float jitter,
                              float add_const, float* out, void* ws, size_t ws_bytes, int* info, int64_t chunks,
                              void* prof_start, void* prof_stop, void* stream);
+
+/*
+ * Posterior prediction of the state at new time points: conditional_predict of
+ * markovflow/conditionals.py:29-83 with _conditional_statistics_from_transitions (:122-203) and base_conditional_predict
+ * (:380-420) fused, one lane per (series, new point).  idx [B,Np] (int64, device): insertion index of each new point
+ * among the N training points (0..N); A_mt, Q_mt [B,Np,d,d]: transition from the previous training point (or from
+ * "minus infinity") to the new point; A_tp, Q_tp: from the new point to the next training point (mf_sde_matern_transitions);
+ * means [B,N,d], covs [B,N,d,d], subsequent_covs [B,N-1,d,d] = Cov(x_{k+1}, x_k): the posterior's marginals; prior_mean [B,d],
+ * prior_cov [B,d,d]: the stationary state, used beyond both ends (pairwise_marginals, conditionals.py:424-485).
+ * out_mean [B,Np,d], out_cov [B,Np,d,d] (NULL: means only).  State dimension 1..9.
+ */
+int mf_sde_conditional_predict_f64(int64_t B, int64_t N, int64_t Np, int d, const int64_t* idx, const double* A_mt,
+                                   const double* Q_mt, const double* A_tp, const double* Q_tp, const double* means,
+                                   const double* covs, const double* subsequent_covs, const double* prior_mean,
+                                   const double* prior_cov, double* out_mean, double* out_cov, int* info, void* stream);
+int mf_sde_conditional_predict_f32(int64_t B, int64_t N, int64_t Np, int d, const int64_t* idx, const float* A_mt,
+                                   const float* Q_mt, const float* A_tp, const float* Q_tp, const float* means,
+                                   const float* covs, const float* subsequent_covs, const float* prior_mean,
+                                   const float* prior_cov, float* out_mean, float* out_cov, int* info, void* stream);
 
 #ifdef __cplusplus
 }

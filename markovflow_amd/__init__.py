@@ -20,11 +20,12 @@ from .state_space_model import StateSpaceModel, state_space_model_from_covarianc
 from . import kernels, models
 from .kernels import IndependentMultiOutput, Matern12, Matern32, Matern52, SDEKernel, StationaryKernel, Sum
 from .models import GaussianProcessRegression
+from .posterior import AnalyticPosteriorProcess, ConditionalProcess
 
 __all__ = [
     "BlockTriDiagonal", "LowerTriangularBlockTriDiagonal", "SymmetricBlockTriDiagonal", "EmissionModel",
     "GaussMarkovDistribution", "check_compatible", "BaseKalmanFilter", "GaussianSites", "KalmanFilter",
     "KalmanFilterWithSites", "KalmanFilterWithSparseSites", "UnivariateGaussianSitesNat", "StateSpaceModel",
     "state_space_model_from_covariances", "kernels", "models", "SDEKernel", "StationaryKernel", "Matern12", "Matern32",
-    "Matern52", "Sum", "IndependentMultiOutput", "GaussianProcessRegression",
+    "Matern52", "Sum", "IndependentMultiOutput", "GaussianProcessRegression", "AnalyticPosteriorProcess", "ConditionalProcess",
 ]

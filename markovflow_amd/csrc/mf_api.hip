@@ -248,12 +248,36 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
                              static_cast<hipEvent_t>(prof_stop), S(stream));                                           \
     }
 
+#define MF_DEFINE4(SUF, T)                                                                                             \
+    int mf_sde_conditional_predict_##SUF(int64_t B, int64_t N, int64_t Np, int d, const int64_t* idx, const T* A_mt,   \
+                                         const T* Q_mt, const T* A_tp, const T* Q_tp, const T* means, const T* covs,   \
+                                         const T* subsequent_covs, const T* prior_mean, const T* prior_cov,            \
+                                         T* out_mean, T* out_cov, int* info, void* stream) {                           \
+        if (B < 0) return -1;                                                                                          \
+        if (N < 1) return -2;                                                                                          \
+        if (Np < 0) return -3;                                                                                         \
+        if (d < 1) return -4;                                                                                          \
+        const auto* t = table_for<T>(d);                                                                               \
+        if (!t) return -100;                                                                                           \
+        if (B == 0 || Np == 0) return 0;                                                                               \
+        if (!idx) return -5;                                                                                           \
+        if (!A_mt || !Q_mt || !A_tp || !Q_tp) return -6;                                                               \
+        if (!means) return -10;                                                                                        \
+        if (out_cov && (!covs || (N > 1 && !subsequent_covs) || !prior_cov)) return -11;                               \
+        if (!prior_mean) return -13;                                                                                   \
+        if (!out_mean) return -15;                                                                                     \
+        return t->sde_predict(B, N, Np, reinterpret_cast<const long long*>(idx), A_mt, Q_mt, A_tp, Q_tp, means, covs,  \
+                              subsequent_covs, prior_mean, prior_cov, out_mean, out_cov, info, S(stream));             \
+    }
+
 MF_DEFINE(f64, double)
 MF_DEFINE(f32, float)
 MF_DEFINE2(f64, double)
 MF_DEFINE2(f32, float)
 MF_DEFINE3(f64, double)
 MF_DEFINE3(f32, float)
+MF_DEFINE4(f64, double)
+MF_DEFINE4(f32, float)
 
 size_t mf_btd_cholesky_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {
     if (B < 1 || T < 1) return 0;

@@ -595,11 +595,20 @@ int gpr_loglik(long B, long Tn, int ncomp, const int* orders, const T* lam, cons
     return reduce_levels<T>(lvl0, B, p, add_const, out, info, st);
 }
 
+template <typename T>
+int sde_predict(long B, long N, long Np, const long long* idx, const T* Amt, const T* Qmt, const T* Atp, const T* Qtp,
+                const T* means, const T* covs, const T* subseq, const T* m0, const T* P0, T* omean, T* ocov, int* info,
+                hipStream_t st) {
+    hipLaunchKernelGGL((sde_predict_kernel<T, D>), dim3((unsigned)cdiv(B * Np, 64)), dim3(64), 0, st, B, N, Np, idx, Amt, Qmt,
+                       Atp, Qtp, means, covs, subseq, m0, P0, omean, ocov, info);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
 template <typename T> const OpsTable<T>* table() {
     static const OpsTable<T> t = {
         &kf_loglik_ws<T>, &kf_loglik<T>, &btd_logdet_quad_ws<T>, &btd_logdet_quad<T>, &btd_cholesky_ws<T>, &btd_cholesky<T>,
         &btd_solve_ws<T>, &btd_solve<T>,    &btd_matvec<T>, &btd_logdet<T>,        &btd_diag_of_inverse_ws<T>, &btd_diag_of_inverse<T>, &btd_udl_ws<T>, &btd_udl<T>,
-        &ssm_precision<T>, &ssm_means<T>, &block_matmul<T>, &gpr_loglik<T>,
+        &ssm_precision<T>, &ssm_means<T>, &block_matmul<T>, &gpr_loglik<T>, &sde_predict<T>,
     };
     return &t;
 }

@@ -642,4 +642,111 @@ __global__ void __launch_bounds__(64) ssm_means_kernel(long Bl, long Br, long Tn
     }
 }
 
+// Conditional prediction of the state at new time points (conditionals.py:29-83,122-203,380-420 of the reference):
+// p(x_t) = N(D mu_- + E mu_+,  T + [D E] S [D E]^T) with
+//   Q-+ = Q_tp + A_tp Q_mt A_tp^T,  E = Q_mt A_tp^T Q-+^-1,  D = A_mt - E A_tp A_mt,  T = Q_mt - Q_mt A_tp^T Q-+^-1 A_tp Q_mt
+// and (mu_-, mu_+, S) the pairwise posterior marginal of the two training points around t (the prior beyond the ends,
+// conditionals.py:424-485).  One lane per (series, new point); idx = insertion index of t among the training points.
+template <typename T, int D>
+__global__ void __launch_bounds__(64) sde_predict_kernel(long B, long N, long Np, const long long* __restrict__ idx,
+                                                         const T* __restrict__ Amt, const T* __restrict__ Qmt,
+                                                         const T* __restrict__ Atp, const T* __restrict__ Qtp,
+                                                         const T* __restrict__ means, const T* __restrict__ covs,
+                                                         const T* __restrict__ subseq, const T* __restrict__ m0,
+                                                         const T* __restrict__ P0, T* __restrict__ omean,
+                                                         T* __restrict__ ocov, int* info) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= B * Np) return;
+    const long s = id / Np;
+    const long i = (long)idx[id];                        // 0 .. N
+    T Am[D][D], Qm[D][D], Ap[D][D], Qp[D][D];
+    load_mat<T, D, D>(Amt + id * D * D, Am);
+    load_mat<T, D, D>(Qmt + id * D * D, Qm);
+    load_mat<T, D, D>(Atp + id * D * D, Ap);
+    load_lower<T, D>(Qtp + id * D * D, Qp);
+    // G = A_tp Q_mt ;  Q-+ (lower) = Q_tp + G A_tp^T
+    T G[D][D];
+    MF_UNROLL for (int r = 0; r < D; ++r)
+        MF_UNROLL for (int c = 0; c < D; ++c) {
+            T a = T(0);
+            MF_UNROLL for (int l = 0; l < D; ++l) a += Ap[r][l] * Qm[l][c];
+            G[r][c] = a;
+        }
+    MF_UNROLL for (int r = 0; r < D; ++r)
+        MF_UNROLL for (int c = 0; c <= r; ++c) {
+            T a = Qp[r][c];
+            MF_UNROLL for (int l = 0; l < D; ++l) a += G[r][l] * Ap[c][l];
+            Qp[r][c] = a;
+        }
+    T Li[D];
+    LogAcc<T> la;
+    la.init();
+    bool bad = false;
+    chol_lower<T, D>(Qp, Li, la, bad);                   // L
+    trsm_left_lower<T, D, D>(Qp, Li, G);                 // V = L^-1 A_tp Q_mt
+    T Tm[D][D];
+    MF_UNROLL for (int r = 0; r < D; ++r) MF_UNROLL for (int c = 0; c <= r; ++c) Tm[r][c] = Qm[r][c];
+    syrk_tn_lower<T, D, D>(G, Tm, T(-1));                // T = Q_mt - V^T V   (lower)
+    trsm_left_lower_t<T, D, D>(Qp, Li, G);               // E^T = L^-T V
+    // D = A_mt - E A_tp A_mt  with E[r][c] = G[c][r]
+    T EA[D][D], Dm[D][D];
+    MF_UNROLL for (int r = 0; r < D; ++r)
+        MF_UNROLL for (int c = 0; c < D; ++c) {
+            T a = T(0);
+            MF_UNROLL for (int l = 0; l < D; ++l) a += G[l][r] * Ap[l][c];
+            EA[r][c] = a;
+        }
+    MF_UNROLL for (int r = 0; r < D; ++r)
+        MF_UNROLL for (int c = 0; c < D; ++c) {
+            T a = Am[r][c];
+            MF_UNROLL for (int l = 0; l < D; ++l) a -= EA[r][l] * Am[l][c];
+            Dm[r][c] = a;
+        }
+    // pairwise marginal around the point
+    T mu_m[D], mu_p[D];
+    const bool has_m = i > 0, has_p = i < N;
+    load_vec<T, D>(has_m ? means + (s * N + i - 1) * D : m0 + s * D, mu_m);
+    load_vec<T, D>(has_p ? means + (s * N + i) * D : m0 + s * D, mu_p);
+    T mean[D];
+    MF_UNROLL for (int r = 0; r < D; ++r) {
+        T a = T(0);
+        MF_UNROLL for (int l = 0; l < D; ++l) a += Dm[r][l] * mu_m[l] + G[l][r] * mu_p[l];
+        mean[r] = a;
+    }
+    store_vec<T, D>(omean + id * D, mean);
+    if (ocov) {
+        // cov = T + D P- D^T + E P+ E^T + E C D^T + (E C D^T)^T,  C = Cov(x+, x-)
+        T Pm[D][D], Pp[D][D], X1[D][D], X2[D][D], Out[D][D];
+        load_mat<T, D, D>(has_m ? covs + (s * N + i - 1) * D * D : P0 + s * D * D, Pm);
+        load_mat<T, D, D>(has_p ? covs + (s * N + i) * D * D : P0 + s * D * D, Pp);
+        MF_UNROLL for (int r = 0; r < D; ++r)
+            MF_UNROLL for (int c = 0; c < D; ++c) {
+                T a = T(0), b = T(0);
+                MF_UNROLL for (int l = 0; l < D; ++l) { a += Dm[r][l] * Pm[l][c]; b += G[l][r] * Pp[l][c]; }
+                X1[r][c] = a;                            // D P-
+                X2[r][c] = b;                            // E P+
+            }
+        if (has_m && has_p) {
+            T C[D][D];
+            load_mat<T, D, D>(subseq + (s * (N - 1) + i - 1) * D * D, C);
+            // X1 += E C   (so that X1 D^T collects D P- D^T + E C D^T), X2 += D C^T
+            MF_UNROLL for (int r = 0; r < D; ++r)
+                MF_UNROLL for (int c = 0; c < D; ++c) {
+                    T a = T(0), b = T(0);
+                    MF_UNROLL for (int l = 0; l < D; ++l) { a += G[l][r] * C[l][c]; b += Dm[r][l] * C[c][l]; }
+                    X1[r][c] += a;
+                    X2[r][c] += b;
+                }
+        }
+        MF_UNROLL for (int r = 0; r < D; ++r)
+            MF_UNROLL for (int c = 0; c < D; ++c) {
+                T a = (r >= c) ? Tm[r][c] : Tm[c][r];
+                MF_UNROLL for (int l = 0; l < D; ++l) a += X1[r][l] * Dm[c][l] + X2[r][l] * G[l][c];
+                Out[r][c] = a;
+            }
+        store_mat<T, D, D>(ocov + id * D * D, Out);
+    }
+    if (bad && info) atomicMax(info, 1);
+}
+
 }  // namespace mf

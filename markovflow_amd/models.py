@@ -2,8 +2,8 @@
 Thin model harness over the Kalman path: ``GaussianProcessRegression`` (mirror of
 ``markovflow/models/gaussian_process_regression.py:29-160``, the direct caller of ``KalmanFilter`` in the reference).
 Only what drives the hot path is mirrored: construction from ``(time_points, observations)`` and an SDE kernel,
-``log_likelihood`` / ``loss`` and the posterior state space model; prediction at new time points
-(``AnalyticPosteriorProcess``), mean functions and training loops belong to the reference's outer layers.
+``log_likelihood`` / ``loss``, the posterior state space model and ``posterior`` (prediction at new time points,
+``markovflow_amd/posterior.py``); mean functions and training loops belong to the reference's outer layers.
 """
 from typing import Optional, Tuple
 
@@ -15,6 +15,7 @@ import torch
 from . import _lib
 from .kalman_filter import KalmanFilter
 from .kernels import IndependentMultiOutput, SDEKernel
+from .posterior import AnalyticPosteriorProcess
 from .state_space_model import StateSpaceModel
 
 
@@ -121,6 +122,16 @@ class GaussianProcessRegression:
 
     def loss(self) -> torch.Tensor:
         return -self.log_likelihood()
+
+    @property
+    def posterior(self) -> AnalyticPosteriorProcess:
+        """Posterior process for inference at new time points (gaussian_process_regression.py:130-148)."""
+        return AnalyticPosteriorProcess(
+            posterior_dist=self._kalman.posterior_state_space_model(),
+            kernel=self._kernel,
+            conditioning_time_points=self._time_points,
+            chol_obs_covariance=self._chol_obs_covariance,
+        )
 
     def posterior_state_space_model(self) -> StateSpaceModel:
         """The smoothed chain on the training time points (what the reference's ``posterior`` is built from, :138-144)."""

@@ -1,0 +1,88 @@
+"""
+Posterior processes: prediction at new time points from the smoothed chain.
+
+Mirror of ``ConditionalProcess`` / ``AnalyticPosteriorProcess`` of ``markovflow/posterior.py:160-258,416-470`` (reference):
+``predict_state`` conditions every new time point on the pairwise posterior marginal of its two neighbouring training
+points (``markovflow/conditionals.py:29-83,122-256,380-485``).  The neighbour search is ``torch.searchsorted`` (the reference
+uses ``tf.searchsorted``); the transitions to / from the new points come from ``mf_sde_matern_transitions_*`` and the
+conditional statistics + projection + marginalisation run in ONE HIP kernel (``mf_sde_conditional_predict_*``, a lane per
+new point).  Sampling (``sample_state_trajectories`` …) and mean functions are not mirrored.
+"""
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from .gauss_markov import GaussMarkovDistribution
+from .kernels import SDEKernel
+
+APPROX_INF = 1e10   # markovflow/base.py:46: the "time" of the stationary prior beyond both ends of the data
+
+
+class ConditionalProcess:
+    """Posterior process built from the marginals ``q(s(Z))`` and the prior conditional ``p(s(.)|s(Z))`` (posterior.py:160-258)."""
+
+    def __init__(self, posterior_dist: GaussMarkovDistribution, kernel: SDEKernel, conditioning_time_points: torch.Tensor) -> None:
+        self.gauss_markov_model = posterior_dist
+        self.kernel = kernel
+        self.conditioning_time_points = conditioning_time_points
+
+    def predict_state(self, new_time_points: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """
+        State mean ``batch + [num_new, state_dim]`` and covariance ``batch + [num_new, state_dim, state_dim]`` at
+        ``new_time_points`` (``batch + [num_new]``, sorted) - posterior.py:207-229.
+        """
+        dist, kern = self.gauss_markov_model, self.kernel
+        train = self.conditioning_time_points
+        batch = tuple(dist.batch_shape)
+        if tuple(new_time_points.shape[:-1]) != batch or tuple(train.shape[:-1]) != batch:
+            raise ValueError("new_time_points and conditioning_time_points must carry the distribution's batch shape")
+        n, n_new, d = train.shape[-1], new_time_points.shape[-1], dist.state_dim
+        dtype, dev = train.dtype, train.device
+        new = new_time_points.to(dtype).contiguous()
+        # insertion indices and the gaps to the neighbours (conditionals.py:231-245; the prior sits at -/+ APPROX_INF)
+        idx = torch.searchsorted(train.contiguous(), new)
+        inf = torch.full(batch + (1,), APPROX_INF, dtype=dtype, device=dev)
+        aug = torch.cat([-inf, train, inf], dim=-1)
+        minus, plus = torch.gather(aug, -1, idx), torch.gather(aug, -1, idx + 1)
+        a_mt, q_mt = kern.transition_statistics(minus, new - minus)
+        a_tp, q_tp = kern.transition_statistics(new, plus - new)
+        means, covs = dist.marginals
+        sub = dist.subsequent_covariances(covs) if n > 1 else None
+        m0 = kern.initial_mean(batch).to(dtype=dtype, device=dev).expand(batch + (d,)).contiguous()
+        p0 = kern.initial_covariance(new[..., :1]).to(dtype=dtype, device=dev)
+        p0 = p0.expand(batch + (d, d)).contiguous()
+        flat = lambda t, k: t.reshape((-1,) + tuple(t.shape[-k:])).contiguous()  # noqa: E731
+        bsz = max(1, int(torch.tensor(batch).prod())) if batch else 1
+        out_mean = torch.empty((bsz, n_new, d), dtype=dtype, device=dev)
+        out_cov = torch.empty((bsz, n_new, d, d), dtype=dtype, device=dev)
+        info = _lib.new_info(dev)
+        _lib.call("mf_sde_conditional_predict", dtype, bsz, n, n_new, d, _lib.ptr(flat(idx, 1)), _lib.ptr(flat(a_mt, 3)),
+                  _lib.ptr(flat(q_mt, 3)), _lib.ptr(flat(a_tp, 3)), _lib.ptr(flat(q_tp, 3)), _lib.ptr(flat(means, 2)),
+                  _lib.ptr(flat(covs, 3)), _lib.ptr(None if sub is None else flat(sub, 3)), _lib.ptr(flat(m0, 1)),
+                  _lib.ptr(flat(p0, 2)), _lib.ptr(out_mean), _lib.ptr(out_cov), _lib.ptr(info), _lib.stream_ptr(dev))
+        _lib.raise_on_info(info, "ConditionalProcess.predict_state")
+        return out_mean.reshape(batch + (n_new, d)), out_cov.reshape(batch + (n_new, d, d))
+
+    def predict_f(self, new_time_points: torch.Tensor, full_output_cov: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Marginal function values at ``new_time_points``: means ``batch + [num_new, output_dim]`` and variances (or full
+        output covariances) - posterior.py:231-258 (zero mean function)."""
+        emission = self.kernel.generate_emission_model(new_time_points)
+        return emission.project_state_marginals_to_f(*self.predict_state(new_time_points), full_output_cov=full_output_cov)
+
+
+class AnalyticPosteriorProcess(ConditionalProcess):
+    """Posterior process of a model with an analytic (Gaussian) likelihood: adds ``predict_y`` (posterior.py:416-470)."""
+
+    def __init__(self, posterior_dist: GaussMarkovDistribution, kernel: SDEKernel, conditioning_time_points: torch.Tensor,
+                 chol_obs_covariance: Optional[torch.Tensor] = None) -> None:
+        super().__init__(posterior_dist, kernel, conditioning_time_points)
+        self._chol_obs_covariance = chol_obs_covariance
+
+    def predict_y(self, new_time_points: torch.Tensor, full_output_cov: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Observation marginals: ``predict_f`` plus the noise covariance (posterior.py:445-470)."""
+        f_mean, f_cov = self.predict_f(new_time_points, full_output_cov=full_output_cov)
+        if self._chol_obs_covariance is None:
+            return f_mean, f_cov
+        noise = self._chol_obs_covariance @ self._chol_obs_covariance.transpose(-1, -2)
+        return f_mean, f_cov + (noise if full_output_cov else torch.diagonal(noise, dim1=-2, dim2=-1))

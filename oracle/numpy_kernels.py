@@ -84,3 +84,21 @@ def dense_kernel_matrix(orders, length_scales, variances, t):
         poly = {1: 1.0, 3: 1.0 + lam * r, 5: 1.0 + lam * r + (lam * r) ** 2 / 3.0}[o]
         out += v * poly * np.exp(-lam * r)
     return out
+
+
+def dense_gp_predict(orders, length_scales, variances, t, y, noise, t_new):
+    """Dense GP posterior of f at t_new (mean, variance) - Rasmussen & Williams eq. 2.25-2.26; the check of
+    markovflow/posterior.py:231-258 (predict_f) used by the reference's GPR tests."""
+    def k(a, b):
+        r = np.abs(a[:, None] - b[None, :])
+        out = np.zeros_like(r)
+        for o, l, v in zip(orders, length_scales, variances):
+            lam = np.sqrt(o) / l
+            poly = {1: 1.0, 3: 1.0 + lam * r, 5: 1.0 + lam * r + (lam * r) ** 2 / 3.0}[o]
+            out += v * poly * np.exp(-lam * r)
+        return out
+    kn = k(t, t) + noise * np.eye(len(t))
+    ks = k(t_new, t)
+    mean = ks @ np.linalg.solve(kn, y)
+    var = np.diag(k(t_new, t_new)) - np.einsum("ij,ji->i", ks, np.linalg.solve(kn, ks.T))
+    return mean, var

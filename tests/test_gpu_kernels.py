@@ -160,3 +160,36 @@ def test_fused_gpr_falls_back_when_not_covered(rng):
     gpr = mfa.GaussianProcessRegression((tt(t), tt(rng.normal(size=(2, 30, 1)))), kern, chol_obs_covariance=tt(0.3 * np.eye(1)))
     assert gpr._fused_log_likelihood_per_series() is None
     assert torch.isfinite(gpr.log_likelihood())
+
+
+# ---- prediction at new time points (posterior.predict_f) ------------------------------------------------------------------------------
+@pytest.mark.parametrize("sig", [(3,), (5, 1), (5, 5), (1, 3, 5)])
+def test_posterior_predict_f_vs_dense_gp(rng, sig):
+    """GaussianProcessRegression.posterior.predict_f / predict_y at new points - before, between, ON and after the training
+    points - against the dense GP predictive distribution (markovflow/posterior.py:231-258, conditionals.py:29-83)."""
+    cls = {1: mfa.Matern12, 3: mfa.Matern32, 5: mfa.Matern52}
+    bsz, n, n_new, noise = 2, 60, 45, 0.05
+    ls, var = [0.6 + 0.5 * j for j in range(len(sig))], [1.0 + 0.3 * j for j in range(len(sig))]
+    t = np.cumsum(0.05 + rng.exponential(0.15, size=(bsz, n)), axis=-1)
+    y = rng.normal(size=(bsz, n, 1))
+    t_new = np.sort(np.concatenate([t[:, :1] - rng.random((bsz, 5)) * 2.0, t[:, -1:] + rng.random((bsz, 5)) * 2.0,
+                                    t[:, 3:8], t[:, :1] + rng.random((bsz, 30)) * (t[:, -1:] - t[:, :1])], axis=-1), axis=-1)
+    parts = [cls[o](l, v, device=DEV) for o, l, v in zip(sig, ls, var)]
+    kern = parts[0] if len(parts) == 1 else mfa.Sum(parts, jitter=1e-10)
+    chol_r = tt(np.sqrt(noise) * np.eye(1))
+    gpr = mfa.GaussianProcessRegression((tt(t), tt(y)), kern, chol_obs_covariance=chol_r)
+    post = gpr.posterior
+    f_mean, f_var = post.predict_f(tt(t_new))
+    y_mean, y_var = post.predict_y(tt(t_new))
+    assert tuple(f_mean.shape) == (bsz, n_new, 1) and tuple(f_var.shape) == (bsz, n_new, 1)
+    for s in range(bsz):
+        mean, v = K.dense_gp_predict(sig, ls, var, t[s], y[s, :, 0], noise, t_new[s])
+        np.testing.assert_allclose(nn(f_mean)[s, :, 0], mean, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(nn(f_var)[s, :, 0], v, rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(nn(y_var)[s, :, 0], v + noise, rtol=1e-5, atol=1e-7)
+    # state covariances are symmetric positive definite, full_output_cov has the output-by-output shape
+    _, cov = post.predict_state(tt(t_new))
+    np.testing.assert_allclose(nn(cov), np.swapaxes(nn(cov), -1, -2), atol=1e-10)
+    assert np.all(np.linalg.eigvalsh(nn(cov)) > -1e-9)
+    _, full = post.predict_f(tt(t_new), full_output_cov=True)
+    assert tuple(full.shape) == (bsz, n_new, 1, 1)
