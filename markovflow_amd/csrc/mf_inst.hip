@@ -604,11 +604,23 @@ int sde_predict(long B, long N, long Np, const long long* idx, const T* Amt, con
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
+template <typename T>
+int kf_grad(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H,
+            const T* y, const T* Rinv, const T* pm, const T* pS, const T* pX, T* gmu0, T* gC0, T* gA, T* gb, T* gC, T* gH,
+            T* gy, T* gOm, int* info, hipStream_t st) {
+    if (m < 1 || m > MF_MAXM) return -3;
+    KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, 0, 1, info, 0};
+    const dim3 grid((unsigned)cdiv(B * Tn, 64)), block(64);
+    if (m == 1) hipLaunchKernelGGL((kf_grad_kernel<T, D, 1>), grid, block, 0, st, a, pm, pS, pX, gmu0, gC0, gA, gb, gC, gH, gy, gOm);
+    else hipLaunchKernelGGL((kf_grad_kernel<T, D, 0>), grid, block, 0, st, a, pm, pS, pX, gmu0, gC0, gA, gb, gC, gH, gy, gOm);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
 template <typename T> const OpsTable<T>* table() {
     static const OpsTable<T> t = {
         &kf_loglik_ws<T>, &kf_loglik<T>, &btd_logdet_quad_ws<T>, &btd_logdet_quad<T>, &btd_cholesky_ws<T>, &btd_cholesky<T>,
         &btd_solve_ws<T>, &btd_solve<T>,    &btd_matvec<T>, &btd_logdet<T>,        &btd_diag_of_inverse_ws<T>, &btd_diag_of_inverse<T>, &btd_udl_ws<T>, &btd_udl<T>,
-        &ssm_precision<T>, &ssm_means<T>, &block_matmul<T>, &gpr_loglik<T>, &sde_predict<T>,
+        &ssm_precision<T>, &ssm_means<T>, &block_matmul<T>, &gpr_loglik<T>, &sde_predict<T>, &kf_grad<T>,
     };
     return &t;
 }

@@ -749,4 +749,151 @@ __global__ void __launch_bounds__(64) sde_predict_kernel(long B, long N, long Np
     if (bad && info) atomicMax(info, 1);
 }
 
+// Gradient of KalmanFilter.log_likelihood with respect to every tensor of the model, by Fisher's
+// identity: grad log p(y) = E_{x|y}[grad log p(x, y)], evaluated from the SMOOTHED pairwise marginals (means m_k, covariances
+// S_k, cross-covariances S_{k+1,k} = Cov(x_{k+1}, x_k)) - exact, and local in time: one lane per (series, time point).
+//   e_k = x_{k+1} - A_k x_k - b_k:  E[e] = m_{k+1} - A m_k - b,  Psi = E[e e^T] = E[e]E[e]^T + S_{k+1} - A S_{k+1,k}^T - S_{k+1,k} A^T + A S_k A^T
+//   d/dA_k = Q^-1 (E[e] m_k^T + S_{k+1,k} - A S_k),  d/db_k = Q^-1 E[e],  d/dcholQ_k = tril(C^-T (C^-1 Psi C^-T - I)),
+//   d/dmu0 = P0^-1 (m_0 - mu0),  d/dcholP0 likewise with Psi_0 = (m_0 - mu0)(m_0 - mu0)^T + S_0,
+//   r_k = y_k - H_k x_k:  d/dH_k = R^-1 (E[r] m_k^T - H S_k),  d/dy_k = -R^-1 E[r],
+//   per-point contribution to d/dR^-1-side: Omega_k = E[r]E[r]^T + H S_k H^T  (reduced over time by the caller).
+// The reference obtains these through TensorFlow's reverse mode over the banded ops (banded_matrices registers gradients).
+template <typename T, int D, int M>
+__global__ void __launch_bounds__(64) kf_grad_kernel(KfArgs<T> a, const T* __restrict__ pm, const T* __restrict__ pS,
+                                                     const T* __restrict__ pX, T* __restrict__ gmu0, T* __restrict__ gC0,
+                                                     T* __restrict__ gA, T* __restrict__ gb, T* __restrict__ gC,
+                                                     T* __restrict__ gH, T* __restrict__ gy, T* __restrict__ gOm) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= a.B * a.Tn) return;
+    const long s = id / a.Tn, k = id % a.Tn;
+    const int m = a.m;
+    constexpr int MM = (M > 0) ? M : MF_MAXM;
+    T mk[D], Sk[D][D];
+    load_vec<T, D>(pm + id * D, mk);
+    load_mat<T, D, D>(pS + id * D * D, Sk);
+    LogAcc<T> la;
+    la.init();
+    bool bad = false;
+    // ---- observation terms of time point k -----------------------------------------------------------------------------
+    {
+        T h[MM][D], r[MM], Rr[MM], HS[MM][D];
+        MF_UNROLL for (int o = 0; o < MM; ++o) {
+            const bool on = (M > 0) || (o < m);
+            T acc = on ? a.y[id * m + o] : T(0);
+            MF_UNROLL for (int i = 0; i < D; ++i) { h[o][i] = on ? a.H[(id * m + o) * D + i] : T(0); acc -= h[o][i] * mk[i]; }
+            r[o] = acc;                                            // E[r]
+        }
+        MF_UNROLL for (int o = 0; o < MM; ++o)
+            MF_UNROLL for (int i = 0; i < D; ++i) {
+                T acc = T(0);
+                MF_UNROLL for (int l = 0; l < D; ++l) acc += h[o][l] * Sk[l][i];
+                HS[o][i] = acc;
+            }
+        MF_UNROLL for (int o = 0; o < MM; ++o) {
+            T acc = T(0);
+            MF_UNROLL for (int p = 0; p < MM; ++p) {
+                const bool on = (M > 0) || (o < m && p < m);
+                acc += (on ? a.Rinv[o * ((M > 0) ? M : m) + p] : T(0)) * r[p];
+            }
+            Rr[o] = acc;
+        }
+        MF_UNROLL for (int o = 0; o < MM; ++o) {
+            if (!((M > 0) || (o < m))) continue;
+            gy[id * m + o] = -Rr[o];
+            // dH = R^-1 (r m^T - H S)
+            MF_UNROLL for (int i = 0; i < D; ++i) {
+                T acc = Rr[o] * mk[i];
+                MF_UNROLL for (int p = 0; p < MM; ++p) {
+                    const bool on = (M > 0) || (p < m);
+                    acc -= (on ? a.Rinv[o * ((M > 0) ? M : m) + p] : T(0)) * HS[p][i];
+                }
+                gH[(id * m + o) * D + i] = acc;
+            }
+            // Omega = r r^T + H S H^T
+            MF_UNROLL for (int p = 0; p < MM; ++p) {
+                if (!((M > 0) || (p < m))) continue;
+                T acc = r[o] * r[p];
+                MF_UNROLL for (int i = 0; i < D; ++i) acc += HS[o][i] * h[p][i];
+                gOm[(id * m + o) * m + p] = acc;
+            }
+        }
+    }
+    // ---- prior of the first state -----------------------------------------------------------------------------------------
+    if (k == 0) {
+        T C[D][D], Ci[D][D], dv[D], u[D], Psi[D][D];
+        load_lower<T, D>(a.cholP0 + s * D * D, C);
+        tri_inv_lower<T, D>(C, Ci, la, bad);
+        MF_UNROLL for (int i = 0; i < D; ++i) dv[i] = mk[i] - a.mu0[s * D + i];
+        trimul_lower_vec<T, D>(Ci, dv, u);                         // C^-1 (m0 - mu0)
+        T g[D];
+        trimulT_lower_vec<T, D>(Ci, u, g);                         // P0^-1 (m0 - mu0)
+        store_vec<T, D>(gmu0 + s * D, g);
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Psi[i][j] = dv[i] * dv[j] + Sk[i][j];
+        // N = C^-1 Psi C^-T - I ;  dC = tril(C^-T N)
+        T N1[D][D], N[D][D], G[D][D];
+        trimul_lower<T, D, D>(Ci, Psi, N1);
+        MF_UNROLL for (int i = 0; i < D; ++i)
+            MF_UNROLL for (int j = 0; j < D; ++j) {
+                T acc = (i == j) ? T(-1) : T(0);
+                MF_UNROLL for (int l = 0; l <= j; ++l) acc += N1[i][l] * Ci[j][l];
+                N[i][j] = acc;
+            }
+        trimulT_lower<T, D, D>(Ci, N, G);
+        store_lower<T, D>(gC0 + s * D * D, G);
+    }
+    // ---- transition k -> k+1 ----------------------------------------------------------------------------------------------
+    if (k + 1 < a.Tn) {
+        const long tid = s * (a.Tn - 1) + k;
+        T mn[D], Sn[D][D], X[D][D], Am[D][D], C[D][D], Ci[D][D];
+        load_vec<T, D>(pm + (id + 1) * D, mn);
+        load_mat<T, D, D>(pS + (id + 1) * D * D, Sn);
+        load_mat<T, D, D>(pX + tid * D * D, X);                    // Cov(x_{k+1}, x_k)
+        load_mat<T, D, D>(a.A + tid * D * D, Am);
+        load_lower<T, D>(a.cholQ + tid * D * D, C);
+        tri_inv_lower<T, D>(C, Ci, la, bad);
+        T eb[D];
+        MF_UNROLL for (int i = 0; i < D; ++i) {
+            T acc = mn[i] - a.b[tid * D + i];
+            MF_UNROLL for (int l = 0; l < D; ++l) acc -= Am[i][l] * mk[l];
+            eb[i] = acc;
+        }
+        // E[e x_k^T] = eb m_k^T + X - A S_k ;  A S_k kept for Psi
+        T AS[D][D], EX[D][D];
+        MF_UNROLL for (int i = 0; i < D; ++i)
+            MF_UNROLL for (int j = 0; j < D; ++j) {
+                T acc = T(0);
+                MF_UNROLL for (int l = 0; l < D; ++l) acc += Am[i][l] * Sk[l][j];
+                AS[i][j] = acc;
+                EX[i][j] = eb[i] * mk[j] + X[i][j] - acc;
+            }
+        // dA = Q^-1 E[e x^T] = C^-T (C^-1 EX) ; db = Q^-1 eb
+        T t1[D][D], dA[D][D], u[D], db[D];
+        trimul_lower<T, D, D>(Ci, EX, t1);
+        trimulT_lower<T, D, D>(Ci, t1, dA);
+        store_mat<T, D, D>(gA + tid * D * D, dA);
+        trimul_lower_vec<T, D>(Ci, eb, u);
+        trimulT_lower_vec<T, D>(Ci, u, db);
+        store_vec<T, D>(gb + tid * D, db);
+        // Psi = eb eb^T + S_{k+1} - A X^T - X A^T + A S_k A^T
+        T Psi[D][D];
+        MF_UNROLL for (int i = 0; i < D; ++i)
+            MF_UNROLL for (int j = 0; j < D; ++j) {
+                T acc = eb[i] * eb[j] + Sn[i][j];
+                MF_UNROLL for (int l = 0; l < D; ++l) acc += AS[i][l] * Am[j][l] - Am[i][l] * X[j][l] - X[i][l] * Am[j][l];
+                Psi[i][j] = acc;
+            }
+        T N1[D][D], N[D][D], G[D][D];
+        trimul_lower<T, D, D>(Ci, Psi, N1);
+        MF_UNROLL for (int i = 0; i < D; ++i)
+            MF_UNROLL for (int j = 0; j < D; ++j) {
+                T acc = (i == j) ? T(-1) : T(0);
+                MF_UNROLL for (int l = 0; l <= j; ++l) acc += N1[i][l] * Ci[j][l];
+                N[i][j] = acc;
+            }
+        trimulT_lower<T, D, D>(Ci, N, G);
+        store_lower<T, D>(gC + tid * D * D, G);
+    }
+    if (bad && a.info) atomicMax(a.info, 1);
+}
+
 }  // namespace mf

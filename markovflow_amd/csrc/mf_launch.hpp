@@ -42,6 +42,9 @@ template <typename T> struct OpsTable {
     int (*sde_predict)(long B, long N, long Np, const long long* idx, const T* Amt, const T* Qmt, const T* Atp, const T* Qtp,
                        const T* means, const T* covs, const T* subseq, const T* m0, const T* P0, T* omean, T* ocov,
                        int* info, hipStream_t st);
+    int (*kf_grad)(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H,
+                   const T* y, const T* Rinv, const T* pm, const T* pS, const T* pX, T* gmu0, T* gC0, T* gA, T* gb, T* gC,
+                   T* gH, T* gy, T* gOm, int* info, hipStream_t st);
 };
 
 constexpr int MF_MAX_D = 9;        // largest state dimension with a register-resident instantiation

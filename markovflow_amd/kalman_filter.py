@@ -23,6 +23,56 @@ from .emission_model import EmissionModel
 from .state_space_model import StateSpaceModel
 
 
+class _LogLikelihoodPerSeries(torch.autograd.Function):
+    """
+    Per-series log-likelihood (without the chain-independent constants) as a differentiable torch function of the flat
+    model tensors.  Forward: the fused HIP pipeline.  Backward: Fisher's identity on the smoothed marginals
+    (``mf_kf_loglik_grad_*``, csrc/mf_kernels.hpp) - the posterior chain, its marginal means / covariances and
+    cross-covariances are all HIP kernels, then ONE local kernel per (series, time point) produces every gradient.
+    Replaces the TensorFlow reverse mode over banded_matrices' registered gradients.
+    """
+
+    @staticmethod
+    def forward(ctx, mu0, cp0, a_s, b_s, cq, h, y, chol_r, chunks):
+        with torch.no_grad():
+            ssm = StateSpaceModel(mu0, cp0, a_s, b_s, cq)
+            kf = KalmanFilter(ssm, EmissionModel(h), y, chol_r)
+            kf._chunks = chunks
+            out = kf._log_likelihood_per_series()
+        ctx.save_for_backward(mu0, cp0, a_s, b_s, cq, h, y, chol_r)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        mu0, cp0, a_s, b_s, cq, h, y, chol_r = ctx.saved_tensors
+        with torch.no_grad():
+            ssm = StateSpaceModel(mu0, cp0, a_s, b_s, cq)
+            kf = KalmanFilter(ssm, EmissionModel(h), y, chol_r)
+            post = kf.posterior_state_space_model()
+            means, covs = post.marginals
+            cross = post.subsequent_covariances(covs)
+            bsz, n, m, d = h.shape
+            r_inv = kf._r_inv.contiguous()
+            g_mu0, g_cp0 = torch.empty_like(mu0), torch.empty_like(cp0)
+            g_a, g_b, g_cq = torch.empty_like(a_s), torch.empty_like(b_s), torch.empty_like(cq)
+            g_h, g_y = torch.empty_like(h), torch.empty_like(y)
+            g_om = torch.empty((bsz, n, m, m), dtype=h.dtype, device=h.device)
+            info = _lib.new_info(h.device)
+            c = lambda t: _lib.ptr(t.contiguous())  # noqa: E731
+            _lib.call("mf_kf_loglik_grad", h.dtype, bsz, n, d, m, c(mu0), c(cp0), c(a_s), c(b_s), c(cq), c(h), c(y), c(r_inv),
+                      c(means), c(covs), c(cross), _lib.ptr(g_mu0), _lib.ptr(g_cp0), _lib.ptr(g_a), _lib.ptr(g_b),
+                      _lib.ptr(g_cq), _lib.ptr(g_h), _lib.ptr(g_y), _lib.ptr(g_om), _lib.ptr(info), _lib.stream_ptr(h.device))
+            w = grad_out.reshape(bsz)
+            bc = lambda g: g * w.reshape((bsz,) + (1,) * (g.dim() - 1))  # noqa: E731
+            # shared observation covariance R = L L^T: d/dL of  -1/2 sum tr(R^-1 Omega)  =  tril(L^-T (L^-1 Omega_w L^-T));
+            # the log-determinant part of R lives in the constants, which torch differentiates outside this function
+            om_w = torch.sum(g_om * w.reshape(bsz, 1, 1, 1), dim=(0, 1))
+            eye = torch.eye(m, dtype=h.dtype, device=h.device)
+            l_inv = torch.linalg.solve_triangular(chol_r, eye, upper=False)
+            g_chol_r = torch.tril(l_inv.transpose(-1, -2) @ (l_inv @ om_w @ l_inv.transpose(-1, -2)))
+        return bc(g_mu0), bc(g_cp0), bc(g_a), bc(g_b), bc(g_cq), bc(g_h), bc(g_y), g_chol_r, None
+
+
 class BaseKalmanFilter(abc.ABC):
     """Kalman filter over a ``StateSpaceModel`` and an ``EmissionModel`` (kalman_filter.py:32-271)."""
 
@@ -124,9 +174,16 @@ class BaseKalmanFilter(abc.ABC):
         _lib.raise_on_info(info, "KalmanFilter.log_likelihood")
         return out
 
+    def _differentiable_per_series(self) -> Optional[torch.Tensor]:
+        """Per-series values through the autograd function when a model tensor requires a gradient (``KalmanFilter`` only)."""
+        return None
+
     def log_likelihood(self) -> torch.Tensor:
         """Log marginal likelihood, summed over ``batch_shape`` (kalman_filter.py:184-255)."""
-        per_series = self._log_likelihood_per_series().reshape(tuple(self.prior_ssm.batch_shape))
+        per_series = self._differentiable_per_series()
+        if per_series is None:
+            per_series = self._log_likelihood_per_series()
+        per_series = per_series.reshape(tuple(self.prior_ssm.batch_shape))
         num_data = self.prior_ssm.num_transitions + 1
         return torch.sum(per_series + self._constant_terms(num_data))
 
@@ -181,6 +238,16 @@ class KalmanFilter(BaseKalmanFilter):
     @property
     def observations(self) -> torch.Tensor:
         return self._observations
+
+    def _differentiable_per_series(self) -> Optional[torch.Tensor]:
+        mu0, cp0, a_s, b_s, cq = self.prior_ssm._flat_params()
+        h, y, _ = self._expanded()
+        tensors = (mu0, cp0, a_s, b_s, cq, h, y, self._chol_obs_covariance)
+        if not torch.is_grad_enabled() or not any(t.requires_grad for t in tensors):
+            return None
+        if self.prior_ssm.state_dim > 9 or h.shape[-2] > 4:
+            raise NotImplementedError("gradients of log_likelihood: state_dim <= 9 and output_dim <= 4")
+        return _LogLikelihoodPerSeries.apply(*tensors, self._chunks)
 
 
 class GaussianSites(abc.ABC):

@@ -83,8 +83,41 @@ class SDEKernel(abc.ABC):
         ref = self._components()[0]._variance_t
         return self._jitter * torch.eye(self.state_dim, dtype=ref.dtype, device=ref.device)
 
+    def _needs_grad(self) -> bool:
+        return torch.is_grad_enabled() and any(
+            c._lengthscale_t.requires_grad or c._variance_t.requires_grad for c in self._components())
+
+    def _torch_transitions(self, time_deltas: torch.Tensor, want_chol: bool, want_cov: bool):
+        """The same closed forms in differentiable torch ops: used only while a hyper-parameter requires a gradient (the
+        HIP generator has no backward); the chain rule then runs  hyper-parameters -> (A, chol Q) -> log-likelihood, the
+        last link being the Fisher-identity kernel of ``KalmanFilter``."""
+        blocks_a, blocks_q = [], []
+        dtm = time_deltas[..., None, None]
+        for c in self._components():
+            lam = c._lambda.to(dtype=time_deltas.dtype, device=time_deltas.device)
+            lam_b = lam[..., None, None, None] if lam.dim() > 0 else lam
+            k = c.state_dim
+            f, pinf = c.feedback_matrix.to(time_deltas), c.steady_state_covariance.to(time_deltas)
+            eye = torch.eye(k, dtype=time_deltas.dtype, device=time_deltas.device)
+            nil = f + (lam[..., None, None] if lam.dim() > 0 else lam) * eye          # nilpotent: (F + lam I)^k = 0
+            nil_b = nil[..., None, :, :] if nil.dim() > 2 else nil
+            a = eye + nil_b * dtm
+            if k == 3:
+                a = a + (nil_b @ nil_b) * (0.5 * dtm ** 2)
+            a = a * torch.exp(-lam_b * dtm)
+            p_b = pinf[..., None, :, :] if pinf.dim() > 2 else pinf
+            q = p_b - a @ p_b @ a.transpose(-1, -2)
+            blocks_a.append(a)
+            blocks_q.append(0.5 * (q + q.transpose(-1, -2)))
+        a_s = _block_diag(blocks_a)
+        q_s = _block_diag(blocks_q) + self.jitter_matrix.to(time_deltas)
+        chol = torch.linalg.cholesky(q_s) if want_chol else None
+        return a_s, chol, (q_s if want_cov else None)
+
     def _device_transitions(self, time_deltas: torch.Tensor, want_chol: bool, want_cov: bool):
         """(A, chol Q, Q) for ``time_deltas`` of shape ``batch_shape + [n]`` through the HIP kernel."""
+        if self._needs_grad():
+            return self._torch_transitions(time_deltas, want_chol, want_cov)
         comps = self._components()
         batch = tuple(time_deltas.shape[:-1])
         n, d = time_deltas.shape[-1], self.state_dim

@@ -76,6 +76,9 @@ class GaussianProcessRegression:
         if (not self.fused or isinstance(self._kernel, IndependentMultiOutput) or len(comps) > 2
                 or self._observations.shape[-1] != 1 or not self._observations.is_cuda):
             return None
+        if torch.is_grad_enabled() and (self._kernel._needs_grad() or self._chol_obs_covariance.requires_grad
+                                        or self._observations.requires_grad):
+            return None                     # the fused kernel has no backward: the differentiable materialised route runs
         batch = tuple(self._time_points.shape[:-1])
         n, dtype, dev = self._time_points.shape[-1], self._observations.dtype, self._observations.device
         t = self._time_points.reshape(-1, n).to(dtype).contiguous()

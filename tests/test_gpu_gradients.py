@@ -1,0 +1,99 @@
+"""
+GPU tests of the gradients of KalmanFilter.log_likelihood.  The reference pins gradients through
+tests/integration/models/test_gaussian_process_regression.py:117-130 (GPR gradients against GPflow's dense GP); here:
+  * every tensor gradient (mu0, cholP0, A, b, cholQ, H, y, cholR) against torch autograd through a DENSE joint-Gaussian
+    restatement of the same model (fp64, CPU) - an independent route to the same derivative;
+  * GPR hyper-parameter gradients (lengthscale, variance per component, noise) against autograd through the dense GP
+    marginal likelihood, the identity the reference tests.
+Tolerance: rtol 1e-6 (Fisher's identity is exact; the smoother's rounding is what is left).
+"""
+import numpy as np
+import pytest
+import torch
+
+import markovflow_amd as mfa
+from test_gpu_kalman import random_ssm
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dense_log_likelihood(mu0, cp0, a_s, b_s, cq, h, y, chol_r):
+    """log N(y; H mu, H Sigma H^T + R) of ONE series from the dense joint of the chain - plain differentiable torch."""
+    n, d = a_s.shape[0] + 1, mu0.shape[0]
+    m = h.shape[1]
+    means, covs = [mu0], [cp0 @ cp0.T]
+    cross = {}
+    for k in range(n - 1):
+        q = cq[k] @ cq[k].T
+        means.append(a_s[k] @ means[k] + b_s[k])
+        covs.append(a_s[k] @ covs[k] @ a_s[k].T + q)
+    big = torch.zeros(n * d, n * d, dtype=mu0.dtype)
+    for i in range(n):
+        big[i * d:(i + 1) * d, i * d:(i + 1) * d] = covs[i]
+        c = covs[i]
+        for j in range(i + 1, n):
+            c = a_s[j - 1] @ c
+            big[j * d:(j + 1) * d, i * d:(i + 1) * d] = c
+            big[i * d:(i + 1) * d, j * d:(j + 1) * d] = c.T
+    hm = torch.zeros(n * m, n * d, dtype=mu0.dtype)
+    for i in range(n):
+        hm[i * m:(i + 1) * m, i * d:(i + 1) * d] = h[i]
+    mean_y = hm @ torch.cat(means)
+    cov_y = hm @ big @ hm.T + torch.block_diag(*[chol_r @ chol_r.T] * n)
+    res = y.reshape(-1) - mean_y
+    return -0.5 * (res @ torch.linalg.solve(cov_y, res) + torch.linalg.slogdet(cov_y)[1] + n * m * np.log(2 * np.pi))
+
+
+@pytest.mark.parametrize("d,m,t,bsz", [(2, 1, 6, 3), (3, 2, 5, 2), (6, 1, 9, 2), (4, 3, 4, 1)])
+def test_tensor_gradients_vs_dense_autograd(rng, d, m, t, bsz):
+    kw = random_ssm(rng, (bsz,), t, d, m, well=True)
+    chol_r = np.linalg.cholesky(0.4 * np.eye(m) + 0.1 * np.ones((m, m)))
+    names = ["mu0", "chol_p0", "a_s", "b_s", "chol_q", "h", "y"]
+    cpu = {k: torch.tensor(kw[k], dtype=torch.float64, requires_grad=True) for k in names}
+    cpu_r = torch.tensor(chol_r, dtype=torch.float64, requires_grad=True)
+    total = sum(dense_log_likelihood(*(cpu[k][s] for k in names), cpu_r) for s in range(bsz))
+    total.backward()
+    gpu = {k: torch.tensor(kw[k], dtype=torch.float64, device=DEV, requires_grad=True) for k in names}
+    gpu_r = torch.tensor(chol_r, dtype=torch.float64, device=DEV, requires_grad=True)
+    ssm = mfa.StateSpaceModel(gpu["mu0"], gpu["chol_p0"], gpu["a_s"], gpu["b_s"], gpu["chol_q"])
+    ll = mfa.KalmanFilter(ssm, mfa.EmissionModel(gpu["h"]), gpu["y"], gpu_r).log_likelihood()
+    assert float(ll.detach()) == pytest.approx(float(total.detach()), rel=1e-10)
+    ll.backward()
+    for k in names:
+        want = cpu[k].grad.numpy()
+        if k in ("chol_p0", "chol_q"):
+            want = np.tril(want)                # the factors are lower triangular by construction: only those entries vary
+        np.testing.assert_allclose(gpu[k].grad.cpu().numpy(), want, rtol=1e-6, atol=1e-8, err_msg=k)
+    np.testing.assert_allclose(gpu_r.grad.cpu().numpy(), np.tril(cpu_r.grad.numpy()), rtol=1e-6, atol=1e-8)
+
+
+def test_gpr_hyperparameter_gradients_vs_dense_gp(rng):
+    """d log p(y) / d (lengthscale, variance, noise std) for Sum(Matern52, Matern32) against autograd through the dense GP
+    marginal likelihood (the check of test_gaussian_process_regression.py:117-130 of the reference)."""
+    n, bsz = 40, 2
+    t = np.cumsum(0.1 + rng.exponential(0.2, size=(bsz, n)), axis=-1)
+    y = rng.normal(size=(bsz, n, 1))
+    vals = dict(l5=0.8, v5=1.2, l3=1.4, v3=0.6, s=0.3)
+    cpu = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in vals.items()}
+    tt_, yt = torch.tensor(t), torch.tensor(y[..., 0])
+    total = 0.0
+    for s in range(bsz):
+        r = (tt_[s][:, None] - tt_[s][None, :]).abs()
+        l5, l3 = np.sqrt(5.0) / cpu["l5"], np.sqrt(3.0) / cpu["l3"]
+        kmat = cpu["v5"] * (1 + l5 * r + (l5 * r) ** 2 / 3) * torch.exp(-l5 * r) + cpu["v3"] * (1 + l3 * r) * torch.exp(-l3 * r)
+        kn = kmat + cpu["s"] ** 2 * torch.eye(n, dtype=torch.float64)
+        total = total - 0.5 * (yt[s] @ torch.linalg.solve(kn, yt[s]) + torch.linalg.slogdet(kn)[1] + n * np.log(2 * np.pi))
+    total.backward()
+    gpu = {k: torch.tensor(v, dtype=torch.float64, device=DEV, requires_grad=True) for k, v in vals.items()}
+    kern = mfa.Sum([mfa.Matern52(gpu["l5"], gpu["v5"]), mfa.Matern32(gpu["l3"], gpu["v3"])])
+    gpr = mfa.GaussianProcessRegression((torch.tensor(t, device=DEV), torch.tensor(y, device=DEV)), kern,
+                                        chol_obs_covariance=gpu["s"].reshape(1, 1))
+    ll = gpr.log_likelihood()
+    assert float(ll.detach()) == pytest.approx(float(total.detach()), rel=1e-9)
+    ll.backward()
+    for k in vals:
+        assert float(gpu[k].grad) == pytest.approx(float(cpu[k].grad), rel=1e-6), k
+    # without gradients requested the fused kernel runs and agrees
+    with torch.no_grad():
+        assert float(gpr.log_likelihood()) == pytest.approx(float(total.detach()), rel=1e-9)
