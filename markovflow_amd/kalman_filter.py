@@ -225,7 +225,7 @@ class KalmanFilter(BaseKalmanFilter):
         if chol.shape[-1] == 1:
             return 1.0 / (chol * chol)            # one tiny kernel pair instead of a potrs call chain
         eye = torch.eye(self.emission.output_dim, dtype=chol.dtype, device=chol.device)
-        return torch.cholesky_solve(eye, chol)
+        return _lib.chol_solve(chol, eye.expand(chol.shape))
 
     @property
     def _log_det_observation_precision(self) -> torch.Tensor:
