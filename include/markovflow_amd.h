@@ -224,6 +224,18 @@ int mf_gpr_matern_loglik_f32(int64_t B, int64_t T, int ncomp, const int* orders,
                              void* prof_start, void* prof_stop, void* stream);
 
 /*
+ * Last line of BaseKalmanFilter.log_likelihood (markovflow/kalman_filter.py:229-231,249-255) as ONE kernel:
+ *   out[0] = sum_s per_series[s] + B * ( host_const - num_points * sum_i log chol_obs[i][i] + extra_const[0] )
+ * per_series [B]: the output of the per-series entry point above; chol_obs [m,m] (nullable): Cholesky factor of the shared
+ * observation covariance, contributing 1/2 T log|R^-1|; extra_const (nullable): one device scalar (e.g. the summed
+ * log-determinants of per-step site precisions); host_const: -1/2 m T log(2 pi).  Accumulates in double.
+ */
+int mf_kf_loglik_total_f64(int64_t B, const double* per_series, int m, const double* chol_obs, int64_t num_points,
+                           const double* extra_const, double host_const, double* out, void* stream);
+int mf_kf_loglik_total_f32(int64_t B, const float* per_series, int m, const float* chol_obs, int64_t num_points,
+                           const float* extra_const, float host_const, float* out, void* stream);
+
+/*
  * Posterior prediction of the state at new time points: conditional_predict of
  * markovflow/conditionals.py:29-83 with _conditional_statistics_from_transitions (:122-203) and base_conditional_predict
  * (:380-420) fused, one lane per (series, new point).  idx [B,Np] (int64, device): insertion index of each new point

@@ -32,6 +32,7 @@ _SIGS = {
     "mf_block_matmul": (_int, [_i64, _i64, _int, "Tp", _i64, "Tp", _i64, "Tp", _vp]),
     "mf_gpr_matern_loglik": (_int, [_i64, _i64, _int, ctypes.POINTER(ctypes.c_int), "Tp", "Tp", _int, "Tp", "Tp", "Tp", "T", "T",
                                     "Tp", _vp, _sz, _vp, _i64, _vp, _vp, _vp]),
+    "mf_kf_loglik_total": (_int, [_i64, "Tp", _int, "Tp", _i64, "Tp", "T", "Tp", _vp]),
     "mf_kf_loglik_grad": (_int, [_i64, _i64, _int, _int] + ["Tp"] * 19 + [_vp, _vp]),
     "mf_sde_conditional_predict": (_int, [_i64, _i64, _i64, _int, _vp, "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", "Tp",
                                           "Tp", "Tp", _vp, _vp]),
@@ -156,6 +157,12 @@ def new_info(device) -> torch.Tensor:
 CHECK_PIVOTS = os.environ.get("MF_CHECK_PIVOTS", "0") == "1"
 
 
-def raise_on_info(info: torch.Tensor, what: str):
-    if CHECK_PIVOTS and int(info.item()) != 0:
+def pivot_info(device) -> Optional[torch.Tensor]:
+    """The `info` flag the product path hands to the C ABI: a zeroed device int when pivots are checked, else NULL (the flag
+    is optional in every entry point; without it a non-positive pivot shows up as NaN, and no fill kernel is launched)."""
+    return new_info(device) if CHECK_PIVOTS else None
+
+
+def raise_on_info(info: Optional[torch.Tensor], what: str):
+    if CHECK_PIVOTS and info is not None and int(info.item()) != 0:
         raise MarkovflowAmdError(f"{what}: matrix is not positive definite")

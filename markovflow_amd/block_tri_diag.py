@@ -248,7 +248,7 @@ class SymmetricBlockTriDiagonal(BlockTriDiagonal):
         sub = None if self._sub_diag is None else _flat(self._sub_diag, 3)
         ldiag = torch.empty_like(diag)
         lsub = None if sub is None else torch.empty_like(sub)
-        info = _lib.new_info(diag.device)
+        info = _lib.pivot_info(diag.device)
         ws_bytes = int(_lib.load().mf_btd_cholesky_workspace_bytes(diag.shape[0], self.outer_dim, self.inner_dim,
                                                                     diag.element_size()))
         ws = _lib.workspace(ws_bytes, diag.device)
@@ -275,7 +275,7 @@ class SymmetricBlockTriDiagonal(BlockTriDiagonal):
         if eta is not None:
             eta_f = _flat(eta, 2)
             m_post, chol_dinv = torch.empty_like(eta_f), torch.empty_like(diag)
-        info = _lib.new_info(diag.device)
+        info = _lib.pivot_info(diag.device)
         ws_bytes = int(_lib.load().mf_btd_udl_workspace_bytes(diag.shape[0], self.outer_dim, self.inner_dim,
                                                                diag.element_size()))
         ws = _lib.workspace(ws_bytes, diag.device)

@@ -62,9 +62,54 @@ int kf_loglik(int64_t B, int64_t Tn, int d, int m, const T* mu0, const T* cholP0
                         info, chunks, static_cast<hipEvent_t>(ev0), static_cast<hipEvent_t>(ev1), S(stream));
 }
 
+
+// sum of the per-series values + B x constant terms (kalman_filter.py:229-231,249-255): one workgroup
+template <typename T>
+__global__ void __launch_bounds__(256) loglik_total_kernel(long B, const T* __restrict__ per_series, int m,
+                                                           const T* __restrict__ chol_obs, long num_points,
+                                                           const T* __restrict__ extra, T host_const, T* __restrict__ out) {
+    __shared__ double part[4];
+    double acc = 0.0;
+    for (long s = threadIdx.x; s < B; s += 256) acc += (double)per_series[s];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double c = (double)host_const;
+        if (chol_obs) {
+            double ld = 0.0;
+            for (int i = 0; i < m; ++i) ld += log(fabs((double)chol_obs[i * m + i]));
+            c -= (double)num_points * ld;
+        }
+        if (extra) c += (double)extra[0];
+        out[0] = (T)(part[0] + part[1] + part[2] + part[3] + (double)B * c);
+    }
+}
+
+template <typename T>
+int loglik_total(int64_t B, const T* per_series, int m, const T* chol_obs, int64_t num_points, const T* extra, T host_const,
+                 T* out, void* stream) {
+    if (B < 0) return -1;
+    if (B > 0 && !per_series) return -2;
+    if (chol_obs && m < 1) return -3;
+    if (!out) return -8;
+    hipLaunchKernelGGL((loglik_total_kernel<T>), dim3(1), dim3(256), 0, S(stream), (long)B, per_series, m, chol_obs,
+                       (long)num_points, extra, host_const, out);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
 }  // namespace
 
 extern "C" {
+
+int mf_kf_loglik_total_f64(int64_t B, const double* per_series, int m, const double* chol_obs, int64_t num_points,
+                           const double* extra_const, double host_const, double* out, void* stream) {
+    return loglik_total<double>(B, per_series, m, chol_obs, num_points, extra_const, host_const, out, stream);
+}
+int mf_kf_loglik_total_f32(int64_t B, const float* per_series, int m, const float* chol_obs, int64_t num_points,
+                           const float* extra_const, float host_const, float* out, void* stream) {
+    return loglik_total<float>(B, per_series, m, chol_obs, num_points, extra_const, host_const, out, stream);
+}
 
 int mf_version(void) { return 1; }
 int mf_max_state_dim(void) { return mf::MF_MAX_D; }

@@ -42,5 +42,5 @@ def sharded_log_likelihood(kalman_filter, group: Optional[dist.ProcessGroup] = N
     Total log marginal likelihood of a batch that is sharded over the ranks: ``kalman_filter`` holds THIS
     rank's series only; the result is identical on every rank.  An empty local shard contributes zero.
     """
-    local = kalman_filter.log_likelihood()
-    return all_reduce_sum(local.reshape(()).clone(), group)
+    local = kalman_filter.log_likelihood().reshape(())     # a fresh tensor: reduced in place (no copy kernel)
+    return all_reduce_sum(local.clone() if local.requires_grad else local, group)

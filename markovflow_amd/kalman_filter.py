@@ -57,7 +57,7 @@ class _LogLikelihoodPerSeries(torch.autograd.Function):
             g_a, g_b, g_cq = torch.empty_like(a_s), torch.empty_like(b_s), torch.empty_like(cq)
             g_h, g_y = torch.empty_like(h), torch.empty_like(y)
             g_om = torch.empty((bsz, n, m, m), dtype=h.dtype, device=h.device)
-            info = _lib.new_info(h.device)
+            info = _lib.pivot_info(h.device)
             c = lambda t: _lib.ptr(t.contiguous())  # noqa: E731
             _lib.call("mf_kf_loglik_grad", h.dtype, bsz, n, d, m, c(mu0), c(cp0), c(a_s), c(b_s), c(cq), c(h), c(y), c(r_inv),
                       c(means), c(covs), c(cross), _lib.ptr(g_mu0), _lib.ptr(g_cp0), _lib.ptr(g_a), _lib.ptr(g_b),
@@ -112,18 +112,19 @@ class BaseKalmanFilter(abc.ABC):
             raise ValueError(f"emission matrix has shape {tuple(h.shape)}, expected [..., {n}, {m}, {d}]")
         h = _flat(h.expand(batch + (n, m, d)), 3)
         y = _flat(self.observations.expand(batch + (n, m)), 2)
-        r_inv = self._r_inv
-        if self._r_inv_per_step:
+        r_inv = self._r_inv                       # evaluated ONCE per call: the property is lazy and uncached
+        per_step = r_inv.dim() > 2
+        if per_step:
             r_inv = _flat(r_inv.expand(batch + (n, m, m)), 3)
         else:
             r_inv = r_inv.contiguous()
-        return h, y, r_inv
+        return h, y, r_inv, per_step
 
     @property
     def _k_inv_post(self) -> SymmetricBlockTriDiagonal:
         """Posterior precision ``K⁻¹ + GᵀΣ⁻¹G`` (kalman_filter.py:86-101)."""
-        h, _, r_inv = self._expanded()
-        diag, sub, _ = self.prior_ssm._precision_and_eta(h, None, r_inv, self._r_inv_per_step, want_eta=False)
+        h, _, r_inv, per_step = self._expanded()
+        diag, sub, _ = self.prior_ssm._precision_and_eta(h, None, r_inv, per_step, want_eta=False)
         return SymmetricBlockTriDiagonal(diag, sub)
 
     @property
@@ -134,9 +135,9 @@ class BaseKalmanFilter(abc.ABC):
 
     def posterior_state_space_model(self) -> StateSpaceModel:
         """Posterior as a state space model (kalman_filter.py:109-182)."""
-        h, y, r_inv = self._expanded()
+        h, y, r_inv, per_step = self._expanded()
         # posterior precision and  GᵀΣ⁻¹y + K⁻¹μ  (kalman_filter.py:149-156) in one parallel kernel
-        diag, sub, eta = self.prior_ssm._precision_and_eta(h, y, r_inv, self._r_inv_per_step, want_eta=True)
+        diag, sub, eta = self.prior_ssm._precision_and_eta(h, y, r_inv, per_step, want_eta=True)
         # backward UDUᵀ sweep, m_post and chol(Δ⁻¹) fused (kalman_filter.py:159-174)
         u_t, _, m_post, chol_dinv = SymmetricBlockTriDiagonal(diag, sub)._udl(eta)
         return StateSpaceModel(
@@ -155,7 +156,7 @@ class BaseKalmanFilter(abc.ABC):
     def _log_likelihood_per_series(self) -> torch.Tensor:
         """Per-series log-likelihood WITHOUT the chain-independent constant terms, shape [B]."""
         mu0, cp0, a_s, b_s, cq = self.prior_ssm._flat_params()
-        h, y, r_inv = self._expanded()
+        h, y, r_inv, per_step = self._expanded()
         bsz, n, d, m = a_s.shape[0], self.prior_ssm.num_transitions + 1, self.prior_ssm.state_dim, h.shape[-2]
         lib = _lib.load()
         esz = a_s.element_size()
@@ -166,9 +167,9 @@ class BaseKalmanFilter(abc.ABC):
             _lib.check(-100, "mf_kf_loglik")
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a_s.device)
         out = torch.empty(bsz, dtype=a_s.dtype, device=a_s.device)
-        info = _lib.new_info(a_s.device)
+        info = _lib.pivot_info(a_s.device)           # None unless MF_CHECK_PIVOTS=1
         _lib.call("mf_kf_loglik", a_s.dtype, bsz, n, d, m, _lib.ptr(mu0), _lib.ptr(cp0), _lib.ptr(a_s),
-                  _lib.ptr(b_s), _lib.ptr(cq), _lib.ptr(h), _lib.ptr(y), _lib.ptr(r_inv), int(self._r_inv_per_step),
+                  _lib.ptr(b_s), _lib.ptr(cq), _lib.ptr(h), _lib.ptr(y), _lib.ptr(r_inv), int(per_step),
                   0.0, _lib.ptr(out), _lib.ptr(ws), ws_bytes, _lib.ptr(info), self._chunks, self._prof_events[0],
                   self._prof_events[1], _lib.stream_ptr(a_s.device))
         _lib.raise_on_info(info, "KalmanFilter.log_likelihood")
@@ -180,12 +181,36 @@ class BaseKalmanFilter(abc.ABC):
 
     def log_likelihood(self) -> torch.Tensor:
         """Log marginal likelihood, summed over ``batch_shape`` (kalman_filter.py:184-255)."""
+        num_data = self.prior_ssm.num_transitions + 1
         per_series = self._differentiable_per_series()
         if per_series is None:
             per_series = self._log_likelihood_per_series()
+            fused = self._fused_total(per_series, num_data)
+            if fused is not None:
+                return fused
         per_series = per_series.reshape(tuple(self.prior_ssm.batch_shape))
-        num_data = self.prior_ssm.num_transitions + 1
         return torch.sum(per_series + self._constant_terms(num_data))
+
+    def _total_terms(self):
+        """``(chol_obs | None, extra device scalar | None)`` for ``mf_kf_loglik_total``: how this filter's
+        ``½ log|Σ⁻¹|`` term is handed to the kernel; ``None`` = no fused form, fall back to the torch expression."""
+        return None
+
+    def _fused_total(self, per_series: torch.Tensor, num_points: int) -> Optional[torch.Tensor]:
+        """``Σ_batch (per_series + constant terms)`` in one kernel instead of ~10 elementwise / reduce launches (each
+        ≈6 µs of dispatch on this GPU: 10 % of a B=1024, T=10000 evaluation)."""
+        terms = self._total_terms()
+        if terms is None:
+            return None
+        chol_obs, extra = terms
+        out = torch.empty((), dtype=per_series.dtype, device=per_series.device)
+        m = self.emission.output_dim
+        cst = -0.5 * math.log(2 * math.pi) * (m * num_points)
+        _lib.call("mf_kf_loglik_total", per_series.dtype, per_series.numel(), _lib.ptr(per_series), m,
+                  _lib.ptr(None if chol_obs is None else chol_obs.contiguous()), num_points,
+                  _lib.ptr(None if extra is None else extra.contiguous()), cst, _lib.ptr(out),
+                  _lib.stream_ptr(per_series.device))
+        return out
 
     def _back_project_y_to_state(self, observations: torch.Tensor) -> torch.Tensor:
         """``(GᵀΣ⁻¹) y`` (kalman_filter.py:257-271)."""
@@ -223,7 +248,7 @@ class KalmanFilter(BaseKalmanFilter):
         """``R⁻¹ = (chol cholᵀ)⁻¹`` (kalman_filter.py:341-348)."""
         chol = self._chol_obs_covariance
         if chol.shape[-1] == 1:
-            return 1.0 / (chol * chol)            # one tiny kernel pair instead of a potrs call chain
+            return chol.pow(-2)                   # one tiny kernel instead of a potrs call chain
         eye = torch.eye(self.emission.output_dim, dtype=chol.dtype, device=chol.device)
         return _lib.chol_solve(chol, eye.expand(chol.shape))
 
@@ -239,9 +264,12 @@ class KalmanFilter(BaseKalmanFilter):
     def observations(self) -> torch.Tensor:
         return self._observations
 
+    def _total_terms(self):
+        return self._chol_obs_covariance, None
+
     def _differentiable_per_series(self) -> Optional[torch.Tensor]:
         mu0, cp0, a_s, b_s, cq = self.prior_ssm._flat_params()
-        h, y, _ = self._expanded()
+        h, y, _, _ = self._expanded()
         tensors = (mu0, cp0, a_s, b_s, cq, h, y, self._chol_obs_covariance)
         if not torch.is_grad_enabled() or not any(t.requires_grad for t in tensors):
             return None
@@ -311,6 +339,10 @@ class KalmanFilterWithSites(BaseKalmanFilter):
     @property
     def _log_det_observation_precision(self):
         return torch.sum(torch.linalg.slogdet(self._r_inv)[1], dim=-1)
+
+    def _total_terms(self):
+        extra = 0.5 * self._log_det_observation_precision
+        return (None, extra.reshape(1)) if extra.numel() == 1 else None
 
     @property
     def observations(self):

@@ -103,7 +103,7 @@ class GaussianProcessRegression:
             return None
         ws = _lib.workspace(ws_bytes, dev)
         out = torch.empty(bsz, dtype=dtype, device=dev)
-        info = _lib.new_info(dev)
+        info = _lib.pivot_info(dev)
         orders = (ctypes.c_int * len(comps))(*[c.order for c in comps])
         fn = getattr(lib, "mf_gpr_matern_loglik" + _lib.suffix(dtype))
         rc = fn(bsz, n, len(comps), orders, _lib.ptr(lam_t), _lib.ptr(var_t), int(per_series), _lib.ptr(t), _lib.ptr(y),

@@ -56,7 +56,7 @@ class ConditionalProcess:
         bsz = max(1, int(torch.tensor(batch).prod())) if batch else 1
         out_mean = torch.empty((bsz, n_new, d), dtype=dtype, device=dev)
         out_cov = torch.empty((bsz, n_new, d, d), dtype=dtype, device=dev)
-        info = _lib.new_info(dev)
+        info = _lib.pivot_info(dev)
         _lib.call("mf_sde_conditional_predict", dtype, bsz, n, n_new, d, _lib.ptr(flat(idx, 1)), _lib.ptr(flat(a_mt, 3)),
                   _lib.ptr(flat(q_mt, 3)), _lib.ptr(flat(a_tp, 3)), _lib.ptr(flat(q_tp, 3)), _lib.ptr(flat(means, 2)),
                   _lib.ptr(flat(covs, 3)), _lib.ptr(None if sub is None else flat(sub, 3)), _lib.ptr(flat(m0, 1)),
