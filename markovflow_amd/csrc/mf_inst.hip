@@ -5,6 +5,7 @@
 #endif
 #include "mf_kernels.hpp"
 #include "mf_kf_lds.hpp"
+#include "mf_kf_x.hpp"
 #include "mf_btd_par.hpp"
 #include "mf_gpr_fused.hpp"
 #include "mf_launch.hpp"
@@ -69,6 +70,19 @@ template <typename T> size_t levels_ws(long B, long P) {
     return total;
 }
 
+// State dimensions whose elimination state (with the spike) does not fit a lane's 512 registers take the kernels of
+// mf_kf_x.hpp (spike in LDS): d >= 7 in fp64, d = 9 in fp32.  MF_KF_X=0 switches them off (A/B timing).
+template <typename T> bool x_path() {
+    static const bool on = [] { const char* e = std::getenv("MF_KF_X"); return !(e && e[0] == '0'); }();
+    return on && ((sizeof(T) == 8 && D >= 7) || (sizeof(T) == 4 && D >= 9));
+}
+// lanes that fill the chip with the spike of every lane in LDS
+template <typename T> long x_target_lanes() {
+    int w = (160 * 1024) / LdsSpike<T, D>::BYTES;
+    w = w > 4 ? 4 : (w < 1 ? 1 : w);
+    return 256L * 64 * w;
+}
+
 // Reduce `cur` (already in workspace or user memory) down to a scalar per series.
 template <typename T>
 int reduce_levels(RedSys<T> cur, long B, char* p, T add_const, T* out, int* info, hipStream_t st) {
@@ -76,8 +90,13 @@ int reduce_levels(RedSys<T> cur, long B, char* p, T add_const, T* out, int* info
         const long P = cdiv(cur.n, RED_CHUNK);
         RedSys<T> nxt = carve<T>(p, B, P);
         const long lanes = B * P;
-        hipLaunchKernelGGL((red_chunk_kernel<T, D, true>), dim3((unsigned)cdiv(lanes, 64)), dim3(64), 0, st, cur, nxt, B,
-                           P, info);
+        constexpr int x_lds = LdsSpike<T, D>::BYTES;
+        if (x_path<T>())
+            hipLaunchKernelGGL((red_chunk_x_kernel<T, D>), dim3((unsigned)cdiv(lanes, 64)), dim3(64), x_lds, st, cur, nxt, B,
+                               P, info);
+        else
+            hipLaunchKernelGGL((red_chunk_kernel<T, D, true>), dim3((unsigned)cdiv(lanes, 64)), dim3(64), 0, st, cur, nxt,
+                               B, P, info);
         cur = nxt;
     }
     hipLaunchKernelGGL((red_final_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, cur, B, add_const, out,
@@ -142,6 +161,23 @@ int kf_loglik(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A,
               size_t ws_bytes, int* info, long chunks, hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
     if (m < 1 || m > MF_MAXM) return -4;
     if (ws_bytes < kf_loglik_ws<T>(B, Tn, chunks) || ws == nullptr) return -15;
+    if (x_path<T>() && Tn >= 2) {
+        long P = chunks > 0 ? (chunks > Tn ? Tn : chunks) : cdiv(x_target_lanes<T>(), B);
+        if (chunks <= 0) {
+            const long maxP = Tn / 4 > 0 ? Tn / 4 : 1;
+            if (P > maxP) P = maxP;
+        }
+        if (P > 1) {
+            KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, info, 0};
+            char* p = static_cast<char*>(ws);
+            RedSys<T> lvl0 = carve<T>(p, B, P);
+            if (ev0) (void)hipEventRecord(ev0, st);
+            constexpr int x_lds = LdsSpike<T, D>::BYTES;
+            hipLaunchKernelGGL((kf_chunk_x_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), x_lds, st, a, lvl0);
+            if (ev1) (void)hipEventRecord(ev1, st);
+            return reduce_levels<T>(lvl0, B, p, add_const, out, info, st);
+        }
+    }
     if (use_lds_kernel<T>(Tn, m, A, cholQ, rinv_per_step)) {
         long P, L;
         lds_partition(B, Tn, chunks, P, L, lds_target_lanes<T>(m, rinv_per_step));
@@ -221,12 +257,18 @@ constexpr long PAR_MIN_BLOCKS = 64;      // never partition chains shorter than 
 constexpr long PAR_MAX_SERIES = 4096;    // with this many series one lane per series already fills the chip
 
 // level-0 chunk length (0 = use the serial one-lane-per-series kernel)
+// chunk length of the reduced levels of the parallel-in-time operators (and the size at which the coarsest level is walked
+// serially).  Sequential depth is ~ 2 r log_r(n): measured on config 3 (scripts/bench_btd.py) - see DESIGN.md 4.3.
+inline long par_radix() {
+    static const long r = [] { const char* e = std::getenv("MF_BTD_RADIX"); const long v = e ? std::atol(e) : 0; return v >= 2 ? v : RED_CHUNK; }();
+    return r;
+}
 inline long par_len0(long B, long n) {
     static const long force = [] { const char* e = std::getenv("MF_BTD_PAR_LEN"); return e ? std::atol(e) : -1L; }();
     if (force >= 0) return (force > 0 && n >= 2 * force) ? force : 0;
     if (B >= PAR_MAX_SERIES || n < PAR_MIN_BLOCKS) return 0;
     long len = cdiv(B * n, 65536);           // aim at one wavefront per SIMD ...
-    if (len < RED_CHUNK) len = RED_CHUNK;     // ... but keep the reduced system at most 1/8 of the input
+    if (len < par_radix()) len = par_radix(); // ... but keep the reduced system at most 1/r of the input
     return n >= 2 * len ? len : 0;
 }
 
@@ -243,8 +285,8 @@ inline ParPlan par_plan(long n0, long len0) {
     do {
         pl.n[l + 1] = cdiv(pl.n[l], pl.len[l]);
         ++l;
-        pl.len[l] = RED_CHUNK;
-    } while (pl.n[l] > RED_FINAL && l < 22);
+        pl.len[l] = par_radix();
+    } while (pl.n[l] > par_radix() && l < 22);
     pl.levels = l;
     return pl;
 }

@@ -9,8 +9,9 @@ idx = [i for i, n in enumerate(names) if "mf::" in n]
 if not idx:
     sys.exit("no mf:: kernels")
 # iterations: find marker positions = elementwise kernels immediately followed (within 30 kernels) by first mf kernel; simpler: cut at gaps
-first_mf = names[idx[0]]
-starts = [i for i in idx if names[i] == first_mf]
+starts = [i + 1 for i, n in enumerate(names) if "CUDAFunctorOnSelf_add<float>" in n]   # the marker of scripts/prof_cfg.py
+if len(starts) >= 2:
+    starts.append(len(rows))
 # the marker is somewhere before each start; an iteration = [starts[k]-back .. starts[k+1]-back)
 if len(starts) < 2:
     lo, hi = 0, len(rows)
@@ -26,5 +27,4 @@ for r in rows[lo:hi]:
     print(f"{(s - t0) / 1e3:10.1f} us  dur {(e - s) / 1e3:9.1f}  gap {gap:7.1f}  {n}")
     prev_end = e
     tot_busy += e - s
-print(f"iteration span {(int(rows[hi - 1]['End_Timestamp']) - t0) / 1e3:.1f} us (to next iteration start: "
-      f"{(int(rows[hi]['Start_Timestamp']) - t0) / 1e3 if hi < len(rows) else float('nan'):.1f}), busy {tot_busy / 1e3:.1f} us, kernels {hi - lo}")
+print(f"iteration span {(int(rows[hi - 1]['End_Timestamp']) - t0) / 1e3:.1f} us, busy {tot_busy / 1e3:.1f} us, kernels {hi - lo}")

@@ -156,6 +156,21 @@ def test_log_likelihood_matches_oracle_fp64(rng, d, m, t, batch):
     np.testing.assert_allclose(float(kf.log_likelihood().cpu()), ref, rtol=1e-9)
 
 
+@pytest.mark.parametrize("d,m", [(7, 1), (8, 2), (9, 3), (9, 1)])
+def test_spike_in_lds_kernels_fp64(rng, d, m):
+    """d >= 7 in fp64 runs the level-0 and reduction kernels that keep the spike in LDS (csrc/mf_kf_x.hpp): long enough
+    chains for two reduction levels, against the oracle and against other partitions of the same chain."""
+    t = 300
+    kw = random_ssm(rng, (2,), t, d, m, well=True)
+    r = rng.normal(size=(m, m)); cov = r @ r.T + np.eye(m)
+    r_inv = np.linalg.inv(cov)
+    ref = np.array([O.kf_log_likelihood(**{k: v[s] for k, v in kw.items()}, r_inv=r_inv) for s in range(2)])
+    cst = -0.5 * np.log(2 * np.pi) * m * t + 0.5 * t * np.linalg.slogdet(r_inv)[1]
+    for chunks in (0, 1, 5, 40, 75):
+        per = loglik_with_chunks(kw, r_inv, chunks)
+        np.testing.assert_allclose(per + cst, ref, rtol=1e-9, err_msg=f"chunks={chunks}")
+
+
 @pytest.mark.parametrize("chunks", [1, 2, 3, 7, 16, 61, 130])
 def test_time_partition_invariance_fp64(rng, chunks):
     """The result must not depend on how the chain is partitioned (ragged chunks included)."""
