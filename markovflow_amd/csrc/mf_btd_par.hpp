@@ -22,6 +22,7 @@
 // the affine recursion z_k = M_k z_{k-1} + c_k,  M_k = -L_k^-1 W_{k-1},  c_k = L_k^-1 r_k.
 #pragma once
 #include "mf_small.hpp"
+#include "mf_kf_x.hpp"
 
 namespace mf {
 
@@ -128,6 +129,69 @@ __global__ void __launch_bounds__(64) par_chol_up_kernel(ParLevel<T> in, long B,
     store_sym<T, D>(oGU + id * D * D, GU);
     store_mat<T, D, D>(oF + id * D * D, X);
     if (bad && info) atomicMax(info, 1);
+}
+
+// The same up-sweep with the spike (X, GU) in LDS - state dimensions whose chunk state does not fit a lane's registers
+// (mf_kf_x.hpp: d >= 7 in fp64, d = 9 in fp32; par_chol_up_kernel<double, 9> spilt 1.4 KB per lane).
+template <typename T, int D>
+__global__ void __launch_bounds__(64) par_chol_up_x_kernel(ParLevel<T> in, long B, long len, long P, T* __restrict__ oDv,
+                                                           T* __restrict__ oGf, T* __restrict__ oGU, T* __restrict__ oF,
+                                                           int* info) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int lane = threadIdx.x;
+    const long total = B * P;
+    const long id_raw = (long)blockIdx.x * 64 + lane;
+    const bool valid = id_raw < total;
+    const long id = valid ? id_raw : total - 1;
+    const long s = id / P, c = id % P;
+    const long k0 = c * len;
+    long k1 = k0 + len;
+    if (k1 > in.n) k1 = in.n;
+    if (!valid) k1 = k0;
+    ElimX<T, D> E;
+    E.init(reinterpret_cast<T*>(smem_raw), lane);
+    for (long k = k0; k < k1; ++k) {
+        const bool last = (k + 1 == k1);
+        T Dn[D][D];
+        {
+            T fut[D][D];
+            par_load_dv<T, D>(in, s, k, Dn);
+            par_future<T, D>(in, s, k, fut);
+            if (last) {
+                store_sym<T, D>(oGf + id * D * D, fut);
+            } else {
+                MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Dn[i][j] += fut[i][j];
+            }
+        }
+        if (k == k0) {
+            if (k > 0) {
+                T X0[D][D];
+                par_load_f<T, D>(in, s, k, X0);
+                MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) E.sp.setX(i, j, X0[i][j]);
+            }
+            MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) E.Phi[i][j] = Dn[i][j];
+            continue;
+        }
+        chol_lower<T, D>(E.Phi, E.Li, E.laL, E.bad);
+        E.laL.init();
+        if (k0 > 0) E.eliminate_spike();                      // V = L^-1 X, GU -= V^T V   (t = 0: gU stays 0)
+        T W[D][D];
+        par_load_f<T, D>(in, s, k, W);
+        trsm_right_lower_t<T, D, D>(E.Phi, E.Li, W);          // W = F_k L^-T
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) E.Phi[i][j] = Dn[i][j];
+        syrk_nt_lower<T, D, D>(W, E.Phi, T(-1));
+        if (k0 > 0) E.propagate_spike(W);
+    }
+    if (valid) {
+        store_sym<T, D>(oDv + id * D * D, E.Phi);
+        T* gu = oGU + id * D * D;
+        T* f = oF + id * D * D;
+        MF_UNROLL for (int i = 0; i < D; ++i) {
+            MF_UNROLL for (int j = 0; j <= i; ++j) { const T v = E.sp.G(i, j); gu[i * D + j] = v; gu[j * D + i] = v; }
+            MF_UNROLL for (int j = 0; j < D; ++j) f[i * D + j] = E.sp.X(i, j);
+        }
+        if (E.bad && info) atomicMax(info, 1);
+    }
 }
 
 // ---- Cholesky: down-sweep on a level >= 1 (also the serial walk of the coarsest level: len >= n, up = null) --------
@@ -433,22 +497,43 @@ __global__ void __launch_bounds__(64) par_means_emit_kernel(long Bl, long Br, lo
 // N = L_k^-T L_k^-1 and G = W_k L_k^-1.  A run of positions composes into one (Gc, Nc):
 //   Gc <- Gc G_p,   Nc <- N_p + G_p^T Nc G_p.
 template <typename T, int D> MF_DEV void congruence_step(const T (&G)[D][D], const T (&N)[D][D], T (&Sig)[D][D]) {
-    // Sig(full symmetric) <- N(lower) + G^T Sig G
-    T SG[D][D];
-    MF_UNROLL for (int i = 0; i < D; ++i)
-        MF_UNROLL for (int j = 0; j < D; ++j) {
-            T a = T(0);
-            MF_UNROLL for (int l = 0; l < D; ++l) a += Sig[i][l] * G[l][j];
-            SG[i][j] = a;
-        }
+    // Sig(full symmetric) <- N(lower) + G^T Sig G, one row of Sig G at a time (no d x d temporary for the product)
     T Out[D][D];
-    MF_UNROLL for (int i = 0; i < D; ++i)
-        MF_UNROLL for (int j = 0; j <= i; ++j) {
-            T a = N[i][j];
-            MF_UNROLL for (int l = 0; l < D; ++l) a += G[l][i] * SG[l][j];
-            Out[i][j] = a;
-        }
+    MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Out[i][j] = N[i][j];
+    MF_UNROLL for (int l = 0; l < D; ++l) {
+        T sg[D];
+        MF_UNROLL for (int j = 0; j < D; ++j) sg[j] = Sig[l][0] * G[0][j];
+        MF_UNROLL for (int q = 1; q < D; ++q) MF_UNROLL for (int j = 0; j < D; ++j) sg[j] += Sig[l][q] * G[q][j];
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Out[i][j] += G[l][i] * sg[j];
+    }
     MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Sig[i][j] = (i >= j) ? Out[i][j] : Out[j][i];
+}
+// The same with Sig held as its lower triangle only (45 instead of 81 registers at d = 9)
+template <typename T, int D> MF_DEV void congruence_step_lower(const T (&G)[D][D], const T (&N)[D][D], T (&S)[D][D]) {
+    T Out[D][D];
+    MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Out[i][j] = N[i][j];
+    MF_UNROLL for (int l = 0; l < D; ++l) {
+        T sg[D];
+        MF_UNROLL for (int j = 0; j < D; ++j) sg[j] = S[l][0] * G[0][j];                      // S(l, 0) = S[l][0]
+        MF_UNROLL for (int q = 1; q < D; ++q) {
+            const T slq = (l >= q) ? S[l][q] : S[q][l];
+            MF_UNROLL for (int j = 0; j < D; ++j) sg[j] += slq * G[q][j];
+        }
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Out[i][j] += G[l][i] * sg[j];
+    }
+    MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) S[i][j] = Out[i][j];
+}
+// Gc <- Gc G for a D x D matrix kept in LDS (element e of this lane at gc[e * 64]); one row at a time, loop not unrolled
+template <typename T, int D> MF_DEV void lds_rows_times(T* gc, const T (&G)[D][D]) {
+#pragma unroll 1
+    for (int i = 0; i < D; ++i) {
+        T* r = gc + i * D * 64;
+        T row[D], o[D];
+        MF_UNROLL for (int l = 0; l < D; ++l) row[l] = r[l * 64];
+        MF_UNROLL for (int j = 0; j < D; ++j) o[j] = row[0] * G[0][j];
+        MF_UNROLL for (int l = 1; l < D; ++l) MF_UNROLL for (int j = 0; j < D; ++j) o[j] += row[l] * G[l][j];
+        MF_UNROLL for (int j = 0; j < D; ++j) r[j * 64] = o[j];
+    }
 }
 // N (lower) and G of block k from the factor
 template <typename T, int D>
@@ -535,6 +620,79 @@ __global__ void __launch_bounds__(64) par_tak_up_kernel(long B, long n, long len
     store_mat<T, D, D>(oN + id * D * D, Nc);
 }
 
+// The two up-sweeps with the composed G of the run in LDS and Nc as a lower triangle (d >= 7 in fp64, see mf_kf_x.hpp)
+template <typename T, int D>
+__global__ void __launch_bounds__(64) par_tak_up0_x_kernel(long B, long n, long len, long P, const T* __restrict__ ldiag,
+                                                           const T* __restrict__ lsub, T* __restrict__ oG, T* __restrict__ oN) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* gc = reinterpret_cast<T*>(smem_raw) + threadIdx.x;
+    const long total = B * P;
+    const long id_raw = (long)blockIdx.x * 64 + threadIdx.x;
+    const bool valid = id_raw < total;
+    const long id = valid ? id_raw : total - 1;
+    const long s = id / P, c = id % P;
+    const long p0 = c * len;
+    long p1 = p0 + len;
+    if (p1 > n) p1 = n;
+    if (!valid) p1 = p0;
+    T Nc[D][D];
+    MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Nc[i][j] = T(0);
+    for (long p = p0; p < p1; ++p) {
+        const long k = n - 1 - p;
+        T N[D][D], G[D][D];
+        takahashi_terms<T, D>(ldiag, lsub, s, n, k, p > 0, N, G);
+        if (p == p0) {
+            MF_UNROLL for (int i = 0; i < D; ++i)
+                MF_UNROLL for (int j = 0; j < D; ++j) {
+                    if (j <= i) Nc[i][j] = N[i][j];
+                    gc[(i * D + j) * 64] = (p > 0) ? G[i][j] : T(0);
+                }
+        } else {
+            congruence_step_lower<T, D>(G, N, Nc);
+            lds_rows_times<T, D>(gc, G);
+        }
+    }
+    if (valid) {
+        store_sym<T, D>(oN + id * D * D, Nc);
+        T* g = oG + id * D * D;
+        MF_UNROLL for (int e = 0; e < D * D; ++e) g[e] = gc[e * 64];
+    }
+}
+
+template <typename T, int D>
+__global__ void __launch_bounds__(64) par_tak_up_x_kernel(long B, long n, long len, long P, const T* __restrict__ Gs,
+                                                          const T* __restrict__ Ns, T* __restrict__ oG, T* __restrict__ oN) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* gc = reinterpret_cast<T*>(smem_raw) + threadIdx.x;
+    const long total = B * P;
+    const long id_raw = (long)blockIdx.x * 64 + threadIdx.x;
+    const bool valid = id_raw < total;
+    const long id = valid ? id_raw : total - 1;
+    const long s = id / P, c = id % P;
+    const long p0 = c * len;
+    long p1 = p0 + len;
+    if (p1 > n) p1 = n;
+    T Nc[D][D];
+    load_lower<T, D>(Ns + (s * n + p0) * D * D, Nc);
+    {
+        const T* g0 = Gs + (s * n + p0) * D * D;
+        MF_UNROLL for (int e = 0; e < D * D; ++e) gc[e * 64] = g0[e];
+    }
+    if (!valid) p1 = p0;
+    for (long p = p0 + 1; p < p1; ++p) {
+        T G[D][D], N[D][D];
+        load_mat<T, D, D>(Gs + (s * n + p) * D * D, G);
+        load_lower<T, D>(Ns + (s * n + p) * D * D, N);
+        congruence_step_lower<T, D>(G, N, Nc);
+        lds_rows_times<T, D>(gc, G);
+    }
+    if (valid) {
+        store_sym<T, D>(oN + id * D * D, Nc);
+        T* g = oG + id * D * D;
+        MF_UNROLL for (int e = 0; e < D * D; ++e) g[e] = gc[e * 64];
+    }
+}
+
 // Sigma at every position of a level >= 1 (coarsest level: len >= n, up = null)
 template <typename T, int D>
 __global__ void __launch_bounds__(64) par_tak_down_kernel(long B, long n, long len, long P, const T* __restrict__ Gs,
@@ -546,18 +704,19 @@ __global__ void __launch_bounds__(64) par_tak_down_kernel(long B, long n, long l
     const long p0 = c * len;
     long p1 = p0 + len;
     if (p1 > n) p1 = n;
-    T Sig[D][D];
-    if (c > 0) load_mat<T, D, D>(up + (s * P + c - 1) * D * D, Sig);
+    T Sig[D][D];                                     // lower triangle
+    MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Sig[i][j] = T(0);
+    if (c > 0) load_lower<T, D>(up + (s * P + c - 1) * D * D, Sig);
     for (long p = p0; p < p1; ++p) {
         if (p > 0) {
             T G[D][D], N[D][D];
             load_mat<T, D, D>(Gs + (s * n + p) * D * D, G);
             load_lower<T, D>(Ns + (s * n + p) * D * D, N);
-            congruence_step<T, D>(G, N, Sig);
+            congruence_step_lower<T, D>(G, N, Sig);
         } else {
-            load_mat<T, D, D>(Ns + (s * n) * D * D, Sig);
+            load_lower<T, D>(Ns + (s * n) * D * D, Sig);
         }
-        store_mat<T, D, D>(Z + (s * n + p) * D * D, Sig);
+        store_sym<T, D>(Z + (s * n + p) * D * D, Sig);
     }
 }
 
@@ -571,28 +730,31 @@ __global__ void __launch_bounds__(64) par_tak_emit_kernel(long B, long n, long l
     const long p0 = c * len;
     long p1 = p0 + len;
     if (p1 > n) p1 = n;
-    T Sig[D][D];
-    if (c > 0) load_mat<T, D, D>(up + (s * P + c - 1) * D * D, Sig);
+    T Sig[D][D];                                     // lower triangle
+    MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Sig[i][j] = T(0);
+    if (c > 0) load_lower<T, D>(up + (s * P + c - 1) * D * D, Sig);
     for (long p = p0; p < p1; ++p) {
         const long k = n - 1 - p;
         T N[D][D], G[D][D];
         takahashi_terms<T, D>(ldiag, lsub, s, n, k, p > 0, N, G);
         if (p > 0) {
             if (osub) {
-                T neg[D][D];
-                MF_UNROLL for (int i = 0; i < D; ++i)
-                    MF_UNROLL for (int j = 0; j < D; ++j) {
-                        T a = T(0);
-                        MF_UNROLL for (int l = 0; l < D; ++l) a += Sig[i][l] * G[l][j];
-                        neg[i][j] = -a;
+                T* o = osub + (s * (n - 1) + k) * D * D;
+                MF_UNROLL for (int i = 0; i < D; ++i) {
+                    T row[D];
+                    MF_UNROLL for (int j = 0; j < D; ++j) row[j] = Sig[i][0] * G[0][j];
+                    MF_UNROLL for (int l = 1; l < D; ++l) {
+                        const T sil = (i >= l) ? Sig[i][l] : Sig[l][i];
+                        MF_UNROLL for (int j = 0; j < D; ++j) row[j] += sil * G[l][j];
                     }
-                store_mat<T, D, D>(osub + (s * (n - 1) + k) * D * D, neg);
+                    MF_UNROLL for (int j = 0; j < D; ++j) o[i * D + j] = -row[j];
+                }
             }
-            congruence_step<T, D>(G, N, Sig);
+            congruence_step_lower<T, D>(G, N, Sig);
         } else {
-            MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Sig[i][j] = (i >= j) ? N[i][j] : N[j][i];
+            MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Sig[i][j] = N[i][j];
         }
-        store_mat<T, D, D>(odiag + (s * n + k) * D * D, Sig);
+        store_sym<T, D>(odiag + (s * n + k) * D * D, Sig);
     }
 }
 

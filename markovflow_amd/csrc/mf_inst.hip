@@ -323,8 +323,13 @@ int btd_cholesky(long B, long n, const T* diag, const T* sub, T* ldiag, T* lsub,
     };
     for (int l = 0; l < pl.levels; ++l) {
         const long P = pl.n[l + 1];
-        hipLaunchKernelGGL((par_chol_up_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, level(l), B,
-                           pl.len[l], P, arr[l + 1].Dv, arr[l + 1].Gf, arr[l + 1].GU, arr[l + 1].F, info);
+        constexpr int x_lds = LdsSpike<T, D>::BYTES;
+        if (x_path<T>())
+            hipLaunchKernelGGL((par_chol_up_x_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), x_lds, st, level(l),
+                               B, pl.len[l], P, arr[l + 1].Dv, arr[l + 1].Gf, arr[l + 1].GU, arr[l + 1].F, info);
+        else
+            hipLaunchKernelGGL((par_chol_up_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, level(l), B,
+                               pl.len[l], P, arr[l + 1].Dv, arr[l + 1].Gf, arr[l + 1].GU, arr[l + 1].F, info);
     }
     {   // coarsest level: one lane per series walks it
         const int l = pl.levels;
@@ -433,13 +438,23 @@ int btd_diag_of_inverse(long B, long n, const T* ldiag, const T* lsub, T* odiag,
         arr[l].N = reinterpret_cast<T*>(p); p += sz;
         arr[l].Z = reinterpret_cast<T*>(p); p += sz;
     }
-    hipLaunchKernelGGL((par_tak_up0_kernel<T, D>), dim3((unsigned)cdiv(B * pl.n[1], 64)), dim3(64), 0, st, B, n, len0,
-                       pl.n[1], ldiag, lsub, arr[1].G, arr[1].N);
+    constexpr int g_lds = D * D * 64 * (int)sizeof(T);      // x path: the composed G of a run lives in LDS
+    if (x_path<T>())
+        hipLaunchKernelGGL((par_tak_up0_x_kernel<T, D>), dim3((unsigned)cdiv(B * pl.n[1], 64)), dim3(64), g_lds, st, B, n,
+                           len0, pl.n[1], ldiag, lsub, arr[1].G, arr[1].N);
+    else
+        hipLaunchKernelGGL((par_tak_up0_kernel<T, D>), dim3((unsigned)cdiv(B * pl.n[1], 64)), dim3(64), 0, st, B, n, len0,
+                           pl.n[1], ldiag, lsub, arr[1].G, arr[1].N);
     for (int l = 1; l < pl.levels; ++l) {
         const long P = pl.n[l + 1];
-        hipLaunchKernelGGL((par_tak_up_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, B, pl.n[l],
-                           pl.len[l], P, static_cast<const T*>(arr[l].G), static_cast<const T*>(arr[l].N), arr[l + 1].G,
-                           arr[l + 1].N);
+        if (x_path<T>())
+            hipLaunchKernelGGL((par_tak_up_x_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), g_lds, st, B, pl.n[l],
+                               pl.len[l], P, static_cast<const T*>(arr[l].G), static_cast<const T*>(arr[l].N),
+                               arr[l + 1].G, arr[l + 1].N);
+        else
+            hipLaunchKernelGGL((par_tak_up_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, B, pl.n[l],
+                               pl.len[l], P, static_cast<const T*>(arr[l].G), static_cast<const T*>(arr[l].N), arr[l + 1].G,
+                               arr[l + 1].N);
     }
     {
         const int l = pl.levels;
@@ -494,8 +509,13 @@ int btd_udl(long B, long n, const T* diag, const T* sub, T* ut, T* chol_d, const
     };
     for (int l = 0; l < pl.levels; ++l) {
         const long P = pl.n[l + 1];
-        hipLaunchKernelGGL((par_chol_up_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, level(l), B,
-                           pl.len[l], P, arr[l + 1].Dv, arr[l + 1].Gf, arr[l + 1].GU, arr[l + 1].F, info);
+        constexpr int x_lds = LdsSpike<T, D>::BYTES;
+        if (x_path<T>())
+            hipLaunchKernelGGL((par_chol_up_x_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), x_lds, st, level(l),
+                               B, pl.len[l], P, arr[l + 1].Dv, arr[l + 1].Gf, arr[l + 1].GU, arr[l + 1].F, info);
+        else
+            hipLaunchKernelGGL((par_chol_up_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, level(l), B,
+                               pl.len[l], P, arr[l + 1].Dv, arr[l + 1].Gf, arr[l + 1].GU, arr[l + 1].F, info);
     }
     {
         const int l = pl.levels;
