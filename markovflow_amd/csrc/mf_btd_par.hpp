@@ -77,7 +77,47 @@ template <typename T, int D> MF_DEV bool par_future(const ParLevel<T>& lv, long 
 // chunk c of series s covers blocks [c len, min(n, (c+1) len)) of `in` and becomes block c of the next level:
 //   oDv = pivot of its last block after the chunk's interior is gone (future part excluded), oGf = that block's
 //   future part, oGU = what the interior adds to the block left of the chunk, oF = coupling last block <-> that block.
-template <typename T, int D>
+// Loads of one block step, issued together, branch-free (a load under a divergent branch is followed by a wait for its
+// merge) and, where the registers allow, one step AHEAD of their use: with one chain per lane nothing else hides the
+// ~2 us of a dependent global load, and the plain form of these loops paid three to four of them per block step - pivot
+// part, the two future parts, the coupling - because each was loaded where it was used.
+// MODE 0: level 0 (the user's blocks, no future parts); 1: level 0 of the block-reversed matrix; 2: a reduced level.
+template <typename T, int D> struct ParStepData {
+    T Dn[D][D];   // lower
+    T g1[D][D];   // lower: Gf part of the future term (MODE 2)
+    T g2[D][D];   // lower: GU part of the future term (MODE 2), valid if has2
+    T W[D][D];    // coupling with the previous block (garbage for block 0)
+    bool has2;
+};
+// one step ahead: fp32 up to d = 7, fp64 up to d = 4 (beyond, two sets of step data do not fit the register file)
+#ifndef MF_PAR_PF
+#define MF_PAR_PF 1
+#endif
+template <typename T, int D> constexpr bool par_prefetch() { return MF_PAR_PF == 2 || (MF_PAR_PF && ((sizeof(T) == 4 && D <= 7) || (sizeof(T) == 8 && D <= 4))); }
+
+template <typename T, int D, int MODE> MF_DEV void par_load_pivot_and_coupling(const ParLevel<T>& in, long s, long k, ParStepData<T, D>& d) {
+    const long kc = k > 0 ? k : 1;                     // block 0 has no coupling: load block 1's, never used
+    if (MODE == 1) {
+        load_lower<T, D>(in.Dv + (s * in.n + (in.n - 1 - k)) * D * D, d.Dn);
+        T St[D][D];
+        load_mat<T, D, D>(in.F + (s * (in.n - 1) + in.n - 1 - kc) * D * D, St);   // sub[n-1-p]: rows k+1, cols k -> transposed
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) d.W[i][j] = St[j][i];
+    } else {
+        load_lower<T, D>(in.Dv + (s * in.n + k) * D * D, d.Dn);
+        load_mat<T, D, D>(in.F + (s * in.f_stride + kc + in.f_off) * D * D, d.W);
+    }
+}
+// step data of block k for the up-sweep (future parts of block k itself)
+template <typename T, int D, int MODE> MF_DEV void par_up_load(const ParLevel<T>& in, long s, long k, ParStepData<T, D>& d) {
+    par_load_pivot_and_coupling<T, D, MODE>(in, s, k, d);
+    if (MODE == 2) {
+        load_lower<T, D>(in.Gf + (s * in.n + k) * D * D, d.g1);
+        d.has2 = k + 1 < in.n;
+        load_lower<T, D>(in.GU + (s * in.n + (d.has2 ? k + 1 : k)) * D * D, d.g2);
+    }
+}
+
+template <typename T, int D, int MODE>
 __global__ void __launch_bounds__(64) par_chol_up_kernel(ParLevel<T> in, long B, long len, long P, T* __restrict__ oDv,
                                                          T* __restrict__ oGf, T* __restrict__ oGU, T* __restrict__ oF,
                                                          int* info) {
@@ -95,35 +135,43 @@ __global__ void __launch_bounds__(64) par_chol_up_kernel(ParLevel<T> in, long B,
     LogAcc<T> la;
     la.init();
     bool bad = false;
+    constexpr bool PF = par_prefetch<T, D>();
+    ParStepData<T, D> cur, nxt;
+    if (PF && k0 < k1) par_up_load<T, D, MODE>(in, s, k0, cur);
     for (long k = k0; k < k1; ++k) {
+        if (PF) par_up_load<T, D, MODE>(in, s, k + 1 < k1 ? k + 1 : k, nxt);
+        else par_up_load<T, D, MODE>(in, s, k, cur);            // all of this step's loads together, before its arithmetic
+        __builtin_amdgcn_sched_barrier(0);
         const bool last = (k + 1 == k1);
-        T Dn[D][D], fut[D][D];
-        par_load_dv<T, D>(in, s, k, Dn);
-        par_future<T, D>(in, s, k, fut);
+        if (MODE == 2) {
+            MF_UNROLL for (int i = 0; i < D; ++i)
+                MF_UNROLL for (int j = 0; j <= i; ++j) cur.g1[i][j] += cur.has2 ? cur.g2[i][j] : T(0);   // future part
+        } else {
+            MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) cur.g1[i][j] = T(0);
+        }
         if (last) {
             // the future part of the chunk's last block travels separately
-            store_sym<T, D>(oGf + id * D * D, fut);
-        } else {
-            MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Dn[i][j] += fut[i][j];
+            store_sym<T, D>(oGf + id * D * D, cur.g1);
+        } else if (MODE == 2) {
+            MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) cur.Dn[i][j] += cur.g1[i][j];
         }
         if (k == k0) {
-            if (k > 0) par_load_f<T, D>(in, s, k, X);
-            MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Phi[i][j] = Dn[i][j];
-            continue;
+            if (k > 0) { MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) X[i][j] = cur.W[i][j]; }
+            MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Phi[i][j] = cur.Dn[i][j];
+        } else {
+            // eliminate block k-1 (pivot complete in Phi): factor, spike towards the block left of the chunk
+            chol_lower<T, D>(Phi, Li, la, bad);
+            la.init();
+            if (k0 > 0) {
+                trsm_left_lower<T, D, D>(Phi, Li, X);            // V = L^-1 X
+                syrk_tn_lower<T, D, D>(X, GU, T(-1));            // GU -= V^T V
+            }
+            trsm_right_lower_t<T, D, D>(Phi, Li, cur.W);         // W = F_k L^-T
+            MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Phi[i][j] = cur.Dn[i][j];
+            syrk_nt_lower<T, D, D>(cur.W, Phi, T(-1));           // next pivot: Dn - W W^T
+            if (k0 > 0) neg_mul_inplace<T, D>(cur.W, X);         // next coupling to the left block: -W V
         }
-        // eliminate block k-1 (pivot complete in Phi): factor, spike towards the block left of the chunk
-        chol_lower<T, D>(Phi, Li, la, bad);
-        la.init();
-        if (k0 > 0) {
-            trsm_left_lower<T, D, D>(Phi, Li, X);            // V = L^-1 X
-            syrk_tn_lower<T, D, D>(X, GU, T(-1));            // GU -= V^T V
-        }
-        T W[D][D];
-        par_load_f<T, D>(in, s, k, W);
-        trsm_right_lower_t<T, D, D>(Phi, Li, W);             // W = F_k L^-T
-        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Phi[i][j] = Dn[i][j];
-        syrk_nt_lower<T, D, D>(W, Phi, T(-1));               // next pivot: Dn - W W^T
-        if (k0 > 0) neg_mul_inplace<T, D>(W, X);             // next coupling to the left block: -W V
+        if (PF) cur = nxt;
     }
     store_sym<T, D>(oDv + id * D * D, Phi);
     store_sym<T, D>(oGU + id * D * D, GU);
@@ -197,6 +245,15 @@ __global__ void __launch_bounds__(64) par_chol_up_x_kernel(ParLevel<T> in, long 
 // ---- Cholesky: down-sweep on a level >= 1 (also the serial walk of the coarsest level: len >= n, up = null) --------
 // writes the natural-order pivots Pn[j] of every block of `lv`; `up` holds the pivots of the next coarser level,
 // whose block c is the last block of chunk c here.
+// step data of block k for the down-sweep (always a reduced level): its own pivot part, the future parts of block k-1
+// (Gf[k-1] + GU[k]), the coupling; for block 0 the loads are clamped to valid addresses and not used
+template <typename T, int D> MF_DEV void par_down_load(const ParLevel<T>& lv, long s, long k, ParStepData<T, D>& d) {
+    par_load_pivot_and_coupling<T, D, 2>(lv, s, k, d);
+    const long kc = k > 0 ? k : 1;
+    load_lower<T, D>(lv.Gf + (s * lv.n + kc - 1) * D * D, d.g1);
+    load_lower<T, D>(lv.GU + (s * lv.n + (kc < lv.n ? kc : 0)) * D * D, d.g2);
+}
+
 template <typename T, int D>
 __global__ void __launch_bounds__(64) par_chol_down_kernel(ParLevel<T> lv, long B, long len, long P,
                                                            const T* __restrict__ up, T* __restrict__ Pn, int* info) {
@@ -210,23 +267,26 @@ __global__ void __launch_bounds__(64) par_chol_down_kernel(ParLevel<T> lv, long 
     LogAcc<T> la;
     la.init();
     bool bad = false;
+    constexpr bool PF = par_prefetch<T, D>();
+    ParStepData<T, D> cur, nxt;
+    if (PF && k0 < k1) par_down_load<T, D>(lv, s, k0, cur);
+    MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Sig[i][j] = T(0);
     if (c > 0) load_lower<T, D>(up + (s * P + c - 1) * D * D, Sig);
     for (long k = k0; k < k1; ++k) {
-        T Dn[D][D];
-        par_load_dv<T, D>(lv, s, k, Dn);
+        if (PF) par_down_load<T, D>(lv, s, k + 1 < k1 ? k + 1 : k, nxt);
+        else par_down_load<T, D>(lv, s, k, cur);
+        __builtin_amdgcn_sched_barrier(0);
         if (k > 0) {
             // pivot of block k-1 at the moment block k is reached: natural pivot + its future part
-            T fut[D][D], W[D][D];
-            par_future<T, D>(lv, s, k - 1, fut);
-            MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Sig[i][j] += fut[i][j];
+            MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Sig[i][j] += cur.g1[i][j] + cur.g2[i][j];
             chol_lower<T, D>(Sig, Li, la, bad);
             la.init();
-            par_load_f<T, D>(lv, s, k, W);
-            trsm_right_lower_t<T, D, D>(Sig, Li, W);
-            syrk_nt_lower<T, D, D>(W, Dn, T(-1));
+            trsm_right_lower_t<T, D, D>(Sig, Li, cur.W);
+            syrk_nt_lower<T, D, D>(cur.W, cur.Dn, T(-1));
         }
-        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Sig[i][j] = Dn[i][j];
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Sig[i][j] = cur.Dn[i][j];
         store_sym<T, D>(Pn + (s * lv.n + k) * D * D, Sig);
+        if (PF) cur = nxt;
     }
     if (bad && info) atomicMax(info, 1);
 }
@@ -247,25 +307,33 @@ __global__ void __launch_bounds__(64) par_chol_emit_kernel(long B, long n, long 
     LogAcc<T> la;
     la.init();
     bool bad = false;
+    struct Step { T S[D][D]; T W[D][D]; };
+    auto load = [&](long k, Step& d) {
+        load_lower<T, D>(diag + (s * n + k) * D * D, d.S);
+        load_mat<T, D, D>(sub + (s * (n - 1) + (k > 0 ? k - 1 : 0)) * D * D, d.W);     // block 0: loaded, not used
+    };
+    constexpr bool PF = par_prefetch<T, D>() || (sizeof(T) == 8 && D <= 6);     // only two matrices per step here
+    Step cur, nxt;
+    if (PF && k0 < k1) load(k0, cur);
     if (c > 0) {
         load_lower<T, D>(up + (s * P + c - 1) * D * D, L);
         chol_lower<T, D>(L, Li, la, bad);
         la.init();
     }
     for (long k = k0; k < k1; ++k) {
-        T S[D][D];
-        load_lower<T, D>(diag + (s * n + k) * D * D, S);
+        if (PF) load(k + 1 < k1 ? k + 1 : k, nxt);
+        else load(k, cur);
+        __builtin_amdgcn_sched_barrier(0);
         if (k > 0) {
-            T W[D][D];
-            load_mat<T, D, D>(sub + (s * (n - 1) + k - 1) * D * D, W);
-            trsm_right_lower_t<T, D, D>(L, Li, W);
-            store_mat<T, D, D>(lsub + (s * (n - 1) + k - 1) * D * D, W);
-            syrk_nt_lower<T, D, D>(W, S, T(-1));
+            trsm_right_lower_t<T, D, D>(L, Li, cur.W);
+            store_mat<T, D, D>(lsub + (s * (n - 1) + k - 1) * D * D, cur.W);
+            syrk_nt_lower<T, D, D>(cur.W, cur.S, T(-1));
         }
-        chol_lower<T, D>(S, Li, la, bad);
+        chol_lower<T, D>(cur.S, Li, la, bad);
         la.init();
-        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) L[i][j] = S[i][j];
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) L[i][j] = cur.S[i][j];
         store_lower<T, D>(ldiag + (s * n + k) * D * D, L);
+        if (PF) cur = nxt;
     }
     if (bad && info) atomicMax(info, 1);
 }

@@ -291,6 +291,17 @@ inline ParPlan par_plan(long n0, long len0) {
     return pl;
 }
 
+// register-resident up-sweep of the parallel-in-time Cholesky; mode 0 / 1: level 0 of the matrix / of the block-reversed
+// matrix, 2: a reduced level
+template <typename T>
+void launch_chol_up(const ParLevel<T>& lv, int mode, long B, long len, long P, T* oDv, T* oGf, T* oGU, T* oF, int* info,
+                    hipStream_t st) {
+    const dim3 grid((unsigned)cdiv(B * P, 64)), block(64);
+    if (mode == 0) hipLaunchKernelGGL((par_chol_up_kernel<T, D, 0>), grid, block, 0, st, lv, B, len, P, oDv, oGf, oGU, oF, info);
+    else if (mode == 1) hipLaunchKernelGGL((par_chol_up_kernel<T, D, 1>), grid, block, 0, st, lv, B, len, P, oDv, oGf, oGU, oF, info);
+    else hipLaunchKernelGGL((par_chol_up_kernel<T, D, 2>), grid, block, 0, st, lv, B, len, P, oDv, oGf, oGU, oF, info);
+}
+
 template <typename T> size_t btd_cholesky_ws(long B, long n) {
     const long len0 = par_len0(B, n);
     if (len0 == 0) return 0;
@@ -328,8 +339,8 @@ int btd_cholesky(long B, long n, const T* diag, const T* sub, T* ldiag, T* lsub,
             hipLaunchKernelGGL((par_chol_up_x_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), x_lds, st, level(l),
                                B, pl.len[l], P, arr[l + 1].Dv, arr[l + 1].Gf, arr[l + 1].GU, arr[l + 1].F, info);
         else
-            hipLaunchKernelGGL((par_chol_up_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, level(l), B,
-                               pl.len[l], P, arr[l + 1].Dv, arr[l + 1].Gf, arr[l + 1].GU, arr[l + 1].F, info);
+            launch_chol_up<T>(level(l), l == 0 ? 0 : 2, B, pl.len[l], P, arr[l + 1].Dv, arr[l + 1].Gf, arr[l + 1].GU,
+                              arr[l + 1].F, info, st);
     }
     {   // coarsest level: one lane per series walks it
         const int l = pl.levels;
@@ -514,8 +525,8 @@ int btd_udl(long B, long n, const T* diag, const T* sub, T* ut, T* chol_d, const
             hipLaunchKernelGGL((par_chol_up_x_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), x_lds, st, level(l),
                                B, pl.len[l], P, arr[l + 1].Dv, arr[l + 1].Gf, arr[l + 1].GU, arr[l + 1].F, info);
         else
-            hipLaunchKernelGGL((par_chol_up_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, level(l), B,
-                               pl.len[l], P, arr[l + 1].Dv, arr[l + 1].Gf, arr[l + 1].GU, arr[l + 1].F, info);
+            launch_chol_up<T>(level(l), l == 0 ? 1 : 2, B, pl.len[l], P, arr[l + 1].Dv, arr[l + 1].Gf, arr[l + 1].GU,
+                              arr[l + 1].F, info, st);
     }
     {
         const int l = pl.levels;
