@@ -340,6 +340,21 @@ __global__ void __launch_bounds__(64) par_chol_emit_kernel(long B, long n, long 
 
 // ---- Solve: affine recursion z_p = M_p z_{p-1} + c_p over positions p (p = k, or n-1-k for the transposed solve) -----
 // level 0 -> level 1: composite map of every chunk from the factor and the right-hand side
+// loads of one position of the level-0 solve kernels, together and branch-free (see ParStepData)
+template <typename T, int D> struct ParSolveStep { T L[D][D]; T x[D]; T W[D][D]; };
+template <typename T, int D>
+MF_DEV void par_solve_load(const T* __restrict__ ldiag, const T* __restrict__ lsub, const T* __restrict__ rhs, long s, long r,
+                           long n, long p, int transpose, ParSolveStep<T, D>& d) {
+    const long k = transpose ? n - 1 - p : p;
+    load_lower<T, D>(ldiag + (s * n + k) * D * D, d.L);
+    load_vec<T, D>(rhs + (r * n + k) * D, d.x);
+    long kw = transpose ? k : k - 1;                   // coupling of position p with p-1; position 0: clamped, not used
+    if (kw < 0) kw = 0;
+    if (kw > n - 2) kw = n - 2;
+    load_mat<T, D, D>(lsub + (s * (n - 1) + kw) * D * D, d.W);
+}
+template <typename T, int D> constexpr bool par_solve_prefetch() { return par_prefetch<T, D>() || (sizeof(T) == 8 && D <= 6); }
+
 template <typename T, int D>
 __global__ void __launch_bounds__(64) par_solve_up0_kernel(long Bl, long Br, long n, long len, long P,
                                                            const T* __restrict__ ldiag, const T* __restrict__ lsub,
@@ -353,23 +368,20 @@ __global__ void __launch_bounds__(64) par_solve_up0_kernel(long Bl, long Br, lon
     if (p1 > n) p1 = n;
     T Pm[D][D], q[D];
     MF_UNROLL for (int i = 0; i < D; ++i) { q[i] = T(0); MF_UNROLL for (int j = 0; j < D; ++j) Pm[i][j] = T(0); }
+    constexpr bool PF = par_solve_prefetch<T, D>();
+    ParSolveStep<T, D> cur, nxt;
+    if (PF && p0 < p1) par_solve_load<T, D>(ldiag, lsub, rhs, s, r, n, p0, transpose, cur);
     for (long p = p0; p < p1; ++p) {
-        const long k = transpose ? n - 1 - p : p;
-        T L[D][D], Li[D], x[D];
-        load_lower<T, D>(ldiag + (s * n + k) * D * D, L);
-        MF_UNROLL for (int i = 0; i < D; ++i) Li[i] = t_rcp<T>(L[i][i]);
-        load_vec<T, D>(rhs + (r * n + k) * D, x);
-        if (lsub && p > 0) {
+        if (PF) par_solve_load<T, D>(ldiag, lsub, rhs, s, r, n, p + 1 < p1 ? p + 1 : p, transpose, nxt);
+        else par_solve_load<T, D>(ldiag, lsub, rhs, s, r, n, p, transpose, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        T Li[D];
+        MF_UNROLL for (int i = 0; i < D; ++i) Li[i] = t_rcp<T>(cur.L[i][i]);
+        if (p > 0) {
             T W[D][D], wq[D], WP[D][D];
-            if (!transpose) {
-                load_mat<T, D, D>(lsub + (s * (n - 1) + k - 1) * D * D, W);
-            } else {
-                T Wt[D][D];
-                load_mat<T, D, D>(lsub + (s * (n - 1) + k) * D * D, Wt);
-                MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) W[i][j] = Wt[j][i];
-            }
+            MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) W[i][j] = transpose ? cur.W[j][i] : cur.W[i][j];
             gemv_n<T, D, D>(W, q, wq);
-            MF_UNROLL for (int i = 0; i < D; ++i) x[i] -= wq[i];
+            MF_UNROLL for (int i = 0; i < D; ++i) cur.x[i] -= wq[i];
             if (p == p0) {
                 MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) WP[i][j] = -W[i][j];
             } else {
@@ -380,11 +392,12 @@ __global__ void __launch_bounds__(64) par_solve_up0_kernel(long Bl, long Br, lon
                         WP[i][j] = -a;
                     }
             }
-            if (!transpose) trsm_left_lower<T, D, D>(L, Li, WP); else trsm_left_lower_t<T, D, D>(L, Li, WP);
+            if (!transpose) trsm_left_lower<T, D, D>(cur.L, Li, WP); else trsm_left_lower_t<T, D, D>(cur.L, Li, WP);
             MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Pm[i][j] = WP[i][j];
         }
-        if (!transpose) trsv_lower<T, D>(L, Li, x); else trsv_lower_t<T, D>(L, Li, x);
-        MF_UNROLL for (int i = 0; i < D; ++i) q[i] = x[i];
+        if (!transpose) trsv_lower<T, D>(cur.L, Li, cur.x); else trsv_lower_t<T, D>(cur.L, Li, cur.x);
+        MF_UNROLL for (int i = 0; i < D; ++i) q[i] = cur.x[i];
+        if (PF) cur = nxt;
     }
     store_mat<T, D, D>(oM + id * D * D, Pm);
     store_vec<T, D>(oc + id * D, q);
@@ -464,29 +477,28 @@ __global__ void __launch_bounds__(64) par_solve_emit_kernel(long Bl, long Br, lo
     const long p0 = c * len;
     long p1 = p0 + len;
     if (p1 > n) p1 = n;
+    constexpr bool PF = par_solve_prefetch<T, D>();
+    ParSolveStep<T, D> cur, nxt;
+    if (PF && p0 < p1) par_solve_load<T, D>(ldiag, lsub, rhs, s, r, n, p0, transpose, cur);
     T z[D];
     MF_UNROLL for (int i = 0; i < D; ++i) z[i] = T(0);
     if (c > 0) load_vec<T, D>(up + (r * P + c - 1) * D, z);
     for (long p = p0; p < p1; ++p) {
         const long k = transpose ? n - 1 - p : p;
-        T L[D][D], Li[D], x[D];
-        load_lower<T, D>(ldiag + (s * n + k) * D * D, L);
-        MF_UNROLL for (int i = 0; i < D; ++i) Li[i] = t_rcp<T>(L[i][i]);
-        load_vec<T, D>(rhs + (r * n + k) * D, x);
-        if (lsub && p > 0) {
-            T W[D][D], wz[D];
-            if (!transpose) {
-                load_mat<T, D, D>(lsub + (s * (n - 1) + k - 1) * D * D, W);
-                gemv_n<T, D, D>(W, z, wz);
-            } else {
-                load_mat<T, D, D>(lsub + (s * (n - 1) + k) * D * D, W);
-                gemv_t<T, D, D>(W, z, wz);
-            }
-            MF_UNROLL for (int i = 0; i < D; ++i) x[i] -= wz[i];
+        if (PF) par_solve_load<T, D>(ldiag, lsub, rhs, s, r, n, p + 1 < p1 ? p + 1 : p, transpose, nxt);
+        else par_solve_load<T, D>(ldiag, lsub, rhs, s, r, n, p, transpose, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        T Li[D];
+        MF_UNROLL for (int i = 0; i < D; ++i) Li[i] = t_rcp<T>(cur.L[i][i]);
+        if (p > 0) {
+            T wz[D];
+            if (!transpose) gemv_n<T, D, D>(cur.W, z, wz); else gemv_t<T, D, D>(cur.W, z, wz);
+            MF_UNROLL for (int i = 0; i < D; ++i) cur.x[i] -= wz[i];
         }
-        if (!transpose) trsv_lower<T, D>(L, Li, x); else trsv_lower_t<T, D>(L, Li, x);
-        MF_UNROLL for (int i = 0; i < D; ++i) z[i] = x[i];
+        if (!transpose) trsv_lower<T, D>(cur.L, Li, cur.x); else trsv_lower_t<T, D>(cur.L, Li, cur.x);
+        MF_UNROLL for (int i = 0; i < D; ++i) z[i] = cur.x[i];
         store_vec<T, D>(out + (r * n + k) * D, z);
+        if (PF) cur = nxt;
     }
 }
 
