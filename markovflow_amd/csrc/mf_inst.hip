@@ -258,9 +258,11 @@ constexpr long PAR_MAX_SERIES = 4096;    // with this many series one lane per s
 
 // level-0 chunk length (0 = use the serial one-lane-per-series kernel)
 // chunk length of the reduced levels of the parallel-in-time operators (and the size at which the coarsest level is walked
-// serially).  Sequential depth is ~ 2 r log_r(n): measured on config 3 (scripts/bench_btd.py) - see DESIGN.md 4.3.
+// serially).  Sequential depth is ~ 2 r log_r(n) block steps against one launch per level: 5 measured best on config 3 and
+// on B=64, T=10000 (scripts/sweep_radix.sh; 8: 192 / 535 us, 5: 166 / 494 us) - see DESIGN.md 4.3.
+constexpr long PAR_RADIX = 5;
 inline long par_radix() {
-    static const long r = [] { const char* e = std::getenv("MF_BTD_RADIX"); const long v = e ? std::atol(e) : 0; return v >= 2 ? v : RED_CHUNK; }();
+    static const long r = [] { const char* e = std::getenv("MF_BTD_RADIX"); const long v = e ? std::atol(e) : 0; return v >= 2 ? v : PAR_RADIX; }();
     return r;
 }
 inline long par_len0(long B, long n) {
@@ -268,7 +270,7 @@ inline long par_len0(long B, long n) {
     if (force >= 0) return (force > 0 && n >= 2 * force) ? force : 0;
     if (B >= PAR_MAX_SERIES || n < PAR_MIN_BLOCKS) return 0;
     long len = cdiv(B * n, 65536);           // aim at one wavefront per SIMD ...
-    if (len < par_radix()) len = par_radix(); // ... but keep the reduced system at most 1/r of the input
+    if (len < RED_CHUNK) len = RED_CHUNK;     // ... but keep the reduced system at most 1/8 of the input
     return n >= 2 * len ? len : 0;
 }
 

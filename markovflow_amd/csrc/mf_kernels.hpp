@@ -245,6 +245,38 @@ MF_DEV void load_red_block(const RedSys<T>& in, long s, long j, T (&Dn)[D][D], T
     }
 }
 
+// All loads of one block of a reduction level, issued together and branch-free (a load under a divergent branch is
+// followed by a wait at the merge; the plain form paid three dependent round trips per block: pivot part, the contribution of
+// the next block's interior, the coupling).  Block 0 has no coupling and the last block no GU term: clamped, flagged.
+template <typename T, int D> struct RedStep {
+    T Dn[D][D];   // lower
+    T rn[D];
+    T g[D][D];    // lower: GU of block j+1
+    T gv[D];
+    T W[D][D];
+    T sc;
+    bool hasg;
+};
+template <typename T, int D> MF_DEV void load_red_step(const RedSys<T>& in, long s, long j, RedStep<T, D>& d) {
+    const long idx = s * in.n + j;
+    load_lower<T, D>(in.Dv + idx * D * D, d.Dn);
+    load_vec<T, D>(in.tv + idx * D, d.rn);
+    d.sc = in.sc ? in.sc[idx] : T(0);
+    d.hasg = in.GU && (j + 1 < in.n);
+    if (in.GU) {
+        const long i2 = (j + 1 < in.n) ? idx + 1 : idx;
+        load_lower<T, D>(in.GU + i2 * D * D, d.g);
+        load_vec<T, D>(in.gU + i2 * D, d.gv);
+    }
+    if (in.n > 1) load_mat<T, D, D>(in.F + (s * in.f_stride + (j > 0 ? j : 1) + in.f_off) * D * D, d.W);
+}
+template <typename T, int D> MF_DEV void red_step_fold(RedStep<T, D>& d) {
+    MF_UNROLL for (int i = 0; i < D; ++i) {
+        d.rn[i] += d.hasg ? d.gv[i] : T(0);
+        MF_UNROLL for (int jj = 0; jj <= i; ++jj) d.Dn[i][jj] += d.hasg ? d.g[i][jj] : T(0);
+    }
+}
+
 template <typename T, int D, bool SPIKE>
 __global__ void __launch_bounds__(64) red_chunk_kernel(RedSys<T> in, RedSys<T> out, long B, long P, int* info) {
     const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -255,28 +287,28 @@ __global__ void __launch_bounds__(64) red_chunk_kernel(RedSys<T> in, RedSys<T> o
     E.init();
     T acc_sc = T(0);
     for (long k = k0; k < k1; ++k) {
-        T Dn[D][D], rn[D], sc;
-        load_red_block<T, D>(in, s, k, Dn, rn, sc);
-        acc_sc += sc;
+        RedStep<T, D> d;
+        load_red_step<T, D>(in, s, k, d);
+        __builtin_amdgcn_sched_barrier(0);
+        red_step_fold<T, D>(d);
+        acc_sc += d.sc;
         if (k == 0) {
             MF_UNROLL for (int i = 0; i < D; ++i) {
-                E.t[i] = rn[i];
-                MF_UNROLL for (int j = 0; j <= i; ++j) E.Phi[i][j] = Dn[i][j];
+                E.t[i] = d.rn[i];
+                MF_UNROLL for (int j = 0; j <= i; ++j) E.Phi[i][j] = d.Dn[i][j];
             }
             continue;
         }
-        T W[D][D];
-        load_mat<T, D, D>(in.F + (s * in.f_stride + k + in.f_off) * D * D, W);
         if (k == k0) {
             MF_UNROLL for (int i = 0; i < D; ++i) {
-                E.t[i] = rn[i];
-                MF_UNROLL for (int j = 0; j < D; ++j) E.X[i][j] = W[i][j];
-                MF_UNROLL for (int j = 0; j <= i; ++j) E.Phi[i][j] = Dn[i][j];
+                E.t[i] = d.rn[i];
+                MF_UNROLL for (int j = 0; j < D; ++j) E.X[i][j] = d.W[i][j];
+                MF_UNROLL for (int j = 0; j <= i; ++j) E.Phi[i][j] = d.Dn[i][j];
             }
         } else {
             E.eliminate();
-            trsm_right_lower_t<T, D, D>(E.Phi, E.Li, W);    // W = S L^-T
-            E.advance(W, Dn, rn);
+            trsm_right_lower_t<T, D, D>(E.Phi, E.Li, d.W);    // W = S L^-T
+            E.advance(d.W, d.Dn, d.rn);
         }
     }
     const T scalar = acc_sc + T(0.5) * E.quad - E.laL.value();
@@ -284,7 +316,8 @@ __global__ void __launch_bounds__(64) red_chunk_kernel(RedSys<T> in, RedSys<T> o
     if (E.bad && info) atomicMax(info, 1);
 }
 
-// Final level: one lane per series walks the remaining n blocks; out[s] = add_const + sum of scalars.
+// Final level: one lane per series walks the remaining n blocks; out[s] = add_const + sum of scalars.  The next block is
+// loaded while the current one is eliminated where two sets of block data fit the registers (fp32; fp64 up to d = 6).
 template <typename T, int D>
 __global__ void __launch_bounds__(64) red_final_kernel(RedSys<T> in, long B, T add_const, T* __restrict__ out, int* info) {
     const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -292,22 +325,49 @@ __global__ void __launch_bounds__(64) red_final_kernel(RedSys<T> in, long B, T a
     Elim<T, D, false> E;
     E.init();
     T acc_sc = T(0);
+    constexpr bool PF = sizeof(T) == 4 || D <= 6;
+    if constexpr (!PF) {
+        // large blocks in fp64: the grouped form spills; pivot part first, coupling where it is used
+        for (long k = 0; k < in.n; ++k) {
+            T Dn[D][D], rn[D], sc;
+            load_red_block<T, D>(in, s, k, Dn, rn, sc);
+            acc_sc += sc;
+            if (k == 0) {
+                MF_UNROLL for (int i = 0; i < D; ++i) {
+                    E.t[i] = rn[i];
+                    MF_UNROLL for (int j = 0; j <= i; ++j) E.Phi[i][j] = Dn[i][j];
+                }
+            } else {
+                T W[D][D];
+                load_mat<T, D, D>(in.F + (s * in.f_stride + k + in.f_off) * D * D, W);
+                E.eliminate();
+                trsm_right_lower_t<T, D, D>(E.Phi, E.Li, W);
+                E.advance(W, Dn, rn);
+            }
+        }
+        E.eliminate();
+        out[s] = add_const + acc_sc + T(0.5) * E.quad - E.laL.value();
+        if (E.bad && info) atomicMax(info, 1);
+        return;
+    }
+    RedStep<T, D> cur, nxt;
+    if (in.n > 0) load_red_step<T, D>(in, s, 0, cur);
     for (long k = 0; k < in.n; ++k) {
-        T Dn[D][D], rn[D], sc;
-        load_red_block<T, D>(in, s, k, Dn, rn, sc);
-        acc_sc += sc;
+        load_red_step<T, D>(in, s, k + 1 < in.n ? k + 1 : k, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        red_step_fold<T, D>(cur);
+        acc_sc += cur.sc;
         if (k == 0) {
             MF_UNROLL for (int i = 0; i < D; ++i) {
-                E.t[i] = rn[i];
-                MF_UNROLL for (int j = 0; j <= i; ++j) E.Phi[i][j] = Dn[i][j];
+                E.t[i] = cur.rn[i];
+                MF_UNROLL for (int j = 0; j <= i; ++j) E.Phi[i][j] = cur.Dn[i][j];
             }
         } else {
-            T W[D][D];
-            load_mat<T, D, D>(in.F + (s * in.f_stride + k + in.f_off) * D * D, W);
             E.eliminate();
-            trsm_right_lower_t<T, D, D>(E.Phi, E.Li, W);
-            E.advance(W, Dn, rn);
+            trsm_right_lower_t<T, D, D>(E.Phi, E.Li, cur.W);
+            E.advance(cur.W, cur.Dn, cur.rn);
         }
+        cur = nxt;
     }
     E.eliminate();
     out[s] = add_const + acc_sc + T(0.5) * E.quad - E.laL.value();
