@@ -17,7 +17,7 @@ from .kalman_filter import (
     UnivariateGaussianSitesNat,
 )
 from .state_space_model import StateSpaceModel, state_space_model_from_covariances
-from . import kernels, models, ssm_gaussian_transformations
+from . import graphs, kernels, models, ssm_gaussian_transformations
 from .kernels import IndependentMultiOutput, Matern12, Matern32, Matern52, SDEKernel, StationaryKernel, Sum
 from .models import GaussianProcessRegression
 from .posterior import AnalyticPosteriorProcess, ConditionalProcess
@@ -26,6 +26,6 @@ __all__ = [
     "BlockTriDiagonal", "LowerTriangularBlockTriDiagonal", "SymmetricBlockTriDiagonal", "EmissionModel",
     "GaussMarkovDistribution", "check_compatible", "BaseKalmanFilter", "GaussianSites", "KalmanFilter",
     "KalmanFilterWithSites", "KalmanFilterWithSparseSites", "UnivariateGaussianSitesNat", "StateSpaceModel",
-    "state_space_model_from_covariances", "kernels", "models", "ssm_gaussian_transformations", "SDEKernel", "StationaryKernel", "Matern12", "Matern32",
+    "state_space_model_from_covariances", "graphs", "kernels", "models", "ssm_gaussian_transformations", "SDEKernel", "StationaryKernel", "Matern12", "Matern32",
     "Matern52", "Sum", "IndependentMultiOutput", "GaussianProcessRegression", "AnalyticPosteriorProcess", "ConditionalProcess",
 ]
