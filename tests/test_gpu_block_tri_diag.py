@@ -171,6 +171,16 @@ def test_non_positive_definite_sets_info(rng):
     assert int(info.item()) == 1
 
 
+def test_check_pivots_switch_raises_like_the_reference(rng, monkeypatch):
+    """Default: no host sync, a non-positive pivot shows up as NaN.  MF_CHECK_PIVOTS=1: raise, as TensorFlow's Cholesky op does."""
+    from markovflow_amd import _lib
+    sym = mfa.SymmetricBlockTriDiagonal(tt(-np.tile(np.eye(3), (2, 4, 1, 1))))
+    assert not torch.isfinite(sym.cholesky.block_diagonal).all()
+    monkeypatch.setattr(_lib, "CHECK_PIVOTS", True)
+    with pytest.raises(_lib.MarkovflowAmdError):
+        sym.cholesky
+
+
 def test_unsupported_state_dim_fails_loudly(rng):
     diag = np.tile(np.eye(40), (1, 3, 1, 1))        # fp64: register kernels to d = 9, LDS-tile kernels to d = 32
     with pytest.raises(NotImplementedError):
