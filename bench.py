@@ -155,6 +155,21 @@ def other_configs(dev):
                 "block steps each), not bytes; the eager figures include the Python-side allocation of outputs and workspace, "
                 "the hipgraph figures replay the captured call (markovflow_amd.graphs)",
         "max_abs_err_vs_exact_factor": float((chol.block_diagonal.double() - ld).abs().max())}
+    # the same operator where it IS bandwidth-bound: many series, one lane per series (B >= 4096), d=6 fp64
+    bb, tb = 16384, 500
+    inp = synthetic.make_ssm(bb, tb, (5, 5), dtype=torch.float64, device=dev)
+    prec = synthetic.kalman_filter_from(inp)._k_inv_post
+    t_b = _time_gpu(lambda: prec.cholesky, iters=5)
+    chol_b = prec.cholesky
+    rhs_b = torch.randn(bb, tb, 6, dtype=torch.float64, device=dev, generator=g)
+    t_bs = _time_gpu(lambda: chol_b.solve(rhs_b), iters=5)
+    out["btd_cholesky_solve_B16384_T500_d6_f64"] = {
+        "cholesky_ms": t_b, "cholesky_algorithmic_GBps": bb * tb * 4 * 36 * 8 / t_b / 1e6,
+        "cholesky_frac_of_hbm_peak": bb * tb * 4 * 36 * 8 / t_b / 1e6 / HBM_PEAK_GBS,
+        "solve_ms": t_bs, "solve_algorithmic_GBps": bb * tb * (2 * 36 + 12) * 8 / t_bs / 1e6,
+        "solve_frac_of_hbm_peak": bb * tb * (2 * 36 + 12) * 8 / t_bs / 1e6 / HBM_PEAK_GBS,
+        "note": "SURVEY 8d bytes per block: cholesky 4 d^2 s, solve (2 d^2 + 2 d) s; one lane per series, natural order"}
+    del inp, prec, chol_b, rhs_b
     # config 4 shape: d=9 (3 x Matern-5/2, 3 outputs), 512 series per GPU (4096 over 8 GPUs), fp64
     inp = synthetic.make_ssm(512, 1000, (5, 5, 5), output_dim=3, dtype=torch.float64, device=dev)
     kf = synthetic.kalman_filter_from(inp)

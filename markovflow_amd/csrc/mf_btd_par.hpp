@@ -312,16 +312,24 @@ __global__ void __launch_bounds__(64) par_chol_emit_kernel(long B, long n, long 
         load_lower<T, D>(diag + (s * n + k) * D * D, d.S);
         load_mat<T, D, D>(sub + (s * (n - 1) + (k > 0 ? k - 1 : 0)) * D * D, d.W);     // block 0: loaded, not used
     };
-    constexpr bool PF = par_prefetch<T, D>() || (sizeof(T) == 8 && D <= 6);     // only two matrices per step here
-    Step cur, nxt;
+    // only two matrices per step here: loads run one step ahead.  Two steps ahead (MF_CHOL_PF2) measured SLOWER for the
+    // factorisation (2.05 -> 2.43 ms at B = 16384, T = 500, d = 6 fp64) and neutral for the solve: both off.
+#ifndef MF_CHOL_PF2
+#define MF_CHOL_PF2 0
+#endif
+    constexpr bool PF2 = MF_CHOL_PF2 && ((sizeof(T) == 8 && D <= 6) || (sizeof(T) == 4 && D <= 8));
+    constexpr bool PF = par_prefetch<T, D>() || (sizeof(T) == 8 && D <= 6) || PF2;
+    Step cur, nxt, nx2;
     if (PF && k0 < k1) load(k0, cur);
+    if (PF2 && k0 < k1) load(k0 + 1 < k1 ? k0 + 1 : k0, nxt);
     if (c > 0) {
         load_lower<T, D>(up + (s * P + c - 1) * D * D, L);
         chol_lower<T, D>(L, Li, la, bad);
         la.init();
     }
     for (long k = k0; k < k1; ++k) {
-        if (PF) load(k + 1 < k1 ? k + 1 : k, nxt);
+        if (PF2) load(k + 2 < k1 ? k + 2 : k1 - 1, nx2);
+        else if (PF) load(k + 1 < k1 ? k + 1 : k, nxt);
         else load(k, cur);
         __builtin_amdgcn_sched_barrier(0);
         if (k > 0) {
@@ -334,6 +342,7 @@ __global__ void __launch_bounds__(64) par_chol_emit_kernel(long B, long n, long 
         MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) L[i][j] = cur.S[i][j];
         store_lower<T, D>(ldiag + (s * n + k) * D * D, L);
         if (PF) cur = nxt;
+        if (PF2) nxt = nx2;
     }
     if (bad && info) atomicMax(info, 1);
 }
@@ -477,15 +486,22 @@ __global__ void __launch_bounds__(64) par_solve_emit_kernel(long Bl, long Br, lo
     const long p0 = c * len;
     long p1 = p0 + len;
     if (p1 > n) p1 = n;
-    constexpr bool PF = par_solve_prefetch<T, D>();
-    ParSolveStep<T, D> cur, nxt;
+#ifndef MF_SOLVE_PF2
+#define MF_SOLVE_PF2 0
+#endif
+    // two positions ahead: measured neutral (1.32 vs 1.37 ms at B = 16384, T = 500, d = 6 fp64, within box-to-box noise): off
+    constexpr bool PF2 = MF_SOLVE_PF2 && ((sizeof(T) == 8 && D <= 6) || (sizeof(T) == 4 && D <= 8));
+    constexpr bool PF = par_solve_prefetch<T, D>() || PF2;
+    ParSolveStep<T, D> cur, nxt, nx2;
     if (PF && p0 < p1) par_solve_load<T, D>(ldiag, lsub, rhs, s, r, n, p0, transpose, cur);
+    if (PF2 && p0 < p1) par_solve_load<T, D>(ldiag, lsub, rhs, s, r, n, p0 + 1 < p1 ? p0 + 1 : p0, transpose, nxt);
     T z[D];
     MF_UNROLL for (int i = 0; i < D; ++i) z[i] = T(0);
     if (c > 0) load_vec<T, D>(up + (r * P + c - 1) * D, z);
     for (long p = p0; p < p1; ++p) {
         const long k = transpose ? n - 1 - p : p;
-        if (PF) par_solve_load<T, D>(ldiag, lsub, rhs, s, r, n, p + 1 < p1 ? p + 1 : p, transpose, nxt);
+        if (PF2) par_solve_load<T, D>(ldiag, lsub, rhs, s, r, n, p + 2 < p1 ? p + 2 : p1 - 1, transpose, nx2);
+        else if (PF) par_solve_load<T, D>(ldiag, lsub, rhs, s, r, n, p + 1 < p1 ? p + 1 : p, transpose, nxt);
         else par_solve_load<T, D>(ldiag, lsub, rhs, s, r, n, p, transpose, cur);
         __builtin_amdgcn_sched_barrier(0);
         T Li[D];
@@ -499,6 +515,7 @@ __global__ void __launch_bounds__(64) par_solve_emit_kernel(long Bl, long Br, lo
         MF_UNROLL for (int i = 0; i < D; ++i) z[i] = cur.x[i];
         store_vec<T, D>(out + (r * n + k) * D, z);
         if (PF) cur = nxt;
+        if (PF2) nxt = nx2;
     }
 }
 

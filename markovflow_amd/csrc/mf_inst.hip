@@ -318,8 +318,14 @@ int btd_cholesky(long B, long n, const T* diag, const T* sub, T* ldiag, T* lsub,
                  hipStream_t st) {
     const long len0 = sub ? par_len0(B, n) : 0;
     if (len0 == 0 || ws == nullptr || ws_bytes < btd_cholesky_ws<T>(B, n)) {
-        hipLaunchKernelGGL((btd_cholesky_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, diag, sub,
-                           ldiag, lsub, info);
+        // one lane per series; with a sub-diagonal the level-0 emit kernel as ONE chunk: same recursion, but the next block's
+        // loads are in flight during the current block's arithmetic
+        if (sub && n >= 2)
+            hipLaunchKernelGGL((par_chol_emit_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, n, 1L, diag,
+                               sub, static_cast<const T*>(nullptr), ldiag, lsub, info);
+        else
+            hipLaunchKernelGGL((btd_cholesky_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, diag, sub,
+                               ldiag, lsub, info);
         return hipGetLastError() == hipSuccess ? 0 : -1000;
     }
     const ParPlan pl = par_plan(n, len0);
@@ -375,8 +381,12 @@ int btd_solve(long Bl, long Br, long n, const T* ldiag, const T* lsub, const T* 
               size_t ws_bytes, hipStream_t st) {
     const long len0 = lsub ? par_len0(Br, n) : 0;
     if (len0 == 0 || ws == nullptr || ws_bytes < btd_solve_ws<T>(Bl, Br, n)) {
-        hipLaunchKernelGGL((btd_solve_kernel<T, D>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Bl, Br, n, ldiag,
-                           lsub, rhs, out, transpose);
+        if (lsub && n >= 2)     // one lane per right-hand side: the level-0 emit kernel as ONE chunk (prefetched loads)
+            hipLaunchKernelGGL((par_solve_emit_kernel<T, D>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Bl, Br, n, n, 1L,
+                               ldiag, lsub, rhs, static_cast<const T*>(nullptr), transpose, out);
+        else
+            hipLaunchKernelGGL((btd_solve_kernel<T, D>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Bl, Br, n, ldiag,
+                               lsub, rhs, out, transpose);
         return hipGetLastError() == hipSuccess ? 0 : -1000;
     }
     const ParPlan pl = par_plan(n, len0);
