@@ -655,6 +655,25 @@ MF_DEV void takahashi_terms(const T* __restrict__ ldiag, const T* __restrict__ l
     }
 }
 
+// the same from blocks that are already in registers
+template <typename T, int D>
+MF_DEV void takahashi_from(const T (&L)[D][D], const T (&W)[D][D], bool has_g, T (&N)[D][D], T (&G)[D][D]) {
+    T Linv[D][D];
+    LogAcc<T> la;
+    la.init();
+    bool bad = false;
+    tri_inv_lower<T, D>(L, Linv, la, bad);
+    trimulT_self_lower<T, D>(Linv, N);
+    if (has_g) {
+        MF_UNROLL for (int i = 0; i < D; ++i)
+            MF_UNROLL for (int j = 0; j < D; ++j) {
+                T a = T(0);
+                MF_UNROLL for (int l = j; l < D; ++l) a += W[i][l] * Linv[l][j];
+                G[i][j] = a;
+            }
+    }
+}
+
 template <typename T, int D>
 __global__ void __launch_bounds__(64) par_tak_up0_kernel(long B, long n, long len, long P, const T* __restrict__ ldiag,
                                                          const T* __restrict__ lsub, T* __restrict__ oG, T* __restrict__ oN) {
@@ -827,13 +846,26 @@ __global__ void __launch_bounds__(64) par_tak_emit_kernel(long B, long n, long l
     const long p0 = c * len;
     long p1 = p0 + len;
     if (p1 > n) p1 = n;
+    struct Step { T L[D][D]; T W[D][D]; };
+    auto load = [&](long p, Step& d) {                 // factor blocks of position p (block k = n-1-p); the coupling of
+        const long k = n - 1 - p;                        // position 0 does not exist: clamped, not used
+        load_lower<T, D>(ldiag + (s * n + k) * D * D, d.L);
+        load_mat<T, D, D>(lsub + (s * (n - 1) + (k < n - 1 ? k : n - 2)) * D * D, d.W);
+    };
+    constexpr bool PF = par_prefetch<T, D>() || (sizeof(T) == 8 && D <= 6);
+    Step cur, nxt;
+    if (PF && p0 < p1) load(p0, cur);
     T Sig[D][D];                                     // lower triangle
     MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Sig[i][j] = T(0);
     if (c > 0) load_lower<T, D>(up + (s * P + c - 1) * D * D, Sig);
     for (long p = p0; p < p1; ++p) {
         const long k = n - 1 - p;
+        if (PF) load(p + 1 < p1 ? p + 1 : p, nxt);
+        else load(p, cur);
+        __builtin_amdgcn_sched_barrier(0);
         T N[D][D], G[D][D];
-        takahashi_terms<T, D>(ldiag, lsub, s, n, k, p > 0, N, G);
+        takahashi_from<T, D>(cur.L, cur.W, p > 0, N, G);
+        if (PF) cur = nxt;
         if (p > 0) {
             if (osub) {
                 T* o = osub + (s * (n - 1) + k) * D * D;

@@ -448,8 +448,12 @@ int btd_diag_of_inverse(long B, long n, const T* ldiag, const T* lsub, T* odiag,
                         hipStream_t st) {
     const long len0 = lsub ? par_len0(B, n) : 0;
     if (len0 == 0 || ws == nullptr || ws_bytes < btd_diag_of_inverse_ws<T>(B, n)) {
-        hipLaunchKernelGGL((btd_diag_of_inverse_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, ldiag,
-                           lsub, odiag, osub);
+        if (lsub && n >= 2)     // one lane per series: the level-0 emit kernel as ONE chunk (prefetched loads)
+            hipLaunchKernelGGL((par_tak_emit_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, n, 1L, ldiag,
+                               lsub, static_cast<const T*>(nullptr), odiag, osub);
+        else
+            hipLaunchKernelGGL((btd_diag_of_inverse_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, ldiag,
+                               lsub, odiag, osub);
         return hipGetLastError() == hipSuccess ? 0 : -1000;
     }
     const ParPlan pl = par_plan(n, len0);

@@ -563,14 +563,25 @@ __global__ void __launch_bounds__(64) btd_udl_kernel(long B, long n, const T* __
     if (s >= B) return;
     T Lp[D][D], Lpi[D], xp[D];   // chol(Delta_{k+1}), its inverse diagonal, x_{k+1}
     bool bad = false;
+    // the loads of a block are issued together, one block ahead of their use where two sets fit the registers
+    struct Step { T Dl[D][D]; T S[D][D]; T x[D]; };
+    auto load = [&](long k, Step& d) {
+        load_lower<T, D>(diag + (s * n + k) * D * D, d.Dl);
+        if (eta) load_vec<T, D>(eta + (s * n + k) * D, d.x);
+        if (n > 1) load_mat<T, D, D>(sub + (s * (n - 1) + (k < n - 1 ? k : n - 2)) * D * D, d.S);   // last block: clamped, unused
+    };
+    constexpr bool PF = sizeof(T) == 4 ? (D <= 8) : (D <= 6);
+    Step cur, nxt;
+    if (PF) load(n - 1, cur);
     for (long k = n - 1; k >= 0; --k) {
+        if (PF) load(k > 0 ? k - 1 : 0, nxt);
+        else load(k, cur);
+        __builtin_amdgcn_sched_barrier(0);
         T Dl[D][D], x[D];
-        load_lower<T, D>(diag + (s * n + k) * D * D, Dl);
-        if (eta) load_vec<T, D>(eta + (s * n + k) * D, x);
+        MF_UNROLL for (int i = 0; i < D; ++i) { x[i] = eta ? cur.x[i] : T(0); MF_UNROLL for (int j = 0; j <= i; ++j) Dl[i][j] = cur.Dl[i][j]; }
         if (k + 1 < n) {
-            T S[D][D], U[D][D];
-            load_mat<T, D, D>(sub + (s * (n - 1) + k) * D * D, S);
-            MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) U[i][j] = S[i][j];
+            T U[D][D];
+            MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) U[i][j] = cur.S[i][j];
             trsm_left_lower<T, D, D>(Lp, Lpi, U);          // L^-1 S
             syrk_tn_lower<T, D, D>(U, Dl, T(-1));          // Delta_k = D_k - S^T Delta_{k+1}^-1 S
             trsm_left_lower_t<T, D, D>(Lp, Lpi, U);        // U_k^T = Delta_{k+1}^-1 S
@@ -581,6 +592,7 @@ __global__ void __launch_bounds__(64) btd_udl_kernel(long B, long n, const T* __
                 MF_UNROLL for (int i = 0; i < D; ++i) x[i] -= ux[i];
             }
         }
+        if (PF) cur = nxt;
         LogAcc<T> la;
         la.init();
         chol_lower<T, D>(Dl, Lpi, la, bad);
