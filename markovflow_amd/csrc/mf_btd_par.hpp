@@ -573,19 +573,34 @@ __global__ void __launch_bounds__(64) par_means_emit_kernel(long Bl, long Br, lo
     if (p1 > n) p1 = n;
     T x[D];
     MF_UNROLL for (int i = 0; i < D; ++i) x[i] = T(0);
+    // a step is one d x d block and one vector: loads run a GROUP of G steps ahead of their use (G = 2 where two groups fit
+    // the registers) - with one recursion per lane the bytes in flight, not the 2 d^2 flops of a step, set the rate
+    constexpr int G = ((sizeof(T) == 8 && D <= 6) || (sizeof(T) == 4 && D <= 8)) ? 2 : 1;
+    struct St { T A[D][D]; T o[D]; };
+    auto load = [&](long p, St& d) {
+        const long pc = p < p1 ? p : p1 - 1;
+        load_vec<T, D>(offs + (r * n + pc) * D, d.o);
+        if (n > 1) load_mat<T, D, D>(A + (s * (n - 1) + (pc > 0 ? pc - 1 : 0)) * D * D, d.A);      // position 0: clamped, unused
+    };
+    St cur[G], nxt[G];
+    if (p0 < p1) { MF_UNROLL for (int q = 0; q < G; ++q) load(p0 + q, cur[q]); }
     if (c > 0) load_vec<T, D>(up + (r * P + c - 1) * D, x);
-    for (long p = p0; p < p1; ++p) {
-        T o[D];
-        load_vec<T, D>(offs + (r * n + p) * D, o);
-        if (p > 0) {
-            T Am[D][D], nx[D];
-            load_mat<T, D, D>(A + (s * (n - 1) + p - 1) * D * D, Am);
-            gemv_n<T, D, D>(Am, x, nx);
-            MF_UNROLL for (int i = 0; i < D; ++i) x[i] = nx[i] + o[i];
-        } else {
-            MF_UNROLL for (int i = 0; i < D; ++i) x[i] = o[i];
+    for (long p = p0; p < p1; p += G) {
+        MF_UNROLL for (int q = 0; q < G; ++q) load(p + G + q, nxt[q]);
+        __builtin_amdgcn_sched_barrier(0);
+        MF_UNROLL for (int q = 0; q < G; ++q) {
+            if (p + q < p1) {
+                if (p + q > 0) {
+                    T nx[D];
+                    gemv_n<T, D, D>(cur[q].A, x, nx);
+                    MF_UNROLL for (int i = 0; i < D; ++i) x[i] = nx[i] + cur[q].o[i];
+                } else {
+                    MF_UNROLL for (int i = 0; i < D; ++i) x[i] = cur[q].o[i];
+                }
+                store_vec<T, D>(out + (r * n + p + q) * D, x);
+            }
         }
-        store_vec<T, D>(out + (r * n + p) * D, x);
+        MF_UNROLL for (int q = 0; q < G; ++q) cur[q] = nxt[q];
     }
 }
 

@@ -601,8 +601,12 @@ int ssm_means(long Bl, long Br, long Tn, const T* A, const T* offs, T* out, void
     const long n = Tn;
     const long len0 = par_len0(Br, n);
     if (len0 == 0 || ws == nullptr || ws_bytes < btd_solve_ws<T>(Bl, Br, n)) {
-        hipLaunchKernelGGL((ssm_means_kernel<T, D>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Bl, Br, Tn, A, offs,
-                           out);
+        if (A && n >= 2)        // one lane per series: the level-0 emit kernel as ONE chunk (loads a group of steps ahead)
+            hipLaunchKernelGGL((par_means_emit_kernel<T, D>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Bl, Br, n, n, 1L, A,
+                               offs, static_cast<const T*>(nullptr), out);
+        else
+            hipLaunchKernelGGL((ssm_means_kernel<T, D>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Bl, Br, Tn, A, offs,
+                               out);
         return hipGetLastError() == hipSuccess ? 0 : -1000;
     }
     // the mean recursion is the affine scan of the triangular solve with M_p = A_{p-1}, c_p = offs_p (same workspace)
