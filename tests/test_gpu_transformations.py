@@ -73,3 +73,20 @@ def test_naturals_and_expectations_vs_dense_and_round_trips(rng, d, t, bsz):
     # the natural parameters rebuild the same distribution: precision blocks agree with StateSpaceModel.precision
     np.testing.assert_allclose(nn(-2 * th_diag), nn(ssm.precision.block_diagonal), rtol=1e-9, atol=1e-10)
     np.testing.assert_allclose(nn(-th_sub), nn(ssm.precision.block_sub_diagonal), rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize("d,t", [(12, 40), (30, 1001)])
+def test_round_trips_at_large_state_dim(rng, d, t):
+    """The largest problem of the reference's suite (tests/unit/test_ssm_gaussian_transformations.py:40-46: d = 30, T = 1001) runs
+    on the LDS-tile / MFMA operator kernels (d > 9, fp64)."""
+    kw = dict(mu0=rng.normal(size=(d,)), chol_p0=np.tril(0.2 * rng.normal(size=(d, d))) / np.sqrt(d) + np.eye(d),
+              a_s=0.6 * np.eye(d) + 0.3 * rng.normal(size=(t - 1, d, d)) / np.sqrt(d), b_s=0.3 * rng.normal(size=(t - 1, d)),
+              chol_q=np.tril(0.2 * rng.normal(size=(t - 1, d, d))) / np.sqrt(d) + 0.7 * np.eye(d))
+    for key in ("chol_p0", "chol_q"):
+        idx = np.arange(d)
+        kw[key][..., idx, idx] = np.abs(kw[key][..., idx, idx])
+    ssm = mfa.StateSpaceModel(tt(kw["mu0"]), tt(kw["chol_p0"]), tt(kw["a_s"]), tt(kw["b_s"]), tt(kw["chol_q"]))
+    want = (kw["a_s"], kw["b_s"], kw["chol_p0"], kw["chol_q"], kw["mu0"])
+    for got in (G.naturals_to_ssm_params(*G.ssm_to_naturals(ssm)), G.expectations_to_ssm_params(*G.ssm_to_expectations(ssm))):
+        for g, w in zip(got, want):
+            np.testing.assert_allclose(nn(g), w, rtol=1e-6, atol=1e-8)
