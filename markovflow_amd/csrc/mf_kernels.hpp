@@ -447,8 +447,9 @@ template <typename T, int D>
 __global__ void __launch_bounds__(256) btd_matvec_kernel(long Bl, long Br, long n, const T* __restrict__ diag,
                                                          const T* __restrict__ sub, const T* __restrict__ x,
                                                          T* __restrict__ out, int mode) {
-    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= Br * n) return;
+    const long id_raw = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = id_raw < Br * n;
+    const long id = valid ? id_raw : Br * n - 1;       // lanes past the end redo the last block (cross-lane moves need them) and store nothing
     const long r = id / n, k = id % n, s = r % Bl;
     T Dk[D][D], xv[D], acc[D];
     load_lower<T, D>(diag + (s * n + k) * D * D, Dk);
@@ -465,14 +466,39 @@ __global__ void __launch_bounds__(256) btd_matvec_kernel(long Bl, long Br, long 
         acc[i] = a;
     }
     if (sub) {
-        if ((mode == 0 || mode == 2) && k > 0) {
+        if (mode == 2) {
+            // symmetric product: every coupling block is needed by two neighbouring blocks.  A lane loads S_k once, keeps
+            // S_k^T x_{k+1} for its own block and hands S_k x_k to the lane of block k+1 (one cross-lane move of d values);
+            // only the first lane of a wave (and of a series) loads the block of its left neighbour itself.
+            T u[D];
+            MF_UNROLL for (int i = 0; i < D; ++i) u[i] = T(0);
+            if (k + 1 < n) {
+                T S[D][D], xn[D], t[D];
+                load_mat<T, D, D>(sub + (s * (n - 1) + k) * D * D, S);
+                load_vec<T, D>(x + (r * n + k + 1) * D, xn);
+                gemv_t<T, D, D>(S, xn, t);
+                gemv_n<T, D, D>(S, xv, u);
+                MF_UNROLL for (int i = 0; i < D; ++i) acc[i] += t[i];
+            }
+            const int lane = threadIdx.x & 63;
+            T from_left[D];
+            MF_UNROLL for (int i = 0; i < D; ++i) from_left[i] = __shfl_up(u[i], 1, 64);
+            if (k > 0) {
+                if (lane == 0) {
+                    T S[D][D], xp[D];
+                    load_mat<T, D, D>(sub + (s * (n - 1) + k - 1) * D * D, S);
+                    load_vec<T, D>(x + (r * n + k - 1) * D, xp);
+                    gemv_n<T, D, D>(S, xp, from_left);
+                }
+                MF_UNROLL for (int i = 0; i < D; ++i) acc[i] += from_left[i];
+            }
+        } else if (mode == 0 && k > 0) {
             T S[D][D], xp[D], t[D];
             load_mat<T, D, D>(sub + (s * (n - 1) + k - 1) * D * D, S);
             load_vec<T, D>(x + (r * n + k - 1) * D, xp);
             gemv_n<T, D, D>(S, xp, t);
             MF_UNROLL for (int i = 0; i < D; ++i) acc[i] += t[i];
-        }
-        if ((mode == 1 || mode == 2) && k + 1 < n) {
+        } else if (mode == 1 && k + 1 < n) {
             T S[D][D], xn[D], t[D];
             load_mat<T, D, D>(sub + (s * (n - 1) + k) * D * D, S);
             load_vec<T, D>(x + (r * n + k + 1) * D, xn);
@@ -480,7 +506,7 @@ __global__ void __launch_bounds__(256) btd_matvec_kernel(long Bl, long Br, long 
             MF_UNROLL for (int i = 0; i < D; ++i) acc[i] += t[i];
         }
     }
-    store_vec<T, D>(out + (r * n + k) * D, acc);
+    if (valid) store_vec<T, D>(out + (r * n + k) * D, acc);
 }
 
 // abs_log_det (block_tri_diag.py:353-366): one wavefront per series
