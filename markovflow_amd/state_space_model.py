@@ -56,11 +56,13 @@ class StateSpaceModel(GaussMarkovDistribution):
                 raise ValueError(f"StateSpaceModel: {name} has shape {tuple(t.shape)}, expected {shape}")
             if t.dtype != initial_mean.dtype or t.device != initial_mean.device:
                 raise ValueError(f"StateSpaceModel: {name} must share dtype and device with initial_mean")
-        self._mu_0 = initial_mean
-        self._A_s = state_transitions
-        self._chol_P_0 = chol_initial_covariance
-        self._chol_Q_s = chol_process_covariances
-        self._b_s = state_offsets
+        self._mu_0 = initial_mean.contiguous()
+        # held contiguous: every kernel call needs contiguous blocks, and a chain built from slices of larger tensors (the
+        # posterior: chol_dinv[..., 1:, :, :]) would otherwise be copied again by every operator that touches it
+        self._A_s = state_transitions.contiguous()
+        self._chol_P_0 = chol_initial_covariance.contiguous()
+        self._chol_Q_s = chol_process_covariances.contiguous()
+        self._b_s = state_offsets.contiguous()
 
     # -- shapes / accessors (state_space_model.py:126-229) ------------------------------------------------
     @property
