@@ -134,6 +134,19 @@ int mf_btd_diag_of_inverse_f32(int64_t B, int64_t T, int d, const float* ldiag, 
                                float* osub, void* ws, size_t ws_bytes, void* stream);
 
 /*
+ * StateSpaceModel.marginal_covariances and subsequent_covariances (markovflow/state_space_model.py:254-275, 326-341) in one
+ * scan: Sigma_0 = P0, Sigma_{k+1} = A_k Sigma_k A_k^T + Q_k, out_sub[k] = Cov(x_{k+1}, x_k) = A_k Sigma_k (nullable).  The
+ * reference takes the block diagonal of the inverse of the assembled precision; the forward recursion yields the same blocks
+ * without assembling or factorising it.  Parallel in time for B < 4096 (workspace = the diag-of-inverse query), one lane per
+ * series otherwise.  T >= 2, state dimension 1..9 (returns -100 above: use precision -> cholesky -> diag_of_inverse).
+ * cholP0 [B,d,d], A, cholQ [B,T-1,d,d]; out_cov [B,T,d,d], out_sub [B,T-1,d,d].
+ */
+int mf_ssm_marginal_covariances_f64(int64_t B, int64_t T, int d, const double* cholP0, const double* A, const double* cholQ,
+                                    double* out_cov, double* out_sub, void* ws, size_t ws_bytes, void* stream);
+int mf_ssm_marginal_covariances_f32(int64_t B, int64_t T, int d, const float* cholP0, const float* A, const float* cholQ,
+                                    float* out_cov, float* out_sub, void* ws, size_t ws_bytes, void* stream);
+
+/*
  * SymmetricBlockTriDiagonal.upper_diagonal_lower  (block_tri_diag.py:438-545, the tf.while_loop):
  * ut [B,T-1,d,d] = U_k^T, chol_d [B,T,d,d] = chol(Delta_k).
  * With eta != NULL ([B,T,d]) it additionally runs the rest of

@@ -216,6 +216,17 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (big) return mf::big_diag_of_inverse_##SUF(B, Tn, d, ldiag, lsub, odiag, osub, S(stream));                  \
         return t->btd_diag_of_inverse(B, Tn, ldiag, lsub, odiag, osub, ws, ws_bytes, S(stream));                       \
     }                                                                                                                  \
+    int mf_ssm_marginal_covariances_##SUF(int64_t B, int64_t Tn, int d, const T* cholP0, const T* A, const T* cholQ,   \
+                                          T* out_cov, T* out_sub, void* ws, size_t ws_bytes, void* stream) {          \
+        MF_HEAD(T, B, Tn, d)                                                                                           \
+        if (Tn < 2) return -2;                                                                                         \
+        if (big) return -100;                                                                                          \
+        if (!cholP0) return -4;                                                                                        \
+        if (!A) return -5;                                                                                             \
+        if (!cholQ) return -6;                                                                                         \
+        if (!out_cov) return -7;                                                                                       \
+        return t->ssm_marginal_covs(B, Tn, cholP0, A, cholQ, out_cov, out_sub, ws, ws_bytes, S(stream));               \
+    }                                                                                                                  \
     int mf_btd_udl_##SUF(int64_t B, int64_t Tn, int d, const T* diag, const T* sub, T* ut, T* chol_d, const T* eta,    \
                          T* m_post, T* chol_dinv, void* ws, size_t ws_bytes, int* info, void* stream) {                \
         MF_HEAD(T, B, Tn, d)                                                                                           \

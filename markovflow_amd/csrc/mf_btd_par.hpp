@@ -689,9 +689,48 @@ MF_DEV void takahashi_from(const T (&L)[D][D], const T (&W)[D][D], bool has_g, T
     }
 }
 
-template <typename T, int D>
-__global__ void __launch_bounds__(64) par_tak_up0_kernel(long B, long n, long len, long P, const T* __restrict__ ldiag,
-                                                         const T* __restrict__ lsub, T* __restrict__ oG, T* __restrict__ oN) {
+// Source of the congruence recursion  Sigma(p) = N_p + G_p^T Sigma(p-1) G_p  of the level-0 kernels below:
+//   SRC 0  block Takahashi on a Cholesky factor (block_diagonal_of_inverse): position p = block n-1-p,
+//          N = L_k^-T L_k^-1, G = W_k L_k^-1;  a = ldiag, b = lsub;
+//   SRC 1  marginal covariances of a state space model, Sigma_{k+1} = A_k Sigma_k A_k^T + Q_k (state_space_model.py:254-275
+//          computes them as the block diagonal of the inverse precision; the forward recursion gives the same blocks without
+//          assembling or factorising the precision): position p = block p, N = C C^T with C = cholP0 (p = 0) or cholQ_{p-1},
+//          G = A_{p-1}^T;  a = cholQ, b = A, c0 = cholP0.
+template <typename T> struct TakSrc {
+    const T* a;
+    const T* b;
+    const T* c0;
+};
+template <typename T, int D, int SRC>
+MF_DEV void tak_load(const TakSrc<T>& src, long s, long n, long p, T (&L)[D][D], T (&W)[D][D]) {
+    if (SRC == 0) {
+        const long k = n - 1 - p;                        // the coupling of position 0 does not exist: clamped, not used
+        load_lower<T, D>(src.a + (s * n + k) * D * D, L);
+        load_mat<T, D, D>(src.b + (s * (n - 1) + (k < n - 1 ? k : n - 2)) * D * D, W);
+    } else {
+        const T* lp = p > 0 ? src.a + (s * (n - 1) + p - 1) * D * D : src.c0 + s * D * D;
+        load_lower<T, D>(lp, L);
+        load_mat<T, D, D>(src.b + (s * (n - 1) + (p > 0 ? p - 1 : 0)) * D * D, W);
+    }
+}
+template <typename T, int D, int SRC>
+MF_DEV void tak_terms(const T (&L)[D][D], const T (&W)[D][D], bool has_g, T (&N)[D][D], T (&G)[D][D]) {
+    if (SRC == 0) {
+        takahashi_from<T, D>(L, W, has_g, N, G);
+    } else {
+        MF_UNROLL for (int i = 0; i < D; ++i)
+            MF_UNROLL for (int j = 0; j <= i; ++j) {
+                T a = L[i][0] * L[j][0];
+                MF_UNROLL for (int q = 1; q <= j; ++q) a += L[i][q] * L[j][q];
+                N[i][j] = a;
+            }
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) G[i][j] = W[j][i];
+    }
+}
+
+template <typename T, int D, int SRC>
+__global__ void __launch_bounds__(64) par_tak_up0_kernel(long B, long n, long len, long P, TakSrc<T> src, T* __restrict__ oG,
+                                                         T* __restrict__ oN) {
     const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= B * P) return;
     const long s = id / P, c = id % P;
@@ -700,9 +739,12 @@ __global__ void __launch_bounds__(64) par_tak_up0_kernel(long B, long n, long le
     if (p1 > n) p1 = n;
     T Gc[D][D], Nc[D][D];
     for (long p = p0; p < p1; ++p) {
-        const long k = n - 1 - p;
         T N[D][D], G[D][D];
-        takahashi_terms<T, D>(ldiag, lsub, s, n, k, p > 0, N, G);
+        {
+            T L[D][D], W[D][D];
+            tak_load<T, D, SRC>(src, s, n, p, L, W);
+            tak_terms<T, D, SRC>(L, W, p > 0, N, G);
+        }
         if (p == p0) {
             MF_UNROLL for (int i = 0; i < D; ++i)
                 MF_UNROLL for (int j = 0; j < D; ++j) { Nc[i][j] = (i >= j) ? N[i][j] : N[j][i]; Gc[i][j] = (p > 0) ? G[i][j] : T(0); }
@@ -752,9 +794,9 @@ __global__ void __launch_bounds__(64) par_tak_up_kernel(long B, long n, long len
 }
 
 // The two up-sweeps with the composed G of the run in LDS and Nc as a lower triangle (d >= 7 in fp64, see mf_kf_x.hpp)
-template <typename T, int D>
-__global__ void __launch_bounds__(64) par_tak_up0_x_kernel(long B, long n, long len, long P, const T* __restrict__ ldiag,
-                                                           const T* __restrict__ lsub, T* __restrict__ oG, T* __restrict__ oN) {
+template <typename T, int D, int SRC>
+__global__ void __launch_bounds__(64) par_tak_up0_x_kernel(long B, long n, long len, long P, TakSrc<T> src, T* __restrict__ oG,
+                                                           T* __restrict__ oN) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* gc = reinterpret_cast<T*>(smem_raw) + threadIdx.x;
     const long total = B * P;
@@ -769,9 +811,12 @@ __global__ void __launch_bounds__(64) par_tak_up0_x_kernel(long B, long n, long 
     T Nc[D][D];
     MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Nc[i][j] = T(0);
     for (long p = p0; p < p1; ++p) {
-        const long k = n - 1 - p;
         T N[D][D], G[D][D];
-        takahashi_terms<T, D>(ldiag, lsub, s, n, k, p > 0, N, G);
+        {
+            T L[D][D], W[D][D];
+            tak_load<T, D, SRC>(src, s, n, p, L, W);
+            tak_terms<T, D, SRC>(L, W, p > 0, N, G);
+        }
         if (p == p0) {
             MF_UNROLL for (int i = 0; i < D; ++i)
                 MF_UNROLL for (int j = 0; j < D; ++j) {
@@ -851,10 +896,10 @@ __global__ void __launch_bounds__(64) par_tak_down_kernel(long B, long n, long l
     }
 }
 
-template <typename T, int D>
-__global__ void __launch_bounds__(64) par_tak_emit_kernel(long B, long n, long len, long P, const T* __restrict__ ldiag,
-                                                          const T* __restrict__ lsub, const T* __restrict__ up,
-                                                          T* __restrict__ odiag, T* __restrict__ osub) {
+template <typename T, int D, int SRC>
+__global__ void __launch_bounds__(64) par_tak_emit_kernel(long B, long n, long len, long P, TakSrc<T> src,
+                                                          const T* __restrict__ up, T* __restrict__ odiag,
+                                                          T* __restrict__ osub) {
     const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= B * P) return;
     const long s = id / P, c = id % P;
@@ -862,11 +907,7 @@ __global__ void __launch_bounds__(64) par_tak_emit_kernel(long B, long n, long l
     long p1 = p0 + len;
     if (p1 > n) p1 = n;
     struct Step { T L[D][D]; T W[D][D]; };
-    auto load = [&](long p, Step& d) {                 // factor blocks of position p (block k = n-1-p); the coupling of
-        const long k = n - 1 - p;                        // position 0 does not exist: clamped, not used
-        load_lower<T, D>(ldiag + (s * n + k) * D * D, d.L);
-        load_mat<T, D, D>(lsub + (s * (n - 1) + (k < n - 1 ? k : n - 2)) * D * D, d.W);
-    };
+    auto load = [&](long p, Step& d) { tak_load<T, D, SRC>(src, s, n, p, d.L, d.W); };
     constexpr bool PF = par_prefetch<T, D>() || (sizeof(T) == 8 && D <= 6);
     Step cur, nxt;
     if (PF && p0 < p1) load(p0, cur);
@@ -874,16 +915,17 @@ __global__ void __launch_bounds__(64) par_tak_emit_kernel(long B, long n, long l
     MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Sig[i][j] = T(0);
     if (c > 0) load_lower<T, D>(up + (s * P + c - 1) * D * D, Sig);
     for (long p = p0; p < p1; ++p) {
-        const long k = n - 1 - p;
+        const long k = SRC == 0 ? n - 1 - p : p;
         if (PF) load(p + 1 < p1 ? p + 1 : p, nxt);
         else load(p, cur);
         __builtin_amdgcn_sched_barrier(0);
         T N[D][D], G[D][D];
-        takahashi_from<T, D>(cur.L, cur.W, p > 0, N, G);
+        tak_terms<T, D, SRC>(cur.L, cur.W, p > 0, N, G);
         if (PF) cur = nxt;
         if (p > 0) {
             if (osub) {
-                T* o = osub + (s * (n - 1) + k) * D * D;
+                // SRC 0: block (k+1, k) of the inverse = -Sigma_{k+1} G_k;  SRC 1: Cov(x_p, x_{p-1}) = A Sigma_{p-1} = (Sigma_{p-1} G)^T
+                T* o = osub + (s * (n - 1) + (SRC == 0 ? k : p - 1)) * D * D;
                 MF_UNROLL for (int i = 0; i < D; ++i) {
                     T row[D];
                     MF_UNROLL for (int j = 0; j < D; ++j) row[j] = Sig[i][0] * G[0][j];
@@ -891,7 +933,8 @@ __global__ void __launch_bounds__(64) par_tak_emit_kernel(long B, long n, long l
                         const T sil = (i >= l) ? Sig[i][l] : Sig[l][i];
                         MF_UNROLL for (int j = 0; j < D; ++j) row[j] += sil * G[l][j];
                     }
-                    MF_UNROLL for (int j = 0; j < D; ++j) o[i * D + j] = -row[j];
+                    if (SRC == 0) { MF_UNROLL for (int j = 0; j < D; ++j) o[i * D + j] = -row[j]; }
+                    else { MF_UNROLL for (int j = 0; j < D; ++j) o[j * D + i] = row[j]; }
                 }
             }
             congruence_step_lower<T, D>(G, N, Sig);

@@ -443,17 +443,15 @@ template <typename T> size_t btd_diag_of_inverse_ws(long B, long n) {
     return total;
 }
 
-template <typename T>
-int btd_diag_of_inverse(long B, long n, const T* ldiag, const T* lsub, T* odiag, T* osub, void* ws, size_t ws_bytes,
-                        hipStream_t st) {
-    const long len0 = lsub ? par_len0(B, n) : 0;
+// Congruence scan Sigma(p) = N_p + G_p^T Sigma(p-1) G_p over the positions of every series (mf_btd_par.hpp: TakSrc):
+// SRC 0 = block Takahashi on a Cholesky factor, SRC 1 = marginal covariances of a state space model.
+template <typename T, int SRC>
+int tak_scan(long B, long n, TakSrc<T> src, T* odiag, T* osub, void* ws, size_t ws_bytes, hipStream_t st) {
+    const long len0 = par_len0(B, n);
     if (len0 == 0 || ws == nullptr || ws_bytes < btd_diag_of_inverse_ws<T>(B, n)) {
-        if (lsub && n >= 2)     // one lane per series: the level-0 emit kernel as ONE chunk (prefetched loads)
-            hipLaunchKernelGGL((par_tak_emit_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, n, 1L, ldiag,
-                               lsub, static_cast<const T*>(nullptr), odiag, osub);
-        else
-            hipLaunchKernelGGL((btd_diag_of_inverse_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, ldiag,
-                               lsub, odiag, osub);
+        // one lane per series: the level-0 emit kernel as ONE chunk (prefetched loads)
+        hipLaunchKernelGGL((par_tak_emit_kernel<T, D, SRC>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, n, 1L, src,
+                           static_cast<const T*>(nullptr), odiag, osub);
         return hipGetLastError() == hipSuccess ? 0 : -1000;
     }
     const ParPlan pl = par_plan(n, len0);
@@ -467,11 +465,11 @@ int btd_diag_of_inverse(long B, long n, const T* ldiag, const T* lsub, T* odiag,
     }
     constexpr int g_lds = D * D * 64 * (int)sizeof(T);      // x path: the composed G of a run lives in LDS
     if (x_path<T>())
-        hipLaunchKernelGGL((par_tak_up0_x_kernel<T, D>), dim3((unsigned)cdiv(B * pl.n[1], 64)), dim3(64), g_lds, st, B, n,
-                           len0, pl.n[1], ldiag, lsub, arr[1].G, arr[1].N);
+        hipLaunchKernelGGL((par_tak_up0_x_kernel<T, D, SRC>), dim3((unsigned)cdiv(B * pl.n[1], 64)), dim3(64), g_lds, st, B, n,
+                           len0, pl.n[1], src, arr[1].G, arr[1].N);
     else
-        hipLaunchKernelGGL((par_tak_up0_kernel<T, D>), dim3((unsigned)cdiv(B * pl.n[1], 64)), dim3(64), 0, st, B, n, len0,
-                           pl.n[1], ldiag, lsub, arr[1].G, arr[1].N);
+        hipLaunchKernelGGL((par_tak_up0_kernel<T, D, SRC>), dim3((unsigned)cdiv(B * pl.n[1], 64)), dim3(64), 0, st, B, n, len0,
+                           pl.n[1], src, arr[1].G, arr[1].N);
     for (int l = 1; l < pl.levels; ++l) {
         const long P = pl.n[l + 1];
         if (x_path<T>())
@@ -495,9 +493,27 @@ int btd_diag_of_inverse(long B, long n, const T* ldiag, const T* lsub, T* odiag,
                            pl.len[l], P, static_cast<const T*>(arr[l].G), static_cast<const T*>(arr[l].N),
                            static_cast<const T*>(arr[l + 1].Z), arr[l].Z);
     }
-    hipLaunchKernelGGL((par_tak_emit_kernel<T, D>), dim3((unsigned)cdiv(B * pl.n[1], 64)), dim3(64), 0, st, B, n, len0,
-                       pl.n[1], ldiag, lsub, static_cast<const T*>(arr[1].Z), odiag, osub);
+    hipLaunchKernelGGL((par_tak_emit_kernel<T, D, SRC>), dim3((unsigned)cdiv(B * pl.n[1], 64)), dim3(64), 0, st, B, n, len0,
+                       pl.n[1], src, static_cast<const T*>(arr[1].Z), odiag, osub);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+template <typename T>
+int btd_diag_of_inverse(long B, long n, const T* ldiag, const T* lsub, T* odiag, T* osub, void* ws, size_t ws_bytes,
+                        hipStream_t st) {
+    if (!lsub || n < 2) {       // block-diagonal factor: nothing to scan
+        hipLaunchKernelGGL((btd_diag_of_inverse_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, ldiag,
+                           lsub, odiag, osub);
+        return hipGetLastError() == hipSuccess ? 0 : -1000;
+    }
+    return tak_scan<T, 0>(B, n, TakSrc<T>{ldiag, lsub, nullptr}, odiag, osub, ws, ws_bytes, st);
+}
+
+// StateSpaceModel.marginal_covariances (+ subsequent_covariances) by the forward recursion; n = T >= 2 blocks
+template <typename T>
+int ssm_marginal_covs(long B, long n, const T* cholP0, const T* A, const T* cholQ, T* ocov, T* osub, void* ws, size_t ws_bytes,
+                      hipStream_t st) {
+    return tak_scan<T, 1>(B, n, TakSrc<T>{cholQ, A, cholP0}, ocov, osub, ws, ws_bytes, st);
 }
 
 template <typename T> size_t btd_udl_ws(long B, long n) {
@@ -712,7 +728,7 @@ int kf_grad(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, c
 template <typename T> const OpsTable<T>* table() {
     static const OpsTable<T> t = {
         &kf_loglik_ws<T>, &kf_loglik<T>, &btd_logdet_quad_ws<T>, &btd_logdet_quad<T>, &btd_cholesky_ws<T>, &btd_cholesky<T>,
-        &btd_solve_ws<T>, &btd_solve<T>,    &btd_matvec<T>, &btd_logdet<T>,        &btd_diag_of_inverse_ws<T>, &btd_diag_of_inverse<T>, &btd_udl_ws<T>, &btd_udl<T>,
+        &btd_solve_ws<T>, &btd_solve<T>,    &btd_matvec<T>, &btd_logdet<T>,        &btd_diag_of_inverse_ws<T>, &btd_diag_of_inverse<T>, &ssm_marginal_covs<T>, &btd_udl_ws<T>, &btd_udl<T>,
         &ssm_precision<T>, &ssm_means<T>, &block_matmul<T>, &gpr_loglik<T>, &sde_predict<T>, &kf_grad<T>,
     };
     return &t;

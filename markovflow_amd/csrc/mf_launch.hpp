@@ -27,6 +27,8 @@ template <typename T> struct OpsTable {
     size_t (*btd_diag_of_inverse_ws)(long B, long n);
     int (*btd_diag_of_inverse)(long B, long n, const T* ldiag, const T* lsub, T* odiag, T* osub, void* ws, size_t ws_bytes,
                                hipStream_t st);
+    int (*ssm_marginal_covs)(long B, long n, const T* cholP0, const T* A, const T* cholQ, T* ocov, T* osub, void* ws,
+                             size_t ws_bytes, hipStream_t st);
     size_t (*btd_udl_ws)(long B, long n);
     int (*btd_udl)(long B, long n, const T* diag, const T* sub, T* ut, T* chol_d, const T* eta, T* m_post,
                    T* chol_dinv, void* ws, size_t ws_bytes, int* info, hipStream_t st);

@@ -49,8 +49,8 @@ class _LogLikelihoodPerSeries(torch.autograd.Function):
             ssm = StateSpaceModel(mu0, cp0, a_s, b_s, cq)
             kf = KalmanFilter(ssm, EmissionModel(h), y, chol_r)
             post = kf.posterior_state_space_model()
-            means, covs = post.marginals
-            cross = post.subsequent_covariances(covs)
+            means = post.marginal_means
+            covs, cross = post.covariance_blocks()             # one forward scan of the posterior chain
             bsz, n, m, d = h.shape
             r_inv = kf._r_inv.contiguous()
             g_mu0, g_cp0 = torch.empty_like(mu0), torch.empty_like(cp0)

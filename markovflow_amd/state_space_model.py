@@ -141,11 +141,32 @@ class StateSpaceModel(GaussMarkovDistribution):
     @property
     def marginal_covariances(self) -> torch.Tensor:
         """Diagonal blocks of the covariance (state_space_model.py:254-262)."""
-        return self.precision.cholesky.block_diagonal_of_inverse()
+        return self._covariance_scan(want_sub=False)[0]
 
     def covariance_blocks(self) -> Tuple[torch.Tensor, torch.Tensor]:
-        covs = self.marginal_covariances
-        return covs, self.subsequent_covariances(covs)
+        """Marginal covariances and ``Cov(x_{k+1}, x_k)`` from ONE scan."""
+        return self._covariance_scan(want_sub=True)
+
+    def _covariance_scan(self, want_sub: bool):
+        """``Σ_0 = P_0, Σ_{k+1} = A_kΣ_kA_kᵀ + Q_k`` (and ``A_kΣ_k``).  The reference takes the block diagonal of the inverse of
+        the assembled precision (``self.precision.cholesky.block_diagonal_of_inverse()``, state_space_model.py:262); the
+        forward recursion gives the same blocks without assembling or factorising anything - one kernel sweep instead of
+        three (parallel in time for few series).  State dimensions beyond the register kernels keep the reference's route."""
+        d, n = self.state_dim, self.num_transitions + 1
+        if d > _lib.load().mf_max_state_dim():
+            covs = self.precision.cholesky.block_diagonal_of_inverse()
+            return covs, (self.subsequent_covariances(covs) if want_sub else None)
+        cp0, a_f, cq = _flat(self._chol_P_0, 2), _flat(self._A_s, 3), _flat(self._chol_Q_s, 3)
+        bsz = a_f.shape[0]
+        covs = torch.empty((bsz, n, d, d), dtype=a_f.dtype, device=a_f.device)
+        sub = torch.empty_like(a_f) if want_sub else None
+        if bsz > 0:
+            ws_bytes = int(_lib.load().mf_btd_diag_of_inverse_workspace_bytes(bsz, n, d, a_f.element_size()))
+            ws = _lib.workspace(ws_bytes, a_f.device)
+            _lib.call("mf_ssm_marginal_covariances", a_f.dtype, bsz, n, d, _lib.ptr(cp0), _lib.ptr(a_f), _lib.ptr(cq),
+                      _lib.ptr(covs), _lib.ptr(sub), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(a_f.device))
+        batch = tuple(self.batch_shape)
+        return covs.reshape(batch + (n, d, d)), (sub.reshape(self._A_s.shape) if want_sub else None)
 
     @property
     def a_inv_block(self) -> LowerTriangularBlockTriDiagonal:
@@ -249,9 +270,8 @@ class StateSpaceModel(GaussMarkovDistribution):
     def kl_divergence(self, dist: GaussMarkovDistribution) -> torch.Tensor:
         """``KL(self ∥ dist)`` with shape ``batch_shape`` (state_space_model.py:528-593)."""
         check_compatible(self, dist)
-        marginal_covs_1 = self.marginal_covariances
+        marginal_covs_1, subsequent_covs_1 = self.covariance_blocks()
         precision_2 = dist.precision
-        subsequent_covs_1 = self.subsequent_covariances(marginal_covs_1)
         trace = torch.sum(precision_2.block_diagonal * marginal_covs_1, dim=(-3, -2, -1)) + 2.0 * torch.sum(
             precision_2.block_sub_diagonal * subsequent_covs_1, dim=(-3, -2, -1))
         mean_diff = dist.marginal_means - self.marginal_means
