@@ -220,3 +220,28 @@ def test_parallel_posterior_state_space_model_vs_oracle(rng, d, m, n):
     np.testing.assert_allclose(nn(post.marginal_means), means, rtol=1e-7, atol=1e-9)
     covs = O.ssm_marginal_covariances(want[1], want[2], want[4])
     np.testing.assert_allclose(nn(post.marginal_covariances), covs, rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("d,n,batch", [(1, 2, ()), (3, 9, (2,)), (6, 64, (3,)), (2, 777, (2, 1)), (6, 1000, (1,)), (9, 300, (2,)), (7, 130, ())])
+def test_covariance_scan_equals_the_reference_route(rng, dtype, d, n, batch):
+    """marginal / subsequent covariances by the forward recursion (mf_ssm_marginal_covariances) against the reference's route:
+    assembled precision -> Cholesky -> block diagonal of the inverse, and A_k Sigma_k (state_space_model.py:254-275,326-341)."""
+    from test_gpu_kalman import random_ssm
+    kw = random_ssm(rng, batch, n, d, 1, well=True)
+    t = lambda x: torch.tensor(np.ascontiguousarray(x), dtype=dtype, device="cuda:0")   # noqa: E731
+    ssm = mfa.StateSpaceModel(t(kw["mu0"]), t(kw["chol_p0"]), t(kw["a_s"]), t(kw["b_s"]), t(kw["chol_q"]))
+    covs, sub = ssm.covariance_blocks()
+    ref_covs = ssm.precision.cholesky.block_diagonal_of_inverse()
+    ref_sub = ssm.subsequent_covariances(ref_covs)
+    tol = dict(rtol=1e-9, atol=1e-11) if dtype == torch.float64 else dict(rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(covs.cpu().numpy(), ref_covs.cpu().numpy(), **tol)
+    np.testing.assert_allclose(sub.cpu().numpy(), ref_sub.cpu().numpy(), **tol)
+    np.testing.assert_allclose(ssm.marginal_covariances.cpu().numpy(), covs.cpu().numpy(), **tol)
+    # explicit recursion in numpy (tests/unit/test_state_space_model.py:63-89 of the reference)
+    if dtype == torch.float64 and not batch:
+        cov = kw["chol_p0"] @ kw["chol_p0"].T
+        for k in range(n - 1):
+            np.testing.assert_allclose(covs[k].cpu().numpy(), cov, rtol=1e-9, atol=1e-11)
+            cov = kw["a_s"][k] @ cov @ kw["a_s"][k].T + kw["chol_q"][k] @ kw["chol_q"][k].T
+        np.testing.assert_allclose(covs[n - 1].cpu().numpy(), cov, rtol=1e-9, atol=1e-11)
