@@ -275,8 +275,9 @@ class StateSpaceModel(GaussMarkovDistribution):
         trace = torch.sum(precision_2.block_diagonal * marginal_covs_1, dim=(-3, -2, -1)) + 2.0 * torch.sum(
             precision_2.block_sub_diagonal * subsequent_covs_1, dim=(-3, -2, -1))
         mean_diff = dist.marginal_means - self.marginal_means
-        l_mean_diff = precision_2.cholesky.dense_mult(mean_diff, transpose_left=True)
-        mahalanobis = torch.sum(l_mean_diff * l_mean_diff, dim=(-2, -1))
+        # the reference forms |L2^T (mu2 - mu1)|^2 with the Cholesky factor of P2 (state_space_model.py:575-583); the same
+        # number is (mu2 - mu1)^T P2 (mu2 - mu1): one symmetric block-tridiagonal product, no factorisation
+        mahalanobis = torch.sum(mean_diff * precision_2.dense_mult(mean_diff), dim=(-2, -1))
         dim = (self.num_transitions + 1) * self.state_dim
         return 0.5 * (trace + mahalanobis - dim - dist.log_det_precision() + self.log_det_precision())
 
