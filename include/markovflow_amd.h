@@ -274,19 +274,20 @@ int mf_sde_conditional_predict_f32(int64_t B, int64_t N, int64_t Np, int d, cons
  * Cov(x_{k+1}, x_k) - exact, local in time, one lane per (series, time point).  Outputs, all per series (not summed over the
  * batch): g_mu0 [B,d], g_cholP0 [B,d,d] (lower), g_A [B,T-1,d,d], g_b [B,T-1,d], g_cholQ [B,T-1,d,d] (lower), g_H [B,T,m,d],
  * g_y [B,T,m], and g_omega [B,T,m,m] = E[r r^T] with r = y - H x, from which the gradient with respect to a shared
- * observation covariance follows by reduction: dll/dcholR = tril(L^-T (L^-1 (sum omega) L^-T - n I)).  Shared R^-1 [m,m];
- * state dimension 1..9, m <= 4.
+ * observation covariance follows by reduction: dll/dcholR = tril(L^-T (L^-1 (sum omega) L^-T - n I)).  weights [B]
+ * (nullable): the incoming gradient of every series' value, applied to all outputs.  Shared R^-1 [m,m]; state dimension
+ * 1..9, m <= 4.
  */
 int mf_kf_loglik_grad_f64(int64_t B, int64_t T, int d, int m, const double* mu0, const double* cholP0, const double* A,
                           const double* b, const double* cholQ, const double* H, const double* y, const double* Rinv,
                           const double* post_mean, const double* post_cov, const double* post_cross, double* g_mu0,
                           double* g_cholP0, double* g_A, double* g_b, double* g_cholQ, double* g_H, double* g_y,
-                          double* g_omega, int* info, void* stream);
+                          double* g_omega, const double* weights, int* info, void* stream);
 int mf_kf_loglik_grad_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const float* cholP0, const float* A,
                           const float* b, const float* cholQ, const float* H, const float* y, const float* Rinv,
                           const float* post_mean, const float* post_cov, const float* post_cross, float* g_mu0,
                           float* g_cholP0, float* g_A, float* g_b, float* g_cholQ, float* g_H, float* g_y, float* g_omega,
-                          int* info, void* stream);
+                          const float* weights, int* info, void* stream);
 
 #ifdef __cplusplus
 }

@@ -330,7 +330,7 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
     int mf_kf_loglik_grad_##SUF(int64_t B, int64_t Tn, int d, int m, const T* mu0, const T* cholP0, const T* A,        \
                                 const T* b, const T* cholQ, const T* H, const T* y, const T* Rinv, const T* post_mean, \
                                 const T* post_cov, const T* post_cross, T* g_mu0, T* g_cholP0, T* g_A, T* g_b,         \
-                                T* g_cholQ, T* g_H, T* g_y, T* g_omega, int* info, void* stream) {                     \
+                                T* g_cholQ, T* g_H, T* g_y, T* g_omega, const T* weights, int* info, void* stream) { \
         MF_HEAD(T, B, Tn, d)                                                                                           \
         if (big) return -100;                                                                                          \
         if (m < 1 || m > 4) return -4;                                                                                 \
@@ -338,7 +338,7 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (!post_mean || !post_cov || (Tn > 1 && !post_cross)) return -13;                                            \
         if (!g_mu0 || !g_cholP0 || (Tn > 1 && (!g_A || !g_b || !g_cholQ)) || !g_H || !g_y || !g_omega) return -16;     \
         return t->kf_grad(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, post_mean, post_cov, post_cross, g_mu0,      \
-                          g_cholP0, g_A, g_b, g_cholQ, g_H, g_y, g_omega, info, S(stream));                            \
+                          g_cholP0, g_A, g_b, g_cholQ, g_H, g_y, g_omega, weights, info, S(stream));                   \
     }
 
 MF_DEFINE(f64, double)

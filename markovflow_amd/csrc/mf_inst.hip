@@ -716,9 +716,9 @@ int sde_predict(long B, long N, long Np, const long long* idx, const T* Amt, con
 template <typename T>
 int kf_grad(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H,
             const T* y, const T* Rinv, const T* pm, const T* pS, const T* pX, T* gmu0, T* gC0, T* gA, T* gb, T* gC, T* gH,
-            T* gy, T* gOm, int* info, hipStream_t st) {
+            T* gy, T* gOm, const T* weights, int* info, hipStream_t st) {
     if (m < 1 || m > MF_MAXM) return -3;
-    KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, 0, 1, info, 0};
+    KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, 0, 1, info, 0, weights};
     const dim3 grid((unsigned)cdiv(B * Tn, 64)), block(64);
     if (m == 1) hipLaunchKernelGGL((kf_grad_kernel<T, D, 1>), grid, block, 0, st, a, pm, pS, pX, gmu0, gC0, gA, gb, gC, gH, gy, gOm);
     else hipLaunchKernelGGL((kf_grad_kernel<T, D, 0>), grid, block, 0, st, a, pm, pS, pX, gmu0, gC0, gA, gb, gC, gH, gy, gOm);

@@ -109,6 +109,7 @@ template <typename T> struct KfArgs {
     long P;              // chunks per series
     int* info;
     int debug;           // timing experiments only: bit 0 = DMA descriptors with zero records (no memory traffic)
+    const T* weights;    // gradient kernel only: per-series factor applied to every output (NULL = 1)
 };
 
 constexpr int MF_MAXM = 4;
@@ -865,6 +866,7 @@ __global__ void __launch_bounds__(64) kf_grad_kernel(KfArgs<T> a, const T* __res
     if (id >= a.B * a.Tn) return;
     const long s = id / a.Tn, k = id % a.Tn;
     const int m = a.m;
+    const T wgt = a.weights ? a.weights[s] : T(1);      // the incoming gradient of this series' value
     constexpr int MM = (M > 0) ? M : MF_MAXM;
     T mk[D], Sk[D][D];
     load_vec<T, D>(pm + id * D, mk);
@@ -897,7 +899,7 @@ __global__ void __launch_bounds__(64) kf_grad_kernel(KfArgs<T> a, const T* __res
         }
         MF_UNROLL for (int o = 0; o < MM; ++o) {
             if (!((M > 0) || (o < m))) continue;
-            gy[id * m + o] = -Rr[o];
+            gy[id * m + o] = -wgt * Rr[o];
             // dH = R^-1 (r m^T - H S)
             MF_UNROLL for (int i = 0; i < D; ++i) {
                 T acc = Rr[o] * mk[i];
@@ -905,14 +907,14 @@ __global__ void __launch_bounds__(64) kf_grad_kernel(KfArgs<T> a, const T* __res
                     const bool on = (M > 0) || (p < m);
                     acc -= (on ? a.Rinv[o * ((M > 0) ? M : m) + p] : T(0)) * HS[p][i];
                 }
-                gH[(id * m + o) * D + i] = acc;
+                gH[(id * m + o) * D + i] = wgt * acc;
             }
             // Omega = r r^T + H S H^T
             MF_UNROLL for (int p = 0; p < MM; ++p) {
                 if (!((M > 0) || (p < m))) continue;
                 T acc = r[o] * r[p];
                 MF_UNROLL for (int i = 0; i < D; ++i) acc += HS[o][i] * h[p][i];
-                gOm[(id * m + o) * m + p] = acc;
+                gOm[(id * m + o) * m + p] = wgt * acc;
             }
         }
     }
@@ -925,6 +927,7 @@ __global__ void __launch_bounds__(64) kf_grad_kernel(KfArgs<T> a, const T* __res
         trimul_lower_vec<T, D>(Ci, dv, u);                         // C^-1 (m0 - mu0)
         T g[D];
         trimulT_lower_vec<T, D>(Ci, u, g);                         // P0^-1 (m0 - mu0)
+        MF_UNROLL for (int i = 0; i < D; ++i) g[i] *= wgt;
         store_vec<T, D>(gmu0 + s * D, g);
         MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Psi[i][j] = dv[i] * dv[j] + Sk[i][j];
         // N = C^-1 Psi C^-T - I ;  dC = tril(C^-T N)
@@ -937,6 +940,7 @@ __global__ void __launch_bounds__(64) kf_grad_kernel(KfArgs<T> a, const T* __res
                 N[i][j] = acc;
             }
         trimulT_lower<T, D, D>(Ci, N, G);
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) G[i][j] *= wgt;
         store_lower<T, D>(gC0 + s * D * D, G);
     }
     // ---- transition k -> k+1 ----------------------------------------------------------------------------------------------
@@ -968,9 +972,11 @@ __global__ void __launch_bounds__(64) kf_grad_kernel(KfArgs<T> a, const T* __res
         T t1[D][D], dA[D][D], u[D], db[D];
         trimul_lower<T, D, D>(Ci, EX, t1);
         trimulT_lower<T, D, D>(Ci, t1, dA);
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) dA[i][j] *= wgt;
         store_mat<T, D, D>(gA + tid * D * D, dA);
         trimul_lower_vec<T, D>(Ci, eb, u);
         trimulT_lower_vec<T, D>(Ci, u, db);
+        MF_UNROLL for (int i = 0; i < D; ++i) db[i] *= wgt;
         store_vec<T, D>(gb + tid * D, db);
         // Psi = eb eb^T + S_{k+1} - A X^T - X A^T + A S_k A^T
         T Psi[D][D];
@@ -989,6 +995,7 @@ __global__ void __launch_bounds__(64) kf_grad_kernel(KfArgs<T> a, const T* __res
                 N[i][j] = acc;
             }
         trimulT_lower<T, D, D>(Ci, N, G);
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) G[i][j] *= wgt;
         store_lower<T, D>(gC + tid * D * D, G);
     }
     if (bad && a.info) atomicMax(a.info, 1);

@@ -46,7 +46,7 @@ template <typename T> struct OpsTable {
                        int* info, hipStream_t st);
     int (*kf_grad)(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H,
                    const T* y, const T* Rinv, const T* pm, const T* pS, const T* pX, T* gmu0, T* gC0, T* gA, T* gb, T* gC,
-                   T* gH, T* gy, T* gOm, int* info, hipStream_t st);
+                   T* gH, T* gy, T* gOm, const T* weights, int* info, hipStream_t st);
 };
 
 constexpr int MF_MAX_D = 9;        // largest state dimension with a register-resident instantiation

@@ -59,18 +59,18 @@ class _LogLikelihoodPerSeries(torch.autograd.Function):
             g_om = torch.empty((bsz, n, m, m), dtype=h.dtype, device=h.device)
             info = _lib.pivot_info(h.device)
             c = lambda t: _lib.ptr(t.contiguous())  # noqa: E731
+            w = grad_out.reshape(bsz).contiguous()              # applied inside the kernel: no scaling passes over the outputs
             _lib.call("mf_kf_loglik_grad", h.dtype, bsz, n, d, m, c(mu0), c(cp0), c(a_s), c(b_s), c(cq), c(h), c(y), c(r_inv),
                       c(means), c(covs), c(cross), _lib.ptr(g_mu0), _lib.ptr(g_cp0), _lib.ptr(g_a), _lib.ptr(g_b),
-                      _lib.ptr(g_cq), _lib.ptr(g_h), _lib.ptr(g_y), _lib.ptr(g_om), _lib.ptr(info), _lib.stream_ptr(h.device))
-            w = grad_out.reshape(bsz)
-            bc = lambda g: g * w.reshape((bsz,) + (1,) * (g.dim() - 1))  # noqa: E731
+                      _lib.ptr(g_cq), _lib.ptr(g_h), _lib.ptr(g_y), _lib.ptr(g_om), _lib.ptr(w), _lib.ptr(info),
+                      _lib.stream_ptr(h.device))
             # shared observation covariance R = L L^T: d/dL of  -1/2 sum tr(R^-1 Omega)  =  tril(L^-T (L^-1 Omega_w L^-T));
             # the log-determinant part of R lives in the constants, which torch differentiates outside this function
-            om_w = torch.sum(g_om * w.reshape(bsz, 1, 1, 1), dim=(0, 1))
+            om_w = torch.sum(g_om, dim=(0, 1))
             eye = torch.eye(m, dtype=h.dtype, device=h.device)
             l_inv = torch.linalg.solve_triangular(chol_r, eye, upper=False)
             g_chol_r = torch.tril(l_inv.transpose(-1, -2) @ (l_inv @ om_w @ l_inv.transpose(-1, -2)))
-        return bc(g_mu0), bc(g_cp0), bc(g_a), bc(g_b), bc(g_cq), bc(g_h), bc(g_y), g_chol_r, None
+        return g_mu0, g_cp0, g_a, g_b, g_cq, g_h, g_y, g_chol_r, None
 
 
 class BaseKalmanFilter(abc.ABC):

@@ -97,3 +97,30 @@ def test_gpr_hyperparameter_gradients_vs_dense_gp(rng):
     # without gradients requested the fused kernel runs and agrees
     with torch.no_grad():
         assert float(gpr.log_likelihood()) == pytest.approx(float(total.detach()), rel=1e-9)
+
+
+def test_per_series_weights_reach_every_gradient(rng):
+    """A loss that weights the series differently: the incoming gradient is applied inside mf_kf_loglik_grad."""
+    d, m, t, bsz = 3, 1, 7, 3
+    kw = random_ssm(rng, (bsz,), t, d, m, well=True)
+    chol_r = np.array([[0.6]])
+    weights = np.array([0.3, -1.7, 2.5])
+    names = ["mu0", "chol_p0", "a_s", "b_s", "chol_q", "h", "y"]
+    cpu = {k: torch.tensor(kw[k], dtype=torch.float64, requires_grad=True) for k in names}
+    cpu_r = torch.tensor(chol_r, dtype=torch.float64, requires_grad=True)
+    total = sum(float(weights[s]) * dense_log_likelihood(*(cpu[k][s] for k in names), cpu_r) for s in range(bsz))
+    total.backward()
+    gpu = {k: torch.tensor(kw[k], dtype=torch.float64, device=DEV, requires_grad=True) for k in names}
+    gpu_r = torch.tensor(chol_r, dtype=torch.float64, device=DEV, requires_grad=True)
+    ssm = mfa.StateSpaceModel(gpu["mu0"], gpu["chol_p0"], gpu["a_s"], gpu["b_s"], gpu["chol_q"])
+    kf = mfa.KalmanFilter(ssm, mfa.EmissionModel(gpu["h"]), gpu["y"], gpu_r)
+    per = kf._differentiable_per_series() + kf._constant_terms(t)
+    loss = torch.sum(per * torch.tensor(weights, dtype=torch.float64, device=DEV))
+    assert float(loss.detach()) == pytest.approx(float(total.detach()), rel=1e-10)
+    loss.backward()
+    for k in names:
+        want = cpu[k].grad.numpy()
+        if k in ("chol_p0", "chol_q"):
+            want = np.tril(want)
+        np.testing.assert_allclose(gpu[k].grad.cpu().numpy(), want, rtol=1e-6, atol=1e-8, err_msg=k)
+    np.testing.assert_allclose(gpu_r.grad.cpu().numpy(), np.tril(cpu_r.grad.numpy()), rtol=1e-6, atol=1e-8)
