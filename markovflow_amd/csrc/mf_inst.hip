@@ -18,8 +18,16 @@ namespace mf {
 namespace {
 
 constexpr int D = MF_D;
-constexpr long RED_CHUNK = 8;    // chunk length of the intermediate reduction levels
-constexpr long RED_FINAL = 8;    // the last level is walked serially once at most this many blocks remain
+constexpr long RED_CHUNK = 8;    // chunk length of the level-0 floor of the parallel-in-time operators
+// reduction levels of the log-likelihood: chunk length, and the size at which the last level is walked serially
+inline long red_chunk() {
+    static const long v = [] { const char* e = std::getenv("MF_RED_CHUNK"); const long x = e ? std::atol(e) : 0; return x >= 2 ? x : 8L; }();
+    return v;
+}
+inline long red_final() {
+    static const long v = [] { const char* e = std::getenv("MF_RED_FINAL"); const long x = e ? std::atol(e) : 0; return x >= 1 ? x : 8L; }();
+    return v;
+}
 
 inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
@@ -63,8 +71,8 @@ inline long auto_chunks(long B, long n) {
 template <typename T> size_t levels_ws(long B, long P) {
     size_t total = red_bytes<T>(B, P);
     long n = P;
-    while (n > RED_FINAL) {
-        n = cdiv(n, RED_CHUNK);
+    while (n > red_final()) {
+        n = cdiv(n, red_chunk());
         total += red_bytes<T>(B, n);
     }
     return total;
@@ -86,8 +94,8 @@ template <typename T> long x_target_lanes() {
 // Reduce `cur` (already in workspace or user memory) down to a scalar per series.
 template <typename T>
 int reduce_levels(RedSys<T> cur, long B, char* p, T add_const, T* out, int* info, hipStream_t st) {
-    while (cur.n > RED_FINAL) {
-        const long P = cdiv(cur.n, RED_CHUNK);
+    while (cur.n > red_final()) {
+        const long P = cdiv(cur.n, red_chunk());
         RedSys<T> nxt = carve<T>(p, B, P);
         const long lanes = B * P;
         constexpr int x_lds = LdsSpike<T, D>::BYTES;
@@ -226,8 +234,8 @@ template <typename T> size_t btd_logdet_quad_ws(long B, long n, long chunks) {
     (void)chunks;
     long nn = n;
     size_t total = 256;
-    while (nn > RED_FINAL) {
-        nn = cdiv(nn, RED_CHUNK);
+    while (nn > red_final()) {
+        nn = cdiv(nn, red_chunk());
         total += red_bytes<T>(B, nn);
     }
     return total;
