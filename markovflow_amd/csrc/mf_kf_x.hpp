@@ -164,16 +164,15 @@ __global__ void __launch_bounds__(64) kf_chunk_x_kernel(KfArgs<T> a, RedSys<T> o
     T acc_yry = T(0), acc_ww = T(0);
 
     for (long k = k0; k < k1; ++k) {
-        T Ci[D][D], w[D];
+        T Ci[D][D], w[D], Bm[D][D];
         {
+            // this step's loads as one group (pointer selects instead of branches; block 0 has no transition: clamped, unused)
             T C[D][D], mvec[D];
-            if (k == 0) {
-                load_lower<T, D>(a.cholP0 + s * D * D, C);
-                load_vec<T, D>(a.mu0 + s * D, mvec);
-            } else {
-                load_lower<T, D>(Qs + (k - 1) * D * D, C);
-                load_vec<T, D>(bs + (k - 1) * D, mvec);
-            }
+            const long kt = k > 0 ? k - 1 : 0;
+            load_lower<T, D>(k == 0 ? a.cholP0 + s * D * D : Qs + kt * D * D, C);
+            load_vec<T, D>(k == 0 ? a.mu0 + s * D : bs + kt * D, mvec);
+            load_mat<T, D, D>(As + kt * D * D, Bm);
+            __builtin_amdgcn_sched_barrier(0);
             tri_inv_lower<T, D>(C, Ci, laC, E.bad);
             laC.renorm();
             trimul_lower_vec<T, D>(Ci, mvec, w);
@@ -186,8 +185,7 @@ __global__ void __launch_bounds__(64) kf_chunk_x_kernel(KfArgs<T> a, RedSys<T> o
             acc_yry += obs_apply_pairs<T, D>(Hs + k * m * D, ys + k * m, Ri, m, E.Phi, E.t);
             continue;
         }
-        T Bm[D][D], btw[D];
-        load_mat<T, D, D>(As + (k - 1) * D * D, Bm);
+        T btw[D];
         trimul_lower_inplace<T, D, D>(Ci, Bm);                 // B = C^-1 A
         gemv_t<T, D, D>(Bm, w, btw);                           // A^T Q^-1 m
         if (k == k0) {
