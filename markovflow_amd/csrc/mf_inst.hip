@@ -138,7 +138,13 @@ template <typename T> long lds_target_lanes(int m, int rinv_per_step) {
     if (rinv_per_step) w = waves(KfLdsCfg<T, D, 1, true>::LDS_TOTAL);
     else if (m == 2) w = waves(KfLdsCfg<T, D, 2, false>::LDS_TOTAL);
     else if (m == 3) w = waves(KfLdsCfg<T, D, 3, false>::LDS_TOTAL);
-    return 256L * 64 * w;
+    long lanes = 256L * 64 * w;
+    // Small blocks: every lane keeps a few partially used 128-B lines alive between two steps, and with one wave on every
+    // SIMD (65 536 lanes x 5 streams x 128 B = 42 MB) they no longer fit the 32 MB of L2 - each line is then fetched twice.
+    // Half the lanes, twice the steps per lane: measured at B=1024, T=10000 (scripts/prof_kf.py --chunks): fp64 d = 1, 2, 3:
+    // 0.50 -> 0.34, 0.55 -> 0.38, 1.00 -> 0.62 ms; fp32 d = 2, 3: 0.51 -> 0.34, 0.77 -> 0.52 ms; fp32 d = 4, 5 best at 3/4.
+    const long small = sizeof(T) == 8 ? (D <= 3 ? 32768L : 65536L) : (D <= 3 ? 32768L : (D <= 5 ? 49152L : 65536L));
+    return lanes < small ? lanes : small;
 }
 
 // chunks per series and transitions per chunk of the LDS kernel
