@@ -152,17 +152,20 @@ int mf_ssm_marginal_covariances_f32(int64_t B, int64_t T, int d, const float* ch
  * With eta != NULL ([B,T,d]) it additionally runs the rest of
  * BaseKalmanFilter.posterior_state_space_model (kalman_filter.py:159-174) in the same sweep:
  * m_post [B,T,d] = [mu0', b'_1...] and chol_dinv [B,T,d,d] = chol(Delta_k^-1) = [cholP0', cholQ'_1...].
+ * chain_layout = 1 (needs eta; state dimension <= 9, else -101) writes the posterior chain the way StateSpaceModel takes it,
+ * so that nothing has to be sliced, copied or negated afterwards: ut holds the posterior transitions A'_k = -(U_k^T), m_post
+ * is [B*d values of mu0' | B*(T-1)*d values of b'] and chol_dinv [B*d*d values of cholP0' | B*(T-1)*d*d values of cholQ'].
  * Few series: Delta_k are the natural-order pivots of the block-REVERSED matrix, so the parallel-in-time Cholesky
  * hierarchy is reused with reversed indexing, and the posterior offsets are an affine scan (scratch from the caller,
  * mf_btd_udl_workspace_bytes; 0 / NULL = one lane per series).
  */
 size_t mf_btd_udl_workspace_bytes(int64_t B, int64_t T, int d, int elem_size);
 int mf_btd_udl_f64(int64_t B, int64_t T, int d, const double* diag, const double* sub, double* ut, double* chol_d,
-                   const double* eta, double* m_post, double* chol_dinv, void* ws, size_t ws_bytes, int* info,
-                   void* stream);
+                   const double* eta, double* m_post, double* chol_dinv, int chain_layout, void* ws, size_t ws_bytes,
+                   int* info, void* stream);
 int mf_btd_udl_f32(int64_t B, int64_t T, int d, const float* diag, const float* sub, float* ut, float* chol_d,
-                   const float* eta, float* m_post, float* chol_dinv, void* ws, size_t ws_bytes, int* info,
-                   void* stream);
+                   const float* eta, float* m_post, float* chol_dinv, int chain_layout, void* ws, size_t ws_bytes,
+                   int* info, void* stream);
 
 /*
  * StateSpaceModel._build_precision (state_space_model.py:431-483), optionally + H^T R^-1 H

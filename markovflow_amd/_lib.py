@@ -26,7 +26,7 @@ _SIGS = {
     "mf_btd_logdet_quad": (_int, [_i64, _i64, _int, "Tp", "Tp", "Tp", "Tp", _vp, _sz, _vp, _vp]),
     "mf_btd_diag_of_inverse": (_int, [_i64, _i64, _int, "Tp", "Tp", "Tp", "Tp", _vp, _sz, _vp]),
     "mf_ssm_marginal_covariances": (_int, [_i64, _i64, _int, "Tp", "Tp", "Tp", "Tp", "Tp", _vp, _sz, _vp]),
-    "mf_btd_udl": (_int, [_i64, _i64, _int, "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", _vp, _sz, _vp, _vp]),
+    "mf_btd_udl": (_int, [_i64, _i64, _int, "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", _int, _vp, _sz, _vp, _vp]),
     "mf_ssm_precision": (_int, [_i64, _i64, _int, _int, "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", _int,
                                 "Tp", "Tp", "Tp", _vp]),
     "mf_ssm_marginal_means": (_int, [_i64, _i64, _i64, _int, "Tp", "Tp", "Tp", _vp, _sz, _vp]),

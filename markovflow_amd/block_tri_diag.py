@@ -268,7 +268,9 @@ class SymmetricBlockTriDiagonal(BlockTriDiagonal):
             self._diag.shape).contiguous()
         return LowerTriangularBlockTriDiagonal(identities, u_t), LowerTriangularBlockTriDiagonal(chol_d)
 
-    def _udl(self, eta: Optional[torch.Tensor]):
+    def _udl(self, eta: Optional[torch.Tensor], chain: bool = False):
+        """``chain=True`` (needs ``eta``): the outputs come in the layout of a posterior ``StateSpaceModel`` - returns
+        ``(transitions = -Uᵀ, chol_d, (mu0', offsets'), (cholP0', cholQ'))`` with every tensor contiguous."""
         diag, sub = _flat(self._diag, 3), _flat(self._sub_diag, 3)
         u_t, chol_d = torch.empty_like(sub), torch.empty_like(diag)
         m_post = chol_dinv = eta_f = None
@@ -281,9 +283,16 @@ class SymmetricBlockTriDiagonal(BlockTriDiagonal):
         ws = _lib.workspace(ws_bytes, diag.device)
         _lib.call("mf_btd_udl", diag.dtype, diag.shape[0], self.outer_dim, self.inner_dim, _lib.ptr(diag),
                   _lib.ptr(sub), _lib.ptr(u_t), _lib.ptr(chol_d), _lib.ptr(eta_f), _lib.ptr(m_post),
-                  _lib.ptr(chol_dinv), _lib.ptr(ws), ws_bytes, _lib.ptr(info), _lib.stream_ptr(diag.device))
+                  _lib.ptr(chol_dinv), int(chain), _lib.ptr(ws), ws_bytes, _lib.ptr(info), _lib.stream_ptr(diag.device))
         _lib.raise_on_info(info, "SymmetricBlockTriDiagonal.upper_diagonal_lower")
         u_t, chol_d = u_t.reshape(self._sub_diag.shape), chol_d.reshape(self._diag.shape)
+        if chain:
+            bsz, n, d = diag.shape[0], self.outer_dim, self.inner_dim
+            batch = tuple(self.batch_shape)
+            mf, cf = m_post.reshape(-1), chol_dinv.reshape(-1)
+            means = (mf[:bsz * d].reshape(batch + (d,)), mf[bsz * d:].reshape(batch + (n - 1, d)))
+            chols = (cf[:bsz * d * d].reshape(batch + (d, d)), cf[bsz * d * d:].reshape(batch + (n - 1, d, d)))
+            return u_t, chol_d, means, chols
         if eta is not None:
             m_post, chol_dinv = m_post.reshape(eta.shape), chol_dinv.reshape(self._diag.shape)
         return u_t, chol_d, m_post, chol_dinv

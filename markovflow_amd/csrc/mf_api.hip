@@ -228,14 +228,18 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         return t->ssm_marginal_covs(B, Tn, cholP0, A, cholQ, out_cov, out_sub, ws, ws_bytes, S(stream));               \
     }                                                                                                                  \
     int mf_btd_udl_##SUF(int64_t B, int64_t Tn, int d, const T* diag, const T* sub, T* ut, T* chol_d, const T* eta,    \
-                         T* m_post, T* chol_dinv, void* ws, size_t ws_bytes, int* info, void* stream) {                \
+                         T* m_post, T* chol_dinv, int chain_layout, void* ws, size_t ws_bytes, int* info,              \
+                         void* stream) {                                                                               \
         MF_HEAD(T, B, Tn, d)                                                                                           \
         if (!diag) return -4;                                                                                          \
         if (Tn > 1 && (!sub || !ut)) return -5;                                                                        \
         if (!chol_d) return -7;                                                                                        \
         if (eta && (!m_post || !chol_dinv)) return -9;                                                                 \
+        if (chain_layout && (!eta || Tn < 2)) return -11;                                                              \
+        if (big && chain_layout) return -101;                                                                          \
         if (big) return mf::big_udl_##SUF(B, Tn, d, diag, sub, ut, chol_d, eta, m_post, chol_dinv, info, S(stream));   \
-        return t->btd_udl(B, Tn, diag, sub, ut, chol_d, eta, m_post, chol_dinv, ws, ws_bytes, info, S(stream));        \
+        return t->btd_udl(B, Tn, diag, sub, ut, chol_d, eta, m_post, chol_dinv, chain_layout, ws, ws_bytes, info,      \
+                          S(stream));                                                                                  \
     }                                                                                                                  \
     int mf_ssm_precision_##SUF(int64_t B, int64_t Tn, int d, int m, const T* mu0, const T* cholP0, const T* A,         \
                                const T* b, const T* cholQ, const T* H, const T* y, const T* Rinv, int rinv_per_step,   \

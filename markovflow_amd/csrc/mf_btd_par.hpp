@@ -1031,10 +1031,10 @@ __global__ void __launch_bounds__(64) par_post_up0_kernel(long B, long n, long l
 
 // level 0: x_k, then m_k = Delta_k^-1 x_k and chol(Delta_k^-1) (kalman_filter.py:159-174)
 template <typename T, int D>
-__global__ void __launch_bounds__(64) par_post_emit_kernel(long B, long n, long len, long P, const T* __restrict__ ut,
+__global__ void __launch_bounds__(64) par_post_emit_kernel(long B, long n, long len, long P, T* __restrict__ ut,
                                                            const T* __restrict__ chol_d, const T* __restrict__ eta,
                                                            const T* __restrict__ up, T* __restrict__ m_post,
-                                                           T* __restrict__ chol_dinv, int* info) {
+                                                           T* __restrict__ chol_dinv, int chain, int* info) {
     const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= B * P) return;
     const long s = id / P, c = id % P;
@@ -1054,8 +1054,13 @@ __global__ void __launch_bounds__(64) par_post_emit_kernel(long B, long n, long 
             load_mat<T, D, D>(ut + (s * (n - 1) + k) * D * D, Ut);
             gemv_t<T, D, D>(Ut, xp, ux);
             MF_UNROLL for (int i = 0; i < D; ++i) x[i] -= ux[i];
+            if (chain) {        // this kernel is the last reader of U_k^T: leave the posterior transition -U_k^T in its place
+                MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Ut[i][j] = -Ut[i][j];
+                store_mat<T, D, D>(ut + (s * (n - 1) + k) * D * D, Ut);
+            }
         }
         MF_UNROLL for (int i = 0; i < D; ++i) xp[i] = x[i];
+        const long ci = chain ? (k == 0 ? s : B + s * (n - 1) + k - 1) : s * n + k;
         T Lp[D][D], Lpi[D], Linv[D][D], Q[D][D], Qi[D];
         load_lower<T, D>(chol_d + (s * n + k) * D * D, Lp);
         LogAcc<T> lb;
@@ -1064,11 +1069,11 @@ __global__ void __launch_bounds__(64) par_post_emit_kernel(long B, long n, long 
         MF_UNROLL for (int i = 0; i < D; ++i) Lpi[i] = Linv[i][i];
         trsv_lower<T, D>(Lp, Lpi, x);
         trsv_lower_t<T, D>(Lp, Lpi, x);                    // m_k = Delta_k^-1 x_k
-        store_vec<T, D>(m_post + (s * n + k) * D, x);
+        store_vec<T, D>(m_post + ci * D, x);
         trimulT_self_lower<T, D>(Linv, Q);
         lb.init();
         chol_lower<T, D>(Q, Qi, lb, bad);
-        store_lower<T, D>(chol_dinv + (s * n + k) * D * D, Q);
+        store_lower<T, D>(chol_dinv + ci * D * D, Q);
     }
     if (bad && info) atomicMax(info, 1);
 }

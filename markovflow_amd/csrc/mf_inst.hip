@@ -542,11 +542,11 @@ template <typename T> size_t btd_udl_ws(long B, long n) {
 
 template <typename T>
 int btd_udl(long B, long n, const T* diag, const T* sub, T* ut, T* chol_d, const T* eta, T* m_post, T* chol_dinv,
-            void* ws, size_t ws_bytes, int* info, hipStream_t st) {
+            int chain, void* ws, size_t ws_bytes, int* info, hipStream_t st) {
     const long len0 = sub ? par_len0(B, n) : 0;
     if (len0 == 0 || ws == nullptr || ws_bytes < btd_udl_ws<T>(B, n)) {
         hipLaunchKernelGGL((btd_udl_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, diag, sub, ut,
-                           chol_d, eta, m_post, chol_dinv, info);
+                           chol_d, eta, m_post, chol_dinv, chain, info);
         return hipGetLastError() == hipSuccess ? 0 : -1000;
     }
     // Delta_k = natural-order pivots of the REVERSED matrix: the Cholesky hierarchy with rev = 1 on level 0
@@ -609,8 +609,8 @@ int btd_udl(long B, long n, const T* diag, const T* sub, T* ut, T* chol_d, const
                                pl.len[l], P, static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c),
                                static_cast<const T*>(arr[l + 1].Z), arr[l].Z);
         }
-        hipLaunchKernelGGL((par_post_emit_kernel<T, D>), g0, dim3(64), 0, st, B, n, len0, pl.n[1], static_cast<const T*>(ut),
-                           static_cast<const T*>(chol_d), eta, static_cast<const T*>(arr[1].Z), m_post, chol_dinv, info);
+        hipLaunchKernelGGL((par_post_emit_kernel<T, D>), g0, dim3(64), 0, st, B, n, len0, pl.n[1], ut,
+                           static_cast<const T*>(chol_d), eta, static_cast<const T*>(arr[1].Z), m_post, chol_dinv, chain, info);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }

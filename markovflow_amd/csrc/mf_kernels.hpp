@@ -585,9 +585,11 @@ template <typename T, int D>
 __global__ void __launch_bounds__(64) btd_udl_kernel(long B, long n, const T* __restrict__ diag,
                                                      const T* __restrict__ sub, T* __restrict__ ut,
                                                      T* __restrict__ chol_d, const T* __restrict__ eta,
-                                                     T* __restrict__ m_post, T* __restrict__ chol_dinv, int* info) {
+                                                     T* __restrict__ m_post, T* __restrict__ chol_dinv, int chain, int* info) {
     const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= B) return;
+    // chain layout (see the header): block 0 of the posterior chain first for all series, then blocks 1.. as [B, n-1, ...]
+    auto chain_idx = [&](long k) { return chain ? (k == 0 ? s : B + s * (n - 1) + k - 1) : s * n + k; };
     T Lp[D][D], Lpi[D], xp[D];   // chol(Delta_{k+1}), its inverse diagonal, x_{k+1}
     bool bad = false;
     // the loads of a block are issued together, one block ahead of their use where two sets fit the registers
@@ -612,12 +614,13 @@ __global__ void __launch_bounds__(64) btd_udl_kernel(long B, long n, const T* __
             trsm_left_lower<T, D, D>(Lp, Lpi, U);          // L^-1 S
             syrk_tn_lower<T, D, D>(U, Dl, T(-1));          // Delta_k = D_k - S^T Delta_{k+1}^-1 S
             trsm_left_lower_t<T, D, D>(Lp, Lpi, U);        // U_k^T = Delta_{k+1}^-1 S
-            store_mat<T, D, D>(ut + (s * (n - 1) + k) * D * D, U);
             if (eta) {
                 T ux[D];
                 gemv_t<T, D, D>(U, xp, ux);                // U_k x_{k+1}
                 MF_UNROLL for (int i = 0; i < D; ++i) x[i] -= ux[i];
             }
+            if (chain) { MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) U[i][j] = -U[i][j]; }
+            store_mat<T, D, D>(ut + (s * (n - 1) + k) * D * D, U);
         }
         if (PF) cur = nxt;
         LogAcc<T> la;
@@ -629,7 +632,7 @@ __global__ void __launch_bounds__(64) btd_udl_kernel(long B, long n, const T* __
             MF_UNROLL for (int i = 0; i < D; ++i) xp[i] = x[i];
             trsv_lower<T, D>(Lp, Lpi, x);
             trsv_lower_t<T, D>(Lp, Lpi, x);                // m_k = Delta_k^-1 x_k
-            store_vec<T, D>(m_post + (s * n + k) * D, x);
+            store_vec<T, D>(m_post + chain_idx(k) * D, x);
             // chol(Delta_k^-1) = chol(L^-T L^-1)
             T Linv[D][D], Q[D][D], Qi[D];
             LogAcc<T> lb;
@@ -637,7 +640,7 @@ __global__ void __launch_bounds__(64) btd_udl_kernel(long B, long n, const T* __
             tri_inv_lower<T, D>(Lp, Linv, lb, bad);
             trimulT_self_lower<T, D>(Linv, Q);
             chol_lower<T, D>(Q, Qi, lb, bad);
-            store_lower<T, D>(chol_dinv + (s * n + k) * D * D, Q);
+            store_lower<T, D>(chol_dinv + chain_idx(k) * D * D, Q);
         }
     }
     if (bad && info) atomicMax(info, 1);

@@ -31,7 +31,7 @@ template <typename T> struct OpsTable {
                              size_t ws_bytes, hipStream_t st);
     size_t (*btd_udl_ws)(long B, long n);
     int (*btd_udl)(long B, long n, const T* diag, const T* sub, T* ut, T* chol_d, const T* eta, T* m_post,
-                   T* chol_dinv, void* ws, size_t ws_bytes, int* info, hipStream_t st);
+                   T* chol_dinv, int chain_layout, void* ws, size_t ws_bytes, int* info, hipStream_t st);
     int (*ssm_precision)(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b,
                          const T* cholQ, const T* H, const T* y, const T* Rinv, int rinv_per_step, T* diag, T* sub,
                          T* eta, hipStream_t st);

@@ -60,7 +60,7 @@ for B in (1, 2, 5):
         if bad: print("cholesky nosub", B, n, d, "OOB:", bad)
         u_t, cd, ef, mp, cdi = Guard((B, n - 1, d, d)), Guard((B, n, d, d)), Guard((B, n, d, d)), Guard((B, n, d, d)), Guard((B, n, d, d))
         wb = int(lib.mf_btd_udl_workspace_bytes(B, n, d, 8)); ws = ws_guard(wb)
-        _lib.call("mf_btd_udl", torch.float64, B, n, d, _lib.ptr(diag.view), _lib.ptr(sub.view), _lib.ptr(u_t.view), _lib.ptr(cd.view), None, None, None,
+        _lib.call("mf_btd_udl", torch.float64, B, n, d, _lib.ptr(diag.view), _lib.ptr(sub.view), _lib.ptr(u_t.view), _lib.ptr(cd.view), None, None, None, 0,
                   _lib.ptr(ws.view) if ws else None, wb, _lib.ptr(info), st)
         torch.cuda.synchronize()
         bad = [nm for nm, g in (("u_t", u_t), ("cd", cd), ("ws", ws)) if g is not None and not g.ok()]
