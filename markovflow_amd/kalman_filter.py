@@ -344,7 +344,11 @@ class KalmanFilterWithSites(BaseKalmanFilter):
 
     @property
     def _log_det_observation_precision(self):
-        return torch.sum(torch.linalg.slogdet(self._r_inv)[1], dim=-1)
+        """``Σ_k log|R_k⁻¹|`` (kalman_filter.py:490-492).  Univariate sites: an element-wise log instead of a batched LU."""
+        r_inv = self._r_inv
+        if r_inv.shape[-1] == 1:
+            return torch.sum(torch.log(torch.abs(r_inv[..., 0, 0])), dim=-1)
+        return torch.sum(torch.linalg.slogdet(r_inv)[1], dim=-1)
 
     def _total_terms(self):
         extra = 0.5 * self._log_det_observation_precision
@@ -385,7 +389,10 @@ class KalmanFilterWithSparseSites(BaseKalmanFilter):
 
     @property
     def _log_det_observation_precision(self):
-        return torch.sum(torch.linalg.slogdet(self._r_inv_data)[1], dim=-1)
+        r_inv = self._r_inv_data
+        if r_inv.shape[-1] == 1:                      # univariate sites: no batched LU
+            return torch.sum(torch.log(torch.abs(r_inv[..., 0, 0])), dim=-1)
+        return torch.sum(torch.linalg.slogdet(r_inv)[1], dim=-1)
 
     @property
     def observations(self):
