@@ -653,22 +653,65 @@ __global__ void __launch_bounds__(64) btd_udl_kernel(long B, long n, const T* __
 template <typename T, int D, int M>
 __global__ void __launch_bounds__(256) ssm_precision_kernel(KfArgs<T> a, T* __restrict__ diag, T* __restrict__ sub,
                                                             T* __restrict__ eta) {
-    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= a.B * a.Tn) return;
+    // Every transition k (A_k, cholQ_k, b_k) feeds TWO blocks: Q_k^-1 into block k+1 and A_k^T Q_k^-1 A_k into block k.  The
+    // lane of block k loads transition k once, keeps the second and hands the first (d(d+1)/2 + d values) to the lane of
+    // block k+1; only block 0 (prior) and the first lane of a wave load "their" Cholesky factor themselves.
+    const long total = a.B * a.Tn;
+    const long id_raw = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = id_raw < total;
+    const long id = valid ? id_raw : total - 1;       // lanes past the end redo the last block (the cross-lane moves need them)
     const long s = id / a.Tn, k = id % a.Tn;
-    const int m = a.m;
-    T C[D][D], Ci[D][D], Dn[D][D], rn[D], mvec[D], w[D];
+    const int m = a.m, lane = threadIdx.x & 63;
     LogAcc<T> la;
     la.init();
     bool bad = false;
-    load_lower<T, D>(k == 0 ? a.cholP0 + s * D * D : a.cholQ + (s * (a.Tn - 1) + k - 1) * D * D, C);
-    tri_inv_lower<T, D>(C, Ci, la, bad);
-    trimulT_self_lower<T, D>(Ci, Dn);
-    MF_UNROLL for (int i = 0; i < D; ++i) rn[i] = T(0);
-    if (eta) {
-        load_vec<T, D>(k == 0 ? a.mu0 + s * D : a.b + (s * (a.Tn - 1) + k - 1) * D, mvec);
-        trimul_lower_vec<T, D>(Ci, mvec, w);
-        trimulT_lower_vec<T, D>(Ci, w, rn);
+    T Dn[D][D], rn[D];                                  // block k: pivot (lower) and information vector
+    T nxtD[D][D], nxtr[D];                              // what transition k gives to block k+1: Q_k^-1, Q_k^-1 b_k
+    MF_UNROLL for (int i = 0; i < D; ++i) {
+        rn[i] = T(0); nxtr[i] = T(0);
+        MF_UNROLL for (int j = 0; j <= i; ++j) { Dn[i][j] = T(0); nxtD[i][j] = T(0); }
+    }
+    if (k + 1 < a.Tn) {
+        T C2[D][D], Ci2[D][D], Bm[D][D];
+        load_lower<T, D>(a.cholQ + (s * (a.Tn - 1) + k) * D * D, C2);
+        load_mat<T, D, D>(a.A + (s * (a.Tn - 1) + k) * D * D, Bm);
+        tri_inv_lower<T, D>(C2, Ci2, la, bad);
+        trimul_lower_inplace<T, D, D>(Ci2, Bm);                     // B = C^-1 A
+        syrk_tn_lower<T, D, D>(Bm, Dn, T(1));                       // A^T Q^-1 A
+        trimulT_self_lower<T, D>(Ci2, nxtD);                        // Q^-1
+        if (eta) {
+            T m2[D], w2[D], btw[D];
+            load_vec<T, D>(a.b + (s * (a.Tn - 1) + k) * D, m2);
+            trimul_lower_vec<T, D>(Ci2, m2, w2);
+            gemv_t<T, D, D>(Bm, w2, btw);
+            MF_UNROLL for (int i = 0; i < D; ++i) rn[i] = -btw[i];
+            trimulT_lower_vec<T, D>(Ci2, w2, nxtr);
+        }
+        neg_trimulT_lower_inplace<T, D, D>(Ci2, Bm);                // -C^-T B = -Q^-1 A
+        if (valid) store_mat<T, D, D>(sub + (s * (a.Tn - 1) + k) * D * D, Bm);
+    }
+    // own part of block k: from the lane on the left (transition k-1), or computed here
+    T ownD[D][D], ownr[D];
+    MF_UNROLL for (int i = 0; i < D; ++i) {
+        ownr[i] = __shfl_up(nxtr[i], 1, 64);
+        MF_UNROLL for (int j = 0; j <= i; ++j) ownD[i][j] = __shfl_up(nxtD[i][j], 1, 64);
+    }
+    if (k == 0 || lane == 0) {
+        T C[D][D], Ci[D][D];
+        load_lower<T, D>(k == 0 ? a.cholP0 + s * D * D : a.cholQ + (s * (a.Tn - 1) + k - 1) * D * D, C);
+        tri_inv_lower<T, D>(C, Ci, la, bad);
+        trimulT_self_lower<T, D>(Ci, ownD);
+        MF_UNROLL for (int i = 0; i < D; ++i) ownr[i] = T(0);
+        if (eta) {
+            T mvec[D], w[D];
+            load_vec<T, D>(k == 0 ? a.mu0 + s * D : a.b + (s * (a.Tn - 1) + k - 1) * D, mvec);
+            trimul_lower_vec<T, D>(Ci, mvec, w);
+            trimulT_lower_vec<T, D>(Ci, w, ownr);
+        }
+    }
+    MF_UNROLL for (int i = 0; i < D; ++i) {
+        rn[i] += ownr[i];
+        MF_UNROLL for (int j = 0; j <= i; ++j) Dn[i][j] += ownD[i][j];
     }
     if (a.H) {
         const T* Ri = a.rinv_per_step ? a.Rinv + (s * a.Tn + k) * m * m : a.Rinv;
@@ -681,26 +724,10 @@ __global__ void __launch_bounds__(256) ssm_precision_kernel(KfArgs<T> a, T* __re
             Obs<T, D, M>::apply(a.H + (s * a.Tn + k) * m * D, zero, Ri, m, Dn, dummy);
         }
     }
-    if (k + 1 < a.Tn) {
-        T C2[D][D], Ci2[D][D], Am[D][D], Bm[D][D], W[D][D];
-        load_lower<T, D>(a.cholQ + (s * (a.Tn - 1) + k) * D * D, C2);
-        tri_inv_lower<T, D>(C2, Ci2, la, bad);
-        load_mat<T, D, D>(a.A + (s * (a.Tn - 1) + k) * D * D, Am);
-        trimul_lower<T, D, D>(Ci2, Am, Bm);
-        syrk_tn_lower<T, D, D>(Bm, Dn, T(1));
-        trimulT_lower<T, D, D>(Ci2, Bm, W);
-        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) W[i][j] = -W[i][j];
-        store_mat<T, D, D>(sub + (s * (a.Tn - 1) + k) * D * D, W);
-        if (eta) {
-            T m2[D], w2[D], btw[D];
-            load_vec<T, D>(a.b + (s * (a.Tn - 1) + k) * D, m2);
-            trimul_lower_vec<T, D>(Ci2, m2, w2);
-            gemv_t<T, D, D>(Bm, w2, btw);
-            MF_UNROLL for (int i = 0; i < D; ++i) rn[i] -= btw[i];
-        }
+    if (valid) {
+        store_sym<T, D>(diag + id * D * D, Dn);
+        if (eta) store_vec<T, D>(eta + id * D, rn);
     }
-    store_sym<T, D>(diag + id * D * D, Dn);
-    if (eta) store_vec<T, D>(eta + id * D, rn);
 }
 
 // Block-wise product out[s, k] = X[s, k] Y[s, k] of two [B, n, d, d] block arrays whose series may be strided
