@@ -1,0 +1,22 @@
+"""Repeat the headline evaluation and a few operators many times and require bit-identical results (LDS-DMA hazards, races)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from markovflow_amd import synthetic
+dev = torch.device("cuda", 0)
+for (b, t, comp, m, dt) in [(1024, 10000, (5, 5), 1, torch.float64), (256, 4096, (3, 3), 1, torch.float64), (512, 1000, (5, 5, 5), 3, torch.float64),
+                            (1024, 3000, (5, 5), 1, torch.float32), (37, 777, (3,), 1, torch.float64)]:
+    kf = synthetic.kalman_filter_from(synthetic.make_ssm(b, t, comp, output_dim=m, dtype=dt, device=dev))
+    ref = kf._log_likelihood_per_series().clone()
+    bad = 0
+    for _ in range(200):
+        bad += int(not torch.equal(torch.nan_to_num(kf._log_likelihood_per_series(), nan=0.0), torch.nan_to_num(ref, nan=0.0)))
+    post = kf.posterior_state_space_model()
+    c0, s0 = post.covariance_blocks()
+    m0 = post.marginal_means
+    bad2 = 0
+    for _ in range(20):
+        p2 = kf.posterior_state_space_model()
+        c1, s1 = p2.covariance_blocks()
+        z = lambda x: torch.nan_to_num(x, nan=0.0)   # noqa: E731
+        bad2 += int(not (torch.equal(z(c0), z(c1)) and torch.equal(z(s0), z(s1)) and torch.equal(z(m0), z(p2.marginal_means))))
+    print(f"B={b} T={t} d={sum((c + 1) // 2 for c in comp)} m={m} {dt}: log-lik mismatching repeats {bad}/200, smoother {bad2}/20, non-finite series {int((~torch.isfinite(ref)).sum())}")
