@@ -1,0 +1,65 @@
+"""Randomised differential campaign GPU (through the Python mirror / C ABI) vs the numpy oracle: random shapes across the
+serial / parallel-in-time thresholds, ragged chunk tails, every state dimension 1..9, m 1..3, explicit chunk counts."""
+import os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import markovflow_amd as mfa
+from oracle import numpy_oracle as O
+from test_gpu_kalman import random_ssm, loglik_with_chunks, build_kf
+
+tt = lambda x: torch.tensor(np.ascontiguousarray(x), dtype=torch.float64, device="cuda:0")   # noqa: E731
+nn = lambda x: x.detach().cpu().numpy()                                                          # noqa: E731
+
+
+def run(n_cases: int, seed: int) -> dict:
+  rng = np.random.default_rng(seed)
+  worst = dict(ll=0.0, post=0.0, chol=0.0, solve=0.0, covs=0.0, kl=0.0)
+  for case in range(n_cases):
+      d = int(rng.integers(1, 10)); m = int(rng.integers(1, 4)); bsz = int(rng.integers(1, 5))
+      t = int(rng.choice([2, 3, 5, 8, 9, 17, 63, 64, 65, 71, 127, 128, 130, 200, 257, 400]))
+      kw = random_ssm(rng, (bsz,), t, d, m, well=True)
+      r = rng.normal(size=(m, m)); cov = r @ r.T + np.eye(m); r_inv = np.linalg.inv(cov)
+      ref = np.array([O.kf_log_likelihood(**{k: v[s] for k, v in kw.items()}, r_inv=r_inv) for s in range(bsz)])
+      cst = -0.5 * np.log(2 * np.pi) * m * t + 0.5 * t * np.linalg.slogdet(r_inv)[1]
+      for chunks in (0, int(rng.integers(1, max(2, t)))):
+          got = loglik_with_chunks(kw, r_inv, chunks) + cst
+          worst["ll"] = max(worst["ll"], float(np.max(np.abs(got - ref) / np.abs(ref))))
+      kf = build_kf(kw, np.linalg.cholesky(cov))
+      post = kf.posterior_state_space_model()
+      means, covs = post.marginals
+      for s in range(bsz):
+          o = O.kf_posterior_ssm(**{k: v[s] for k, v in kw.items()}, r_inv=r_inv)
+          om = O.ssm_marginal_means(o[0], o[2], o[3]); oc = O.ssm_marginal_covariances(o[1], o[2], o[4])
+          worst["post"] = max(worst["post"], float(np.max(np.abs(nn(means)[s] - om)) / (1 + np.max(np.abs(om)))),
+                              float(np.max(np.abs(nn(covs)[s] - oc)) / (1 + np.max(np.abs(oc)))))
+      prior = kf.prior_ssm
+      pc, ps = prior.covariance_blocks()
+      oc = O.ssm_marginal_covariances(kw["chol_p0"][0], kw["a_s"][0], kw["chol_q"][0])
+      worst["covs"] = max(worst["covs"], float(np.max(np.abs(nn(pc)[0] - oc)) / (1 + np.max(np.abs(oc)))),
+                          float(np.max(np.abs(nn(ps)[0] - O.ssm_subsequent_covariances(kw["a_s"][0], oc))) / (1 + np.max(np.abs(oc)))))
+      prec = kf._k_inv_post
+      ch = prec.cholesky
+      dense = nn(prec.to_dense())
+      lref = np.linalg.cholesky(dense)
+      worst["chol"] = max(worst["chol"], float(np.max(np.abs(nn(ch.to_dense()) - lref)) / (1 + np.max(np.abs(lref)))))
+      rhs = rng.normal(size=(bsz, t, d))
+      for tr in (False, True):
+          sol = nn(ch.solve(tt(rhs), transpose_left=tr)).reshape(bsz, -1)
+          want = np.stack([np.linalg.solve(lref[s].T if tr else lref[s], rhs[s].reshape(-1)) for s in range(bsz)])
+          worst["solve"] = max(worst["solve"], float(np.max(np.abs(sol - want)) / (1 + np.max(np.abs(want)))))
+      kl = nn(post.kl_divergence(prior))
+      s = 0
+      o = O.kf_posterior_ssm(**{k: v[s] for k, v in kw.items()}, r_inv=r_inv)
+      klref = O.ssm_kl_divergence(o, (kw["mu0"][s], kw["chol_p0"][s], kw["a_s"][s], kw["b_s"][s], kw["chol_q"][s]))
+      worst["kl"] = max(worst["kl"], float(abs(kl[s] - klref) / (1 + abs(klref))))
+  return worst
+
+
+if __name__ == "__main__":
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    t0 = time.time()
+    worst = run(n_cases, int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+    print(f"{n_cases} random cases in {time.time() - t0:.0f} s; worst relative deviations vs the oracle:", {k: f"{v:.2e}" for k, v in worst.items()})
+    assert all(v < 1e-7 for v in worst.values()), worst
+    print("fuzz ok")
