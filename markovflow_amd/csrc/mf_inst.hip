@@ -112,7 +112,7 @@ int reduce_levels(RedSys<T> cur, long B, char* p, T add_const, T* out, int* info
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
-// The LDS-DMA streaming kernel (mf_kf_lds.hpp) covers: up to 3 outputs with a shared observation precision,
+// The LDS-DMA streaming kernel (mf_kf_lds.hpp) covers: up to 4 outputs with a shared observation precision,
 // or one output with per-step precisions (sites); matrix rows that are a whole number of 16-B units; 16-B aligned
 // tensors; at least one transition.  Everything else takes kf_chunk_kernel (direct loads).
 template <typename T, int M, bool RSTEP> constexpr bool lds_supported() { return KfLdsCfg<T, D, M, RSTEP>::SUPPORTED; }
@@ -128,6 +128,7 @@ template <typename T> bool use_lds_kernel(long Tn, int m, const void* A, const v
         case 1: return lds_supported<T, 1, false>();
         case 2: return lds_supported<T, 2, false>();
         case 3: return lds_supported<T, 3, false>();
+        case 4: return lds_supported<T, 4, false>() && (sizeof(T) == 4 || D <= 5);   // fp64 d >= 6: spills, no faster than direct loads
         default: return false;
     }
 }
@@ -138,6 +139,7 @@ template <typename T> long lds_target_lanes(int m, int rinv_per_step) {
     if (rinv_per_step) w = waves(KfLdsCfg<T, D, 1, true>::LDS_TOTAL);
     else if (m == 2) w = waves(KfLdsCfg<T, D, 2, false>::LDS_TOTAL);
     else if (m == 3) w = waves(KfLdsCfg<T, D, 3, false>::LDS_TOTAL);
+    else if (m == 4) w = waves(KfLdsCfg<T, D, 4, false>::LDS_TOTAL);
     long lanes = 256L * 64 * w;
     // Small blocks: every lane keeps a few partially used 128-B lines alive between two steps, and with one wave on every
     // SIMD (65 536 lanes x 5 streams x 128 B = 42 MB) they no longer fit the 32 MB of L2 - each line is then fetched twice.
@@ -175,7 +177,9 @@ int kf_loglik(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A,
               size_t ws_bytes, int* info, long chunks, hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
     if (m < 1 || m > MF_MAXM) return -4;
     if (ws_bytes < kf_loglik_ws<T>(B, Tn, chunks) || ws == nullptr) return -15;
-    if (x_path<T>() && Tn >= 2) {
+    // (fp64 d = 6 with four outputs: the streaming kernel spills and the plain direct-load kernel runs at 17 % - the spike-in-LDS
+    // kernel with its grouped loads is the better home)
+    if ((x_path<T>() || (sizeof(T) == 8 && D == 6 && m == 4)) && Tn >= 2) {
         long P = chunks > 0 ? (chunks > Tn ? Tn : chunks) : cdiv(x_target_lanes<T>(), B);
         if (chunks <= 0) {
             const long maxP = Tn / 4 > 0 ? Tn / 4 : 1;
@@ -214,7 +218,8 @@ int kf_loglik(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A,
         if (rinv_per_step) launch(integral_constant<int, 1>{}, integral_constant<bool, true>{});
         else if (m == 1) launch(integral_constant<int, 1>{}, integral_constant<bool, false>{});
         else if (m == 2) launch(integral_constant<int, 2>{}, integral_constant<bool, false>{});
-        else launch(integral_constant<int, 3>{}, integral_constant<bool, false>{});
+        else if (m == 3) launch(integral_constant<int, 3>{}, integral_constant<bool, false>{});
+        else launch(integral_constant<int, 4>{}, integral_constant<bool, false>{});
         if (ev1) (void)hipEventRecord(ev1, st);
         return reduce_levels<T>(lvl0, B, p, add_const, out, info, st);
     }

@@ -296,7 +296,8 @@ def test_full_size_partition_invariance_and_linearity():
 
 # ---- the LDS-DMA streaming kernel beyond m = 1 / shared R (even d: rows are whole 16-B units) -----------------------------------
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
-@pytest.mark.parametrize("d,m,t", [(2, 2, 33), (4, 2, 50), (6, 3, 64), (8, 2, 20), (6, 2, 300), (4, 3, 129)])
+@pytest.mark.parametrize("d,m,t", [(2, 2, 33), (4, 2, 50), (6, 3, 64), (8, 2, 20), (6, 2, 300), (4, 3, 129), (6, 4, 64), (5, 4, 100),
+                                   (3, 4, 40), (8, 4, 70)])
 def test_streaming_kernel_multi_output(rng, dtype, d, m, t):
     kw = random_ssm(rng, (5,), t, d, m, well=True)
     if dtype == torch.float32:
