@@ -29,8 +29,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-leve
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024, help="series per GPU")
     ap.add_argument("--time-points", type=int, default=10000)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
@@ -57,20 +57,50 @@ class HipEvents:
         return float(ms.value)
 
 
+def _cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _native_oracle():
+    """Compile oracle/c/mf_oracle.c for THIS host (-march=native) into a scratch directory; None if that fails (the
+    -march=x86-64-v3 library shipped with the repo is used then).  Building the checker is not using it."""
+    import subprocess
+    import tempfile
+
+    src = os.path.join(ROOT, "oracle", "c", "mf_oracle.c")
+    out = os.path.join(tempfile.mkdtemp(prefix="mf_oracle_"), "libmf_oracle_native.so")
+    cmd = ["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-std=gnu11", "-shared", "-o", out, src, "-lm"]
+    try:
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+        return out
+    except Exception:
+        return None
+
+
 def cpu_baseline(inputs, seconds: float):
-    """Time the C restatement of the reference algorithm on a bounded sample of the same workload."""
+    """Time the C restatement of the reference algorithm (oracle/c/mf_oracle.c, dimensions d=6 / m=1 fixed at compile time,
+    built for this host) on the same workload: the WHOLE batch on all host threads, and a bounded sample on one thread."""
     import numpy as np
 
     from oracle import c_oracle as C
 
+    native = _native_oracle()
+    if native is not None:
+        C.use_library(native)
     cores = C.num_threads()
-    t = inputs["H"].shape[1]
-    take = min(inputs["H"].shape[0], 4 * cores)
+    bsz, t = inputs["H"].shape[0], inputs["H"].shape[1]
 
-    def host(k, n):
-        return inputs[k][:n].detach().cpu().numpy().astype(np.float64)
+    def host(k):
+        return inputs[k].detach().cpu().numpy().astype(np.float64, copy=False)
 
-    arrs = {k: host(k, take) for k in ("mu0", "cholP0", "A", "b", "cholQ", "H", "y")}
+    arrs = {k: host(k) for k in ("mu0", "cholP0", "A", "b", "cholQ", "H", "y")}
     r_inv = np.linalg.inv((inputs["cholR"] @ inputs["cholR"].T).cpu().numpy().astype(np.float64))
 
     def run(n):
@@ -79,20 +109,28 @@ def cpu_baseline(inputs, seconds: float):
                           arrs["H"][:n], arrs["y"][:n], r_inv)
         return time.perf_counter() - t0, out
 
-    dt, out = run(take)                       # warm-up + calibration
-    reps = max(1, int(seconds / max(dt, 1e-3)))
-    best = dt
-    total = 0.0
-    for _ in range(reps):
-        dt, out = run(take)
-        best = min(best, dt)
-        total += dt
-        if total > 2.5 * seconds:
-            break
+    def best_of(n, budget):
+        dt, out = run(n)                      # warm-up + calibration
+        best, total, reps = dt, 0.0, 0
+        while total < budget and reps < 50:
+            dt, out = run(n)
+            best, total, reps = min(best, dt), total + dt, reps + 1
+        return best, reps, out
+
+    C.set_num_threads(cores)
+    best_all, reps_all, out = best_of(bsz, 0.6 * seconds)
+    C.set_num_threads(1)
+    n1 = max(1, min(bsz, 32))
+    best_1, reps_1, _ = best_of(n1, 0.4 * seconds)
+    C.set_num_threads(cores)
     return {
-        "value": take * t / best, "unit": "steps/s", "cores": cores, "kind": "port",
-        "sample": f"{take} series x {t} time points (d={arrs['A'].shape[-1]}, fp64), best of {reps} passes; "
-                  "C restatement of the reference algorithm (oracle/c/mf_oracle.c), OpenMP over series",
+        "value": bsz * t / best_all, "unit": "steps/s", "cores": cores, "kind": "port",
+        "value_1_thread": n1 * t / best_1, "cpu_model": _cpu_model(),
+        "build": "gcc -O3 -march=native -fopenmp" if native else "gcc -O3 -march=x86-64-v3 -fopenmp (shipped build)",
+        "sample": f"all threads: the whole batch, {bsz} series x {t} time points (d={arrs['A'].shape[-1]}, m=1, fp64), best of "
+                  f"{reps_all} passes; 1 thread: {n1} series x {t}, best of {reps_1}; C restatement of the reference algorithm "
+                  "(oracle/c/mf_oracle.c: precision assembly, banded Cholesky, solve - state and output dimensions fixed "
+                  "at compile time for d=6, m=1), OpenMP over series",
     }, out
 
 
@@ -213,25 +251,57 @@ def other_configs(dev):
     return out
 
 
+def launch_ranks(args) -> int:
+    """`bench.py --gpus N` without a launcher: THIS process stays GPU-free (nothing here initialises HIP) and starts N fresh
+    rank processes through torch.distributed.run, one per GPU, RCCL rendezvous on 127.0.0.1; rank 0's JSON line goes
+    straight to our stdout and we exit with the children's return code (never exec over a process that touched the GPU)."""
+    import socket
+    import subprocess
+
+    import torch
+
+    have = torch.cuda.device_count()          # counts devices without creating a HIP context on this image
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: needed by RCCL on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # under torch.distributed.run
+    if args.gpus > 1 and not launched:
+        sys.exit(launch_ranks(args))
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # under torch.distributed.run
-    if world > 1 or launched:
+    if launched and world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} does not match the launcher's WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+    if launched:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # RCCL on ROCm
+        world = dist.get_world_size()
     else:
         dist = None
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if dist is not None else 0)
 
+    from markovflow_amd import _lib
     from markovflow_amd import distributed as mfd
     from markovflow_amd import synthetic
 
@@ -272,6 +342,11 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        ones = torch.ones(1, dtype=torch.float64, device=dev)      # proof that RCCL saw every rank
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_seen = int(ones.item())
+    else:
+        ranks_seen = 1
 
     esz = 8 if dtype == torch.float64 else 4
     bytes_per_step = synthetic.loglik_bytes_per_step(d, m, esz)
@@ -285,7 +360,8 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fh:
             entry = json.load(fh).get(f"kf_loglik B={bsz} T={tn} d={d} m={m} {args.dtype}")
-        if entry and args.chunks == 0:
+        # only when the counters were collected on THIS build of the library (mf_version): a stale figure is worse than none
+        if entry and args.chunks == 0 and entry.get("library_version") == int(_lib.load().mf_version()):
             traffic, traffic_src = entry["traffic_bytes"], entry["source"]
     except OSError:
         pass
@@ -295,6 +371,7 @@ def main():
         "value": value,
         "unit": "steps/s",
         "n_gpus": world,
+        "ranks_seen": ranks_seen,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,

@@ -95,6 +95,12 @@ def suffix(dtype: torch.dtype) -> str:
     raise TypeError(f"markovflow_amd supports float32 and float64 tensors, got {dtype}")
 
 
+class DevPtr(ctypes.c_void_p):
+    """A device pointer that remembers the tensor it came from, so that ``call`` can check scalar type and device."""
+    dtype = None
+    device = None
+
+
 def ptr(t: Optional[torch.Tensor]):
     """Device pointer of a contiguous HIP tensor (None -> NULL)."""
     if t is None:
@@ -104,9 +110,20 @@ def ptr(t: Optional[torch.Tensor]):
             "markovflow_amd kernels run on an MI355X only: got a CPU tensor and there is no CPU fallback. "
             "Move the inputs to device 'cuda'."
         )
+    if t.requires_grad and torch.is_grad_enabled():
+        # the kernels behind the C ABI have no autograd graph: a result computed from this tensor would silently drop its
+        # gradient.  Differentiable entry points (KalmanFilter*.log_likelihood, StateSpaceModel.kl_divergence) run their
+        # kernels inside torch.autograd.Function, i.e. under no_grad, and never get here with grad mode on.
+        raise NotImplementedError(
+            "this markovflow_amd operation is not differentiable: an input requires a gradient. Differentiable are "
+            "KalmanFilter / KalmanFilterWithSites / KalmanFilterWithSparseSites .log_likelihood() and "
+            "StateSpaceModel.kl_divergence(); detach() the inputs or wrap the call in torch.no_grad() for anything else."
+        )
     if not t.is_contiguous():
         raise RuntimeError("internal error: non-contiguous tensor passed to the C ABI")
-    return ctypes.c_void_p(t.data_ptr())
+    p = DevPtr(t.data_ptr())
+    p.dtype, p.device = t.dtype, t.device
+    return p
 
 
 def stream_ptr(device) -> ctypes.c_void_p:
@@ -131,9 +148,29 @@ def check(rc: int, what: str):
     raise ValueError(f"{what}: invalid argument #{-rc} (see include/markovflow_amd.h)")
 
 
-def call(base: str, dtype: torch.dtype, *args):
+def call_rc(base: str, dtype: torch.dtype, *args) -> int:
+    """Dispatch ``base_f32`` / ``base_f64`` and return the ABI's return code.  Every floating-point tensor argument must have
+    the dispatch dtype and all tensors must live on one device (a float32 buffer read as doubles would run past its end); the
+    launch happens with that device current."""
     fn = getattr(load(), base + suffix(dtype))
-    check(fn(*args), base)
+    device = None
+    for a in args:
+        if isinstance(a, DevPtr):
+            if a.dtype.is_floating_point and a.dtype != dtype:
+                raise TypeError(f"{base}: got a {a.dtype} tensor in a {dtype} call; all tensors of one model must share a dtype")
+            if device is None:
+                device = a.device
+            elif a.device != device:
+                raise ValueError(f"{base}: tensors on different devices ({device} and {a.device})")
+    raise_pending()
+    if device is None:
+        return fn(*args)
+    with torch.cuda.device(device):
+        return fn(*args)
+
+
+def call(base: str, dtype: torch.dtype, *args):
+    check(call_rc(base, dtype, *args), base)
 
 
 def workspace(nbytes: int, device) -> Optional[torch.Tensor]:
@@ -150,20 +187,87 @@ def chol_solve(chol: torch.Tensor, rhs: torch.Tensor) -> torch.Tensor:
 
 
 def new_info(device) -> torch.Tensor:
+    """A zeroed device int for callers that drive the C ABI themselves (the `info` argument accepts any device-visible int)."""
     return torch.zeros(1, dtype=torch.int32, device=device)
 
 
-# Debug switch: when set, every factorisation synchronises and raises on a non-positive pivot, the way
-# TensorFlow's Cholesky op raises in the reference.  Off by default (no host sync on the hot path).
+def same_dtype_device(ref: torch.Tensor, what: str, **tensors):
+    """ValueError unless every given tensor shares ``ref``'s dtype and device (the reference raises a TF dtype error)."""
+    for name, t in tensors.items():
+        if t is None:
+            continue
+        if t.dtype != ref.dtype or t.device != ref.device:
+            raise ValueError(f"{what}: {name} is {t.dtype} on {t.device}, the state space model is {ref.dtype} on {ref.device}")
+
+
+# ---- non-positive pivots -------------------------------------------------------------------------------------------------
+# TensorFlow's Cholesky op raises on a matrix that is not positive definite (block_tri_diag.py:423-436).  Here every
+# factorising kernel gets a flag that lives in PINNED HOST memory (the GPU writes it across the bus, and only when a pivot
+# fails - the success path costs nothing: no fill kernel, no copy, no sync).  Results are NaN from the failing block on.
+#   * default: the flag is looked at (a host read) at the start of every later library call and by ``check_errors()``;
+#     a failure raises MarkovflowAmdError there, naming the operations issued since the last clean look;
+#   * MF_CHECK_PIVOTS=1 (or ``set_synchronous_checks(True)``): every factorising call synchronises its stream and raises
+#     at once, exactly where TensorFlow would.
 CHECK_PIVOTS = os.environ.get("MF_CHECK_PIVOTS", "0") == "1"
+_flags = {}      # device index -> (pinned int32 tensor, its address for the C ABI, the same int as a ctypes view)
+_issued = []     # names of factorising calls since the last clean look
 
 
-def pivot_info(device) -> Optional[torch.Tensor]:
-    """The `info` flag the product path hands to the C ABI: a zeroed device int when pivots are checked, else NULL (the flag
-    is optional in every entry point; without it a non-positive pivot shows up as NaN, and no fill kernel is launched)."""
-    return new_info(device) if CHECK_PIVOTS else None
+def set_synchronous_checks(on: bool):
+    global CHECK_PIVOTS
+    CHECK_PIVOTS = bool(on)
 
 
-def raise_on_info(info: Optional[torch.Tensor], what: str):
-    if CHECK_PIVOTS and info is not None and int(info.item()) != 0:
-        raise MarkovflowAmdError(f"{what}: matrix is not positive definite")
+def pivot_info(device):
+    """The `info` argument of a factorising entry point: pointer to this device's pinned host flag."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("markovflow_amd kernels run on an MI355X only: got a CPU tensor and there is no CPU fallback. "
+                           "Move the inputs to device 'cuda'.")
+    idx = device.index
+    idx = torch.cuda.current_device() if idx is None else idx
+    if idx not in _flags:
+        flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+        _flags[idx] = (flag, ctypes.c_void_p(flag.data_ptr()), ctypes.c_int.from_address(flag.data_ptr()))
+    return _flags[idx][1]
+
+
+def _take_failures():
+    bad = False
+    for _, _, view in _flags.values():
+        if view.value != 0:
+            view.value = 0
+            bad = True
+    if not bad:
+        _issued.clear()
+        return None
+    ops = ", ".join(dict.fromkeys(_issued)) or "a factorisation"
+    _issued.clear()
+    return ops
+
+
+def raise_pending():
+    """Raise if a kernel that has FINISHED since the last look met a non-positive pivot (no synchronisation)."""
+    if _flags and _issued:
+        ops = _take_failures()
+        if ops is not None:
+            raise MarkovflowAmdError(f"matrix is not positive definite (non-positive pivot) in one of: {ops}")
+
+
+def check_errors():
+    """Synchronise every device this library has used and raise if any factorisation met a non-positive pivot."""
+    for idx in _flags:
+        torch.cuda.synchronize(idx)
+    raise_pending()
+
+
+def raise_on_info(info, what: str, device=None):
+    """Called after a factorising launch.  Synchronous mode: wait and raise now; default: remember the name."""
+    _issued.append(what)
+    if len(_issued) > 64:
+        del _issued[:-64]
+    if CHECK_PIVOTS:
+        torch.cuda.current_stream(device).synchronize()
+        ops = _take_failures()
+        if ops is not None:
+            raise MarkovflowAmdError(f"{what}: matrix is not positive definite")

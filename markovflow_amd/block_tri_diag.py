@@ -253,9 +253,9 @@ class SymmetricBlockTriDiagonal(BlockTriDiagonal):
                                                                     diag.element_size()))
         ws = _lib.workspace(ws_bytes, diag.device)
         _lib.call("mf_btd_cholesky", diag.dtype, diag.shape[0], self.outer_dim, self.inner_dim, _lib.ptr(diag),
-                  _lib.ptr(sub), _lib.ptr(ldiag), _lib.ptr(lsub), _lib.ptr(ws), ws_bytes, _lib.ptr(info),
+                  _lib.ptr(sub), _lib.ptr(ldiag), _lib.ptr(lsub), _lib.ptr(ws), ws_bytes, info,
                   _lib.stream_ptr(diag.device))
-        _lib.raise_on_info(info, "SymmetricBlockTriDiagonal.cholesky")
+        _lib.raise_on_info(info, "SymmetricBlockTriDiagonal.cholesky", diag.device)
         return LowerTriangularBlockTriDiagonal(
             ldiag.reshape(self._diag.shape), None if lsub is None else lsub.reshape(self._sub_diag.shape)
         )
@@ -283,8 +283,8 @@ class SymmetricBlockTriDiagonal(BlockTriDiagonal):
         ws = _lib.workspace(ws_bytes, diag.device)
         _lib.call("mf_btd_udl", diag.dtype, diag.shape[0], self.outer_dim, self.inner_dim, _lib.ptr(diag),
                   _lib.ptr(sub), _lib.ptr(u_t), _lib.ptr(chol_d), _lib.ptr(eta_f), _lib.ptr(m_post),
-                  _lib.ptr(chol_dinv), int(chain), _lib.ptr(ws), ws_bytes, _lib.ptr(info), _lib.stream_ptr(diag.device))
-        _lib.raise_on_info(info, "SymmetricBlockTriDiagonal.upper_diagonal_lower")
+                  _lib.ptr(chol_dinv), int(chain), _lib.ptr(ws), ws_bytes, info, _lib.stream_ptr(diag.device))
+        _lib.raise_on_info(info, "SymmetricBlockTriDiagonal.upper_diagonal_lower", diag.device)
         u_t, chol_d = u_t.reshape(self._sub_diag.shape), chol_d.reshape(self._diag.shape)
         if chain:
             bsz, n, d = diag.shape[0], self.outer_dim, self.inner_dim

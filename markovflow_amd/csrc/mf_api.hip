@@ -36,7 +36,7 @@ int kf_loglik(int64_t B, int64_t Tn, int d, int m, const T* mu0, const T* cholP0
     const auto* t = table_for<T>(d);
     // experiment knob: state dimensions >= MF_BIG_FROM take the LDS-tile / MFMA path even where a register-resident
     // instantiation exists
-    static const int big_from = [] { const char* e = std::getenv("MF_BIG_FROM"); return e ? std::atoi(e) : 1000; }();
+    static const int big_from = [] { const char* e = mf::mf_knob("MF_BIG_FROM"); return e ? std::atoi(e) : 1000; }();
     const bool big = (!t || d >= big_from) && d <= (sizeof(T) == 4 ? mf::MF_MAX_D_BIG : mf::MF_MAX_D_BIG_F64);
     if (!t && !big) return -100;
     if (m < 1 || m > (big ? 32 : 4)) return -4;
@@ -111,7 +111,7 @@ int mf_kf_loglik_total_f32(int64_t B, const float* per_series, int m, const floa
     return loglik_total<float>(B, per_series, m, chol_obs, num_points, extra_const, host_const, out, stream);
 }
 
-int mf_version(void) { return 1; }
+int mf_version(void) { return 2; }
 int mf_max_state_dim(void) { return mf::MF_MAX_D; }
 
 size_t mf_kf_loglik_workspace_bytes(int64_t B, int64_t T, int d, int elem_size, int64_t chunks) {

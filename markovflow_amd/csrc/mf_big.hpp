@@ -14,6 +14,7 @@
 #pragma once
 #include "mf_kernels.hpp"
 
+#include "mf_env.hpp"
 #include <cstdlib>
 
 namespace mf {

@@ -577,7 +577,7 @@ template <int DP> __global__ void __launch_bounds__(NTHR) big_kf_chunk_kernel(Bi
         }
     }
     store_chunk_big<DP>(sm, out, id, d, (real)(-0.5 * (acc_yry + acc_ww) + 0.5 * quad - logC - logL));
-    if (threadIdx.x == 0 && bad && a.info) atomicMax(a.info, 1);
+    if (threadIdx.x == 0 && bad && a.info) raise_info(a.info);
 }
 
 // Reduction level: RedSys(n) -> RedSys(P) (FINAL: P = 1, the last block is eliminated too and out_scalar written).
@@ -623,7 +623,7 @@ __global__ void __launch_bounds__(NTHR) big_red_kernel(RedSys<real> in, RedSys<r
     } else {
         store_chunk_big<DP>(sm, out, id, d, (real)(acc_sc + 0.5 * quad - logL));
     }
-    if (threadIdx.x == 0 && bad && info) atomicMax(info, 1);
+    if (threadIdx.x == 0 && bad && info) raise_info(info);
 }
 
 
@@ -655,7 +655,7 @@ inline RedSys<real> carve_big(char*& p, long B, long n, int d) {
 
 // chunks per series: enough workgroups for two rounds over the 256 CUs, chunks of at least 4 transitions
 inline void big_partition(long B, long Tn, long chunks, long& P, long& L) {
-    static const long target = [] { const char* e = std::getenv("MF_BIG_TARGET_WGS"); return e ? std::atol(e) : 512L; }();
+    static const long target = [] { const char* e = mf_knob("MF_BIG_TARGET_WGS"); return e ? std::atol(e) : 512L; }();
     const long nt = Tn - 1;
     if (nt < 1) { P = 1; L = 1; return; }
     long want = chunks > 0 ? chunks : cdivl(target, B);

@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(NTHR) bigop_cholesky_kernel(long B, long n, in
         store_tile_lower<DP>(ldiag + (s * n + k) * dd, S, d);
         __syncthreads();
     }
-    if (threadIdx.x == 0 && bad && info) atomicMax(info, 1);
+    if (threadIdx.x == 0 && bad && info) raise_info(info);
 }
 
 // LowerTriangularBlockTriDiagonal.solve (block_tri_diag.py:339-351), workgroup per right-hand-side series
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(NTHR) bigop_udl_kernel(long B, long n, int d, 
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0 && bad && info) atomicMax(info, 1);
+    if (threadIdx.x == 0 && bad && info) raise_info(info);
 }
 
 // StateSpaceModel._build_precision (+ H^T R^-1 H, + information vector): workgroup per (series, block)

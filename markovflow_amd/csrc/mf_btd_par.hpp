@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(64) par_chol_up_kernel(ParLevel<T> in, long B,
     store_sym<T, D>(oDv + id * D * D, Phi);
     store_sym<T, D>(oGU + id * D * D, GU);
     store_mat<T, D, D>(oF + id * D * D, X);
-    if (bad && info) atomicMax(info, 1);
+    if (bad && info) raise_info(info);
 }
 
 // The same up-sweep with the spike (X, GU) in LDS - state dimensions whose chunk state does not fit a lane's registers
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(64) par_chol_up_x_kernel(ParLevel<T> in, long 
             MF_UNROLL for (int j = 0; j <= i; ++j) { const T v = E.sp.G(i, j); gu[i * D + j] = v; gu[j * D + i] = v; }
             MF_UNROLL for (int j = 0; j < D; ++j) f[i * D + j] = E.sp.X(i, j);
         }
-        if (E.bad && info) atomicMax(info, 1);
+        if (E.bad && info) raise_info(info);
     }
 }
 
@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(64) par_chol_down_kernel(ParLevel<T> lv, long 
         store_sym<T, D>(Pn + (s * lv.n + k) * D * D, Sig);
         if (PF) cur = nxt;
     }
-    if (bad && info) atomicMax(info, 1);
+    if (bad && info) raise_info(info);
 }
 
 // ---- Cholesky: level 0, emits the factor ----------------------------------------------------------------------
@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(64) par_chol_emit_kernel(long B, long n, long 
         if (PF) cur = nxt;
         if (PF2) nxt = nx2;
     }
-    if (bad && info) atomicMax(info, 1);
+    if (bad && info) raise_info(info);
 }
 
 // ---- Solve: affine recursion z_p = M_p z_{p-1} + c_p over positions p (p = k, or n-1-k for the transposed solve) -----
@@ -985,7 +985,7 @@ __global__ void __launch_bounds__(64) par_udl_emit_kernel(long B, long n, long l
         MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Lp[i][j] = Dl[i][j];
         store_lower<T, D>(chol_d + (s * n + k) * D * D, Lp);
     }
-    if (bad && info) atomicMax(info, 1);
+    if (bad && info) raise_info(info);
 }
 
 // posterior chain, backward affine recursion over positions:  x(p) = eta_k - U_k x(p-1),  U_k = (ut[k])^T, k = n-1-p
@@ -1075,7 +1075,7 @@ __global__ void __launch_bounds__(64) par_post_emit_kernel(long B, long n, long 
         chol_lower<T, D>(Q, Qi, lb, bad);
         store_lower<T, D>(chol_dinv + ci * D * D, Q);
     }
-    if (bad && info) atomicMax(info, 1);
+    if (bad && info) raise_info(info);
 }
 
 }  // namespace mf

@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(64) gpr_chunk_kernel(GprArgs<T> a, RedSys<T> o
     for (long j = 1; j < len; ++j) step(std::integral_constant<bool, false>{}, j);
     const T scalar = T(-0.5) * (acc_yry + acc_ww) + T(0.5) * E.quad - laC.value() - E.laL.value();
     store_chunk<T, D, SPIKE>(out, id, E, scalar);
-    if (E.bad && a.info) atomicMax(a.info, 1);
+    if (E.bad && a.info) raise_info(a.info);
 }
 
 }  // namespace mf

@@ -21,11 +21,11 @@ constexpr int D = MF_D;
 constexpr long RED_CHUNK = 8;    // chunk length of the level-0 floor of the parallel-in-time operators
 // reduction levels of the log-likelihood: chunk length, and the size at which the last level is walked serially
 inline long red_chunk() {
-    static const long v = [] { const char* e = std::getenv("MF_RED_CHUNK"); const long x = e ? std::atol(e) : 0; return x >= 2 ? x : 8L; }();
+    static const long v = [] { const char* e = mf_knob("MF_RED_CHUNK"); const long x = e ? std::atol(e) : 0; return x >= 2 ? x : 8L; }();
     return v;
 }
 inline long red_final() {
-    static const long v = [] { const char* e = std::getenv("MF_RED_FINAL"); const long x = e ? std::atol(e) : 0; return x >= 1 ? x : 8L; }();
+    static const long v = [] { const char* e = mf_knob("MF_RED_FINAL"); const long x = e ? std::atol(e) : 0; return x >= 1 ? x : 8L; }();
     return v;
 }
 
@@ -58,7 +58,7 @@ template <typename T> RedSys<T> carve(char*& p, long B, long n) {
 // (256 CUs x 4 SIMDs x 64 lanes), but never chunks shorter than 4 blocks.
 inline long auto_chunks(long B, long n) {
     static const long target = [] {
-        const char* e = std::getenv("MF_TARGET_LANES");
+        const char* e = mf_knob("MF_TARGET_LANES");
         return e ? std::atol(e) : 65536L;
     }();
     long P = cdiv(target, B);
@@ -81,7 +81,7 @@ template <typename T> size_t levels_ws(long B, long P) {
 // State dimensions whose elimination state (with the spike) does not fit a lane's 512 registers take the kernels of
 // mf_kf_x.hpp (spike in LDS): d >= 7 in fp64, d = 9 in fp32.  MF_KF_X=0 switches them off (A/B timing).
 template <typename T> bool x_path() {
-    static const bool on = [] { const char* e = std::getenv("MF_KF_X"); return !(e && e[0] == '0'); }();
+    static const bool on = [] { const char* e = mf_knob("MF_KF_X"); return !(e && e[0] == '0'); }();
     return on && ((sizeof(T) == 8 && D >= 7) || (sizeof(T) == 4 && D >= 9));
 }
 // lanes that fill the chip with the spike of every lane in LDS
@@ -116,13 +116,12 @@ int reduce_levels(RedSys<T> cur, long B, char* p, T add_const, T* out, int* info
 // or one output with per-step precisions (sites); matrix rows that are a whole number of 16-B units; 16-B aligned
 // tensors; at least one transition.  Everything else takes kf_chunk_kernel (direct loads).
 template <typename T, int M, bool RSTEP> constexpr bool lds_supported() { return KfLdsCfg<T, D, M, RSTEP>::SUPPORTED; }
-template <typename T> bool use_lds_kernel(long Tn, int m, const void* A, const void* cholQ, int rinv_per_step) {
+template <typename T> bool use_lds_kernel(long Tn, int m, int rinv_per_step) {
     static const bool force_direct = [] {
-        const char* e = std::getenv("MF_KF_IMPL");
+        const char* e = mf_knob("MF_KF_IMPL");
         return e && std::string(e) == "direct";
     }();
     if (force_direct || Tn < 2) return false;
-    if ((reinterpret_cast<size_t>(A) | reinterpret_cast<size_t>(cholQ)) & 15) return false;
     if (rinv_per_step) return m == 1 && lds_supported<T, 1, true>();
     switch (m) {
         case 1: return lds_supported<T, 1, false>();
@@ -164,19 +163,15 @@ inline void lds_partition(long B, long Tn, long chunks, long& P, long& L, long t
     P = cdiv(nt, L);
 }
 
-template <typename T> size_t kf_loglik_ws(long B, long Tn, long chunks) {
-    const long P = chunks > 0 ? (chunks > Tn ? Tn : chunks) : auto_chunks(B, Tn);
-    long P2 = 1, L2 = 1;
-    if (Tn >= 2) lds_partition(B, Tn, chunks, P2, L2);      // the 4-waves-per-CU partition is the largest one
-    return levels_ws<T>(B, P > P2 ? P : P2);
-}
-
-template <typename T>
-int kf_loglik(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ,
-              const T* H, const T* y, const T* Rinv, int rinv_per_step, T add_const, T* out, void* ws,
-              size_t ws_bytes, int* info, long chunks, hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
-    if (m < 1 || m > MF_MAXM) return -4;
-    if (ws_bytes < kf_loglik_ws<T>(B, Tn, chunks) || ws == nullptr) return -15;
+// Which level-0 kernel evaluates a call, and with which time partition.  ONE function decides it for the launcher and for the
+// workspace query, so the two can never disagree.
+enum KfPath { KF_PATH_X, KF_PATH_LDS, KF_PATH_DIRECT };
+struct KfPlan {
+    KfPath path;
+    long P, L;       // chunks per series; transitions per chunk (LDS kernel)
+};
+template <typename T> KfPlan kf_plan(long B, long Tn, int m, int rinv_per_step, long chunks, bool aligned16) {
+    KfPlan pl{KF_PATH_DIRECT, 1, 0};
     // (fp64 d = 6 with four outputs: the streaming kernel spills and the plain direct-load kernel runs at 17 % - the spike-in-LDS
     // kernel with its grouped loads is the better home)
     if ((x_path<T>() || (sizeof(T) == 8 && D == 6 && m == 4)) && Tn >= 2) {
@@ -186,25 +181,63 @@ int kf_loglik(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A,
             if (P > maxP) P = maxP;
         }
         if (P > 1) {
-            KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, info, 0};
-            char* p = static_cast<char*>(ws);
-            RedSys<T> lvl0 = carve<T>(p, B, P);
-            if (ev0) (void)hipEventRecord(ev0, st);
-            constexpr int x_lds = LdsSpike<T, D>::BYTES;
-            hipLaunchKernelGGL((kf_chunk_x_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), x_lds, st, a, lvl0);
-            if (ev1) (void)hipEventRecord(ev1, st);
-            return reduce_levels<T>(lvl0, B, p, add_const, out, info, st);
+            pl.path = KF_PATH_X;
+            pl.P = P;
+            return pl;
         }
     }
-    if (use_lds_kernel<T>(Tn, m, A, cholQ, rinv_per_step)) {
-        long P, L;
-        lds_partition(B, Tn, chunks, P, L, lds_target_lanes<T>(m, rinv_per_step));
-        static const int dbg = [] { const char* e = std::getenv("MF_KF_DEBUG"); return e ? std::atoi(e) : 0; }();
-        KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, info, dbg};
-        char* p = static_cast<char*>(ws);
-        RedSys<T> lvl0 = carve<T>(p, B, P);
-        const dim3 grid((unsigned)cdiv(B * P, 64)), block(64);
-        if (ev0) (void)hipEventRecord(ev0, st);
+    if (aligned16 && use_lds_kernel<T>(Tn, m, rinv_per_step)) {
+        pl.path = KF_PATH_LDS;
+        lds_partition(B, Tn, chunks, pl.P, pl.L, lds_target_lanes<T>(m, rinv_per_step));
+        return pl;
+    }
+    pl.P = chunks > 0 ? (chunks > Tn ? Tn : chunks) : auto_chunks(B, Tn);
+    return pl;
+}
+
+// Workspace of the log-likelihood: the call's m / per-step flag / alignment are not arguments of the query, so it is sized
+// for the largest partition any of them can choose.
+template <typename T> size_t kf_loglik_ws(long B, long Tn, long chunks) {
+    long pmax = 1;
+    for (int per_step = 0; per_step < 2; ++per_step)
+        for (int m = 1; m <= MF_MAXM; ++m)
+            for (int al = 0; al < 2; ++al) {
+                const long P = kf_plan<T>(B, Tn, m, per_step, chunks, al != 0).P;
+                if (P > pmax) pmax = P;
+            }
+    if (Tn >= 2) {                                            // the fused GPR route (gpr_loglik) partitions like this
+        long P = 1, L = 1;
+        lds_partition(B, Tn, chunks, P, L);
+        if (P > pmax) pmax = P;
+    }
+    return levels_ws<T>(B, pmax);
+}
+
+template <typename T>
+int kf_loglik(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ,
+              const T* H, const T* y, const T* Rinv, int rinv_per_step, T add_const, T* out, void* ws,
+              size_t ws_bytes, int* info, long chunks, hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
+    if (m < 1 || m > MF_MAXM) return -4;
+    if (ws == nullptr) return -15;
+    const bool aligned16 = ((reinterpret_cast<size_t>(A) | reinterpret_cast<size_t>(cholQ)) & 15) == 0;
+    const KfPlan pl = kf_plan<T>(B, Tn, m, rinv_per_step, chunks, aligned16);
+    const long P = pl.P;
+    if (ws_bytes < levels_ws<T>(B, P)) return -15;          // checked against the partition that is actually launched
+    int dbg = 0;
+#ifdef MF_EXPERIMENT
+    static const int dbg_env = [] { const char* e = mf_knob("MF_KF_DEBUG"); return e ? std::atoi(e) : 0; }();
+    dbg = dbg_env;
+#endif
+    KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, info, dbg};
+    char* p = static_cast<char*>(ws);
+    RedSys<T> lvl0 = carve<T>(p, B, P);
+    const dim3 grid((unsigned)cdiv(B * P, 64)), block(64);
+    if (ev0) (void)hipEventRecord(ev0, st);
+    if (pl.path == KF_PATH_X) {
+        constexpr int x_lds = LdsSpike<T, D>::BYTES;
+        hipLaunchKernelGGL((kf_chunk_x_kernel<T, D>), grid, block, x_lds, st, a, lvl0);
+    } else if (pl.path == KF_PATH_LDS) {
+        const long L = pl.L;
         auto launch = [&](auto mtag, auto rtag) {
             constexpr int M = decltype(mtag)::value;
             constexpr bool RS = decltype(rtag)::value;
@@ -220,17 +253,7 @@ int kf_loglik(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A,
         else if (m == 2) launch(integral_constant<int, 2>{}, integral_constant<bool, false>{});
         else if (m == 3) launch(integral_constant<int, 3>{}, integral_constant<bool, false>{});
         else launch(integral_constant<int, 4>{}, integral_constant<bool, false>{});
-        if (ev1) (void)hipEventRecord(ev1, st);
-        return reduce_levels<T>(lvl0, B, p, add_const, out, info, st);
-    }
-    const long P = chunks > 0 ? (chunks > Tn ? Tn : chunks) : auto_chunks(B, Tn);
-    KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, info, 0};
-    char* p = static_cast<char*>(ws);
-    RedSys<T> lvl0 = carve<T>(p, B, P);
-    const long lanes = B * P;
-    const dim3 grid((unsigned)cdiv(lanes, 64)), block(64);
-    if (ev0) (void)hipEventRecord(ev0, st);
-    if (P > 1) {
+    } else if (P > 1) {
         if (m == 1) hipLaunchKernelGGL((kf_chunk_kernel<T, D, 1, true>), grid, block, 0, st, a, lvl0);
         else hipLaunchKernelGGL((kf_chunk_kernel<T, D, 0, true>), grid, block, 0, st, a, lvl0);
     } else {
@@ -281,11 +304,11 @@ constexpr long PAR_MAX_SERIES = 4096;    // with this many series one lane per s
 // on B=64, T=10000 (scripts/sweep_radix.sh; 8: 192 / 535 us, 5: 166 / 494 us) - see DESIGN.md 4.3.
 constexpr long PAR_RADIX = 5;
 inline long par_radix() {
-    static const long r = [] { const char* e = std::getenv("MF_BTD_RADIX"); const long v = e ? std::atol(e) : 0; return v >= 2 ? v : PAR_RADIX; }();
+    static const long r = [] { const char* e = mf_knob("MF_BTD_RADIX"); const long v = e ? std::atol(e) : 0; return v >= 2 ? v : PAR_RADIX; }();
     return r;
 }
 inline long par_len0(long B, long n) {
-    static const long force = [] { const char* e = std::getenv("MF_BTD_PAR_LEN"); return e ? std::atol(e) : -1L; }();
+    static const long force = [] { const char* e = mf_knob("MF_BTD_PAR_LEN"); return e ? std::atol(e) : -1L; }();
     if (force >= 0) return (force > 0 && n >= 2 * force) ? force : 0;
     if (B >= PAR_MAX_SERIES || n < PAR_MIN_BLOCKS) return 0;
     long len = cdiv(B * n, 65536);           // aim at one wavefront per SIMD ...
@@ -701,9 +724,10 @@ int gpr_loglik(long B, long Tn, int ncomp, const int* orders, const T* lam, cons
                hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
     const int o0 = orders[0], o1 = ncomp > 1 ? orders[1] : 0;
     if (ncomp > 2) return -101;
-    if (ws_bytes < kf_loglik_ws<T>(B, Tn, chunks) || ws == nullptr) return -15;
+    if (ws == nullptr) return -15;
     long P = 1, L = 1;
     if (Tn >= 2) lds_partition(B, Tn, chunks, P, L);
+    if (ws_bytes < levels_ws<T>(B, P)) return -15;          // checked against the partition that is actually launched
     GprArgs<T> a{B, Tn, lam, var, per_series ? (long)ncomp : 0L, t, y, rinv, jitter, P, L, info};
     char* p = static_cast<char*>(ws);
     RedSys<T> lvl0 = carve<T>(p, B, P);

@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(64) kf_chunk_kernel(KfArgs<T> a, RedSys<T> out
     }
     const T scalar = T(-0.5) * (acc_yry + acc_ww) + T(0.5) * E.quad - laC.value() - E.laL.value();
     store_chunk<T, D, SPIKE>(out, id, E, scalar);
-    if (E.bad && a.info) atomicMax(a.info, 1);
+    if (E.bad && a.info) raise_info(a.info);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(64) red_chunk_kernel(RedSys<T> in, RedSys<T> o
     }
     const T scalar = acc_sc + T(0.5) * E.quad - E.laL.value();
     store_chunk<T, D, SPIKE>(out, id, E, scalar);
-    if (E.bad && info) atomicMax(info, 1);
+    if (E.bad && info) raise_info(info);
 }
 
 // Final level: one lane per series walks the remaining n blocks; out[s] = add_const + sum of scalars.  The next block is
@@ -348,7 +348,7 @@ __global__ void __launch_bounds__(64) red_final_kernel(RedSys<T> in, long B, T a
         }
         E.eliminate();
         out[s] = add_const + acc_sc + T(0.5) * E.quad - E.laL.value();
-        if (E.bad && info) atomicMax(info, 1);
+        if (E.bad && info) raise_info(info);
         return;
     }
     RedStep<T, D> cur, nxt;
@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(64) red_final_kernel(RedSys<T> in, long B, T a
     }
     E.eliminate();
     out[s] = add_const + acc_sc + T(0.5) * E.quad - E.laL.value();
-    if (E.bad && info) atomicMax(info, 1);
+    if (E.bad && info) raise_info(info);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(64) btd_cholesky_kernel(long B, long n, const 
         MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) L[i][j] = S[i][j];
         store_lower<T, D>(ldiag + (s * n + k) * D * D, L);
     }
-    if (bad && info) atomicMax(info, 1);
+    if (bad && info) raise_info(info);
 }
 
 // K2  LowerTriangularBlockTriDiagonal.solve (block_tri_diag.py:339-351); rhs series r uses factor r % Bl
@@ -643,7 +643,7 @@ __global__ void __launch_bounds__(64) btd_udl_kernel(long B, long n, const T* __
             store_lower<T, D>(chol_dinv + chain_idx(k) * D * D, Q);
         }
     }
-    if (bad && info) atomicMax(info, 1);
+    if (bad && info) raise_info(info);
 }
 
 // Posterior precision + information vector, one lane per (series, block):
@@ -875,7 +875,7 @@ __global__ void __launch_bounds__(64) sde_predict_kernel(long B, long N, long Np
             }
         store_mat<T, D, D>(ocov + id * D * D, Out);
     }
-    if (bad && info) atomicMax(info, 1);
+    if (bad && info) raise_info(info);
 }
 
 // Gradient of KalmanFilter.log_likelihood with respect to every tensor of the model, by Fisher's
@@ -1028,7 +1028,7 @@ __global__ void __launch_bounds__(64) kf_grad_kernel(KfArgs<T> a, const T* __res
         MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) G[i][j] *= wgt;
         store_lower<T, D>(gC + tid * D * D, G);
     }
-    if (bad && a.info) atomicMax(a.info, 1);
+    if (bad && a.info) raise_info(a.info);
 }
 
 }  // namespace mf

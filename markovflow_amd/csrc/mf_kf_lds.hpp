@@ -511,7 +511,7 @@ __global__ void __launch_bounds__(64) kf_chunk_lds_kernel(KfArgs<T> a, long L, R
     if (valid) {
         const T scalar = T(-0.5) * (acc_yry + acc_ww) + T(0.5) * E.quad - laC.value() - E.laL.value();
         store_chunk<T, D, SPIKE>(out, id, E, scalar);
-        if (E.bad && a.info) atomicMax(a.info, 1);
+        if (E.bad && a.info) raise_info(a.info);
 #ifdef MF_CHECKSUM
         out.GU[id * D * D + 0] = cs_A; out.GU[id * D * D + 1] = cs_C; out.GU[id * D * D + 2] = cs_b;
         out.gU[id * D + 0] = cs_H; out.gU[id * D + 1] = cs_y;

@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(64) kf_chunk_x_kernel(KfArgs<T> a, RedSys<T> o
     if (valid) {
         const T scalar = T(-0.5) * (acc_yry + acc_ww) + T(0.5) * E.quad - laC.value() - E.laL.value();
         E.store(out, id, scalar);
-        if (E.bad && a.info) atomicMax(a.info, 1);
+        if (E.bad && a.info) raise_info(a.info);
     }
 }
 
@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(64) red_chunk_x_kernel(RedSys<T> in, RedSys<T>
     if (valid) {
         const T scalar = acc_sc + T(0.5) * E.quad - E.laL.value();
         E.store(out, id, scalar);
-        if (E.bad && info) atomicMax(info, 1);
+        if (E.bad && info) raise_info(info);
     }
 }
 

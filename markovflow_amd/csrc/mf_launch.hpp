@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
+#include "mf_env.hpp"
+
 namespace mf {
 
 template <typename T> struct OpsTable {

@@ -181,6 +181,13 @@ int run(int64_t B, int64_t n, int ncomp, const int* orders, const T* lam, const 
     if (!A) return -10;
     const long total = B * n;
     const size_t lds = size_t(64) * size_t((sp.d * sp.d) | 1) * sizeof(T);
+    // one wave's staging image: past the 64 KB a kernel gets by default the limit is raised explicitly (gfx950: 160 KB per
+    // workgroup); past that the state dimension is not supported by this kernel
+    if (lds > size_t(160) * 1024) return -100;
+    if (lds > size_t(64) * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&matern_transitions_kernel<T>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return -100;
     hipLaunchKernelGGL((matern_transitions_kernel<T>), dim3((unsigned)((total + 63) / 64)), dim3(64), lds,
                        static_cast<hipStream_t>(stream), (long)B, (long)n, sp, lam, var, per_series ? (long)ncomp : 0L, dt,
                        jitter, A, cholQ, Q);

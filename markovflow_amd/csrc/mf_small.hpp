@@ -8,6 +8,15 @@
 #include <hip/hip_runtime.h>
 
 #define MF_DEV __device__ __forceinline__
+
+namespace mf {
+// Raise the caller's `info` flag (non-positive pivot).  A plain system-scope store of 1, not an atomic RMW: the flag may live
+// in pinned HOST memory (markovflow_amd/_lib.py keeps it there so that the success path needs no fill kernel, copy or sync),
+// and a store crosses the bus on every platform while a PCIe atomic may not; all writers write the same value.
+__device__ __forceinline__ void raise_info(int* info) {
+    __hip_atomic_store(info, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}   // namespace mf
 #define MF_UNROLL _Pragma("unroll")
 
 namespace mf {

@@ -62,7 +62,7 @@ class _LogLikelihoodPerSeries(torch.autograd.Function):
             w = grad_out.reshape(bsz).contiguous()              # applied inside the kernel: no scaling passes over the outputs
             _lib.call("mf_kf_loglik_grad", h.dtype, bsz, n, d, m, c(mu0), c(cp0), c(a_s), c(b_s), c(cq), c(h), c(y), c(r_inv),
                       c(means), c(covs), c(cross), _lib.ptr(g_mu0), _lib.ptr(g_cp0), _lib.ptr(g_a), _lib.ptr(g_b),
-                      _lib.ptr(g_cq), _lib.ptr(g_h), _lib.ptr(g_y), _lib.ptr(g_om), _lib.ptr(w), _lib.ptr(info),
+                      _lib.ptr(g_cq), _lib.ptr(g_h), _lib.ptr(g_y), _lib.ptr(g_om), _lib.ptr(w), info,
                       _lib.stream_ptr(h.device))
             # shared observation covariance R = L L^T: d/dL of  -1/2 sum tr(R^-1 Omega)  =  tril(L^-T (L^-1 Omega_w L^-T));
             # the log-determinant part of R lives in the constants, which torch differentiates outside this function
@@ -110,9 +110,12 @@ class BaseKalmanFilter(abc.ABC):
         h = self.emission.emission_matrix
         if tuple(h.shape[-3:]) != (n, m, d):
             raise ValueError(f"emission matrix has shape {tuple(h.shape)}, expected [..., {n}, {m}, {d}]")
-        h = _flat(h.expand(batch + (n, m, d)), 3)
-        y = _flat(self.observations.expand(batch + (n, m)), 2)
+        y = self.observations
         r_inv = self._r_inv                       # evaluated ONCE per call: the property is lazy and uncached
+        _lib.same_dtype_device(self.prior_ssm.state_transitions, type(self).__name__, emission_matrix=h, observations=y,
+                               observation_precision=r_inv)
+        h = _flat(h.expand(batch + (n, m, d)), 3)
+        y = _flat(y.expand(batch + (n, m)), 2)
         per_step = r_inv.dim() > 2
         if per_step:
             r_inv = _flat(r_inv.expand(batch + (n, m, m)), 3)
@@ -176,9 +179,9 @@ class BaseKalmanFilter(abc.ABC):
         info = _lib.pivot_info(a_s.device)           # None unless MF_CHECK_PIVOTS=1
         _lib.call("mf_kf_loglik", a_s.dtype, bsz, n, d, m, _lib.ptr(mu0), _lib.ptr(cp0), _lib.ptr(a_s),
                   _lib.ptr(b_s), _lib.ptr(cq), _lib.ptr(h), _lib.ptr(y), _lib.ptr(r_inv), int(per_step),
-                  0.0, _lib.ptr(out), _lib.ptr(ws), ws_bytes, _lib.ptr(info), self._chunks, self._prof_events[0],
+                  0.0, _lib.ptr(out), _lib.ptr(ws), ws_bytes, info, self._chunks, self._prof_events[0],
                   self._prof_events[1], _lib.stream_ptr(a_s.device))
-        _lib.raise_on_info(info, "KalmanFilter.log_likelihood")
+        _lib.raise_on_info(info, "KalmanFilter.log_likelihood", a_s.device)
         return out
 
     def _differentiable_per_series(self) -> Optional[torch.Tensor]:
@@ -246,6 +249,8 @@ class KalmanFilter(BaseKalmanFilter):
         shape = tuple(state_space_model.batch_shape) + (state_space_model.num_transitions + 1, m)
         if tuple(observations.shape) != shape:
             raise ValueError("The shape of the observations and the state-space-model parameters are not compatible")
+        _lib.same_dtype_device(state_space_model.state_transitions, "KalmanFilter", observations=observations,
+                               chol_obs_covariance=chol_obs_covariance, emission_matrix=emission_model.emission_matrix)
         self._chol_obs_covariance = chol_obs_covariance
         self._observations = observations
 

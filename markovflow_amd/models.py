@@ -37,6 +37,10 @@ class GaussianProcessRegression:
             raise ValueError("chol_obs_covariance must have shape [observation_dim, observation_dim]")
         if tuple(time_points.shape) != tuple(observations.shape[:-1]):
             raise ValueError("time_points must have shape observations.shape[:-1]")
+        # one dtype and one device for the whole model, as the reference's default_float() (a float32 buffer handed to a
+        # float64 kernel would be read past its end)
+        _lib.same_dtype_device(observations, "GaussianProcessRegression", time_points=time_points,
+                               chol_obs_covariance=chol_obs_covariance)
         self._kernel = kernel
         self._time_points = time_points
         self._observations = observations
@@ -105,14 +109,14 @@ class GaussianProcessRegression:
         out = torch.empty(bsz, dtype=dtype, device=dev)
         info = _lib.pivot_info(dev)
         orders = (ctypes.c_int * len(comps))(*[c.order for c in comps])
-        fn = getattr(lib, "mf_gpr_matern_loglik" + _lib.suffix(dtype))
-        rc = fn(bsz, n, len(comps), orders, _lib.ptr(lam_t), _lib.ptr(var_t), int(per_series), _lib.ptr(t), _lib.ptr(y),
-                _lib.ptr(rinv), self._kernel._jitter, 0.0, _lib.ptr(out), _lib.ptr(ws), ws_bytes, _lib.ptr(info),
-                self._chunks, self._prof_events[0], self._prof_events[1], _lib.stream_ptr(dev))
+        rc = _lib.call_rc("mf_gpr_matern_loglik", dtype, bsz, n, len(comps), orders, _lib.ptr(lam_t), _lib.ptr(var_t),
+                          int(per_series), _lib.ptr(t), _lib.ptr(y), _lib.ptr(rinv), self._kernel._jitter, 0.0, _lib.ptr(out),
+                          _lib.ptr(ws), ws_bytes, info, self._chunks, self._prof_events[0], self._prof_events[1],
+                          _lib.stream_ptr(dev))
         if rc == -101:
             return None                     # component signature not instantiated: materialise instead
         _lib.check(rc, "mf_gpr_matern_loglik")
-        _lib.raise_on_info(info, "GaussianProcessRegression.log_likelihood")
+        _lib.raise_on_info(info, "GaussianProcessRegression.log_likelihood", dev)
         const = -0.5 * math.log(2 * math.pi) * n + 0.5 * n * torch.log(rinv[0])
         return (out + const).reshape(batch)
 

@@ -60,8 +60,8 @@ class ConditionalProcess:
         _lib.call("mf_sde_conditional_predict", dtype, bsz, n, n_new, d, _lib.ptr(flat(idx, 1)), _lib.ptr(flat(a_mt, 3)),
                   _lib.ptr(flat(q_mt, 3)), _lib.ptr(flat(a_tp, 3)), _lib.ptr(flat(q_tp, 3)), _lib.ptr(flat(means, 2)),
                   _lib.ptr(flat(covs, 3)), _lib.ptr(None if sub is None else flat(sub, 3)), _lib.ptr(flat(m0, 1)),
-                  _lib.ptr(flat(p0, 2)), _lib.ptr(out_mean), _lib.ptr(out_cov), _lib.ptr(info), _lib.stream_ptr(dev))
-        _lib.raise_on_info(info, "ConditionalProcess.predict_state")
+                  _lib.ptr(flat(p0, 2)), _lib.ptr(out_mean), _lib.ptr(out_cov), info, _lib.stream_ptr(dev))
+        _lib.raise_on_info(info, "ConditionalProcess.predict_state", dev)
         return out_mean.reshape(batch + (n_new, d)), out_cov.reshape(batch + (n_new, d, d))
 
     def predict_f(self, new_time_points: torch.Tensor, full_output_cov: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:

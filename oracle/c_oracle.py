@@ -43,12 +43,24 @@ def num_threads() -> int:
     return int(lib().mf_oracle_num_threads())
 
 
-def kf_loglik(mu0, chol_p0, a_s, b_s, chol_q, h, y, r_inv, per_step=False):
-    """Per-series log-likelihood [B] for [B,...] inputs (see mf_oracle_kf_loglik_f64)."""
+def set_num_threads(n: int) -> None:
+    lib().mf_oracle_set_num_threads(ctypes.c_int(int(n)))
+
+
+def use_library(path: str) -> None:
+    """Switch to another build of the same source (bench.py compiles one with -march=native on the box it runs on)."""
+    global _lib
+    _lib = ctypes.CDLL(path)
+
+
+def kf_loglik(mu0, chol_p0, a_s, b_s, chol_q, h, y, r_inv, per_step=False, generic=False):
+    """Per-series log-likelihood [B] for [B,...] inputs (see mf_oracle_kf_loglik_f64).  ``generic``: the entry point whose loop
+    bounds are run-time values only (d = 6 / d = 4 with one output otherwise take a compile-time-sized instance)."""
     mu0, chol_p0, a_s, b_s, chol_q, h, y, r_inv = map(_c, (mu0, chol_p0, a_s, b_s, chol_q, h, y, r_inv))
     bsz, t, m, d = h.shape
     out = np.zeros(bsz)
-    rc = lib().mf_oracle_kf_loglik_f64(
+    fn = lib().mf_oracle_kf_loglik_generic_f64 if generic else lib().mf_oracle_kf_loglik_f64
+    rc = fn(
         ctypes.c_int64(bsz), ctypes.c_int64(t), ctypes.c_int(d), ctypes.c_int(m), _p(mu0), _p(chol_p0),
         _p(a_s), _p(b_s), _p(chol_q), _p(h), _p(y), _p(r_inv), ctypes.c_int(int(per_step)), _p(out))
     if rc != 0:

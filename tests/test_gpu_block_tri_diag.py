@@ -171,14 +171,28 @@ def test_non_positive_definite_sets_info(rng):
     assert int(info.item()) == 1
 
 
-def test_check_pivots_switch_raises_like_the_reference(rng, monkeypatch):
-    """Default: no host sync, a non-positive pivot shows up as NaN.  MF_CHECK_PIVOTS=1: raise, as TensorFlow's Cholesky op does."""
+def test_non_positive_pivot_is_reported_like_the_reference(rng, monkeypatch):
+    """TensorFlow's Cholesky op raises on a matrix that is not positive definite (block_tri_diag.py:423-436).  Here the kernels
+    raise a flag in pinned host memory: by default it is looked at without synchronising (next library call, or
+    check_errors()); in synchronous mode (MF_CHECK_PIVOTS=1) the factorising call itself raises."""
     from markovflow_amd import _lib
+    _lib.check_errors()                                                   # start clean
     sym = mfa.SymmetricBlockTriDiagonal(tt(-np.tile(np.eye(3), (2, 4, 1, 1))))
-    assert not torch.isfinite(sym.cholesky.block_diagonal).all()
+    assert not torch.isfinite(sym.cholesky.block_diagonal).all()          # the result itself is NaN
+    with pytest.raises(_lib.MarkovflowAmdError, match="SymmetricBlockTriDiagonal.cholesky"):
+        _lib.check_errors()
+    _lib.check_errors()                                                   # reported once, then clean again
+    sym.cholesky
+    torch.cuda.synchronize()
+    good = mfa.SymmetricBlockTriDiagonal(tt(np.tile(np.eye(3), (2, 4, 1, 1))))
+    with pytest.raises(_lib.MarkovflowAmdError):                          # the next library call notices the finished failure
+        good.cholesky
+    assert torch.isfinite(good.cholesky.block_diagonal).all()
+    _lib.check_errors()
     monkeypatch.setattr(_lib, "CHECK_PIVOTS", True)
     with pytest.raises(_lib.MarkovflowAmdError):
         sym.cholesky
+    good.cholesky                                                         # and a clean call stays clean
 
 
 def test_unsupported_state_dim_fails_loudly(rng):

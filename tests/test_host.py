@@ -145,3 +145,31 @@ def test_as_band_layout_and_round_trip(d, t, has_sub, batch):
         np.testing.assert_allclose(back.block_sub_diagonal.numpy(), sub.numpy())
     else:
         assert back.block_sub_diagonal is None
+
+
+def test_mixed_dtypes_are_rejected_before_any_launch():
+    """A float32 observation buffer handed to a float64 chain would be read past its end by the kernels: ValueError, as the
+    reference's dtype check."""
+    import markovflow_amd as mfa
+    d, n = 2, 5
+    f64 = dict(dtype=torch.float64)
+    ssm = mfa.StateSpaceModel(torch.zeros(d, **f64), torch.eye(d, **f64), torch.eye(d, **f64).expand(n - 1, d, d).contiguous(),
+                              torch.zeros(n - 1, d, **f64), torch.eye(d, **f64).expand(n - 1, d, d).contiguous())
+    em = mfa.EmissionModel(torch.ones(n, 1, d, **f64))
+    with pytest.raises(ValueError, match="observations"):
+        mfa.KalmanFilter(ssm, em, torch.zeros(n, 1, dtype=torch.float32), torch.eye(1, **f64))
+    with pytest.raises(ValueError, match="chol_obs_covariance"):
+        mfa.KalmanFilter(ssm, em, torch.zeros(n, 1, **f64), torch.eye(1, dtype=torch.float32))
+    with pytest.raises(ValueError, match="emission_matrix"):
+        mfa.KalmanFilter(ssm, mfa.EmissionModel(torch.ones(n, 1, d, dtype=torch.float32)), torch.zeros(n, 1, **f64), torch.eye(1, **f64))
+    with pytest.raises(ValueError, match="time_points"):
+        mfa.GaussianProcessRegression((torch.arange(n, **f64), torch.zeros(n, 1, dtype=torch.float32)), mfa.Matern32(1.0, 1.0))
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`bench.py --gpus N` starts its own ranks; with fewer GPUs than asked it exits non-zero instead of reporting n_gpus=1."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 2 and "--gpus 64" in proc.stderr

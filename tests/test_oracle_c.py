@@ -48,3 +48,12 @@ def test_c_cholesky_solve(name):
     np.testing.assert_allclose(ld, g["chol_diag"], rtol=2e-6, atol=1e-7)
     np.testing.assert_allclose(C.btd_solve(ld, ls, g["rhs"]), g["solve_l"], rtol=2e-6, atol=1e-7)
     np.testing.assert_allclose(C.btd_solve(ld, ls, g["rhs"], transpose=True), g["solve_lt"], rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("d", [4, 6])
+def test_c_loglik_fixed_size_instance_equals_generic(rng, d):
+    """d = 6 / d = 4 with one output run a compile-time-sized instance (the timed CPU baseline): same numbers as the generic one."""
+    kw = random_ssm(rng, 4, 50, d, 1)
+    r_inv = np.array([[2.5]])
+    np.testing.assert_allclose(C.kf_loglik(**kw, r_inv=r_inv), C.kf_loglik(**kw, r_inv=r_inv, generic=True), rtol=1e-12)
+    np.testing.assert_allclose(C.kf_loglik(**kw, r_inv=r_inv), O.kf_log_likelihood(**kw, r_inv=r_inv, per_series=True), rtol=1e-10)
