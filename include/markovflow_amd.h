@@ -271,26 +271,63 @@ int mf_sde_conditional_predict_f32(int64_t B, int64_t N, int64_t Np, int d, cons
                                    const float* prior_cov, float* out_mean, float* out_cov, int* info, void* stream);
 
 /*
- * Gradient of the KalmanFilter log-likelihood with respect to every tensor of the model (the reference
- * gets it from TensorFlow's reverse mode over the banded ops).  Fisher's identity, grad log p(y) = E_{x|y}[grad log p(x, y)],
- * evaluated from the smoothed marginals the caller passes in: post_mean [B,T,d], post_cov [B,T,d,d], post_cross [B,T-1,d,d] =
- * Cov(x_{k+1}, x_k) - exact, local in time, one lane per (series, time point).  Outputs, all per series (not summed over the
- * batch): g_mu0 [B,d], g_cholP0 [B,d,d] (lower), g_A [B,T-1,d,d], g_b [B,T-1,d], g_cholQ [B,T-1,d,d] (lower), g_H [B,T,m,d],
- * g_y [B,T,m], and g_omega [B,T,m,m] = E[r r^T] with r = y - H x, from which the gradient with respect to a shared
- * observation covariance follows by reduction: dll/dcholR = tril(L^-T (L^-1 (sum omega) L^-T - n I)).  weights [B]
- * (nullable): the incoming gradient of every series' value, applied to all outputs.  Shared R^-1 [m,m]; state dimension
- * 1..9, m <= 4.
+ * Gradient of the Kalman log-likelihood with respect to every tensor of the model (the reference
+ * gets it from TensorFlow's reverse mode over the banded ops: tests/integration/models/test_gaussian_process_regression.py:117-130,
+ * markovflow/models/variational_cvi.py:138-161 for the sites variants).  Fisher's identity,
+ * grad log p(y) = E_{x|y}[grad log p(x, y)], evaluated from the smoothed marginals the caller passes in:
+ * post_mean [B,T,d], post_cov [B,T,d,d], post_cross [B,T-1,d,d] = Cov(x_{k+1}, x_k) - exact, local in time, one lane per
+ * (series, time point).  Outputs, all per series (not summed over the batch): g_mu0 [B,d], g_cholP0 [B,d,d] (lower),
+ * g_A [B,T-1,d,d], g_b [B,T-1,d], g_cholQ [B,T-1,d,d] (lower), g_H [B,T,m,d], g_y [B,T,m], and g_omega [B,T,m,m] =
+ * E[r r^T] with r = y - H x: the derivative of the log-likelihood with respect to the observation PRECISION of time point k
+ * is -1/2 g_omega[k] (+ 1/2 R_k from the log-determinant, which the caller owns).  Rinv: shared [m,m] (rinv_per_step = 0) or
+ * [B,T,m,m] (1: KalmanFilterWithSites / WithSparseSites).  H = NULL: no emission model - the expected score of the bare chain
+ * under the given moments (used for the q2 half of the KL gradient); y, Rinv, g_H, g_y, g_omega are then ignored.
+ * weights [B] (nullable): the incoming gradient of every series' value, applied to all outputs.  State dimension 1..9, m <= 4.
  */
 int mf_kf_loglik_grad_f64(int64_t B, int64_t T, int d, int m, const double* mu0, const double* cholP0, const double* A,
                           const double* b, const double* cholQ, const double* H, const double* y, const double* Rinv,
-                          const double* post_mean, const double* post_cov, const double* post_cross, double* g_mu0,
-                          double* g_cholP0, double* g_A, double* g_b, double* g_cholQ, double* g_H, double* g_y,
-                          double* g_omega, const double* weights, int* info, void* stream);
+                          int rinv_per_step, const double* post_mean, const double* post_cov, const double* post_cross,
+                          double* g_mu0, double* g_cholP0, double* g_A, double* g_b, double* g_cholQ, double* g_H,
+                          double* g_y, double* g_omega, const double* weights, int* info, void* stream);
 int mf_kf_loglik_grad_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const float* cholP0, const float* A,
                           const float* b, const float* cholQ, const float* H, const float* y, const float* Rinv,
-                          const float* post_mean, const float* post_cov, const float* post_cross, float* g_mu0,
-                          float* g_cholP0, float* g_A, float* g_b, float* g_cholQ, float* g_H, float* g_y, float* g_omega,
-                          const float* weights, int* info, void* stream);
+                          int rinv_per_step, const float* post_mean, const float* post_cov, const float* post_cross,
+                          float* g_mu0, float* g_cholP0, float* g_A, float* g_b, float* g_cholQ, float* g_H, float* g_y,
+                          float* g_omega, const float* weights, int* info, void* stream);
+
+/*
+ * Gradient of  KL(q1 || q2)  between two state space models (markovflow/state_space_model.py:528-593; differentiated by
+ * TensorFlow in the reference, pinned by tests/integration/models/test_variational.py:123-132) with respect to the parameters
+ * of q1: ONE backward sweep per series carrying the adjoints of q1's marginal mean and covariance (csrc/mf_kl_grad.hpp).
+ * means_1 [B,T,d], covs_1 [B,T,d,d]: marginals of q1 (mf_ssm_marginal_means / mf_ssm_marginal_covariances).  Outputs per series:
+ * g_mu0 [B,d], g_cholP0 [B,d,d] (lower), g_A [B,T-1,d,d], g_b [B,T-1,d], g_cholQ [B,T-1,d,d] (lower), scaled by weights [B]
+ * (nullable).  The gradient with respect to q2 is MINUS mf_kf_loglik_grad with H = NULL, q2's parameters and q1's moments.
+ * State dimension 1..9.
+ */
+int mf_ssm_kl_grad_f64(int64_t B, int64_t T, int d, const double* mu0_1, const double* cholP0_1, const double* A_1,
+                       const double* b_1, const double* cholQ_1, const double* mu0_2, const double* cholP0_2, const double* A_2,
+                       const double* b_2, const double* cholQ_2, const double* means_1, const double* covs_1,
+                       const double* weights, double* g_mu0, double* g_cholP0, double* g_A, double* g_b, double* g_cholQ,
+                       int* info, void* stream);
+int mf_ssm_kl_grad_f32(int64_t B, int64_t T, int d, const float* mu0_1, const float* cholP0_1, const float* A_1,
+                       const float* b_1, const float* cholQ_1, const float* mu0_2, const float* cholP0_2, const float* A_2,
+                       const float* b_2, const float* cholQ_2, const float* means_1, const float* covs_1, const float* weights,
+                       float* g_mu0, float* g_cholP0, float* g_A, float* g_b, float* g_cholQ, int* info, void* stream);
+
+/*
+ * Adjoint of the marginal recursion  m_{k+1} = A_k m_k + b_k,  S_{k+1} = A_k S_k A_k^T + Q_k  (markovflow/state_space_model.py:232-262,
+ * differentiated by TensorFlow in the reference: the expected log-likelihood of every variational model goes through
+ * `marginals`, models/variational.py:150, models/sparse_variational.py:178-192).  Given the incoming gradients g_means [B,T,d] and
+ * g_covs [B,T,d,d] (either may be NULL = zero) of a scalar with respect to the marginal means / covariances, and the
+ * marginals themselves (means, covs), the gradients with respect to mu0, cholP0 (lower), A, b and cholQ (lower).  One backward
+ * sweep per series.  State dimension 1..9.
+ */
+int mf_ssm_marginals_grad_f64(int64_t B, int64_t T, int d, const double* cholP0, const double* A, const double* cholQ,
+                              const double* means, const double* covs, const double* g_means, const double* g_covs,
+                              double* g_mu0, double* g_cholP0, double* g_A, double* g_b, double* g_cholQ, void* stream);
+int mf_ssm_marginals_grad_f32(int64_t B, int64_t T, int d, const float* cholP0, const float* A, const float* cholQ,
+                              const float* means, const float* covs, const float* g_means, const float* g_covs, float* g_mu0,
+                              float* g_cholP0, float* g_A, float* g_b, float* g_cholQ, void* stream);
 
 #ifdef __cplusplus
 }

@@ -332,17 +332,44 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
 
 #define MF_DEFINE5(SUF, T)                                                                                             \
     int mf_kf_loglik_grad_##SUF(int64_t B, int64_t Tn, int d, int m, const T* mu0, const T* cholP0, const T* A,        \
-                                const T* b, const T* cholQ, const T* H, const T* y, const T* Rinv, const T* post_mean, \
-                                const T* post_cov, const T* post_cross, T* g_mu0, T* g_cholP0, T* g_A, T* g_b,         \
-                                T* g_cholQ, T* g_H, T* g_y, T* g_omega, const T* weights, int* info, void* stream) { \
+                                const T* b, const T* cholQ, const T* H, const T* y, const T* Rinv, int rinv_per_step,  \
+                                const T* post_mean, const T* post_cov, const T* post_cross, T* g_mu0, T* g_cholP0,     \
+                                T* g_A, T* g_b, T* g_cholQ, T* g_H, T* g_y, T* g_omega, const T* weights, int* info,   \
+                                void* stream) {                                                                        \
         MF_HEAD(T, B, Tn, d)                                                                                           \
         if (big) return -100;                                                                                          \
         if (m < 1 || m > 4) return -4;                                                                                 \
-        if (!mu0 || !cholP0 || (Tn > 1 && (!A || !b || !cholQ)) || !H || !y || !Rinv) return -5;                       \
-        if (!post_mean || !post_cov || (Tn > 1 && !post_cross)) return -13;                                            \
-        if (!g_mu0 || !g_cholP0 || (Tn > 1 && (!g_A || !g_b || !g_cholQ)) || !g_H || !g_y || !g_omega) return -16;     \
+        if (!mu0 || !cholP0 || (Tn > 1 && (!A || !b || !cholQ))) return -5;                                            \
+        if (H && (!y || !Rinv)) return -11;                                                                            \
+        if (!post_mean || !post_cov || (Tn > 1 && !post_cross)) return -14;                                            \
+        if (!g_mu0 || !g_cholP0 || (Tn > 1 && (!g_A || !g_b || !g_cholQ))) return -17;                                 \
+        if (H && (!g_H || !g_y || !g_omega)) return -22;                                                               \
         return t->kf_grad(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, post_mean, post_cov, post_cross, g_mu0,      \
-                          g_cholP0, g_A, g_b, g_cholQ, g_H, g_y, g_omega, weights, info, S(stream));                   \
+                          g_cholP0, g_A, g_b, g_cholQ, g_H, g_y, g_omega, weights, rinv_per_step, info, S(stream));    \
+    }                                                                                                                  \
+    int mf_ssm_kl_grad_##SUF(int64_t B, int64_t Tn, int d, const T* mu0_1, const T* cholP0_1, const T* A_1,            \
+                             const T* b_1, const T* cholQ_1, const T* mu0_2, const T* cholP0_2, const T* A_2,          \
+                             const T* b_2, const T* cholQ_2, const T* means_1, const T* covs_1, const T* weights,      \
+                             T* g_mu0, T* g_cholP0, T* g_A, T* g_b, T* g_cholQ, int* info, void* stream) {             \
+        MF_HEAD(T, B, Tn, d)                                                                                           \
+        if (big) return -100;                                                                                          \
+        if (!mu0_1 || !cholP0_1 || (Tn > 1 && (!A_1 || !b_1 || !cholQ_1))) return -4;                                  \
+        if (!mu0_2 || !cholP0_2 || (Tn > 1 && (!A_2 || !b_2 || !cholQ_2))) return -9;                                  \
+        if (Tn > 1 && (!means_1 || !covs_1)) return -14;                                                               \
+        if (!g_mu0 || !g_cholP0 || (Tn > 1 && (!g_A || !g_b || !g_cholQ))) return -17;                                 \
+        return t->kl_grad(B, Tn, mu0_1, cholP0_1, A_1, b_1, cholQ_1, mu0_2, cholP0_2, A_2, b_2, cholQ_2, means_1,      \
+                          covs_1, weights, g_mu0, g_cholP0, g_A, g_b, g_cholQ, info, S(stream));                       \
+    }                                                                                                                  \
+    int mf_ssm_marginals_grad_##SUF(int64_t B, int64_t Tn, int d, const T* cholP0, const T* A, const T* cholQ,         \
+                                    const T* means, const T* covs, const T* g_means, const T* g_covs, T* g_mu0,        \
+                                    T* g_cholP0, T* g_A, T* g_b, T* g_cholQ, void* stream) {                           \
+        MF_HEAD(T, B, Tn, d)                                                                                           \
+        if (big) return -100;                                                                                          \
+        if (!cholP0 || (Tn > 1 && (!A || !cholQ))) return -4;                                                          \
+        if (Tn > 1 && (!means || !covs)) return -7;                                                                    \
+        if (!g_mu0 || !g_cholP0 || (Tn > 1 && (!g_A || !g_b || !g_cholQ))) return -11;                                 \
+        return t->marginals_grad(B, Tn, cholP0, A, cholQ, means, covs, g_means, g_covs, g_mu0, g_cholP0, g_A, g_b,     \
+                                 g_cholQ, S(stream));                                                                  \
     }
 
 MF_DEFINE(f64, double)

@@ -8,6 +8,7 @@
 #include "mf_kf_x.hpp"
 #include "mf_btd_par.hpp"
 #include "mf_gpr_fused.hpp"
+#include "mf_kl_grad.hpp"
 #include "mf_launch.hpp"
 
 #include <cstdlib>
@@ -759,12 +760,29 @@ int sde_predict(long B, long N, long Np, const long long* idx, const T* Amt, con
 template <typename T>
 int kf_grad(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H,
             const T* y, const T* Rinv, const T* pm, const T* pS, const T* pX, T* gmu0, T* gC0, T* gA, T* gb, T* gC, T* gH,
-            T* gy, T* gOm, const T* weights, int* info, hipStream_t st) {
+            T* gy, T* gOm, const T* weights, int rinv_per_step, int* info, hipStream_t st) {
     if (m < 1 || m > MF_MAXM) return -3;
-    KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, 0, 1, info, 0, weights};
+    KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, 1, info, 0, weights};
     const dim3 grid((unsigned)cdiv(B * Tn, 64)), block(64);
     if (m == 1) hipLaunchKernelGGL((kf_grad_kernel<T, D, 1>), grid, block, 0, st, a, pm, pS, pX, gmu0, gC0, gA, gb, gC, gH, gy, gOm);
     else hipLaunchKernelGGL((kf_grad_kernel<T, D, 0>), grid, block, 0, st, a, pm, pS, pX, gmu0, gC0, gA, gb, gC, gH, gy, gOm);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+template <typename T>
+int kl_grad(long B, long Tn, const T* mu0_1, const T* C0_1, const T* A_1, const T* b_1, const T* C_1, const T* mu0_2,
+            const T* C0_2, const T* A_2, const T* b_2, const T* C_2, const T* pm, const T* pS, const T* weights, T* gmu0,
+            T* gC0, T* gA, T* gb, T* gC, int* info, hipStream_t st) {
+    KlGradArgs<T, D> a{B, Tn, mu0_1, C0_1, A_1, b_1, C_1, mu0_2, C0_2, A_2, b_2, C_2, pm, pS, weights, gmu0, gC0, gA, gb, gC, info};
+    hipLaunchKernelGGL((ssm_kl_grad_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+template <typename T>
+int marginals_grad(long B, long Tn, const T* C0, const T* A, const T* C, const T* pm, const T* pS, const T* gm, const T* gS,
+                   T* gmu0, T* gC0, T* gA, T* gb, T* gC, hipStream_t st) {
+    hipLaunchKernelGGL((ssm_marginals_grad_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, Tn, C0, A, C, pm,
+                       pS, gm, gS, gmu0, gC0, gA, gb, gC);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
@@ -772,7 +790,7 @@ template <typename T> const OpsTable<T>* table() {
     static const OpsTable<T> t = {
         &kf_loglik_ws<T>, &kf_loglik<T>, &btd_logdet_quad_ws<T>, &btd_logdet_quad<T>, &btd_cholesky_ws<T>, &btd_cholesky<T>,
         &btd_solve_ws<T>, &btd_solve<T>,    &btd_matvec<T>, &btd_logdet<T>,        &btd_diag_of_inverse_ws<T>, &btd_diag_of_inverse<T>, &ssm_marginal_covs<T>, &btd_udl_ws<T>, &btd_udl<T>,
-        &ssm_precision<T>, &ssm_means<T>, &block_matmul<T>, &gpr_loglik<T>, &sde_predict<T>, &kf_grad<T>,
+        &ssm_precision<T>, &ssm_means<T>, &block_matmul<T>, &gpr_loglik<T>, &sde_predict<T>, &kf_grad<T>, &kl_grad<T>, &marginals_grad<T>,
     };
     return &t;
 }

@@ -904,8 +904,9 @@ __global__ void __launch_bounds__(64) kf_grad_kernel(KfArgs<T> a, const T* __res
     LogAcc<T> la;
     la.init();
     bool bad = false;
-    // ---- observation terms of time point k -----------------------------------------------------------------------------
-    {
+    // ---- observation terms of time point k (skipped without an emission model: the score of a bare chain) ----------------
+    if (a.H != nullptr) {
+        const T* __restrict__ Rv = a.Rinv + (a.rinv_per_step ? id * m * m : 0);      // shared [m,m] or per step [B,T,m,m]
         T h[MM][D], r[MM], Rr[MM], HS[MM][D];
         MF_UNROLL for (int o = 0; o < MM; ++o) {
             const bool on = (M > 0) || (o < m);
@@ -923,7 +924,7 @@ __global__ void __launch_bounds__(64) kf_grad_kernel(KfArgs<T> a, const T* __res
             T acc = T(0);
             MF_UNROLL for (int p = 0; p < MM; ++p) {
                 const bool on = (M > 0) || (o < m && p < m);
-                acc += (on ? a.Rinv[o * ((M > 0) ? M : m) + p] : T(0)) * r[p];
+                acc += (on ? Rv[o * ((M > 0) ? M : m) + p] : T(0)) * r[p];
             }
             Rr[o] = acc;
         }
@@ -935,7 +936,7 @@ __global__ void __launch_bounds__(64) kf_grad_kernel(KfArgs<T> a, const T* __res
                 T acc = Rr[o] * mk[i];
                 MF_UNROLL for (int p = 0; p < MM; ++p) {
                     const bool on = (M > 0) || (p < m);
-                    acc -= (on ? a.Rinv[o * ((M > 0) ? M : m) + p] : T(0)) * HS[p][i];
+                    acc -= (on ? Rv[o * ((M > 0) ? M : m) + p] : T(0)) * HS[p][i];
                 }
                 gH[(id * m + o) * D + i] = wgt * acc;
             }

@@ -48,7 +48,12 @@ template <typename T> struct OpsTable {
                        int* info, hipStream_t st);
     int (*kf_grad)(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H,
                    const T* y, const T* Rinv, const T* pm, const T* pS, const T* pX, T* gmu0, T* gC0, T* gA, T* gb, T* gC,
-                   T* gH, T* gy, T* gOm, const T* weights, int* info, hipStream_t st);
+                   T* gH, T* gy, T* gOm, const T* weights, int rinv_per_step, int* info, hipStream_t st);
+    int (*kl_grad)(long B, long Tn, const T* mu0_1, const T* C0_1, const T* A_1, const T* b_1, const T* C_1, const T* mu0_2,
+                   const T* C0_2, const T* A_2, const T* b_2, const T* C_2, const T* pm, const T* pS, const T* weights,
+                   T* gmu0, T* gC0, T* gA, T* gb, T* gC, int* info, hipStream_t st);
+    int (*marginals_grad)(long B, long Tn, const T* C0, const T* A, const T* C, const T* pm, const T* pS, const T* gm,
+                          const T* gS, T* gmu0, T* gC0, T* gA, T* gb, T* gC, hipStream_t st);
 };
 
 constexpr int MF_MAX_D = 9;        // largest state dimension with a register-resident instantiation

@@ -26,33 +26,34 @@ from .state_space_model import StateSpaceModel
 class _LogLikelihoodPerSeries(torch.autograd.Function):
     """
     Per-series log-likelihood (without the chain-independent constants) as a differentiable torch function of the flat
-    model tensors.  Forward: the fused HIP pipeline.  Backward: Fisher's identity on the smoothed marginals
-    (``mf_kf_loglik_grad_*``, csrc/mf_kernels.hpp) - the posterior chain, its marginal means / covariances and
-    cross-covariances are all HIP kernels, then ONE local kernel per (series, time point) produces every gradient.
-    Replaces the TensorFlow reverse mode over banded_matrices' registered gradients.
+    model tensors and the observation PRECISION (shared ``[m, m]`` or per step ``[B, T, m, m]``: the sites variants).
+    Forward: the fused HIP pipeline.  Backward: Fisher's identity on the smoothed marginals (``mf_kf_loglik_grad_*``,
+    csrc/mf_kernels.hpp) - the posterior chain, its marginal means / covariances and cross-covariances are all HIP kernels,
+    then ONE local kernel per (series, time point) produces every gradient.  How the precision depends on the user's
+    parameters (``chol_obs_covariance``, site natural parameters, the scatter onto a grid) is plain torch outside this
+    function.  Replaces the TensorFlow reverse mode over banded_matrices' registered gradients (SURVEY.md §8f rank 2;
+    callers: models/gaussian_process_regression.py:150-160, models/variational_cvi.py:138-161).
     """
 
     @staticmethod
-    def forward(ctx, mu0, cp0, a_s, b_s, cq, h, y, chol_r, chunks):
+    def forward(ctx, mu0, cp0, a_s, b_s, cq, h, y, r_inv, chunks):
         with torch.no_grad():
-            ssm = StateSpaceModel(mu0, cp0, a_s, b_s, cq)
-            kf = KalmanFilter(ssm, EmissionModel(h), y, chol_r)
+            kf = _RawFilter(StateSpaceModel(mu0, cp0, a_s, b_s, cq), EmissionModel(h), y, r_inv)
             kf._chunks = chunks
             out = kf._log_likelihood_per_series()
-        ctx.save_for_backward(mu0, cp0, a_s, b_s, cq, h, y, chol_r)
+        ctx.save_for_backward(mu0, cp0, a_s, b_s, cq, h, y, r_inv)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        mu0, cp0, a_s, b_s, cq, h, y, chol_r = ctx.saved_tensors
+        mu0, cp0, a_s, b_s, cq, h, y, r_inv = ctx.saved_tensors
         with torch.no_grad():
-            ssm = StateSpaceModel(mu0, cp0, a_s, b_s, cq)
-            kf = KalmanFilter(ssm, EmissionModel(h), y, chol_r)
+            kf = _RawFilter(StateSpaceModel(mu0, cp0, a_s, b_s, cq), EmissionModel(h), y, r_inv)
             post = kf.posterior_state_space_model()
             means = post.marginal_means
             covs, cross = post.covariance_blocks()             # one forward scan of the posterior chain
             bsz, n, m, d = h.shape
-            r_inv = kf._r_inv.contiguous()
+            per_step = r_inv.dim() > 2
             g_mu0, g_cp0 = torch.empty_like(mu0), torch.empty_like(cp0)
             g_a, g_b, g_cq = torch.empty_like(a_s), torch.empty_like(b_s), torch.empty_like(cq)
             g_h, g_y = torch.empty_like(h), torch.empty_like(y)
@@ -61,16 +62,14 @@ class _LogLikelihoodPerSeries(torch.autograd.Function):
             c = lambda t: _lib.ptr(t.contiguous())  # noqa: E731
             w = grad_out.reshape(bsz).contiguous()              # applied inside the kernel: no scaling passes over the outputs
             _lib.call("mf_kf_loglik_grad", h.dtype, bsz, n, d, m, c(mu0), c(cp0), c(a_s), c(b_s), c(cq), c(h), c(y), c(r_inv),
-                      c(means), c(covs), c(cross), _lib.ptr(g_mu0), _lib.ptr(g_cp0), _lib.ptr(g_a), _lib.ptr(g_b),
-                      _lib.ptr(g_cq), _lib.ptr(g_h), _lib.ptr(g_y), _lib.ptr(g_om), _lib.ptr(w), info,
+                      int(per_step), c(means), c(covs), c(cross), _lib.ptr(g_mu0), _lib.ptr(g_cp0), _lib.ptr(g_a),
+                      _lib.ptr(g_b), _lib.ptr(g_cq), _lib.ptr(g_h), _lib.ptr(g_y), _lib.ptr(g_om), _lib.ptr(w), info,
                       _lib.stream_ptr(h.device))
-            # shared observation covariance R = L L^T: d/dL of  -1/2 sum tr(R^-1 Omega)  =  tril(L^-T (L^-1 Omega_w L^-T));
-            # the log-determinant part of R lives in the constants, which torch differentiates outside this function
-            om_w = torch.sum(g_om, dim=(0, 1))
-            eye = torch.eye(m, dtype=h.dtype, device=h.device)
-            l_inv = torch.linalg.solve_triangular(chol_r, eye, upper=False)
-            g_chol_r = torch.tril(l_inv.transpose(-1, -2) @ (l_inv @ om_w @ l_inv.transpose(-1, -2)))
-        return g_mu0, g_cp0, g_a, g_b, g_cq, g_h, g_y, g_chol_r, None
+            _lib.raise_on_info(info, "log_likelihood (backward)", h.device)
+            # d/dR_k^-1 of  -1/2 E[r_k^T R_k^-1 r_k]  =  -1/2 Omega_k (already weighted); a shared precision collects every point.
+            # The log-determinant of the precision lives in the constants, which torch differentiates outside this function.
+            g_r_inv = -0.5 * g_om if per_step else -0.5 * torch.sum(g_om, dim=(0, 1))
+        return g_mu0, g_cp0, g_a, g_b, g_cq, g_h, g_y, g_r_inv, None
 
 
 class BaseKalmanFilter(abc.ABC):
@@ -162,10 +161,10 @@ class BaseKalmanFilter(abc.ABC):
         cst = -0.5 * math.log(2 * math.pi) * (self.emission.output_dim * num_points)
         return cst + 0.5 * self._log_det_observation_precision
 
-    def _log_likelihood_per_series(self) -> torch.Tensor:
+    def _log_likelihood_per_series(self, expanded=None) -> torch.Tensor:
         """Per-series log-likelihood WITHOUT the chain-independent constant terms, shape [B]."""
         mu0, cp0, a_s, b_s, cq = self.prior_ssm._flat_params()
-        h, y, r_inv, per_step = self._expanded()
+        h, y, r_inv, per_step = expanded if expanded is not None else self._expanded()
         bsz, n, d, m = a_s.shape[0], self.prior_ssm.num_transitions + 1, self.prior_ssm.state_dim, h.shape[-2]
         lib = _lib.load()
         esz = a_s.element_size()
@@ -184,16 +183,24 @@ class BaseKalmanFilter(abc.ABC):
         _lib.raise_on_info(info, "KalmanFilter.log_likelihood", a_s.device)
         return out
 
-    def _differentiable_per_series(self) -> Optional[torch.Tensor]:
-        """Per-series values through the autograd function when a model tensor requires a gradient (``KalmanFilter`` only)."""
-        return None
+    def _per_series(self):
+        """``(per-series values [B], differentiable?)``: through the autograd function when any tensor of the model (chain,
+        emission, observations, observation precision / sites) requires a gradient, else the plain fused call.  The
+        emission / observation tensors are expanded (and the lazy observation precision evaluated) once."""
+        expanded = self._expanded()
+        if torch.is_grad_enabled():
+            tensors = self.prior_ssm._flat_params() + expanded[:3]
+            if any(t.requires_grad for t in tensors):
+                if self.prior_ssm.state_dim > _lib.load().mf_max_state_dim() or expanded[0].shape[-2] > 4:
+                    raise NotImplementedError("gradients of log_likelihood: state_dim <= 9 and output_dim <= 4")
+                return _LogLikelihoodPerSeries.apply(*tensors, self._chunks), True
+        return self._log_likelihood_per_series(expanded), False
 
     def log_likelihood(self) -> torch.Tensor:
         """Log marginal likelihood, summed over ``batch_shape`` (kalman_filter.py:184-255)."""
         num_data = self.prior_ssm.num_transitions + 1
-        per_series = self._differentiable_per_series()
-        if per_series is None:
-            per_series = self._log_likelihood_per_series()
+        per_series, differentiable = self._per_series()
+        if not differentiable:
             fused = self._fused_total(per_series, num_data)
             if fused is not None:
                 return fused
@@ -278,15 +285,22 @@ class KalmanFilter(BaseKalmanFilter):
     def _total_terms(self):
         return self._chol_obs_covariance, None
 
-    def _differentiable_per_series(self) -> Optional[torch.Tensor]:
-        mu0, cp0, a_s, b_s, cq = self.prior_ssm._flat_params()
-        h, y, _, _ = self._expanded()
-        tensors = (mu0, cp0, a_s, b_s, cq, h, y, self._chol_obs_covariance)
-        if not torch.is_grad_enabled() or not any(t.requires_grad for t in tensors):
-            return None
-        if self.prior_ssm.state_dim > 9 or h.shape[-2] > 4:
-            raise NotImplementedError("gradients of log_likelihood: state_dim <= 9 and output_dim <= 4")
-        return _LogLikelihoodPerSeries.apply(*tensors, self._chunks)
+
+class _RawFilter(BaseKalmanFilter):
+    """Filter over flat tensors with the observation precision given as is (shared ``[m, m]`` or per step ``[B, T, m, m]``):
+    what the autograd functions evaluate inside."""
+
+    def __init__(self, state_space_model, emission_model, observations, r_inv):
+        super().__init__(state_space_model, emission_model)
+        self._obs, self._precision = observations, r_inv
+
+    @property
+    def _r_inv(self):
+        return self._precision
+
+    @property
+    def observations(self):
+        return self._obs
 
 
 class GaussianSites(abc.ABC):
@@ -424,6 +438,6 @@ class KalmanFilterWithSparseSites(BaseKalmanFilter):
 
     def log_likelihood(self) -> torch.Tensor:
         """Log marginal likelihood; only observed points count in the constants (kalman_filter.py:579-626)."""
-        per_series = self._log_likelihood_per_series()
+        per_series, _ = self._per_series()
         num_data = self.observations_index.shape[0]
         return torch.sum(per_series + self._constant_terms(num_data))

@@ -133,15 +133,38 @@ class StateSpaceModel(GaussMarkovDistribution):
         return out.reshape(lead + (self.num_transitions + 1, self.state_dim))
 
     # -- marginals ----------------------------------------------------------------------------------------
+    def _needs_grad(self) -> bool:
+        return torch.is_grad_enabled() and any(
+            t.requires_grad for t in (self._mu_0, self._chol_P_0, self._A_s, self._b_s, self._chol_Q_s))
+
+    def _differentiable_marginals(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self.state_dim > _lib.load().mf_max_state_dim():
+            raise NotImplementedError("gradients of the marginals: state_dim <= 9")
+        means, covs = _Marginals.apply(*self._flat_params())
+        batch, n, d = tuple(self.batch_shape), self.num_transitions + 1, self.state_dim
+        return means.reshape(batch + (n, d)), covs.reshape(batch + (n, d, d))
+
     @property
     def marginal_means(self) -> torch.Tensor:
         """``μ_{k+1} = A_k μ_k + b_k`` (state_space_model.py:232-251)."""
+        if self._needs_grad():
+            return self._differentiable_marginals()[0]
         return self._propagate(self.concatenated_state_offsets)
 
     @property
     def marginal_covariances(self) -> torch.Tensor:
         """Diagonal blocks of the covariance (state_space_model.py:254-262)."""
+        if self._needs_grad():
+            return self._differentiable_marginals()[1]
         return self._covariance_scan(want_sub=False)[0]
+
+    @property
+    def marginals(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Marginal means and covariances (gauss_markov.py:107-117); differentiable with respect to the chain's parameters
+        (``_Marginals``: the expected log-likelihood of the variational models goes through here)."""
+        if self._needs_grad():
+            return self._differentiable_marginals()
+        return self.marginal_means, self.marginal_covariances
 
     def covariance_blocks(self) -> Tuple[torch.Tensor, torch.Tensor]:
         """Marginal covariances and ``Cov(x_{k+1}, x_k)`` from ONE scan."""
@@ -219,10 +242,17 @@ class StateSpaceModel(GaussMarkovDistribution):
         def leaf(t):
             return t.detach().clone().requires_grad_(True)
 
-        ssm = StateSpaceModel(leaf(self._mu_0), torch.tril(leaf(self._chol_P_0)), leaf(self._A_s), leaf(self._b_s),
-                              torch.tril(leaf(self._chol_Q_s)))
+        leaves = (leaf(self._mu_0), leaf(self._chol_P_0), leaf(self._A_s), leaf(self._b_s), leaf(self._chol_Q_s))
+        ssm = StateSpaceModel(leaves[0], torch.tril(leaves[1]), leaves[2], leaves[3], torch.tril(leaves[4]))
+        ssm._trainable = leaves
         check_compatible(ssm, self)
         return ssm
+
+    @property
+    def trainable_variables(self) -> Tuple[torch.Tensor, ...]:
+        """The leaf tensors of a trainable copy, in constructor order (``tf.Module.trainable_variables`` in the reference);
+        empty for a chain that was not made by ``create_trainable_copy``."""
+        return getattr(self, "_trainable", ())
 
     def _build_precision(self) -> SymmetricBlockTriDiagonal:
         """``K⁻¹ = A⁻ᵀ Q⁻¹ A⁻¹`` in block form (state_space_model.py:431-483)."""
@@ -268,8 +298,18 @@ class StateSpaceModel(GaussMarkovDistribution):
         return torch.sum(self._log_pdf_factors(states), dim=-1)
 
     def kl_divergence(self, dist: GaussMarkovDistribution) -> torch.Tensor:
-        """``KL(self ∥ dist)`` with shape ``batch_shape`` (state_space_model.py:528-593)."""
+        """``KL(self ∥ dist)`` with shape ``batch_shape`` (state_space_model.py:528-593).  Differentiable with respect to the
+        parameters of both chains (``_KLDivergence``)."""
         check_compatible(self, dist)
+        if torch.is_grad_enabled() and isinstance(dist, StateSpaceModel):
+            tensors = self._flat_params() + dist._flat_params()
+            if any(t.requires_grad for t in tensors):
+                if self.state_dim > _lib.load().mf_max_state_dim():
+                    raise NotImplementedError("gradients of kl_divergence: state_dim <= 9")
+                return _KLDivergence.apply(*tensors).reshape(tuple(self.batch_shape))
+        return self._kl_divergence_value(dist)
+
+    def _kl_divergence_value(self, dist: GaussMarkovDistribution) -> torch.Tensor:
         marginal_covs_1, subsequent_covs_1 = self.covariance_blocks()
         precision_2 = dist.precision
         trace = torch.sum(precision_2.block_diagonal * marginal_covs_1, dim=(-3, -2, -1)) + 2.0 * torch.sum(
@@ -289,6 +329,85 @@ class StateSpaceModel(GaussMarkovDistribution):
         l_mean = self.precision.cholesky.dense_mult(self.marginals[0], transpose_left=True)
         mahalanobis = torch.sum(l_mean * l_mean, dim=(-2, -1))
         return 0.5 * (cst + log_det + mahalanobis)
+
+
+class _KLDivergence(torch.autograd.Function):
+    """
+    ``KL(q1 ∥ q2)`` per series as a differentiable function of the flat parameters of both chains.  Forward: the operator
+    kernels.  Backward: the divergence is a sum of terms local in time over q1's marginals, so
+      * the gradient with respect to q2 is MINUS the expected complete-data score of q2 under q1's marginals - the same local
+        kernel as the log-likelihood's backward, without an emission model (``mf_kf_loglik_grad_*`` with ``H = NULL``);
+      * the gradient with respect to q1 is the local partial derivative plus the adjoint of q1's moment recursion: one backward
+        sweep per series (``mf_ssm_kl_grad_*``, csrc/mf_kl_grad.hpp).
+    The reference differentiates state_space_model.py:528-593 through TensorFlow (pinned by
+    tests/integration/models/test_variational.py:123-132: the ELBO gradient vanishes at the optimum).
+    """
+
+    @staticmethod
+    def forward(ctx, *tensors):
+        with torch.no_grad():
+            q1, q2 = StateSpaceModel(*tensors[:5]), StateSpaceModel(*tensors[5:])
+            out = q1._kl_divergence_value(q2)
+        ctx.save_for_backward(*tensors)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        tensors = ctx.saved_tensors
+        mu1, c01, a1, b1, c1, mu2, c02, a2, b2, c2 = tensors
+        with torch.no_grad():
+            q1 = StateSpaceModel(mu1, c01, a1, b1, c1)
+            means = q1.marginal_means
+            covs, cross = q1.covariance_blocks()
+            bsz, d = mu1.shape
+            n = a1.shape[1] + 1
+            dev, dtype = mu1.device, mu1.dtype
+            w = grad_out.reshape(bsz).contiguous()
+            c = lambda t: _lib.ptr(t.contiguous())  # noqa: E731
+            info = _lib.pivot_info(dev)
+            g1 = [torch.empty_like(t) for t in (mu1, c01, a1, b1, c1)]
+            _lib.call("mf_ssm_kl_grad", dtype, bsz, n, d, c(mu1), c(c01), c(a1), c(b1), c(c1), c(mu2), c(c02), c(a2), c(b2),
+                      c(c2), c(means), c(covs), _lib.ptr(w), *[_lib.ptr(g) for g in g1], info, _lib.stream_ptr(dev))
+            g2 = [torch.empty_like(t) for t in (mu2, c02, a2, b2, c2)]
+            neg_w = (-w).contiguous()
+            _lib.call("mf_kf_loglik_grad", dtype, bsz, n, d, 1, c(mu2), c(c02), c(a2), c(b2), c(c2), None, None, None, 0,
+                      c(means), c(covs), c(cross), *[_lib.ptr(g) for g in g2], None, None, None, _lib.ptr(neg_w), info,
+                      _lib.stream_ptr(dev))
+            _lib.raise_on_info(info, "kl_divergence (backward)", dev)
+        return (*g1, *g2)
+
+
+class _Marginals(torch.autograd.Function):
+    """
+    ``(marginal means [B,T,d], marginal covariances [B,T,d,d])`` as a differentiable function of the flat chain parameters.
+    Forward: the mean recursion and the covariance scan (HIP).  Backward: the adjoint of both recursions in ONE backward sweep
+    per series (``mf_ssm_marginals_grad_*``, csrc/mf_kl_grad.hpp).  The reference differentiates
+    state_space_model.py:232-262 through TensorFlow (models/variational.py:150, models/sparse_variational.py:178-192).
+    """
+
+    @staticmethod
+    def forward(ctx, mu0, cp0, a_s, b_s, cq):
+        with torch.no_grad():
+            ssm = StateSpaceModel(mu0, cp0, a_s, b_s, cq)
+            means = ssm._propagate(ssm.concatenated_state_offsets)
+            covs = ssm._covariance_scan(want_sub=False)[0]
+        ctx.save_for_backward(cp0, a_s, cq, means, covs)
+        return means, covs
+
+    @staticmethod
+    def backward(ctx, g_means, g_covs):
+        cp0, a_s, cq, means, covs = ctx.saved_tensors
+        bsz, nt, d = a_s.shape[0], a_s.shape[1], a_s.shape[-1]
+        with torch.no_grad():
+            g_mu0 = torch.empty((bsz, d), dtype=a_s.dtype, device=a_s.device)
+            g_cp0, g_a, g_cq = torch.empty_like(cp0), torch.empty_like(a_s), torch.empty_like(cq)
+            g_b = torch.empty((bsz, nt, d), dtype=a_s.dtype, device=a_s.device)
+            c = lambda t: None if t is None else _lib.ptr(t.contiguous())  # noqa: E731
+            if bsz > 0:
+                _lib.call("mf_ssm_marginals_grad", a_s.dtype, bsz, nt + 1, d, c(cp0), c(a_s), c(cq), c(means), c(covs),
+                          c(g_means), c(g_covs), _lib.ptr(g_mu0), _lib.ptr(g_cp0), _lib.ptr(g_a), _lib.ptr(g_b), _lib.ptr(g_cq),
+                          _lib.stream_ptr(a_s.device))
+        return g_mu0, g_cp0, g_a, g_b, g_cq
 
 
 def state_space_model_from_covariances(

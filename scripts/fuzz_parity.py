@@ -35,9 +35,10 @@ def run(n_cases: int, seed: int) -> dict:
                               float(np.max(np.abs(nn(covs)[s] - oc)) / (1 + np.max(np.abs(oc)))))
       prior = kf.prior_ssm
       pc, ps = prior.covariance_blocks()
-      oc = O.ssm_marginal_covariances(kw["chol_p0"][0], kw["a_s"][0], kw["chol_q"][0])
-      worst["covs"] = max(worst["covs"], float(np.max(np.abs(nn(pc)[0] - oc)) / (1 + np.max(np.abs(oc)))),
-                          float(np.max(np.abs(nn(ps)[0] - O.ssm_subsequent_covariances(kw["a_s"][0], oc))) / (1 + np.max(np.abs(oc)))))
+      for s in range(bsz):                                   # every series, not only the first
+          oc = O.ssm_marginal_covariances(kw["chol_p0"][s], kw["a_s"][s], kw["chol_q"][s])
+          worst["covs"] = max(worst["covs"], float(np.max(np.abs(nn(pc)[s] - oc)) / (1 + np.max(np.abs(oc)))),
+                              float(np.max(np.abs(nn(ps)[s] - O.ssm_subsequent_covariances(kw["a_s"][s], oc))) / (1 + np.max(np.abs(oc)))))
       prec = kf._k_inv_post
       ch = prec.cholesky
       dense = nn(prec.to_dense())
@@ -49,10 +50,10 @@ def run(n_cases: int, seed: int) -> dict:
           want = np.stack([np.linalg.solve(lref[s].T if tr else lref[s], rhs[s].reshape(-1)) for s in range(bsz)])
           worst["solve"] = max(worst["solve"], float(np.max(np.abs(sol - want)) / (1 + np.max(np.abs(want)))))
       kl = nn(post.kl_divergence(prior))
-      s = 0
-      o = O.kf_posterior_ssm(**{k: v[s] for k, v in kw.items()}, r_inv=r_inv)
-      klref = O.ssm_kl_divergence(o, (kw["mu0"][s], kw["chol_p0"][s], kw["a_s"][s], kw["b_s"][s], kw["chol_q"][s]))
-      worst["kl"] = max(worst["kl"], float(abs(kl[s] - klref) / (1 + abs(klref))))
+      for s in range(bsz):
+          o = O.kf_posterior_ssm(**{k: v[s] for k, v in kw.items()}, r_inv=r_inv)
+          klref = O.ssm_kl_divergence(o, (kw["mu0"][s], kw["chol_p0"][s], kw["a_s"][s], kw["b_s"][s], kw["chol_q"][s]))
+          worst["kl"] = max(worst["kl"], float(abs(kl[s] - klref) / (1 + abs(klref))))
   return worst
 
 

@@ -1,0 +1,98 @@
+"""
+BASELINE.json's configurations at their FULL shapes, every series checked:
+  config 2  KalmanFilter.log_likelihood, B=256, T=4096, d=4, fp64 - its automatic time partition (256 chunks of 16 steps) is
+            a code path of its own; every series against the C restatement of the reference algorithm (oracle/c);
+  config 3  SymmetricBlockTriDiagonal.cholesky + solve, T=100000, d=6, fp32, one chain - on the posterior precision of a real
+            state space model (not a synthetic factor), against the fp64 C oracle;
+  config 4  per-GPU shape B=512, T=1000, d=9 (3 x Matern-5/2), m=3, fp64: log-likelihood, posterior marginals and
+            KL(posterior || prior) for EVERY series against the oracles.
+Tolerances are written at each assertion.  The chains are Matern state space models (markovflow/kernels/matern.py closed forms),
+i.e. ill-conditioned on purpose: that is what the reference's users feed the path.
+"""
+import numpy as np
+import pytest
+import torch
+
+import markovflow_amd as mfa
+from markovflow_amd import synthetic
+from oracle import c_oracle as C
+from oracle import numpy_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _host(inp):
+    return {k: v.detach().cpu().numpy().astype(np.float64) for k, v in inp.items()}
+
+
+def test_config2_full_shape_every_series_vs_c_oracle():
+    bsz, t = 256, 4096
+    inp = synthetic.make_ssm(bsz, t, (3, 3), dtype=torch.float64, device=DEV)
+    kf = synthetic.kalman_filter_from(inp)
+    per = (kf._log_likelihood_per_series() + kf._constant_terms(t)).cpu().numpy()
+    hst = _host(inp)
+    r_inv = np.linalg.inv(hst["cholR"] @ hst["cholR"].T)
+    ref = C.kf_loglik(hst["mu0"], hst["cholP0"], hst["A"], hst["b"], hst["cholQ"], hst["H"], hst["y"], r_inv)
+    assert per.shape == ref.shape == (bsz,)
+    np.testing.assert_allclose(per, ref, rtol=1e-9)                      # per series, fp64
+    assert float(kf.log_likelihood()) == pytest.approx(float(ref.sum()), rel=1e-10)
+    # the automatic partition really is the many-short-chunks one; an explicit single chunk agrees with it
+    kf._chunks = 1
+    np.testing.assert_allclose((kf._log_likelihood_per_series() + kf._constant_terms(t)).cpu().numpy(), ref, rtol=1e-9)
+
+
+def test_config4_shape_loglik_posterior_and_kl_every_series():
+    bsz, t, d, m = 512, 1000, 9, 3
+    inp = synthetic.make_ssm(bsz, t, (5, 5, 5), output_dim=3, dtype=torch.float64, device=DEV)
+    kf = synthetic.kalman_filter_from(inp)
+    hst = _host(inp)
+    r_inv = np.linalg.inv(hst["cholR"] @ hst["cholR"].T)
+    args = (hst["mu0"], hst["cholP0"], hst["A"], hst["b"], hst["cholQ"], hst["H"], hst["y"], r_inv)
+    # log-likelihood, every series: fp64, rtol 1e-9 against the C restatement
+    per = (kf._log_likelihood_per_series() + kf._constant_terms(t)).cpu().numpy()
+    np.testing.assert_allclose(per, C.kf_loglik(*args), rtol=1e-9)
+    # posterior chain -> marginal means / covariances of every series against the numpy oracle's posterior chain.
+    # Matern-5/2 process covariances over gaps of ~0.1 have eigenvalues down to 1e-9 (the jitter): both sides lose about half
+    # the digits in the UDU^T sweep, so means are compared to 1e-6 of the state scale and covariances to rtol 1e-5.
+    post = kf.posterior_state_space_model()
+    mu0p, cp0p, ap, bp, cqp = O.kf_posterior_ssm(*args)
+    ref_means = O.ssm_marginal_means(mu0p, ap, bp)
+    ref_covs = O.ssm_marginal_covariances(cp0p, ap, cqp)
+    means, covs = post.marginal_means.cpu().numpy(), post.marginal_covariances.cpu().numpy()
+    scale = np.abs(ref_means).max(axis=(1, 2), keepdims=True)
+    assert np.max(np.abs(means - ref_means) / scale) < 1e-6
+    cscale = np.abs(ref_covs).max(axis=(2, 3), keepdims=True)
+    assert np.max(np.abs(covs - ref_covs) / cscale) < 1e-5
+    # KL(posterior || prior), every series (the ELBO term of config 4's sparse-variational model)
+    kl = post.kl_divergence(kf.prior_ssm).cpu().numpy()
+    prior = (hst["mu0"], hst["cholP0"], hst["A"], hst["b"], hst["cholQ"])
+    ref_kl = O.ssm_kl_divergence((mu0p, cp0p, ap, bp, cqp), prior)
+    assert kl.shape == (bsz,) and np.all(ref_kl > 0)
+    np.testing.assert_allclose(kl, ref_kl, rtol=1e-6)
+
+
+def test_config3_cholesky_and_solve_on_a_real_posterior_precision_fp32():
+    """T = 100000, d = 6, fp32, one chain: the posterior precision K^-1 + H^T R^-1 H of a sum of three Matern-3/2 components
+    (gaps 0.2 + Exp(0.3): well enough conditioned for fp32), factorised by the parallel-in-time path, against the fp64
+    C oracle on the same (fp32-rounded) matrix.  Tolerance: 2e-3 of the block scale (fp32, ~1e5 dependent block steps)."""
+    n, d = 100000, 6
+    inp = synthetic.make_ssm(1, n, (3, 3, 3), dtype=torch.float64, device=DEV, dt_min=0.2, dt_scale=0.3)
+    prec = synthetic.kalman_filter_from(inp)._k_inv_post
+    diag32 = prec.block_diagonal.float().contiguous()
+    sub32 = prec.block_sub_diagonal.float().contiguous()
+    sym = mfa.SymmetricBlockTriDiagonal(diag32, sub32)
+    chol = sym.cholesky
+    ld_ref, ls_ref = C.btd_cholesky(diag32.double().cpu().numpy(), sub32.double().cpu().numpy())
+    ld, ls = chol.block_diagonal.cpu().numpy().astype(np.float64), chol.block_sub_diagonal.cpu().numpy().astype(np.float64)
+    assert np.isfinite(ld).all() and np.isfinite(ls).all()
+    sc = np.abs(ld_ref).max(axis=(-2, -1), keepdims=True)
+    assert np.max(np.abs(ld - ld_ref) / sc) < 2e-3
+    assert np.max(np.abs(ls - ls_ref) / sc[:, 1:]) < 2e-3
+    rhs = torch.randn(1, n, d, dtype=torch.float32, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+    out = chol.solve(rhs).cpu().numpy().astype(np.float64)
+    ref = C.btd_solve(ld_ref, ls_ref, rhs.double().cpu().numpy())
+    assert np.max(np.abs(out - ref)) < 2e-3 * np.abs(ref).max()
+    out_t = chol.solve(rhs, transpose_left=True).cpu().numpy().astype(np.float64)
+    ref_t = C.btd_solve(ld_ref, ls_ref, rhs.double().cpu().numpy(), transpose=True)
+    assert np.max(np.abs(out_t - ref_t)) < 2e-3 * np.abs(ref_t).max()
