@@ -315,6 +315,20 @@ int mf_ssm_kl_grad_f32(int64_t B, int64_t T, int d, const float* mu0_1, const fl
                        float* g_mu0, float* g_cholP0, float* g_A, float* g_b, float* g_cholQ, int* info, void* stream);
 
 /*
+ * KL(q1 || q2) between two state space models, one scalar per series (markovflow/state_space_model.py:528-593), fused: ONE
+ * forward sweep per series carries q1's marginal mean and covariance in registers and accumulates the divergence from the
+ * local form  1/2 sum_k [ tr(Q2^-1 Q1) + tr(Q2^-1 dA S_k dA^T) + eps_k^T Q2^-1 eps_k ] - T d / 2 + log-determinants
+ * (csrc/mf_kl_grad.hpp) - the ten parameter tensors are read once and nothing else touches HBM.  One lane per series:
+ * meant for batches that fill the chip (the Python layer takes the operator route for few, long chains).  State dimension 1..9.
+ */
+int mf_ssm_kl_divergence_f64(int64_t B, int64_t T, int d, const double* mu0_1, const double* cholP0_1, const double* A_1,
+                             const double* b_1, const double* cholQ_1, const double* mu0_2, const double* cholP0_2,
+                             const double* A_2, const double* b_2, const double* cholQ_2, double* out, int* info, void* stream);
+int mf_ssm_kl_divergence_f32(int64_t B, int64_t T, int d, const float* mu0_1, const float* cholP0_1, const float* A_1,
+                             const float* b_1, const float* cholQ_1, const float* mu0_2, const float* cholP0_2, const float* A_2,
+                             const float* b_2, const float* cholQ_2, float* out, int* info, void* stream);
+
+/*
  * Adjoint of the marginal recursion  m_{k+1} = A_k m_k + b_k,  S_{k+1} = A_k S_k A_k^T + Q_k  (markovflow/state_space_model.py:232-262,
  * differentiated by TensorFlow in the reference: the expected log-likelihood of every variational model goes through
  * `marginals`, models/variational.py:150, models/sparse_variational.py:178-192).  Given the incoming gradients g_means [B,T,d] and

@@ -360,6 +360,17 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         return t->kl_grad(B, Tn, mu0_1, cholP0_1, A_1, b_1, cholQ_1, mu0_2, cholP0_2, A_2, b_2, cholQ_2, means_1,      \
                           covs_1, weights, g_mu0, g_cholP0, g_A, g_b, g_cholQ, info, S(stream));                       \
     }                                                                                                                  \
+    int mf_ssm_kl_divergence_##SUF(int64_t B, int64_t Tn, int d, const T* mu0_1, const T* cholP0_1, const T* A_1,      \
+                                   const T* b_1, const T* cholQ_1, const T* mu0_2, const T* cholP0_2, const T* A_2,    \
+                                   const T* b_2, const T* cholQ_2, T* out, int* info, void* stream) {                  \
+        MF_HEAD(T, B, Tn, d)                                                                                           \
+        if (big) return -100;                                                                                          \
+        if (!mu0_1 || !cholP0_1 || (Tn > 1 && (!A_1 || !b_1 || !cholQ_1))) return -4;                                  \
+        if (!mu0_2 || !cholP0_2 || (Tn > 1 && (!A_2 || !b_2 || !cholQ_2))) return -9;                                  \
+        if (!out) return -14;                                                                                          \
+        return t->kl(B, Tn, mu0_1, cholP0_1, A_1, b_1, cholQ_1, mu0_2, cholP0_2, A_2, b_2, cholQ_2, out, info,         \
+                     S(stream));                                                                                       \
+    }                                                                                                                  \
     int mf_ssm_marginals_grad_##SUF(int64_t B, int64_t Tn, int d, const T* cholP0, const T* A, const T* cholQ,         \
                                     const T* means, const T* covs, const T* g_means, const T* g_covs, T* g_mu0,        \
                                     T* g_cholP0, T* g_A, T* g_b, T* g_cholQ, void* stream) {                           \

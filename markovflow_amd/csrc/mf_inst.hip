@@ -779,6 +779,14 @@ int kl_grad(long B, long Tn, const T* mu0_1, const T* C0_1, const T* A_1, const 
 }
 
 template <typename T>
+int kl_value(long B, long Tn, const T* mu0_1, const T* C0_1, const T* A_1, const T* b_1, const T* C_1, const T* mu0_2,
+             const T* C0_2, const T* A_2, const T* b_2, const T* C_2, T* out, int* info, hipStream_t st) {
+    hipLaunchKernelGGL((ssm_kl_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, Tn, mu0_1, C0_1, A_1, b_1, C_1,
+                       mu0_2, C0_2, A_2, b_2, C_2, out, info);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+template <typename T>
 int marginals_grad(long B, long Tn, const T* C0, const T* A, const T* C, const T* pm, const T* pS, const T* gm, const T* gS,
                    T* gmu0, T* gC0, T* gA, T* gb, T* gC, hipStream_t st) {
     hipLaunchKernelGGL((ssm_marginals_grad_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, Tn, C0, A, C, pm,
@@ -790,7 +798,7 @@ template <typename T> const OpsTable<T>* table() {
     static const OpsTable<T> t = {
         &kf_loglik_ws<T>, &kf_loglik<T>, &btd_logdet_quad_ws<T>, &btd_logdet_quad<T>, &btd_cholesky_ws<T>, &btd_cholesky<T>,
         &btd_solve_ws<T>, &btd_solve<T>,    &btd_matvec<T>, &btd_logdet<T>,        &btd_diag_of_inverse_ws<T>, &btd_diag_of_inverse<T>, &ssm_marginal_covs<T>, &btd_udl_ws<T>, &btd_udl<T>,
-        &ssm_precision<T>, &ssm_means<T>, &block_matmul<T>, &gpr_loglik<T>, &sde_predict<T>, &kf_grad<T>, &kl_grad<T>, &marginals_grad<T>,
+        &ssm_precision<T>, &ssm_means<T>, &block_matmul<T>, &gpr_loglik<T>, &sde_predict<T>, &kf_grad<T>, &kl_grad<T>, &kl_value<T>, &marginals_grad<T>,
     };
     return &t;
 }

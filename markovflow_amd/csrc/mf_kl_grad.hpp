@@ -20,6 +20,115 @@
 
 namespace mf {
 
+// ---- the divergence itself, fused ----------------------------------------------------------------------------------------
+// The same local form gives KL(q1 || q2) in ONE forward sweep per series that carries q1's marginal (m_k, S_k) in registers:
+//   KL = 1/2 [ |C0_2^-1 C0_1|_F^2 + |C0_2^-1 d0|^2 ] + sum_k 1/2 [ |C2_k^-1 C1_k|_F^2 + tr(W_k S_k W_k^T) + |C2_k^-1 eps_k|^2 ]
+//        - T d / 2 + sum log|C2| - sum log|C1|,        W_k = C2_k^-1 dA_k,  eps_k = dA_k m_k + db_k.
+// Reads the ten parameter tensors once ((4 d^2 + 2 d) s bytes per step) and writes one scalar per series: nothing of the
+// reference's route - marginal covariances of q1, precision of q2, a block-sparse trace, two mean scans, a symmetric product
+// (state_space_model.py:569-593) - is materialised.  One lane per series: used when there are enough series to fill the chip.
+template <typename T, int D>
+__global__ void __launch_bounds__(64) ssm_kl_kernel(long B, long Tn, const T* __restrict__ mu0_1, const T* __restrict__ C0_1,
+                                                    const T* __restrict__ A_1, const T* __restrict__ b_1,
+                                                    const T* __restrict__ C_1, const T* __restrict__ mu0_2,
+                                                    const T* __restrict__ C0_2, const T* __restrict__ A_2,
+                                                    const T* __restrict__ b_2, const T* __restrict__ C_2, T* __restrict__ out,
+                                                    int* info) {
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= B) return;
+    LogAcc<T> l1, l2;
+    l1.init();
+    l2.init();
+    bool bad = false;
+    T m[D], S[D][D];        // S: lower triangle
+    T acc = T(0);
+    // squared Frobenius norm of C2i * C1 (lower x lower) and S <- (C1 C1^T) (+ S if `add`)
+    auto chol_terms = [&](const T (&C2i)[D][D], const T (&C1)[D][D]) {
+        T sum = T(0);
+        MF_UNROLL for (int i = 0; i < D; ++i)
+            MF_UNROLL for (int j = 0; j <= i; ++j) {
+                T a = T(0);
+                MF_UNROLL for (int l = j; l <= i; ++l) a += C2i[i][l] * C1[l][j];
+                sum += a * a;
+            }
+        return sum;
+    };
+    {
+        T C1[D][D], C2[D][D], C2i[D][D], d0[D], u[D];
+        load_lower<T, D>(C0_1 + s * D * D, C1);
+        load_lower<T, D>(C0_2 + s * D * D, C2);
+        tri_inv_lower<T, D>(C2, C2i, l2, bad);
+        MF_UNROLL for (int i = 0; i < D; ++i) {
+            l1.mul(C1[i][i]);
+            bad |= !(C1[i][i] != T(0));
+            m[i] = mu0_1[s * D + i];
+            d0[i] = m[i] - mu0_2[s * D + i];
+        }
+        trimul_lower_vec<T, D>(C2i, d0, u);
+        acc += chol_terms(C2i, C1) + dot_self<T, D>(u);
+        MF_UNROLL for (int i = 0; i < D; ++i)
+            MF_UNROLL for (int j = 0; j <= i; ++j) {
+                T a = T(0);
+                MF_UNROLL for (int l = 0; l <= j; ++l) a += C1[i][l] * C1[j][l];
+                S[i][j] = a;
+            }
+    }
+    for (long k = 0; k + 1 < Tn; ++k) {
+        const long tid = s * (Tn - 1) + k;
+        T A1[D][D], W[D][D], C1[D][D], C2[D][D], C2i[D][D], eps[D], u[D], mn[D];
+        load_mat<T, D, D>(A_1 + tid * D * D, A1);
+        load_mat<T, D, D>(A_2 + tid * D * D, W);
+        load_lower<T, D>(C_1 + tid * D * D, C1);
+        load_lower<T, D>(C_2 + tid * D * D, C2);
+        MF_UNROLL for (int i = 0; i < D; ++i) {
+            mn[i] = b_1[tid * D + i];
+            eps[i] = mn[i] - b_2[tid * D + i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        tri_inv_lower<T, D>(C2, C2i, l2, bad);
+        MF_UNROLL for (int i = 0; i < D; ++i) {
+            l1.mul(C1[i][i]);
+            bad |= !(C1[i][i] != T(0));
+            MF_UNROLL for (int j = 0; j < D; ++j) W[i][j] = A1[i][j] - W[i][j];          // dA
+        }
+        MF_UNROLL for (int j = 0; j < D; ++j)
+            MF_UNROLL for (int i = 0; i < D; ++i) {
+                eps[i] += W[i][j] * m[j];
+                mn[i] += A1[i][j] * m[j];
+            }
+        trimul_lower_vec<T, D>(C2i, eps, u);
+        acc += chol_terms(C2i, C1) + dot_self<T, D>(u);
+        trimul_lower_inplace<T, D, D>(C2i, W);                                            // W = C2^-1 dA
+        // tr(W S W^T) = sum_ij (W S)_ij W_ij with S symmetric (held in its lower triangle)
+        MF_UNROLL for (int i = 0; i < D; ++i) {
+            T row[D];
+            MF_UNROLL for (int j = 0; j < D; ++j) row[j] = T(0);
+            MF_UNROLL for (int l = 0; l < D; ++l)
+                MF_UNROLL for (int j = 0; j < D; ++j) row[j] += W[i][l] * ((l >= j) ? S[l][j] : S[j][l]);
+            MF_UNROLL for (int j = 0; j < D; ++j) acc += row[j] * W[i][j];
+        }
+        // S <- A1 S A1^T + C1 C1^T,  m <- A1 m + b1
+        T AS[D][D];
+        MF_UNROLL for (int i = 0; i < D; ++i) {
+            MF_UNROLL for (int j = 0; j < D; ++j) AS[i][j] = T(0);
+            MF_UNROLL for (int l = 0; l < D; ++l)
+                MF_UNROLL for (int j = 0; j < D; ++j) AS[i][j] += A1[i][l] * ((l >= j) ? S[l][j] : S[j][l]);
+        }
+        MF_UNROLL for (int i = 0; i < D; ++i)
+            MF_UNROLL for (int j = 0; j <= i; ++j) {
+                T a = T(0);
+                MF_UNROLL for (int l = 0; l < D; ++l) a += AS[i][l] * A1[j][l];
+                MF_UNROLL for (int l = 0; l <= j; ++l) a += C1[i][l] * C1[j][l];
+                S[i][j] = a;
+            }
+        MF_UNROLL for (int i = 0; i < D; ++i) m[i] = mn[i];
+        l1.renorm();
+        l2.renorm();
+    }
+    out[s] = T(0.5) * (acc - T(Tn) * T(D)) + l2.value() - l1.value();
+    if (bad && info) raise_info(info);
+}
+
 template <typename T, int D>
 struct KlGradArgs {
     long B, Tn;

@@ -309,7 +309,26 @@ class StateSpaceModel(GaussMarkovDistribution):
                 return _KLDivergence.apply(*tensors).reshape(tuple(self.batch_shape))
         return self._kl_divergence_value(dist)
 
+    # batches at least this large (or chains this short) take the fused one-lane-per-series sweep; fewer, longer chains keep
+    # the operator route, whose scans are parallel in time
+    _KL_FUSED_MIN_SERIES = 2048
+    _KL_FUSED_MAX_SERIAL_BLOCKS = 64
+
     def _kl_divergence_value(self, dist: GaussMarkovDistribution) -> torch.Tensor:
+        bsz = int(math.prod(self.batch_shape))
+        n, d = self.num_transitions + 1, self.state_dim
+        if isinstance(dist, StateSpaceModel) and d <= _lib.load().mf_max_state_dim() and bsz > 0 and (
+                bsz >= self._KL_FUSED_MIN_SERIES or n <= self._KL_FUSED_MAX_SERIAL_BLOCKS):
+            out = torch.empty(bsz, dtype=self._A_s.dtype, device=self._A_s.device)
+            info = _lib.pivot_info(out.device)
+            _lib.call("mf_ssm_kl_divergence", out.dtype, bsz, n, d, *[_lib.ptr(t) for t in self._flat_params()],
+                      *[_lib.ptr(t) for t in dist._flat_params()], _lib.ptr(out), info, _lib.stream_ptr(out.device))
+            _lib.raise_on_info(info, "StateSpaceModel.kl_divergence", out.device)
+            return out.reshape(tuple(self.batch_shape))
+        return self._kl_divergence_operators(dist)
+
+    def _kl_divergence_operators(self, dist: GaussMarkovDistribution) -> torch.Tensor:
+        """The reference's route (state_space_model.py:569-593) over the operator kernels."""
         marginal_covs_1, subsequent_covs_1 = self.covariance_blocks()
         precision_2 = dist.precision
         trace = torch.sum(precision_2.block_diagonal * marginal_covs_1, dim=(-3, -2, -1)) + 2.0 * torch.sum(

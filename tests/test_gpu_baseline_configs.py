@@ -49,9 +49,12 @@ def test_config4_shape_loglik_posterior_and_kl_every_series():
     hst = _host(inp)
     r_inv = np.linalg.inv(hst["cholR"] @ hst["cholR"].T)
     args = (hst["mu0"], hst["cholP0"], hst["A"], hst["b"], hst["cholQ"], hst["H"], hst["y"], r_inv)
-    # log-likelihood, every series: fp64, rtol 1e-9 against the C restatement
+    # log-likelihood, every series, fp64 against the C restatement: rtol 5e-9.  (Three Matern-5/2 components at gaps of ~0.1:
+    # the process covariances have eigenvalues down to the 1e-9 jitter, and two different elimination orders - natural order
+    # in the oracle, partitioned on the GPU - then differ by up to 1.7e-9 on 2 % of the series; measured r02.  The better
+    # conditioned configurations above and below hold 1e-9.)
     per = (kf._log_likelihood_per_series() + kf._constant_terms(t)).cpu().numpy()
-    np.testing.assert_allclose(per, C.kf_loglik(*args), rtol=1e-9)
+    np.testing.assert_allclose(per, C.kf_loglik(*args), rtol=5e-9)
     # posterior chain -> marginal means / covariances of every series against the numpy oracle's posterior chain.
     # Matern-5/2 process covariances over gaps of ~0.1 have eigenvalues down to 1e-9 (the jitter): both sides lose about half
     # the digits in the UDU^T sweep, so means are compared to 1e-6 of the state scale and covariances to rtol 1e-5.

@@ -402,3 +402,20 @@ def test_operations_without_a_backward_fail_loudly(rng):
     with torch.no_grad():
         assert torch.isfinite(kf.posterior_state_space_model().marginal_means).all()
     assert torch.isfinite(ssm.create_non_trainable_copy().precision.cholesky.block_diagonal).all()
+
+
+@pytest.mark.parametrize("d,t,bsz", [(1, 1 + 1, 3), (3, 100, 4), (6, 257, 2), (9, 70, 2)])
+def test_kl_fused_sweep_and_operator_route_agree_with_the_oracle(rng, monkeypatch, d, t, bsz):
+    """kl_divergence has two routes: the fused one-lane-per-series sweep (many series / short chains) and the reference's
+    route over the operator kernels (few long chains).  Both against the numpy restatement of state_space_model.py:528-593."""
+    from oracle import numpy_oracle as O
+    kw1 = random_ssm(rng, (bsz,), t, d, 1, well=True)
+    kw2 = random_ssm(rng, (bsz,), t, d, 1, well=True)
+    ref = O.ssm_kl_divergence(tuple(kw1[k] for k in CHAIN), tuple(kw2[k] for k in CHAIN))
+    q1 = mfa.StateSpaceModel(*(tt(kw1[k]) for k in CHAIN))
+    q2 = mfa.StateSpaceModel(*(tt(kw2[k]) for k in CHAIN))
+    monkeypatch.setattr(mfa.StateSpaceModel, "_KL_FUSED_MIN_SERIES", 1)
+    fused = q1.kl_divergence(q2).cpu().numpy()
+    ops = q1._kl_divergence_operators(q2).cpu().numpy()
+    np.testing.assert_allclose(fused, ref, rtol=1e-9)
+    np.testing.assert_allclose(ops, ref, rtol=1e-9)
