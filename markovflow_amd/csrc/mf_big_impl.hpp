@@ -499,6 +499,23 @@ struct BigArgs {
     int* info;
 };
 
+// Phase timing of the level-0 step (diagnostic builds only: -DMF_BIG_STAMP; scripts/bench_big.py prints the table that
+// block 0 emits).  s_memtime on thread 0 between the phases of a step, accumulated over the chunk.
+#ifdef MF_BIG_STAMP
+#define MF_STAMP_DECL unsigned long long st_acc[12] = {0}, st_prev = __builtin_readcyclecounter();
+#define MF_STAMP(i) { const unsigned long long now = __builtin_readcyclecounter(); st_acc[i] += now - st_prev; st_prev = now; }
+#define MF_STAMP_PRINT(steps)                                                                                          \
+    if (blockIdx.x == 1 && threadIdx.x == 0) {                                                                         \
+        printf("big step phases (memtime ticks per step, %ld steps):", (long)(steps));                                 \
+        for (int i = 0; i < 12; ++i) printf(" [%d] %.0f", i, (double)st_acc[i] / (double)((steps) > 0 ? (steps) : 1)); \
+        printf("\n");                                                                                                  \
+    }
+#else
+#define MF_STAMP_DECL
+#define MF_STAMP(i)
+#define MF_STAMP_PRINT(steps)
+#endif
+
 // Level 0: workgroup (s, c) eliminates the transitions [c L, min((c+1) L, T-1)) of series s.
 template <int DP> __global__ void __launch_bounds__(NTHR) big_kf_chunk_kernel(BigArgs a, RedSys<real> out) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -543,19 +560,26 @@ template <int DP> __global__ void __launch_bounds__(NTHR) big_kf_chunk_kernel(Bi
         pfb = (threadIdx.x < d) ? a.b[(s * nt + tau) * d + threadIdx.x] : 0.f;
     };
     if (len > 0) prefetch(tau0);
+    MF_STAMP_DECL
     for (long j = 0; j < len; ++j) {
         const long tau = tau0 + j;
+        MF_STAMP(11)
         pfC.store(U1);
         pfA.store(U2);
         if (threadIdx.x < DP) sm.vec(V_M)[threadIdx.x] = pfb;
         __syncthreads();
         if (j + 1 < len) prefetch(tau + 1);      // in flight during the whole step
+        MF_STAMP(0)
         logC += (double)factor_invert<DP, false>(U1, Ci, bad, sm.scratch());
+        MF_STAMP(1)
         matvec<DP, 0>(Ci, sm.vec(V_M), sm.vec(V_W), 1.f, 0.f, sm.scratch());
         acc_ww += (double)sumsq<DP>(sm.vec(V_W));
+        MF_STAMP(2)
         gemm<DP, 0, 0, 0, K_A_LOWER, O_FULL>(Ci, U2, U1, 1.f);                                    // Bm = Ci A
         __syncthreads();
+        MF_STAMP(3)
         matvec<DP, 1>(U1, sm.vec(V_W), sm.vec(V_BTW), 1.f, 0.f, sm.scratch());                    // Bm^T w
+        MF_STAMP(2)
         if (j == 0 && spike) {
             // the block on the left is the chunk's separator: its coupling seeds the spike
             gemm<DP, 1, 0, 0, K_FULL, O_FULL>(U1, U1, sm.tile(T_GU), 1.f);                         // GU = Bm^T Bm
@@ -567,15 +591,36 @@ template <int DP> __global__ void __launch_bounds__(NTHR) big_kf_chunk_kernel(Bi
             gemm<DP, 1, 0, 1, K_FULL, O_FULL>(U1, U1, Phi, 1.f);                                  // Phi += Bm^T Bm
             if (threadIdx.x < DP) sm.vec(V_T)[threadIdx.x] -= sm.vec(V_BTW)[threadIdx.x];
             __syncthreads();
+            MF_STAMP(4)
+#ifdef MF_BIG_STAMP
+            logL += (double)factor_invert<DP, true>(sm.tile(T_PHI), sm.tile(T_U2), bad, sm.scratch());
+            MF_STAMP(5)
+            matvec<DP, 0>(sm.tile(T_U2), sm.vec(V_T), sm.vec(V_Z), 1.f, 0.f, sm.scratch());
+            quad += (double)sumsq<DP>(sm.vec(V_Z));
+            MF_STAMP(2)
+            if (spike) {
+                gemm<DP, 0, 0, 0, K_A_LOWER, O_FULL>(sm.tile(T_U2), sm.tile(T_X), sm.tile(T_U4), 1.f);
+                __syncthreads();
+                gemm<DP, 1, 0, 1, K_FULL, O_FULL>(sm.tile(T_U4), sm.tile(T_U4), sm.tile(T_GU), -1.f);
+                MF_STAMP(6)
+                matvec<DP, 1>(sm.tile(T_U4), sm.vec(V_Z), sm.vec(V_GU), -1.f, 1.f, sm.scratch());
+                MF_STAMP(2)
+            }
+#else
             eliminate<DP>(sm, spike, logL, quad, bad);
+#endif
             gemm<DP, 0, 1, 0, K_B_UPPER, O_FULL>(U1, U2, sm.tile(T_X), 1.f);                       // Y = Bm Linv^T
             __syncthreads();
             gemm<DP, 1, 0, 0, K_A_UPPER, O_FULL>(Ci, sm.tile(T_X), U1, -1.f);                      // W = -Ci^T Y
             __syncthreads();
+            MF_STAMP(7)
             own_terms(tau + 1, sm.vec(V_RN));
+            MF_STAMP(8)
             advance<DP>(sm, spike);
+            MF_STAMP(9)
         }
     }
+    MF_STAMP_PRINT(len)
     store_chunk_big<DP>(sm, out, id, d, (real)(-0.5 * (acc_yry + acc_ww) + 0.5 * quad - logC - logL));
     if (threadIdx.x == 0 && bad && a.info) raise_info(a.info);
 }

@@ -85,6 +85,11 @@ template <typename T> bool x_path() {
     static const bool on = [] { const char* e = mf_knob("MF_KF_X"); return !(e && e[0] == '0'); }();
     return on && ((sizeof(T) == 8 && D >= 7) || (sizeof(T) == 4 && D >= 9));
 }
+// H_k, y_k staged in LDS by the spike-in-LDS kernel (several outputs): only when the larger image keeps the waves per CU
+template <typename T> bool x_obs_lds(int m) {
+    const int a = LdsSpike<T, D>::BYTES, b = a + LdsObs<T, D>::bytes(m);
+    return (160 * 1024) / b >= 1 && ((160 * 1024) / b == (160 * 1024) / a || (160 * 1024) / b >= 4);
+}
 // lanes that fill the chip with the spike of every lane in LDS
 template <typename T> long x_target_lanes() {
     int w = (160 * 1024) / LdsSpike<T, D>::BYTES;
@@ -236,7 +241,18 @@ int kf_loglik(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A,
     if (ev0) (void)hipEventRecord(ev0, st);
     if (pl.path == KF_PATH_X) {
         constexpr int x_lds = LdsSpike<T, D>::BYTES;
-        hipLaunchKernelGGL((kf_chunk_x_kernel<T, D>), grid, block, x_lds, st, a, lvl0);
+        if (m > 1 && x_obs_lds<T>(m)) {
+            const int lds = x_lds + LdsObs<T, D>::bytes(m);
+            if (lds > 64 * 1024) {         // past the default dynamic-LDS limit of a kernel: raise it (once per process)
+                static const hipError_t raised = hipFuncSetAttribute(
+                    reinterpret_cast<const void*>(&kf_chunk_x_kernel<T, D, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                    x_lds + LdsObs<T, D>::bytes(MF_MAXM));
+                if (raised != hipSuccess) return -1000;
+            }
+            hipLaunchKernelGGL((kf_chunk_x_kernel<T, D, true>), grid, block, lds, st, a, lvl0);
+        } else {
+            hipLaunchKernelGGL((kf_chunk_x_kernel<T, D, false>), grid, block, x_lds, st, a, lvl0);
+        }
     } else if (pl.path == KF_PATH_LDS) {
         const long L = pl.L;
         auto launch = [&](auto mtag, auto rtag) {

@@ -139,8 +139,52 @@ MF_DEV T obs_apply_pairs(const T* __restrict__ Hk, const T* __restrict__ yk, con
     return yry;
 }
 
+// The same with H_k (m x D) and y_k staged in LDS by the step's load group (element e of lane l at word e * 64 + l): with
+// several outputs the pair-by-pair form above pays a dependent global round trip per (output, output) pair - 12 per step at
+// m = 3 with one or two waves per CU to hide them.  OBS_LDS is chosen by the launcher when the image still fits the CU with the
+// same number of waves (mf_inst.hip: x_obs_lds).
+template <typename T, int D> struct LdsObs {
+    static constexpr int bytes(int m) { return (m * D + m) * 64 * (int)sizeof(T); }      // sized for the call's m outputs
+    T* h;
+    T* y;
+    MF_DEV void bind(T* base, int lane, int m) { h = base + lane; y = base + m * D * 64 + lane; }
+    // the step's observation rows: global -> registers -> LDS, issued with the step's other loads
+    MF_DEV void stage(const T* __restrict__ Hk, const T* __restrict__ yk, int m) const {
+        T hv[MF_MAXM][D], yv[MF_MAXM];
+        MF_UNROLL for (int o = 0; o < MF_MAXM; ++o) {
+            const int oc = o < m ? o : m - 1;                       // clamped: always a valid address, unused rows ignored
+            yv[o] = yk[oc];
+            MF_UNROLL for (int i = 0; i < D; ++i) hv[o][i] = Hk[oc * D + i];
+        }
+        MF_UNROLL for (int o = 0; o < MF_MAXM; ++o) {
+            if (o < m) {
+                y[o * 64] = yv[o];
+                MF_UNROLL for (int i = 0; i < D; ++i) h[(o * D + i) * 64] = hv[o][i];
+            }
+        }
+    }
+    MF_DEV T apply(const T* __restrict__ Ri, int m, T (&Phi)[D][D], T (&t)[D]) const {
+        T yry = T(0);
+        for (int o = 0; o < m; ++o) {
+            T ry = T(0);
+            for (int p = 0; p < m; ++p) ry += Ri[o * m + p] * y[p * 64];
+            yry += y[o * 64] * ry;
+            T ho[D];
+            MF_UNROLL for (int i = 0; i < D; ++i) ho[i] = h[(o * D + i) * 64];
+            MF_UNROLL for (int i = 0; i < D; ++i) t[i] += ho[i] * ry;
+            for (int p = 0; p < m; ++p) {
+                const T r = Ri[o * m + p];
+                T hp[D];
+                MF_UNROLL for (int j = 0; j < D; ++j) hp[j] = r * h[(p * D + j) * 64];
+                MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Phi[i][j] += ho[i] * hp[j];
+            }
+        }
+        return yry;
+    }
+};
+
 // Level 0, chunk convention of kf_chunk_kernel: chunk c owns blocks [c T / P, (c+1) T / P).
-template <typename T, int D>
+template <typename T, int D, bool OBS_LDS = false>
 __global__ void __launch_bounds__(64) kf_chunk_x_kernel(KfArgs<T> a, RedSys<T> out) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int lane = threadIdx.x;
@@ -159,9 +203,15 @@ __global__ void __launch_bounds__(64) kf_chunk_x_kernel(KfArgs<T> a, RedSys<T> o
 
     ElimX<T, D> E;
     E.init(reinterpret_cast<T*>(smem_raw), lane);
+    LdsObs<T, D> ob;
+    ob.bind(reinterpret_cast<T*>(smem_raw + LdsSpike<T, D>::BYTES), lane, a.m);
     LogAcc<T> laC;
     laC.init();
     T acc_yry = T(0), acc_ww = T(0);
+    auto observe = [&](long k, const T* Ri) {
+        if constexpr (OBS_LDS) return ob.apply(Ri, m, E.Phi, E.t);
+        else return obs_apply_pairs<T, D>(Hs + k * m * D, ys + k * m, Ri, m, E.Phi, E.t);
+    };
 
     for (long k = k0; k < k1; ++k) {
         T Ci[D][D], w[D], Bm[D][D];
@@ -172,6 +222,7 @@ __global__ void __launch_bounds__(64) kf_chunk_x_kernel(KfArgs<T> a, RedSys<T> o
             load_lower<T, D>(k == 0 ? a.cholP0 + s * D * D : Qs + kt * D * D, C);
             load_vec<T, D>(k == 0 ? a.mu0 + s * D : bs + kt * D, mvec);
             load_mat<T, D, D>(As + kt * D * D, Bm);
+            if constexpr (OBS_LDS) ob.stage(Hs + k * m * D, ys + k * m, m);
             __builtin_amdgcn_sched_barrier(0);
             tri_inv_lower<T, D>(C, Ci, laC, E.bad);
             laC.renorm();
@@ -182,7 +233,7 @@ __global__ void __launch_bounds__(64) kf_chunk_x_kernel(KfArgs<T> a, RedSys<T> o
         if (k == 0) {
             trimulT_self_lower<T, D>(Ci, E.Phi);
             trimulT_lower_vec<T, D>(Ci, w, E.t);
-            acc_yry += obs_apply_pairs<T, D>(Hs + k * m * D, ys + k * m, Ri, m, E.Phi, E.t);
+            acc_yry += observe(k, Ri);
             continue;
         }
         T btw[D];
@@ -201,7 +252,7 @@ __global__ void __launch_bounds__(64) kf_chunk_x_kernel(KfArgs<T> a, RedSys<T> o
             MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) E.sp.setX(i, j, Bm[i][j]);
             trimulT_self_lower<T, D>(Ci, E.Phi);
             trimulT_lower_vec<T, D>(Ci, w, E.t);
-            acc_yry += obs_apply_pairs<T, D>(Hs + k * m * D, ys + k * m, Ri, m, E.Phi, E.t);
+            acc_yry += observe(k, Ri);
             continue;
         }
         syrk_tn_lower<T, D, D>(Bm, E.Phi, T(1));               // D_{k-1} complete
@@ -219,7 +270,7 @@ __global__ void __launch_bounds__(64) kf_chunk_x_kernel(KfArgs<T> a, RedSys<T> o
             trimulT_lower_vec<T, D>(Ci, w, rn);
             MF_UNROLL for (int i = 0; i < D; ++i) E.t[i] = rn[i] - wz[i];
         }
-        acc_yry += obs_apply_pairs<T, D>(Hs + k * m * D, ys + k * m, Ri, m, E.Phi, E.t);
+        acc_yry += observe(k, Ri);
         syrk_nt_lower<T, D, D>(Bm, E.Phi, T(-1));
     }
     if (valid) {
