@@ -162,11 +162,9 @@ def other_configs(dev):
     inp = synthetic.make_ssm(256, 4096, (3, 3), dtype=torch.float64, device=dev)
     kf = synthetic.kalman_filter_from(inp)
     ms = _time_gpu(kf.log_likelihood)
-    ms_g = _time_gpu(mfa.graphs.capture(kf.log_likelihood))
     out["config2_loglik_B256_T4096_d4_f64"] = {
         "ms": ms, "steps_per_s": 256 * 4096 / ms * 1e3,
-        "algorithmic_GBps": 256 * 4096 * synthetic.loglik_bytes_per_step(4, 1, 8) / ms / 1e6,
-        "ms_hipgraph_replay": ms_g, "steps_per_s_hipgraph_replay": 256 * 4096 / ms_g * 1e3}
+        "algorithmic_GBps": 256 * 4096 * synthetic.loglik_bytes_per_step(4, 1, 8) / ms / 1e6}
     # config 3: SymmetricBlockTriDiagonal.cholesky + solve, T=100000 d=6 fp32, one chain (parallel-in-time path)
     n, d = 100000, 6
     g = torch.Generator(device=dev); g.manual_seed(3)
@@ -182,16 +180,13 @@ def other_configs(dev):
     chol = sym.cholesky
     t_c = _time_gpu(lambda: sym.cholesky)
     t_s = _time_gpu(lambda: chol.solve(rhs))
-    t_cg = _time_gpu(mfa.graphs.capture(lambda: sym.cholesky.block_diagonal))
-    t_sg = _time_gpu(mfa.graphs.capture(lambda: chol.solve(rhs)))
     out["config3_btd_T100000_d6_f32_B1"] = {
         "cholesky_us": t_c * 1e3, "solve_us": t_s * 1e3,
-        "cholesky_us_hipgraph_replay": t_cg * 1e3, "solve_us_hipgraph_replay": t_sg * 1e3,
         "cholesky_algorithmic_GBps": n * 4 * d * d * 4 / t_c / 1e6, "solve_algorithmic_GBps": n * (2 * d * d + 2 * d) * 4 / t_s / 1e6,
         "frac_of_hbm_peak_cholesky": n * 4 * d * d * 4 / t_c / 1e6 / HBM_PEAK_GBS,
         "note": "one chain: bound by the dependent block steps of the multi-level elimination (13 launches of 5-8 dependent "
-                "block steps each), not bytes; the eager figures include the Python-side allocation of outputs and workspace, "
-                "the hipgraph figures replay the captured call (markovflow_amd.graphs)",
+                "block steps each, ~1.5 k instructions per step on one lane), not bytes; the figures include the Python-side "
+                "allocation of outputs and workspace",
         "max_abs_err_vs_exact_factor": float((chol.block_diagonal.double() - ld).abs().max())}
     # the same operator where it IS bandwidth-bound: many series, one lane per series (B >= 4096), d=6 fp64
     bb, tb = 16384, 500

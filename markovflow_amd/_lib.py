@@ -221,6 +221,28 @@ def set_synchronous_checks(on: bool):
     CHECK_PIVOTS = bool(on)
 
 
+class errors_as_nan:
+    """Context manager: inside it a non-positive pivot is NOT raised (results are NaN from the failing block on, as the kernels
+    leave them) and whatever was flagged is forgotten on exit.  For exploratory runs, e.g. float32 on chains whose process
+    covariances are below float32 resolution."""
+
+    def __enter__(self):
+        global _suppress
+        _suppress += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _suppress
+        _suppress -= 1
+        for idx in _flags:
+            torch.cuda.synchronize(idx)
+        _take_failures()
+        return False
+
+
+_suppress = 0
+
+
 def pivot_info(device):
     """The `info` argument of a factorising entry point: pointer to this device's pinned host flag."""
     device = torch.device(device)
@@ -251,7 +273,7 @@ def _take_failures():
 
 def raise_pending():
     """Raise if a kernel that has FINISHED since the last look met a non-positive pivot (no synchronisation)."""
-    if _flags and _issued:
+    if _flags and _issued and not _suppress:
         ops = _take_failures()
         if ops is not None:
             raise MarkovflowAmdError(f"matrix is not positive definite (non-positive pivot) in one of: {ops}")
@@ -269,7 +291,7 @@ def raise_on_info(info, what: str, device=None):
     _issued.append(what)
     if len(_issued) > 64:
         del _issued[:-64]
-    if CHECK_PIVOTS:
+    if CHECK_PIVOTS and not _suppress:
         torch.cuda.current_stream(device).synchronize()
         ops = _take_failures()
         if ops is not None:

@@ -34,7 +34,31 @@ __device__ __forceinline__ double bcast(double v, int src) {
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
-__device__ __forceinline__ float mf_log(float x) { return logf(x); }
+// The same broadcast WITHIN each row of 16 lanes (DPP row_newbcast): for data that is replicated across the four rows of a
+// wavefront (the diagonal-tile kernels: lane l works on row l & 15).  One v_mov_b32_dpp per dword instead of a v_readlane into an
+// SGPR (whose consumer has to wait out the VALU-writes-SGPR hazard); `src` must be a compile-time constant after unrolling.
+template <int SRC> __device__ __forceinline__ int dpp_row_bcast(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, 0x150 + SRC, 0xF, 0xF, false);
+}
+__device__ __forceinline__ int bcast16_bits(int v, int src) {
+    switch (src & 15) {
+        case 0: return dpp_row_bcast<0>(v);   case 1: return dpp_row_bcast<1>(v);   case 2: return dpp_row_bcast<2>(v);
+        case 3: return dpp_row_bcast<3>(v);   case 4: return dpp_row_bcast<4>(v);   case 5: return dpp_row_bcast<5>(v);
+        case 6: return dpp_row_bcast<6>(v);   case 7: return dpp_row_bcast<7>(v);   case 8: return dpp_row_bcast<8>(v);
+        case 9: return dpp_row_bcast<9>(v);   case 10: return dpp_row_bcast<10>(v); case 11: return dpp_row_bcast<11>(v);
+        case 12: return dpp_row_bcast<12>(v); case 13: return dpp_row_bcast<13>(v); case 14: return dpp_row_bcast<14>(v);
+        default: return dpp_row_bcast<15>(v);
+    }
+}
+__device__ __forceinline__ float bcast16(float v, int src) { return __int_as_float(bcast16_bits(__float_as_int(v), src)); }
+__device__ __forceinline__ double bcast16(double v, int src) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)bcast16_bits((int)(unsigned)b, src);
+    const unsigned hi = (unsigned)bcast16_bits((int)(unsigned)(b >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// natural logarithm for the running log-determinant: the hardware log2 (one instruction, ~1 ulp of fp32) in fp32
+__device__ __forceinline__ float mf_log(float x) { return __log2f(x) * 0.6931471805599453094f; }
 __device__ __forceinline__ double mf_log(double x) { return log(x); }
 }  // namespace bigcommon
 }  // namespace mf

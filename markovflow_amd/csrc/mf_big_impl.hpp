@@ -405,6 +405,7 @@ enum { V_M = 0, V_W = 1, V_BTW = 2, V_T = 3, V_Z = 4, V_GU = 5, V_RN = 6, V_TMP 
 
 // Observation terms of one block: Phi += H^T R^-1 H, tvec += H^T R^-1 y, returns y^T R^-1 y (uniform).
 // Rs already holds R^-1 when it is shared; per-step precisions are loaded here.  Ends with a barrier.
+// Hk == NULL: H_k and y_k were already put into Hs / ys by the caller (the level-0 kernel prefetches them one step ahead).
 template <int DP>
 __device__ __forceinline__ real obs_terms(const Smem<DP>& sm, real* __restrict__ Phi, real* __restrict__ tvec,
                                            const real* __restrict__ Hk, const real* __restrict__ yk,
@@ -412,13 +413,15 @@ __device__ __forceinline__ real obs_terms(const Smem<DP>& sm, real* __restrict__
     constexpr int LD = Geo<DP>::LD;
     const int mp = (m + 15) & ~15;
     real *Hs = sm.Hs(), *Gs = sm.Gs(), *Rs = sm.Rs(), *ys = sm.ys(), *rys = sm.rys();
-    for (int e = threadIdx.x; e < mp * DP; e += NTHR) {
-        const int o = e / DP, i = e % DP;
-        Hs[o * LD + i] = (o < m && i < d) ? Hk[o * d + i] : 0.f;
+    if (Hk) {
+        for (int e = threadIdx.x; e < mp * DP; e += NTHR) {
+            const int o = e / DP, i = e % DP;
+            Hs[o * LD + i] = (o < m && i < d) ? Hk[o * d + i] : 0.f;
+        }
+        if (threadIdx.x < m) ys[threadIdx.x] = yk ? yk[threadIdx.x] : real(0);      // yk == NULL: precision only
     }
     if (Rk) for (int e = threadIdx.x; e < m * m; e += NTHR) Rs[e] = Rk[e];
-    if (threadIdx.x < m) ys[threadIdx.x] = yk ? yk[threadIdx.x] : real(0);      // yk == NULL: precision only
-    __syncthreads();
+    if (Hk || Rk) __syncthreads();
     {   // G = R^-1 H on the matrix cores: (mp/16) x NT output tiles of 16 x 16, K = mp
         constexpr int NT = Geo<DP>::NT;
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
@@ -429,7 +432,9 @@ __device__ __forceinline__ real obs_terms(const Smem<DP>& sm, real* __restrict__
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     const int p = 16 * kt + 4 * q + kk;
-                    const real av = (o < m && p < m) ? Rs[o * m + p] : real(0);
+                    // R^-1 is symmetric: read it down a column (consecutive lanes -> consecutive words) instead of along a row
+                    // (stride m = 32 words: every lane of the wave on the same LDS bank)
+                    const real av = (o < m && p < m) ? Rs[p * m + o] : real(0);
                     acc = mfma(av, Hs[p * LD + 16 * tj + r], acc);
                 }
             }
@@ -439,7 +444,7 @@ __device__ __forceinline__ real obs_terms(const Smem<DP>& sm, real* __restrict__
     }
     if (threadIdx.x < m) {
         real a = 0.f;
-        for (int p = 0; p < m; ++p) a += Rs[threadIdx.x * m + p] * ys[p];
+        for (int p = 0; p < m; ++p) a += Rs[p * m + threadIdx.x] * ys[p];          // symmetric: conflict-free column read
         rys[threadIdx.x] = a;
     }
     __syncthreads();
@@ -449,8 +454,11 @@ __device__ __forceinline__ real obs_terms(const Smem<DP>& sm, real* __restrict__
         for (int o = 0; o < m; ++o) a += Hs[o * LD + threadIdx.x] * rys[o];
         tvec[threadIdx.x] += a;
     }
-    real yry = 0.f;
-    for (int o = 0; o < m; ++o) yry += ys[o] * rys[o];
+    // y^T R^-1 y: one product per lane and a wave reduction (every wave holds the same value; m <= 32 < 64 lanes)
+    const int lane = threadIdx.x & 63;
+    real yry = lane < m ? ys[lane] * rys[lane] : real(0);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) yry += __shfl_xor(yry, off);
     __syncthreads();
     return yry;
 }
@@ -536,11 +544,13 @@ template <int DP> __global__ void __launch_bounds__(NTHR) big_kf_chunk_kernel(Bi
     real *Phi = sm.tile(T_PHI), *U1 = sm.tile(T_U1), *U2 = sm.tile(T_U2), *Ci = sm.tile(T_U3);
 
     // pivot part Q^-1 (+ observation) and rhs part of the block a Cholesky factor C (already inverted into Ci) leads to
-    auto own_terms = [&](long blk, real* tvec) {
+    // `staged`: H and y of the block are already in LDS (prefetched one step ahead with the transition)
+    auto own_terms = [&](long blk, real* tvec, bool staged) {
         gemm<DP, 1, 0, 0, K_A_UPPER, O_FULL>(Ci, Ci, Phi, 1.f);                                   // Phi = Ci^T Ci
         matvec<DP, 1>(Ci, sm.vec(V_W), tvec, 1.f, 0.f, sm.scratch());                             // Ci^T w
         const real* Rk = a.rinv_per_step ? a.Rinv + (s * a.Tn + blk) * m * m : nullptr;
-        acc_yry += (double)obs_terms<DP>(sm, Phi, tvec, a.H + (s * a.Tn + blk) * m * d, a.y + (s * a.Tn + blk) * m, Rk, d, m);
+        acc_yry += (double)obs_terms<DP>(sm, Phi, tvec, staged ? nullptr : a.H + (s * a.Tn + blk) * m * d,
+                                         a.y + (s * a.Tn + blk) * m, Rk, d, m);
     };
 
     if (c == 0) {   // block 0: the prior
@@ -550,14 +560,40 @@ template <int DP> __global__ void __launch_bounds__(NTHR) big_kf_chunk_kernel(Bi
         logC += (double)factor_invert<DP, false>(U1, Ci, bad, sm.scratch());
         matvec<DP, 0>(Ci, sm.vec(V_M), sm.vec(V_W), 1.f, 0.f, sm.scratch());
         acc_ww += (double)sumsq<DP>(sm.vec(V_W));
-        own_terms(0, sm.vec(V_T));
+        own_terms(0, sm.vec(V_T), false);
     }
     TilePrefetch<DP> pfC, pfA;
     real pfb = 0.f;
+    // H (m x d, zero-padded to mp x DP in LDS) and y of the block the transition leads to: NH values per thread
+    constexpr int NH = MAXM_BIG * DP / NTHR;
+    real pfH[NH], pfy = 0.f;
+    const int mp_all = (m + 15) & ~15;
     auto prefetch = [&](long tau) {
         pfC.load(a.cholQ + (s * nt + tau) * d * d, d, true, true);
         pfA.load(a.A + (s * nt + tau) * d * d, d, false, false);
         pfb = (threadIdx.x < d) ? a.b[(s * nt + tau) * d + threadIdx.x] : 0.f;
+    };
+    // The observation rows of the block a transition leads to are needed at the END of its step (own_terms).  Their loads are
+    // issued in the middle of the step - after the factorisation, whose unrolled diagonal-tile code has no registers to
+    // spare - and land in LDS just before own_terms: the latency hides behind the two GEMMs in between.
+    auto load_obs = [&](long blk) {
+        const real* Hn = a.H + (s * a.Tn + blk) * m * d;
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int e = threadIdx.x + i * NTHR, o = e / DP, c2 = e % DP;
+            pfH[i] = (o < m && c2 < d) ? Hn[o * d + c2] : 0.f;
+        }
+        pfy = (threadIdx.x < m) ? a.y[(s * a.Tn + blk) * m + threadIdx.x] : 0.f;
+    };
+    auto stage_obs = [&]() {
+        constexpr int LDh = Geo<DP>::LD;
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int e = threadIdx.x + i * NTHR;
+            if (e < mp_all * DP) sm.Hs()[(e / DP) * LDh + (e % DP)] = pfH[i];
+        }
+        if (threadIdx.x < m) sm.ys()[threadIdx.x] = pfy;
+        __syncthreads();
     };
     if (len > 0) prefetch(tau0);
     MF_STAMP_DECL
@@ -582,11 +618,12 @@ template <int DP> __global__ void __launch_bounds__(NTHR) big_kf_chunk_kernel(Bi
         MF_STAMP(2)
         if (j == 0 && spike) {
             // the block on the left is the chunk's separator: its coupling seeds the spike
+            load_obs(tau + 1);
             gemm<DP, 1, 0, 0, K_FULL, O_FULL>(U1, U1, sm.tile(T_GU), 1.f);                         // GU = Bm^T Bm
             gemm<DP, 1, 0, 0, K_A_UPPER, O_FULL>(Ci, U1, sm.tile(T_X), -1.f);                      // X = -Ci^T Bm
             if (threadIdx.x < DP) sm.vec(V_GU)[threadIdx.x] = -sm.vec(V_BTW)[threadIdx.x];
-            __syncthreads();
-            own_terms(tau + 1, sm.vec(V_T));
+            stage_obs();
+            own_terms(tau + 1, sm.vec(V_T), true);
         } else {
             gemm<DP, 1, 0, 1, K_FULL, O_FULL>(U1, U1, Phi, 1.f);                                  // Phi += Bm^T Bm
             if (threadIdx.x < DP) sm.vec(V_T)[threadIdx.x] -= sm.vec(V_BTW)[threadIdx.x];
@@ -609,12 +646,13 @@ template <int DP> __global__ void __launch_bounds__(NTHR) big_kf_chunk_kernel(Bi
 #else
             eliminate<DP>(sm, spike, logL, quad, bad);
 #endif
+            load_obs(tau + 1);
             gemm<DP, 0, 1, 0, K_B_UPPER, O_FULL>(U1, U2, sm.tile(T_X), 1.f);                       // Y = Bm Linv^T
             __syncthreads();
             gemm<DP, 1, 0, 0, K_A_UPPER, O_FULL>(Ci, sm.tile(T_X), U1, -1.f);                      // W = -Ci^T Y
-            __syncthreads();
+            stage_obs();
             MF_STAMP(7)
-            own_terms(tau + 1, sm.vec(V_RN));
+            own_terms(tau + 1, sm.vec(V_RN), true);
             MF_STAMP(8)
             advance<DP>(sm, spike);
             MF_STAMP(9)

@@ -44,3 +44,25 @@ def sharded_log_likelihood(kalman_filter, group: Optional[dist.ProcessGroup] = N
     """
     local = kalman_filter.log_likelihood().reshape(())     # a fresh tensor: reduced in place (no copy kernel)
     return all_reduce_sum(local.clone() if local.requires_grad else local, group)
+
+
+def sharded_kl_divergence(dist_q, dist_p, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """
+    ``sum over ALL series of KL(q_s || p_s)`` when both chains hold THIS rank's series only (the KL term of a variational
+    model is a sum over the batch: ``models/sparse_variational.py:178-182`` of the reference).  One scalar all-reduce.
+    """
+    local = torch.sum(dist_q.kl_divergence(dist_p)).reshape(())
+    return all_reduce_sum(local.clone() if local.requires_grad else local, group)
+
+
+def sharded_elbo(expected_log_likelihood: torch.Tensor, kl_divergence: torch.Tensor,
+                 group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """
+    Evidence lower bound of a batch sharded over the ranks (BASELINE config 4): every rank passes the variational expectations
+    and the KL terms of ITS series (any shape; summed here), the result - identical on every rank - is
+    ``sum_all E_q[log p(y|f)] - sum_all KL`` (``models/sparse_variational.py:192``).  The two partial sums travel as ONE
+    all-reduce of a single scalar.  Gradients: the value is returned detached from the collective - differentiate the LOCAL
+    terms (each rank owns the parameters of its own series; shared hyper-parameters need the usual gradient all-reduce).
+    """
+    local = (torch.sum(expected_log_likelihood) - torch.sum(kl_divergence)).reshape(())
+    return all_reduce_sum(local.detach().clone(), group)

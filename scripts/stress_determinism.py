@@ -1,10 +1,15 @@
 """Repeat the headline evaluation and a few operators many times and require bit-identical results (LDS-DMA hazards, races)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import contextlib
+import markovflow_amd as mfa
 from markovflow_amd import synthetic
 dev = torch.device("cuda", 0)
 for (b, t, comp, m, dt) in [(1024, 10000, (5, 5), 1, torch.float64), (256, 4096, (3, 3), 1, torch.float64), (512, 1000, (5, 5, 5), 3, torch.float64),
                             (1024, 3000, (5, 5), 1, torch.float32), (37, 777, (3,), 1, torch.float64)]:
+  # the float32 Matern-5/2 configuration is non-finite by construction (process covariances below float32 resolution): NaN
+  # results must still be bit-identical from run to run, so the pivot errors are turned into NaN there
+  with (mfa.errors_as_nan() if dt == torch.float32 else contextlib.nullcontext()):
     kf = synthetic.kalman_filter_from(synthetic.make_ssm(b, t, comp, output_dim=m, dtype=dt, device=dev))
     ref = kf._log_likelihood_per_series().clone()
     bad = 0

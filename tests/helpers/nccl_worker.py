@@ -45,13 +45,16 @@ def main():
     kf = mfa.KalmanFilter(ssm, mfa.EmissionModel(loc["h"]), loc["y"], torch.tensor([[0.5]] if m == 1 else 0.5 * np.eye(m),
                                                                                     dtype=torch.float64, device=dev))
     total = mfd.sharded_log_likelihood(kf)
+    # the variational exchange step of BASELINE config 4: sum over all series of KL(posterior || prior), one scalar all-reduce
+    kl_total = mfd.sharded_kl_divergence(kf.posterior_state_space_model(), ssm) if hi > lo else mfd.all_reduce_sum(
+        torch.zeros((), dtype=torch.float64, device=dev))
     ones = torch.ones(1, dtype=torch.float64, device=dev)
     dist.all_reduce(ones)
     every = [torch.zeros((), dtype=torch.float64, device=dev) for _ in range(world)]
     dist.all_gather(every, total)
     if rank == 0:
         with open(out_path, "w") as fh:
-            json.dump({"world": world, "ranks_seen": int(ones.item()), "total": float(total),
+            json.dump({"world": world, "ranks_seen": int(ones.item()), "total": float(total), "kl_total": float(kl_total),
                        "per_rank_totals": [float(x) for x in every], "backend": dist.get_backend()}, fh)
     dist.destroy_process_group()
 

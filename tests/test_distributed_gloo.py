@@ -94,3 +94,51 @@ def test_shard_bounds_partition_the_batch(n, world):
 def test_all_reduce_is_identity_without_process_group():
     x = torch.tensor(3.5, dtype=torch.float64)
     assert mfd.all_reduce_sum(x) is x and float(x) == 3.5
+
+
+class _OracleBackedChain:
+    """Stands in for a StateSpaceModel that holds one rank's series: kl_divergence() per local series from the numpy oracle."""
+
+    def __init__(self, params):
+        self.params = params
+
+    def kl_divergence(self, other):
+        if self.params[0].shape[0] == 0:
+            return torch.zeros(0, dtype=torch.float64)
+        return torch.tensor(O.ssm_kl_divergence(self.params, other.params), dtype=torch.float64)
+
+
+def _elbo_worker(rank, world, port, bsz, results):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        q, p = _inputs(bsz, seed=7), _inputs(bsz, seed=8)
+        lo, hi = mfd.shard_bounds(bsz, rank, world)
+        names = ("mu0", "chol_p0", "a_s", "b_s", "chol_q")
+        ql = _OracleBackedChain(tuple(q[k][lo:hi] for k in names))
+        pl = _OracleBackedChain(tuple(p[k][lo:hi] for k in names))
+        kl = mfd.sharded_kl_divergence(ql, pl)
+        ell = torch.tensor(np.arange(bsz, dtype=np.float64)[lo:hi] * 0.25)        # any per-series expectation
+        elbo = mfd.sharded_elbo(ell, ql.kl_divergence(pl))
+        results[rank] = (float(kl), float(elbo))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bsz", [6, 3, 1])
+def test_sharded_kl_and_elbo_world2_gloo(bsz):
+    """BASELINE config 4's exchange step: the ELBO of a batch sharded over the ranks is one scalar all-reduce."""
+    world = 2
+    with mp.Manager() as manager:
+        results = manager.dict()
+        mp.spawn(_elbo_worker, args=(world, _free_port(), bsz, results), nprocs=world, join=True)
+        results = dict(results)
+    names = ("mu0", "chol_p0", "a_s", "b_s", "chol_q")
+    q, p = _inputs(bsz, seed=7), _inputs(bsz, seed=8)
+    kl = float(np.sum(O.ssm_kl_divergence(tuple(q[k] for k in names), tuple(p[k] for k in names))))
+    ell = float(np.sum(np.arange(bsz) * 0.25))
+    for rank in range(world):
+        assert results[rank][0] == pytest.approx(kl, rel=1e-12)
+        assert results[rank][1] == pytest.approx(ell - kl, rel=1e-12)
+    assert results[0] == results[1]

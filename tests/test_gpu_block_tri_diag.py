@@ -193,6 +193,11 @@ def test_non_positive_pivot_is_reported_like_the_reference(rng, monkeypatch):
     with pytest.raises(_lib.MarkovflowAmdError):
         sym.cholesky
     good.cholesky                                                         # and a clean call stays clean
+    monkeypatch.setattr(_lib, "CHECK_PIVOTS", False)
+    with mfa.errors_as_nan():                                             # opt-out: NaN results, nothing raised, nothing left behind
+        assert not torch.isfinite(sym.cholesky.block_diagonal).all()
+        good.cholesky
+    _lib.check_errors()
 
 
 def test_unsupported_state_dim_fails_loudly(rng):

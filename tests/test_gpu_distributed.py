@@ -51,6 +51,9 @@ def test_sharded_log_likelihood_nccl(tmp_path, world, bsz, t, d, m):
     expect = float(O.kf_log_likelihood(r_inv=r_inv, **full))
     assert res["total"] == pytest.approx(expect, rel=1e-9)
     assert all(v == res["total"] for v in res["per_rank_totals"])          # identical on every rank
+    post = O.kf_posterior_ssm(r_inv=r_inv, **full)
+    prior = tuple(full[k] for k in ("mu0", "chol_p0", "a_s", "b_s", "chol_q"))
+    assert res["kl_total"] == pytest.approx(float(np.sum(O.ssm_kl_divergence(post, prior))), rel=1e-8)
 
 
 @pytest.mark.parametrize("gpus", [1, 2])
