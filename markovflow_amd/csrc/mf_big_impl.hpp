@@ -139,7 +139,16 @@ __device__ __forceinline__ real diag_tile(real* __restrict__ S, real* __restrict
 #pragma unroll
     for (int k = 0; k < 16; ++k) a[k] = S[i * LD + k];
     real logsum = 0.f;
+    // column `i` of the inverse by forward substitution; L[row][k] is lane `row`'s a[k]
+    // (column-oriented: once x[k] is final every later row takes its contribution - independent updates instead of one
+    // dependent accumulation chain per row)
+    real x[16];
+#pragma unroll
+    for (int row = 0; row < 16; ++row) x[row] = (row == i) ? 1.f : 0.f;
     if (CHOL) {
+        // The factorisation and the substitution are ONE loop: step j of the inverse needs column j of L only, which is final
+        // as soon as step j of the Cholesky has scaled it.  The two recurrences are independent chains of ~190 cycles per step
+        // each; fused, the second one fills the issue slots the first leaves empty (r02: [5] of profiles/r02_big_v3_phases.txt).
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const real p = bcast(a[j], j);
@@ -149,8 +158,13 @@ __device__ __forceinline__ real diag_tile(real* __restrict__ S, real* __restrict
             logsum += 0.5f * mf_log(p);
             const real lij = a[j] * ri;
             a[j] = lij;
+            x[j] *= ri;
 #pragma unroll
-            for (int k = j + 1; k < 16; ++k) a[k] -= lij * bcast(lij, k);
+            for (int k = j + 1; k < 16; ++k) {
+                const real lkj = bcast(lij, k);          // L[k][j]: one broadcast feeds the trailing update AND the substitution
+                a[k] -= lij * lkj;
+                x[k] -= lkj * x[j];
+            }
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k)
@@ -163,18 +177,12 @@ __device__ __forceinline__ real diag_tile(real* __restrict__ S, real* __restrict
             rd[j] = t_rcp<real>(p);
             logsum += mf_log((p < 0 ? -p : p));
         }
-    }
-    // column `i` of the inverse by forward substitution; L[row][k] is lane `row`'s a[k]
-    // (column-oriented: once x[k] is final every later row takes its contribution - independent updates instead of one
-    // dependent accumulation chain per row)
-    real x[16];
 #pragma unroll
-    for (int row = 0; row < 16; ++row) x[row] = (row == i) ? 1.f : 0.f;
+        for (int k = 0; k < 16; ++k) {
+            x[k] *= rd[k];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        x[k] *= rd[k];
-#pragma unroll
-        for (int row = k + 1; row < 16; ++row) x[row] -= bcast(a[k], row) * x[k];
+            for (int row = k + 1; row < 16; ++row) x[row] -= bcast(a[k], row) * x[k];
+        }
     }
     if (lane < 16) {
 #pragma unroll
