@@ -315,6 +315,24 @@ int mf_ssm_kl_grad_f32(int64_t B, int64_t T, int d, const float* mu0_1, const fl
                        float* g_mu0, float* g_cholP0, float* g_A, float* g_b, float* g_cholQ, int* info, void* stream);
 
 /*
+ * BaseKalmanFilter.posterior_state_space_model (markovflow/kalman_filter.py:109-182) fused: ONE backward sweep per series
+ * assembles the posterior precision / information vector block by block (state_space_model.py:431-483,
+ * kalman_filter.py:86-101,149-156) inside the U D U^T recursion (block_tri_diag.py:438-545) and writes the five tensors of the
+ * posterior chain directly: a_post [B,T-1,d,d] (= -U^T), mu0_post [B,d], b_post [B,T-1,d], cholP0_post [B,d,d],
+ * cholQ_post [B,T-1,d,d].  4 d^2 s bytes per block instead of the 8 d^2 s of mf_ssm_precision + mf_btd_udl.  One lane per
+ * series (the Python layer uses it for batches that fill the chip, the two-kernel route with its parallel-in-time sweep
+ * otherwise).  Rinv shared [m,m] or per step [B,T,m,m]; m <= 4; state dimension 1..9.
+ */
+int mf_kf_posterior_chain_f64(int64_t B, int64_t T, int d, int m, const double* mu0, const double* cholP0, const double* A,
+                              const double* b, const double* cholQ, const double* H, const double* y, const double* Rinv,
+                              int rinv_per_step, double* a_post, double* mu0_post, double* b_post, double* cholP0_post,
+                              double* cholQ_post, int* info, void* stream);
+int mf_kf_posterior_chain_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const float* cholP0, const float* A,
+                              const float* b, const float* cholQ, const float* H, const float* y, const float* Rinv,
+                              int rinv_per_step, float* a_post, float* mu0_post, float* b_post, float* cholP0_post,
+                              float* cholQ_post, int* info, void* stream);
+
+/*
  * KL(q1 || q2) between two state space models, one scalar per series (markovflow/state_space_model.py:528-593), fused: ONE
  * forward sweep per series carries q1's marginal mean and covariance in registers and accumulates the divergence from the
  * local form  1/2 sum_k [ tr(Q2^-1 Q1) + tr(Q2^-1 dA S_k dA^T) + eps_k^T Q2^-1 eps_k ] - T d / 2 + log-determinants

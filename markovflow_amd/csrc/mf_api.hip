@@ -360,6 +360,19 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         return t->kl_grad(B, Tn, mu0_1, cholP0_1, A_1, b_1, cholQ_1, mu0_2, cholP0_2, A_2, b_2, cholQ_2, means_1,      \
                           covs_1, weights, g_mu0, g_cholP0, g_A, g_b, g_cholQ, info, S(stream));                       \
     }                                                                                                                  \
+    int mf_kf_posterior_chain_##SUF(int64_t B, int64_t Tn, int d, int m, const T* mu0, const T* cholP0, const T* A,    \
+                                    const T* b, const T* cholQ, const T* H, const T* y, const T* Rinv,                 \
+                                    int rinv_per_step, T* a_post, T* mu0_post, T* b_post, T* cholP0_post,              \
+                                    T* cholQ_post, int* info, void* stream) {                                          \
+        MF_HEAD(T, B, Tn, d)                                                                                           \
+        if (big) return -100;                                                                                          \
+        if (m < 1 || m > 4) return -4;                                                                                 \
+        if (!mu0 || !cholP0 || (Tn > 1 && (!A || !b || !cholQ))) return -5;                                            \
+        if (!H || !y || !Rinv) return -10;                                                                             \
+        if (!mu0_post || !cholP0_post || (Tn > 1 && (!a_post || !b_post || !cholQ_post))) return -14;                  \
+        return t->posterior_chain(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, a_post, mu0_post,     \
+                                  b_post, cholP0_post, cholQ_post, info, S(stream));                                   \
+    }                                                                                                                  \
     int mf_ssm_kl_divergence_##SUF(int64_t B, int64_t Tn, int d, const T* mu0_1, const T* cholP0_1, const T* A_1,      \
                                    const T* b_1, const T* cholQ_1, const T* mu0_2, const T* cholP0_2, const T* A_2,    \
                                    const T* b_2, const T* cholQ_2, T* out, int* info, void* stream) {                  \

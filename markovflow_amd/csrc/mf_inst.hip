@@ -9,6 +9,7 @@
 #include "mf_btd_par.hpp"
 #include "mf_gpr_fused.hpp"
 #include "mf_kl_grad.hpp"
+#include "mf_post.hpp"
 #include "mf_launch.hpp"
 
 #include <cstdlib>
@@ -795,6 +796,18 @@ int kl_grad(long B, long Tn, const T* mu0_1, const T* C0_1, const T* A_1, const 
 }
 
 template <typename T>
+int posterior_chain(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H,
+                    const T* y, const T* Rinv, int rinv_per_step, T* a_post, T* mu0_post, T* b_post, T* cp0_post, T* cq_post,
+                    int* info, hipStream_t st) {
+    if (m < 1 || m > MF_MAXM) return -4;
+    KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, 1, info, 0};
+    const dim3 grid((unsigned)cdiv(B, 64)), block(64);
+    if (m == 1) hipLaunchKernelGGL((kf_posterior_chain_kernel<T, D, 1>), grid, block, 0, st, a, a_post, mu0_post, b_post, cp0_post, cq_post);
+    else hipLaunchKernelGGL((kf_posterior_chain_kernel<T, D, 0>), grid, block, 0, st, a, a_post, mu0_post, b_post, cp0_post, cq_post);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+template <typename T>
 int kl_value(long B, long Tn, const T* mu0_1, const T* C0_1, const T* A_1, const T* b_1, const T* C_1, const T* mu0_2,
              const T* C0_2, const T* A_2, const T* b_2, const T* C_2, T* out, int* info, hipStream_t st) {
     hipLaunchKernelGGL((ssm_kl_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, Tn, mu0_1, C0_1, A_1, b_1, C_1,
@@ -814,7 +827,7 @@ template <typename T> const OpsTable<T>* table() {
     static const OpsTable<T> t = {
         &kf_loglik_ws<T>, &kf_loglik<T>, &btd_logdet_quad_ws<T>, &btd_logdet_quad<T>, &btd_cholesky_ws<T>, &btd_cholesky<T>,
         &btd_solve_ws<T>, &btd_solve<T>,    &btd_matvec<T>, &btd_logdet<T>,        &btd_diag_of_inverse_ws<T>, &btd_diag_of_inverse<T>, &ssm_marginal_covs<T>, &btd_udl_ws<T>, &btd_udl<T>,
-        &ssm_precision<T>, &ssm_means<T>, &block_matmul<T>, &gpr_loglik<T>, &sde_predict<T>, &kf_grad<T>, &kl_grad<T>, &kl_value<T>, &marginals_grad<T>,
+        &ssm_precision<T>, &ssm_means<T>, &block_matmul<T>, &gpr_loglik<T>, &sde_predict<T>, &kf_grad<T>, &kl_grad<T>, &posterior_chain<T>, &kl_value<T>, &marginals_grad<T>,
     };
     return &t;
 }

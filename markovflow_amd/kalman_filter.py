@@ -135,9 +135,34 @@ class BaseKalmanFilter(abc.ABC):
         num_data = self.prior_ssm.num_transitions + 1
         return num_data * torch.linalg.slogdet(self._r_inv)[1]
 
+    # batches at least this large (or chains this short) take the fused one-lane-per-series sweep (mf_kf_posterior_chain)
+    _POST_FUSED_MIN_SERIES = 2048
+    _POST_FUSED_MAX_SERIAL_BLOCKS = 64
+
+    def _posterior_chain_fused(self, h, y, r_inv, per_step) -> Optional[StateSpaceModel]:
+        mu0, cp0, a_s, b_s, cq = self.prior_ssm._flat_params()
+        bsz, n, d, m = a_s.shape[0], self.prior_ssm.num_transitions + 1, self.prior_ssm.state_dim, h.shape[-2]
+        if d > _lib.load().mf_max_state_dim() or m > 4 or bsz == 0 or not (
+                bsz >= self._POST_FUSED_MIN_SERIES or n <= self._POST_FUSED_MAX_SERIAL_BLOCKS):
+            return None
+        a_p, b_p, cq_p = torch.empty_like(a_s), torch.empty_like(b_s), torch.empty_like(cq)
+        mu0_p, cp0_p = torch.empty_like(mu0), torch.empty_like(cp0)
+        info = _lib.pivot_info(a_s.device)
+        _lib.call("mf_kf_posterior_chain", a_s.dtype, bsz, n, d, m, _lib.ptr(mu0), _lib.ptr(cp0), _lib.ptr(a_s), _lib.ptr(b_s),
+                  _lib.ptr(cq), _lib.ptr(h), _lib.ptr(y), _lib.ptr(r_inv), int(per_step), _lib.ptr(a_p), _lib.ptr(mu0_p),
+                  _lib.ptr(b_p), _lib.ptr(cp0_p), _lib.ptr(cq_p), info, _lib.stream_ptr(a_s.device))
+        _lib.raise_on_info(info, "posterior_state_space_model", a_s.device)
+        batch = tuple(self.prior_ssm.batch_shape)
+        return StateSpaceModel(initial_mean=mu0_p.reshape(batch + (d,)), chol_initial_covariance=cp0_p.reshape(batch + (d, d)),
+                               state_transitions=a_p.reshape(batch + (n - 1, d, d)), state_offsets=b_p.reshape(batch + (n - 1, d)),
+                               chol_process_covariances=cq_p.reshape(batch + (n - 1, d, d)))
+
     def posterior_state_space_model(self) -> StateSpaceModel:
         """Posterior as a state space model (kalman_filter.py:109-182)."""
         h, y, r_inv, per_step = self._expanded()
+        fused = self._posterior_chain_fused(h, y, r_inv, per_step)
+        if fused is not None:
+            return fused
         # posterior precision and  GᵀΣ⁻¹y + K⁻¹μ  (kalman_filter.py:149-156) in one parallel kernel
         diag, sub, eta = self.prior_ssm._precision_and_eta(h, y, r_inv, per_step, want_eta=True)
         # backward UDUᵀ sweep, m_post and chol(Δ⁻¹) fused (kalman_filter.py:159-174)

@@ -339,3 +339,31 @@ def test_empty_batch_is_a_no_op(rng):
     assert tuple(ssm.precision.cholesky.block_diagonal.shape) == (0, t, d, d)
     assert tuple(kf.posterior_state_space_model().marginal_covariances.shape) == (0, t, d, d)
     assert tuple(ssm.sample(3).shape) == (3, 0, t, d)
+
+
+@pytest.mark.parametrize("d,m,t,bsz,per_step", [(1, 1, 2, 3, False), (6, 1, 100, 3, False), (9, 3, 70, 2, False), (4, 1, 37, 2, True),
+                                                 (6, 2, 5, 2, False), (3, 1, 300, 2, False)])
+def test_posterior_chain_fused_sweep_and_two_kernel_route_agree_with_the_oracle(rng, monkeypatch, d, m, t, bsz, per_step):
+    """posterior_state_space_model has two routes: ONE backward sweep that assembles the posterior precision inside the U D U^T
+    recursion (mf_kf_posterior_chain: batches that fill the chip / short chains) and precision assembly + U D U^T sweep (few long
+    chains: parallel in time).  Both against the numpy restatement of kalman_filter.py:109-182, all five tensors."""
+    kw = random_ssm(rng, (bsz,), t, d, m, well=True)
+    if per_step:
+        r_inv = rng.uniform(0.5, 2.0, size=(bsz, t, m, m))
+        ssm = mfa.StateSpaceModel(*(tt(kw[k]) for k in ("mu0", "chol_p0", "a_s", "b_s", "chol_q")))
+        from markovflow_amd.kalman_filter import _RawFilter
+        kf = _RawFilter(ssm, mfa.EmissionModel(tt(kw["h"])), tt(kw["y"]), tt(r_inv))
+    else:
+        r = rng.normal(size=(m, m)); cov = r @ r.T + np.eye(m); r_inv = np.linalg.inv(cov)
+        kf = build_kf(kw, np.linalg.cholesky(cov))
+    want = O.kf_posterior_ssm(**kw, r_inv=r_inv)
+    monkeypatch.setattr(mfa.BaseKalmanFilter, "_POST_FUSED_MIN_SERIES", 1)
+    fused = kf.posterior_state_space_model()
+    monkeypatch.setattr(mfa.BaseKalmanFilter, "_POST_FUSED_MIN_SERIES", 10 ** 9)
+    monkeypatch.setattr(mfa.BaseKalmanFilter, "_POST_FUSED_MAX_SERIAL_BLOCKS", 0)
+    ops = kf.posterior_state_space_model()
+    for post in (fused, ops):
+        got = (post.initial_mean, post.cholesky_initial_covariance, post.state_transitions, post.state_offsets,
+               post.cholesky_process_covariances)
+        for g, w in zip(got, want):
+            np.testing.assert_allclose(nn(g), w, rtol=1e-8, atol=1e-10)
