@@ -202,7 +202,18 @@ def other_configs(dev):
         "solve_ms": t_bs, "solve_algorithmic_GBps": bb * tb * (2 * 36 + 12) * 8 / t_bs / 1e6,
         "solve_frac_of_hbm_peak": bb * tb * (2 * 36 + 12) * 8 / t_bs / 1e6 / HBM_PEAK_GBS,
         "note": "SURVEY 8d bytes per block: cholesky 4 d^2 s, solve (2 d^2 + 2 d) s; one lane per series, natural order"}
-    del inp, prec, chol_b, rhs_b
+    # the composite entry points at the same shape: fused one-lane-per-series sweeps since round 2
+    kf_b = synthetic.kalman_filter_from(inp)
+    t_post = _time_gpu(kf_b.posterior_state_space_model, iters=5)
+    post_b = kf_b.posterior_state_space_model()
+    t_kl = _time_gpu(lambda: post_b.kl_divergence(kf_b.prior_ssm), iters=5)
+    out["composites_B16384_T500_d6_f64"] = {
+        "posterior_state_space_model_ms": t_post, "kl_divergence_ms": t_kl,
+        "posterior_algorithmic_GBps": bb * tb * (4 * 36 + 3 * 6 + 2) * 8 / t_post / 1e6,
+        "kl_algorithmic_GBps": bb * tb * (4 * 36 + 2 * 6) * 8 / t_kl / 1e6,
+        "note": "bytes per block: posterior reads A, cholQ, b, H, y and writes A', cholQ', b' ((4 d^2 + 3 d + 2) s); "
+                "kl_divergence reads both chains ((4 d^2 + 2 d) s) and writes one scalar per series"}
+    del inp, prec, chol_b, rhs_b, kf_b, post_b
     # config 4 shape: d=9 (3 x Matern-5/2, 3 outputs), 512 series per GPU (4096 over 8 GPUs), fp64
     inp = synthetic.make_ssm(512, 1000, (5, 5, 5), output_dim=3, dtype=torch.float64, device=dev)
     kf = synthetic.kalman_filter_from(inp)
