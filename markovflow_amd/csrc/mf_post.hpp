@@ -43,7 +43,10 @@ __global__ void __launch_bounds__(64) kf_posterior_chain_kernel(KfArgs<T> a, T* 
             MF_UNROLL for (int e = 0; e < MO; ++e) d.y[e] = a.y[(s * n + k) * MO + e];
         }
     };
-    constexpr bool PF = (M > 0) && (sizeof(T) == 4 ? (D <= 8) : (D <= 6));
+#ifndef MF_POST_PF
+#define MF_POST_PF 1
+#endif
+    constexpr bool PF = MF_POST_PF && (M > 0) && (sizeof(T) == 4 ? (D <= 8) : (D <= 6));
     Step cur, nxt;
     if (PF) load(n - 1, cur);
     for (long k = n - 1; k >= 0; --k) {
