@@ -136,14 +136,38 @@ template <typename St> struct DmaStream {
             if (St::ALL) off = (unsigned)cu * St::UNIT;
             else off = *reinterpret_cast<const unsigned*>(smem + gtab + cu * 4);
             vo[i] = rel + off;
+#ifdef MF_EXPERIMENT
+            // ablation "what would a line ring buy" (MF_KF_DEBUG bit 3): bits 24..28 carry the unit's index in its row, bits
+            // 29..30 the 32-byte phase of the row's first step (valid offsets stay below 2^24)
+            if (pack_base != 0xffffffffu && rel < MF_DMA_INVALID)
+                vo[i] |= ((((pack_base + rel) >> 5) & 3u) << 29) | ((unsigned)(off / St::UNIT) << 24);
+#endif
         }
     }
+#ifdef MF_EXPERIMENT
+    unsigned pack_base = 0xffffffffu;     // low 32 bits of the stream's base address when the ablation is on
+    unsigned step_next = 0;               // index (within the chunk) of the step whose rows are being fetched
+    bool skip_carried = false;
+    // the offset actually issued: a unit that lies in the row's first 128-B line, when that line is shared with the previous
+    // row (row start not on a line boundary), is NOT fetched (results are garbage - timing / traffic experiment only)
+    MF_DEV unsigned exp_offset(unsigned v) const {
+        if (pack_base == 0xffffffffu || v >= MF_DMA_INVALID) return v;
+        const unsigned phase = ((v >> 29) + step_next) & 3u, gu = (v >> 24) & 31u, off = v & 0xffffffu;
+        const bool carried = skip_carried && phase != 0u && gu < 8u - 2u * phase;
+        return carried ? MF_DMA_INVALID : off;
+    }
+#endif
     // issue DMA instructions [i0, i1) of this stream
     template <int I0, int I1> MF_DEV void issue(mf_v4i srd, unsigned lds_base) const {
         MF_UNROLL for (int i = I0; i < I1; ++i) {
             if (i < St::NI) {
-                if (St::UNIT == 16) dma_b128<(St::UG >= 8)>(srd, lds_base + i * 1024, vo[i]);
-                else dma_b32(srd, lds_base + i * 256, vo[i]);
+#ifdef MF_EXPERIMENT
+                const unsigned voff = exp_offset(vo[i]);
+#else
+                const unsigned voff = vo[i];
+#endif
+                if (St::UNIT == 16) dma_b128<(St::UG >= 8)>(srd, lds_base + i * 1024, voff);
+                else dma_b32(srd, lds_base + i * 256, voff);
             }
         }
     }
@@ -428,6 +452,12 @@ __global__ void __launch_bounds__(64) kf_chunk_lds_kernel(KfArgs<T> a, long L, R
     // the LDS tables must be visible to every lane before the first DMA address is formed (one wave: a
     // wait on the LDS counter is enough) and the plain loads above must be done before DMAs are counted
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifdef MF_EXPERIMENT
+    if (a.debug & 8) {
+        dA.pack_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pA);
+        dC.pack_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pC);
+    }
+#endif
     dA.init(smem, lane, Cfg::OFF_relA, 0);
     dC.init(smem, lane, Cfg::OFF_relA, Cfg::OFF_gtabC);
     db.init(smem, lane, Cfg::OFF_relb, 0);
@@ -470,6 +500,11 @@ __global__ void __launch_bounds__(64) kf_chunk_lds_kernel(KfArgs<T> a, long L, R
 #else
 #define MF_CHECKSUM_ACC
 #endif
+#ifdef MF_EXPERIMENT
+#define MF_EXP_STEP_NEXT { dA.step_next = dC.step_next = (unsigned)(j + 1); dA.skip_carried = dC.skip_carried = (a.debug & 8) != 0; }
+#else
+#define MF_EXP_STEP_NEXT
+#endif
 #define MF_NOPUMP_ISSUE pump.unpumped();
 #define MF_KF_LDS_STEP(FIRST)                                                                                         \
     {                                                                                                                 \
@@ -498,6 +533,7 @@ __global__ void __launch_bounds__(64) kf_chunk_lds_kernel(KfArgs<T> a, long L, R
                         make_srd(pH, eH, a.debug | ((a.debug >> 1) & 1)),                                             \
                         make_srd(py, ey, a.debug | ((a.debug >> 1) & 1)),                                             \
                         make_srd(pR, eR, a.debug | ((a.debug >> 1) & 1)), lds0, more, yfetch};                        \
+        MF_EXP_STEP_NEXT                                                                                              \
         MF_NOPUMP_ISSUE                                                                                               \
         const bool active = j < len;                                                                                  \
         kf_lds_step<T, D, M, SPIKE, FIRST>(E, laC, acc_yry, acc_ww, C, mvec, hk, yk, Rsh, Bm, pump, active, c > 0);    \

@@ -9,6 +9,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1024); ap.add_argument("--T", type=int, default=10000)
 ap.add_argument("--d", type=int, default=6); ap.add_argument("--dtype", default="f64")
 ap.add_argument("--chunks", type=int, default=0); ap.add_argument("--iters", type=int, default=5); ap.add_argument("--m", type=int, default=1)
+ap.add_argument("--nan-ok", action="store_true", help="experiment builds that produce garbage on purpose: never raise on a pivot")
 args = ap.parse_args()
 dev = torch.device("cuda:0"); dt = torch.float64 if args.dtype == "f64" else torch.float32
 B, T, d = args.batch, args.T, args.d
@@ -27,7 +28,10 @@ hip = ctypes.CDLL("libamdhip64.so")
 e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
 hip.hipEventCreate(ctypes.byref(e0)); hip.hipEventCreate(ctypes.byref(e1))
 kf._prof_events = (e0, e1)
+import contextlib
 ms = []
+ctx = mfa.errors_as_nan() if args.nan_ok else contextlib.nullcontext()
+ctx.__enter__()
 for i in range(args.iters + 2):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     ll = kf.log_likelihood(); torch.cuda.synchronize(); wall = (time.perf_counter() - t0) * 1e3
