@@ -315,6 +315,13 @@ int mf_ssm_kl_grad_f32(int64_t B, int64_t T, int d, const float* mu0_1, const fl
                        float* g_mu0, float* g_cholP0, float* g_A, float* g_b, float* g_cholQ, int* info, void* stream);
 
 /*
+ * KalmanFilter._r_inv (markovflow/kalman_filter.py:341-348): R^-1 = (L L^T)^-1 from the Cholesky factor L [m,m] of the shared
+ * observation covariance (the reference: tf.linalg.cholesky_solve against the identity), out [m,m].  m <= 32; one launch.
+ */
+int mf_obs_precision_from_chol_f64(int m, const double* chol, double* out, int* info, void* stream);
+int mf_obs_precision_from_chol_f32(int m, const float* chol, float* out, int* info, void* stream);
+
+/*
  * BaseKalmanFilter.posterior_state_space_model (markovflow/kalman_filter.py:109-182) fused: ONE backward sweep per series
  * assembles the posterior precision / information vector block by block (state_space_model.py:431-483,
  * kalman_filter.py:86-101,149-156) inside the U D U^T recursion (block_tri_diag.py:438-545) and writes the five tensors of the

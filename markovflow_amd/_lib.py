@@ -36,6 +36,7 @@ _SIGS = {
     "mf_kf_loglik_total": (_int, [_i64, "Tp", _int, "Tp", _i64, "Tp", "T", "Tp", _vp]),
     "mf_kf_loglik_grad": (_int, [_i64, _i64, _int, _int] + ["Tp"] * 8 + [_int] + ["Tp"] * 12 + [_vp, _vp]),
     "mf_ssm_kl_grad": (_int, [_i64, _i64, _int] + ["Tp"] * 18 + [_vp, _vp]),
+    "mf_obs_precision_from_chol": (_int, [_int, "Tp", "Tp", _vp, _vp]),
     "mf_kf_posterior_chain": (_int, [_i64, _i64, _int, _int] + ["Tp"] * 8 + [_int] + ["Tp"] * 5 + [_vp, _vp]),
     "mf_ssm_kl_divergence": (_int, [_i64, _i64, _int] + ["Tp"] * 11 + [_vp, _vp]),
     "mf_ssm_marginals_grad": (_int, [_i64, _i64, _int] + ["Tp"] * 12 + [_vp]),

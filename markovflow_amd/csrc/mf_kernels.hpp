@@ -287,9 +287,18 @@ __global__ void __launch_bounds__(64) red_chunk_kernel(RedSys<T> in, RedSys<T> o
     Elim<T, D, SPIKE> E;
     E.init();
     T acc_sc = T(0);
+    // small blocks: the next block's loads are in flight while the current one is eliminated (a second set of block data fits
+    // the registers next to the spike up to d = 4 in fp64, d = 6 in fp32); these levels are pure latency - 8 dependent steps
+    // on a fraction of the chip - and are a third of an evaluation at BASELINE config 2 (B=256, T=4096, d=4)
+#ifndef MF_RED_PF
+#define MF_RED_PF 1
+#endif
+    constexpr bool PF = MF_RED_PF && (sizeof(T) == 4 ? (D <= 6) : (D <= 4));
+    RedStep<T, D> d, nxt;
+    if (PF && k0 < k1) load_red_step<T, D>(in, s, k0, d);
     for (long k = k0; k < k1; ++k) {
-        RedStep<T, D> d;
-        load_red_step<T, D>(in, s, k, d);
+        if (PF) load_red_step<T, D>(in, s, k + 1 < k1 ? k + 1 : k, nxt);
+        else load_red_step<T, D>(in, s, k, d);
         __builtin_amdgcn_sched_barrier(0);
         red_step_fold<T, D>(d);
         acc_sc += d.sc;
@@ -298,6 +307,7 @@ __global__ void __launch_bounds__(64) red_chunk_kernel(RedSys<T> in, RedSys<T> o
                 E.t[i] = d.rn[i];
                 MF_UNROLL for (int j = 0; j <= i; ++j) E.Phi[i][j] = d.Dn[i][j];
             }
+            if (PF) d = nxt;
             continue;
         }
         if (k == k0) {
@@ -311,6 +321,7 @@ __global__ void __launch_bounds__(64) red_chunk_kernel(RedSys<T> in, RedSys<T> o
             trsm_right_lower_t<T, D, D>(E.Phi, E.Li, d.W);    // W = S L^-T
             E.advance(d.W, d.Dn, d.rn);
         }
+        if (PF) d = nxt;
     }
     const T scalar = acc_sc + T(0.5) * E.quad - E.laL.value();
     store_chunk<T, D, SPIKE>(out, id, E, scalar);

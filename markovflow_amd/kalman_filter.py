@@ -292,8 +292,16 @@ class KalmanFilter(BaseKalmanFilter):
         chol = self._chol_obs_covariance
         if chol.shape[-1] == 1:
             return chol.pow(-2)                   # one tiny kernel instead of a potrs call chain
-        eye = torch.eye(self.emission.output_dim, dtype=chol.dtype, device=chol.device)
-        return _lib.chol_solve(chol, eye.expand(chol.shape))
+        m = self.emission.output_dim
+        if chol.is_cuda and m <= 32 and not (chol.requires_grad and torch.is_grad_enabled()):
+            # one launch (mf_obs_precision_from_chol) instead of an identity + two triangular solves = eleven small kernels
+            out = torch.empty_like(chol, memory_format=torch.contiguous_format)
+            info = _lib.pivot_info(chol.device)
+            _lib.call("mf_obs_precision_from_chol", chol.dtype, m, _lib.ptr(chol.contiguous()), _lib.ptr(out), info,
+                      _lib.stream_ptr(chol.device))
+            return out
+        eye = torch.eye(m, dtype=chol.dtype, device=chol.device)
+        return _lib.chol_solve(chol, eye.expand(chol.shape))               # differentiable route
 
     @property
     def _log_det_observation_precision(self) -> torch.Tensor:

@@ -1,7 +1,8 @@
 """Run one configuration a few times (for rocprofv3 --kernel-trace): python3 scripts/prof_cfg.py head|c2|c4ll|c4kl [iters]"""
 import sys
 import torch
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import markovflow_amd as mfa
 from markovflow_amd import synthetic
 
