@@ -22,12 +22,15 @@ namespace {
 constexpr int D = MF_D;
 constexpr long RED_CHUNK = 8;    // chunk length of the level-0 floor of the parallel-in-time operators
 // reduction levels of the log-likelihood: chunk length, and the size at which the last level is walked serially
+// (d >= 7: a reduction step is ~10 k instructions on one lane, so the levels are cut shorter - 64 -> 16 -> 4 -> walk 4 is 12
+// dependent steps in three launches instead of 16 in two)
+constexpr long RED_DEFAULT = D >= 7 ? 4 : 8;
 inline long red_chunk() {
-    static const long v = [] { const char* e = mf_knob("MF_RED_CHUNK"); const long x = e ? std::atol(e) : 0; return x >= 2 ? x : 8L; }();
+    static const long v = [] { const char* e = mf_knob("MF_RED_CHUNK"); const long x = e ? std::atol(e) : 0; return x >= 2 ? x : RED_DEFAULT; }();
     return v;
 }
 inline long red_final() {
-    static const long v = [] { const char* e = mf_knob("MF_RED_FINAL"); const long x = e ? std::atol(e) : 0; return x >= 1 ? x : 8L; }();
+    static const long v = [] { const char* e = mf_knob("MF_RED_FINAL"); const long x = e ? std::atol(e) : 0; return x >= 1 ? x : RED_DEFAULT; }();
     return v;
 }
 
