@@ -290,10 +290,11 @@ class KalmanFilter(BaseKalmanFilter):
     def _r_inv(self) -> torch.Tensor:
         """``R⁻¹ = (chol cholᵀ)⁻¹`` (kalman_filter.py:341-348)."""
         chol = self._chol_obs_covariance
-        if chol.shape[-1] == 1:
-            return chol.pow(-2)                   # one tiny kernel instead of a potrs call chain
         m = self.emission.output_dim
-        if chol.is_cuda and m <= 32 and not (chol.requires_grad and torch.is_grad_enabled()):
+        differentiable = chol.requires_grad and torch.is_grad_enabled()
+        if chol.shape[-1] == 1 and (differentiable or not chol.is_cuda):
+            return chol.pow(-2)                   # (two element-wise launches: square, reciprocal)
+        if chol.is_cuda and m <= 32 and not differentiable:
             # one launch (mf_obs_precision_from_chol) instead of an identity + two triangular solves = eleven small kernels
             out = torch.empty_like(chol, memory_format=torch.contiguous_format)
             info = _lib.pivot_info(chol.device)
