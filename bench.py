@@ -281,6 +281,23 @@ def launch_ranks(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
+class _StdoutToStderr:
+    """File descriptor 1 points at stderr while this is active: RCCL prints a version banner to STDOUT when its communicator
+    is created, and rank 0's stdout must carry exactly one JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def main():
     args = parse()
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # under torch.distributed.run
@@ -300,7 +317,11 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # RCCL on ROCm
+        with _StdoutToStderr():
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # RCCL on ROCm
+            probe = torch.ones(1, device=torch.device("cuda", local_rank))
+            dist.all_reduce(probe)                                # the communicator (and RCCL's banner) is created here
+            torch.cuda.synchronize()
         world = dist.get_world_size()
     else:
         dist = None
