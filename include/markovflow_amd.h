@@ -298,7 +298,9 @@ int mf_kf_loglik_grad_f32(int64_t B, int64_t T, int d, int m, const float* mu0, 
 /*
  * Gradient of  KL(q1 || q2)  between two state space models (markovflow/state_space_model.py:528-593; differentiated by
  * TensorFlow in the reference, pinned by tests/integration/models/test_variational.py:123-132) with respect to the parameters
- * of q1: ONE backward sweep per series carrying the adjoints of q1's marginal mean and covariance (csrc/mf_kl_grad.hpp).
+ * of q1: the adjoints of q1's marginal mean and covariance, lam_k = n_k + A^T lam_{k+1}, M_k = N_k + A^T M_{k+1} A, in three
+ * kernels - per-step inputs (parallel), a light sequential recursion per series, per-step parameter gradients (parallel);
+ * csrc/mf_kl_grad.hpp.  ws: mf_ssm_adjoint_workspace_bytes.
  * means_1 [B,T,d], covs_1 [B,T,d,d]: marginals of q1 (mf_ssm_marginal_means / mf_ssm_marginal_covariances).  Outputs per series:
  * g_mu0 [B,d], g_cholP0 [B,d,d] (lower), g_A [B,T-1,d,d], g_b [B,T-1,d], g_cholQ [B,T-1,d,d] (lower), scaled by weights [B]
  * (nullable).  The gradient with respect to q2 is MINUS mf_kf_loglik_grad with H = NULL, q2's parameters and q1's moments.
@@ -308,11 +310,12 @@ int mf_ssm_kl_grad_f64(int64_t B, int64_t T, int d, const double* mu0_1, const d
                        const double* b_1, const double* cholQ_1, const double* mu0_2, const double* cholP0_2, const double* A_2,
                        const double* b_2, const double* cholQ_2, const double* means_1, const double* covs_1,
                        const double* weights, double* g_mu0, double* g_cholP0, double* g_A, double* g_b, double* g_cholQ,
-                       int* info, void* stream);
+                       void* ws, size_t ws_bytes, int* info, void* stream);
 int mf_ssm_kl_grad_f32(int64_t B, int64_t T, int d, const float* mu0_1, const float* cholP0_1, const float* A_1,
                        const float* b_1, const float* cholQ_1, const float* mu0_2, const float* cholP0_2, const float* A_2,
                        const float* b_2, const float* cholQ_2, const float* means_1, const float* covs_1, const float* weights,
-                       float* g_mu0, float* g_cholP0, float* g_A, float* g_b, float* g_cholQ, int* info, void* stream);
+                       float* g_mu0, float* g_cholP0, float* g_A, float* g_b, float* g_cholQ, void* ws, size_t ws_bytes,
+                       int* info, void* stream);
 
 /*
  * KalmanFilter._r_inv (markovflow/kalman_filter.py:341-348): R^-1 = (L L^T)^-1 from the Cholesky factor L [m,m] of the shared
@@ -358,15 +361,21 @@ int mf_ssm_kl_divergence_f32(int64_t B, int64_t T, int d, const float* mu0_1, co
  * differentiated by TensorFlow in the reference: the expected log-likelihood of every variational model goes through
  * `marginals`, models/variational.py:150, models/sparse_variational.py:178-192).  Given the incoming gradients g_means [B,T,d] and
  * g_covs [B,T,d,d] (either may be NULL = zero) of a scalar with respect to the marginal means / covariances, and the
- * marginals themselves (means, covs), the gradients with respect to mu0, cholP0 (lower), A, b and cholQ (lower).  One backward
- * sweep per series.  State dimension 1..9.
+ * marginals themselves (means, covs), the gradients with respect to mu0, cholP0 (lower), A, b and cholQ (lower): the same
+ * recursion as mf_ssm_kl_grad with (N_k, n_k) = (g_covs_k + g_covs_k^T, g_means_k), then a parallel kernel.  ws:
+ * mf_ssm_adjoint_workspace_bytes.  State dimension 1..9.
  */
 int mf_ssm_marginals_grad_f64(int64_t B, int64_t T, int d, const double* cholP0, const double* A, const double* cholQ,
                               const double* means, const double* covs, const double* g_means, const double* g_covs,
-                              double* g_mu0, double* g_cholP0, double* g_A, double* g_b, double* g_cholQ, void* stream);
+                              double* g_mu0, double* g_cholP0, double* g_A, double* g_b, double* g_cholQ, void* ws,
+                              size_t ws_bytes, void* stream);
 int mf_ssm_marginals_grad_f32(int64_t B, int64_t T, int d, const float* cholP0, const float* A, const float* cholQ,
                               const float* means, const float* covs, const float* g_means, const float* g_covs, float* g_mu0,
-                              float* g_cholP0, float* g_A, float* g_b, float* g_cholQ, void* stream);
+                              float* g_cholP0, float* g_A, float* g_b, float* g_cholQ, void* ws, size_t ws_bytes, void* stream);
+
+/* Workspace of mf_ssm_kl_grad_* and mf_ssm_marginals_grad_*: per (series, block) the inputs (N_k, n_k) and the results
+ * (M_k, lambda_k) of the adjoint recursion - (2 d^2 + 2 d) elements. */
+size_t mf_ssm_adjoint_workspace_bytes(int64_t B, int64_t T, int d, int elem_size);
 
 #ifdef __cplusplus
 }

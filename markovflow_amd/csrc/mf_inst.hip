@@ -789,12 +789,32 @@ int kf_grad(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, c
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
+// workspace of the adjoint sweeps: N, n, M, lam for every (series, block)
+template <typename T> size_t adjoint_ws(long B, long Tn) {
+    return 2 * align_up(size_t(B) * Tn * D * D * sizeof(T)) + 2 * align_up(size_t(B) * Tn * D * sizeof(T));
+}
+template <typename T> AdjointWs<T, D> carve_adjoint(void* ws, long B, long Tn) {
+    char* p = static_cast<char*>(ws);
+    AdjointWs<T, D> w;
+    w.N = reinterpret_cast<T*>(p); p += align_up(size_t(B) * Tn * D * D * sizeof(T));
+    w.M = reinterpret_cast<T*>(p); p += align_up(size_t(B) * Tn * D * D * sizeof(T));
+    w.n = reinterpret_cast<T*>(p); p += align_up(size_t(B) * Tn * D * sizeof(T));
+    w.lam = reinterpret_cast<T*>(p);
+    return w;
+}
+
 template <typename T>
 int kl_grad(long B, long Tn, const T* mu0_1, const T* C0_1, const T* A_1, const T* b_1, const T* C_1, const T* mu0_2,
             const T* C0_2, const T* A_2, const T* b_2, const T* C_2, const T* pm, const T* pS, const T* weights, T* gmu0,
-            T* gC0, T* gA, T* gb, T* gC, int* info, hipStream_t st) {
-    KlGradArgs<T, D> a{B, Tn, mu0_1, C0_1, A_1, b_1, C_1, mu0_2, C0_2, A_2, b_2, C_2, pm, pS, weights, gmu0, gC0, gA, gb, gC, info};
-    hipLaunchKernelGGL((ssm_kl_grad_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, a);
+            T* gC0, T* gA, T* gb, T* gC, void* ws, size_t ws_bytes, int* info, hipStream_t st) {
+    if (ws == nullptr || ws_bytes < adjoint_ws<T>(B, Tn)) return -21;
+    const AdjointWs<T, D> w = carve_adjoint<T>(ws, B, Tn);
+    const dim3 per_step((unsigned)cdiv(B * Tn, 64)), per_series((unsigned)cdiv(B, 64)), block(64);
+    hipLaunchKernelGGL((ssm_kl_adjoint_inputs_kernel<T, D>), per_step, block, 0, st, B, Tn, A_1, b_1, A_2, b_2, C_2, pm, w, info);
+    hipLaunchKernelGGL((ssm_adjoint_scan_kernel<T, D>), per_series, block, 0, st, B, Tn, A_1, static_cast<const T*>(nullptr),
+                       static_cast<const T*>(nullptr), 1, w);
+    AdjointLocalArgs<T, D> a{B, Tn, mu0_1, C0_1, A_1, b_1, C_1, mu0_2, C0_2, A_2, b_2, C_2, pm, pS, weights, gmu0, gC0, gA, gb, gC, info};
+    hipLaunchKernelGGL((ssm_adjoint_local_kernel<T, D, true>), per_step, block, 0, st, a, w);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
@@ -820,9 +840,14 @@ int kl_value(long B, long Tn, const T* mu0_1, const T* C0_1, const T* A_1, const
 
 template <typename T>
 int marginals_grad(long B, long Tn, const T* C0, const T* A, const T* C, const T* pm, const T* pS, const T* gm, const T* gS,
-                   T* gmu0, T* gC0, T* gA, T* gb, T* gC, hipStream_t st) {
-    hipLaunchKernelGGL((ssm_marginals_grad_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, Tn, C0, A, C, pm,
-                       pS, gm, gS, gmu0, gC0, gA, gb, gC);
+                   T* gmu0, T* gC0, T* gA, T* gb, T* gC, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (ws == nullptr || ws_bytes < adjoint_ws<T>(B, Tn)) return -16;
+    const AdjointWs<T, D> w = carve_adjoint<T>(ws, B, Tn);
+    const dim3 per_step((unsigned)cdiv(B * Tn, 64)), per_series((unsigned)cdiv(B, 64)), block(64);
+    hipLaunchKernelGGL((ssm_adjoint_scan_kernel<T, D>), per_series, block, 0, st, B, Tn, A, gm, gS, 0, w);
+    AdjointLocalArgs<T, D> a{B, Tn, nullptr, C0, A, nullptr, C, nullptr, nullptr, nullptr, nullptr, nullptr, pm, pS, nullptr,
+                             gmu0, gC0, gA, gb, gC, nullptr};
+    hipLaunchKernelGGL((ssm_adjoint_local_kernel<T, D, false>), per_step, block, 0, st, a, w);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
@@ -830,7 +855,7 @@ template <typename T> const OpsTable<T>* table() {
     static const OpsTable<T> t = {
         &kf_loglik_ws<T>, &kf_loglik<T>, &btd_logdet_quad_ws<T>, &btd_logdet_quad<T>, &btd_cholesky_ws<T>, &btd_cholesky<T>,
         &btd_solve_ws<T>, &btd_solve<T>,    &btd_matvec<T>, &btd_logdet<T>,        &btd_diag_of_inverse_ws<T>, &btd_diag_of_inverse<T>, &ssm_marginal_covs<T>, &btd_udl_ws<T>, &btd_udl<T>,
-        &ssm_precision<T>, &ssm_means<T>, &block_matmul<T>, &gpr_loglik<T>, &sde_predict<T>, &kf_grad<T>, &kl_grad<T>, &posterior_chain<T>, &kl_value<T>, &marginals_grad<T>,
+        &ssm_precision<T>, &ssm_means<T>, &block_matmul<T>, &gpr_loglik<T>, &sde_predict<T>, &kf_grad<T>, &kl_grad<T>, &posterior_chain<T>, &kl_value<T>, &marginals_grad<T>, &adjoint_ws<T>,
     };
     return &t;
 }

@@ -6,7 +6,7 @@
 //   KL = 1/2 tr(P0_2^-1 (S_0 + d0 d0^T)) + 1/2 sum_k [ tr(Q2_k^-1 Q1_k) + tr(Q2_k^-1 dA_k (S_k + m_k m_k^T) dA_k^T)
 //        + 2 db_k^T Q2_k^-1 dA_k m_k + db_k^T Q2_k^-1 db_k ] - H(q1) + terms of q2 alone,
 // so the gradient is the local partial derivative plus the adjoint of the moment recursion  m_{k+1} = A1 m_k + b1,
-// S_{k+1} = A1 S_k A1^T + Q1  - ONE backward sweep per series carrying  lam_k (d)  and  M_k = 2 dKL/dS_k (d x d, symmetric):
+// S_{k+1} = A1 S_k A1^T + Q1  - a backward recursion per series for  lam_k (d)  and  M_k = 2 dKL/dS_k (d x d, symmetric):
 //   lam_k = dA_k^T Q2_k^-1 eps_k + A1_k^T lam_{k+1},      eps_k = dA_k m_k + db_k,
 //   M_k   = dA_k^T Q2_k^-1 dA_k + A1_k^T M_{k+1} A1_k,    lam_{T-1} = 0, M_{T-1} = 0,
 //   dKL/db1_k = Q2_k^-1 eps_k + lam_{k+1},
@@ -14,7 +14,8 @@
 //   dKL/dC1_k = tril((Q2_k^-1 + M_{k+1}) C1_k) - diag(1 / C1_k)          (Q1 = C1 C1^T; the last term is the entropy),
 //   dKL/dmu0_1 = P0_2^-1 d0 + lam_0,   dKL/dC0_1 = tril((P0_2^-1 + M_0) C0_1) - diag(1 / C0_1).
 // The gradient with respect to q2 is local in time (minus the expected complete-data score of q2 under q1's marginals) and
-// comes from kf_grad_kernel.  One lane per series, natural (backward) order.
+// comes from kf_grad_kernel.  The recursion and the local parts run as three kernels (below: "the adjoint in three kernels");
+// `marginals` (state_space_model.py:232-262) has the same adjoint with the incoming gradients as (N_k, n_k).
 #pragma once
 #include "mf_small.hpp"
 
@@ -129,219 +130,257 @@ __global__ void __launch_bounds__(64) ssm_kl_kernel(long B, long Tn, const T* __
     if (bad && info) raise_info(info);
 }
 
+// ---- the adjoint in three kernels (round 2, second form) ------------------------------------------------------------------
+// The ONE-sweep forms of the two adjoints (everything inside the sequential loop) were correct but slow where it matters: at
+// BASELINE config 4's shape (B = 512, T = 1000, d = 9) a step carried four d x d matrices plus the state, spilt 3.2 KB per lane
+// and took 70 us - 70 ms per backward on 8 wavefronts.  Both adjoints are the same recursion
+//     M_k = N_k + A_k^T M_{k+1} A_k,      lam_k = n_k + A_k^T lam_{k+1}            (M = 2 dF/dS_k, symmetric; lam = dF/dm_k)
+// driven by per-step inputs (N_k, n_k) that are LOCAL in time, and followed by parameter gradients that are local given
+// (M_{k+1}, lam_{k+1}).  So:
+//   1. a parallel kernel, one lane per (series, step), forms (N_k, n_k)              [KL only; `marginals` reads them directly]
+//   2. a LIGHT sequential sweep, one lane per series, runs the recursion and writes M_k, lam_k: the only state is M (lower),
+//      one transition matrix and one column - 180 doubles at d = 9, no spills
+//   3. a parallel kernel, one lane per (series, step), turns (M_{k+1}, lam_{k+1}) into the gradients of A_k, b_k, cholQ_k
+//      (the lane of step 0 also does mu0 and cholP0), row by row so that no d x d temporary is ever held whole.
+// Workspace: N [B,T,d,d], n [B,T,d], M [B,T,d,d], lam [B,T,d].
+
+template <typename T, int D> struct AdjointWs {
+    T *N, *n, *M, *lam;
+};
+
+// ---- 1. KL: per-step inputs of the recursion ----------------------------------------------------------------------------------
+//   N_k = dA_k^T Q2_k^-1 dA_k,   n_k = dA_k^T Q2_k^-1 eps_k   for k < T-1;   N_{T-1} = 0, n_{T-1} = 0.
 template <typename T, int D>
-struct KlGradArgs {
+__global__ void __launch_bounds__(64) ssm_kl_adjoint_inputs_kernel(long B, long Tn, const T* __restrict__ A_1,
+                                                                   const T* __restrict__ b_1, const T* __restrict__ A_2,
+                                                                   const T* __restrict__ b_2, const T* __restrict__ C_2,
+                                                                   const T* __restrict__ pm, AdjointWs<T, D> ws, int* info) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= B * Tn) return;
+    const long s = id / Tn, k = id % Tn;
+    T* Nout = ws.N + id * D * D;
+    T* nout = ws.n + id * D;
+    if (k + 1 >= Tn) {
+        MF_UNROLL for (int e = 0; e < D * D; ++e) Nout[e] = T(0);
+        MF_UNROLL for (int e = 0; e < D; ++e) nout[e] = T(0);
+        return;
+    }
+    const long tid = s * (Tn - 1) + k;
+    T W[D][D], C2[D][D], C2i[D][D], mk[D], eps[D], u[D], qe[D];
+    {
+        T A1[D][D];
+        load_mat<T, D, D>(A_1 + tid * D * D, A1);
+        load_mat<T, D, D>(A_2 + tid * D * D, W);
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) W[i][j] = A1[i][j] - W[i][j];      // dA
+    }
+    load_lower<T, D>(C_2 + tid * D * D, C2);
+    load_vec<T, D>(pm + id * D, mk);
+    MF_UNROLL for (int i = 0; i < D; ++i) eps[i] = b_1[tid * D + i] - b_2[tid * D + i];
+    LogAcc<T> la;
+    la.init();
+    bool bad = false;
+    tri_inv_lower<T, D>(C2, C2i, la, bad);
+    MF_UNROLL for (int j = 0; j < D; ++j) MF_UNROLL for (int i = 0; i < D; ++i) eps[i] += W[i][j] * mk[j];
+    trimul_lower_vec<T, D>(C2i, eps, u);
+    trimulT_lower_vec<T, D>(C2i, u, qe);                         // Q2^-1 eps
+    MF_UNROLL for (int j = 0; j < D; ++j) {
+        T acc = T(0);
+        MF_UNROLL for (int i = 0; i < D; ++i) acc += W[i][j] * qe[i];
+        nout[j] = acc;                                           // dA^T Q2^-1 eps
+    }
+    trimul_lower_inplace<T, D, D>(C2i, W);                       // C2^-1 dA
+    MF_UNROLL for (int i = 0; i < D; ++i)
+        MF_UNROLL for (int j = 0; j <= i; ++j) {
+            T acc = T(0);
+            MF_UNROLL for (int l = 0; l < D; ++l) acc += W[l][i] * W[l][j];
+            Nout[i * D + j] = acc;
+            Nout[j * D + i] = acc;
+        }
+    if (bad && info) raise_info(info);
+}
+
+// ---- 2. the recursion ---------------------------------------------------------------------------------------------------------
+// Inputs either from the workspace (ws.N symmetric, ws.n) or, for `marginals`, straight from the incoming gradients:
+// N_k = gS_k + gS_k^T, n_k = gm_k (either may be NULL = zero).
+template <typename T, int D>
+__global__ void __launch_bounds__(64) ssm_adjoint_scan_kernel(long B, long Tn, const T* __restrict__ A, const T* __restrict__ gm,
+                                                              const T* __restrict__ gS, int from_ws, AdjointWs<T, D> ws) {
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= B) return;
+    T M[D][D], lam[D];                                           // M: lower triangle
+    MF_UNROLL for (int i = 0; i < D; ++i) {
+        lam[i] = T(0);
+        MF_UNROLL for (int j = 0; j <= i; ++j) M[i][j] = T(0);
+    }
+    for (long k = Tn - 1; k >= 0; --k) {
+        const long id = s * Tn + k;
+        T Mn[D][D], ln[D];                                       // the inputs of block k
+        if (from_ws) {
+            load_lower<T, D>(ws.N + id * D * D, Mn);
+            load_vec<T, D>(ws.n + id * D, ln);
+        } else {
+            MF_UNROLL for (int i = 0; i < D; ++i) {
+                ln[i] = gm ? gm[id * D + i] : T(0);
+                MF_UNROLL for (int j = 0; j <= i; ++j) Mn[i][j] = gS ? gS[(id * D + i) * D + j] + gS[(id * D + j) * D + i] : T(0);
+            }
+        }
+        if (k + 1 < Tn) {
+            T Am[D][D];
+            load_mat<T, D, D>(A + (s * (Tn - 1) + k) * D * D, Am);
+            __builtin_amdgcn_sched_barrier(0);
+            // lam <- n_k + A^T lam ;  M <- N_k + A^T (M A), one column of M A at a time
+            MF_UNROLL for (int j = 0; j < D; ++j) {
+                T acc = T(0);
+                MF_UNROLL for (int i = 0; i < D; ++i) acc += Am[i][j] * lam[i];
+                ln[j] += acc;
+            }
+            MF_UNROLL for (int j = 0; j < D; ++j) {
+                T col[D];                                        // (M A)[:, j]
+                MF_UNROLL for (int i = 0; i < D; ++i) col[i] = T(0);
+                MF_UNROLL for (int l = 0; l < D; ++l)
+                    MF_UNROLL for (int i = 0; i < D; ++i) col[i] += ((i >= l) ? M[i][l] : M[l][i]) * Am[l][j];
+                MF_UNROLL for (int i = j; i < D; ++i) {          // lower triangle of A^T (M A): rows i >= j
+                    T acc = T(0);
+                    MF_UNROLL for (int l = 0; l < D; ++l) acc += Am[l][i] * col[l];
+                    Mn[i][j] += acc;
+                }
+            }
+        }
+        MF_UNROLL for (int i = 0; i < D; ++i) {
+            lam[i] = ln[i];
+            MF_UNROLL for (int j = 0; j <= i; ++j) M[i][j] = Mn[i][j];
+        }
+        store_sym<T, D>(ws.M + id * D * D, M);
+        store_vec<T, D>(ws.lam + id * D, lam);
+    }
+}
+
+// ---- 3. parameter gradients, local in time --------------------------------------------------------------------------------------
+// KL = true:  db = w (Q2^-1 eps + lam_{k+1}),  dA = w ((Q2^-1 eps + lam_{k+1}) m_k^T + (Q2^-1 dA + M_{k+1} A1) S_k),
+//             dC = w (tril((Q2^-1 + M_{k+1}) C1) - diag(1 / C1));   step 0 also: dmu0 = w (P0_2^-1 d0 + lam_0),
+//             dC0 = w (tril((P0_2^-1 + M_0) C0_1) - diag(1 / C0_1)).
+// KL = false (`marginals`):  db = lam_{k+1},  dA = lam_{k+1} m_k^T + M_{k+1} A S_k,  dC = tril(M_{k+1} C);  dmu0 = lam_0,
+//             dC0 = tril(M_0 C0).
+template <typename T, int D> struct AdjointLocalArgs {
     long B, Tn;
-    const T *mu0_1, *C0_1, *A_1, *b_1, *C_1;
-    const T *mu0_2, *C0_2, *A_2, *b_2, *C_2;
+    const T *mu0_1, *C0_1, *A_1, *b_1, *C_1;          // the chain whose gradients are formed
+    const T *mu0_2, *C0_2, *A_2, *b_2, *C_2;          // KL only: the second chain
     const T *pm, *pS, *weights;
     T *gmu0, *gC0, *gA, *gb, *gC;
     int* info;
 };
 
-// out(lower, incl. diagonal) = tril((C2i^T C2i + M) C1) - diag(1 / C1);   C1, C2i lower triangular, M full symmetric
+// out(lower) = w * (tril((Qinv + Msym) C) - ent * diag(1 / C));  Qinv = Ci^T Ci (Ci lower, may be NULL), Msym symmetric full
 template <typename T, int D>
-MF_DEV void kl_chol_grad(const T (&C2i)[D][D], const T (&M)[D][D], const T (&C1)[D][D], T w, T* __restrict__ dst) {
-    T t1[D][D], G[D][D];
-    // t1 = C2i C1 (lower x lower); only the lower triangle is non-zero
-    MF_UNROLL for (int i = 0; i < D; ++i)
-        MF_UNROLL for (int j = 0; j < D; ++j) {
-            T acc = T(0);
-            MF_UNROLL for (int l = 0; l < D; ++l)
-                if (l <= i && j <= l) acc += C2i[i][l] * C1[l][j];
-            t1[i][j] = acc;
-        }
-    // G = tril(C2i^T t1 + M C1)
+MF_DEV void adjoint_chol_grad(const T (*Ci)[D], const T (&Ms)[D][D], const T (&C)[D][D], T w, bool entropy, T* __restrict__ dst) {
+    T t1[D][D];
+    if (Ci) {
+        MF_UNROLL for (int i = 0; i < D; ++i)
+            MF_UNROLL for (int j = 0; j < D; ++j) {
+                T acc = T(0);
+                MF_UNROLL for (int l = 0; l < D; ++l)
+                    if (l <= i && j <= l) acc += Ci[i][l] * C[l][j];
+                t1[i][j] = acc;
+            }
+    }
+    T G[D][D];
     MF_UNROLL for (int i = 0; i < D; ++i)
         MF_UNROLL for (int j = 0; j <= i; ++j) {
             T acc = T(0);
-            MF_UNROLL for (int l = i; l < D; ++l) acc += C2i[l][i] * t1[l][j];
-            MF_UNROLL for (int l = j; l < D; ++l) acc += M[i][l] * C1[l][j];
-            G[i][j] = w * (acc - ((i == j) ? t_rcp<T>(C1[i][i]) : T(0)));
+            if (Ci) { MF_UNROLL for (int l = i; l < D; ++l) acc += Ci[l][i] * t1[l][j]; }
+            MF_UNROLL for (int l = j; l < D; ++l) acc += Ms[i][l] * C[l][j];
+            G[i][j] = w * (acc - ((entropy && i == j) ? t_rcp<T>(C[i][i]) : T(0)));
         }
     store_lower<T, D>(dst, G);
 }
 
-template <typename T, int D>
-__global__ void __launch_bounds__(64) ssm_kl_grad_kernel(KlGradArgs<T, D> a) {
-    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= a.B) return;
-    const T w = a.weights ? a.weights[s] : T(1);
-    T lam[D], M[D][D];
-    MF_UNROLL for (int i = 0; i < D; ++i) {
-        lam[i] = T(0);
-        MF_UNROLL for (int j = 0; j < D; ++j) M[i][j] = T(0);
-    }
+template <typename T, int D, bool KL>
+__global__ void __launch_bounds__(64) ssm_adjoint_local_kernel(AdjointLocalArgs<T, D> a, AdjointWs<T, D> ws) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= a.B * a.Tn) return;
+    const long s = id / a.Tn, k = id % a.Tn;
+    const T w = (KL && a.weights) ? a.weights[s] : T(1);
     LogAcc<T> la;
     la.init();
     bool bad = false;
-    for (long k = a.Tn - 2; k >= 0; --k) {
-        const long tid = s * (a.Tn - 1) + k, id = s * a.Tn + k;
-        T A1[D][D], dA[D][D], C2[D][D], C2i[D][D], mk[D], eps[D];
-        load_mat<T, D, D>(a.A_1 + tid * D * D, A1);
-        load_mat<T, D, D>(a.A_2 + tid * D * D, dA);
-        load_lower<T, D>(a.C_2 + tid * D * D, C2);
-        load_vec<T, D>(a.pm + id * D, mk);
-        MF_UNROLL for (int i = 0; i < D; ++i) {
-            eps[i] = a.b_1[tid * D + i] - a.b_2[tid * D + i];
-            MF_UNROLL for (int j = 0; j < D; ++j) dA[i][j] = A1[i][j] - dA[i][j];
-        }
-        tri_inv_lower<T, D>(C2, C2i, la, bad);
-        la.init();                                              // the running product is not used here
-        MF_UNROLL for (int j = 0; j < D; ++j) MF_UNROLL for (int i = 0; i < D; ++i) eps[i] += dA[i][j] * mk[j];
-        T u[D], gl[D];
-        trimul_lower_vec<T, D>(C2i, eps, u);
-        trimulT_lower_vec<T, D>(C2i, u, gl);                    // Q2^-1 eps
-        // adjoint of the mean, part 1 (needs Q2^-1 eps before lam is folded into gl)
-        T lam_new[D];
-        MF_UNROLL for (int j = 0; j < D; ++j) lam_new[j] = T(0);
-        MF_UNROLL for (int i = 0; i < D; ++i)
-            MF_UNROLL for (int j = 0; j < D; ++j) lam_new[j] += dA[i][j] * gl[i] + A1[i][j] * lam[i];
-        MF_UNROLL for (int i = 0; i < D; ++i) gl[i] += lam[i];
-        T W[D][D], G[D][D], MA[D][D];
-        trimul_lower<T, D, D>(C2i, dA, W);                      // C2^-1 dA
-        trimulT_lower<T, D, D>(C2i, W, G);                      // Q2^-1 dA
-        MF_UNROLL for (int i = 0; i < D; ++i) {
-            MF_UNROLL for (int j = 0; j < D; ++j) MA[i][j] = M[i][0] * A1[0][j];
-            MF_UNROLL for (int l = 1; l < D; ++l)
-                MF_UNROLL for (int j = 0; j < D; ++j) MA[i][j] += M[i][l] * A1[l][j];
-            MF_UNROLL for (int j = 0; j < D; ++j) G[i][j] += MA[i][j];
-        }
-        {
-            // dA1 = w (gl m_k^T + G S_k),  db1 = w gl
-            T Sk[D][D], out[D][D];
-            load_mat<T, D, D>(a.pS + id * D * D, Sk);
-            MF_UNROLL for (int i = 0; i < D; ++i) {
-                MF_UNROLL for (int j = 0; j < D; ++j) out[i][j] = gl[i] * mk[j];
-                MF_UNROLL for (int l = 0; l < D; ++l)
-                    MF_UNROLL for (int j = 0; j < D; ++j) out[i][j] += G[i][l] * Sk[l][j];
-                MF_UNROLL for (int j = 0; j < D; ++j) out[i][j] *= w;
-            }
-            store_mat<T, D, D>(a.gA + tid * D * D, out);
-            MF_UNROLL for (int i = 0; i < D; ++i) a.gb[tid * D + i] = w * gl[i];
-        }
-        {
-            T C1[D][D];
-            MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) C1[i][j] = T(0);
-            load_lower<T, D>(a.C_1 + tid * D * D, C1);
-            MF_UNROLL for (int i = 0; i < D; ++i) bad |= !(C1[i][i] != T(0));
-            kl_chol_grad<T, D>(C2i, M, C1, w, a.gC + tid * D * D);
-        }
-        // M <- W^T W + A1^T (M A1)
-        MF_UNROLL for (int i = 0; i < D; ++i)
-            MF_UNROLL for (int j = 0; j < D; ++j) {
-                T acc = T(0);
-                MF_UNROLL for (int l = 0; l < D; ++l) acc += W[l][i] * W[l][j] + A1[l][i] * MA[l][j];
-                M[i][j] = acc;
-            }
-        // keep M exactly symmetric (it is in exact arithmetic; rounding would otherwise drift over long chains)
-        MF_UNROLL for (int i = 0; i < D; ++i)
-            MF_UNROLL for (int j = 0; j < i; ++j) {
-                const T v = T(0.5) * (M[i][j] + M[j][i]);
-                M[i][j] = v;
-                M[j][i] = v;
-            }
-        MF_UNROLL for (int i = 0; i < D; ++i) lam[i] = lam_new[i];
-    }
-    {
-        T C2[D][D], C2i[D][D], d0[D], u[D], g[D], C1[D][D];
-        load_lower<T, D>(a.C0_2 + s * D * D, C2);
-        tri_inv_lower<T, D>(C2, C2i, la, bad);
-        MF_UNROLL for (int i = 0; i < D; ++i) d0[i] = a.mu0_1[s * D + i] - a.mu0_2[s * D + i];
-        trimul_lower_vec<T, D>(C2i, d0, u);
-        trimulT_lower_vec<T, D>(C2i, u, g);
-        MF_UNROLL for (int i = 0; i < D; ++i) a.gmu0[s * D + i] = w * (g[i] + lam[i]);
+    if (k == 0) {
+        // ---- prior of the first state ----------------------------------------------------------------------------------
+        T M0[D][D], C1[D][D], g[D];
+        load_mat<T, D, D>(ws.M + id * D * D, M0);
+        load_vec<T, D>(ws.lam + id * D, g);
         MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) C1[i][j] = T(0);
         load_lower<T, D>(a.C0_1 + s * D * D, C1);
-        MF_UNROLL for (int i = 0; i < D; ++i) bad |= !(C1[i][i] != T(0));
-        kl_chol_grad<T, D>(C2i, M, C1, w, a.gC0 + s * D * D);
+        if (KL) {
+            T C2[D][D], C2i[D][D], d0[D], u[D], q[D];
+            load_lower<T, D>(a.C0_2 + s * D * D, C2);
+            tri_inv_lower<T, D>(C2, C2i, la, bad);
+            MF_UNROLL for (int i = 0; i < D; ++i) {
+                d0[i] = a.mu0_1[s * D + i] - a.mu0_2[s * D + i];
+                bad |= !(C1[i][i] != T(0));
+            }
+            trimul_lower_vec<T, D>(C2i, d0, u);
+            trimulT_lower_vec<T, D>(C2i, u, q);
+            MF_UNROLL for (int i = 0; i < D; ++i) a.gmu0[s * D + i] = w * (q[i] + g[i]);
+            adjoint_chol_grad<T, D>(C2i, M0, C1, w, true, a.gC0 + s * D * D);
+        } else {
+            MF_UNROLL for (int i = 0; i < D; ++i) a.gmu0[s * D + i] = g[i];
+            adjoint_chol_grad<T, D>(static_cast<const T(*)[D]>(nullptr), M0, C1, T(1), false, a.gC0 + s * D * D);
+        }
+    }
+    if (k + 1 >= a.Tn) {
+        if (bad && a.info) raise_info(a.info);
+        return;
+    }
+    // ---- transition k -> k+1 ---------------------------------------------------------------------------------------------
+    const long tid = s * (a.Tn - 1) + k;
+    T Mn[D][D], gl[D], A1[D][D], mk[D];
+    load_mat<T, D, D>(ws.M + (id + 1) * D * D, Mn);               // M_{k+1} (symmetric, stored full)
+    load_vec<T, D>(ws.lam + (id + 1) * D, gl);                    // lam_{k+1}
+    load_mat<T, D, D>(a.A_1 + tid * D * D, A1);
+    load_vec<T, D>(a.pm + id * D, mk);
+    T C2i[D][D], W[D][D];                                         // KL only
+    if (KL) {
+        T C2[D][D], eps[D], u[D], qe[D];
+        load_mat<T, D, D>(a.A_2 + tid * D * D, W);
+        load_lower<T, D>(a.C_2 + tid * D * D, C2);
+        MF_UNROLL for (int i = 0; i < D; ++i) {
+            eps[i] = a.b_1[tid * D + i] - a.b_2[tid * D + i];
+            MF_UNROLL for (int j = 0; j < D; ++j) W[i][j] = A1[i][j] - W[i][j];
+        }
+        tri_inv_lower<T, D>(C2, C2i, la, bad);
+        MF_UNROLL for (int j = 0; j < D; ++j) MF_UNROLL for (int i = 0; i < D; ++i) eps[i] += W[i][j] * mk[j];
+        trimul_lower_vec<T, D>(C2i, eps, u);
+        trimulT_lower_vec<T, D>(C2i, u, qe);
+        MF_UNROLL for (int i = 0; i < D; ++i) gl[i] += qe[i];
+        trimul_lower_inplace<T, D, D>(C2i, W);                    // C2^-1 dA   (Q2^-1 dA = C2i^T W, formed row by row below)
+    }
+    MF_UNROLL for (int i = 0; i < D; ++i) a.gb[tid * D + i] = w * gl[i];
+    {
+        // dA row by row: G[i][:] = sum_l M[i][l] A1[l][:] (+ sum_{l >= i} C2i[l][i] W[l][:]);  out[i][:] = gl[i] m^T + G[i][:] S
+        T Sk[D][D];
+        load_mat<T, D, D>(a.pS + id * D * D, Sk);
+        MF_UNROLL for (int i = 0; i < D; ++i) {
+            T grow[D], orow[D];
+            MF_UNROLL for (int j = 0; j < D; ++j) grow[j] = T(0);
+            MF_UNROLL for (int l = 0; l < D; ++l) MF_UNROLL for (int j = 0; j < D; ++j) grow[j] += Mn[i][l] * A1[l][j];
+            if (KL) { MF_UNROLL for (int l = i; l < D; ++l) MF_UNROLL for (int j = 0; j < D; ++j) grow[j] += C2i[l][i] * W[l][j]; }
+            MF_UNROLL for (int j = 0; j < D; ++j) orow[j] = gl[i] * mk[j];
+            MF_UNROLL for (int l = 0; l < D; ++l) MF_UNROLL for (int j = 0; j < D; ++j) orow[j] += grow[l] * Sk[l][j];
+            MF_UNROLL for (int j = 0; j < D; ++j) a.gA[(tid * D + i) * D + j] = w * orow[j];
+        }
+    }
+    {
+        T C1[D][D];
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) C1[i][j] = T(0);
+        load_lower<T, D>(a.C_1 + tid * D * D, C1);
+        if (KL) {
+            MF_UNROLL for (int i = 0; i < D; ++i) bad |= !(C1[i][i] != T(0));
+            adjoint_chol_grad<T, D>(C2i, Mn, C1, w, true, a.gC + tid * D * D);
+        } else {
+            adjoint_chol_grad<T, D>(static_cast<const T(*)[D]>(nullptr), Mn, C1, T(1), false, a.gC + tid * D * D);
+        }
     }
     if (bad && a.info) raise_info(a.info);
-}
-
-
-// Adjoint of the moment recursion itself: given the incoming gradients gm [B,T,d] and gS [B,T,d,d] of a scalar with respect to
-// the marginal means and covariances of a chain (either may be NULL = zero), the gradients with respect to the chain's
-// parameters.  This is what makes `StateSpaceModel.marginals` differentiable (the reference differentiates
-// state_space_model.py:232-262 through TensorFlow; the expected log-likelihood term of every variational model goes through
-// it, e.g. models/variational.py:150, sparse_variational.py:178-192):
-//   lam_k = gm_k + A_k^T lam_{k+1},   L_k = sym(gS_k) + A_k^T L_{k+1} A_k,
-//   db_k = lam_{k+1},  dA_k = lam_{k+1} m_k^T + 2 L_{k+1} A_k S_k,  dC_k = 2 tril(L_{k+1} C_k),  dmu0 = lam_0,  dC0 = 2 tril(L_0 C0).
-template <typename T, int D>
-__global__ void __launch_bounds__(64) ssm_marginals_grad_kernel(long B, long Tn, const T* __restrict__ C0,
-                                                                const T* __restrict__ A, const T* __restrict__ C,
-                                                                const T* __restrict__ pm, const T* __restrict__ pS,
-                                                                const T* __restrict__ gm, const T* __restrict__ gS,
-                                                                T* __restrict__ gmu0, T* __restrict__ gC0, T* __restrict__ gA,
-                                                                T* __restrict__ gb, T* __restrict__ gC) {
-    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= B) return;
-    T lam[D], L[D][D];
-    auto add_incoming = [&](long id, bool first) {
-        MF_UNROLL for (int i = 0; i < D; ++i) {
-            const T v = gm ? gm[id * D + i] : T(0);
-            lam[i] = first ? v : lam[i] + v;
-        }
-        MF_UNROLL for (int i = 0; i < D; ++i)
-            MF_UNROLL for (int j = 0; j <= i; ++j) {
-                const T v = gS ? T(0.5) * (gS[(id * D + i) * D + j] + gS[(id * D + j) * D + i]) : T(0);
-                const T nv = first ? v : T(0.5) * (L[i][j] + L[j][i]) + v;
-                L[i][j] = nv;
-                L[j][i] = nv;
-            }
-    };
-    add_incoming(s * Tn + Tn - 1, true);
-    for (long k = Tn - 2; k >= 0; --k) {
-        const long tid = s * (Tn - 1) + k, id = s * Tn + k;
-        T Am[D][D], Cm[D][D], mk[D], Sk[D][D], LA[D][D], out[D][D];
-        load_mat<T, D, D>(A + tid * D * D, Am);
-        load_vec<T, D>(pm + id * D, mk);
-        load_mat<T, D, D>(pS + id * D * D, Sk);
-        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Cm[i][j] = T(0);
-        load_lower<T, D>(C + tid * D * D, Cm);
-        MF_UNROLL for (int i = 0; i < D; ++i) gb[tid * D + i] = lam[i];
-        MF_UNROLL for (int i = 0; i < D; ++i) {
-            MF_UNROLL for (int j = 0; j < D; ++j) LA[i][j] = L[i][0] * Am[0][j];
-            MF_UNROLL for (int l = 1; l < D; ++l)
-                MF_UNROLL for (int j = 0; j < D; ++j) LA[i][j] += L[i][l] * Am[l][j];
-        }
-        MF_UNROLL for (int i = 0; i < D; ++i) {
-            MF_UNROLL for (int j = 0; j < D; ++j) out[i][j] = lam[i] * mk[j];
-            MF_UNROLL for (int l = 0; l < D; ++l)
-                MF_UNROLL for (int j = 0; j < D; ++j) out[i][j] += T(2) * LA[i][l] * Sk[l][j];
-        }
-        store_mat<T, D, D>(gA + tid * D * D, out);
-        MF_UNROLL for (int i = 0; i < D; ++i)
-            MF_UNROLL for (int j = 0; j <= i; ++j) {
-                T acc = T(0);
-                MF_UNROLL for (int l = j; l < D; ++l) acc += L[i][l] * Cm[l][j];
-                out[i][j] = T(2) * acc;
-            }
-        store_lower<T, D>(gC + tid * D * D, out);
-        // lam <- A^T lam,  L <- A^T (L A);  then the incoming gradients of block k
-        T ln[D];
-        MF_UNROLL for (int j = 0; j < D; ++j) ln[j] = T(0);
-        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) ln[j] += Am[i][j] * lam[i];
-        MF_UNROLL for (int i = 0; i < D; ++i) lam[i] = ln[i];
-        MF_UNROLL for (int i = 0; i < D; ++i)
-            MF_UNROLL for (int j = 0; j < D; ++j) {
-                T acc = T(0);
-                MF_UNROLL for (int l = 0; l < D; ++l) acc += Am[l][i] * LA[l][j];
-                L[i][j] = acc;
-            }
-        add_incoming(id, false);
-    }
-    MF_UNROLL for (int i = 0; i < D; ++i) gmu0[s * D + i] = lam[i];
-    T Cm[D][D], out[D][D];
-    MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Cm[i][j] = T(0);
-    load_lower<T, D>(C0 + s * D * D, Cm);
-    MF_UNROLL for (int i = 0; i < D; ++i)
-        MF_UNROLL for (int j = 0; j <= i; ++j) {
-            T acc = T(0);
-            MF_UNROLL for (int l = j; l < D; ++l) acc += L[i][l] * Cm[l][j];
-            out[i][j] = T(2) * acc;
-        }
-    store_lower<T, D>(gC0 + s * D * D, out);
 }
 
 }  // namespace mf

@@ -385,8 +385,11 @@ class _KLDivergence(torch.autograd.Function):
             c = lambda t: _lib.ptr(t.contiguous())  # noqa: E731
             info = _lib.pivot_info(dev)
             g1 = [torch.empty_like(t) for t in (mu1, c01, a1, b1, c1)]
+            ws_bytes = int(_lib.load().mf_ssm_adjoint_workspace_bytes(bsz, n, d, mu1.element_size()))
+            ws = _lib.workspace(ws_bytes, dev)
             _lib.call("mf_ssm_kl_grad", dtype, bsz, n, d, c(mu1), c(c01), c(a1), c(b1), c(c1), c(mu2), c(c02), c(a2), c(b2),
-                      c(c2), c(means), c(covs), _lib.ptr(w), *[_lib.ptr(g) for g in g1], info, _lib.stream_ptr(dev))
+                      c(c2), c(means), c(covs), _lib.ptr(w), *[_lib.ptr(g) for g in g1], _lib.ptr(ws), ws_bytes, info,
+                      _lib.stream_ptr(dev))
             g2 = [torch.empty_like(t) for t in (mu2, c02, a2, b2, c2)]
             neg_w = (-w).contiguous()
             _lib.call("mf_kf_loglik_grad", dtype, bsz, n, d, 1, c(mu2), c(c02), c(a2), c(b2), c(c2), None, None, None, 0,
@@ -423,9 +426,11 @@ class _Marginals(torch.autograd.Function):
             g_b = torch.empty((bsz, nt, d), dtype=a_s.dtype, device=a_s.device)
             c = lambda t: None if t is None else _lib.ptr(t.contiguous())  # noqa: E731
             if bsz > 0:
+                ws_bytes = int(_lib.load().mf_ssm_adjoint_workspace_bytes(bsz, nt + 1, d, a_s.element_size()))
+                ws = _lib.workspace(ws_bytes, a_s.device)
                 _lib.call("mf_ssm_marginals_grad", a_s.dtype, bsz, nt + 1, d, c(cp0), c(a_s), c(cq), c(means), c(covs),
                           c(g_means), c(g_covs), _lib.ptr(g_mu0), _lib.ptr(g_cp0), _lib.ptr(g_a), _lib.ptr(g_b), _lib.ptr(g_cq),
-                          _lib.stream_ptr(a_s.device))
+                          _lib.ptr(ws), ws_bytes, _lib.stream_ptr(a_s.device))
         return g_mu0, g_cp0, g_a, g_b, g_cq
 
 
