@@ -521,7 +521,19 @@ __global__ void __launch_bounds__(64) par_solve_emit_kernel(long Bl, long Br, lo
 
 
 // ---- StateSpaceModel.marginal_means in parallel in time: x_p = A_{p-1} x_{p-1} + o_p is already an affine recursion ------
-template <typename T, int D>
+// REV: the transposed recursion run backwards, lam_k = o_k + A_k^T lam_{k+1} (the adjoint of the means, mf_kl_grad.hpp):
+// position p is block n-1-p and its matrix is A_{n-1-p}^T.
+template <typename T, int D, bool REV>
+MF_DEV void means_load_a(const T* __restrict__ A, long s, long n, long p, T (&Am)[D][D]) {
+    if (!REV) {
+        load_mat<T, D, D>(A + (s * (n - 1) + (p > 0 ? p - 1 : 0)) * D * D, Am);      // position 0: clamped, unused
+    } else {
+        T At[D][D];
+        load_mat<T, D, D>(A + (s * (n - 1) + (p > 0 ? n - 1 - p : n - 2)) * D * D, At);
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Am[i][j] = At[j][i];
+    }
+}
+template <typename T, int D, bool REV = false>
 __global__ void __launch_bounds__(64) par_means_up0_kernel(long Bl, long Br, long n, long len, long P,
                                                            const T* __restrict__ A, const T* __restrict__ offs,
                                                            T* __restrict__ oM, T* __restrict__ oc) {
@@ -535,10 +547,10 @@ __global__ void __launch_bounds__(64) par_means_up0_kernel(long Bl, long Br, lon
     MF_UNROLL for (int i = 0; i < D; ++i) { q[i] = T(0); MF_UNROLL for (int j = 0; j < D; ++j) Pm[i][j] = T(0); }
     for (long p = p0; p < p1; ++p) {
         T o[D];
-        load_vec<T, D>(offs + (r * n + p) * D, o);
+        load_vec<T, D>(offs + (r * n + (REV ? n - 1 - p : p)) * D, o);
         if (p > 0) {
             T Am[D][D], nq[D];
-            load_mat<T, D, D>(A + (s * (n - 1) + p - 1) * D * D, Am);
+            means_load_a<T, D, REV>(A, s, n, p, Am);
             gemv_n<T, D, D>(Am, q, nq);
             MF_UNROLL for (int i = 0; i < D; ++i) q[i] = nq[i] + o[i];
             if (p == p0) {
@@ -561,7 +573,7 @@ __global__ void __launch_bounds__(64) par_means_up0_kernel(long Bl, long Br, lon
     store_vec<T, D>(oc + id * D, q);
 }
 
-template <typename T, int D>
+template <typename T, int D, bool REV = false>
 __global__ void __launch_bounds__(64) par_means_emit_kernel(long Bl, long Br, long n, long len, long P,
                                                             const T* __restrict__ A, const T* __restrict__ offs,
                                                             const T* __restrict__ up, T* __restrict__ out) {
@@ -579,8 +591,8 @@ __global__ void __launch_bounds__(64) par_means_emit_kernel(long Bl, long Br, lo
     struct St { T A[D][D]; T o[D]; };
     auto load = [&](long p, St& d) {
         const long pc = p < p1 ? p : p1 - 1;
-        load_vec<T, D>(offs + (r * n + pc) * D, d.o);
-        if (n > 1) load_mat<T, D, D>(A + (s * (n - 1) + (pc > 0 ? pc - 1 : 0)) * D * D, d.A);      // position 0: clamped, unused
+        load_vec<T, D>(offs + (r * n + (REV ? n - 1 - pc : pc)) * D, d.o);
+        if (n > 1) means_load_a<T, D, REV>(A, s, n, pc, d.A);
     };
     St cur[G], nxt[G];
     if (p0 < p1) { MF_UNROLL for (int q = 0; q < G; ++q) load(p0 + q, cur[q]); }
@@ -597,7 +609,7 @@ __global__ void __launch_bounds__(64) par_means_emit_kernel(long Bl, long Br, lo
                 } else {
                     MF_UNROLL for (int i = 0; i < D; ++i) x[i] = cur[q].o[i];
                 }
-                store_vec<T, D>(out + (r * n + p + q) * D, x);
+                store_vec<T, D>(out + (r * n + (REV ? n - 1 - (p + q) : p + q)) * D, x);
             }
         }
         MF_UNROLL for (int q = 0; q < G; ++q) cur[q] = nxt[q];
@@ -696,6 +708,9 @@ MF_DEV void takahashi_from(const T (&L)[D][D], const T (&W)[D][D], bool has_g, T
 //          computes them as the block diagonal of the inverse precision; the forward recursion gives the same blocks without
 //          assembling or factorising the precision): position p = block p, N = C C^T with C = cholP0 (p = 0) or cholQ_{p-1},
 //          G = A_{p-1}^T;  a = cholQ, b = A, c0 = cholP0.
+//   SRC 2  adjoint of those marginal covariances, M_k = N_k + A_k^T M_{k+1} A_k (the reverse-mode sweep of `marginals` and of
+//          kl_divergence, mf_kl_grad.hpp): position p = block n-1-p, N read from a buffer of symmetric blocks, G = A_k;
+//          a = N [B,n,D,D], b = A.
 template <typename T> struct TakSrc {
     const T* a;
     const T* b;
@@ -707,6 +722,10 @@ MF_DEV void tak_load(const TakSrc<T>& src, long s, long n, long p, T (&L)[D][D],
         const long k = n - 1 - p;                        // the coupling of position 0 does not exist: clamped, not used
         load_lower<T, D>(src.a + (s * n + k) * D * D, L);
         load_mat<T, D, D>(src.b + (s * (n - 1) + (k < n - 1 ? k : n - 2)) * D * D, W);
+    } else if (SRC == 2) {
+        const long k = n - 1 - p;                        // block n-1 (position 0) has no transition: clamped, not used
+        load_lower<T, D>(src.a + (s * n + k) * D * D, L);
+        if (n > 1) load_mat<T, D, D>(src.b + (s * (n - 1) + (k < n - 1 ? k : n - 2)) * D * D, W);
     } else {
         const T* lp = p > 0 ? src.a + (s * (n - 1) + p - 1) * D * D : src.c0 + s * D * D;
         load_lower<T, D>(lp, L);
@@ -717,6 +736,11 @@ template <typename T, int D, int SRC>
 MF_DEV void tak_terms(const T (&L)[D][D], const T (&W)[D][D], bool has_g, T (&N)[D][D], T (&G)[D][D]) {
     if (SRC == 0) {
         takahashi_from<T, D>(L, W, has_g, N, G);
+    } else if (SRC == 2) {
+        MF_UNROLL for (int i = 0; i < D; ++i) {
+            MF_UNROLL for (int j = 0; j <= i; ++j) N[i][j] = L[i][j];
+            MF_UNROLL for (int j = 0; j < D; ++j) G[i][j] = W[i][j];
+        }
     } else {
         MF_UNROLL for (int i = 0; i < D; ++i)
             MF_UNROLL for (int j = 0; j <= i; ++j) {
@@ -915,7 +939,7 @@ __global__ void __launch_bounds__(64) par_tak_emit_kernel(long B, long n, long l
     MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Sig[i][j] = T(0);
     if (c > 0) load_lower<T, D>(up + (s * P + c - 1) * D * D, Sig);
     for (long p = p0; p < p1; ++p) {
-        const long k = SRC == 0 ? n - 1 - p : p;
+        const long k = SRC == 1 ? p : n - 1 - p;
         if (PF) load(p + 1 < p1 ? p + 1 : p, nxt);
         else load(p, cur);
         __builtin_amdgcn_sched_barrier(0);
@@ -925,7 +949,7 @@ __global__ void __launch_bounds__(64) par_tak_emit_kernel(long B, long n, long l
         if (p > 0) {
             if (osub) {
                 // SRC 0: block (k+1, k) of the inverse = -Sigma_{k+1} G_k;  SRC 1: Cov(x_p, x_{p-1}) = A Sigma_{p-1} = (Sigma_{p-1} G)^T
-                T* o = osub + (s * (n - 1) + (SRC == 0 ? k : p - 1)) * D * D;
+                T* o = osub + (s * (n - 1) + (SRC == 1 ? p - 1 : k)) * D * D;
                 MF_UNROLL for (int i = 0; i < D; ++i) {
                     T row[D];
                     MF_UNROLL for (int j = 0; j < D; ++j) row[j] = Sig[i][0] * G[0][j];
@@ -933,7 +957,7 @@ __global__ void __launch_bounds__(64) par_tak_emit_kernel(long B, long n, long l
                         const T sil = (i >= l) ? Sig[i][l] : Sig[l][i];
                         MF_UNROLL for (int j = 0; j < D; ++j) row[j] += sil * G[l][j];
                     }
-                    if (SRC == 0) { MF_UNROLL for (int j = 0; j < D; ++j) o[i * D + j] = -row[j]; }
+                    if (SRC != 1) { MF_UNROLL for (int j = 0; j < D; ++j) o[i * D + j] = -row[j]; }
                     else { MF_UNROLL for (int j = 0; j < D; ++j) o[j * D + i] = row[j]; }
                 }
             }

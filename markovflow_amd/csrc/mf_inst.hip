@@ -675,13 +675,13 @@ int ssm_precision(long B, long Tn, int m, const T* mu0, const T* cholP0, const T
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
-template <typename T>
+template <typename T, bool REV = false>
 int ssm_means(long Bl, long Br, long Tn, const T* A, const T* offs, T* out, void* ws, size_t ws_bytes, hipStream_t st) {
     const long n = Tn;
     const long len0 = par_len0(Br, n);
     if (len0 == 0 || ws == nullptr || ws_bytes < btd_solve_ws<T>(Bl, Br, n)) {
-        if (A && n >= 2)        // one lane per series: the level-0 emit kernel as ONE chunk (loads a group of steps ahead)
-            hipLaunchKernelGGL((par_means_emit_kernel<T, D>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Bl, Br, n, n, 1L, A,
+        if ((A && n >= 2) || REV)   // one lane per series: the level-0 emit kernel as ONE chunk (loads a group of steps ahead)
+            hipLaunchKernelGGL((par_means_emit_kernel<T, D, REV>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Bl, Br, n, n, 1L, A,
                                offs, static_cast<const T*>(nullptr), out);
         else
             hipLaunchKernelGGL((ssm_means_kernel<T, D>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Bl, Br, Tn, A, offs,
@@ -697,7 +697,7 @@ int ssm_means(long Bl, long Br, long Tn, const T* A, const T* offs, T* out, void
         arr[l].c = reinterpret_cast<T*>(p); p += align_up(size_t(Br) * pl.n[l] * D * sizeof(T));
         arr[l].Z = reinterpret_cast<T*>(p); p += align_up(size_t(Br) * pl.n[l] * D * sizeof(T));
     }
-    hipLaunchKernelGGL((par_means_up0_kernel<T, D>), dim3((unsigned)cdiv(Br * pl.n[1], 64)), dim3(64), 0, st, Bl, Br, n,
+    hipLaunchKernelGGL((par_means_up0_kernel<T, D, REV>), dim3((unsigned)cdiv(Br * pl.n[1], 64)), dim3(64), 0, st, Bl, Br, n,
                        len0, pl.n[1], A, offs, arr[1].M, arr[1].c);
     for (int l = 1; l < pl.levels; ++l) {
         const long P = pl.n[l + 1];
@@ -717,7 +717,7 @@ int ssm_means(long Bl, long Br, long Tn, const T* A, const T* offs, T* out, void
                            pl.len[l], P, static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c),
                            static_cast<const T*>(arr[l + 1].Z), arr[l].Z);
     }
-    hipLaunchKernelGGL((par_means_emit_kernel<T, D>), dim3((unsigned)cdiv(Br * pl.n[1], 64)), dim3(64), 0, st, Bl, Br, n,
+    hipLaunchKernelGGL((par_means_emit_kernel<T, D, REV>), dim3((unsigned)cdiv(Br * pl.n[1], 64)), dim3(64), 0, st, Bl, Br, n,
                        len0, pl.n[1], A, offs, static_cast<const T*>(arr[1].Z), out);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
@@ -789,9 +789,14 @@ int kf_grad(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, c
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
-// workspace of the adjoint sweeps: N, n, M, lam for every (series, block)
+// workspace of the adjoint sweeps: N, n, M, lam for every (series, block) + the scratch of the two scans in time
+template <typename T> size_t adjoint_scan_ws(long B, long Tn) {
+    const size_t a = btd_diag_of_inverse_ws<T>(B, Tn), b = btd_solve_ws<T>(B, B, Tn);
+    return a > b ? a : b;
+}
 template <typename T> size_t adjoint_ws(long B, long Tn) {
-    return 2 * align_up(size_t(B) * Tn * D * D * sizeof(T)) + 2 * align_up(size_t(B) * Tn * D * sizeof(T));
+    return 2 * align_up(size_t(B) * Tn * D * D * sizeof(T)) + 2 * align_up(size_t(B) * Tn * D * sizeof(T)) +
+           adjoint_scan_ws<T>(B, Tn);
 }
 template <typename T> AdjointWs<T, D> carve_adjoint(void* ws, long B, long Tn) {
     char* p = static_cast<char*>(ws);
@@ -802,6 +807,21 @@ template <typename T> AdjointWs<T, D> carve_adjoint(void* ws, long B, long Tn) {
     w.lam = reinterpret_cast<T*>(p);
     return w;
 }
+// M_k = N_k + A_k^T M_{k+1} A_k and lam_k = n_k + A_k^T lam_{k+1} from the workspace inputs: few series -> the congruence and
+// affine scans in time (mf_btd_par.hpp, SRC 2 / REV), many series -> one lane per series
+template <typename T>
+int adjoint_scan(long B, long Tn, const T* A, const AdjointWs<T, D>& w, void* ws, hipStream_t st) {
+    if (par_len0(B, Tn) == 0 || Tn < 2) {
+        hipLaunchKernelGGL((ssm_adjoint_scan_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, Tn, A,
+                           static_cast<const T*>(nullptr), static_cast<const T*>(nullptr), 1, w);
+        return hipGetLastError() == hipSuccess ? 0 : -1000;
+    }
+    char* scratch = static_cast<char*>(ws) + (adjoint_ws<T>(B, Tn) - adjoint_scan_ws<T>(B, Tn));
+    const size_t bytes = adjoint_scan_ws<T>(B, Tn);
+    int rc = tak_scan<T, 2>(B, Tn, TakSrc<T>{w.N, A, nullptr}, w.M, static_cast<T*>(nullptr), scratch, bytes, st);
+    if (rc != 0) return rc;
+    return ssm_means<T, true>(B, B, Tn, A, static_cast<const T*>(w.n), w.lam, scratch, bytes, st);
+}
 
 template <typename T>
 int kl_grad(long B, long Tn, const T* mu0_1, const T* C0_1, const T* A_1, const T* b_1, const T* C_1, const T* mu0_2,
@@ -811,8 +831,7 @@ int kl_grad(long B, long Tn, const T* mu0_1, const T* C0_1, const T* A_1, const 
     const AdjointWs<T, D> w = carve_adjoint<T>(ws, B, Tn);
     const dim3 per_step((unsigned)cdiv(B * Tn, 64)), per_series((unsigned)cdiv(B, 64)), block(64);
     hipLaunchKernelGGL((ssm_kl_adjoint_inputs_kernel<T, D>), per_step, block, 0, st, B, Tn, A_1, b_1, A_2, b_2, C_2, pm, w, info);
-    hipLaunchKernelGGL((ssm_adjoint_scan_kernel<T, D>), per_series, block, 0, st, B, Tn, A_1, static_cast<const T*>(nullptr),
-                       static_cast<const T*>(nullptr), 1, w);
+    if (int rc = adjoint_scan<T>(B, Tn, A_1, w, ws, st)) return rc;
     AdjointLocalArgs<T, D> a{B, Tn, mu0_1, C0_1, A_1, b_1, C_1, mu0_2, C0_2, A_2, b_2, C_2, pm, pS, weights, gmu0, gC0, gA, gb, gC, info};
     hipLaunchKernelGGL((ssm_adjoint_local_kernel<T, D, true>), per_step, block, 0, st, a, w);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
@@ -844,7 +863,12 @@ int marginals_grad(long B, long Tn, const T* C0, const T* A, const T* C, const T
     if (ws == nullptr || ws_bytes < adjoint_ws<T>(B, Tn)) return -16;
     const AdjointWs<T, D> w = carve_adjoint<T>(ws, B, Tn);
     const dim3 per_step((unsigned)cdiv(B * Tn, 64)), per_series((unsigned)cdiv(B, 64)), block(64);
-    hipLaunchKernelGGL((ssm_adjoint_scan_kernel<T, D>), per_series, block, 0, st, B, Tn, A, gm, gS, 0, w);
+    if (par_len0(B, Tn) == 0 || Tn < 2) {
+        hipLaunchKernelGGL((ssm_adjoint_scan_kernel<T, D>), per_series, block, 0, st, B, Tn, A, gm, gS, 0, w);
+    } else {
+        hipLaunchKernelGGL((ssm_adjoint_sym_inputs_kernel<T, D>), per_step, block, 0, st, B * Tn, gm, gS, w);
+        if (int rc = adjoint_scan<T>(B, Tn, A, w, ws, st)) return rc;
+    }
     AdjointLocalArgs<T, D> a{B, Tn, nullptr, C0, A, nullptr, C, nullptr, nullptr, nullptr, nullptr, nullptr, pm, pS, nullptr,
                              gmu0, gC0, gA, gb, gC, nullptr};
     hipLaunchKernelGGL((ssm_adjoint_local_kernel<T, D, false>), per_step, block, 0, st, a, w);
@@ -855,7 +879,7 @@ template <typename T> const OpsTable<T>* table() {
     static const OpsTable<T> t = {
         &kf_loglik_ws<T>, &kf_loglik<T>, &btd_logdet_quad_ws<T>, &btd_logdet_quad<T>, &btd_cholesky_ws<T>, &btd_cholesky<T>,
         &btd_solve_ws<T>, &btd_solve<T>,    &btd_matvec<T>, &btd_logdet<T>,        &btd_diag_of_inverse_ws<T>, &btd_diag_of_inverse<T>, &ssm_marginal_covs<T>, &btd_udl_ws<T>, &btd_udl<T>,
-        &ssm_precision<T>, &ssm_means<T>, &block_matmul<T>, &gpr_loglik<T>, &sde_predict<T>, &kf_grad<T>, &kl_grad<T>, &posterior_chain<T>, &kl_value<T>, &marginals_grad<T>, &adjoint_ws<T>,
+        &ssm_precision<T>, &ssm_means<T, false>, &block_matmul<T>, &gpr_loglik<T>, &sde_predict<T>, &kf_grad<T>, &kl_grad<T>, &posterior_chain<T>, &kl_value<T>, &marginals_grad<T>, &adjoint_ws<T>,
     };
     return &t;
 }

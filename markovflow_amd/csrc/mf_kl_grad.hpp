@@ -255,6 +255,21 @@ __global__ void __launch_bounds__(64) ssm_adjoint_scan_kernel(long B, long Tn, c
     }
 }
 
+// the inputs of the `marginals` adjoint in the workspace layout of the scans: N = gS + gS^T (lower), n = gm
+template <typename T, int D>
+__global__ void __launch_bounds__(64) ssm_adjoint_sym_inputs_kernel(long blocks, const T* __restrict__ gm,
+                                                                    const T* __restrict__ gS, AdjointWs<T, D> ws) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= blocks) return;
+    T N[D][D], v[D];
+    MF_UNROLL for (int i = 0; i < D; ++i) {
+        v[i] = gm ? gm[id * D + i] : T(0);
+        MF_UNROLL for (int j = 0; j <= i; ++j) N[i][j] = gS ? gS[(id * D + i) * D + j] + gS[(id * D + j) * D + i] : T(0);
+    }
+    store_sym<T, D>(ws.N + id * D * D, N);
+    store_vec<T, D>(ws.n + id * D, v);
+}
+
 // ---- 3. parameter gradients, local in time --------------------------------------------------------------------------------------
 // KL = true:  db = w (Q2^-1 eps + lam_{k+1}),  dA = w ((Q2^-1 eps + lam_{k+1}) m_k^T + (Q2^-1 dA + M_{k+1} A1) S_k),
 //             dC = w (tril((Q2^-1 + M_{k+1}) C1) - diag(1 / C1));   step 0 also: dmu0 = w (P0_2^-1 d0 + lam_0),
