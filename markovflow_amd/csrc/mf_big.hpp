@@ -16,6 +16,7 @@
 
 #include "mf_env.hpp"
 #include <cstdlib>
+#include <type_traits>
 
 namespace mf {
 namespace bigcommon {
@@ -56,6 +57,30 @@ __device__ __forceinline__ double bcast16(double v, int src) {
     const unsigned lo = (unsigned)bcast16_bits((int)(unsigned)b, src);
     const unsigned hi = (unsigned)bcast16_bits((int)(unsigned)(b >> 32), src);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// The broadcast as the DPP operand of the consuming instruction itself (fp32): no SGPR (with v_readlane the sixteen steps of a
+// diagonal tile keep > 100 broadcast values in SGPRs and the compiler spills them to VGPR lanes: v_writelane / v_readlane per
+// value) and no extra VGPR.  Inline asm is opaque to the hazard recogniser, so the two wait states a DPP read needs after a VALU
+// write of the same VGPR are in the string: FRESH marks the first DPP use of a value the VALU has just produced - it is passed
+// as in/out so that every later use is ordered behind this one.
+template <int K> __device__ __forceinline__ float mov_bcast16(float s) {
+    float d;
+    asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(s), "n"(K));
+    return d;
+}
+// d -= bcast16(s, K) * t
+template <int K> __device__ __forceinline__ void fnma_bcast16(float& d, float s, float t) {
+    asm("v_fmac_f32_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(s), "v"(t), "n"(K));
+}
+template <int K> __device__ __forceinline__ void fnma_bcast16_fresh(float& d, float& s, float t) {
+    asm("s_nop 1\n\tv_fmac_f32_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d), "+v"(s) : "v"(t), "n"(K));
+}
+// compile-time loop: f(std::integral_constant<int, I>) for I = BEGIN ... END-1 (the DPP lane select is an immediate)
+template <int BEGIN, int END, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (BEGIN < END) {
+        f(std::integral_constant<int, BEGIN>{});
+        static_for<BEGIN + 1, END>(f);
+    }
 }
 // natural logarithm for the running log-determinant: the hardware log2 (one instruction, ~1 ulp of fp32) in fp32
 __device__ __forceinline__ float mf_log(float x) { return __log2f(x) * 0.6931471805599453094f; }

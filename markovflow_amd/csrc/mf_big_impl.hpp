@@ -145,6 +145,44 @@ __device__ __forceinline__ real diag_tile(real* __restrict__ S, real* __restrict
     real x[16];
 #pragma unroll
     for (int row = 0; row < 16; ++row) x[row] = (row == i) ? 1.f : 0.f;
+    if constexpr (sizeof(real) == 4) {
+        // fp32: every broadcast is the DPP operand (row_newbcast) of the instruction that consumes it (mf_big.hpp) - with
+        // v_readlane the broadcast values of a tile lived in > 100 SGPRs, spilt to VGPR lanes and back
+        if (CHOL) {
+            static_for<0, 16>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const real p = mov_bcast16<j>(a[j]);
+                bad |= !(p > 0.f);
+                const real ri = t_rsqrt<real>(p);
+                logsum += 0.5f * mf_log(p);
+                real lij = a[j] * ri;
+                x[j] *= ri;
+                if constexpr (j + 1 < 16) {
+                    const real l0 = lij;
+                    fnma_bcast16_fresh<j + 1>(a[j + 1], lij, l0);        // the next pivot first: it is the dependent chain
+                    static_for<j + 2, 16>([&](auto kc) { constexpr int k = decltype(kc)::value; fnma_bcast16<k>(a[k], lij, lij); });
+                    static_for<j + 1, 16>([&](auto kc) { constexpr int k = decltype(kc)::value; fnma_bcast16<k>(x[k], lij, x[j]); });
+                }
+                a[j] = lij;
+            });
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (lane < 16) S[i * LD + k] = (k <= i) ? a[k] : 0.f;
+        } else {
+            static_for<0, 16>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const real p = mov_bcast16<j>(a[j]);
+                bad |= !(p != 0.f);
+                rd[j] = t_rcp<real>(p);
+                logsum += mf_log((p < 0 ? -p : p));
+            });
+            static_for<0, 16>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                x[k] *= rd[k];
+                static_for<k + 1, 16>([&](auto rc) { constexpr int row = decltype(rc)::value; fnma_bcast16<row>(x[row], a[k], x[k]); });
+            });
+        }
+    } else
     if (CHOL) {
         // The factorisation and the substitution are ONE loop: step j of the inverse needs column j of L only, which is final
         // as soon as step j of the Cholesky has scaled it.  The two recurrences are independent chains of ~190 cycles per step
@@ -191,95 +229,136 @@ __device__ __forceinline__ real diag_tile(real* __restrict__ S, real* __restrict
     return logsum;
 }
 
+// ---- 16 x 16 tile tasks of the blocked factorisation / inversion: each is worked by ONE wavefront ------------------------------
+// S_ti,jb <- S_ti,jb Inv_jb,jb^T  (panel: L_ij, one 16-deep product, in place)
+template <int LD> __device__ __forceinline__ void fi_panel_tile(real* __restrict__ S, const real* __restrict__ Inv, int ti, int jb) {
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    real4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int k = 16 * jb + 4 * kk + q;
+        acc = mfma(S[(16 * ti + r) * LD + k], Inv[(16 * jb + r) * LD + k], acc);          // Inv_jj[r][k] = (Inv_jj^T)[k][r]
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) S[(16 * ti + acc_row(q, e)) * LD + 16 * jb + r] = acc[e];
+}
+// S_ti,tk -= L_ti,jb L_tk,jb^T  (trailing update)
+template <int LD> __device__ __forceinline__ void fi_trailing_tile(real* __restrict__ S, int ti, int tk, int jb) {
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    real4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int k = 16 * jb + 4 * kk + q;
+        acc = mfma(S[(16 * ti + r) * LD + k], S[(16 * tk + r) * LD + k], acc);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) S[(16 * ti + acc_row(q, e)) * LD + 16 * tk + r] -= acc[e];
+}
+// Inv_ti,tj <- T_ti,tj = sum_{k=tj}^{ti-1} L_ti,k Inv_k,tj  (first half of an off-diagonal block of the inverse)
+template <int LD> __device__ __forceinline__ void fi_inv_t_tile(const real* __restrict__ S, real* __restrict__ Inv, int ti, int tj) {
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    real4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int kt = tj; kt < ti; ++kt) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int k = 16 * kt + 4 * kk + q;
+            acc = mfma(S[(16 * ti + r) * LD + k], Inv[k * LD + 16 * tj + r], acc);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Inv[(16 * ti + acc_row(q, e)) * LD + 16 * tj + r] = acc[e];
+}
+// Inv_ti,tj <- -Inv_ti,ti T_ti,tj  (second half, in place)
+template <int LD> __device__ __forceinline__ void fi_inv_finish_tile(real* __restrict__ Inv, int ti, int tj) {
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    real4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int k = 4 * kk + q;
+        acc = mfma(Inv[(16 * ti + r) * LD + 16 * ti + k], Inv[(16 * ti + k) * LD + 16 * tj + r], acc);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Inv[(16 * ti + acc_row(q, e)) * LD + 16 * tj + r] = -acc[e];
+}
+
 // (CHOL) S <- chol(S) lower with zeros above inside the diagonal tiles, Inv <- L^-1 (full lower, upper tiles zeroed);
 // (!CHOL) Inv <- S^-1 for lower-triangular S.  Returns log|det L| in wave 0 (valid on every lane of wave 0).
 // All threads must call; ends with a barrier.
+//
+// CHOL schedule (look-ahead): the four diagonal tiles are a dependent chain on wave 0 (~2 k cycles each); everything else
+// hides beside it.  Phases, one barrier each:
+//   P0      wave 0: diagonal tile 0                         | waves 1-3: zero the upper tiles of Inv
+//   A(jb)   panel tiles (ti, jb), ti > jb  +  second halves of the inverse's block row jb (-Inv_jj T_j,tj)
+//   B(jb)   wave 0: trailing update of tile (jb+1, jb+1), then diagonal tile jb+1
+//           waves 1-3: the other trailing tiles  +  first halves T_(jb+1),tj of the inverse's next block row
+// = 2 NT phases instead of the 3 NT + 2 (NT - 1) of a phase per kind of work (r02: [5] of profiles/r02_big_v5_phases.txt).
 template <int DP, bool CHOL>
 __device__ __forceinline__ real factor_invert(real* __restrict__ S, real* __restrict__ Inv, bool& bad,
                                                real* __restrict__ red) {
-    constexpr int LD = Geo<DP>::LD, NT = Geo<DP>::NT;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    constexpr int LD = Geo<DP>::LD, NT = Geo<DP>::NT, NW = NTHR / 64;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     real logdet = 0.f;
+    if (CHOL) {
+        if (wave == 0) {
+            logdet += diag_tile<LD, true>(S, Inv, bad);
+        } else {
+            for (int e = threadIdx.x - 64; e < DP * DP; e += NTHR - 64) {
+                const int row = e / DP, col = e % DP;
+                if ((col >> 4) > (row >> 4)) Inv[row * LD + col] = 0.f;
+            }
+        }
+        __syncthreads();
+        for (int jb = 0; jb < NT; ++jb) {
+            // A(jb): at most NT - 1 <= 3 tasks; wave 0 takes the panel tile it needs next
+            {
+                const int panels = NT - 1 - jb;
+                for (int t = wave; t < NT - 1; t += NW) {
+                    if (t < panels) fi_panel_tile<LD>(S, Inv, jb + 1 + t, jb);
+                    else fi_inv_finish_tile<LD>(Inv, jb, t - panels);
+                }
+            }
+            __syncthreads();
+            if (jb + 1 == NT) break;
+            // B(jb)
+            if (wave == 0) {
+                fi_trailing_tile<LD>(S, jb + 1, jb + 1, jb);
+                logdet += diag_tile<LD, true>(S + 16 * (jb + 1) * LD + 16 * (jb + 1), Inv + 16 * (jb + 1) * LD + 16 * (jb + 1), bad);
+            } else {
+                int cnt = 0;
+                for (int ti = jb + 1; ti < NT; ++ti)
+                    for (int tk = jb + 1; tk <= ti; ++tk) {
+                        if (ti == jb + 1) continue;                      // (jb+1, jb+1) is wave 0's
+                        if ((cnt++ % (NW - 1)) + 1 == wave) fi_trailing_tile<LD>(S, ti, tk, jb);
+                    }
+                for (int tj = 0; tj <= jb; ++tj)
+                    if ((cnt++ % (NW - 1)) + 1 == wave) fi_inv_t_tile<LD>(S, Inv, jb + 1, tj);
+            }
+            __syncthreads();
+        }
+        return logdet;
+    }
     // zero the strictly-upper tiles of Inv
     for (int e = threadIdx.x; e < DP * DP; e += NTHR) {
         const int row = e / DP, col = e % DP;
         if ((col >> 4) > (row >> 4)) Inv[row * LD + col] = 0.f;
     }
-    if (!CHOL) {
+    {
         // the diagonal tiles of a triangular matrix invert independently: one per wave; the per-wave
         // log-determinants and pivot flags meet through eight words of `red`
         real mine = 0.f;
         bool mybad = false;
-        for (int jb = wave; jb < NT; jb += NTHR / 64)
+        for (int jb = wave; jb < NT; jb += NW)
             mine += diag_tile<LD, false>(S + 16 * jb * LD + 16 * jb, Inv + 16 * jb * LD + 16 * jb, mybad);
         if (lane == 0) { red[wave] = mine; red[4 + wave] = mybad ? 1.f : 0.f; }
         __syncthreads();
         logdet = red[0] + red[1] + red[2] + red[3];
         bad |= (red[4] + red[5] + red[6] + red[7]) != 0.f;
     }
-    for (int jb = 0; CHOL && jb < NT; ++jb) {
-        if (wave == 0) logdet += diag_tile<LD, CHOL>(S + 16 * jb * LD + 16 * jb, Inv + 16 * jb * LD + 16 * jb, bad);
-        __syncthreads();
-        if (CHOL) {
-            // panel: L_ij = S_ij Inv_jj^T   (one 16-deep product per tile, in place)
-            for (int ti = jb + 1 + wave; ti < NT; ti += NTHR / 64) {
-                real4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int k = 16 * jb + 4 * kk + q;
-                    const real a = S[(16 * ti + r) * LD + k];
-                    const real b = Inv[(16 * jb + r) * LD + k];          // Inv_jj[r][k] = (Inv_jj^T)[k][r]
-                    acc = mfma(a, b, acc);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) S[(16 * ti + acc_row(q, e)) * LD + 16 * jb + r] = acc[e];
-            }
-            __syncthreads();
-            // trailing update: S_ik -= L_ij L_kj^T for i >= k > jb
-            int cnt = 0;
-            for (int ti = jb + 1; ti < NT; ++ti)
-                for (int tk = jb + 1; tk <= ti; ++tk, ++cnt) {
-                    if ((cnt & 3) != wave) continue;
-                    real4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        const int k = 16 * jb + 4 * kk + q;
-                        const real a = S[(16 * ti + r) * LD + k];
-                        const real b = S[(16 * tk + r) * LD + k];
-                        acc = mfma(a, b, acc);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) S[(16 * ti + acc_row(q, e)) * LD + 16 * tk + r] -= acc[e];
-                }
-            __syncthreads();
-        }
-    }
     // off-diagonal blocks of the inverse, block row by block row:  Inv_ij = -Inv_ii sum_{k=j}^{i-1} L_ik Inv_kj
     for (int ti = 1; ti < NT; ++ti) {
-        for (int tj = wave; tj < ti; tj += NTHR / 64) {
-            real4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int kt = tj; kt < ti; ++kt) {
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int k = 16 * kt + 4 * kk + q;
-                    acc = mfma(S[(16 * ti + r) * LD + k], Inv[k * LD + 16 * tj + r], acc);
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) Inv[(16 * ti + acc_row(q, e)) * LD + 16 * tj + r] = acc[e];   // T_ij, temporarily
-        }
+        for (int tj = wave; tj < ti; tj += NW) fi_inv_t_tile<LD>(S, Inv, ti, tj);
         __syncthreads();
-        for (int tj = wave; tj < ti; tj += NTHR / 64) {
-            real4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int k = 4 * kk + q;
-                acc = mfma(Inv[(16 * ti + r) * LD + 16 * ti + k],
-                                                           Inv[(16 * ti + k) * LD + 16 * tj + r], acc);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) Inv[(16 * ti + acc_row(q, e)) * LD + 16 * tj + r] = -acc[e];
-        }
+        for (int tj = wave; tj < ti; tj += NW) fi_inv_finish_tile<LD>(Inv, ti, tj);
         __syncthreads();
     }
     return logdet;
