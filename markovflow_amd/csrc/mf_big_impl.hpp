@@ -255,10 +255,13 @@ template <int LD> __device__ __forceinline__ void fi_trailing_tile(real* __restr
     for (int e = 0; e < 4; ++e) S[(16 * ti + acc_row(q, e)) * LD + 16 * tk + r] -= acc[e];
 }
 // Inv_ti,tj <- T_ti,tj = sum_{k=tj}^{ti-1} L_ti,k Inv_k,tj  (first half of an off-diagonal block of the inverse)
-template <int LD> __device__ __forceinline__ void fi_inv_t_tile(const real* __restrict__ S, real* __restrict__ Inv, int ti, int tj) {
+// (kend: the sum stops before block kend - the recursive order of the triangular inverse)
+template <int LD> __device__ __forceinline__ void fi_inv_t_tile(const real* __restrict__ S, real* __restrict__ Inv, int ti, int tj,
+                                                                int kend = 1 << 30) {
     const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     real4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int kt = tj; kt < ti; ++kt) {
+    if (kend > ti) kend = ti;
+    for (int kt = tj; kt < kend; ++kt) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int k = 16 * kt + 4 * kk + q;
@@ -279,6 +282,28 @@ template <int LD> __device__ __forceinline__ void fi_inv_finish_tile(real* __res
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) Inv[(16 * ti + acc_row(q, e)) * LD + 16 * tj + r] = -acc[e];
+}
+
+// Column tj of the lower-left 2 x 2 block of the inverse from its first halves T_2j, T_3j (in Inv_2j, Inv_3j):
+// Inv_3j = -(Inv_32 T_2j + Inv_33 T_3j), Inv_2j = -Inv_22 T_2j; both products are formed before either tile is overwritten.
+template <int LD, int NT> __device__ __forceinline__ void fi_inv_finish_rows23(real* __restrict__ Inv, int tj) {
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    real4 a2 = {0.f, 0.f, 0.f, 0.f}, a3 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int k = 4 * kk + q;
+        const real t2 = Inv[(32 + k) * LD + 16 * tj + r];
+        a2 = mfma(Inv[(32 + r) * LD + 32 + k], t2, a2);
+        if (NT >= 4) {
+            a3 = mfma(Inv[(48 + r) * LD + 32 + k], t2, a3);
+            a3 = mfma(Inv[(48 + r) * LD + 48 + k], Inv[(48 + k) * LD + 16 * tj + r], a3);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        Inv[(32 + acc_row(q, e)) * LD + 16 * tj + r] = -a2[e];
+        if (NT >= 4) Inv[(48 + acc_row(q, e)) * LD + 16 * tj + r] = -a3[e];
+    }
 }
 
 // (CHOL) S <- chol(S) lower with zeros above inside the diagonal tiles, Inv <- L^-1 (full lower, upper tiles zeroed);
@@ -354,11 +379,23 @@ __device__ __forceinline__ real factor_invert(real* __restrict__ S, real* __rest
         logdet = red[0] + red[1] + red[2] + red[3];
         bad |= (red[4] + red[5] + red[6] + red[7]) != 0.f;
     }
-    // off-diagonal blocks of the inverse, block row by block row:  Inv_ij = -Inv_ii sum_{k=j}^{i-1} L_ik Inv_kj
-    for (int ti = 1; ti < NT; ++ti) {
-        for (int tj = wave; tj < ti; tj += NW) fi_inv_t_tile<LD>(S, Inv, ti, tj);
+    // off-diagonal blocks of the inverse, Inv_ij = -Inv_ii sum_{k=j}^{i-1} L_ik Inv_kj, in the recursive 2 x 2 order: first the
+    // blocks (1,0) and (3,2) inside the two halves, then the block rows 2, 3 against the finished upper half - four phases for
+    // NT = 4 instead of the six of a row-by-row sweep, and all four waves busy in the last two
+    if (NT >= 2) {
+        if (wave == 0) fi_inv_t_tile<LD>(S, Inv, 1, 0);
+        if (wave == 1 && NT >= 4) fi_inv_t_tile<LD>(S, Inv, 3, 2);
         __syncthreads();
-        for (int tj = wave; tj < ti; tj += NW) fi_inv_finish_tile<LD>(Inv, ti, tj);
+        if (wave == 0) fi_inv_finish_tile<LD>(Inv, 1, 0);
+        if (wave == 1 && NT >= 4) fi_inv_finish_tile<LD>(Inv, 3, 2);
+        __syncthreads();
+    }
+    if (NT >= 3) {
+        // T_ij = sum_{k=j}^{1} L_ik Inv_kj for i in {2, 3}, j in {0, 1}: the sum stops at the upper half (k <= 1)
+        for (int t = wave; t < 2 * (NT - 2); t += NW) fi_inv_t_tile<LD>(S, Inv, 2 + (t >> 1), t & 1, 2);
+        __syncthreads();
+        // [Inv_2j; Inv_3j] = -[Inv_22 0; Inv_32 Inv_33] [T_2j; T_3j]: one wave per column j, row 3 first (it reads T_2j)
+        if (wave < 2) fi_inv_finish_rows23<LD, NT>(Inv, wave);
         __syncthreads();
     }
     return logdet;
@@ -529,17 +566,26 @@ __device__ __forceinline__ real obs_terms(const Smem<DP>& sm, real* __restrict__
             for (int e = 0; e < 4; ++e) Gs[(16 * ti + acc_row(q, e)) * LD + 16 * tj + r] = acc[e];
         }
     }
-    if (threadIdx.x < m) {
+    {   // R^-1 y: wave w takes outputs 8 w ... 8 w + 7 with eight lanes per output (m <= 32; R^-1 symmetric: read down a column)
+        const int lane = threadIdx.x & 63, o = 8 * (threadIdx.x >> 6) + (lane & 7), part = lane >> 3;
         real a = 0.f;
-        for (int p = 0; p < m; ++p) a += Rs[p * m + threadIdx.x] * ys[p];          // symmetric: conflict-free column read
-        rys[threadIdx.x] = a;
+        if (o < m)
+            for (int p = part; p < m; p += 8) a += Rs[p * m + o] * ys[p];
+        a += __shfl_xor(a, 8);
+        a += __shfl_xor(a, 16);
+        a += __shfl_xor(a, 32);
+        if (part == 0 && o < m) rys[o] = a;
     }
     __syncthreads();
     gemm<DP, 1, 0, 1, K_FULL, O_FULL>(Hs, Gs, Phi, 1.f, mp / 16);
-    if (threadIdx.x < DP) {
+    {   // tvec += H^T (R^-1 y): wave w takes outputs 16 w ... 16 w + 15 with four lanes per output
+        const int lane = threadIdx.x & 63, i = 16 * (threadIdx.x >> 6) + (lane & 15), part = lane >> 4;
         real a = 0.f;
-        for (int o = 0; o < m; ++o) a += Hs[o * LD + threadIdx.x] * rys[o];
-        tvec[threadIdx.x] += a;
+        if (i < DP)
+            for (int o = part; o < m; o += 4) a += Hs[o * LD + i] * rys[o];
+        a += __shfl_xor(a, 16);
+        a += __shfl_xor(a, 32);
+        if (part == 0 && i < DP) tvec[i] += a;
     }
     // y^T R^-1 y: one product per lane and a wave reduction (every wave holds the same value; m <= 32 < 64 lanes)
     const int lane = threadIdx.x & 63;
