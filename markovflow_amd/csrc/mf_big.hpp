@@ -61,8 +61,8 @@ __device__ __forceinline__ double bcast16(double v, int src) {
 // The broadcast as the DPP operand of the consuming instruction itself (fp32): no SGPR (with v_readlane the sixteen steps of a
 // diagonal tile keep > 100 broadcast values in SGPRs and the compiler spills them to VGPR lanes: v_writelane / v_readlane per
 // value) and no extra VGPR.  Inline asm is opaque to the hazard recogniser, so the two wait states a DPP read needs after a VALU
-// write of the same VGPR are in the string: FRESH marks the first DPP use of a value the VALU has just produced - it is passed
-// as in/out so that every later use is ordered behind this one.
+// write of the same VGPR (the producing instruction, or a copy / AGPR reload the register allocator put in front) are part of
+// every asm statement: one s_nop 1 in front of the DPP instructions of a statement, none of which writes a DPP source.
 template <int K> __device__ __forceinline__ float mov_bcast16(float s) {
     float d;
     asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(s), "n"(K));
@@ -70,10 +70,58 @@ template <int K> __device__ __forceinline__ float mov_bcast16(float s) {
 }
 // d -= bcast16(s, K) * t
 template <int K> __device__ __forceinline__ void fnma_bcast16(float& d, float s, float t) {
-    asm("v_fmac_f32_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(s), "v"(t), "n"(K));
+    asm("s_nop 1\n\tv_fmac_f32_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(s), "v"(t), "n"(K));
 }
-template <int K> __device__ __forceinline__ void fnma_bcast16_fresh(float& d, float& s, float t) {
-    asm("s_nop 1\n\tv_fmac_f32_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d), "+v"(s) : "v"(t), "n"(K));
+// v[k] -= bcast16(s, k) * t for k = K0 ... 15 as ONE statement (one s_nop for up to fifteen DPP instructions).  Generated:
+//   for K0 in 1..15: outputs %0.. = v[K0..15], then s, t
+template <int K0> __device__ __forceinline__ void fnma_bcast16_from(float (&v)[16], float s, float t) {
+#define MF_DPP_FMA(i, k) "\n\tv_fmac_f32_dpp %" #i ", -%[s], %[t] row_newbcast:" #k " row_mask:0xf bank_mask:0xf"
+    if constexpr (K0 == 1)
+        asm("s_nop 1" MF_DPP_FMA(0, 1) MF_DPP_FMA(1, 2) MF_DPP_FMA(2, 3) MF_DPP_FMA(3, 4) MF_DPP_FMA(4, 5) MF_DPP_FMA(5, 6) MF_DPP_FMA(6, 7) MF_DPP_FMA(7, 8) MF_DPP_FMA(8, 9) MF_DPP_FMA(9, 10) MF_DPP_FMA(10, 11) MF_DPP_FMA(11, 12) MF_DPP_FMA(12, 13) MF_DPP_FMA(13, 14) MF_DPP_FMA(14, 15)
+            : "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]) : [s] "v"(s), [t] "v"(t));
+    else if constexpr (K0 == 2)
+        asm("s_nop 1" MF_DPP_FMA(0, 2) MF_DPP_FMA(1, 3) MF_DPP_FMA(2, 4) MF_DPP_FMA(3, 5) MF_DPP_FMA(4, 6) MF_DPP_FMA(5, 7) MF_DPP_FMA(6, 8) MF_DPP_FMA(7, 9) MF_DPP_FMA(8, 10) MF_DPP_FMA(9, 11) MF_DPP_FMA(10, 12) MF_DPP_FMA(11, 13) MF_DPP_FMA(12, 14) MF_DPP_FMA(13, 15)
+            : "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]) : [s] "v"(s), [t] "v"(t));
+    else if constexpr (K0 == 3)
+        asm("s_nop 1" MF_DPP_FMA(0, 3) MF_DPP_FMA(1, 4) MF_DPP_FMA(2, 5) MF_DPP_FMA(3, 6) MF_DPP_FMA(4, 7) MF_DPP_FMA(5, 8) MF_DPP_FMA(6, 9) MF_DPP_FMA(7, 10) MF_DPP_FMA(8, 11) MF_DPP_FMA(9, 12) MF_DPP_FMA(10, 13) MF_DPP_FMA(11, 14) MF_DPP_FMA(12, 15)
+            : "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]) : [s] "v"(s), [t] "v"(t));
+    else if constexpr (K0 == 4)
+        asm("s_nop 1" MF_DPP_FMA(0, 4) MF_DPP_FMA(1, 5) MF_DPP_FMA(2, 6) MF_DPP_FMA(3, 7) MF_DPP_FMA(4, 8) MF_DPP_FMA(5, 9) MF_DPP_FMA(6, 10) MF_DPP_FMA(7, 11) MF_DPP_FMA(8, 12) MF_DPP_FMA(9, 13) MF_DPP_FMA(10, 14) MF_DPP_FMA(11, 15)
+            : "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]) : [s] "v"(s), [t] "v"(t));
+    else if constexpr (K0 == 5)
+        asm("s_nop 1" MF_DPP_FMA(0, 5) MF_DPP_FMA(1, 6) MF_DPP_FMA(2, 7) MF_DPP_FMA(3, 8) MF_DPP_FMA(4, 9) MF_DPP_FMA(5, 10) MF_DPP_FMA(6, 11) MF_DPP_FMA(7, 12) MF_DPP_FMA(8, 13) MF_DPP_FMA(9, 14) MF_DPP_FMA(10, 15)
+            : "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]) : [s] "v"(s), [t] "v"(t));
+    else if constexpr (K0 == 6)
+        asm("s_nop 1" MF_DPP_FMA(0, 6) MF_DPP_FMA(1, 7) MF_DPP_FMA(2, 8) MF_DPP_FMA(3, 9) MF_DPP_FMA(4, 10) MF_DPP_FMA(5, 11) MF_DPP_FMA(6, 12) MF_DPP_FMA(7, 13) MF_DPP_FMA(8, 14) MF_DPP_FMA(9, 15)
+            : "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]) : [s] "v"(s), [t] "v"(t));
+    else if constexpr (K0 == 7)
+        asm("s_nop 1" MF_DPP_FMA(0, 7) MF_DPP_FMA(1, 8) MF_DPP_FMA(2, 9) MF_DPP_FMA(3, 10) MF_DPP_FMA(4, 11) MF_DPP_FMA(5, 12) MF_DPP_FMA(6, 13) MF_DPP_FMA(7, 14) MF_DPP_FMA(8, 15)
+            : "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]) : [s] "v"(s), [t] "v"(t));
+    else if constexpr (K0 == 8)
+        asm("s_nop 1" MF_DPP_FMA(0, 8) MF_DPP_FMA(1, 9) MF_DPP_FMA(2, 10) MF_DPP_FMA(3, 11) MF_DPP_FMA(4, 12) MF_DPP_FMA(5, 13) MF_DPP_FMA(6, 14) MF_DPP_FMA(7, 15)
+            : "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]) : [s] "v"(s), [t] "v"(t));
+    else if constexpr (K0 == 9)
+        asm("s_nop 1" MF_DPP_FMA(0, 9) MF_DPP_FMA(1, 10) MF_DPP_FMA(2, 11) MF_DPP_FMA(3, 12) MF_DPP_FMA(4, 13) MF_DPP_FMA(5, 14) MF_DPP_FMA(6, 15)
+            : "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]) : [s] "v"(s), [t] "v"(t));
+    else if constexpr (K0 == 10)
+        asm("s_nop 1" MF_DPP_FMA(0, 10) MF_DPP_FMA(1, 11) MF_DPP_FMA(2, 12) MF_DPP_FMA(3, 13) MF_DPP_FMA(4, 14) MF_DPP_FMA(5, 15)
+            : "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]) : [s] "v"(s), [t] "v"(t));
+    else if constexpr (K0 == 11)
+        asm("s_nop 1" MF_DPP_FMA(0, 11) MF_DPP_FMA(1, 12) MF_DPP_FMA(2, 13) MF_DPP_FMA(3, 14) MF_DPP_FMA(4, 15)
+            : "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]) : [s] "v"(s), [t] "v"(t));
+    else if constexpr (K0 == 12)
+        asm("s_nop 1" MF_DPP_FMA(0, 12) MF_DPP_FMA(1, 13) MF_DPP_FMA(2, 14) MF_DPP_FMA(3, 15)
+            : "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]) : [s] "v"(s), [t] "v"(t));
+    else if constexpr (K0 == 13)
+        asm("s_nop 1" MF_DPP_FMA(0, 13) MF_DPP_FMA(1, 14) MF_DPP_FMA(2, 15)
+            : "+v"(v[13]), "+v"(v[14]), "+v"(v[15]) : [s] "v"(s), [t] "v"(t));
+    else if constexpr (K0 == 14)
+        asm("s_nop 1" MF_DPP_FMA(0, 14) MF_DPP_FMA(1, 15)
+            : "+v"(v[14]), "+v"(v[15]) : [s] "v"(s), [t] "v"(t));
+    else if constexpr (K0 == 15)
+        asm("s_nop 1" MF_DPP_FMA(0, 15)
+            : "+v"(v[15]) : [s] "v"(s), [t] "v"(t));
+#undef MF_DPP_FMA
 }
 // compile-time loop: f(std::integral_constant<int, I>) for I = BEGIN ... END-1 (the DPP lane select is an immediate)
 template <int BEGIN, int END, typename F> __device__ __forceinline__ void static_for(F&& f) {

@@ -155,13 +155,12 @@ __device__ __forceinline__ real diag_tile(real* __restrict__ S, real* __restrict
                 bad |= !(p > 0.f);
                 const real ri = t_rsqrt<real>(p);
                 logsum += 0.5f * mf_log(p);
-                real lij = a[j] * ri;
+                const real lij = a[j] * ri;
                 x[j] *= ri;
                 if constexpr (j + 1 < 16) {
-                    const real l0 = lij;
-                    fnma_bcast16_fresh<j + 1>(a[j + 1], lij, l0);        // the next pivot first: it is the dependent chain
-                    static_for<j + 2, 16>([&](auto kc) { constexpr int k = decltype(kc)::value; fnma_bcast16<k>(a[k], lij, lij); });
-                    static_for<j + 1, 16>([&](auto kc) { constexpr int k = decltype(kc)::value; fnma_bcast16<k>(x[k], lij, x[j]); });
+                    fnma_bcast16<j + 1>(a[j + 1], lij, lij);             // the next pivot first: it is the dependent chain
+                    if constexpr (j + 2 < 16) fnma_bcast16_from<j + 2>(a, lij, lij);
+                    fnma_bcast16_from<j + 1>(x, lij, x[j]);
                 }
                 a[j] = lij;
             });
@@ -179,7 +178,7 @@ __device__ __forceinline__ real diag_tile(real* __restrict__ S, real* __restrict
             static_for<0, 16>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
                 x[k] *= rd[k];
-                static_for<k + 1, 16>([&](auto rc) { constexpr int row = decltype(rc)::value; fnma_bcast16<row>(x[row], a[k], x[k]); });
+                if constexpr (k + 1 < 16) fnma_bcast16_from<k + 1>(x, a[k], x[k]);
             });
         }
     } else
@@ -194,7 +193,7 @@ __device__ __forceinline__ real diag_tile(real* __restrict__ S, real* __restrict
             const real ri = t_rsqrt<real>(p);
             rd[j] = ri;
             logsum += 0.5f * mf_log(p);
-            const real lij = a[j] * ri;
+            const const real lij = a[j] * ri;
             a[j] = lij;
             x[j] *= ri;
 #pragma unroll
