@@ -227,6 +227,19 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (!out_cov) return -7;                                                                                       \
         return t->ssm_marginal_covs(B, Tn, cholP0, A, cholQ, out_cov, out_sub, ws, ws_bytes, S(stream));               \
     }                                                                                                                  \
+    int mf_ssm_marginals_##SUF(int64_t B, int64_t Tn, int d, const T* mu0, const T* cholP0, const T* A, const T* b,    \
+                               const T* cholQ, T* out_mean, T* out_cov, T* out_sub, void* stream) {                   \
+        MF_HEAD(T, B, Tn, d)                                                                                           \
+        if (Tn < 2 || big) return -101;                                                                                \
+        if (!mu0) return -4;                                                                                           \
+        if (!cholP0) return -5;                                                                                        \
+        if (!A) return -6;                                                                                             \
+        if (!b) return -7;                                                                                             \
+        if (!cholQ) return -8;                                                                                         \
+        if (!out_mean) return -9;                                                                                      \
+        if (!out_cov) return -10;                                                                                      \
+        return t->ssm_marginals(B, Tn, mu0, cholP0, A, b, cholQ, out_mean, out_cov, out_sub, S(stream));               \
+    }                                                                                                                  \
     int mf_btd_udl_##SUF(int64_t B, int64_t Tn, int d, const T* diag, const T* sub, T* ut, T* chol_d, const T* eta,    \
                          T* m_post, T* chol_dinv, int chain_layout, void* ws, size_t ws_bytes, int* info,              \
                          void* stream) {                                                                               \

@@ -193,7 +193,7 @@ __device__ __forceinline__ real diag_tile(real* __restrict__ S, real* __restrict
             const real ri = t_rsqrt<real>(p);
             rd[j] = ri;
             logsum += 0.5f * mf_log(p);
-            const const real lij = a[j] * ri;
+            const real lij = a[j] * ri;
             a[j] = lij;
             x[j] *= ri;
 #pragma unroll

@@ -920,19 +920,30 @@ __global__ void __launch_bounds__(64) par_tak_down_kernel(long B, long n, long l
     }
 }
 
-template <typename T, int D, int SRC>
+// MEAN (SRC 1, ONE chunk per series): the marginal means mu_p = A_{p-1} mu_{p-1} + b_{p-1} ride along - `marginals` in one sweep that
+// reads A once (mf_ssm_marginals_*)
+template <typename T> struct TakMean {
+    const T* mu0;      // [B, D]
+    const T* b;        // [B, n-1, D]
+    T* out;            // [B, n, D]
+};
+template <typename T, int D, int SRC, bool MEAN = false>
 __global__ void __launch_bounds__(64) par_tak_emit_kernel(long B, long n, long len, long P, TakSrc<T> src,
                                                           const T* __restrict__ up, T* __restrict__ odiag,
-                                                          T* __restrict__ osub) {
+                                                          T* __restrict__ osub, TakMean<T> mean = TakMean<T>{}) {
     const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= B * P) return;
     const long s = id / P, c = id % P;
     const long p0 = c * len;
     long p1 = p0 + len;
     if (p1 > n) p1 = n;
-    struct Step { T L[D][D]; T W[D][D]; };
-    auto load = [&](long p, Step& d) { tak_load<T, D, SRC>(src, s, n, p, d.L, d.W); };
+    struct Step { T L[D][D]; T W[D][D]; T o[MEAN ? D : 1]; };
+    auto load = [&](long p, Step& d) {
+        tak_load<T, D, SRC>(src, s, n, p, d.L, d.W);
+        if constexpr (MEAN) load_vec<T, D>(p > 0 ? mean.b + (s * (n - 1) + p - 1) * D : mean.mu0 + s * D, d.o);
+    };
     constexpr bool PF = par_prefetch<T, D>() || (sizeof(T) == 8 && D <= 6);
+    T mu[MEAN ? D : 1];
     Step cur, nxt;
     if (PF && p0 < p1) load(p0, cur);
     T Sig[D][D];                                     // lower triangle
@@ -945,6 +956,16 @@ __global__ void __launch_bounds__(64) par_tak_emit_kernel(long B, long n, long l
         __builtin_amdgcn_sched_barrier(0);
         T N[D][D], G[D][D];
         tak_terms<T, D, SRC>(cur.L, cur.W, p > 0, N, G);
+        if constexpr (MEAN) {
+            if (p > 0) {
+                T nm[D];
+                gemv_n<T, D, D>(cur.W, mu, nm);
+                MF_UNROLL for (int i = 0; i < D; ++i) mu[i] = nm[i] + cur.o[i];
+            } else {
+                MF_UNROLL for (int i = 0; i < D; ++i) mu[i] = cur.o[i];
+            }
+            store_vec<T, D>(mean.out + (s * n + p) * D, mu);
+        }
         if (PF) cur = nxt;
         if (p > 0) {
             if (osub) {

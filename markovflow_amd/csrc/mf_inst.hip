@@ -579,6 +579,17 @@ int ssm_marginal_covs(long B, long n, const T* cholP0, const T* A, const T* chol
     return tak_scan<T, 1>(B, n, TakSrc<T>{cholQ, A, cholP0}, ocov, osub, ws, ws_bytes, st);
 }
 
+// `marginals` (means + covariances [+ Cov(x_{k+1}, x_k)]) in ONE sweep per series; only where one lane per series is the
+// chosen decomposition anyway (many series or a short chain) - otherwise -101 and the caller runs the two scans in time
+template <typename T>
+int ssm_marginals(long B, long n, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, T* omean, T* ocov,
+                  T* osub, hipStream_t st) {
+    if (n < 2 || par_len0(B, n) != 0) return -101;
+    hipLaunchKernelGGL((par_tak_emit_kernel<T, D, 1, true>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, n, 1L,
+                       TakSrc<T>{cholQ, A, cholP0}, static_cast<const T*>(nullptr), ocov, osub, TakMean<T>{mu0, b, omean});
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
 template <typename T> size_t btd_udl_ws(long B, long n) {
     const long len0 = par_len0(B, n);
     if (len0 == 0) return 0;
@@ -879,7 +890,7 @@ template <typename T> const OpsTable<T>* table() {
     static const OpsTable<T> t = {
         &kf_loglik_ws<T>, &kf_loglik<T>, &btd_logdet_quad_ws<T>, &btd_logdet_quad<T>, &btd_cholesky_ws<T>, &btd_cholesky<T>,
         &btd_solve_ws<T>, &btd_solve<T>,    &btd_matvec<T>, &btd_logdet<T>,        &btd_diag_of_inverse_ws<T>, &btd_diag_of_inverse<T>, &ssm_marginal_covs<T>, &btd_udl_ws<T>, &btd_udl<T>,
-        &ssm_precision<T>, &ssm_means<T, false>, &block_matmul<T>, &gpr_loglik<T>, &sde_predict<T>, &kf_grad<T>, &kl_grad<T>, &posterior_chain<T>, &kl_value<T>, &marginals_grad<T>, &adjoint_ws<T>,
+        &ssm_precision<T>, &ssm_means<T, false>, &block_matmul<T>, &gpr_loglik<T>, &sde_predict<T>, &kf_grad<T>, &kl_grad<T>, &posterior_chain<T>, &kl_value<T>, &marginals_grad<T>, &adjoint_ws<T>, &ssm_marginals<T>,
     };
     return &t;
 }

@@ -50,8 +50,7 @@ class _LogLikelihoodPerSeries(torch.autograd.Function):
         with torch.no_grad():
             kf = _RawFilter(StateSpaceModel(mu0, cp0, a_s, b_s, cq), EmissionModel(h), y, r_inv)
             post = kf.posterior_state_space_model()
-            means = post.marginal_means
-            covs, cross = post.covariance_blocks()             # one forward scan of the posterior chain
+            means, covs, cross = post._moments(want_sub=True)  # one forward sweep (or two scans) of the posterior chain
             bsz, n, m, d = h.shape
             per_step = r_inv.dim() > 2
             g_mu0, g_cp0 = torch.empty_like(mu0), torch.empty_like(cp0)

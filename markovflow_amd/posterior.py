@@ -47,8 +47,7 @@ class ConditionalProcess:
         minus, plus = torch.gather(aug, -1, idx), torch.gather(aug, -1, idx + 1)
         a_mt, q_mt = kern.transition_statistics(minus, new - minus)
         a_tp, q_tp = kern.transition_statistics(new, plus - new)
-        means = dist.marginal_means
-        covs, sub = dist.covariance_blocks() if n > 1 else (dist.marginal_covariances, None)
+        means, covs, sub = dist._moments(want_sub=n > 1)
         m0 = kern.initial_mean(batch).to(dtype=dtype, device=dev).expand(batch + (d,)).contiguous()
         p0 = kern.initial_covariance(new[..., :1]).to(dtype=dtype, device=dev)
         p0 = p0.expand(batch + (d, d)).contiguous()

@@ -38,8 +38,7 @@ def _eye_like(m: torch.Tensor) -> torch.Tensor:
 def ssm_to_expectations(ssm: StateSpaceModel) -> T3:
     """``(eta_linear [..,N+1,D], eta_diag [..,N+1,D,D], eta_subdiag [..,N,D,D])``: ``E[x]``, the diagonal and the lower
     sub-diagonal blocks of ``E[x x^T]`` (ssm_gaussian_transformations.py:32-89)."""
-    means = ssm.marginal_means
-    covs, sub_covs = ssm.covariance_blocks()
+    means, covs, sub_covs = ssm._moments(want_sub=True)
     eta_diag = covs + _outer(means, means)
     eta_subdiag = sub_covs + _outer(means[..., 1:, :], means[..., :-1, :])
     return means, eta_diag, eta_subdiag

@@ -164,11 +164,35 @@ class StateSpaceModel(GaussMarkovDistribution):
         (``_Marginals``: the expected log-likelihood of the variational models goes through here)."""
         if self._needs_grad():
             return self._differentiable_marginals()
-        return self.marginal_means, self.marginal_covariances
+        return self._moments(want_sub=False)[:2]
 
     def covariance_blocks(self) -> Tuple[torch.Tensor, torch.Tensor]:
         """Marginal covariances and ``Cov(x_{k+1}, x_k)`` from ONE scan."""
         return self._covariance_scan(want_sub=True)
+
+    def _moments(self, want_sub: bool):
+        """``(marginal_means, marginal_covariances, Cov(x_{k+1}, x_k) or None)`` without gradients.  Where one lane per series is
+        the decomposition anyway (many series or a short chain) the means ride along the covariance sweep: one kernel that
+        reads ``A`` once (``mf_ssm_marginals_*``); otherwise (-101 from the ABI) the two scans in time."""
+        d, n = self.state_dim, self.num_transitions + 1
+        mu0, cp0, a_f, b_f, cq = self._flat_params()
+        bsz = a_f.shape[0]
+        if bsz > 0 and n > 1 and d <= _lib.load().mf_max_state_dim():
+            means = torch.empty((bsz, n, d), dtype=a_f.dtype, device=a_f.device)
+            covs = torch.empty((bsz, n, d, d), dtype=a_f.dtype, device=a_f.device)
+            sub = torch.empty_like(a_f) if want_sub else None
+            rc = _lib.call_rc("mf_ssm_marginals", a_f.dtype, bsz, n, d, _lib.ptr(mu0), _lib.ptr(cp0), _lib.ptr(a_f),
+                              _lib.ptr(b_f), _lib.ptr(cq), _lib.ptr(means), _lib.ptr(covs), _lib.ptr(sub),
+                              _lib.stream_ptr(a_f.device))
+            if rc == 0:
+                batch = tuple(self.batch_shape)
+                return (means.reshape(batch + (n, d)), covs.reshape(batch + (n, d, d)),
+                        sub.reshape(self._A_s.shape) if want_sub else None)
+            if rc != -101:
+                _lib.check(rc, "mf_ssm_marginals")
+        means = self._propagate(self.concatenated_state_offsets)
+        covs, sub = self._covariance_scan(want_sub=want_sub)
+        return means, covs, sub
 
     def _covariance_scan(self, want_sub: bool):
         """``Σ_0 = P_0, Σ_{k+1} = A_kΣ_kA_kᵀ + Q_k`` (and ``A_kΣ_k``).  The reference takes the block diagonal of the inverse of
@@ -376,8 +400,7 @@ class _KLDivergence(torch.autograd.Function):
         mu1, c01, a1, b1, c1, mu2, c02, a2, b2, c2 = tensors
         with torch.no_grad():
             q1 = StateSpaceModel(mu1, c01, a1, b1, c1)
-            means = q1.marginal_means
-            covs, cross = q1.covariance_blocks()
+            means, covs, cross = q1._moments(want_sub=True)
             bsz, d = mu1.shape
             n = a1.shape[1] + 1
             dev, dtype = mu1.device, mu1.dtype
@@ -411,8 +434,7 @@ class _Marginals(torch.autograd.Function):
     def forward(ctx, mu0, cp0, a_s, b_s, cq):
         with torch.no_grad():
             ssm = StateSpaceModel(mu0, cp0, a_s, b_s, cq)
-            means = ssm._propagate(ssm.concatenated_state_offsets)
-            covs = ssm._covariance_scan(want_sub=False)[0]
+            means, covs, _ = ssm._moments(want_sub=False)
         ctx.save_for_backward(cp0, a_s, cq, means, covs)
         return means, covs
 

@@ -268,6 +268,37 @@ def test_state_space_model_vs_dense_joint():
     assert tr.state_transitions.requires_grad and not s1.create_non_trainable_copy().state_transitions.requires_grad
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("d,t,bsz", [(1, 2, 1), (4, 10, 3), (9, 33, 2), (6, 100, 2), (9, 70, 1), (3, 12, 4100)])
+def test_marginals_in_one_sweep_match_the_explicit_recursion(rng, dtype, d, t, bsz):
+    """gauss_markov.py:107-117 / state_space_model.py:232-262,326-341: means, covariances and Cov(x_{k+1}, x_k).  Short chains
+    and batches of >= 4096 series take ONE sweep per series (mf_ssm_marginals), the others the two scans in time."""
+    kw = random_ssm(rng, (bsz,), t, d, 1, well=True)
+    ssm = mfa.StateSpaceModel(*(tt(kw[k], dtype) for k in ("mu0", "chol_p0", "a_s", "b_s", "chol_q")))
+    means, covs, sub = ssm._moments(want_sub=True)
+    pick = np.unique(np.linspace(0, bsz - 1, min(bsz, 6)).astype(int))
+    em, ec, es = [], [], []
+    for s_ in pick:
+        mean, cov = kw["mu0"][s_], kw["chol_p0"][s_] @ kw["chol_p0"][s_].T
+        ms, cs, ss = [mean], [cov], []
+        for k in range(t - 1):
+            a, c = kw["a_s"][s_, k], kw["chol_q"][s_, k]
+            ss.append(a @ cov)
+            mean, cov = a @ mean + kw["b_s"][s_, k], a @ cov @ a.T + c @ c.T
+            ms.append(mean); cs.append(cov)
+        em.append(np.stack(ms)); ec.append(np.stack(cs)); es.append(np.stack(ss))
+    rtol, atol = (1e-10, 1e-12) if dtype == torch.float64 else (2e-4, 2e-5)
+    np.testing.assert_allclose(nn(means)[pick], np.stack(em), rtol=rtol, atol=atol)
+    np.testing.assert_allclose(nn(covs)[pick], np.stack(ec), rtol=rtol, atol=atol)
+    np.testing.assert_allclose(nn(sub)[pick], np.stack(es), rtol=rtol, atol=atol)
+    # the public properties (separate scans) agree with the fused sweep to rounding
+    np.testing.assert_allclose(nn(ssm.marginal_means), nn(means), rtol=rtol, atol=atol)
+    np.testing.assert_allclose(nn(ssm.marginal_covariances), nn(covs), rtol=rtol, atol=atol)
+    m2, c2 = ssm.marginals          # without the cross-covariances: the same sweep, another instantiation
+    np.testing.assert_allclose(nn(m2), nn(means), rtol=rtol, atol=atol)
+    np.testing.assert_allclose(nn(c2), nn(covs), rtol=rtol, atol=atol)
+
+
 # ------------------------------------------------------------------------------------------------ full-size properties
 def test_full_size_partition_invariance_and_linearity():
     """
