@@ -358,15 +358,22 @@ int mf_kf_posterior_chain_f32(int64_t B, int64_t T, int d, int m, const float* m
  * KL(q1 || q2) between two state space models, one scalar per series (markovflow/state_space_model.py:528-593), fused: ONE
  * forward sweep per series carries q1's marginal mean and covariance in registers and accumulates the divergence from the
  * local form  1/2 sum_k [ tr(Q2^-1 Q1) + tr(Q2^-1 dA S_k dA^T) + eps_k^T Q2^-1 eps_k ] - T d / 2 + log-determinants
- * (csrc/mf_kl_grad.hpp) - the ten parameter tensors are read once and nothing else touches HBM.  One lane per series:
- * meant for batches that fill the chip (the Python layer takes the operator route for few, long chains).  State dimension 1..9.
+ * (csrc/mf_kl_grad.hpp) - the ten parameter tensors are read once and nothing else touches HBM.  One lane per series when the
+ * batch fills the chip.  With few, long chains (mf_ssm_kl_workspace_bytes > 0 and a workspace of that size) q1's marginals come
+ * from the scans in time and the same local terms are formed by one lane per (series, step) and summed per series; on that
+ * route the marginals of q1 can be kept: out_means [B,T,d], out_covs [B,T,d,d], out_cross [B,T-1,d,d] = Cov(x_{k+1}, x_k) (each
+ * nullable) - exactly what mf_ssm_kl_grad / mf_kf_loglik_grad need.  Asking for them on the lane-per-series route is error -15.
+ * State dimension 1..9.
  */
+size_t mf_ssm_kl_workspace_bytes(int64_t B, int64_t T, int d, int elem_size);
 int mf_ssm_kl_divergence_f64(int64_t B, int64_t T, int d, const double* mu0_1, const double* cholP0_1, const double* A_1,
                              const double* b_1, const double* cholQ_1, const double* mu0_2, const double* cholP0_2,
-                             const double* A_2, const double* b_2, const double* cholQ_2, double* out, int* info, void* stream);
+                             const double* A_2, const double* b_2, const double* cholQ_2, double* out, double* out_means,
+                             double* out_covs, double* out_cross, void* ws, size_t ws_bytes, int* info, void* stream);
 int mf_ssm_kl_divergence_f32(int64_t B, int64_t T, int d, const float* mu0_1, const float* cholP0_1, const float* A_1,
                              const float* b_1, const float* cholQ_1, const float* mu0_2, const float* cholP0_2, const float* A_2,
-                             const float* b_2, const float* cholQ_2, float* out, int* info, void* stream);
+                             const float* b_2, const float* cholQ_2, float* out, float* out_means, float* out_covs,
+                             float* out_cross, void* ws, size_t ws_bytes, int* info, void* stream);
 
 /*
  * Adjoint of the marginal recursion  m_{k+1} = A_k m_k + b_k,  S_{k+1} = A_k S_k A_k^T + Q_k  (markovflow/state_space_model.py:232-262,

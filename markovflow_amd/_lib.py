@@ -39,7 +39,7 @@ _SIGS = {
     "mf_ssm_kl_grad": (_int, [_i64, _i64, _int] + ["Tp"] * 18 + [_vp, _sz, _vp, _vp]),
     "mf_obs_precision_from_chol": (_int, [_int, "Tp", "Tp", _vp, _vp]),
     "mf_kf_posterior_chain": (_int, [_i64, _i64, _int, _int] + ["Tp"] * 8 + [_int] + ["Tp"] * 5 + [_vp, _vp]),
-    "mf_ssm_kl_divergence": (_int, [_i64, _i64, _int] + ["Tp"] * 11 + [_vp, _vp]),
+    "mf_ssm_kl_divergence": (_int, [_i64, _i64, _int] + ["Tp"] * 14 + [_vp, _sz, _vp, _vp]),
     "mf_ssm_marginals_grad": (_int, [_i64, _i64, _int] + ["Tp"] * 12 + [_vp, _sz, _vp]),
     "mf_sde_conditional_predict": (_int, [_i64, _i64, _i64, _int, _vp, "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", "Tp",
                                           "Tp", "Tp", _vp, _vp]),
@@ -54,6 +54,7 @@ _PLAIN = {
     "mf_kf_loglik_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _i64]),
     "mf_btd_logdet_quad_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
     "mf_ssm_adjoint_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
+    "mf_ssm_kl_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
     "mf_btd_cholesky_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
     "mf_btd_solve_workspace_bytes": (_sz, [_i64, _i64, _i64, _int, _int]),
     "mf_btd_diag_of_inverse_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),

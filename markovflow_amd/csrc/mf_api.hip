@@ -389,14 +389,15 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
     }                                                                                                                  \
     int mf_ssm_kl_divergence_##SUF(int64_t B, int64_t Tn, int d, const T* mu0_1, const T* cholP0_1, const T* A_1,      \
                                    const T* b_1, const T* cholQ_1, const T* mu0_2, const T* cholP0_2, const T* A_2,    \
-                                   const T* b_2, const T* cholQ_2, T* out, int* info, void* stream) {                  \
+                                   const T* b_2, const T* cholQ_2, T* out, T* out_means, T* out_covs,          \
+                                   T* out_cross, void* ws, size_t ws_bytes, int* info, void* stream) {                 \
         MF_HEAD(T, B, Tn, d)                                                                                           \
         if (big) return -100;                                                                                          \
         if (!mu0_1 || !cholP0_1 || (Tn > 1 && (!A_1 || !b_1 || !cholQ_1))) return -4;                                  \
         if (!mu0_2 || !cholP0_2 || (Tn > 1 && (!A_2 || !b_2 || !cholQ_2))) return -9;                                  \
         if (!out) return -14;                                                                                          \
-        return t->kl(B, Tn, mu0_1, cholP0_1, A_1, b_1, cholQ_1, mu0_2, cholP0_2, A_2, b_2, cholQ_2, out, info,         \
-                     S(stream));                                                                                       \
+        return t->kl(B, Tn, mu0_1, cholP0_1, A_1, b_1, cholQ_1, mu0_2, cholP0_2, A_2, b_2, cholQ_2, out, out_means,    \
+                     out_covs, out_cross, ws, ws_bytes, info, S(stream));                                              \
     }                                                                                                                  \
     int mf_ssm_marginals_grad_##SUF(int64_t B, int64_t Tn, int d, const T* cholP0, const T* A, const T* cholQ,         \
                                     const T* means, const T* covs, const T* g_means, const T* g_covs, T* g_mu0,        \
@@ -446,6 +447,13 @@ size_t mf_btd_udl_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {
     if (elem_size == 4) { const auto* t = table_for<float>(d); return t ? t->btd_udl_ws(B, T) : 0; }
     const auto* t = table_for<double>(d);
     return t ? t->btd_udl_ws(B, T) : 0;
+}
+
+size_t mf_ssm_kl_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {
+    if (B < 1 || T < 1) return 0;
+    if (elem_size == 4) { const auto* t = table_for<float>(d); return t ? t->kl_ws(B, T) : 0; }
+    const auto* t = table_for<double>(d);
+    return t ? t->kl_ws(B, T) : 0;
 }
 
 size_t mf_ssm_adjoint_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {

@@ -860,9 +860,41 @@ int posterior_chain(long B, long Tn, int m, const T* mu0, const T* cholP0, const
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
+// kl_divergence with few series: workspace of the route over q1's marginals (0: one lane per series is the route)
+template <typename T> size_t kl_ws(long B, long Tn) {
+    if (Tn < 2 || par_len0(B, Tn) == 0) return 0;
+    return align_up(size_t(B) * Tn * D * D * sizeof(T)) + 2 * align_up(size_t(B) * Tn * D * sizeof(T)) +
+           align_up(size_t(B) * Tn * sizeof(T)) + adjoint_scan_ws<T>(B, Tn);
+}
+
 template <typename T>
 int kl_value(long B, long Tn, const T* mu0_1, const T* C0_1, const T* A_1, const T* b_1, const T* C_1, const T* mu0_2,
-             const T* C0_2, const T* A_2, const T* b_2, const T* C_2, T* out, int* info, hipStream_t st) {
+             const T* C0_2, const T* A_2, const T* b_2, const T* C_2, T* out, T* out_means, T* out_covs, T* out_cross,
+             void* ws, size_t ws_bytes, int* info, hipStream_t st) {
+    const size_t need = kl_ws<T>(B, Tn);
+    if (need != 0 && ws != nullptr && ws_bytes >= need) {
+        // few series: q1's marginals by the scans in time, then every term is local (mf_kl_grad.hpp)
+        char* p = static_cast<char*>(ws);
+        T* pS = reinterpret_cast<T*>(p); p += align_up(size_t(B) * Tn * D * D * sizeof(T));
+        T* pm = reinterpret_cast<T*>(p); p += align_up(size_t(B) * Tn * D * sizeof(T));
+        T* offs = reinterpret_cast<T*>(p); p += align_up(size_t(B) * Tn * D * sizeof(T));
+        T* part = reinterpret_cast<T*>(p); p += align_up(size_t(B) * Tn * sizeof(T));
+        const size_t scratch = adjoint_scan_ws<T>(B, Tn);
+        if (out_covs) pS = out_covs;
+        if (out_means) pm = out_means;
+        int rc = tak_scan<T, 1>(B, Tn, TakSrc<T>{C_1, A_1, C0_1}, pS, out_cross, p, scratch, st);
+        if (rc != 0) return rc;
+        hipLaunchKernelGGL((concat_offsets_kernel<T, D>), dim3((unsigned)cdiv(B * Tn * D, 256)), dim3(256), 0, st, B, Tn, mu0_1,
+                           b_1, offs);
+        rc = ssm_means<T, false>(B, B, Tn, A_1, static_cast<const T*>(offs), pm, p, scratch, st);
+        if (rc != 0) return rc;
+        hipLaunchKernelGGL((ssm_kl_local_kernel<T, D>), dim3((unsigned)cdiv(B * Tn, 64)), dim3(64), 0, st, B, Tn, mu0_1, C0_1,
+                           A_1, b_1, C_1, mu0_2, C0_2, A_2, b_2, C_2, static_cast<const T*>(pm), static_cast<const T*>(pS),
+                           part, info);
+        hipLaunchKernelGGL((row_sum_kernel<T>), dim3((unsigned)B), dim3(64), 0, st, Tn, static_cast<const T*>(part), out);
+        return hipGetLastError() == hipSuccess ? 0 : -1000;
+    }
+    if (out_means || out_covs || out_cross) return -15;      // the moments exist on the route above only
     hipLaunchKernelGGL((ssm_kl_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, Tn, mu0_1, C0_1, A_1, b_1, C_1,
                        mu0_2, C0_2, A_2, b_2, C_2, out, info);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
@@ -890,7 +922,7 @@ template <typename T> const OpsTable<T>* table() {
     static const OpsTable<T> t = {
         &kf_loglik_ws<T>, &kf_loglik<T>, &btd_logdet_quad_ws<T>, &btd_logdet_quad<T>, &btd_cholesky_ws<T>, &btd_cholesky<T>,
         &btd_solve_ws<T>, &btd_solve<T>,    &btd_matvec<T>, &btd_logdet<T>,        &btd_diag_of_inverse_ws<T>, &btd_diag_of_inverse<T>, &ssm_marginal_covs<T>, &btd_udl_ws<T>, &btd_udl<T>,
-        &ssm_precision<T>, &ssm_means<T, false>, &block_matmul<T>, &gpr_loglik<T>, &sde_predict<T>, &kf_grad<T>, &kl_grad<T>, &posterior_chain<T>, &kl_value<T>, &marginals_grad<T>, &adjoint_ws<T>, &ssm_marginals<T>,
+        &ssm_precision<T>, &ssm_means<T, false>, &block_matmul<T>, &gpr_loglik<T>, &sde_predict<T>, &kf_grad<T>, &kl_grad<T>, &posterior_chain<T>, &kl_value<T>, &marginals_grad<T>, &adjoint_ws<T>, &ssm_marginals<T>, &kl_ws<T>,
     };
     return &t;
 }

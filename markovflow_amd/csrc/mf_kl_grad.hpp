@@ -130,6 +130,106 @@ __global__ void __launch_bounds__(64) ssm_kl_kernel(long B, long Tn, const T* __
     if (bad && info) raise_info(info);
 }
 
+// ---- the divergence with few series: local in time given q1's marginals ---------------------------------------------------
+// With too few series for a lane each, q1's marginals (m_k, S_k) come from the scans in time (mf_btd_par.hpp) and every term of
+// the sum above is local: lane (s, k) forms the term of transition k (and, for k = 0, of the initial state); a wave per series
+// then adds the T partial values.  The marginals are outputs as well - the backward needs exactly these (mf_ssm_kl_grad).
+template <typename T, int D>
+__global__ void __launch_bounds__(64) ssm_kl_local_kernel(long B, long Tn, const T* __restrict__ mu0_1, const T* __restrict__ C0_1,
+                                                          const T* __restrict__ A_1, const T* __restrict__ b_1,
+                                                          const T* __restrict__ C_1, const T* __restrict__ mu0_2,
+                                                          const T* __restrict__ C0_2, const T* __restrict__ A_2,
+                                                          const T* __restrict__ b_2, const T* __restrict__ C_2,
+                                                          const T* __restrict__ pm, const T* __restrict__ pS,
+                                                          T* __restrict__ part, int* info) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= B * Tn) return;
+    const long s = id / Tn, k = id % Tn;
+    LogAcc<T> l1, l2;
+    l1.init();
+    l2.init();
+    bool bad = false;
+    T acc = T(0);
+    auto chol_terms = [&](const T (&C2i)[D][D], const T (&C1)[D][D]) {        // |C2^-1 C1|_F^2 (lower x lower)
+        T sum = T(0);
+        MF_UNROLL for (int i = 0; i < D; ++i)
+            MF_UNROLL for (int j = 0; j <= i; ++j) {
+                T a = T(0);
+                MF_UNROLL for (int l = j; l <= i; ++l) a += C2i[i][l] * C1[l][j];
+                sum += a * a;
+            }
+        return sum;
+    };
+    T m[D];
+    load_vec<T, D>(pm + id * D, m);
+    if (k == 0) {
+        T C1[D][D], C2[D][D], C2i[D][D], d0[D], u[D];
+        load_lower<T, D>(C0_1 + s * D * D, C1);
+        load_lower<T, D>(C0_2 + s * D * D, C2);
+        tri_inv_lower<T, D>(C2, C2i, l2, bad);
+        MF_UNROLL for (int i = 0; i < D; ++i) {
+            l1.mul(C1[i][i]);
+            bad |= !(C1[i][i] != T(0));
+            d0[i] = m[i] - mu0_2[s * D + i];
+        }
+        trimul_lower_vec<T, D>(C2i, d0, u);
+        acc += chol_terms(C2i, C1) + dot_self<T, D>(u);
+    }
+    if (k + 1 < Tn) {
+        const long tid = s * (Tn - 1) + k;
+        T W[D][D], C1[D][D], C2[D][D], C2i[D][D], eps[D], u[D];
+        {
+            T A1[D][D];
+            load_mat<T, D, D>(A_1 + tid * D * D, A1);
+            load_mat<T, D, D>(A_2 + tid * D * D, W);
+            MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) W[i][j] = A1[i][j] - W[i][j];    // dA
+        }
+        load_lower<T, D>(C_1 + tid * D * D, C1);
+        load_lower<T, D>(C_2 + tid * D * D, C2);
+        MF_UNROLL for (int i = 0; i < D; ++i) eps[i] = b_1[tid * D + i] - b_2[tid * D + i];
+        tri_inv_lower<T, D>(C2, C2i, l2, bad);
+        MF_UNROLL for (int i = 0; i < D; ++i) {
+            l1.mul(C1[i][i]);
+            bad |= !(C1[i][i] != T(0));
+        }
+        MF_UNROLL for (int j = 0; j < D; ++j) MF_UNROLL for (int i = 0; i < D; ++i) eps[i] += W[i][j] * m[j];
+        trimul_lower_vec<T, D>(C2i, eps, u);
+        acc += chol_terms(C2i, C1) + dot_self<T, D>(u);
+        trimul_lower_inplace<T, D, D>(C2i, W);                                            // W = C2^-1 dA
+        T S[D][D];
+        load_lower<T, D>(pS + id * D * D, S);
+        MF_UNROLL for (int i = 0; i < D; ++i) {
+            T row[D];
+            MF_UNROLL for (int j = 0; j < D; ++j) row[j] = T(0);
+            MF_UNROLL for (int l = 0; l < D; ++l)
+                MF_UNROLL for (int j = 0; j < D; ++j) row[j] += W[i][l] * ((l >= j) ? S[l][j] : S[j][l]);
+            MF_UNROLL for (int j = 0; j < D; ++j) acc += row[j] * W[i][j];
+        }
+    }
+    part[id] = T(0.5) * (acc - T(D)) + l2.value() - l1.value();
+    if (bad && info) raise_info(info);
+}
+
+// out[s] = sum_k part[s, k]: one wavefront per series (fixed order: deterministic)
+template <typename T>
+__global__ void __launch_bounds__(64) row_sum_kernel(long n, const T* __restrict__ part, T* __restrict__ out) {
+    const long s = blockIdx.x;
+    T a = T(0);
+    for (long k = threadIdx.x; k < n; k += 64) a += part[s * n + k];
+    MF_UNROLL for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+    if (threadIdx.x == 0) out[s] = a;
+}
+
+// (mu0, b) -> the [B, n, D] offsets of the mean recursion
+template <typename T, int D>
+__global__ void __launch_bounds__(256) concat_offsets_kernel(long B, long n, const T* __restrict__ mu0, const T* __restrict__ b,
+                                                             T* __restrict__ offs) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B * n * D) return;
+    const long s = e / (n * D), r = e % (n * D);
+    offs[e] = r < D ? mu0[s * D + r] : b[s * (n - 1) * D + r - D];
+}
+
 // ---- the adjoint in three kernels (round 2, second form) ------------------------------------------------------------------
 // The ONE-sweep forms of the two adjoints (everything inside the sequential loop) were correct but slow where it matters: at
 // BASELINE config 4's shape (B = 512, T = 1000, d = 9) a step carried four d x d matrices plus the state, spilt 3.2 KB per lane

@@ -56,12 +56,14 @@ template <typename T> struct OpsTable {
                            const T* H, const T* y, const T* Rinv, int rinv_per_step, T* a_post, T* mu0_post, T* b_post,
                            T* cp0_post, T* cq_post, int* info, hipStream_t st);
     int (*kl)(long B, long Tn, const T* mu0_1, const T* C0_1, const T* A_1, const T* b_1, const T* C_1, const T* mu0_2,
-              const T* C0_2, const T* A_2, const T* b_2, const T* C_2, T* out, int* info, hipStream_t st);
+              const T* C0_2, const T* A_2, const T* b_2, const T* C_2, T* out, T* out_means, T* out_covs, T* out_cross, void* ws,
+              size_t ws_bytes, int* info, hipStream_t st);
     int (*marginals_grad)(long B, long Tn, const T* C0, const T* A, const T* C, const T* pm, const T* pS, const T* gm,
                           const T* gS, T* gmu0, T* gC0, T* gA, T* gb, T* gC, void* ws, size_t ws_bytes, hipStream_t st);
     size_t (*adjoint_ws)(long B, long Tn);
     int (*ssm_marginals)(long B, long n, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, T* omean,
                          T* ocov, T* osub, hipStream_t st);
+    size_t (*kl_ws)(long B, long Tn);
 };
 
 constexpr int MF_MAX_D = 9;        // largest state dimension with a register-resident instantiation

@@ -333,23 +333,32 @@ class StateSpaceModel(GaussMarkovDistribution):
                 return _KLDivergence.apply(*tensors).reshape(tuple(self.batch_shape))
         return self._kl_divergence_value(dist)
 
-    # batches at least this large (or chains this short) take the fused one-lane-per-series sweep; fewer, longer chains keep
-    # the operator route, whose scans are parallel in time
-    _KL_FUSED_MIN_SERIES = 2048
-    _KL_FUSED_MAX_SERIAL_BLOCKS = 64
-
-    def _kl_divergence_value(self, dist: GaussMarkovDistribution) -> torch.Tensor:
+    def _kl_divergence_value(self, dist: GaussMarkovDistribution, keep_moments: bool = False):
+        """The divergence from its local form (``mf_ssm_kl_divergence_*``): one sweep per series when the batch fills the chip,
+        else the marginals of ``self`` by the scans in time + one lane per (series, step).  ``keep_moments``: also return
+        ``(means, covs, cross)`` of ``self`` when that second route computed them (else ``None``) - the backward needs them.
+        Other distributions and state dimensions beyond the register kernels take the reference's operator route."""
         bsz = int(math.prod(self.batch_shape))
         n, d = self.num_transitions + 1, self.state_dim
-        if isinstance(dist, StateSpaceModel) and d <= _lib.load().mf_max_state_dim() and bsz > 0 and (
-                bsz >= self._KL_FUSED_MIN_SERIES or n <= self._KL_FUSED_MAX_SERIAL_BLOCKS):
-            out = torch.empty(bsz, dtype=self._A_s.dtype, device=self._A_s.device)
-            info = _lib.pivot_info(out.device)
-            _lib.call("mf_ssm_kl_divergence", out.dtype, bsz, n, d, *[_lib.ptr(t) for t in self._flat_params()],
-                      *[_lib.ptr(t) for t in dist._flat_params()], _lib.ptr(out), info, _lib.stream_ptr(out.device))
-            _lib.raise_on_info(info, "StateSpaceModel.kl_divergence", out.device)
-            return out.reshape(tuple(self.batch_shape))
-        return self._kl_divergence_operators(dist)
+        if isinstance(dist, StateSpaceModel) and d <= _lib.load().mf_max_state_dim() and bsz > 0:
+            dtype, dev = self._A_s.dtype, self._A_s.device
+            out = torch.empty(bsz, dtype=dtype, device=dev)
+            ws_bytes = int(_lib.load().mf_ssm_kl_workspace_bytes(bsz, n, d, out.element_size()))
+            ws = _lib.workspace(ws_bytes, dev)
+            moments = None
+            if keep_moments and ws_bytes > 0:
+                moments = (torch.empty((bsz, n, d), dtype=dtype, device=dev), torch.empty((bsz, n, d, d), dtype=dtype, device=dev),
+                           torch.empty((bsz, n - 1, d, d), dtype=dtype, device=dev))
+            info = _lib.pivot_info(dev)
+            _lib.call("mf_ssm_kl_divergence", dtype, bsz, n, d, *[_lib.ptr(t) for t in self._flat_params()],
+                      *[_lib.ptr(t) for t in dist._flat_params()], _lib.ptr(out),
+                      *([_lib.ptr(t) for t in moments] if moments else [None, None, None]), _lib.ptr(ws), ws_bytes, info,
+                      _lib.stream_ptr(dev))
+            _lib.raise_on_info(info, "StateSpaceModel.kl_divergence", dev)
+            out = out.reshape(tuple(self.batch_shape))
+            return (out, moments) if keep_moments else out
+        out = self._kl_divergence_operators(dist)
+        return (out, None) if keep_moments else out
 
     def _kl_divergence_operators(self, dist: GaussMarkovDistribution) -> torch.Tensor:
         """The reference's route (state_space_model.py:569-593) over the operator kernels."""
@@ -390,17 +399,19 @@ class _KLDivergence(torch.autograd.Function):
     def forward(ctx, *tensors):
         with torch.no_grad():
             q1, q2 = StateSpaceModel(*tensors[:5]), StateSpaceModel(*tensors[5:])
-            out = q1._kl_divergence_value(q2)
-        ctx.save_for_backward(*tensors)
+            out, moments = q1._kl_divergence_value(q2, keep_moments=True)
+        ctx.save_for_backward(*tensors, *(moments or ()))
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         tensors = ctx.saved_tensors
-        mu1, c01, a1, b1, c1, mu2, c02, a2, b2, c2 = tensors
+        mu1, c01, a1, b1, c1, mu2, c02, a2, b2, c2 = tensors[:10]
         with torch.no_grad():
-            q1 = StateSpaceModel(mu1, c01, a1, b1, c1)
-            means, covs, cross = q1._moments(want_sub=True)
+            if len(tensors) > 10:         # few series: the forward's scans already produced q1's moments
+                means, covs, cross = tensors[10:]
+            else:
+                means, covs, cross = StateSpaceModel(mu1, c01, a1, b1, c1)._moments(want_sub=True)
             bsz, d = mu1.shape
             n = a1.shape[1] + 1
             dev, dtype = mu1.device, mu1.dtype

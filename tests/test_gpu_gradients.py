@@ -405,18 +405,32 @@ def test_operations_without_a_backward_fail_loudly(rng):
     assert torch.isfinite(ssm.create_non_trainable_copy().precision.cholesky.block_diagonal).all()
 
 
-@pytest.mark.parametrize("d,t,bsz", [(1, 1 + 1, 3), (3, 100, 4), (6, 257, 2), (9, 70, 2)])
-def test_kl_fused_sweep_and_operator_route_agree_with_the_oracle(rng, monkeypatch, d, t, bsz):
-    """kl_divergence has two routes: the fused one-lane-per-series sweep (many series / short chains) and the reference's
-    route over the operator kernels (few long chains).  Both against the numpy restatement of state_space_model.py:528-593."""
+@pytest.mark.parametrize("d,t,bsz", [(1, 1 + 1, 3), (3, 100, 4), (6, 257, 2), (9, 70, 2), (7, 130, 1), (2, 64, 5)])
+def test_kl_routes_agree_with_the_oracle(rng, d, t, bsz):
+    """kl_divergence has three routes: one sweep per series (many series / short chains), the marginals of q1 by the scans in
+    time + one lane per (series, step) (few long chains: t >= 64 here), and the reference's route over the operator kernels
+    (other distributions, d > 9).  All against the numpy restatement of state_space_model.py:528-593; on the second route the
+    moments handed to the backward are the marginals of q1."""
     from oracle import numpy_oracle as O
+    from markovflow_amd import _lib
     kw1 = random_ssm(rng, (bsz,), t, d, 1, well=True)
     kw2 = random_ssm(rng, (bsz,), t, d, 1, well=True)
     ref = O.ssm_kl_divergence(tuple(kw1[k] for k in CHAIN), tuple(kw2[k] for k in CHAIN))
     q1 = mfa.StateSpaceModel(*(tt(kw1[k]) for k in CHAIN))
     q2 = mfa.StateSpaceModel(*(tt(kw2[k]) for k in CHAIN))
-    monkeypatch.setattr(mfa.StateSpaceModel, "_KL_FUSED_MIN_SERIES", 1)
-    fused = q1.kl_divergence(q2).cpu().numpy()
-    ops = q1._kl_divergence_operators(q2).cpu().numpy()
-    np.testing.assert_allclose(fused, ref, rtol=1e-9)
-    np.testing.assert_allclose(ops, ref, rtol=1e-9)
+    value, moments = q1._kl_divergence_value(q2, keep_moments=True)
+    np.testing.assert_allclose(value.cpu().numpy(), ref, rtol=1e-9)
+    ws_bytes = int(_lib.load().mf_ssm_kl_workspace_bytes(bsz, t, d, 8))
+    assert (ws_bytes > 0) == (t >= 64) and (moments is not None) == (t >= 64)
+    if moments is not None:
+        means, covs, cross = q1._moments(want_sub=True)
+        for got, want in zip(moments, (means, covs, cross)):
+            np.testing.assert_allclose(got.cpu().numpy(), want.reshape(got.shape).cpu().numpy(), rtol=1e-11, atol=1e-13)
+    # the sweep per series, whatever the shape: no workspace
+    out = torch.empty(bsz, dtype=torch.float64, device=DEV)
+    info = _lib.pivot_info(out.device)
+    _lib.call("mf_ssm_kl_divergence", out.dtype, bsz, t, d, *[_lib.ptr(x) for x in q1._flat_params()],
+              *[_lib.ptr(x) for x in q2._flat_params()], _lib.ptr(out), None, None, None, None, 0, info,
+              _lib.stream_ptr(out.device))
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-9)
+    np.testing.assert_allclose(q1._kl_divergence_operators(q2).cpu().numpy(), ref, rtol=1e-9)
