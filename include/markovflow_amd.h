@@ -138,7 +138,9 @@ int mf_btd_diag_of_inverse_f32(int64_t B, int64_t T, int d, const float* ldiag, 
  * scan: Sigma_0 = P0, Sigma_{k+1} = A_k Sigma_k A_k^T + Q_k, out_sub[k] = Cov(x_{k+1}, x_k) = A_k Sigma_k (nullable).  The
  * reference takes the block diagonal of the inverse of the assembled precision; the forward recursion yields the same blocks
  * without assembling or factorising it.  Parallel in time for B < 4096 (workspace = the diag-of-inverse query), one lane per
- * series otherwise.  T >= 2, state dimension 1..9 (returns -100 above: use precision -> cholesky -> diag_of_inverse).
+ * series otherwise.  T >= 2.  State dimension 1..9 in registers; 10..64 (fp32) / 10..32 (fp64) on the LDS-tile / MFMA engine,
+ * partitioned in time: chunk maps S -> M S M^T + N, a walk over the chunk boundaries, re-start per chunk (three launches;
+ * workspace from the same query, one workgroup per series without it); -100 above.
  * cholP0 [B,d,d], A, cholQ [B,T-1,d,d]; out_cov [B,T,d,d], out_sub [B,T-1,d,d].
  */
 int mf_ssm_marginal_covariances_f64(int64_t B, int64_t T, int d, const double* cholP0, const double* A, const double* cholQ,

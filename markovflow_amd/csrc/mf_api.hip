@@ -220,11 +220,11 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
                                           T* out_cov, T* out_sub, void* ws, size_t ws_bytes, void* stream) {          \
         MF_HEAD(T, B, Tn, d)                                                                                           \
         if (Tn < 2) return -2;                                                                                         \
-        if (big) return -100;                                                                                          \
         if (!cholP0) return -4;                                                                                        \
         if (!A) return -5;                                                                                             \
         if (!cholQ) return -6;                                                                                         \
         if (!out_cov) return -7;                                                                                       \
+        if (big) return mf::big_marginal_covs_##SUF(B, Tn, d, cholP0, A, cholQ, out_cov, out_sub, ws, ws_bytes, S(stream)); \
         return t->ssm_marginal_covs(B, Tn, cholP0, A, cholQ, out_cov, out_sub, ws, ws_bytes, S(stream));               \
     }                                                                                                                  \
     int mf_ssm_marginals_##SUF(int64_t B, int64_t Tn, int d, const T* mu0, const T* cholP0, const T* A, const T* b,    \
@@ -437,6 +437,9 @@ size_t mf_btd_solve_workspace_bytes(int64_t Bl, int64_t Br, int64_t T, int d, in
 
 size_t mf_btd_diag_of_inverse_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {
     if (B < 1 || T < 1) return 0;
+    // large d: the (time-partitioned) covariance recursion of mf_ssm_marginal_covariances is the only user of a workspace
+    const bool big = d > mf::MF_MAX_D && d <= (elem_size == 4 ? mf::MF_MAX_D_BIG : mf::MF_MAX_D_BIG_F64);
+    if (big) return mf::big_marginal_covs_ws(B, T, d, elem_size);
     if (elem_size == 4) { const auto* t = table_for<float>(d); return t ? t->btd_diag_of_inverse_ws(B, T) : 0; }
     const auto* t = table_for<double>(d);
     return t ? t->btd_diag_of_inverse_ws(B, T) : 0;

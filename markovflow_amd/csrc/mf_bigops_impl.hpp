@@ -305,6 +305,94 @@ __global__ void __launch_bounds__(64) bigop_block_matmul_kernel(long B, long n, 
     }
 }
 
+// ---- StateSpaceModel.marginal_covariances / subsequent_covariances for large d, partitioned in time --------------------------
+// The reference takes the block diagonal of the inverse of the assembled precision (state_space_model.py:254-262); the forward
+// recursion  S_0 = P0,  S_{k+1} = A_k S_k A_k^T + Q_k  gives the same blocks with three products per step and, being a
+// congruence recursion, splits over time like the small-d scan (mf_btd_par.hpp): pass 0 - workgroup (series, chunk) composes the
+// chunk's map  S -> M S M^T + N  (M = product of the chunk's A, N = the recursion started from zero); pass 1 - one workgroup
+// per series walks the P chunk boundaries; pass 2 - workgroup (series, chunk) restarts from its boundary value and writes
+// every block (and A_k S_k = Cov(x_{k+1}, x_k)).  7 products per step on P chunks instead of 3 on one workgroup per series.
+template <int DP, bool EMIT>
+__global__ void __launch_bounds__(NTHR) bigop_cov_chunk_kernel(long B, long n, int d, long P, long L, const real* __restrict__ cholP0,
+                                                              const real* __restrict__ A, const real* __restrict__ cholQ,
+                                                              real* __restrict__ wsM, real* __restrict__ wsN,
+                                                              const real* __restrict__ start, real* __restrict__ ocov,
+                                                              real* __restrict__ osub) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const Smem<DP> sm{reinterpret_cast<real*>(smem_raw)};
+    const long s = blockIdx.x / P, c = blockIdx.x % P;
+    const long nt = n - 1, dd = (long)d * d, k0 = c * L;
+    long k1 = k0 + L;
+    if (k1 > nt) k1 = nt;
+    if (!EMIT && (c + 1 == P || k0 >= k1)) return;               // the last chunk's map is never applied
+    real *At = sm.tile(0), *Ct = sm.tile(1), *S = sm.tile(2), *T1 = sm.tile(3), *M = sm.tile(4);
+    if (EMIT) {
+        if (c == 0) {
+            load_tile<DP>(Ct, cholP0 + s * dd, nullptr, d, true, false);
+            __syncthreads();
+            gemm<DP, 0, 1, 0, K_A_LOWER, O_FULL>(Ct, Ct, S, 1.f);                    // P0 = C0 C0^T
+            __syncthreads();
+            store_tile<DP>(ocov + (s * n) * dd, S, d);
+        } else {
+            load_tile<DP>(S, start + (s * P + c) * dd, nullptr, d, false, false);
+        }
+    } else {
+        zero_tile<DP>(S);
+        for (int e = threadIdx.x; e < DP * DP; e += NTHR) M[(e / DP) * Geo<DP>::LD + (e % DP)] = (e / DP == e % DP) ? 1.f : 0.f;
+    }
+    __syncthreads();
+    for (long k = k0; k < k1; ++k) {
+        load_tile<DP>(At, A + (s * nt + k) * dd, nullptr, d, false, false);
+        load_tile<DP>(Ct, cholQ + (s * nt + k) * dd, nullptr, d, true, false);
+        __syncthreads();
+        gemm<DP, 0, 0, 0, K_FULL, O_FULL>(At, S, T1, 1.f);                           // T1 = A S
+        __syncthreads();
+        if (EMIT && osub) store_tile<DP>(osub + (s * nt + k) * dd, T1, d);
+        gemm<DP, 0, 1, 0, K_FULL, O_FULL>(T1, At, S, 1.f);                           // S = A S A^T
+        gemm<DP, 0, 1, 1, K_A_LOWER, O_FULL>(Ct, Ct, S, 1.f);                        //   + C C^T (same output tiles per wave)
+        __syncthreads();
+        if (EMIT) {
+            store_tile<DP>(ocov + (s * n + k + 1) * dd, S, d);
+        } else {
+            gemm<DP, 0, 0, 0, K_FULL, O_FULL>(At, M, T1, 1.f);                       // M <- A M
+            real* t = M; M = T1; T1 = t;
+        }
+        __syncthreads();
+    }
+    if (!EMIT) {
+        store_tile<DP>(wsM + (s * P + c) * dd, M, d);
+        store_tile<DP>(wsN + (s * P + c) * dd, S, d);
+    }
+}
+// pass 1: start[c + 1] = M_c start[c] M_c^T + N_c along the chunk boundaries of one series
+template <int DP>
+__global__ void __launch_bounds__(NTHR) bigop_cov_boundary_kernel(long B, int d, long P, const real* __restrict__ cholP0,
+                                                                 const real* __restrict__ wsM, const real* __restrict__ wsN,
+                                                                 real* __restrict__ start) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const Smem<DP> sm{reinterpret_cast<real*>(smem_raw)};
+    constexpr int LD = Geo<DP>::LD;
+    const long s = blockIdx.x, dd = (long)d * d;
+    real *Mt = sm.tile(0), *Nt = sm.tile(1), *S = sm.tile(2), *T1 = sm.tile(3);
+    load_tile<DP>(Nt, cholP0 + s * dd, nullptr, d, true, false);
+    __syncthreads();
+    gemm<DP, 0, 1, 0, K_A_LOWER, O_FULL>(Nt, Nt, S, 1.f);
+    __syncthreads();
+    for (long c = 0; c + 1 < P; ++c) {
+        load_tile<DP>(Mt, wsM + (s * P + c) * dd, nullptr, d, false, false);
+        load_tile<DP>(Nt, wsN + (s * P + c) * dd, nullptr, d, false, false);
+        __syncthreads();
+        gemm<DP, 0, 0, 0, K_FULL, O_FULL>(Mt, S, T1, 1.f);
+        __syncthreads();
+        gemm<DP, 0, 1, 0, K_FULL, O_FULL>(T1, Mt, S, 1.f);
+        __syncthreads();
+        for (int e = threadIdx.x; e < DP * DP; e += NTHR) S[(e / DP) * LD + (e % DP)] += Nt[(e / DP) * LD + (e % DP)];
+        __syncthreads();
+        store_tile<DP>(start + (s * P + c + 1) * dd, S, d);
+        __syncthreads();
+    }
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------------------
 #define MF_BIGOP_DISPATCH(CALL)                    \
     if (d <= 16) { CALL(16) }                      \
@@ -373,6 +461,45 @@ inline int op_ssm_precision(long B, long Tn, int d, int m, const real* mu0, cons
 }
 inline int op_means(long Bl, long Br, long Tn, int d, const real* A, const real* offs, real* out, hipStream_t st) {
     hipLaunchKernelGGL(bigop_means_kernel, dim3((unsigned)Br), dim3(64), 0, st, Bl, Br, Tn, d, A, offs, out);
+    return big_ok();
+}
+// chunks per series of the covariance recursion: about two workgroups per CU, chunks of at least eight transitions
+inline long cov_chunks(long B, long n) {
+    long P = 512 / (B > 0 ? B : 1);
+    if (P < 1) P = 1;
+    while (P > 1 && (n - 1) / P < 8) --P;
+    return P;
+}
+inline size_t marginal_covs_ws(long B, long n, int d) {
+    const long P = cov_chunks(B, n);
+    return P > 1 ? 3 * size_t(B) * P * d * d * sizeof(real) : 0;
+}
+inline int op_marginal_covs(long B, long n, int d, const real* cholP0, const real* A, const real* cholQ, real* ocov, real* osub,
+                            void* ws, size_t ws_bytes, hipStream_t st) {
+    long P = cov_chunks(B, n);
+    if (P > 1 && (ws == nullptr || ws_bytes < marginal_covs_ws(B, n, d))) P = 1;
+    const long L = (n - 1 + P - 1) / P;
+    P = (n - 1 + L - 1) / L;                                   // no empty chunks
+    real* wsM = static_cast<real*>(ws);
+    real* wsN = P > 1 ? wsM + size_t(B) * P * d * d : nullptr;
+    real* start = P > 1 ? wsN + size_t(B) * P * d * d : nullptr;
+#define MF_C(DP)                                                                                                       \
+    { static const bool ok = big_attr(&bigop_cov_chunk_kernel<DP, false>, Smem<DP>::BYTES) &&                            \
+                             big_attr(&bigop_cov_chunk_kernel<DP, true>, Smem<DP>::BYTES) &&                             \
+                             big_attr(&bigop_cov_boundary_kernel<DP>, Smem<DP>::BYTES);                                  \
+      if (!ok) return -1000;                                                                                           \
+      if (P > 1) {                                                                                                     \
+          hipLaunchKernelGGL((bigop_cov_chunk_kernel<DP, false>), dim3((unsigned)(B * P)), dim3(NTHR), Smem<DP>::BYTES, st, B, n, d, P, L, \
+                             cholP0, A, cholQ, wsM, wsN, static_cast<const real*>(nullptr), static_cast<real*>(nullptr),  \
+                             static_cast<real*>(nullptr));                                                              \
+          hipLaunchKernelGGL((bigop_cov_boundary_kernel<DP>), dim3((unsigned)B), dim3(NTHR), Smem<DP>::BYTES, st, B, d, P, cholP0, \
+                             static_cast<const real*>(wsM), static_cast<const real*>(wsN), start);                      \
+      }                                                                                                                \
+      hipLaunchKernelGGL((bigop_cov_chunk_kernel<DP, true>), dim3((unsigned)(B * P)), dim3(NTHR), Smem<DP>::BYTES, st, B, n, d, P, L, \
+                         cholP0, A, cholQ, static_cast<real*>(nullptr), static_cast<real*>(nullptr),                    \
+                         static_cast<const real*>(start), ocov, osub); }
+    MF_BIGOP_DISPATCH(MF_C)
+#undef MF_C
     return big_ok();
 }
 inline int op_block_matmul(long B, long n, int d, const real* X, long xs, const real* Y, long ys, real* out, hipStream_t st) {

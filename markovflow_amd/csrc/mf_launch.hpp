@@ -72,6 +72,7 @@ constexpr int MF_MAX_D_BIG_F64 = 32;  // the same in fp64 (seven d x d tiles mus
 
 // mf_big_inst.hip
 size_t big_kf_loglik_ws(long B, long Tn, int d, long chunks, int elem_size);
+size_t big_marginal_covs_ws(long B, long n, int d, int elem_size);
 int big_kf_loglik_f64(long B, long Tn, int d, int m, const double* mu0, const double* cholP0, const double* A,
                       const double* b, const double* cholQ, const double* H, const double* y, const double* Rinv,
                       int rinv_per_step, double add_const, double* out, void* ws, size_t ws_bytes, int* info, long chunks,
@@ -95,7 +96,9 @@ int big_kf_loglik_f32(long B, long Tn, int d, int m, const float* mu0, const flo
                                 const T* cholQ, const T* H, const T* y, const T* Rinv, int rinv_per_step, T* diag, T* sub,    \
                                 T* eta, hipStream_t st);                                                                     \
     int big_means_##SUF(long Bl, long Br, long Tn, int d, const T* A, const T* offs, T* out, hipStream_t st);                \
-    int big_block_matmul_##SUF(long B, long n, int d, const T* X, long xs, const T* Y, long ys, T* out, hipStream_t st);
+    int big_block_matmul_##SUF(long B, long n, int d, const T* X, long xs, const T* Y, long ys, T* out, hipStream_t st);    \
+    int big_marginal_covs_##SUF(long B, long n, int d, const T* cholP0, const T* A, const T* cholQ, T* ocov, T* osub, void* ws, \
+                                size_t ws_bytes, hipStream_t st);
 MF_DECLARE_BIG(f32, float)
 MF_DECLARE_BIG(f64, double)
 #undef MF_DECLARE_BIG

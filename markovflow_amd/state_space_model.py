@@ -198,9 +198,12 @@ class StateSpaceModel(GaussMarkovDistribution):
         """``Σ_0 = P_0, Σ_{k+1} = A_kΣ_kA_kᵀ + Q_k`` (and ``A_kΣ_k``).  The reference takes the block diagonal of the inverse of
         the assembled precision (``self.precision.cholesky.block_diagonal_of_inverse()``, state_space_model.py:262); the
         forward recursion gives the same blocks without assembling or factorising anything - one kernel sweep instead of
-        three (parallel in time for few series).  State dimensions beyond the register kernels keep the reference's route."""
+        three (parallel in time for few series; for d > 9 on the LDS-tile / MFMA engine, partitioned in time).  State
+        dimensions beyond that engine keep the reference's route."""
         d, n = self.state_dim, self.num_transitions + 1
-        if d > _lib.load().mf_max_state_dim():
+        lib = _lib.load()
+        d_max = lib.mf_max_state_dim_f32_loglik() if self._A_s.dtype == torch.float32 else lib.mf_max_state_dim_f64_loglik()
+        if d > d_max or n < 2:
             covs = self.precision.cholesky.block_diagonal_of_inverse()
             return covs, (self.subsequent_covariances(covs) if want_sub else None)
         cp0, a_f, cq = _flat(self._chol_P_0, 2), _flat(self._A_s, 3), _flat(self._chol_Q_s, 3)

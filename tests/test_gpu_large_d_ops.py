@@ -97,3 +97,35 @@ def test_large_d_posterior_marginals_and_kl(rng, dtype, d, m):
     # the log-likelihood of the same model agrees with the operator route: 0.5 |L^-1 eta|^2 - log|L| through cholesky/solve
     ref = O.kf_log_likelihood(**kw, r_inv=np.linalg.inv(cov))
     np.testing.assert_allclose(float(kf.log_likelihood().cpu()), ref, rtol=1e-9 if dtype == torch.float64 else 3e-4)
+
+
+@pytest.mark.parametrize("dtype,d", [(torch.float64, 10), (torch.float64, 19), (torch.float64, 32), (torch.float32, 12),
+                                     (torch.float32, 33), (torch.float32, 64)])
+@pytest.mark.parametrize("bsz,t", [(2, 3), (3, 40), (1, 700), (5, 129)])
+def test_large_d_marginal_covariances_partitioned_in_time(rng, dtype, d, bsz, t):
+    """state_space_model.py:254-275,326-341 for d > 9: the forward recursion on the LDS-tile / MFMA engine.  Chains long enough
+    for more than one chunk per series (t = 129, 700) take the three-pass partition, the others one workgroup per series; both
+    against the explicit recursion, and the reference's route (precision -> cholesky -> block_diagonal_of_inverse) as a check
+    of the identity itself in fp64."""
+    kw = random_ssm(rng, (bsz,), t, d, 1, well=True)
+    if dtype == torch.float32:
+        kw = {k: v.astype(np.float32).astype(np.float64) for k, v in kw.items()}
+    ssm = mfa.StateSpaceModel(*(tt(kw[k], dtype) for k in ("mu0", "chol_p0", "a_s", "b_s", "chol_q")))
+    covs, sub = ssm.covariance_blocks()
+    ec, es = [], []
+    for s_ in range(bsz):
+        cov = kw["chol_p0"][s_] @ kw["chol_p0"][s_].T
+        cs, ss = [cov], []
+        for k in range(t - 1):
+            a, c = kw["a_s"][s_, k], kw["chol_q"][s_, k]
+            ss.append(a @ cov)
+            cov = a @ cov @ a.T + c @ c.T
+            cs.append(cov)
+        ec.append(np.stack(cs)); es.append(np.stack(ss))
+    tol = TOL[dtype]
+    np.testing.assert_allclose(nn(covs), np.stack(ec), **tol)
+    np.testing.assert_allclose(nn(sub), np.stack(es), **tol)
+    np.testing.assert_allclose(nn(ssm.marginal_covariances), np.stack(ec), **tol)
+    if dtype == torch.float64 and t <= 40:
+        ref = ssm.precision.cholesky.block_diagonal_of_inverse()
+        np.testing.assert_allclose(nn(ref), np.stack(ec), rtol=1e-7, atol=1e-9)
