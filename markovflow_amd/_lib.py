@@ -30,7 +30,7 @@ _SIGS = {
     "mf_ssm_precision": (_int, [_i64, _i64, _int, _int, "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", _int,
                                 "Tp", "Tp", "Tp", _vp]),
     "mf_ssm_marginal_means": (_int, [_i64, _i64, _i64, _int, "Tp", "Tp", "Tp", _vp, _sz, _vp]),
-    "mf_ssm_marginals": (_int, [_i64, _i64, _int] + ["Tp"] * 8 + [_vp]),
+    "mf_ssm_marginals": (_int, [_i64, _i64, _int] + ["Tp"] * 8 + [_vp, _sz, _vp]),
     "mf_block_matmul": (_int, [_i64, _i64, _int, "Tp", _i64, "Tp", _i64, "Tp", _vp]),
     "mf_gpr_matern_loglik": (_int, [_i64, _i64, _int, ctypes.POINTER(ctypes.c_int), "Tp", "Tp", _int, "Tp", "Tp", "Tp", "T", "T",
                                     "Tp", _vp, _sz, _vp, _i64, _vp, _vp, _vp]),

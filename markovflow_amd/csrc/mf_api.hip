@@ -224,13 +224,15 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (!A) return -5;                                                                                             \
         if (!cholQ) return -6;                                                                                         \
         if (!out_cov) return -7;                                                                                       \
-        if (big) return mf::big_marginal_covs_##SUF(B, Tn, d, cholP0, A, cholQ, out_cov, out_sub, ws, ws_bytes, S(stream)); \
+        if (big) return mf::big_marginal_covs_##SUF(B, Tn, d, nullptr, cholP0, A, nullptr, cholQ, nullptr, out_cov, out_sub, \
+                                                    ws, ws_bytes, S(stream));                                          \
         return t->ssm_marginal_covs(B, Tn, cholP0, A, cholQ, out_cov, out_sub, ws, ws_bytes, S(stream));               \
     }                                                                                                                  \
     int mf_ssm_marginals_##SUF(int64_t B, int64_t Tn, int d, const T* mu0, const T* cholP0, const T* A, const T* b,    \
-                               const T* cholQ, T* out_mean, T* out_cov, T* out_sub, void* stream) {                   \
+                               const T* cholQ, T* out_mean, T* out_cov, T* out_sub, void* ws, size_t ws_bytes,        \
+                               void* stream) {                                                                        \
         MF_HEAD(T, B, Tn, d)                                                                                           \
-        if (Tn < 2 || big) return -101;                                                                                \
+        if (Tn < 2) return -101;                                                                                       \
         if (!mu0) return -4;                                                                                           \
         if (!cholP0) return -5;                                                                                        \
         if (!A) return -6;                                                                                             \
@@ -238,6 +240,8 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (!cholQ) return -8;                                                                                         \
         if (!out_mean) return -9;                                                                                      \
         if (!out_cov) return -10;                                                                                      \
+        if (big) return mf::big_marginal_covs_##SUF(B, Tn, d, mu0, cholP0, A, b, cholQ, out_mean, out_cov, out_sub, ws, \
+                                                    ws_bytes, S(stream));                                              \
         return t->ssm_marginals(B, Tn, mu0, cholP0, A, b, cholQ, out_mean, out_cov, out_sub, S(stream));               \
     }                                                                                                                  \
     int mf_btd_udl_##SUF(int64_t B, int64_t Tn, int d, const T* diag, const T* sub, T* ut, T* chol_d, const T* eta,    \

@@ -59,9 +59,9 @@ int big_kf_loglik_f64(long B, long Tn, int d, int m, const double* mu0, const do
     int big_block_matmul_##SUF(long B, long n, int d, const T* X, long xs, const T* Y, long ys, T* out, hipStream_t st) {     \
         return NS::op_block_matmul(B, n, d, X, xs, Y, ys, out, st);                                                          \
     }                                                                                                                        \
-    int big_marginal_covs_##SUF(long B, long n, int d, const T* cholP0, const T* A, const T* cholQ, T* ocov, T* osub, void* ws, \
-                                size_t ws_bytes, hipStream_t st) {                                                           \
-        return NS::op_marginal_covs(B, n, d, cholP0, A, cholQ, ocov, osub, ws, ws_bytes, st);                                \
+    int big_marginal_covs_##SUF(long B, long n, int d, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ,  \
+                                T* omean, T* ocov, T* osub, void* ws, size_t ws_bytes, hipStream_t st) {                     \
+        return NS::op_marginal_covs(B, n, d, mu0, cholP0, A, b, cholQ, omean, ocov, osub, ws, ws_bytes, st);                 \
     }
 size_t big_marginal_covs_ws(long B, long n, int d, int elem_size) {
     return elem_size == 4 ? big::marginal_covs_ws(B, n, d) : bigd::marginal_covs_ws(B, n, d);

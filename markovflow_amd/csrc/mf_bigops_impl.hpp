@@ -312,15 +312,22 @@ __global__ void __launch_bounds__(64) bigop_block_matmul_kernel(long B, long n, 
 // chunk's map  S -> M S M^T + N  (M = product of the chunk's A, N = the recursion started from zero); pass 1 - one workgroup
 // per series walks the P chunk boundaries; pass 2 - workgroup (series, chunk) restarts from its boundary value and writes
 // every block (and A_k S_k = Cov(x_{k+1}, x_k)).  7 products per step on P chunks instead of 3 on one workgroup per series.
+struct BigMeanArgs {
+    const real *mu0, *b;      // [B, d], [B, n-1, d]; b == NULL: covariances only
+    real* out;                // [B, n, d] (emit pass)
+    real* wsv;                // [B, P, d]: chunk offsets v_c (pass 0)
+    real* start;              // [B, P, d]: means at the chunk boundaries (pass 1 -> 2)
+};
 template <int DP, bool EMIT>
 __global__ void __launch_bounds__(NTHR) bigop_cov_chunk_kernel(long B, long n, int d, long P, long L, const real* __restrict__ cholP0,
                                                               const real* __restrict__ A, const real* __restrict__ cholQ,
                                                               real* __restrict__ wsM, real* __restrict__ wsN,
                                                               const real* __restrict__ start, real* __restrict__ ocov,
-                                                              real* __restrict__ osub) {
+                                                              real* __restrict__ osub, BigMeanArgs mean) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const Smem<DP> sm{reinterpret_cast<real*>(smem_raw)};
     const long s = blockIdx.x / P, c = blockIdx.x % P;
+    real *mv = sm.vec(0), *mt = sm.vec(1);                        // the mean and its successor (marginal means ride along)
     const long nt = n - 1, dd = (long)d * d, k0 = c * L;
     long k1 = k0 + L;
     if (k1 > nt) k1 = nt;
@@ -336,17 +343,29 @@ __global__ void __launch_bounds__(NTHR) bigop_cov_chunk_kernel(long B, long n, i
         } else {
             load_tile<DP>(S, start + (s * P + c) * dd, nullptr, d, false, false);
         }
+        if (mean.out) {
+            load_vec_lds<DP>(mv, c == 0 ? mean.mu0 + s * d : mean.start + (s * P + c) * d, nullptr, d);
+            if (c == 0 && threadIdx.x < d) mean.out[(s * n) * d + threadIdx.x] = mean.mu0[s * d + threadIdx.x];
+        }
     } else {
         zero_tile<DP>(S);
         for (int e = threadIdx.x; e < DP * DP; e += NTHR) M[(e / DP) * Geo<DP>::LD + (e % DP)] = (e / DP == e % DP) ? 1.f : 0.f;
+        if (threadIdx.x < DP) mv[threadIdx.x] = 0.f;
     }
     __syncthreads();
     for (long k = k0; k < k1; ++k) {
         load_tile<DP>(At, A + (s * nt + k) * dd, nullptr, d, false, false);
         load_tile<DP>(Ct, cholQ + (s * nt + k) * dd, nullptr, d, true, false);
+        if (mean.b) load_vec_lds<DP>(mt, mean.b + (s * nt + k) * d, nullptr, d);
         __syncthreads();
         gemm<DP, 0, 0, 0, K_FULL, O_FULL>(At, S, T1, 1.f);                           // T1 = A S
-        __syncthreads();
+        if (mean.b) {
+            matvec<DP, 0>(At, mv, mt, 1.f, 1.f, sm.scratch());                       // b + A m (ends with a barrier)
+            real* t = mv; mv = mt; mt = t;
+            if (EMIT && threadIdx.x < d) mean.out[(s * n + k + 1) * d + threadIdx.x] = mv[threadIdx.x];
+        } else {
+            __syncthreads();
+        }
         if (EMIT && osub) store_tile<DP>(osub + (s * nt + k) * dd, T1, d);
         gemm<DP, 0, 1, 0, K_FULL, O_FULL>(T1, At, S, 1.f);                           // S = A S A^T
         gemm<DP, 0, 1, 1, K_A_LOWER, O_FULL>(Ct, Ct, S, 1.f);                        //   + C C^T (same output tiles per wave)
@@ -362,28 +381,38 @@ __global__ void __launch_bounds__(NTHR) bigop_cov_chunk_kernel(long B, long n, i
     if (!EMIT) {
         store_tile<DP>(wsM + (s * P + c) * dd, M, d);
         store_tile<DP>(wsN + (s * P + c) * dd, S, d);
+        if (mean.b && threadIdx.x < d) mean.wsv[(s * P + c) * d + threadIdx.x] = mv[threadIdx.x];
     }
 }
 // pass 1: start[c + 1] = M_c start[c] M_c^T + N_c along the chunk boundaries of one series
 template <int DP>
 __global__ void __launch_bounds__(NTHR) bigop_cov_boundary_kernel(long B, int d, long P, const real* __restrict__ cholP0,
                                                                  const real* __restrict__ wsM, const real* __restrict__ wsN,
-                                                                 real* __restrict__ start) {
+                                                                 real* __restrict__ start, BigMeanArgs mean) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const Smem<DP> sm{reinterpret_cast<real*>(smem_raw)};
     constexpr int LD = Geo<DP>::LD;
     const long s = blockIdx.x, dd = (long)d * d;
     real *Mt = sm.tile(0), *Nt = sm.tile(1), *S = sm.tile(2), *T1 = sm.tile(3);
+    real *mv = sm.vec(0), *mt = sm.vec(1);
     load_tile<DP>(Nt, cholP0 + s * dd, nullptr, d, true, false);
+    if (mean.b) load_vec_lds<DP>(mv, mean.mu0 + s * d, nullptr, d);
     __syncthreads();
     gemm<DP, 0, 1, 0, K_A_LOWER, O_FULL>(Nt, Nt, S, 1.f);
     __syncthreads();
     for (long c = 0; c + 1 < P; ++c) {
         load_tile<DP>(Mt, wsM + (s * P + c) * dd, nullptr, d, false, false);
         load_tile<DP>(Nt, wsN + (s * P + c) * dd, nullptr, d, false, false);
+        if (mean.b) load_vec_lds<DP>(mt, mean.wsv + (s * P + c) * d, nullptr, d);
         __syncthreads();
         gemm<DP, 0, 0, 0, K_FULL, O_FULL>(Mt, S, T1, 1.f);
-        __syncthreads();
+        if (mean.b) {
+            matvec<DP, 0>(Mt, mv, mt, 1.f, 1.f, sm.scratch());                       // v_c + M_c m
+            real* t = mv; mv = mt; mt = t;
+            if (threadIdx.x < d) mean.start[(s * P + c + 1) * d + threadIdx.x] = mv[threadIdx.x];
+        } else {
+            __syncthreads();
+        }
         gemm<DP, 0, 1, 0, K_FULL, O_FULL>(T1, Mt, S, 1.f);
         __syncthreads();
         for (int e = threadIdx.x; e < DP * DP; e += NTHR) S[(e / DP) * LD + (e % DP)] += Nt[(e / DP) * LD + (e % DP)];
@@ -472,10 +501,11 @@ inline long cov_chunks(long B, long n) {
 }
 inline size_t marginal_covs_ws(long B, long n, int d) {
     const long P = cov_chunks(B, n);
-    return P > 1 ? 3 * size_t(B) * P * d * d * sizeof(real) : 0;
+    return P > 1 ? (3 * size_t(B) * P * d * d + 2 * size_t(B) * P * d) * sizeof(real) : 0;
 }
-inline int op_marginal_covs(long B, long n, int d, const real* cholP0, const real* A, const real* cholQ, real* ocov, real* osub,
-                            void* ws, size_t ws_bytes, hipStream_t st) {
+// mu0, b, omean all NULL: covariances only
+inline int op_marginal_covs(long B, long n, int d, const real* mu0, const real* cholP0, const real* A, const real* b,
+                            const real* cholQ, real* omean, real* ocov, real* osub, void* ws, size_t ws_bytes, hipStream_t st) {
     long P = cov_chunks(B, n);
     if (P > 1 && (ws == nullptr || ws_bytes < marginal_covs_ws(B, n, d))) P = 1;
     const long L = (n - 1 + P - 1) / P;
@@ -483,6 +513,8 @@ inline int op_marginal_covs(long B, long n, int d, const real* cholP0, const rea
     real* wsM = static_cast<real*>(ws);
     real* wsN = P > 1 ? wsM + size_t(B) * P * d * d : nullptr;
     real* start = P > 1 ? wsN + size_t(B) * P * d * d : nullptr;
+    real* wsv = P > 1 ? start + size_t(B) * P * d * d : nullptr;
+    const BigMeanArgs mean{mu0, omean ? b : nullptr, omean, wsv, P > 1 ? wsv + size_t(B) * P * d : nullptr};
 #define MF_C(DP)                                                                                                       \
     { static const bool ok = big_attr(&bigop_cov_chunk_kernel<DP, false>, Smem<DP>::BYTES) &&                            \
                              big_attr(&bigop_cov_chunk_kernel<DP, true>, Smem<DP>::BYTES) &&                             \
@@ -491,13 +523,13 @@ inline int op_marginal_covs(long B, long n, int d, const real* cholP0, const rea
       if (P > 1) {                                                                                                     \
           hipLaunchKernelGGL((bigop_cov_chunk_kernel<DP, false>), dim3((unsigned)(B * P)), dim3(NTHR), Smem<DP>::BYTES, st, B, n, d, P, L, \
                              cholP0, A, cholQ, wsM, wsN, static_cast<const real*>(nullptr), static_cast<real*>(nullptr),  \
-                             static_cast<real*>(nullptr));                                                              \
+                             static_cast<real*>(nullptr), mean);                                                        \
           hipLaunchKernelGGL((bigop_cov_boundary_kernel<DP>), dim3((unsigned)B), dim3(NTHR), Smem<DP>::BYTES, st, B, d, P, cholP0, \
-                             static_cast<const real*>(wsM), static_cast<const real*>(wsN), start);                      \
+                             static_cast<const real*>(wsM), static_cast<const real*>(wsN), start, mean);                \
       }                                                                                                                \
       hipLaunchKernelGGL((bigop_cov_chunk_kernel<DP, true>), dim3((unsigned)(B * P)), dim3(NTHR), Smem<DP>::BYTES, st, B, n, d, P, L, \
                          cholP0, A, cholQ, static_cast<real*>(nullptr), static_cast<real*>(nullptr),                    \
-                         static_cast<const real*>(start), ocov, osub); }
+                         static_cast<const real*>(start), ocov, osub, mean); }
     MF_BIGOP_DISPATCH(MF_C)
 #undef MF_C
     return big_ok();

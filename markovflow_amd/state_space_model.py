@@ -177,13 +177,17 @@ class StateSpaceModel(GaussMarkovDistribution):
         d, n = self.state_dim, self.num_transitions + 1
         mu0, cp0, a_f, b_f, cq = self._flat_params()
         bsz = a_f.shape[0]
-        if bsz > 0 and n > 1 and d <= _lib.load().mf_max_state_dim():
+        lib = _lib.load()
+        d_max = lib.mf_max_state_dim_f32_loglik() if a_f.dtype == torch.float32 else lib.mf_max_state_dim_f64_loglik()
+        if bsz > 0 and n > 1 and d <= d_max:
             means = torch.empty((bsz, n, d), dtype=a_f.dtype, device=a_f.device)
             covs = torch.empty((bsz, n, d, d), dtype=a_f.dtype, device=a_f.device)
             sub = torch.empty_like(a_f) if want_sub else None
+            ws_bytes = int(lib.mf_btd_diag_of_inverse_workspace_bytes(bsz, n, d, a_f.element_size())) if d > lib.mf_max_state_dim() else 0
+            ws = _lib.workspace(ws_bytes, a_f.device)
             rc = _lib.call_rc("mf_ssm_marginals", a_f.dtype, bsz, n, d, _lib.ptr(mu0), _lib.ptr(cp0), _lib.ptr(a_f),
-                              _lib.ptr(b_f), _lib.ptr(cq), _lib.ptr(means), _lib.ptr(covs), _lib.ptr(sub),
-                              _lib.stream_ptr(a_f.device))
+                              _lib.ptr(b_f), _lib.ptr(cq), _lib.ptr(means), _lib.ptr(covs), _lib.ptr(sub), _lib.ptr(ws),
+                              ws_bytes, _lib.stream_ptr(a_f.device))
             if rc == 0:
                 batch = tuple(self.batch_shape)
                 return (means.reshape(batch + (n, d)), covs.reshape(batch + (n, d, d)),

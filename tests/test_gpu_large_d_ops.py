@@ -112,20 +112,28 @@ def test_large_d_marginal_covariances_partitioned_in_time(rng, dtype, d, bsz, t)
         kw = {k: v.astype(np.float32).astype(np.float64) for k, v in kw.items()}
     ssm = mfa.StateSpaceModel(*(tt(kw[k], dtype) for k in ("mu0", "chol_p0", "a_s", "b_s", "chol_q")))
     covs, sub = ssm.covariance_blocks()
-    ec, es = [], []
+    ec, es, em = [], [], []
     for s_ in range(bsz):
-        cov = kw["chol_p0"][s_] @ kw["chol_p0"][s_].T
-        cs, ss = [cov], []
+        mean, cov = kw["mu0"][s_], kw["chol_p0"][s_] @ kw["chol_p0"][s_].T
+        cs, ss, ms = [cov], [], [mean]
         for k in range(t - 1):
             a, c = kw["a_s"][s_, k], kw["chol_q"][s_, k]
             ss.append(a @ cov)
-            cov = a @ cov @ a.T + c @ c.T
-            cs.append(cov)
-        ec.append(np.stack(cs)); es.append(np.stack(ss))
+            mean, cov = a @ mean + kw["b_s"][s_, k], a @ cov @ a.T + c @ c.T
+            cs.append(cov); ms.append(mean)
+        ec.append(np.stack(cs)); es.append(np.stack(ss)); em.append(np.stack(ms))
     tol = TOL[dtype]
     np.testing.assert_allclose(nn(covs), np.stack(ec), **tol)
     np.testing.assert_allclose(nn(sub), np.stack(es), **tol)
     np.testing.assert_allclose(nn(ssm.marginal_covariances), np.stack(ec), **tol)
+    # `marginals`: the means ride along the same three passes
+    means, covs2, sub2 = ssm._moments(want_sub=True)
+    np.testing.assert_allclose(nn(means), np.stack(em), **tol)
+    np.testing.assert_allclose(nn(covs2), np.stack(ec), **tol)
+    np.testing.assert_allclose(nn(sub2), np.stack(es), **tol)
+    np.testing.assert_allclose(nn(ssm.marginal_means), np.stack(em), **tol)
+    m2, c2 = ssm.marginals
+    np.testing.assert_allclose(nn(m2), np.stack(em), **tol)
     if dtype == torch.float64 and t <= 40:
         ref = ssm.precision.cholesky.block_diagonal_of_inverse()
         np.testing.assert_allclose(nn(ref), np.stack(ec), rtol=1e-7, atol=1e-9)
