@@ -369,11 +369,11 @@ class StateSpaceModel(GaussMarkovDistribution):
 
     def _kl_divergence_operators(self, dist: GaussMarkovDistribution) -> torch.Tensor:
         """The reference's route (state_space_model.py:569-593) over the operator kernels."""
-        marginal_covs_1, subsequent_covs_1 = self.covariance_blocks()
+        means_1, marginal_covs_1, subsequent_covs_1 = self._moments(want_sub=True)
         precision_2 = dist.precision
         trace = torch.sum(precision_2.block_diagonal * marginal_covs_1, dim=(-3, -2, -1)) + 2.0 * torch.sum(
             precision_2.block_sub_diagonal * subsequent_covs_1, dim=(-3, -2, -1))
-        mean_diff = dist.marginal_means - self.marginal_means
+        mean_diff = dist.marginal_means - means_1
         # the reference forms |L2^T (mu2 - mu1)|^2 with the Cholesky factor of P2 (state_space_model.py:575-583); the same
         # number is (mu2 - mu1)^T P2 (mu2 - mu1): one symmetric block-tridiagonal product, no factorisation
         mahalanobis = torch.sum(mean_diff * precision_2.dense_mult(mean_diff), dim=(-2, -1))

@@ -25,3 +25,10 @@ def ref():
 t_ref = timeit(ref, 1)
 a, b = ssm.covariance_blocks(); c, e = ref()
 print(f"d=64 T=2048 B=8 f32 covariance_blocks: forward recursion (partitioned) {t_new:.2f} ms, reference route over the large-d operators {t_ref:.2f} ms; max rel diff {float((a-c).abs().max()/c.abs().max()):.2e}")
+H = torch.randn(B, T, 32, d, dtype=dt, device=dev, generator=g) / d ** 0.5
+kf = mfa.KalmanFilter(ssm, mfa.EmissionModel(H), torch.randn(B, T, 32, dtype=dt, device=dev, generator=g), 0.3 * torch.eye(32, dtype=dt, device=dev))
+t_post = timeit(lambda: kf.posterior_state_space_model(), 1)
+post = kf.posterior_state_space_model()
+t_kl = timeit(lambda: post.kl_divergence(ssm), 1)
+t_chol = timeit(lambda: ssm.precision.cholesky, 1)
+print(f"posterior_state_space_model {t_post:.1f} ms, kl_divergence(posterior || prior) {t_kl:.1f} ms, precision.cholesky {t_chol:.1f} ms, log_likelihood {timeit(lambda: kf.log_likelihood()):.2f} ms")
