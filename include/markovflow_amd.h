@@ -172,7 +172,8 @@ int mf_ssm_marginals_f32(int64_t B, int64_t T, int d, const float* mu0, const fl
  * m_post [B,T,d] = [mu0', b'_1...] and chol_dinv [B,T,d,d] = chol(Delta_k^-1) = [cholP0', cholQ'_1...].
  * chain_layout = 1 (needs eta; state dimension <= 9, else -101) writes the posterior chain the way StateSpaceModel takes it,
  * so that nothing has to be sliced, copied or negated afterwards: ut holds the posterior transitions A'_k = -(U_k^T), m_post
- * is [B*d values of mu0' | B*(T-1)*d values of b'] and chol_dinv [B*d*d values of cholP0' | B*(T-1)*d*d values of cholQ'].
+ * is [B*d values of mu0' | B*(T-1)*d values of b'] and chol_dinv [B*d*d values of cholP0' | B*(T-1)*d*d values of cholQ'];
+ * chol_d may be NULL in this mode (the chain does not contain it: one d x d block per step less to write).
  * Few series: Delta_k are the natural-order pivots of the block-REVERSED matrix, so the parallel-in-time Cholesky
  * hierarchy is reused with reversed indexing, and the posterior offsets are an affine scan (scratch from the caller,
  * mf_btd_udl_workspace_bytes; 0 / NULL = one lane per series).

@@ -272,7 +272,7 @@ class SymmetricBlockTriDiagonal(BlockTriDiagonal):
         """``chain=True`` (needs ``eta``): the outputs come in the layout of a posterior ``StateSpaceModel`` - returns
         ``(transitions = -Uᵀ, chol_d, (mu0', offsets'), (cholP0', cholQ'))`` with every tensor contiguous."""
         diag, sub = _flat(self._diag, 3), _flat(self._sub_diag, 3)
-        u_t, chol_d = torch.empty_like(sub), torch.empty_like(diag)
+        u_t, chol_d = torch.empty_like(sub), (None if chain else torch.empty_like(diag))   # the chain does not contain chol_D
         m_post = chol_dinv = eta_f = None
         if eta is not None:
             eta_f = _flat(eta, 2)
@@ -285,7 +285,8 @@ class SymmetricBlockTriDiagonal(BlockTriDiagonal):
                   _lib.ptr(sub), _lib.ptr(u_t), _lib.ptr(chol_d), _lib.ptr(eta_f), _lib.ptr(m_post),
                   _lib.ptr(chol_dinv), int(chain), _lib.ptr(ws), ws_bytes, info, _lib.stream_ptr(diag.device))
         _lib.raise_on_info(info, "SymmetricBlockTriDiagonal.upper_diagonal_lower", diag.device)
-        u_t, chol_d = u_t.reshape(self._sub_diag.shape), chol_d.reshape(self._diag.shape)
+        u_t = u_t.reshape(self._sub_diag.shape)
+        chol_d = None if chol_d is None else chol_d.reshape(self._diag.shape)
         if chain:
             bsz, n, d = diag.shape[0], self.outer_dim, self.inner_dim
             batch = tuple(self.batch_shape)

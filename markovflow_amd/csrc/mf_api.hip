@@ -250,7 +250,7 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         MF_HEAD(T, B, Tn, d)                                                                                           \
         if (!diag) return -4;                                                                                          \
         if (Tn > 1 && (!sub || !ut)) return -5;                                                                        \
-        if (!chol_d) return -7;                                                                                        \
+        if (!chol_d && !chain_layout) return -7;                                                                       \
         if (eta && (!m_post || !chol_dinv)) return -9;                                                                 \
         if (chain_layout && (!eta || Tn < 2)) return -11;                                                              \
         if (big && chain_layout) return -101;                                                                          \

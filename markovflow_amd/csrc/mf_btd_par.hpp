@@ -997,7 +997,11 @@ __global__ void __launch_bounds__(64) par_tak_emit_kernel(long B, long n, long l
 template <typename T, int D>
 __global__ void __launch_bounds__(64) par_udl_emit_kernel(long B, long n, long len, long P, const T* __restrict__ diag,
                                                           const T* __restrict__ sub, const T* __restrict__ up,
-                                                          T* __restrict__ ut, T* __restrict__ chol_d, int* info) {
+                                                          T* __restrict__ ut, T* __restrict__ chol_d,
+                                                          T* __restrict__ chol_dinv, int chain, int* info) {
+    // chain (posterior_state_space_model in StateSpaceModel's layout): ut receives the posterior transitions -U_k^T and
+    // chol_dinv the factors chol(Delta_k^-1) right here, where chol(Delta_k) is in registers - the offsets kernel
+    // (par_post_emit_kernel) then only runs the affine recursion; chol_d is optional in that mode
     const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= B * P) return;
     const long s = id / P, c = id % P;
@@ -1023,12 +1027,23 @@ __global__ void __launch_bounds__(64) par_udl_emit_kernel(long B, long n, long l
             trsm_left_lower<T, D, D>(Lp, Lpi, U);          // L^-1 S
             syrk_tn_lower<T, D, D>(U, Dl, T(-1));          // Delta_k = D_k - S^T Delta_{k+1}^-1 S
             trsm_left_lower_t<T, D, D>(Lp, Lpi, U);        // U_k^T = Delta_{k+1}^-1 S
+            if (chain) { MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) U[i][j] = -U[i][j]; }
             store_mat<T, D, D>(ut + (s * (n - 1) + k) * D * D, U);
         }
         chol_lower<T, D>(Dl, Lpi, la, bad);
         la.init();
         MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Lp[i][j] = Dl[i][j];
-        store_lower<T, D>(chol_d + (s * n + k) * D * D, Lp);
+        if (chol_d) store_lower<T, D>(chol_d + (s * n + k) * D * D, Lp);
+        if (chain) {
+            // chol(Delta_k^-1) = chol(L^-T L^-1), at its place in the chain: block 0 of all series first, then [B, n-1]
+            T Linv[D][D], Q[D][D], Qi[D];
+            tri_inv_lower<T, D>(Lp, Linv, la, bad);
+            trimulT_self_lower<T, D>(Linv, Q);
+            la.init();
+            chol_lower<T, D>(Q, Qi, la, bad);
+            la.init();
+            store_lower<T, D>(chol_dinv + (k == 0 ? s : B + s * (n - 1) + k - 1) * D * D, Q);
+        }
     }
     if (bad && info) raise_info(info);
 }
@@ -1036,7 +1051,8 @@ __global__ void __launch_bounds__(64) par_udl_emit_kernel(long B, long n, long l
 // posterior chain, backward affine recursion over positions:  x(p) = eta_k - U_k x(p-1),  U_k = (ut[k])^T, k = n-1-p
 template <typename T, int D>
 __global__ void __launch_bounds__(64) par_post_up0_kernel(long B, long n, long len, long P, const T* __restrict__ ut,
-                                                          const T* __restrict__ eta, T* __restrict__ oM, T* __restrict__ oc) {
+                                                          const T* __restrict__ eta, T* __restrict__ oM, T* __restrict__ oc,
+                                                          int neg) {      // neg: ut holds -U_k^T (chain layout)
     const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= B * P) return;
     const long s = id / P, c = id % P;
@@ -1052,6 +1068,7 @@ __global__ void __launch_bounds__(64) par_post_up0_kernel(long B, long n, long l
         if (p > 0) {
             T Ut[D][D], uq[D];
             load_mat<T, D, D>(ut + (s * (n - 1) + k) * D * D, Ut);
+            if (neg) { MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Ut[i][j] = -Ut[i][j]; }
             gemv_t<T, D, D>(Ut, q, uq);                    // U_k q
             MF_UNROLL for (int i = 0; i < D; ++i) q[i] = e[i] - uq[i];
             T nP[D][D];
@@ -1098,14 +1115,20 @@ __global__ void __launch_bounds__(64) par_post_emit_kernel(long B, long n, long 
             T Ut[D][D], ux[D];
             load_mat<T, D, D>(ut + (s * (n - 1) + k) * D * D, Ut);
             gemv_t<T, D, D>(Ut, xp, ux);
-            MF_UNROLL for (int i = 0; i < D; ++i) x[i] -= ux[i];
-            if (chain) {        // this kernel is the last reader of U_k^T: leave the posterior transition -U_k^T in its place
-                MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Ut[i][j] = -Ut[i][j];
-                store_mat<T, D, D>(ut + (s * (n - 1) + k) * D * D, Ut);
-            }
+            // chain: the emit kernel of the factorisation already left -U_k^T (the posterior transition) in ut
+            MF_UNROLL for (int i = 0; i < D; ++i) x[i] = chain ? x[i] + ux[i] : x[i] - ux[i];
         }
         MF_UNROLL for (int i = 0; i < D; ++i) xp[i] = x[i];
         const long ci = chain ? (k == 0 ? s : B + s * (n - 1) + k - 1) : s * n + k;
+        if (chain) {
+            // m_k = Delta_k^-1 x_k = C (C^T x) with C = chol(Delta_k^-1), written by the emit kernel of the factorisation
+            T C[D][D], u[D], mk[D];
+            load_lower<T, D>(chol_dinv + ci * D * D, C);
+            trimulT_lower_vec<T, D>(C, x, u);
+            trimul_lower_vec<T, D>(C, u, mk);
+            store_vec<T, D>(m_post + ci * D, mk);
+            continue;
+        }
         T Lp[D][D], Lpi[D], Linv[D][D], Q[D][D], Qi[D];
         load_lower<T, D>(chol_d + (s * n + k) * D * D, Lp);
         LogAcc<T> lb;

@@ -646,11 +646,11 @@ int btd_udl(long B, long n, const T* diag, const T* sub, T* ut, T* chol_d, const
     }
     const dim3 g0((unsigned)cdiv(B * pl.n[1], 64));
     hipLaunchKernelGGL((par_udl_emit_kernel<T, D>), g0, dim3(64), 0, st, B, n, len0, pl.n[1], diag, sub,
-                       static_cast<const T*>(arr[1].Pn), ut, chol_d, info);
+                       static_cast<const T*>(arr[1].Pn), ut, chol_d, chol_dinv, chain, info);
     if (eta) {
         // x_k = eta_k - U_k x_{k+1}: affine scan over the reversed positions, then the per-block finish
         hipLaunchKernelGGL((par_post_up0_kernel<T, D>), g0, dim3(64), 0, st, B, n, len0, pl.n[1], static_cast<const T*>(ut),
-                           eta, arr[1].M, arr[1].c);
+                           eta, arr[1].M, arr[1].c, chain);
         for (int l = 1; l < pl.levels; ++l) {
             const long P = pl.n[l + 1];
             hipLaunchKernelGGL((par_affine_up_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, B, pl.n[l],

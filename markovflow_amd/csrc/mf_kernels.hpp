@@ -638,7 +638,7 @@ __global__ void __launch_bounds__(64) btd_udl_kernel(long B, long n, const T* __
         la.init();
         chol_lower<T, D>(Dl, Lpi, la, bad);
         MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Lp[i][j] = Dl[i][j];
-        store_lower<T, D>(chol_d + (s * n + k) * D * D, Lp);
+        if (chol_d) store_lower<T, D>(chol_d + (s * n + k) * D * D, Lp);
         if (eta) {
             MF_UNROLL for (int i = 0; i < D; ++i) xp[i] = x[i];
             trsv_lower<T, D>(Lp, Lpi, x);
