@@ -150,13 +150,15 @@ int mf_ssm_marginal_covariances_f32(int64_t B, int64_t T, int d, const float* ch
 
 /*
  * GaussMarkovDistribution.marginals (+ StateSpaceModel.subsequent_covariances)  (gauss_markov.py:107-117,
- * state_space_model.py:232-262,326-341) in ONE sweep per series: mu_{k+1} = A_k mu_k + b_k rides along the covariance recursion of
- * mf_ssm_marginal_covariances, A is read once.  Only where one lane per series is the chosen decomposition (B >= 4096 or
- * T < 64); returns -101 otherwise (and for d > 9) - the caller then uses mf_ssm_marginal_means + mf_ssm_marginal_covariances,
- * which scan in time.  State dimension 10..64 (fp32) / 10..32 (fp64): always available - the means ride along the three passes
- * of the time-partitioned covariance recursion (workspace: mf_btd_diag_of_inverse_workspace_bytes; unused for d <= 9).
+ * state_space_model.py:232-262,326-341) with ONE kernel writing all three: mu_{k+1} = A_k mu_k + b_k rides along the covariance
+ * recursion of mf_ssm_marginal_covariances, A is read once.  Many series (B >= 4096) or a short chain (T < 64): one sweep per
+ * series, no workspace.  Few long chains: the up / down sweeps of the two scans in time, then one emit kernel that restarts both
+ * recursions at the chunk boundaries (workspace: mf_ssm_marginals_workspace_bytes; -101 without it - the caller then uses
+ * mf_ssm_marginal_means + mf_ssm_marginal_covariances).  State dimension 10..64 (fp32) / 10..32 (fp64): the means ride along
+ * the three passes of the time-partitioned covariance recursion (same workspace query).
  * mu0 [B,d], b [B,T-1,d]; out_mean [B,T,d], out_cov [B,T,d,d], out_sub [B,T-1,d,d] (nullable).
  */
+size_t mf_ssm_marginals_workspace_bytes(int64_t B, int64_t T, int d, int elem_size);
 int mf_ssm_marginals_f64(int64_t B, int64_t T, int d, const double* mu0, const double* cholP0, const double* A, const double* b,
                          const double* cholQ, double* out_mean, double* out_cov, double* out_sub, void* ws, size_t ws_bytes,
                          void* stream);

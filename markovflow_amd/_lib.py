@@ -55,6 +55,7 @@ _PLAIN = {
     "mf_btd_logdet_quad_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
     "mf_ssm_adjoint_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
     "mf_ssm_kl_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
+    "mf_ssm_marginals_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
     "mf_btd_cholesky_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
     "mf_btd_solve_workspace_bytes": (_sz, [_i64, _i64, _i64, _int, _int]),
     "mf_btd_diag_of_inverse_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),

@@ -242,7 +242,7 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (!out_cov) return -10;                                                                                      \
         if (big) return mf::big_marginal_covs_##SUF(B, Tn, d, mu0, cholP0, A, b, cholQ, out_mean, out_cov, out_sub, ws, \
                                                     ws_bytes, S(stream));                                              \
-        return t->ssm_marginals(B, Tn, mu0, cholP0, A, b, cholQ, out_mean, out_cov, out_sub, S(stream));               \
+        return t->ssm_marginals(B, Tn, mu0, cholP0, A, b, cholQ, out_mean, out_cov, out_sub, ws, ws_bytes, S(stream)); \
     }                                                                                                                  \
     int mf_btd_udl_##SUF(int64_t B, int64_t Tn, int d, const T* diag, const T* sub, T* ut, T* chol_d, const T* eta,    \
                          T* m_post, T* chol_dinv, int chain_layout, void* ws, size_t ws_bytes, int* info,              \
@@ -454,6 +454,15 @@ size_t mf_btd_udl_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {
     if (elem_size == 4) { const auto* t = table_for<float>(d); return t ? t->btd_udl_ws(B, T) : 0; }
     const auto* t = table_for<double>(d);
     return t ? t->btd_udl_ws(B, T) : 0;
+}
+
+size_t mf_ssm_marginals_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {
+    if (B < 1 || T < 1) return 0;
+    const bool big = d > mf::MF_MAX_D && d <= (elem_size == 4 ? mf::MF_MAX_D_BIG : mf::MF_MAX_D_BIG_F64);
+    if (big) return mf::big_marginal_covs_ws(B, T, d, elem_size);
+    if (elem_size == 4) { const auto* t = table_for<float>(d); return t ? t->marginals_ws(B, T) : 0; }
+    const auto* t = table_for<double>(d);
+    return t ? t->marginals_ws(B, T) : 0;
 }
 
 size_t mf_ssm_kl_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {

@@ -920,12 +920,13 @@ __global__ void __launch_bounds__(64) par_tak_down_kernel(long B, long n, long l
     }
 }
 
-// MEAN (SRC 1, ONE chunk per series): the marginal means mu_p = A_{p-1} mu_{p-1} + b_{p-1} ride along - `marginals` in one sweep that
-// reads A once (mf_ssm_marginals_*)
+// MEAN (SRC 1): the marginal means mu_p = A_{p-1} mu_{p-1} + b_{p-1} ride along - `marginals` in one sweep that reads A once
+// (mf_ssm_marginals_*).  One chunk per series, or - with the means at the chunk ends from the affine scan (`up`) - many.
 template <typename T> struct TakMean {
     const T* mu0;      // [B, D]
     const T* b;        // [B, n-1, D]
     T* out;            // [B, n, D]
+    const T* up;       // [B, P, D]: mean at the last position of every chunk (P > 1), else NULL
 };
 template <typename T, int D, int SRC, bool MEAN = false>
 __global__ void __launch_bounds__(64) par_tak_emit_kernel(long B, long n, long len, long P, TakSrc<T> src,
@@ -949,6 +950,9 @@ __global__ void __launch_bounds__(64) par_tak_emit_kernel(long B, long n, long l
     T Sig[D][D];                                     // lower triangle
     MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Sig[i][j] = T(0);
     if (c > 0) load_lower<T, D>(up + (s * P + c - 1) * D * D, Sig);
+    if constexpr (MEAN) {
+        if (c > 0) load_vec<T, D>(mean.up + (s * P + c - 1) * D, mu);
+    }
     for (long p = p0; p < p1; ++p) {
         const long k = SRC == 1 ? p : n - 1 - p;
         if (PF) load(p + 1 < p1 ? p + 1 : p, nxt);

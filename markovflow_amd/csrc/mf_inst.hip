@@ -509,9 +509,11 @@ template <typename T> size_t btd_diag_of_inverse_ws(long B, long n) {
 // Congruence scan Sigma(p) = N_p + G_p^T Sigma(p-1) G_p over the positions of every series (mf_btd_par.hpp: TakSrc):
 // SRC 0 = block Takahashi on a Cholesky factor, SRC 1 = marginal covariances of a state space model.
 template <typename T, int SRC>
-int tak_scan(long B, long n, TakSrc<T> src, T* odiag, T* osub, void* ws, size_t ws_bytes, hipStream_t st) {
+int tak_scan(long B, long n, TakSrc<T> src, T* odiag, T* osub, void* ws, size_t ws_bytes, hipStream_t st,
+             const T** up_only = nullptr) {      // up_only: stop before the emit kernel and hand out the chunk-start values
     const long len0 = par_len0(B, n);
     if (len0 == 0 || ws == nullptr || ws_bytes < btd_diag_of_inverse_ws<T>(B, n)) {
+        if (up_only) return -16;
         // one lane per series: the level-0 emit kernel as ONE chunk (prefetched loads)
         hipLaunchKernelGGL((par_tak_emit_kernel<T, D, SRC>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, n, 1L, src,
                            static_cast<const T*>(nullptr), odiag, osub);
@@ -556,6 +558,7 @@ int tak_scan(long B, long n, TakSrc<T> src, T* odiag, T* osub, void* ws, size_t 
                            pl.len[l], P, static_cast<const T*>(arr[l].G), static_cast<const T*>(arr[l].N),
                            static_cast<const T*>(arr[l + 1].Z), arr[l].Z);
     }
+    if (up_only) { *up_only = arr[1].Z; return hipGetLastError() == hipSuccess ? 0 : -1000; }
     hipLaunchKernelGGL((par_tak_emit_kernel<T, D, SRC>), dim3((unsigned)cdiv(B * pl.n[1], 64)), dim3(64), 0, st, B, n, len0,
                        pl.n[1], src, static_cast<const T*>(arr[1].Z), odiag, osub);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
@@ -577,17 +580,6 @@ template <typename T>
 int ssm_marginal_covs(long B, long n, const T* cholP0, const T* A, const T* cholQ, T* ocov, T* osub, void* ws, size_t ws_bytes,
                       hipStream_t st) {
     return tak_scan<T, 1>(B, n, TakSrc<T>{cholQ, A, cholP0}, ocov, osub, ws, ws_bytes, st);
-}
-
-// `marginals` (means + covariances [+ Cov(x_{k+1}, x_k)]) in ONE sweep per series; only where one lane per series is the
-// chosen decomposition anyway (many series or a short chain) - otherwise -101 and the caller runs the two scans in time
-template <typename T>
-int ssm_marginals(long B, long n, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, T* omean, T* ocov,
-                  T* osub, hipStream_t st) {
-    if (n < 2 || par_len0(B, n) != 0) return -101;
-    hipLaunchKernelGGL((par_tak_emit_kernel<T, D, 1, true>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, n, 1L,
-                       TakSrc<T>{cholQ, A, cholP0}, static_cast<const T*>(nullptr), ocov, osub, TakMean<T>{mu0, b, omean});
-    return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
 template <typename T> size_t btd_udl_ws(long B, long n) {
@@ -687,10 +679,12 @@ int ssm_precision(long B, long Tn, int m, const T* mu0, const T* cholP0, const T
 }
 
 template <typename T, bool REV = false>
-int ssm_means(long Bl, long Br, long Tn, const T* A, const T* offs, T* out, void* ws, size_t ws_bytes, hipStream_t st) {
+int ssm_means(long Bl, long Br, long Tn, const T* A, const T* offs, T* out, void* ws, size_t ws_bytes, hipStream_t st,
+              const T** up_only = nullptr) {      // up_only: stop before the emit kernel and hand out the chunk-end means
     const long n = Tn;
     const long len0 = par_len0(Br, n);
     if (len0 == 0 || ws == nullptr || ws_bytes < btd_solve_ws<T>(Bl, Br, n)) {
+        if (up_only) return -16;
         if ((A && n >= 2) || REV)   // one lane per series: the level-0 emit kernel as ONE chunk (loads a group of steps ahead)
             hipLaunchKernelGGL((par_means_emit_kernel<T, D, REV>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Bl, Br, n, n, 1L, A,
                                offs, static_cast<const T*>(nullptr), out);
@@ -728,8 +722,50 @@ int ssm_means(long Bl, long Br, long Tn, const T* A, const T* offs, T* out, void
                            pl.len[l], P, static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c),
                            static_cast<const T*>(arr[l + 1].Z), arr[l].Z);
     }
+    if (up_only) { *up_only = arr[1].Z; return hipGetLastError() == hipSuccess ? 0 : -1000; }
     hipLaunchKernelGGL((par_means_emit_kernel<T, D, REV>), dim3((unsigned)cdiv(Br * pl.n[1], 64)), dim3(64), 0, st, Bl, Br, n,
                        len0, pl.n[1], A, offs, static_cast<const T*>(arr[1].Z), out);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+template <typename T>
+int ssm_means_entry(long Bl, long Br, long Tn, const T* A, const T* offs, T* out, void* ws, size_t ws_bytes, hipStream_t st) {
+    return ssm_means<T, false>(Bl, Br, Tn, A, offs, out, ws, ws_bytes, st);
+}
+
+// `marginals` (means + covariances [+ Cov(x_{k+1}, x_k)]) in ONE sweep per series; only where one lane per series is the
+// chosen decomposition anyway (many series or a short chain) - otherwise -101 and the caller runs the two scans in time
+// With few series both recursions are scans in time whose up / down sweeps stay separate (congruence and affine maps), but ONE
+// emit kernel restarts both from the chunk boundaries (workspace: marginals_ws; -101 without it: the caller's two scans).
+template <typename T> size_t marginals_ws(long B, long n) {
+    if (n < 2 || par_len0(B, n) == 0) return 0;
+    return align_up(size_t(B) * n * D * sizeof(T)) + align_up(btd_diag_of_inverse_ws<T>(B, n)) + btd_solve_ws<T>(B, B, n);
+}
+template <typename T>
+int ssm_marginals(long B, long n, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, T* omean, T* ocov,
+                  T* osub, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (n < 2) return -101;
+    const TakSrc<T> src{cholQ, A, cholP0};
+    const long len0 = par_len0(B, n);
+    if (len0 == 0) {
+        hipLaunchKernelGGL((par_tak_emit_kernel<T, D, 1, true>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, n, 1L, src,
+                           static_cast<const T*>(nullptr), ocov, osub, TakMean<T>{mu0, b, omean, nullptr});
+        return hipGetLastError() == hipSuccess ? 0 : -1000;
+    }
+    if (ws == nullptr || ws_bytes < marginals_ws<T>(B, n)) return -101;
+    char* p = static_cast<char*>(ws);
+    T* offs = reinterpret_cast<T*>(p); p += align_up(size_t(B) * n * D * sizeof(T));
+    char* ws_cov = p; p += align_up(btd_diag_of_inverse_ws<T>(B, n));
+    char* ws_mean = p;
+    const T *up_cov = nullptr, *up_mean = nullptr;
+    int rc = tak_scan<T, 1>(B, n, src, ocov, osub, ws_cov, btd_diag_of_inverse_ws<T>(B, n), st, &up_cov);
+    if (rc != 0) return rc;
+    hipLaunchKernelGGL((concat_offsets_kernel<T, D>), dim3((unsigned)cdiv(B * n * D, 256)), dim3(256), 0, st, B, n, mu0, b, offs);
+    rc = ssm_means<T, false>(B, B, n, A, static_cast<const T*>(offs), omean, ws_mean, btd_solve_ws<T>(B, B, n), st, &up_mean);
+    if (rc != 0) return rc;
+    const long P = par_plan(n, len0).n[1];
+    hipLaunchKernelGGL((par_tak_emit_kernel<T, D, 1, true>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, B, n, len0, P, src,
+                       up_cov, ocov, osub, TakMean<T>{mu0, b, omean, up_mean});
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
@@ -863,8 +899,8 @@ int posterior_chain(long B, long Tn, int m, const T* mu0, const T* cholP0, const
 // kl_divergence with few series: workspace of the route over q1's marginals (0: one lane per series is the route)
 template <typename T> size_t kl_ws(long B, long Tn) {
     if (Tn < 2 || par_len0(B, Tn) == 0) return 0;
-    return align_up(size_t(B) * Tn * D * D * sizeof(T)) + 2 * align_up(size_t(B) * Tn * D * sizeof(T)) +
-           align_up(size_t(B) * Tn * sizeof(T)) + adjoint_scan_ws<T>(B, Tn);
+    return align_up(size_t(B) * Tn * D * D * sizeof(T)) + align_up(size_t(B) * Tn * D * sizeof(T)) +
+           align_up(size_t(B) * Tn * sizeof(T)) + marginals_ws<T>(B, Tn);
 }
 
 template <typename T>
@@ -877,16 +913,10 @@ int kl_value(long B, long Tn, const T* mu0_1, const T* C0_1, const T* A_1, const
         char* p = static_cast<char*>(ws);
         T* pS = reinterpret_cast<T*>(p); p += align_up(size_t(B) * Tn * D * D * sizeof(T));
         T* pm = reinterpret_cast<T*>(p); p += align_up(size_t(B) * Tn * D * sizeof(T));
-        T* offs = reinterpret_cast<T*>(p); p += align_up(size_t(B) * Tn * D * sizeof(T));
         T* part = reinterpret_cast<T*>(p); p += align_up(size_t(B) * Tn * sizeof(T));
-        const size_t scratch = adjoint_scan_ws<T>(B, Tn);
         if (out_covs) pS = out_covs;
         if (out_means) pm = out_means;
-        int rc = tak_scan<T, 1>(B, Tn, TakSrc<T>{C_1, A_1, C0_1}, pS, out_cross, p, scratch, st);
-        if (rc != 0) return rc;
-        hipLaunchKernelGGL((concat_offsets_kernel<T, D>), dim3((unsigned)cdiv(B * Tn * D, 256)), dim3(256), 0, st, B, Tn, mu0_1,
-                           b_1, offs);
-        rc = ssm_means<T, false>(B, B, Tn, A_1, static_cast<const T*>(offs), pm, p, scratch, st);
+        const int rc = ssm_marginals<T>(B, Tn, mu0_1, C0_1, A_1, b_1, C_1, pm, pS, out_cross, p, marginals_ws<T>(B, Tn), st);
         if (rc != 0) return rc;
         hipLaunchKernelGGL((ssm_kl_local_kernel<T, D>), dim3((unsigned)cdiv(B * Tn, 64)), dim3(64), 0, st, B, Tn, mu0_1, C0_1,
                            A_1, b_1, C_1, mu0_2, C0_2, A_2, b_2, C_2, static_cast<const T*>(pm), static_cast<const T*>(pS),
@@ -922,7 +952,7 @@ template <typename T> const OpsTable<T>* table() {
     static const OpsTable<T> t = {
         &kf_loglik_ws<T>, &kf_loglik<T>, &btd_logdet_quad_ws<T>, &btd_logdet_quad<T>, &btd_cholesky_ws<T>, &btd_cholesky<T>,
         &btd_solve_ws<T>, &btd_solve<T>,    &btd_matvec<T>, &btd_logdet<T>,        &btd_diag_of_inverse_ws<T>, &btd_diag_of_inverse<T>, &ssm_marginal_covs<T>, &btd_udl_ws<T>, &btd_udl<T>,
-        &ssm_precision<T>, &ssm_means<T, false>, &block_matmul<T>, &gpr_loglik<T>, &sde_predict<T>, &kf_grad<T>, &kl_grad<T>, &posterior_chain<T>, &kl_value<T>, &marginals_grad<T>, &adjoint_ws<T>, &ssm_marginals<T>, &kl_ws<T>,
+        &ssm_precision<T>, &ssm_means_entry<T>, &block_matmul<T>, &gpr_loglik<T>, &sde_predict<T>, &kf_grad<T>, &kl_grad<T>, &posterior_chain<T>, &kl_value<T>, &marginals_grad<T>, &adjoint_ws<T>, &ssm_marginals<T>, &kl_ws<T>, &marginals_ws<T>,
     };
     return &t;
 }

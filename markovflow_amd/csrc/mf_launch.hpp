@@ -62,8 +62,9 @@ template <typename T> struct OpsTable {
                           const T* gS, T* gmu0, T* gC0, T* gA, T* gb, T* gC, void* ws, size_t ws_bytes, hipStream_t st);
     size_t (*adjoint_ws)(long B, long Tn);
     int (*ssm_marginals)(long B, long n, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, T* omean,
-                         T* ocov, T* osub, hipStream_t st);
+                         T* ocov, T* osub, void* ws, size_t ws_bytes, hipStream_t st);
     size_t (*kl_ws)(long B, long Tn);
+    size_t (*marginals_ws)(long B, long n);
 };
 
 constexpr int MF_MAX_D = 9;        // largest state dimension with a register-resident instantiation

@@ -183,7 +183,7 @@ class StateSpaceModel(GaussMarkovDistribution):
             means = torch.empty((bsz, n, d), dtype=a_f.dtype, device=a_f.device)
             covs = torch.empty((bsz, n, d, d), dtype=a_f.dtype, device=a_f.device)
             sub = torch.empty_like(a_f) if want_sub else None
-            ws_bytes = int(lib.mf_btd_diag_of_inverse_workspace_bytes(bsz, n, d, a_f.element_size())) if d > lib.mf_max_state_dim() else 0
+            ws_bytes = int(lib.mf_ssm_marginals_workspace_bytes(bsz, n, d, a_f.element_size()))
             ws = _lib.workspace(ws_bytes, a_f.device)
             rc = _lib.call_rc("mf_ssm_marginals", a_f.dtype, bsz, n, d, _lib.ptr(mu0), _lib.ptr(cp0), _lib.ptr(a_f),
                               _lib.ptr(b_f), _lib.ptr(cq), _lib.ptr(means), _lib.ptr(covs), _lib.ptr(sub), _lib.ptr(ws),

@@ -269,10 +269,11 @@ def test_state_space_model_vs_dense_joint():
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
-@pytest.mark.parametrize("d,t,bsz", [(1, 2, 1), (4, 10, 3), (9, 33, 2), (6, 100, 2), (9, 70, 1), (3, 12, 4100)])
+@pytest.mark.parametrize("d,t,bsz", [(1, 2, 1), (4, 10, 3), (9, 33, 2), (6, 100, 2), (9, 70, 1), (3, 12, 4100), (7, 333, 3), (2, 1000, 1), (5, 64, 7)])
 def test_marginals_in_one_sweep_match_the_explicit_recursion(rng, dtype, d, t, bsz):
     """gauss_markov.py:107-117 / state_space_model.py:232-262,326-341: means, covariances and Cov(x_{k+1}, x_k).  Short chains
-    and batches of >= 4096 series take ONE sweep per series (mf_ssm_marginals), the others the two scans in time."""
+    and batches of >= 4096 series take ONE sweep per series (mf_ssm_marginals); few long chains the up / down sweeps of the two
+    scans in time and ONE emit kernel for both recursions."""
     kw = random_ssm(rng, (bsz,), t, d, 1, well=True)
     ssm = mfa.StateSpaceModel(*(tt(kw[k], dtype) for k in ("mu0", "chol_p0", "a_s", "b_s", "chol_q")))
     means, covs, sub = ssm._moments(want_sub=True)
