@@ -324,19 +324,21 @@ int mf_kf_loglik_grad_f32(int64_t B, int64_t T, int d, int m, const float* mu0, 
  * csrc/mf_kl_grad.hpp.  ws: mf_ssm_adjoint_workspace_bytes.
  * means_1 [B,T,d], covs_1 [B,T,d,d]: marginals of q1 (mf_ssm_marginal_means / mf_ssm_marginal_covariances).  Outputs per series:
  * g_mu0 [B,d], g_cholP0 [B,d,d] (lower), g_A [B,T-1,d,d], g_b [B,T-1,d], g_cholQ [B,T-1,d,d] (lower), scaled by weights [B]
- * (nullable).  The gradient with respect to q2 is MINUS mf_kf_loglik_grad with H = NULL, q2's parameters and q1's moments.
+ * (nullable).  adj_N [B,T,d,d], adj_n [B,T,d] (both or neither): the inputs of the recursion when the forward kept them
+ * (mf_ssm_kl_divergence: out_N, out_n); NULL: they are formed here.
+ * The gradient with respect to q2 is MINUS mf_kf_loglik_grad with H = NULL, q2's parameters and q1's moments.
  * State dimension 1..9.
  */
 int mf_ssm_kl_grad_f64(int64_t B, int64_t T, int d, const double* mu0_1, const double* cholP0_1, const double* A_1,
                        const double* b_1, const double* cholQ_1, const double* mu0_2, const double* cholP0_2, const double* A_2,
                        const double* b_2, const double* cholQ_2, const double* means_1, const double* covs_1,
-                       const double* weights, double* g_mu0, double* g_cholP0, double* g_A, double* g_b, double* g_cholQ,
-                       void* ws, size_t ws_bytes, int* info, void* stream);
+                       const double* weights, const double* adj_N, const double* adj_n, double* g_mu0, double* g_cholP0,
+                       double* g_A, double* g_b, double* g_cholQ, void* ws, size_t ws_bytes, int* info, void* stream);
 int mf_ssm_kl_grad_f32(int64_t B, int64_t T, int d, const float* mu0_1, const float* cholP0_1, const float* A_1,
                        const float* b_1, const float* cholQ_1, const float* mu0_2, const float* cholP0_2, const float* A_2,
                        const float* b_2, const float* cholQ_2, const float* means_1, const float* covs_1, const float* weights,
-                       float* g_mu0, float* g_cholP0, float* g_A, float* g_b, float* g_cholQ, void* ws, size_t ws_bytes,
-                       int* info, void* stream);
+                       const float* adj_N, const float* adj_n, float* g_mu0, float* g_cholP0, float* g_A, float* g_b,
+                       float* g_cholQ, void* ws, size_t ws_bytes, int* info, void* stream);
 
 /*
  * KalmanFilter._r_inv (markovflow/kalman_filter.py:341-348): R^-1 = (L L^T)^-1 from the Cholesky factor L [m,m] of the shared
@@ -372,17 +374,20 @@ int mf_kf_posterior_chain_f32(int64_t B, int64_t T, int d, int m, const float* m
  * from the scans in time and the same local terms are formed by one lane per (series, step) and summed per series; on that
  * route the marginals of q1 can be kept: out_means [B,T,d], out_covs [B,T,d,d], out_cross [B,T-1,d,d] = Cov(x_{k+1}, x_k) (each
  * nullable) - exactly what mf_ssm_kl_grad / mf_kf_loglik_grad need.  Asking for them on the lane-per-series route is error -15.
+ * out_N [B,T,d,d], out_n [B,T,d] (both or neither; either route): N_k = dA_k^T Q2_k^-1 dA_k, n_k = dA_k^T Q2_k^-1 eps_k, the
+ * inputs of the adjoint recursion of mf_ssm_kl_grad - by-products of the forward sweep that save the backward a kernel.
  * State dimension 1..9.
  */
 size_t mf_ssm_kl_workspace_bytes(int64_t B, int64_t T, int d, int elem_size);
 int mf_ssm_kl_divergence_f64(int64_t B, int64_t T, int d, const double* mu0_1, const double* cholP0_1, const double* A_1,
                              const double* b_1, const double* cholQ_1, const double* mu0_2, const double* cholP0_2,
                              const double* A_2, const double* b_2, const double* cholQ_2, double* out, double* out_means,
-                             double* out_covs, double* out_cross, void* ws, size_t ws_bytes, int* info, void* stream);
+                             double* out_covs, double* out_cross, double* out_N, double* out_n, void* ws, size_t ws_bytes,
+                             int* info, void* stream);
 int mf_ssm_kl_divergence_f32(int64_t B, int64_t T, int d, const float* mu0_1, const float* cholP0_1, const float* A_1,
                              const float* b_1, const float* cholQ_1, const float* mu0_2, const float* cholP0_2, const float* A_2,
                              const float* b_2, const float* cholQ_2, float* out, float* out_means, float* out_covs,
-                             float* out_cross, void* ws, size_t ws_bytes, int* info, void* stream);
+                             float* out_cross, float* out_N, float* out_n, void* ws, size_t ws_bytes, int* info, void* stream);
 
 /*
  * Adjoint of the marginal recursion  m_{k+1} = A_k m_k + b_k,  S_{k+1} = A_k S_k A_k^T + Q_k  (markovflow/state_space_model.py:232-262,

@@ -36,10 +36,10 @@ _SIGS = {
                                     "Tp", _vp, _sz, _vp, _i64, _vp, _vp, _vp]),
     "mf_kf_loglik_total": (_int, [_i64, "Tp", _int, "Tp", _i64, "Tp", "T", "Tp", _vp]),
     "mf_kf_loglik_grad": (_int, [_i64, _i64, _int, _int] + ["Tp"] * 8 + [_int] + ["Tp"] * 12 + [_vp, _vp]),
-    "mf_ssm_kl_grad": (_int, [_i64, _i64, _int] + ["Tp"] * 18 + [_vp, _sz, _vp, _vp]),
+    "mf_ssm_kl_grad": (_int, [_i64, _i64, _int] + ["Tp"] * 20 + [_vp, _sz, _vp, _vp]),
     "mf_obs_precision_from_chol": (_int, [_int, "Tp", "Tp", _vp, _vp]),
     "mf_kf_posterior_chain": (_int, [_i64, _i64, _int, _int] + ["Tp"] * 8 + [_int] + ["Tp"] * 5 + [_vp, _vp]),
-    "mf_ssm_kl_divergence": (_int, [_i64, _i64, _int] + ["Tp"] * 14 + [_vp, _sz, _vp, _vp]),
+    "mf_ssm_kl_divergence": (_int, [_i64, _i64, _int] + ["Tp"] * 16 + [_vp, _sz, _vp, _vp]),
     "mf_ssm_marginals_grad": (_int, [_i64, _i64, _int] + ["Tp"] * 12 + [_vp, _sz, _vp]),
     "mf_sde_conditional_predict": (_int, [_i64, _i64, _i64, _int, _vp, "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", "Tp",
                                           "Tp", "Tp", _vp, _vp]),

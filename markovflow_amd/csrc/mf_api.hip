@@ -367,16 +367,17 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
     int mf_ssm_kl_grad_##SUF(int64_t B, int64_t Tn, int d, const T* mu0_1, const T* cholP0_1, const T* A_1,            \
                              const T* b_1, const T* cholQ_1, const T* mu0_2, const T* cholP0_2, const T* A_2,          \
                              const T* b_2, const T* cholQ_2, const T* means_1, const T* covs_1, const T* weights,      \
-                             T* g_mu0, T* g_cholP0, T* g_A, T* g_b, T* g_cholQ, void* ws, size_t ws_bytes, int* info,  \
-                             void* stream) {                                                                           \
+                             const T* adj_N, const T* adj_n, T* g_mu0, T* g_cholP0, T* g_A, T* g_b, T* g_cholQ,        \
+                             void* ws, size_t ws_bytes, int* info, void* stream) {                                     \
         MF_HEAD(T, B, Tn, d)                                                                                           \
         if (big) return -100;                                                                                          \
         if (!mu0_1 || !cholP0_1 || (Tn > 1 && (!A_1 || !b_1 || !cholQ_1))) return -4;                                  \
         if (!mu0_2 || !cholP0_2 || (Tn > 1 && (!A_2 || !b_2 || !cholQ_2))) return -9;                                  \
         if (!means_1 || !covs_1) return -14;                                                                           \
-        if (!g_mu0 || !g_cholP0 || (Tn > 1 && (!g_A || !g_b || !g_cholQ))) return -17;                                 \
+        if (!g_mu0 || !g_cholP0 || (Tn > 1 && (!g_A || !g_b || !g_cholQ))) return -19;                                 \
         return t->kl_grad(B, Tn, mu0_1, cholP0_1, A_1, b_1, cholQ_1, mu0_2, cholP0_2, A_2, b_2, cholQ_2, means_1,      \
-                          covs_1, weights, g_mu0, g_cholP0, g_A, g_b, g_cholQ, ws, ws_bytes, info, S(stream));         \
+                          covs_1, weights, adj_N, adj_n, g_mu0, g_cholP0, g_A, g_b, g_cholQ, ws, ws_bytes, info,       \
+                          S(stream));                                                                                  \
     }                                                                                                                  \
     int mf_kf_posterior_chain_##SUF(int64_t B, int64_t Tn, int d, int m, const T* mu0, const T* cholP0, const T* A,    \
                                     const T* b, const T* cholQ, const T* H, const T* y, const T* Rinv,                 \
@@ -394,14 +395,15 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
     int mf_ssm_kl_divergence_##SUF(int64_t B, int64_t Tn, int d, const T* mu0_1, const T* cholP0_1, const T* A_1,      \
                                    const T* b_1, const T* cholQ_1, const T* mu0_2, const T* cholP0_2, const T* A_2,    \
                                    const T* b_2, const T* cholQ_2, T* out, T* out_means, T* out_covs,          \
-                                   T* out_cross, void* ws, size_t ws_bytes, int* info, void* stream) {                 \
+                                   T* out_cross, T* out_N, T* out_n, void* ws, size_t ws_bytes, int* info,             \
+                                   void* stream) {                                                                     \
         MF_HEAD(T, B, Tn, d)                                                                                           \
         if (big) return -100;                                                                                          \
         if (!mu0_1 || !cholP0_1 || (Tn > 1 && (!A_1 || !b_1 || !cholQ_1))) return -4;                                  \
         if (!mu0_2 || !cholP0_2 || (Tn > 1 && (!A_2 || !b_2 || !cholQ_2))) return -9;                                  \
         if (!out) return -14;                                                                                          \
         return t->kl(B, Tn, mu0_1, cholP0_1, A_1, b_1, cholQ_1, mu0_2, cholP0_2, A_2, b_2, cholQ_2, out, out_means,    \
-                     out_covs, out_cross, ws, ws_bytes, info, S(stream));                                              \
+                     out_covs, out_cross, out_N, out_n, ws, ws_bytes, info, S(stream));                                \
     }                                                                                                                  \
     int mf_ssm_marginals_grad_##SUF(int64_t B, int64_t Tn, int d, const T* cholP0, const T* A, const T* cholQ,         \
                                     const T* means, const T* covs, const T* g_means, const T* g_covs, T* g_mu0,        \

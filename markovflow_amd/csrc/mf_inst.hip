@@ -872,12 +872,19 @@ int adjoint_scan(long B, long Tn, const T* A, const AdjointWs<T, D>& w, void* ws
 
 template <typename T>
 int kl_grad(long B, long Tn, const T* mu0_1, const T* C0_1, const T* A_1, const T* b_1, const T* C_1, const T* mu0_2,
-            const T* C0_2, const T* A_2, const T* b_2, const T* C_2, const T* pm, const T* pS, const T* weights, T* gmu0,
-            T* gC0, T* gA, T* gb, T* gC, void* ws, size_t ws_bytes, int* info, hipStream_t st) {
-    if (ws == nullptr || ws_bytes < adjoint_ws<T>(B, Tn)) return -21;
-    const AdjointWs<T, D> w = carve_adjoint<T>(ws, B, Tn);
+            const T* C0_2, const T* A_2, const T* b_2, const T* C_2, const T* pm, const T* pS, const T* weights,
+            const T* in_N, const T* in_n, T* gmu0, T* gC0, T* gA, T* gb, T* gC, void* ws, size_t ws_bytes, int* info,
+            hipStream_t st) {
+    if (ws == nullptr || ws_bytes < adjoint_ws<T>(B, Tn)) return -23;
+    if ((in_N == nullptr) != (in_n == nullptr)) return -17;
+    AdjointWs<T, D> w = carve_adjoint<T>(ws, B, Tn);
     const dim3 per_step((unsigned)cdiv(B * Tn, 64)), per_series((unsigned)cdiv(B, 64)), block(64);
-    hipLaunchKernelGGL((ssm_kl_adjoint_inputs_kernel<T, D>), per_step, block, 0, st, B, Tn, A_1, b_1, A_2, b_2, C_2, pm, w, info);
+    if (in_N) {       // the forward sweep kept the inputs of the recursion (mf_ssm_kl_divergence: out_N, out_n); only read here
+        w.N = const_cast<T*>(in_N);
+        w.n = const_cast<T*>(in_n);
+    } else {
+        hipLaunchKernelGGL((ssm_kl_adjoint_inputs_kernel<T, D>), per_step, block, 0, st, B, Tn, A_1, b_1, A_2, b_2, C_2, pm, w, info);
+    }
     if (int rc = adjoint_scan<T>(B, Tn, A_1, w, ws, st)) return rc;
     AdjointLocalArgs<T, D> a{B, Tn, mu0_1, C0_1, A_1, b_1, C_1, mu0_2, C0_2, A_2, b_2, C_2, pm, pS, weights, gmu0, gC0, gA, gb, gC, info};
     hipLaunchKernelGGL((ssm_adjoint_local_kernel<T, D, true>), per_step, block, 0, st, a, w);
@@ -906,7 +913,8 @@ template <typename T> size_t kl_ws(long B, long Tn) {
 template <typename T>
 int kl_value(long B, long Tn, const T* mu0_1, const T* C0_1, const T* A_1, const T* b_1, const T* C_1, const T* mu0_2,
              const T* C0_2, const T* A_2, const T* b_2, const T* C_2, T* out, T* out_means, T* out_covs, T* out_cross,
-             void* ws, size_t ws_bytes, int* info, hipStream_t st) {
+             T* out_N, T* out_n, void* ws, size_t ws_bytes, int* info, hipStream_t st) {
+    if ((out_N == nullptr) != (out_n == nullptr)) return -18;
     const size_t need = kl_ws<T>(B, Tn);
     if (need != 0 && ws != nullptr && ws_bytes >= need) {
         // few series: q1's marginals by the scans in time, then every term is local (mf_kl_grad.hpp)
@@ -920,13 +928,13 @@ int kl_value(long B, long Tn, const T* mu0_1, const T* C0_1, const T* A_1, const
         if (rc != 0) return rc;
         hipLaunchKernelGGL((ssm_kl_local_kernel<T, D>), dim3((unsigned)cdiv(B * Tn, 64)), dim3(64), 0, st, B, Tn, mu0_1, C0_1,
                            A_1, b_1, C_1, mu0_2, C0_2, A_2, b_2, C_2, static_cast<const T*>(pm), static_cast<const T*>(pS),
-                           part, info);
+                           part, out_N, out_n, info);
         hipLaunchKernelGGL((row_sum_kernel<T>), dim3((unsigned)B), dim3(64), 0, st, Tn, static_cast<const T*>(part), out);
         return hipGetLastError() == hipSuccess ? 0 : -1000;
     }
     if (out_means || out_covs || out_cross) return -15;      // the moments exist on the route above only
     hipLaunchKernelGGL((ssm_kl_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, Tn, mu0_1, C0_1, A_1, b_1, C_1,
-                       mu0_2, C0_2, A_2, b_2, C_2, out, info);
+                       mu0_2, C0_2, A_2, b_2, C_2, out, out_N, out_n, info);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 

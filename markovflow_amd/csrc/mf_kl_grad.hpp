@@ -21,6 +21,27 @@
 
 namespace mf {
 
+// N = W^T W (symmetric, stored full), n = W^T u  with  W = C2^-1 dA,  u = C2^-1 eps: the adjoint recursion's inputs of a step
+template <typename T, int D> MF_DEV void kl_store_adjoint_inputs(const T (&W)[D][D], const T (&u)[D], T* __restrict__ Nout,
+                                                                T* __restrict__ nout) {
+    MF_UNROLL for (int j = 0; j < D; ++j) {
+        T acc = T(0);
+        MF_UNROLL for (int i = 0; i < D; ++i) acc += W[i][j] * u[i];
+        nout[j] = acc;
+    }
+    MF_UNROLL for (int i = 0; i < D; ++i)
+        MF_UNROLL for (int j = 0; j <= i; ++j) {
+            T acc = T(0);
+            MF_UNROLL for (int l = 0; l < D; ++l) acc += W[l][i] * W[l][j];
+            Nout[i * D + j] = acc;
+            Nout[j * D + i] = acc;
+        }
+}
+template <typename T, int D> MF_DEV void kl_zero_adjoint_inputs(T* __restrict__ Nout, T* __restrict__ nout) {
+    MF_UNROLL for (int e = 0; e < D * D; ++e) Nout[e] = T(0);
+    MF_UNROLL for (int e = 0; e < D; ++e) nout[e] = T(0);
+}
+
 // ---- the divergence itself, fused ----------------------------------------------------------------------------------------
 // The same local form gives KL(q1 || q2) in ONE forward sweep per series that carries q1's marginal (m_k, S_k) in registers:
 //   KL = 1/2 [ |C0_2^-1 C0_1|_F^2 + |C0_2^-1 d0|^2 ] + sum_k 1/2 [ |C2_k^-1 C1_k|_F^2 + tr(W_k S_k W_k^T) + |C2_k^-1 eps_k|^2 ]
@@ -34,7 +55,9 @@ __global__ void __launch_bounds__(64) ssm_kl_kernel(long B, long Tn, const T* __
                                                     const T* __restrict__ C_1, const T* __restrict__ mu0_2,
                                                     const T* __restrict__ C0_2, const T* __restrict__ A_2,
                                                     const T* __restrict__ b_2, const T* __restrict__ C_2, T* __restrict__ out,
-                                                    int* info) {
+                                                    T* __restrict__ oN, T* __restrict__ on, int* info) {
+    // oN [B,T,D,D], on [B,T,D] (nullable): N_k = W_k^T W_k, n_k = W_k^T C2_k^-1 eps_k - the inputs of the adjoint recursion of the
+    // backward (mf_ssm_kl_grad), which are by-products of this sweep
     const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= B) return;
     LogAcc<T> l1, l2;
@@ -100,6 +123,7 @@ __global__ void __launch_bounds__(64) ssm_kl_kernel(long B, long Tn, const T* __
         trimul_lower_vec<T, D>(C2i, eps, u);
         acc += chol_terms(C2i, C1) + dot_self<T, D>(u);
         trimul_lower_inplace<T, D, D>(C2i, W);                                            // W = C2^-1 dA
+        if (oN) kl_store_adjoint_inputs<T, D>(W, u, oN + (s * Tn + k) * D * D, on + (s * Tn + k) * D);
         // tr(W S W^T) = sum_ij (W S)_ij W_ij with S symmetric (held in its lower triangle)
         MF_UNROLL for (int i = 0; i < D; ++i) {
             T row[D];
@@ -127,6 +151,7 @@ __global__ void __launch_bounds__(64) ssm_kl_kernel(long B, long Tn, const T* __
         l2.renorm();
     }
     out[s] = T(0.5) * (acc - T(Tn) * T(D)) + l2.value() - l1.value();
+    if (oN) kl_zero_adjoint_inputs<T, D>(oN + (s * Tn + Tn - 1) * D * D, on + (s * Tn + Tn - 1) * D);
     if (bad && info) raise_info(info);
 }
 
@@ -141,7 +166,8 @@ __global__ void __launch_bounds__(64) ssm_kl_local_kernel(long B, long Tn, const
                                                           const T* __restrict__ C0_2, const T* __restrict__ A_2,
                                                           const T* __restrict__ b_2, const T* __restrict__ C_2,
                                                           const T* __restrict__ pm, const T* __restrict__ pS,
-                                                          T* __restrict__ part, int* info) {
+                                                          T* __restrict__ part, T* __restrict__ oN, T* __restrict__ on,
+                                                          int* info) {
     const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= B * Tn) return;
     const long s = id / Tn, k = id % Tn;
@@ -196,6 +222,7 @@ __global__ void __launch_bounds__(64) ssm_kl_local_kernel(long B, long Tn, const
         trimul_lower_vec<T, D>(C2i, eps, u);
         acc += chol_terms(C2i, C1) + dot_self<T, D>(u);
         trimul_lower_inplace<T, D, D>(C2i, W);                                            // W = C2^-1 dA
+        if (oN) kl_store_adjoint_inputs<T, D>(W, u, oN + id * D * D, on + id * D);
         T S[D][D];
         load_lower<T, D>(pS + id * D * D, S);
         MF_UNROLL for (int i = 0; i < D; ++i) {
@@ -207,6 +234,7 @@ __global__ void __launch_bounds__(64) ssm_kl_local_kernel(long B, long Tn, const
         }
     }
     part[id] = T(0.5) * (acc - T(D)) + l2.value() - l1.value();
+    if (oN && k + 1 >= Tn) kl_zero_adjoint_inputs<T, D>(oN + id * D * D, on + id * D);
     if (bad && info) raise_info(info);
 }
 

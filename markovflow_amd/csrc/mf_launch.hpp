@@ -51,13 +51,14 @@ template <typename T> struct OpsTable {
                    T* gH, T* gy, T* gOm, const T* weights, int rinv_per_step, int* info, hipStream_t st);
     int (*kl_grad)(long B, long Tn, const T* mu0_1, const T* C0_1, const T* A_1, const T* b_1, const T* C_1, const T* mu0_2,
                    const T* C0_2, const T* A_2, const T* b_2, const T* C_2, const T* pm, const T* pS, const T* weights,
-                   T* gmu0, T* gC0, T* gA, T* gb, T* gC, void* ws, size_t ws_bytes, int* info, hipStream_t st);
+                   const T* in_N, const T* in_n, T* gmu0, T* gC0, T* gA, T* gb, T* gC, void* ws, size_t ws_bytes, int* info,
+                   hipStream_t st);
     int (*posterior_chain)(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ,
                            const T* H, const T* y, const T* Rinv, int rinv_per_step, T* a_post, T* mu0_post, T* b_post,
                            T* cp0_post, T* cq_post, int* info, hipStream_t st);
     int (*kl)(long B, long Tn, const T* mu0_1, const T* C0_1, const T* A_1, const T* b_1, const T* C_1, const T* mu0_2,
-              const T* C0_2, const T* A_2, const T* b_2, const T* C_2, T* out, T* out_means, T* out_covs, T* out_cross, void* ws,
-              size_t ws_bytes, int* info, hipStream_t st);
+              const T* C0_2, const T* A_2, const T* b_2, const T* C_2, T* out, T* out_means, T* out_covs, T* out_cross,
+              T* out_N, T* out_n, void* ws, size_t ws_bytes, int* info, hipStream_t st);
     int (*marginals_grad)(long B, long Tn, const T* C0, const T* A, const T* C, const T* pm, const T* pS, const T* gm,
                           const T* gS, T* gmu0, T* gC0, T* gA, T* gb, T* gC, void* ws, size_t ws_bytes, hipStream_t st);
     size_t (*adjoint_ws)(long B, long Tn);

@@ -342,8 +342,9 @@ class StateSpaceModel(GaussMarkovDistribution):
 
     def _kl_divergence_value(self, dist: GaussMarkovDistribution, keep_moments: bool = False):
         """The divergence from its local form (``mf_ssm_kl_divergence_*``): one sweep per series when the batch fills the chip,
-        else the marginals of ``self`` by the scans in time + one lane per (series, step).  ``keep_moments``: also return
-        ``(means, covs, cross)`` of ``self`` when that second route computed them (else ``None``) - the backward needs them.
+        else the marginals of ``self`` by the scans in time + one lane per (series, step).  ``keep_moments`` (the forward of
+        ``_KLDivergence``): also return what the backward can reuse - ``(means, covs, cross)`` of ``self`` when that second
+        route computed them (else ``None``) and the inputs ``(N, n)`` of the adjoint recursion, by-products of either route.
         Other distributions and state dimensions beyond the register kernels take the reference's operator route."""
         bsz = int(math.prod(self.batch_shape))
         n, d = self.num_transitions + 1, self.state_dim
@@ -352,20 +353,23 @@ class StateSpaceModel(GaussMarkovDistribution):
             out = torch.empty(bsz, dtype=dtype, device=dev)
             ws_bytes = int(_lib.load().mf_ssm_kl_workspace_bytes(bsz, n, d, out.element_size()))
             ws = _lib.workspace(ws_bytes, dev)
-            moments = None
+            moments = adjoint_inputs = None
             if keep_moments and ws_bytes > 0:
                 moments = (torch.empty((bsz, n, d), dtype=dtype, device=dev), torch.empty((bsz, n, d, d), dtype=dtype, device=dev),
                            torch.empty((bsz, n - 1, d, d), dtype=dtype, device=dev))
+            if keep_moments:
+                adjoint_inputs = (torch.empty((bsz, n, d, d), dtype=dtype, device=dev), torch.empty((bsz, n, d), dtype=dtype, device=dev))
             info = _lib.pivot_info(dev)
             _lib.call("mf_ssm_kl_divergence", dtype, bsz, n, d, *[_lib.ptr(t) for t in self._flat_params()],
                       *[_lib.ptr(t) for t in dist._flat_params()], _lib.ptr(out),
-                      *([_lib.ptr(t) for t in moments] if moments else [None, None, None]), _lib.ptr(ws), ws_bytes, info,
+                      *([_lib.ptr(t) for t in moments] if moments else [None, None, None]),
+                      *([_lib.ptr(t) for t in adjoint_inputs] if adjoint_inputs else [None, None]), _lib.ptr(ws), ws_bytes, info,
                       _lib.stream_ptr(dev))
             _lib.raise_on_info(info, "StateSpaceModel.kl_divergence", dev)
             out = out.reshape(tuple(self.batch_shape))
-            return (out, moments) if keep_moments else out
+            return (out, moments, adjoint_inputs) if keep_moments else out
         out = self._kl_divergence_operators(dist)
-        return (out, None) if keep_moments else out
+        return (out, None, None) if keep_moments else out
 
     def _kl_divergence_operators(self, dist: GaussMarkovDistribution) -> torch.Tensor:
         """The reference's route (state_space_model.py:569-593) over the operator kernels."""
@@ -406,8 +410,9 @@ class _KLDivergence(torch.autograd.Function):
     def forward(ctx, *tensors):
         with torch.no_grad():
             q1, q2 = StateSpaceModel(*tensors[:5]), StateSpaceModel(*tensors[5:])
-            out, moments = q1._kl_divergence_value(q2, keep_moments=True)
-        ctx.save_for_backward(*tensors, *(moments or ()))
+            out, moments, adjoint_inputs = q1._kl_divergence_value(q2, keep_moments=True)
+        ctx.has_moments, ctx.has_adjoint_inputs = moments is not None, adjoint_inputs is not None
+        ctx.save_for_backward(*tensors, *(moments or ()), *(adjoint_inputs or ()))
         return out
 
     @staticmethod
@@ -415,10 +420,13 @@ class _KLDivergence(torch.autograd.Function):
         tensors = ctx.saved_tensors
         mu1, c01, a1, b1, c1, mu2, c02, a2, b2, c2 = tensors[:10]
         with torch.no_grad():
-            if len(tensors) > 10:         # few series: the forward's scans already produced q1's moments
-                means, covs, cross = tensors[10:]
+            extra = list(tensors[10:])
+            if ctx.has_moments:           # few series: the forward's scans already produced q1's moments
+                means, covs, cross = extra[:3]
+                extra = extra[3:]
             else:
                 means, covs, cross = StateSpaceModel(mu1, c01, a1, b1, c1)._moments(want_sub=True)
+            adj_n_mat, adj_n_vec = extra if ctx.has_adjoint_inputs else (None, None)   # inputs of the adjoint recursion
             bsz, d = mu1.shape
             n = a1.shape[1] + 1
             dev, dtype = mu1.device, mu1.dtype
@@ -429,8 +437,8 @@ class _KLDivergence(torch.autograd.Function):
             ws_bytes = int(_lib.load().mf_ssm_adjoint_workspace_bytes(bsz, n, d, mu1.element_size()))
             ws = _lib.workspace(ws_bytes, dev)
             _lib.call("mf_ssm_kl_grad", dtype, bsz, n, d, c(mu1), c(c01), c(a1), c(b1), c(c1), c(mu2), c(c02), c(a2), c(b2),
-                      c(c2), c(means), c(covs), _lib.ptr(w), *[_lib.ptr(g) for g in g1], _lib.ptr(ws), ws_bytes, info,
-                      _lib.stream_ptr(dev))
+                      c(c2), c(means), c(covs), _lib.ptr(w), _lib.ptr(adj_n_mat), _lib.ptr(adj_n_vec),
+                      *[_lib.ptr(g) for g in g1], _lib.ptr(ws), ws_bytes, info, _lib.stream_ptr(dev))
             g2 = [torch.empty_like(t) for t in (mu2, c02, a2, b2, c2)]
             neg_w = (-w).contiguous()
             _lib.call("mf_kf_loglik_grad", dtype, bsz, n, d, 1, c(mu2), c(c02), c(a2), c(b2), c(c2), None, None, None, 0,

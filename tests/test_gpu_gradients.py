@@ -418,7 +418,22 @@ def test_kl_routes_agree_with_the_oracle(rng, d, t, bsz):
     ref = O.ssm_kl_divergence(tuple(kw1[k] for k in CHAIN), tuple(kw2[k] for k in CHAIN))
     q1 = mfa.StateSpaceModel(*(tt(kw1[k]) for k in CHAIN))
     q2 = mfa.StateSpaceModel(*(tt(kw2[k]) for k in CHAIN))
-    value, moments = q1._kl_divergence_value(q2, keep_moments=True)
+    value, moments, adjoint_inputs = q1._kl_divergence_value(q2, keep_moments=True)
+    # the inputs of the backward's recursion, by-products of either forward route: N_k = dA^T Q2^-1 dA, n_k = dA^T Q2^-1 eps_k
+    means_ref = q1._moments(want_sub=False)[0].cpu().numpy()
+    for s_ in range(bsz):
+        for k in (0, t // 2, t - 2, t - 1):
+            if k < 0:
+                continue
+            if k == t - 1:
+                want_n_mat, want_n_vec = np.zeros((d, d)), np.zeros(d)
+            else:
+                da = kw1["a_s"][s_, k] - kw2["a_s"][s_, k]
+                q2i = np.linalg.inv(kw2["chol_q"][s_, k] @ kw2["chol_q"][s_, k].T)
+                eps = da @ means_ref[s_, k] + kw1["b_s"][s_, k] - kw2["b_s"][s_, k]
+                want_n_mat, want_n_vec = da.T @ q2i @ da, da.T @ q2i @ eps
+            np.testing.assert_allclose(adjoint_inputs[0][s_, k].cpu().numpy(), want_n_mat, rtol=1e-8, atol=1e-10)
+            np.testing.assert_allclose(adjoint_inputs[1][s_, k].cpu().numpy(), want_n_vec, rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(value.cpu().numpy(), ref, rtol=1e-9)
     ws_bytes = int(_lib.load().mf_ssm_kl_workspace_bytes(bsz, t, d, 8))
     assert (ws_bytes > 0) == (t >= 64) and (moments is not None) == (t >= 64)
@@ -430,7 +445,7 @@ def test_kl_routes_agree_with_the_oracle(rng, d, t, bsz):
     out = torch.empty(bsz, dtype=torch.float64, device=DEV)
     info = _lib.pivot_info(out.device)
     _lib.call("mf_ssm_kl_divergence", out.dtype, bsz, t, d, *[_lib.ptr(x) for x in q1._flat_params()],
-              *[_lib.ptr(x) for x in q2._flat_params()], _lib.ptr(out), None, None, None, None, 0, info,
+              *[_lib.ptr(x) for x in q2._flat_params()], _lib.ptr(out), None, None, None, None, None, None, 0, info,
               _lib.stream_ptr(out.device))
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-9)
     np.testing.assert_allclose(q1._kl_divergence_operators(q2).cpu().numpy(), ref, rtol=1e-9)
