@@ -267,14 +267,18 @@ class StateSpaceModel(GaussMarkovDistribution):
     def create_trainable_copy(self) -> "StateSpaceModel":
         """Copy with leaf parameters that require grad (state_space_model.py:396-429).
 
-        The reference wraps the Choleskys in a FillTriangular bijector; here the lower-triangular
-        structure is kept by construction (``tril`` of a leaf tensor).
+        The reference wraps the Choleskys in a FillTriangular bijector, evaluated on every access.  Here the chain holds the
+        leaves themselves - an optimiser's in-place update is what the next evaluation reads - and the Cholesky leaves are
+        lower-triangular matrices that stay so: a gradient hook keeps the lower triangle of whatever gradient reaches them.
         """
         def leaf(t):
             return t.detach().clone().requires_grad_(True)
 
-        leaves = (leaf(self._mu_0), leaf(self._chol_P_0), leaf(self._A_s), leaf(self._b_s), leaf(self._chol_Q_s))
-        ssm = StateSpaceModel(leaves[0], torch.tril(leaves[1]), leaves[2], leaves[3], torch.tril(leaves[4]))
+        leaves = (leaf(self._mu_0), leaf(torch.tril(self._chol_P_0)), leaf(self._A_s), leaf(self._b_s),
+                  leaf(torch.tril(self._chol_Q_s)))
+        leaves[1].register_hook(torch.tril)
+        leaves[4].register_hook(torch.tril)
+        ssm = StateSpaceModel(*leaves)
         ssm._trainable = leaves
         check_compatible(ssm, self)
         return ssm

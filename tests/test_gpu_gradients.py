@@ -449,3 +449,27 @@ def test_kl_routes_agree_with_the_oracle(rng, d, t, bsz):
               _lib.stream_ptr(out.device))
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-9)
     np.testing.assert_allclose(q1._kl_divergence_operators(q2).cpu().numpy(), ref, rtol=1e-9)
+
+
+def test_trainable_copy_follows_optimiser_steps(rng):
+    """The reference's trainable copy re-evaluates its bijectors on every access (state_space_model.py:396-429): after an
+    optimiser step the chain must see the NEW parameters, and its Cholesky factors must stay lower triangular."""
+    kw = random_ssm(rng, (3,), 20, 4, 1, well=True)
+    prior = mfa.StateSpaceModel(*(tt(kw[k]) for k in CHAIN))
+    kw2 = random_ssm(rng, (3,), 20, 4, 1, well=True)
+    q = mfa.StateSpaceModel(*(tt(kw2[k]) for k in CHAIN)).create_trainable_copy()
+    opt = torch.optim.SGD(q.trainable_variables, lr=1e-2)
+    values = []
+    for _ in range(3):
+        opt.zero_grad()
+        kl = q.kl_divergence(prior).sum()
+        kl.backward()
+        values.append(float(kl.detach()))
+        opt.step()
+    assert values[0] > values[1] > values[2]                       # gradient steps on the leaves reach the next evaluation
+    leaves = q.trainable_variables
+    assert torch.equal(q.cholesky_process_covariances.detach(), leaves[4].detach())
+    assert float(torch.triu(leaves[4].detach(), diagonal=1).abs().max()) == 0.0
+    assert float(torch.triu(leaves[1].detach(), diagonal=1).abs().max()) == 0.0
+    fresh = mfa.StateSpaceModel(*(t.detach() for t in leaves)).kl_divergence(prior).sum()
+    assert float(q.kl_divergence(prior).sum().detach()) == pytest.approx(float(fresh), rel=1e-12)
