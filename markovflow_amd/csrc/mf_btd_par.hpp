@@ -752,9 +752,32 @@ MF_DEV void tak_terms(const T (&L)[D][D], const T (&W)[D][D], bool has_g, T (&N)
     }
 }
 
-template <typename T, int D, int SRC>
+// MEAN (SRC 1): the level-0 up-sweep of the marginal MEANS rides along (the chunk's affine map x -> M x + q: M is the transpose
+// of the composed G, q needs one matrix-vector product per step with the transition that is loaded anyway) - outputs in the
+// layout of par_means_up0_kernel, so that the affine levels above run unchanged
+template <typename T> struct TakMeanUp {
+    const T* mu0;      // [B, D]
+    const T* b;        // [B, n-1, D]
+    T* oM;             // [B, P, D, D]
+    T* oc;             // [B, P, D]
+};
+template <typename T, int D, bool MEAN>
+MF_DEV void tak_mean_step(const TakMeanUp<T>& m, long s, long n, long p, const T (&G)[D][D], T (&q)[MEAN ? D : 1]) {
+    if constexpr (MEAN) {
+        T o[D];
+        load_vec<T, D>(p > 0 ? m.b + (s * (n - 1) + p - 1) * D : m.mu0 + s * D, o);
+        if (p > 0) {
+            T nq[D];
+            gemv_t<T, D, D>(G, q, nq);                       // A q with G = A^T
+            MF_UNROLL for (int i = 0; i < D; ++i) q[i] = nq[i] + o[i];
+        } else {
+            MF_UNROLL for (int i = 0; i < D; ++i) q[i] = o[i];
+        }
+    }
+}
+template <typename T, int D, int SRC, bool MEAN = false>
 __global__ void __launch_bounds__(64) par_tak_up0_kernel(long B, long n, long len, long P, TakSrc<T> src, T* __restrict__ oG,
-                                                         T* __restrict__ oN) {
+                                                         T* __restrict__ oN, TakMeanUp<T> mup = TakMeanUp<T>{}) {
     const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= B * P) return;
     const long s = id / P, c = id % P;
@@ -762,6 +785,8 @@ __global__ void __launch_bounds__(64) par_tak_up0_kernel(long B, long n, long le
     long p1 = p0 + len;
     if (p1 > n) p1 = n;
     T Gc[D][D], Nc[D][D];
+    T q[MEAN ? D : 1];
+    MF_UNROLL for (int i = 0; i < (MEAN ? D : 1); ++i) q[i] = T(0);
     for (long p = p0; p < p1; ++p) {
         T N[D][D], G[D][D];
         {
@@ -769,6 +794,7 @@ __global__ void __launch_bounds__(64) par_tak_up0_kernel(long B, long n, long le
             tak_load<T, D, SRC>(src, s, n, p, L, W);
             tak_terms<T, D, SRC>(L, W, p > 0, N, G);
         }
+        tak_mean_step<T, D, MEAN>(mup, s, n, p, G, q);
         if (p == p0) {
             MF_UNROLL for (int i = 0; i < D; ++i)
                 MF_UNROLL for (int j = 0; j < D; ++j) { Nc[i][j] = (i >= j) ? N[i][j] : N[j][i]; Gc[i][j] = (p > 0) ? G[i][j] : T(0); }
@@ -786,6 +812,12 @@ __global__ void __launch_bounds__(64) par_tak_up0_kernel(long B, long n, long le
     }
     store_mat<T, D, D>(oG + id * D * D, Gc);
     store_mat<T, D, D>(oN + id * D * D, Nc);
+    if constexpr (MEAN) {
+        T Mt[D][D];
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Mt[i][j] = Gc[j][i];
+        store_mat<T, D, D>(mup.oM + id * D * D, Mt);
+        store_vec<T, D>(mup.oc + id * D, q);
+    }
 }
 
 template <typename T, int D>
@@ -818,9 +850,9 @@ __global__ void __launch_bounds__(64) par_tak_up_kernel(long B, long n, long len
 }
 
 // The two up-sweeps with the composed G of the run in LDS and Nc as a lower triangle (d >= 7 in fp64, see mf_kf_x.hpp)
-template <typename T, int D, int SRC>
+template <typename T, int D, int SRC, bool MEAN = false>
 __global__ void __launch_bounds__(64) par_tak_up0_x_kernel(long B, long n, long len, long P, TakSrc<T> src, T* __restrict__ oG,
-                                                           T* __restrict__ oN) {
+                                                           T* __restrict__ oN, TakMeanUp<T> mup = TakMeanUp<T>{}) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* gc = reinterpret_cast<T*>(smem_raw) + threadIdx.x;
     const long total = B * P;
@@ -834,6 +866,8 @@ __global__ void __launch_bounds__(64) par_tak_up0_x_kernel(long B, long n, long 
     if (!valid) p1 = p0;
     T Nc[D][D];
     MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Nc[i][j] = T(0);
+    T q[MEAN ? D : 1];
+    MF_UNROLL for (int i = 0; i < (MEAN ? D : 1); ++i) q[i] = T(0);
     for (long p = p0; p < p1; ++p) {
         T N[D][D], G[D][D];
         {
@@ -841,6 +875,7 @@ __global__ void __launch_bounds__(64) par_tak_up0_x_kernel(long B, long n, long 
             tak_load<T, D, SRC>(src, s, n, p, L, W);
             tak_terms<T, D, SRC>(L, W, p > 0, N, G);
         }
+        tak_mean_step<T, D, MEAN>(mup, s, n, p, G, q);
         if (p == p0) {
             MF_UNROLL for (int i = 0; i < D; ++i)
                 MF_UNROLL for (int j = 0; j < D; ++j) {
@@ -856,6 +891,11 @@ __global__ void __launch_bounds__(64) par_tak_up0_x_kernel(long B, long n, long 
         store_sym<T, D>(oN + id * D * D, Nc);
         T* g = oG + id * D * D;
         MF_UNROLL for (int e = 0; e < D * D; ++e) g[e] = gc[e * 64];
+        if constexpr (MEAN) {
+            T* mt = mup.oM + id * D * D;
+            MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) mt[i * D + j] = gc[(j * D + i) * 64];
+            store_vec<T, D>(mup.oc + id * D, q);
+        }
     }
 }
 

@@ -510,7 +510,8 @@ template <typename T> size_t btd_diag_of_inverse_ws(long B, long n) {
 // SRC 0 = block Takahashi on a Cholesky factor, SRC 1 = marginal covariances of a state space model.
 template <typename T, int SRC>
 int tak_scan(long B, long n, TakSrc<T> src, T* odiag, T* osub, void* ws, size_t ws_bytes, hipStream_t st,
-             const T** up_only = nullptr) {      // up_only: stop before the emit kernel and hand out the chunk-start values
+             const T** up_only = nullptr,        // up_only: stop before the emit kernel and hand out the chunk-start values
+             TakMeanUp<T> mup = TakMeanUp<T>{}) {  // mup.oc != NULL (SRC 1): the level-0 up-sweep of the means rides along
     const long len0 = par_len0(B, n);
     if (len0 == 0 || ws == nullptr || ws_bytes < btd_diag_of_inverse_ws<T>(B, n)) {
         if (up_only) return -16;
@@ -529,12 +530,19 @@ int tak_scan(long B, long n, TakSrc<T> src, T* odiag, T* osub, void* ws, size_t 
         arr[l].Z = reinterpret_cast<T*>(p); p += sz;
     }
     constexpr int g_lds = D * D * 64 * (int)sizeof(T);      // x path: the composed G of a run lives in LDS
-    if (x_path<T>())
+    if (SRC == 1 && mup.oc != nullptr) {
+        if (x_path<T>())
+            hipLaunchKernelGGL((par_tak_up0_x_kernel<T, D, 1, true>), dim3((unsigned)cdiv(B * pl.n[1], 64)), dim3(64), g_lds, st, B,
+                               n, len0, pl.n[1], src, arr[1].G, arr[1].N, mup);
+        else
+            hipLaunchKernelGGL((par_tak_up0_kernel<T, D, 1, true>), dim3((unsigned)cdiv(B * pl.n[1], 64)), dim3(64), 0, st, B, n,
+                               len0, pl.n[1], src, arr[1].G, arr[1].N, mup);
+    } else if (x_path<T>())
         hipLaunchKernelGGL((par_tak_up0_x_kernel<T, D, SRC>), dim3((unsigned)cdiv(B * pl.n[1], 64)), dim3(64), g_lds, st, B, n,
-                           len0, pl.n[1], src, arr[1].G, arr[1].N);
+                           len0, pl.n[1], src, arr[1].G, arr[1].N, TakMeanUp<T>{});
     else
         hipLaunchKernelGGL((par_tak_up0_kernel<T, D, SRC>), dim3((unsigned)cdiv(B * pl.n[1], 64)), dim3(64), 0, st, B, n, len0,
-                           pl.n[1], src, arr[1].G, arr[1].N);
+                           pl.n[1], src, arr[1].G, arr[1].N, TakMeanUp<T>{});
     for (int l = 1; l < pl.levels; ++l) {
         const long P = pl.n[l + 1];
         if (x_path<T>())
@@ -680,7 +688,8 @@ int ssm_precision(long B, long Tn, int m, const T* mu0, const T* cholP0, const T
 
 template <typename T, bool REV = false>
 int ssm_means(long Bl, long Br, long Tn, const T* A, const T* offs, T* out, void* ws, size_t ws_bytes, hipStream_t st,
-              const T** up_only = nullptr) {      // up_only: stop before the emit kernel and hand out the chunk-end means
+              const T** up_only = nullptr,        // up_only: stop before the emit kernel and hand out the chunk-end means
+              bool have_up0 = false) {            // level 1 (M, c at the head of ws) was already filled by the caller
     const long n = Tn;
     const long len0 = par_len0(Br, n);
     if (len0 == 0 || ws == nullptr || ws_bytes < btd_solve_ws<T>(Bl, Br, n)) {
@@ -702,8 +711,9 @@ int ssm_means(long Bl, long Br, long Tn, const T* A, const T* offs, T* out, void
         arr[l].c = reinterpret_cast<T*>(p); p += align_up(size_t(Br) * pl.n[l] * D * sizeof(T));
         arr[l].Z = reinterpret_cast<T*>(p); p += align_up(size_t(Br) * pl.n[l] * D * sizeof(T));
     }
-    hipLaunchKernelGGL((par_means_up0_kernel<T, D, REV>), dim3((unsigned)cdiv(Br * pl.n[1], 64)), dim3(64), 0, st, Bl, Br, n,
-                       len0, pl.n[1], A, offs, arr[1].M, arr[1].c);
+    if (!have_up0)
+        hipLaunchKernelGGL((par_means_up0_kernel<T, D, REV>), dim3((unsigned)cdiv(Br * pl.n[1], 64)), dim3(64), 0, st, Bl, Br, n,
+                           len0, pl.n[1], A, offs, arr[1].M, arr[1].c);
     for (int l = 1; l < pl.levels; ++l) {
         const long P = pl.n[l + 1];
         hipLaunchKernelGGL((par_affine_up_kernel<T, D>), dim3((unsigned)cdiv(Br * P, 64)), dim3(64), 0, st, Br, pl.n[l],
@@ -739,7 +749,7 @@ int ssm_means_entry(long Bl, long Br, long Tn, const T* A, const T* offs, T* out
 // emit kernel restarts both from the chunk boundaries (workspace: marginals_ws; -101 without it: the caller's two scans).
 template <typename T> size_t marginals_ws(long B, long n) {
     if (n < 2 || par_len0(B, n) == 0) return 0;
-    return align_up(size_t(B) * n * D * sizeof(T)) + align_up(btd_diag_of_inverse_ws<T>(B, n)) + btd_solve_ws<T>(B, B, n);
+    return align_up(btd_diag_of_inverse_ws<T>(B, n)) + btd_solve_ws<T>(B, B, n);
 }
 template <typename T>
 int ssm_marginals(long B, long n, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, T* omean, T* ocov,
@@ -754,16 +764,20 @@ int ssm_marginals(long B, long n, const T* mu0, const T* cholP0, const T* A, con
     }
     if (ws == nullptr || ws_bytes < marginals_ws<T>(B, n)) return -101;
     char* p = static_cast<char*>(ws);
-    T* offs = reinterpret_cast<T*>(p); p += align_up(size_t(B) * n * D * sizeof(T));
     char* ws_cov = p; p += align_up(btd_diag_of_inverse_ws<T>(B, n));
     char* ws_mean = p;
-    const T *up_cov = nullptr, *up_mean = nullptr;
-    int rc = tak_scan<T, 1>(B, n, src, ocov, osub, ws_cov, btd_diag_of_inverse_ws<T>(B, n), st, &up_cov);
-    if (rc != 0) return rc;
-    hipLaunchKernelGGL((concat_offsets_kernel<T, D>), dim3((unsigned)cdiv(B * n * D, 256)), dim3(256), 0, st, B, n, mu0, b, offs);
-    rc = ssm_means<T, false>(B, B, n, A, static_cast<const T*>(offs), omean, ws_mean, btd_solve_ws<T>(B, B, n), st, &up_mean);
-    if (rc != 0) return rc;
     const long P = par_plan(n, len0).n[1];
+    // level 1 of the means' hierarchy (M, c at the head of its workspace: the carve of ssm_means) is filled by the level-0
+    // up-sweep of the covariances, which has every transition in registers anyway
+    T* m1 = reinterpret_cast<T*>(ws_mean);
+    T* c1 = reinterpret_cast<T*>(ws_mean + align_up(size_t(B) * P * D * D * sizeof(T)));
+    const T *up_cov = nullptr, *up_mean = nullptr;
+    int rc = tak_scan<T, 1>(B, n, src, ocov, osub, ws_cov, btd_diag_of_inverse_ws<T>(B, n), st, &up_cov,
+                            TakMeanUp<T>{mu0, b, m1, c1});
+    if (rc != 0) return rc;
+    rc = ssm_means<T, false>(B, B, n, A, static_cast<const T*>(nullptr), omean, ws_mean, btd_solve_ws<T>(B, B, n), st, &up_mean,
+                             true);
+    if (rc != 0) return rc;
     hipLaunchKernelGGL((par_tak_emit_kernel<T, D, 1, true>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, B, n, len0, P, src,
                        up_cov, ocov, osub, TakMean<T>{mu0, b, omean, up_mean});
     return hipGetLastError() == hipSuccess ? 0 : -1000;
