@@ -372,8 +372,9 @@ int mf_kf_posterior_chain_f32(int64_t B, int64_t T, int d, int m, const float* m
  * (csrc/mf_kl_grad.hpp) - the ten parameter tensors are read once and nothing else touches HBM.  One lane per series when the
  * batch fills the chip.  With few, long chains (mf_ssm_kl_workspace_bytes > 0 and a workspace of that size) q1's marginals come
  * from the scans in time and the same local terms are formed by one lane per (series, step) and summed per series; on that
- * route the marginals of q1 can be kept: out_means [B,T,d], out_covs [B,T,d,d], out_cross [B,T-1,d,d] = Cov(x_{k+1}, x_k) (each
- * nullable) - exactly what mf_ssm_kl_grad / mf_kf_loglik_grad need.  Asking for them on the lane-per-series route is error -15.
+ * route the marginals of q1 can be kept: out_means [B,T,d], out_covs [B,T,d,d], out_cross [B,T-1,d,d] = Cov(x_{k+1}, x_k) (means
+ * and covariances together, the cross-covariances optionally on top; -15 otherwise) - exactly what mf_ssm_kl_grad /
+ * mf_kf_loglik_grad need; the sweep per series carries the same quantities in registers and writes them on request.
  * out_N [B,T,d,d], out_n [B,T,d] (both or neither; either route): N_k = dA_k^T Q2_k^-1 dA_k, n_k = dA_k^T Q2_k^-1 eps_k, the
  * inputs of the adjoint recursion of mf_ssm_kl_grad - by-products of the forward sweep that save the backward a kernel.
  * State dimension 1..9.

@@ -946,9 +946,10 @@ int kl_value(long B, long Tn, const T* mu0_1, const T* C0_1, const T* A_1, const
         hipLaunchKernelGGL((row_sum_kernel<T>), dim3((unsigned)B), dim3(64), 0, st, Tn, static_cast<const T*>(part), out);
         return hipGetLastError() == hipSuccess ? 0 : -1000;
     }
-    if (out_means || out_covs || out_cross) return -15;      // the moments exist on the route above only
+    if ((out_means != nullptr) != (out_covs != nullptr) || (out_cross && !out_means)) return -15;
+    if (Tn < 2 && out_cross) out_cross = nullptr;
     hipLaunchKernelGGL((ssm_kl_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, Tn, mu0_1, C0_1, A_1, b_1, C_1,
-                       mu0_2, C0_2, A_2, b_2, C_2, out, out_N, out_n, info);
+                       mu0_2, C0_2, A_2, b_2, C_2, out, out_N, out_n, out_means, out_covs, out_cross, info);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 

@@ -55,7 +55,10 @@ __global__ void __launch_bounds__(64) ssm_kl_kernel(long B, long Tn, const T* __
                                                     const T* __restrict__ C_1, const T* __restrict__ mu0_2,
                                                     const T* __restrict__ C0_2, const T* __restrict__ A_2,
                                                     const T* __restrict__ b_2, const T* __restrict__ C_2, T* __restrict__ out,
-                                                    T* __restrict__ oN, T* __restrict__ on, int* info) {
+                                                    T* __restrict__ oN, T* __restrict__ on, T* __restrict__ omean,
+                                                    T* __restrict__ ocov, T* __restrict__ ocross, int* info) {
+    // omean [B,T,D], ocov [B,T,D,D], ocross [B,T-1,D,D] (nullable, all or none): q1's marginals and Cov(x_{k+1}, x_k) = A1_k S_k,
+    // which this sweep carries in registers anyway - the backward needs them (mf_ssm_kl_grad, mf_kf_loglik_grad)
     // oN [B,T,D,D], on [B,T,D] (nullable): N_k = W_k^T W_k, n_k = W_k^T C2_k^-1 eps_k - the inputs of the adjoint recursion of the
     // backward (mf_ssm_kl_grad), which are by-products of this sweep
     const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -99,6 +102,10 @@ __global__ void __launch_bounds__(64) ssm_kl_kernel(long B, long Tn, const T* __
     }
     for (long k = 0; k + 1 < Tn; ++k) {
         const long tid = s * (Tn - 1) + k;
+        if (omean) {
+            store_vec<T, D>(omean + (s * Tn + k) * D, m);
+            store_sym<T, D>(ocov + (s * Tn + k) * D * D, S);
+        }
         T A1[D][D], W[D][D], C1[D][D], C2[D][D], C2i[D][D], eps[D], u[D], mn[D];
         load_mat<T, D, D>(A_1 + tid * D * D, A1);
         load_mat<T, D, D>(A_2 + tid * D * D, W);
@@ -139,6 +146,7 @@ __global__ void __launch_bounds__(64) ssm_kl_kernel(long B, long Tn, const T* __
             MF_UNROLL for (int l = 0; l < D; ++l)
                 MF_UNROLL for (int j = 0; j < D; ++j) AS[i][j] += A1[i][l] * ((l >= j) ? S[l][j] : S[j][l]);
         }
+        if (ocross) store_mat<T, D, D>(ocross + tid * D * D, AS);
         MF_UNROLL for (int i = 0; i < D; ++i)
             MF_UNROLL for (int j = 0; j <= i; ++j) {
                 T a = T(0);
@@ -151,6 +159,10 @@ __global__ void __launch_bounds__(64) ssm_kl_kernel(long B, long Tn, const T* __
         l2.renorm();
     }
     out[s] = T(0.5) * (acc - T(Tn) * T(D)) + l2.value() - l1.value();
+    if (omean) {
+        store_vec<T, D>(omean + (s * Tn + Tn - 1) * D, m);
+        store_sym<T, D>(ocov + (s * Tn + Tn - 1) * D * D, S);
+    }
     if (oN) kl_zero_adjoint_inputs<T, D>(oN + (s * Tn + Tn - 1) * D * D, on + (s * Tn + Tn - 1) * D);
     if (bad && info) raise_info(info);
 }

@@ -347,8 +347,8 @@ class StateSpaceModel(GaussMarkovDistribution):
     def _kl_divergence_value(self, dist: GaussMarkovDistribution, keep_moments: bool = False):
         """The divergence from its local form (``mf_ssm_kl_divergence_*``): one sweep per series when the batch fills the chip,
         else the marginals of ``self`` by the scans in time + one lane per (series, step).  ``keep_moments`` (the forward of
-        ``_KLDivergence``): also return what the backward can reuse - ``(means, covs, cross)`` of ``self`` when that second
-        route computed them (else ``None``) and the inputs ``(N, n)`` of the adjoint recursion, by-products of either route.
+        ``_KLDivergence``): also return what the backward can reuse - ``(means, covs, cross)`` of ``self`` and the inputs
+        ``(N, n)`` of the adjoint recursion, by-products of either route.
         Other distributions and state dimensions beyond the register kernels take the reference's operator route."""
         bsz = int(math.prod(self.batch_shape))
         n, d = self.num_transitions + 1, self.state_dim
@@ -358,7 +358,7 @@ class StateSpaceModel(GaussMarkovDistribution):
             ws_bytes = int(_lib.load().mf_ssm_kl_workspace_bytes(bsz, n, d, out.element_size()))
             ws = _lib.workspace(ws_bytes, dev)
             moments = adjoint_inputs = None
-            if keep_moments and ws_bytes > 0:
+            if keep_moments and n > 1:
                 moments = (torch.empty((bsz, n, d), dtype=dtype, device=dev), torch.empty((bsz, n, d, d), dtype=dtype, device=dev),
                            torch.empty((bsz, n - 1, d, d), dtype=dtype, device=dev))
             if keep_moments:

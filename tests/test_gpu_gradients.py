@@ -409,8 +409,8 @@ def test_operations_without_a_backward_fail_loudly(rng):
 def test_kl_routes_agree_with_the_oracle(rng, d, t, bsz):
     """kl_divergence has three routes: one sweep per series (many series / short chains), the marginals of q1 by the scans in
     time + one lane per (series, step) (few long chains: t >= 64 here), and the reference's route over the operator kernels
-    (other distributions, d > 9).  All against the numpy restatement of state_space_model.py:528-593; on the second route the
-    moments handed to the backward are the marginals of q1."""
+    (other distributions, d > 9).  All against the numpy restatement of state_space_model.py:528-593; the moments handed to the
+    backward are the marginals of q1 on either route."""
     from oracle import numpy_oracle as O
     from markovflow_amd import _lib
     kw1 = random_ssm(rng, (bsz,), t, d, 1, well=True)
@@ -436,7 +436,7 @@ def test_kl_routes_agree_with_the_oracle(rng, d, t, bsz):
             np.testing.assert_allclose(adjoint_inputs[1][s_, k].cpu().numpy(), want_n_vec, rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(value.cpu().numpy(), ref, rtol=1e-9)
     ws_bytes = int(_lib.load().mf_ssm_kl_workspace_bytes(bsz, t, d, 8))
-    assert (ws_bytes > 0) == (t >= 64) and (moments is not None) == (t >= 64)
+    assert (ws_bytes > 0) == (t >= 64) and moments is not None      # both routes hand q1's moments to the backward
     if moments is not None:
         means, covs, cross = q1._moments(want_sub=True)
         for got, want in zip(moments, (means, covs, cross)):
