@@ -6,6 +6,7 @@
 #include "mf_kernels.hpp"
 #include "mf_kf_lds.hpp"
 #include "mf_kf_x.hpp"
+#include "mf_row.hpp"
 #include "mf_btd_par.hpp"
 #include "mf_gpr_fused.hpp"
 #include "mf_kl_grad.hpp"
@@ -175,13 +176,36 @@ inline void lds_partition(long B, long Tn, long chunks, long& P, long& L, long t
 
 // Which level-0 kernel evaluates a call, and with which time partition.  ONE function decides it for the launcher and for the
 // workspace query, so the two can never disagree.
-enum KfPath { KF_PATH_X, KF_PATH_LDS, KF_PATH_DIRECT };
+enum KfPath { KF_PATH_ROW, KF_PATH_X, KF_PATH_LDS, KF_PATH_DIRECT };
+// The row kernels (mf_row.hpp: one 16-lane DPP row per chunk) take the log-likelihood wherever the spike-in-LDS kernels did.
+// MF_KF_ROW=0 switches them off (A/B timing, experiment builds only).
+template <typename T> bool row_path() {
+    static const bool on = [] { const char* e = mf_knob("MF_KF_ROW"); return !(e && e[0] == '0'); }();
+    return on && D + 1 <= 16 && ((sizeof(T) == 8 && D >= 7) || (sizeof(T) == 4 && D >= 9));
+}
+// rows that fill the chip: four per wavefront, three wavefronts per SIMD (~150 registers per lane)
+inline long row_target_rows() {
+    static const long v = [] { const char* e = mf_knob("MF_ROW_TARGET"); const long x = e ? std::atol(e) : 0; return x > 0 ? x : 256L * 4 * 3 * 4; }();
+    return v;
+}
 struct KfPlan {
     KfPath path;
     long P, L;       // chunks per series; transitions per chunk (LDS kernel)
 };
 template <typename T> KfPlan kf_plan(long B, long Tn, int m, int rinv_per_step, long chunks, bool aligned16) {
     KfPlan pl{KF_PATH_DIRECT, 1, 0};
+    if (row_path<T>() && Tn >= 2 && m >= 1 && m <= MF_MAXM) {
+        long P = chunks > 0 ? (chunks > Tn ? Tn : chunks) : cdiv(row_target_rows(), B);
+        if (chunks <= 0) {
+            const long maxP = Tn / 4 > 0 ? Tn / 4 : 1;
+            if (P > maxP) P = maxP;
+        }
+        if (row::row_offsets_fit(Tn, P, D, m, (int)sizeof(T))) {
+            pl.path = KF_PATH_ROW;
+            pl.P = P;
+            return pl;
+        }
+    }
     // (fp64 d = 6 with four outputs: the streaming kernel spills and the plain direct-load kernel runs at 17 % - the spike-in-LDS
     // kernel with its grouped loads is the better home)
     if ((x_path<T>() || (sizeof(T) == 8 && D == 6 && m == 4)) && Tn >= 2) {
@@ -243,7 +267,21 @@ int kf_loglik(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A,
     RedSys<T> lvl0 = carve<T>(p, B, P);
     const dim3 grid((unsigned)cdiv(B * P, 64)), block(64);
     if (ev0) (void)hipEventRecord(ev0, st);
-    if (pl.path == KF_PATH_X) {
+    if (pl.path == KF_PATH_ROW) {
+        if constexpr (D >= 7 && D + 1 <= 16) {
+            const dim3 rgrid((unsigned)cdiv(B * P, 4));
+            auto launch = [&](auto mtag) {
+                constexpr int M = decltype(mtag)::value;
+                if (rinv_per_step) hipLaunchKernelGGL((row::kf_row_kernel<T, D, M, true>), rgrid, block, 0, st, a, lvl0);
+                else hipLaunchKernelGGL((row::kf_row_kernel<T, D, M, false>), rgrid, block, 0, st, a, lvl0);
+            };
+            using std::integral_constant;
+            if (m == 1) launch(integral_constant<int, 1>{});
+            else if (m == 2) launch(integral_constant<int, 2>{});
+            else if (m == 3) launch(integral_constant<int, 3>{});
+            else launch(integral_constant<int, 4>{});
+        }
+    } else if (pl.path == KF_PATH_X) {
         constexpr int x_lds = LdsSpike<T, D>::BYTES;
         if (m > 1 && x_obs_lds<T>(m)) {
             const int lds = x_lds + LdsObs<T, D>::bytes(m);
