@@ -74,14 +74,27 @@ inline long auto_chunks(long B, long n) {
     return P;
 }
 
-template <typename T> size_t levels_ws(long B, long P) {
+template <typename T> size_t levels_ws(long B, long P, long rc = 0, long rf = 0) {
+    if (rc <= 0) rc = red_chunk();
+    if (rf <= 0) rf = red_final();
     size_t total = red_bytes<T>(B, P);
     long n = P;
-    while (n > red_final()) {
-        n = cdiv(n, red_chunk());
+    while (n > rf) {
+        n = cdiv(n, rc);
         total += red_bytes<T>(B, n);
     }
     return total;
+}
+// reduction levels in row form (mf_row.hpp): a step costs ~450 instructions issued by a single wavefront per SIMD, so the
+// levels are cut short: chunks of ROW_RED_CHUNK blocks, the last <= ROW_RED_FINAL blocks walked by one row per series
+constexpr long ROW_RED_CHUNK = 6, ROW_RED_FINAL = 4;
+inline long row_red_chunk() {
+    static const long v = [] { const char* e = mf_knob("MF_ROW_RED_CHUNK"); const long x = e ? std::atol(e) : 0; return x >= 2 ? x : ROW_RED_CHUNK; }();
+    return v;
+}
+inline long row_red_final() {
+    static const long v = [] { const char* e = mf_knob("MF_ROW_RED_FINAL"); const long x = e ? std::atol(e) : 0; return x >= 1 ? x : ROW_RED_FINAL; }();
+    return v;
 }
 
 // State dimensions whose elimination state (with the spike) does not fit a lane's 512 registers take the kernels of
@@ -120,6 +133,22 @@ int reduce_levels(RedSys<T> cur, long B, char* p, T add_const, T* out, int* info
     }
     hipLaunchKernelGGL((red_final_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, cur, B, add_const, out,
                        info);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+// The same with the row kernels (used behind the row level-0 kernel).
+template <typename T>
+int reduce_levels_row(RedSys<T> cur, long B, char* p, T add_const, T* out, int* info, hipStream_t st) {
+    if constexpr (D >= 7 && D + 1 <= 16) {
+        while (cur.n > row_red_final()) {
+            const long P = cdiv(cur.n, row_red_chunk());
+            RedSys<T> nxt = carve<T>(p, B, P);
+            hipLaunchKernelGGL((row::red_row_kernel<T, D>), dim3((unsigned)cdiv(B * P, 4)), dim3(64), 0, st, cur, nxt, B, P, info);
+            cur = nxt;
+        }
+        hipLaunchKernelGGL((row::red_row_final_kernel<T, D>), dim3((unsigned)cdiv(B, 4)), dim3(64), 0, st, cur, B, add_const, out,
+                           info);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
@@ -192,6 +221,9 @@ struct KfPlan {
     KfPath path;
     long P, L;       // chunks per series; transitions per chunk (LDS kernel)
 };
+template <typename T> size_t plan_ws(long B, const KfPlan& pl) {
+    return pl.path == KF_PATH_ROW ? levels_ws<T>(B, pl.P, row_red_chunk(), row_red_final()) : levels_ws<T>(B, pl.P);
+}
 template <typename T> KfPlan kf_plan(long B, long Tn, int m, int rinv_per_step, long chunks, bool aligned16) {
     KfPlan pl{KF_PATH_DIRECT, 1, 0};
     if (row_path<T>() && Tn >= 2 && m >= 1 && m <= MF_MAXM) {
@@ -232,19 +264,20 @@ template <typename T> KfPlan kf_plan(long B, long Tn, int m, int rinv_per_step, 
 // Workspace of the log-likelihood: the call's m / per-step flag / alignment are not arguments of the query, so it is sized
 // for the largest partition any of them can choose.
 template <typename T> size_t kf_loglik_ws(long B, long Tn, long chunks) {
-    long pmax = 1;
+    size_t need = levels_ws<T>(B, 1);
     for (int per_step = 0; per_step < 2; ++per_step)
         for (int m = 1; m <= MF_MAXM; ++m)
             for (int al = 0; al < 2; ++al) {
-                const long P = kf_plan<T>(B, Tn, m, per_step, chunks, al != 0).P;
-                if (P > pmax) pmax = P;
+                const size_t w = plan_ws<T>(B, kf_plan<T>(B, Tn, m, per_step, chunks, al != 0));
+                if (w > need) need = w;
             }
     if (Tn >= 2) {                                            // the fused GPR route (gpr_loglik) partitions like this
         long P = 1, L = 1;
         lds_partition(B, Tn, chunks, P, L);
-        if (P > pmax) pmax = P;
+        const size_t w = levels_ws<T>(B, P);
+        if (w > need) need = w;
     }
-    return levels_ws<T>(B, pmax);
+    return need;
 }
 
 template <typename T>
@@ -256,7 +289,7 @@ int kf_loglik(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A,
     const bool aligned16 = ((reinterpret_cast<size_t>(A) | reinterpret_cast<size_t>(cholQ)) & 15) == 0;
     const KfPlan pl = kf_plan<T>(B, Tn, m, rinv_per_step, chunks, aligned16);
     const long P = pl.P;
-    if (ws_bytes < levels_ws<T>(B, P)) return -15;          // checked against the partition that is actually launched
+    if (ws_bytes < plan_ws<T>(B, pl)) return -15;           // checked against the partition that is actually launched
     int dbg = 0;
 #ifdef MF_EXPERIMENT
     static const int dbg_env = [] { const char* e = mf_knob("MF_KF_DEBUG"); return e ? std::atoi(e) : 0; }();
@@ -320,6 +353,7 @@ int kf_loglik(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A,
         else hipLaunchKernelGGL((kf_chunk_kernel<T, D, 0, false>), grid, block, 0, st, a, lvl0);
     }
     if (ev1) (void)hipEventRecord(ev1, st);
+    if (pl.path == KF_PATH_ROW) return reduce_levels_row<T>(lvl0, B, p, add_const, out, info, st);
     return reduce_levels<T>(lvl0, B, p, add_const, out, info, st);
 }
 

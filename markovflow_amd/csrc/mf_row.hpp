@@ -77,6 +77,21 @@ template <> struct Dpp<float> {
     }
 };
 
+// 1 / sqrt(x): hardware seed (relative error <= 2^-22) and ONE third-order correction r (1 + e/2 + 3e^2/8), e = 1 - x r^2:
+// the truncation error 5 e^3 / 16 is below 2^-67, six instructions instead of the nine of two Newton steps (t_rsqrt) on the
+// critical path of every pivot - here a pivot's chain serves four chunks, not sixty-four.
+MF_DEV double row_rsqrt(double x) {
+    const double r = __builtin_amdgcn_rsq(x);
+    const double e = __builtin_fma(-(x * r), r, 1.0);
+    const double q = e * __builtin_fma(e, 0.375, 0.5);
+    return __builtin_fma(r, q, r);
+}
+MF_DEV float row_rsqrt(float x) {
+    const float r = __builtin_amdgcn_rsqf(x);
+    const float e = __builtin_fmaf(-(x * r), r, 1.0f);
+    return __builtin_fmaf(r, 0.5f * e, r);
+}
+
 // The registers of v are DPP sources from here on: their definitions stay above, two wait states follow.
 template <typename T> MF_DEV void tie(T& x) { asm volatile("" : "+v"(x)); }      // (asm statements cannot sit in a lambda: host pass)
 template <typename T, int N> MF_DEV void fence(T (&v)[N]) {
@@ -117,7 +132,7 @@ template <typename T, int D, int M> struct RowChunk {
     T Id[D];       // Id[i] = (r == i)
     T ED;          // (r == D)
     LogAcc<T> laC; // lanes < D: prod of own diagonal elements of the transition factors
-    LogAcc<T> laL; // replicated: prod diag(L)
+    LogAcc<T> laL; // replicated: prod of the pivots = prod diag(L)^2
     bool bad;
 
     MF_DEV void init(int r) {
@@ -246,8 +261,8 @@ template <typename T, int D, int M> struct RowChunk {
             fence1(Phi[jj]);
             const T s = P::template bcast<jj>(Phi[jj]);
             bad |= !(s > T(0));
-            const T inv = t_rsqrt<T>(s);
-            laL.mul(s * inv);
+            const T inv = row_rsqrt(s);
+            laL.mul(s);                                   // the pivots themselves: log|L| = log(prod) / 2
             Phi[jj] *= inv;
             Xa[jj] *= inv;
             W[jj] = S[jj] * inv;
@@ -410,7 +425,7 @@ __global__ void __launch_bounds__(64, 3) kf_row_kernel(KfArgs<T> a, RedSys<T> ou
     T lc = T(0);
     sfor<D>([&](auto i) { lc += P::template bcast<decltype(i)::value>(logc); });
     const T scalar = T(-0.5) * (P::template bcast<D>(yr) + P::template bcast<D>(w2)) + T(0.5) * P::template bcast<D>(qd) - lc -
-                     E.laL.value();
+                     T(0.5) * E.laL.value();
     if (valid) {
         if (r < D) {
             T* dv = out.Dv + id * D * D + r * D;
@@ -430,6 +445,195 @@ __global__ void __launch_bounds__(64, 3) kf_row_kernel(KfArgs<T> a, RedSys<T> ou
         }
         if (E.bad && a.info) raise_info(a.info);
     }
+}
+
+// ---- reduction levels of the log-likelihood in row form -----------------------------------------------------------------------
+// The reduced block-tridiagonal system a level leaves (RedSys: pivot parts Dv, contributions GU / gU to the block on the left,
+// couplings F, right-hand sides tv, scalars) is reduced again by the same partitioned elimination; a row per (series, chunk).
+// Same conventions as red_chunk_kernel / red_final_kernel (mf_kernels.hpp): block j's pivot is Dv_j + GU_{j+1}, its right-hand
+// side tv_j + gU_{j+1}, F_j couples block j (rows) with block j - 1 (columns).
+template <typename T, int D> struct RowElim {
+    using P = Dpp<T>;
+    T Phi[D];      // lanes < D: row r of the current pivot; lane D: its right-hand side
+    T Xa[D];       // lanes < D: column r of the coupling to the chunk's left separator
+    T GU[D];       // lanes < D: row r of the separator's accumulated pivot contribution
+    T gU, quad;
+    LogAcc<T> laL;
+    bool bad;
+
+    MF_DEV void init() {
+        sfor<D>([&](auto i) { Phi[decltype(i)::value] = T(0); Xa[decltype(i)::value] = T(0); GU[decltype(i)::value] = T(0); });
+        gU = quad = T(0);
+        laL.init();
+        bad = false;
+    }
+    // Eliminates the current block and moves to the next one.  S: rows of the coupling F (lanes < D; lane D: anything),
+    // Dn: rows of the next pivot (lane D: the next right-hand side).  Lane D's S row becomes the current right-hand side, so
+    // z = L^-1 t comes out of the same substitution as W = F L^-T.
+    template <bool SPIKE> MF_DEV void advance(T (&S)[D], const T (&Dn)[D], bool is_vec) {
+        sfor<D>([&](auto j) { S[decltype(j)::value] = is_vec ? Phi[decltype(j)::value] : S[decltype(j)::value]; });
+        T W[D];
+        sfor<D>([&](auto j) {
+            constexpr int jj = decltype(j)::value;
+            fence1(Phi[jj]);
+            const T s = P::template bcast<jj>(Phi[jj]);
+            bad |= !(s > T(0));
+            const T inv = row_rsqrt(s);
+            laL.mul(s);                                   // the pivots themselves: log|L| = log(prod) / 2
+            Phi[jj] *= inv;
+            if constexpr (SPIKE) Xa[jj] *= inv;
+            W[jj] = S[jj] * inv;
+            fence1(Phi[jj]);
+            sfor2<jj + 1, D>([&](auto k) {
+                constexpr int kk = decltype(k)::value;
+                P::template fnmac<kk>(Phi[kk], Phi[jj], Phi[jj]);
+                if constexpr (SPIKE) P::template fnmac<kk>(Xa[kk], Phi[jj], Xa[jj]);
+                P::template fnmac<kk>(S[kk], Phi[jj], W[jj]);
+            });
+        });
+        laL.renorm();
+        sfor<D>([&](auto k) { quad = __builtin_fma(W[decltype(k)::value], W[decltype(k)::value], quad); });
+        fence(W);
+        if constexpr (SPIKE) {
+            fence(Xa);
+            T Xn[D];
+            sfor<D>([&](auto i) { Xn[decltype(i)::value] = T(0); });
+            sfor<D>([&](auto k) {
+                constexpr int kk = decltype(k)::value;
+                sfor<D>([&](auto j) {
+                    constexpr int jj = decltype(j)::value;
+                    P::template fnmac<jj>(GU[jj], Xa[kk], Xa[kk]);
+                    P::template fnmac<jj>(Xn[jj], W[kk], Xa[kk]);
+                });
+                P::template fnmac<D>(gU, W[kk], Xa[kk]);
+            });
+            sfor<D>([&](auto i) { Xa[decltype(i)::value] = Xn[decltype(i)::value]; });
+        }
+        sfor<D>([&](auto j) { Phi[decltype(j)::value] = Dn[decltype(j)::value]; });
+        sfor<D>([&](auto k) {
+            constexpr int kk = decltype(k)::value;
+            sfor<D>([&](auto j) { P::template fnmac<decltype(j)::value>(Phi[decltype(j)::value], W[kk], W[kk]); });
+        });
+    }
+    // The last block of a series: Cholesky with the right-hand side as one more row (lane D), so that its row of the
+    // factor is z; quad and the log-determinant complete.
+    MF_DEV void finish() {
+        sfor<D>([&](auto j) {
+            constexpr int jj = decltype(j)::value;
+            fence1(Phi[jj]);
+            const T s = P::template bcast<jj>(Phi[jj]);
+            bad |= !(s > T(0));
+            const T inv = row_rsqrt(s);
+            laL.mul(s);                                   // the pivots themselves: log|L| = log(prod) / 2
+            Phi[jj] *= inv;
+            fence1(Phi[jj]);
+            sfor2<jj + 1, D>([&](auto k) { P::template fnmac<decltype(k)::value>(Phi[decltype(k)::value], Phi[jj], Phi[jj]); });
+        });
+        laL.renorm();
+        sfor<D>([&](auto k) { quad = __builtin_fma(Phi[decltype(k)::value], Phi[decltype(k)::value], quad); });   // lane D: |z|^2
+    }
+};
+
+// Loads of one reduced block for the lanes of a row: pivot rows (lane D: the right-hand side) with the contribution of the
+// next block's interior folded in.  Plain global loads through per-lane pointers: the four tensors are different allocations
+// of one workspace (or user tensors), the lanes < D read matrix rows and lane D reads vectors.
+template <typename T, int D>
+MF_DEV void load_red_rows(const RedSys<T>& in, long s, long k, int r, T (&Dn)[D], T& sc) {
+    const long idx = s * in.n + k;
+    const bool vec = r >= D;
+    const int rc = r < D ? r : 0;
+    const T* p = vec ? in.tv + idx * D : in.Dv + idx * D * D + rc * D;
+    const bool fold = in.GU != nullptr && k + 1 < in.n;
+    const long idn = fold ? idx + 1 : idx;
+    const T* g = in.GU == nullptr ? p : (vec ? in.gU + idn * D : in.GU + idn * D * D + rc * D);
+    const T f = fold ? T(1) : T(0);
+    sfor<D>([&](auto j) { Dn[decltype(j)::value] = __builtin_fma(g[decltype(j)::value], f, p[decltype(j)::value]); });
+    sc = in.sc ? in.sc[idx] : T(0);
+}
+
+// One level: RedSys(n) -> RedSys(P); 64 threads = 4 rows = 4 (series, chunk) pairs; chunk c owns blocks [c n / P, (c+1) n / P).
+template <typename T, int D>
+__global__ void __launch_bounds__(64, 3) red_row_kernel(RedSys<T> in, RedSys<T> out, long B, long Pn, int* info) {
+    const int lane = threadIdx.x, r = lane & 15;
+    const int rc = r < D ? r : 0;
+    const long total = B * Pn;
+    const long id_raw = (long)blockIdx.x * 4 + (lane >> 4);
+    const bool valid = id_raw < total;
+    const long id = valid ? id_raw : total - 1;
+    const long s = id / Pn, c = id % Pn;
+    const long k0 = (c * in.n) / Pn, k1 = ((c + 1) * in.n) / Pn;
+    RowElim<T, D> E;
+    E.init();
+    T acc_sc;
+    {
+        T Dn[D];
+        load_red_rows<T, D>(in, s, k0, r, Dn, acc_sc);
+        // coupling of the chunk's first block to the separator on its left, as columns (zero for the first chunk of a series)
+        const long kf = k0 > 0 ? k0 : (in.n > 1 ? 1 : 0);
+        const T* fcol = in.F + (s * in.f_stride + kf + in.f_off) * D * D + rc;
+        const T keep = (k0 > 0 && r < D) ? T(1) : T(0);
+        sfor<D>([&](auto i) {
+            E.Phi[decltype(i)::value] = Dn[decltype(i)::value];
+            E.Xa[decltype(i)::value] = in.n > 1 ? fcol[decltype(i)::value * D] * keep : T(0);
+        });
+    }
+    for (long k = k0 + 1; k < k1; ++k) {
+        asm volatile("s_nop 4");
+        T Dn[D], S[D], sc;
+        load_red_rows<T, D>(in, s, k, r, Dn, sc);
+        const T* frow = in.F + (s * in.f_stride + k + in.f_off) * D * D + rc * D;
+        sfor<D>([&](auto j) { S[decltype(j)::value] = frow[decltype(j)::value]; });
+        acc_sc += sc;
+        E.template advance<true>(S, Dn, r == D);
+    }
+    if (valid) {
+        if (r < D) {
+            T* dv = out.Dv + id * D * D + r * D;
+            T* gu = out.GU + id * D * D + r * D;
+            T* f = out.F + id * D * D + r;
+            sfor<D>([&](auto j) {
+                constexpr int jj = decltype(j)::value;
+                dv[jj] = E.Phi[jj];
+                gu[jj] = E.GU[jj];
+                f[jj * D] = E.Xa[jj];
+            });
+            out.gU[id * D + r] = E.gU;
+        } else if (r == D) {
+            T* tv = out.tv + id * D;
+            sfor<D>([&](auto j) { tv[decltype(j)::value] = E.Phi[decltype(j)::value]; });
+            out.sc[id] = acc_sc + T(0.5) * (E.quad - E.laL.value());        // lane D holds |z|^2
+        }
+        if (E.bad && info) raise_info(info);
+    }
+}
+
+// Last level: a row per series walks the remaining blocks; out[s] = add_const + scalars + 0.5 |z|^2 - log|L|.
+template <typename T, int D>
+__global__ void __launch_bounds__(64, 3) red_row_final_kernel(RedSys<T> in, long B, T add_const, T* __restrict__ out, int* info) {
+    const int lane = threadIdx.x, r = lane & 15;
+    const int rc = r < D ? r : 0;
+    const long id_raw = (long)blockIdx.x * 4 + (lane >> 4);
+    const bool valid = id_raw < B;
+    const long s = valid ? id_raw : B - 1;
+    RowElim<T, D> E;
+    E.init();
+    T acc_sc;
+    {
+        T Dn[D];
+        load_red_rows<T, D>(in, s, 0, r, Dn, acc_sc);
+        sfor<D>([&](auto i) { E.Phi[decltype(i)::value] = Dn[decltype(i)::value]; });
+    }
+    for (long k = 1; k < in.n; ++k) {
+        T Dn[D], S[D], sc;
+        load_red_rows<T, D>(in, s, k, r, Dn, sc);
+        const T* frow = in.F + (s * in.f_stride + k + in.f_off) * D * D + rc * D;
+        sfor<D>([&](auto j) { S[decltype(j)::value] = frow[decltype(j)::value]; });
+        acc_sc += sc;
+        E.template advance<false>(S, Dn, r == D);
+    }
+    E.finish();
+    if (valid && r == D) out[s] = add_const + acc_sc + T(0.5) * (E.quad - E.laL.value());
+    if (valid && E.bad && info) raise_info(info);
 }
 
 }   // namespace row
