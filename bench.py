@@ -38,7 +38,32 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the brief timing of BASELINE configs 2-5")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="exercise the multi-rank launch only: ranks join a gloo group, shard the batch, all-reduce a probe and "
+                         "print n_gpus / ranks_seen; no GPU is touched (runs in CI without one)")
     return ap.parse_args()
+
+
+def visible_gpus() -> int:
+    """GPUs a rank could use, counted WITHOUT opening the HIP / HSA runtime (the launching process must stay GPU-free: a
+    process that has initialised the GPU must never be the parent that gets replaced or forked into ranks): KFD topology
+    nodes that have SIMDs, cut down by the *_VISIBLE_DEVICES lists."""
+    import glob
+
+    n = 0
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            with open(path) as fh:
+                for line in fh:
+                    if line.startswith("simd_count"):
+                        n += int(line.split()[1]) > 0
+        except (OSError, ValueError, IndexError):
+            pass
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        lst = os.environ.get(var)
+        if lst is not None:
+            n = min(n, len([x for x in lst.split(",") if x.strip()]))
+    return n
 
 
 class HipEvents:
@@ -258,27 +283,59 @@ def other_configs(dev):
 
 
 def launch_ranks(args) -> int:
-    """`bench.py --gpus N` without a launcher: THIS process stays GPU-free (nothing here initialises HIP) and starts N fresh
-    rank processes through torch.distributed.run, one per GPU, RCCL rendezvous on 127.0.0.1; rank 0's JSON line goes
-    straight to our stdout and we exit with the children's return code (never exec over a process that touched the GPU)."""
+    """`bench.py --gpus N` without a launcher: THIS process stays GPU-free - it imports neither torch nor any HIP library and
+    counts GPUs from sysfs - and starts N fresh rank processes through torch.distributed.run, one per GPU, rendezvous on
+    127.0.0.1; rank 0's JSON line goes straight to our stdout and we exit with the children's return code (child processes
+    only: never exec over, or fork from, a process that touched the GPU)."""
     import socket
     import subprocess
 
-    import torch
-
-    have = torch.cuda.device_count()          # counts devices without creating a HIP context on this image
-    if have < args.gpus:
-        print(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible", file=sys.stderr)
-        return 2
+    if not args.dry_launch:
+        have = visible_gpus()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible", file=sys.stderr)
+            return 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: needed by RCCL on this driver
-    env.setdefault("OMP_NUM_THREADS", "8")
+    # dmabuf IPC: this image's host driver supports no legacy IPC handles - without it RCCL's communicator setup (and any
+    # CUDA-tensor sharing across processes) fails with `hipIpcGetMemHandle: invalid argument` (environment notes of the pool)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8" if not args.dry_launch else "1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    assert "torch" not in sys.modules, "the launching process must not import torch (it has to stay GPU-free)"
     return subprocess.call(cmd, env=env)
+
+
+def dry_rank(args) -> int:
+    """A rank of `--dry-launch`: the launch plumbing (spawn, port, argv, environment, stdout discipline, return code) and the
+    sharding arithmetic with a gloo group instead of RCCL and no kernels."""
+    import torch
+    import torch.distributed as dist
+
+    from markovflow_amd import distributed as mfd
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} does not match the launcher's WORLD_SIZE={world}", file=sys.stderr)
+        return 2
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    with _StdoutToStderr():
+        dist.init_process_group(backend="gloo")
+    ones = torch.ones(1, dtype=torch.float64)
+    dist.all_reduce(ones)
+    lo, hi = mfd.shard_bounds(args.batch * world, rank, world)          # weak scaling: every rank owns args.batch series
+    owned = torch.tensor([float(hi - lo)], dtype=torch.float64)
+    dist.all_reduce(owned)
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": dist.get_world_size(), "ranks_seen": int(ones.item()),
+                          "series_total": int(owned.item()), "series_per_gpu": args.batch,
+                          "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}))
+    dist.destroy_process_group()
+    return 0
 
 
 class _StdoutToStderr:
@@ -303,6 +360,11 @@ def main():
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # under torch.distributed.run
     if args.gpus > 1 and not launched:
         sys.exit(launch_ranks(args))
+    if args.dry_launch:
+        if not launched:
+            print("bench.py: --dry-launch needs --gpus N > 1 (or a torch.distributed.run launcher)", file=sys.stderr)
+            sys.exit(2)
+        sys.exit(dry_rank(args))
     import torch
 
     rank = int(os.environ.get("RANK", "0"))

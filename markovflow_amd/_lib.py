@@ -242,7 +242,7 @@ class errors_as_nan:
         _suppress -= 1
         for idx in _flags:
             torch.cuda.synchronize(idx)
-        _take_failures()
+        _take_failures(synced=True)
         return False
 
 
@@ -263,24 +263,30 @@ def pivot_info(device):
     return _flags[idx][1]
 
 
-def _take_failures():
+def _take_failures(synced: bool = False):
+    """Look at every device's flag.  A raised flag is cleared and reported with the names issued so far.  A clean look only
+    forgets the names when it came after a synchronisation (``synced``): without one, a kernel issued earlier may still be
+    running and raise the flag later - its name has to survive this look (a factorisation followed by any
+    non-factorising call used to lose it)."""
     bad = False
     for _, _, view in _flags.values():
         if view.value != 0:
             view.value = 0
             bad = True
     if not bad:
-        _issued.clear()
+        if synced:
+            _issued.clear()
         return None
     ops = ", ".join(dict.fromkeys(_issued)) or "a factorisation"
     _issued.clear()
     return ops
 
 
-def raise_pending():
-    """Raise if a kernel that has FINISHED since the last look met a non-positive pivot (no synchronisation)."""
-    if _flags and _issued and not _suppress:
-        ops = _take_failures()
+def raise_pending(synced: bool = False):
+    """Raise if a kernel that has FINISHED since the last look met a non-positive pivot (no synchronisation).  The flag is
+    read whenever this library has handed one to a kernel, whether or not a name is on record."""
+    if _flags and not _suppress:
+        ops = _take_failures(synced)
         if ops is not None:
             raise MarkovflowAmdError(f"matrix is not positive definite (non-positive pivot) in one of: {ops}")
 
@@ -289,7 +295,36 @@ def check_errors():
     """Synchronise every device this library has used and raise if any factorisation met a non-positive pivot."""
     for idx in _flags:
         torch.cuda.synchronize(idx)
-    raise_pending()
+    raise_pending(synced=True)
+
+
+# Methods through which a result reaches the host.  Each of them synchronises the producing stream, so when it returns the
+# pinned flag is final for everything the result depends on: the look that follows costs one host read and raises exactly
+# where a user of the reference would first SEE a bad number.
+_HOST_READS = {"item", "tolist", "cpu", "numpy", "__float__", "__int__", "__bool__", "__array__", "__repr__", "__str__",
+               "__format__"}
+
+
+class CheckedTensor(torch.Tensor):
+    """What the scalar-valued entry points return (``log_likelihood``, ``kl_divergence``, ...): a tensor that looks at the
+    pivot flag after every host read (``float(x)``, ``x.item()``, ``x.cpu()``, ``print(x)`` ...) and raises
+    MarkovflowAmdError if a factorisation behind it failed - TensorFlow raises inside ``cholesky``
+    (block_tri_diag.py:423-436); here the error surfaces at the first point where the host can observe the value, without
+    a synchronisation of its own.  Arithmetic on it returns CheckedTensors again."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        out = super().__torch_function__(func, types, args, kwargs or {})
+        if getattr(func, "__name__", "") in _HOST_READS:
+            raise_pending()
+        return out
+
+
+def checked(t: torch.Tensor) -> torch.Tensor:
+    """Wrap a result so that host reads look at the pivot flag (no-op inside ``errors_as_nan`` / in synchronous mode)."""
+    if _suppress or CHECK_PIVOTS or not isinstance(t, torch.Tensor) or t.requires_grad:
+        return t
+    return t.as_subclass(CheckedTensor)
 
 
 def raise_on_info(info, what: str, device=None):
@@ -299,6 +334,6 @@ def raise_on_info(info, what: str, device=None):
         del _issued[:-64]
     if CHECK_PIVOTS and not _suppress:
         torch.cuda.current_stream(device).synchronize()
-        ops = _take_failures()
+        ops = _take_failures(synced=True)
         if ops is not None:
             raise MarkovflowAmdError(f"{what}: matrix is not positive definite")

@@ -227,9 +227,9 @@ class BaseKalmanFilter(abc.ABC):
         if not differentiable:
             fused = self._fused_total(per_series, num_data)
             if fused is not None:
-                return fused
+                return _lib.checked(fused)
         per_series = per_series.reshape(tuple(self.prior_ssm.batch_shape))
-        return torch.sum(per_series + self._constant_terms(num_data))
+        return _lib.checked(torch.sum(per_series + self._constant_terms(num_data)))
 
     def _total_terms(self):
         """``(chol_obs | None, extra device scalar | None)`` for ``mf_kf_loglik_total``: how this filter's
@@ -299,6 +299,7 @@ class KalmanFilter(BaseKalmanFilter):
             info = _lib.pivot_info(chol.device)
             _lib.call("mf_obs_precision_from_chol", chol.dtype, m, _lib.ptr(chol.contiguous()), _lib.ptr(out), info,
                       _lib.stream_ptr(chol.device))
+            _lib.raise_on_info(info, "KalmanFilter (observation precision)", chol.device)
             return out
         eye = torch.eye(m, dtype=chol.dtype, device=chol.device)
         return _lib.chol_solve(chol, eye.expand(chol.shape))               # differentiable route

@@ -124,7 +124,7 @@ class GaussianProcessRegression:
         """``log p(y | ϑ)`` summed over the batch (gaussian_process_regression.py:150-160)."""
         per_series = self._fused_log_likelihood_per_series()
         if per_series is not None:
-            return torch.sum(per_series)
+            return _lib.checked(torch.sum(per_series))
         return self._kalman.log_likelihood()
 
     def loss(self) -> torch.Tensor:

@@ -342,7 +342,7 @@ class StateSpaceModel(GaussMarkovDistribution):
                 if self.state_dim > _lib.load().mf_max_state_dim():
                     raise NotImplementedError("gradients of kl_divergence: state_dim <= 9")
                 return _KLDivergence.apply(*tensors).reshape(tuple(self.batch_shape))
-        return self._kl_divergence_value(dist)
+        return _lib.checked(self._kl_divergence_value(dist))
 
     def _kl_divergence_value(self, dist: GaussMarkovDistribution, keep_moments: bool = False):
         """The divergence from its local form (``mf_ssm_kl_divergence_*``): one sweep per series when the batch fills the chip,

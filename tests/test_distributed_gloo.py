@@ -1,5 +1,5 @@
 """
-Multi-process (world_size 2, gloo, CPU) test of the batch-sharded path of markovflow_amd.distributed.
+Multi-process (world sizes 2, 4 and 8, gloo, CPU) test of the batch-sharded path of markovflow_amd.distributed.
 
 The HIP kernels cannot run here, so every rank's LOCAL log-likelihood comes from the numpy oracle (the
 checker); what is under test is the host logic of the sharded path: contiguous, non-overlapping, exhaustive
@@ -64,19 +64,21 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("bsz", [6, 5, 1])
-def test_sharded_log_likelihood_world2_gloo(bsz):
-    world = 2
+@pytest.mark.parametrize("world,bsz", [(2, 6), (2, 5), (2, 1), (4, 5), (4, 3), (8, 11), (8, 3)])
+def test_sharded_log_likelihood_gloo(world, bsz):
+    """world sizes 2, 4, 8 with even, uneven and EMPTY shards (bsz < world): the 8-GPU node's layout, on CPU"""
     with mp.Manager() as manager:
         results = manager.dict()
         mp.spawn(_worker, args=(world, _free_port(), bsz, results), nprocs=world, join=True)
         results = dict(results)
     expect = float(O.kf_log_likelihood(r_inv=np.array([[4.0]]), **_inputs(bsz)))
-    bounds = sorted((lo, hi) for lo, hi, _ in results.values())
-    assert bounds[0][0] == 0 and bounds[-1][1] == bsz and bounds[0][1] == bounds[1][0]
+    assert sorted(results) == list(range(world))
+    bounds = [results[r][:2] for r in range(world)]                      # contiguous, in rank order, exhaustive
+    assert bounds[0][0] == 0 and bounds[-1][1] == bsz
+    assert all(bounds[r][1] == bounds[r + 1][0] for r in range(world - 1))
     for rank in range(world):
         assert results[rank][2] == pytest.approx(expect, rel=1e-12)
-    assert results[0][2] == results[1][2]          # bit-identical on every rank
+    assert len({results[r][2] for r in range(world)}) == 1               # bit-identical on every rank
 
 
 @pytest.mark.parametrize("n,world", [(0, 1), (1, 8), (7, 8), (8, 8), (1024, 8), (4099, 8), (5, 2)])
@@ -126,10 +128,10 @@ def _elbo_worker(rank, world, port, bsz, results):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("bsz", [6, 3, 1])
-def test_sharded_kl_and_elbo_world2_gloo(bsz):
-    """BASELINE config 4's exchange step: the ELBO of a batch sharded over the ranks is one scalar all-reduce."""
-    world = 2
+@pytest.mark.parametrize("world,bsz", [(2, 6), (2, 3), (2, 1), (4, 6), (4, 2), (8, 12), (8, 5)])
+def test_sharded_kl_and_elbo_gloo(world, bsz):
+    """BASELINE config 4's exchange step: the ELBO of a batch sharded over the ranks is one scalar all-reduce (world sizes
+    2, 4, 8; uneven and empty shards)."""
     with mp.Manager() as manager:
         results = manager.dict()
         mp.spawn(_elbo_worker, args=(world, _free_port(), bsz, results), nprocs=world, join=True)
@@ -141,4 +143,4 @@ def test_sharded_kl_and_elbo_world2_gloo(bsz):
     for rank in range(world):
         assert results[rank][0] == pytest.approx(kl, rel=1e-12)
         assert results[rank][1] == pytest.approx(ell - kl, rel=1e-12)
-    assert results[0] == results[1]
+    assert len({results[r] for r in range(world)}) == 1

@@ -200,6 +200,46 @@ def test_non_positive_pivot_is_reported_like_the_reference(rng, monkeypatch):
     _lib.check_errors()
 
 
+def test_a_failure_survives_later_library_calls_until_it_is_looked_at(rng):
+    """failing cholesky, then a NON-factorising call (solve) while the first kernel may still be running, then
+    check_errors(): the failure must be raised and must name the cholesky.  (A clean unsynchronised look used to forget the
+    names on record, and check_errors() then skipped the flag.)"""
+    from markovflow_amd import _lib
+    _lib.check_errors()
+    n = 4000                                                             # long enough to still be running at the next call
+    diag = np.tile(np.eye(3), (2, n, 1, 1))
+    diag[:, -1] = -np.eye(3)                                              # the LAST block fails: the flag is raised late
+    sym = mfa.SymmetricBlockTriDiagonal(tt(diag))
+    chol = sym.cholesky
+    try:
+        chol.solve(tt(np.ones((2, n, 3))))                                # may or may not see the flag already
+        with pytest.raises(_lib.MarkovflowAmdError, match="SymmetricBlockTriDiagonal.cholesky"):
+            _lib.check_errors()
+    except _lib.MarkovflowAmdError as e:                                  # the kernel had already finished: raised by solve's look
+        assert "SymmetricBlockTriDiagonal.cholesky" in str(e)
+    _lib.check_errors()
+
+
+def test_a_bad_log_likelihood_raises_when_the_host_reads_it(rng):
+    """TensorFlow raises inside the Cholesky (block_tri_diag.py:423-436).  `float(kf.log_likelihood())` on a model whose
+    posterior precision is not positive definite raises here too - at the host read, which is the synchronisation the
+    caller performs anyway - without check_errors() and without MF_CHECK_PIVOTS."""
+    from markovflow_amd import _lib
+    from markovflow_amd import synthetic
+    _lib.check_errors()
+    inp = synthetic.make_ssm(3, 40, (3, 3), dtype=torch.float64, device=DEV)
+    good = float(synthetic.kalman_filter_from(inp).log_likelihood())
+    assert np.isfinite(good)
+    inp["cholQ"][1, 17] = 0.0                                             # a singular process covariance in one series
+    kf = synthetic.kalman_filter_from(inp)
+    ll = kf.log_likelihood()                                              # nothing raised yet: no host read, no synchronisation
+    with pytest.raises(_lib.MarkovflowAmdError, match="log_likelihood"):
+        float(ll)
+    _lib.check_errors()                                                   # reported once
+    with mfa.errors_as_nan():
+        assert not np.isfinite(float(kf.log_likelihood()))
+
+
 def test_unsupported_state_dim_fails_loudly(rng):
     diag = np.tile(np.eye(40), (1, 3, 1, 1))        # fp64: register kernels to d = 9, LDS-tile kernels to d = 32
     with pytest.raises(NotImplementedError):

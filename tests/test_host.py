@@ -173,3 +173,71 @@ def test_bench_refuses_more_gpus_than_visible():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], capture_output=True, text=True, timeout=300)
     assert proc.returncode == 2 and "--gpus 64" in proc.stderr
+
+
+@pytest.mark.parametrize("gpus", [2, 4, 8])
+def test_bench_dry_launch_runs_the_rank_plumbing_without_a_gpu(gpus):
+    """`bench.py --gpus N --dry-launch`: the GPU-free parent (it asserts that it never imported torch) spawns N ranks through
+    torch.distributed.run; they join a gloo group, shard the batch and all-reduce a probe.  Port / argv / environment /
+    stdout discipline / return code of the real multi-GPU launch, in CI."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--dry-launch", "--batch", "1000"],
+                          capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, proc.stdout                                    # rank 0's stdout carries exactly one JSON line
+    out = json.loads(lines[0])
+    assert out["dry_launch"] and out["n_gpus"] == gpus and out["ranks_seen"] == gpus
+    assert out["series_total"] == 1000 * gpus and out["ipc_mode_legacy"] == "0"
+
+
+def test_visible_gpus_opens_no_runtime():
+    """The launcher counts GPUs from sysfs: no torch, no HIP library in the process afterwards."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import bench; n = bench.visible_gpus(); "
+            "assert 'torch' not in sys.modules; "
+            "maps = open('/proc/self/maps').read(); assert 'libamdhip64' not in maps and 'libhsa-runtime' not in maps; print(n)" % root)
+    proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert proc.returncode == 0, proc.stderr
+    assert int(proc.stdout.strip()) >= 0
+
+
+def test_deferred_pivot_failures_keep_their_names_until_a_synchronised_look():
+    """an unsynchronised clean look at the pivot flag must not forget the factorisations on record; the
+    flag is read whether or not a name is recorded; a synchronised clean look clears the record.  (CPU: a stand-in flag.)"""
+    import ctypes
+    from markovflow_amd import _lib
+    flag = torch.zeros(1, dtype=torch.int32)
+    saved_flags, saved_issued = dict(_lib._flags), list(_lib._issued)
+    try:
+        _lib._flags.clear()
+        _lib._issued.clear()
+        _lib._flags[0] = (flag, ctypes.c_void_p(flag.data_ptr()), ctypes.c_int.from_address(flag.data_ptr()))
+        _lib._issued.append("SymmetricBlockTriDiagonal.cholesky")
+        _lib.raise_pending()                                   # e.g. the look at the start of a later solve: kernel still running
+        assert _lib._issued == ["SymmetricBlockTriDiagonal.cholesky"]
+        flag[0] = 1                                            # ... the kernel finishes and raises the flag
+        with pytest.raises(_lib.MarkovflowAmdError, match="SymmetricBlockTriDiagonal.cholesky"):
+            _lib.raise_pending(synced=True)
+        assert int(flag[0]) == 0 and _lib._issued == []
+        flag[0] = 1                                            # a flag without any name on record is still reported
+        with pytest.raises(_lib.MarkovflowAmdError, match="a factorisation"):
+            _lib.raise_pending()
+        _lib._issued.append("x")
+        _lib.raise_pending(synced=True)                        # synchronised and clean: the record is dropped
+        assert _lib._issued == []
+        # results that reach the host look at the flag
+        val = _lib.checked(torch.tensor(2.0, dtype=torch.float64))
+        assert float(val + 1) == 3.0
+        flag[0] = 1
+        with pytest.raises(_lib.MarkovflowAmdError):
+            (val * 2).item()
+    finally:
+        _lib._flags.clear()
+        _lib._flags.update(saved_flags)
+        _lib._issued[:] = saved_issued
