@@ -124,6 +124,32 @@ def make_ssm(
     return out
 
 
+def make_dense_ssm(batch: int, num_points: int, state_dim: int, output_dim: int, *, dtype=torch.float32, device="cuda",
+                   seed: int = DEFAULT_SEED, noise_std: float = 0.3) -> Dict[str, torch.Tensor]:
+    """
+    The shape of BASELINE config 5 (spatio-temporal model: ``state_dim`` = 64 latent states behind ``output_dim`` = 32 spatial
+    outputs, ``models/spatio_temporal_variational.py:45-85`` of the reference): dense, well-conditioned random transitions
+    ``A_k = 0.9 I + N(0, 0.09 / d)``, process factors ``tril(N(0, 0.09 / d)) + 0.5 I``, a dense emission matrix.  Same keys as
+    :func:`make_ssm`.
+    """
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    d, n, m = state_dim, num_points, output_dim
+    kw = dict(dtype=dtype, device=device, generator=gen)
+    eye = torch.eye(d, dtype=dtype, device=device)
+    sc = 0.3 / d ** 0.5
+    return {
+        "A": 0.9 * eye + sc * torch.randn(batch, n - 1, d, d, **kw),
+        "cholQ": torch.tril(sc * torch.randn(batch, n - 1, d, d, **kw)) + 0.5 * eye,
+        "cholP0": torch.tril(0.1 * torch.randn(batch, d, d, **kw)) + eye,
+        "mu0": torch.randn(batch, d, **kw),
+        "b": 0.1 * torch.randn(batch, n - 1, d, **kw),
+        "H": torch.randn(batch, n, m, d, **kw) / d ** 0.5,
+        "y": torch.randn(batch, n, m, **kw),
+        "cholR": noise_std * torch.eye(m, dtype=dtype, device=device),
+    }
+
+
 def kalman_filter_from(inputs: Dict[str, torch.Tensor]):
     """Build ``KalmanFilter`` from the dict returned by :func:`make_ssm`."""
     from . import EmissionModel, KalmanFilter, StateSpaceModel

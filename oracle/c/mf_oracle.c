@@ -22,6 +22,7 @@
 #include <string.h>
 
 #define MAXD 64
+#define MAXM 32
 /* every helper is force-inlined: the fixed-size entry points below (d = 6, m = 1: the benchmark configuration) call the same
  * code with literal dimensions, so the compiler unrolls and vectorises it the way a build specialised for that model would -
  * the timed CPU baseline is then not handicapped by run-time loop bounds */
@@ -187,11 +188,11 @@ int mf_oracle_btd_solve_f64(int64_t B, int64_t T, int d, const double *ldiag, co
 MF_INLINE int kf_loglik_body(int64_t B, int64_t T, const int d, const int m, const double *mu0, const double *cholP0,
                             const double *A, const double *b, const double *cholQ, const double *H,
                             const double *y, const double *Rinv, int rinv_per_step, double *out) {
-    if (d > MAXD || m > 8) return -3;
+    if (d > MAXD || m > MAXM) return -3;
     int bad = 0;
     double logdet_rinv = 0.0;
     if (!rinv_per_step) {
-        double tmp[64];
+        double tmp[MAXM * MAXM];
         memcpy(tmp, Rinv, sizeof(double) * m * m);
         if (chol_lower(tmp, m)) return -12;
         for (int i = 0; i < m; ++i) logdet_rinv += 2.0 * log(tmp[i * m + i]);
@@ -210,18 +211,23 @@ MF_INLINE int kf_loglik_body(int64_t B, int64_t T, const int d, const int m, con
             const double *ys = y + (size_t)s * T * m;
             const double *P0 = cholP0 + (size_t)s * d * d;
             build_precision((int)T, d, P0, As, Qs, diag, sub);
-            double mu[MAXD], nxt[MAXD], disp[8], rv[8];
+            double mu[MAXD], nxt[MAXD], disp[MAXM], rv[MAXM], rh[MAXM * MAXD];
             memcpy(mu, mu0 + (size_t)s * d, sizeof(double) * d);
             double term1 = 0.0;
             for (int64_t k = 0; k < T; ++k) {
                 const double *ri = rinv_per_step ? Rinv + ((size_t)s * T + k) * m * m : Rinv;
                 const double *h = Hs + (size_t)k * m * d;
                 double *dk = diag + (size_t)k * d * d;
-                for (int i = 0; i < d; ++i)                       /* + H^T R^-1 H */
+                for (int o = 0; o < m; ++o)                       /* R^-1 H, then + H^T (R^-1 H) */
                     for (int j = 0; j < d; ++j) {
                         double acc = 0.0;
-                        for (int o = 0; o < m; ++o)
-                            for (int p = 0; p < m; ++p) acc += h[o * d + i] * ri[o * m + p] * h[p * d + j];
+                        for (int p = 0; p < m; ++p) acc += ri[o * m + p] * h[p * d + j];
+                        rh[o * d + j] = acc;
+                    }
+                for (int i = 0; i < d; ++i)
+                    for (int j = 0; j < d; ++j) {
+                        double acc = 0.0;
+                        for (int o = 0; o < m; ++o) acc += h[o * d + i] * rh[o * d + j];
                         dk[i * d + j] += acc;
                     }
                 for (int o = 0; o < m; ++o) {                     /* disp = y - H mu */
