@@ -409,13 +409,19 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    # per-step durations from events recorded on the launch stream inside the timed region (no synchronisation between steps):
+    # the JSON line carries min / median beside the wall-clock mean, 20-100 steps of ~1.5 ms are a small sample
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        marks[i].record()
         ll = step()
+    marks[args.steps].record()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     # dominant-kernel duration: separate short loop so that reading the events does not perturb the timed region
     kernel_ms = []
     for _ in range(min(args.steps, 10)):
@@ -445,8 +451,11 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fh:
             entry = json.load(fh).get(f"kf_loglik B={bsz} T={tn} d={d} m={m} {args.dtype}")
-        # only when the counters were collected on THIS build of the library (mf_version): a stale figure is worse than none
-        if entry and args.chunks == 0 and entry.get("library_version") == int(_lib.load().mf_version()):
+        # only when the counters were collected on exactly THESE library sources (sha256 over markovflow_amd/csrc + the header,
+        # scripts/csrc_hash.py): a stale figure is worse than none
+        from scripts.csrc_hash import csrc_hash
+
+        if entry and args.chunks == 0 and entry.get("csrc_sha256") == csrc_hash(ROOT):
             traffic, traffic_src = entry["traffic_bytes"], entry["source"]
     except OSError:
         pass
@@ -460,6 +469,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
+        "ms_per_step_min": step_ms[0], "ms_per_step_median": step_ms[len(step_ms) // 2],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

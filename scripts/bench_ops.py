@@ -1,5 +1,8 @@
-"""Times every operator entry point of the C ABI at one shape and prints algorithmic GB/s (bytes per block as in
-DESIGN.md section 4.2).  Usage: python3 scripts/bench_ops.py [--batch B --T T --d d --dtype f64]."""
+"""Times every operator entry point of the C ABI at one shape and prints algorithmic GB/s.  The byte model of every row is
+that of the algorithm THIS library runs (inputs read once + outputs written once) - not of the
+reference's route: `marginal_covariances` is one forward sweep over A and cholQ (3 d^2), the fused `kl_divergence` reads both
+chains once (4 d^2 + 2 d), the fused posterior chain reads the model and writes the chain (4 d^2 + ...).  A figure above the
+8 TB/s HBM peak means the byte model is wrong and the script says so.  Usage: python3 scripts/bench_ops.py [--batch B --T T --d d --dtype f64]."""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,6 +19,7 @@ inp = synthetic.make_ssm(a.batch, a.T, comp, dtype=dt, device=dev)
 kf = synthetic.kalman_filter_from(inp)
 ssm = kf.prior_ssm
 B, T, d, s = a.batch, a.T, a.d, (8 if dt == torch.float64 else 4)
+m = inp["H"].shape[-2]
 
 def timeit(fn):
     for _ in range(2): fn()
@@ -31,7 +35,7 @@ chol = post_prec.cholesky
 rhs = torch.randn(B, T, d, dtype=dt, device=dev)
 post = kf.posterior_state_space_model()
 rows = [
-    ("KalmanFilter.log_likelihood", kf.log_likelihood, 2 * d * d + 3 * d + 1),
+    ("KalmanFilter.log_likelihood", kf.log_likelihood, synthetic.loglik_bytes_per_step(d, m, 1)),
     ("_k_inv_post (ssm_precision)", lambda: kf._k_inv_post, 4 * d * d + d),
     ("Sym.cholesky", lambda: post_prec.cholesky, 4 * d * d),
     ("Lower.solve", lambda: chol.solve(rhs), 2 * d * d + 2 * d),
@@ -41,11 +45,12 @@ rows = [
     ("Lower.block_diagonal_of_inverse", chol.block_diagonal_of_inverse, 3 * d * d),
     ("Sym.upper_diagonal_lower", post_prec.upper_diagonal_lower, 4 * d * d),
     ("ssm.marginal_means", lambda: ssm.marginal_means, d * d + 2 * d),
-    ("ssm.marginal_covariances", lambda: ssm.marginal_covariances, 7 * d * d),
-    ("kf.posterior_state_space_model", kf.posterior_state_space_model, 6 * d * d + 4 * d),
-    ("post.kl_divergence(prior)", lambda: post.kl_divergence(ssm), 8 * d * d),
+    ("ssm.marginal_covariances", lambda: ssm.marginal_covariances, 3 * d * d),
+    ("kf.posterior_state_space_model", kf.posterior_state_space_model, 4 * d * d + 2 * d + m * d + m),
+    ("post.kl_divergence(prior)", lambda: post.kl_divergence(ssm), 4 * d * d + 2 * d),
 ]
 print(f"B={B} T={T} d={d} {a.dtype}  (time includes Python-side output allocation; GB/s = algorithmic bytes / time)")
 for name, fn, elems in rows:
     ms = timeit(fn)
-    print(f"  {name:34s} {ms:9.3f} ms   {B * T * elems * s / ms / 1e6:9.1f} GB/s")
+    gbs = B * T * elems * s / ms / 1e6
+    print(f"  {name:34s} {ms:9.3f} ms   {gbs:9.1f} GB/s" + ("   <-- ABOVE THE HBM PEAK: byte model wrong" if gbs > 8000 else ""))
