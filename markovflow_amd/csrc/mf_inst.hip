@@ -7,6 +7,7 @@
 #include "mf_kf_lds.hpp"
 #include "mf_kf_x.hpp"
 #include "mf_row.hpp"
+#include "mf_row_par.hpp"
 #include "mf_btd_par.hpp"
 #include "mf_gpr_fused.hpp"
 #include "mf_kl_grad.hpp"
@@ -409,6 +410,14 @@ inline long par_len0(long B, long n) {
     return n >= 2 * len ? len : 0;
 }
 
+// The parallel-in-time Cholesky / solve hierarchy in row form (mf_row_par.hpp: a 16-lane row per chunk instead of a lane):
+// from d = 5 on, where a block step on one lane is > 1 k instructions.  MF_BTD_ROW=0 / 1 forces it off / on (experiment builds).
+template <typename T> bool row_par_path() {
+    static const int force = [] { const char* e = mf_knob("MF_BTD_ROW"); return e ? std::atoi(e) : -1; }();
+    if (D + 1 > 16 || D < 2) return false;
+    return force >= 0 ? force != 0 : D >= 5;
+}
+
 struct ParPlan {
     int levels;          // number of reduced levels (>= 1)
     long n[24];          // n[0] = T, n[l] = blocks per series on level l
@@ -475,6 +484,34 @@ int btd_cholesky(long B, long n, const T* diag, const T* sub, T* ldiag, T* lsub,
         if (l == 0) return ParLevel<T>{diag, nullptr, nullptr, sub, n, n - 1, -1, 0};
         return ParLevel<T>{arr[l].Dv, arr[l].Gf, arr[l].GU, arr[l].F, pl.n[l], pl.n[l], 0, 0};
     };
+    if (row_par_path<T>()) {
+        if constexpr (D >= 2 && D + 1 <= 16) {
+            const dim3 blk(64);
+            auto rgrid = [](long rows) { return dim3((unsigned)cdiv(rows, 4)); };
+            for (int l = 0; l < pl.levels; ++l) {
+                const long P = pl.n[l + 1];
+                if (l == 0)
+                    hipLaunchKernelGGL((row::row_chol_up_kernel<T, D, false>), rgrid(B * P), blk, 0, st, level(l), B, pl.len[l], P,
+                                       arr[l + 1].Dv, arr[l + 1].Gf, arr[l + 1].GU, arr[l + 1].F, info);
+                else
+                    hipLaunchKernelGGL((row::row_chol_up_kernel<T, D, true>), rgrid(B * P), blk, 0, st, level(l), B, pl.len[l], P,
+                                       arr[l + 1].Dv, arr[l + 1].Gf, arr[l + 1].GU, arr[l + 1].F, info);
+            }
+            {
+                const int l = pl.levels;
+                hipLaunchKernelGGL((row::row_chol_down_kernel<T, D>), rgrid(B), blk, 0, st, level(l), B, pl.n[l], 1L,
+                                   static_cast<const T*>(nullptr), arr[l].Pn, info);
+            }
+            for (int l = pl.levels - 1; l >= 1; --l) {
+                const long P = pl.n[l + 1];
+                hipLaunchKernelGGL((row::row_chol_down_kernel<T, D>), rgrid(B * P), blk, 0, st, level(l), B, pl.len[l], P,
+                                   static_cast<const T*>(arr[l + 1].Pn), arr[l].Pn, info);
+            }
+            hipLaunchKernelGGL((row::row_chol_emit_kernel<T, D>), rgrid(B * pl.n[1]), blk, 0, st, B, n, len0, pl.n[1], diag, sub,
+                               static_cast<const T*>(arr[1].Pn), ldiag, lsub, info);
+        }
+        return hipGetLastError() == hipSuccess ? 0 : -1000;
+    }
     for (int l = 0; l < pl.levels; ++l) {
         const long P = pl.n[l + 1];
         constexpr int x_lds = LdsSpike<T, D>::BYTES;
@@ -531,6 +568,34 @@ int btd_solve(long Bl, long Br, long n, const T* ldiag, const T* lsub, const T* 
         arr[l].M = reinterpret_cast<T*>(p); p += align_up(size_t(Br) * pl.n[l] * D * D * sizeof(T));
         arr[l].c = reinterpret_cast<T*>(p); p += align_up(size_t(Br) * pl.n[l] * D * sizeof(T));
         arr[l].Z = reinterpret_cast<T*>(p); p += align_up(size_t(Br) * pl.n[l] * D * sizeof(T));
+    }
+    if (row_par_path<T>()) {
+        if constexpr (D >= 2 && D + 1 <= 16) {
+            const dim3 blk(64);
+            auto rgrid = [](long rows) { return dim3((unsigned)cdiv(rows, 4)); };
+            hipLaunchKernelGGL((row::row_solve_up0_kernel<T, D>), rgrid(Br * pl.n[1]), blk, 0, st, Bl, Br, n, len0, pl.n[1], ldiag,
+                               lsub, rhs, transpose, arr[1].M, arr[1].c);
+            for (int l = 1; l < pl.levels; ++l) {
+                const long P = pl.n[l + 1];
+                hipLaunchKernelGGL((row::row_affine_up_kernel<T, D>), rgrid(Br * P), blk, 0, st, Br, pl.n[l], pl.len[l], P,
+                                   static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c), arr[l + 1].M, arr[l + 1].c);
+            }
+            {
+                const int l = pl.levels;
+                hipLaunchKernelGGL((row::row_affine_down_kernel<T, D>), rgrid(Br), blk, 0, st, Br, pl.n[l], pl.n[l], 1L,
+                                   static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c),
+                                   static_cast<const T*>(nullptr), arr[l].Z);
+            }
+            for (int l = pl.levels - 1; l >= 1; --l) {
+                const long P = pl.n[l + 1];
+                hipLaunchKernelGGL((row::row_affine_down_kernel<T, D>), rgrid(Br * P), blk, 0, st, Br, pl.n[l], pl.len[l], P,
+                                   static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c),
+                                   static_cast<const T*>(arr[l + 1].Z), arr[l].Z);
+            }
+            hipLaunchKernelGGL((row::row_solve_emit_kernel<T, D>), rgrid(Br * pl.n[1]), blk, 0, st, Bl, Br, n, len0, pl.n[1], ldiag,
+                               lsub, rhs, static_cast<const T*>(arr[1].Z), transpose, out);
+        }
+        return hipGetLastError() == hipSuccess ? 0 : -1000;
     }
     hipLaunchKernelGGL((par_solve_up0_kernel<T, D>), dim3((unsigned)cdiv(Br * pl.n[1], 64)), dim3(64), 0, st, Bl, Br, n,
                        len0, pl.n[1], ldiag, lsub, rhs, transpose, arr[1].M, arr[1].c);
