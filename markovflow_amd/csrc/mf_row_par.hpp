@@ -15,7 +15,7 @@ namespace mf {
 namespace row {
 
 // wavefronts per SIMD the kernels below are compiled for: 128 registers (4 waves) hold the state up to 7 doubles per row
-constexpr int row_par_waves(int elem, int d) { return elem * d > 56 ? 3 : 4; }
+constexpr int row_par_waves(int elem, int d) { return elem * d > 56 ? 2 : 4; }   // (two sets of step data: one step of prefetch)
 
 // chunk (series s, chunk c) of the row this lane belongs to; rows past the end repeat the last chunk and store nothing
 struct RowChunkId {
@@ -118,7 +118,11 @@ template <typename T, int D> MF_DEV void load_col(const T* __restrict__ blk, int
     sfor<D>([&](auto j) { v[decltype(j)::value] = blk[decltype(j)::value * D + rc]; });
 }
 
+// Every kernel below loads the data of step k + 1 BEFORE it works step k (branch-free: clamped indices and flags): with one
+// chain per row nothing else hides the ~1-2 us of a dependent global load, and a row's step is now shorter than that.
+
 // ---- Cholesky: up-sweep (par_chol_up_kernel).  REDUCED: the level has future parts (Gf, GU); level 0 has none. ----
+template <typename T, int D> struct RowUpStep { T Dn[D], g1[D], g2[D], S[D]; T f2; };
 template <typename T, int D, bool REDUCED>
 __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_chol_up_kernel(ParLevel<T> in, long B, long len, long P, T* __restrict__ oDv,
                                                            T* __restrict__ oGf, T* __restrict__ oGU, T* __restrict__ oF,
@@ -129,38 +133,41 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_chol_up_k
     if (k1 > in.n) k1 = in.n;
     RowFact<T, D> E;
     E.init();
+    auto load = [&](long k, RowUpStep<T, D>& d) {
+        load_row<T, D>(in.Dv + (q.s * in.n + k) * D * D, q.rc, d.Dn);
+        if constexpr (REDUCED) {
+            const bool has2 = k + 1 < in.n;
+            load_row<T, D>(in.Gf + (q.s * in.n + k) * D * D, q.rc, d.g1);
+            load_row<T, D>(in.GU + (q.s * in.n + (has2 ? k + 1 : k)) * D * D, q.rc, d.g2);
+            d.f2 = has2 ? T(1) : T(0);
+        }
+        const long kc = k > 0 ? k : 1;                               // block 0 has no coupling: clamped, unused
+        load_row<T, D>(in.F + (q.s * in.f_stride + kc + in.f_off) * D * D, q.rc, d.S);
+    };
+    RowUpStep<T, D> cur, nxt;
+    load(k0, cur);
+    {   // coupling of the chunk's first block to its left neighbour, as columns
+        T xc[D];
+        const long kc = k0 > 0 ? k0 : 1;
+        load_col<T, D>(in.F + (q.s * in.f_stride + kc + in.f_off) * D * D, q.rc, xc);
+        const T keep = k0 > 0 ? T(1) : T(0);
+        sfor<D>([&](auto j) { E.Xa[decltype(j)::value] = xc[decltype(j)::value] * keep; });
+    }
     for (long k = k0; k < k1; ++k) {
         asm volatile("s_nop 4");
+        load(k + 1 < k1 ? k + 1 : k, nxt);
         const bool last = k + 1 == k1;
-        T Dn[D], fut[D];
-        load_row<T, D>(in.Dv + (q.s * in.n + k) * D * D, q.rc, Dn);
-        if constexpr (REDUCED) {
-            T g2[D];
-            const bool has2 = k + 1 < in.n;
-            load_row<T, D>(in.Gf + (q.s * in.n + k) * D * D, q.rc, fut);
-            load_row<T, D>(in.GU + (q.s * in.n + (has2 ? k + 1 : k)) * D * D, q.rc, g2);
-            const T f = has2 ? T(1) : T(0);
-            sfor<D>([&](auto j) { fut[decltype(j)::value] = __builtin_fma(g2[decltype(j)::value], f, fut[decltype(j)::value]); });
-        } else {
-            sfor<D>([&](auto j) { fut[decltype(j)::value] = T(0); });
-        }
+        T fut[D];
+        if constexpr (REDUCED) sfor<D>([&](auto j) { fut[decltype(j)::value] = __builtin_fma(cur.g2[decltype(j)::value], cur.f2, cur.g1[decltype(j)::value]); });
+        else sfor<D>([&](auto j) { fut[decltype(j)::value] = T(0); });
         if (last) {
             if (q.valid && q.r < D) sfor<D>([&](auto j) { oGf[q.id * D * D + q.r * D + decltype(j)::value] = fut[decltype(j)::value]; });
         } else if (REDUCED) {
-            sfor<D>([&](auto j) { Dn[decltype(j)::value] += fut[decltype(j)::value]; });
+            sfor<D>([&](auto j) { cur.Dn[decltype(j)::value] += fut[decltype(j)::value]; });
         }
-        const long kc = k > 0 ? k : 1;                               // block 0 has no coupling: clamped, unused
-        const T* fblk = in.F + (q.s * in.f_stride + kc + in.f_off) * D * D;
-        if (k == k0) {
-            const T keep = k > 0 ? T(1) : T(0);
-            T xc[D];
-            load_col<T, D>(fblk, q.rc, xc);
-            sfor<D>([&](auto j) { E.Phi[decltype(j)::value] = Dn[decltype(j)::value]; E.Xa[decltype(j)::value] = in.n > 1 ? xc[decltype(j)::value] * keep : T(0); });
-        } else {
-            T S[D];
-            load_row<T, D>(fblk, q.rc, S);
-            E.template advance<true, false>(S, Dn, q.r, nullptr, nullptr);
-        }
+        if (k == k0) sfor<D>([&](auto j) { E.Phi[decltype(j)::value] = cur.Dn[decltype(j)::value]; });
+        else E.template advance<true, false>(cur.S, cur.Dn, q.r, nullptr, nullptr);
+        cur = nxt;
     }
     if (q.valid && q.r < D) {
         sfor<D>([&](auto j) {
@@ -183,23 +190,29 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_chol_down
     if (k1 > lv.n) k1 = lv.n;
     RowFact<T, D> E;
     E.init();
+    // step data of block k: its own pivot part, the future parts of block k - 1 (Gf[k-1] + GU[k]), the coupling; block 0: clamped
+    auto load = [&](long k, RowUpStep<T, D>& d) {
+        const long kc = k > 0 ? k : 1;
+        load_row<T, D>(lv.Dv + (q.s * lv.n + k) * D * D, q.rc, d.Dn);
+        load_row<T, D>(lv.Gf + (q.s * lv.n + kc - 1) * D * D, q.rc, d.g1);
+        load_row<T, D>(lv.GU + (q.s * lv.n + (kc < lv.n ? kc : 0)) * D * D, q.rc, d.g2);
+        load_row<T, D>(lv.F + (q.s * lv.f_stride + (kc < lv.n ? kc : 0) + lv.f_off) * D * D, q.rc, d.S);
+    };
+    RowUpStep<T, D> cur, nxt;
+    load(k0, cur);
     if (q.c > 0) load_row<T, D>(up + (q.s * P + q.c - 1) * D * D, q.rc, E.Phi);
     for (long k = k0; k < k1; ++k) {
         asm volatile("s_nop 4");
-        T Dn[D];
-        load_row<T, D>(lv.Dv + (q.s * lv.n + k) * D * D, q.rc, Dn);
+        load(k + 1 < k1 ? k + 1 : k, nxt);
         if (k > 0) {
             // the pivot of block k - 1 at the moment block k is reached: natural-order pivot + its future part
-            T g1[D], g2[D], S[D];
-            load_row<T, D>(lv.Gf + (q.s * lv.n + k - 1) * D * D, q.rc, g1);
-            load_row<T, D>(lv.GU + (q.s * lv.n + k) * D * D, q.rc, g2);
-            load_row<T, D>(lv.F + (q.s * lv.f_stride + k + lv.f_off) * D * D, q.rc, S);
-            sfor<D>([&](auto j) { E.Phi[decltype(j)::value] += g1[decltype(j)::value] + g2[decltype(j)::value]; });
-            E.template advance<false, false>(S, Dn, q.r, nullptr, nullptr);
+            sfor<D>([&](auto j) { E.Phi[decltype(j)::value] += cur.g1[decltype(j)::value] + cur.g2[decltype(j)::value]; });
+            E.template advance<false, false>(cur.S, cur.Dn, q.r, nullptr, nullptr);
         } else {
-            sfor<D>([&](auto j) { E.Phi[decltype(j)::value] = Dn[decltype(j)::value]; });
+            sfor<D>([&](auto j) { E.Phi[decltype(j)::value] = cur.Dn[decltype(j)::value]; });
         }
         if (q.valid && q.r < D) sfor<D>([&](auto j) { Pn[(q.s * lv.n + k) * D * D + q.r * D + decltype(j)::value] = E.Phi[decltype(j)::value]; });
+        cur = nxt;
     }
     if (q.valid && E.bad && info) raise_info(info);
 }
@@ -218,6 +231,15 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_chol_emit
     const bool st = q.valid && q.r < D;
     auto lrow = [&](long k) { return st ? ldiag + (q.s * n + k) * D * D + q.r * D : nullptr; };
     auto wrow = [&](long kw) { return st ? lsub + (q.s * (n - 1) + kw) * D * D + q.r * D : nullptr; };
+    struct Step { T Dn[D], S[D]; };
+    // step k: the pivot part of block k + 1 and the coupling sub[k] of block k + 1 with block k (clamped at the end)
+    auto load = [&](long k, Step& d) {
+        const long kn = k + 1 < n ? k + 1 : n - 1, ks = k < n - 1 ? k : n - 2;
+        load_row<T, D>(diag + (q.s * n + kn) * D * D, q.rc, d.Dn);
+        load_row<T, D>(sub + (q.s * (n - 1) + (ks > 0 ? ks : 0)) * D * D, q.rc, d.S);
+    };
+    Step cur, nxt;
+    load(k0, cur);
     {
         T Dn[D];
         load_row<T, D>(diag + (q.s * n + k0) * D * D, q.rc, Dn);
@@ -232,10 +254,9 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_chol_emit
     }
     for (long k = k0; k + 1 < k1; ++k) {
         asm volatile("s_nop 4");
-        T Dn[D], S[D];
-        load_row<T, D>(diag + (q.s * n + k + 1) * D * D, q.rc, Dn);
-        load_row<T, D>(sub + (q.s * (n - 1) + k) * D * D, q.rc, S);
-        E.template advance<false, true>(S, Dn, q.r, lrow(k), wrow(k));
+        load(k + 2 < k1 ? k + 1 : k, nxt);
+        E.template advance<false, true>(cur.S, cur.Dn, q.r, lrow(k), wrow(k));
+        cur = nxt;
     }
     E.factor(q.r, lrow(k1 - 1));
     if (q.valid && E.bad && info) raise_info(info);
@@ -256,56 +277,65 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_solve_up0
     long p1 = p0 + len;
     if (p1 > n) p1 = n;
     const bool vec = q.r >= D;                                       // lane D (and its idle shadows): the vector column
-    T col[D];
-    sfor<D>([&](auto i) { col[decltype(i)::value] = T(0); });
+    struct Step { T Lrow[D], Wrow[D], rv[D], diag; };
+    auto load = [&](long p, Step& d) {
+        const long k = transpose ? n - 1 - p : p;
+        load_row<T, D>(ldiag + (s * n + k) * D * D, q.rc, d.Lrow);
+        d.diag = ldiag[(s * n + k) * D * D + q.rc * (D + 1)];
+        const T* rv = rhs + (rr * n + k) * D;
+        sfor<D>([&](auto i) { d.rv[decltype(i)::value] = rv[decltype(i)::value]; });
+        long kw = transpose ? k : k - 1;                             // coupling of position p with p - 1; position 0: clamped, unused
+        kw = kw < 0 ? 0 : (kw > n - 2 ? n - 2 : kw);
+        load_row<T, D>(lsub + (s * (n - 1) + kw) * D * D, q.rc, d.Wrow);
+    };
+    Step cur, nxt;
+    load(p0, cur);
+    T col[D], wc[D];
+    sfor<D>([&](auto i) { col[decltype(i)::value] = T(0); wc[decltype(i)::value] = T(0); });
+    if (p0 > 0) {
+        // the chunk starts from the identity map: Pm = -Wop, i.e. own column of W (forward) or own row (transposed)
+        const long k = transpose ? n - 1 - p0 : p0, kw = transpose ? k : k - 1;
+        const T* wblk = lsub + (s * (n - 1) + kw) * D * D;
+        if (transpose) load_row<T, D>(wblk, q.rc, wc); else load_col<T, D>(wblk, q.rc, wc);
+    }
     for (long p = p0; p < p1; ++p) {
         asm volatile("s_nop 4");
-        const long k = transpose ? n - 1 - p : p;
-        T Lrow[D], out[D];
-        load_row<T, D>(ldiag + (s * n + k) * D * D, q.rc, Lrow);
-        T dinv = t_rcp<T>(ldiag[(s * n + k) * D * D + q.rc * (D + 1)]);
-        const T* rv = rhs + (rr * n + k) * D;
-        sfor<D>([&](auto i) { out[decltype(i)::value] = vec ? rv[decltype(i)::value] : T(0); });
-        if (p > 0) {
-            long kw = transpose ? k : k - 1;
-            const T* wblk = lsub + (s * (n - 1) + kw) * D * D;
-            if (p == p0) {
-                // the chunk starts from the identity map: Pm = -Wop, i.e. own column of W (forward) or own row (transposed)
-                T wc[D];
-                if (transpose) load_row<T, D>(wblk, q.rc, wc); else load_col<T, D>(wblk, q.rc, wc);
-                sfor<D>([&](auto i) { out[decltype(i)::value] = vec ? out[decltype(i)::value] : -wc[decltype(i)::value]; });
+        load(p + 1 < p1 ? p + 1 : p, nxt);
+        T out[D];
+        T dinv = t_rcp<T>(cur.diag);
+        sfor<D>([&](auto i) { out[decltype(i)::value] = vec ? cur.rv[decltype(i)::value] : T(0); });
+        if (p == p0) {
+            sfor<D>([&](auto i) { out[decltype(i)::value] = vec ? out[decltype(i)::value] : -wc[decltype(i)::value]; });
+        } else {
+            fence(cur.Wrow);
+            if (!transpose) {
+                sfor<D>([&](auto j) {
+                    constexpr int jj = decltype(j)::value;
+                    sfor<D>([&](auto i) { Pp::template fnmac<decltype(i)::value>(out[decltype(i)::value], cur.Wrow[jj], col[jj]); });
+                });
             } else {
-                T Wrow[D];
-                load_row<T, D>(wblk, q.rc, Wrow);
-                fence(Wrow);
-                if (!transpose) {
-                    sfor<D>([&](auto j) {
-                        constexpr int jj = decltype(j)::value;
-                        sfor<D>([&](auto i) { Pp::template fnmac<decltype(i)::value>(out[decltype(i)::value], Wrow[jj], col[jj]); });
-                    });
-                } else {
-                    sfor<D>([&](auto j) {
-                        constexpr int jj = decltype(j)::value;
-                        sfor<D>([&](auto i) { Pp::template fnmac<jj>(out[decltype(i)::value], Wrow[decltype(i)::value], col[jj]); });
-                    });
-                }
+                sfor<D>([&](auto j) {
+                    constexpr int jj = decltype(j)::value;
+                    sfor<D>([&](auto i) { Pp::template fnmac<jj>(out[decltype(i)::value], cur.Wrow[decltype(i)::value], col[jj]); });
+                });
             }
         }
-        fence(Lrow);
+        fence(cur.Lrow);
         fence1(dinv);
         if (!transpose) {
             sfor<D>([&](auto kq) {
                 constexpr int kk = decltype(kq)::value;
                 col[kk] = out[kk] * Pp::template bcast<kk>(dinv);
-                sfor2<kk + 1, D>([&](auto i) { Pp::template fnmac<decltype(i)::value>(out[decltype(i)::value], Lrow[kk], col[kk]); });
+                sfor2<kk + 1, D>([&](auto i) { Pp::template fnmac<decltype(i)::value>(out[decltype(i)::value], cur.Lrow[kk], col[kk]); });
             });
         } else {
             sfor<D>([&](auto kq) {
                 constexpr int kk = D - 1 - decltype(kq)::value;
                 col[kk] = out[kk] * Pp::template bcast<kk>(dinv);
-                sfor<kk>([&](auto i) { Pp::template fnmac<kk>(out[decltype(i)::value], Lrow[decltype(i)::value], col[kk]); });
+                sfor<kk>([&](auto i) { Pp::template fnmac<kk>(out[decltype(i)::value], cur.Lrow[decltype(i)::value], col[kk]); });
             });
         }
+        cur = nxt;
     }
     if (q.valid) {
         if (q.r < D) sfor<D>([&](auto i) { oM[q.id * D * D + decltype(i)::value * D + q.r] = col[decltype(i)::value]; });
@@ -324,6 +354,14 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_affine_up
     long p1 = p0 + len;
     if (p1 > n) p1 = n;
     const bool vec = q.r >= D;
+    struct Step { T Mrow[D], cp[D]; };
+    auto load = [&](long p, Step& d) {
+        load_row<T, D>(M + (rr * n + p) * D * D, q.rc, d.Mrow);
+        const T* cp = cv + (rr * n + p) * D;
+        sfor<D>([&](auto i) { d.cp[decltype(i)::value] = cp[decltype(i)::value]; });
+    };
+    Step cur, nxt;
+    load(p0 + 1 < p1 ? p0 + 1 : p0, cur);
     T col[D];
     {
         T mc[D];
@@ -333,16 +371,16 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_affine_up
     }
     for (long p = p0 + 1; p < p1; ++p) {
         asm volatile("s_nop 4");
-        T Mrow[D], out[D];
-        load_row<T, D>(M + (rr * n + p) * D * D, q.rc, Mrow);
-        const T* cp = cv + (rr * n + p) * D;
-        sfor<D>([&](auto i) { out[decltype(i)::value] = vec ? cp[decltype(i)::value] : T(0); });
-        fence(Mrow);
+        load(p + 1 < p1 ? p + 1 : p, nxt);
+        T out[D];
+        sfor<D>([&](auto i) { out[decltype(i)::value] = vec ? cur.cp[decltype(i)::value] : T(0); });
+        fence(cur.Mrow);
         sfor<D>([&](auto j) {
             constexpr int jj = decltype(j)::value;
-            sfor<D>([&](auto i) { Pp::template fmac<decltype(i)::value>(out[decltype(i)::value], Mrow[jj], col[jj]); });
+            sfor<D>([&](auto i) { Pp::template fmac<decltype(i)::value>(out[decltype(i)::value], cur.Mrow[jj], col[jj]); });
         });
         sfor<D>([&](auto i) { col[decltype(i)::value] = out[decltype(i)::value]; });
+        cur = nxt;
     }
     if (q.valid) {
         if (q.r < D) sfor<D>([&](auto i) { oM[q.id * D * D + decltype(i)::value * D + q.r] = col[decltype(i)::value]; });
@@ -362,19 +400,26 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_affine_do
     const long p0 = q.c * len;
     long p1 = p0 + len;
     if (p1 > n) p1 = n;
+    struct Step { T Mrow[D], c; };
+    auto load = [&](long p, Step& d) {
+        load_row<T, D>(M + (rr * n + p) * D * D, q.rc, d.Mrow);
+        d.c = cv[(rr * n + p) * D + q.rc];
+    };
+    Step cur, nxt;
+    load(p0, cur);
     T z = T(0);
     if (q.c > 0) z = up[(rr * P + q.c - 1) * D + q.rc];
     for (long p = p0; p < p1; ++p) {
         asm volatile("s_nop 4");
-        T acc = cv[(rr * n + p) * D + q.rc];
+        load(p + 1 < p1 ? p + 1 : p, nxt);
+        T acc = cur.c;
         if (p > 0) {
-            T Mrow[D];
-            load_row<T, D>(M + (rr * n + p) * D * D, q.rc, Mrow);
             fence1(z);
-            sfor<D>([&](auto j) { Pp::template fmac<decltype(j)::value>(acc, z, Mrow[decltype(j)::value]); });
+            sfor<D>([&](auto j) { Pp::template fmac<decltype(j)::value>(acc, z, cur.Mrow[decltype(j)::value]); });
         }
         z = acc;
         if (q.valid && q.r < D) Z[(rr * n + p) * D + q.r] = z;
+        cur = nxt;
     }
 }
 
@@ -391,29 +436,38 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_solve_emi
     const long p0 = q.c * len;
     long p1 = p0 + len;
     if (p1 > n) p1 = n;
+    struct Step { T Lv[D], Wv[D], diag, x; };
+    // own row of L and of W (forward) or own columns (transposed)
+    auto load = [&](long p, Step& d) {
+        const long k = transpose ? n - 1 - p : p;
+        const T* lblk = ldiag + (s * n + k) * D * D;
+        long kw = transpose ? k : k - 1;
+        kw = kw < 0 ? 0 : (kw > n - 2 ? n - 2 : kw);
+        const T* wblk = lsub + (s * (n - 1) + kw) * D * D;
+        if (!transpose) { load_row<T, D>(lblk, q.rc, d.Lv); load_row<T, D>(wblk, q.rc, d.Wv); }
+        else { load_col<T, D>(lblk, q.rc, d.Lv); load_col<T, D>(wblk, q.rc, d.Wv); }
+        d.diag = lblk[q.rc * (D + 1)];
+        d.x = rhs[(rr * n + k) * D + q.rc];
+    };
+    Step cur, nxt;
+    load(p0, cur);
     T z = T(0);
     if (q.c > 0) z = up[(rr * P + q.c - 1) * D + q.rc];
     for (long p = p0; p < p1; ++p) {
         asm volatile("s_nop 4");
+        load(p + 1 < p1 ? p + 1 : p, nxt);
         const long k = transpose ? n - 1 - p : p;
-        // own row of L (forward) or own column (transposed), entries outside the lower triangle forced to zero
-        T Lv[D];
-        const T* lblk = ldiag + (s * n + k) * D * D;
-        if (!transpose) load_row<T, D>(lblk, q.rc, Lv); else load_col<T, D>(lblk, q.rc, Lv);
+        // entries outside the lower triangle forced to zero
         sfor<D>([&](auto j) {
             constexpr int jj = decltype(j)::value;
             const bool in_tri = transpose ? jj >= q.rc : jj <= q.rc;
-            Lv[jj] = in_tri ? Lv[jj] : T(0);
+            cur.Lv[jj] = in_tri ? cur.Lv[jj] : T(0);
         });
-        const T dinv = t_rcp<T>(lblk[q.rc * (D + 1)]);
-        T x = rhs[(rr * n + k) * D + q.rc];
+        const T dinv = t_rcp<T>(cur.diag);
+        T x = cur.x;
         if (p > 0) {
-            const long kw = transpose ? k : k - 1;
-            const T* wblk = lsub + (s * (n - 1) + kw) * D * D;
-            T Wv[D];
-            if (!transpose) load_row<T, D>(wblk, q.rc, Wv); else load_col<T, D>(wblk, q.rc, Wv);
             fence1(z);
-            sfor<D>([&](auto j) { Pp::template fnmac<decltype(j)::value>(x, z, Wv[decltype(j)::value]); });
+            sfor<D>([&](auto j) { Pp::template fnmac<decltype(j)::value>(x, z, cur.Wv[decltype(j)::value]); });
         }
         T res = T(0);
         if (!transpose) {
@@ -422,7 +476,7 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_solve_emi
                 T xs = x * dinv;
                 res = q.rc == kk ? xs : res;
                 fence1(xs);
-                Pp::template fnmac<kk>(x, xs, Lv[kk]);               // x_i -= L[i][kk] z_kk   (zero above the diagonal)
+                Pp::template fnmac<kk>(x, xs, cur.Lv[kk]);           // x_i -= L[i][kk] z_kk   (zero above the diagonal)
             });
         } else {
             sfor<D>([&](auto kq) {
@@ -430,11 +484,12 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_solve_emi
                 T xs = x * dinv;
                 res = q.rc == kk ? xs : res;
                 fence1(xs);
-                Pp::template fnmac<kk>(x, xs, Lv[kk]);               // x_i -= L[kk][i] z_kk   (own column of L)
+                Pp::template fnmac<kk>(x, xs, cur.Lv[kk]);           // x_i -= L[kk][i] z_kk   (own column of L)
             });
         }
         z = res;
         if (q.valid && q.r < D) outp[(rr * n + k) * D + q.r] = z;
+        cur = nxt;
     }
 }
 

@@ -35,6 +35,6 @@ def _clean_pivot_flags():
         if _lib._flags:
             import torch
             torch.cuda.synchronize()
-            _lib._take_failures()
+            _lib._take_failures(synced=True)
     except Exception:
         pass

@@ -226,18 +226,22 @@ def test_a_bad_log_likelihood_raises_when_the_host_reads_it(rng):
     caller performs anyway - without check_errors() and without MF_CHECK_PIVOTS."""
     from markovflow_amd import _lib
     from markovflow_amd import synthetic
+    torch.cuda.synchronize()
     _lib.check_errors()
     inp = synthetic.make_ssm(3, 40, (3, 3), dtype=torch.float64, device=DEV)
-    good = float(synthetic.kalman_filter_from(inp).log_likelihood())
+    try:
+        good = float(synthetic.kalman_filter_from(inp).log_likelihood())
+    except _lib.MarkovflowAmdError as exc:                                # (seen once in ~10 runs of the whole suite, never alone)
+        pytest.fail(f"a positive definite model was flagged: {exc}")
     assert np.isfinite(good)
     inp["cholQ"][1, 17] = 0.0                                             # a singular process covariance in one series
     kf = synthetic.kalman_filter_from(inp)
     ll = kf.log_likelihood()                                              # nothing raised yet: no host read, no synchronisation
     with pytest.raises(_lib.MarkovflowAmdError, match="log_likelihood"):
         float(ll)
-    _lib.check_errors()                                                   # reported once
-    with mfa.errors_as_nan():
+    with mfa.errors_as_nan():                                             # opt-out: NaN, nothing raised, nothing left behind
         assert not np.isfinite(float(kf.log_likelihood()))
+    _lib.check_errors()
 
 
 def test_unsupported_state_dim_fails_loudly(rng):
