@@ -418,6 +418,9 @@ template <typename T> bool row_par_path() {
     return force >= 0 ? force != 0 : D >= 5;
 }
 
+// one step of prefetch in the row kernels when the level-0 rows are at most four wavefronts per SIMD
+inline bool row_par_prefetch(long rows0) { return rows0 <= 4L * 256 * 4 * 4; }
+
 struct ParPlan {
     int levels;          // number of reduced levels (>= 1)
     long n[24];          // n[0] = T, n[l] = blocks per series on level l
@@ -488,27 +491,33 @@ int btd_cholesky(long B, long n, const T* diag, const T* sub, T* ldiag, T* lsub,
         if constexpr (D >= 2 && D + 1 <= 16) {
             const dim3 blk(64);
             auto rgrid = [](long rows) { return dim3((unsigned)cdiv(rows, 4)); };
-            for (int l = 0; l < pl.levels; ++l) {
-                const long P = pl.n[l + 1];
-                if (l == 0)
-                    hipLaunchKernelGGL((row::row_chol_up_kernel<T, D, false>), rgrid(B * P), blk, 0, st, level(l), B, pl.len[l], P,
-                                       arr[l + 1].Dv, arr[l + 1].Gf, arr[l + 1].GU, arr[l + 1].F, info);
-                else
-                    hipLaunchKernelGGL((row::row_chol_up_kernel<T, D, true>), rgrid(B * P), blk, 0, st, level(l), B, pl.len[l], P,
-                                       arr[l + 1].Dv, arr[l + 1].Gf, arr[l + 1].GU, arr[l + 1].F, info);
-            }
-            {
-                const int l = pl.levels;
-                hipLaunchKernelGGL((row::row_chol_down_kernel<T, D>), rgrid(B), blk, 0, st, level(l), B, pl.n[l], 1L,
-                                   static_cast<const T*>(nullptr), arr[l].Pn, info);
-            }
-            for (int l = pl.levels - 1; l >= 1; --l) {
-                const long P = pl.n[l + 1];
-                hipLaunchKernelGGL((row::row_chol_down_kernel<T, D>), rgrid(B * P), blk, 0, st, level(l), B, pl.len[l], P,
-                                   static_cast<const T*>(arr[l + 1].Pn), arr[l].Pn, info);
-            }
-            hipLaunchKernelGGL((row::row_chol_emit_kernel<T, D>), rgrid(B * pl.n[1]), blk, 0, st, B, n, len0, pl.n[1], diag, sub,
-                               static_cast<const T*>(arr[1].Pn), ldiag, lsub, info);
+            auto run = [&](auto pf) {
+                constexpr bool PF = decltype(pf)::value;
+                for (int l = 0; l < pl.levels; ++l) {
+                    const long P = pl.n[l + 1];
+                    if (l == 0)
+                        hipLaunchKernelGGL((row::row_chol_up_kernel<T, D, false, PF>), rgrid(B * P), blk, 0, st, level(l), B, pl.len[l],
+                                           P, arr[l + 1].Dv, arr[l + 1].Gf, arr[l + 1].GU, arr[l + 1].F, info);
+                    else
+                        hipLaunchKernelGGL((row::row_chol_up_kernel<T, D, true, PF>), rgrid(B * P), blk, 0, st, level(l), B, pl.len[l],
+                                           P, arr[l + 1].Dv, arr[l + 1].Gf, arr[l + 1].GU, arr[l + 1].F, info);
+                }
+                {
+                    const int l = pl.levels;
+                    hipLaunchKernelGGL((row::row_chol_down_kernel<T, D, PF>), rgrid(B), blk, 0, st, level(l), B, pl.n[l], 1L,
+                                       static_cast<const T*>(nullptr), arr[l].Pn, info);
+                }
+                for (int l = pl.levels - 1; l >= 1; --l) {
+                    const long P = pl.n[l + 1];
+                    hipLaunchKernelGGL((row::row_chol_down_kernel<T, D, PF>), rgrid(B * P), blk, 0, st, level(l), B, pl.len[l], P,
+                                       static_cast<const T*>(arr[l + 1].Pn), arr[l].Pn, info);
+                }
+                hipLaunchKernelGGL((row::row_chol_emit_kernel<T, D, PF>), rgrid(B * pl.n[1]), blk, 0, st, B, n, len0, pl.n[1], diag,
+                                   sub, static_cast<const T*>(arr[1].Pn), ldiag, lsub, info);
+            };
+            // few rows (one long chain): nothing but a prefetch hides a step's loads; many rows: other wavefronts do, and the
+            // second set of step data would only cost occupancy
+            if (row_par_prefetch(B * pl.n[1])) run(std::true_type{}); else run(std::false_type{});
         }
         return hipGetLastError() == hipSuccess ? 0 : -1000;
     }
@@ -573,27 +582,31 @@ int btd_solve(long Bl, long Br, long n, const T* ldiag, const T* lsub, const T* 
         if constexpr (D >= 2 && D + 1 <= 16) {
             const dim3 blk(64);
             auto rgrid = [](long rows) { return dim3((unsigned)cdiv(rows, 4)); };
-            hipLaunchKernelGGL((row::row_solve_up0_kernel<T, D>), rgrid(Br * pl.n[1]), blk, 0, st, Bl, Br, n, len0, pl.n[1], ldiag,
-                               lsub, rhs, transpose, arr[1].M, arr[1].c);
-            for (int l = 1; l < pl.levels; ++l) {
-                const long P = pl.n[l + 1];
-                hipLaunchKernelGGL((row::row_affine_up_kernel<T, D>), rgrid(Br * P), blk, 0, st, Br, pl.n[l], pl.len[l], P,
-                                   static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c), arr[l + 1].M, arr[l + 1].c);
-            }
-            {
-                const int l = pl.levels;
-                hipLaunchKernelGGL((row::row_affine_down_kernel<T, D>), rgrid(Br), blk, 0, st, Br, pl.n[l], pl.n[l], 1L,
-                                   static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c),
-                                   static_cast<const T*>(nullptr), arr[l].Z);
-            }
-            for (int l = pl.levels - 1; l >= 1; --l) {
-                const long P = pl.n[l + 1];
-                hipLaunchKernelGGL((row::row_affine_down_kernel<T, D>), rgrid(Br * P), blk, 0, st, Br, pl.n[l], pl.len[l], P,
-                                   static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c),
-                                   static_cast<const T*>(arr[l + 1].Z), arr[l].Z);
-            }
-            hipLaunchKernelGGL((row::row_solve_emit_kernel<T, D>), rgrid(Br * pl.n[1]), blk, 0, st, Bl, Br, n, len0, pl.n[1], ldiag,
-                               lsub, rhs, static_cast<const T*>(arr[1].Z), transpose, out);
+            auto run = [&](auto pf) {
+                constexpr bool PF = decltype(pf)::value;
+                hipLaunchKernelGGL((row::row_solve_up0_kernel<T, D, PF>), rgrid(Br * pl.n[1]), blk, 0, st, Bl, Br, n, len0, pl.n[1],
+                                   ldiag, lsub, rhs, transpose, arr[1].M, arr[1].c);
+                for (int l = 1; l < pl.levels; ++l) {
+                    const long P = pl.n[l + 1];
+                    hipLaunchKernelGGL((row::row_affine_up_kernel<T, D, PF>), rgrid(Br * P), blk, 0, st, Br, pl.n[l], pl.len[l], P,
+                                       static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c), arr[l + 1].M, arr[l + 1].c);
+                }
+                {
+                    const int l = pl.levels;
+                    hipLaunchKernelGGL((row::row_affine_down_kernel<T, D, PF>), rgrid(Br), blk, 0, st, Br, pl.n[l], pl.n[l], 1L,
+                                       static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c),
+                                       static_cast<const T*>(nullptr), arr[l].Z);
+                }
+                for (int l = pl.levels - 1; l >= 1; --l) {
+                    const long P = pl.n[l + 1];
+                    hipLaunchKernelGGL((row::row_affine_down_kernel<T, D, PF>), rgrid(Br * P), blk, 0, st, Br, pl.n[l], pl.len[l], P,
+                                       static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c),
+                                       static_cast<const T*>(arr[l + 1].Z), arr[l].Z);
+                }
+                hipLaunchKernelGGL((row::row_solve_emit_kernel<T, D, PF>), rgrid(Br * pl.n[1]), blk, 0, st, Bl, Br, n, len0, pl.n[1],
+                                   ldiag, lsub, rhs, static_cast<const T*>(arr[1].Z), transpose, out);
+            };
+            if (row_par_prefetch(Br * pl.n[1])) run(std::true_type{}); else run(std::false_type{});
         }
         return hipGetLastError() == hipSuccess ? 0 : -1000;
     }

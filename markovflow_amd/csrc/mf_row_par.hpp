@@ -15,7 +15,8 @@ namespace mf {
 namespace row {
 
 // wavefronts per SIMD the kernels below are compiled for: 128 registers (4 waves) hold the state up to 7 doubles per row
-constexpr int row_par_waves(int elem, int d) { return elem * d > 56 ? 2 : 4; }   // (two sets of step data: one step of prefetch)
+// (PF: two sets of step data are live, one step of prefetch - chosen by the launcher when the rows are too few to hide a load)
+constexpr int row_par_waves(int elem, int d, bool pf) { return elem * d > 56 ? (pf ? 2 : 3) : 4; }
 
 // chunk (series s, chunk c) of the row this lane belongs to; rows past the end repeat the last chunk and store nothing
 struct RowChunkId {
@@ -123,8 +124,8 @@ template <typename T, int D> MF_DEV void load_col(const T* __restrict__ blk, int
 
 // ---- Cholesky: up-sweep (par_chol_up_kernel).  REDUCED: the level has future parts (Gf, GU); level 0 has none. ----
 template <typename T, int D> struct RowUpStep { T Dn[D], g1[D], g2[D], S[D]; T f2; };
-template <typename T, int D, bool REDUCED>
-__global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_chol_up_kernel(ParLevel<T> in, long B, long len, long P, T* __restrict__ oDv,
+template <typename T, int D, bool REDUCED, bool PF>
+__global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, PF)) row_chol_up_kernel(ParLevel<T> in, long B, long len, long P, T* __restrict__ oDv,
                                                            T* __restrict__ oGf, T* __restrict__ oGU, T* __restrict__ oF,
                                                            int* info) {
     const RowChunkId q = row_chunk_id<D>(B, P);
@@ -145,7 +146,7 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_chol_up_k
         load_row<T, D>(in.F + (q.s * in.f_stride + kc + in.f_off) * D * D, q.rc, d.S);
     };
     RowUpStep<T, D> cur, nxt;
-    load(k0, cur);
+    if constexpr (PF) load(k0, cur);
     {   // coupling of the chunk's first block to its left neighbour, as columns
         T xc[D];
         const long kc = k0 > 0 ? k0 : 1;
@@ -155,7 +156,7 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_chol_up_k
     }
     for (long k = k0; k < k1; ++k) {
         asm volatile("s_nop 4");
-        load(k + 1 < k1 ? k + 1 : k, nxt);
+        if constexpr (PF) load(k + 1 < k1 ? k + 1 : k, nxt); else load(k, cur);
         const bool last = k + 1 == k1;
         T fut[D];
         if constexpr (REDUCED) sfor<D>([&](auto j) { fut[decltype(j)::value] = __builtin_fma(cur.g2[decltype(j)::value], cur.f2, cur.g1[decltype(j)::value]); });
@@ -167,7 +168,7 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_chol_up_k
         }
         if (k == k0) sfor<D>([&](auto j) { E.Phi[decltype(j)::value] = cur.Dn[decltype(j)::value]; });
         else E.template advance<true, false>(cur.S, cur.Dn, q.r, nullptr, nullptr);
-        cur = nxt;
+        if constexpr (PF) cur = nxt;
     }
     if (q.valid && q.r < D) {
         sfor<D>([&](auto j) {
@@ -181,8 +182,8 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_chol_up_k
 }
 
 // ---- Cholesky: down-sweep on a reduced level (par_chol_down_kernel; also the serial walk of the coarsest level) ----
-template <typename T, int D>
-__global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_chol_down_kernel(ParLevel<T> lv, long B, long len, long P, const T* __restrict__ up,
+template <typename T, int D, bool PF>
+__global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, PF)) row_chol_down_kernel(ParLevel<T> lv, long B, long len, long P, const T* __restrict__ up,
                                                              T* __restrict__ Pn, int* info) {
     const RowChunkId q = row_chunk_id<D>(B, P);
     const long k0 = q.c * len;
@@ -199,11 +200,11 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_chol_down
         load_row<T, D>(lv.F + (q.s * lv.f_stride + (kc < lv.n ? kc : 0) + lv.f_off) * D * D, q.rc, d.S);
     };
     RowUpStep<T, D> cur, nxt;
-    load(k0, cur);
+    if constexpr (PF) load(k0, cur);
     if (q.c > 0) load_row<T, D>(up + (q.s * P + q.c - 1) * D * D, q.rc, E.Phi);
     for (long k = k0; k < k1; ++k) {
         asm volatile("s_nop 4");
-        load(k + 1 < k1 ? k + 1 : k, nxt);
+        if constexpr (PF) load(k + 1 < k1 ? k + 1 : k, nxt); else load(k, cur);
         if (k > 0) {
             // the pivot of block k - 1 at the moment block k is reached: natural-order pivot + its future part
             sfor<D>([&](auto j) { E.Phi[decltype(j)::value] += cur.g1[decltype(j)::value] + cur.g2[decltype(j)::value]; });
@@ -212,14 +213,14 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_chol_down
             sfor<D>([&](auto j) { E.Phi[decltype(j)::value] = cur.Dn[decltype(j)::value]; });
         }
         if (q.valid && q.r < D) sfor<D>([&](auto j) { Pn[(q.s * lv.n + k) * D * D + q.r * D + decltype(j)::value] = E.Phi[decltype(j)::value]; });
-        cur = nxt;
+        if constexpr (PF) cur = nxt;
     }
     if (q.valid && E.bad && info) raise_info(info);
 }
 
 // ---- Cholesky: level 0 emits the factor (par_chol_emit_kernel): chunk c restarts from the pivot of block c len - 1 ----
-template <typename T, int D>
-__global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_chol_emit_kernel(long B, long n, long len, long P, const T* __restrict__ diag,
+template <typename T, int D, bool PF>
+__global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, PF)) row_chol_emit_kernel(long B, long n, long len, long P, const T* __restrict__ diag,
                                                              const T* __restrict__ sub, const T* __restrict__ up,
                                                              T* __restrict__ ldiag, T* __restrict__ lsub, int* info) {
     const RowChunkId q = row_chunk_id<D>(B, P);
@@ -239,7 +240,7 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_chol_emit
         load_row<T, D>(sub + (q.s * (n - 1) + (ks > 0 ? ks : 0)) * D * D, q.rc, d.S);
     };
     Step cur, nxt;
-    load(k0, cur);
+    if constexpr (PF) load(k0, cur);
     {
         T Dn[D];
         load_row<T, D>(diag + (q.s * n + k0) * D * D, q.rc, Dn);
@@ -254,9 +255,9 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_chol_emit
     }
     for (long k = k0; k + 1 < k1; ++k) {
         asm volatile("s_nop 4");
-        load(k + 2 < k1 ? k + 1 : k, nxt);
+        if constexpr (PF) load(k + 2 < k1 ? k + 1 : k, nxt); else load(k, cur);
         E.template advance<false, true>(cur.S, cur.Dn, q.r, lrow(k), wrow(k));
-        cur = nxt;
+        if constexpr (PF) cur = nxt;
     }
     E.factor(q.r, lrow(k1 - 1));
     if (q.valid && E.bad && info) raise_info(info);
@@ -265,8 +266,8 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_chol_emit
 // ---- Solve: affine recursion z_p = M_p z_{p-1} + c_p over positions p (p = k, or n - 1 - k for the transposed solve) ----
 // level 0 -> level 1 (par_solve_up0_kernel): the composite map (Pm, q) of every chunk.  Lanes < D hold the columns of Pm, lane D
 // holds q: the coupling product and the substitution with the factor act on all D + 1 columns in the same instructions.
-template <typename T, int D>
-__global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_solve_up0_kernel(long Bl, long Br, long n, long len, long P,
+template <typename T, int D, bool PF>
+__global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, PF)) row_solve_up0_kernel(long Bl, long Br, long n, long len, long P,
                                                              const T* __restrict__ ldiag, const T* __restrict__ lsub,
                                                              const T* __restrict__ rhs, int transpose, T* __restrict__ oM,
                                                              T* __restrict__ oc) {
@@ -289,7 +290,7 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_solve_up0
         load_row<T, D>(lsub + (s * (n - 1) + kw) * D * D, q.rc, d.Wrow);
     };
     Step cur, nxt;
-    load(p0, cur);
+    if constexpr (PF) load(p0, cur);
     T col[D], wc[D];
     sfor<D>([&](auto i) { col[decltype(i)::value] = T(0); wc[decltype(i)::value] = T(0); });
     if (p0 > 0) {
@@ -300,7 +301,7 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_solve_up0
     }
     for (long p = p0; p < p1; ++p) {
         asm volatile("s_nop 4");
-        load(p + 1 < p1 ? p + 1 : p, nxt);
+        if constexpr (PF) load(p + 1 < p1 ? p + 1 : p, nxt); else load(p, cur);
         T out[D];
         T dinv = t_rcp<T>(cur.diag);
         sfor<D>([&](auto i) { out[decltype(i)::value] = vec ? cur.rv[decltype(i)::value] : T(0); });
@@ -335,7 +336,7 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_solve_up0
                 sfor<kk>([&](auto i) { Pp::template fnmac<kk>(out[decltype(i)::value], cur.Lrow[decltype(i)::value], col[kk]); });
             });
         }
-        cur = nxt;
+        if constexpr (PF) cur = nxt;
     }
     if (q.valid) {
         if (q.r < D) sfor<D>([&](auto i) { oM[q.id * D * D + decltype(i)::value * D + q.r] = col[decltype(i)::value]; });
@@ -344,8 +345,8 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_solve_up0
 }
 
 // level l -> level l + 1 (l >= 1): compose explicit maps (par_affine_up_kernel)
-template <typename T, int D>
-__global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_affine_up_kernel(long Br, long n, long len, long P, const T* __restrict__ M,
+template <typename T, int D, bool PF>
+__global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, PF)) row_affine_up_kernel(long Br, long n, long len, long P, const T* __restrict__ M,
                                                              const T* __restrict__ cv, T* __restrict__ oM, T* __restrict__ oc) {
     using Pp = Dpp<T>;
     const RowChunkId q = row_chunk_id<D>(Br, P);
@@ -361,7 +362,7 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_affine_up
         sfor<D>([&](auto i) { d.cp[decltype(i)::value] = cp[decltype(i)::value]; });
     };
     Step cur, nxt;
-    load(p0 + 1 < p1 ? p0 + 1 : p0, cur);
+    if constexpr (PF) load(p0 + 1 < p1 ? p0 + 1 : p0, cur);
     T col[D];
     {
         T mc[D];
@@ -371,7 +372,7 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_affine_up
     }
     for (long p = p0 + 1; p < p1; ++p) {
         asm volatile("s_nop 4");
-        load(p + 1 < p1 ? p + 1 : p, nxt);
+        if constexpr (PF) load(p + 1 < p1 ? p + 1 : p, nxt); else load(p, cur);
         T out[D];
         sfor<D>([&](auto i) { out[decltype(i)::value] = vec ? cur.cp[decltype(i)::value] : T(0); });
         fence(cur.Mrow);
@@ -380,7 +381,7 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_affine_up
             sfor<D>([&](auto i) { Pp::template fmac<decltype(i)::value>(out[decltype(i)::value], cur.Mrow[jj], col[jj]); });
         });
         sfor<D>([&](auto i) { col[decltype(i)::value] = out[decltype(i)::value]; });
-        cur = nxt;
+        if constexpr (PF) cur = nxt;
     }
     if (q.valid) {
         if (q.r < D) sfor<D>([&](auto i) { oM[q.id * D * D + decltype(i)::value * D + q.r] = col[decltype(i)::value]; });
@@ -390,8 +391,8 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_affine_up
 
 // down-sweep on a level >= 1 (and, with len >= n and up = null, the serial walk of the coarsest level): z distributed over
 // the lanes (lane i holds z_i), one broadcast-FMA per column of M
-template <typename T, int D>
-__global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_affine_down_kernel(long Br, long n, long len, long P, const T* __restrict__ M,
+template <typename T, int D, bool PF>
+__global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, PF)) row_affine_down_kernel(long Br, long n, long len, long P, const T* __restrict__ M,
                                                                const T* __restrict__ cv, const T* __restrict__ up,
                                                                T* __restrict__ Z) {
     using Pp = Dpp<T>;
@@ -406,12 +407,12 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_affine_do
         d.c = cv[(rr * n + p) * D + q.rc];
     };
     Step cur, nxt;
-    load(p0, cur);
+    if constexpr (PF) load(p0, cur);
     T z = T(0);
     if (q.c > 0) z = up[(rr * P + q.c - 1) * D + q.rc];
     for (long p = p0; p < p1; ++p) {
         asm volatile("s_nop 4");
-        load(p + 1 < p1 ? p + 1 : p, nxt);
+        if constexpr (PF) load(p + 1 < p1 ? p + 1 : p, nxt); else load(p, cur);
         T acc = cur.c;
         if (p > 0) {
             fence1(z);
@@ -419,14 +420,14 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_affine_do
         }
         z = acc;
         if (q.valid && q.r < D) Z[(rr * n + p) * D + q.r] = z;
-        cur = nxt;
+        if constexpr (PF) cur = nxt;
     }
 }
 
 // level 0 (par_solve_emit_kernel): every chunk redoes its substitution from the known incoming vector and writes the solution;
 // z, the right-hand side and the substitution are distributed over the lanes (lane i holds component i)
-template <typename T, int D>
-__global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_solve_emit_kernel(long Bl, long Br, long n, long len, long P,
+template <typename T, int D, bool PF>
+__global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, PF)) row_solve_emit_kernel(long Bl, long Br, long n, long len, long P,
                                                               const T* __restrict__ ldiag, const T* __restrict__ lsub,
                                                               const T* __restrict__ rhs, const T* __restrict__ up, int transpose,
                                                               T* __restrict__ outp) {
@@ -450,12 +451,12 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_solve_emi
         d.x = rhs[(rr * n + k) * D + q.rc];
     };
     Step cur, nxt;
-    load(p0, cur);
+    if constexpr (PF) load(p0, cur);
     T z = T(0);
     if (q.c > 0) z = up[(rr * P + q.c - 1) * D + q.rc];
     for (long p = p0; p < p1; ++p) {
         asm volatile("s_nop 4");
-        load(p + 1 < p1 ? p + 1 : p, nxt);
+        if constexpr (PF) load(p + 1 < p1 ? p + 1 : p, nxt); else load(p, cur);
         const long k = transpose ? n - 1 - p : p;
         // entries outside the lower triangle forced to zero
         sfor<D>([&](auto j) {
@@ -489,7 +490,7 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D)) row_solve_emi
         }
         z = res;
         if (q.valid && q.r < D) outp[(rr * n + k) * D + q.r] = z;
-        cur = nxt;
+        if constexpr (PF) cur = nxt;
     }
 }
 
