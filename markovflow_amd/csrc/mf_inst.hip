@@ -8,6 +8,7 @@
 #include "mf_kf_x.hpp"
 #include "mf_row.hpp"
 #include "mf_row_par.hpp"
+#include "mf_row_scan.hpp"
 #include "mf_btd_par.hpp"
 #include "mf_gpr_fused.hpp"
 #include "mf_kl_grad.hpp"
@@ -679,6 +680,39 @@ int tak_scan(long B, long n, TakSrc<T> src, T* odiag, T* osub, void* ws, size_t 
         arr[l].N = reinterpret_cast<T*>(p); p += sz;
         arr[l].Z = reinterpret_cast<T*>(p); p += sz;
     }
+    if constexpr (SRC == 1 && D >= 2 && D + 1 <= 16) {
+        if (row_par_path<T>()) {     // the forward covariance (and mean) scan in row form (mf_row_scan.hpp)
+            const dim3 blk(64);
+            auto rgrid = [](long rows) { return dim3((unsigned)cdiv(rows, 4)); };
+            if (mup.oc != nullptr)
+                hipLaunchKernelGGL((row::row_cov_up0_kernel<T, D, true>), rgrid(B * pl.n[1]), blk, 0, st, B, n, len0, pl.n[1], src,
+                                   arr[1].G, arr[1].N, mup);
+            else
+                hipLaunchKernelGGL((row::row_cov_up0_kernel<T, D, false>), rgrid(B * pl.n[1]), blk, 0, st, B, n, len0, pl.n[1], src,
+                                   arr[1].G, arr[1].N, TakMeanUp<T>{});
+            for (int l = 1; l < pl.levels; ++l) {
+                const long P = pl.n[l + 1];
+                hipLaunchKernelGGL((row::row_cov_up_kernel<T, D>), rgrid(B * P), blk, 0, st, B, pl.n[l], pl.len[l], P,
+                                   static_cast<const T*>(arr[l].G), static_cast<const T*>(arr[l].N), arr[l + 1].G, arr[l + 1].N);
+            }
+            {
+                const int l = pl.levels;
+                hipLaunchKernelGGL((row::row_cov_down_kernel<T, D>), rgrid(B), blk, 0, st, B, pl.n[l], pl.n[l], 1L,
+                                   static_cast<const T*>(arr[l].G), static_cast<const T*>(arr[l].N), static_cast<const T*>(nullptr),
+                                   arr[l].Z);
+            }
+            for (int l = pl.levels - 1; l >= 1; --l) {
+                const long P = pl.n[l + 1];
+                hipLaunchKernelGGL((row::row_cov_down_kernel<T, D>), rgrid(B * P), blk, 0, st, B, pl.n[l], pl.len[l], P,
+                                   static_cast<const T*>(arr[l].G), static_cast<const T*>(arr[l].N),
+                                   static_cast<const T*>(arr[l + 1].Z), arr[l].Z);
+            }
+            if (up_only) { *up_only = arr[1].Z; return hipGetLastError() == hipSuccess ? 0 : -1000; }
+            hipLaunchKernelGGL((row::row_cov_emit_kernel<T, D, false>), rgrid(B * pl.n[1]), blk, 0, st, B, n, len0, pl.n[1], src,
+                               static_cast<const T*>(arr[1].Z), odiag, osub, TakMean<T>{});
+            return hipGetLastError() == hipSuccess ? 0 : -1000;
+        }
+    }
     constexpr int g_lds = D * D * 64 * (int)sizeof(T);      // x path: the composed G of a run lives in LDS
     if (SRC == 1 && mup.oc != nullptr) {
         if (x_path<T>())
@@ -928,6 +962,13 @@ int ssm_marginals(long B, long n, const T* mu0, const T* cholP0, const T* A, con
     rc = ssm_means<T, false>(B, B, n, A, static_cast<const T*>(nullptr), omean, ws_mean, btd_solve_ws<T>(B, B, n), st, &up_mean,
                              true);
     if (rc != 0) return rc;
+    if constexpr (D >= 2 && D + 1 <= 16) {
+        if (row_par_path<T>()) {
+            hipLaunchKernelGGL((row::row_cov_emit_kernel<T, D, true>), dim3((unsigned)cdiv(B * P, 4)), dim3(64), 0, st, B, n, len0, P,
+                               src, up_cov, ocov, osub, TakMean<T>{mu0, b, omean, up_mean});
+            return hipGetLastError() == hipSuccess ? 0 : -1000;
+        }
+    }
     hipLaunchKernelGGL((par_tak_emit_kernel<T, D, 1, true>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, B, n, len0, P, src,
                        up_cov, ocov, osub, TakMean<T>{mu0, b, omean, up_mean});
     return hipGetLastError() == hipSuccess ? 0 : -1000;
@@ -1090,6 +1131,14 @@ int kl_value(long B, long Tn, const T* mu0_1, const T* C0_1, const T* A_1, const
         if (out_means) pm = out_means;
         const int rc = ssm_marginals<T>(B, Tn, mu0_1, C0_1, A_1, b_1, C_1, pm, pS, out_cross, p, marginals_ws<T>(B, Tn), st);
         if (rc != 0) return rc;
+        bool row_local = false;
+        if constexpr (D >= 2 && D + 1 <= 16) row_local = row_par_path<T>();
+        if (row_local) {
+            if constexpr (D >= 2 && D + 1 <= 16)
+                hipLaunchKernelGGL((row::row_kl_local_kernel<T, D>), dim3((unsigned)cdiv(B * Tn, 4)), dim3(64), 0, st, B, Tn, mu0_1,
+                                   C0_1, A_1, b_1, C_1, mu0_2, C0_2, A_2, b_2, C_2, static_cast<const T*>(pm),
+                                   static_cast<const T*>(pS), part, out_N, out_n, info);
+        } else
         hipLaunchKernelGGL((ssm_kl_local_kernel<T, D>), dim3((unsigned)cdiv(B * Tn, 64)), dim3(64), 0, st, B, Tn, mu0_1, C0_1,
                            A_1, b_1, C_1, mu0_2, C0_2, A_2, b_2, C_2, static_cast<const T*>(pm), static_cast<const T*>(pS),
                            part, out_N, out_n, info);

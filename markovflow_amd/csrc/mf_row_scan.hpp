@@ -1,0 +1,352 @@
+// Row forms (mf_row.hpp: one 16-lane DPP row per sub-problem) of the forward covariance / mean scans in time behind
+// StateSpaceModel.marginals (state_space_model.py:232-275) and of the local form of kl_divergence (state_space_model.py:528-593),
+// i.e. of par_tak_*<SRC = 1> (mf_btd_par.hpp) and ssm_kl_local_kernel (mf_kl_grad.hpp): same levels, same workspace tensors and
+// results.  At d = 9 those are the kernels a sparse-variational model's ELBO spends its time in (BASELINE config 4: the KL of
+// the posterior chain against the prior was 1.72 ms at 512 series x 1000 steps, 1.4 ms of it in these four kernels, each of
+// them a ~5 k-instruction step on one lane with the composed map in LDS).
+//
+// The recursion  Sigma_p = A Sigma_{p-1} A^T + C C^T,  mu_p = A mu_{p-1} + b  in row layout (lane i holds row i):
+//     A S      = sum_k own A_k * bcast_k(S_j)           (P Q form)
+//     (AS) A^T = sum_k own (AS)_k * bcast_j(A_k)        (P Q^T form)
+//     C C^T    = sum_{k <= j} own C_k * bcast_j(C_k)
+// and a vector is one more column handled by the same instructions (distributed over the lanes: lane i holds element i).
+#pragma once
+#include "mf_kl_grad.hpp"
+#include "mf_row_par.hpp"
+
+namespace mf {
+namespace row {
+
+// out[j] (+)= sum_k own a[k] * bcast_k(b[j])   for j < NJ:   rows of A B from rows of A and of B
+template <typename T, int D, int NJ> MF_DEV void row_mul(const T (&a)[D], const T (&b)[NJ], T (&out)[NJ]) {
+    using P = Dpp<T>;
+    sfor<D>([&](auto k) {
+        constexpr int kk = decltype(k)::value;
+        sfor<NJ>([&](auto j) { P::template fmac<kk>(out[decltype(j)::value], b[decltype(j)::value], a[kk]); });
+    });
+}
+// out[j] += sum_k own a[k] * bcast_j(b[k])     rows of A B^T from rows of A and of B
+template <typename T, int D> MF_DEV void row_mul_t(const T (&a)[D], const T (&b)[D], T (&out)[D]) {
+    using P = Dpp<T>;
+    sfor<D>([&](auto k) {
+        constexpr int kk = decltype(k)::value;
+        sfor<D>([&](auto j) { P::template fmac<decltype(j)::value>(out[decltype(j)::value], b[kk], a[kk]); });
+    });
+}
+// out[j] = sum_{k <= j} own c[k] * bcast_j(c[k]):  rows of C C^T for lower-triangular C (c: own row, zero above the diagonal)
+template <typename T, int D> MF_DEV void row_cct(const T (&c)[D], T (&out)[D]) {
+    using P = Dpp<T>;
+    sfor<D>([&](auto j) { out[decltype(j)::value] = T(0); });
+    sfor<D>([&](auto k) {
+        constexpr int kk = decltype(k)::value;
+        sfor2<kk, D>([&](auto j) { P::template fmac<decltype(j)::value>(out[decltype(j)::value], c[kk], c[kk]); });
+    });
+}
+template <typename T, int D> MF_DEV void load_row_lower(const T* __restrict__ blk, int rc, T (&v)[D]) {
+    sfor<D>([&](auto j) { v[decltype(j)::value] = decltype(j)::value <= rc ? blk[rc * D + decltype(j)::value] : T(0); });
+}
+
+// one position of the level-0 kernels: the transition into position p (p = 0: the prior)
+template <typename T, int D> struct RowCovStep {
+    T Arow[D], Crow[D], o;       // rows of A_{p-1} (zero for p = 0), of cholQ_{p-1} / cholP0 (zero above the diagonal), own offset element
+};
+template <typename T, int D, bool MEAN>
+MF_DEV void load_cov_step(const TakSrc<T>& src, const T* mu0, const T* b, long s, long n, long p, int rc, RowCovStep<T, D>& d) {
+    const long kt = p > 0 ? p - 1 : 0;
+    const T* cblk = p > 0 ? src.a + (s * (n - 1) + kt) * D * D : src.c0 + s * D * D;
+    load_row_lower<T, D>(cblk, rc, d.Crow);
+    if (n > 1) {
+        const T keep = p > 0 ? T(1) : T(0);
+        load_row<T, D>(src.b + (s * (n - 1) + kt) * D * D, rc, d.Arow);
+        sfor<D>([&](auto j) { d.Arow[decltype(j)::value] *= keep; });
+    } else {
+        sfor<D>([&](auto j) { d.Arow[decltype(j)::value] = T(0); });
+    }
+    if constexpr (MEAN) d.o = p > 0 ? b[(s * (n - 1) + kt) * D + rc] : mu0[s * D + rc];
+    else d.o = T(0);
+}
+
+// ---- level 0 up-sweep (par_tak_up0_kernel<SRC = 1>): the chunk's map  Sigma -> Mc Sigma Mc^T + Nc,  mu -> Mc mu + q ----
+template <typename T, int D, bool MEAN>
+__global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, false)) row_cov_up0_kernel(long B, long n, long len, long P, TakSrc<T> src,
+                                                                                           T* __restrict__ oG, T* __restrict__ oN,
+                                                                                           TakMeanUp<T> mup) {
+    const RowChunkId q = row_chunk_id<D>(B, P);
+    const long p0 = q.c * len;
+    long p1 = p0 + len;
+    if (p1 > n) p1 = n;
+    T Mr[D + 1], Nr[D];          // rows of Mc with the offset q as column D; rows of Nc
+    for (long p = p0; p < p1; ++p) {
+        asm volatile("s_nop 4");
+        RowCovStep<T, D> d;
+        load_cov_step<T, D, MEAN>(src, mup.mu0, mup.b, q.s, n, p, q.rc, d);
+        T Nn[D];
+        fence(d.Crow);
+        row_cct<T, D>(d.Crow, Nn);
+        if (p == p0) {
+            sfor<D>([&](auto j) { Mr[decltype(j)::value] = d.Arow[decltype(j)::value]; Nr[decltype(j)::value] = Nn[decltype(j)::value]; });
+            Mr[D] = d.o;
+        } else {
+            T T1[D + 1], T2[D];
+            sfor<D + 1>([&](auto j) { T1[decltype(j)::value] = T(0); });
+            sfor<D>([&](auto j) { T2[decltype(j)::value] = T(0); });
+            fence(Mr);
+            fence(Nr);
+            row_mul<T, D, D + 1>(d.Arow, Mr, T1);                     // A [Mc | q]
+            row_mul<T, D, D>(d.Arow, Nr, T2);                         // A Nc
+            fence(d.Arow);
+            row_mul_t<T, D>(T2, d.Arow, Nn);                          // + (A Nc) A^T
+            sfor<D>([&](auto j) { Mr[decltype(j)::value] = T1[decltype(j)::value]; Nr[decltype(j)::value] = Nn[decltype(j)::value]; });
+            Mr[D] = T1[D] + d.o;
+        }
+    }
+    if (q.valid && q.r < D) {
+        sfor<D>([&](auto j) {
+            constexpr int jj = decltype(j)::value;
+            oG[q.id * D * D + jj * D + q.r] = Mr[jj];                 // G = Mc^T
+            oN[q.id * D * D + q.r * D + jj] = Nr[jj];
+            if constexpr (MEAN) mup.oM[q.id * D * D + q.r * D + jj] = Mr[jj];
+        });
+        if constexpr (MEAN) mup.oc[q.id * D + q.r] = Mr[D];
+    }
+}
+
+// ---- reduced levels, up (par_tak_up_kernel): compose the maps of a run of chunks ----
+template <typename T, int D>
+__global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, false)) row_cov_up_kernel(long B, long n, long len, long P,
+                                                                                          const T* __restrict__ Gs, const T* __restrict__ Ns,
+                                                                                          T* __restrict__ oG, T* __restrict__ oN) {
+    const RowChunkId q = row_chunk_id<D>(B, P);
+    const long p0 = q.c * len;
+    long p1 = p0 + len;
+    if (p1 > n) p1 = n;
+    T Mr[D], Nr[D];
+    load_col<T, D>(Gs + (q.s * n + p0) * D * D, q.rc, Mr);            // rows of M = columns of G
+    load_row<T, D>(Ns + (q.s * n + p0) * D * D, q.rc, Nr);
+    for (long p = p0 + 1; p < p1; ++p) {
+        asm volatile("s_nop 4");
+        T Mp[D], Nn[D], T1[D], T2[D];
+        load_col<T, D>(Gs + (q.s * n + p) * D * D, q.rc, Mp);
+        load_row<T, D>(Ns + (q.s * n + p) * D * D, q.rc, Nn);
+        sfor<D>([&](auto j) { T1[decltype(j)::value] = T(0); T2[decltype(j)::value] = T(0); });
+        fence(Mr);
+        fence(Nr);
+        row_mul<T, D, D>(Mp, Mr, T1);
+        row_mul<T, D, D>(Mp, Nr, T2);
+        fence(Mp);
+        row_mul_t<T, D>(T2, Mp, Nn);
+        sfor<D>([&](auto j) { Mr[decltype(j)::value] = T1[decltype(j)::value]; Nr[decltype(j)::value] = Nn[decltype(j)::value]; });
+    }
+    if (q.valid && q.r < D) {
+        sfor<D>([&](auto j) {
+            constexpr int jj = decltype(j)::value;
+            oG[q.id * D * D + jj * D + q.r] = Mr[jj];
+            oN[q.id * D * D + q.r * D + jj] = Nr[jj];
+        });
+    }
+}
+
+// ---- reduced levels, down (par_tak_down_kernel): Sigma at every position of the level ----
+template <typename T, int D>
+__global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, false)) row_cov_down_kernel(long B, long n, long len, long P,
+                                                                                            const T* __restrict__ Gs, const T* __restrict__ Ns,
+                                                                                            const T* __restrict__ up, T* __restrict__ Z) {
+    const RowChunkId q = row_chunk_id<D>(B, P);
+    const long p0 = q.c * len;
+    long p1 = p0 + len;
+    if (p1 > n) p1 = n;
+    T Sr[D];
+    sfor<D>([&](auto j) { Sr[decltype(j)::value] = T(0); });
+    if (q.c > 0) load_row<T, D>(up + (q.s * P + q.c - 1) * D * D, q.rc, Sr);
+    for (long p = p0; p < p1; ++p) {
+        asm volatile("s_nop 4");
+        T Nn[D];
+        load_row<T, D>(Ns + (q.s * n + p) * D * D, q.rc, Nn);
+        if (p > 0) {
+            T Mp[D], T2[D];
+            load_col<T, D>(Gs + (q.s * n + p) * D * D, q.rc, Mp);
+            sfor<D>([&](auto j) { T2[decltype(j)::value] = T(0); });
+            fence(Sr);
+            row_mul<T, D, D>(Mp, Sr, T2);
+            fence(Mp);
+            row_mul_t<T, D>(T2, Mp, Nn);
+        }
+        sfor<D>([&](auto j) { Sr[decltype(j)::value] = Nn[decltype(j)::value]; });
+        if (q.valid && q.r < D) sfor<D>([&](auto j) { Z[(q.s * n + p) * D * D + q.r * D + decltype(j)::value] = Sr[decltype(j)::value]; });
+    }
+}
+
+// ---- level 0 emit (par_tak_emit_kernel<SRC = 1>): every chunk restarts from its boundary values and writes the marginal
+// covariances, Cov(x_p, x_{p-1}) = A Sigma_{p-1} (osub, optional) and - MEAN - the marginal means ----
+template <typename T, int D, bool MEAN>
+__global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, false)) row_cov_emit_kernel(long B, long n, long len, long P, TakSrc<T> src,
+                                                                                            const T* __restrict__ up, T* __restrict__ odiag,
+                                                                                            T* __restrict__ osub, TakMean<T> mean) {
+    using Pp = Dpp<T>;
+    const RowChunkId q = row_chunk_id<D>(B, P);
+    const long p0 = q.c * len;
+    long p1 = p0 + len;
+    if (p1 > n) p1 = n;
+    T Sr[D], mu = T(0);
+    sfor<D>([&](auto j) { Sr[decltype(j)::value] = T(0); });
+    if (q.c > 0) {
+        load_row<T, D>(up + (q.s * P + q.c - 1) * D * D, q.rc, Sr);
+        if constexpr (MEAN) mu = mean.up[(q.s * P + q.c - 1) * D + q.rc];
+    }
+    const bool st = q.valid && q.r < D;
+    for (long p = p0; p < p1; ++p) {
+        asm volatile("s_nop 4");
+        RowCovStep<T, D> d;
+        load_cov_step<T, D, MEAN>(src, mean.mu0, mean.b, q.s, n, p, q.rc, d);
+        T Nn[D];
+        fence(d.Crow);
+        row_cct<T, D>(d.Crow, Nn);
+        if (p > 0) {
+            T T2[D];
+            sfor<D>([&](auto j) { T2[decltype(j)::value] = T(0); });
+            fence(Sr);
+            row_mul<T, D, D>(d.Arow, Sr, T2);                          // A Sigma_{p-1}
+            if (osub && st) sfor<D>([&](auto j) { osub[(q.s * (n - 1) + p - 1) * D * D + q.r * D + decltype(j)::value] = T2[decltype(j)::value]; });
+            fence(d.Arow);
+            row_mul_t<T, D>(T2, d.Arow, Nn);
+            if constexpr (MEAN) {
+                T acc = d.o;
+                fence1(mu);
+                sfor<D>([&](auto k) { Pp::template fmac<decltype(k)::value>(acc, mu, d.Arow[decltype(k)::value]); });
+                mu = acc;
+            }
+        } else if constexpr (MEAN) {
+            mu = d.o;
+        }
+        sfor<D>([&](auto j) { Sr[decltype(j)::value] = Nn[decltype(j)::value]; });
+        if (st) {
+            sfor<D>([&](auto j) { odiag[(q.s * n + p) * D * D + q.r * D + decltype(j)::value] = Sr[decltype(j)::value]; });
+            if constexpr (MEAN) mean.out[(q.s * n + p) * D + q.r] = mu;
+        }
+    }
+}
+
+// ---- kl_divergence, local form (ssm_kl_local_kernel): a row per (series, step) ----
+// term(C2, C1, X): 1/2 [ |C2^-1 C1|_F^2 + |C2^-1 x|^2 (+ tr(W S W^T), W = C2^-1 X) ] + log|C2| - log|C1| with the D columns of X in
+// the lanes < D and the vector x in lane D: both go through ONE substitution with C2's rows broadcast.
+template <typename T, int D> struct RowKlTerm {
+    using P = Dpp<T>;
+    // in-lane forward substitution: col <- C2^-1 col   (C2r: own row of C2, dinv: own 1 / diagonal element)
+    static MF_DEV void solve(T (&C2r)[D], T dinv, T (&col)[D]) {
+        sfor<D>([&](auto kq) {
+            constexpr int kk = decltype(kq)::value;
+            col[kk] *= P::template bcast<kk>(dinv);
+            sfor2<kk + 1, D>([&](auto i) { P::template fnmac<decltype(i)::value>(col[decltype(i)::value], C2r[kk], col[kk]); });
+        });
+    }
+};
+
+template <typename T, int D>
+__global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, false)) row_kl_local_kernel(
+    long B, long Tn, const T* __restrict__ mu0_1, const T* __restrict__ C0_1, const T* __restrict__ A_1, const T* __restrict__ b_1,
+    const T* __restrict__ C_1, const T* __restrict__ mu0_2, const T* __restrict__ C0_2, const T* __restrict__ A_2,
+    const T* __restrict__ b_2, const T* __restrict__ C_2, const T* __restrict__ pm, const T* __restrict__ pS, T* __restrict__ part,
+    T* __restrict__ oN, T* __restrict__ on, int* info) {
+    using P = Dpp<T>;
+    using K = RowKlTerm<T, D>;
+    const RowChunkId q = row_chunk_id<D>(B * Tn, 1);                  // one row per (series, step): id = s Tn + k
+    const long id = q.id, s = id / Tn, k = id % Tn;
+    const int r = q.r, rc = q.rc;
+    const T in_mat = r < D ? T(1) : T(0), in_vec = r == D ? T(1) : T(0);
+    bool bad = false;
+    T val = T(0);                                                     // this lane's share of the row's value
+    T mdist = pm[id * D + rc];
+    // ---- the transition k -> k + 1 (absent at the last step of a series: flagged, loads clamped) ----
+    const bool has_t = k + 1 < Tn;
+    const long tid = s * (Tn - 1) + (has_t ? k : (Tn > 1 ? Tn - 2 : 0));
+    if (Tn > 1) {
+        const T tf = has_t ? T(1) : T(0);
+        T C2r[D], Xc[D], Yc[D], dAr[D];
+        load_row_lower<T, D>(C_2 + tid * D * D, rc, C2r);
+        const T c2d = C_2[tid * D * D + rc * (D + 1)], c1d = C_1[tid * D * D + rc * (D + 1)];
+        bad |= has_t && r < D && (!(c2d != T(0)) || !(c1d != T(0)));
+        T dinv = t_rcp<T>(c2d);
+        {
+            T a1[D], a2[D];
+            load_col<T, D>(A_1 + tid * D * D, rc, a1);
+            load_col<T, D>(A_2 + tid * D * D, rc, a2);
+            sfor<D>([&](auto i) { Xc[decltype(i)::value] = (a1[decltype(i)::value] - a2[decltype(i)::value]) * in_mat; });
+            load_row<T, D>(A_1 + tid * D * D, rc, a1);
+            load_row<T, D>(A_2 + tid * D * D, rc, a2);
+            sfor<D>([&](auto i) { dAr[decltype(i)::value] = a1[decltype(i)::value] - a2[decltype(i)::value]; });
+        }
+        sfor<D>([&](auto i) { Yc[decltype(i)::value] = decltype(i)::value >= rc ? C_1[tid * D * D + decltype(i)::value * D + rc] * in_mat : T(0); });
+        // eps = db + dA m, distributed, then into lane D's column
+        T eps = b_1[tid * D + rc] - b_2[tid * D + rc];
+        fence1(mdist);
+        sfor<D>([&](auto j) { P::template fmac<decltype(j)::value>(eps, mdist, dAr[decltype(j)::value]); });
+        fence1(eps);
+        sfor<D>([&](auto i) { P::template fmac<decltype(i)::value>(Xc[decltype(i)::value], eps, in_vec); });
+        fence(C2r);
+        fence1(dinv);
+        K::solve(C2r, dinv, Xc);                                       // lanes < D: columns of W = C2^-1 dA; lane D: u = C2^-1 eps
+        K::solve(C2r, dinv, Yc);                                       // lanes < D: columns of C2^-1 C1
+        T acc = T(0);
+        sfor<D>([&](auto i) { acc = __builtin_fma(Yc[decltype(i)::value], Yc[decltype(i)::value], acc); });
+        // lanes < D: (W S W^T)_jj from own row of S; lane D: |u|^2 - the same multiply-add with its own column as "W S"
+        T Srow[D], WS[D];
+        load_row<T, D>(pS + id * D * D, rc, Srow);
+        sfor<D>([&](auto i) { WS[decltype(i)::value] = Xc[decltype(i)::value] * in_vec; });
+        fence(Xc);
+        sfor<D>([&](auto l) {
+            constexpr int ll = decltype(l)::value;
+            const T sl = Srow[ll] * in_mat;
+            sfor<D>([&](auto i) { P::template fmac<ll>(WS[decltype(i)::value], Xc[decltype(i)::value], sl); });
+        });
+        sfor<D>([&](auto i) { acc = __builtin_fma(WS[decltype(i)::value], Xc[decltype(i)::value], acc); });
+        const T lg = log(c2d < T(0) ? -c2d : c2d) - log(c1d < T(0) ? -c1d : c1d);
+        val = tf * (T(0.5) * acc + in_mat * lg);
+        if (oN) {
+            // adjoint inputs of the backward: N = W^T W, n = W^T u (zero at the last step)
+            T Nrow[D], nv = T(0);
+            sfor<D>([&](auto j) { Nrow[decltype(j)::value] = T(0); });
+            sfor<D>([&](auto i) {
+                constexpr int ii = decltype(i)::value;
+                sfor<D>([&](auto j) { P::template fmac<decltype(j)::value>(Nrow[decltype(j)::value], Xc[ii], Xc[ii]); });
+                P::template fmac<D>(nv, Xc[ii], Xc[ii]);
+            });
+            if (q.valid && r < D) {
+                sfor<D>([&](auto j) { oN[id * D * D + r * D + decltype(j)::value] = tf * Nrow[decltype(j)::value]; });
+                on[id * D + r] = tf * nv;
+            }
+        }
+    } else if (oN && q.valid && r < D) {
+        sfor<D>([&](auto j) { oN[id * D * D + r * D + decltype(j)::value] = T(0); });
+        on[id * D + r] = T(0);
+    }
+    // ---- the initial state (k = 0 rows only; whole rows take or skip the branch) ----
+    if (k == 0) {
+        asm volatile("s_nop 4");
+        T C2r[D], Yc[D];
+        load_row_lower<T, D>(C0_2 + s * D * D, rc, C2r);
+        const T c2d = C0_2[s * D * D + rc * (D + 1)], c1d = C0_1[s * D * D + rc * (D + 1)];
+        bad |= r < D && (!(c2d != T(0)) || !(c1d != T(0)));
+        T dinv = t_rcp<T>(c2d);
+        sfor<D>([&](auto i) { Yc[decltype(i)::value] = decltype(i)::value >= rc ? C0_1[s * D * D + decltype(i)::value * D + rc] * in_mat : T(0); });
+        T d0 = mdist - mu0_2[s * D + rc];
+        fence1(d0);
+        sfor<D>([&](auto i) { P::template fmac<decltype(i)::value>(Yc[decltype(i)::value], d0, in_vec); });    // lane D: m_0 - mu0_2
+        fence(C2r);
+        fence1(dinv);
+        K::solve(C2r, dinv, Yc);
+        T acc = T(0);
+        sfor<D>([&](auto i) { acc = __builtin_fma(Yc[decltype(i)::value], Yc[decltype(i)::value], acc); });
+        const T lg = log(c2d < T(0) ? -c2d : c2d) - log(c1d < T(0) ? -c1d : c1d);
+        val += (in_mat + in_vec) * T(0.5) * acc + in_mat * lg;
+    }
+    // ---- sum over the lanes 0..D of the row ----
+    asm volatile("s_nop 4");
+    fence1(val);
+    T tot = T(0);
+    sfor<D + 1>([&](auto i) { tot += P::template bcast<decltype(i)::value>(val); });
+    if (q.valid && r == 0) part[id] = tot - T(0.5) * T(D);
+    if (q.valid && bad && info) raise_info(info);
+}
+
+}   // namespace row
+}   // namespace mf
