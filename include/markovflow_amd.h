@@ -47,7 +47,9 @@ int mf_max_state_dim_f64_loglik(void);   /* mf_kf_loglik_f64 only: the same on f
  * Inputs: mu0 [B,d], cholP0 [B,d,d], A [B,T-1,d,d], b [B,T-1,d], cholQ [B,T-1,d,d],
  *         H [B,T,m,d], y [B,T,m], Rinv [m,m] (rinv_per_step=0, KalmanFilter) or [B,T,m,m]
  *         (rinv_per_step=1, KalmanFilterWithSites / WithSparseSites), 1 <= m <= 4.
- * State dimension: 1..9 in fp32 and fp64 (one lane per (series, time-chunk), registers); 10 <= d <= 64 (fp32) or
+ * State dimension: 1..9 in fp32 and fp64: one lane per (series, time-chunk) with the state in registers up to d = 6 (fp32: 8),
+ *         above that one 16-lane DPP row per (series, time-chunk) with one matrix row per lane (csrc/mf_row.hpp -
+ *         BASELINE config 4, d = 9); 10 <= d <= 64 (fp32) or
  *         10 <= d <= 32 (fp64) with 1 <= m <= 32 run one workgroup per (series, time-chunk) on LDS tiles and
  *         f32 / f64 MFMA (csrc/mf_big.hpp - BASELINE config 5, state_dim = 64).
  * Output: out[s] = add_const + term1 + term2 + 1/2 log|K^-1| - log|L|  (kalman_filter.py:233-253), i.e. the

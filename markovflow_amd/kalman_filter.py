@@ -53,6 +53,11 @@ class _LogLikelihoodPerSeries(torch.autograd.Function):
             means, covs, cross = post._moments(want_sub=True)  # one forward sweep (or two scans) of the posterior chain
             bsz, n, m, d = h.shape
             per_step = r_inv.dim() > 2
+            if d > _lib.load().mf_max_state_dim() or m > 4:
+                # beyond the register-resident local kernel (BASELINE config 5: d = 64, m = 32): the same closed forms as
+                # batched d x d products - plain rocBLAS GEMMs / triangular solves on the smoothed moments, which themselves
+                # come from the HIP kernels above (posterior chain; covariance / mean recursion partitioned in time on MFMA)
+                return _local_gradients_dense(mu0, cp0, a_s, b_s, cq, h, y, r_inv, means, covs, cross, grad_out.reshape(bsz)) + (None,)
             g_mu0, g_cp0 = torch.empty_like(mu0), torch.empty_like(cp0)
             g_a, g_b, g_cq = torch.empty_like(a_s), torch.empty_like(b_s), torch.empty_like(cq)
             g_h, g_y = torch.empty_like(h), torch.empty_like(y)
@@ -69,6 +74,61 @@ class _LogLikelihoodPerSeries(torch.autograd.Function):
             # The log-determinant of the precision lives in the constants, which torch differentiates outside this function.
             g_r_inv = -0.5 * g_om if per_step else -0.5 * torch.sum(g_om, dim=(0, 1))
         return g_mu0, g_cp0, g_a, g_b, g_cq, g_h, g_y, g_r_inv, None
+
+
+def _local_gradients_dense(mu0, cp0, a_s, b_s, cq, h, y, r_inv, means, covs, cross, w):
+    """Fisher's identity, ``grad log p(y) = E_{x|y}[grad log p(x, y)]``, in closed form from the smoothed moments
+    ``means [B,T,d]``, ``covs [B,T,d,d]``, ``cross = Cov(x_{k+1}, x_k) [B,T-1,d,d]`` - what ``mf_kf_loglik_grad_*`` evaluates
+    with one lane per (series, time point) for d <= 9, here as batched matrix products for 10 <= d <= 64:
+
+        e_k = x_{k+1} - A_k x_k - b_k,   E[e] = m_{k+1} - A m_k - b,   E[e x_k^T] = X_k - A S_k + E[e] m_k^T,
+        Psi_k = E[e e^T] = S_{k+1} - A X_k^T - X_k A^T + A S_k A^T + E[e] E[e]^T,
+        d/dA = Q^-1 E[e x^T],  d/db = Q^-1 E[e],  d/dC = tril(C^-T (C^-1 Psi C^-T - I)),           (Q = C C^T)
+        r_k = y_k - H_k x_k:  d/dH = R^-1 (E[r] m^T - H S),  d/dy = -R^-1 E[r],  d/dR^-1 = -1/2 (E[r] E[r]^T + H S H^T).
+
+    Returns the gradients of ``(mu0, cholP0, A, b, cholQ, H, y, R^-1)``, each weighted by the incoming ``w [B]``
+    (reference: TensorFlow reverse mode through kalman_filter.py:184-255; pinned by
+    tests/integration/models/test_variational.py:123-132 there)."""
+    tri = torch.linalg.solve_triangular
+    tr = lambda t: t.transpose(-1, -2)                                    # noqa: E731
+
+    def chol_grad(chol, psi):
+        """``tril(C^-T (C^-1 Psi C^-T - I))`` for symmetric ``psi``."""
+        z = tri(chol, psi, upper=False)                                   # C^-1 Psi
+        z = tri(chol, tr(z), upper=False)                                 # C^-1 Psi C^-T (symmetric)
+        z = z - torch.eye(chol.shape[-1], dtype=chol.dtype, device=chol.device)
+        return torch.tril(tri(tr(chol), z, upper=True))
+
+    def q_inv(chol, rhs):
+        return tri(tr(chol), tri(chol, rhs, upper=False), upper=True)
+
+    wv, wm = w.reshape(-1, 1, 1), w.reshape(-1, 1, 1, 1)
+    # the initial state
+    d0 = means[:, 0] - mu0
+    g_mu0 = q_inv(cp0, d0[..., None])[..., 0] * w.reshape(-1, 1)
+    g_cp0 = chol_grad(cp0, covs[:, 0] + d0[..., :, None] * d0[..., None, :]) * wv
+    # the transitions
+    if a_s.shape[1] > 0:
+        m_prev, m_next = means[:, :-1], means[:, 1:]
+        s_prev, s_next = covs[:, :-1], covs[:, 1:]
+        e_bar = m_next - (a_s @ m_prev[..., None])[..., 0] - b_s
+        a_s_prev = a_s @ s_prev
+        e_xt = cross - a_s_prev + e_bar[..., :, None] * m_prev[..., None, :]
+        a_xt = a_s @ tr(cross)
+        psi = s_next - a_xt - tr(a_xt) + a_s_prev @ tr(a_s) + e_bar[..., :, None] * e_bar[..., None, :]
+        g_a = q_inv(cq, e_xt) * wm
+        g_b = q_inv(cq, e_bar[..., None])[..., 0] * wv
+        g_cq = chol_grad(cq, psi) * wm
+    else:
+        g_a, g_b, g_cq = torch.zeros_like(a_s), torch.zeros_like(b_s), torch.zeros_like(cq)
+    # the observations
+    r_bar = y - (h @ means[..., None])[..., 0]
+    h_s = h @ covs
+    g_h = (r_inv @ (r_bar[..., :, None] * means[..., None, :] - h_s)) * wm
+    g_y = -(r_inv @ r_bar[..., None])[..., 0] * wv
+    g_om = (r_bar[..., :, None] * r_bar[..., None, :] + h_s @ tr(h)) * wm
+    g_r_inv = -0.5 * g_om if r_inv.dim() > 2 else -0.5 * torch.sum(g_om, dim=(0, 1))
+    return g_mu0, g_cp0, g_a, g_b, g_cq, g_h, g_y, g_r_inv
 
 
 class BaseKalmanFilter(abc.ABC):
@@ -215,8 +275,6 @@ class BaseKalmanFilter(abc.ABC):
         if torch.is_grad_enabled():
             tensors = self.prior_ssm._flat_params() + expanded[:3]
             if any(t.requires_grad for t in tensors):
-                if self.prior_ssm.state_dim > _lib.load().mf_max_state_dim() or expanded[0].shape[-2] > 4:
-                    raise NotImplementedError("gradients of log_likelihood: state_dim <= 9 and output_dim <= 4")
                 return _LogLikelihoodPerSeries.apply(*tensors, self._chunks), True
         return self._log_likelihood_per_series(expanded), False
 

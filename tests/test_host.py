@@ -241,3 +241,35 @@ def test_deferred_pivot_failures_keep_their_names_until_a_synchronised_look():
         _lib._flags.clear()
         _lib._flags.update(saved_flags)
         _lib._issued[:] = saved_issued
+
+
+def test_dense_local_gradients_match_autograd_of_the_dense_joint():
+    """The closed forms behind the log-likelihood gradients for d > 9 (kalman_filter._local_gradients_dense: Fisher's identity on
+    smoothed moments) against torch autograd through the dense joint Gaussian - on the CPU, with the moments from the numpy
+    oracle's posterior chain; per-series weights included.  (The GPU path differs only in where the moments come from.)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import numpy_oracle as O
+    from markovflow_amd.kalman_filter import _local_gradients_dense
+    from test_gpu_gradients import dense_log_likelihood
+    rng = np.random.default_rng(3)
+    bsz, t, d, m = 2, 5, 12, 3
+    vals = dict(mu0=rng.normal(size=(bsz, d)), cp0=np.tril(0.2 * rng.normal(size=(bsz, d, d))) + np.eye(d),
+                a=0.7 * np.eye(d) + 0.1 * rng.normal(size=(bsz, t - 1, d, d)), b=0.1 * rng.normal(size=(bsz, t - 1, d)),
+                cq=np.tril(0.1 * rng.normal(size=(bsz, t - 1, d, d))) + 0.5 * np.eye(d), h=rng.normal(size=(bsz, t, m, d)),
+                y=rng.normal(size=(bsz, t, m)))
+    chol_r = np.linalg.cholesky(0.4 * np.eye(m) + 0.1 * np.ones((m, m)))
+    r_inv = np.linalg.inv(chol_r @ chol_r.T)
+    mu0p, cp0p, ap, bp, cqp = O.kf_posterior_ssm(*vals.values(), r_inv)
+    means, covs = O.ssm_marginal_means(mu0p, ap, bp), O.ssm_marginal_covariances(cp0p, ap, cqp)
+    cross = ap @ covs[:, :-1]
+    w = np.array([0.7, -1.3])
+    cpu = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in vals.items()}
+    cr = torch.tensor(chol_r, requires_grad=True)
+    sum(w[s] * dense_log_likelihood(*(cpu[k][s] for k in vals), cr) for s in range(bsz)).backward()
+    tt = lambda a: torch.tensor(a, dtype=torch.float64)   # noqa: E731
+    got = _local_gradients_dense(*(tt(v) for v in vals.values()), tt(r_inv), tt(means), tt(covs), tt(cross), tt(w))
+    for k, g in zip(vals, got[:7]):
+        want = cpu[k].grad.numpy()
+        want = np.tril(want) if k in ("cp0", "cq") else want
+        np.testing.assert_allclose(g.numpy(), want, rtol=1e-9, atol=1e-11, err_msg=k)
