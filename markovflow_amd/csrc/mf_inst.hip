@@ -9,6 +9,7 @@
 #include "mf_row.hpp"
 #include "mf_row_par.hpp"
 #include "mf_row_scan.hpp"
+#include "mf_row_grad.hpp"
 #include "mf_btd_par.hpp"
 #include "mf_gpr_fused.hpp"
 #include "mf_kl_grad.hpp"
@@ -898,6 +899,31 @@ int ssm_means(long Bl, long Br, long Tn, const T* A, const T* offs, T* out, void
     if (!have_up0)
         hipLaunchKernelGGL((par_means_up0_kernel<T, D, REV>), dim3((unsigned)cdiv(Br * pl.n[1], 64)), dim3(64), 0, st, Bl, Br, n,
                            len0, pl.n[1], A, offs, arr[1].M, arr[1].c);
+    bool row_levels = false;
+    if constexpr (D >= 2 && D + 1 <= 16) row_levels = row_par_path<T>();
+    if (row_levels) {
+        if constexpr (D >= 2 && D + 1 <= 16) {     // the reduced levels of the affine scan in row form (mf_row_par.hpp)
+            const dim3 blk(64);
+            auto rgrid = [](long rows) { return dim3((unsigned)cdiv(rows, 4)); };
+            for (int l = 1; l < pl.levels; ++l) {
+                const long P = pl.n[l + 1];
+                hipLaunchKernelGGL((row::row_affine_up_kernel<T, D, false>), rgrid(Br * P), blk, 0, st, Br, pl.n[l], pl.len[l], P,
+                                   static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c), arr[l + 1].M, arr[l + 1].c);
+            }
+            {
+                const int l = pl.levels;
+                hipLaunchKernelGGL((row::row_affine_down_kernel<T, D, false>), rgrid(Br), blk, 0, st, Br, pl.n[l], pl.n[l], 1L,
+                                   static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c),
+                                   static_cast<const T*>(nullptr), arr[l].Z);
+            }
+            for (int l = pl.levels - 1; l >= 1; --l) {
+                const long P = pl.n[l + 1];
+                hipLaunchKernelGGL((row::row_affine_down_kernel<T, D, false>), rgrid(Br * P), blk, 0, st, Br, pl.n[l], pl.len[l], P,
+                                   static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c),
+                                   static_cast<const T*>(arr[l + 1].Z), arr[l].Z);
+            }
+        }
+    } else {
     for (int l = 1; l < pl.levels; ++l) {
         const long P = pl.n[l + 1];
         hipLaunchKernelGGL((par_affine_up_kernel<T, D>), dim3((unsigned)cdiv(Br * P, 64)), dim3(64), 0, st, Br, pl.n[l],
@@ -915,6 +941,7 @@ int ssm_means(long Bl, long Br, long Tn, const T* A, const T* offs, T* out, void
         hipLaunchKernelGGL((par_affine_down_kernel<T, D>), dim3((unsigned)cdiv(Br * P, 64)), dim3(64), 0, st, Br, pl.n[l],
                            pl.len[l], P, static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c),
                            static_cast<const T*>(arr[l + 1].Z), arr[l].Z);
+    }
     }
     if (up_only) { *up_only = arr[1].Z; return hipGetLastError() == hipSuccess ? 0 : -1000; }
     hipLaunchKernelGGL((par_means_emit_kernel<T, D, REV>), dim3((unsigned)cdiv(Br * pl.n[1], 64)), dim3(64), 0, st, Bl, Br, n,
@@ -1036,6 +1063,24 @@ int kf_grad(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, c
     if (m < 1 || m > MF_MAXM) return -3;
     KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, 1, info, 0, weights};
     const dim3 grid((unsigned)cdiv(B * Tn, 64)), block(64);
+    // from d = 7 on (where the lane-per-point kernel spills) a 16-lane row per (series, time point): mf_row_grad.hpp
+    static const int row_force = [] { const char* e = mf_knob("MF_GRAD_ROW"); return e ? std::atoi(e) : -1; }();
+    if constexpr (D >= 2 && D + 1 <= 16) {
+        if (row_force >= 0 ? row_force != 0 : D >= 7) {
+            const dim3 rgrid((unsigned)cdiv(B * Tn, 4));
+            auto launch = [&](auto mtag) {
+                constexpr int M = decltype(mtag)::value;
+                hipLaunchKernelGGL((row::row_kf_grad_kernel<T, D, M>), rgrid, block, 0, st, a, pm, pS, pX, gmu0, gC0, gA, gb, gC, gH, gy,
+                                   gOm);
+            };
+            using std::integral_constant;
+            if (m == 1) launch(integral_constant<int, 1>{});
+            else if (m == 2) launch(integral_constant<int, 2>{});
+            else if (m == 3) launch(integral_constant<int, 3>{});
+            else launch(integral_constant<int, 4>{});
+            return hipGetLastError() == hipSuccess ? 0 : -1000;
+        }
+    }
     if (m == 1) hipLaunchKernelGGL((kf_grad_kernel<T, D, 1>), grid, block, 0, st, a, pm, pS, pX, gmu0, gC0, gA, gb, gC, gH, gy, gOm);
     else hipLaunchKernelGGL((kf_grad_kernel<T, D, 0>), grid, block, 0, st, a, pm, pS, pX, gmu0, gC0, gA, gb, gC, gH, gy, gOm);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
@@ -1092,7 +1137,10 @@ int kl_grad(long B, long Tn, const T* mu0_1, const T* C0_1, const T* A_1, const 
     }
     if (int rc = adjoint_scan<T>(B, Tn, A_1, w, ws, st)) return rc;
     AdjointLocalArgs<T, D> a{B, Tn, mu0_1, C0_1, A_1, b_1, C_1, mu0_2, C0_2, A_2, b_2, C_2, pm, pS, weights, gmu0, gC0, gA, gb, gC, info};
-    hipLaunchKernelGGL((ssm_adjoint_local_kernel<T, D, true>), per_step, block, 0, st, a, w);
+    if constexpr (D >= 7 && D + 1 <= 16)
+        hipLaunchKernelGGL((row::row_adjoint_local_kernel<T, D, true>), dim3((unsigned)cdiv(B * Tn, 4)), block, 0, st, a, w);
+    else
+        hipLaunchKernelGGL((ssm_adjoint_local_kernel<T, D, true>), per_step, block, 0, st, a, w);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
@@ -1166,7 +1214,10 @@ int marginals_grad(long B, long Tn, const T* C0, const T* A, const T* C, const T
     }
     AdjointLocalArgs<T, D> a{B, Tn, nullptr, C0, A, nullptr, C, nullptr, nullptr, nullptr, nullptr, nullptr, pm, pS, nullptr,
                              gmu0, gC0, gA, gb, gC, nullptr};
-    hipLaunchKernelGGL((ssm_adjoint_local_kernel<T, D, false>), per_step, block, 0, st, a, w);
+    if constexpr (D >= 7 && D + 1 <= 16)
+        hipLaunchKernelGGL((row::row_adjoint_local_kernel<T, D, false>), dim3((unsigned)cdiv(B * Tn, 4)), block, 0, st, a, w);
+    else
+        hipLaunchKernelGGL((ssm_adjoint_local_kernel<T, D, false>), per_step, block, 0, st, a, w);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 

@@ -249,8 +249,22 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, false)) row_kl
     T* __restrict__ oN, T* __restrict__ on, int* info) {
     using P = Dpp<T>;
     using K = RowKlTerm<T, D>;
-    const RowChunkId q = row_chunk_id<D>(B * Tn, 1);                  // one row per (series, step): id = s Tn + k
-    const long id = q.id, s = id / Tn, k = id % Tn;
+    // one row per (series, step): id = s Tn + k.  The row does little more than two substitutions and one product, so its index
+    // arithmetic counts: 32-bit when the problem allows (a 64-bit division is ~100 instructions on this machine)
+    RowChunkId q;
+    {
+        const int lane = threadIdx.x;
+        q.r = lane & 15;
+        q.rc = q.r < D ? q.r : D - 1;
+        const long total = B * Tn;
+        const long id_raw = (long)blockIdx.x * 4 + (lane >> 4);
+        q.valid = id_raw < total;
+        q.id = q.valid ? id_raw : total - 1;
+    }
+    const long id = q.id;
+    long s, k;
+    if (B * Tn < (1L << 31)) { const unsigned su = (unsigned)id / (unsigned)Tn; s = su; k = (long)((unsigned)id - su * (unsigned)Tn); }
+    else { s = id / Tn; k = id % Tn; }
     const int r = q.r, rc = q.rc;
     const T in_mat = r < D ? T(1) : T(0), in_vec = r == D ? T(1) : T(0);
     bool bad = false;
@@ -299,7 +313,8 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, false)) row_kl
             sfor<D>([&](auto i) { P::template fmac<ll>(WS[decltype(i)::value], Xc[decltype(i)::value], sl); });
         });
         sfor<D>([&](auto i) { acc = __builtin_fma(WS[decltype(i)::value], Xc[decltype(i)::value], acc); });
-        const T lg = log(c2d < T(0) ? -c2d : c2d) - log(c1d < T(0) ? -c1d : c1d);
+        const T ratio = c2d * t_rcp<T>(c1d);                           // log|c2| - log|c1| in one logarithm
+        const T lg = log(ratio < T(0) ? -ratio : ratio);
         val = tf * (T(0.5) * acc + in_mat * lg);
         if (oN) {
             // adjoint inputs of the backward: N = W^T W, n = W^T u (zero at the last step)
@@ -336,7 +351,8 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, false)) row_kl
         K::solve(C2r, dinv, Yc);
         T acc = T(0);
         sfor<D>([&](auto i) { acc = __builtin_fma(Yc[decltype(i)::value], Yc[decltype(i)::value], acc); });
-        const T lg = log(c2d < T(0) ? -c2d : c2d) - log(c1d < T(0) ? -c1d : c1d);
+        const T ratio = c2d * t_rcp<T>(c1d);
+        const T lg = log(ratio < T(0) ? -ratio : ratio);
         val += (in_mat + in_vec) * T(0.5) * acc + in_mat * lg;
     }
     // ---- sum over the lanes 0..D of the row ----
