@@ -681,16 +681,16 @@ int tak_scan(long B, long n, TakSrc<T> src, T* odiag, T* osub, void* ws, size_t 
         arr[l].N = reinterpret_cast<T*>(p); p += sz;
         arr[l].Z = reinterpret_cast<T*>(p); p += sz;
     }
-    if constexpr (SRC == 1 && D >= 2 && D + 1 <= 16) {
-        if (row_par_path<T>()) {     // the forward covariance (and mean) scan in row form (mf_row_scan.hpp)
+    if constexpr ((SRC == 1 || SRC == 2) && D >= 2 && D + 1 <= 16) {
+        if (row_par_path<T>()) {     // the covariance (and mean) scan / its adjoint in row form (mf_row_scan.hpp)
             const dim3 blk(64);
             auto rgrid = [](long rows) { return dim3((unsigned)cdiv(rows, 4)); };
-            if (mup.oc != nullptr)
-                hipLaunchKernelGGL((row::row_cov_up0_kernel<T, D, true>), rgrid(B * pl.n[1]), blk, 0, st, B, n, len0, pl.n[1], src,
+            if (SRC == 1 && mup.oc != nullptr)
+                hipLaunchKernelGGL((row::row_cov_up0_kernel<T, D, 1, true>), rgrid(B * pl.n[1]), blk, 0, st, B, n, len0, pl.n[1], src,
                                    arr[1].G, arr[1].N, mup);
             else
-                hipLaunchKernelGGL((row::row_cov_up0_kernel<T, D, false>), rgrid(B * pl.n[1]), blk, 0, st, B, n, len0, pl.n[1], src,
-                                   arr[1].G, arr[1].N, TakMeanUp<T>{});
+                hipLaunchKernelGGL((row::row_cov_up0_kernel<T, D, SRC, false>), rgrid(B * pl.n[1]), blk, 0, st, B, n, len0, pl.n[1],
+                                   src, arr[1].G, arr[1].N, TakMeanUp<T>{});
             for (int l = 1; l < pl.levels; ++l) {
                 const long P = pl.n[l + 1];
                 hipLaunchKernelGGL((row::row_cov_up_kernel<T, D>), rgrid(B * P), blk, 0, st, B, pl.n[l], pl.len[l], P,
@@ -709,7 +709,7 @@ int tak_scan(long B, long n, TakSrc<T> src, T* odiag, T* osub, void* ws, size_t 
                                    static_cast<const T*>(arr[l + 1].Z), arr[l].Z);
             }
             if (up_only) { *up_only = arr[1].Z; return hipGetLastError() == hipSuccess ? 0 : -1000; }
-            hipLaunchKernelGGL((row::row_cov_emit_kernel<T, D, false>), rgrid(B * pl.n[1]), blk, 0, st, B, n, len0, pl.n[1], src,
+            hipLaunchKernelGGL((row::row_cov_emit_kernel<T, D, SRC, false>), rgrid(B * pl.n[1]), blk, 0, st, B, n, len0, pl.n[1], src,
                                static_cast<const T*>(arr[1].Z), odiag, osub, TakMean<T>{});
             return hipGetLastError() == hipSuccess ? 0 : -1000;
         }
@@ -896,11 +896,17 @@ int ssm_means(long Bl, long Br, long Tn, const T* A, const T* offs, T* out, void
         arr[l].c = reinterpret_cast<T*>(p); p += align_up(size_t(Br) * pl.n[l] * D * sizeof(T));
         arr[l].Z = reinterpret_cast<T*>(p); p += align_up(size_t(Br) * pl.n[l] * D * sizeof(T));
     }
-    if (!have_up0)
-        hipLaunchKernelGGL((par_means_up0_kernel<T, D, REV>), dim3((unsigned)cdiv(Br * pl.n[1], 64)), dim3(64), 0, st, Bl, Br, n,
-                           len0, pl.n[1], A, offs, arr[1].M, arr[1].c);
     bool row_levels = false;
     if constexpr (D >= 2 && D + 1 <= 16) row_levels = row_par_path<T>();
+    if (!have_up0) {
+        if (row_levels) {
+            if constexpr (D >= 2 && D + 1 <= 16)
+                hipLaunchKernelGGL((row::row_means_up0_kernel<T, D, REV>), dim3((unsigned)cdiv(Br * pl.n[1], 4)), dim3(64), 0, st, Bl, Br,
+                                   n, len0, pl.n[1], A, offs, arr[1].M, arr[1].c);
+        } else
+        hipLaunchKernelGGL((par_means_up0_kernel<T, D, REV>), dim3((unsigned)cdiv(Br * pl.n[1], 64)), dim3(64), 0, st, Bl, Br, n,
+                           len0, pl.n[1], A, offs, arr[1].M, arr[1].c);
+    }
     if (row_levels) {
         if constexpr (D >= 2 && D + 1 <= 16) {     // the reduced levels of the affine scan in row form (mf_row_par.hpp)
             const dim3 blk(64);
@@ -944,6 +950,12 @@ int ssm_means(long Bl, long Br, long Tn, const T* A, const T* offs, T* out, void
     }
     }
     if (up_only) { *up_only = arr[1].Z; return hipGetLastError() == hipSuccess ? 0 : -1000; }
+    if (row_levels) {
+        if constexpr (D >= 2 && D + 1 <= 16)
+            hipLaunchKernelGGL((row::row_means_emit_kernel<T, D, REV>), dim3((unsigned)cdiv(Br * pl.n[1], 4)), dim3(64), 0, st, Bl, Br, n,
+                               len0, pl.n[1], A, offs, static_cast<const T*>(arr[1].Z), out);
+        return hipGetLastError() == hipSuccess ? 0 : -1000;
+    }
     hipLaunchKernelGGL((par_means_emit_kernel<T, D, REV>), dim3((unsigned)cdiv(Br * pl.n[1], 64)), dim3(64), 0, st, Bl, Br, n,
                        len0, pl.n[1], A, offs, static_cast<const T*>(arr[1].Z), out);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
@@ -991,7 +1003,7 @@ int ssm_marginals(long B, long n, const T* mu0, const T* cholP0, const T* A, con
     if (rc != 0) return rc;
     if constexpr (D >= 2 && D + 1 <= 16) {
         if (row_par_path<T>()) {
-            hipLaunchKernelGGL((row::row_cov_emit_kernel<T, D, true>), dim3((unsigned)cdiv(B * P, 4)), dim3(64), 0, st, B, n, len0, P,
+            hipLaunchKernelGGL((row::row_cov_emit_kernel<T, D, 1, true>), dim3((unsigned)cdiv(B * P, 4)), dim3(64), 0, st, B, n, len0, P,
                                src, up_cov, ocov, osub, TakMean<T>{mu0, b, omean, up_mean});
             return hipGetLastError() == hipSuccess ? 0 : -1000;
         }
@@ -1209,7 +1221,11 @@ int marginals_grad(long B, long Tn, const T* C0, const T* A, const T* C, const T
     if (par_len0(B, Tn) == 0 || Tn < 2) {
         hipLaunchKernelGGL((ssm_adjoint_scan_kernel<T, D>), per_series, block, 0, st, B, Tn, A, gm, gS, 0, w);
     } else {
-        hipLaunchKernelGGL((ssm_adjoint_sym_inputs_kernel<T, D>), per_step, block, 0, st, B * Tn, gm, gS, w);
+        if constexpr (D >= 2 && D + 1 <= 16)
+            hipLaunchKernelGGL((row::row_adjoint_sym_inputs_kernel<T, D>), dim3((unsigned)cdiv(B * Tn, 4)), block, 0, st, B * Tn, gm, gS,
+                               w.N, w.n);
+        else
+            hipLaunchKernelGGL((ssm_adjoint_sym_inputs_kernel<T, D>), per_step, block, 0, st, B * Tn, gm, gS, w);
         if (int rc = adjoint_scan<T>(B, Tn, A, w, ws, st)) return rc;
     }
     AdjointLocalArgs<T, D> a{B, Tn, nullptr, C0, A, nullptr, C, nullptr, nullptr, nullptr, nullptr, nullptr, pm, pS, nullptr,

@@ -46,28 +46,40 @@ template <typename T, int D> MF_DEV void load_row_lower(const T* __restrict__ bl
     sfor<D>([&](auto j) { v[decltype(j)::value] = decltype(j)::value <= rc ? blk[rc * D + decltype(j)::value] : T(0); });
 }
 
-// one position of the level-0 kernels: the transition into position p (p = 0: the prior)
+// one position of the level-0 kernels:  Sigma(p) = Mp Sigma(p-1) Mp^T + N_p  (mu(p) = Mp mu(p-1) + o_p)
+//   SRC 1 (marginal covariances / means, forward): block p; Mp = A_{p-1}, N = C C^T with C = cholQ_{p-1} (p = 0: cholP0, Mp = 0),
+//          o = b_{p-1} (mu0);  src.a = cholQ, src.b = A, src.c0 = cholP0.
+//   SRC 2 (their adjoint, M_k = N_k + A_k^T M_{k+1} A_k, backward): position p = block n-1-p; Mp = A_k^T (rows = columns of
+//          A_k; position 0: none), N_k read from a buffer of symmetric blocks;  src.a = N [B,n,D,D], src.b = A.
 template <typename T, int D> struct RowCovStep {
-    T Arow[D], Crow[D], o;       // rows of A_{p-1} (zero for p = 0), of cholQ_{p-1} / cholP0 (zero above the diagonal), own offset element
+    T Arow[D], Nn[D], o;         // own row of Mp (zero for position 0), own row of N_p, own offset element
 };
-template <typename T, int D, bool MEAN>
+template <typename T, int D, int SRC, bool MEAN>
 MF_DEV void load_cov_step(const TakSrc<T>& src, const T* mu0, const T* b, long s, long n, long p, int rc, RowCovStep<T, D>& d) {
-    const long kt = p > 0 ? p - 1 : 0;
-    const T* cblk = p > 0 ? src.a + (s * (n - 1) + kt) * D * D : src.c0 + s * D * D;
-    load_row_lower<T, D>(cblk, rc, d.Crow);
-    if (n > 1) {
-        const T keep = p > 0 ? T(1) : T(0);
-        load_row<T, D>(src.b + (s * (n - 1) + kt) * D * D, rc, d.Arow);
-        sfor<D>([&](auto j) { d.Arow[decltype(j)::value] *= keep; });
+    const T keep = p > 0 ? T(1) : T(0);
+    if constexpr (SRC == 1) {
+        const long kt = p > 0 ? p - 1 : 0;
+        const T* cblk = p > 0 ? src.a + (s * (n - 1) + kt) * D * D : src.c0 + s * D * D;
+        T Crow[D];
+        load_row_lower<T, D>(cblk, rc, Crow);
+        if (n > 1) load_row<T, D>(src.b + (s * (n - 1) + kt) * D * D, rc, d.Arow);
+        else sfor<D>([&](auto j) { d.Arow[decltype(j)::value] = T(0); });
+        if constexpr (MEAN) d.o = p > 0 ? b[(s * (n - 1) + kt) * D + rc] : mu0[s * D + rc];
+        else d.o = T(0);
+        fence(Crow);
+        row_cct<T, D>(Crow, d.Nn);
     } else {
-        sfor<D>([&](auto j) { d.Arow[decltype(j)::value] = T(0); });
+        const long k = n - 1 - p;
+        load_row<T, D>(src.a + (s * n + k) * D * D, rc, d.Nn);
+        if (n > 1) load_col<T, D>(src.b + (s * (n - 1) + (k < n - 1 ? k : n - 2)) * D * D, rc, d.Arow);
+        else sfor<D>([&](auto j) { d.Arow[decltype(j)::value] = T(0); });
+        d.o = T(0);
     }
-    if constexpr (MEAN) d.o = p > 0 ? b[(s * (n - 1) + kt) * D + rc] : mu0[s * D + rc];
-    else d.o = T(0);
+    sfor<D>([&](auto j) { d.Arow[decltype(j)::value] *= keep; });
 }
 
 // ---- level 0 up-sweep (par_tak_up0_kernel<SRC = 1>): the chunk's map  Sigma -> Mc Sigma Mc^T + Nc,  mu -> Mc mu + q ----
-template <typename T, int D, bool MEAN>
+template <typename T, int D, int SRC, bool MEAN>
 __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, false)) row_cov_up0_kernel(long B, long n, long len, long P, TakSrc<T> src,
                                                                                            T* __restrict__ oG, T* __restrict__ oN,
                                                                                            TakMeanUp<T> mup) {
@@ -79,10 +91,8 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, false)) row_co
     for (long p = p0; p < p1; ++p) {
         asm volatile("s_nop 4");
         RowCovStep<T, D> d;
-        load_cov_step<T, D, MEAN>(src, mup.mu0, mup.b, q.s, n, p, q.rc, d);
-        T Nn[D];
-        fence(d.Crow);
-        row_cct<T, D>(d.Crow, Nn);
+        load_cov_step<T, D, SRC, MEAN>(src, mup.mu0, mup.b, q.s, n, p, q.rc, d);
+        T (&Nn)[D] = d.Nn;
         if (p == p0) {
             sfor<D>([&](auto j) { Mr[decltype(j)::value] = d.Arow[decltype(j)::value]; Nr[decltype(j)::value] = Nn[decltype(j)::value]; });
             Mr[D] = d.o;
@@ -178,7 +188,7 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, false)) row_co
 
 // ---- level 0 emit (par_tak_emit_kernel<SRC = 1>): every chunk restarts from its boundary values and writes the marginal
 // covariances, Cov(x_p, x_{p-1}) = A Sigma_{p-1} (osub, optional) and - MEAN - the marginal means ----
-template <typename T, int D, bool MEAN>
+template <typename T, int D, int SRC, bool MEAN>
 __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, false)) row_cov_emit_kernel(long B, long n, long len, long P, TakSrc<T> src,
                                                                                             const T* __restrict__ up, T* __restrict__ odiag,
                                                                                             T* __restrict__ osub, TakMean<T> mean) {
@@ -197,16 +207,17 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, false)) row_co
     for (long p = p0; p < p1; ++p) {
         asm volatile("s_nop 4");
         RowCovStep<T, D> d;
-        load_cov_step<T, D, MEAN>(src, mean.mu0, mean.b, q.s, n, p, q.rc, d);
-        T Nn[D];
-        fence(d.Crow);
-        row_cct<T, D>(d.Crow, Nn);
+        load_cov_step<T, D, SRC, MEAN>(src, mean.mu0, mean.b, q.s, n, p, q.rc, d);
+        T (&Nn)[D] = d.Nn;
+        const long k = SRC == 1 ? p : n - 1 - p;                      // block this position writes
         if (p > 0) {
             T T2[D];
             sfor<D>([&](auto j) { T2[decltype(j)::value] = T(0); });
             fence(Sr);
             row_mul<T, D, D>(d.Arow, Sr, T2);                          // A Sigma_{p-1}
-            if (osub && st) sfor<D>([&](auto j) { osub[(q.s * (n - 1) + p - 1) * D * D + q.r * D + decltype(j)::value] = T2[decltype(j)::value]; });
+            if constexpr (SRC == 1) {
+                if (osub && st) sfor<D>([&](auto j) { osub[(q.s * (n - 1) + p - 1) * D * D + q.r * D + decltype(j)::value] = T2[decltype(j)::value]; });
+            }
             fence(d.Arow);
             row_mul_t<T, D>(T2, d.Arow, Nn);
             if constexpr (MEAN) {
@@ -220,10 +231,94 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, false)) row_co
         }
         sfor<D>([&](auto j) { Sr[decltype(j)::value] = Nn[decltype(j)::value]; });
         if (st) {
-            sfor<D>([&](auto j) { odiag[(q.s * n + p) * D * D + q.r * D + decltype(j)::value] = Sr[decltype(j)::value]; });
-            if constexpr (MEAN) mean.out[(q.s * n + p) * D + q.r] = mu;
+            sfor<D>([&](auto j) { odiag[(q.s * n + k) * D * D + q.r * D + decltype(j)::value] = Sr[decltype(j)::value]; });
+            if constexpr (MEAN) mean.out[(q.s * n + k) * D + q.r] = mu;
         }
     }
+}
+
+// ---- the affine scan of the means alone (par_means_up0_kernel / par_means_emit_kernel): x_p = Mp x_{p-1} + o_p ----
+// REV: the transposed recursion run backwards, lam_k = o_k + A_k^T lam_{k+1} (the adjoint of the means): position p is block
+// n-1-p and its matrix is A_{n-1-p}^T.  offs [Br, n, D] may be NULL (zero offsets).
+template <typename T, int D, bool REV>
+MF_DEV void load_mean_step(const T* __restrict__ A, const T* __restrict__ offs, long s, long rr, long n, long p, int rc, T (&Mrow)[D], T& o) {
+    const T keep = p > 0 ? T(1) : T(0);
+    if (n > 1) {
+        if (!REV) load_row<T, D>(A + (s * (n - 1) + (p > 0 ? p - 1 : 0)) * D * D, rc, Mrow);
+        else load_col<T, D>(A + (s * (n - 1) + (p > 0 ? n - 1 - p : n - 2)) * D * D, rc, Mrow);
+    } else {
+        sfor<D>([&](auto j) { Mrow[decltype(j)::value] = T(0); });
+    }
+    sfor<D>([&](auto j) { Mrow[decltype(j)::value] *= keep; });
+    o = offs ? offs[(rr * n + (REV ? n - 1 - p : p)) * D + rc] : T(0);
+}
+template <typename T, int D, bool REV>
+__global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, false)) row_means_up0_kernel(long Bl, long Br, long n, long len, long P,
+                                                                                             const T* __restrict__ A, const T* __restrict__ offs,
+                                                                                             T* __restrict__ oM, T* __restrict__ oc) {
+    const RowChunkId q = row_chunk_id<D>(Br, P);
+    const long rr = q.s, s = rr % Bl;
+    const long p0 = q.c * len;
+    long p1 = p0 + len;
+    if (p1 > n) p1 = n;
+    T Mr[D + 1];                                                      // rows of the composed map with its offset as column D
+    for (long p = p0; p < p1; ++p) {
+        asm volatile("s_nop 4");
+        T Mrow[D], o;
+        load_mean_step<T, D, REV>(A, offs, s, rr, n, p, q.rc, Mrow, o);
+        if (p == p0) {
+            sfor<D>([&](auto j) { Mr[decltype(j)::value] = Mrow[decltype(j)::value]; });
+            Mr[D] = o;
+        } else {
+            T T1[D + 1];
+            sfor<D + 1>([&](auto j) { T1[decltype(j)::value] = T(0); });
+            fence(Mr);
+            row_mul<T, D, D + 1>(Mrow, Mr, T1);
+            sfor<D>([&](auto j) { Mr[decltype(j)::value] = T1[decltype(j)::value]; });
+            Mr[D] = T1[D] + o;
+        }
+    }
+    if (q.valid && q.r < D) {
+        sfor<D>([&](auto j) { oM[q.id * D * D + q.r * D + decltype(j)::value] = Mr[decltype(j)::value]; });
+        oc[q.id * D + q.r] = Mr[D];
+    }
+}
+template <typename T, int D, bool REV>
+__global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, false)) row_means_emit_kernel(long Bl, long Br, long n, long len, long P,
+                                                                                              const T* __restrict__ A, const T* __restrict__ offs,
+                                                                                              const T* __restrict__ up, T* __restrict__ out) {
+    using Pp = Dpp<T>;
+    const RowChunkId q = row_chunk_id<D>(Br, P);
+    const long rr = q.s, s = rr % Bl;
+    const long p0 = q.c * len;
+    long p1 = p0 + len;
+    if (p1 > n) p1 = n;
+    T x = T(0);
+    if (q.c > 0) x = up[(rr * P + q.c - 1) * D + q.rc];
+    for (long p = p0; p < p1; ++p) {
+        asm volatile("s_nop 4");
+        T Mrow[D], o;
+        load_mean_step<T, D, REV>(A, offs, s, rr, n, p, q.rc, Mrow, o);
+        T acc = o;
+        fence1(x);
+        sfor<D>([&](auto l) { Pp::template fmac<decltype(l)::value>(acc, x, Mrow[decltype(l)::value]); });
+        x = acc;
+        if (q.valid && q.r < D) out[(rr * n + (REV ? n - 1 - p : p)) * D + q.r] = x;
+    }
+}
+
+// the inputs of the `marginals` adjoint in the workspace layout of the scans (ssm_adjoint_sym_inputs_kernel): N = gS + gS^T, n = gm;
+// a row per block - lane r reads row r and column r of gS
+template <typename T, int D>
+__global__ void __launch_bounds__(64) row_adjoint_sym_inputs_kernel(long blocks, const T* __restrict__ gm, const T* __restrict__ gS,
+                                                                    T* __restrict__ oN, T* __restrict__ on) {
+    const RowChunkId q = row_chunk_id<D>(blocks, 1);
+    if (!(q.valid && q.r < D)) return;
+    sfor<D>([&](auto j) {
+        constexpr int jj = decltype(j)::value;
+        oN[q.id * D * D + q.r * D + jj] = gS ? gS[q.id * D * D + q.r * D + jj] + gS[q.id * D * D + jj * D + q.r] : T(0);
+    });
+    on[q.id * D + q.r] = gm ? gm[q.id * D + q.r] : T(0);
 }
 
 // ---- kl_divergence, local form (ssm_kl_local_kernel): a row per (series, step) ----
