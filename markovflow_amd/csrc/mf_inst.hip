@@ -10,6 +10,7 @@
 #include "mf_row_par.hpp"
 #include "mf_row_scan.hpp"
 #include "mf_row_grad.hpp"
+#include "mf_row_post.hpp"
 #include "mf_btd_par.hpp"
 #include "mf_gpr_fused.hpp"
 #include "mf_kl_grad.hpp"
@@ -809,6 +810,59 @@ int btd_udl(long B, long n, const T* diag, const T* sub, T* ut, T* chol_d, const
         if (l == 0) return ParLevel<T>{diag, nullptr, nullptr, sub, n, n - 1, -1, 1};
         return ParLevel<T>{arr[l].Dv, arr[l].Gf, arr[l].GU, arr[l].F, pl.n[l], pl.n[l], 0, 0};
     };
+    if constexpr (D >= 2 && D + 1 <= 16) {
+        if (row_par_path<T>() && (chain || eta == nullptr)) {
+            // everything in row form (mf_row_par.hpp, mf_row_post.hpp): reversed up-sweep, down-sweep, emit, the offsets' affine scan
+            const dim3 blk(64);
+            auto rgrid = [](long rows) { return dim3((unsigned)cdiv(rows, 4)); };
+            for (int l = 0; l < pl.levels; ++l) {
+                const long P = pl.n[l + 1];
+                if (l == 0)
+                    hipLaunchKernelGGL((row::row_chol_up_kernel<T, D, false, false>), rgrid(B * P), blk, 0, st, level(l), B, pl.len[l], P,
+                                       arr[l + 1].Dv, arr[l + 1].Gf, arr[l + 1].GU, arr[l + 1].F, info);
+                else
+                    hipLaunchKernelGGL((row::row_chol_up_kernel<T, D, true, false>), rgrid(B * P), blk, 0, st, level(l), B, pl.len[l], P,
+                                       arr[l + 1].Dv, arr[l + 1].Gf, arr[l + 1].GU, arr[l + 1].F, info);
+            }
+            {
+                const int l = pl.levels;
+                hipLaunchKernelGGL((row::row_chol_down_kernel<T, D, false>), rgrid(B), blk, 0, st, level(l), B, pl.n[l], 1L,
+                                   static_cast<const T*>(nullptr), arr[l].Pn, info);
+            }
+            for (int l = pl.levels - 1; l >= 1; --l) {
+                const long P = pl.n[l + 1];
+                hipLaunchKernelGGL((row::row_chol_down_kernel<T, D, false>), rgrid(B * P), blk, 0, st, level(l), B, pl.len[l], P,
+                                   static_cast<const T*>(arr[l + 1].Pn), arr[l].Pn, info);
+            }
+            hipLaunchKernelGGL((row::row_udl_emit_kernel<T, D>), rgrid(B * pl.n[1]), blk, 0, st, B, n, len0, pl.n[1], diag, sub,
+                               static_cast<const T*>(arr[1].Pn), ut, chol_d, chol_dinv, chain, info);
+            if (eta) {
+                hipLaunchKernelGGL((row::row_means_up0_kernel<T, D, true>), rgrid(B * pl.n[1]), blk, 0, st, B, B, n, len0, pl.n[1],
+                                   static_cast<const T*>(ut), eta, arr[1].M, arr[1].c, T(1));      // ut = -U^T: x = eta + ut^T x'
+                for (int l = 1; l < pl.levels; ++l) {
+                    const long P = pl.n[l + 1];
+                    hipLaunchKernelGGL((row::row_affine_up_kernel<T, D, false>), rgrid(B * P), blk, 0, st, B, pl.n[l], pl.len[l], P,
+                                       static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c), arr[l + 1].M, arr[l + 1].c);
+                }
+                {
+                    const int l = pl.levels;
+                    hipLaunchKernelGGL((row::row_affine_down_kernel<T, D, false>), rgrid(B), blk, 0, st, B, pl.n[l], pl.n[l], 1L,
+                                       static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c),
+                                       static_cast<const T*>(nullptr), arr[l].Z);
+                }
+                for (int l = pl.levels - 1; l >= 1; --l) {
+                    const long P = pl.n[l + 1];
+                    hipLaunchKernelGGL((row::row_affine_down_kernel<T, D, false>), rgrid(B * P), blk, 0, st, B, pl.n[l], pl.len[l], P,
+                                       static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c),
+                                       static_cast<const T*>(arr[l + 1].Z), arr[l].Z);
+                }
+                hipLaunchKernelGGL((row::row_post_emit_kernel<T, D>), rgrid(B * pl.n[1]), blk, 0, st, B, n, len0, pl.n[1],
+                                   static_cast<const T*>(ut), eta, static_cast<const T*>(arr[1].Z), m_post,
+                                   static_cast<const T*>(chol_dinv));
+            }
+            return hipGetLastError() == hipSuccess ? 0 : -1000;
+        }
+    }
     for (int l = 0; l < pl.levels; ++l) {
         const long P = pl.n[l + 1];
         constexpr int x_lds = LdsSpike<T, D>::BYTES;
@@ -865,6 +919,21 @@ int ssm_precision(long B, long Tn, int m, const T* mu0, const T* cholP0, const T
                   const T* H, const T* y, const T* Rinv, int rinv_per_step, T* diag, T* sub, T* eta, hipStream_t st) {
     if (H && (m < 1 || m > MF_MAXM)) return -3;
     KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, 1, nullptr, 0};
+    if constexpr (D >= 2 && D + 1 <= 16) {
+        if (row_par_path<T>() && D >= 7) {       // (below d = 7 the lane-per-block kernel with its shared inversions is faster)
+            const dim3 rgrid((unsigned)cdiv(B * Tn, 4));
+            auto launch = [&](auto mtag) {
+                constexpr int M = decltype(mtag)::value;
+                hipLaunchKernelGGL((row::row_ssm_precision_kernel<T, D, M>), rgrid, dim3(64), 0, st, a, diag, sub, eta);
+            };
+            using std::integral_constant;
+            if (!H || m == 1) launch(integral_constant<int, 1>{});
+            else if (m == 2) launch(integral_constant<int, 2>{});
+            else if (m == 3) launch(integral_constant<int, 3>{});
+            else launch(integral_constant<int, 4>{});
+            return hipGetLastError() == hipSuccess ? 0 : -1000;
+        }
+    }
     const dim3 grid((unsigned)cdiv(B * Tn, 256)), block(256);
     if (m == 1) hipLaunchKernelGGL((ssm_precision_kernel<T, D, 1>), grid, block, 0, st, a, diag, sub, eta);
     else hipLaunchKernelGGL((ssm_precision_kernel<T, D, 0>), grid, block, 0, st, a, diag, sub, eta);
@@ -902,7 +971,7 @@ int ssm_means(long Bl, long Br, long Tn, const T* A, const T* offs, T* out, void
         if (row_levels) {
             if constexpr (D >= 2 && D + 1 <= 16)
                 hipLaunchKernelGGL((row::row_means_up0_kernel<T, D, REV>), dim3((unsigned)cdiv(Br * pl.n[1], 4)), dim3(64), 0, st, Bl, Br,
-                                   n, len0, pl.n[1], A, offs, arr[1].M, arr[1].c);
+                                   n, len0, pl.n[1], A, offs, arr[1].M, arr[1].c, T(1));
         } else
         hipLaunchKernelGGL((par_means_up0_kernel<T, D, REV>), dim3((unsigned)cdiv(Br * pl.n[1], 64)), dim3(64), 0, st, Bl, Br, n,
                            len0, pl.n[1], A, offs, arr[1].M, arr[1].c);
@@ -953,7 +1022,7 @@ int ssm_means(long Bl, long Br, long Tn, const T* A, const T* offs, T* out, void
     if (row_levels) {
         if constexpr (D >= 2 && D + 1 <= 16)
             hipLaunchKernelGGL((row::row_means_emit_kernel<T, D, REV>), dim3((unsigned)cdiv(Br * pl.n[1], 4)), dim3(64), 0, st, Bl, Br, n,
-                               len0, pl.n[1], A, offs, static_cast<const T*>(arr[1].Z), out);
+                               len0, pl.n[1], A, offs, static_cast<const T*>(arr[1].Z), out, T(1));
         return hipGetLastError() == hipSuccess ? 0 : -1000;
     }
     hipLaunchKernelGGL((par_means_emit_kernel<T, D, REV>), dim3((unsigned)cdiv(Br * pl.n[1], 64)), dim3(64), 0, st, Bl, Br, n,

@@ -135,6 +135,13 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, PF)) row_chol_
     RowFact<T, D> E;
     E.init();
     auto load = [&](long k, RowUpStep<T, D>& d) {
+        if (!REDUCED && in.rev) {
+            // level 0 of the block-REVERSED matrix (upper_diagonal_lower): position k is block n-1-k, the coupling transposed
+            const long kc = k > 0 ? k : 1;
+            load_row<T, D>(in.Dv + (q.s * in.n + (in.n - 1 - k)) * D * D, q.rc, d.Dn);
+            load_col<T, D>(in.F + (q.s * (in.n - 1) + in.n - 1 - kc) * D * D, q.rc, d.S);
+            return;
+        }
         load_row<T, D>(in.Dv + (q.s * in.n + k) * D * D, q.rc, d.Dn);
         if constexpr (REDUCED) {
             const bool has2 = k + 1 < in.n;
@@ -150,7 +157,8 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, PF)) row_chol_
     {   // coupling of the chunk's first block to its left neighbour, as columns
         T xc[D];
         const long kc = k0 > 0 ? k0 : 1;
-        load_col<T, D>(in.F + (q.s * in.f_stride + kc + in.f_off) * D * D, q.rc, xc);
+        if (!REDUCED && in.rev) load_row<T, D>(in.F + (q.s * (in.n - 1) + in.n - 1 - kc) * D * D, q.rc, xc);
+        else load_col<T, D>(in.F + (q.s * in.f_stride + kc + in.f_off) * D * D, q.rc, xc);
         const T keep = k0 > 0 ? T(1) : T(0);
         sfor<D>([&](auto j) { E.Xa[decltype(j)::value] = xc[decltype(j)::value] * keep; });
     }

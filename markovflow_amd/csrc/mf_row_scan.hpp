@@ -239,10 +239,11 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, false)) row_co
 
 // ---- the affine scan of the means alone (par_means_up0_kernel / par_means_emit_kernel): x_p = Mp x_{p-1} + o_p ----
 // REV: the transposed recursion run backwards, lam_k = o_k + A_k^T lam_{k+1} (the adjoint of the means): position p is block
-// n-1-p and its matrix is A_{n-1-p}^T.  offs [Br, n, D] may be NULL (zero offsets).
+// n-1-p and its matrix is A_{n-1-p}^T.  offs [Br, n, D] may be NULL (zero offsets).  `sign` multiplies the matrix (the posterior
+// offsets x_k = eta_k - U_k x_{k+1} are this scan with A = U^T, sign = -1, or with the chain's -U^T and sign = +1).
 template <typename T, int D, bool REV>
-MF_DEV void load_mean_step(const T* __restrict__ A, const T* __restrict__ offs, long s, long rr, long n, long p, int rc, T (&Mrow)[D], T& o) {
-    const T keep = p > 0 ? T(1) : T(0);
+MF_DEV void load_mean_step(const T* __restrict__ A, const T* __restrict__ offs, long s, long rr, long n, long p, int rc, T sign, T (&Mrow)[D], T& o) {
+    const T keep = p > 0 ? sign : T(0);
     if (n > 1) {
         if (!REV) load_row<T, D>(A + (s * (n - 1) + (p > 0 ? p - 1 : 0)) * D * D, rc, Mrow);
         else load_col<T, D>(A + (s * (n - 1) + (p > 0 ? n - 1 - p : n - 2)) * D * D, rc, Mrow);
@@ -255,7 +256,7 @@ MF_DEV void load_mean_step(const T* __restrict__ A, const T* __restrict__ offs, 
 template <typename T, int D, bool REV>
 __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, false)) row_means_up0_kernel(long Bl, long Br, long n, long len, long P,
                                                                                              const T* __restrict__ A, const T* __restrict__ offs,
-                                                                                             T* __restrict__ oM, T* __restrict__ oc) {
+                                                                                             T* __restrict__ oM, T* __restrict__ oc, T sign) {
     const RowChunkId q = row_chunk_id<D>(Br, P);
     const long rr = q.s, s = rr % Bl;
     const long p0 = q.c * len;
@@ -265,7 +266,7 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, false)) row_me
     for (long p = p0; p < p1; ++p) {
         asm volatile("s_nop 4");
         T Mrow[D], o;
-        load_mean_step<T, D, REV>(A, offs, s, rr, n, p, q.rc, Mrow, o);
+        load_mean_step<T, D, REV>(A, offs, s, rr, n, p, q.rc, sign, Mrow, o);
         if (p == p0) {
             sfor<D>([&](auto j) { Mr[decltype(j)::value] = Mrow[decltype(j)::value]; });
             Mr[D] = o;
@@ -286,7 +287,7 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, false)) row_me
 template <typename T, int D, bool REV>
 __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, false)) row_means_emit_kernel(long Bl, long Br, long n, long len, long P,
                                                                                               const T* __restrict__ A, const T* __restrict__ offs,
-                                                                                              const T* __restrict__ up, T* __restrict__ out) {
+                                                                                              const T* __restrict__ up, T* __restrict__ out, T sign) {
     using Pp = Dpp<T>;
     const RowChunkId q = row_chunk_id<D>(Br, P);
     const long rr = q.s, s = rr % Bl;
@@ -298,7 +299,7 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, false)) row_me
     for (long p = p0; p < p1; ++p) {
         asm volatile("s_nop 4");
         T Mrow[D], o;
-        load_mean_step<T, D, REV>(A, offs, s, rr, n, p, q.rc, Mrow, o);
+        load_mean_step<T, D, REV>(A, offs, s, rr, n, p, q.rc, sign, Mrow, o);
         T acc = o;
         fence1(x);
         sfor<D>([&](auto l) { Pp::template fmac<decltype(l)::value>(acc, x, Mrow[decltype(l)::value]); });
