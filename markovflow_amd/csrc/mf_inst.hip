@@ -919,21 +919,6 @@ int ssm_precision(long B, long Tn, int m, const T* mu0, const T* cholP0, const T
                   const T* H, const T* y, const T* Rinv, int rinv_per_step, T* diag, T* sub, T* eta, hipStream_t st) {
     if (H && (m < 1 || m > MF_MAXM)) return -3;
     KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, 1, nullptr, 0};
-    if constexpr (D >= 2 && D + 1 <= 16) {
-        if (row_par_path<T>() && D >= 7) {       // (below d = 7 the lane-per-block kernel with its shared inversions is faster)
-            const dim3 rgrid((unsigned)cdiv(B * Tn, 4));
-            auto launch = [&](auto mtag) {
-                constexpr int M = decltype(mtag)::value;
-                hipLaunchKernelGGL((row::row_ssm_precision_kernel<T, D, M>), rgrid, dim3(64), 0, st, a, diag, sub, eta);
-            };
-            using std::integral_constant;
-            if (!H || m == 1) launch(integral_constant<int, 1>{});
-            else if (m == 2) launch(integral_constant<int, 2>{});
-            else if (m == 3) launch(integral_constant<int, 3>{});
-            else launch(integral_constant<int, 4>{});
-            return hipGetLastError() == hipSuccess ? 0 : -1000;
-        }
-    }
     const dim3 grid((unsigned)cdiv(B * Tn, 256)), block(256);
     if (m == 1) hipLaunchKernelGGL((ssm_precision_kernel<T, D, 1>), grid, block, 0, st, a, diag, sub, eta);
     else hipLaunchKernelGGL((ssm_precision_kernel<T, D, 0>), grid, block, 0, st, a, diag, sub, eta);
