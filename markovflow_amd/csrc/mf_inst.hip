@@ -1030,7 +1030,7 @@ template <typename T> size_t marginals_ws(long B, long n) {
 }
 template <typename T>
 int ssm_marginals(long B, long n, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, T* omean, T* ocov,
-                  T* osub, void* ws, size_t ws_bytes, hipStream_t st) {
+                  T* osub, void* ws, size_t ws_bytes, hipStream_t st, const T** boundaries = nullptr) {
     if (n < 2) return -101;
     const TakSrc<T> src{cholQ, A, cholP0};
     const long len0 = par_len0(B, n);
@@ -1055,6 +1055,11 @@ int ssm_marginals(long B, long n, const T* mu0, const T* cholP0, const T* A, con
     rc = ssm_means<T, false>(B, B, n, A, static_cast<const T*>(nullptr), omean, ws_mean, btd_solve_ws<T>(B, B, n), st, &up_mean,
                              true);
     if (rc != 0) return rc;
+    if (boundaries) {          // the caller runs its own level-0 emit (kl_value: the fused KL emit)
+        boundaries[0] = up_cov;
+        boundaries[1] = up_mean;
+        return 0;
+    }
     if constexpr (D >= 2 && D + 1 <= 16) {
         if (row_par_path<T>()) {
             hipLaunchKernelGGL((row::row_cov_emit_kernel<T, D, 1, true>), dim3((unsigned)cdiv(B * P, 4)), dim3(64), 0, st, B, n, len0, P,
@@ -1065,6 +1070,12 @@ int ssm_marginals(long B, long n, const T* mu0, const T* cholP0, const T* A, con
     hipLaunchKernelGGL((par_tak_emit_kernel<T, D, 1, true>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, B, n, len0, P, src,
                        up_cov, ocov, osub, TakMean<T>{mu0, b, omean, up_mean});
     return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+template <typename T>
+int ssm_marginals_entry(long B, long n, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, T* omean, T* ocov,
+                        T* osub, void* ws, size_t ws_bytes, hipStream_t st) {
+    return ssm_marginals<T>(B, n, mu0, cholP0, A, b, cholQ, omean, ocov, osub, ws, ws_bytes, st);
 }
 
 template <typename T>
@@ -1243,10 +1254,26 @@ int kl_value(long B, long Tn, const T* mu0_1, const T* C0_1, const T* A_1, const
         T* part = reinterpret_cast<T*>(p); p += align_up(size_t(B) * Tn * sizeof(T));
         if (out_covs) pS = out_covs;
         if (out_means) pm = out_means;
-        const int rc = ssm_marginals<T>(B, Tn, mu0_1, C0_1, A_1, b_1, C_1, pm, pS, out_cross, p, marginals_ws<T>(B, Tn), st);
-        if (rc != 0) return rc;
         bool row_local = false;
         if constexpr (D >= 2 && D + 1 <= 16) row_local = row_par_path<T>();
+        if (row_local) {
+            if constexpr (D >= 2 && D + 1 <= 16) {
+                // row form: the scans up to the chunk boundaries, then ONE level-0 kernel that restarts q1's moments and evaluates
+                // the divergence's terms from them (mf_row_scan.hpp: row_kl_emit_kernel); moments only written when asked for
+                const long len0 = par_len0(B, Tn);
+                const long P = par_plan(Tn, len0).n[1];
+                const T* bnd[2] = {nullptr, nullptr};
+                const int rcb = ssm_marginals<T>(B, Tn, mu0_1, C0_1, A_1, b_1, C_1, pm, pS, out_cross, p, marginals_ws<T>(B, Tn), st, bnd);
+                if (rcb != 0) return rcb;
+                const row::RowKlChains<T, D> ch{mu0_1, C0_1, A_1, b_1, C_1, mu0_2, C0_2, A_2, b_2, C_2};
+                hipLaunchKernelGGL((row::row_kl_emit_kernel<T, D>), dim3((unsigned)cdiv(B * P, 4)), dim3(64), 0, st, B, Tn, len0, P, ch,
+                                   bnd[0], bnd[1], out_means, out_covs, out_cross, out_N, out_n, part, info);
+                hipLaunchKernelGGL((row_sum_kernel<T>), dim3((unsigned)B), dim3(64), 0, st, P, static_cast<const T*>(part), out);
+                return hipGetLastError() == hipSuccess ? 0 : -1000;
+            }
+        }
+        const int rc = ssm_marginals<T>(B, Tn, mu0_1, C0_1, A_1, b_1, C_1, pm, pS, out_cross, p, marginals_ws<T>(B, Tn), st);
+        if (rc != 0) return rc;
         if (row_local) {
             if constexpr (D >= 2 && D + 1 <= 16)
                 hipLaunchKernelGGL((row::row_kl_local_kernel<T, D>), dim3((unsigned)cdiv(B * Tn, 4)), dim3(64), 0, st, B, Tn, mu0_1,
@@ -1295,7 +1322,7 @@ template <typename T> const OpsTable<T>* table() {
     static const OpsTable<T> t = {
         &kf_loglik_ws<T>, &kf_loglik<T>, &btd_logdet_quad_ws<T>, &btd_logdet_quad<T>, &btd_cholesky_ws<T>, &btd_cholesky<T>,
         &btd_solve_ws<T>, &btd_solve<T>,    &btd_matvec<T>, &btd_logdet<T>,        &btd_diag_of_inverse_ws<T>, &btd_diag_of_inverse<T>, &ssm_marginal_covs<T>, &btd_udl_ws<T>, &btd_udl<T>,
-        &ssm_precision<T>, &ssm_means_entry<T>, &block_matmul<T>, &gpr_loglik<T>, &sde_predict<T>, &kf_grad<T>, &kl_grad<T>, &posterior_chain<T>, &kl_value<T>, &marginals_grad<T>, &adjoint_ws<T>, &ssm_marginals<T>, &kl_ws<T>, &marginals_ws<T>,
+        &ssm_precision<T>, &ssm_means_entry<T>, &block_matmul<T>, &gpr_loglik<T>, &sde_predict<T>, &kf_grad<T>, &kl_grad<T>, &posterior_chain<T>, &kl_value<T>, &marginals_grad<T>, &adjoint_ws<T>, &ssm_marginals_entry<T>, &kl_ws<T>, &marginals_ws<T>,
     };
     return &t;
 }

@@ -460,5 +460,146 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, false)) row_kl
     if (q.valid && bad && info) raise_info(info);
 }
 
+// ---- kl_divergence with few series, fused: the level-0 emit of q1's covariance / mean scan evaluates the divergence's local
+// terms on the way (row_cov_emit_kernel + row_kl_local_kernel in one kernel).  A chunk restarts (m, S) from its boundary values,
+// and at position p it has exactly what the term of transition p-1 -> p needs, (m_{p-1}, S_{p-1}), in registers: the moments are
+// neither written nor read back unless the caller wants them (the backward does: omean / ocov / ocross / oN / on).  One partial
+// value per chunk; a wave per series adds them in a fixed order. ----
+template <typename T, int D> struct RowKlChains {
+    const T *mu0_1, *C0_1, *A_1, *b_1, *C_1, *mu0_2, *C0_2, *A_2, *b_2, *C_2;
+};
+template <typename T, int D>
+__global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, true)) row_kl_emit_kernel(      // (two waves per SIMD at d >= 8 fp64: no spills)
+    long B, long n, long len, long Pn, RowKlChains<T, D> ch, const T* __restrict__ up_cov, const T* __restrict__ up_mean,
+    T* __restrict__ omean, T* __restrict__ ocov, T* __restrict__ ocross, T* __restrict__ oN, T* __restrict__ on,
+    T* __restrict__ part, int* info) {
+    using P = Dpp<T>;
+    using K = RowKlTerm<T, D>;
+    const RowChunkId q = row_chunk_id<D>(B, Pn);
+    const long s = q.s;
+    const int r = q.r, rc = q.rc;
+    const long p0 = q.c * len;
+    long p1 = p0 + len;
+    if (p1 > n) p1 = n;
+    const bool st = q.valid && r < D;
+    const T in_mat = r < D ? T(1) : T(0), in_vec = r == D ? T(1) : T(0);
+    const TakSrc<T> src{ch.C_1, ch.A_1, ch.C0_1};
+    bool bad = false;
+    T val = T(0);
+    T Sr[D], mu = T(0);
+    sfor<D>([&](auto j) { Sr[decltype(j)::value] = T(0); });
+    if (q.c > 0) {
+        load_row<T, D>(up_cov + (s * Pn + q.c - 1) * D * D, rc, Sr);
+        mu = up_mean[(s * Pn + q.c - 1) * D + rc];
+    }
+    // 1/2 [ |C2^-1 C1|_F^2 + |C2^-1 x|^2 ] + log|C2| - log|C1| from own rows / columns; X: columns of a matrix in lanes < D and the
+    // vector x in lane D (both solved in place), returns this lane's share
+    auto chol_term = [&](const T* c2blk, const T* c1blk, T (&Xc)[D]) {
+        T C2r[D], Yc[D];
+        load_row_lower<T, D>(c2blk, rc, C2r);
+        const T c2d = c2blk[rc * (D + 1)], c1d = c1blk[rc * (D + 1)];
+        bad |= r < D && (!(c2d != T(0)) || !(c1d != T(0)));
+        T dinv = t_rcp<T>(c2d);
+        sfor<D>([&](auto i) { Yc[decltype(i)::value] = decltype(i)::value >= rc ? c1blk[decltype(i)::value * D + rc] * in_mat : T(0); });
+        fence(C2r);
+        fence1(dinv);
+        K::solve(C2r, dinv, Xc);
+        K::solve(C2r, dinv, Yc);
+        T acc = T(0);
+        sfor<D>([&](auto i) { acc = __builtin_fma(Yc[decltype(i)::value], Yc[decltype(i)::value], acc); });
+        const T ratio = c2d * t_rcp<T>(c1d);
+        return T(0.5) * acc + in_mat * log(ratio < T(0) ? -ratio : ratio);
+    };
+    for (long p = p0; p < p1; ++p) {
+        asm volatile("s_nop 4");
+        RowCovStep<T, D> d;
+        load_cov_step<T, D, 1, true>(src, ch.mu0_1, ch.b_1, s, n, p, rc, d);
+        if (p == 0) {
+            // ---- the initial state: m_0 = mu0_1 ----
+            T Xc[D];
+            T d0 = d.o - ch.mu0_2[s * D + rc];
+            sfor<D>([&](auto i) { Xc[decltype(i)::value] = T(0); });
+            fence1(d0);
+            sfor<D>([&](auto i) { P::template fmac<decltype(i)::value>(Xc[decltype(i)::value], d0, in_vec); });
+            T v = chol_term(ch.C0_2 + s * D * D, ch.C0_1 + s * D * D, Xc);
+            T acc = T(0);
+            sfor<D>([&](auto i) { acc = __builtin_fma(Xc[decltype(i)::value], Xc[decltype(i)::value], acc); });
+            val += v + in_vec * T(0.5) * acc;
+        } else {
+            // ---- the term of transition p-1 -> p, from (m_{p-1}, S_{p-1}) = (mu, Sr) ----
+            const long tid = s * (n - 1) + p - 1;
+            T Xc[D], dAr[D];
+            {
+                T a1[D], a2[D];
+                load_col<T, D>(ch.A_1 + tid * D * D, rc, a1);
+                load_col<T, D>(ch.A_2 + tid * D * D, rc, a2);
+                sfor<D>([&](auto i) { Xc[decltype(i)::value] = (a1[decltype(i)::value] - a2[decltype(i)::value]) * in_mat; });
+                load_row<T, D>(ch.A_2 + tid * D * D, rc, a2);
+                sfor<D>([&](auto i) { dAr[decltype(i)::value] = d.Arow[decltype(i)::value] - a2[decltype(i)::value]; });
+            }
+            T eps = d.o - ch.b_2[tid * D + rc];
+            fence1(mu);
+            sfor<D>([&](auto j) { P::template fmac<decltype(j)::value>(eps, mu, dAr[decltype(j)::value]); });      // db + dA m
+            fence1(eps);
+            sfor<D>([&](auto i) { P::template fmac<decltype(i)::value>(Xc[decltype(i)::value], eps, in_vec); });
+            T v = chol_term(ch.C_2 + tid * D * D, ch.C_1 + tid * D * D, Xc);        // Xc: columns of W = C2^-1 dA; lane D: u = C2^-1 eps
+            T WS[D], acc = T(0);
+            sfor<D>([&](auto i) { WS[decltype(i)::value] = Xc[decltype(i)::value] * in_vec; });
+            fence(Xc);
+            sfor<D>([&](auto l) {
+                constexpr int ll = decltype(l)::value;
+                const T sl = Sr[ll] * in_mat;
+                sfor<D>([&](auto i) { P::template fmac<ll>(WS[decltype(i)::value], Xc[decltype(i)::value], sl); });
+            });
+            sfor<D>([&](auto i) { acc = __builtin_fma(WS[decltype(i)::value], Xc[decltype(i)::value], acc); });
+            val += v + T(0.5) * acc;
+            if (oN) {                                                 // adjoint inputs of the backward at step p-1: N = W^T W, n = W^T u
+                T Nrow[D], nv = T(0);
+                sfor<D>([&](auto j) { Nrow[decltype(j)::value] = T(0); });
+                sfor<D>([&](auto i) {
+                    constexpr int ii = decltype(i)::value;
+                    sfor<D>([&](auto j) { P::template fmac<decltype(j)::value>(Nrow[decltype(j)::value], Xc[ii], Xc[ii]); });
+                    P::template fmac<D>(nv, Xc[ii], Xc[ii]);
+                });
+                if (st) {
+                    sfor<D>([&](auto j) { oN[(s * n + p - 1) * D * D + r * D + decltype(j)::value] = Nrow[decltype(j)::value]; });
+                    on[(s * n + p - 1) * D + r] = nv;
+                }
+            }
+        }
+        // ---- (m_p, S_p) ----
+        if (p > 0) {
+            T T2[D];
+            sfor<D>([&](auto j) { T2[decltype(j)::value] = T(0); });
+            fence(Sr);
+            row_mul<T, D, D>(d.Arow, Sr, T2);
+            if (ocross && st) sfor<D>([&](auto j) { ocross[(s * (n - 1) + p - 1) * D * D + r * D + decltype(j)::value] = T2[decltype(j)::value]; });
+            fence(d.Arow);
+            row_mul_t<T, D>(T2, d.Arow, d.Nn);
+            T acc = d.o;
+            fence1(mu);
+            sfor<D>([&](auto l) { P::template fmac<decltype(l)::value>(acc, mu, d.Arow[decltype(l)::value]); });
+            mu = acc;
+        } else {
+            mu = d.o;
+        }
+        sfor<D>([&](auto j) { Sr[decltype(j)::value] = d.Nn[decltype(j)::value]; });
+        if (st) {
+            if (ocov) sfor<D>([&](auto j) { ocov[(s * n + p) * D * D + r * D + decltype(j)::value] = Sr[decltype(j)::value]; });
+            if (omean) omean[(s * n + p) * D + r] = mu;
+            if (oN && p + 1 == n) {                                   // no transition leaves the last step
+                sfor<D>([&](auto j) { oN[(s * n + p) * D * D + r * D + decltype(j)::value] = T(0); });
+                on[(s * n + p) * D + r] = T(0);
+            }
+        }
+    }
+    asm volatile("s_nop 4");
+    fence1(val);
+    T tot = T(0);
+    sfor<D + 1>([&](auto i) { tot += P::template bcast<decltype(i)::value>(val); });
+    if (q.valid && r == 0) part[q.id] = tot - T(0.5) * T(D) * T(p1 - p0);
+    if (q.valid && bad && info) raise_info(info);
+}
+
 }   // namespace row
 }   // namespace mf
