@@ -138,8 +138,6 @@ class StateSpaceModel(GaussMarkovDistribution):
             t.requires_grad for t in (self._mu_0, self._chol_P_0, self._A_s, self._b_s, self._chol_Q_s))
 
     def _differentiable_marginals(self) -> Tuple[torch.Tensor, torch.Tensor]:
-        if self.state_dim > _lib.load().mf_max_state_dim():
-            raise NotImplementedError("gradients of the marginals: state_dim <= 9")
         means, covs = _Marginals.apply(*self._flat_params())
         batch, n, d = tuple(self.batch_shape), self.num_transitions + 1, self.state_dim
         return means.reshape(batch + (n, d)), covs.reshape(batch + (n, d, d))
@@ -339,8 +337,6 @@ class StateSpaceModel(GaussMarkovDistribution):
         if torch.is_grad_enabled() and isinstance(dist, StateSpaceModel):
             tensors = self._flat_params() + dist._flat_params()
             if any(t.requires_grad for t in tensors):
-                if self.state_dim > _lib.load().mf_max_state_dim():
-                    raise NotImplementedError("gradients of kl_divergence: state_dim <= 9")
                 return _KLDivergence.apply(*tensors).reshape(tuple(self.batch_shape))
         return _lib.checked(self._kl_divergence_value(dist))
 
@@ -398,6 +394,67 @@ class StateSpaceModel(GaussMarkovDistribution):
         return 0.5 * (cst + log_det + mahalanobis)
 
 
+# ---- gradients beyond the register-resident kernels (10 <= d <= 64: BASELINE config 5's state dimension) ---------------------------
+# The HIP kernels give the VALUES for every state dimension; the adjoint kernels (mf_ssm_kl_grad_*, mf_ssm_marginals_grad_*) stop at
+# d = 9.  Above that the backward re-evaluates the quantity with differentiable batched products - the moment recursion as a
+# parallel scan in time (log2 T rounds of [B, T, d, d] GEMMs: plain rocBLAS calls, no sequential loop over T) - and lets torch
+# differentiate that.  Same numbers as the forward (checked), an order of magnitude slower than a dedicated adjoint kernel would be.
+def _dense_moments(mu0, cp0, a_s, b_s, cq):
+    """Differentiable ``(means [B,T,d], covs [B,T,d,d])`` of a chain: inclusive scan of the maps x -> A x + b, S -> A S A^T + Q."""
+    tr = lambda t: t.transpose(-1, -2)                                    # noqa: E731
+    n = a_s.shape[1] + 1
+    if n == 1:
+        return mu0[:, None], (cp0 @ tr(cp0))[:, None]
+    phi, beta, sig = a_s, b_s, cq @ tr(cq)                                # element k: the map of transition k
+    off = 1
+    while off < n - 1:                                                    # Hillis-Steele: element k absorbs element k - off
+        p2, b2, s2 = phi[:, off:], beta[:, off:], sig[:, off:]
+        p1, b1, s1 = phi[:, :-off], beta[:, :-off], sig[:, :-off]
+        phi = torch.cat([phi[:, :off], p2 @ p1], dim=1)
+        beta = torch.cat([beta[:, :off], (p2 @ b1[..., None])[..., 0] + b2], dim=1)
+        sig = torch.cat([sig[:, :off], p2 @ s1 @ tr(p2) + s2], dim=1)
+        off *= 2
+    p0 = cp0 @ tr(cp0)
+    means = torch.cat([mu0[:, None], (phi @ mu0[:, None, :, None])[..., 0] + beta], dim=1)
+    covs = torch.cat([p0[:, None], phi @ p0[:, None] @ tr(phi) + sig], dim=1)
+    return means, covs
+
+
+def _dense_kl(q1, q2):
+    """Differentiable ``KL(q1 || q2)`` per series in its local form (mf_kl_grad.hpp): q1's marginals by ``_dense_moments``, then
+    ``1/2 [|C2^-1 C1|^2 + tr(W S W^T) + |C2^-1 eps|^2] + log|C2| - log|C1|`` per transition (W = C2^-1 dA, eps = dA m + db) and the
+    same for the initial state, minus ``T d / 2``."""
+    mu1, c01, a1, b1, c1 = q1
+    mu2, c02, a2, b2, c2 = q2
+    tri = torch.linalg.solve_triangular
+    logdiag = lambda c: torch.sum(torch.log(torch.abs(torch.diagonal(c, dim1=-2, dim2=-1))), dim=-1)   # noqa: E731
+    means, covs = _dense_moments(mu1, c01, a1, b1, c1)
+    n, d = a1.shape[1] + 1, mu1.shape[-1]
+    u0 = tri(c02, (mu1 - mu2)[..., None], upper=False)
+    out = 0.5 * (torch.sum(tri(c02, c01, upper=False) ** 2, dim=(-2, -1)) + torch.sum(u0 ** 2, dim=(-2, -1))) + logdiag(c02) - logdiag(c01)
+    if n > 1:
+        m_k, s_k = means[:, :-1], covs[:, :-1]
+        d_a = a1 - a2
+        eps = (d_a @ m_k[..., None])[..., 0] + (b1 - b2)
+        w = tri(c2, d_a, upper=False)
+        u = tri(c2, eps[..., None], upper=False)
+        terms = 0.5 * (torch.sum(tri(c2, c1, upper=False) ** 2, dim=(-2, -1)) + torch.sum((w @ s_k) * w, dim=(-2, -1))
+                       + torch.sum(u ** 2, dim=(-2, -1))) + logdiag(c2) - logdiag(c1)
+        out = out + torch.sum(terms, dim=-1)
+    return out - 0.5 * n * d
+
+
+def _dense_backward(fn, tensors, grad_outputs):
+    """Gradients of ``fn(*tensors)`` (a tuple of tensors) for the incoming ``grad_outputs``, by re-evaluation under autograd."""
+    with torch.enable_grad():
+        leaves = [t.detach().requires_grad_(True) for t in tensors]
+        outs = fn(*leaves)
+        outs = outs if isinstance(outs, tuple) else (outs,)
+        pairs = [(o, g) for o, g in zip(outs, grad_outputs) if g is not None]
+        grads = torch.autograd.grad([o for o, _ in pairs], leaves, [g for _, g in pairs], allow_unused=True)
+    return tuple(torch.zeros_like(t) if g is None else g for t, g in zip(tensors, grads))
+
+
 class _KLDivergence(torch.autograd.Function):
     """
     ``KL(q1 ∥ q2)`` per series as a differentiable function of the flat parameters of both chains.  Forward: the operator
@@ -423,6 +480,10 @@ class _KLDivergence(torch.autograd.Function):
     def backward(ctx, grad_out):
         tensors = ctx.saved_tensors
         mu1, c01, a1, b1, c1, mu2, c02, a2, b2, c2 = tensors[:10]
+        if mu1.shape[-1] > _lib.load().mf_max_state_dim():
+            grads = _dense_backward(lambda *t: _dense_kl(t[:5], t[5:]), tensors[:10], (grad_out.reshape(mu1.shape[0]),))
+            # the chain's factors are lower triangular by construction: only those entries vary
+            return tuple(torch.tril(g) if i % 5 in (1, 4) else g for i, g in enumerate(grads))
         with torch.no_grad():
             extra = list(tensors[10:])
             if ctx.has_moments:           # few series: the forward's scans already produced q1's moments
@@ -465,11 +526,17 @@ class _Marginals(torch.autograd.Function):
         with torch.no_grad():
             ssm = StateSpaceModel(mu0, cp0, a_s, b_s, cq)
             means, covs, _ = ssm._moments(want_sub=False)
-        ctx.save_for_backward(cp0, a_s, cq, means, covs)
+        if a_s.shape[-1] > _lib.load().mf_max_state_dim():
+            ctx.save_for_backward(mu0, cp0, a_s, b_s, cq)           # the dense backward re-evaluates the recursion
+        else:
+            ctx.save_for_backward(cp0, a_s, cq, means, covs)
         return means, covs
 
     @staticmethod
     def backward(ctx, g_means, g_covs):
+        if len(ctx.saved_tensors) == 5 and ctx.saved_tensors[0].dim() == 2:       # (mu0, ...): state_dim > 9
+            grads = _dense_backward(_dense_moments, ctx.saved_tensors, (g_means, g_covs))
+            return tuple(torch.tril(g) if i in (1, 4) else g for i, g in enumerate(grads))
         cp0, a_s, cq, means, covs = ctx.saved_tensors
         bsz, nt, d = a_s.shape[0], a_s.shape[1], a_s.shape[-1]
         with torch.no_grad():

@@ -273,3 +273,23 @@ def test_dense_local_gradients_match_autograd_of_the_dense_joint():
         want = cpu[k].grad.numpy()
         want = np.tril(want) if k in ("cp0", "cq") else want
         np.testing.assert_allclose(g.numpy(), want, rtol=1e-9, atol=1e-11, err_msg=k)
+
+
+@pytest.mark.parametrize("t", [1, 2, 3, 7, 12])
+def test_dense_scan_of_the_moments_and_local_kl_match_the_oracle(t):
+    """What the backward of `marginals` / `kl_divergence` re-evaluates for state dimensions above 9 (state_space_model._dense_moments:
+    the recursion as a parallel scan in batched products; _dense_kl: the local form of the divergence) against the numpy oracle."""
+    from oracle import numpy_oracle as O
+    from markovflow_amd.state_space_model import _dense_kl, _dense_moments
+
+    def chain(seed, bsz=2, d=11):
+        r = np.random.default_rng(seed)
+        return (r.normal(size=(bsz, d)), np.tril(0.2 * r.normal(size=(bsz, d, d))) + np.eye(d),
+                0.7 * np.eye(d) + 0.1 * r.normal(size=(bsz, t - 1, d, d)), 0.1 * r.normal(size=(bsz, t - 1, d)),
+                np.tril(0.1 * r.normal(size=(bsz, t - 1, d, d))) + 0.5 * np.eye(d))
+    q1, q2 = chain(3), chain(4)
+    t1, t2 = [torch.tensor(x) for x in q1], [torch.tensor(x) for x in q2]
+    means, covs = _dense_moments(*t1)
+    np.testing.assert_allclose(means.numpy(), O.ssm_marginal_means(q1[0], q1[2], q1[3]), rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(covs.numpy(), O.ssm_marginal_covariances(q1[1], q1[2], q1[4]), rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(_dense_kl(t1, t2).numpy(), O.ssm_kl_divergence(q1, q2), rtol=1e-11)
