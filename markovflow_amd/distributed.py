@@ -61,8 +61,13 @@ def sharded_elbo(expected_log_likelihood: torch.Tensor, kl_divergence: torch.Ten
     Evidence lower bound of a batch sharded over the ranks (BASELINE config 4): every rank passes the variational expectations
     and the KL terms of ITS series (any shape; summed here), the result - identical on every rank - is
     ``sum_all E_q[log p(y|f)] - sum_all KL`` (``models/sparse_variational.py:192``).  The two partial sums travel as ONE
-    all-reduce of a single scalar.  Gradients: the value is returned detached from the collective - differentiate the LOCAL
-    terms (each rank owns the parameters of its own series; shared hyper-parameters need the usual gradient all-reduce).
+    all-reduce of a single scalar.  Gradients: the returned value carries the graph of THIS rank's terms (backward() gives the
+    gradients of the local series' parameters; shared hyper-parameters need the usual gradient all-reduce on top).
     """
     local = (torch.sum(expected_log_likelihood) - torch.sum(kl_divergence)).reshape(())
-    return all_reduce_sum(local.detach().clone(), group)
+    if not local.requires_grad:
+        return all_reduce_sum(local.clone(), group)
+    # keep the LOCAL graph: value = the all-reduced total, gradient = that of this rank's terms (each rank owns its series'
+    # parameters; shared hyper-parameters need the usual gradient all-reduce on top)
+    total = all_reduce_sum(local.detach().clone(), group)
+    return local + (total - local.detach())

@@ -444,6 +444,12 @@ def _dense_kl(q1, q2):
     return out - 0.5 * n * d
 
 
+def _dense_route(mu0, a_s) -> bool:
+    """The backward by re-evaluation: state dimensions above the adjoint kernels', and the degenerate shapes they do not take
+    (an empty local shard of a sharded batch, a chain without transitions)."""
+    return mu0.shape[-1] > _lib.load().mf_max_state_dim() or mu0.shape[0] == 0 or a_s.shape[1] == 0
+
+
 def _dense_backward(fn, tensors, grad_outputs):
     """Gradients of ``fn(*tensors)`` (a tuple of tensors) for the incoming ``grad_outputs``, by re-evaluation under autograd."""
     with torch.enable_grad():
@@ -480,7 +486,7 @@ class _KLDivergence(torch.autograd.Function):
     def backward(ctx, grad_out):
         tensors = ctx.saved_tensors
         mu1, c01, a1, b1, c1, mu2, c02, a2, b2, c2 = tensors[:10]
-        if mu1.shape[-1] > _lib.load().mf_max_state_dim():
+        if _dense_route(mu1, a1):
             grads = _dense_backward(lambda *t: _dense_kl(t[:5], t[5:]), tensors[:10], (grad_out.reshape(mu1.shape[0]),))
             # the chain's factors are lower triangular by construction: only those entries vary
             return tuple(torch.tril(g) if i % 5 in (1, 4) else g for i, g in enumerate(grads))
@@ -526,7 +532,7 @@ class _Marginals(torch.autograd.Function):
         with torch.no_grad():
             ssm = StateSpaceModel(mu0, cp0, a_s, b_s, cq)
             means, covs, _ = ssm._moments(want_sub=False)
-        if a_s.shape[-1] > _lib.load().mf_max_state_dim():
+        if _dense_route(mu0, a_s):
             ctx.save_for_backward(mu0, cp0, a_s, b_s, cq)           # the dense backward re-evaluates the recursion
         else:
             ctx.save_for_backward(cp0, a_s, cq, means, covs)

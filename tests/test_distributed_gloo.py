@@ -123,6 +123,11 @@ def _elbo_worker(rank, world, port, bsz, results):
         kl = mfd.sharded_kl_divergence(ql, pl)
         ell = torch.tensor(np.arange(bsz, dtype=np.float64)[lo:hi] * 0.25)        # any per-series expectation
         elbo = mfd.sharded_elbo(ell, ql.kl_divergence(pl))
+        # with a differentiable local term the total keeps THIS rank's graph: same value, local gradient
+        scale = torch.ones(hi - lo, dtype=torch.float64, requires_grad=True)
+        elbo_g = mfd.sharded_elbo(ell * scale, ql.kl_divergence(pl))
+        elbo_g.backward()
+        assert float(elbo_g) == float(elbo) and torch.equal(scale.grad, ell)
         results[rank] = (float(kl), float(elbo))
     finally:
         dist.destroy_process_group()
