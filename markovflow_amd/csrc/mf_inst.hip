@@ -413,12 +413,22 @@ inline long par_len0(long B, long n) {
     return n >= 2 * len ? len : 0;
 }
 
-// The parallel-in-time Cholesky / solve hierarchy in row form (mf_row_par.hpp: a 16-lane row per chunk instead of a lane):
-// from d = 5 on, where a block step on one lane is > 1 k instructions.  MF_BTD_ROW=0 / 1 forces it off / on (experiment builds).
-template <typename T> bool row_par_path() {
+// The parallel-in-time operators in row form (mf_row_par.hpp, mf_row_scan.hpp, mf_row_post.hpp: a 16-lane row per chunk instead
+// of a lane).  From d = 7 on always (a lane's state no longer fits its registers).  At d = 5, 6 the lane-per-chunk kernels are
+// register resident and carry 64 chunks per wavefront against the row kernels' 4, so the row form only pays where the
+// DEPENDENT block steps are the run time, i.e. with few level-0 chunks (`rows0`): measured at d = 6 - one chain of 10^5 blocks
+// (12 500 chunks) 167 -> 96 us, B=64 T=10^4 (80 000) 520 -> 430 us, but B=1024 T=2000 (256 000) 0.99 -> 1.08 ms and the
+// headline-shape backward 19.5 -> 22.5 ms.  MF_BTD_ROW=0 / 1 forces it off / on (experiment builds).
+template <typename T> bool row_par_path(long rows0) {
     static const int force = [] { const char* e = mf_knob("MF_BTD_ROW"); return e ? std::atoi(e) : -1; }();
     if (D + 1 > 16 || D < 2) return false;
-    return force >= 0 ? force != 0 : D >= 5;
+    if (force >= 0) return force != 0;
+    return D >= 7 || (D >= 5 && rows0 <= 131072);
+}
+// level-0 chunks of the time partition all of these operators share
+inline long par_rows0(long B, long n) {
+    const long len0 = par_len0(B, n);
+    return len0 > 0 ? B * cdiv(n, len0) : B;
 }
 
 // one step of prefetch in the row kernels when the level-0 rows are at most four wavefronts per SIMD
@@ -490,7 +500,7 @@ int btd_cholesky(long B, long n, const T* diag, const T* sub, T* ldiag, T* lsub,
         if (l == 0) return ParLevel<T>{diag, nullptr, nullptr, sub, n, n - 1, -1, 0};
         return ParLevel<T>{arr[l].Dv, arr[l].Gf, arr[l].GU, arr[l].F, pl.n[l], pl.n[l], 0, 0};
     };
-    if (row_par_path<T>()) {
+    if (row_par_path<T>(B * pl.n[1])) {
         if constexpr (D >= 2 && D + 1 <= 16) {
             const dim3 blk(64);
             auto rgrid = [](long rows) { return dim3((unsigned)cdiv(rows, 4)); };
@@ -581,7 +591,7 @@ int btd_solve(long Bl, long Br, long n, const T* ldiag, const T* lsub, const T* 
         arr[l].c = reinterpret_cast<T*>(p); p += align_up(size_t(Br) * pl.n[l] * D * sizeof(T));
         arr[l].Z = reinterpret_cast<T*>(p); p += align_up(size_t(Br) * pl.n[l] * D * sizeof(T));
     }
-    if (row_par_path<T>()) {
+    if (row_par_path<T>(Br * pl.n[1])) {
         if constexpr (D >= 2 && D + 1 <= 16) {
             const dim3 blk(64);
             auto rgrid = [](long rows) { return dim3((unsigned)cdiv(rows, 4)); };
@@ -683,7 +693,7 @@ int tak_scan(long B, long n, TakSrc<T> src, T* odiag, T* osub, void* ws, size_t 
         arr[l].Z = reinterpret_cast<T*>(p); p += sz;
     }
     if constexpr ((SRC == 1 || SRC == 2) && D >= 2 && D + 1 <= 16) {
-        if (row_par_path<T>()) {     // the covariance (and mean) scan / its adjoint in row form (mf_row_scan.hpp)
+        if (row_par_path<T>(B * pl.n[1])) {     // the covariance (and mean) scan / its adjoint in row form (mf_row_scan.hpp)
             const dim3 blk(64);
             auto rgrid = [](long rows) { return dim3((unsigned)cdiv(rows, 4)); };
             if (SRC == 1 && mup.oc != nullptr)
@@ -811,7 +821,7 @@ int btd_udl(long B, long n, const T* diag, const T* sub, T* ut, T* chol_d, const
         return ParLevel<T>{arr[l].Dv, arr[l].Gf, arr[l].GU, arr[l].F, pl.n[l], pl.n[l], 0, 0};
     };
     if constexpr (D >= 2 && D + 1 <= 16) {
-        if (row_par_path<T>() && (chain || eta == nullptr)) {
+        if (row_par_path<T>(B * pl.n[1]) && (chain || eta == nullptr)) {
             // everything in row form (mf_row_par.hpp, mf_row_post.hpp): reversed up-sweep, down-sweep, emit, the offsets' affine scan
             const dim3 blk(64);
             auto rgrid = [](long rows) { return dim3((unsigned)cdiv(rows, 4)); };
@@ -951,7 +961,7 @@ int ssm_means(long Bl, long Br, long Tn, const T* A, const T* offs, T* out, void
         arr[l].Z = reinterpret_cast<T*>(p); p += align_up(size_t(Br) * pl.n[l] * D * sizeof(T));
     }
     bool row_levels = false;
-    if constexpr (D >= 2 && D + 1 <= 16) row_levels = row_par_path<T>();
+    if constexpr (D >= 2 && D + 1 <= 16) row_levels = row_par_path<T>(Br * pl.n[1]);
     if (!have_up0) {
         if (row_levels) {
             if constexpr (D >= 2 && D + 1 <= 16)
@@ -1061,7 +1071,7 @@ int ssm_marginals(long B, long n, const T* mu0, const T* cholP0, const T* A, con
         return 0;
     }
     if constexpr (D >= 2 && D + 1 <= 16) {
-        if (row_par_path<T>()) {
+        if (row_par_path<T>(B * P)) {
             hipLaunchKernelGGL((row::row_cov_emit_kernel<T, D, 1, true>), dim3((unsigned)cdiv(B * P, 4)), dim3(64), 0, st, B, n, len0, P,
                                src, up_cov, ocov, osub, TakMean<T>{mu0, b, omean, up_mean});
             return hipGetLastError() == hipSuccess ? 0 : -1000;
@@ -1255,7 +1265,7 @@ int kl_value(long B, long Tn, const T* mu0_1, const T* C0_1, const T* A_1, const
         if (out_covs) pS = out_covs;
         if (out_means) pm = out_means;
         bool row_local = false;
-        if constexpr (D >= 2 && D + 1 <= 16) row_local = row_par_path<T>();
+        if constexpr (D >= 2 && D + 1 <= 16) row_local = row_par_path<T>(par_rows0(B, Tn));
         if (row_local) {
             if constexpr (D >= 2 && D + 1 <= 16) {
                 // row form: the scans up to the chunk boundaries, then ONE level-0 kernel that restarts q1's moments and evaluates
