@@ -293,3 +293,13 @@ def test_dense_scan_of_the_moments_and_local_kl_match_the_oracle(t):
     np.testing.assert_allclose(means.numpy(), O.ssm_marginal_means(q1[0], q1[2], q1[3]), rtol=1e-12, atol=1e-13)
     np.testing.assert_allclose(covs.numpy(), O.ssm_marginal_covariances(q1[1], q1[2], q1[4]), rtol=1e-12, atol=1e-13)
     np.testing.assert_allclose(_dense_kl(t1, t2).numpy(), O.ssm_kl_divergence(q1, q2), rtol=1e-11)
+
+
+def test_row_kernel_emulation_matches_the_oracle():
+    """scripts/row_sim.py executes the op sequence of the row kernels (csrc/mf_row.hpp) register by register with the one
+    cross-lane primitive they use - on the CPU, against the numpy oracle: the layout / sign bookkeeping of the kernel's design."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("row_sim", os.path.join(ROOT, "scripts", "row_sim.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main()          # asserts the worst relative deviation over its cases < 1e-10
