@@ -163,7 +163,7 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (!ldiag) return -6;                                                                                         \
         if (sub && !lsub) return -7;                                                                                   \
         if (Tn == 1) sub = nullptr;                                                                                    \
-        if (big) return mf::big_cholesky_##SUF(B, Tn, d, diag, sub, ldiag, lsub, info, S(stream));                     \
+        if (big) return mf::big_cholesky_##SUF(B, Tn, d, diag, sub, ldiag, lsub, ws, ws_bytes, info, S(stream));      \
         return t->btd_cholesky(B, Tn, diag, sub, ldiag, lsub, ws, ws_bytes, info, S(stream));                          \
     }                                                                                                                  \
     int mf_btd_solve_##SUF(int64_t Bl, int64_t Br, int64_t Tn, int d, const T* ldiag, const T* lsub, const T* rhs,     \
@@ -254,7 +254,8 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (eta && (!m_post || !chol_dinv)) return -9;                                                                 \
         if (chain_layout && (!eta || Tn < 2)) return -11;                                                              \
         if (big && chain_layout) return -101;                                                                          \
-        if (big) return mf::big_udl_##SUF(B, Tn, d, diag, sub, ut, chol_d, eta, m_post, chol_dinv, info, S(stream));   \
+        if (big) return mf::big_udl_##SUF(B, Tn, d, diag, sub, ut, chol_d, eta, m_post, chol_dinv, ws, ws_bytes, info, \
+                                       S(stream));                                                                 \
         return t->btd_udl(B, Tn, diag, sub, ut, chol_d, eta, m_post, chol_dinv, chain_layout, ws, ws_bytes, info,      \
                           S(stream));                                                                                  \
     }                                                                                                                  \
@@ -428,8 +429,13 @@ MF_DEFINE4(f32, float)
 MF_DEFINE5(f64, double)
 MF_DEFINE5(f32, float)
 
+static bool big_dim(int d, int elem_size) {
+    return d > mf::MF_MAX_D && d <= (elem_size == 4 ? mf::MF_MAX_D_BIG : mf::MF_MAX_D_BIG_F64);
+}
+
 size_t mf_btd_cholesky_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {
     if (B < 1 || T < 1) return 0;
+    if (big_dim(d, elem_size)) return mf::big_btd_par_ws(B, T, d, 0, elem_size);
     if (elem_size == 4) { const auto* t = table_for<float>(d); return t ? t->btd_cholesky_ws(B, T) : 0; }
     const auto* t = table_for<double>(d);
     return t ? t->btd_cholesky_ws(B, T) : 0;
@@ -453,6 +459,7 @@ size_t mf_btd_diag_of_inverse_workspace_bytes(int64_t B, int64_t T, int d, int e
 
 size_t mf_btd_udl_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {
     if (B < 1 || T < 1) return 0;
+    if (big_dim(d, elem_size)) return mf::big_btd_par_ws(B, T, d, 1, elem_size);
     if (elem_size == 4) { const auto* t = table_for<float>(d); return t ? t->btd_udl_ws(B, T) : 0; }
     const auto* t = table_for<double>(d);
     return t ? t->btd_udl_ws(B, T) : 0;

@@ -140,6 +140,7 @@ __device__ __forceinline__ double mf_log(double x) { return log(x); }
 #define MF_BIG_NS big
 #include "mf_big_impl.hpp"
 #include "mf_bigops_impl.hpp"
+#include "mf_bigpar_impl.hpp"
 #undef MF_BIG_T
 #undef MF_BIG_NS
 // fp64: v_mfma_f64_16x16x4_f64 (same operand maps, accumulator rows q + 4 e); seven tiles fit up to DP = 32
@@ -147,5 +148,6 @@ __device__ __forceinline__ double mf_log(double x) { return log(x); }
 #define MF_BIG_NS bigd
 #include "mf_big_impl.hpp"
 #include "mf_bigops_impl.hpp"
+#include "mf_bigpar_impl.hpp"
 #undef MF_BIG_T
 #undef MF_BIG_NS

@@ -27,8 +27,9 @@ int big_kf_loglik_f64(long B, long Tn, int d, int m, const double* mu0, const do
 
 
 #define MF_BIG_EXPORT(SUF, T, NS)                                                                                            \
-    int big_cholesky_##SUF(long B, long n, int d, const T* diag, const T* sub, T* ldiag, T* lsub, int* info, hipStream_t st) { \
-        return NS::op_cholesky(B, n, d, diag, sub, ldiag, lsub, info, st);                                                   \
+    int big_cholesky_##SUF(long B, long n, int d, const T* diag, const T* sub, T* ldiag, T* lsub, void* ws, size_t ws_bytes,   \
+                           int* info, hipStream_t st) {                                                                      \
+        return NS::op_cholesky_par(B, n, d, diag, sub, ldiag, lsub, ws, ws_bytes, info, st);                                 \
     }                                                                                                                        \
     int big_solve_##SUF(long Bl, long Br, long n, int d, const T* ldiag, const T* lsub, const T* rhs, T* out, int transpose,  \
                         hipStream_t st) {                                                                                    \
@@ -45,8 +46,8 @@ int big_kf_loglik_f64(long B, long Tn, int d, int m, const double* mu0, const do
         return NS::op_diag_of_inverse(B, n, d, ldiag, lsub, odiag, osub, st);                                                \
     }                                                                                                                        \
     int big_udl_##SUF(long B, long n, int d, const T* diag, const T* sub, T* ut, T* chol_d, const T* eta, T* m_post,          \
-                      T* chol_dinv, int* info, hipStream_t st) {                                                             \
-        return NS::op_udl(B, n, d, diag, sub, ut, chol_d, eta, m_post, chol_dinv, info, st);                                 \
+                      T* chol_dinv, void* ws, size_t ws_bytes, int* info, hipStream_t st) {                                  \
+        return NS::op_udl_par(B, n, d, diag, sub, ut, chol_d, eta, m_post, chol_dinv, ws, ws_bytes, info, st);               \
     }                                                                                                                        \
     int big_ssm_precision_##SUF(long B, long Tn, int d, int m, const T* mu0, const T* cholP0, const T* A, const T* b,         \
                                 const T* cholQ, const T* H, const T* y, const T* Rinv, int rinv_per_step, T* diag, T* sub,    \
@@ -65,6 +66,10 @@ int big_kf_loglik_f64(long B, long Tn, int d, int m, const double* mu0, const do
     }
 size_t big_marginal_covs_ws(long B, long n, int d, int elem_size) {
     return elem_size == 4 ? big::marginal_covs_ws(B, n, d) : bigd::marginal_covs_ws(B, n, d);
+}
+// workspace of the time-partitioned factorisations (mf_bigpar_impl.hpp); chain: the posterior chain's right-hand-side maps too
+size_t big_btd_par_ws(long B, long n, int d, int chain, int elem_size) {
+    return elem_size == 4 ? big::bigpar_ws(B, n, d, chain != 0) : bigd::bigpar_ws(B, n, d, chain != 0);
 }
 MF_BIG_EXPORT(f32, float, big)
 MF_BIG_EXPORT(f64, double, bigd)

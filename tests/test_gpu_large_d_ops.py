@@ -137,3 +137,47 @@ def test_large_d_marginal_covariances_partitioned_in_time(rng, dtype, d, bsz, t)
     if dtype == torch.float64 and t <= 40:
         ref = ssm.precision.cholesky.block_diagonal_of_inverse()
         np.testing.assert_allclose(nn(ref), np.stack(ec), rtol=1e-7, atol=1e-9)
+
+
+# ---- time-partitioned factorisations (csrc/mf_bigpar_impl.hpp): chains long enough for >= 4 chunks per series ----------------------
+PAR_CASES = [(torch.float64, 10), (torch.float64, 19), (torch.float64, 32), (torch.float32, 12), (torch.float32, 33),
+             (torch.float32, 48), (torch.float32, 64)]
+
+
+@pytest.mark.parametrize("dtype,d", PAR_CASES)
+@pytest.mark.parametrize("bsz,n", [(1, 67), (3, 300), (2, 32)])
+def test_large_d_cholesky_and_udl_partitioned_in_time(rng, dtype, d, bsz, n):
+    """block_tri_diag.py:423-436 / :438-545 on chains cut into chunks (up-sweep with a spike, chunk-end pivots, emit): the NATURAL
+    ORDER factors, block by block, against the oracle's serial recursions; ragged last chunks (67 = 8 x 9 - 5, 300 = 37 x 9 - 33)."""
+    diag, sub = scaled_spd_btd(rng, (bsz,), n, d, True)
+    if dtype == torch.float32:
+        diag, sub = diag.astype(np.float32).astype(np.float64), sub.astype(np.float32).astype(np.float64)
+    tol = TOL[dtype]
+    sym = mfa.SymmetricBlockTriDiagonal(tt(diag, dtype), tt(sub, dtype))
+    chol = sym.cholesky
+    ld, ls = O.btd_cholesky(diag, sub)
+    np.testing.assert_allclose(nn(chol.block_diagonal), np.tril(ld), **tol)
+    np.testing.assert_allclose(nn(chol.block_sub_diagonal), ls, **tol)
+    u_t, chol_d = sym.upper_diagonal_lower()
+    want_u, want_c = O.btd_upper_diagonal_lower(diag, sub)
+    np.testing.assert_allclose(nn(u_t.block_sub_diagonal), want_u, **tol)
+    np.testing.assert_allclose(nn(chol_d.block_diagonal), np.tril(want_c), **tol)
+
+
+@pytest.mark.parametrize("dtype,d,m,t", [(torch.float64, 14, 1, 90), (torch.float64, 32, 3, 41), (torch.float32, 20, 2, 260),
+                                         (torch.float32, 64, 32, 70)])
+def test_large_d_posterior_chain_partitioned_in_time(rng, dtype, d, m, t):
+    """kalman_filter.py:109-182 for d > 9 on a chain long enough for the partition: all five tensors of the posterior chain (the
+    means come from the affine recursion restarted at the chunk boundaries) against the oracle."""
+    kw = random_ssm(rng, (2,), t, d, m, well=True)
+    if dtype == torch.float32:
+        kw = {k: v.astype(np.float32).astype(np.float64) for k, v in kw.items()}
+    cov = 0.4 * np.eye(m)
+    kf = build_kf(kw, np.linalg.cholesky(cov), dtype=dtype)
+    tol = dict(rtol=1e-7, atol=1e-9) if dtype == torch.float64 else dict(rtol=5e-3, atol=5e-4)
+    post = kf.posterior_state_space_model()
+    want = O.kf_posterior_ssm(**kw, r_inv=np.linalg.inv(cov))
+    got = (post.initial_mean, post.cholesky_initial_covariance, post.state_transitions, post.state_offsets,
+           post.cholesky_process_covariances)
+    for g, w in zip(got, want):
+        np.testing.assert_allclose(nn(g), w, **tol)
