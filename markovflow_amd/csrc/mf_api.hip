@@ -174,7 +174,7 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (!rhs) return -7;                                                                                           \
         if (!out) return -8;                                                                                           \
         if (Tn == 1) lsub = nullptr;                                                                                   \
-        if (big) return mf::big_solve_##SUF(Bl, Br, Tn, d, ldiag, lsub, rhs, out, transpose, S(stream));               \
+        if (big) return mf::big_solve_##SUF(Bl, Br, Tn, d, ldiag, lsub, rhs, out, transpose, ws, ws_bytes, S(stream)); \
         return t->btd_solve(Bl, Br, Tn, ldiag, lsub, rhs, out, transpose, ws, ws_bytes, S(stream));                    \
     }                                                                                                                  \
     int mf_btd_matvec_##SUF(int64_t Bl, int64_t Br, int64_t Tn, int d, const T* diag, const T* sub, const T* x,        \
@@ -213,7 +213,7 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (!odiag) return -6;                                                                                         \
         if (Tn == 1) lsub = nullptr;                                                                                   \
         if (!lsub) osub = nullptr;                                                                                     \
-        if (big) return mf::big_diag_of_inverse_##SUF(B, Tn, d, ldiag, lsub, odiag, osub, S(stream));                  \
+        if (big) return mf::big_diag_of_inverse_##SUF(B, Tn, d, ldiag, lsub, odiag, osub, ws, ws_bytes, S(stream));   \
         return t->btd_diag_of_inverse(B, Tn, ldiag, lsub, odiag, osub, ws, ws_bytes, S(stream));                       \
     }                                                                                                                  \
     int mf_ssm_marginal_covariances_##SUF(int64_t B, int64_t Tn, int d, const T* cholP0, const T* A, const T* cholQ,   \
@@ -442,6 +442,7 @@ size_t mf_btd_cholesky_workspace_bytes(int64_t B, int64_t T, int d, int elem_siz
 }
 size_t mf_btd_solve_workspace_bytes(int64_t Bl, int64_t Br, int64_t T, int d, int elem_size) {
     if (Bl < 1 || Br < 1 || T < 1) return 0;
+    if (big_dim(d, elem_size)) return mf::big_btd_solve_ws(Bl, Br, T, d, elem_size);
     if (elem_size == 4) { const auto* t = table_for<float>(d); return t ? t->btd_solve_ws(Bl, Br, T) : 0; }
     const auto* t = table_for<double>(d);
     return t ? t->btd_solve_ws(Bl, Br, T) : 0;
@@ -449,9 +450,12 @@ size_t mf_btd_solve_workspace_bytes(int64_t Bl, int64_t Br, int64_t T, int d, in
 
 size_t mf_btd_diag_of_inverse_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {
     if (B < 1 || T < 1) return 0;
-    // large d: the (time-partitioned) covariance recursion of mf_ssm_marginal_covariances is the only user of a workspace
-    const bool big = d > mf::MF_MAX_D && d <= (elem_size == 4 ? mf::MF_MAX_D_BIG : mf::MF_MAX_D_BIG_F64);
-    if (big) return mf::big_marginal_covs_ws(B, T, d, elem_size);
+    // large d: one buffer sized for both users of this query - the time-partitioned Takahashi recursion of
+    // mf_btd_diag_of_inverse and the covariance recursion of mf_ssm_marginal_covariances
+    if (big_dim(d, elem_size)) {
+        const size_t a = mf::big_marginal_covs_ws(B, T, d, elem_size), b = mf::big_btd_tak_ws(B, T, d, elem_size);
+        return a > b ? a : b;
+    }
     if (elem_size == 4) { const auto* t = table_for<float>(d); return t ? t->btd_diag_of_inverse_ws(B, T) : 0; }
     const auto* t = table_for<double>(d);
     return t ? t->btd_diag_of_inverse_ws(B, T) : 0;

@@ -32,8 +32,8 @@ int big_kf_loglik_f64(long B, long Tn, int d, int m, const double* mu0, const do
         return NS::op_cholesky_par(B, n, d, diag, sub, ldiag, lsub, ws, ws_bytes, info, st);                                 \
     }                                                                                                                        \
     int big_solve_##SUF(long Bl, long Br, long n, int d, const T* ldiag, const T* lsub, const T* rhs, T* out, int transpose,  \
-                        hipStream_t st) {                                                                                    \
-        return NS::op_solve(Bl, Br, n, d, ldiag, lsub, rhs, out, transpose, st);                                             \
+                        void* ws, size_t ws_bytes, hipStream_t st) {                                                         \
+        return NS::op_solve_par(Bl, Br, n, d, ldiag, lsub, rhs, out, transpose, ws, ws_bytes, st);                           \
     }                                                                                                                        \
     int big_matvec_##SUF(long Bl, long Br, long n, int d, const T* diag, const T* sub, const T* x, T* out, int mode,          \
                          hipStream_t st) {                                                                                   \
@@ -42,8 +42,9 @@ int big_kf_loglik_f64(long B, long Tn, int d, int m, const double* mu0, const do
     int big_logdet_##SUF(long B, long n, int d, const T* ldiag, T* out, hipStream_t st) {                                    \
         return NS::op_logdet(B, n, d, ldiag, out, st);                                                                       \
     }                                                                                                                        \
-    int big_diag_of_inverse_##SUF(long B, long n, int d, const T* ldiag, const T* lsub, T* odiag, T* osub, hipStream_t st) {  \
-        return NS::op_diag_of_inverse(B, n, d, ldiag, lsub, odiag, osub, st);                                                \
+    int big_diag_of_inverse_##SUF(long B, long n, int d, const T* ldiag, const T* lsub, T* odiag, T* osub, void* ws,          \
+                                  size_t ws_bytes, hipStream_t st) {                                                         \
+        return NS::op_diag_of_inverse_par(B, n, d, ldiag, lsub, odiag, osub, ws, ws_bytes, st);                              \
     }                                                                                                                        \
     int big_udl_##SUF(long B, long n, int d, const T* diag, const T* sub, T* ut, T* chol_d, const T* eta, T* m_post,          \
                       T* chol_dinv, void* ws, size_t ws_bytes, int* info, hipStream_t st) {                                  \
@@ -70,6 +71,12 @@ size_t big_marginal_covs_ws(long B, long n, int d, int elem_size) {
 // workspace of the time-partitioned factorisations (mf_bigpar_impl.hpp); chain: the posterior chain's right-hand-side maps too
 size_t big_btd_par_ws(long B, long n, int d, int chain, int elem_size) {
     return elem_size == 4 ? big::bigpar_ws(B, n, d, chain != 0) : bigd::bigpar_ws(B, n, d, chain != 0);
+}
+size_t big_btd_solve_ws(long Bl, long Br, long n, int d, int elem_size) {
+    return elem_size == 4 ? big::bigpar_solve_ws(Bl, Br, n, d) : bigd::bigpar_solve_ws(Bl, Br, n, d);
+}
+size_t big_btd_tak_ws(long B, long n, int d, int elem_size) {
+    return elem_size == 4 ? big::bigpar_tak_ws(B, n, d) : bigd::bigpar_tak_ws(B, n, d);
 }
 MF_BIG_EXPORT(f32, float, big)
 MF_BIG_EXPORT(f64, double, bigd)

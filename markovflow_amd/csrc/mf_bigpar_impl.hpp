@@ -261,6 +261,189 @@ __global__ void __launch_bounds__(NTHR) bigpar_udl_means_kernel(long B, long n, 
     }
 }
 
+// ---- solve ---------------------------------------------------------------------------------------------------------------------------
+// positions p (TR: p <-> block n-1-p):  z_p = Ainv_p (r_p - C_p z_{p-1}),  Ainv = L_k^-1 / L_k^-T,  C = lsub[k-1] / lsub[k]^T.
+// compose: chunk c (< P-1) runs the recursion from z = 0 (-> a_c) and composes N_c = prod(-Ainv_p C_p) beside it.
+template <int DP, int TR>
+__global__ void __launch_bounds__(NTHR) bigpar_solve_compose_kernel(long Bl, long Br, long n, int d, long P, long L,
+                                                                   const real* __restrict__ ldiag, const real* __restrict__ lsub,
+                                                                   const real* __restrict__ rhs, real* __restrict__ oN,
+                                                                   real* __restrict__ oa) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const Smem<DP> sm{reinterpret_cast<real*>(smem_raw)};
+    const long r = blockIdx.x / (P - 1), c = blockIdx.x % (P - 1), s = r % Bl;
+    const long p0 = c * L, dd = (long)d * d;
+    long p1 = p0 + L;
+    if (p1 > n) p1 = n;
+    real *Lt = sm.tile(0), *Linv = sm.tile(1), *C = sm.tile(2), *N = sm.tile(3), *T1 = sm.tile(4), *N2 = sm.tile(5);
+    real *z = sm.vec(0), *x = sm.vec(1);
+    bool bad = false;
+    if (threadIdx.x < 64) z[threadIdx.x] = 0;
+    if (c > 0) identity_tile<DP>(N);
+    __syncthreads();
+    for (long p = p0; p < p1; ++p) {
+        const long k = TR ? n - 1 - p : p;
+        load_tile<DP>(Lt, ldiag + (s * n + k) * dd, nullptr, d, true, true);
+        load_vec_lds<DP>(x, rhs + (r * n + k) * d, nullptr, d);
+        const bool coupled = p > 0;
+        if (coupled) load_tile<DP>(C, lsub + (s * (n - 1) + (TR ? k : k - 1)) * dd, nullptr, d, false, false);
+        __syncthreads();
+        if (coupled) matvec<DP, TR>(C, z, x, -1.f, 1.f, sm.scratch());
+        (void)factor_invert<DP, false>(Lt, Linv, bad, sm.scratch());
+        matvec<DP, TR>(Linv, x, z, 1.f, 0.f, sm.scratch());
+        if (c > 0) {
+            gemm<DP, TR, 0, 0, K_FULL, O_FULL>(C, N, T1, 1.f);
+            __syncthreads();
+            gemm<DP, TR, 0, 0, TR ? K_A_UPPER : K_A_LOWER, O_FULL>(Linv, T1, N2, -1.f);
+            real* t = N; N = N2; N2 = t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < d) oa[(r * P + c) * d + threadIdx.x] = z[threadIdx.x];
+    if (c > 0) store_tile<DP>(oN + (r * P + c) * dd, N, d);
+}
+// emit: chunk c walks the maps of the chunks before it, then the plain recursion over its own blocks
+template <int DP, int TR>
+__global__ void __launch_bounds__(NTHR) bigpar_solve_emit_kernel(long Bl, long Br, long n, int d, long P, long L,
+                                                                const real* __restrict__ ldiag, const real* __restrict__ lsub,
+                                                                const real* __restrict__ rhs, const real* __restrict__ wN,
+                                                                const real* __restrict__ wa, real* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const Smem<DP> sm{reinterpret_cast<real*>(smem_raw)};
+    const long r = blockIdx.x / P, c = blockIdx.x % P, s = r % Bl;
+    const long p0 = c * L, dd = (long)d * d;
+    long p1 = p0 + L;
+    if (p1 > n) p1 = n;
+    real *Lt = sm.tile(0), *Linv = sm.tile(1), *C = sm.tile(2);
+    real *z = sm.vec(0), *x = sm.vec(1);
+    bool bad = false;
+    if (threadIdx.x < 64) z[threadIdx.x] = 0;
+    __syncthreads();
+    for (long j = 0; j < c; ++j) {
+        load_vec_lds<DP>(x, wa + (r * P + j) * d, nullptr, d);
+        if (j > 0) load_tile<DP>(C, wN + (r * P + j) * dd, nullptr, d, false, false);
+        __syncthreads();
+        if (j > 0) matvec<DP, 0>(C, z, x, 1.f, 1.f, sm.scratch());
+        if (threadIdx.x < 64) z[threadIdx.x] = x[threadIdx.x];
+        __syncthreads();
+    }
+    for (long p = p0; p < p1; ++p) {
+        const long k = TR ? n - 1 - p : p;
+        load_tile<DP>(Lt, ldiag + (s * n + k) * dd, nullptr, d, true, true);
+        load_vec_lds<DP>(x, rhs + (r * n + k) * d, nullptr, d);
+        const bool coupled = p > 0;
+        if (coupled) load_tile<DP>(C, lsub + (s * (n - 1) + (TR ? k : k - 1)) * dd, nullptr, d, false, false);
+        __syncthreads();
+        if (coupled) matvec<DP, TR>(C, z, x, -1.f, 1.f, sm.scratch());
+        (void)factor_invert<DP, false>(Lt, Linv, bad, sm.scratch());
+        matvec<DP, TR>(Linv, x, z, 1.f, 0.f, sm.scratch());
+        if (threadIdx.x < d) out[(r * n + k) * d + threadIdx.x] = z[threadIdx.x];
+        __syncthreads();
+    }
+}
+
+// ---- block_diagonal_of_inverse (block Takahashi, block_tri_diag.py:318-337) ----------------------------------------------------------------
+// positions p = n-1-k:  Sigma_p = C_p + G_p^T Sigma_{p-1} G_p,  C = L^-T L^-1,  G = W L^-1 (W = lsub[k]) - a congruence recursion.
+// compose: chunk c (< P-1) leaves  Sigma_end = Nc + Mc^T Sigma_start Mc  (Mc = G_{p0} ... G_{p1-1}; chunk 0 starts uncoupled: Nc only).
+template <int DP>
+__global__ void __launch_bounds__(NTHR) bigpar_tak_compose_kernel(long B, long n, int d, long P, long L, const real* __restrict__ ldiag,
+                                                                 const real* __restrict__ lsub, real* __restrict__ oM,
+                                                                 real* __restrict__ oN) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const Smem<DP> sm{reinterpret_cast<real*>(smem_raw)};
+    const long s = blockIdx.x / (P - 1), c = blockIdx.x % (P - 1);
+    const long p0 = c * L, dd = (long)d * d;
+    long p1 = p0 + L;
+    if (p1 > n) p1 = n;
+    real *G = sm.tile(0), *Linv = sm.tile(1), *W = sm.tile(2), *Cn = sm.tile(3), *Nc = sm.tile(4), *M = sm.tile(5), *M2 = sm.tile(6);
+    bool bad = false;
+    zero_tile<DP>(Nc);
+    if (c > 0) identity_tile<DP>(M);
+    __syncthreads();
+    for (long p = p0; p < p1; ++p) {
+        const long k = n - 1 - p;
+        load_tile<DP>(G, ldiag + (s * n + k) * dd, nullptr, d, true, true);            // L_k, replaced by G_k below
+        const bool coupled = p > 0;
+        if (coupled) load_tile<DP>(W, lsub + (s * (n - 1) + k) * dd, nullptr, d, false, false);
+        __syncthreads();
+        (void)factor_invert<DP, false>(G, Linv, bad, sm.scratch());
+        gemm<DP, 1, 0, 0, K_A_UPPER, O_FULL>(Linv, Linv, Cn, 1.f);                      // L^-T L^-1
+        if (coupled) {
+            gemm<DP, 0, 0, 0, K_B_LOWER, O_FULL>(W, Linv, G, 1.f);                      // G = W L^-1
+            __syncthreads();
+            gemm<DP, 0, 0, 0, K_FULL, O_FULL>(Nc, G, W, 1.f);                           // Nc G   (W is free)
+            if (c > 0) gemm<DP, 0, 0, 0, K_FULL, O_FULL>(M, G, M2, 1.f);                // M <- M G
+            __syncthreads();
+            gemm<DP, 1, 0, 1, K_FULL, O_FULL>(G, W, Cn, 1.f);                           // + G^T Nc G
+            if (c > 0) { real* t = M; M = M2; M2 = t; }
+        }
+        __syncthreads();
+        { real* t = Nc; Nc = Cn; Cn = t; }
+    }
+    store_tile<DP>(oN + (s * P + c) * dd, Nc, d);
+    if (c > 0) store_tile<DP>(oM + (s * P + c) * dd, M, d);
+}
+// start[s, c] = Sigma at the end of chunk c - 1 (c = 1 ... P-1)
+template <int DP>
+__global__ void __launch_bounds__(NTHR) bigpar_tak_boundary_kernel(long B, int d, long P, const real* __restrict__ wM,
+                                                                  const real* __restrict__ wN, real* __restrict__ start) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const Smem<DP> sm{reinterpret_cast<real*>(smem_raw)};
+    const long s = blockIdx.x, dd = (long)d * d;
+    real *S = sm.tile(0), *Mt = sm.tile(1), *T1 = sm.tile(2), *Nt = sm.tile(3);
+    load_tile<DP>(S, wN + (s * P) * dd, nullptr, d, false, false);
+    __syncthreads();
+    store_tile<DP>(start + (s * P + 1) * dd, S, d);
+    for (long c = 1; c + 1 < P; ++c) {
+        load_tile<DP>(Mt, wM + (s * P + c) * dd, nullptr, d, false, false);
+        load_tile<DP>(Nt, wN + (s * P + c) * dd, nullptr, d, false, false);
+        __syncthreads();
+        gemm<DP, 0, 0, 0, K_FULL, O_FULL>(S, Mt, T1, 1.f);
+        __syncthreads();
+        gemm<DP, 1, 0, 0, K_FULL, O_FULL>(Mt, T1, S, 1.f);                              // M^T Sigma M
+        __syncthreads();
+        add_tile<DP>(S, Nt);
+        __syncthreads();
+        store_tile<DP>(start + (s * P + c + 1) * dd, S, d);
+    }
+}
+template <int DP>
+__global__ void __launch_bounds__(NTHR) bigpar_tak_emit_kernel(long B, long n, int d, long P, long L, const real* __restrict__ ldiag,
+                                                              const real* __restrict__ lsub, const real* __restrict__ start,
+                                                              real* __restrict__ odiag, real* __restrict__ osub) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const Smem<DP> sm{reinterpret_cast<real*>(smem_raw)};
+    constexpr int LD = Geo<DP>::LD;
+    const long s = blockIdx.x / P, c = blockIdx.x % P;
+    const long p0 = c * L, dd = (long)d * d;
+    long p1 = p0 + L;
+    if (p1 > n) p1 = n;
+    real *G = sm.tile(0), *Linv = sm.tile(1), *W = sm.tile(2), *Sig = sm.tile(3), *Out = sm.tile(4);
+    bool bad = false;
+    if (c > 0) load_tile<DP>(Sig, start + (s * P + c) * dd, nullptr, d, false, false);
+    for (long p = p0; p < p1; ++p) {
+        const long k = n - 1 - p;
+        load_tile<DP>(G, ldiag + (s * n + k) * dd, nullptr, d, true, true);
+        const bool coupled = p > 0;
+        if (coupled) load_tile<DP>(W, lsub + (s * (n - 1) + k) * dd, nullptr, d, false, false);
+        __syncthreads();
+        (void)factor_invert<DP, false>(G, Linv, bad, sm.scratch());
+        gemm<DP, 1, 0, 0, K_A_UPPER, O_FULL>(Linv, Linv, Out, 1.f);
+        if (coupled) {
+            gemm<DP, 0, 0, 0, K_B_LOWER, O_FULL>(W, Linv, G, 1.f);
+            __syncthreads();
+            gemm<DP, 0, 0, 0, K_FULL, O_FULL>(Sig, G, W, 1.f);                          // Sigma_{k+1} G
+            __syncthreads();
+            if (osub)
+                for (int e = threadIdx.x; e < d * d; e += NTHR) osub[(s * (n - 1) + k) * dd + e] = -W[(e / d) * LD + (e % d)];
+            gemm<DP, 1, 0, 1, K_FULL, O_FULL>(G, W, Out, 1.f);
+        }
+        __syncthreads();
+        store_tile<DP>(odiag + (s * n + k) * dd, Out, d);
+        { real* t = Sig; Sig = Out; Out = t; }
+    }
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------------------------
 // chunks per series: one round of workgroups over the 256 CUs (as many per CU as the LDS carve allows), chunks of at least 8 blocks;
 // fewer than 4 chunks: the one-workgroup-per-series kernels
@@ -336,6 +519,64 @@ inline int op_udl_par(long B, long n, int d, const real* diag, const real* sub, 
           hipLaunchKernelGGL((bigpar_udl_means_kernel<DP>), dim3((unsigned)(B * P)), dim3(NTHR), SmemVec<DP>::BYTES, st, B, n, d, \
                              P, L, static_cast<const real*>(ut), static_cast<const real*>(chol_dinv), eta,               \
                              static_cast<const real*>(w.N), static_cast<const real*>(w.a), m_post); }
+    MF_BIGOP_DISPATCH(MF_C)
+#undef MF_C
+    return big_ok();
+}
+
+// solve: N [Br, P, d, d] and a [Br, P, d]
+inline size_t bigpar_solve_ws(long Bl, long Br, long n, int d) {
+    long P, L;
+    bigpar_partition(Br, n, d, P, L);
+    if (P == 1) return 0;
+    return size_t(Br) * P * d * d * sizeof(real) + align_up_big(size_t(Br) * P * d * sizeof(real));
+}
+inline int op_solve_par(long Bl, long Br, long n, int d, const real* ldiag, const real* lsub, const real* rhs, real* out, int transpose,
+                        void* ws, size_t ws_bytes, hipStream_t st) {
+    long P, L;
+    bigpar_partition(Br, n, d, P, L);
+    if (P == 1 || !lsub || !ws || ws_bytes < bigpar_solve_ws(Bl, Br, n, d)) return op_solve(Bl, Br, n, d, ldiag, lsub, rhs, out, transpose, st);
+    real* wN = static_cast<real*>(ws);
+    real* wa = wN + size_t(Br) * P * d * d;
+#define MF_S(DP, TR)                                                                                                    \
+    { static const bool ok = big_attr(&bigpar_solve_compose_kernel<DP, TR>, Smem<DP>::BYTES) &&                          \
+                             big_attr(&bigpar_solve_emit_kernel<DP, TR>, Smem<DP>::BYTES);                               \
+      if (!ok) return -1000;                                                                                            \
+      hipLaunchKernelGGL((bigpar_solve_compose_kernel<DP, TR>), dim3((unsigned)(Br * (P - 1))), dim3(NTHR), Smem<DP>::BYTES, st, Bl, Br, \
+                         n, d, P, L, ldiag, lsub, rhs, wN, wa);                                                          \
+      hipLaunchKernelGGL((bigpar_solve_emit_kernel<DP, TR>), dim3((unsigned)(Br * P)), dim3(NTHR), Smem<DP>::BYTES, st, Bl, Br, n, d, \
+                         P, L, ldiag, lsub, rhs, static_cast<const real*>(wN), static_cast<const real*>(wa), out); }
+#define MF_C(DP) if (transpose) MF_S(DP, 1) else MF_S(DP, 0)
+    MF_BIGOP_DISPATCH(MF_C)
+#undef MF_C
+#undef MF_S
+    return big_ok();
+}
+
+// block_diagonal_of_inverse: M, N, start [B, P, d, d]
+inline size_t bigpar_tak_ws(long B, long n, int d) {
+    long P, L;
+    bigpar_partition(B, n, d, P, L);
+    return P == 1 ? 0 : 3 * size_t(B) * P * d * d * sizeof(real);
+}
+inline int op_diag_of_inverse_par(long B, long n, int d, const real* ldiag, const real* lsub, real* odiag, real* osub, void* ws,
+                                  size_t ws_bytes, hipStream_t st) {
+    long P, L;
+    bigpar_partition(B, n, d, P, L);
+    if (P == 1 || !lsub || !ws || ws_bytes < bigpar_tak_ws(B, n, d)) return op_diag_of_inverse(B, n, d, ldiag, lsub, odiag, osub, st);
+    const size_t blk = size_t(B) * P * d * d;
+    real *wM = static_cast<real*>(ws), *wN = wM + blk, *start = wN + blk;
+#define MF_C(DP)                                                                                                        \
+    { static const bool ok = big_attr(&bigpar_tak_compose_kernel<DP>, Smem<DP>::BYTES) &&                                \
+                             big_attr(&bigpar_tak_boundary_kernel<DP>, Smem<DP>::BYTES) &&                               \
+                             big_attr(&bigpar_tak_emit_kernel<DP>, Smem<DP>::BYTES);                                     \
+      if (!ok) return -1000;                                                                                            \
+      hipLaunchKernelGGL((bigpar_tak_compose_kernel<DP>), dim3((unsigned)(B * (P - 1))), dim3(NTHR), Smem<DP>::BYTES, st, B, n, d, P, L, \
+                         ldiag, lsub, wM, wN);                                                                           \
+      hipLaunchKernelGGL((bigpar_tak_boundary_kernel<DP>), dim3((unsigned)B), dim3(NTHR), Smem<DP>::BYTES, st, B, d, P,  \
+                         static_cast<const real*>(wM), static_cast<const real*>(wN), start);                             \
+      hipLaunchKernelGGL((bigpar_tak_emit_kernel<DP>), dim3((unsigned)(B * P)), dim3(NTHR), Smem<DP>::BYTES, st, B, n, d, P, L, ldiag, \
+                         lsub, static_cast<const real*>(start), odiag, osub); }
     MF_BIGOP_DISPATCH(MF_C)
 #undef MF_C
     return big_ok();

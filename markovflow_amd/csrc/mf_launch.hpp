@@ -88,11 +88,12 @@ int big_kf_loglik_f32(long B, long Tn, int d, int m, const float* mu0, const flo
     int big_cholesky_##SUF(long B, long n, int d, const T* diag, const T* sub, T* ldiag, T* lsub, void* ws, size_t ws_bytes,  \
                            int* info, hipStream_t st);                                                                       \
     int big_solve_##SUF(long Bl, long Br, long n, int d, const T* ldiag, const T* lsub, const T* rhs, T* out, int transpose,  \
-                        hipStream_t st);                                                                                     \
+                        void* ws, size_t ws_bytes, hipStream_t st);                                                          \
     int big_matvec_##SUF(long Bl, long Br, long n, int d, const T* diag, const T* sub, const T* x, T* out, int mode,          \
                          hipStream_t st);                                                                                    \
     int big_logdet_##SUF(long B, long n, int d, const T* ldiag, T* out, hipStream_t st);                                     \
-    int big_diag_of_inverse_##SUF(long B, long n, int d, const T* ldiag, const T* lsub, T* odiag, T* osub, hipStream_t st);   \
+    int big_diag_of_inverse_##SUF(long B, long n, int d, const T* ldiag, const T* lsub, T* odiag, T* osub, void* ws,          \
+                                  size_t ws_bytes, hipStream_t st);                                                          \
     int big_udl_##SUF(long B, long n, int d, const T* diag, const T* sub, T* ut, T* chol_d, const T* eta, T* m_post,          \
                       T* chol_dinv, void* ws, size_t ws_bytes, int* info, hipStream_t st);                                   \
     int big_ssm_precision_##SUF(long B, long Tn, int d, int m, const T* mu0, const T* cholP0, const T* A, const T* b,         \
@@ -103,6 +104,8 @@ int big_kf_loglik_f32(long B, long Tn, int d, int m, const float* mu0, const flo
     int big_marginal_covs_##SUF(long B, long n, int d, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ,  \
                                 T* omean, T* ocov, T* osub, void* ws, size_t ws_bytes, hipStream_t st);
 size_t big_btd_par_ws(long B, long n, int d, int chain, int elem_size);
+size_t big_btd_solve_ws(long Bl, long Br, long n, int d, int elem_size);
+size_t big_btd_tak_ws(long B, long n, int d, int elem_size);
 MF_DECLARE_BIG(f32, float)
 MF_DECLARE_BIG(f64, double)
 #undef MF_DECLARE_BIG

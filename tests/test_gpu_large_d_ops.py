@@ -162,6 +162,17 @@ def test_large_d_cholesky_and_udl_partitioned_in_time(rng, dtype, d, bsz, n):
     want_u, want_c = O.btd_upper_diagonal_lower(diag, sub)
     np.testing.assert_allclose(nn(u_t.block_sub_diagonal), want_u, **tol)
     np.testing.assert_allclose(nn(chol_d.block_diagonal), np.tril(want_c), **tol)
+    # solve (both orientations; a second right-hand side per factor: the broadcast of block_tri_diag.py:339-351) and the block
+    # diagonal / sub-diagonal of the inverse, on the exact factor
+    exact = mfa.LowerTriangularBlockTriDiagonal(tt(np.tril(ld), dtype), tt(ls, dtype))
+    rhs = rng.normal(size=(2, bsz, n, d))
+    r = tt(rhs, dtype)
+    np.testing.assert_allclose(nn(exact.solve(r)), O.btd_solve(ld, ls, rhs), **tol)
+    np.testing.assert_allclose(nn(exact.solve(r, transpose_left=True)), O.btd_solve(ld, ls, rhs, transpose_left=True), **tol)
+    inv_d, inv_s = O.btd_block_diagonal_of_inverse(ld, ls, return_sub=True)
+    got_d, got_s = exact._diag_and_sub_of_inverse(want_sub=True)
+    np.testing.assert_allclose(nn(got_d), inv_d, **tol)
+    np.testing.assert_allclose(nn(got_s), inv_s, **tol)
 
 
 @pytest.mark.parametrize("dtype,d,m,t", [(torch.float64, 14, 1, 90), (torch.float64, 32, 3, 41), (torch.float32, 20, 2, 260),
