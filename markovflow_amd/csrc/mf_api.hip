@@ -282,7 +282,7 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (Tn > 1 && !A) return -5;                                                                                   \
         if (!offs) return -6;                                                                                          \
         if (!out) return -7;                                                                                           \
-        if (big) return mf::big_means_##SUF(Bl, Br, Tn, d, A, offs, out, S(stream));                                   \
+        if (big) return mf::big_means_##SUF(Bl, Br, Tn, d, A, offs, out, ws, ws_bytes, S(stream));                     \
         return t->ssm_means(Bl, Br, Tn, A, offs, out, ws, ws_bytes, S(stream));                                        \
     }
 

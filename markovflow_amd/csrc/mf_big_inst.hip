@@ -55,8 +55,9 @@ int big_kf_loglik_f64(long B, long Tn, int d, int m, const double* mu0, const do
                                 T* eta, hipStream_t st) {                                                                    \
         return NS::op_ssm_precision(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, diag, sub, eta, st);   \
     }                                                                                                                        \
-    int big_means_##SUF(long Bl, long Br, long Tn, int d, const T* A, const T* offs, T* out, hipStream_t st) {               \
-        return NS::op_means(Bl, Br, Tn, d, A, offs, out, st);                                                                \
+    int big_means_##SUF(long Bl, long Br, long Tn, int d, const T* A, const T* offs, T* out, void* ws, size_t ws_bytes,       \
+                        hipStream_t st) {                                                                                    \
+        return NS::op_means_par(Bl, Br, Tn, d, A, offs, out, ws, ws_bytes, st);                                              \
     }                                                                                                                        \
     int big_block_matmul_##SUF(long B, long n, int d, const T* X, long xs, const T* Y, long ys, T* out, hipStream_t st) {     \
         return NS::op_block_matmul(B, n, d, X, xs, Y, ys, out, st);                                                          \

@@ -342,6 +342,75 @@ __global__ void __launch_bounds__(NTHR) bigpar_solve_emit_kernel(long Bl, long B
     }
 }
 
+// ---- marginal means / sample propagation (state_space_model.py:232-251):  x_k = A_{k-1} x_{k-1} + offs_k,  x_0 = offs_0 --------------
+template <int DP, int NTILES> struct SmemLite {
+    static constexpr int FLOATS = NTILES * Geo<DP>::TILE + 4 * 64 + 256;
+    static constexpr int BYTES = FLOATS * (int)sizeof(real);
+};
+template <int DP>
+__global__ void __launch_bounds__(NTHR) bigpar_means_compose_kernel(long Bl, long Br, long n, int d, long P, long L,
+                                                                   const real* __restrict__ A, const real* __restrict__ offs,
+                                                                   real* __restrict__ oN, real* __restrict__ oa) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    real* base = reinterpret_cast<real*>(smem_raw);
+    real *At = base, *N = base + Geo<DP>::TILE, *N2 = N + Geo<DP>::TILE;
+    real *x = N2 + Geo<DP>::TILE, *xn = x + 64, *scratch = xn + 192;
+    const long r = blockIdx.x / (P - 1), c = blockIdx.x % (P - 1), s = r % Bl;
+    const long k0 = c * L, dd = (long)d * d;
+    long k1 = k0 + L;
+    if (k1 > n) k1 = n;
+    if (threadIdx.x < 64) x[threadIdx.x] = 0;
+    if (c > 0) identity_tile<DP>(N);
+    __syncthreads();
+    for (long k = k0; k < k1; ++k) {
+        load_vec_lds<DP>(xn, offs + (r * n + k) * d, nullptr, d);
+        if (k > 0) load_tile<DP>(At, A + (s * (n - 1) + k - 1) * dd, nullptr, d, false, false);
+        __syncthreads();
+        if (k > 0) matvec<DP, 0>(At, x, xn, 1.f, 1.f, scratch);
+        if (c > 0) {
+            gemm<DP, 0, 0, 0, K_FULL, O_FULL>(At, N, N2, 1.f);
+            real* t = N; N = N2; N2 = t;
+        }
+        if (threadIdx.x < 64) x[threadIdx.x] = xn[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x < d) oa[(r * P + c) * d + threadIdx.x] = x[threadIdx.x];
+    if (c > 0) store_tile<DP>(oN + (r * P + c) * dd, N, d);
+}
+template <int DP>
+__global__ void __launch_bounds__(NTHR) bigpar_means_emit_kernel(long Bl, long Br, long n, int d, long P, long L,
+                                                                const real* __restrict__ A, const real* __restrict__ offs,
+                                                                const real* __restrict__ wN, const real* __restrict__ wa,
+                                                                real* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    real* base = reinterpret_cast<real*>(smem_raw);
+    real* At = base;
+    real *x = base + Geo<DP>::TILE, *xn = x + 64, *scratch = xn + 192;
+    const long r = blockIdx.x / P, c = blockIdx.x % P, s = r % Bl;
+    const long k0 = c * L, dd = (long)d * d;
+    long k1 = k0 + L;
+    if (k1 > n) k1 = n;
+    if (threadIdx.x < 64) x[threadIdx.x] = 0;
+    __syncthreads();
+    for (long j = 0; j < c; ++j) {
+        load_vec_lds<DP>(xn, wa + (r * P + j) * d, nullptr, d);
+        if (j > 0) load_tile<DP>(At, wN + (r * P + j) * dd, nullptr, d, false, false);
+        __syncthreads();
+        if (j > 0) matvec<DP, 0>(At, x, xn, 1.f, 1.f, scratch);
+        if (threadIdx.x < 64) x[threadIdx.x] = xn[threadIdx.x];
+        __syncthreads();
+    }
+    for (long k = k0; k < k1; ++k) {
+        load_vec_lds<DP>(xn, offs + (r * n + k) * d, nullptr, d);
+        if (k > 0) load_tile<DP>(At, A + (s * (n - 1) + k - 1) * dd, nullptr, d, false, false);
+        __syncthreads();
+        if (k > 0) matvec<DP, 0>(At, x, xn, 1.f, 1.f, scratch);
+        if (threadIdx.x < d) out[(r * n + k) * d + threadIdx.x] = xn[threadIdx.x];
+        if (threadIdx.x < 64) x[threadIdx.x] = xn[threadIdx.x];
+        __syncthreads();
+    }
+}
+
 // ---- block_diagonal_of_inverse (block Takahashi, block_tri_diag.py:318-337) ----------------------------------------------------------------
 // positions p = n-1-k:  Sigma_p = C_p + G_p^T Sigma_{p-1} G_p,  C = L^-T L^-1,  G = W L^-1 (W = lsub[k]) - a congruence recursion.
 // compose: chunk c (< P-1) leaves  Sigma_end = Nc + Mc^T Sigma_start Mc  (Mc = G_{p0} ... G_{p1-1}; chunk 0 starts uncoupled: Nc only).
@@ -550,6 +619,27 @@ inline int op_solve_par(long Bl, long Br, long n, int d, const real* ldiag, cons
     MF_BIGOP_DISPATCH(MF_C)
 #undef MF_C
 #undef MF_S
+    return big_ok();
+}
+
+// marginal means: the workspace of the solve (N [Br, P, d, d], a [Br, P, d])
+inline int op_means_par(long Bl, long Br, long n, int d, const real* A, const real* offs, real* out, void* ws, size_t ws_bytes,
+                        hipStream_t st) {
+    long P, L;
+    bigpar_partition(Br, n, d, P, L);
+    if (P == 1 || !ws || ws_bytes < bigpar_solve_ws(Bl, Br, n, d)) return op_means(Bl, Br, n, d, A, offs, out, st);
+    real* wN = static_cast<real*>(ws);
+    real* wa = wN + size_t(Br) * P * d * d;
+#define MF_C(DP)                                                                                                        \
+    { static const bool ok = big_attr(&bigpar_means_compose_kernel<DP>, SmemLite<DP, 3>::BYTES) &&                       \
+                             big_attr(&bigpar_means_emit_kernel<DP>, SmemLite<DP, 1>::BYTES);                            \
+      if (!ok) return -1000;                                                                                            \
+      hipLaunchKernelGGL((bigpar_means_compose_kernel<DP>), dim3((unsigned)(Br * (P - 1))), dim3(NTHR), (SmemLite<DP, 3>::BYTES), st, Bl, \
+                         Br, n, d, P, L, A, offs, wN, wa);                                                               \
+      hipLaunchKernelGGL((bigpar_means_emit_kernel<DP>), dim3((unsigned)(Br * P)), dim3(NTHR), (SmemLite<DP, 1>::BYTES), st, Bl, Br, n, \
+                         d, P, L, A, offs, static_cast<const real*>(wN), static_cast<const real*>(wa), out); }
+    MF_BIGOP_DISPATCH(MF_C)
+#undef MF_C
     return big_ok();
 }
 

@@ -375,12 +375,15 @@ class StateSpaceModel(GaussMarkovDistribution):
         """The reference's route (state_space_model.py:569-593) over the operator kernels."""
         means_1, marginal_covs_1, subsequent_covs_1 = self._moments(want_sub=True)
         precision_2 = dist.precision
-        trace = torch.sum(precision_2.block_diagonal * marginal_covs_1, dim=(-3, -2, -1)) + 2.0 * torch.sum(
-            precision_2.block_sub_diagonal * subsequent_covs_1, dim=(-3, -2, -1))
+        # sums over the blocks first, then over time: a reduction of [.., T, d, d] straight to batch_shape runs on one
+        # workgroup per series (0.42 ms each at B = 8, T = 2048, d = 64)
+        def total(t):
+            return torch.sum(torch.sum(t, dim=(-2, -1)), dim=-1)
+        trace = total(precision_2.block_diagonal * marginal_covs_1) + 2.0 * total(precision_2.block_sub_diagonal * subsequent_covs_1)
         mean_diff = dist.marginal_means - means_1
         # the reference forms |L2^T (mu2 - mu1)|^2 with the Cholesky factor of P2 (state_space_model.py:575-583); the same
         # number is (mu2 - mu1)^T P2 (mu2 - mu1): one symmetric block-tridiagonal product, no factorisation
-        mahalanobis = torch.sum(mean_diff * precision_2.dense_mult(mean_diff), dim=(-2, -1))
+        mahalanobis = torch.sum(torch.sum(mean_diff * precision_2.dense_mult(mean_diff), dim=-1), dim=-1)
         dim = (self.num_transitions + 1) * self.state_dim
         return 0.5 * (trace + mahalanobis - dim - dist.log_det_precision() + self.log_det_precision())
 

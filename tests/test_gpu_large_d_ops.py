@@ -192,3 +192,8 @@ def test_large_d_posterior_chain_partitioned_in_time(rng, dtype, d, m, t):
            post.cholesky_process_covariances)
     for g, w in zip(got, want):
         np.testing.assert_allclose(nn(g), w, **tol)
+    # marginal means alone: the affine recursion cut into chunks (state_space_model.py:232-251)
+    np.testing.assert_allclose(nn(post.marginal_means), O.ssm_marginal_means(want[0], want[2], want[3]), **tol)
+    np.testing.assert_allclose(nn(kf.prior_ssm.marginal_means), O.ssm_marginal_means(kw["mu0"], kw["a_s"], kw["b_s"]), **tol)
+    kl = O.ssm_kl_divergence(want, (kw["mu0"], kw["chol_p0"], kw["a_s"], kw["b_s"], kw["chol_q"]))
+    np.testing.assert_allclose(nn(post.kl_divergence(kf.prior_ssm)), kl, rtol=1e-6 if dtype == torch.float64 else 2e-2)
