@@ -78,6 +78,9 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
  * factorisation is parallelised in time by a multi-level partitioned elimination that still returns the
  * natural-order factor (csrc/mf_btd_par.hpp); that path needs scratch: ws_bytes >=
  * mf_btd_cholesky_workspace_bytes(...) (0 = the serial kernel will be used; ws may then be NULL).
+ * The same holds for 10 <= d <= 64 (f32) / 32 (f64) on the LDS-tile / MFMA engine: few series are cut into chunks in time
+ * (csrc/mf_bigpar_impl.hpp) - also for mf_btd_solve, mf_btd_diag_of_inverse, mf_btd_udl and mf_ssm_marginal_means, each with the
+ * workspace its own query names; a NULL or short workspace selects the one-workgroup-per-series kernels, never an error.
  */
 size_t mf_btd_cholesky_workspace_bytes(int64_t B, int64_t T, int d, int elem_size);
 int mf_btd_cholesky_f64(int64_t B, int64_t T, int d, const double* diag, const double* sub, double* ldiag,
