@@ -355,13 +355,16 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
                                 T* g_A, T* g_b, T* g_cholQ, T* g_H, T* g_y, T* g_omega, const T* weights, int* info,   \
                                 void* stream) {                                                                        \
         MF_HEAD(T, B, Tn, d)                                                                                           \
-        if (big) return -100;                                                                                          \
-        if (m < 1 || m > 4) return -4;                                                                                 \
+        if (m < 1 || m > (big ? 32 : 4)) return -4;                                                                    \
         if (!mu0 || !cholP0 || (Tn > 1 && (!A || !b || !cholQ))) return -5;                                            \
         if (H && (!y || !Rinv)) return -11;                                                                            \
         if (!post_mean || !post_cov || (Tn > 1 && !post_cross)) return -14;                                            \
         if (!g_mu0 || !g_cholP0 || (Tn > 1 && (!g_A || !g_b || !g_cholQ))) return -17;                                 \
         if (H && (!g_H || !g_y || !g_omega)) return -22;                                                               \
+        if (big && !weights) return -25;                                                                               \
+        if (big) return mf::big_kf_grad_##SUF(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step,        \
+                                              post_mean, post_cov, post_cross, weights, g_mu0, g_cholP0, g_A, g_b,     \
+                                              g_cholQ, g_H, g_y, g_omega, S(stream));                                  \
         return t->kf_grad(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, post_mean, post_cov, post_cross, g_mu0,      \
                           g_cholP0, g_A, g_b, g_cholQ, g_H, g_y, g_omega, weights, rinv_per_step, info, S(stream));    \
     }                                                                                                                  \

@@ -141,6 +141,7 @@ __device__ __forceinline__ double mf_log(double x) { return log(x); }
 #include "mf_big_impl.hpp"
 #include "mf_bigops_impl.hpp"
 #include "mf_bigpar_impl.hpp"
+#include "mf_biggrad_impl.hpp"
 #undef MF_BIG_T
 #undef MF_BIG_NS
 // fp64: v_mfma_f64_16x16x4_f64 (same operand maps, accumulator rows q + 4 e); seven tiles fit up to DP = 32
@@ -149,5 +150,6 @@ __device__ __forceinline__ double mf_log(double x) { return log(x); }
 #include "mf_big_impl.hpp"
 #include "mf_bigops_impl.hpp"
 #include "mf_bigpar_impl.hpp"
+#include "mf_biggrad_impl.hpp"
 #undef MF_BIG_T
 #undef MF_BIG_NS

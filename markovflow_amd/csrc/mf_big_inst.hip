@@ -62,6 +62,13 @@ int big_kf_loglik_f64(long B, long Tn, int d, int m, const double* mu0, const do
     int big_block_matmul_##SUF(long B, long n, int d, const T* X, long xs, const T* Y, long ys, T* out, hipStream_t st) {     \
         return NS::op_block_matmul(B, n, d, X, xs, Y, ys, out, st);                                                          \
     }                                                                                                                        \
+    int big_kf_grad_##SUF(long B, long Tn, int d, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, \
+                          const T* H, const T* y, const T* Rinv, int rinv_per_step, const T* mean, const T* cov,             \
+                          const T* cross, const T* w, T* g_mu0, T* g_cholP0, T* g_A, T* g_b, T* g_cholQ, T* g_H, T* g_y,     \
+                          T* g_om, hipStream_t st) {                                                                         \
+        return NS::op_kf_grad(NS::BigGradArgs{B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, mean, cov,   \
+                                              cross, w, g_mu0, g_cholP0, g_A, g_b, g_cholQ, g_H, g_y, g_om}, st);            \
+    }                                                                                                                        \
     int big_marginal_covs_##SUF(long B, long n, int d, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ,  \
                                 T* omean, T* ocov, T* osub, void* ws, size_t ws_bytes, hipStream_t st) {                     \
         return NS::op_marginal_covs(B, n, d, mu0, cholP0, A, b, cholQ, omean, ocov, osub, ws, ws_bytes, st);                 \

@@ -102,6 +102,10 @@ int big_kf_loglik_f32(long B, long Tn, int d, int m, const float* mu0, const flo
     int big_means_##SUF(long Bl, long Br, long Tn, int d, const T* A, const T* offs, T* out, void* ws, size_t ws_bytes,       \
                         hipStream_t st);                                                                                     \
     int big_block_matmul_##SUF(long B, long n, int d, const T* X, long xs, const T* Y, long ys, T* out, hipStream_t st);    \
+    int big_kf_grad_##SUF(long B, long Tn, int d, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, \
+                          const T* H, const T* y, const T* Rinv, int rinv_per_step, const T* mean, const T* cov,             \
+                          const T* cross, const T* w, T* g_mu0, T* g_cholP0, T* g_A, T* g_b, T* g_cholQ, T* g_H, T* g_y,     \
+                          T* g_om, hipStream_t st);                                                                          \
     int big_marginal_covs_##SUF(long B, long n, int d, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ,  \
                                 T* omean, T* ocov, T* osub, void* ws, size_t ws_bytes, hipStream_t st);
 size_t big_btd_par_ws(long B, long n, int d, int chain, int elem_size);
