@@ -275,6 +275,14 @@ def other_configs(dev):
         "executed_TFLOPs": bsz * tn * exe / ms / 1e9, "frac_of_f32_mfma_peak_executed": bsz * tn * exe / ms / 1e9 / 157.3,
         "note": "whole log_likelihood() incl. reduction levels; flop models 9 d^3 (algorithmic, SURVEY 8d) and 15 d^3 (executed by "
                 "the partitioned elimination); MFMA busy counters: profiles/"}
+    # the operators around it at the same shape: partitioned in time on the same tile engine since round 3 (csrc/mf_bigpar_impl.hpp)
+    prec = kf.prior_ssm.precision
+    t_chol = _time_gpu(lambda: mfa.SymmetricBlockTriDiagonal(prec.block_diagonal, prec.block_sub_diagonal).cholesky, iters=3, warm=1)
+    t_post = _time_gpu(kf.posterior_state_space_model, iters=3, warm=1)
+    out["config5_operators_d64_T2048_m32_B8_f32"] = {
+        "cholesky_ms": t_chol, "posterior_state_space_model_ms": t_post,
+        "note": "SymmetricBlockTriDiagonal.cholesky of the prior precision and KalmanFilter.posterior_state_space_model (precision "
+                "assembly + U D U^T + chain means), time-partitioned (round 2: 54 ms / 81 ms with one workgroup per series)"}
     return out
 
 

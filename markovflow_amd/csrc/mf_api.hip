@@ -26,6 +26,22 @@ template <> const mf::OpsTable<double>* table_for<double>(int d) {
 
 inline hipStream_t S(void* s) { return static_cast<hipStream_t>(s); }
 
+template <typename T> const mf::RowWideTable<T>* rowwide_for(int d);
+template <> const mf::RowWideTable<float>* rowwide_for<float>(int d) {
+    switch (d) {
+        case 10: return mf::rowwide_f32_d10(); case 11: return mf::rowwide_f32_d11(); case 12: return mf::rowwide_f32_d12();
+        case 13: return mf::rowwide_f32_d13(); case 14: return mf::rowwide_f32_d14(); case 15: return mf::rowwide_f32_d15();
+        default: return nullptr;
+    }
+}
+template <> const mf::RowWideTable<double>* rowwide_for<double>(int d) {
+    switch (d) {
+        case 10: return mf::rowwide_f64_d10(); case 11: return mf::rowwide_f64_d11(); case 12: return mf::rowwide_f64_d12();
+        case 13: return mf::rowwide_f64_d13(); case 14: return mf::rowwide_f64_d14(); case 15: return mf::rowwide_f64_d15();
+        default: return nullptr;
+    }
+}
+
 template <typename T>
 int kf_loglik(int64_t B, int64_t Tn, int d, int m, const T* mu0, const T* cholP0, const T* A, const T* b,
               const T* cholQ, const T* H, const T* y, const T* Rinv, int rinv_per_step, T add_const, T* out, void* ws,
@@ -48,6 +64,13 @@ int kf_loglik(int64_t B, int64_t Tn, int d, int m, const T* mu0, const T* cholP0
     if (!y) return -11;
     if (!Rinv) return -12;
     if (!out) return -15;
+    if (!t) {
+        // 10 <= d <= 15 with at most four outputs: the row kernels (one 16-lane row per chunk), as for d = 7 ... 9
+        const auto* rw = rowwide_for<T>(d);
+        if (rw && Tn >= 2 && m <= 4 && rw->usable(B, Tn, m, chunks))
+            return rw->kf_loglik(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, add_const, out, ws, ws_bytes, info,
+                                 chunks, static_cast<hipEvent_t>(ev0), static_cast<hipEvent_t>(ev1), S(stream));
+    }
     if (big) {
         if constexpr (sizeof(T) == 4)
             return mf::big_kf_loglik_f32(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, add_const, out,
@@ -119,12 +142,14 @@ size_t mf_kf_loglik_workspace_bytes(int64_t B, int64_t T, int d, int elem_size, 
     if (elem_size == 4) {
         const auto* t = table_for<float>(d);
         const size_t small = t ? t->kf_loglik_ws(B, T, chunks) : 0;
-        const size_t large = (d >= 1 && d <= mf::MF_MAX_D_BIG && B >= 1 && T >= 1) ? mf::big_kf_loglik_ws(B, T, d, chunks, 4) : 0;
+        size_t large = (d >= 1 && d <= mf::MF_MAX_D_BIG && B >= 1 && T >= 1) ? mf::big_kf_loglik_ws(B, T, d, chunks, 4) : 0;
+        if (const auto* rw = rowwide_for<float>(d)) { const size_t w = rw->kf_loglik_ws(B, T, chunks); if (w > large) large = w; }
         return small > large ? small : large;
     }
     const auto* t = table_for<double>(d);
     const size_t small = t ? t->kf_loglik_ws(B, T, chunks) : 0;
-    const size_t large = (d >= 1 && d <= mf::MF_MAX_D_BIG_F64 && B >= 1 && T >= 1) ? mf::big_kf_loglik_ws(B, T, d, chunks, 8) : 0;
+    size_t large = (d >= 1 && d <= mf::MF_MAX_D_BIG_F64 && B >= 1 && T >= 1) ? mf::big_kf_loglik_ws(B, T, d, chunks, 8) : 0;
+    if (const auto* rw = rowwide_for<double>(d)) { const size_t w = rw->kf_loglik_ws(B, T, chunks); if (w > large) large = w; }
     return small > large ? small : large;
 }
 int mf_max_state_dim_f32_loglik(void) { return mf::MF_MAX_D_BIG; }

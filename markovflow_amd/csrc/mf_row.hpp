@@ -311,6 +311,10 @@ template <typename T, int M> struct RiRegs {
     MF_DEV T operator()(int o, int q) const { return v[o * M + q]; }
 };
 
+// Wavefronts per SIMD the row kernels are compiled for: a row-distributed matrix costs d registers (2 d in fp64) per lane, the
+// elimination state ~ 9 matrices: three waves up to d = 9 (168 registers), two up to d = 12 (256), one beyond (512 with AGPRs).
+constexpr int row_waves_per_simd(int d) { return d <= 9 ? 3 : d <= 12 ? 2 : 1; }
+
 // True when every wave-relative byte offset of a launch stays below ROW_MAXOFF (a wave's four chunks span at most
 // ceil(4 / P) + 1 series).
 inline bool row_offsets_fit(long Tn, long P, int D, int M, int elem) {
@@ -322,7 +326,7 @@ inline bool row_offsets_fit(long Tn, long P, int D, int M, int elem) {
 // Level 0 of the log-likelihood, chunk convention and output of kf_chunk_x_kernel: chunk c owns blocks [c T / P, (c+1) T / P)
 // and leaves its last block as a reduced block.  64 threads = 4 rows = 4 chunks.
 template <typename T, int D, int M, bool RSTEP>
-__global__ void __launch_bounds__(64, 3) kf_row_kernel(KfArgs<T> a, RedSys<T> out) {
+__global__ void __launch_bounds__(64, row_waves_per_simd(D)) kf_row_kernel(KfArgs<T> a, RedSys<T> out) {
     static_assert(D + 1 <= 16 && M <= D, "one row of 16 lanes per chunk");
     constexpr unsigned S = sizeof(T);
     const int lane = threadIdx.x;
@@ -553,7 +557,7 @@ MF_DEV void load_red_rows(const RedSys<T>& in, long s, long k, int r, T (&Dn)[D]
 
 // One level: RedSys(n) -> RedSys(P); 64 threads = 4 rows = 4 (series, chunk) pairs; chunk c owns blocks [c n / P, (c+1) n / P).
 template <typename T, int D>
-__global__ void __launch_bounds__(64, 3) red_row_kernel(RedSys<T> in, RedSys<T> out, long B, long Pn, int* info) {
+__global__ void __launch_bounds__(64, row_waves_per_simd(D)) red_row_kernel(RedSys<T> in, RedSys<T> out, long B, long Pn, int* info) {
     const int lane = threadIdx.x, r = lane & 15;
     const int rc = r < D ? r : 0;
     const long total = B * Pn;
@@ -609,7 +613,7 @@ __global__ void __launch_bounds__(64, 3) red_row_kernel(RedSys<T> in, RedSys<T> 
 
 // Last level: a row per series walks the remaining blocks; out[s] = add_const + scalars + 0.5 |z|^2 - log|L|.
 template <typename T, int D>
-__global__ void __launch_bounds__(64, 3) red_row_final_kernel(RedSys<T> in, long B, T add_const, T* __restrict__ out, int* info) {
+__global__ void __launch_bounds__(64, row_waves_per_simd(D)) red_row_final_kernel(RedSys<T> in, long B, T add_const, T* __restrict__ out, int* info) {
     const int lane = threadIdx.x, r = lane & 15;
     const int rc = r < D ? r : 0;
     const long id_raw = (long)blockIdx.x * 4 + (lane >> 4);

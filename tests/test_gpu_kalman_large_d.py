@@ -136,3 +136,52 @@ def test_large_d_edge_shapes(rng, dtype):
     cov = 0.5 * np.eye(32)
     ref = O.kf_log_likelihood(**kw, r_inv=np.linalg.inv(cov))
     np.testing.assert_allclose(float(build_kf(kw, np.linalg.cholesky(cov), dtype=dtype).log_likelihood().cpu()), ref, rtol=tol)
+
+
+# ---- 10 <= d <= 15: the row kernels (csrc/mf_rowwide_inst.hip), as for d = 7 ... 9 ---------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float64, F32])
+@pytest.mark.parametrize("d,m,t,batch", [(10, 1, 7, (2,)), (11, 3, 130, (3,)), (12, 4, 64, (2,)), (13, 2, 33, ()), (14, 3, 200, (2,)),
+                                         (15, 4, 90, (3,)), (15, 1, 2, (1,)), (12, 3, 1000, (5,))])
+def test_row_kernels_10_to_15_vs_oracle(rng, dtype, d, m, t, batch):
+    """kalman_filter.py:184-255 for 10 <= d <= 15 with up to four outputs: one 16-lane row per (series, chunk); every series
+    against the oracle (fp64: 1e-9; fp32 on fp32-rounded inputs: 3e-4)."""
+    kw = random_ssm(rng, batch, t, d, m, well=True)
+    if dtype == F32:
+        kw = rounded(kw)
+    cov = 0.5 * np.eye(m) + 0.1 * np.ones((m, m))
+    chol_r = np.linalg.cholesky(cov).astype(np.float32).astype(np.float64)
+    r_inv = np.linalg.inv(chol_r @ chol_r.T)
+    kf = build_kf(kw, chol_r, dtype=dtype)
+    ref = O.kf_log_likelihood(**kw, r_inv=r_inv, per_series=True)
+    got = nn(kf._log_likelihood_per_series() + kf._constant_terms(t)).reshape(np.shape(ref))
+    np.testing.assert_allclose(got, ref, rtol=1e-9 if dtype == torch.float64 else RTOL)
+
+
+@pytest.mark.parametrize("chunks", [1, 2, 7, 24, 70, 140])
+@pytest.mark.parametrize("d", [10, 13, 15])
+def test_row_kernels_10_to_15_time_partition_invariance(rng, d, chunks):
+    """Any partition of the time axis (up to three reduction levels: 140 chunks -> 24 -> 4) gives the same value per series."""
+    m, t = 3, 281
+    kw = random_ssm(rng, (2,), t, d, m, well=True)
+    r_inv = np.array([[2.0, 0.3, 0.0], [0.3, 1.5, 0.1], [0.0, 0.1, 1.0]])
+    ref = O.kf_log_likelihood(**kw, r_inv=r_inv, per_series=True)
+    cst = -0.5 * np.log(2 * np.pi) * m * t + 0.5 * t * np.linalg.slogdet(r_inv)[1]
+    got = loglik_with_chunks(kw, r_inv, chunks, dtype=torch.float64)
+    np.testing.assert_allclose(got + cst, ref, rtol=1e-9)
+
+
+def test_row_kernels_10_to_15_per_step_precisions_and_fallback(rng):
+    """Per-step observation precisions (sites, kalman_filter.py:437-497) at d = 12 through the row kernel; five outputs at d = 12
+    are beyond it and take the LDS-tile path - same oracle, same tolerance."""
+    d, t = 12, 60
+    kw = random_ssm(rng, (), t, d, 1, well=True)
+    prec = 0.5 + rng.random(size=(t, 1, 1))
+    ssm = mfa.StateSpaceModel(*(tt(kw[k], torch.float64) for k in ("mu0", "chol_p0", "a_s", "b_s", "chol_q")))
+    sites = mfa.UnivariateGaussianSitesNat(nat1=tt(kw["y"] * prec[..., 0], torch.float64), nat2=tt(-0.5 * prec, torch.float64))
+    kf = mfa.KalmanFilterWithSites(ssm, mfa.EmissionModel(tt(kw["h"], torch.float64)), sites)
+    ref = O.kf_log_likelihood(**kw, r_inv=prec, log_det_obs_precision=np.sum(np.log(prec)))
+    np.testing.assert_allclose(float(kf.log_likelihood().cpu()), ref, rtol=1e-9)
+    kw5 = random_ssm(rng, (2,), t, d, 5, well=True)
+    chol_r = np.linalg.cholesky(0.5 * np.eye(5) + 0.1)
+    ref5 = O.kf_log_likelihood(**kw5, r_inv=np.linalg.inv(chol_r @ chol_r.T))
+    np.testing.assert_allclose(float(build_kf(kw5, chol_r, dtype=torch.float64).log_likelihood().cpu()), ref5, rtol=1e-9)
