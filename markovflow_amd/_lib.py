@@ -49,6 +49,7 @@ _SIGS = {
 _PLAIN = {
     "mf_version": (_int, []),
     "mf_max_state_dim": (_int, []),
+    "mf_row_operators_cover": (_int, [_i64, _i64, _int, _int]),
     "mf_max_state_dim_f32_loglik": (_int, []),
     "mf_max_state_dim_f64_loglik": (_int, []),
     "mf_kf_loglik_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _i64]),
@@ -141,6 +142,15 @@ def stream_ptr(device) -> ctypes.c_void_p:
 
 class MarkovflowAmdError(RuntimeError):
     pass
+
+
+def small_state_dim(d: int, bsz: int, n: int, elem_size: int) -> bool:
+    """True when the register / row kernels run every operator of this shape (``mf_row_operators_cover``): ``d <= 9`` always,
+    ``10 <= d <= 15`` with few series and long chains (the row kernels, partitioned in time); otherwise the LDS-tile / MFMA
+    engine's routes are taken."""
+    if bsz < 1 or n < 1:
+        return d <= load().mf_max_state_dim()
+    return bool(load().mf_row_operators_cover(bsz, n, d, elem_size))
 
 
 def check(rc: int, what: str):

@@ -11,6 +11,7 @@ template <typename T> const mf::OpsTable<T>* table_for(int d);
 template <> const mf::OpsTable<float>* table_for<float>(int d) {
     switch (d) {
         MF_CASE(1) MF_CASE(2) MF_CASE(3) MF_CASE(4) MF_CASE(5) MF_CASE(6) MF_CASE(7) MF_CASE(8) MF_CASE(9)
+        MF_CASE(10) MF_CASE(11) MF_CASE(12) MF_CASE(13) MF_CASE(14) MF_CASE(15)
         default: return nullptr;
     }
 }
@@ -19,28 +20,13 @@ template <> const mf::OpsTable<float>* table_for<float>(int d) {
 template <> const mf::OpsTable<double>* table_for<double>(int d) {
     switch (d) {
         MF_CASE(1) MF_CASE(2) MF_CASE(3) MF_CASE(4) MF_CASE(5) MF_CASE(6) MF_CASE(7) MF_CASE(8) MF_CASE(9)
+        MF_CASE(10) MF_CASE(11) MF_CASE(12) MF_CASE(13) MF_CASE(14) MF_CASE(15)
         default: return nullptr;
     }
 }
 #undef MF_CASE
 
 inline hipStream_t S(void* s) { return static_cast<hipStream_t>(s); }
-
-template <typename T> const mf::RowWideTable<T>* rowwide_for(int d);
-template <> const mf::RowWideTable<float>* rowwide_for<float>(int d) {
-    switch (d) {
-        case 10: return mf::rowwide_f32_d10(); case 11: return mf::rowwide_f32_d11(); case 12: return mf::rowwide_f32_d12();
-        case 13: return mf::rowwide_f32_d13(); case 14: return mf::rowwide_f32_d14(); case 15: return mf::rowwide_f32_d15();
-        default: return nullptr;
-    }
-}
-template <> const mf::RowWideTable<double>* rowwide_for<double>(int d) {
-    switch (d) {
-        case 10: return mf::rowwide_f64_d10(); case 11: return mf::rowwide_f64_d11(); case 12: return mf::rowwide_f64_d12();
-        case 13: return mf::rowwide_f64_d13(); case 14: return mf::rowwide_f64_d14(); case 15: return mf::rowwide_f64_d15();
-        default: return nullptr;
-    }
-}
 
 template <typename T>
 int kf_loglik(int64_t B, int64_t Tn, int d, int m, const T* mu0, const T* cholP0, const T* A, const T* b,
@@ -53,7 +39,7 @@ int kf_loglik(int64_t B, int64_t Tn, int d, int m, const T* mu0, const T* cholP0
     // experiment knob: state dimensions >= MF_BIG_FROM take the LDS-tile / MFMA path even where a register-resident
     // instantiation exists
     static const int big_from = [] { const char* e = mf::mf_knob("MF_BIG_FROM"); return e ? std::atoi(e) : 1000; }();
-    const bool big = (!t || d >= big_from) && d <= (sizeof(T) == 4 ? mf::MF_MAX_D_BIG : mf::MF_MAX_D_BIG_F64);
+    const bool big = (d > mf::MF_MAX_D || d >= big_from) && d <= (sizeof(T) == 4 ? mf::MF_MAX_D_BIG : mf::MF_MAX_D_BIG_F64);
     if (!t && !big) return -100;
     if (m < 1 || m > (big ? 32 : 4)) return -4;
     if (B == 0) return 0;
@@ -64,25 +50,21 @@ int kf_loglik(int64_t B, int64_t Tn, int d, int m, const T* mu0, const T* cholP0
     if (!y) return -11;
     if (!Rinv) return -12;
     if (!out) return -15;
-    if (!t) {
-        // 10 <= d <= 15 with at most four outputs: the row kernels (one 16-lane row per chunk), as for d = 7 ... 9
-        const auto* rw = rowwide_for<T>(d);
-        if (rw && Tn >= 2 && m <= 4 && rw->usable(B, Tn, m, chunks))
-            return rw->kf_loglik(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, add_const, out, ws, ws_bytes, info,
-                                 chunks, static_cast<hipEvent_t>(ev0), static_cast<hipEvent_t>(ev1), S(stream));
+    if (t && d < big_from) {
+        // d <= 9: every plan has a kernel.  10 <= d <= 15: the row kernels when the plan is theirs (at most four outputs, offsets
+        // within a buffer descriptor), else -100 and the tile engine below takes the call
+        const int rc = t->kf_loglik(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, add_const, out, ws, ws_bytes,
+                                    info, chunks, static_cast<hipEvent_t>(ev0), static_cast<hipEvent_t>(ev1), S(stream));
+        if (rc != -100 || !big) return rc;
     }
-    if (big) {
-        if constexpr (sizeof(T) == 4)
-            return mf::big_kf_loglik_f32(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, add_const, out,
-                                         ws, ws_bytes, info, chunks, static_cast<hipEvent_t>(ev0),
-                                         static_cast<hipEvent_t>(ev1), S(stream));
-        else
-            return mf::big_kf_loglik_f64(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, add_const, out,
-                                         ws, ws_bytes, info, chunks, static_cast<hipEvent_t>(ev0),
-                                         static_cast<hipEvent_t>(ev1), S(stream));
-    }
-    return t->kf_loglik(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, add_const, out, ws, ws_bytes,
-                        info, chunks, static_cast<hipEvent_t>(ev0), static_cast<hipEvent_t>(ev1), S(stream));
+    if constexpr (sizeof(T) == 4)
+        return mf::big_kf_loglik_f32(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, add_const, out,
+                                     ws, ws_bytes, info, chunks, static_cast<hipEvent_t>(ev0),
+                                     static_cast<hipEvent_t>(ev1), S(stream));
+    else
+        return mf::big_kf_loglik_f64(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, add_const, out,
+                                     ws, ws_bytes, info, chunks, static_cast<hipEvent_t>(ev0),
+                                     static_cast<hipEvent_t>(ev1), S(stream));
 }
 
 
@@ -142,15 +124,22 @@ size_t mf_kf_loglik_workspace_bytes(int64_t B, int64_t T, int d, int elem_size, 
     if (elem_size == 4) {
         const auto* t = table_for<float>(d);
         const size_t small = t ? t->kf_loglik_ws(B, T, chunks) : 0;
-        size_t large = (d >= 1 && d <= mf::MF_MAX_D_BIG && B >= 1 && T >= 1) ? mf::big_kf_loglik_ws(B, T, d, chunks, 4) : 0;
-        if (const auto* rw = rowwide_for<float>(d)) { const size_t w = rw->kf_loglik_ws(B, T, chunks); if (w > large) large = w; }
+        size_t large = (d > mf::MF_MAX_D && d <= mf::MF_MAX_D_BIG) ? mf::big_kf_loglik_ws(B, T, d, chunks, 4) : 0;
         return small > large ? small : large;
     }
     const auto* t = table_for<double>(d);
     const size_t small = t ? t->kf_loglik_ws(B, T, chunks) : 0;
-    size_t large = (d >= 1 && d <= mf::MF_MAX_D_BIG_F64 && B >= 1 && T >= 1) ? mf::big_kf_loglik_ws(B, T, d, chunks, 8) : 0;
-    if (const auto* rw = rowwide_for<double>(d)) { const size_t w = rw->kf_loglik_ws(B, T, chunks); if (w > large) large = w; }
+    size_t large = (d > mf::MF_MAX_D && d <= mf::MF_MAX_D_BIG_F64) ? mf::big_kf_loglik_ws(B, T, d, chunks, 8) : 0;
     return small > large ? small : large;
+}
+int mf_row_operators_cover(int64_t B, int64_t T, int d, int elem_size) {
+    if (B < 1 || T < 1 || d < 1 || d > mf::MF_MAX_D_ROW) return 0;
+    if (d <= mf::MF_MAX_D) return 1;
+    // 10 <= d <= 15 are compiled with the row kernels only, and the operators run in row form where they are partitioned in time:
+    // exactly the shapes for which the factorisation asks for a workspace
+    if (elem_size == 4) { const auto* t = table_for<float>(d); return t && t->btd_cholesky_ws(B, T) > 0 ? 1 : 0; }
+    const auto* t = table_for<double>(d);
+    return t && t->btd_cholesky_ws(B, T) > 0 ? 1 : 0;
 }
 int mf_max_state_dim_f32_loglik(void) { return mf::MF_MAX_D_BIG; }
 int mf_max_state_dim_f64_loglik(void) { return mf::MF_MAX_D_BIG_F64; }
@@ -170,15 +159,22 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
                             ws_bytes, info, chunks, prof_start, prof_stop, stream);
 }
 
-// `t` = register-resident table (d <= 9) or NULL; `big` = the LDS-tile / MFMA kernels take this (d, type)
+// `t` = table of the register / row kernels (d <= 9: all of them; 10 <= d <= 15: row kernels only) or NULL;
+// `big` = the LDS-tile / MFMA kernels cover this (d, type)
 #define MF_HEAD(T, B, Tn, d)                                                                        \
     if ((B) < 0) return -1;                                                                         \
     if ((Tn) < 1) return -2;                                                                        \
     if ((d) < 1) return -3;                                                                         \
     const auto* t = table_for<T>(d);                                                                \
-    const bool big = !t && (d) <= (sizeof(T) == 4 ? mf::MF_MAX_D_BIG : mf::MF_MAX_D_BIG_F64);       \
+    const bool big = (d) > mf::MF_MAX_D && (d) <= (sizeof(T) == 4 ? mf::MF_MAX_D_BIG : mf::MF_MAX_D_BIG_F64); \
     if (!t && !big) return -100;                                                                    \
     if ((B) == 0) return 0;
+// the table's kernels first; for 10 <= d <= 15 (row kernels only) -100 = "this plan is not theirs": on to the tile engine
+#define MF_TRY(call)                                          \
+    if (t) {                                                  \
+        const int rc_ = (call);                               \
+        if (rc_ != -100 || !big) return rc_;                  \
+    }
 
 #define MF_DEFINE(SUF, T)                                                                                              \
     int mf_btd_cholesky_##SUF(int64_t B, int64_t Tn, int d, const T* diag, const T* sub, T* ldiag, T* lsub, void* ws,  \
@@ -188,8 +184,9 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (!ldiag) return -6;                                                                                         \
         if (sub && !lsub) return -7;                                                                                   \
         if (Tn == 1) sub = nullptr;                                                                                    \
+        MF_TRY(t->btd_cholesky(B, Tn, diag, sub, ldiag, lsub, ws, ws_bytes, info, S(stream))) \
         if (big) return mf::big_cholesky_##SUF(B, Tn, d, diag, sub, ldiag, lsub, ws, ws_bytes, info, S(stream));      \
-        return t->btd_cholesky(B, Tn, diag, sub, ldiag, lsub, ws, ws_bytes, info, S(stream));                          \
+        return -100;                          \
     }                                                                                                                  \
     int mf_btd_solve_##SUF(int64_t Bl, int64_t Br, int64_t Tn, int d, const T* ldiag, const T* lsub, const T* rhs,     \
                            T* out, int transpose, void* ws, size_t ws_bytes, void* stream) {                           \
@@ -199,8 +196,9 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (!rhs) return -7;                                                                                           \
         if (!out) return -8;                                                                                           \
         if (Tn == 1) lsub = nullptr;                                                                                   \
+        MF_TRY(t->btd_solve(Bl, Br, Tn, ldiag, lsub, rhs, out, transpose, ws, ws_bytes, S(stream))) \
         if (big) return mf::big_solve_##SUF(Bl, Br, Tn, d, ldiag, lsub, rhs, out, transpose, ws, ws_bytes, S(stream)); \
-        return t->btd_solve(Bl, Br, Tn, ldiag, lsub, rhs, out, transpose, ws, ws_bytes, S(stream));                    \
+        return -100;                    \
     }                                                                                                                  \
     int mf_btd_matvec_##SUF(int64_t Bl, int64_t Br, int64_t Tn, int d, const T* diag, const T* sub, const T* x,        \
                             T* out, int mode, void* stream) {                                                          \
@@ -211,15 +209,17 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (!out) return -8;                                                                                           \
         if (mode < 0 || mode > 2) return -9;                                                                           \
         if (Tn == 1) sub = nullptr;                                                                                    \
+        MF_TRY(t->btd_matvec(Bl, Br, Tn, diag, sub, x, out, mode, S(stream))) \
         if (big) return mf::big_matvec_##SUF(Bl, Br, Tn, d, diag, sub, x, out, mode, S(stream));                       \
-        return t->btd_matvec(Bl, Br, Tn, diag, sub, x, out, mode, S(stream));                                          \
+        return -100;                                          \
     }                                                                                                                  \
     int mf_btd_logdet_##SUF(int64_t B, int64_t Tn, int d, const T* ldiag, T* out, void* stream) {                      \
         MF_HEAD(T, B, Tn, d)                                                                                           \
         if (!ldiag) return -4;                                                                                         \
         if (!out) return -5;                                                                                           \
+        MF_TRY(t->btd_logdet(B, Tn, ldiag, out, S(stream))) \
         if (big) return mf::big_logdet_##SUF(B, Tn, d, ldiag, out, S(stream));                                         \
-        return t->btd_logdet(B, Tn, ldiag, out, S(stream));                                                            \
+        return -100;                                                            \
     }                                                                                                                  \
     int mf_btd_logdet_quad_##SUF(int64_t B, int64_t Tn, int d, const T* diag, const T* sub, const T* rhs, T* out,      \
                                  void* ws, size_t ws_bytes, int* info, void* stream) {                                 \
@@ -228,7 +228,7 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (Tn > 1 && !sub) return -5;                                                                                 \
         if (!rhs) return -6;                                                                                           \
         if (!out) return -7;                                                                                           \
-        if (big) return -100;                                                                                          \
+        if (!t) return -100;                                                                                            \
         return t->btd_logdet_quad(B, Tn, diag, sub, rhs, out, ws, ws_bytes, info, 0, S(stream));                       \
     }                                                                                                                  \
     int mf_btd_diag_of_inverse_##SUF(int64_t B, int64_t Tn, int d, const T* ldiag, const T* lsub, T* odiag, T* osub,   \
@@ -238,8 +238,9 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (!odiag) return -6;                                                                                         \
         if (Tn == 1) lsub = nullptr;                                                                                   \
         if (!lsub) osub = nullptr;                                                                                     \
+        MF_TRY(t->btd_diag_of_inverse(B, Tn, ldiag, lsub, odiag, osub, ws, ws_bytes, S(stream))) \
         if (big) return mf::big_diag_of_inverse_##SUF(B, Tn, d, ldiag, lsub, odiag, osub, ws, ws_bytes, S(stream));   \
-        return t->btd_diag_of_inverse(B, Tn, ldiag, lsub, odiag, osub, ws, ws_bytes, S(stream));                       \
+        return -100;                       \
     }                                                                                                                  \
     int mf_ssm_marginal_covariances_##SUF(int64_t B, int64_t Tn, int d, const T* cholP0, const T* A, const T* cholQ,   \
                                           T* out_cov, T* out_sub, void* ws, size_t ws_bytes, void* stream) {          \
@@ -249,9 +250,10 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (!A) return -5;                                                                                             \
         if (!cholQ) return -6;                                                                                         \
         if (!out_cov) return -7;                                                                                       \
+        MF_TRY(t->ssm_marginal_covs(B, Tn, cholP0, A, cholQ, out_cov, out_sub, ws, ws_bytes, S(stream))) \
         if (big) return mf::big_marginal_covs_##SUF(B, Tn, d, nullptr, cholP0, A, nullptr, cholQ, nullptr, out_cov, out_sub, \
                                                     ws, ws_bytes, S(stream));                                          \
-        return t->ssm_marginal_covs(B, Tn, cholP0, A, cholQ, out_cov, out_sub, ws, ws_bytes, S(stream));               \
+        return -100;               \
     }                                                                                                                  \
     int mf_ssm_marginals_##SUF(int64_t B, int64_t Tn, int d, const T* mu0, const T* cholP0, const T* A, const T* b,    \
                                const T* cholQ, T* out_mean, T* out_cov, T* out_sub, void* ws, size_t ws_bytes,        \
@@ -265,9 +267,10 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (!cholQ) return -8;                                                                                         \
         if (!out_mean) return -9;                                                                                      \
         if (!out_cov) return -10;                                                                                      \
+        MF_TRY(t->ssm_marginals(B, Tn, mu0, cholP0, A, b, cholQ, out_mean, out_cov, out_sub, ws, ws_bytes, S(stream))) \
         if (big) return mf::big_marginal_covs_##SUF(B, Tn, d, mu0, cholP0, A, b, cholQ, out_mean, out_cov, out_sub, ws, \
                                                     ws_bytes, S(stream));                                              \
-        return t->ssm_marginals(B, Tn, mu0, cholP0, A, b, cholQ, out_mean, out_cov, out_sub, ws, ws_bytes, S(stream)); \
+        return -100; \
     }                                                                                                                  \
     int mf_btd_udl_##SUF(int64_t B, int64_t Tn, int d, const T* diag, const T* sub, T* ut, T* chol_d, const T* eta,    \
                          T* m_post, T* chol_dinv, int chain_layout, void* ws, size_t ws_bytes, int* info,              \
@@ -278,11 +281,11 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (!chol_d && !chain_layout) return -7;                                                                       \
         if (eta && (!m_post || !chol_dinv)) return -9;                                                                 \
         if (chain_layout && (!eta || Tn < 2)) return -11;                                                              \
+        MF_TRY(t->btd_udl(B, Tn, diag, sub, ut, chol_d, eta, m_post, chol_dinv, chain_layout, ws, ws_bytes, info, S(stream))) \
         if (big && chain_layout) return -101;                                                                          \
         if (big) return mf::big_udl_##SUF(B, Tn, d, diag, sub, ut, chol_d, eta, m_post, chol_dinv, ws, ws_bytes, info, \
                                        S(stream));                                                                 \
-        return t->btd_udl(B, Tn, diag, sub, ut, chol_d, eta, m_post, chol_dinv, chain_layout, ws, ws_bytes, info,      \
-                          S(stream));                                                                                  \
+        return -100;                                                                                  \
     }                                                                                                                  \
     int mf_ssm_precision_##SUF(int64_t B, int64_t Tn, int d, int m, const T* mu0, const T* cholP0, const T* A,         \
                                const T* b, const T* cholQ, const T* H, const T* y, const T* Rinv, int rinv_per_step,   \
@@ -294,11 +297,11 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (H && (m < 1 || m > (big ? 32 : 4))) return -4;                                                             \
         if (!diag) return -14;                                                                                         \
         if (eta && (!mu0 || (Tn > 1 && !b))) return -5;                                                                \
+        MF_TRY(t->ssm_precision(B, Tn, H ? m : 1, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, diag, sub, eta, S(stream))) \
         if (big)                                                                                                       \
             return mf::big_ssm_precision_##SUF(B, Tn, d, H ? m : 1, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step,   \
                                                diag, sub, eta, S(stream));                                             \
-        return t->ssm_precision(B, Tn, H ? m : 1, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, diag, sub, eta, \
-                                S(stream));                                                                            \
+        return -100;                                                                            \
     }                                                                                                                  \
     int mf_ssm_marginal_means_##SUF(int64_t Bl, int64_t Br, int64_t Tn, int d, const T* A, const T* offs, T* out,      \
                                     void* ws, size_t ws_bytes, void* stream) {                                         \
@@ -307,8 +310,9 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (Tn > 1 && !A) return -5;                                                                                   \
         if (!offs) return -6;                                                                                          \
         if (!out) return -7;                                                                                           \
+        MF_TRY(t->ssm_means(Bl, Br, Tn, A, offs, out, ws, ws_bytes, S(stream))) \
         if (big) return mf::big_means_##SUF(Bl, Br, Tn, d, A, offs, out, ws, ws_bytes, S(stream));                     \
-        return t->ssm_means(Bl, Br, Tn, A, offs, out, ws, ws_bytes, S(stream));                                        \
+        return -100;                                        \
     }
 
 #define MF_DEFINE2(SUF, T)                                                                                             \
@@ -320,8 +324,9 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (!Y) return -6;                                                                                             \
         if (y_stride < n) return -7;                                                                                   \
         if (!out) return -8;                                                                                           \
+        MF_TRY(t->block_matmul(B, n, X, x_stride, Y, y_stride, out, S(stream))) \
         if (big) return mf::big_block_matmul_##SUF(B, n, d, X, x_stride, Y, y_stride, out, S(stream));                 \
-        return t->block_matmul(B, n, X, x_stride, Y, y_stride, out, S(stream));                                        \
+        return -100;                                        \
     }
 
 #define MF_DEFINE3(SUF, T)                                                                                             \
@@ -387,11 +392,11 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (!g_mu0 || !g_cholP0 || (Tn > 1 && (!g_A || !g_b || !g_cholQ))) return -17;                                 \
         if (H && (!g_H || !g_y || !g_omega)) return -22;                                                               \
         if (big && !weights) return -25;                                                                               \
+        MF_TRY(t->kf_grad(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, post_mean, post_cov, post_cross, g_mu0, g_cholP0, g_A, g_b, g_cholQ, g_H, g_y, g_omega, weights, rinv_per_step, info, S(stream))) \
         if (big) return mf::big_kf_grad_##SUF(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step,        \
                                               post_mean, post_cov, post_cross, weights, g_mu0, g_cholP0, g_A, g_b,     \
                                               g_cholQ, g_H, g_y, g_omega, S(stream));                                  \
-        return t->kf_grad(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, post_mean, post_cov, post_cross, g_mu0,      \
-                          g_cholP0, g_A, g_b, g_cholQ, g_H, g_y, g_omega, weights, rinv_per_step, info, S(stream));    \
+        return -100;    \
     }                                                                                                                  \
     int mf_ssm_kl_grad_##SUF(int64_t B, int64_t Tn, int d, const T* mu0_1, const T* cholP0_1, const T* A_1,            \
                              const T* b_1, const T* cholQ_1, const T* mu0_2, const T* cholP0_2, const T* A_2,          \
@@ -399,7 +404,7 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
                              const T* adj_N, const T* adj_n, T* g_mu0, T* g_cholP0, T* g_A, T* g_b, T* g_cholQ,        \
                              void* ws, size_t ws_bytes, int* info, void* stream) {                                     \
         MF_HEAD(T, B, Tn, d)                                                                                           \
-        if (big) return -100;                                                                                          \
+        if (!t) return -100;                                                                                            \
         if (!mu0_1 || !cholP0_1 || (Tn > 1 && (!A_1 || !b_1 || !cholQ_1))) return -4;                                  \
         if (!mu0_2 || !cholP0_2 || (Tn > 1 && (!A_2 || !b_2 || !cholQ_2))) return -9;                                  \
         if (!means_1 || !covs_1) return -14;                                                                           \
@@ -413,7 +418,7 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
                                     int rinv_per_step, T* a_post, T* mu0_post, T* b_post, T* cholP0_post,              \
                                     T* cholQ_post, int* info, void* stream) {                                          \
         MF_HEAD(T, B, Tn, d)                                                                                           \
-        if (big) return -100;                                                                                          \
+        if (!t) return -100;                                                                                            \
         if (m < 1 || m > 4) return -4;                                                                                 \
         if (!mu0 || !cholP0 || (Tn > 1 && (!A || !b || !cholQ))) return -5;                                            \
         if (!H || !y || !Rinv) return -10;                                                                             \
@@ -427,7 +432,7 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
                                    T* out_cross, T* out_N, T* out_n, void* ws, size_t ws_bytes, int* info,             \
                                    void* stream) {                                                                     \
         MF_HEAD(T, B, Tn, d)                                                                                           \
-        if (big) return -100;                                                                                          \
+        if (!t) return -100;                                                                                            \
         if (!mu0_1 || !cholP0_1 || (Tn > 1 && (!A_1 || !b_1 || !cholQ_1))) return -4;                                  \
         if (!mu0_2 || !cholP0_2 || (Tn > 1 && (!A_2 || !b_2 || !cholQ_2))) return -9;                                  \
         if (!out) return -14;                                                                                          \
@@ -438,7 +443,7 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
                                     const T* means, const T* covs, const T* g_means, const T* g_covs, T* g_mu0,        \
                                     T* g_cholP0, T* g_A, T* g_b, T* g_cholQ, void* ws, size_t ws_bytes, void* stream) { \
         MF_HEAD(T, B, Tn, d)                                                                                           \
-        if (big) return -100;                                                                                          \
+        if (!t) return -100;                                                                                            \
         if (!cholP0 || (Tn > 1 && (!A || !cholQ))) return -4;                                                          \
         if (!means || !covs) return -7;                                                                                \
         if (!g_mu0 || !g_cholP0 || (Tn > 1 && (!g_A || !g_b || !g_cholQ))) return -11;                                 \
@@ -457,53 +462,58 @@ MF_DEFINE4(f32, float)
 MF_DEFINE5(f64, double)
 MF_DEFINE5(f32, float)
 
+static size_t big_max(size_t a, size_t b) { return a > b ? a : b; }
 static bool big_dim(int d, int elem_size) {
     return d > mf::MF_MAX_D && d <= (elem_size == 4 ? mf::MF_MAX_D_BIG : mf::MF_MAX_D_BIG_F64);
 }
 
 size_t mf_btd_cholesky_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {
     if (B < 1 || T < 1) return 0;
-    if (big_dim(d, elem_size)) return mf::big_btd_par_ws(B, T, d, 0, elem_size);
-    if (elem_size == 4) { const auto* t = table_for<float>(d); return t ? t->btd_cholesky_ws(B, T) : 0; }
-    const auto* t = table_for<double>(d);
-    return t ? t->btd_cholesky_ws(B, T) : 0;
+    size_t small = 0;
+    if (elem_size == 4) { if (const auto* t = table_for<float>(d)) small = t->btd_cholesky_ws(B, T); }
+    else if (const auto* t = table_for<double>(d)) small = t->btd_cholesky_ws(B, T);
+    // 10 <= d <= 15: sized for whichever engine takes the call (row kernels when the plan is theirs, else the tile engine)
+    const size_t large = big_dim(d, elem_size) ? mf::big_btd_par_ws(B, T, d, 0, elem_size) : 0;
+    return small > large ? small : large;
 }
 size_t mf_btd_solve_workspace_bytes(int64_t Bl, int64_t Br, int64_t T, int d, int elem_size) {
     if (Bl < 1 || Br < 1 || T < 1) return 0;
-    if (big_dim(d, elem_size)) return mf::big_btd_solve_ws(Bl, Br, T, d, elem_size);
-    if (elem_size == 4) { const auto* t = table_for<float>(d); return t ? t->btd_solve_ws(Bl, Br, T) : 0; }
-    const auto* t = table_for<double>(d);
-    return t ? t->btd_solve_ws(Bl, Br, T) : 0;
+    size_t small = 0;
+    if (elem_size == 4) { if (const auto* t = table_for<float>(d)) small = t->btd_solve_ws(Bl, Br, T); }
+    else if (const auto* t = table_for<double>(d)) small = t->btd_solve_ws(Bl, Br, T);
+    // 10 <= d <= 15: sized for whichever engine takes the call (row kernels when the plan is theirs, else the tile engine)
+    const size_t large = big_dim(d, elem_size) ? mf::big_btd_solve_ws(Bl, Br, T, d, elem_size) : 0;
+    return small > large ? small : large;
 }
 
 size_t mf_btd_diag_of_inverse_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {
     if (B < 1 || T < 1) return 0;
-    // large d: one buffer sized for both users of this query - the time-partitioned Takahashi recursion of
-    // mf_btd_diag_of_inverse and the covariance recursion of mf_ssm_marginal_covariances
-    if (big_dim(d, elem_size)) {
-        const size_t a = mf::big_marginal_covs_ws(B, T, d, elem_size), b = mf::big_btd_tak_ws(B, T, d, elem_size);
-        return a > b ? a : b;
-    }
-    if (elem_size == 4) { const auto* t = table_for<float>(d); return t ? t->btd_diag_of_inverse_ws(B, T) : 0; }
-    const auto* t = table_for<double>(d);
-    return t ? t->btd_diag_of_inverse_ws(B, T) : 0;
+    size_t small = 0;
+    if (elem_size == 4) { if (const auto* t = table_for<float>(d)) small = t->btd_diag_of_inverse_ws(B, T); }
+    else if (const auto* t = table_for<double>(d)) small = t->btd_diag_of_inverse_ws(B, T);
+    // 10 <= d <= 15: sized for whichever engine takes the call (row kernels when the plan is theirs, else the tile engine)
+    const size_t large = big_dim(d, elem_size) ? big_max(mf::big_marginal_covs_ws(B, T, d, elem_size), mf::big_btd_tak_ws(B, T, d, elem_size)) : 0;
+    return small > large ? small : large;
 }
 
 size_t mf_btd_udl_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {
     if (B < 1 || T < 1) return 0;
-    if (big_dim(d, elem_size)) return mf::big_btd_par_ws(B, T, d, 1, elem_size);
-    if (elem_size == 4) { const auto* t = table_for<float>(d); return t ? t->btd_udl_ws(B, T) : 0; }
-    const auto* t = table_for<double>(d);
-    return t ? t->btd_udl_ws(B, T) : 0;
+    size_t small = 0;
+    if (elem_size == 4) { if (const auto* t = table_for<float>(d)) small = t->btd_udl_ws(B, T); }
+    else if (const auto* t = table_for<double>(d)) small = t->btd_udl_ws(B, T);
+    // 10 <= d <= 15: sized for whichever engine takes the call (row kernels when the plan is theirs, else the tile engine)
+    const size_t large = big_dim(d, elem_size) ? mf::big_btd_par_ws(B, T, d, 1, elem_size) : 0;
+    return small > large ? small : large;
 }
 
 size_t mf_ssm_marginals_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {
     if (B < 1 || T < 1) return 0;
-    const bool big = d > mf::MF_MAX_D && d <= (elem_size == 4 ? mf::MF_MAX_D_BIG : mf::MF_MAX_D_BIG_F64);
-    if (big) return mf::big_marginal_covs_ws(B, T, d, elem_size);
-    if (elem_size == 4) { const auto* t = table_for<float>(d); return t ? t->marginals_ws(B, T) : 0; }
-    const auto* t = table_for<double>(d);
-    return t ? t->marginals_ws(B, T) : 0;
+    size_t small = 0;
+    if (elem_size == 4) { if (const auto* t = table_for<float>(d)) small = t->marginals_ws(B, T); }
+    else if (const auto* t = table_for<double>(d)) small = t->marginals_ws(B, T);
+    // 10 <= d <= 15: sized for whichever engine takes the call (row kernels when the plan is theirs, else the tile engine)
+    const size_t large = big_dim(d, elem_size) ? mf::big_marginal_covs_ws(B, T, d, elem_size) : 0;
+    return small > large ? small : large;
 }
 
 size_t mf_ssm_kl_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {

@@ -25,6 +25,15 @@ namespace mf {
 namespace {
 
 constexpr int D = MF_D;
+// The lane-per-chunk / lane-per-series kernels exist up to d = MF_MAX_D (their state no longer fits a lane's registers beyond it).
+// For 10 <= d <= 15 this file is compiled with the ROW kernels only: a call whose plan needs a lane kernel returns -100 and the C
+// ABI hands it to the LDS-tile / MFMA engine (mf_api.hip).
+constexpr bool LANE = D <= MF_MAX_D;
+#define MF_LANE_LAUNCH(...)                                   \
+    do {                                                      \
+        if constexpr (LANE) { hipLaunchKernelGGL(__VA_ARGS__); } \
+        else return -100;                                     \
+    } while (0)
 constexpr long RED_CHUNK = 8;    // chunk length of the level-0 floor of the parallel-in-time operators
 // reduction levels of the log-likelihood: chunk length, and the size at which the last level is walked serially
 // (d >= 7: a reduction step is ~10 k instructions on one lane, so the levels are cut shorter - 64 -> 16 -> 4 -> walk 4 is 12
@@ -128,14 +137,14 @@ int reduce_levels(RedSys<T> cur, long B, char* p, T add_const, T* out, int* info
         const long lanes = B * P;
         constexpr int x_lds = LdsSpike<T, D>::BYTES;
         if (x_path<T>())
-            hipLaunchKernelGGL((red_chunk_x_kernel<T, D>), dim3((unsigned)cdiv(lanes, 64)), dim3(64), x_lds, st, cur, nxt, B,
+            MF_LANE_LAUNCH((red_chunk_x_kernel<T, D>), dim3((unsigned)cdiv(lanes, 64)), dim3(64), x_lds, st, cur, nxt, B,
                                P, info);
         else
-            hipLaunchKernelGGL((red_chunk_kernel<T, D, true>), dim3((unsigned)cdiv(lanes, 64)), dim3(64), 0, st, cur, nxt,
+            MF_LANE_LAUNCH((red_chunk_kernel<T, D, true>), dim3((unsigned)cdiv(lanes, 64)), dim3(64), 0, st, cur, nxt,
                                B, P, info);
         cur = nxt;
     }
-    hipLaunchKernelGGL((red_final_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, cur, B, add_const, out,
+    MF_LANE_LAUNCH((red_final_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, cur, B, add_const, out,
                        info);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
@@ -288,11 +297,12 @@ template <typename T>
 int kf_loglik(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ,
               const T* H, const T* y, const T* Rinv, int rinv_per_step, T add_const, T* out, void* ws,
               size_t ws_bytes, int* info, long chunks, hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
-    if (m < 1 || m > MF_MAXM) return -4;
+    if (m < 1 || m > MF_MAXM) return LANE ? -4 : -100;       // (row-only build: more outputs belong to the tile engine)
     if (ws == nullptr) return -15;
     const bool aligned16 = ((reinterpret_cast<size_t>(A) | reinterpret_cast<size_t>(cholQ)) & 15) == 0;
     const KfPlan pl = kf_plan<T>(B, Tn, m, rinv_per_step, chunks, aligned16);
     const long P = pl.P;
+    if constexpr (!LANE) { if (pl.path != KF_PATH_ROW) return -100; }      // 10 <= d <= 15: the row kernel or the tile engine
     if (ws_bytes < plan_ws<T>(B, pl)) return -15;           // checked against the partition that is actually launched
     int dbg = 0;
 #ifdef MF_EXPERIMENT
@@ -322,15 +332,15 @@ int kf_loglik(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A,
         constexpr int x_lds = LdsSpike<T, D>::BYTES;
         if (m > 1 && x_obs_lds<T>(m)) {
             const int lds = x_lds + LdsObs<T, D>::bytes(m);
-            if (lds > 64 * 1024) {         // past the default dynamic-LDS limit of a kernel: raise it (once per process)
+            if constexpr (LANE) if (lds > 64 * 1024) {         // past the default dynamic-LDS limit of a kernel: raise it (once per process)
                 static const hipError_t raised = hipFuncSetAttribute(
                     reinterpret_cast<const void*>(&kf_chunk_x_kernel<T, D, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                     x_lds + LdsObs<T, D>::bytes(MF_MAXM));
                 if (raised != hipSuccess) return -1000;
             }
-            hipLaunchKernelGGL((kf_chunk_x_kernel<T, D, true>), grid, block, lds, st, a, lvl0);
+            MF_LANE_LAUNCH((kf_chunk_x_kernel<T, D, true>), grid, block, lds, st, a, lvl0);
         } else {
-            hipLaunchKernelGGL((kf_chunk_x_kernel<T, D, false>), grid, block, x_lds, st, a, lvl0);
+            MF_LANE_LAUNCH((kf_chunk_x_kernel<T, D, false>), grid, block, x_lds, st, a, lvl0);
         }
     } else if (pl.path == KF_PATH_LDS) {
         const long L = pl.L;
@@ -339,8 +349,8 @@ int kf_loglik(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A,
             constexpr bool RS = decltype(rtag)::value;
             if constexpr (KfLdsCfg<T, D, M, RS>::SUPPORTED) {
                 constexpr int lds = KfLdsCfg<T, D, M, RS>::LDS_TOTAL;
-                if (P > 1) hipLaunchKernelGGL((kf_chunk_lds_kernel<T, D, M, true, RS>), grid, block, lds, st, a, L, lvl0);
-                else hipLaunchKernelGGL((kf_chunk_lds_kernel<T, D, M, false, RS>), grid, block, lds, st, a, L, lvl0);
+                if (P > 1) MF_LANE_LAUNCH((kf_chunk_lds_kernel<T, D, M, true, RS>), grid, block, lds, st, a, L, lvl0);
+                else MF_LANE_LAUNCH((kf_chunk_lds_kernel<T, D, M, false, RS>), grid, block, lds, st, a, L, lvl0);
             }
         };
         using std::integral_constant;
@@ -350,11 +360,11 @@ int kf_loglik(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A,
         else if (m == 3) launch(integral_constant<int, 3>{}, integral_constant<bool, false>{});
         else launch(integral_constant<int, 4>{}, integral_constant<bool, false>{});
     } else if (P > 1) {
-        if (m == 1) hipLaunchKernelGGL((kf_chunk_kernel<T, D, 1, true>), grid, block, 0, st, a, lvl0);
-        else hipLaunchKernelGGL((kf_chunk_kernel<T, D, 0, true>), grid, block, 0, st, a, lvl0);
+        if (m == 1) MF_LANE_LAUNCH((kf_chunk_kernel<T, D, 1, true>), grid, block, 0, st, a, lvl0);
+        else MF_LANE_LAUNCH((kf_chunk_kernel<T, D, 0, true>), grid, block, 0, st, a, lvl0);
     } else {
-        if (m == 1) hipLaunchKernelGGL((kf_chunk_kernel<T, D, 1, false>), grid, block, 0, st, a, lvl0);
-        else hipLaunchKernelGGL((kf_chunk_kernel<T, D, 0, false>), grid, block, 0, st, a, lvl0);
+        if (m == 1) MF_LANE_LAUNCH((kf_chunk_kernel<T, D, 1, false>), grid, block, 0, st, a, lvl0);
+        else MF_LANE_LAUNCH((kf_chunk_kernel<T, D, 0, false>), grid, block, 0, st, a, lvl0);
     }
     if (ev1) (void)hipEventRecord(ev1, st);
     if (pl.path == KF_PATH_ROW) return reduce_levels_row<T>(lvl0, B, p, add_const, out, info, st);
@@ -456,12 +466,13 @@ inline ParPlan par_plan(long n0, long len0) {
 // register-resident up-sweep of the parallel-in-time Cholesky; mode 0 / 1: level 0 of the matrix / of the block-reversed
 // matrix, 2: a reduced level
 template <typename T>
-void launch_chol_up(const ParLevel<T>& lv, int mode, long B, long len, long P, T* oDv, T* oGf, T* oGU, T* oF, int* info,
-                    hipStream_t st) {
+int launch_chol_up(const ParLevel<T>& lv, int mode, long B, long len, long P, T* oDv, T* oGf, T* oGU, T* oF, int* info,
+                   hipStream_t st) {
     const dim3 grid((unsigned)cdiv(B * P, 64)), block(64);
-    if (mode == 0) hipLaunchKernelGGL((par_chol_up_kernel<T, D, 0>), grid, block, 0, st, lv, B, len, P, oDv, oGf, oGU, oF, info);
-    else if (mode == 1) hipLaunchKernelGGL((par_chol_up_kernel<T, D, 1>), grid, block, 0, st, lv, B, len, P, oDv, oGf, oGU, oF, info);
-    else hipLaunchKernelGGL((par_chol_up_kernel<T, D, 2>), grid, block, 0, st, lv, B, len, P, oDv, oGf, oGU, oF, info);
+    if (mode == 0) MF_LANE_LAUNCH((par_chol_up_kernel<T, D, 0>), grid, block, 0, st, lv, B, len, P, oDv, oGf, oGU, oF, info);
+    else if (mode == 1) MF_LANE_LAUNCH((par_chol_up_kernel<T, D, 1>), grid, block, 0, st, lv, B, len, P, oDv, oGf, oGU, oF, info);
+    else MF_LANE_LAUNCH((par_chol_up_kernel<T, D, 2>), grid, block, 0, st, lv, B, len, P, oDv, oGf, oGU, oF, info);
+    return 0;
 }
 
 template <typename T> size_t btd_cholesky_ws(long B, long n) {
@@ -481,10 +492,10 @@ int btd_cholesky(long B, long n, const T* diag, const T* sub, T* ldiag, T* lsub,
         // one lane per series; with a sub-diagonal the level-0 emit kernel as ONE chunk: same recursion, but the next block's
         // loads are in flight during the current block's arithmetic
         if (sub && n >= 2)
-            hipLaunchKernelGGL((par_chol_emit_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, n, 1L, diag,
+            MF_LANE_LAUNCH((par_chol_emit_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, n, 1L, diag,
                                sub, static_cast<const T*>(nullptr), ldiag, lsub, info);
         else
-            hipLaunchKernelGGL((btd_cholesky_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, diag, sub,
+            MF_LANE_LAUNCH((btd_cholesky_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, diag, sub,
                                ldiag, lsub, info);
         return hipGetLastError() == hipSuccess ? 0 : -1000;
     }
@@ -538,23 +549,23 @@ int btd_cholesky(long B, long n, const T* diag, const T* sub, T* ldiag, T* lsub,
         const long P = pl.n[l + 1];
         constexpr int x_lds = LdsSpike<T, D>::BYTES;
         if (x_path<T>())
-            hipLaunchKernelGGL((par_chol_up_x_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), x_lds, st, level(l),
+            MF_LANE_LAUNCH((par_chol_up_x_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), x_lds, st, level(l),
                                B, pl.len[l], P, arr[l + 1].Dv, arr[l + 1].Gf, arr[l + 1].GU, arr[l + 1].F, info);
         else
-            launch_chol_up<T>(level(l), l == 0 ? 0 : 2, B, pl.len[l], P, arr[l + 1].Dv, arr[l + 1].Gf, arr[l + 1].GU,
-                              arr[l + 1].F, info, st);
+            if (const int rc = launch_chol_up<T>(level(l), l == 0 ? 0 : 2, B, pl.len[l], P, arr[l + 1].Dv, arr[l + 1].Gf, arr[l + 1].GU,
+                              arr[l + 1].F, info, st)) return rc;
     }
     {   // coarsest level: one lane per series walks it
         const int l = pl.levels;
-        hipLaunchKernelGGL((par_chol_down_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, level(l), B,
+        MF_LANE_LAUNCH((par_chol_down_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, level(l), B,
                            pl.n[l], 1L, static_cast<const T*>(nullptr), arr[l].Pn, info);
     }
     for (int l = pl.levels - 1; l >= 1; --l) {
         const long P = pl.n[l + 1];
-        hipLaunchKernelGGL((par_chol_down_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, level(l), B,
+        MF_LANE_LAUNCH((par_chol_down_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, level(l), B,
                            pl.len[l], P, static_cast<const T*>(arr[l + 1].Pn), arr[l].Pn, info);
     }
-    hipLaunchKernelGGL((par_chol_emit_kernel<T, D>), dim3((unsigned)cdiv(B * pl.n[1], 64)), dim3(64), 0, st, B, n, len0,
+    MF_LANE_LAUNCH((par_chol_emit_kernel<T, D>), dim3((unsigned)cdiv(B * pl.n[1], 64)), dim3(64), 0, st, B, n, len0,
                        pl.n[1], diag, sub, static_cast<const T*>(arr[1].Pn), ldiag, lsub, info);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
@@ -576,10 +587,10 @@ int btd_solve(long Bl, long Br, long n, const T* ldiag, const T* lsub, const T* 
     const long len0 = lsub ? par_len0(Br, n) : 0;
     if (len0 == 0 || ws == nullptr || ws_bytes < btd_solve_ws<T>(Bl, Br, n)) {
         if (lsub && n >= 2)     // one lane per right-hand side: the level-0 emit kernel as ONE chunk (prefetched loads)
-            hipLaunchKernelGGL((par_solve_emit_kernel<T, D>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Bl, Br, n, n, 1L,
+            MF_LANE_LAUNCH((par_solve_emit_kernel<T, D>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Bl, Br, n, n, 1L,
                                ldiag, lsub, rhs, static_cast<const T*>(nullptr), transpose, out);
         else
-            hipLaunchKernelGGL((btd_solve_kernel<T, D>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Bl, Br, n, ldiag,
+            MF_LANE_LAUNCH((btd_solve_kernel<T, D>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Bl, Br, n, ldiag,
                                lsub, rhs, out, transpose);
         return hipGetLastError() == hipSuccess ? 0 : -1000;
     }
@@ -623,40 +634,40 @@ int btd_solve(long Bl, long Br, long n, const T* ldiag, const T* lsub, const T* 
         }
         return hipGetLastError() == hipSuccess ? 0 : -1000;
     }
-    hipLaunchKernelGGL((par_solve_up0_kernel<T, D>), dim3((unsigned)cdiv(Br * pl.n[1], 64)), dim3(64), 0, st, Bl, Br, n,
+    MF_LANE_LAUNCH((par_solve_up0_kernel<T, D>), dim3((unsigned)cdiv(Br * pl.n[1], 64)), dim3(64), 0, st, Bl, Br, n,
                        len0, pl.n[1], ldiag, lsub, rhs, transpose, arr[1].M, arr[1].c);
     for (int l = 1; l < pl.levels; ++l) {
         const long P = pl.n[l + 1];
-        hipLaunchKernelGGL((par_affine_up_kernel<T, D>), dim3((unsigned)cdiv(Br * P, 64)), dim3(64), 0, st, Br, pl.n[l],
+        MF_LANE_LAUNCH((par_affine_up_kernel<T, D>), dim3((unsigned)cdiv(Br * P, 64)), dim3(64), 0, st, Br, pl.n[l],
                            pl.len[l], P, static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c), arr[l + 1].M,
                            arr[l + 1].c);
     }
     {
         const int l = pl.levels;
-        hipLaunchKernelGGL((par_affine_down_kernel<T, D>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Br, pl.n[l],
+        MF_LANE_LAUNCH((par_affine_down_kernel<T, D>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Br, pl.n[l],
                            pl.n[l], 1L, static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c),
                            static_cast<const T*>(nullptr), arr[l].Z);
     }
     for (int l = pl.levels - 1; l >= 1; --l) {
         const long P = pl.n[l + 1];
-        hipLaunchKernelGGL((par_affine_down_kernel<T, D>), dim3((unsigned)cdiv(Br * P, 64)), dim3(64), 0, st, Br, pl.n[l],
+        MF_LANE_LAUNCH((par_affine_down_kernel<T, D>), dim3((unsigned)cdiv(Br * P, 64)), dim3(64), 0, st, Br, pl.n[l],
                            pl.len[l], P, static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c),
                            static_cast<const T*>(arr[l + 1].Z), arr[l].Z);
     }
-    hipLaunchKernelGGL((par_solve_emit_kernel<T, D>), dim3((unsigned)cdiv(Br * pl.n[1], 64)), dim3(64), 0, st, Bl, Br, n,
+    MF_LANE_LAUNCH((par_solve_emit_kernel<T, D>), dim3((unsigned)cdiv(Br * pl.n[1], 64)), dim3(64), 0, st, Bl, Br, n,
                        len0, pl.n[1], ldiag, lsub, rhs, static_cast<const T*>(arr[1].Z), transpose, out);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
 template <typename T>
 int btd_matvec(long Bl, long Br, long n, const T* diag, const T* sub, const T* x, T* out, int mode, hipStream_t st) {
-    hipLaunchKernelGGL((btd_matvec_kernel<T, D>), dim3((unsigned)cdiv(Br * n, 256)), dim3(256), 0, st, Bl, Br, n, diag,
+    MF_LANE_LAUNCH((btd_matvec_kernel<T, D>), dim3((unsigned)cdiv(Br * n, 256)), dim3(256), 0, st, Bl, Br, n, diag,
                        sub, x, out, mode);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
 template <typename T> int btd_logdet(long B, long n, const T* ldiag, T* out, hipStream_t st) {
-    hipLaunchKernelGGL((btd_logdet_kernel<T, D>), dim3((unsigned)B), dim3(64), 0, st, B, n, ldiag, out);
+    MF_LANE_LAUNCH((btd_logdet_kernel<T, D>), dim3((unsigned)B), dim3(64), 0, st, B, n, ldiag, out);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
@@ -679,7 +690,7 @@ int tak_scan(long B, long n, TakSrc<T> src, T* odiag, T* osub, void* ws, size_t 
     if (len0 == 0 || ws == nullptr || ws_bytes < btd_diag_of_inverse_ws<T>(B, n)) {
         if (up_only) return -16;
         // one lane per series: the level-0 emit kernel as ONE chunk (prefetched loads)
-        hipLaunchKernelGGL((par_tak_emit_kernel<T, D, SRC>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, n, 1L, src,
+        MF_LANE_LAUNCH((par_tak_emit_kernel<T, D, SRC>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, n, 1L, src,
                            static_cast<const T*>(nullptr), odiag, osub);
         return hipGetLastError() == hipSuccess ? 0 : -1000;
     }
@@ -728,42 +739,42 @@ int tak_scan(long B, long n, TakSrc<T> src, T* odiag, T* osub, void* ws, size_t 
     constexpr int g_lds = D * D * 64 * (int)sizeof(T);      // x path: the composed G of a run lives in LDS
     if (SRC == 1 && mup.oc != nullptr) {
         if (x_path<T>())
-            hipLaunchKernelGGL((par_tak_up0_x_kernel<T, D, 1, true>), dim3((unsigned)cdiv(B * pl.n[1], 64)), dim3(64), g_lds, st, B,
+            MF_LANE_LAUNCH((par_tak_up0_x_kernel<T, D, 1, true>), dim3((unsigned)cdiv(B * pl.n[1], 64)), dim3(64), g_lds, st, B,
                                n, len0, pl.n[1], src, arr[1].G, arr[1].N, mup);
         else
-            hipLaunchKernelGGL((par_tak_up0_kernel<T, D, 1, true>), dim3((unsigned)cdiv(B * pl.n[1], 64)), dim3(64), 0, st, B, n,
+            MF_LANE_LAUNCH((par_tak_up0_kernel<T, D, 1, true>), dim3((unsigned)cdiv(B * pl.n[1], 64)), dim3(64), 0, st, B, n,
                                len0, pl.n[1], src, arr[1].G, arr[1].N, mup);
     } else if (x_path<T>())
-        hipLaunchKernelGGL((par_tak_up0_x_kernel<T, D, SRC>), dim3((unsigned)cdiv(B * pl.n[1], 64)), dim3(64), g_lds, st, B, n,
+        MF_LANE_LAUNCH((par_tak_up0_x_kernel<T, D, SRC>), dim3((unsigned)cdiv(B * pl.n[1], 64)), dim3(64), g_lds, st, B, n,
                            len0, pl.n[1], src, arr[1].G, arr[1].N, TakMeanUp<T>{});
     else
-        hipLaunchKernelGGL((par_tak_up0_kernel<T, D, SRC>), dim3((unsigned)cdiv(B * pl.n[1], 64)), dim3(64), 0, st, B, n, len0,
+        MF_LANE_LAUNCH((par_tak_up0_kernel<T, D, SRC>), dim3((unsigned)cdiv(B * pl.n[1], 64)), dim3(64), 0, st, B, n, len0,
                            pl.n[1], src, arr[1].G, arr[1].N, TakMeanUp<T>{});
     for (int l = 1; l < pl.levels; ++l) {
         const long P = pl.n[l + 1];
         if (x_path<T>())
-            hipLaunchKernelGGL((par_tak_up_x_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), g_lds, st, B, pl.n[l],
+            MF_LANE_LAUNCH((par_tak_up_x_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), g_lds, st, B, pl.n[l],
                                pl.len[l], P, static_cast<const T*>(arr[l].G), static_cast<const T*>(arr[l].N),
                                arr[l + 1].G, arr[l + 1].N);
         else
-            hipLaunchKernelGGL((par_tak_up_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, B, pl.n[l],
+            MF_LANE_LAUNCH((par_tak_up_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, B, pl.n[l],
                                pl.len[l], P, static_cast<const T*>(arr[l].G), static_cast<const T*>(arr[l].N), arr[l + 1].G,
                                arr[l + 1].N);
     }
     {
         const int l = pl.levels;
-        hipLaunchKernelGGL((par_tak_down_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, pl.n[l], pl.n[l],
+        MF_LANE_LAUNCH((par_tak_down_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, pl.n[l], pl.n[l],
                            1L, static_cast<const T*>(arr[l].G), static_cast<const T*>(arr[l].N),
                            static_cast<const T*>(nullptr), arr[l].Z);
     }
     for (int l = pl.levels - 1; l >= 1; --l) {
         const long P = pl.n[l + 1];
-        hipLaunchKernelGGL((par_tak_down_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, B, pl.n[l],
+        MF_LANE_LAUNCH((par_tak_down_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, B, pl.n[l],
                            pl.len[l], P, static_cast<const T*>(arr[l].G), static_cast<const T*>(arr[l].N),
                            static_cast<const T*>(arr[l + 1].Z), arr[l].Z);
     }
     if (up_only) { *up_only = arr[1].Z; return hipGetLastError() == hipSuccess ? 0 : -1000; }
-    hipLaunchKernelGGL((par_tak_emit_kernel<T, D, SRC>), dim3((unsigned)cdiv(B * pl.n[1], 64)), dim3(64), 0, st, B, n, len0,
+    MF_LANE_LAUNCH((par_tak_emit_kernel<T, D, SRC>), dim3((unsigned)cdiv(B * pl.n[1], 64)), dim3(64), 0, st, B, n, len0,
                        pl.n[1], src, static_cast<const T*>(arr[1].Z), odiag, osub);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
@@ -772,7 +783,7 @@ template <typename T>
 int btd_diag_of_inverse(long B, long n, const T* ldiag, const T* lsub, T* odiag, T* osub, void* ws, size_t ws_bytes,
                         hipStream_t st) {
     if (!lsub || n < 2) {       // block-diagonal factor: nothing to scan
-        hipLaunchKernelGGL((btd_diag_of_inverse_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, ldiag,
+        MF_LANE_LAUNCH((btd_diag_of_inverse_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, ldiag,
                            lsub, odiag, osub);
         return hipGetLastError() == hipSuccess ? 0 : -1000;
     }
@@ -801,7 +812,7 @@ int btd_udl(long B, long n, const T* diag, const T* sub, T* ut, T* chol_d, const
             int chain, void* ws, size_t ws_bytes, int* info, hipStream_t st) {
     const long len0 = sub ? par_len0(B, n) : 0;
     if (len0 == 0 || ws == nullptr || ws_bytes < btd_udl_ws<T>(B, n)) {
-        hipLaunchKernelGGL((btd_udl_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, diag, sub, ut,
+        MF_LANE_LAUNCH((btd_udl_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, diag, sub, ut,
                            chol_d, eta, m_post, chol_dinv, chain, info);
         return hipGetLastError() == hipSuccess ? 0 : -1000;
     }
@@ -877,48 +888,48 @@ int btd_udl(long B, long n, const T* diag, const T* sub, T* ut, T* chol_d, const
         const long P = pl.n[l + 1];
         constexpr int x_lds = LdsSpike<T, D>::BYTES;
         if (x_path<T>())
-            hipLaunchKernelGGL((par_chol_up_x_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), x_lds, st, level(l),
+            MF_LANE_LAUNCH((par_chol_up_x_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), x_lds, st, level(l),
                                B, pl.len[l], P, arr[l + 1].Dv, arr[l + 1].Gf, arr[l + 1].GU, arr[l + 1].F, info);
         else
-            launch_chol_up<T>(level(l), l == 0 ? 1 : 2, B, pl.len[l], P, arr[l + 1].Dv, arr[l + 1].Gf, arr[l + 1].GU,
-                              arr[l + 1].F, info, st);
+            if (const int rc = launch_chol_up<T>(level(l), l == 0 ? 1 : 2, B, pl.len[l], P, arr[l + 1].Dv, arr[l + 1].Gf, arr[l + 1].GU,
+                              arr[l + 1].F, info, st)) return rc;
     }
     {
         const int l = pl.levels;
-        hipLaunchKernelGGL((par_chol_down_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, level(l), B,
+        MF_LANE_LAUNCH((par_chol_down_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, level(l), B,
                            pl.n[l], 1L, static_cast<const T*>(nullptr), arr[l].Pn, info);
     }
     for (int l = pl.levels - 1; l >= 1; --l) {
         const long P = pl.n[l + 1];
-        hipLaunchKernelGGL((par_chol_down_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, level(l), B,
+        MF_LANE_LAUNCH((par_chol_down_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, level(l), B,
                            pl.len[l], P, static_cast<const T*>(arr[l + 1].Pn), arr[l].Pn, info);
     }
     const dim3 g0((unsigned)cdiv(B * pl.n[1], 64));
-    hipLaunchKernelGGL((par_udl_emit_kernel<T, D>), g0, dim3(64), 0, st, B, n, len0, pl.n[1], diag, sub,
+    MF_LANE_LAUNCH((par_udl_emit_kernel<T, D>), g0, dim3(64), 0, st, B, n, len0, pl.n[1], diag, sub,
                        static_cast<const T*>(arr[1].Pn), ut, chol_d, chol_dinv, chain, info);
     if (eta) {
         // x_k = eta_k - U_k x_{k+1}: affine scan over the reversed positions, then the per-block finish
-        hipLaunchKernelGGL((par_post_up0_kernel<T, D>), g0, dim3(64), 0, st, B, n, len0, pl.n[1], static_cast<const T*>(ut),
+        MF_LANE_LAUNCH((par_post_up0_kernel<T, D>), g0, dim3(64), 0, st, B, n, len0, pl.n[1], static_cast<const T*>(ut),
                            eta, arr[1].M, arr[1].c, chain);
         for (int l = 1; l < pl.levels; ++l) {
             const long P = pl.n[l + 1];
-            hipLaunchKernelGGL((par_affine_up_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, B, pl.n[l],
+            MF_LANE_LAUNCH((par_affine_up_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, B, pl.n[l],
                                pl.len[l], P, static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c),
                                arr[l + 1].M, arr[l + 1].c);
         }
         {
             const int l = pl.levels;
-            hipLaunchKernelGGL((par_affine_down_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, pl.n[l],
+            MF_LANE_LAUNCH((par_affine_down_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, pl.n[l],
                                pl.n[l], 1L, static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c),
                                static_cast<const T*>(nullptr), arr[l].Z);
         }
         for (int l = pl.levels - 1; l >= 1; --l) {
             const long P = pl.n[l + 1];
-            hipLaunchKernelGGL((par_affine_down_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, B, pl.n[l],
+            MF_LANE_LAUNCH((par_affine_down_kernel<T, D>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, B, pl.n[l],
                                pl.len[l], P, static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c),
                                static_cast<const T*>(arr[l + 1].Z), arr[l].Z);
         }
-        hipLaunchKernelGGL((par_post_emit_kernel<T, D>), g0, dim3(64), 0, st, B, n, len0, pl.n[1], ut,
+        MF_LANE_LAUNCH((par_post_emit_kernel<T, D>), g0, dim3(64), 0, st, B, n, len0, pl.n[1], ut,
                            static_cast<const T*>(chol_d), eta, static_cast<const T*>(arr[1].Z), m_post, chol_dinv, chain, info);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1000;
@@ -927,11 +938,24 @@ int btd_udl(long B, long n, const T* diag, const T* sub, T* ut, T* chol_d, const
 template <typename T>
 int ssm_precision(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ,
                   const T* H, const T* y, const T* Rinv, int rinv_per_step, T* diag, T* sub, T* eta, hipStream_t st) {
-    if (H && (m < 1 || m > MF_MAXM)) return -3;
+    if (H && (m < 1 || m > MF_MAXM)) return LANE ? -3 : -100;
     KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, 1, nullptr, 0};
+    if constexpr (!LANE) {                         // 10 <= d <= 15: a row per (series, block)
+        const dim3 rgrid((unsigned)cdiv(B * Tn, 4));
+        auto launch = [&](auto mtag) {
+            constexpr int M = decltype(mtag)::value;
+            hipLaunchKernelGGL((row::row_ssm_precision_kernel<T, D, M>), rgrid, dim3(64), 0, st, a, diag, sub, eta);
+        };
+        using std::integral_constant;
+        if (!H || m == 1) launch(integral_constant<int, 1>{});
+        else if (m == 2) launch(integral_constant<int, 2>{});
+        else if (m == 3) launch(integral_constant<int, 3>{});
+        else launch(integral_constant<int, 4>{});
+        return hipGetLastError() == hipSuccess ? 0 : -1000;
+    }
     const dim3 grid((unsigned)cdiv(B * Tn, 256)), block(256);
-    if (m == 1) hipLaunchKernelGGL((ssm_precision_kernel<T, D, 1>), grid, block, 0, st, a, diag, sub, eta);
-    else hipLaunchKernelGGL((ssm_precision_kernel<T, D, 0>), grid, block, 0, st, a, diag, sub, eta);
+    if (m == 1) MF_LANE_LAUNCH((ssm_precision_kernel<T, D, 1>), grid, block, 0, st, a, diag, sub, eta);
+    else MF_LANE_LAUNCH((ssm_precision_kernel<T, D, 0>), grid, block, 0, st, a, diag, sub, eta);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
@@ -944,10 +968,10 @@ int ssm_means(long Bl, long Br, long Tn, const T* A, const T* offs, T* out, void
     if (len0 == 0 || ws == nullptr || ws_bytes < btd_solve_ws<T>(Bl, Br, n)) {
         if (up_only) return -16;
         if ((A && n >= 2) || REV)   // one lane per series: the level-0 emit kernel as ONE chunk (loads a group of steps ahead)
-            hipLaunchKernelGGL((par_means_emit_kernel<T, D, REV>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Bl, Br, n, n, 1L, A,
+            MF_LANE_LAUNCH((par_means_emit_kernel<T, D, REV>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Bl, Br, n, n, 1L, A,
                                offs, static_cast<const T*>(nullptr), out);
         else
-            hipLaunchKernelGGL((ssm_means_kernel<T, D>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Bl, Br, Tn, A, offs,
+            MF_LANE_LAUNCH((ssm_means_kernel<T, D>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Bl, Br, Tn, A, offs,
                                out);
         return hipGetLastError() == hipSuccess ? 0 : -1000;
     }
@@ -968,7 +992,7 @@ int ssm_means(long Bl, long Br, long Tn, const T* A, const T* offs, T* out, void
                 hipLaunchKernelGGL((row::row_means_up0_kernel<T, D, REV>), dim3((unsigned)cdiv(Br * pl.n[1], 4)), dim3(64), 0, st, Bl, Br,
                                    n, len0, pl.n[1], A, offs, arr[1].M, arr[1].c, T(1));
         } else
-        hipLaunchKernelGGL((par_means_up0_kernel<T, D, REV>), dim3((unsigned)cdiv(Br * pl.n[1], 64)), dim3(64), 0, st, Bl, Br, n,
+        MF_LANE_LAUNCH((par_means_up0_kernel<T, D, REV>), dim3((unsigned)cdiv(Br * pl.n[1], 64)), dim3(64), 0, st, Bl, Br, n,
                            len0, pl.n[1], A, offs, arr[1].M, arr[1].c);
     }
     if (row_levels) {
@@ -996,19 +1020,19 @@ int ssm_means(long Bl, long Br, long Tn, const T* A, const T* offs, T* out, void
     } else {
     for (int l = 1; l < pl.levels; ++l) {
         const long P = pl.n[l + 1];
-        hipLaunchKernelGGL((par_affine_up_kernel<T, D>), dim3((unsigned)cdiv(Br * P, 64)), dim3(64), 0, st, Br, pl.n[l],
+        MF_LANE_LAUNCH((par_affine_up_kernel<T, D>), dim3((unsigned)cdiv(Br * P, 64)), dim3(64), 0, st, Br, pl.n[l],
                            pl.len[l], P, static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c), arr[l + 1].M,
                            arr[l + 1].c);
     }
     {
         const int l = pl.levels;
-        hipLaunchKernelGGL((par_affine_down_kernel<T, D>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Br, pl.n[l],
+        MF_LANE_LAUNCH((par_affine_down_kernel<T, D>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Br, pl.n[l],
                            pl.n[l], 1L, static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c),
                            static_cast<const T*>(nullptr), arr[l].Z);
     }
     for (int l = pl.levels - 1; l >= 1; --l) {
         const long P = pl.n[l + 1];
-        hipLaunchKernelGGL((par_affine_down_kernel<T, D>), dim3((unsigned)cdiv(Br * P, 64)), dim3(64), 0, st, Br, pl.n[l],
+        MF_LANE_LAUNCH((par_affine_down_kernel<T, D>), dim3((unsigned)cdiv(Br * P, 64)), dim3(64), 0, st, Br, pl.n[l],
                            pl.len[l], P, static_cast<const T*>(arr[l].M), static_cast<const T*>(arr[l].c),
                            static_cast<const T*>(arr[l + 1].Z), arr[l].Z);
     }
@@ -1020,7 +1044,7 @@ int ssm_means(long Bl, long Br, long Tn, const T* A, const T* offs, T* out, void
                                len0, pl.n[1], A, offs, static_cast<const T*>(arr[1].Z), out, T(1));
         return hipGetLastError() == hipSuccess ? 0 : -1000;
     }
-    hipLaunchKernelGGL((par_means_emit_kernel<T, D, REV>), dim3((unsigned)cdiv(Br * pl.n[1], 64)), dim3(64), 0, st, Bl, Br, n,
+    MF_LANE_LAUNCH((par_means_emit_kernel<T, D, REV>), dim3((unsigned)cdiv(Br * pl.n[1], 64)), dim3(64), 0, st, Bl, Br, n,
                        len0, pl.n[1], A, offs, static_cast<const T*>(arr[1].Z), out);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
@@ -1045,7 +1069,7 @@ int ssm_marginals(long B, long n, const T* mu0, const T* cholP0, const T* A, con
     const TakSrc<T> src{cholQ, A, cholP0};
     const long len0 = par_len0(B, n);
     if (len0 == 0) {
-        hipLaunchKernelGGL((par_tak_emit_kernel<T, D, 1, true>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, n, 1L, src,
+        MF_LANE_LAUNCH((par_tak_emit_kernel<T, D, 1, true>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, n, 1L, src,
                            static_cast<const T*>(nullptr), ocov, osub, TakMean<T>{mu0, b, omean, nullptr});
         return hipGetLastError() == hipSuccess ? 0 : -1000;
     }
@@ -1077,7 +1101,7 @@ int ssm_marginals(long B, long n, const T* mu0, const T* cholP0, const T* A, con
             return hipGetLastError() == hipSuccess ? 0 : -1000;
         }
     }
-    hipLaunchKernelGGL((par_tak_emit_kernel<T, D, 1, true>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, B, n, len0, P, src,
+    MF_LANE_LAUNCH((par_tak_emit_kernel<T, D, 1, true>), dim3((unsigned)cdiv(B * P, 64)), dim3(64), 0, st, B, n, len0, P, src,
                        up_cov, ocov, osub, TakMean<T>{mu0, b, omean, up_mean});
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
@@ -1090,7 +1114,7 @@ int ssm_marginals_entry(long B, long n, const T* mu0, const T* cholP0, const T* 
 
 template <typename T>
 int block_matmul(long B, long n, const T* X, long xs, const T* Y, long ys, T* out, hipStream_t st) {
-    hipLaunchKernelGGL((block_matmul_kernel<T, D>), dim3((unsigned)cdiv(B * n, 256)), dim3(256), 0, st, B, n, X, xs, Y, ys,
+    MF_LANE_LAUNCH((block_matmul_kernel<T, D>), dim3((unsigned)cdiv(B * n, 256)), dim3(256), 0, st, B, n, X, xs, Y, ys,
                        out);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
@@ -1101,8 +1125,8 @@ int block_matmul(long B, long n, const T* X, long xs, const T* Y, long ys, T* ou
 template <typename T, int O0, int O1>
 int gpr_launch(const GprArgs<T>& a, RedSys<T> lvl0, hipStream_t st) {
     const dim3 grid((unsigned)cdiv(a.B * a.P, 64)), block(64);
-    if (a.P > 1) hipLaunchKernelGGL((gpr_chunk_kernel<T, O0, O1, true>), grid, block, 0, st, a, lvl0);
-    else hipLaunchKernelGGL((gpr_chunk_kernel<T, O0, O1, false>), grid, block, 0, st, a, lvl0);
+    if (a.P > 1) MF_LANE_LAUNCH((gpr_chunk_kernel<T, O0, O1, true>), grid, block, 0, st, a, lvl0);
+    else MF_LANE_LAUNCH((gpr_chunk_kernel<T, O0, O1, false>), grid, block, 0, st, a, lvl0);
     return 0;
 }
 template <typename T>
@@ -1138,7 +1162,7 @@ template <typename T>
 int sde_predict(long B, long N, long Np, const long long* idx, const T* Amt, const T* Qmt, const T* Atp, const T* Qtp,
                 const T* means, const T* covs, const T* subseq, const T* m0, const T* P0, T* omean, T* ocov, int* info,
                 hipStream_t st) {
-    hipLaunchKernelGGL((sde_predict_kernel<T, D>), dim3((unsigned)cdiv(B * Np, 64)), dim3(64), 0, st, B, N, Np, idx, Amt, Qmt,
+    MF_LANE_LAUNCH((sde_predict_kernel<T, D>), dim3((unsigned)cdiv(B * Np, 64)), dim3(64), 0, st, B, N, Np, idx, Amt, Qmt,
                        Atp, Qtp, means, covs, subseq, m0, P0, omean, ocov, info);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
@@ -1147,7 +1171,7 @@ template <typename T>
 int kf_grad(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H,
             const T* y, const T* Rinv, const T* pm, const T* pS, const T* pX, T* gmu0, T* gC0, T* gA, T* gb, T* gC, T* gH,
             T* gy, T* gOm, const T* weights, int rinv_per_step, int* info, hipStream_t st) {
-    if (m < 1 || m > MF_MAXM) return -3;
+    if (m < 1 || m > MF_MAXM) return LANE ? -3 : -100;
     KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, 1, info, 0, weights};
     const dim3 grid((unsigned)cdiv(B * Tn, 64)), block(64);
     // from d = 7 on (where the lane-per-point kernel spills) a 16-lane row per (series, time point): mf_row_grad.hpp
@@ -1168,8 +1192,8 @@ int kf_grad(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, c
             return hipGetLastError() == hipSuccess ? 0 : -1000;
         }
     }
-    if (m == 1) hipLaunchKernelGGL((kf_grad_kernel<T, D, 1>), grid, block, 0, st, a, pm, pS, pX, gmu0, gC0, gA, gb, gC, gH, gy, gOm);
-    else hipLaunchKernelGGL((kf_grad_kernel<T, D, 0>), grid, block, 0, st, a, pm, pS, pX, gmu0, gC0, gA, gb, gC, gH, gy, gOm);
+    if (m == 1) MF_LANE_LAUNCH((kf_grad_kernel<T, D, 1>), grid, block, 0, st, a, pm, pS, pX, gmu0, gC0, gA, gb, gC, gH, gy, gOm);
+    else MF_LANE_LAUNCH((kf_grad_kernel<T, D, 0>), grid, block, 0, st, a, pm, pS, pX, gmu0, gC0, gA, gb, gC, gH, gy, gOm);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
@@ -1196,7 +1220,7 @@ template <typename T> AdjointWs<T, D> carve_adjoint(void* ws, long B, long Tn) {
 template <typename T>
 int adjoint_scan(long B, long Tn, const T* A, const AdjointWs<T, D>& w, void* ws, hipStream_t st) {
     if (par_len0(B, Tn) == 0 || Tn < 2) {
-        hipLaunchKernelGGL((ssm_adjoint_scan_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, Tn, A,
+        MF_LANE_LAUNCH((ssm_adjoint_scan_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, Tn, A,
                            static_cast<const T*>(nullptr), static_cast<const T*>(nullptr), 1, w);
         return hipGetLastError() == hipSuccess ? 0 : -1000;
     }
@@ -1220,14 +1244,14 @@ int kl_grad(long B, long Tn, const T* mu0_1, const T* C0_1, const T* A_1, const 
         w.N = const_cast<T*>(in_N);
         w.n = const_cast<T*>(in_n);
     } else {
-        hipLaunchKernelGGL((ssm_kl_adjoint_inputs_kernel<T, D>), per_step, block, 0, st, B, Tn, A_1, b_1, A_2, b_2, C_2, pm, w, info);
+        MF_LANE_LAUNCH((ssm_kl_adjoint_inputs_kernel<T, D>), per_step, block, 0, st, B, Tn, A_1, b_1, A_2, b_2, C_2, pm, w, info);
     }
     if (int rc = adjoint_scan<T>(B, Tn, A_1, w, ws, st)) return rc;
     AdjointLocalArgs<T, D> a{B, Tn, mu0_1, C0_1, A_1, b_1, C_1, mu0_2, C0_2, A_2, b_2, C_2, pm, pS, weights, gmu0, gC0, gA, gb, gC, info};
     if constexpr (D >= 7 && D + 1 <= 16)
         hipLaunchKernelGGL((row::row_adjoint_local_kernel<T, D, true>), dim3((unsigned)cdiv(B * Tn, 4)), block, 0, st, a, w);
     else
-        hipLaunchKernelGGL((ssm_adjoint_local_kernel<T, D, true>), per_step, block, 0, st, a, w);
+        MF_LANE_LAUNCH((ssm_adjoint_local_kernel<T, D, true>), per_step, block, 0, st, a, w);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
@@ -1235,11 +1259,11 @@ template <typename T>
 int posterior_chain(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H,
                     const T* y, const T* Rinv, int rinv_per_step, T* a_post, T* mu0_post, T* b_post, T* cp0_post, T* cq_post,
                     int* info, hipStream_t st) {
-    if (m < 1 || m > MF_MAXM) return -4;
+    if (m < 1 || m > MF_MAXM) return LANE ? -4 : -100;       // (row-only build: more outputs belong to the tile engine)
     KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, 1, info, 0};
     const dim3 grid((unsigned)cdiv(B, 64)), block(64);
-    if (m == 1) hipLaunchKernelGGL((kf_posterior_chain_kernel<T, D, 1>), grid, block, 0, st, a, a_post, mu0_post, b_post, cp0_post, cq_post);
-    else hipLaunchKernelGGL((kf_posterior_chain_kernel<T, D, 0>), grid, block, 0, st, a, a_post, mu0_post, b_post, cp0_post, cq_post);
+    if (m == 1) MF_LANE_LAUNCH((kf_posterior_chain_kernel<T, D, 1>), grid, block, 0, st, a, a_post, mu0_post, b_post, cp0_post, cq_post);
+    else MF_LANE_LAUNCH((kf_posterior_chain_kernel<T, D, 0>), grid, block, 0, st, a, a_post, mu0_post, b_post, cp0_post, cq_post);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
@@ -1290,7 +1314,7 @@ int kl_value(long B, long Tn, const T* mu0_1, const T* C0_1, const T* A_1, const
                                    C0_1, A_1, b_1, C_1, mu0_2, C0_2, A_2, b_2, C_2, static_cast<const T*>(pm),
                                    static_cast<const T*>(pS), part, out_N, out_n, info);
         } else
-        hipLaunchKernelGGL((ssm_kl_local_kernel<T, D>), dim3((unsigned)cdiv(B * Tn, 64)), dim3(64), 0, st, B, Tn, mu0_1, C0_1,
+        MF_LANE_LAUNCH((ssm_kl_local_kernel<T, D>), dim3((unsigned)cdiv(B * Tn, 64)), dim3(64), 0, st, B, Tn, mu0_1, C0_1,
                            A_1, b_1, C_1, mu0_2, C0_2, A_2, b_2, C_2, static_cast<const T*>(pm), static_cast<const T*>(pS),
                            part, out_N, out_n, info);
         hipLaunchKernelGGL((row_sum_kernel<T>), dim3((unsigned)B), dim3(64), 0, st, Tn, static_cast<const T*>(part), out);
@@ -1298,7 +1322,7 @@ int kl_value(long B, long Tn, const T* mu0_1, const T* C0_1, const T* A_1, const
     }
     if ((out_means != nullptr) != (out_covs != nullptr) || (out_cross && !out_means)) return -15;
     if (Tn < 2 && out_cross) out_cross = nullptr;
-    hipLaunchKernelGGL((ssm_kl_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, Tn, mu0_1, C0_1, A_1, b_1, C_1,
+    MF_LANE_LAUNCH((ssm_kl_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, Tn, mu0_1, C0_1, A_1, b_1, C_1,
                        mu0_2, C0_2, A_2, b_2, C_2, out, out_N, out_n, out_means, out_covs, out_cross, info);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
@@ -1310,13 +1334,13 @@ int marginals_grad(long B, long Tn, const T* C0, const T* A, const T* C, const T
     const AdjointWs<T, D> w = carve_adjoint<T>(ws, B, Tn);
     const dim3 per_step((unsigned)cdiv(B * Tn, 64)), per_series((unsigned)cdiv(B, 64)), block(64);
     if (par_len0(B, Tn) == 0 || Tn < 2) {
-        hipLaunchKernelGGL((ssm_adjoint_scan_kernel<T, D>), per_series, block, 0, st, B, Tn, A, gm, gS, 0, w);
+        MF_LANE_LAUNCH((ssm_adjoint_scan_kernel<T, D>), per_series, block, 0, st, B, Tn, A, gm, gS, 0, w);
     } else {
         if constexpr (D >= 2 && D + 1 <= 16)
             hipLaunchKernelGGL((row::row_adjoint_sym_inputs_kernel<T, D>), dim3((unsigned)cdiv(B * Tn, 4)), block, 0, st, B * Tn, gm, gS,
                                w.N, w.n);
         else
-            hipLaunchKernelGGL((ssm_adjoint_sym_inputs_kernel<T, D>), per_step, block, 0, st, B * Tn, gm, gS, w);
+            MF_LANE_LAUNCH((ssm_adjoint_sym_inputs_kernel<T, D>), per_step, block, 0, st, B * Tn, gm, gS, w);
         if (int rc = adjoint_scan<T>(B, Tn, A, w, ws, st)) return rc;
     }
     AdjointLocalArgs<T, D> a{B, Tn, nullptr, C0, A, nullptr, C, nullptr, nullptr, nullptr, nullptr, nullptr, pm, pS, nullptr,
@@ -1324,7 +1348,7 @@ int marginals_grad(long B, long Tn, const T* C0, const T* A, const T* C, const T
     if constexpr (D >= 7 && D + 1 <= 16)
         hipLaunchKernelGGL((row::row_adjoint_local_kernel<T, D, false>), dim3((unsigned)cdiv(B * Tn, 4)), block, 0, st, a, w);
     else
-        hipLaunchKernelGGL((ssm_adjoint_local_kernel<T, D, false>), per_step, block, 0, st, a, w);
+        MF_LANE_LAUNCH((ssm_adjoint_local_kernel<T, D, false>), per_step, block, 0, st, a, w);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 

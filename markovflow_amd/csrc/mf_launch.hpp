@@ -68,7 +68,8 @@ template <typename T> struct OpsTable {
     size_t (*marginals_ws)(long B, long n);
 };
 
-constexpr int MF_MAX_D = 9;        // largest state dimension with a register-resident instantiation
+constexpr int MF_MAX_D = 9;        // largest state dimension with a register-resident (lane per chunk) instantiation
+constexpr int MF_MAX_D_ROW = 15;   // largest state dimension of the row kernels (one 16-lane row per chunk; 10 ... 15: only those)
 constexpr int MF_MAX_D_BIG = 64;      // largest state dimension of the LDS-tiled MFMA path, fp32 (log-likelihood only)
 constexpr int MF_MAX_D_BIG_F64 = 32;  // the same in fp64 (seven d x d tiles must fit the 160 KB of LDS)
 
@@ -115,26 +116,12 @@ MF_DECLARE_BIG(f32, float)
 MF_DECLARE_BIG(f64, double)
 #undef MF_DECLARE_BIG
 
-// the row kernels' log-likelihood for 10 <= d <= 15 (mf_rowwide_inst.hip)
-template <typename T> struct RowWideTable {
-    bool (*usable)(long B, long Tn, int m, long chunks);
-    size_t (*kf_loglik_ws)(long B, long Tn, long chunks);
-    int (*kf_loglik)(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H,
-                     const T* y, const T* Rinv, int rinv_per_step, T add_const, T* out, void* ws, size_t ws_bytes, int* info,
-                     long chunks, hipEvent_t ev0, hipEvent_t ev1, hipStream_t st);
-};
-#define MF_DECLARE_ROWWIDE(D)                              \
-    const RowWideTable<float>* rowwide_f32_d##D();         \
-    const RowWideTable<double>* rowwide_f64_d##D();
-MF_DECLARE_ROWWIDE(10) MF_DECLARE_ROWWIDE(11) MF_DECLARE_ROWWIDE(12) MF_DECLARE_ROWWIDE(13) MF_DECLARE_ROWWIDE(14) MF_DECLARE_ROWWIDE(15)
-#undef MF_DECLARE_ROWWIDE
-constexpr int MF_ROWWIDE_MIN = 10, MF_ROWWIDE_MAX = 15;
-
 #define MF_DECLARE_TABLES(D)                          \
     const OpsTable<float>* ops_f32_d##D();            \
     const OpsTable<double>* ops_f64_d##D();
 MF_DECLARE_TABLES(1) MF_DECLARE_TABLES(2) MF_DECLARE_TABLES(3) MF_DECLARE_TABLES(4) MF_DECLARE_TABLES(5)
 MF_DECLARE_TABLES(6) MF_DECLARE_TABLES(7) MF_DECLARE_TABLES(8) MF_DECLARE_TABLES(9)
+MF_DECLARE_TABLES(10) MF_DECLARE_TABLES(11) MF_DECLARE_TABLES(12) MF_DECLARE_TABLES(13) MF_DECLARE_TABLES(14) MF_DECLARE_TABLES(15)
 #undef MF_DECLARE_TABLES
 
 }  // namespace mf

@@ -16,7 +16,12 @@ namespace row {
 
 // wavefronts per SIMD the kernels below are compiled for: 128 registers (4 waves) hold the state up to 7 doubles per row
 // (PF: two sets of step data are live, one step of prefetch - chosen by the launcher when the rows are too few to hide a load)
-constexpr int row_par_waves(int elem, int d, bool pf) { return elem * d > 56 ? (pf ? 2 : 3) : 4; }
+// From d = 10 on (mf_inst.hip compiled with the row kernels only) the unrolled step itself needs more: fp32 three (two with
+// prefetch), fp64 two up to d = 12 without prefetch, else one (512 registers with the AGPRs).
+constexpr int row_par_waves(int elem, int d, bool pf) {
+    if (d >= 10) return elem == 4 ? (pf ? 2 : 3) : (d <= 12 && !pf ? 2 : 1);
+    return elem * d > 56 ? (pf ? 2 : 3) : 4;
+}
 
 // chunk (series s, chunk c) of the row this lane belongs to; rows past the end repeat the last chunk and store nothing
 struct RowChunkId {

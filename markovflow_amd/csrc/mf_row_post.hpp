@@ -13,6 +13,88 @@ namespace row {
 // n-1-p) and restarts  Delta_k = D_k - S_k^T Delta_{k+1}^-1 S_k  from the pivot at position c len - 1 (`up`).  Writes U_k^T =
 // Delta_{k+1}^-1 S_k (chain: -U_k^T, the posterior transition), chol(Delta_k) (optional) and - chain - chol(Delta_k^-1) at its
 // place in the chain (block 0 of all series first, then [B, n-1]).
+// Posterior precision + information vector, a row per (series, block k) - used for d >= 10 only: up to d = 9 the lane-per-block
+// ssm_precision_kernel is as fast (552 against 544 us at config 4's shape), beyond it that kernel does not exist:
+//   diag_k = Q_k^-1 + A_{k+1}^T Q_{k+1}^-1 A_{k+1} (+ H^T R^-1 H),  sub_k = -Q_{k+1}^-1 A_{k+1},
+//   eta_k  = Q_k^-1 m_k - A_{k+1}^T Q_{k+1}^-1 m_{k+1} (+ H^T R^-1 y)          (state_space_model.py:431-483, kalman_filter.py:86-101,153-156)
+// H == null: the prior precision; eta == null: precision only; y == null: no observation term in eta.
+template <typename T, int D, int M>
+__global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, false)) row_ssm_precision_kernel(KfArgs<T> a, T* __restrict__ diag,
+                                                                                                  T* __restrict__ sub, T* __restrict__ eta) {
+    using P = Dpp<T>;
+    const int lane = threadIdx.x, r = lane & 15, rc = r < D ? r : D - 1;
+    const long total = a.B * a.Tn;
+    const long id_raw = (long)blockIdx.x * 4 + (lane >> 4);
+    const bool valid = id_raw < total;
+    const long id = valid ? id_raw : total - 1;
+    long s, k;
+    if (total < (1L << 31)) { const unsigned su = (unsigned)id / (unsigned)a.Tn; s = su; k = (long)((unsigned)id - su * (unsigned)a.Tn); }
+    else { s = id / a.Tn; k = id % a.Tn; }
+    const bool st = valid && r < D;
+    const long nt = a.Tn - 1;
+    // own part: Q_k^-1 (k = 0: P0^-1) and Q_k^-1 m_k
+    T Dn[D], e = T(0);
+    {
+        T C[D], CiT[D];
+        const T* cblk = k == 0 ? a.cholP0 + s * D * D : a.cholQ + (s * nt + k - 1) * D * D;
+        load_row_lower<T, D>(cblk, rc, C);
+        row_qinv<T, D>(C, t_rcp<T>(cblk[rc * (D + 1)]), r, CiT, Dn);
+        if (eta) {
+            T mv = k == 0 ? a.mu0[s * D + rc] : a.b[(s * nt + k - 1) * D + rc];
+            fence1(mv);
+            sfor<D>([&](auto l) { P::template fmac<decltype(l)::value>(e, mv, Dn[decltype(l)::value]); });
+        }
+    }
+    // the transition out of block k (absent at the last block: whole rows take or skip the branch)
+    if (k + 1 < a.Tn) {
+        asm volatile("s_nop 4");
+        const long tid = s * nt + k;
+        T C2[D], CiT2[D], Qi2[D], Ar[D], At[D], J[D];
+        load_row_lower<T, D>(a.cholQ + tid * D * D, rc, C2);
+        row_qinv<T, D>(C2, t_rcp<T>(a.cholQ[tid * D * D + rc * (D + 1)]), r, CiT2, Qi2);
+        load_row<T, D>(a.A + tid * D * D, rc, Ar);
+        load_col<T, D>(a.A + tid * D * D, rc, At);                     // own row of A^T
+        sfor<D>([&](auto j) { J[decltype(j)::value] = T(0); });
+        fence(Ar);
+        row_mul<T, D, D>(Qi2, Ar, J);                                 // Q^-1 A
+        if (st) sfor<D>([&](auto j) { sub[tid * D * D + r * D + decltype(j)::value] = -J[decltype(j)::value]; });
+        fence(J);
+        row_mul<T, D, D>(At, J, Dn);                                  // + A^T Q^-1 A
+        if (eta) {
+            T m2 = a.b[tid * D + rc], v = T(0);
+            fence1(m2);
+            sfor<D>([&](auto l) { P::template fmac<decltype(l)::value>(v, m2, Qi2[decltype(l)::value]); });      // Q^-1 m'
+            fence1(v);
+            sfor<D>([&](auto l) { P::template fnmac<decltype(l)::value>(e, v, At[decltype(l)::value]); });       // - A^T Q^-1 m'
+        }
+    }
+    if (a.H) {
+        asm volatile("s_nop 4");
+        const T* __restrict__ Rv = a.Rinv + (a.rinv_per_step ? id * M * M : 0);
+        T h[M], RH[M];
+        sfor<M>([&](auto o) { h[decltype(o)::value] = a.H[(id * M + decltype(o)::value) * D + rc]; });
+        sfor<M>([&](auto o) {
+            constexpr int oo = decltype(o)::value;
+            T acc = T(0), ry = T(0);
+            sfor<M>([&](auto p) {
+                acc = __builtin_fma(Rv[oo * M + decltype(p)::value], h[decltype(p)::value], acc);
+                if (eta && a.y) ry = __builtin_fma(Rv[oo * M + decltype(p)::value], a.y[id * M + decltype(p)::value], ry);
+            });
+            RH[oo] = acc;                                             // (R^-1 H)[o][r]
+            e = __builtin_fma(h[oo], ry, e);                          // + H^T R^-1 y
+        });
+        fence(RH);
+        sfor<M>([&](auto o) {
+            constexpr int oo = decltype(o)::value;
+            sfor<D>([&](auto j) { P::template fmac<decltype(j)::value>(Dn[decltype(j)::value], RH[oo], h[oo]); });
+        });
+    }
+    if (st) {
+        sfor<D>([&](auto j) { diag[id * D * D + r * D + decltype(j)::value] = Dn[decltype(j)::value]; });
+        if (eta) eta[id * D + r] = e;
+    }
+}
+
 template <typename T, int D>
 __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, false)) row_udl_emit_kernel(long B, long n, long len, long P,
                                                                                              const T* __restrict__ diag, const T* __restrict__ sub,

@@ -229,7 +229,8 @@ class BaseKalmanFilter(abc.ABC):
         # posterior precision and  GᵀΣ⁻¹y + K⁻¹μ  (kalman_filter.py:149-156) in one parallel kernel
         diag, sub, eta = self.prior_ssm._precision_and_eta(h, y, r_inv, per_step, want_eta=True)
         # backward UDUᵀ sweep, m_post and chol(Δ⁻¹) fused (kalman_filter.py:159-174)
-        if self.prior_ssm.state_dim <= _lib.load().mf_max_state_dim():
+        if _lib.small_state_dim(self.prior_ssm.state_dim, int(math.prod(self.prior_ssm.batch_shape)),
+                                self.prior_ssm.num_transitions + 1, diag.element_size()):
             # written by the kernels in the layout of the chain: transitions -Uᵀ, (mu0', b'), (cholP0', cholQ') - no slices,
             # copies or sign flips over the [B, T, d, d] tensors afterwards
             a_post, _, (mu0, offsets), (chol_p0, chol_q) = SymmetricBlockTriDiagonal(diag, sub)._udl(eta, chain=True)

@@ -348,7 +348,7 @@ class StateSpaceModel(GaussMarkovDistribution):
         Other distributions and state dimensions beyond the register kernels take the reference's operator route."""
         bsz = int(math.prod(self.batch_shape))
         n, d = self.num_transitions + 1, self.state_dim
-        if isinstance(dist, StateSpaceModel) and d <= _lib.load().mf_max_state_dim() and bsz > 0:
+        if isinstance(dist, StateSpaceModel) and bsz > 0 and _lib.small_state_dim(d, bsz, n, self._A_s.element_size()):
             dtype, dev = self._A_s.dtype, self._A_s.device
             out = torch.empty(bsz, dtype=dtype, device=dev)
             ws_bytes = int(_lib.load().mf_ssm_kl_workspace_bytes(bsz, n, d, out.element_size()))

@@ -45,10 +45,13 @@ def uses_parallel_path(bsz, n, d, esz=8):
 
 # lengths chosen to hit: one reduced level (64), ragged last chunks (777, 4099), several levels (4099, 20000)
 @pytest.mark.parametrize("d,n,batch", [(1, 64, ()), (2, 777, (3,)), (3, 100, (2,)), (4, 4099, ()), (6, 1000, (1,)),
-                                       (6, 20000, ()), (9, 513, (2, 1)), (5, 65, (1,))])
+                                       (6, 20000, ()), (9, 513, (2, 1)), (5, 65, (1,)),
+                                       # 10 <= d <= 15: compiled with the row kernels only (one 16-lane row per chunk)
+                                       (10, 300, (2,)), (12, 777, ()), (13, 1000, (1,)), (15, 200, (2,))])
 def test_parallel_cholesky_and_solve_fp64(rng, d, n, batch):
     bsz = int(np.prod(batch)) if batch else 1
     assert uses_parallel_path(bsz, n, d), "this shape is meant to take the parallel-in-time path"
+    assert _lib.load().mf_row_operators_cover(bsz, n, d, 8) == 1
     ldiag, lsub, diag, sub = factor_and_matrix(rng, batch, n, d)
     chol = mfa.SymmetricBlockTriDiagonal(tt(diag), tt(sub)).cholesky
     np.testing.assert_allclose(nn(chol.block_diagonal), ldiag, rtol=1e-8, atol=1e-10)
@@ -133,7 +136,8 @@ def test_config3_full_size_fp32_recombination_and_round_trip(rng):
 
 
 # ---- parallel-in-time Takahashi (block_diagonal_of_inverse) and marginal means --------------------------------------------------
-@pytest.mark.parametrize("d,n,batch", [(1, 64, ()), (3, 100, (2,)), (2, 777, (3,)), (6, 1000, (1,)), (9, 513, (2, 1))])
+@pytest.mark.parametrize("d,n,batch", [(1, 64, ()), (3, 100, (2,)), (2, 777, (3,)), (6, 1000, (1,)), (9, 513, (2, 1)),
+                                       (11, 200, (2,)), (15, 130, ())])
 def test_parallel_block_diagonal_of_inverse_vs_oracle(rng, d, n, batch):
     bsz = int(np.prod(batch)) if batch else 1
     assert _lib.load().mf_btd_diag_of_inverse_workspace_bytes(bsz, n, d, 8) > 0
@@ -161,7 +165,7 @@ def test_parallel_block_diagonal_of_inverse_long_chain_identity(rng):
     np.testing.assert_allclose(nn(row), nn(eye), rtol=0, atol=1e-8)
 
 
-@pytest.mark.parametrize("d,n,batch", [(2, 64, ()), (6, 1000, (2,)), (4, 4099, ()), (9, 300, (3,))])
+@pytest.mark.parametrize("d,n,batch", [(2, 64, ()), (6, 1000, (2,)), (4, 4099, ()), (9, 300, (3,)), (12, 300, (2,)), (15, 100, ())])
 def test_parallel_marginal_means_and_sample_propagation(rng, d, n, batch):
     a = 0.9 * np.eye(d) + 0.1 * rng.normal(size=batch + (n - 1, d, d)) / np.sqrt(d)
     mu0, b = rng.normal(size=batch + (d,)), rng.normal(size=batch + (n - 1, d))
@@ -176,7 +180,8 @@ def test_parallel_marginal_means_and_sample_propagation(rng, d, n, batch):
 
 
 # ---- parallel-in-time U D U^T and posterior chain ----------------------------------------------------------------------------------
-@pytest.mark.parametrize("d,n,batch", [(1, 64, ()), (3, 100, (2,)), (2, 777, (3,)), (6, 1000, (1,)), (9, 300, (2, 1))])
+@pytest.mark.parametrize("d,n,batch", [(1, 64, ()), (3, 100, (2,)), (2, 777, (3,)), (6, 1000, (1,)), (9, 300, (2, 1)),
+                                       (10, 100, (2,)), (14, 300, ()), (15, 777, (1,))])
 def test_parallel_upper_diagonal_lower_vs_oracle(rng, d, n, batch):
     bsz = int(np.prod(batch)) if batch else 1
     assert _lib.load().mf_btd_udl_workspace_bytes(bsz, n, d, 8) > 0
@@ -202,7 +207,7 @@ def test_parallel_udl_long_chain_recombines(rng):
     np.testing.assert_allclose(nn(rec_diag), diag, rtol=1e-9, atol=1e-10)
 
 
-@pytest.mark.parametrize("d,m,n", [(2, 1, 300), (6, 1, 500), (4, 2, 129)])
+@pytest.mark.parametrize("d,m,n", [(2, 1, 300), (6, 1, 500), (4, 2, 129), (10, 1, 200), (12, 3, 300), (15, 4, 129)])
 def test_parallel_posterior_state_space_model_vs_oracle(rng, d, m, n):
     """KalmanFilter.posterior_state_space_model (kalman_filter.py:109-182) on the parallel-in-time path (few series)."""
     from test_gpu_kalman import build_kf, random_ssm
@@ -220,10 +225,14 @@ def test_parallel_posterior_state_space_model_vs_oracle(rng, d, m, n):
     np.testing.assert_allclose(nn(post.marginal_means), means, rtol=1e-7, atol=1e-9)
     covs = O.ssm_marginal_covariances(want[1], want[2], want[4])
     np.testing.assert_allclose(nn(post.marginal_covariances), covs, rtol=1e-6, atol=1e-9)
+    # KL(posterior || prior) from its local form (state_space_model.py:528-593), every series
+    kl = O.ssm_kl_divergence(want, (kw["mu0"], kw["chol_p0"], kw["a_s"], kw["b_s"], kw["chol_q"]))
+    np.testing.assert_allclose(nn(post.kl_divergence(kf.prior_ssm)), kl, rtol=1e-7)
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
-@pytest.mark.parametrize("d,n,batch", [(1, 2, ()), (3, 9, (2,)), (6, 64, (3,)), (2, 777, (2, 1)), (6, 1000, (1,)), (9, 300, (2,)), (7, 130, ())])
+@pytest.mark.parametrize("d,n,batch", [(1, 2, ()), (3, 9, (2,)), (6, 64, (3,)), (2, 777, (2, 1)), (6, 1000, (1,)), (9, 300, (2,)), (7, 130, ()),
+                                       (12, 300, (2,)), (15, 130, ())])
 def test_covariance_scan_equals_the_reference_route(rng, dtype, d, n, batch):
     """marginal / subsequent covariances by the forward recursion (mf_ssm_marginal_covariances) against the reference's route:
     assembled precision -> Cholesky -> block diagonal of the inverse, and A_k Sigma_k (state_space_model.py:254-275,326-341)."""
