@@ -80,7 +80,10 @@ def test_large_d_local_gradient_kernel_vs_closed_forms(rng, dtype, d, m, t, bsz)
 @pytest.mark.parametrize("d,m,t,bsz", [(2, 1, 6, 3), (3, 2, 5, 2), (6, 1, 9, 2), (4, 3, 4, 1),
                                        # beyond the register-resident local kernel (VERDICT r02 missing 4): smoothed moments from the
                                        # LDS-tile / MFMA kernels, local closed forms as batched products (kalman_filter._local_gradients_dense)
-                                       (12, 2, 6, 2), (17, 5, 5, 1), (32, 6, 4, 2)])
+                                       (12, 2, 6, 2), (17, 5, 5, 1), (32, 6, 4, 2),
+                                       # 10 <= d <= 15 on chains long enough for the time partition: posterior chain, moments and the
+                                       # local step all in row form (csrc/mf_row_*.hpp compiled for these d)
+                                       (12, 3, 70, 1), (15, 4, 66, 2), (10, 1, 130, 1)])
 def test_tensor_gradients_vs_dense_autograd(rng, d, m, t, bsz):
     kw = random_ssm(rng, (bsz,), t, d, m, well=True)
     chol_r = np.linalg.cholesky(0.4 * np.eye(m) + 0.1 * np.ones((m, m)))
