@@ -448,9 +448,12 @@ def _dense_kl(q1, q2):
 
 
 def _dense_route(mu0, a_s) -> bool:
-    """The backward by re-evaluation: state dimensions above the adjoint kernels', and the degenerate shapes they do not take
+    """The backward by re-evaluation: state dimensions (and, for 10 <= d <= 15, shapes) above the adjoint kernels', and the degenerate shapes they do not take
     (an empty local shard of a sharded batch, a chain without transitions)."""
-    return mu0.shape[-1] > _lib.load().mf_max_state_dim() or mu0.shape[0] == 0 or a_s.shape[1] == 0
+    if mu0.shape[0] == 0 or a_s.shape[1] == 0:
+        return True
+    # (10 <= d <= 15 take the HIP adjoint sweeps where the row kernels run the operators: few series, long chains)
+    return not _lib.small_state_dim(mu0.shape[-1], mu0.shape[0], a_s.shape[1] + 1, mu0.element_size())
 
 
 def _dense_backward(fn, tensors, grad_outputs):

@@ -348,7 +348,9 @@ CHAIN = ["mu0", "chol_p0", "a_s", "b_s", "chol_q"]
 # chains of >= 64 blocks with few series take the scans in time for the adjoint sweep (d >= 7: the LDS variant of the scan)
 @pytest.mark.parametrize("d,t,bsz", [(1, 2, 2), (2, 6, 3), (3, 40, 2), (6, 70, 2), (9, 33, 1), (8, 90, 1), (5, 203, 3), (1, 64, 2),
                                      # d > 9: values from the large-d kernels, backward by the scan in batched products
-                                     (12, 9, 2), (20, 5, 1)])
+                                     (12, 9, 2), (20, 5, 1),
+                                     # 10 <= d <= 15, long chains: the adjoint sweeps and the local step in row form
+                                     (12, 80, 2), (15, 70, 1), (10, 130, 1)])
 def test_kl_divergence_gradients_vs_dense_autograd(rng, d, t, bsz):
     """d KL(q1 || q2) / d (every parameter of q1 AND q2) against autograd through the dense Gaussian KL (the reference
     differentiates state_space_model.py:528-593 through TensorFlow)."""
@@ -376,7 +378,8 @@ def test_kl_gradient_vanishes_at_equal_chains(rng):
         assert float(g1[k].grad.abs().max()) < 1e-9 and float(g2[k].grad.abs().max()) < 1e-9, k
 
 
-@pytest.mark.parametrize("d,t,bsz", [(2, 5, 2), (4, 80, 2), (9, 20, 1), (9, 70, 1), (7, 131, 2), (1, 300, 1), (12, 33, 2), (24, 9, 1)])
+@pytest.mark.parametrize("d,t,bsz", [(2, 5, 2), (4, 80, 2), (9, 20, 1), (9, 70, 1), (7, 131, 2), (1, 300, 1), (12, 33, 2), (24, 9, 1),
+                                     (12, 100, 2), (15, 70, 1)])
 def test_marginals_gradients_vs_recursion_autograd(rng, d, t, bsz):
     """A random linear functional of the marginal means and covariances, differentiated through `marginals`."""
     kw = random_ssm(rng, (bsz,), t, d, 1, well=True)
