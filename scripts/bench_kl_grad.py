@@ -12,7 +12,7 @@ def timeit(fn, iters=5):
     for _ in range(iters): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / iters * 1e3
 
-SHAPES = [(16384, 500, (5, 5), 1), (512, 1000, (5, 5, 5), 3)]
+SHAPES = [(16384, 500, (5, 5), 1), (512, 1000, (5, 5, 5), 3), (512, 1000, (5, 5, 5, 5), 4), (512, 1000, (5, 5, 5, 5, 5), 1)]
 if len(sys.argv) > 1:          # python3 scripts/bench_kl_grad.py 0   -> the first shape only (for rocprofv3)
     SHAPES = [SHAPES[int(sys.argv[1])]]
 for (b, t, comp, m) in SHAPES:
