@@ -39,7 +39,9 @@ int kf_loglik(int64_t B, int64_t Tn, int d, int m, const T* mu0, const T* cholP0
     // experiment knob: state dimensions >= MF_BIG_FROM take the LDS-tile / MFMA path even where a register-resident
     // instantiation exists
     static const int big_from = [] { const char* e = mf::mf_knob("MF_BIG_FROM"); return e ? std::atoi(e) : 1000; }();
-    const bool big = (d > mf::MF_MAX_D || d >= big_from) && d <= (sizeof(T) == 4 ? mf::MF_MAX_D_BIG : mf::MF_MAX_D_BIG_F64);
+    // (more than four outputs: the tile engine at ANY state dimension - its tiles pad d to 16 - so that the observation
+    // dimension is not capped at the register kernels' four)
+    const bool big = (d > mf::MF_MAX_D || d >= big_from || m > 4) && d <= (sizeof(T) == 4 ? mf::MF_MAX_D_BIG : mf::MF_MAX_D_BIG_F64);
     if (!t && !big) return -100;
     if (m < 1 || m > (big ? 32 : 4)) return -4;
     if (B == 0) return 0;
@@ -50,7 +52,7 @@ int kf_loglik(int64_t B, int64_t Tn, int d, int m, const T* mu0, const T* cholP0
     if (!y) return -11;
     if (!Rinv) return -12;
     if (!out) return -15;
-    if (t && d < big_from) {
+    if (t && d < big_from && m <= 4) {
         // d <= 9: every plan has a kernel.  10 <= d <= 15: the row kernels when the plan is theirs (at most four outputs, offsets
         // within a buffer descriptor), else -100 and the tile engine below takes the call
         const int rc = t->kf_loglik(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, add_const, out, ws, ws_bytes,
@@ -124,12 +126,12 @@ size_t mf_kf_loglik_workspace_bytes(int64_t B, int64_t T, int d, int elem_size, 
     if (elem_size == 4) {
         const auto* t = table_for<float>(d);
         const size_t small = t ? t->kf_loglik_ws(B, T, chunks) : 0;
-        size_t large = (d > mf::MF_MAX_D && d <= mf::MF_MAX_D_BIG) ? mf::big_kf_loglik_ws(B, T, d, chunks, 4) : 0;
+        size_t large = (d <= mf::MF_MAX_D_BIG) ? mf::big_kf_loglik_ws(B, T, d, chunks, 4) : 0;   // (d <= 9 too: more than four outputs)
         return small > large ? small : large;
     }
     const auto* t = table_for<double>(d);
     const size_t small = t ? t->kf_loglik_ws(B, T, chunks) : 0;
-    size_t large = (d > mf::MF_MAX_D && d <= mf::MF_MAX_D_BIG_F64) ? mf::big_kf_loglik_ws(B, T, d, chunks, 8) : 0;
+    size_t large = (d <= mf::MF_MAX_D_BIG_F64) ? mf::big_kf_loglik_ws(B, T, d, chunks, 8) : 0;
     return small > large ? small : large;
 }
 int mf_row_operators_cover(int64_t B, int64_t T, int d, int elem_size) {
@@ -294,9 +296,12 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (!cholP0) return -6;                                                                                        \
         if (Tn > 1 && (!A || !cholQ || !sub)) return -7;                                                               \
         if (H && !Rinv) return -12;                                                                                    \
-        if (H && (m < 1 || m > (big ? 32 : 4))) return -4;                                                             \
+        if (H && (m < 1 || m > 32)) return -4;                                                                         \
         if (!diag) return -14;                                                                                         \
         if (eta && (!mu0 || (Tn > 1 && !b))) return -5;                                                                \
+        if (H && m > 4)      /* more than four outputs: the tile engine at any d */                                    \
+            return mf::big_ssm_precision_##SUF(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step,       \
+                                               diag, sub, eta, S(stream));                                             \
         MF_TRY(t->ssm_precision(B, Tn, H ? m : 1, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, diag, sub, eta, S(stream))) \
         if (big)                                                                                                       \
             return mf::big_ssm_precision_##SUF(B, Tn, d, H ? m : 1, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step,   \
@@ -385,13 +390,17 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
                                 T* g_A, T* g_b, T* g_cholQ, T* g_H, T* g_y, T* g_omega, const T* weights, int* info,   \
                                 void* stream) {                                                                        \
         MF_HEAD(T, B, Tn, d)                                                                                           \
-        if (m < 1 || m > (big ? 32 : 4)) return -4;                                                                    \
+        if (m < 1 || m > 32) return -4;                                                                                \
         if (!mu0 || !cholP0 || (Tn > 1 && (!A || !b || !cholQ))) return -5;                                            \
         if (H && (!y || !Rinv)) return -11;                                                                            \
         if (!post_mean || !post_cov || (Tn > 1 && !post_cross)) return -14;                                            \
         if (!g_mu0 || !g_cholP0 || (Tn > 1 && (!g_A || !g_b || !g_cholQ))) return -17;                                 \
         if (H && (!g_H || !g_y || !g_omega)) return -22;                                                               \
-        if (big && !weights) return -25;                                                                               \
+        if ((big || m > 4) && !weights) return -25;                                                                    \
+        if (H && m > 4)      /* more than four outputs: the tile kernel at any d (m <= d rounded up to 16) */           \
+            return mf::big_kf_grad_##SUF(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step,             \
+                                         post_mean, post_cov, post_cross, weights, g_mu0, g_cholP0, g_A, g_b,          \
+                                         g_cholQ, g_H, g_y, g_omega, S(stream));                                       \
         MF_TRY(t->kf_grad(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, post_mean, post_cov, post_cross, g_mu0, g_cholP0, g_A, g_b, g_cholQ, g_H, g_y, g_omega, weights, rinv_per_step, info, S(stream))) \
         if (big) return mf::big_kf_grad_##SUF(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step,        \
                                               post_mean, post_cov, post_cross, weights, g_mu0, g_cholP0, g_A, g_b,     \

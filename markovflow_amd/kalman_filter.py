@@ -53,11 +53,11 @@ class _LogLikelihoodPerSeries(torch.autograd.Function):
             means, covs, cross = post._moments(want_sub=True)  # one forward sweep (or two scans) of the posterior chain
             bsz, n, m, d = h.shape
             per_step = r_inv.dim() > 2
-            big = d > _lib.load().mf_max_state_dim()
-            if (not big and m > 4) or (big and m > 16 * ((d + 15) // 16)):
-                # an observation dimension beyond the local kernels (register-resident: m <= 4; LDS tiles: m <= d rounded up to
-                # 16): the same closed forms as batched products on the smoothed moments, which themselves come from the HIP
-                # kernels above.  BASELINE config 5 (d = 64, m = 32) takes the tile kernel below (csrc/mf_biggrad_impl.hpp).
+            if m > 16 * ((d + 15) // 16):
+                # an observation dimension beyond the local kernels (register / row kernels: m <= 4; LDS tiles, which the C ABI
+                # picks for more outputs at any d: m <= d rounded up to 16): the same closed forms as batched products on the
+                # smoothed moments, which themselves come from the HIP kernels above.  BASELINE config 5 (d = 64, m = 32) takes
+                # the tile kernel below (csrc/mf_biggrad_impl.hpp).
                 return _local_gradients_dense(mu0, cp0, a_s, b_s, cq, h, y, r_inv, means, covs, cross, grad_out.reshape(bsz)) + (None,)
             g_mu0, g_cp0 = torch.empty_like(mu0), torch.empty_like(cp0)
             g_a, g_b, g_cq = torch.empty_like(a_s), torch.empty_like(b_s), torch.empty_like(cq)

@@ -83,7 +83,9 @@ def test_large_d_local_gradient_kernel_vs_closed_forms(rng, dtype, d, m, t, bsz)
                                        (12, 2, 6, 2), (17, 5, 5, 1), (32, 6, 4, 2),
                                        # 10 <= d <= 15 on chains long enough for the time partition: posterior chain, moments and the
                                        # local step all in row form (csrc/mf_row_*.hpp compiled for these d)
-                                       (12, 3, 70, 1), (15, 4, 66, 2), (10, 1, 130, 1)])
+                                       (12, 3, 70, 1), (15, 4, 66, 2), (10, 1, 130, 1),
+                                       # more than four outputs at d <= 9: value and local step on the tile engine
+                                       (3, 6, 12, 2), (9, 7, 20, 1)])
 def test_tensor_gradients_vs_dense_autograd(rng, d, m, t, bsz):
     kw = random_ssm(rng, (bsz,), t, d, m, well=True)
     chol_r = np.linalg.cholesky(0.4 * np.eye(m) + 0.1 * np.ones((m, m)))

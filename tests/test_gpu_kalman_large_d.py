@@ -185,3 +185,28 @@ def test_row_kernels_10_to_15_per_step_precisions_and_fallback(rng):
     chol_r = np.linalg.cholesky(0.5 * np.eye(5) + 0.1)
     ref5 = O.kf_log_likelihood(**kw5, r_inv=np.linalg.inv(chol_r @ chol_r.T))
     np.testing.assert_allclose(float(build_kf(kw5, chol_r, dtype=torch.float64).log_likelihood().cpu()), ref5, rtol=1e-9)
+
+
+# ---- more than four outputs at d <= 9: the tile engine (its tiles pad d to 16), the reference has no such cap ----------------------------
+@pytest.mark.parametrize("dtype", [torch.float64, F32])
+@pytest.mark.parametrize("d,m,t,batch", [(3, 6, 40, (2,)), (9, 7, 130, (3,)), (1, 5, 9, ()), (6, 32, 20, (2,)), (5, 5, 300, (1,))])
+def test_more_than_four_outputs_at_small_state_dimension(rng, dtype, d, m, t, batch):
+    """kalman_filter.py:184-255 / :109-182 with output_dim > 4 and state_dim <= 9 (five independent Matern-1/2 outputs are d = m = 5):
+    log-likelihood per series and the posterior chain against the oracle."""
+    kw = random_ssm(rng, batch, t, d, m, well=True)
+    if dtype == F32:
+        kw = rounded(kw)
+    cov = 0.5 * np.eye(m) + 0.1 * np.ones((m, m))
+    chol_r = np.linalg.cholesky(cov).astype(np.float32).astype(np.float64)
+    r_inv = np.linalg.inv(chol_r @ chol_r.T)
+    kf = build_kf(kw, chol_r, dtype=dtype)
+    ref = O.kf_log_likelihood(**kw, r_inv=r_inv, per_series=True)
+    got = nn(kf._log_likelihood_per_series() + kf._constant_terms(t)).reshape(np.shape(ref))
+    np.testing.assert_allclose(got, ref, rtol=1e-9 if dtype == torch.float64 else RTOL)
+    post = kf.posterior_state_space_model()
+    want = O.kf_posterior_ssm(**kw, r_inv=r_inv)
+    got = (post.initial_mean, post.cholesky_initial_covariance, post.state_transitions, post.state_offsets,
+           post.cholesky_process_covariances)
+    tol = dict(rtol=1e-7, atol=1e-9) if dtype == torch.float64 else dict(rtol=5e-3, atol=5e-4)
+    for g, w in zip(got, want):
+        np.testing.assert_allclose(nn(g), w, **tol)
