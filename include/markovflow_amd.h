@@ -51,12 +51,13 @@ int mf_max_state_dim_f64_loglik(void);   /* mf_kf_loglik_f64 only: the same on f
  *   log_det_precision (state_space_model.py:343-373).
  * Inputs: mu0 [B,d], cholP0 [B,d,d], A [B,T-1,d,d], b [B,T-1,d], cholQ [B,T-1,d,d],
  *         H [B,T,m,d], y [B,T,m], Rinv [m,m] (rinv_per_step=0, KalmanFilter) or [B,T,m,m]
- *         (rinv_per_step=1, KalmanFilterWithSites / WithSparseSites), 1 <= m <= 4.
+ *         (rinv_per_step=1, KalmanFilterWithSites / WithSparseSites), 1 <= m <= 32 (up to four outputs: the register / row
+ *         kernels; more: the LDS-tile kernels, at any state dimension).
  * State dimension: 1..9 in fp32 and fp64: one lane per (series, time-chunk) with the state in registers up to d = 6 (fp32: 8),
  *         above that one 16-lane DPP row per (series, time-chunk) with one matrix row per lane (csrc/mf_row.hpp -
- *         BASELINE config 4, d = 9); 10 <= d <= 64 (fp32) or
- *         10 <= d <= 32 (fp64) with 1 <= m <= 32 run one workgroup per (series, time-chunk) on LDS tiles and
- *         f32 / f64 MFMA (csrc/mf_big.hpp - BASELINE config 5, state_dim = 64).
+ *         BASELINE config 4, d = 9) - the rows also take 10 <= d <= 15 with up to four outputs; beyond that (and with more
+ *         than four outputs at any d) 1 <= d <= 64 (fp32) or 32 (fp64) with 1 <= m <= 32 run one workgroup per (series,
+ *         time-chunk) on LDS tiles and f32 / f64 MFMA (csrc/mf_big.hpp - BASELINE config 5, state_dim = 64).
  * Output: out[s] = add_const + term1 + term2 + 1/2 log|K^-1| - log|L|  (kalman_filter.py:233-253), i.e. the
  *         per-series log-likelihood; the terms that do not depend on the chain,
  *         -1/2 m T log(2 pi) + 1/2 log|Sigma^-1|  (kalman_filter.py:229-231,249-253), are passed in add_const.
@@ -313,7 +314,9 @@ int mf_sde_conditional_predict_f32(int64_t B, int64_t N, int64_t Np, int d, cons
  * is -1/2 g_omega[k] (+ 1/2 R_k from the log-determinant, which the caller owns).  Rinv: shared [m,m] (rinv_per_step = 0) or
  * [B,T,m,m] (1: KalmanFilterWithSites / WithSparseSites).  H = NULL: no emission model - the expected score of the bare chain
  * under the given moments (used for the q2 half of the KL gradient); y, Rinv, g_H, g_y, g_omega are then ignored.
- * weights [B] (nullable): the incoming gradient of every series' value, applied to all outputs.  State dimension 1..9, m <= 4.
+ * weights [B] (nullable): the incoming gradient of every series' value, applied to all outputs (required for d > 9 or m > 4).
+ * State dimension 1..9 with m <= 4: register kernels; 10..15 with m <= 4: row kernels; otherwise (d <= 64 fp32 / 32 fp64, m <= d
+ * rounded up to 16) one LDS-tile workgroup per (series, time point) (csrc/mf_biggrad_impl.hpp).
  */
 int mf_kf_loglik_grad_f64(int64_t B, int64_t T, int d, int m, const double* mu0, const double* cholP0, const double* A,
                           const double* b, const double* cholQ, const double* H, const double* y, const double* Rinv,
