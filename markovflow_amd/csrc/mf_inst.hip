@@ -703,8 +703,10 @@ int tak_scan(long B, long n, TakSrc<T> src, T* odiag, T* osub, void* ws, size_t 
         arr[l].N = reinterpret_cast<T*>(p); p += sz;
         arr[l].Z = reinterpret_cast<T*>(p); p += sz;
     }
-    if constexpr ((SRC == 1 || SRC == 2) && D >= 2 && D + 1 <= 16) {
-        if (row_par_path<T>(B * pl.n[1])) {     // the covariance (and mean) scan / its adjoint in row form (mf_row_scan.hpp)
+    if constexpr (D >= 2 && D + 1 <= 16) {
+        // the covariance (and mean) scan / its adjoint in row form (mf_row_scan.hpp); the Takahashi recursion on a factor (SRC 0)
+        // from d = 7 on (below, the register-resident lane kernels carry 64 chunks per wavefront)
+        if (row_par_path<T>(B * pl.n[1]) && (SRC != 0 || D >= 7)) {
             const dim3 blk(64);
             auto rgrid = [](long rows) { return dim3((unsigned)cdiv(rows, 4)); };
             if (SRC == 1 && mup.oc != nullptr)

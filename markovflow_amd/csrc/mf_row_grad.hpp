@@ -23,26 +23,6 @@ template <typename T, int D> MF_DEV void row_mul_t_sub(const T (&a)[D], const T 
     });
 }
 
-// From the rows of a lower-triangular C (zero above the diagonal) and the own 1 / C[r][r]:
-//   CiT: lane l holds column l of C^-1 (CiT[j] = Ci[j][l]),  Qi: lane i holds row i of Q^-1 = C^-T C^-1.
-template <typename T, int D> MF_DEV void row_qinv(T (&Crow)[D], T dinv, int r, T (&CiT)[D], T (&Qi)[D]) {
-    using P = Dpp<T>;
-    T acc[D];
-    sfor<D>([&](auto i) { acc[decltype(i)::value] = r == decltype(i)::value ? T(1) : T(0); });
-    fence(Crow);
-    fence1(dinv);
-    sfor<D>([&](auto kq) {
-        constexpr int kk = decltype(kq)::value;
-        CiT[kk] = acc[kk] * P::template bcast<kk>(dinv);
-        sfor2<kk + 1, D>([&](auto i) { P::template fnmac<decltype(i)::value>(acc[decltype(i)::value], Crow[kk], CiT[kk]); });
-    });
-    fence(CiT);
-    sfor<D>([&](auto j) { Qi[decltype(j)::value] = T(0); });
-    sfor<D>([&](auto l) {                                   // Ci[l][j] = 0 for l < j: exact zeros, skipped
-        constexpr int ll = decltype(l)::value;
-        sfor<ll + 1>([&](auto j) { P::template fmac<decltype(j)::value>(Qi[decltype(j)::value], CiT[ll], CiT[ll]); });
-    });
-}
 // G = (Q^-1 Psi - I) C^-T, rows; only j <= r is meaningful (the lower triangle)
 template <typename T, int D> MF_DEV void row_chol_grad(const T (&Qi)[D], T (&Psi)[D], const T (&CiT)[D], int r, T (&G)[D]) {
     using P = Dpp<T>;

@@ -46,7 +46,30 @@ template <typename T, int D> MF_DEV void load_row_lower(const T* __restrict__ bl
     sfor<D>([&](auto j) { v[decltype(j)::value] = decltype(j)::value <= rc ? blk[rc * D + decltype(j)::value] : T(0); });
 }
 
+// From the rows of a lower-triangular C (zero above the diagonal) and the own 1 / C[r][r]:
+//   CiT: lane l holds column l of C^-1 (CiT[j] = Ci[j][l]),  Qi: lane i holds row i of Q^-1 = C^-T C^-1.
+template <typename T, int D> MF_DEV void row_qinv(T (&Crow)[D], T dinv, int r, T (&CiT)[D], T (&Qi)[D]) {
+    using P = Dpp<T>;
+    T acc[D];
+    sfor<D>([&](auto i) { acc[decltype(i)::value] = r == decltype(i)::value ? T(1) : T(0); });
+    fence(Crow);
+    fence1(dinv);
+    sfor<D>([&](auto kq) {
+        constexpr int kk = decltype(kq)::value;
+        CiT[kk] = acc[kk] * P::template bcast<kk>(dinv);
+        sfor2<kk + 1, D>([&](auto i) { P::template fnmac<decltype(i)::value>(acc[decltype(i)::value], Crow[kk], CiT[kk]); });
+    });
+    fence(CiT);
+    sfor<D>([&](auto j) { Qi[decltype(j)::value] = T(0); });
+    sfor<D>([&](auto l) {                                   // Ci[l][j] = 0 for l < j: exact zeros, skipped
+        constexpr int ll = decltype(l)::value;
+        sfor<ll + 1>([&](auto j) { P::template fmac<decltype(j)::value>(Qi[decltype(j)::value], CiT[ll], CiT[ll]); });
+    });
+}
 // one position of the level-0 kernels:  Sigma(p) = Mp Sigma(p-1) Mp^T + N_p  (mu(p) = Mp mu(p-1) + o_p)
+//   SRC 0 (block Takahashi on a Cholesky factor, block_tri_diag.py:318-337, backward): position p = block k = n-1-p;
+//          Sigma_k = L_k^-T L_k^-1 + G_k^T Sigma_{k+1} G_k with G_k = W_k L_k^-1: Mp = G_k^T = L_k^-T W_k^T, N = L_k^-T L_k^-1;
+//          src.a = ldiag, src.b = lsub.
 //   SRC 1 (marginal covariances / means, forward): block p; Mp = A_{p-1}, N = C C^T with C = cholQ_{p-1} (p = 0: cholP0, Mp = 0),
 //          o = b_{p-1} (mu0);  src.a = cholQ, src.b = A, src.c0 = cholP0.
 //   SRC 2 (their adjoint, M_k = N_k + A_k^T M_{k+1} A_k, backward): position p = block n-1-p; Mp = A_k^T (rows = columns of
@@ -57,7 +80,21 @@ template <typename T, int D> struct RowCovStep {
 template <typename T, int D, int SRC, bool MEAN>
 MF_DEV void load_cov_step(const TakSrc<T>& src, const T* mu0, const T* b, long s, long n, long p, int rc, RowCovStep<T, D>& d) {
     const T keep = p > 0 ? T(1) : T(0);
-    if constexpr (SRC == 1) {
+    if constexpr (SRC == 0) {
+        const long k = n - 1 - p;
+        const T* lblk = src.a + (s * n + k) * D * D;
+        T Crow[D], CiT[D];
+        load_row_lower<T, D>(lblk, rc, Crow);
+        row_qinv<T, D>(Crow, t_rcp<T>(lblk[rc * (D + 1)]), rc, CiT, d.Nn);          // N = L^-T L^-1; CiT: own row of L^-T
+        sfor<D>([&](auto j) { d.Arow[decltype(j)::value] = T(0); });
+        if (n > 1) {
+            T Wt[D];
+            load_col<T, D>(src.b + (s * (n - 1) + (k < n - 1 ? k : n - 2)) * D * D, rc, Wt);   // row rc of W^T
+            fence(Wt);
+            row_mul<T, D, D>(CiT, Wt, d.Arow);                                      // rows of L^-T W^T = G^T
+        }
+        d.o = T(0);
+    } else if constexpr (SRC == 1) {
         const long kt = p > 0 ? p - 1 : 0;
         const T* cblk = p > 0 ? src.a + (s * (n - 1) + kt) * D * D : src.c0 + s * D * D;
         T Crow[D];
@@ -217,6 +254,8 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, false)) row_co
             row_mul<T, D, D>(d.Arow, Sr, T2);                          // A Sigma_{p-1}
             if constexpr (SRC == 1) {
                 if (osub && st) sfor<D>([&](auto j) { osub[(q.s * (n - 1) + p - 1) * D * D + q.r * D + decltype(j)::value] = T2[decltype(j)::value]; });
+            } else if constexpr (SRC == 0) {       // sub-diagonal block of the inverse: -Sigma_{k+1} G_k = -(G^T Sigma)^T
+                if (osub && st) sfor<D>([&](auto j) { osub[(q.s * (n - 1) + k) * D * D + decltype(j)::value * D + q.r] = -T2[decltype(j)::value]; });
             }
             fence(d.Arow);
             row_mul_t<T, D>(T2, d.Arow, Nn);

@@ -137,7 +137,7 @@ def test_config3_full_size_fp32_recombination_and_round_trip(rng):
 
 # ---- parallel-in-time Takahashi (block_diagonal_of_inverse) and marginal means --------------------------------------------------
 @pytest.mark.parametrize("d,n,batch", [(1, 64, ()), (3, 100, (2,)), (2, 777, (3,)), (6, 1000, (1,)), (9, 513, (2, 1)),
-                                       (11, 200, (2,)), (15, 130, ())])
+                                       (11, 200, (2,)), (15, 130, ()), (7, 300, (2,)), (8, 1000, ()), (12, 2000, (1,))])
 def test_parallel_block_diagonal_of_inverse_vs_oracle(rng, d, n, batch):
     bsz = int(np.prod(batch)) if batch else 1
     assert _lib.load().mf_btd_diag_of_inverse_workspace_bytes(bsz, n, d, 8) > 0
