@@ -34,9 +34,10 @@ extern "C" {
 int mf_version(void);
 int mf_max_state_dim(void);              /* every entry point, fp32 and fp64: register-resident kernels (9)       */
 /* 1 when the register / row kernels run EVERY operator for this shape: d <= 9 always; 10 <= d <= 15 (row kernels only: one
- * 16-lane row per chunk) when the operators are partitioned in time (few series, long chains) - otherwise, and for d >= 16,
- * the LDS-tile / MFMA engine takes the call (same entry points; the chain-layout and fused variants then return -100 / -101).
- * mf_kf_loglik itself uses the row kernels for every 10 <= d <= 15 with at most four outputs. */
+ * 16-lane row per chunk; many series or short chains run them with one chunk per series) for every chain of at least two
+ * blocks - otherwise, and for d >= 16, the LDS-tile / MFMA engine takes the call (same entry points; the chain-layout and
+ * fused variants then return -100 / -101).  With more than four outputs the observation side (log-likelihood, precision
+ * assembly, gradient step) goes to the tile engine at any d. */
 int mf_row_operators_cover(int64_t B, int64_t T, int d, int elem_size);
 int mf_max_state_dim_f32_loglik(void);   /* mf_kf_loglik_f32 only: LDS-tiled MFMA kernels for 10 <= d <= 64       */
 int mf_max_state_dim_f64_loglik(void);   /* mf_kf_loglik_f64 only: the same on f64 MFMA for 10 <= d <= 32         */

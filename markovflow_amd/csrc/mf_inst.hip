@@ -417,10 +417,13 @@ inline long par_radix() {
 inline long par_len0(long B, long n) {
     static const long force = [] { const char* e = mf_knob("MF_BTD_PAR_LEN"); return e ? std::atol(e) : -1L; }();
     if (force >= 0) return (force > 0 && n >= 2 * force) ? force : 0;
-    if (B >= PAR_MAX_SERIES || n < PAR_MIN_BLOCKS) return 0;
+    if constexpr (LANE) { if (B >= PAR_MAX_SERIES || n < PAR_MIN_BLOCKS) return 0; }
     long len = cdiv(B * n, 65536);           // aim at one wavefront per SIMD ...
     if (len < RED_CHUNK) len = RED_CHUNK;     // ... but keep the reduced system at most 1/8 of the input
-    return n >= 2 * len ? len : 0;
+    if (n >= 2 * len) return len;
+    // row-only builds (10 <= d <= 15) have no lane-per-series kernels to fall back on: many series or short chains run the same
+    // row kernels with ONE chunk per series (the up-sweep of a whole series has no spike; the emit pass is the serial recursion)
+    return (!LANE && n >= 2) ? n : 0;
 }
 
 // The parallel-in-time operators in row form (mf_row_par.hpp, mf_row_scan.hpp, mf_row_post.hpp: a 16-lane row per chunk instead

@@ -207,11 +207,13 @@ def test_parallel_udl_long_chain_recombines(rng):
     np.testing.assert_allclose(nn(rec_diag), diag, rtol=1e-9, atol=1e-10)
 
 
-@pytest.mark.parametrize("d,m,n", [(2, 1, 300), (6, 1, 500), (4, 2, 129), (10, 1, 200), (12, 3, 300), (15, 4, 129)])
+@pytest.mark.parametrize("d,m,n", [(2, 1, 300), (6, 1, 500), (4, 2, 129), (10, 1, 200), (12, 3, 300), (15, 4, 129),
+                                   # 10 <= d <= 15, chains too short to cut: the same row kernels with one chunk per series
+                                   (12, 3, 9), (15, 2, 2), (10, 4, 40)])
 def test_parallel_posterior_state_space_model_vs_oracle(rng, d, m, n):
     """KalmanFilter.posterior_state_space_model (kalman_filter.py:109-182) on the parallel-in-time path (few series)."""
     from test_gpu_kalman import build_kf, random_ssm
-    kw = random_ssm(rng, (2,), n, d, m)
+    kw = random_ssm(rng, (2,), n, d, m, well=d >= 10)
     cov = 0.4 * np.eye(m)
     kf = build_kf(kw, np.linalg.cholesky(cov))
     post = kf.posterior_state_space_model()
@@ -254,3 +256,25 @@ def test_covariance_scan_equals_the_reference_route(rng, dtype, d, n, batch):
             np.testing.assert_allclose(covs[k].cpu().numpy(), cov, rtol=1e-9, atol=1e-11)
             cov = kw["a_s"][k] @ cov @ kw["a_s"][k].T + kw["chol_q"][k] @ kw["chol_q"][k].T
         np.testing.assert_allclose(covs[n - 1].cpu().numpy(), cov, rtol=1e-9, atol=1e-11)
+
+
+def test_row_only_dimensions_with_many_short_series(rng):
+    """d = 13 with 4100 series of 12 points: beyond the partition's series limit the row-only build runs one chunk per series
+    (mf_row_operators_cover = 1 for every shape) - posterior chain, marginals and KL of every series against the oracle."""
+    from test_gpu_kalman import build_kf, random_ssm
+    d, m, n, bsz = 13, 2, 12, 4100
+    assert _lib.load().mf_row_operators_cover(bsz, n, d, 8) == 1
+    kw = random_ssm(rng, (bsz,), n, d, m, well=True)
+    cov = 0.4 * np.eye(m)
+    kf = build_kf(kw, np.linalg.cholesky(cov))
+    post = kf.posterior_state_space_model()
+    want = O.kf_posterior_ssm(**kw, r_inv=np.linalg.inv(cov))
+    got = (post.initial_mean, post.cholesky_initial_covariance, post.state_transitions, post.state_offsets,
+           post.cholesky_process_covariances)
+    for g, w in zip(got, want):
+        np.testing.assert_allclose(nn(g), w, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(nn(post.marginal_covariances), O.ssm_marginal_covariances(want[1], want[2], want[4]), rtol=1e-6, atol=1e-9)
+    kl = O.ssm_kl_divergence(want, (kw["mu0"], kw["chol_p0"], kw["a_s"], kw["b_s"], kw["chol_q"]))
+    np.testing.assert_allclose(nn(post.kl_divergence(kf.prior_ssm)), kl, rtol=1e-7)
+    ref = O.kf_log_likelihood(**kw, r_inv=np.linalg.inv(cov), per_series=True)
+    np.testing.assert_allclose(nn(kf._log_likelihood_per_series() + kf._constant_terms(n)), ref, rtol=1e-9)
