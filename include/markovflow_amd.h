@@ -260,8 +260,14 @@ int mf_sde_matern_transitions_f32(int64_t B, int64_t n, int ncomp, const int* or
  * zero mean function, H = [1 0 .. | 1 0 ..].  Arguments as for mf_sde_matern_transitions_* - orders: HOST array, ncomp <= 2 - plus
  * time points t [B,T] (strictly increasing), observations y [B,T], rinv [1] (device: 1 / noise variance); out[s] as
  * mf_kf_loglik_*: add_const carries -T/2 log 2 pi + T/2 log rinv.  Workspace: the size mf_kf_loglik_workspace_bytes returns.
- * Returns -101 when the component signature is not instantiated (supported: (1), (3), (5), (3,3), (5,3), (3,5), (5,5));
- * the caller then materialises the model (mf_sde_matern_transitions + mf_kf_loglik).
+ * Returns -101 when the component signature is not instantiated - supported: (1), (3), (5), (3,3), (5,3), (3,5), (5,5) on the
+ * register kernels (d <= 6) and ANY concatenation of up to 15 components with 7 <= d <= 15 on the row kernels
+ * (csrc/mf_row_gpr.hpp: every lane generates its own row of chol Q_k and column of A_k) - the caller then materialises the
+ * model (mf_sde_matern_transitions + mf_kf_loglik).
+ *
+ * mf_gpr_matern_multi_loglik_*: the same for IndependentMultiOutput (kernels/sde_kernel.py:826-880: one output per component,
+ * H[o] = e_{first state of component o}; BASELINE config 4 = three Matern-5/2 components, three outputs): y [B,T,m] with
+ * m = ncomp <= 4, rinv [m,m]; 7 <= d <= 15 (row kernels), -101 otherwise.
  */
 int mf_gpr_matern_loglik_f64(int64_t B, int64_t T, int ncomp, const int* orders, const double* lam, const double* var,
                              int per_series, const double* t, const double* y, const double* rinv, double jitter,
@@ -271,6 +277,14 @@ int mf_gpr_matern_loglik_f32(int64_t B, int64_t T, int ncomp, const int* orders,
                              int per_series, const float* t, const float* y, const float* rinv, float jitter,
                              float add_const, float* out, void* ws, size_t ws_bytes, int* info, int64_t chunks,
                              void* prof_start, void* prof_stop, void* stream);
+int mf_gpr_matern_multi_loglik_f64(int64_t B, int64_t T, int ncomp, const int* orders, const double* lam, const double* var,
+                                   int per_series, const double* t, const double* y, int m, const double* rinv, double jitter,
+                                   double add_const, double* out, void* ws, size_t ws_bytes, int* info, int64_t chunks,
+                                   void* prof_start, void* prof_stop, void* stream);
+int mf_gpr_matern_multi_loglik_f32(int64_t B, int64_t T, int ncomp, const int* orders, const float* lam, const float* var,
+                                   int per_series, const float* t, const float* y, int m, const float* rinv, float jitter,
+                                   float add_const, float* out, void* ws, size_t ws_bytes, int* info, int64_t chunks,
+                                   void* prof_start, void* prof_stop, void* stream);
 
 /*
  * Last line of BaseKalmanFilter.log_likelihood (markovflow/kalman_filter.py:229-231,249-255) as ONE kernel:

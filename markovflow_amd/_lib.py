@@ -34,6 +34,8 @@ _SIGS = {
     "mf_block_matmul": (_int, [_i64, _i64, _int, "Tp", _i64, "Tp", _i64, "Tp", _vp]),
     "mf_gpr_matern_loglik": (_int, [_i64, _i64, _int, ctypes.POINTER(ctypes.c_int), "Tp", "Tp", _int, "Tp", "Tp", "Tp", "T", "T",
                                     "Tp", _vp, _sz, _vp, _i64, _vp, _vp, _vp]),
+    "mf_gpr_matern_multi_loglik": (_int, [_i64, _i64, _int, ctypes.POINTER(ctypes.c_int), "Tp", "Tp", _int, "Tp", "Tp", _int, "Tp",
+                                          "T", "T", "Tp", _vp, _sz, _vp, _i64, _vp, _vp, _vp]),
     "mf_kf_loglik_total": (_int, [_i64, "Tp", _int, "Tp", _i64, "Tp", "T", "Tp", _vp]),
     "mf_kf_loglik_grad": (_int, [_i64, _i64, _int, _int] + ["Tp"] * 8 + [_int] + ["Tp"] * 12 + [_vp, _vp]),
     "mf_ssm_kl_grad": (_int, [_i64, _i64, _int] + ["Tp"] * 20 + [_vp, _sz, _vp, _vp]),

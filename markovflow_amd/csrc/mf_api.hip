@@ -105,6 +105,34 @@ int loglik_total(int64_t B, const T* per_series, int m, const T* chol_obs, int64
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
+// the fused GPR routes share one body: `m` outputs, `multi` = one output per component
+template <typename T>
+int gpr_matern_loglik(int64_t B, int64_t Tn, int ncomp, const int* orders, const T* lam, const T* var, int per_series,
+                      const T* t_pts, const T* y, int m, int multi, const T* rinv, T jitter, T add_const, T* out, void* ws,
+                      size_t ws_bytes, int* info, int64_t chunks, void* prof_start, void* prof_stop, void* stream) {
+    if (B < 0) return -1;
+    if (Tn < 1) return -2;
+    if (ncomp < 1 || !orders) return -3;
+    int d = 0;
+    for (int c = 0; c < ncomp; ++c) {
+        if (orders[c] != 1 && orders[c] != 3 && orders[c] != 5) return -4;
+        d += (orders[c] + 1) / 2;
+    }
+    const auto* t = table_for<T>(d);
+    if (!t) return -101;
+    if (m < 1 || m > 4) return -101;
+    if (B == 0) return 0;
+    if (!lam) return -5;
+    if (!var) return -6;
+    if (!t_pts) return -8;
+    if (!y) return -9;
+    if (!rinv) return -10;
+    if (!out) return -13;
+    return t->gpr_loglik(B, Tn, ncomp, orders, lam, var, per_series, t_pts, y, m, multi, rinv, jitter, add_const, out, ws,
+                         ws_bytes, info, chunks, static_cast<hipEvent_t>(prof_start), static_cast<hipEvent_t>(prof_stop),
+                         S(stream));
+}
+
 }  // namespace
 
 extern "C" {
@@ -339,26 +367,16 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
                                    int per_series, const T* t_pts, const T* y, const T* rinv, T jitter, T add_const,   \
                                    T* out, void* ws, size_t ws_bytes, int* info, int64_t chunks, void* prof_start,     \
                                    void* prof_stop, void* stream) {                                                    \
-        if (B < 0) return -1;                                                                                          \
-        if (Tn < 1) return -2;                                                                                         \
-        if (ncomp < 1 || !orders) return -3;                                                                           \
-        int d = 0;                                                                                                     \
-        for (int c = 0; c < ncomp; ++c) {                                                                              \
-            if (orders[c] != 1 && orders[c] != 3 && orders[c] != 5) return -4;                                         \
-            d += (orders[c] + 1) / 2;                                                                                  \
-        }                                                                                                              \
-        const auto* t = table_for<T>(d);                                                                               \
-        if (!t || ncomp > 2) return -101;                                                                              \
-        if (B == 0) return 0;                                                                                          \
-        if (!lam) return -5;                                                                                           \
-        if (!var) return -6;                                                                                           \
-        if (!t_pts) return -8;                                                                                         \
-        if (!y) return -9;                                                                                             \
-        if (!rinv) return -10;                                                                                         \
-        if (!out) return -13;                                                                                          \
-        return t->gpr_loglik(B, Tn, ncomp, orders, lam, var, per_series, t_pts, y, rinv, jitter, add_const, out, ws,   \
-                             ws_bytes, info, chunks, static_cast<hipEvent_t>(prof_start),                              \
-                             static_cast<hipEvent_t>(prof_stop), S(stream));                                           \
+        return gpr_matern_loglik<T>(B, Tn, ncomp, orders, lam, var, per_series, t_pts, y, 1, 0, rinv, jitter, add_const, \
+                                    out, ws, ws_bytes, info, chunks, prof_start, prof_stop, stream);                   \
+    }                                                                                                                  \
+    int mf_gpr_matern_multi_loglik_##SUF(int64_t B, int64_t Tn, int ncomp, const int* orders, const T* lam,            \
+                                         const T* var, int per_series, const T* t_pts, const T* y, int m,              \
+                                         const T* rinv, T jitter, T add_const, T* out, void* ws, size_t ws_bytes,      \
+                                         int* info, int64_t chunks, void* prof_start, void* prof_stop, void* stream) { \
+        if (m != ncomp) return -10;                                                                                    \
+        return gpr_matern_loglik<T>(B, Tn, ncomp, orders, lam, var, per_series, t_pts, y, m, 1, rinv, jitter, add_const, \
+                                    out, ws, ws_bytes, info, chunks, prof_start, prof_stop, stream);                   \
     }
 
 #define MF_DEFINE4(SUF, T)                                                                                             \

@@ -11,6 +11,7 @@
 #include "mf_row_scan.hpp"
 #include "mf_row_grad.hpp"
 #include "mf_row_post.hpp"
+#include "mf_row_gpr.hpp"
 #include "mf_btd_par.hpp"
 #include "mf_gpr_fused.hpp"
 #include "mf_kl_grad.hpp"
@@ -1136,10 +1137,31 @@ int gpr_launch(const GprArgs<T>& a, RedSys<T> lvl0, hipStream_t st) {
 }
 template <typename T>
 int gpr_loglik(long B, long Tn, int ncomp, const int* orders, const T* lam, const T* var, int per_series, const T* t,
-               const T* y, const T* rinv, T jitter, T add_const, T* out, void* ws, size_t ws_bytes, int* info, long chunks,
-               hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
+               const T* y, int m, int multi, const T* rinv, T jitter, T add_const, T* out, void* ws, size_t ws_bytes, int* info,
+               long chunks, hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
+    if constexpr (D >= 7 && D + 1 <= 16) {
+        // 7 <= d <= 15: any concatenation of components, one output (Sum) or one per component (up to four), generated inside the
+        // row kernel (mf_row_gpr.hpp)
+        if (ncomp > row::GPR_MAX_COMP || m < 1 || m > MF_MAXM || (multi ? m != ncomp : m != 1)) return -101;
+        if (ws == nullptr) return -15;
+        const KfPlan pl = kf_plan<T>(B, Tn, m, 0, chunks, true);
+        if (pl.path != KF_PATH_ROW) return -101;
+        if (ws_bytes < plan_ws<T>(B, pl)) return -15;
+        row::GprRowArgs<T> a{B, Tn, ncomp, multi, {}, lam, var, per_series ? (long)ncomp : 0L, t, y, rinv, jitter, pl.P, info};
+        for (int c = 0; c < ncomp; ++c) a.order[c] = orders[c];
+        char* p = static_cast<char*>(ws);
+        RedSys<T> lvl0 = carve<T>(p, B, pl.P);
+        const dim3 rgrid((unsigned)cdiv(B * pl.P, 4)), block(64);
+        if (ev0) (void)hipEventRecord(ev0, st);
+        if (m == 1) hipLaunchKernelGGL((row::gpr_row_kernel<T, D, 1>), rgrid, block, 0, st, a, lvl0);
+        else if (m == 2) hipLaunchKernelGGL((row::gpr_row_kernel<T, D, 2>), rgrid, block, 0, st, a, lvl0);
+        else if (m == 3) hipLaunchKernelGGL((row::gpr_row_kernel<T, D, 3>), rgrid, block, 0, st, a, lvl0);
+        else hipLaunchKernelGGL((row::gpr_row_kernel<T, D, 4>), rgrid, block, 0, st, a, lvl0);
+        if (ev1) (void)hipEventRecord(ev1, st);
+        return reduce_levels_row<T>(lvl0, B, p, add_const, out, info, st);
+    }
     const int o0 = orders[0], o1 = ncomp > 1 ? orders[1] : 0;
-    if (ncomp > 2) return -101;
+    if (ncomp > 2 || m != 1 || multi) return -101;
     if (ws == nullptr) return -15;
     long P = 1, L = 1;
     if (Tn >= 2) lds_partition(B, Tn, chunks, P, L);

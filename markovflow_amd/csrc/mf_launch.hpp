@@ -41,8 +41,8 @@ template <typename T> struct OpsTable {
                      hipStream_t st);
     int (*block_matmul)(long B, long n, const T* X, long xs, const T* Y, long ys, T* out, hipStream_t st);
     int (*gpr_loglik)(long B, long Tn, int ncomp, const int* orders, const T* lam, const T* var, int per_series, const T* t,
-                      const T* y, const T* rinv, T jitter, T add_const, T* out, void* ws, size_t ws_bytes, int* info,
-                      long chunks, hipEvent_t ev0, hipEvent_t ev1, hipStream_t st);
+                      const T* y, int m, int multi, const T* rinv, T jitter, T add_const, T* out, void* ws, size_t ws_bytes,
+                      int* info, long chunks, hipEvent_t ev0, hipEvent_t ev1, hipStream_t st);
     int (*sde_predict)(long B, long N, long Np, const long long* idx, const T* Amt, const T* Qmt, const T* Atp, const T* Qtp,
                        const T* means, const T* covs, const T* subseq, const T* m0, const T* P0, T* omean, T* ocov,
                        int* info, hipStream_t st);

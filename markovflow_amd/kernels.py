@@ -179,7 +179,8 @@ class SDEKernel(abc.ABC):
         p0 = p0.expand(batch + tuple(p0.shape[-2:])).contiguous()
         return StateSpaceModel(
             initial_mean=self.initial_mean(batch).to(dtype=a_s.dtype, device=a_s.device).expand(batch + (self.state_dim,)).contiguous(),
-            chol_initial_covariance=torch.linalg.cholesky(p0),
+            # (P-infinity + jitter is positive definite by construction: no info check, hence no host synchronisation)
+            chol_initial_covariance=torch.linalg.cholesky_ex(p0, check_errors=False)[0],
             state_transitions=a_s,
             state_offsets=self.state_offsets(time_points[..., :-1], deltas).to(dtype=a_s.dtype),
             chol_process_covariances=chol_q,
@@ -216,6 +217,11 @@ class StationaryKernel(SDEKernel, abc.ABC):
     def initial_mean(self, batch_shape) -> torch.Tensor:
         ref = self._components()[0]._variance_t
         return torch.zeros(tuple(batch_shape) + (self.state_dim,), dtype=ref.dtype, device=ref.device)
+
+    def state_offsets(self, transition_times: torch.Tensor, time_deltas: torch.Tensor) -> torch.Tensor:
+        """Zero: a stationary kernel's state has zero mean (sde_kernel.py:460-475 evaluates ``(I - A_k) 0``) - known without
+        looking at the device, where the generic form has to test the mean (a host synchronisation per model build)."""
+        return torch.zeros(tuple(time_deltas.shape) + (self.state_dim,), dtype=time_deltas.dtype, device=time_deltas.device)
 
     def initial_covariance(self, initial_time_point: torch.Tensor) -> torch.Tensor:
         """``P∞ + jitter`` (sde_kernel.py:402-419)."""

@@ -77,8 +77,13 @@ class GaussianProcessRegression:
         """Per-series log-likelihood through ``mf_gpr_matern_loglik_*`` (kernel -> SSM generation fused into the Kalman
         sweep: 16 bytes per step instead of the materialised tensors); ``None`` when the kernel / shapes are not covered."""
         comps = self._kernel._components()
-        if (not self.fused or isinstance(self._kernel, IndependentMultiOutput) or len(comps) > 2
-                or self._observations.shape[-1] != 1 or not self._observations.is_cuda):
+        multi = isinstance(self._kernel, IndependentMultiOutput)
+        m = self._observations.shape[-1]
+        d = self._kernel.state_dim
+        # register kernels (d <= 6): one or two components, one output; row kernels (7 <= d <= 15): any concatenation, one
+        # output (Sum) or one per component (IndependentMultiOutput, up to four) - BASELINE config 4 is 3 x Matern-5/2, 3 outputs
+        rows = 7 <= d <= 15 and len(comps) <= 15 and (m == len(comps) <= 4 if multi else m == 1)
+        if not self.fused or not self._observations.is_cuda or not (rows or (not multi and len(comps) <= 2 and m == 1)):
             return None
         if torch.is_grad_enabled() and (self._kernel._needs_grad() or self._chol_obs_covariance.requires_grad
                                         or self._observations.requires_grad):
@@ -86,7 +91,7 @@ class GaussianProcessRegression:
         batch = tuple(self._time_points.shape[:-1])
         n, dtype, dev = self._time_points.shape[-1], self._observations.dtype, self._observations.device
         t = self._time_points.reshape(-1, n).to(dtype).contiguous()
-        y = self._observations.reshape(-1, n).contiguous()
+        y = self._observations.reshape(-1, n, m).contiguous()
         bsz = t.shape[0]
         if bsz == 0 or n < 1:
             return None
@@ -99,8 +104,10 @@ class GaussianProcessRegression:
         else:
             lam_t, var_t = torch.stack(lam).contiguous(), torch.stack(var).contiguous()
         chol = self._chol_obs_covariance.to(dtype=dtype, device=dev)
-        rinv = (1.0 / (chol * chol)).reshape(1).contiguous()
-        d = self._kernel.state_dim
+        if m == 1:
+            rinv = (1.0 / (chol * chol)).reshape(1, 1).contiguous()
+        else:
+            rinv = torch.cholesky_inverse(chol.reshape(m, m)).contiguous()
         lib = _lib.load()
         ws_bytes = int(lib.mf_kf_loglik_workspace_bytes(bsz, n, d, t.element_size(), self._chunks))
         if ws_bytes == 0:
@@ -109,15 +116,19 @@ class GaussianProcessRegression:
         out = torch.empty(bsz, dtype=dtype, device=dev)
         info = _lib.pivot_info(dev)
         orders = (ctypes.c_int * len(comps))(*[c.order for c in comps])
-        rc = _lib.call_rc("mf_gpr_matern_loglik", dtype, bsz, n, len(comps), orders, _lib.ptr(lam_t), _lib.ptr(var_t),
-                          int(per_series), _lib.ptr(t), _lib.ptr(y), _lib.ptr(rinv), self._kernel._jitter, 0.0, _lib.ptr(out),
-                          _lib.ptr(ws), ws_bytes, info, self._chunks, self._prof_events[0], self._prof_events[1],
-                          _lib.stream_ptr(dev))
+        tail = (self._kernel._jitter, 0.0, _lib.ptr(out), _lib.ptr(ws), ws_bytes, info, self._chunks, self._prof_events[0],
+                self._prof_events[1], _lib.stream_ptr(dev))
+        head = (bsz, n, len(comps), orders, _lib.ptr(lam_t), _lib.ptr(var_t), int(per_series), _lib.ptr(t), _lib.ptr(y))
+        if multi:
+            rc = _lib.call_rc("mf_gpr_matern_multi_loglik", dtype, *head, m, _lib.ptr(rinv), *tail)
+        else:
+            rc = _lib.call_rc("mf_gpr_matern_loglik", dtype, *head, _lib.ptr(rinv), *tail)
         if rc == -101:
             return None                     # component signature not instantiated: materialise instead
         _lib.check(rc, "mf_gpr_matern_loglik")
         _lib.raise_on_info(info, "GaussianProcessRegression.log_likelihood", dev)
-        const = -0.5 * math.log(2 * math.pi) * n + 0.5 * n * torch.log(rinv[0])
+        log_det_rinv = torch.log(rinv[0, 0]) if m == 1 else -2.0 * torch.sum(torch.log(torch.diagonal(chol.reshape(m, m))))
+        const = -0.5 * math.log(2 * math.pi) * n * m + 0.5 * n * log_det_rinv
         return (out + const).reshape(batch)
 
     def log_likelihood(self) -> torch.Tensor:

@@ -31,7 +31,9 @@ def timeit(fn):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / a.iters * 1e3, r
 gpr.fused = True
 ms_f, ll_f = timeit(gpr.log_likelihood)
-f = ctypes.c_float(); hip.hipEventElapsedTime(ctypes.byref(f), e0, e1)
+f = ctypes.c_float()
+if hip.hipEventElapsedTime(ctypes.byref(f), e0, e1) != 0:      # signature outside the fused kernel: the events were never recorded
+    f.value = float('nan'); hip.hipGetLastError()
 gpr.fused = False
 ms_m, ll_m = timeit(gpr.log_likelihood)
 d = kern.state_dim

@@ -153,10 +153,48 @@ def test_fused_gpr_log_likelihood_equals_materialised_route(rng, dtype, sig):
     assert float(gpr.log_likelihood().cpu()) == pytest.approx(float(ref.sum().cpu()), rel=tol)
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("sig,multi", [((5, 5, 5), False), ((5, 5, 5), True), ((5, 3, 1, 3), False), ((5, 5, 5, 5), True),
+                                       ((3, 3, 3, 3, 3, 3, 3), False), ((5, 5, 5, 5, 5), False), ((5, 3, 3), True), ((1,) * 8, False)])
+def test_fused_gpr_row_kernel_equals_materialised_route(rng, dtype, sig, multi):
+    """The row form of the fused route (csrc/mf_row_gpr.hpp, 7 <= d <= 15): any concatenation of Matern components as a Sum kernel
+    (one output) or as IndependentMultiOutput (one output per component; BASELINE config 4 = 3 x Matern-5/2, 3 outputs), against
+    the materialised route (mf_sde_matern_transitions + mf_kf_loglik) and, through it, the oracle; several time partitions;
+    per-series hyper-parameters; a full observation noise covariance for the multi-output form."""
+    cls = {1: mfa.Matern12, 3: mfa.Matern32, 5: mfa.Matern52}
+    bsz, n = 3, 170
+    f64 = dtype == torch.float64
+    t = np.cumsum((0.05 if f64 else 0.4) + rng.exponential(0.1 if f64 else 0.3, size=(bsz, n)), axis=-1)
+    m = len(sig) if multi else 1
+    y = rng.normal(size=(bsz, n, m))
+    jit = 1e-9 if f64 else 1e-4
+    parts = [cls[o](tt(0.5 + rng.random(bsz), dtype), tt(0.5 + rng.random(bsz), dtype), jitter=jit) for o in sig]
+    kern = mfa.IndependentMultiOutput(parts, jitter=jit) if multi else mfa.Sum(parts, jitter=jit)
+    assert 7 <= kern.state_dim <= 15
+    cov = 0.1 * np.eye(m) + 0.02 * np.ones((m, m))
+    gpr = mfa.GaussianProcessRegression((tt(t, dtype), tt(y, dtype)), kern, chol_obs_covariance=tt(np.linalg.cholesky(cov), dtype))
+    fused = gpr._fused_log_likelihood_per_series()
+    if not f64 and kern.state_dim < 9:
+        # fp32 keeps the register kernels up to d = 8 (csrc/mf_inst.hip: row_path): no row form, the model is materialised
+        assert fused is None and torch.isfinite(gpr.log_likelihood())
+        return
+    assert fused is not None, "this signature is meant to be covered by the row form of the fused kernel"
+    ref = gpr._kalman._log_likelihood_per_series() + gpr._kalman._constant_terms(n)
+    tol = 1e-9 if f64 else 2e-3
+    np.testing.assert_allclose(nn(fused), nn(ref), rtol=tol)
+    for chunks in (1, 3, 16):
+        gpr._chunks = chunks
+        np.testing.assert_allclose(nn(gpr._fused_log_likelihood_per_series()), nn(ref), rtol=tol)
+    gpr._chunks = 0
+    assert float(gpr.log_likelihood().cpu()) == pytest.approx(float(ref.sum().cpu()), rel=tol)
+
+
 def test_fused_gpr_falls_back_when_not_covered(rng):
-    """Three components / several outputs are not fused: log_likelihood takes the materialised route (still all HIP)."""
+    """Three components below d = 7 (the register kernels generate one or two) are not fused: log_likelihood takes the
+    materialised route (still all HIP)."""
     t = np.cumsum(0.1 + rng.random(size=(2, 30)), axis=-1)
     kern = mfa.Sum([mfa.Matern12(1.0, 1.0, device=DEV), mfa.Matern32(1.0, 1.0, device=DEV), mfa.Matern52(1.0, 1.0, device=DEV)])
+    assert kern.state_dim == 6
     gpr = mfa.GaussianProcessRegression((tt(t), tt(rng.normal(size=(2, 30, 1)))), kern, chol_obs_covariance=tt(0.3 * np.eye(1)))
     assert gpr._fused_log_likelihood_per_series() is None
     assert torch.isfinite(gpr.log_likelihood())
