@@ -262,6 +262,23 @@ def other_configs(dev):
         "note": "GaussianProcessRegression.log_likelihood through mf_gpr_matern_loglik (A_k, chol Q_k generated in registers); "
                 "NOT the headline metric: the boundary differs (time points + hyper-parameters instead of SSM tensors)"}
     del t_pts, y_obs, gpr
+    # config 4's MODEL: IndependentMultiOutput of three Matern-5/2 kernels (d = 9, 3 outputs), 512 series x 1000 points, from
+    # (t, y, hyper-parameters): fused into the row kernel since round 3 (csrc/mf_row_gpr.hpp) against the materialised route
+    bsz, tn = 512, 1000
+    t_pts = torch.cumsum(0.05 + 0.05 * torch.empty(bsz, tn, dtype=torch.float64, device=dev).exponential_(1.0, generator=g), dim=-1)
+    y_obs = torch.randn(bsz, tn, 3, dtype=torch.float64, device=dev, generator=g)
+    parts = [mfa.Matern52(0.5 + 1.5 * torch.rand(bsz, dtype=torch.float64, device=dev, generator=g),
+                          0.5 + 1.5 * torch.rand(bsz, dtype=torch.float64, device=dev, generator=g)) for _ in range(3)]
+    gpr = mfa.GaussianProcessRegression((t_pts, y_obs), mfa.IndependentMultiOutput(parts, jitter=1e-9),
+                                        chol_obs_covariance=(0.1 ** 0.5) * torch.eye(3, dtype=torch.float64, device=dev))
+    ms = _time_gpu(gpr.log_likelihood, iters=10)
+    gpr.fused = False
+    ms_mat = _time_gpu(gpr.log_likelihood, iters=5)
+    out["config4_gpr_3xMatern52_3outputs_B512_T1000_d9_f64"] = {
+        "fused_ms": ms, "materialised_ms": ms_mat, "fused_steps_per_s": bsz * tn / ms * 1e3,
+        "note": "GaussianProcessRegression.log_likelihood from (t, y, hyper-parameters): mf_gpr_matern_multi_loglik (every lane of the "
+                "row kernel generates its row of chol Q_k / column of A_k) against mf_sde_matern_transitions + mf_kf_loglik"}
+    del t_pts, y_obs, gpr
     # config 5: state_dim 64, T=2048, fp32, 32 spatial outputs, 8 series (LDS-tiled MFMA path)
     bsz, tn, d, m = 8, 2048, 64, 32
     kf = synthetic.kalman_filter_from(synthetic.make_dense_ssm(bsz, tn, d, m, dtype=torch.float32, device=dev))
