@@ -53,6 +53,12 @@ class ConditionalProcess:
         p0 = p0.expand(batch + (d, d)).contiguous()
         flat = lambda t, k: t.reshape((-1,) + tuple(t.shape[-k:])).contiguous()  # noqa: E731
         bsz = max(1, int(torch.tensor(batch).prod())) if batch else 1
+        if d > _lib.load().mf_max_state_dim():
+            # beyond the lane-per-point kernel (d <= 9): the same closed forms as batched products (the posterior chain and its
+            # moments above come from the row kernels / the tile engine)
+            mean, cov = _predict_state_dense(flat(idx, 1), flat(a_mt, 3), flat(q_mt, 3), flat(a_tp, 3), flat(q_tp, 3), flat(means, 2),
+                                             flat(covs, 3), None if sub is None else flat(sub, 3), flat(m0, 1), flat(p0, 2))
+            return mean.reshape(batch + (n_new, d)), cov.reshape(batch + (n_new, d, d))
         out_mean = torch.empty((bsz, n_new, d), dtype=dtype, device=dev)
         out_cov = torch.empty((bsz, n_new, d, d), dtype=dtype, device=dev)
         info = _lib.pivot_info(dev)
@@ -68,6 +74,36 @@ class ConditionalProcess:
         output covariances) - posterior.py:231-258 (zero mean function)."""
         emission = self.kernel.generate_emission_model(new_time_points)
         return emission.project_state_marginals_to_f(*self.predict_state(new_time_points), full_output_cov=full_output_cov)
+
+
+def _predict_state_dense(idx, a_mt, q_mt, a_tp, q_tp, means, covs, sub, m0, p0):
+    """``mf_sde_conditional_predict_*`` (csrc/mf_kernels.hpp: sde_predict_kernel) as batched products, for state dimensions beyond
+    that kernel: ``p(x_t) = N(D mu_- + E mu_+, T + [D E] S [D E]^T)`` with ``Q-+ = Q_tp + A_tp Q_mt A_tp^T``,
+    ``E = Q_mt A_tp^T Q-+^-1``, ``D = A_mt - E A_tp A_mt``, ``T = Q_mt - Q_mt A_tp^T Q-+^-1 A_tp Q_mt`` and ``(mu_-, mu_+, S)`` the
+    pairwise posterior marginal of the training points around ``t`` - the prior beyond the ends (conditionals.py:29-83,122-203,
+    380-485).  ``idx [B, Np]``: insertion index of every new point; everything else flat over the batch."""
+    tr = lambda t: t.transpose(-1, -2)                                   # noqa: E731
+    tri = torch.linalg.solve_triangular
+    n = means.shape[1]
+    g = a_tp @ q_mt
+    chol = torch.linalg.cholesky_ex(q_tp + g @ tr(a_tp), check_errors=False)[0]
+    v = tri(chol, g, upper=False)                                         # L^-1 A_tp Q_mt
+    t_m = q_mt - tr(v) @ v
+    e = tr(tri(tr(chol), v, upper=True))                                  # E = (L^-T V)^T
+    d_m = a_mt - e @ a_tp @ a_mt
+    has_m, has_p = (idx > 0), (idx < n)
+    pick = lambda src, i, k: torch.gather(src, 1, i.reshape(i.shape + (1,) * k).expand(i.shape + tuple(src.shape[2:])))  # noqa: E731
+    im, ip = (idx - 1).clamp(min=0), idx.clamp(max=n - 1)
+    mu_m = torch.where(has_m[..., None], pick(means, im, 1), m0[:, None, :])
+    mu_p = torch.where(has_p[..., None], pick(means, ip, 1), m0[:, None, :])
+    mean = (d_m @ mu_m[..., None] + e @ mu_p[..., None])[..., 0]
+    p_m = torch.where(has_m[..., None, None], pick(covs, im, 2), p0[:, None])
+    p_p = torch.where(has_p[..., None, None], pick(covs, ip, 2), p0[:, None])
+    x1, x2 = d_m @ p_m, e @ p_p
+    if sub is not None and n > 1:
+        c = pick(sub, im.clamp(max=n - 2), 2) * (has_m & has_p)[..., None, None].to(sub.dtype)     # Cov(x_+, x_-)
+        x1, x2 = x1 + e @ c, x2 + d_m @ tr(c)
+    return mean, t_m + x1 @ tr(d_m) + x2 @ tr(e)
 
 
 class AnalyticPosteriorProcess(ConditionalProcess):

@@ -201,7 +201,7 @@ def test_fused_gpr_falls_back_when_not_covered(rng):
 
 
 # ---- prediction at new time points (posterior.predict_f) ------------------------------------------------------------------------------
-@pytest.mark.parametrize("sig", [(3,), (5, 1), (5, 5), (1, 3, 5)])
+@pytest.mark.parametrize("sig", [(3,), (5, 1), (5, 5), (1, 3, 5), (5, 5, 5, 5), (3, 3, 3, 3, 3)])
 def test_posterior_predict_f_vs_dense_gp(rng, sig):
     """GaussianProcessRegression.posterior.predict_f / predict_y at new points - before, between, ON and after the training
     points - against the dense GP predictive distribution (markovflow/posterior.py:231-258, conditionals.py:29-83)."""
