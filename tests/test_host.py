@@ -303,3 +303,45 @@ def test_row_kernel_emulation_matches_the_oracle():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     mod.main()          # asserts the worst relative deviation over its cases < 1e-10
+
+
+def test_dense_prediction_closed_forms_against_joint_gaussian_conditioning():
+    """posterior._predict_state_dense (the route of state dimensions beyond the lane-per-point kernel) against a direct numpy
+    evaluation of conditionals.py:29-83,122-203 of the reference: x_t | x_-, x_+ ~ N(D x_- + E x_+, T), marginalised over the
+    pairwise posterior of the neighbours (the prior beyond the ends)."""
+    import numpy as np
+    import torch
+    from markovflow_amd.posterior import _predict_state_dense
+
+    rng = np.random.default_rng(5)
+    b, n, npts, d = 2, 5, 7, 11
+
+    def spd(*lead):
+        a = rng.normal(size=lead + (d, d))
+        return a @ np.swapaxes(a, -1, -2) + 0.5 * np.eye(d)
+
+    idx = np.array([[0, 1, 2, 3, 4, 5, 5], [0, 0, 2, 2, 3, 5, 1]])
+    a_mt, a_tp = 0.5 * rng.normal(size=(b, npts, d, d)), 0.5 * rng.normal(size=(b, npts, d, d))
+    q_mt, q_tp = spd(b, npts), spd(b, npts)
+    means, m0 = rng.normal(size=(b, n, d)), rng.normal(size=(b, d))
+    p0 = spd(b)
+    # a consistent joint over the training points is not needed: any pairwise (P-, P+, C) with a PSD joint will do
+    joint = spd(b, n)                                                       # marginal covariances
+    sub = 0.1 * rng.normal(size=(b, n - 1, d, d))                           # Cov(x_{k+1}, x_k)
+    t = lambda x: torch.tensor(x)                                            # noqa: E731
+    mean, cov = _predict_state_dense(t(idx), t(a_mt), t(q_mt), t(a_tp), t(q_tp), t(means), t(joint), t(sub), t(m0), t(p0))
+    for s in range(b):
+        for j in range(npts):
+            i = idx[s, j]
+            am, ap, qm, qp = a_mt[s, j], a_tp[s, j], q_mt[s, j], q_tp[s, j]
+            qpm = qp + ap @ qm @ ap.T
+            e = qm @ ap.T @ np.linalg.inv(qpm)
+            dm = am - e @ ap @ am
+            tm = qm - qm @ ap.T @ np.linalg.inv(qpm) @ ap @ qm
+            mu_m, pm = (means[s, i - 1], joint[s, i - 1]) if i > 0 else (m0[s], p0[s])
+            mu_p, pp = (means[s, i], joint[s, i]) if i < n else (m0[s], p0[s])
+            c = sub[s, i - 1] if 0 < i < n else np.zeros((d, d))
+            want_mean = dm @ mu_m + e @ mu_p
+            want_cov = tm + dm @ pm @ dm.T + e @ pp @ e.T + e @ c @ dm.T + dm @ c.T @ e.T
+            np.testing.assert_allclose(mean[s, j].numpy(), want_mean, rtol=1e-10, atol=1e-12)
+            np.testing.assert_allclose(cov[s, j].numpy(), want_cov, rtol=1e-9, atol=1e-11)
