@@ -56,8 +56,8 @@ int mf_max_state_dim_f64_loglik(void);   /* mf_kf_loglik_f64 only: the same on f
  *         kernels; more: the LDS-tile kernels, at any state dimension).
  * State dimension: 1..9 in fp32 and fp64: one lane per (series, time-chunk) with the state in registers up to d = 6 (fp32: 8),
  *         above that one 16-lane DPP row per (series, time-chunk) with one matrix row per lane (csrc/mf_row.hpp -
- *         BASELINE config 4, d = 9) - the rows also take 10 <= d <= 15 with up to four outputs; beyond that (and with more
- *         than four outputs at any d) 1 <= d <= 64 (fp32) or 32 (fp64) with 1 <= m <= 32 run one workgroup per (series,
+ *         BASELINE config 4, d = 9) - the rows also take 10 <= d <= 15, there with up to EIGHT outputs; beyond that (and with
+ *         more outputs than the register / row kernels take, at any d) 1 <= d <= 64 (fp32) or 32 (fp64) with 1 <= m <= 32 run one workgroup per (series,
  *         time-chunk) on LDS tiles and f32 / f64 MFMA (csrc/mf_big.hpp - BASELINE config 5, state_dim = 64).
  * Output: out[s] = add_const + term1 + term2 + 1/2 log|K^-1| - log|L|  (kalman_filter.py:233-253), i.e. the
  *         per-series log-likelihood; the terms that do not depend on the chain,
@@ -267,7 +267,7 @@ int mf_sde_matern_transitions_f32(int64_t B, int64_t n, int ncomp, const int* or
  *
  * mf_gpr_matern_multi_loglik_*: the same for IndependentMultiOutput (kernels/sde_kernel.py:826-880: one output per component,
  * H[o] = e_{first state of component o}; BASELINE config 4 = three Matern-5/2 components, three outputs): y [B,T,m] with
- * m = ncomp <= 4, rinv [m,m]; 7 <= d <= 15 (row kernels), -101 otherwise.
+ * m = ncomp <= 4 (<= 8 for d >= 10), rinv [m,m]; 7 <= d <= 15 (row kernels), -101 otherwise.
  */
 int mf_gpr_matern_loglik_f64(int64_t B, int64_t T, int ncomp, const int* orders, const double* lam, const double* var,
                              int per_series, const double* t, const double* y, const double* rinv, double jitter,

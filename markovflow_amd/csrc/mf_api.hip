@@ -52,7 +52,7 @@ int kf_loglik(int64_t B, int64_t Tn, int d, int m, const T* mu0, const T* cholP0
     if (!y) return -11;
     if (!Rinv) return -12;
     if (!out) return -15;
-    if (t && d < big_from && m <= 4) {
+    if (t && d < big_from && m <= (d > mf::MF_MAX_D ? 8 : 4)) {
         // d <= 9: every plan has a kernel.  10 <= d <= 15: the row kernels when the plan is theirs (at most four outputs, offsets
         // within a buffer descriptor), else -100 and the tile engine below takes the call
         const int rc = t->kf_loglik(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, add_const, out, ws, ws_bytes,
@@ -120,7 +120,7 @@ int gpr_matern_loglik(int64_t B, int64_t Tn, int ncomp, const int* orders, const
     }
     const auto* t = table_for<T>(d);
     if (!t) return -101;
-    if (m < 1 || m > 4) return -101;
+    if (m < 1 || m > (d > mf::MF_MAX_D ? 8 : 4)) return -101;
     if (B == 0) return 0;
     if (!lam) return -5;
     if (!var) return -6;

@@ -30,6 +30,9 @@ constexpr int D = MF_D;
 // For 10 <= d <= 15 this file is compiled with the ROW kernels only: a call whose plan needs a lane kernel returns -100 and the C
 // ABI hands it to the LDS-tile / MFMA engine (mf_api.hip).
 constexpr bool LANE = D <= MF_MAX_D;
+// outputs of the row log-likelihood kernels: four wherever lane kernels share the entry point, eight in the row-only builds (k
+// independent Matern-3/2 outputs are d = 2 k, m = k: five to seven outputs live at d = 10 ... 14)
+constexpr int ROW_MAXM = LANE ? MF_MAXM : 8;
 #define MF_LANE_LAUNCH(...)                                   \
     do {                                                      \
         if constexpr (LANE) { hipLaunchKernelGGL(__VA_ARGS__); } \
@@ -240,7 +243,7 @@ template <typename T> size_t plan_ws(long B, const KfPlan& pl) {
 }
 template <typename T> KfPlan kf_plan(long B, long Tn, int m, int rinv_per_step, long chunks, bool aligned16) {
     KfPlan pl{KF_PATH_DIRECT, 1, 0};
-    if (row_path<T>() && Tn >= 2 && m >= 1 && m <= MF_MAXM) {
+    if (row_path<T>() && Tn >= 2 && m >= 1 && m <= ROW_MAXM) {
         long P = chunks > 0 ? (chunks > Tn ? Tn : chunks) : cdiv(row_target_rows(), B);
         if (chunks <= 0) {
             const long maxP = Tn / 4 > 0 ? Tn / 4 : 1;
@@ -280,7 +283,7 @@ template <typename T> KfPlan kf_plan(long B, long Tn, int m, int rinv_per_step, 
 template <typename T> size_t kf_loglik_ws(long B, long Tn, long chunks) {
     size_t need = levels_ws<T>(B, 1);
     for (int per_step = 0; per_step < 2; ++per_step)
-        for (int m = 1; m <= MF_MAXM; ++m)
+        for (int m = 1; m <= ROW_MAXM; ++m)
             for (int al = 0; al < 2; ++al) {
                 const size_t w = plan_ws<T>(B, kf_plan<T>(B, Tn, m, per_step, chunks, al != 0));
                 if (w > need) need = w;
@@ -298,7 +301,7 @@ template <typename T>
 int kf_loglik(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ,
               const T* H, const T* y, const T* Rinv, int rinv_per_step, T add_const, T* out, void* ws,
               size_t ws_bytes, int* info, long chunks, hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
-    if (m < 1 || m > MF_MAXM) return LANE ? -4 : -100;       // (row-only build: more outputs belong to the tile engine)
+    if (m < 1 || m > ROW_MAXM) return LANE ? -4 : -100;      // (row-only build: more outputs belong to the tile engine)
     if (ws == nullptr) return -15;
     const bool aligned16 = ((reinterpret_cast<size_t>(A) | reinterpret_cast<size_t>(cholQ)) & 15) == 0;
     const KfPlan pl = kf_plan<T>(B, Tn, m, rinv_per_step, chunks, aligned16);
@@ -327,7 +330,13 @@ int kf_loglik(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A,
             if (m == 1) launch(integral_constant<int, 1>{});
             else if (m == 2) launch(integral_constant<int, 2>{});
             else if (m == 3) launch(integral_constant<int, 3>{});
-            else launch(integral_constant<int, 4>{});
+            else if (m == 4) launch(integral_constant<int, 4>{});
+            else if constexpr (!LANE) {
+                if (m == 5) launch(integral_constant<int, 5>{});
+                else if (m == 6) launch(integral_constant<int, 6>{});
+                else if (m == 7) launch(integral_constant<int, 7>{});
+                else launch(integral_constant<int, 8>{});
+            }
         }
     } else if (pl.path == KF_PATH_X) {
         constexpr int x_lds = LdsSpike<T, D>::BYTES;
@@ -1142,7 +1151,7 @@ int gpr_loglik(long B, long Tn, int ncomp, const int* orders, const T* lam, cons
     if constexpr (D >= 7 && D + 1 <= 16) {
         // 7 <= d <= 15: any concatenation of components, one output (Sum) or one per component (up to four), generated inside the
         // row kernel (mf_row_gpr.hpp)
-        if (ncomp > row::GPR_MAX_COMP || m < 1 || m > MF_MAXM || (multi ? m != ncomp : m != 1)) return -101;
+        if (ncomp > row::GPR_MAX_COMP || m < 1 || m > ROW_MAXM || (multi ? m != ncomp : m != 1)) return -101;
         if (ws == nullptr) return -15;
         const KfPlan pl = kf_plan<T>(B, Tn, m, 0, chunks, true);
         if (pl.path != KF_PATH_ROW) return -101;
@@ -1156,7 +1165,13 @@ int gpr_loglik(long B, long Tn, int ncomp, const int* orders, const T* lam, cons
         if (m == 1) hipLaunchKernelGGL((row::gpr_row_kernel<T, D, 1>), rgrid, block, 0, st, a, lvl0);
         else if (m == 2) hipLaunchKernelGGL((row::gpr_row_kernel<T, D, 2>), rgrid, block, 0, st, a, lvl0);
         else if (m == 3) hipLaunchKernelGGL((row::gpr_row_kernel<T, D, 3>), rgrid, block, 0, st, a, lvl0);
-        else hipLaunchKernelGGL((row::gpr_row_kernel<T, D, 4>), rgrid, block, 0, st, a, lvl0);
+        else if (m == 4) hipLaunchKernelGGL((row::gpr_row_kernel<T, D, 4>), rgrid, block, 0, st, a, lvl0);
+        else if constexpr (!LANE) {
+            if (m == 5) hipLaunchKernelGGL((row::gpr_row_kernel<T, D, 5>), rgrid, block, 0, st, a, lvl0);
+            else if (m == 6) hipLaunchKernelGGL((row::gpr_row_kernel<T, D, 6>), rgrid, block, 0, st, a, lvl0);
+            else if (m == 7) hipLaunchKernelGGL((row::gpr_row_kernel<T, D, 7>), rgrid, block, 0, st, a, lvl0);
+            else hipLaunchKernelGGL((row::gpr_row_kernel<T, D, 8>), rgrid, block, 0, st, a, lvl0);
+        }
         if (ev1) (void)hipEventRecord(ev1, st);
         return reduce_levels_row<T>(lvl0, B, p, add_const, out, info, st);
     }

@@ -81,8 +81,8 @@ class GaussianProcessRegression:
         m = self._observations.shape[-1]
         d = self._kernel.state_dim
         # register kernels (d <= 6): one or two components, one output; row kernels (7 <= d <= 15): any concatenation, one
-        # output (Sum) or one per component (IndependentMultiOutput, up to four) - BASELINE config 4 is 3 x Matern-5/2, 3 outputs
-        rows = 7 <= d <= 15 and len(comps) <= 15 and (m == len(comps) <= 4 if multi else m == 1)
+        # output (Sum) or one per component (IndependentMultiOutput, up to four; eight for d >= 10) - BASELINE config 4 is 3 x Matern-5/2, 3 outputs
+        rows = 7 <= d <= 15 and len(comps) <= 15 and (m == len(comps) <= (8 if d >= 10 else 4) if multi else m == 1)
         if not self.fused or not self._observations.is_cuda or not (rows or (not multi and len(comps) <= 2 and m == 1)):
             return None
         if torch.is_grad_enabled() and (self._kernel._needs_grad() or self._chol_obs_covariance.requires_grad

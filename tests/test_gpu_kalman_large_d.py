@@ -141,7 +141,9 @@ def test_large_d_edge_shapes(rng, dtype):
 # ---- 10 <= d <= 15: the row kernels (csrc/mf_rowwide_inst.hip), as for d = 7 ... 9 ---------------------------------------------------
 @pytest.mark.parametrize("dtype", [torch.float64, F32])
 @pytest.mark.parametrize("d,m,t,batch", [(10, 1, 7, (2,)), (11, 3, 130, (3,)), (12, 4, 64, (2,)), (13, 2, 33, ()), (14, 3, 200, (2,)),
-                                         (15, 4, 90, (3,)), (15, 1, 2, (1,)), (12, 3, 1000, (5,))])
+                                         (15, 4, 90, (3,)), (15, 1, 2, (1,)), (12, 3, 1000, (5,)),
+                                         # five to eight outputs: still the row kernels in the row-only builds
+                                         (10, 5, 60, (2,)), (14, 7, 130, (2,)), (15, 8, 33, (1,)), (12, 6, 200, (3,))])
 def test_row_kernels_10_to_15_vs_oracle(rng, dtype, d, m, t, batch):
     """kalman_filter.py:184-255 for 10 <= d <= 15 with up to four outputs: one 16-lane row per (series, chunk); every series
     against the oracle (fp64: 1e-9; fp32 on fp32-rounded inputs: 3e-4)."""
@@ -172,7 +174,7 @@ def test_row_kernels_10_to_15_time_partition_invariance(rng, d, chunks):
 
 def test_row_kernels_10_to_15_per_step_precisions_and_fallback(rng):
     """Per-step observation precisions (sites, kalman_filter.py:437-497) at d = 12 through the row kernel; five outputs at d = 12
-    are beyond it and take the LDS-tile path - same oracle, same tolerance."""
+    are within the row-only builds' eight, nine outputs are beyond them and take the LDS-tile path - same oracle, same tolerance."""
     d, t = 12, 60
     kw = random_ssm(rng, (), t, d, 1, well=True)
     prec = 0.5 + rng.random(size=(t, 1, 1))
@@ -181,8 +183,8 @@ def test_row_kernels_10_to_15_per_step_precisions_and_fallback(rng):
     kf = mfa.KalmanFilterWithSites(ssm, mfa.EmissionModel(tt(kw["h"], torch.float64)), sites)
     ref = O.kf_log_likelihood(**kw, r_inv=prec, log_det_obs_precision=np.sum(np.log(prec)))
     np.testing.assert_allclose(float(kf.log_likelihood().cpu()), ref, rtol=1e-9)
-    kw5 = random_ssm(rng, (2,), t, d, 5, well=True)
-    chol_r = np.linalg.cholesky(0.5 * np.eye(5) + 0.1)
+    kw5 = random_ssm(rng, (2,), t, d, 9, well=True)
+    chol_r = np.linalg.cholesky(0.5 * np.eye(9) + 0.1)
     ref5 = O.kf_log_likelihood(**kw5, r_inv=np.linalg.inv(chol_r @ chol_r.T))
     np.testing.assert_allclose(float(build_kf(kw5, chol_r, dtype=torch.float64).log_likelihood().cpu()), ref5, rtol=1e-9)
 

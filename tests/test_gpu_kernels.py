@@ -155,7 +155,9 @@ def test_fused_gpr_log_likelihood_equals_materialised_route(rng, dtype, sig):
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 @pytest.mark.parametrize("sig,multi", [((5, 5, 5), False), ((5, 5, 5), True), ((5, 3, 1, 3), False), ((5, 5, 5, 5), True),
-                                       ((3, 3, 3, 3, 3, 3, 3), False), ((5, 5, 5, 5, 5), False), ((5, 3, 3), True), ((1,) * 8, False)])
+                                       ((3, 3, 3, 3, 3, 3, 3), False), ((5, 5, 5, 5, 5), False), ((5, 3, 3), True), ((1,) * 8, False),
+                                       # five to eight independent outputs (row-only builds, d >= 10)
+                                       ((3,) * 5, True), ((3,) * 7, True), ((5,) * 5, True), ((1,) * 8 + (3,), False), ((3, 1) * 4, True)])
 def test_fused_gpr_row_kernel_equals_materialised_route(rng, dtype, sig, multi):
     """The row form of the fused route (csrc/mf_row_gpr.hpp, 7 <= d <= 15): any concatenation of Matern components as a Sum kernel
     (one output) or as IndependentMultiOutput (one output per component; BASELINE config 4 = 3 x Matern-5/2, 3 outputs), against
