@@ -7,7 +7,8 @@
 // kf_row_kernel reads a transition's (A_k, chol Q_k, b_k, H_k) - 1.6 kB per step at d = 9; here every lane generates its own row
 // of chol Q_k and its own column of A_k from dt_k and its component's two hyper-parameters (closed forms of kernels/matern.py:
 // 66-86, :299-356, :434-501; Q = P_inf - A P_inf A^T + jitter, sde_kernel.py:421-446), so a step reads 8 (1 + m) bytes.  The lanes
-// of one component compute the same 3 x 3 block: at most ~150 instructions per step against the ~1 000 of the elimination.
+// of one component compute the same 3 x 3 block (~200 instructions per step, one exp and three rsqrt among them, against the
+// ~1 000 of the elimination).
 #pragma once
 #include "mf_row.hpp"
 
@@ -27,52 +28,51 @@ template <typename T> struct GprRowArgs {
     int* info;
 };
 
-// one component's transition over dt: own row i of chol Q (crow, lower) and own column i of A (acol); prior: chol(P_inf + jitter)
+// one component's transition over dt: own row i of chol Q (crow, lower) and own column i of A (acol); prior: chol(P_inf + jitter).
+// A = exp(-l dt) (I + N dt + N^2 dt^2 / 2) with N = F + l I nilpotent; for Matern-5/2, N = [[l,1,0],[0,l,1],[-l^3,-3l^2,-2l]] and
+// N^2 = [[l^2,2l,1],[-l^3,-2l^2,-l],[l^4,2l^3,l^2]] written out, and Q = P - (A P) A^T with the five non-zeros of P_inf
+// (v, v l^2 / 3 twice with a minus sign in the corners, v l^4) - ~60 multiply-adds instead of the generic triple loops' ~250.
 template <typename T> MF_DEV void gpr_component(int order, T l, T v, T dt, T jitter, bool prior, int i, T (&crow)[3], T (&acol)[3]) {
-    T A[3][3], Pm[3][3], C[3][3];
-    MF_UNROLL for (int a = 0; a < 3; ++a) MF_UNROLL for (int b = 0; b < 3; ++b) { A[a][b] = T(0); Pm[a][b] = T(0); C[a][b] = T(0); }
-    const T e = exp(-l * dt);
-    int K;
+    T A[3][3], Q[3][3];                         // Q: lower triangle; rows / columns beyond the component's size: identity
+    MF_UNROLL for (int a = 0; a < 3; ++a) MF_UNROLL for (int b = 0; b < 3; ++b) { A[a][b] = T(0); Q[a][b] = a == b ? T(1) : T(0); }
+    const T e = prior ? T(0) : exp(-l * dt);
     if (order == 1) {
-        K = 1;
         A[0][0] = e;
-        Pm[0][0] = v;
+        Q[0][0] = v - e * e * v + jitter;
     } else if (order == 3) {
-        K = 2;
+        const T l2 = l * l, p1 = v * l2;
         A[0][0] = e * (T(1) + l * dt);
         A[0][1] = e * dt;
-        A[1][0] = -e * l * l * dt;
+        A[1][0] = -e * l2 * dt;
         A[1][1] = e * (T(1) - l * dt);
-        Pm[0][0] = v;
-        Pm[1][1] = v * l * l;
+        Q[0][0] = v - (A[0][0] * A[0][0] * v + A[0][1] * A[0][1] * p1) + jitter;
+        Q[1][0] = -(A[1][0] * A[0][0] * v + A[1][1] * A[0][1] * p1);
+        Q[1][1] = p1 - (A[1][0] * A[1][0] * v + A[1][1] * A[1][1] * p1) + jitter;
     } else {
-        K = 3;
-        const T l2 = l * l, l3 = l2 * l, h = T(0.5) * dt * dt;
-        const T N[3][3] = {{l, T(1), T(0)}, {T(0), l, T(1)}, {-l3, -T(3) * l2, -T(2) * l}};
-        MF_UNROLL for (int a = 0; a < 3; ++a)
-            MF_UNROLL for (int b = 0; b < 3; ++b) {
-                T n2 = T(0);
-                MF_UNROLL for (int q = 0; q < 3; ++q) n2 += N[a][q] * N[q][b];
-                A[a][b] = e * ((a == b ? T(1) : T(0)) + N[a][b] * dt + n2 * h);
-            }
-        const T l23 = l2 / T(3);
-        Pm[0][0] = v;
-        Pm[0][2] = -v * l23;
-        Pm[2][0] = -v * l23;
-        Pm[1][1] = v * l23;
-        Pm[2][2] = v * l2 * l2;
-    }
-    // Q = P - A P A^T + jitter on the K x K block (rows / columns beyond K: identity, never read)
-    T Q[3][3];
-    MF_UNROLL for (int a = 0; a < 3; ++a)
-        MF_UNROLL for (int b = 0; b <= a; ++b) {
-            T s = T(0);
-            if (!prior) {
-                MF_UNROLL for (int p = 0; p < 3; ++p)
-                    MF_UNROLL for (int q = 0; q < 3; ++q) s += A[a][p] * Pm[p][q] * A[b][q];
-            }
-            Q[a][b] = (a < K && b < K) ? Pm[a][b] - s + (a == b ? jitter : T(0)) : (a == b ? T(1) : T(0));
+        const T l2 = l * l, l3 = l2 * l, l4 = l2 * l2, h = T(0.5) * dt * dt;
+        A[0][0] = e * (T(1) + l * dt + l2 * h);
+        A[0][1] = e * (dt + T(2) * l * h);
+        A[0][2] = e * h;
+        A[1][0] = -e * l3 * h;
+        A[1][1] = e * (T(1) + l * dt - T(2) * l2 * h);
+        A[1][2] = e * (dt - l * h);
+        A[2][0] = e * (l4 * h - l3 * dt);
+        A[2][1] = e * (T(2) * l3 * h - T(3) * l2 * dt);
+        A[2][2] = e * (T(1) - T(2) * l * dt + l2 * h);
+        const T kap = v * l2 / T(3), p22 = v * l4;
+        T Mx[3][3];                              // A P
+        MF_UNROLL for (int a = 0; a < 3; ++a) {
+            Mx[a][0] = A[a][0] * v - A[a][2] * kap;
+            Mx[a][1] = A[a][1] * kap;
+            Mx[a][2] = A[a][2] * p22 - A[a][0] * kap;
         }
+        const T P[3][3] = {{v, T(0), -kap}, {T(0), kap, T(0)}, {-kap, T(0), p22}};
+        MF_UNROLL for (int a = 0; a < 3; ++a)
+            MF_UNROLL for (int b = 0; b <= a; ++b)
+                Q[a][b] = P[a][b] - (Mx[a][0] * A[b][0] + Mx[a][1] * A[b][1] + Mx[a][2] * A[b][2]) + (a == b ? jitter : T(0));
+    }
+    T C[3][3];
+    MF_UNROLL for (int a = 0; a < 3; ++a) MF_UNROLL for (int b = 0; b < 3; ++b) C[a][b] = T(0);
     MF_UNROLL for (int b = 0; b < 3; ++b) {
         T s = Q[b][b];
         MF_UNROLL for (int p = 0; p < b; ++p) s -= C[b][p] * C[b][p];
@@ -86,13 +86,17 @@ template <typename T> MF_DEV void gpr_component(int order, T l, T v, T dt, T jit
     }
     MF_UNROLL for (int b = 0; b < 3; ++b) {
         crow[b] = i == 0 ? C[0][b] : (i == 1 ? C[1][b] : C[2][b]);
-        acol[b] = prior ? T(0) : (i == 0 ? A[b][0] : (i == 1 ? A[b][1] : A[b][2]));
+        acol[b] = i == 0 ? A[b][0] : (i == 1 ? A[b][1] : A[b][2]);
     }
 }
 
 // Level 0 of the log-likelihood, conventions of kf_row_kernel (chunk c owns blocks [c T / P, (c+1) T / P); 64 threads = 4 chunks).
+// One wavefront per SIMD fewer than kf_row_kernel: the generator's 3 x 3 temporaries sit on top of the elimination state (at three
+// waves / 168 registers the d = 9 kernel spilt 230 B per lane inside the loop), and with no loads to hide the third wave buys little:
+// level-0 kernel at config 4's size 0.455 -> 0.377 ms together with the written-out closed forms of gpr_component.
+constexpr int gpr_row_waves(int d) { return d <= 9 ? 2 : row_waves_per_simd(d); }        // (d >= 10: already two / one)
 template <typename T, int D, int M>
-__global__ void __launch_bounds__(64, row_waves_per_simd(D)) gpr_row_kernel(GprRowArgs<T> a, RedSys<T> out) {
+__global__ void __launch_bounds__(64, gpr_row_waves(D)) gpr_row_kernel(GprRowArgs<T> a, RedSys<T> out) {
     static_assert(D + 1 <= 16 && M <= D, "one row of 16 lanes per chunk");
     const int lane = threadIdx.x;
     const int r = lane & 15;

@@ -95,19 +95,32 @@ class GaussianProcessRegression:
         bsz = t.shape[0]
         if bsz == 0 or n < 1:
             return None
-        lam = [c._lambda.to(dtype=dtype, device=dev) for c in comps]
-        var = [c._variance_t.to(dtype=dtype, device=dev) for c in comps]
-        per_series = any(x.dim() > 0 for x in lam + var)
-        if per_series:
-            lam_t = torch.stack([x.expand(batch).reshape(-1) for x in lam], dim=-1).contiguous()
-            var_t = torch.stack([x.expand(batch).reshape(-1) for x in var], dim=-1).contiguous()
+        # the kernel's hyper-parameter tensors ([B, ncomp] or [ncomp]), the noise precision and its log-determinant: a dozen
+        # small launches - at config 4's size more host time (0.25 ms) than the whole sweep takes on the device - so they are
+        # kept until a source tensor is replaced or written in place (tensor identity + autograd version counter)
+        sources = [c._lengthscale_t for c in comps] + [c._variance_t for c in comps] + [self._chol_obs_covariance]
+        key = (dtype, dev, batch) + tuple(x._version for x in sources)
+        cached = getattr(self, "_fused_cache", None)
+        if (cached is not None and cached[0] == key and len(cached[1]) == len(sources)
+                and all(a is b for a, b in zip(cached[1], sources))):          # (the cache holds the tensors: ids are not reused)
+            per_series, lam_t, var_t, chol, rinv, log_det_rinv = cached[2:]
         else:
-            lam_t, var_t = torch.stack(lam).contiguous(), torch.stack(var).contiguous()
-        chol = self._chol_obs_covariance.to(dtype=dtype, device=dev)
-        if m == 1:
-            rinv = (1.0 / (chol * chol)).reshape(1, 1).contiguous()
-        else:
-            rinv = torch.cholesky_inverse(chol.reshape(m, m)).contiguous()
+            lam = [c._lambda.to(dtype=dtype, device=dev) for c in comps]
+            var = [c._variance_t.to(dtype=dtype, device=dev) for c in comps]
+            per_series = any(x.dim() > 0 for x in lam + var)
+            if per_series:
+                lam_t = torch.stack([x.expand(batch).reshape(-1) for x in lam], dim=-1).contiguous()
+                var_t = torch.stack([x.expand(batch).reshape(-1) for x in var], dim=-1).contiguous()
+            else:
+                lam_t, var_t = torch.stack(lam).contiguous(), torch.stack(var).contiguous()
+            chol = self._chol_obs_covariance.to(dtype=dtype, device=dev)
+            if m == 1:
+                rinv = (1.0 / (chol * chol)).reshape(1, 1).contiguous()
+                log_det_rinv = torch.log(rinv[0, 0])
+            else:
+                rinv = torch.cholesky_inverse(chol.reshape(m, m)).contiguous()
+                log_det_rinv = -2.0 * torch.sum(torch.log(torch.diagonal(chol.reshape(m, m))))
+            self._fused_cache = (key, sources, per_series, lam_t, var_t, chol, rinv, log_det_rinv)
         lib = _lib.load()
         ws_bytes = int(lib.mf_kf_loglik_workspace_bytes(bsz, n, d, t.element_size(), self._chunks))
         if ws_bytes == 0:
@@ -127,7 +140,6 @@ class GaussianProcessRegression:
             return None                     # component signature not instantiated: materialise instead
         _lib.check(rc, "mf_gpr_matern_loglik")
         _lib.raise_on_info(info, "GaussianProcessRegression.log_likelihood", dev)
-        log_det_rinv = torch.log(rinv[0, 0]) if m == 1 else -2.0 * torch.sum(torch.log(torch.diagonal(chol.reshape(m, m))))
         const = -0.5 * math.log(2 * math.pi) * n * m + 0.5 * n * log_det_rinv
         return (out + const).reshape(batch)
 

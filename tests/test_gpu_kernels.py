@@ -233,3 +233,32 @@ def test_posterior_predict_f_vs_dense_gp(rng, sig):
     assert np.all(np.linalg.eigvalsh(nn(cov)) > -1e-9)
     _, full = post.predict_f(tt(t_new), full_output_cov=True)
     assert tuple(full.shape) == (bsz, n_new, 1, 1)
+
+
+def test_fused_gpr_follows_hyper_parameter_updates(rng):
+    """The fused route keeps its hyper-parameter tensors between calls: an in-place update (an optimiser step) or a replaced
+    tensor must be seen by the next call."""
+    bsz, n = 2, 80
+    t = np.cumsum(0.05 + rng.exponential(0.1, size=(bsz, n)), axis=-1)
+    y = rng.normal(size=(bsz, n, 3))
+    parts = [mfa.Matern52(tt(0.5 + rng.random(bsz)), tt(0.5 + rng.random(bsz)), jitter=1e-9) for _ in range(3)]
+    kern = mfa.IndependentMultiOutput(parts, jitter=1e-9)
+    chol = tt(np.sqrt(0.1) * np.eye(3))
+    gpr = mfa.GaussianProcessRegression((tt(t), tt(y)), kern, chol_obs_covariance=chol)
+
+    def both():
+        gpr.fused = True
+        a = float(gpr.log_likelihood().cpu())
+        gpr.fused = False
+        return a, float(gpr.log_likelihood().cpu())
+    a0, b0 = both()
+    assert a0 == pytest.approx(b0, rel=1e-10)
+    parts[1]._lengthscale_t.mul_(1.7)                    # in place
+    a1, b1 = both()
+    assert a1 == pytest.approx(b1, rel=1e-10) and abs(a1 - a0) > 1e-6 * abs(a0)
+    parts[2]._variance_t = parts[2]._variance_t * 0.5    # replaced
+    a2, b2 = both()
+    assert a2 == pytest.approx(b2, rel=1e-10) and abs(a2 - a1) > 1e-6 * abs(a1)
+    chol.mul_(1.3)                                       # the noise factor, in place
+    a3, b3 = both()
+    assert a3 == pytest.approx(b3, rel=1e-10) and abs(a3 - a2) > 1e-6 * abs(a2)
