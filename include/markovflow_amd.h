@@ -254,6 +254,20 @@ int mf_sde_matern_transitions_f32(int64_t B, int64_t n, int ncomp, const int* or
                                   void* stream);
 
 /*
+ * Reverse mode of mf_sde_matern_transitions_* with respect to the hyper-parameters (the reference differentiates matern.py /
+ * sde_kernel.py:421-446 and the Cholesky through TensorFlow: the GPR training step): for incoming gradients g_A, g_cholQ
+ * [B,n,d,d] (either may be NULL) writes out[b, k, c, 0 / 1] = d/d lam_c, d/d var_c of <g_A[b,k], A_k> + <g_cholQ[b,k], chol Q_k>;
+ * the caller sums over k (and over b for shared hyper-parameters).  One lane per (series, transition), the generator's closed
+ * forms evaluated in forward mode (csrc/mf_sde.hip: Dual2).
+ */
+int mf_sde_matern_transitions_grad_f64(int64_t B, int64_t n, int ncomp, const int* orders, const double* lam, const double* var,
+                                       int per_series, const double* dt, double jitter, const double* g_A, const double* g_cholQ,
+                                       double* out, void* stream);
+int mf_sde_matern_transitions_grad_f32(int64_t B, int64_t n, int ncomp, const int* orders, const float* lam, const float* var,
+                                       int per_series, const float* dt, float jitter, const float* g_A, const float* g_cholQ,
+                                       float* out, void* stream);
+
+/*
  * GaussianProcessRegression.log_likelihood (markovflow/models/gaussian_process_regression.py:150-160) for a Matern kernel or
  * a Sum of two, with the kernel -> state-space-model step FUSED into the Kalman sweep: A_k and chol(Q_k) are generated in
  * registers from dt_k = t_{k+1} - t_k, so a step reads 16 bytes (t, y) instead of the materialised tensors.  One output,

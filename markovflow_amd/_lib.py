@@ -47,6 +47,8 @@ _SIGS = {
                                           "Tp", "Tp", _vp, _vp]),
     "mf_sde_matern_transitions": (_int, [_i64, _i64, _int, ctypes.POINTER(ctypes.c_int), "Tp", "Tp", _int, "Tp", "T",
                                          "Tp", "Tp", "Tp", _vp]),
+    "mf_sde_matern_transitions_grad": (_int, [_i64, _i64, _int, ctypes.POINTER(ctypes.c_int), "Tp", "Tp", _int, "Tp", "T",
+                                              "Tp", "Tp", "Tp", _vp]),
 }
 _PLAIN = {
     "mf_version": (_int, []),

@@ -31,6 +31,38 @@ template <typename T> __device__ __forceinline__ T t_sqrt_(T x);
 template <> __device__ __forceinline__ float t_sqrt_<float>(float x) { return sqrtf(x); }
 template <> __device__ __forceinline__ double t_sqrt_<double>(double x) { return sqrt(x); }
 
+// Forward-mode derivative carrier with two tangents (d/d lam, d/d var): the gradient kernel below instantiates the SAME closed
+// forms (Comp::build, comp_chol) with it, so the derivative cannot drift from the value code.
+template <typename T> struct Dual2 {
+    T v, a, b;
+    __device__ __forceinline__ Dual2() {}
+    __device__ __forceinline__ Dual2(T x) : v(x), a(T(0)), b(T(0)) {}
+    __device__ __forceinline__ Dual2(T x, T da, T db) : v(x), a(da), b(db) {}
+};
+template <typename T> __device__ __forceinline__ Dual2<T> operator+(Dual2<T> x, Dual2<T> y) { return {x.v + y.v, x.a + y.a, x.b + y.b}; }
+template <typename T> __device__ __forceinline__ Dual2<T> operator-(Dual2<T> x, Dual2<T> y) { return {x.v - y.v, x.a - y.a, x.b - y.b}; }
+template <typename T> __device__ __forceinline__ Dual2<T> operator-(Dual2<T> x) { return {-x.v, -x.a, -x.b}; }
+template <typename T> __device__ __forceinline__ Dual2<T> operator*(Dual2<T> x, Dual2<T> y) {
+    return {x.v * y.v, x.a * y.v + x.v * y.a, x.b * y.v + x.v * y.b};
+}
+template <typename T> __device__ __forceinline__ Dual2<T> operator/(Dual2<T> x, Dual2<T> y) {
+    const T q = x.v / y.v;
+    return {q, (x.a - q * y.a) / y.v, (x.b - q * y.b) / y.v};
+}
+template <typename T> __device__ __forceinline__ Dual2<T>& operator+=(Dual2<T>& x, Dual2<T> y) { x = x + y; return x; }
+template <typename T> __device__ __forceinline__ Dual2<T>& operator-=(Dual2<T>& x, Dual2<T> y) { x = x - y; return x; }
+template <typename T> __device__ __forceinline__ bool operator==(Dual2<T> x, Dual2<T> y) { return x.v == y.v; }
+template <> __device__ __forceinline__ Dual2<float> t_exp<Dual2<float>>(Dual2<float> x) { const float e = expf(x.v); return {e, e * x.a, e * x.b}; }
+template <> __device__ __forceinline__ Dual2<double> t_exp<Dual2<double>>(Dual2<double> x) { const double e = exp(x.v); return {e, e * x.a, e * x.b}; }
+template <> __device__ __forceinline__ Dual2<float> t_sqrt_<Dual2<float>>(Dual2<float> x) {
+    const float r = sqrtf(x.v);
+    return {r, 0.5f * x.a / r, 0.5f * x.b / r};
+}
+template <> __device__ __forceinline__ Dual2<double> t_sqrt_<Dual2<double>>(Dual2<double> x) {
+    const double r = sqrt(x.v);
+    return {r, 0.5 * x.a / r, 0.5 * x.b / r};
+}
+
 // A (K x K) and Pinf (K x K) of one Matern component; lam = sqrt(order) / lengthscale
 template <typename T, int K> struct Comp {
     T A[K][K], P[K][K];
@@ -72,22 +104,17 @@ template <typename T, int K> struct Comp {
     }
 };
 
-// the component's blocks of ONE of A / chol(Q) / Q (which = 0 / 1 / 2) into a d x d image `blk` (an exactly zero Q passes
-// through as a zero factor)
+// Q = Pinf - A Pinf A^T + jitter (symmetrised) and its lower Cholesky factor L (an exactly zero Q passes through as a zero factor:
+// `zero`)
 template <typename T, int K>
-__device__ __forceinline__ void emit(const Comp<T, K>& c, T jitter, int d, int off, int which, T* __restrict__ blk) {
-    if (which == 0) {
-        for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) blk[(off + i) * d + off + j] = c.A[i][j];
-        return;
-    }
-    T AP[K][K], Q[K][K];
+__device__ __forceinline__ void comp_chol(const Comp<T, K>& c, T jitter, T (&Q)[K][K], T (&L)[K][K], bool& zero, bool want_chol) {
+    T AP[K][K];
     for (int i = 0; i < K; ++i)
         for (int j = 0; j < K; ++j) {
             T a = T(0);
             for (int l = 0; l < K; ++l) a += c.A[i][l] * c.P[l][j];
             AP[i][j] = a;
         }
-    bool zero = true;
     for (int i = 0; i < K; ++i)
         for (int j = 0; j < K; ++j) {
             T a = T(0);
@@ -96,27 +123,33 @@ __device__ __forceinline__ void emit(const Comp<T, K>& c, T jitter, int d, int o
         }
     for (int i = 0; i < K; ++i)
         for (int j = 0; j < i; ++j) { const T m = T(0.5) * (Q[i][j] + Q[j][i]); Q[i][j] = m; Q[j][i] = m; }
-    if (which == 2) {
-        for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) blk[(off + i) * d + off + j] = Q[i][j];
-        return;
-    }
-    for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) zero &= (Q[i][j] == T(0));
-    T L[K][K];
-    for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) L[i][j] = T(0);
-    if (!zero) {
-        for (int j = 0; j < K; ++j) {
-            T s = Q[j][j];
-            for (int l = 0; l < j; ++l) s -= L[j][l] * L[j][l];
-            const T ljj = t_sqrt_<T>(s);
-            L[j][j] = ljj;
-            for (int i = j + 1; i < K; ++i) {
-                T v = Q[i][j];
-                for (int l = 0; l < j; ++l) v -= L[i][l] * L[j][l];
-                L[i][j] = v / ljj;
-            }
+    zero = true;
+    for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) { zero &= (Q[i][j] == T(0)); L[i][j] = T(0); }
+    if (!want_chol || zero) return;
+    for (int j = 0; j < K; ++j) {
+        T s = Q[j][j];
+        for (int l = 0; l < j; ++l) s -= L[j][l] * L[j][l];
+        const T ljj = t_sqrt_<T>(s);
+        L[j][j] = ljj;
+        for (int i = j + 1; i < K; ++i) {
+            T v = Q[i][j];
+            for (int l = 0; l < j; ++l) v -= L[i][l] * L[j][l];
+            L[i][j] = v / ljj;
         }
     }
-    for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) blk[(off + i) * d + off + j] = L[i][j];
+}
+
+// the component's blocks of ONE of A / chol(Q) / Q (which = 0 / 1 / 2) into a d x d image `blk`
+template <typename T, int K>
+__device__ __forceinline__ void emit(const Comp<T, K>& c, T jitter, int d, int off, int which, T* __restrict__ blk) {
+    if (which == 0) {
+        for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) blk[(off + i) * d + off + j] = c.A[i][j];
+        return;
+    }
+    T Q[K][K], L[K][K];
+    bool zero;
+    comp_chol<T, K>(c, jitter, Q, L, zero, which == 1);
+    for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) blk[(off + i) * d + off + j] = which == 2 ? Q[i][j] : L[i][j];
 }
 
 // One wavefront per 64 consecutive (series, transition) pairs: every lane builds its d x d block in an LDS slice (odd
@@ -194,6 +227,93 @@ int run(int64_t B, int64_t n, int ncomp, const int* orders, const T* lam, const 
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
+// ---- reverse mode of the generator: d/d(lam, var) of  sum_k <gA_k, A_k> + <gC_k, chol Q_k> ----------------------------------------------
+// (the hyper-parameter gradient of GaussianProcessRegression.log_likelihood: the reference differentiates matern.py / sde_kernel.py
+// :421-446 and the banded Cholesky through TensorFlow; here gA, gC come from the Fisher-identity backward of the log-likelihood.)
+// One lane per (series, transition): the component's closed forms in forward mode (Dual2: tangents d/d lam, d/d var), contracted
+// with the incoming gradients' diagonal blocks; out [B, n, ncomp, 2] - summed over the transitions by the caller (deterministic).
+template <typename T, int K>
+__device__ __forceinline__ void grad_component(T lam, T var, T dt, T jitter, int d, int off, const T* __restrict__ gA,
+                                               const T* __restrict__ gC, T& g_lam, T& g_var) {
+    using Du = Dual2<T>;
+    Comp<Du, K> c;
+    c.build(Du(lam, T(1), T(0)), Du(var, T(0), T(1)), Du(dt));
+    g_lam = T(0);
+    g_var = T(0);
+    if (gA) {
+        for (int i = 0; i < K; ++i)
+            for (int j = 0; j < K; ++j) {
+                const T g = gA[(off + i) * d + off + j];
+                g_lam += g * c.A[i][j].a;
+                g_var += g * c.A[i][j].b;
+            }
+    }
+    if (gC) {
+        Du Q[K][K], L[K][K];
+        bool zero;
+        comp_chol<Du, K>(c, Du(jitter), Q, L, zero, true);
+        if (!zero) {
+            for (int i = 0; i < K; ++i)
+                for (int j = 0; j <= i; ++j) {
+                    const T g = gC[(off + i) * d + off + j];
+                    g_lam += g * L[i][j].a;
+                    g_var += g * L[i][j].b;
+                }
+        }
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(64) matern_transitions_grad_kernel(long B, long n, Spec sp, const T* __restrict__ lam,
+                                                                     const T* __restrict__ var, long hstride,
+                                                                     const T* __restrict__ dt, T jitter, const T* __restrict__ gA,
+                                                                     const T* __restrict__ gC, T* __restrict__ out) {
+    const long id = (long)blockIdx.x * 64 + threadIdx.x;
+    if (id >= B * n) return;
+    const long s = id / n;
+    const int d = sp.d;
+    const T delta = dt[id];
+    const T* ga = gA ? gA + id * d * d : nullptr;
+    const T* gc = gC ? gC + id * d * d : nullptr;
+    for (int c = 0; c < sp.ncomp; ++c) {
+        const T l = lam[s * hstride + c], v = var[s * hstride + c];
+        T gl, gv;
+        if (sp.order[c] == 1) grad_component<T, 1>(l, v, delta, jitter, d, sp.off[c], ga, gc, gl, gv);
+        else if (sp.order[c] == 3) grad_component<T, 2>(l, v, delta, jitter, d, sp.off[c], ga, gc, gl, gv);
+        else grad_component<T, 3>(l, v, delta, jitter, d, sp.off[c], ga, gc, gl, gv);
+        out[(id * sp.ncomp + c) * 2] = gl;
+        out[(id * sp.ncomp + c) * 2 + 1] = gv;
+    }
+}
+
+template <typename T>
+int run_grad(int64_t B, int64_t n, int ncomp, const int* orders, const T* lam, const T* var, int per_series, const T* dt, T jitter,
+             const T* gA, const T* gC, T* out, void* stream) {
+    if (B < 0) return -1;
+    if (n < 0) return -2;
+    if (ncomp < 1 || ncomp > MAXC) return -3;
+    if (!orders) return -4;
+    Spec sp;
+    sp.ncomp = ncomp;
+    int off = 0;
+    for (int c = 0; c < ncomp; ++c) {
+        if (orders[c] != 1 && orders[c] != 3 && orders[c] != 5) return -4;
+        sp.order[c] = orders[c];
+        sp.off[c] = off;
+        off += (orders[c] + 1) / 2;
+    }
+    sp.d = off;
+    if (B == 0 || n == 0) return 0;
+    if (!lam) return -5;
+    if (!var) return -6;
+    if (!dt) return -8;
+    if (!out) return -12;
+    const long total = B * n;
+    hipLaunchKernelGGL((matern_transitions_grad_kernel<T>), dim3((unsigned)((total + 63) / 64)), dim3(64), 0,
+                       static_cast<hipStream_t>(stream), (long)B, (long)n, sp, lam, var, per_series ? (long)ncomp : 0L, dt, jitter,
+                       gA, gC, out);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
 // R^-1 = (L L^T)^-1 from the Cholesky factor of the observation covariance (KalmanFilter._r_inv, kalman_filter.py:341-348: a
 // tf.linalg.cholesky_solve against the identity).  m <= 32: one wavefront, thread j solves column j of L^-1 by forward
 // substitution, then the threads share the m^2 entries of L^-T L^-1.  ONE launch instead of the eleven small torch / rocBLAS
@@ -250,6 +370,17 @@ int mf_sde_matern_transitions_f32(int64_t B, int64_t n, int ncomp, const int* or
                                   int per_series, const float* dt, float jitter, float* A, float* cholQ, float* Q,
                                   void* stream) {
     return run<float>(B, n, ncomp, orders, lam, var, per_series, dt, jitter, A, cholQ, Q, stream);
+}
+
+int mf_sde_matern_transitions_grad_f64(int64_t B, int64_t n, int ncomp, const int* orders, const double* lam, const double* var,
+                                       int per_series, const double* dt, double jitter, const double* g_A, const double* g_cholQ,
+                                       double* out, void* stream) {
+    return run_grad<double>(B, n, ncomp, orders, lam, var, per_series, dt, jitter, g_A, g_cholQ, out, stream);
+}
+int mf_sde_matern_transitions_grad_f32(int64_t B, int64_t n, int ncomp, const int* orders, const float* lam, const float* var,
+                                       int per_series, const float* dt, float jitter, const float* g_A, const float* g_cholQ,
+                                       float* out, void* stream) {
+    return run_grad<float>(B, n, ncomp, orders, lam, var, per_series, dt, jitter, g_A, g_cholQ, out, stream);
 }
 
 }  // extern "C"

@@ -116,11 +116,14 @@ class SDEKernel(abc.ABC):
 
     def _device_transitions(self, time_deltas: torch.Tensor, want_chol: bool, want_cov: bool):
         """(A, chol Q, Q) for ``time_deltas`` of shape ``batch_shape + [n]`` through the HIP kernel."""
-        if self._needs_grad():
-            return self._torch_transitions(time_deltas, want_chol, want_cov)
         comps = self._components()
         batch = tuple(time_deltas.shape[:-1])
         n, d = time_deltas.shape[-1], self.state_dim
+        needs_grad = self._needs_grad()
+        if needs_grad and (want_cov or not time_deltas.is_cuda or (torch.is_grad_enabled() and time_deltas.requires_grad)
+                           or time_deltas.numel() == 0):
+            # Q itself, or a gradient with respect to the time points, is asked for: differentiable torch ops
+            return self._torch_transitions(time_deltas, want_chol, want_cov)
         dt = time_deltas.reshape(-1, n).contiguous()
         bsz = dt.shape[0]
         lam = [c._lambda.to(dtype=dt.dtype, device=dt.device) for c in comps]
@@ -131,6 +134,13 @@ class SDEKernel(abc.ABC):
             var_t = torch.stack([x.expand(batch).reshape(-1) for x in var], dim=-1).contiguous()
         else:
             lam_t, var_t = torch.stack(lam).contiguous(), torch.stack(var).contiguous()
+        if needs_grad:
+            # hyper-parameters under a gradient (the GPR training step): HIP generator forward AND backward
+            # (_MaternTransitions); lam_t / var_t were assembled from the leaves by differentiable torch ops above
+            a_s, chol = _MaternTransitions.apply(dt, lam_t, var_t, tuple(c.order for c in comps), bool(per_series), float(self._jitter),
+                                                 bool(want_chol))
+            shape = batch + (n, d, d)
+            return a_s.reshape(shape), (chol.reshape(shape) if want_chol else None), None
         orders = (ctypes.c_int * len(comps))(*[c.order for c in comps])
         a_s = torch.empty((bsz, n, d, d), dtype=dt.dtype, device=dt.device)
         chol = torch.empty_like(a_s) if want_chol else None
@@ -199,6 +209,49 @@ class SDEKernel(abc.ABC):
     def __add__(self, other: "SDEKernel") -> "Sum":
         assert self.output_dim == other.output_dim                         # sde_kernel.py:342-345
         return Sum([self, other])
+
+
+class _MaternTransitions(torch.autograd.Function):
+    """``(A [B,n,d,d], chol Q [B,n,d,d])`` of a concatenation of Matern components as a differentiable function of the stacked
+    hyper-parameters ``lam [B,ncomp] | [ncomp]`` (= sqrt(order) / lengthscale) and ``var`` - forward: the HIP generator
+    (``mf_sde_matern_transitions_*``); backward: the same closed forms in forward mode inside one kernel per (series, transition)
+    (``mf_sde_matern_transitions_grad_*``), summed over the transitions here.  The reference differentiates matern.py /
+    sde_kernel.py:421-446 and a batched Cholesky through TensorFlow; the torch restatement of that (``_torch_transitions``) cost
+    350 of the 373 ms of a GPR training step at B=1024, T=10000, d=6."""
+
+    @staticmethod
+    def forward(ctx, dt, lam_t, var_t, orders, per_series, jitter, want_chol):
+        bsz, n = dt.shape
+        d = sum((o + 1) // 2 for o in orders)
+        c_orders = (ctypes.c_int * len(orders))(*orders)
+        a_s = torch.empty((bsz, n, d, d), dtype=dt.dtype, device=dt.device)
+        chol = torch.empty_like(a_s) if want_chol else None
+        lam_c, var_c = lam_t.detach().contiguous(), var_t.detach().contiguous()
+        _lib.call("mf_sde_matern_transitions", dt.dtype, bsz, n, len(orders), c_orders, _lib.ptr(lam_c), _lib.ptr(var_c),
+                  int(per_series), _lib.ptr(dt.detach()), jitter, _lib.ptr(a_s), _lib.ptr(chol), None, _lib.stream_ptr(dt.device))
+        ctx.save_for_backward(dt.detach(), lam_c, var_c)
+        ctx.meta = (orders, per_series, jitter)
+        if not want_chol:
+            chol = a_s.new_zeros(())
+            ctx.mark_non_differentiable(chol)
+        return a_s, chol
+
+    @staticmethod
+    def backward(ctx, g_a, g_chol):
+        dt, lam_c, var_c = ctx.saved_tensors
+        orders, per_series, jitter = ctx.meta
+        bsz, n = dt.shape
+        c_orders = (ctypes.c_int * len(orders))(*orders)
+        part = torch.empty((bsz, n, len(orders), 2), dtype=dt.dtype, device=dt.device)
+        with torch.no_grad():
+            ga = None if g_a is None else g_a.contiguous()
+            gc = None if (g_chol is None or g_chol.dim() == 0) else g_chol.contiguous()
+            _lib.call("mf_sde_matern_transitions_grad", dt.dtype, bsz, n, len(orders), c_orders, _lib.ptr(lam_c), _lib.ptr(var_c),
+                      int(per_series), _lib.ptr(dt), jitter, _lib.ptr(ga), _lib.ptr(gc), _lib.ptr(part), _lib.stream_ptr(dt.device))
+            g = torch.sum(part, dim=1)                                   # [B, ncomp, 2]
+            if not per_series:
+                g = torch.sum(g, dim=0)                                  # shared hyper-parameters: [ncomp, 2]
+        return None, g[..., 0].contiguous(), g[..., 1].contiguous(), None, None, None, None
 
 
 class StationaryKernel(SDEKernel, abc.ABC):
