@@ -262,3 +262,34 @@ def test_fused_gpr_follows_hyper_parameter_updates(rng):
     chol.mul_(1.3)                                       # the noise factor, in place
     a3, b3 = both()
     assert a3 == pytest.approx(b3, rel=1e-10) and abs(a3 - a2) > 1e-6 * abs(a2)
+
+
+@pytest.mark.parametrize("per_series", [True, False])
+@pytest.mark.parametrize("sig", [(5, 3, 1), (5, 5, 5), (3,), (1, 1)])
+def test_generator_backward_equals_autograd_through_the_closed_forms(rng, sig, per_series):
+    """mf_sde_matern_transitions_grad_* (the closed forms of matern.py / sde_kernel.py:421-446 + Cholesky in forward mode, one kernel)
+    against torch autograd through the same closed forms (kernels._torch_transitions): gradients of a random linear functional of
+    (A, chol Q) with respect to every lengthscale and variance, per-series and shared hyper-parameters."""
+    cls = {1: mfa.Matern12, 3: mfa.Matern32, 5: mfa.Matern52}
+    bsz, n = 3, 40
+    dts = tt(0.05 + rng.exponential(0.2, size=(bsz, n)))
+
+    def leaves():
+        shape = (bsz,) if per_series else ()
+        return ([tt(0.5 + rng.random(shape)).requires_grad_(True) for _ in sig], [tt(0.5 + rng.random(shape)).requires_grad_(True) for _ in sig])
+    ls, var = leaves()
+    kern_parts = [cls[o](l, v, jitter=1e-8) for o, l, v in zip(sig, ls, var)]
+    kern = kern_parts[0] if len(sig) == 1 else mfa.Sum(kern_parts, jitter=1e-8)
+    d = kern.state_dim
+    w_a, w_c = tt(rng.normal(size=(bsz, n, d, d))), torch.tril(tt(rng.normal(size=(bsz, n, d, d))))
+    a_s, chol, _ = kern._device_transitions(dts, True, False)               # HIP forward + backward
+    (torch.sum(w_a * a_s) + torch.sum(w_c * chol)).backward()
+    got = [x.grad.clone() for x in ls + var]
+    for x in ls + var:
+        x.grad = None
+    a_t, chol_t, _ = kern._torch_transitions(dts, True, False)              # differentiable torch ops
+    np.testing.assert_allclose(nn(a_s), nn(a_t), rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(nn(chol), nn(chol_t), rtol=1e-9, atol=1e-12)
+    (torch.sum(w_a * a_t) + torch.sum(w_c * chol_t)).backward()
+    for g, x in zip(got, ls + var):
+        np.testing.assert_allclose(nn(g), nn(x.grad), rtol=1e-8, atol=1e-10)
