@@ -153,10 +153,12 @@ int reduce_levels(RedSys<T> cur, long B, char* p, T add_const, T* out, int* info
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
-// The same with the row kernels (used behind the row level-0 kernel).
+// The same with the row kernels (used behind the row level-0 kernel - and, for d = 4 ... 6, behind the lane-per-chunk level-0
+// kernels too: the levels have few blocks (B x 8, then B) and a row's reduction step is ~300 instructions against a lane's ~2 700).
+constexpr bool ROW_RED_SMALL = D >= 4 && D <= 6;
 template <typename T>
 int reduce_levels_row(RedSys<T> cur, long B, char* p, T add_const, T* out, int* info, hipStream_t st) {
-    if constexpr (D >= 7 && D + 1 <= 16) {
+    if constexpr ((D >= 7 || ROW_RED_SMALL) && D + 1 <= 16) {
         while (cur.n > row_red_final()) {
             const long P = cdiv(cur.n, row_red_chunk());
             RedSys<T> nxt = carve<T>(p, B, P);
@@ -238,8 +240,9 @@ struct KfPlan {
     KfPath path;
     long P, L;       // chunks per series; transitions per chunk (LDS kernel)
 };
+inline bool row_reduction(KfPath path) { return path == KF_PATH_ROW || (ROW_RED_SMALL && path == KF_PATH_LDS); }
 template <typename T> size_t plan_ws(long B, const KfPlan& pl) {
-    return pl.path == KF_PATH_ROW ? levels_ws<T>(B, pl.P, row_red_chunk(), row_red_final()) : levels_ws<T>(B, pl.P);
+    return row_reduction(pl.path) ? levels_ws<T>(B, pl.P, row_red_chunk(), row_red_final()) : levels_ws<T>(B, pl.P);
 }
 template <typename T> KfPlan kf_plan(long B, long Tn, int m, int rinv_per_step, long chunks, bool aligned16) {
     KfPlan pl{KF_PATH_DIRECT, 1, 0};
@@ -291,7 +294,7 @@ template <typename T> size_t kf_loglik_ws(long B, long Tn, long chunks) {
     if (Tn >= 2) {                                            // the fused GPR route (gpr_loglik) partitions like this
         long P = 1, L = 1;
         lds_partition(B, Tn, chunks, P, L);
-        const size_t w = levels_ws<T>(B, P);
+        const size_t w = ROW_RED_SMALL ? levels_ws<T>(B, P, row_red_chunk(), row_red_final()) : levels_ws<T>(B, P);
         if (w > need) need = w;
     }
     return need;
@@ -377,7 +380,7 @@ int kf_loglik(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A,
         else MF_LANE_LAUNCH((kf_chunk_kernel<T, D, 0, false>), grid, block, 0, st, a, lvl0);
     }
     if (ev1) (void)hipEventRecord(ev1, st);
-    if (pl.path == KF_PATH_ROW) return reduce_levels_row<T>(lvl0, B, p, add_const, out, info, st);
+    if (row_reduction(pl.path)) return reduce_levels_row<T>(lvl0, B, p, add_const, out, info, st);
     return reduce_levels<T>(lvl0, B, p, add_const, out, info, st);
 }
 
@@ -1180,7 +1183,8 @@ int gpr_loglik(long B, long Tn, int ncomp, const int* orders, const T* lam, cons
     if (ws == nullptr) return -15;
     long P = 1, L = 1;
     if (Tn >= 2) lds_partition(B, Tn, chunks, P, L);
-    if (ws_bytes < levels_ws<T>(B, P)) return -15;          // checked against the partition that is actually launched
+    const size_t need = ROW_RED_SMALL ? levels_ws<T>(B, P, row_red_chunk(), row_red_final()) : levels_ws<T>(B, P);
+    if (ws_bytes < need) return -15;                        // checked against the partition that is actually launched
     GprArgs<T> a{B, Tn, lam, var, per_series ? (long)ncomp : 0L, t, y, rinv, jitter, P, L, info};
     char* p = static_cast<char*>(ws);
     RedSys<T> lvl0 = carve<T>(p, B, P);
@@ -1197,6 +1201,7 @@ int gpr_loglik(long B, long Tn, int ncomp, const int* orders, const T* lam, cons
     if constexpr (D == 6) { if (o0 == 5 && o1 == 5) rc = gpr_launch<T, 5, 5>(a, lvl0, st); }
     if (rc != 0) return rc;
     if (ev1) (void)hipEventRecord(ev1, st);
+    if (ROW_RED_SMALL) return reduce_levels_row<T>(lvl0, B, p, add_const, out, info, st);
     return reduce_levels<T>(lvl0, B, p, add_const, out, info, st);
 }
 
