@@ -274,10 +274,23 @@ def other_configs(dev):
     ms = _time_gpu(gpr.log_likelihood, iters=10)
     gpr.fused = False
     ms_mat = _time_gpu(gpr.log_likelihood, iters=5)
+    # the training step of the same model: forward + backward w.r.t. lengthscales, variances and the noise factor
+    ls = [(0.5 + 1.5 * torch.rand(bsz, dtype=torch.float64, device=dev, generator=g)).requires_grad_(True) for _ in range(3)]
+    vs = [(0.5 + 1.5 * torch.rand(bsz, dtype=torch.float64, device=dev, generator=g)).requires_grad_(True) for _ in range(3)]
+    chol_r = ((0.1 ** 0.5) * torch.eye(3, dtype=torch.float64, device=dev)).requires_grad_(True)
+
+    def train_step():
+        for x in ls + vs + [chol_r]:
+            x.grad = None
+        kern = mfa.IndependentMultiOutput([mfa.Matern52(l, v, jitter=1e-9) for l, v in zip(ls, vs)], jitter=1e-9)
+        mfa.GaussianProcessRegression((t_pts, y_obs), kern, chol_obs_covariance=chol_r).log_likelihood().backward()
+    ms_train = _time_gpu(train_step, iters=5)
     out["config4_gpr_3xMatern52_3outputs_B512_T1000_d9_f64"] = {
-        "fused_ms": ms, "materialised_ms": ms_mat, "fused_steps_per_s": bsz * tn / ms * 1e3,
+        "fused_ms": ms, "materialised_ms": ms_mat, "fused_steps_per_s": bsz * tn / ms * 1e3, "training_step_ms": ms_train,
         "note": "GaussianProcessRegression.log_likelihood from (t, y, hyper-parameters): mf_gpr_matern_multi_loglik (every lane of the "
-                "row kernel generates its row of chol Q_k / column of A_k) against mf_sde_matern_transitions + mf_kf_loglik"}
+                "row kernel generates its row of chol Q_k / column of A_k) against mf_sde_matern_transitions + mf_kf_loglik; "
+                "training_step_ms: log_likelihood forward + backward w.r.t. every hyper-parameter (HIP generator backward + "
+                "Fisher-identity backward of the filter)"}
     del t_pts, y_obs, gpr
     # config 5: state_dim 64, T=2048, fp32, 32 spatial outputs, 8 series (LDS-tiled MFMA path)
     bsz, tn, d, m = 8, 2048, 64, 32
