@@ -231,9 +231,18 @@ template <typename T> bool row_path() {
     static const bool on = [] { const char* e = mf_knob("MF_KF_ROW"); return !(e && e[0] == '0'); }();
     return on && D + 1 <= 16 && ((sizeof(T) == 8 && D >= 7) || (sizeof(T) == 4 && D >= 9));
 }
-// rows that fill the chip: four per wavefront, three wavefronts per SIMD (~150 registers per lane)
-inline long row_target_rows() {
-    static const long v = [] { const char* e = mf_knob("MF_ROW_TARGET"); const long x = e ? std::atol(e) : 0; return x > 0 ? x : 256L * 4 * 3 * 4; }();
+// rows that fill the chip ONCE: four per wavefront, as many wavefronts per SIMD as the level-0 kernel's registers allow - three up to
+// d = 9 (~150 registers per lane); in the row-only builds two (fp64, d <= 12) or one (fp64, d >= 13), three in fp32.  A partial
+// second round of rows costs a whole one (B=512, T=1000, fp64, d = 15: 8 chunks per series = 4 096 rows 0.82 ms, 12 chunks 1.01 ms),
+// whole multiples are equal within noise (16: 0.83, 24: 0.85 ms; scripts/sweep_row_chunks.py) - the smallest one has the least
+// reduction work and workspace.
+template <typename T> long row_target_rows() {
+    static const long v = [] {
+        const char* e = mf_knob("MF_ROW_TARGET");
+        const long x = e ? std::atol(e) : 0;
+        const int waves = (sizeof(T) == 4 || D <= 9) ? 3 : row::row_waves_per_simd(D);
+        return x > 0 ? x : 256L * 4 * waves * 4;
+    }();
     return v;
 }
 struct KfPlan {
@@ -247,7 +256,7 @@ template <typename T> size_t plan_ws(long B, const KfPlan& pl) {
 template <typename T> KfPlan kf_plan(long B, long Tn, int m, int rinv_per_step, long chunks, bool aligned16) {
     KfPlan pl{KF_PATH_DIRECT, 1, 0};
     if (row_path<T>() && Tn >= 2 && m >= 1 && m <= ROW_MAXM) {
-        long P = chunks > 0 ? (chunks > Tn ? Tn : chunks) : cdiv(row_target_rows(), B);
+        long P = chunks > 0 ? (chunks > Tn ? Tn : chunks) : cdiv(row_target_rows<T>(), B);
         if (chunks <= 0) {
             const long maxP = Tn / 4 > 0 ? Tn / 4 : 1;
             if (P > maxP) P = maxP;
