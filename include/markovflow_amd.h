@@ -390,22 +390,35 @@ int mf_obs_precision_from_chol_f64(int m, const double* chol, double* out, int* 
 int mf_obs_precision_from_chol_f32(int m, const float* chol, float* out, int* info, void* stream);
 
 /*
- * BaseKalmanFilter.posterior_state_space_model (markovflow/kalman_filter.py:109-182) fused: ONE backward sweep per series
- * assembles the posterior precision / information vector block by block (state_space_model.py:431-483,
- * kalman_filter.py:86-101,149-156) inside the U D U^T recursion (block_tri_diag.py:438-545) and writes the five tensors of the
- * posterior chain directly: a_post [B,T-1,d,d] (= -U^T), mu0_post [B,d], b_post [B,T-1,d], cholP0_post [B,d,d],
- * cholQ_post [B,T-1,d,d].  4 d^2 s bytes per block instead of the 8 d^2 s of mf_ssm_precision + mf_btd_udl.  One lane per
- * series (the Python layer uses it for batches that fill the chip, the two-kernel route with its parallel-in-time sweep
- * otherwise).  Rinv shared [m,m] or per step [B,T,m,m]; m <= 4; state dimension 1..9.
+ * BaseKalmanFilter.posterior_state_space_model (markovflow/kalman_filter.py:109-182) fused: the posterior precision and the
+ * information vector (state_space_model.py:431-483, kalman_filter.py:86-101,149-156) are assembled block by block INSIDE the
+ * backward U D U^T recursion (block_tri_diag.py:438-545) and the five tensors of the posterior chain are written directly:
+ * a_post [B,T-1,d,d] (= -U^T), mu0_post [B,d], b_post [B,T-1,d], cholP0_post [B,d,d], cholQ_post [B,T-1,d,d].  Nothing else
+ * touches HBM: the precision, its factor and the solves of the reference's route (mf_ssm_precision + mf_btd_udl here) never exist.
+ * Rinv shared [m,m] or per step [B,T,m,m]; m <= 4; state dimension 1..9.  Two forms:
+ *   ws == NULL           one lane per series, ONE backward sweep: (4 d^2 + 3 d + m d + m) s bytes per step.  For batches that
+ *                        fill the chip (thousands of series) and for short chains.
+ *   ws != NULL           (mf_kf_posterior_chain_workspace_bytes > 0 and a workspace of that size; d <= 6, m <= 3 or m = 1 with
+ *                        per-step precisions, 16-byte aligned tensors - otherwise the call quietly takes the first form):
+ *                        partitioned in TIME like mf_kf_loglik and streamed by LDS-DMA (csrc/mf_post_lds.hpp).  Pass 1: a lane
+ *                        per (series, chunk) eliminates its chunk backwards with the fill-in carried to the chunk's right end;
+ *                        pass 2: a scan over the chunk summaries gives the recursion's state at every chunk boundary; pass 3:
+ *                        every chunk restarts the recursion there and writes the chain.  The inputs are read twice, coalesced,
+ *                        every output once.  `chunks` = chunks per series (0 = fill the chip); prof_start / prof_stop: optional
+ *                        hipEvent_t recorded on `stream` around the three kernels.
  */
+size_t mf_kf_posterior_chain_workspace_bytes(int64_t B, int64_t T, int d, int m, int rinv_per_step, int elem_size,
+                                             int64_t chunks);
 int mf_kf_posterior_chain_f64(int64_t B, int64_t T, int d, int m, const double* mu0, const double* cholP0, const double* A,
                               const double* b, const double* cholQ, const double* H, const double* y, const double* Rinv,
                               int rinv_per_step, double* a_post, double* mu0_post, double* b_post, double* cholP0_post,
-                              double* cholQ_post, int* info, void* stream);
+                              double* cholQ_post, void* ws, size_t ws_bytes, int* info, int64_t chunks, void* prof_start,
+                              void* prof_stop, void* stream);
 int mf_kf_posterior_chain_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const float* cholP0, const float* A,
                               const float* b, const float* cholQ, const float* H, const float* y, const float* Rinv,
                               int rinv_per_step, float* a_post, float* mu0_post, float* b_post, float* cholP0_post,
-                              float* cholQ_post, int* info, void* stream);
+                              float* cholQ_post, void* ws, size_t ws_bytes, int* info, int64_t chunks, void* prof_start,
+                              void* prof_stop, void* stream);
 
 /*
  * KL(q1 || q2) between two state space models, one scalar per series (markovflow/state_space_model.py:528-593), fused: ONE

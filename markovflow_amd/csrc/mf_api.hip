@@ -26,6 +26,24 @@ template <> const mf::OpsTable<double>* table_for<double>(int d) {
 }
 #undef MF_CASE
 
+template <typename T> const mf::PostOps<T>* post_table_for(int d);
+#define MF_CASE(D) case D: return mf::post_ops_f32_d##D();
+template <> const mf::PostOps<float>* post_table_for<float>(int d) {
+    switch (d) {
+        MF_CASE(1) MF_CASE(2) MF_CASE(3) MF_CASE(4) MF_CASE(5) MF_CASE(6)
+        default: return nullptr;
+    }
+}
+#undef MF_CASE
+#define MF_CASE(D) case D: return mf::post_ops_f64_d##D();
+template <> const mf::PostOps<double>* post_table_for<double>(int d) {
+    switch (d) {
+        MF_CASE(1) MF_CASE(2) MF_CASE(3) MF_CASE(4) MF_CASE(5) MF_CASE(6)
+        default: return nullptr;
+    }
+}
+#undef MF_CASE
+
 inline hipStream_t S(void* s) { return static_cast<hipStream_t>(s); }
 
 template <typename T>
@@ -443,13 +461,23 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
     int mf_kf_posterior_chain_##SUF(int64_t B, int64_t Tn, int d, int m, const T* mu0, const T* cholP0, const T* A,    \
                                     const T* b, const T* cholQ, const T* H, const T* y, const T* Rinv,                 \
                                     int rinv_per_step, T* a_post, T* mu0_post, T* b_post, T* cholP0_post,              \
-                                    T* cholQ_post, int* info, void* stream) {                                          \
+                                    T* cholQ_post, void* ws, size_t ws_bytes, int* info, int64_t chunks,               \
+                                    void* prof_start, void* prof_stop, void* stream) {                                 \
         MF_HEAD(T, B, Tn, d)                                                                                           \
         if (!t) return -100;                                                                                            \
         if (m < 1 || m > 4) return -4;                                                                                 \
         if (!mu0 || !cholP0 || (Tn > 1 && (!A || !b || !cholQ))) return -5;                                            \
         if (!H || !y || !Rinv) return -10;                                                                             \
         if (!mu0_post || !cholP0_post || (Tn > 1 && (!a_post || !b_post || !cholQ_post))) return -14;                  \
+        if (ws != nullptr && ws_bytes > 0) {       /* the streamed, time-partitioned kernels (mf_post_lds.hpp) */     \
+            if (const auto* pt = post_table_for<T>(d)) {                                                               \
+                const int rc = pt->chain(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, a_post,        \
+                                         mu0_post, b_post, cholP0_post, cholQ_post, ws, ws_bytes, info, chunks,        \
+                                         static_cast<hipEvent_t>(prof_start), static_cast<hipEvent_t>(prof_stop),      \
+                                         S(stream));                                                                   \
+                if (rc != -101) return rc;         /* -101: not their call (outputs, alignment): one lane per series */ \
+            }                                                                                                          \
+        }                                                                                                              \
         return t->posterior_chain(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, a_post, mu0_post,     \
                                   b_post, cholP0_post, cholQ_post, info, S(stream));                                   \
     }                                                                                                                  \
@@ -555,6 +583,14 @@ size_t mf_ssm_adjoint_workspace_bytes(int64_t B, int64_t T, int d, int elem_size
     if (elem_size == 4) { const auto* t = table_for<float>(d); return t ? t->adjoint_ws(B, T) : 0; }
     const auto* t = table_for<double>(d);
     return t ? t->adjoint_ws(B, T) : 0;
+}
+
+size_t mf_kf_posterior_chain_workspace_bytes(int64_t B, int64_t T, int d, int m, int rinv_per_step, int elem_size,
+                                             int64_t chunks) {
+    if (B < 1 || T < 2 || d < 1 || m < 1) return 0;
+    if (elem_size == 4) { const auto* t = post_table_for<float>(d); return t ? t->ws(B, T, m, rinv_per_step, chunks) : 0; }
+    const auto* t = post_table_for<double>(d);
+    return t ? t->ws(B, T, m, rinv_per_step, chunks) : 0;
 }
 
 size_t mf_btd_logdet_quad_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {

@@ -38,7 +38,7 @@ template <typename T, int D, bool SPIKE> struct Elim {
     LogAcc<T> laL; // prod diag(L)
     bool bad;
 
-    MF_DEV void init() {
+    MF_HD void init() {
         MF_UNROLL for (int i = 0; i < D; ++i) {
             t[i] = T(0); gU[i] = T(0); Li[i] = T(0);
             MF_UNROLL for (int j = 0; j < D; ++j) { Phi[i][j] = T(0); X[i][j] = T(0); GU[i][j] = T(0); }
@@ -48,17 +48,17 @@ template <typename T, int D, bool SPIKE> struct Elim {
         bad = false;
     }
     // Factor the (complete) pivot in Phi, solve for z and the spike V, fold V into the separator.
-    MF_DEV void eliminate() {
+    MF_HD void eliminate() {
         eliminate_main();
         eliminate_spike();
     }
-    MF_DEV void eliminate_main() {
+    MF_HD void eliminate_main() {
         chol_lower<T, D>(Phi, Li, laL, bad);
         laL.renorm();
         trsv_lower<T, D>(Phi, Li, t);
         quad += dot_self<T, D>(t);
     }
-    MF_DEV void eliminate_spike() {
+    MF_HD void eliminate_spike() {
         if (SPIKE) {
             trsm_left_lower<T, D, D>(Phi, Li, X);
             syrk_tn_lower<T, D, D>(X, GU, T(-1));
@@ -69,7 +69,7 @@ template <typename T, int D, bool SPIKE> struct Elim {
     }
     // After eliminate(): move to the next block whose coupling to the eliminated one is W L^T
     // (W = S L^-T already formed by the caller); Dn / rn are the next block's own pivot / rhs parts.
-    MF_DEV void advance(const T (&W)[D][D], const T (&Dn)[D][D], const T (&rn)[D]) {
+    MF_HD void advance(const T (&W)[D][D], const T (&Dn)[D][D], const T (&rn)[D]) {
         T wz[D];
         gemv_n<T, D, D>(W, t, wz);
         MF_UNROLL for (int i = 0; i < D; ++i) {
@@ -82,7 +82,7 @@ template <typename T, int D, bool SPIKE> struct Elim {
 };
 
 template <typename T, int D, bool SPIKE>
-MF_DEV void store_chunk(const RedSys<T>& out, long idx, const Elim<T, D, SPIKE>& E, T scalar) {
+MF_HD void store_chunk(const RedSys<T>& out, long idx, const Elim<T, D, SPIKE>& E, T scalar) {
     store_sym<T, D>(out.Dv + idx * D * D, E.Phi);
     store_vec<T, D>(out.tv + idx * D, E.t);
     store_sym<T, D>(out.GU + idx * D * D, E.GU);
@@ -116,7 +116,7 @@ constexpr int MF_MAXM = 4;
 
 template <typename T, int D, int M> struct Obs {
     // adds H^T R^-1 H to Phi (lower), H^T R^-1 y to t and returns y^T R^-1 y
-    static MF_DEV T apply(const T* __restrict__ Hk, const T* __restrict__ yk, const T* __restrict__ Ri, int m,
+    static MF_HD T apply(const T* __restrict__ Hk, const T* __restrict__ yk, const T* __restrict__ Ri, int m,
                           T (&Phi)[D][D], T (&t)[D]) {
         constexpr int MM = (M > 0) ? M : MF_MAXM;
         T h[MM][D], yv[MM], rh[MM][D], ry[MM];

@@ -68,6 +68,15 @@ template <typename T> struct OpsTable {
     size_t (*marginals_ws)(long B, long n);
 };
 
+// streamed, time-partitioned posterior chain (mf_post_lds.hpp, instantiated by mf_post_inst.hip for d = 1 ... MF_MAX_D_POST)
+template <typename T> struct PostOps {
+    size_t (*ws)(long B, long Tn, int m, int rinv_per_step, long chunks);      // 0: not this route's call
+    int (*chain)(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H,
+                 const T* y, const T* Rinv, int rinv_per_step, T* a_post, T* mu0_post, T* b_post, T* cp0_post, T* cq_post,
+                 void* ws, size_t ws_bytes, int* info, long chunks, hipEvent_t ev0, hipEvent_t ev1, hipStream_t st);
+};
+constexpr int MF_MAX_D_POST = 6;
+
 constexpr int MF_MAX_D = 9;        // largest state dimension with a register-resident (lane per chunk) instantiation
 constexpr int MF_MAX_D_ROW = 15;   // largest state dimension of the row kernels (one 16-lane row per chunk; 10 ... 15: only those)
 constexpr int MF_MAX_D_BIG = 64;      // largest state dimension of the LDS-tiled MFMA path, fp32 (log-likelihood only)
@@ -123,5 +132,10 @@ MF_DECLARE_TABLES(1) MF_DECLARE_TABLES(2) MF_DECLARE_TABLES(3) MF_DECLARE_TABLES
 MF_DECLARE_TABLES(6) MF_DECLARE_TABLES(7) MF_DECLARE_TABLES(8) MF_DECLARE_TABLES(9)
 MF_DECLARE_TABLES(10) MF_DECLARE_TABLES(11) MF_DECLARE_TABLES(12) MF_DECLARE_TABLES(13) MF_DECLARE_TABLES(14) MF_DECLARE_TABLES(15)
 #undef MF_DECLARE_TABLES
+#define MF_DECLARE_POST(D)                            \
+    const PostOps<float>* post_ops_f32_d##D();        \
+    const PostOps<double>* post_ops_f64_d##D();
+MF_DECLARE_POST(1) MF_DECLARE_POST(2) MF_DECLARE_POST(3) MF_DECLARE_POST(4) MF_DECLARE_POST(5) MF_DECLARE_POST(6)
+#undef MF_DECLARE_POST
 
 }  // namespace mf

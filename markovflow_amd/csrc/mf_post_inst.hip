@@ -1,0 +1,128 @@
+// Instantiates the streamed, time-partitioned posterior-chain kernels (mf_post_lds.hpp) for ONE state dimension (compile with
+// -DMF_D=<d>) and both scalar types, and exports their launch table (mf_launch.hpp: PostOps).  A translation unit of its own:
+// the kernels are large (two ~2 500-instruction sweeps per output count) and share nothing with mf_inst.hip but headers.
+#ifndef MF_D
+#error "compile with -DMF_D=<state dimension>"
+#endif
+#include "mf_post_lds.hpp"
+#include "mf_launch.hpp"
+
+#include <type_traits>
+
+namespace mf {
+namespace {
+
+constexpr int D = MF_D;
+inline long cdiv(long a, long b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
+
+// outputs / observation-precision forms with a streaming instantiation (the LDS image and the per-step DMA count of
+// KfLdsCfg must fit, as for the log-likelihood kernel)
+template <typename T, int M, bool RS> constexpr bool post_supported() { return KfLdsCfg<T, D, M, RS>::SUPPORTED; }
+template <typename T> bool post_covers(int m, int per_step) {
+    if (per_step) return m == 1 && post_supported<T, 1, true>();
+    switch (m) {
+        case 1: return post_supported<T, 1, false>();
+        case 2: return post_supported<T, 2, false>();
+        case 3: return post_supported<T, 3, false>();
+        default: return false;
+    }
+}
+template <typename T> int post_lds_bytes(int m, int per_step) {
+    if (per_step) return KfLdsCfg<T, D, 1, true>::LDS_TOTAL;
+    return m == 1 ? KfLdsCfg<T, D, 1, false>::LDS_TOTAL : (m == 2 ? KfLdsCfg<T, D, 2, false>::LDS_TOTAL : KfLdsCfg<T, D, 3, false>::LDS_TOTAL);
+}
+
+// chunks per series (P) and transitions per chunk (L): one wavefront on every SIMD the LDS image leaves room for
+struct PostPlan { long P, L; };
+template <typename T> PostPlan post_plan(long B, long Tn, int m, int per_step, long chunks) {
+    const long nt = Tn - 1;
+    int w = (160 * 1024) / post_lds_bytes<T>(m, per_step);
+    w = w > 4 ? 4 : (w < 1 ? 1 : w);
+    long want = chunks > 0 ? chunks : cdiv(256L * 64 * w, B);
+    if (chunks <= 0) {
+        const long maxP = nt / 4 > 0 ? nt / 4 : 1;      // never chunks shorter than four transitions
+        if (want > maxP) want = maxP;
+    }
+    if (want > nt) want = nt;
+    if (want < 1) want = 1;
+    PostPlan pl;
+    pl.L = cdiv(nt, want);
+    pl.P = cdiv(nt, pl.L);
+    return pl;
+}
+
+// summaries (Dv, GU, F: D*D each; tv, gU: D each; sc) + boundary states (Psi: D*D, psi: D) per (series, chunk)
+template <typename T> size_t post_ws_for(long B, long P) {
+    const size_t nb = size_t(B) * P;
+    return align_up(nb * (3 * D * D + 2 * D + 1) * sizeof(T)) + align_up(nb * D * D * sizeof(T)) + align_up(nb * D * sizeof(T));
+}
+// 0 = this call is not the streamed kernels' (the caller keeps its other routes)
+template <typename T> size_t post_ws(long B, long Tn, int m, int per_step, long chunks) {
+    if (B < 1 || Tn < 2 || !post_covers<T>(m, per_step)) return 0;
+    const PostPlan pl = post_plan<T>(B, Tn, m, per_step, chunks);
+    return post_ws_for<T>(B, pl.P) + 256;
+}
+
+template <typename T>
+int post_chain(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H,
+               const T* y, const T* Rinv, int rinv_per_step, T* a_post, T* mu0_post, T* b_post, T* cp0_post, T* cq_post,
+               void* ws, size_t ws_bytes, int* info, long chunks, hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
+    if (B < 1 || Tn < 2 || !post_covers<T>(m, rinv_per_step)) return -101;
+    // LDS-DMA moves 16-byte units: the streamed tensors must be 16-byte aligned (torch allocations are)
+    if (((reinterpret_cast<size_t>(A) | reinterpret_cast<size_t>(cholQ)) & 15) != 0) return -101;
+    const PostPlan pl = post_plan<T>(B, Tn, m, rinv_per_step, chunks);
+    if (ws == nullptr || ws_bytes < post_ws_for<T>(B, pl.P)) return -21;
+    const long P = pl.P, L = pl.L;
+    char* p = static_cast<char*>(ws);
+    RedSys<T> sum;
+    {
+        T* base = reinterpret_cast<T*>(p);
+        const long nb = B * P;
+        sum.Dv = base; sum.GU = sum.Dv + nb * D * D; sum.F = sum.GU + nb * D * D; sum.tv = sum.F + nb * D * D;
+        sum.gU = sum.tv + nb * D; sum.sc = sum.gU + nb * D;
+        sum.n = P; sum.f_stride = P; sum.f_off = 0;
+        p += align_up(size_t(nb) * (3 * D * D + 2 * D + 1) * sizeof(T));
+    }
+    T* bPsi = reinterpret_cast<T*>(p); p += align_up(size_t(B) * P * D * D * sizeof(T));
+    T* bpsi = reinterpret_cast<T*>(p);
+    KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, info, 0, nullptr};
+    const PostOut<T> po{a_post, mu0_post, b_post, cp0_post, cq_post, bPsi, bpsi};
+    const dim3 grid((unsigned)cdiv(B * P, 64)), block(64);
+    auto launch = [&](auto mtag, auto rtag) {
+        constexpr int M = decltype(mtag)::value;
+        constexpr bool RS = decltype(rtag)::value;
+        if constexpr (KfLdsCfg<T, D, M, RS>::SUPPORTED) {
+            constexpr int lds = KfLdsCfg<T, D, M, RS>::LDS_TOTAL;
+            constexpr int scan_lds = PostScanLds<T, D>::BYTES;
+            if (ev0) (void)hipEventRecord(ev0, st);
+            if (P > 1) {
+                hipLaunchKernelGGL((post_lds_kernel<T, D, M, RS, false>), grid, block, lds, st, a, L, sum, po);
+                hipLaunchKernelGGL((post_scan_kernel<T, D>), dim3((unsigned)B), block, scan_lds, st, sum, B, bPsi, bpsi,
+                                   info);
+            }
+            hipLaunchKernelGGL((post_lds_kernel<T, D, M, RS, true>), grid, block, lds, st, a, L, sum, po);
+            if (ev1) (void)hipEventRecord(ev1, st);
+        }
+    };
+    using std::integral_constant;
+    if (rinv_per_step) launch(integral_constant<int, 1>{}, integral_constant<bool, true>{});
+    else if (m == 1) launch(integral_constant<int, 1>{}, integral_constant<bool, false>{});
+    else if (m == 2) launch(integral_constant<int, 2>{}, integral_constant<bool, false>{});
+    else launch(integral_constant<int, 3>{}, integral_constant<bool, false>{});
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+template <typename T> const PostOps<T>* table() {
+    static const PostOps<T> t = {&post_ws<T>, &post_chain<T>};
+    return &t;
+}
+
+}  // namespace
+
+#define MF_CAT2(a, b) a##b
+#define MF_CAT(a, b) MF_CAT2(a, b)
+const PostOps<float>* MF_CAT(post_ops_f32_d, MF_D)() { return table<float>(); }
+const PostOps<double>* MF_CAT(post_ops_f64_d, MF_D)() { return table<double>(); }
+
+}  // namespace mf

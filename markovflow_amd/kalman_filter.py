@@ -146,6 +146,7 @@ class BaseKalmanFilter(abc.ABC):
     # an optional pair of hipEvent_t handles recorded around the dominant kernel (used by bench.py)
     _chunks = 0
     _prof_events = (None, None)
+    _post_prof_events = (None, None)     # hipEvent_t pair around the kernels of posterior_state_space_model (bench.py)
 
     @property
     @abc.abstractmethod
@@ -198,22 +199,34 @@ class BaseKalmanFilter(abc.ABC):
         num_data = self.prior_ssm.num_transitions + 1
         return num_data * torch.linalg.slogdet(self._r_inv)[1]
 
-    # batches at least this large (or chains this short) take the fused one-lane-per-series sweep (mf_kf_posterior_chain)
+    # batches at least this large (or chains this short) take the fused one-lane-per-series sweep (mf_kf_posterior_chain
+    # without a workspace); fewer, longer series the same sweep partitioned in time and streamed by LDS-DMA (with one)
     _POST_FUSED_MIN_SERIES = 2048
     _POST_FUSED_MAX_SERIAL_BLOCKS = 64
+    _POST_STREAMED = True
 
     def _posterior_chain_fused(self, h, y, r_inv, per_step) -> Optional[StateSpaceModel]:
         mu0, cp0, a_s, b_s, cq = self.prior_ssm._flat_params()
         bsz, n, d, m = a_s.shape[0], self.prior_ssm.num_transitions + 1, self.prior_ssm.state_dim, h.shape[-2]
-        if d > _lib.load().mf_max_state_dim() or m > 4 or bsz == 0 or not (
-                bsz >= self._POST_FUSED_MIN_SERIES or n <= self._POST_FUSED_MAX_SERIAL_BLOCKS):
+        lib = _lib.load()
+        if d > lib.mf_max_state_dim() or m > 4 or bsz == 0:
+            return None
+        serial = bsz >= self._POST_FUSED_MIN_SERIES or n <= self._POST_FUSED_MAX_SERIAL_BLOCKS
+        ws, ws_bytes = None, 0
+        if not serial and self._POST_STREAMED and (a_s.data_ptr() | cq.data_ptr()) % 16 == 0:
+            ws_bytes = int(lib.mf_kf_posterior_chain_workspace_bytes(bsz, n, d, m, int(per_step), a_s.element_size(),
+                                                                     self._chunks))
+            if ws_bytes:
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a_s.device)
+        if not serial and ws is None:
             return None
         a_p, b_p, cq_p = torch.empty_like(a_s), torch.empty_like(b_s), torch.empty_like(cq)
         mu0_p, cp0_p = torch.empty_like(mu0), torch.empty_like(cp0)
         info = _lib.pivot_info(a_s.device)
         _lib.call("mf_kf_posterior_chain", a_s.dtype, bsz, n, d, m, _lib.ptr(mu0), _lib.ptr(cp0), _lib.ptr(a_s), _lib.ptr(b_s),
                   _lib.ptr(cq), _lib.ptr(h), _lib.ptr(y), _lib.ptr(r_inv), int(per_step), _lib.ptr(a_p), _lib.ptr(mu0_p),
-                  _lib.ptr(b_p), _lib.ptr(cp0_p), _lib.ptr(cq_p), info, _lib.stream_ptr(a_s.device))
+                  _lib.ptr(b_p), _lib.ptr(cp0_p), _lib.ptr(cq_p), _lib.ptr(ws), ws_bytes, info, self._chunks,
+                  self._post_prof_events[0], self._post_prof_events[1], _lib.stream_ptr(a_s.device))
         _lib.raise_on_info(info, "posterior_state_space_model", a_s.device)
         batch = tuple(self.prior_ssm.batch_shape)
         return StateSpaceModel(initial_mean=mu0_p.reshape(batch + (d,)), chol_initial_covariance=cp0_p.reshape(batch + (d, d)),
