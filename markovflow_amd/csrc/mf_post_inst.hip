@@ -28,9 +28,10 @@ template <typename T> bool post_covers(int m, int per_step) {
         default: return false;
     }
 }
+// LDS per wavefront of the emit pass (input image + staging of the output rows); both passes share one time partition
 template <typename T> int post_lds_bytes(int m, int per_step) {
-    if (per_step) return KfLdsCfg<T, D, 1, true>::LDS_TOTAL;
-    return m == 1 ? KfLdsCfg<T, D, 1, false>::LDS_TOTAL : (m == 2 ? KfLdsCfg<T, D, 2, false>::LDS_TOTAL : KfLdsCfg<T, D, 3, false>::LDS_TOTAL);
+    if (per_step) return PostLds<T, D, 1, true>::TOTAL;
+    return m == 1 ? PostLds<T, D, 1, false>::TOTAL : (m == 2 ? PostLds<T, D, 2, false>::TOTAL : PostLds<T, D, 3, false>::TOTAL);
 }
 
 // chunks per series (P) and transitions per chunk (L): one wavefront on every SIMD the LDS image leaves room for
@@ -93,7 +94,8 @@ int post_chain(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A
         constexpr int M = decltype(mtag)::value;
         constexpr bool RS = decltype(rtag)::value;
         if constexpr (KfLdsCfg<T, D, M, RS>::SUPPORTED) {
-            constexpr int lds = KfLdsCfg<T, D, M, RS>::LDS_TOTAL;
+            constexpr int lds = KfLdsCfg<T, D, M, RS>::LDS_TOTAL, lds_emit = PostLds<T, D, M, RS>::TOTAL;
+            static_assert(lds_emit <= 64 * 1024, "emit pass: LDS image + staging beyond the default dynamic-LDS limit");
             constexpr int scan_lds = PostScanLds<T, D>::BYTES;
             if (ev0) (void)hipEventRecord(ev0, st);
             if (P > 1) {
@@ -101,7 +103,7 @@ int post_chain(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A
                 hipLaunchKernelGGL((post_scan_kernel<T, D>), dim3((unsigned)B), block, scan_lds, st, sum, B, bPsi, bpsi,
                                    info);
             }
-            hipLaunchKernelGGL((post_lds_kernel<T, D, M, RS, true>), grid, block, lds, st, a, L, sum, po);
+            hipLaunchKernelGGL((post_lds_kernel<T, D, M, RS, true>), grid, block, lds_emit, st, a, L, sum, po);
             if (ev1) (void)hipEventRecord(ev1, st);
         }
     };

@@ -25,12 +25,159 @@ template <typename T> struct PostOut {
     const T* bPsi; const T* bpsi;                                 // boundary state per consumer chunk [B, P, D, D] / [B, P, D] (EMIT)
 };
 
-// KfArgs::P = chunks per series, L = transitions per chunk.  Position e of a chunk = transition tau0 + e; the wave walks
-// e = nsteps-1 ... 0 (a chunk shorter than the wave's longest idles FIRST, so that all lanes end on their chunk's first
-// transition and every DMA address is >= the tensor's start).
+// ---- coalesced output rows -------------------------------------------------------------------------------------------
+// A lane produces whole rows of the posterior chain (A'_t: d x d, cholQ'_t: d x d, b'_t: d) for ITS chunk; stored directly,
+// one store instruction of the wave touches 64 different 128-B lines.  Instead the rows go through an LDS staging buffer:
+// every lane writes (a piece of) its row, then instruction i of a wave stores unit 64 i + lane of the row-major image, i.e.
+// consecutive lanes store consecutive 16-B units of a row - the mirror image of the LDS-DMA loads.  `buffer_store` with the
+// row offsets of the input streams (same shapes); a row that must not be written (lane without a chunk, chunk not yet
+// active) gets an out-of-range offset, which the buffer range check drops.
+//
+// What a store costs (measured on MI355X, B=1024, T=10000, d=6 fp64; profiles/r04_post_store_path.txt,
+// scripts/micro/store_rate.hip): a SIMD's store path takes one 1-KB store instruction per write round trip - 50-85 cycles on
+// an idle chip, ~330 while every CU streams 3 TB/s of reads - and the issuing wave is only held when its NEXT store finds the
+// path busy; VALU work between two stores hides it.  The step's 39 stores are issued in five bursts (where the rows exist),
+// so a wave pays ~13 k cycles per step for them on top of 15 k of arithmetic: emit pass 3.9 ms against 1.8 ms with the
+// stores dropped by the range check.  Tried and measured slower: `nt` stores (4.6 ms), 256-B aligned rows (3.6 ms: the
+// partial lines are not the cost), all stores of a CU issued by a fourth, storing wavefront fed through LDS (4.3-4.8 ms: one
+// SIMD's store path carries a third of what three carry).  What would hide them is a store every ~350 cycles of arithmetic.
+constexpr int MF_POST_STAGE_CAP = 9472;        // bytes of staging per matrix piece (d = 6 fp64: two pieces of 9 units)
+template <int ROWB> struct OutGeom {
+    static constexpr int UNIT = (ROWB % 16 == 0) ? 16 : ((ROWB % 8 == 0) ? 8 : 4);
+    static constexpr int UG = ROWB / UNIT;                          // units per row
+    static constexpr int pieces() { for (int n = 1; n <= UG; ++n) if (UG % n == 0 && 64 * ROWB / n <= MF_POST_STAGE_CAP) return n; return UG; }
+    static constexpr int NP = pieces();
+    static constexpr int PU = UG / NP;                              // units per piece
+    static constexpr int PIECE_BYTES = PU * UNIT;                   // bytes of a row in one piece
+    static constexpr int STAGE_BYTES = 64 * PU * UNIT;
+};
+// what DmaStream needs to know of a piece: NU units of UNIT bytes per row, all kept
+template <int NU, int UNIT_> struct OutPiece {
+    static constexpr int U = NU, NI = NU, UNIT = UNIT_, UG = NU;
+    static constexpr bool ALL = true;
+};
+template <int UNIT> struct OutWord;
+template <> struct OutWord<16> { typedef int type __attribute__((ext_vector_type(4))); };
+template <> struct OutWord<8> { typedef int type __attribute__((ext_vector_type(2))); };
+template <> struct OutWord<4> { typedef int type; };
+// The read-back of the staged image goes to ACCUMULATION registers and is stored from there ("a" operands; gfx950 has one
+// unified register file, ds_read and buffer_store take AGPRs): the emit step keeps all 256 VGPRs busy, and with VGPR
+// destinations hipcc reuses ONE register quadruple for every unit - read, wait for the LDS, store, 39 times per step.  All
+// reads of a piece are issued first, one wait, then the stores.
+// Hazards hipcc cannot see inside asm: the descriptor may just have been written by v_readfirstlane (5 wait states before a
+// VMEM instruction reads an SGPR a VALU instruction wrote: leading s_nop 4), and a store of more than 64 bits needs one wait
+// state before its data registers are overwritten (trailing s_nop 0).
+template <int OFF> MF_DEV void lds_read_a(OutWord<16>::type& v, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(v) : "v"(addr), "n"(OFF) : "memory"); }
+template <int OFF> MF_DEV void lds_read_a(OutWord<8>::type& v, unsigned addr) { asm volatile("ds_read_b64 %0, %1 offset:%2" : "=a"(v) : "v"(addr), "n"(OFF) : "memory"); }
+template <int OFF> MF_DEV void lds_read_a(OutWord<4>::type& v, unsigned addr) { asm volatile("ds_read_b32 %0, %1 offset:%2" : "=a"(v) : "v"(addr), "n"(OFF) : "memory"); }
+MF_DEV void buf_store(OutWord<16>::type v, mf_v4i srd, unsigned voff) {
+    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 0" :: "a"(v), "v"(voff), "s"(srd) : "memory");
+}
+MF_DEV void buf_store(OutWord<8>::type v, mf_v4i srd, unsigned voff) {
+    asm volatile("s_nop 4\n\tbuffer_store_dwordx2 %0, %1, %2, 0 offen\n\ts_nop 0" :: "a"(v), "v"(voff), "s"(srd) : "memory");
+}
+MF_DEV void buf_store(OutWord<4>::type v, mf_v4i srd, unsigned voff) {
+    asm volatile("s_nop 4\n\tbuffer_store_dword %0, %1, %2, 0 offen\n\ts_nop 0" :: "a"(v), "v"(voff), "s"(srd) : "memory");
+}
+// LDS words shared between wavefronts of a workgroup (flags, descriptors): volatile accesses the compiler must not cache
+MF_DEV unsigned lds_ld_u32(unsigned addr) {
+    unsigned x;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(x) : "v"(addr) : "memory");
+    return x;
+}
+MF_DEV void lds_st_u32(unsigned addr, unsigned x) { asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(x) : "memory"); }
+
+template <typename T, int D, int M, bool RSTEP> struct PostLds {
+    using Cfg = KfLdsCfg<T, D, M, RSTEP>;
+    using GM = OutGeom<D * D * (int)sizeof(T)>;
+    using Gv = OutGeom<D * (int)sizeof(T)>;
+    static constexpr int OFF_stageM = ((Cfg::LDS_TOTAL + 15) / 16) * 16;
+    static constexpr int OFF_stagev = OFF_stageM + GM::STAGE_BYTES;
+    static constexpr int OFF_len = OFF_stagev + ((Gv::STAGE_BYTES + 15) / 16) * 16;
+    static constexpr int TOTAL = OFF_len + 256;                     // one wavefront's image + staging
+};
+
+// rows of one output tensor: `row[e]` of every lane, piece by piece through the staging buffer
+template <typename T, typename G> struct RowFlush {
+    using Piece = OutPiece<G::PU, G::UNIT>;
+    using W = typename OutWord<G::UNIT>::type;
+    static constexpr int EPU = G::UNIT / (int)sizeof(T);           // elements per unit
+    // validity of the row that instruction i of a piece moves, at position e (slow path: some chunk of the wave is not active yet)
+    static MF_DEV unsigned guarded(const char* smem, int off_len, int lane, int i, long e, unsigned vo) {
+        const int q0 = lane / G::PU, c0 = lane - q0 * G::PU;
+        const int a = (64 * i) / G::PU, b = (64 * i) % G::PU;
+        const int row = q0 + a + ((c0 + b >= G::PU) ? 1 : 0);
+        const int len = *reinterpret_cast<const int*>(smem + off_len + row * 4);
+        return e < (long)len ? vo : MF_DMA_INVALID;
+    }
+    template <int I = 0> static MF_DEV void read_back(W (&v)[G::PU], unsigned addr) {
+        if constexpr (I < G::PU) {
+            lds_read_a<I * 64 * G::UNIT>(v[I], addr);
+            read_back<I + 1>(v, addr);
+        }
+    }
+    // this lane's part of piece PIECE into the staging buffer
+    template <int PIECE> static MF_DEV void stage(char* smem, int off_stage, int lane, const T* row) {
+        T* dst = reinterpret_cast<T*>(smem + off_stage + lane * (G::PU * G::UNIT));
+        MF_UNROLL for (int k = 0; k < G::PU * EPU; ++k) dst[k] = row[PIECE * G::PU * EPU + k];
+    }
+    // the staged piece -> global memory; srd: the wave's rows of this tensor at the current position, advanced to the piece
+    static MF_DEV void store(const char* smem, int off_stage, int off_len, int lane, const DmaStream<Piece>& ds, mf_v4i srd,
+                             bool fast, long e) {
+        // (the asm statements are `volatile` with a memory clobber: staging stores are issued before them, and the LDS executes
+        // one wave's operations in order - also against the previous piece's reads of the same buffer)
+        W v[G::PU];
+        read_back(v, (unsigned)(size_t)smem + (unsigned)off_stage + (unsigned)lane * G::UNIT);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        MF_UNROLL for (int i = 0; i < G::PU; ++i) {
+            const unsigned vo = fast ? ds.vo[i] : guarded(smem, off_len, lane, i, e, ds.vo[i]);
+            buf_store(v[i], srd, vo);
+        }
+    }
+};
+
+// The emit step's sink (mf_post_math.hpp: post_emit_step) on the device: the computing wave stages and stores its own rows.
+template <typename T, int D, int M, bool RSTEP> struct PostSink {
+    using PL = PostLds<T, D, M, RSTEP>;
+    using GM = typename PL::GM;
+    using Gv = typename PL::Gv;
+    using PieceM = OutPiece<GM::PU, GM::UNIT>;
+    using Piecev = OutPiece<Gv::PU, Gv::UNIT>;
+    char* smem; int lane;                       // this wave's LDS image
+    const DmaStream<PieceM>& dM; const DmaStream<Piecev>& dv;
+    unsigned long long qA, qC, qb, fA, fC, fb;  // this position's rows of a_post, cholQ_post, b_post; the tensors' ends
+    bool fast; long e;
+
+    template <int PIECE = 0> MF_DEV void matrix(const T* row, unsigned long long q, unsigned long long f) const {
+        if constexpr (PIECE < GM::NP) {
+            RowFlush<T, GM>::template stage<PIECE>(smem, PL::OFF_stageM, lane, row);
+            RowFlush<T, GM>::store(smem, PL::OFF_stageM, PL::OFF_len, lane, dM, make_srd(q + PIECE * GM::PIECE_BYTES, f), fast, e);
+            matrix<PIECE + 1>(row, q, f);
+        }
+    }
+    MF_DEV void factor(const T (&Gi)[D][D], const T (&mean)[D], bool) const {
+        T row[D * D];
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) row[i * D + j] = (j <= i) ? Gi[i][j] : T(0);
+        matrix(row, qC, fC);
+        static_assert(Gv::NP == 1, "a row of d elements is one piece");
+        RowFlush<T, Gv>::template stage<0>(smem, PL::OFF_stagev, lane, mean);
+        RowFlush<T, Gv>::store(smem, PL::OFF_stagev, PL::OFF_len, lane, dv, make_srd(qb, fb), fast, e);
+    }
+    MF_DEV void transition(const T (&Ap)[D][D], bool) const {
+        T row[D * D];
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) row[i * D + j] = Ap[i][j];
+        matrix(row, qA, fA);
+    }
+};
+
+// Passes 1 and 3: one wavefront per workgroup = 64 (series, chunk) lanes.  KfArgs::P = chunks per series, L = transitions per
+// chunk.  Position e of a chunk = transition tau0 + e; the wave walks e = nsteps-1 ... 0 (a chunk shorter than the wave's
+// longest idles FIRST, so that all lanes end on their chunk's first transition and every DMA address is >= the tensor's start).
 template <typename T, int D, int M, bool RSTEP, bool EMIT>
 __global__ void __launch_bounds__(64) post_lds_kernel(KfArgs<T> a, long L, RedSys<T> out, PostOut<T> po) {
     using Cfg = KfLdsCfg<T, D, M, RSTEP>;
+    using PL = PostLds<T, D, M, RSTEP>;
+    using Sink = PostSink<T, D, M, RSTEP>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const long total = a.B * a.P;
@@ -52,6 +199,13 @@ __global__ void __launch_bounds__(64) post_lds_kernel(KfArgs<T> a, long L, RedSy
         nsteps = o > nsteps ? o : nsteps;
     }
     nsteps = __builtin_amdgcn_readfirstlane((int)nsteps);
+    // shortest chunk of the wave (lanes without one count as 0): from position minlen - 1 down every row of the wave is stored
+    long minlen = len;
+    MF_UNROLL for (int off = 32; off > 0; off >>= 1) {
+        const long o = __shfl_xor((long long)minlen, off);
+        minlen = o < minlen ? o : minlen;
+    }
+    minlen = __builtin_amdgcn_readfirstlane((int)minlen);
 
     // ---- DMA set-up: per-row offsets into LDS tables, wave-uniform stream pointers ---------------------
     const unsigned long long offA = (unsigned long long)(s * nt + tau0) * (D * D * S);
@@ -69,6 +223,7 @@ __global__ void __launch_bounds__(64) post_lds_kernel(KfArgs<T> a, long L, RedSy
         tab[Cfg::OFF_relH / 4 + lane] = rowok ? (unsigned)(offH - offH0) : MF_DMA_INVALID;
         tab[Cfg::OFF_rely / 4 + lane] = rowok ? (unsigned)(offy - offy0) : MF_DMA_INVALID;
         tab[Cfg::OFF_relR / 4 + lane] = rowok ? (unsigned)(offR - offR0) : MF_DMA_INVALID;
+        if (EMIT) reinterpret_cast<int*>(smem)[PL::OFF_len / 4 + lane] = rowok ? (int)len : 0;
         if (lane < Cfg::StC::U) {
             unsigned g = 0;
             MF_UNROLL for (int cc = 0; cc < Cfg::StC::U; ++cc) if (lane == cc) g = (unsigned)Cfg::StC::global_unit(cc);
@@ -109,12 +264,29 @@ __global__ void __launch_bounds__(64) post_lds_kernel(KfArgs<T> a, long L, RedSy
     // the LDS tables must be visible to every lane before the first DMA address is formed (one wave: a wait on the LDS
     // counter is enough) and the plain loads above must be done before DMAs are counted
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (EMIT) {
+        // hipcc's wait-count pass does not look into asm: for it the boundary loads above are still in flight, and since their
+        // first use is INSIDE the loop (whose header merges the pre-header state back in on every iteration) it put a
+        // `s_waitcnt vmcnt(0)` in front of four groups of instructions of every step - each one a full drain of the next step's
+        // DMA prefetch (and of the output stores).  Touching the values here makes it place that wait once, before the loop.
+        MF_UNROLL for (int i = 0; i < D; ++i) {
+            asm volatile("" : "+v"(E.t[i]));
+            MF_UNROLL for (int j = 0; j <= i; ++j) asm volatile("" : "+v"(E.Phi[i][j]));
+        }
+    }
     dA.init(smem, lane, Cfg::OFF_relA, 0);
     dC.init(smem, lane, Cfg::OFF_relA, Cfg::OFF_gtabC);
     db.init(smem, lane, Cfg::OFF_relb, 0);
     dH.init(smem, lane, Cfg::OFF_relH, 0);
     dy.init(smem, lane, Cfg::OFF_rely, 0);
     if (RSTEP) dR.init(smem, lane, Cfg::OFF_relR, 0);
+    // output rows (EMIT): the pieces of a d x d row and of a d row, with the row offsets of the input streams of the same shape
+    DmaStream<typename Sink::PieceM> dOM;
+    DmaStream<typename Sink::Piecev> dOv;
+    if (EMIT) {
+        dOM.init(smem, lane, Cfg::OFF_relA, 0);
+        dOv.init(smem, lane, Cfg::OFF_relb, 0);
+    }
 
     const RowReader<T, typename Cfg::StA> rA(smem, Cfg::OFF_A, lane);
     const RowReader<T, typename Cfg::StC> rC(smem, Cfg::OFF_C, lane);
@@ -129,10 +301,13 @@ __global__ void __launch_bounds__(64) post_lds_kernel(KfArgs<T> a, long L, RedSy
                 make_srd(py, ey), make_srd(pR, eR), lds0, true};
         p0.template all<0>();
     }
-    // output rows of this lane's chunk (EMIT): transition tau0 + e of series s
-    T* oA = po.a_post + (s * nt + tau0) * D * D;
-    T* oC = po.cq_post + (s * nt + tau0) * D * D;
-    T* ob = po.b_post + (s * nt + tau0) * D;
+    // output rows (EMIT): wave-uniform pointers to the wave's rows at the current position, walking downwards like the inputs
+    unsigned long long qA = (unsigned long long)po.a_post + offA0 + (unsigned long long)e_top * (D * D * S);
+    unsigned long long qC = (unsigned long long)po.cq_post + offA0 + (unsigned long long)e_top * (D * D * S);
+    unsigned long long qb = (unsigned long long)po.b_post + offb0 + (unsigned long long)e_top * (D * S);
+    const unsigned long long fA = (unsigned long long)po.a_post + (unsigned long long)a.B * nt * (D * D * S);
+    const unsigned long long fC = (unsigned long long)po.cq_post + (unsigned long long)a.B * nt * (D * D * S);
+    const unsigned long long fb = (unsigned long long)po.b_post + (unsigned long long)a.B * nt * (D * S);
 
 #define MF_POST_LDS_STEP(FIRST)                                                                                       \
     {                                                                                                                 \
@@ -156,14 +331,10 @@ __global__ void __launch_bounds__(64) post_lds_kernel(KfArgs<T> a, long L, RedSy
                         make_srd(pH, eH), make_srd(py, ey), make_srd(pR, eR), lds0, more, yfetch};                    \
         pump.unpumped();                                                                                              \
         const bool active = e < len;                                                                                  \
-        if (EMIT) {                                                                                                   \
-            T mean[D], Gi[D][D];                                                                                      \
-            post_emit_step<T, D, M>(E.Phi, E.t, E.bad, C, mvec, hk, yk, Rsh, Bm, mean, Gi, pump, active);             \
-            if (active) {                                                                                             \
-                store_mat<T, D, D>(oA + e * D * D, Bm);                                                               \
-                store_lower<T, D>(oC + e * D * D, Gi);                                                                \
-                store_vec<T, D>(ob + e * D, mean);                                                                    \
-            }                                                                                                         \
+        if constexpr (EMIT) {                                                                                         \
+            Sink sink{smem, lane, dOM, dOv, qA, qC, qb, fA, fC, fb, e < minlen, e};                                   \
+            qA -= D * D * S; qC -= D * D * S; qb -= D * S;                                                            \
+            post_emit_step<T, D, M>(E.Phi, E.t, E.bad, C, mvec, hk, yk, Rsh, Bm, pump, sink, active);                 \
         } else {                                                                                                      \
             post_up_step<T, D, M, FIRST>(E, C, mvec, hk, yk, Rsh, Bm, pump, active, c + 1 < a.P);                     \
         }                                                                                                             \

@@ -186,13 +186,15 @@ template <typename T, int D> MF_HD void post_combine(const PostSummary<T, D>& a,
 }
 
 // ---- pass 3 ("emit"): one transition of the textbook backward recursion, restarted from a chunk boundary ----------------
-// (Phi, t) = (Psi, psi) of block t+1 on entry, of block t on exit.  Outputs of the posterior chain at index t:
-// Bm: A_t on entry, A'_{t+1} = -Delta_{t+1}^-1 S_t on exit; mean = Delta_{t+1}^-1 x_{t+1} (-> b'_t); Gi = chol(Delta_{t+1}^-1)
-// (-> cholQ'_t).
-template <typename T, int D, int M, typename Pump>
+// (Phi, t) = (Psi, psi) of block t+1 on entry, of block t on exit.  Outputs of the posterior chain at index t go to `sink`
+// as soon as they exist, so that their stores are in flight during the rest of the step:
+//   sink.factor(Gi, mean)   Gi = chol(Delta_{t+1}^-1) (-> cholQ'_t),  mean = Delta_{t+1}^-1 x_{t+1} (-> b'_t)
+//   sink.transition(Ap)     A'_{t+1} = -Delta_{t+1}^-1 S_t
+// Bm: A_t on entry (destroyed).  Sinks are called by ALL lanes (a device sink moves other lanes' rows); `active` is theirs to use.
+template <typename T, int D, int M, typename Pump, typename Sink>
 MF_HD void post_emit_step(T (&Phi)[D][D], T (&t)[D], bool& bad, const T (&C)[D][D], const T (&mvec)[D],
-                          const T (&hk)[M * D], const T (&yk)[M], const T (&Rsh)[M * M], T (&Bm)[D][D], T (&mean)[D],
-                          T (&Gi)[D][D], const Pump& pump, bool active) {
+                          const T (&hk)[M * D], const T (&yk)[M], const T (&Rsh)[M * M], T (&Bm)[D][D], const Pump& pump,
+                          Sink& sink, bool active) {
     T Ci[D][D], w[D], z[D];
     if (active) {
         LogAcc<T> unused;
@@ -208,39 +210,46 @@ MF_HD void post_emit_step(T (&Phi)[D][D], T (&t)[D], bool& bad, const T (&C)[D][
     }
     pump.template small<1>();
     pump.template big<0>();
-    if (active) {
-        T Gd[D];
-        chol_lower_rev<T, D>(Phi, Gd, bad);                     // Delta = G^T G
-        tri_inv_lower_d<T, D>(Phi, Gd, Gi);                     // chol(Delta^-1) = G^-1
-        trimulT_lower_vec<T, D>(Gi, t, z);                      // z = G^-T x
-        trimul_lower_vec<T, D>(Gi, z, mean);                    // Delta^-1 x
-    }
-    pump.template big<1>();
-    T Pn[D][D], pn[D];
-    if (active) {
-        trimul_lower_inplace<T, D, D>(Ci, Bm);                  // B = C^-1 A
-        gemv_t<T, D, D>(Bm, w, pn);
-        MF_UNROLL for (int i = 0; i < D; ++i) {
-            pn[i] = -pn[i];
-            MF_UNROLL for (int j = 0; j <= i; ++j) Pn[i][j] = T(0);
+    {
+        T Gi[D][D], mean[D];
+        if (active) {
+            T Gd[D];
+            chol_lower_rev<T, D>(Phi, Gd, bad);                 // Delta = G^T G
+            tri_inv_lower_d<T, D>(Phi, Gd, Gi);                 // chol(Delta^-1) = G^-1
+            trimulT_lower_vec<T, D>(Gi, t, z);                  // z = G^-T x
+            trimul_lower_vec<T, D>(Gi, z, mean);                // Delta^-1 x
         }
-        syrk_tn_lower<T, D, D>(Bm, Pn, T(1));                   // A^T Q^-1 A
-    }
-    pump.template big<2>();
-    if (active) {
-        trimulT_lower_inplace<T, D, D>(Ci, Bm);                 // -S_t = Q^-1 A
-        trimulT_lower_inplace<T, D, D>(Gi, Bm);                 // Vn = G^-T (-S)
-        syrk_tn_lower<T, D, D>(Bm, Pn, T(-1));                  // Psi_t = A^T Q^-1 A - S^T Delta^-1 S
-        T vz[D];
-        gemv_t<T, D, D>(Bm, z, vz);
-        MF_UNROLL for (int i = 0; i < D; ++i) pn[i] += vz[i];   // psi_t = -A^T Q^-1 b - S^T Delta^-1 x
-    }
-    pump.template big<3>();
-    if (active) {
-        trimul_lower_inplace<T, D, D>(Gi, Bm);                  // A'_{t+1} = -Delta^-1 S = G^-1 Vn
-        MF_UNROLL for (int i = 0; i < D; ++i) {
-            t[i] = pn[i];
-            MF_UNROLL for (int j = 0; j <= i; ++j) Phi[i][j] = Pn[i][j];
+        sink.factor(Gi, mean, active);
+        pump.template big<1>();
+        T Pn[D][D], pn[D];
+        if (active) {
+            trimul_lower_inplace<T, D, D>(Ci, Bm);              // B = C^-1 A
+            gemv_t<T, D, D>(Bm, w, pn);
+            MF_UNROLL for (int i = 0; i < D; ++i) {
+                pn[i] = -pn[i];
+                MF_UNROLL for (int j = 0; j <= i; ++j) Pn[i][j] = T(0);
+            }
+            syrk_tn_lower<T, D, D>(Bm, Pn, T(1));               // A^T Q^-1 A
+        }
+        pump.template big<2>();
+        {
+            T Ap[D][D];
+            if (active) {
+                trimulT_lower_inplace<T, D, D>(Ci, Bm);         // -S_t = Q^-1 A
+                trimulT_lower_inplace<T, D, D>(Gi, Bm);         // Vn = G^-T (-S)
+                trimul_lower<T, D, D>(Gi, Bm, Ap);              // A'_{t+1} = -Delta^-1 S = G^-1 Vn
+            }
+            sink.transition(Ap, active);
+        }
+        pump.template big<3>();
+        if (active) {
+            syrk_tn_lower<T, D, D>(Bm, Pn, T(-1));              // Psi_t = A^T Q^-1 A - S^T Delta^-1 S
+            T vz[D];
+            gemv_t<T, D, D>(Bm, z, vz);
+            MF_UNROLL for (int i = 0; i < D; ++i) {
+                t[i] = pn[i] + vz[i];                           // psi_t = -A^T Q^-1 b - S^T Delta^-1 x
+                MF_UNROLL for (int j = 0; j <= i; ++j) Phi[i][j] = Pn[i][j];
+            }
         }
     }
 }

@@ -10,6 +10,16 @@
 namespace {
 using namespace mf;
 
+// where the emit step hands over its outputs: plain stores at index k of the posterior chain
+template <typename T, int D> struct HostSink {
+    T* a_post; T* b_post; T* cq_post; long k;
+    void factor(const T (&Gi)[D][D], const T (&mean)[D], bool) {
+        store_lower<T, D>(cq_post + k * D * D, Gi);
+        store_vec<T, D>(b_post + k * D, mean);
+    }
+    void transition(const T (&Ap)[D][D], bool) { store_mat<T, D, D>(a_post + k * D * D, Ap); }
+};
+
 template <typename T, int D, int M>
 int run(long B, long Tn, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H, const T* y,
         const T* Rinv, int per_step, long L, T* a_post, T* mu0_post, T* b_post, T* cp0_post, T* cq_post) {
@@ -70,13 +80,10 @@ int run(long B, long Tn, const T* mu0, const T* cholP0, const T* A, const T* b, 
                 }
             }
             for (long e = len - 1; e >= 0; --e) {
-                T C[D][D] = {}, mv[D], hk[M * D], yk[M], Rsh[M * M], Bm[D][D], mean[D], Gi[D][D] = {};
+                T C[D][D] = {}, mv[D], hk[M * D], yk[M], Rsh[M * M], Bm[D][D];
                 load_step(tau0 + e, C, mv, hk, yk, Rsh, Bm);
-                post_emit_step<T, D, M>(Phi, t, bad, C, mv, hk, yk, Rsh, Bm, mean, Gi, NoPump{}, true);
-                const long k = s * nt + tau0 + e;
-                store_mat<T, D, D>(a_post + k * D * D, Bm);
-                store_vec<T, D>(b_post + k * D, mean);
-                store_lower<T, D>(cq_post + k * D * D, Gi);
+                HostSink<T, D> sink{a_post, b_post, cq_post, s * nt + tau0 + e};
+                post_emit_step<T, D, M>(Phi, t, bad, C, mv, hk, yk, Rsh, Bm, NoPump{}, sink, true);
             }
             if (c == 0) {
                 T C[D][D] = {}, mv[D], hk[M * D], yk[M], Rsh[M * M], mean[D], Gi[D][D] = {};
