@@ -226,14 +226,43 @@ def same_dtype_device(ref: torch.Tensor, what: str, **tensors):
 
 # ---- non-positive pivots -------------------------------------------------------------------------------------------------
 # TensorFlow's Cholesky op raises on a matrix that is not positive definite (block_tri_diag.py:423-436).  Here every
-# factorising kernel gets a flag that lives in PINNED HOST memory (the GPU writes it across the bus, and only when a pivot
-# fails - the success path costs nothing: no fill kernel, no copy, no sync).  Results are NaN from the failing block on.
-#   * default: the flag is looked at (a host read) at the start of every later library call and by ``check_errors()``;
-#     a failure raises MarkovflowAmdError there, naming the operations issued since the last clean look;
+# factorising kernel gets `info`, ONE int in DEVICE memory per (device, stream), and raises it with a plain store; results are
+# NaN from the failing block on.  Right behind every factorising launch a 4-byte device-to-host copy of that int into a pinned
+# mirror is queued ON THE SAME STREAM: whenever the host has synchronised with the stream (a host read of a result, an
+# explicit synchronisation) the mirror holds the final word - nothing crosses the bus outside stream order, so a failure can
+# be neither missed nor attributed to a later call (rounds 1-3 had the kernels write a pinned host flag directly: that store
+# could land after `synchronize()` had returned).
+#   * default: the scalar results are CheckedTensors (below) - the host read of one raises MarkovflowAmdError; the mirror is
+#     also looked at (no synchronisation) at the start of every later library call and by ``check_errors()`` (which
+#     synchronises), naming the operations issued since the last clean synchronised look;
 #   * MF_CHECK_PIVOTS=1 (or ``set_synchronous_checks(True)``): every factorising call synchronises its stream and raises
 #     at once, exactly where TensorFlow would.
 CHECK_PIVOTS = os.environ.get("MF_CHECK_PIVOTS", "0") == "1"
-_flags = {}      # device index -> (pinned int32 tensor, its address for the C ABI, the same int as a ctypes view)
+
+
+class _Flag:
+    """The `info` word of one (device, stream) and its pinned host mirror."""
+
+    def __init__(self, device_index: int, stream):
+        self.stream = stream
+        self.dev = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", device_index))
+        self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.view = ctypes.c_int.from_address(self.host.data_ptr())
+        self.ptr = ctypes.c_void_p(self.dev.data_ptr())
+
+    def mirror(self):
+        """Queue the copy of the device word behind whatever the stream holds."""
+        with torch.cuda.stream(self.stream):
+            self.host.copy_(self.dev, non_blocking=True)
+
+    def clear(self):
+        """After a SYNCHRONISED look that found the flag raised: every copy queued so far has landed."""
+        with torch.cuda.stream(self.stream):
+            self.dev.zero_()
+        self.view.value = 0
+
+
+_flags = {}      # (device index, stream handle) -> _Flag
 _issued = []     # names of factorising calls since the last clean look
 
 
@@ -255,9 +284,7 @@ class errors_as_nan:
     def __exit__(self, *exc):
         global _suppress
         _suppress -= 1
-        for idx in _flags:
-            torch.cuda.synchronize(idx)
-        _take_failures(synced=True)
+        _take_failures(synced=False, synchronise=True)
         return False
 
 
@@ -265,31 +292,39 @@ _suppress = 0
 
 
 def pivot_info(device):
-    """The `info` argument of a factorising entry point: pointer to this device's pinned host flag."""
+    """The `info` argument of a factorising entry point: pointer to the device int of (this device, its current stream)."""
     device = torch.device(device)
     if device.type != "cuda":
         raise RuntimeError("markovflow_amd kernels run on an MI355X only: got a CPU tensor and there is no CPU fallback. "
                            "Move the inputs to device 'cuda'.")
     idx = device.index
     idx = torch.cuda.current_device() if idx is None else idx
-    if idx not in _flags:
-        flag = torch.zeros(1, dtype=torch.int32).pin_memory()
-        _flags[idx] = (flag, ctypes.c_void_p(flag.data_ptr()), ctypes.c_int.from_address(flag.data_ptr()))
-    return _flags[idx][1]
+    stream = torch.cuda.current_stream(idx)
+    key = (idx, stream.cuda_stream)
+    if key not in _flags:
+        _flags[key] = _Flag(idx, stream)
+    return _flags[key].ptr
 
 
-def _take_failures(synced: bool = False):
-    """Look at every device's flag.  A raised flag is cleared and reported with the names issued so far.  A clean look only
-    forgets the names when it came after a synchronisation (``synced``): without one, a kernel issued earlier may still be
-    running and raise the flag later - its name has to survive this look (a factorisation followed by any
-    non-factorising call used to lose it)."""
+def _take_failures(synced: bool = False, synchronise: bool = False):
+    """Look at every mirror.  ``synchronise``: wait for every stream that holds a flag first (then the look is final).
+    ``synced``: the caller has just synchronised with the streams (a host read, ``torch.cuda.synchronize``).  A raised flag
+    is cleared - after a synchronisation of its stream, so that no copy of the old value is still under way - and reported
+    with the names issued so far.  A clean look only forgets the names when it was a synchronised one: without that a kernel
+    issued earlier may still be running and raise the flag later, and its name has to survive this look."""
+    final = synced or synchronise
+    if synchronise:
+        for f in _flags.values():
+            f.stream.synchronize()
     bad = False
-    for _, _, view in _flags.values():
-        if view.value != 0:
-            view.value = 0
+    for f in _flags.values():
+        if f.view.value != 0:
+            if not final:
+                f.stream.synchronize()
+            f.clear()
             bad = True
     if not bad:
-        if synced:
+        if final:
             _issued.clear()
         return None
     ops = ", ".join(dict.fromkeys(_issued)) or "a factorisation"
@@ -298,8 +333,8 @@ def _take_failures(synced: bool = False):
 
 
 def raise_pending(synced: bool = False):
-    """Raise if a kernel that has FINISHED since the last look met a non-positive pivot (no synchronisation).  The flag is
-    read whenever this library has handed one to a kernel, whether or not a name is on record."""
+    """Raise if a factorisation whose flag copy has LANDED met a non-positive pivot (no synchronisation of its own).
+    ``synced``: the caller has synchronised with the producing stream, so every copy queued before has landed."""
     if _flags and not _suppress:
         ops = _take_failures(synced)
         if ops is not None:
@@ -307,10 +342,14 @@ def raise_pending(synced: bool = False):
 
 
 def check_errors():
-    """Synchronise every device this library has used and raise if any factorisation met a non-positive pivot."""
-    for idx in _flags:
-        torch.cuda.synchronize(idx)
-    raise_pending(synced=True)
+    """Synchronise every stream this library has handed a flag to and raise if any factorisation met a non-positive pivot."""
+    if _flags and not _suppress:
+        ops = _take_failures(synchronise=True)
+        if ops is not None:
+            raise MarkovflowAmdError(f"matrix is not positive definite (non-positive pivot) in one of: {ops}")
+    elif _flags:
+        for f in _flags.values():
+            f.stream.synchronize()
 
 
 # Methods through which a result reaches the host.  Each of them synchronises the producing stream, so when it returns the
@@ -330,8 +369,13 @@ class CheckedTensor(torch.Tensor):
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         out = super().__torch_function__(func, types, args, kwargs or {})
-        if getattr(func, "__name__", "") in _HOST_READS:
-            raise_pending()
+        if getattr(func, "__name__", "") in _HOST_READS and _flags and not _suppress:
+            # the read has synchronised the stream the value was produced on; a flag of ANOTHER stream (rare) is waited for
+            cur = torch.cuda.current_stream().cuda_stream if torch.cuda.is_initialized() else 0
+            for f in _flags.values():
+                if f.stream.cuda_stream != cur:
+                    f.stream.synchronize()
+            raise_pending(synced=True)
         return out
 
 
@@ -343,12 +387,21 @@ def checked(t: torch.Tensor) -> torch.Tensor:
 
 
 def raise_on_info(info, what: str, device=None):
-    """Called after a factorising launch.  Synchronous mode: wait and raise now; default: remember the name."""
+    """Called right after a factorising launch: queues the copy of the flag into its pinned mirror behind the kernel.
+    Synchronous mode: wait and raise now; default: remember the name."""
     _issued.append(what)
     if len(_issued) > 64:
         del _issued[:-64]
+    if info is None:
+        return
+    idx = torch.device(device).index if device is not None else None
+    idx = torch.cuda.current_device() if idx is None else idx
+    stream = torch.cuda.current_stream(idx)
+    flag = _flags.get((idx, stream.cuda_stream))
+    if flag is not None:
+        flag.mirror()
     if CHECK_PIVOTS and not _suppress:
-        torch.cuda.current_stream(device).synchronize()
+        stream.synchronize()
         ops = _take_failures(synced=True)
         if ops is not None:
             raise MarkovflowAmdError(f"{what}: matrix is not positive definite")

@@ -13,11 +13,11 @@
 #define MF_HD __host__ __device__ __forceinline__
 
 namespace mf {
-// Raise the caller's `info` flag (non-positive pivot).  A plain system-scope store of 1, not an atomic RMW: the flag may live
-// in pinned HOST memory (markovflow_amd/_lib.py keeps it there so that the success path needs no fill kernel, copy or sync),
-// and a store crosses the bus on every platform while a PCIe atomic may not; all writers write the same value.
+// Raise the caller's `info` flag (non-positive pivot): one int in DEVICE memory; all writers write the same value.  The host
+// learns of it through a stream-ordered copy queued behind the kernel (markovflow_amd/_lib.py), never through a store of
+// the kernel's own across the bus - that one could land after the stream's synchronisation had returned.
 __device__ __forceinline__ void raise_info(int* info) {
-    __hip_atomic_store(info, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(info, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 }   // namespace mf
 #define MF_UNROLL _Pragma("unroll")

@@ -69,5 +69,7 @@ def sharded_elbo(expected_log_likelihood: torch.Tensor, kl_divergence: torch.Ten
         return all_reduce_sum(local.clone(), group)
     # keep the LOCAL graph: value = the all-reduced total, gradient = that of this rank's terms (each rank owns its series'
     # parameters; shared hyper-parameters need the usual gradient all-reduce on top)
+    # `total + 0`: the added term is exactly zero, so the VALUE is the all-reduced total bit for bit on every rank (ranks that
+    # branch on it - early stopping, a line search - stay together; `local + (total - local)` rounds differently per rank)
     total = all_reduce_sum(local.detach().clone(), group)
-    return local + (total - local.detach())
+    return total + (local - local.detach())

@@ -277,7 +277,7 @@ class BaseKalmanFilter(abc.ABC):
             _lib.check(-100, "mf_kf_loglik")
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a_s.device)
         out = torch.empty(bsz, dtype=a_s.dtype, device=a_s.device)
-        info = _lib.pivot_info(a_s.device)           # None unless MF_CHECK_PIVOTS=1
+        info = _lib.pivot_info(a_s.device)
         _lib.call("mf_kf_loglik", a_s.dtype, bsz, n, d, m, _lib.ptr(mu0), _lib.ptr(cp0), _lib.ptr(a_s),
                   _lib.ptr(b_s), _lib.ptr(cq), _lib.ptr(h), _lib.ptr(y), _lib.ptr(r_inv), int(per_step),
                   0.0, _lib.ptr(out), _lib.ptr(ws), ws_bytes, info, self._chunks, self._prof_events[0],

@@ -1,7 +1,13 @@
 """
-Scan gfx950 assembly (hipcc -save-temps .s, or llvm-objdump -d output) of the row kernels for the one hazard the compiler cannot
-see inside asm statements: a DPP instruction whose broadcast operand (src0) was written by a VALU instruction in one of the
-two preceding issue slots (s_nop N counts N + 1 slots).  Also prints registers, scratch and the instruction mix per kernel.
+Scan gfx950 assembly (hipcc -save-temps .s, or llvm-objdump -d output) of the row kernels for the hazards the compiler cannot
+see inside asm statements:
+  * a DPP instruction whose broadcast operand (src0) was written by a VALU instruction in one of the two preceding issue slots;
+  * a DPP instruction within five issue slots of a VALU write to EXEC (v_cmpx*, or a VALU instruction with `exec` as its
+    destination; scalar writes - s_and_saveexec, s_mov exec - are not a DPP hazard: LLVM's GCNHazardRecognizer::checkDPPHazards
+    counts VALU definitions only) - in program order AND across every branch into a label (the slots before the branch
+    count, the branch itself is one).
+(s_nop N counts N + 1 slots.)  Also prints registers, scratch and the instruction mix per kernel.  Part of the build:
+csrc/Makefile runs it on every translation unit that holds row kernels and fails on a hazard.
 
     python3 scripts/check_dpp_hazards.py markovflow_amd/csrc/build/mf_inst-hip-amdgcn-amd-amdhsa-gfx950.s [name-filter]
 Exit code 1 when a hazard is found.
@@ -22,6 +28,61 @@ def regs_of(tok):
     return set()
 
 
+def writes_exec(t):
+    op = t.split()[0]
+    if op.startswith("v_cmpx"):
+        return True
+    if op.startswith("v_") and len(t.split()) > 1:
+        dst = t[len(op):].strip().split(",")[0].strip()
+        return dst in ("exec", "exec_lo", "exec_hi")
+    return False
+
+
+def slots(t):
+    return int(t.split()[1], 0) + 1 if t.split()[0] == "s_nop" else 1
+
+
+def exec_hazards(body, need=5):
+    """DPP instructions reached with fewer than `need` issue slots since a write to EXEC."""
+    seq = [(k, t) for k, t in body if k in ("ins", "label")]
+    labels = {t: i for i, (k, t) in enumerate(seq) if k == "label"}
+    # entry[i]: the smallest number of slots since an EXEC write with which position i can be reached (None: >= need)
+    entry = {}
+    for i, (k, t) in enumerate(seq):
+        if k == "ins" and t.split()[0] in ("s_branch", "s_cbranch_scc0", "s_cbranch_scc1", "s_cbranch_vccz", "s_cbranch_vccnz",
+                                           "s_cbranch_execz", "s_cbranch_execnz"):
+            tgt = t.split()[-1]
+            if tgt not in labels:
+                continue
+            # slots between the last EXEC write before the branch and the branch (inclusive of the branch)
+            dist, j = 1, i - 1
+            found = None
+            while j >= 0 and dist <= need:
+                kk, tt = seq[j]
+                if kk == "ins":
+                    if writes_exec(tt):
+                        found = dist
+                        break
+                    dist += slots(tt)
+                j -= 1
+            if found is not None:
+                p = labels[tgt]
+                entry[p] = min(entry.get(p, need), found)
+    out = []
+    since = need                         # slots since the last EXEC write on the fall-through path
+    for i, (k, t) in enumerate(seq):
+        if k == "label":
+            since = min(since, entry.get(i, need))
+            continue
+        if ("dpp" in t.split()[0] or "row_newbcast" in t) and since < need:
+            out.append((i, t + f"   [only {since} slot(s) after a write to EXEC]", since))
+        if writes_exec(t):
+            since = 0
+        else:
+            since = min(need, since + slots(t))
+    return out
+
+
 def main():
     path = sys.argv[1]
     flt = sys.argv[2] if len(sys.argv) > 2 else "row"
@@ -37,6 +98,9 @@ def main():
         t = line.strip()
         if t.startswith(".amdhsa_kernel") or t.startswith(".section") or t.startswith(".end_amdhsa_kernel"):
             name = None if t.startswith(".section") else name
+        if re.match(r"^\.?L?[A-Za-z_][\w.$]*:$", t) and not t.startswith(";"):
+            body.append(("label", t[:-1]))
+            continue
         if not t or t.startswith((";", ".", "//")) or t.endswith(":"):
             if t.startswith("; NumVgprs") or t.startswith("; ScratchSize") or t.startswith("; Occupancy") or t.startswith("; NumSgprs"):
                 body.append(("meta", t))
@@ -71,6 +135,7 @@ def main():
                 recent = (recent + [wr])[-2:]
             else:
                 recent = (recent + [set()])[-2:]
+        hazards += exec_hazards(body)
         print(f"{kname[:100]}\n   {len(ins)} instructions  {dict(mix)}\n   {'  '.join(meta)}")
         for i, t, back in hazards[:10]:
             print(f"   HAZARD at instruction {i} (source written {back} slot(s) before): {t}")

@@ -33,10 +33,6 @@ def _clean_pivot_flags():
     try:
         from markovflow_amd import _lib
         if _lib._flags:
-            import time
-            import torch
-            torch.cuda.synchronize()
-            time.sleep(0.002)          # a flag write that is still crossing the bus when the synchronisation returns lands first
-            _lib._take_failures(synced=True)
+            _lib._take_failures(synchronise=True)
     except Exception:
         pass

@@ -128,7 +128,10 @@ def _elbo_worker(rank, world, port, bsz, results):
         elbo_g = mfd.sharded_elbo(ell * scale, ql.kl_divergence(pl))
         elbo_g.backward()
         assert float(elbo_g) == float(elbo) and torch.equal(scale.grad, ell)
-        results[rank] = (float(kl), float(elbo))
+        # awkward magnitudes: `local + (total - local)` would round differently on every rank
+        big = torch.tensor([1e8 / 3.0 * (rank + 1)], dtype=torch.float64, requires_grad=True)
+        elbo_big = mfd.sharded_elbo(big * 1.0000001, torch.zeros(1, dtype=torch.float64))
+        results[rank] = (float(kl), float(elbo), float(elbo_g), float(elbo_big))
     finally:
         dist.destroy_process_group()
 
@@ -148,4 +151,5 @@ def test_sharded_kl_and_elbo_gloo(world, bsz):
     for rank in range(world):
         assert results[rank][0] == pytest.approx(kl, rel=1e-12)
         assert results[rank][1] == pytest.approx(ell - kl, rel=1e-12)
+    # bit-identical on every rank: the plain totals AND the totals that carry a local graph
     assert len({results[r] for r in range(world)}) == 1

@@ -1,0 +1,92 @@
+"""
+The non-positive-pivot channel is deterministic: TensorFlow's Cholesky raises inside the op
+(/root/reference/markovflow/block_tri_diag.py:423-436); here a kernel raises ONE int in device memory and the host learns of
+it through a 4-byte copy queued on the same stream right behind the kernel (markovflow_amd/_lib.py) - after any
+synchronisation with that stream the answer is final: no failure is missed, none is attributed to a later call.  No sleeps,
+no retries.
+"""
+import numpy as np
+import pytest
+import torch
+
+import markovflow_amd as mfa
+from markovflow_amd import _lib, synthetic
+from test_gpu_kalman import DEV, tt
+
+pytestmark = pytest.mark.gpu
+
+
+def _spd_and_not(rng, n=12, d=3):
+    good = np.tile(4.0 * np.eye(d), (2, n, 1, 1)) + 0.1 * rng.normal(size=(2, n, d, d))
+    good = good + np.swapaxes(good, -1, -2)
+    bad = good.copy()
+    bad[1, n // 2] = -np.eye(d)
+    sub = 0.1 * rng.normal(size=(2, n - 1, d, d))
+    return good, bad, sub
+
+
+def test_failure_injection_500_times_no_stale_and_no_missed_flag(rng):
+    """Alternate factorisations of a positive definite and of an indefinite matrix, 500 times: every bad one is reported by the
+    next check_errors(), no good one ever is - also when the good one is issued right after a bad one was reported."""
+    good, bad, sub = _spd_and_not(rng)
+    g, b, s = tt(good), tt(bad), tt(sub)
+    _lib.check_errors()
+    missed = stale = 0
+    for i in range(500):
+        mfa.SymmetricBlockTriDiagonal(b, s).cholesky
+        try:
+            _lib.check_errors()
+            missed += 1
+        except mfa.MarkovflowAmdError as exc:
+            assert "cholesky" in str(exc)
+        mfa.SymmetricBlockTriDiagonal(g, s).cholesky
+        try:
+            _lib.check_errors()
+        except mfa.MarkovflowAmdError:
+            stale += 1
+    assert (missed, stale) == (0, 0)
+
+
+def test_host_read_of_a_result_raises_every_time_and_only_then(rng):
+    """`float(kf.log_likelihood())`: 200 alternations of a model with a singular process covariance and a sound one, no
+    synchronisation but the host read itself."""
+    inp = synthetic.make_ssm(3, 40, (3, 3), dtype=torch.float64, device=DEV)
+    bad = dict(inp)
+    bad["cholQ"] = inp["cholQ"].clone()
+    bad["cholQ"][1, 17] = 0.0
+    kf_good, kf_bad = synthetic.kalman_filter_from(inp), synthetic.kalman_filter_from(bad)
+    _lib.check_errors()
+    for i in range(200):
+        with pytest.raises(mfa.MarkovflowAmdError, match="log_likelihood"):
+            float(kf_bad.log_likelihood())
+        assert np.isfinite(float(kf_good.log_likelihood()))
+    _lib.check_errors()
+
+
+def test_flags_are_per_stream(rng):
+    """A failing factorisation on one stream and sound ones on another: check_errors() reports it once, naming the operation;
+    the host read of a result computed on the sound stream synchronises with the other stream's flag too (an error is never
+    lost), and afterwards everything is clean."""
+    good, bad, sub = _spd_and_not(rng)
+    g, b, s = tt(good), tt(bad), tt(sub)
+    inp = synthetic.make_ssm(3, 40, (3, 3), dtype=torch.float64, device=DEV)
+    kf = synthetic.kalman_filter_from(inp)
+    torch.cuda.synchronize()
+    _lib.check_errors()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(s1):
+        mfa.SymmetricBlockTriDiagonal(b, s).cholesky
+    with torch.cuda.stream(s2):
+        ll = kf.log_likelihood()
+    assert len({k[1] for k in _lib._flags}) >= 2
+    with pytest.raises(mfa.MarkovflowAmdError, match="cholesky"):
+        _lib.check_errors()
+    with torch.cuda.stream(s2):
+        assert np.isfinite(float(ll))                 # the failure was reported and cleared: this read is clean
+        mfa.SymmetricBlockTriDiagonal(g, s).cholesky
+    with torch.cuda.stream(s1):
+        mfa.SymmetricBlockTriDiagonal(b, s).cholesky
+    with torch.cuda.stream(s2):
+        with pytest.raises(mfa.MarkovflowAmdError):   # a sound result read on s2 while s1 holds a failure: not lost
+            float(kf.log_likelihood())
+    _lib.check_errors()

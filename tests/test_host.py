@@ -213,11 +213,22 @@ def test_deferred_pivot_failures_keep_their_names_until_a_synchronised_look():
     import ctypes
     from markovflow_amd import _lib
     flag = torch.zeros(1, dtype=torch.int32)
+
+    class _HostStandIn:                 # what _lib._Flag offers, without a device: the mirror word, a stream, clear()
+        view = ctypes.c_int.from_address(flag.data_ptr())
+
+        class stream:
+            cuda_stream = 0
+            synchronize = staticmethod(lambda: None)
+
+        def clear(self):
+            self.view.value = 0
+
     saved_flags, saved_issued = dict(_lib._flags), list(_lib._issued)
     try:
         _lib._flags.clear()
         _lib._issued.clear()
-        _lib._flags[0] = (flag, ctypes.c_void_p(flag.data_ptr()), ctypes.c_int.from_address(flag.data_ptr()))
+        _lib._flags[(0, 0)] = _HostStandIn()
         _lib._issued.append("SymmetricBlockTriDiagonal.cholesky")
         _lib.raise_pending()                                   # e.g. the look at the start of a later solve: kernel still running
         assert _lib._issued == ["SymmetricBlockTriDiagonal.cholesky"]
