@@ -35,6 +35,10 @@ def parse():
     ap.add_argument("--time-points", type=int, default=10000)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--chunks", type=int, default=0, help="time partitions per series (0 = automatic)")
+    ap.add_argument("--workload", default="target", choices=["target", "config4"],
+                    help="target: the headline (KalmanFilter.log_likelihood, B=1024/GPU, T=10000, d=6); config4: BASELINE config 4's "
+                         "per-GPU shard (512 series, T=1000, 3 x Matern-5/2 with 3 outputs, d=9) - log-likelihood + KL(q || prior), "
+                         "one scalar all-reduce (sharded_elbo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the brief timing of BASELINE configs 2-5")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
@@ -316,6 +320,110 @@ def other_configs(dev):
     return out
 
 
+def smoother_and_backward(kf, inputs, bsz, tn, d, m, esz):
+    """The other half of "filter / smoother" at the headline shape: posterior_state_space_model() and the
+    backward of log_likelihood() on the SAME resident inputs, with algorithmic GB/s - bytes every implementation must move:
+    posterior reads A, cholQ, b, H, y and writes A', cholQ', b' ((4 d^2 + 3 d + m d + m) s per step); the backward reads the
+    inputs and writes one gradient per input element ((4 d^2 + 2 d + 2 m d + 2 m) s)."""
+    import torch
+
+    import markovflow_amd as mfa
+
+    out = {}
+    ev = HipEvents()
+    kf._post_prof_events = (ev.start, ev.stop)
+    ms = _time_gpu(kf.posterior_state_space_model, iters=5)
+    kern = []
+    for _ in range(3):
+        kf.posterior_state_space_model()
+        kern.append(ev.elapsed_ms())
+    kf._post_prof_events = (None, None)
+    b_post = bsz * tn * (4 * d * d + 3 * d + m * d + m) * esz
+    out["posterior_TGT"] = {
+        "ms": ms, "kernels_ms": sum(kern) / len(kern), "algorithmic_GBps": b_post / ms / 1e6,
+        "frac_of_hbm_peak": b_post / ms / 1e6 / HBM_PEAK_GBS,
+        "kernels": "mf::post_lds_kernel<EMIT=false> (reversed elimination per chunk) + mf::post_scan_kernel + "
+                   "mf::post_lds_kernel<EMIT=true>; round 3: mf_ssm_precision + parallel-in-time U D U^T + affine scan, 11.2 ms",
+        "note": f"KalmanFilter.posterior_state_space_model B={bsz} T={tn} d={d} m={m}: all five tensors of the posterior chain"}
+    p = kf.prior_ssm
+    leaves = [t.detach().clone().requires_grad_(True) for t in (p.initial_mean, p.cholesky_initial_covariance, p.state_transitions,
+                                                                p.state_offsets, p.cholesky_process_covariances)]
+    kfg = mfa.KalmanFilter(mfa.StateSpaceModel(*leaves), kf.emission, kf.observations, inputs["cholR"])
+    fwd, bwd = [], []
+    for i in range(4):
+        for x in leaves:
+            x.grad = None
+        torch.cuda.synchronize()
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record(); ll = kfg.log_likelihood(); e1.record(); ll.backward(); e2.record()
+        torch.cuda.synchronize()
+        if i:
+            fwd.append(e0.elapsed_time(e1)); bwd.append(e1.elapsed_time(e2))
+    b_bwd = bsz * tn * (4 * d * d + 2 * d + 2 * m * d + 2 * m) * esz
+    f_ms, b_ms = sorted(fwd)[len(fwd) // 2], sorted(bwd)[len(bwd) // 2]
+    out["loglik_backward_TGT"] = {
+        "forward_ms": f_ms, "backward_ms": b_ms, "backward_over_forward": b_ms / f_ms,
+        "backward_algorithmic_GBps": b_bwd / b_ms / 1e6, "backward_frac_of_hbm_peak": b_bwd / b_ms / 1e6 / HBM_PEAK_GBS,
+        "note": "KalmanFilter.log_likelihood().backward() w.r.t. mu0, cholP0, A, b, cholQ (Fisher's identity: streamed posterior "
+                "chain -> smoothed moments -> local closed forms); round 3: 21.8 ms"}
+    return out
+
+
+def config4_rank(args, dev, dist, rank, world, dtype) -> int:
+    """BASELINE config 4's per-GPU shard as the timed step (so that a scaling run measures it too): 512 series x 1000 points,
+    IndependentMultiOutput(3 x Matern-5/2) with 3 outputs (d = 9); step = log-likelihood of the shard + KL(q || prior) of the
+    shard with q the exact posterior chain, combined by sharded_elbo - ONE scalar all-reduce, as models/sparse_variational.py:178-192
+    of the reference sums its terms.  Rank 0 prints one JSON line with its own metric name (never the headline's)."""
+    import torch
+
+    from markovflow_amd import distributed as mfd
+    from markovflow_amd import synthetic
+
+    bsz, tn, d, m = 512, 1000, 9, 3
+    inputs = synthetic.make_ssm(bsz, tn, (5, 5, 5), output_dim=3, dtype=dtype, device=dev, seed=synthetic.DEFAULT_SEED + rank)
+    kf = synthetic.kalman_filter_from(inputs)
+    q = kf.posterior_state_space_model()
+
+    def step():
+        return mfd.sharded_elbo(kf.log_likelihood(), q.kl_divergence(kf.prior_ssm))
+
+    for _ in range(args.warmup):
+        val = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        val = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ranks_seen = 1
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        ones = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_seen = int(ones.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "config 4 shard: log-lik + KL steps/sec (BxT) at d=9, m=3", "value": world * bsz * tn * args.steps / elapsed,
+            "unit": "steps/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"KalmanFilter.log_likelihood + StateSpaceModel.kl_divergence, B={bsz}/GPU T={tn} d={d} m={m} "
+                                   f"{args.dtype} (BASELINE config 4: 4096 series over 8 GPUs), sharded_elbo",
+                       "series_per_gpu": bsz, "time_points": tn, "state_dim": d, "output_dim": m,
+                       "parallelism": f"batch-sharded x{world}, one scalar RCCL all-reduce"},
+            "elbo_like_value": float(val.item())}))
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
+
+
 def launch_ranks(args) -> int:
     """`bench.py --gpus N` without a launcher: THIS process stays GPU-free - it imports neither torch nor any HIP library and
     counts GPUs from sysfs - and starts N fresh rank processes through torch.distributed.run, one per GPU, rendezvous on
@@ -429,6 +537,8 @@ def main():
     from markovflow_amd import synthetic
 
     dtype = torch.float64 if args.dtype == "f64" else torch.float32
+    if args.workload == "config4":
+        sys.exit(config4_rank(args, dev, dist, rank, world, dtype))
     bsz, tn, d, m = args.batch, args.time_points, 6, 1
     # every rank generates its own series (never replicated): weak scaling over the batch axis
     inputs = synthetic.make_ssm(bsz, tn, (5, 5), dtype=dtype, device=dev, seed=synthetic.DEFAULT_SEED + rank)
@@ -538,6 +648,11 @@ def main():
         rel = float(np.max(np.abs(per + cst - cpu_out) / np.abs(cpu_out)))
         result["cpu_baseline"]["max_rel_diff_vs_gpu"] = rel
     if rank == 0 and world == 1 and not args.no_other_configs:
+        try:
+            result["smoother_and_backward"] = smoother_and_backward(kf, inputs, bsz, tn, d, m, esz)
+        except Exception as exc:
+            result["smoother_and_backward"] = {"error": repr(exc)}
+        del kf, inputs
         try:
             result["other_configs"] = other_configs(dev)
         except Exception as exc:   # the headline line must still be printed

@@ -4,7 +4,7 @@ Synthetic state-space inputs of the shapes BASELINE.json names, generated on the
 This is the generator SURVEY.md §8(d) describes: per-series Matérn hyper-parameters, closed-form
 ``A_k = exp(F Δt_k)`` and ``Q_k = P∞ − A_k P∞ A_kᵀ`` (the closed forms of the reference's
 ``markovflow/kernels/matern.py:299-356,434-501`` and ``kernels/sde_kernel.py:421-446``, restated -
-checked against the reference's scipy-expm test kernels in tests/test_synthetic.py), every tensor
+checked against the reference's scipy-expm test kernels in tests/test_host.py::test_synthetic_closed_forms_match_reference_expm_kernels), every tensor
 materialised at full ``[B, T-1, d, d]`` shape the way ``StateSpaceModel`` requires
 (``state_space_model.py:111-116``).  It is input plumbing for tests and bench.py, not part of the
 timed path.

@@ -326,6 +326,22 @@ def test_full_size_partition_invariance_and_linearity():
     np.testing.assert_allclose(total, np.sum(per_auto + cst), rtol=1e-12)
 
 
+def test_full_size_every_series_against_the_c_oracle():
+    """The headline shape (B=1024, T=10000, d=6, m=1, fp64): EVERY series' log-likelihood against the C restatement of the
+    reference algorithm (oracle/c/mf_oracle.c: one series per host thread, natural-order recursion), rtol 1e-8 - the check
+    bench.py makes after its timed region, as a test."""
+    from markovflow_amd import synthetic
+    from oracle import c_oracle as C
+    inp = synthetic.make_ssm(1024, 10000, (5, 5), dtype=torch.float64, device=DEV)
+    kf = synthetic.kalman_filter_from(inp)
+    per = nn(kf._log_likelihood_per_series())
+    arrs = [nn(inp[k]) for k in ("mu0", "cholP0", "A", "b", "cholQ", "H", "y")]
+    ref = C.kf_loglik(*arrs, np.array([[1.0 / 0.1]]))
+    cst = -0.5 * np.log(2 * np.pi) * 10000 + 0.5 * 10000 * np.log(10.0)
+    assert np.all(np.isfinite(per)) and ref.shape == (1024,)
+    np.testing.assert_allclose(per + cst, ref, rtol=1e-8)
+
+
 # ---- the LDS-DMA streaming kernel beyond m = 1 / shared R (even d: rows are whole 16-B units) -----------------------------------
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 @pytest.mark.parametrize("d,m,t", [(2, 2, 33), (4, 2, 50), (6, 3, 64), (8, 2, 20), (6, 2, 300), (4, 3, 129), (6, 4, 64), (5, 4, 100),
