@@ -1,0 +1,190 @@
+"""
+Reverse mode through the block-tridiagonal OPERATORS.
+
+banded_matrices registers a gradient for every op (``/root/reference/markovflow/block_tri_diag.py:22-31``), so TensorFlow
+differentiates through ``precision``, ``cholesky``, ``solve``, ``block_diagonal_of_inverse`` - the CVI models build their
+posterior exactly that way (``models/variational_cvi.py:105-136``: ``dist_p.precision -> naturals_to_ssm_params``) and
+differentiate the ELBO w.r.t. the kernel's hyper-parameters through it (``:402``).  Here: ``torch.autograd.Function``s whose
+FORWARD is the HIP kernel behind the operator and whose backward is
+
+* ``solve`` / ``dense_mult`` / ``abs_log_det``: closed forms on the operator's own kernels (one transposed solve / product +
+  outer products that are local in time) - as fast as the forward;
+* ``cholesky``: the block recurrence ``L_k = chol(D_k - W_{k-1} W_{k-1}^T)``, ``W_k = S_k L_k^-T`` run backwards (the classic
+  ``L^-T Phi(L^T Lbar) L^-1`` adjoint per pivot, chained through ``W``): a loop over the blocks of batched d x d torch
+  products - sequential in time, O(T) small launches: the functional closure of the gap, not a fast path;
+* ``block_diagonal_of_inverse`` (+ sub-diagonal blocks): the block Takahashi recursion re-evaluated in differentiable torch ops.
+
+Values always come from the HIP kernels; only the adjoints above are torch.
+"""
+from typing import Optional
+
+import torch
+
+
+def _tr(x):
+    return x.transpose(-1, -2)
+
+
+def _chol_adjoint(chol: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    """Adjoint of ``L = chol(P)`` for symmetric ``P`` (batched): ``sym(L^-T Phi(L^T Lbar) L^-1)``, ``Phi`` = lower triangle
+    with the diagonal halved."""
+    phi = torch.tril(_tr(chol) @ torch.tril(g))
+    phi = phi - 0.5 * torch.diag_embed(torch.diagonal(phi, dim1=-2, dim2=-1))
+    x = torch.linalg.solve_triangular(_tr(chol), phi, upper=True)               # L^-T Phi
+    x = torch.linalg.solve_triangular(chol, x, upper=False, left=False)         # ... L^-1
+    return 0.5 * (x + _tr(x))
+
+
+class BtdCholesky(torch.autograd.Function):
+    """``SymmetricBlockTriDiagonal.cholesky`` (block_tri_diag.py:423-436).  ``run(diag, sub) -> (ldiag, lsub)`` is the kernel."""
+
+    @staticmethod
+    def forward(ctx, run, diag, sub):
+        ldiag, lsub = run(diag.detach(), None if sub is None else sub.detach())
+        ctx.has_sub = sub is not None
+        ctx.save_for_backward(ldiag, lsub if lsub is not None else ldiag.new_zeros(0))
+        if lsub is None:
+            return ldiag, None
+        return ldiag, lsub
+
+    @staticmethod
+    def backward(ctx, g_ldiag, g_lsub):
+        ldiag, lsub = ctx.saved_tensors
+        n = ldiag.shape[-3]
+        lbar = torch.tril(g_ldiag).clone() if g_ldiag is not None else torch.zeros_like(ldiag)
+        if not ctx.has_sub:
+            return None, _chol_adjoint(ldiag, lbar), None               # independent blocks: one batched adjoint
+        wbar_in = g_lsub if g_lsub is not None else torch.zeros_like(lsub)
+        dbar, sbar = torch.empty_like(ldiag), torch.empty_like(lsub)
+        for k in range(n - 1, -1, -1):
+            pbar = _chol_adjoint(ldiag[..., k, :, :], lbar[..., k, :, :])
+            dbar[..., k, :, :] = pbar
+            if k > 0:
+                w = lsub[..., k - 1, :, :]
+                wbar = wbar_in[..., k - 1, :, :] - 2.0 * pbar @ w                            # P_k = D_k - W W^T
+                sb = torch.linalg.solve_triangular(ldiag[..., k - 1, :, :], wbar, upper=False, left=False)   # W = S L^-T
+                sbar[..., k - 1, :, :] = sb
+                lbar[..., k - 1, :, :] -= torch.tril(_tr(sb) @ w)
+        return None, dbar, sbar
+
+
+class BtdSolve(torch.autograd.Function):
+    """``LowerTriangularBlockTriDiagonal.solve`` (block_tri_diag.py:339-351): ``x = L^-1 r`` or ``L^-T r``; ``r`` may carry
+    extra leading dimensions (one factor, many right-hand sides).  ``run(ldiag, lsub, rhs, transpose)`` is the kernel."""
+
+    @staticmethod
+    def forward(ctx, run, ldiag, lsub, rhs, transpose):
+        out = run(ldiag.detach(), None if lsub is None else lsub.detach(), rhs.detach(), transpose)
+        ctx.run, ctx.transpose, ctx.has_sub = run, transpose, lsub is not None
+        ctx.save_for_backward(ldiag, lsub if lsub is not None else ldiag.new_zeros(0), out)
+        ctx.rhs_shape = rhs.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        ldiag, lsub, x = ctx.saved_tensors
+        lsub = lsub if ctx.has_sub else None
+        rbar = ctx.run(ldiag, lsub, g_out.contiguous(), not ctx.transpose)       # r-bar = L^-T x-bar (resp. L^-1 x-bar)
+        # L-bar = -band(r-bar x^T) for L^-1, -band(x r-bar^T) for L^-T; extra leading dimensions of the right-hand side are summed
+        a, b = (rbar, x) if not ctx.transpose else (x, rbar)
+        extra = a.dim() - (ldiag.dim() - 1)
+        red = tuple(range(extra))
+        gd = -(a[..., :, :, None] * b[..., :, None, :])
+        gd = torch.tril(gd.sum(dim=red) if red else gd)
+        gs = None
+        if ctx.has_sub:
+            gs = -(a[..., 1:, :, None] * b[..., :-1, None, :])
+            gs = gs.sum(dim=red) if red else gs
+        g_rhs = rbar
+        while g_rhs.dim() > len(ctx.rhs_shape):
+            g_rhs = g_rhs.sum(dim=0)
+        for i, (have, want) in enumerate(zip(g_rhs.shape, ctx.rhs_shape)):
+            if want == 1 and have != 1:
+                g_rhs = g_rhs.sum(dim=i, keepdim=True)
+        return None, gd, gs, g_rhs, None
+
+
+class BtdMatvec(torch.autograd.Function):
+    """``BlockTriDiagonal.dense_mult`` (block_tri_diag.py:175-199); mode 0: ``L x``, 1: ``L^T x``, 2: symmetric ``M x``."""
+
+    @staticmethod
+    def forward(ctx, run, diag, sub, right, mode):
+        out = run(diag.detach(), None if sub is None else sub.detach(), right.detach(), mode)
+        ctx.run, ctx.mode, ctx.has_sub = run, mode, sub is not None
+        ctx.save_for_backward(diag, sub if sub is not None else diag.new_zeros(0), right)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        diag, sub, x = ctx.saved_tensors
+        sub = sub if ctx.has_sub else None
+        mode = ctx.mode
+        g = g.contiguous()
+        gx = ctx.run(diag, sub, g, {0: 1, 1: 0, 2: 2}[mode])
+        extra = g.dim() - (diag.dim() - 1)
+        red = tuple(range(extra))
+        outer = lambda u, v: (u[..., :, None] * v[..., None, :])            # noqa: E731
+        if mode == 0:
+            gd, gs = torch.tril(outer(g, x)), (outer(g[..., 1:, :], x[..., :-1, :]) if sub is not None else None)
+        elif mode == 1:
+            gd, gs = torch.tril(outer(x, g)), (outer(x[..., 1:, :], g[..., :-1, :]) if sub is not None else None)
+        else:       # symmetric: the lower triangle of the blocks stands for both; the gradient is w.r.t. the symmetric blocks
+            full = outer(g, x)
+            gd = 0.5 * (full + _tr(full))
+            gs = (outer(g[..., 1:, :], x[..., :-1, :]) + outer(x[..., 1:, :], g[..., :-1, :])) if sub is not None else None
+        if red:
+            gd = gd.sum(dim=red)
+            gs = None if gs is None else gs.sum(dim=red)
+        while gx.dim() > x.dim():
+            gx = gx.sum(dim=0)
+        for i, (have, want) in enumerate(zip(gx.shape, x.shape)):
+            if want == 1 and have != 1:
+                gx = gx.sum(dim=i, keepdim=True)
+        return None, gd, gs, gx, None
+
+
+class BtdInverseBlocks(torch.autograd.Function):
+    """Diagonal (and sub-diagonal) blocks of ``(L L^T)^-1`` (block_tri_diag.py:318-337; block Takahashi)."""
+
+    @staticmethod
+    def forward(ctx, run, ldiag, lsub, want_sub):
+        odiag, osub = run(ldiag.detach(), None if lsub is None else lsub.detach(), want_sub)
+        ctx.has_sub, ctx.want_sub = lsub is not None, want_sub and lsub is not None
+        ctx.save_for_backward(ldiag, lsub if lsub is not None else ldiag.new_zeros(0))
+        return odiag, osub
+
+    @staticmethod
+    def backward(ctx, g_diag, g_sub):
+        ldiag, lsub = ctx.saved_tensors
+        with torch.enable_grad():
+            chol = ldiag.detach().requires_grad_(True)
+            w = lsub.detach().requires_grad_(True) if ctx.has_sub else None
+            eye = torch.eye(chol.shape[-1], dtype=chol.dtype, device=chol.device).expand(chol.shape)
+            linv = torch.linalg.solve_triangular(torch.tril(chol), eye, upper=False)
+            base = _tr(linv) @ linv
+            n = chol.shape[-3]
+            if w is None:
+                sig, subs = base, None
+            else:
+                gk = w @ linv[..., :-1, :, :]                               # G_k = W_k L_k^-1
+                blocks, sblocks = [None] * n, [None] * (n - 1)
+                blocks[n - 1] = base[..., n - 1, :, :]
+                for k in range(n - 2, -1, -1):
+                    g = gk[..., k, :, :]
+                    blocks[k] = base[..., k, :, :] + _tr(g) @ blocks[k + 1] @ g
+                    sblocks[k] = -blocks[k + 1] @ g
+                sig = torch.stack(blocks, dim=-3)
+                subs = torch.stack(sblocks, dim=-3) if n > 1 else None
+            outs, gouts = [sig], [g_diag if g_diag is not None else torch.zeros_like(sig)]
+            if ctx.want_sub and subs is not None and g_sub is not None:
+                outs.append(subs)
+                gouts.append(g_sub)
+            ins = [chol] + ([w] if w is not None else [])
+            grads = torch.autograd.grad(outs, ins, gouts, allow_unused=True)
+        g_chol = torch.tril(grads[0]) if grads[0] is not None else None
+        g_w = grads[1] if w is not None else None
+        return None, g_chol, g_w, None
+
+
+def needs_grad(*tensors: Optional[torch.Tensor]) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)

@@ -12,6 +12,7 @@ from typing import Optional, Tuple
 
 import torch
 
+from . import _autograd_ops as _ag
 from . import _lib
 
 
@@ -125,14 +126,10 @@ class BlockTriDiagonal(abc.ABC):
     # -- products (block_tri_diag.py:175-199) ----------------------------------------------------------
     def dense_mult(self, right: torch.Tensor, transpose_left: bool = False) -> torch.Tensor:
         """``L x`` (or ``Lᵀ x``; symmetric objects ignore nothing: transposing them is a no-op)."""
-        right_b, out_shape = self._broadcast_right(right)
         mode = 2 if self._symmetric else (1 if transpose_left else 0)
-        out = torch.empty_like(right_b)
-        sub = None if self._sub_diag is None else _flat(self._sub_diag, 3)
-        _lib.call("mf_btd_matvec", self._diag.dtype, self._batch_numel, right_b.shape[0], self.outer_dim,
-                  self.inner_dim, _lib.ptr(_flat(self._diag, 3)), _lib.ptr(sub), _lib.ptr(right_b), _lib.ptr(out),
-                  mode, _lib.stream_ptr(self._diag.device))
-        return out.reshape(out_shape)
+        if _ag.needs_grad(self._diag, self._sub_diag, right):
+            return _ag.BtdMatvec.apply(_matvec_kernel, self._diag, self._sub_diag, right, mode)
+        return _matvec_kernel(self._diag, self._sub_diag, right, mode)
 
     @abc.abstractmethod
     def __add__(self, other):
@@ -191,6 +188,11 @@ class LowerTriangularBlockTriDiagonal(BlockTriDiagonal):
         return self._diag_and_sub_of_inverse(want_sub=False)[0]
 
     def _diag_and_sub_of_inverse(self, want_sub: bool):
+        if _ag.needs_grad(self._diag, self._sub_diag):
+            return _ag.BtdInverseBlocks.apply(_inverse_blocks_kernel, self._diag, self._sub_diag, want_sub)
+        return _inverse_blocks_kernel(self._diag, self._sub_diag, want_sub)
+
+    def _diag_and_sub_of_inverse_kernel(self, want_sub: bool):
         diag = _flat(self._diag, 3)
         sub = None if self._sub_diag is None else _flat(self._sub_diag, 3)
         odiag = torch.empty_like(diag)
@@ -207,7 +209,12 @@ class LowerTriangularBlockTriDiagonal(BlockTriDiagonal):
         return odiag, osub
 
     def solve(self, right: torch.Tensor, transpose_left: bool = False) -> torch.Tensor:
-        """``L⁻¹ x`` or ``L⁻ᵀ x`` (block_tri_diag.py:339-351)."""
+        """``L⁻¹ x`` or ``L⁻ᵀ x`` (block_tri_diag.py:339-351).  Differentiable w.r.t. the factor and the right-hand side."""
+        if _ag.needs_grad(self._diag, self._sub_diag, right):
+            return _ag.BtdSolve.apply(_solve_kernel, self._diag, self._sub_diag, right, bool(transpose_left))
+        return self._solve_kernel(right, transpose_left)
+
+    def _solve_kernel(self, right: torch.Tensor, transpose_left: bool = False) -> torch.Tensor:
         right_b, out_shape = self._broadcast_right(right)
         diag = _flat(self._diag, 3)
         sub = None if self._sub_diag is None else _flat(self._sub_diag, 3)
@@ -222,6 +229,8 @@ class LowerTriangularBlockTriDiagonal(BlockTriDiagonal):
 
     def abs_log_det(self) -> torch.Tensor:
         """``log |det L|`` with shape ``batch_shape`` (block_tri_diag.py:353-366)."""
+        if _ag.needs_grad(self._diag):
+            return torch.sum(torch.log(torch.abs(torch.diagonal(self._diag, dim1=-2, dim2=-1))), dim=(-1, -2))
         diag = _flat(self._diag, 3)
         out = torch.empty(diag.shape[0], dtype=diag.dtype, device=diag.device)
         _lib.call("mf_btd_logdet", diag.dtype, diag.shape[0], self.outer_dim, self.inner_dim, _lib.ptr(diag),
@@ -243,7 +252,13 @@ class SymmetricBlockTriDiagonal(BlockTriDiagonal):
 
     @property
     def cholesky(self) -> LowerTriangularBlockTriDiagonal:
-        """Natural-order Cholesky factor (block_tri_diag.py:423-436)."""
+        """Natural-order Cholesky factor (block_tri_diag.py:423-436).  Differentiable (``_autograd_ops.BtdCholesky``)."""
+        if _ag.needs_grad(self._diag, self._sub_diag):
+            ldiag, lsub = _ag.BtdCholesky.apply(_cholesky_kernel, self._diag, self._sub_diag)
+            return LowerTriangularBlockTriDiagonal(ldiag, lsub)
+        return self._cholesky_kernel()
+
+    def _cholesky_kernel(self) -> LowerTriangularBlockTriDiagonal:
         diag = _flat(self._diag, 3)
         sub = None if self._sub_diag is None else _flat(self._sub_diag, 3)
         ldiag = torch.empty_like(diag)
@@ -297,6 +312,31 @@ class SymmetricBlockTriDiagonal(BlockTriDiagonal):
         if eta is not None:
             m_post, chol_dinv = m_post.reshape(eta.shape), chol_dinv.reshape(self._diag.shape)
         return u_t, chol_d, m_post, chol_dinv
+
+
+# the kernels behind the differentiable operators, as plain functions of tensors (what _autograd_ops' Functions call)
+def _cholesky_kernel(diag, sub):
+    chol = SymmetricBlockTriDiagonal(diag.contiguous(), None if sub is None else sub.contiguous())._cholesky_kernel()
+    return chol.block_diagonal, chol.block_sub_diagonal
+
+
+def _solve_kernel(ldiag, lsub, rhs, transpose):
+    return LowerTriangularBlockTriDiagonal(ldiag, lsub)._solve_kernel(rhs, transpose)
+
+
+def _inverse_blocks_kernel(ldiag, lsub, want_sub):
+    return LowerTriangularBlockTriDiagonal(ldiag, lsub)._diag_and_sub_of_inverse_kernel(want_sub)
+
+
+def _matvec_kernel(diag, sub, right, mode):
+    op = BlockTriDiagonal.__new__(SymmetricBlockTriDiagonal if mode == 2 else LowerTriangularBlockTriDiagonal)
+    BlockTriDiagonal.__init__(op, diag, mode == 2, sub)
+    right_b, out_shape = op._broadcast_right(right)
+    out = torch.empty_like(right_b)
+    sub_f = None if sub is None else _flat(sub, 3)
+    _lib.call("mf_btd_matvec", diag.dtype, op._batch_numel, right_b.shape[0], op.outer_dim, op.inner_dim,
+              _lib.ptr(_flat(diag, 3)), _lib.ptr(sub_f), _lib.ptr(right_b), _lib.ptr(out), mode, _lib.stream_ptr(diag.device))
+    return out.reshape(out_shape)
 
 
 def _banded_to_block_tri(banded: torch.Tensor, block_size: int) -> LowerTriangularBlockTriDiagonal:

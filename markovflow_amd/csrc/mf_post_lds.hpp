@@ -25,32 +25,26 @@ template <typename T> struct PostOut {
     const T* bPsi; const T* bpsi;                                 // boundary state per consumer chunk [B, P, D, D] / [B, P, D] (EMIT)
 };
 
-// ---- coalesced output rows -------------------------------------------------------------------------------------------
+// ---- coalesced output rows, one store at a time ---------------------------------------------------------------------------
 // A lane produces whole rows of the posterior chain (A'_t: d x d, cholQ'_t: d x d, b'_t: d) for ITS chunk; stored directly,
 // one store instruction of the wave touches 64 different 128-B lines.  Instead the rows go through an LDS staging buffer:
-// every lane writes (a piece of) its row, then instruction i of a wave stores unit 64 i + lane of the row-major image, i.e.
-// consecutive lanes store consecutive 16-B units of a row - the mirror image of the LDS-DMA loads.  `buffer_store` with the
-// row offsets of the input streams (same shapes); a row that must not be written (lane without a chunk, chunk not yet
+// every lane writes (half of) its row, then store instruction i of the wave moves unit 64 i + lane of the row-major image,
+// i.e. consecutive lanes store consecutive 16-B units of a row - the mirror image of the LDS-DMA loads.  `buffer_store` with
+// the row offsets of the input streams (same shapes); a row that must not be written (lane without a chunk, chunk not yet
 // active) gets an out-of-range offset, which the buffer range check drops.
 //
-// What a store costs (measured on MI355X, B=1024, T=10000, d=6 fp64; profiles/r04_post_store_path.txt,
+// WHEN the stores are issued (measured on MI355X, B=1024, T=10000, d=6 fp64; profiles/r04_post_store_path.txt,
 // scripts/micro/store_rate.hip): a SIMD's store path takes one 1-KB store instruction per write round trip - 50-85 cycles on
-// an idle chip, ~330 while every CU streams 3 TB/s of reads - and the issuing wave is only held when its NEXT store finds the
-// path busy; VALU work between two stores hides it.  The step's 39 stores are issued in five bursts (where the rows exist),
-// so a wave pays ~13 k cycles per step for them on top of 15 k of arithmetic: emit pass 3.9 ms against 1.8 ms with the
-// stores dropped by the range check.  Tried and measured slower: `nt` stores (4.6 ms), 256-B aligned rows (3.6 ms: the
-// partial lines are not the cost), all stores of a CU issued by a fourth, storing wavefront fed through LDS (4.3-4.8 ms: one
-// SIMD's store path carries a third of what three carry).  What would hide them is a store every ~350 cycles of arithmetic.
-constexpr int MF_POST_STAGE_CAP = 9472;        // bytes of staging per matrix piece (d = 6 fp64: two pieces of 9 units)
-template <int ROWB> struct OutGeom {
-    static constexpr int UNIT = (ROWB % 16 == 0) ? 16 : ((ROWB % 8 == 0) ? 8 : 4);
-    static constexpr int UG = ROWB / UNIT;                          // units per row
-    static constexpr int pieces() { for (int n = 1; n <= UG; ++n) if (UG % n == 0 && 64 * ROWB / n <= MF_POST_STAGE_CAP) return n; return UG; }
-    static constexpr int NP = pieces();
-    static constexpr int PU = UG / NP;                              // units per piece
-    static constexpr int PIECE_BYTES = PU * UNIT;                   // bytes of a row in one piece
-    static constexpr int STAGE_BYTES = 64 * PU * UNIT;
-};
+// an idle chip, ~330 while every CU streams 3 TB/s of reads - and the issuing wave is held only when its NEXT store finds the
+// path busy; arithmetic between two stores hides it (64 fp64 FMAs between stores: the store costs nothing).  Issued in
+// bursts where the rows become available, a step's 39 stores cost the wave ~13 k cycles on top of 15 k of arithmetic (emit
+// pass 3.9 ms against 1.8 ms with every store dropped by the range check).  So the emit step (post_emit_step) calls
+// `tick<SITE>()` every ~30 multiply-adds and the sink issues ONE store per tick from the piece that is staged: the first half
+// of chol(Delta^-1) and b' while the products up to A' run, its second half after them, the first half of A' during the rest
+// of the step and the second half during the NEXT step's factorisation (its rows wait in the staging buffer across the loop's
+// back edge).  Tried and measured slower: `nt` stores (4.6 ms), 256-B aligned rows (3.6 ms: partial lines are not the
+// cost), all stores of a CU issued by a fourth, storing wavefront fed through LDS (4.3-4.8 ms: one SIMD's store path carries
+// a third of what three carry).
 // what DmaStream needs to know of a piece: NU units of UNIT bytes per row, all kept
 template <int NU, int UNIT_> struct OutPiece {
     static constexpr int U = NU, NI = NU, UNIT = UNIT_, UG = NU;
@@ -61,15 +55,13 @@ template <> struct OutWord<16> { typedef int type __attribute__((ext_vector_type
 template <> struct OutWord<8> { typedef int type __attribute__((ext_vector_type(2))); };
 template <> struct OutWord<4> { typedef int type; };
 // The read-back of the staged image goes to ACCUMULATION registers and is stored from there ("a" operands; gfx950 has one
-// unified register file, ds_read and buffer_store take AGPRs): the emit step keeps all 256 VGPRs busy, and with VGPR
-// destinations hipcc reuses ONE register quadruple for every unit - read, wait for the LDS, store, 39 times per step.  All
-// reads of a piece are issued first, one wait, then the stores.
+// unified register file, ds_read and buffer_store take AGPRs): the emit step keeps all 256 VGPRs busy.
 // Hazards hipcc cannot see inside asm: the descriptor may just have been written by v_readfirstlane (5 wait states before a
 // VMEM instruction reads an SGPR a VALU instruction wrote: leading s_nop 4), and a store of more than 64 bits needs one wait
 // state before its data registers are overwritten (trailing s_nop 0).
-template <int OFF> MF_DEV void lds_read_a(OutWord<16>::type& v, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(v) : "v"(addr), "n"(OFF) : "memory"); }
-template <int OFF> MF_DEV void lds_read_a(OutWord<8>::type& v, unsigned addr) { asm volatile("ds_read_b64 %0, %1 offset:%2" : "=a"(v) : "v"(addr), "n"(OFF) : "memory"); }
-template <int OFF> MF_DEV void lds_read_a(OutWord<4>::type& v, unsigned addr) { asm volatile("ds_read_b32 %0, %1 offset:%2" : "=a"(v) : "v"(addr), "n"(OFF) : "memory"); }
+MF_DEV void lds_read_a(OutWord<16>::type& v, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=a"(v) : "v"(addr) : "memory"); }
+MF_DEV void lds_read_a(OutWord<8>::type& v, unsigned addr) { asm volatile("ds_read_b64 %0, %1" : "=a"(v) : "v"(addr) : "memory"); }
+MF_DEV void lds_read_a(OutWord<4>::type& v, unsigned addr) { asm volatile("ds_read_b32 %0, %1" : "=a"(v) : "v"(addr) : "memory"); }
 MF_DEV void buf_store(OutWord<16>::type v, mf_v4i srd, unsigned voff) {
     asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 0" :: "a"(v), "v"(voff), "s"(srd) : "memory");
 }
@@ -79,94 +71,147 @@ MF_DEV void buf_store(OutWord<8>::type v, mf_v4i srd, unsigned voff) {
 MF_DEV void buf_store(OutWord<4>::type v, mf_v4i srd, unsigned voff) {
     asm volatile("s_nop 4\n\tbuffer_store_dword %0, %1, %2, 0 offen\n\ts_nop 0" :: "a"(v), "v"(voff), "s"(srd) : "memory");
 }
-// LDS words shared between wavefronts of a workgroup (flags, descriptors): volatile accesses the compiler must not cache
-MF_DEV unsigned lds_ld_u32(unsigned addr) {
-    unsigned x;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(x) : "v"(addr) : "memory");
-    return x;
-}
-MF_DEV void lds_st_u32(unsigned addr, unsigned x) { asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(x) : "memory"); }
 
+// Geometry of the outputs of one step: a d x d row is handled as two halves of H0 and D - H0 matrix rows, a d row whole.
 template <typename T, int D, int M, bool RSTEP> struct PostLds {
     using Cfg = KfLdsCfg<T, D, M, RSTEP>;
-    using GM = OutGeom<D * D * (int)sizeof(T)>;
-    using Gv = OutGeom<D * (int)sizeof(T)>;
+    static constexpr int S = (int)sizeof(T);
+    static constexpr int H0 = (D + 1) / 2;
+    static constexpr int B0 = H0 * D * S, B1 = (D - H0) * D * S, Bv = D * S;      // bytes of the two halves and of a vector row
+    static constexpr int unit() { for (int u = 16; u > 4; u /= 2) if (B0 % u == 0 && B1 % u == 0 && Bv % u == 0) return u; return 4; }
+    static constexpr int UNIT = unit();
+    static constexpr int U0 = B0 / UNIT, U1 = B1 / UNIT, Uv = Bv / UNIT;          // store instructions per piece
     static constexpr int OFF_stageM = ((Cfg::LDS_TOTAL + 15) / 16) * 16;
-    static constexpr int OFF_stagev = OFF_stageM + GM::STAGE_BYTES;
-    static constexpr int OFF_len = OFF_stagev + ((Gv::STAGE_BYTES + 15) / 16) * 16;
+    static constexpr int OFF_stagev = OFF_stageM + 64 * B0;
+    static constexpr int OFF_len = OFF_stagev + ((64 * Bv + 15) / 16) * 16;
     static constexpr int TOTAL = OFF_len + 256;                     // one wavefront's image + staging
 };
 
-// rows of one output tensor: `row[e]` of every lane, piece by piece through the staging buffer
-template <typename T, typename G> struct RowFlush {
-    using Piece = OutPiece<G::PU, G::UNIT>;
-    using W = typename OutWord<G::UNIT>::type;
-    static constexpr int EPU = G::UNIT / (int)sizeof(T);           // elements per unit
-    // validity of the row that instruction i of a piece moves, at position e (slow path: some chunk of the wave is not active yet)
+// One staged piece: 64 rows x NU units in an LDS buffer; unit u of the image (u = 64 i + lane for store instruction i) is read
+// back one instruction ahead of its store.
+template <typename T, int NU, int UNIT> struct StagedPiece {
+    using W = typename OutWord<UNIT>::type;
+    static constexpr int EPU = UNIT / (int)sizeof(T);
+    // validity of the row that instruction i moves, at position e (slow path: some chunk of the wave is not active yet)
     static MF_DEV unsigned guarded(const char* smem, int off_len, int lane, int i, long e, unsigned vo) {
-        const int q0 = lane / G::PU, c0 = lane - q0 * G::PU;
-        const int a = (64 * i) / G::PU, b = (64 * i) % G::PU;
-        const int row = q0 + a + ((c0 + b >= G::PU) ? 1 : 0);
+        const int q0 = lane / NU, c0 = lane - q0 * NU;
+        const int a = (64 * i) / NU, b = (64 * i) % NU;
+        const int row = q0 + a + ((c0 + b >= NU) ? 1 : 0);
         const int len = *reinterpret_cast<const int*>(smem + off_len + row * 4);
         return e < (long)len ? vo : MF_DMA_INVALID;
     }
-    template <int I = 0> static MF_DEV void read_back(W (&v)[G::PU], unsigned addr) {
-        if constexpr (I < G::PU) {
-            lds_read_a<I * 64 * G::UNIT>(v[I], addr);
-            read_back<I + 1>(v, addr);
+    // this lane's NU * EPU elements into the buffer, then the read of unit 0 is started
+    static MF_DEV void stage(char* smem, int off_stage, int lane, const T* row, W& q0) {
+        if constexpr (NU > 0) {
+            T* dst = reinterpret_cast<T*>(smem + off_stage + lane * (NU * UNIT));
+            MF_UNROLL for (int k = 0; k < NU * EPU; ++k) dst[k] = row[k];
+            // (asm volatile with a memory clobber: the stores above are issued first, and the LDS executes one wave's operations in order)
+            lds_read_a(q0, (unsigned)(size_t)smem + (unsigned)off_stage + (unsigned)lane * UNIT);
         }
     }
-    // this lane's part of piece PIECE into the staging buffer
-    template <int PIECE> static MF_DEV void stage(char* smem, int off_stage, int lane, const T* row) {
-        T* dst = reinterpret_cast<T*>(smem + off_stage + lane * (G::PU * G::UNIT));
-        MF_UNROLL for (int k = 0; k < G::PU * EPU; ++k) dst[k] = row[PIECE * G::PU * EPU + k];
-    }
-    // the staged piece -> global memory; srd: the wave's rows of this tensor at the current position, advanced to the piece
-    static MF_DEV void store(const char* smem, int off_stage, int off_len, int lane, const DmaStream<Piece>& ds, mf_v4i srd,
-                             bool fast, long e) {
-        // (the asm statements are `volatile` with a memory clobber: staging stores are issued before them, and the LDS executes
-        // one wave's operations in order - also against the previous piece's reads of the same buffer)
-        W v[G::PU];
-        read_back(v, (unsigned)(size_t)smem + (unsigned)off_stage + (unsigned)lane * G::UNIT);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        MF_UNROLL for (int i = 0; i < G::PU; ++i) {
-            const unsigned vo = fast ? ds.vo[i] : guarded(smem, off_len, lane, i, e, ds.vo[i]);
-            buf_store(v[i], srd, vo);
+    // store unit I (already on its way into q[I & 1]) and start the read of unit I + 1
+    template <int I> static MF_DEV void unit(const char* smem, int off_stage, int off_len, int lane, const unsigned (&vo)[NU > 0 ? NU : 1],
+                                             mf_v4i srd, bool fast, long e, W& qa, W& qb) {
+        if constexpr (I < NU) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned off = fast ? vo[I] : guarded(smem, off_len, lane, I, e, vo[I]);
+            buf_store((I & 1) ? qb : qa, srd, off);
+            if constexpr (I + 1 < NU)
+                lds_read_a(((I + 1) & 1) ? qb : qa, (unsigned)(size_t)smem + (unsigned)off_stage + (unsigned)(64 * (I + 1) + lane) * UNIT);
         }
     }
 };
 
-// The emit step's sink (mf_post_math.hpp: post_emit_step) on the device: the computing wave stages and stores its own rows.
+// The emit step's sink (mf_post_math.hpp: post_emit_step) on the device.  It lives across the steps of the loop: the second half
+// of A' of step j is stored during step j + 1.
 template <typename T, int D, int M, bool RSTEP> struct PostSink {
     using PL = PostLds<T, D, M, RSTEP>;
-    using GM = typename PL::GM;
-    using Gv = typename PL::Gv;
-    using PieceM = OutPiece<GM::PU, GM::UNIT>;
-    using Piecev = OutPiece<Gv::PU, Gv::UNIT>;
-    char* smem; int lane;                       // this wave's LDS image
-    const DmaStream<PieceM>& dM; const DmaStream<Piecev>& dv;
-    unsigned long long qA, qC, qb, fA, fC, fb;  // this position's rows of a_post, cholQ_post, b_post; the tensors' ends
-    bool fast; long e;
+    static constexpr int H0 = PL::H0, U0 = PL::U0, U1 = PL::U1, Uv = PL::Uv, UNIT = PL::UNIT;
+    using W = typename OutWord<UNIT>::type;
+    using P0 = StagedPiece<T, U0, UNIT>;
+    using P1 = StagedPiece<T, U1, UNIT>;
+    using Pv = StagedPiece<T, Uv, UNIT>;
+    char* smem; int lane;
+    DmaStream<OutPiece<U0, UNIT>> d0;              // row offsets per store instruction: first / second half of a matrix row, vector row
+    DmaStream<OutPiece<(U1 > 0 ? U1 : 1), UNIT>> d1;
+    DmaStream<OutPiece<Uv, UNIT>> dv;
+    unsigned long long qA, qC, qb, fA, fC, fb;     // this position's rows of a_post, cholQ_post, b_post; the tensors' ends
+    long e, minlen;
+    bool have_prev;                                // the previous step left the second half of its A' in the staging buffer
+    W ma, mb, va, vb;                              // read-back registers: matrix pieces, vector piece
+    mf_v4i sM, sv;                                 // descriptors of the staged matrix piece / vector piece
 
-    template <int PIECE = 0> MF_DEV void matrix(const T* row, unsigned long long q, unsigned long long f) const {
-        if constexpr (PIECE < GM::NP) {
-            RowFlush<T, GM>::template stage<PIECE>(smem, PL::OFF_stageM, lane, row);
-            RowFlush<T, GM>::store(smem, PL::OFF_stageM, PL::OFF_len, lane, dM, make_srd(q + PIECE * GM::PIECE_BYTES, f), fast, e);
-            matrix<PIECE + 1>(row, q, f);
+    MF_DEV void init(char* smem_, int lane_, int rel_mat, int rel_vec) {
+        smem = smem_; lane = lane_;
+        d0.init(smem, lane, rel_mat, 0);
+        if constexpr (U1 > 0) d1.init(smem, lane, rel_mat, 0);
+        dv.init(smem, lane, rel_vec, 0);
+        have_prev = false;
+    }
+    // windows of tick sites (post_emit_step's map) and the units a site stores: units [i U / W, (i + 1) U / W) at site S0 + i
+    template <int SITE, int S0, int S1, int U, typename F> MF_DEV void window(F&& f) {
+        if constexpr (SITE >= S0 && SITE < S1 && U > 0) {
+            constexpr int i = SITE - S0, Wd = S1 - S0;
+            static_for<(i * U) / Wd, ((i + 1) * U) / Wd>(f);
         }
     }
-    MF_DEV void factor(const T (&Gi)[D][D], const T (&mean)[D], bool) const {
-        T row[D * D];
-        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) row[i * D + j] = (j <= i) ? Gi[i][j] : T(0);
-        matrix(row, qC, fC);
-        static_assert(Gv::NP == 1, "a row of d elements is one piece");
-        RowFlush<T, Gv>::template stage<0>(smem, PL::OFF_stagev, lane, mean);
-        RowFlush<T, Gv>::store(smem, PL::OFF_stagev, PL::OFF_len, lane, dv, make_srd(qb, fb), fast, e);
+    template <int SITE> MF_DEV void tick(bool) {
+        constexpr int C0a = 9, C0b = 10 + D, Cva = C0b, Cvb = 10 + 2 * D, C1a = Cvb, C1b = 10 + 4 * D, A0a = 34, A0b = 34 + (D - H0) + D + 1;
+        // the second half of the PREVIOUS step's A' (position e + 1; its descriptor was built when it was staged)
+        if (have_prev)
+            window<SITE, 0, 9, U1>([&](auto ic) {
+                P1::template unit<decltype(ic)::value>(smem, PL::OFF_stageM, PL::OFF_len, lane, d1.vo, sM, e + 1 < minlen, e + 1, ma, mb);
+            });
+        window<SITE, C0a, C0b, U0>([&](auto ic) {
+            P0::template unit<decltype(ic)::value>(smem, PL::OFF_stageM, PL::OFF_len, lane, d0.vo, sM, e < minlen, e, ma, mb);
+        });
+        window<SITE, Cva, Cvb, Uv>([&](auto ic) {
+            Pv::template unit<decltype(ic)::value>(smem, PL::OFF_stagev, PL::OFF_len, lane, dv.vo, sv, e < minlen, e, va, vb);
+        });
+        window<SITE, C1a, C1b, U1>([&](auto ic) {
+            P1::template unit<decltype(ic)::value>(smem, PL::OFF_stageM, PL::OFF_len, lane, d1.vo, sM, e < minlen, e, ma, mb);
+        });
+        window<SITE, A0a, A0b, U0>([&](auto ic) {
+            P0::template unit<decltype(ic)::value>(smem, PL::OFF_stageM, PL::OFF_len, lane, d0.vo, sM, e < minlen, e, ma, mb);
+        });
     }
-    MF_DEV void transition(const T (&Ap)[D][D], bool) const {
-        T row[D * D];
-        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) row[i * D + j] = Ap[i][j];
-        matrix(row, qA, fA);
+    MF_DEV void stage_factor(const T (&Gi)[D][D], const T (&mean)[D], bool) {
+        T row[H0 * D];
+        MF_UNROLL for (int i = 0; i < H0; ++i) MF_UNROLL for (int j = 0; j < D; ++j) row[i * D + j] = (j <= i) ? Gi[i][j] : T(0);
+        sM = make_srd(qC, fC);
+        P0::stage(smem, PL::OFF_stageM, lane, row, ma);
+        sv = make_srd(qb, fb);
+        Pv::stage(smem, PL::OFF_stagev, lane, mean, va);
+    }
+    MF_DEV void stage_factor_rest(const T (&Gi)[D][D], bool) {
+        if constexpr (U1 > 0) {
+            T row[(D - H0) * D];
+            MF_UNROLL for (int i = H0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) row[(i - H0) * D + j] = (j <= i) ? Gi[i][j] : T(0);
+            sM = make_srd(qC + PL::B0, fC);
+            P1::stage(smem, PL::OFF_stageM, lane, row, ma);
+        }
+    }
+    template <int HALF, int R> MF_DEV void stage_transition(const T (&Ap)[R][D], bool) {
+        T row[R * D];
+        MF_UNROLL for (int i = 0; i < R; ++i) MF_UNROLL for (int j = 0; j < D; ++j) row[i * D + j] = Ap[i][j];
+        if constexpr (HALF == 0) {
+            sM = make_srd(qA, fA);
+            P0::stage(smem, PL::OFF_stageM, lane, row, ma);
+        } else {
+            sM = make_srd(qA + PL::B0, fA);
+            P1::stage(smem, PL::OFF_stageM, lane, row, ma);
+            have_prev = true;
+        }
+    }
+    // after the last step: the second half of its A' is still staged (position `e` of that step)
+    MF_DEV void flush() {
+        if constexpr (U1 > 0) {
+            if (have_prev)
+                static_for<0, U1>([&](auto ic) {
+                    P1::template unit<decltype(ic)::value>(smem, PL::OFF_stageM, PL::OFF_len, lane, d1.vo, sM, e < minlen, e, ma, mb);
+                });
+        }
+        have_prev = false;
     }
 };
 
@@ -280,13 +325,9 @@ __global__ void __launch_bounds__(64) post_lds_kernel(KfArgs<T> a, long L, RedSy
     dH.init(smem, lane, Cfg::OFF_relH, 0);
     dy.init(smem, lane, Cfg::OFF_rely, 0);
     if (RSTEP) dR.init(smem, lane, Cfg::OFF_relR, 0);
-    // output rows (EMIT): the pieces of a d x d row and of a d row, with the row offsets of the input streams of the same shape
-    DmaStream<typename Sink::PieceM> dOM;
-    DmaStream<typename Sink::Piecev> dOv;
-    if (EMIT) {
-        dOM.init(smem, lane, Cfg::OFF_relA, 0);
-        dOv.init(smem, lane, Cfg::OFF_relb, 0);
-    }
+    // output rows (EMIT): row offsets of the input streams of the same shape
+    Sink sink;
+    if (EMIT) sink.init(smem, lane, Cfg::OFF_relA, Cfg::OFF_relb);
 
     const RowReader<T, typename Cfg::StA> rA(smem, Cfg::OFF_A, lane);
     const RowReader<T, typename Cfg::StC> rC(smem, Cfg::OFF_C, lane);
@@ -308,6 +349,7 @@ __global__ void __launch_bounds__(64) post_lds_kernel(KfArgs<T> a, long L, RedSy
     const unsigned long long fA = (unsigned long long)po.a_post + (unsigned long long)a.B * nt * (D * D * S);
     const unsigned long long fC = (unsigned long long)po.cq_post + (unsigned long long)a.B * nt * (D * D * S);
     const unsigned long long fb = (unsigned long long)po.b_post + (unsigned long long)a.B * nt * (D * S);
+    if (EMIT) { sink.fA = fA; sink.fC = fC; sink.fb = fb; sink.minlen = minlen; sink.e = 0; }
 
 #define MF_POST_LDS_STEP(FIRST)                                                                                       \
     {                                                                                                                 \
@@ -332,7 +374,7 @@ __global__ void __launch_bounds__(64) post_lds_kernel(KfArgs<T> a, long L, RedSy
         pump.unpumped();                                                                                              \
         const bool active = e < len;                                                                                  \
         if constexpr (EMIT) {                                                                                         \
-            Sink sink{smem, lane, dOM, dOv, qA, qC, qb, fA, fC, fb, e < minlen, e};                                   \
+            sink.qA = qA; sink.qC = qC; sink.qb = qb; sink.e = e;                                                     \
             qA -= D * D * S; qC -= D * D * S; qb -= D * S;                                                            \
             post_emit_step<T, D, M>(E.Phi, E.t, E.bad, C, mvec, hk, yk, Rsh, Bm, pump, sink, active);                 \
         } else {                                                                                                      \
@@ -343,6 +385,7 @@ __global__ void __launch_bounds__(64) post_lds_kernel(KfArgs<T> a, long L, RedSy
     if (nsteps > 0) MF_POST_LDS_STEP(true)
     for (j = 1; j < nsteps; ++j) MF_POST_LDS_STEP(false)
 #undef MF_POST_LDS_STEP
+    if (EMIT) sink.flush();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (EMIT) {
         if (valid && c == 0) {     // block 0: the prior closes the chain

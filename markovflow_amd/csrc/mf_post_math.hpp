@@ -17,6 +17,7 @@
 // lane by lane against the numpy oracle (no GPU in the build container).
 #pragma once
 #include "mf_kernels.hpp"
+#include <type_traits>
 
 namespace mf {
 
@@ -185,65 +186,169 @@ template <typename T, int D> MF_HD void post_combine(const PostSummary<T, D>& a,
     }
 }
 
+// compile-time loop: f(std::integral_constant<int, I>) for I = I0 ... I1-1 (a tick site needs its index as a constant)
+template <int I0, int I1, typename F> MF_HD void static_for(F&& f) {
+    if constexpr (I0 < I1) {
+        f(std::integral_constant<int, I0>{});
+        static_for<I0 + 1, I1>(f);
+    }
+}
+
 // ---- pass 3 ("emit"): one transition of the textbook backward recursion, restarted from a chunk boundary ----------------
-// (Phi, t) = (Psi, psi) of block t+1 on entry, of block t on exit.  Outputs of the posterior chain at index t go to `sink`
-// as soon as they exist, so that their stores are in flight during the rest of the step:
-//   sink.factor(Gi, mean)   Gi = chol(Delta_{t+1}^-1) (-> cholQ'_t),  mean = Delta_{t+1}^-1 x_{t+1} (-> b'_t)
-//   sink.transition(Ap)     A'_{t+1} = -Delta_{t+1}^-1 S_t
-// Bm: A_t on entry (destroyed).  Sinks are called by ALL lanes (a device sink moves other lanes' rows); `active` is theirs to use.
+// (Phi, t) = (Psi, psi) of block t+1 on entry, of block t on exit.  Bm: A_t on entry (destroyed).  The outputs of the posterior
+// chain at index t are handed to `sink` in pieces, as soon as they exist:
+//   sink.stage_factor(Gi, mean)      Gi = chol(Delta_{t+1}^-1) (-> cholQ'_t; the sink takes rows 0 .. D/2-1 now),
+//                                    mean = Delta_{t+1}^-1 x_{t+1} (-> b'_t)
+//   sink.stage_factor_rest(Gi)       rows D/2 .. D-1 of the same factor
+//   sink.stage_transition<HALF>(Ap)  rows [HALF D/2, ...) of A'_{t+1} = -Delta_{t+1}^-1 S_t (Ap holds these rows only)
+// Between the arithmetic the step calls sink.tick<SITE>() at EMIT_SITES places spaced ~25-35 multiply-adds apart: a device
+// sink issues ONE store instruction per tick (mf_post_lds.hpp: a SIMD's store path takes a 1-KB store per ~350 cycles under
+// load and only the NEXT store waits for it, so stores spread through the arithmetic cost nothing, stores issued back to
+// back cost ~13 k cycles per step).  Site map: [0, 9) while (Delta, x) is completed and factored - the previous step's last
+// piece drains there -, [9, 34) the products up to A' (the factor's pieces drain), [34, 44) the rest.
+// Sinks are called by ALL lanes (a device sink moves other lanes' rows); `active` is theirs to use.
+constexpr int EMIT_SITES = 44;
 template <typename T, int D, int M, typename Pump, typename Sink>
 MF_HD void post_emit_step(T (&Phi)[D][D], T (&t)[D], bool& bad, const T (&C)[D][D], const T (&mvec)[D],
                           const T (&hk)[M * D], const T (&yk)[M], const T (&Rsh)[M * M], T (&Bm)[D][D], const Pump& pump,
                           Sink& sink, bool active) {
+    constexpr int H0 = (D + 1) / 2;                             // rows in the first half of a matrix output
     T Ci[D][D], w[D], z[D];
     if (active) {
         LogAcc<T> unused;
         unused.init();
         tri_inv_lower<T, D>(C, Ci, unused, bad);
     }
+    sink.template tick<0>(active);
     pump.template small<0>();
     if (active) {
         trimul_lower_vec<T, D>(Ci, mvec, w);
         trimulT_self_lower_acc<T, D>(Ci, Phi);
+    }
+    sink.template tick<1>(active);
+    if (active) {
         trimulT_lower_vec_acc<T, D>(Ci, w, t);
         Obs<T, D, M>::apply(hk, yk, Rsh, M, Phi, t);            // (Phi, t) = (Delta_{t+1}, x_{t+1})
     }
+    sink.template tick<2>(active);
     pump.template small<1>();
     pump.template big<0>();
+    T Gi[D][D], mean[D];
     {
-        T Gi[D][D], mean[D];
+        // Delta = G^T G from the last row upwards (chol_lower_rev), two rows per tick site
+        T Gd[D];
+        static_for<0, 3>([&](auto ic) {
+            constexpr int K = decltype(ic)::value;
+            if (active) {
+                MF_UNROLL for (int j = D - 1 - (K * D) / 3; j > D - 1 - ((K + 1) * D) / 3; --j) {
+                    const T s = Phi[j][j];
+                    bad |= !(s > T(0));
+                    const T inv = t_rsqrt<T>(s);
+                    Phi[j][j] = s * inv;
+                    Gd[j] = inv;
+                    MF_UNROLL for (int i = 0; i < j; ++i) Phi[j][i] *= inv;
+                    MF_UNROLL for (int k = 0; k < j; ++k)
+                        MF_UNROLL for (int i = 0; i <= k; ++i) Phi[k][i] -= Phi[j][k] * Phi[j][i];
+                }
+            }
+            sink.template tick<3 + K>(active);
+        });
+        if (active) tri_inv_lower_d<T, D>(Phi, Gd, Gi);         // chol(Delta^-1) = G^-1
+        sink.template tick<6>(active);
         if (active) {
-            T Gd[D];
-            chol_lower_rev<T, D>(Phi, Gd, bad);                 // Delta = G^T G
-            tri_inv_lower_d<T, D>(Phi, Gd, Gi);                 // chol(Delta^-1) = G^-1
             trimulT_lower_vec<T, D>(Gi, t, z);                  // z = G^-T x
             trimul_lower_vec<T, D>(Gi, z, mean);                // Delta^-1 x
         }
-        sink.factor(Gi, mean, active);
-        pump.template big<1>();
-        T Pn[D][D], pn[D];
+        sink.template tick<7>(active);
+        sink.template tick<8>(active);
+    }
+    sink.stage_factor(Gi, mean, active);
+    pump.template big<1>();
+    T Pn[D][D], pn[D];
+    // B = C^-1 A in place, bottom-up, a row per site
+    static_for<0, D>([&](auto ic) {
+        constexpr int i = D - 1 - decltype(ic)::value;
         if (active) {
-            trimul_lower_inplace<T, D, D>(Ci, Bm);              // B = C^-1 A
-            gemv_t<T, D, D>(Bm, w, pn);
-            MF_UNROLL for (int i = 0; i < D; ++i) {
-                pn[i] = -pn[i];
-                MF_UNROLL for (int j = 0; j <= i; ++j) Pn[i][j] = T(0);
-            }
-            syrk_tn_lower<T, D, D>(Bm, Pn, T(1));               // A^T Q^-1 A
+            MF_UNROLL for (int j = 0; j < D; ++j) Bm[i][j] *= Ci[i][i];
+            MF_UNROLL for (int k = 0; k < i; ++k)
+                MF_UNROLL for (int j = 0; j < D; ++j) Bm[i][j] += Ci[i][k] * Bm[k][j];
         }
-        pump.template big<2>();
-        {
-            T Ap[D][D];
+        sink.template tick<9 + (D - 1 - i)>(active);
+    });
+    if (active) {
+        gemv_t<T, D, D>(Bm, w, pn);
+        MF_UNROLL for (int i = 0; i < D; ++i) {
+            pn[i] = -pn[i];
+            MF_UNROLL for (int j = 0; j <= i; ++j) Pn[i][j] = T(0);
+        }
+    }
+    sink.template tick<9 + D>(active);
+    pump.template big<2>();
+    // A^T Q^-1 A = B^T B, a row of B per site
+    static_for<0, D>([&](auto ic) {
+        constexpr int k = decltype(ic)::value;
+        if (active) {
+            MF_UNROLL for (int i = 0; i < D; ++i)
+                MF_UNROLL for (int j = 0; j <= i; ++j) Pn[i][j] += Bm[k][i] * Bm[k][j];
+        }
+        sink.template tick<10 + D + k>(active);
+    });
+    sink.stage_factor_rest(Gi, active);
+    // -S_t = Q^-1 A = C^-T B in place, top-down
+    static_for<0, D>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if (active) {
+            MF_UNROLL for (int j = 0; j < D; ++j) Bm[i][j] *= Ci[i][i];
+            MF_UNROLL for (int k = i + 1; k < D; ++k)
+                MF_UNROLL for (int j = 0; j < D; ++j) Bm[i][j] += Ci[k][i] * Bm[k][j];
+        }
+        sink.template tick<10 + 2 * D + i>(active);
+    });
+    pump.template big<3>();
+    // Vn = G^-T (-S) in place, top-down
+    static_for<0, D>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if (active) {
+            MF_UNROLL for (int j = 0; j < D; ++j) Bm[i][j] *= Gi[i][i];
+            MF_UNROLL for (int k = i + 1; k < D; ++k)
+                MF_UNROLL for (int j = 0; j < D; ++j) Bm[i][j] += Gi[k][i] * Bm[k][j];
+        }
+        sink.template tick<10 + 3 * D + i>(active);
+    });
+    static_assert(10 + 4 * D <= 34 && D <= 6, "site map of post_emit_step: state dimensions up to 6");
+    // A'_{t+1} = -Delta^-1 S = G^-1 Vn, the first rows
+    {
+        T Ap[H0][D];
+        if (active) {
+            MF_UNROLL for (int i = 0; i < H0; ++i) {
+                MF_UNROLL for (int j = 0; j < D; ++j) Ap[i][j] = Gi[i][0] * Bm[0][j];
+                MF_UNROLL for (int k = 1; k <= i; ++k)
+                    MF_UNROLL for (int j = 0; j < D; ++j) Ap[i][j] += Gi[i][k] * Bm[k][j];
+            }
+        }
+        sink.template stage_transition<0>(Ap, active);
+    }
+    {
+        T Ap[D - H0 > 0 ? D - H0 : 1][D];
+        static_for<H0, D>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
             if (active) {
-                trimulT_lower_inplace<T, D, D>(Ci, Bm);         // -S_t = Q^-1 A
-                trimulT_lower_inplace<T, D, D>(Gi, Bm);         // Vn = G^-T (-S)
-                trimul_lower<T, D, D>(Gi, Bm, Ap);              // A'_{t+1} = -Delta^-1 S = G^-1 Vn
+                MF_UNROLL for (int j = 0; j < D; ++j) Ap[i - H0][j] = Gi[i][0] * Bm[0][j];
+                MF_UNROLL for (int k = 1; k <= i; ++k)
+                    MF_UNROLL for (int j = 0; j < D; ++j) Ap[i - H0][j] += Gi[i][k] * Bm[k][j];
             }
-            sink.transition(Ap, active);
-        }
-        pump.template big<3>();
+            sink.template tick<34 + (i - H0)>(active);
+        });
+        // Psi_t = A^T Q^-1 A - S^T Delta^-1 S, a row of Vn per site
+        static_for<0, D>([&](auto ic) {
+            constexpr int k = decltype(ic)::value;
+            if (active) {
+                MF_UNROLL for (int i = 0; i < D; ++i)
+                    MF_UNROLL for (int j = 0; j <= i; ++j) Pn[i][j] -= Bm[k][i] * Bm[k][j];
+            }
+            sink.template tick<34 + (D - H0) + k>(active);
+        });
         if (active) {
-            syrk_tn_lower<T, D, D>(Bm, Pn, T(-1));              // Psi_t = A^T Q^-1 A - S^T Delta^-1 S
             T vz[D];
             gemv_t<T, D, D>(Bm, z, vz);
             MF_UNROLL for (int i = 0; i < D; ++i) {
@@ -251,6 +356,9 @@ MF_HD void post_emit_step(T (&Phi)[D][D], T (&t)[D], bool& bad, const T (&C)[D][
                 MF_UNROLL for (int j = 0; j <= i; ++j) Phi[i][j] = Pn[i][j];
             }
         }
+        sink.template tick<34 + (D - H0) + D>(active);
+        static_assert(34 + (D - H0) + D < EMIT_SITES, "site map of post_emit_step");
+        if constexpr (D - H0 > 0) sink.template stage_transition<1>(Ap, active);
     }
 }
 

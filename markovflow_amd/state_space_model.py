@@ -288,7 +288,21 @@ class StateSpaceModel(GaussMarkovDistribution):
         return getattr(self, "_trainable", ())
 
     def _build_precision(self) -> SymmetricBlockTriDiagonal:
-        """``K⁻¹ = A⁻ᵀ Q⁻¹ A⁻¹`` in block form (state_space_model.py:431-483)."""
+        """``K⁻¹ = A⁻ᵀ Q⁻¹ A⁻¹`` in block form (state_space_model.py:431-483).  With parameters that require a gradient the
+        blocks are formed by batched, differentiable d x d products (all blocks at once: the assembly is local in time) so
+        that the reference's ``dist_p.precision -> naturals_to_ssm_params`` chain (models/variational_cvi.py:105-136) can be
+        differentiated; otherwise by the fused kernel."""
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (self._chol_P_0, self._A_s, self._chol_Q_s)):
+            chols = self.concatenated_cholesky_process_covariance                       # [cholP0, cholQ_1 ...]
+            eye = torch.eye(self.state_dim, dtype=chols.dtype, device=chols.device).expand(chols.shape)
+            q_inv = _lib.chol_solve(chols, eye)
+            q_inv = 0.5 * (q_inv + q_inv.transpose(-1, -2))
+            if self.num_transitions == 0:
+                return SymmetricBlockTriDiagonal(q_inv)
+            j = q_inv[..., 1:, :, :] @ self._A_s                                        # Q_{k+1}^-1 A_{k+1}
+            ata = self._A_s.transpose(-1, -2) @ j
+            diag = q_inv + torch.cat([ata, torch.zeros_like(ata[..., :1, :, :])], dim=-3)
+            return SymmetricBlockTriDiagonal(diag, -j)
         diag, sub, _ = self._precision_and_eta(None, None, None, False, want_eta=False)
         return SymmetricBlockTriDiagonal(diag, sub)
 

@@ -10,14 +10,22 @@
 namespace {
 using namespace mf;
 
-// where the emit step hands over its outputs: plain stores at index k of the posterior chain
+// where the emit step hands over its outputs: plain stores at index k of the posterior chain (tick sites: nothing to do)
 template <typename T, int D> struct HostSink {
+    static constexpr int H0 = (D + 1) / 2;
     T* a_post; T* b_post; T* cq_post; long k;
-    void factor(const T (&Gi)[D][D], const T (&mean)[D], bool) {
-        store_lower<T, D>(cq_post + k * D * D, Gi);
+    template <int SITE> void tick(bool) { static_assert(SITE >= 0 && SITE < EMIT_SITES, "tick site out of range"); }
+    void stage_factor(const T (&Gi)[D][D], const T (&mean)[D], bool) {
+        for (int i = 0; i < H0; ++i) for (int j = 0; j < D; ++j) cq_post[k * D * D + i * D + j] = j <= i ? Gi[i][j] : T(0);
         store_vec<T, D>(b_post + k * D, mean);
     }
-    void transition(const T (&Ap)[D][D], bool) { store_mat<T, D, D>(a_post + k * D * D, Ap); }
+    void stage_factor_rest(const T (&Gi)[D][D], bool) {
+        for (int i = H0; i < D; ++i) for (int j = 0; j < D; ++j) cq_post[k * D * D + i * D + j] = j <= i ? Gi[i][j] : T(0);
+    }
+    template <int HALF, int R> void stage_transition(const T (&Ap)[R][D], bool) {
+        const int r0 = HALF * H0, r1 = HALF ? D : H0;
+        for (int i = r0; i < r1; ++i) for (int j = 0; j < D; ++j) a_post[k * D * D + i * D + j] = Ap[i - r0][j];
+    }
 };
 
 template <typename T, int D, int M>

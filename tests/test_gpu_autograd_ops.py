@@ -1,0 +1,117 @@
+"""
+Reverse mode through the block-tridiagonal OPERATORS on the GPU: the autograd Functions of
+markovflow_amd/_autograd_ops.py over the HIP kernels, against torch's reverse mode through the dense matrices, and the chain the
+reference's CVI models differentiate - ``dist_p.precision -> naturals_to_ssm_params -> kl_divergence``
+(/root/reference/markovflow/models/variational_cvi.py:105-136,402; the operators' gradients there come from banded_matrices,
+block_tri_diag.py:22-31) - against central differences of the same (forward-only, oracle-checked) kernels.  fp64.
+"""
+import numpy as np
+import pytest
+import torch
+
+import markovflow_amd as mfa
+from markovflow_amd import ssm_gaussian_transformations as G
+from test_autograd_ops import blocks_of, dense_of, random_spd
+from test_gpu_kalman import DEV, nn, random_ssm, tt
+
+pytestmark = pytest.mark.gpu
+F64 = torch.float64
+
+
+def dev(x):
+    return None if x is None else x.to(DEV)
+
+
+@pytest.mark.parametrize("batch,n,d", [((), 7, 3), ((2,), 70, 6), ((3,), 5, 2), ((), 40, 9)])
+def test_cholesky_solve_inverse_blocks_and_products_vs_dense_autograd(batch, n, d):
+    rng = np.random.default_rng(5)
+    (diag, sub), _ = random_spd(rng, batch, n, d)
+    rhs = torch.tensor(rng.normal(size=(2,) + batch + (n, d)), dtype=F64)
+    w1, w2, w3, w4 = (torch.tensor(rng.normal(size=s), dtype=F64, device=DEV) for s in
+                      (batch + (n, d, d), batch + (n - 1, d, d), (2,) + batch + (n, d), (2,) + batch + (n, d)))
+
+    def loss(dg, sb, r, native):
+        if native:
+            sym = mfa.SymmetricBlockTriDiagonal(dg, sb)
+            chol = sym.cholesky
+            inv_d, inv_s = chol._diag_and_sub_of_inverse(want_sub=True)
+            x, xt = chol.solve(r), chol.solve(r, transpose_left=True)
+            prod = sym.dense_mult(r) + chol.dense_mult(r) + chol.dense_mult(r, transpose_left=True)
+            logdet = chol.abs_log_det()
+        else:
+            full = dense_of(0.5 * (dg + dg.transpose(-1, -2)), sb, True)
+            cf = torch.linalg.cholesky(full)
+            inv_d, inv_s = blocks_of(torch.linalg.inv(full), n, d)
+            flat = r.reshape(r.shape[:-2] + (n * d, 1))
+            x = torch.linalg.solve_triangular(cf, flat, upper=False).reshape(r.shape)
+            xt = torch.linalg.solve_triangular(cf.transpose(-1, -2), flat, upper=True).reshape(r.shape)
+            prod = ((full + cf + cf.transpose(-1, -2)) @ flat).reshape(r.shape)
+            logdet = torch.sum(torch.log(torch.diagonal(cf, dim1=-2, dim2=-1)), dim=-1)
+        return (torch.sum(inv_d * w1) + torch.sum(inv_s * w2) + torch.sum(x * w3) + torch.sum(xt * w4) + torch.sum(prod * w3)
+                + torch.sum(logdet))
+
+    grads = []
+    for native in (True, False):
+        dg, sb, r = (dev(t).clone().requires_grad_(True) for t in (diag, sub, rhs))
+        val = loss(dg, sb, r, native)
+        val.backward()
+        grads.append((float(val), dg.grad, sb.grad, r.grad))
+    assert grads[0][0] == pytest.approx(grads[1][0], rel=1e-9)
+    for g1, g2 in zip(grads[0][1:], grads[1][1:]):
+        scale = float(g2.abs().max())
+        assert float((g1 - g2).abs().max()) <= 1e-8 * scale
+
+
+def test_precision_is_differentiable(rng):
+    kw = random_ssm(rng, (2,), 12, 3, 1, well=True)
+    leaves = [tt(kw[k]).requires_grad_(True) for k in ("mu0", "chol_p0", "a_s", "b_s", "chol_q")]
+    ssm = mfa.StateSpaceModel(*leaves)
+    prec = ssm.precision
+    plain = mfa.StateSpaceModel(*(x.detach() for x in leaves)).precision
+    np.testing.assert_allclose(nn(prec.block_diagonal), nn(plain.block_diagonal), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(nn(prec.block_sub_diagonal), nn(plain.block_sub_diagonal), rtol=1e-10, atol=1e-12)
+    (prec.block_diagonal.sum() + 2 * prec.block_sub_diagonal.sum()).backward()
+    assert all(x.grad is not None and bool(torch.isfinite(x.grad).all()) for x in (leaves[1], leaves[2], leaves[4]))
+
+
+def _cvi_kl(lengthscale, variance, t_pts, nat1, nat2):
+    """KL(q || p) with p the Matern-3/2 prior and q = prior x Gaussian sites, built the way variational_cvi.py:105-136 builds it."""
+    kern = mfa.Matern32(lengthscale, variance, jitter=1e-9)
+    dist_p = kern.state_space_model(t_pts)
+    prec = dist_p.precision
+    h = kern.generate_emission_model(t_pts).emission_matrix                        # [.., T, 1, d]
+    theta_lin = (h.transpose(-1, -2) @ nat1[..., None])[..., 0]
+    theta_diag = -0.5 * prec.block_diagonal + h.transpose(-1, -2) @ nat2 @ h
+    theta_sub = -prec.block_sub_diagonal
+    a_s, offsets, chol_p0, chol_q, mu0 = G.naturals_to_ssm_params(theta_lin, theta_diag, theta_sub)
+    dist_q = mfa.StateSpaceModel(mu0, chol_p0, a_s, offsets, chol_q)
+    return torch.sum(dist_q.kl_divergence(dist_p))
+
+
+def test_cvi_shaped_gradient_through_precision_and_naturals(rng):
+    """d KL / d lengthscale, d KL / d variance and d KL / d sites through the whole chain against central differences."""
+    bsz, n = 2, 60
+    t_pts = torch.cumsum(0.05 + 0.1 * torch.rand(bsz, n, dtype=F64, device=DEV), dim=-1)
+    nat1 = tt(rng.normal(size=(bsz, n, 1)))
+    nat2 = tt(-0.5 * rng.uniform(0.5, 2.0, size=(bsz, n, 1, 1)))
+    ls0 = tt(np.array([0.7, 1.3]))
+    var0 = tt(np.array([1.2, 0.8]))
+    ls, var = ls0.clone().requires_grad_(True), var0.clone().requires_grad_(True)
+    n1, n2 = nat1.clone().requires_grad_(True), nat2.clone().requires_grad_(True)
+    kl = _cvi_kl(ls, var, t_pts, n1, n2)
+    kl.backward()
+    with torch.no_grad():
+        for which, base, grad in (("lengthscale", ls0, ls.grad), ("variance", var0, var.grad)):
+            for i in range(bsz):
+                hstep = 1e-6
+                up, dn = base.clone(), base.clone()
+                up[i] += hstep; dn[i] -= hstep
+                args_up = (up, var0) if which == "lengthscale" else (ls0, up)
+                args_dn = (dn, var0) if which == "lengthscale" else (ls0, dn)
+                fd = (float(_cvi_kl(*args_up, t_pts, nat1, nat2)) - float(_cvi_kl(*args_dn, t_pts, nat1, nat2))) / (2 * hstep)
+                assert float(grad[i]) == pytest.approx(fd, rel=2e-5, abs=1e-7), which
+        d1 = tt(rng.normal(size=nat1.shape))
+        hstep = 1e-6
+        fd = (float(_cvi_kl(ls0, var0, t_pts, nat1 + hstep * d1, nat2)) - float(_cvi_kl(ls0, var0, t_pts, nat1 - hstep * d1, nat2))) / (2 * hstep)
+        assert float(torch.sum(n1.grad * d1)) == pytest.approx(fd, rel=2e-5, abs=1e-7)
+        assert bool(torch.isfinite(n2.grad).all())
