@@ -6,9 +6,12 @@ Mirror of ``ConditionalProcess`` / ``AnalyticPosteriorProcess`` of ``markovflow/
 points (``markovflow/conditionals.py:29-83,122-256,380-485``).  The neighbour search is ``torch.searchsorted`` (the reference
 uses ``tf.searchsorted``); the transitions to / from the new points come from ``mf_sde_matern_transitions_*`` and the
 conditional statistics + projection + marginalisation run in ONE HIP kernel (``mf_sde_conditional_predict_*``, a lane per
-new point).  Sampling (``sample_state_trajectories`` …) and mean functions are not mirrored.
+new point).  ``sample_state_trajectories`` / ``sample_state`` / ``sample_f`` (posterior.py:45-138,260-412) draw joint samples by
+Matheron's rule, as the reference does: a joint prior sample at the new and the conditioning points (the kernel's state space
+model on the merged, sorted time points - generated and propagated by the HIP kernels), a posterior sample at the conditioning
+points, and the local conditional-mean correction.  Mean functions are not mirrored (zero mean).
 """
-from typing import Optional, Tuple
+from typing import Optional, Sequence, Tuple, Union
 
 import torch
 
@@ -68,6 +71,60 @@ class ConditionalProcess:
                   _lib.ptr(flat(p0, 2)), _lib.ptr(out_mean), _lib.ptr(out_cov), info, _lib.stream_ptr(dev))
         _lib.raise_on_info(info, "ConditionalProcess.predict_state", dev)
         return out_mean.reshape(batch + (n_new, d)), out_cov.reshape(batch + (n_new, d, d))
+
+    def sample_state_trajectories(self, new_time_points: torch.Tensor, sample_shape: Union[int, Sequence[int]],
+                                  *, input_data=None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Joint state samples at ``new_time_points`` and at the conditioning points (posterior.py:260-374; Appendix 2 of
+        "Doubly Sparse Variational Gaussian Processes"):  ``[s_p, u_p] ~ p(s([t, z]))``, ``u_o ~ q(s(z))``,
+        ``s_o = s_p - E[s(t) | s(z) = u_p - u_o]`` - the conditional mean only involves the two conditioning states around each
+        new point.  Returns ``(sample_shape + batch + [num_new, d], sample_shape + batch + [num_conditioning, d])``."""
+        shape = (sample_shape,) if isinstance(sample_shape, int) else tuple(sample_shape)
+        dist, kern, train = self.gauss_markov_model, self.kernel, self.conditioning_time_points
+        batch = tuple(dist.batch_shape)
+        new = new_time_points.to(train.dtype)
+        n, n_new = train.shape[-1], new.shape[-1]
+        joint = torch.cat([train, new], dim=-1)
+        sort_ind = torch.argsort(joint, dim=-1)
+        sorted_samples = kern.state_space_model(torch.gather(joint, -1, sort_ind).contiguous()).sample(shape)
+        unsort = torch.argsort(sort_ind, dim=-1)
+        unsort = unsort.expand(shape + tuple(unsort.shape))[..., None].expand(shape + batch + (n + n_new, sorted_samples.shape[-1]))
+        joint_samples = torch.gather(sorted_samples, -2, unsort)
+        prior_cond, prior_new = joint_samples[..., :n, :], joint_samples[..., n:, :]
+        post_cond = dist.sample(shape)
+        delta = prior_cond - post_cond
+        # infinitely far from the data the posterior reverts to the prior: the correction vanishes beyond both ends
+        pad = torch.zeros_like(delta[..., :1, :])
+        delta_aug = torch.cat([pad, delta, pad], dim=-2)
+        idx = torch.searchsorted(train.contiguous(), new.contiguous())
+        gidx = idx.expand(shape + tuple(idx.shape))[..., None].expand(shape + batch + (n_new, delta.shape[-1]))
+        u_minus, u_plus = torch.gather(delta_aug, -2, gidx), torch.gather(delta_aug, -2, gidx + 1)
+        d_m, e_m = self._conditional_mean_projection(new, idx)
+        correction = (d_m @ u_minus[..., None] + e_m @ u_plus[..., None])[..., 0]
+        return prior_new - correction, post_cond
+
+    def _conditional_mean_projection(self, new: torch.Tensor, idx: torch.Tensor):
+        """``E[s(t) | s(z_-), s(z_+)] = D s(z_-) + E s(z_+)`` for every new point (conditionals.py:29-83,122-203):
+        ``E = Q_mt A_tp^T (Q_tp + A_tp Q_mt A_tp^T)^-1``, ``D = A_mt - E A_tp A_mt`` from the prior transitions z_- -> t -> z_+."""
+        kern, train = self.kernel, self.conditioning_time_points
+        batch = tuple(train.shape[:-1])
+        inf = torch.full(batch + (1,), APPROX_INF, dtype=train.dtype, device=train.device)
+        aug = torch.cat([-inf, train, inf], dim=-1)
+        minus, plus = torch.gather(aug, -1, idx), torch.gather(aug, -1, idx + 1)
+        a_mt, q_mt = kern.transition_statistics(minus, new - minus)
+        a_tp, q_tp = kern.transition_statistics(new, plus - new)
+        g = a_tp @ q_mt
+        e_m = torch.linalg.solve(q_tp + g @ a_tp.transpose(-1, -2), g).transpose(-1, -2)
+        return a_mt - e_m @ a_tp @ a_mt, e_m
+
+    def sample_state(self, new_time_points: torch.Tensor, sample_shape, *, input_data=None) -> torch.Tensor:
+        """State samples at ``new_time_points``, ``sample_shape + batch + [num_new, d]`` (posterior.py:45-76)."""
+        return self.sample_state_trajectories(new_time_points, sample_shape, input_data=input_data)[0]
+
+    def sample_f(self, new_time_points: torch.Tensor, sample_shape, *, input_data=None) -> torch.Tensor:
+        """Function samples (projected states), ``sample_shape + batch + [num_new, output_dim]`` (posterior.py:376-412; zero
+        mean function)."""
+        states = self.sample_state(new_time_points, sample_shape)
+        return self.kernel.generate_emission_model(new_time_points).project_state_to_f(states)
 
     def predict_f(self, new_time_points: torch.Tensor, full_output_cov: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
         """Marginal function values at ``new_time_points``: means ``batch + [num_new, output_dim]`` and variances (or full

@@ -237,6 +237,10 @@ class StateSpaceModel(GaussMarkovDistribution):
         cond = self.concatenated_state_offsets + z
         if cond.numel() == 0:
             return cond
+        if self._needs_grad():
+            # reparameterised: x = A^-1 (offsets + chol eps) as the reference writes it (state_space_model.py:307-322), through
+            # the differentiable bidiagonal solve - gradients reach every parameter of the chain
+            return self.a_inv_block.solve(cond)
         return self._propagate(cond)
 
     def subsequent_covariances(self, marginal_covariances: torch.Tensor) -> torch.Tensor:

@@ -34,7 +34,7 @@ def blocks_of(m, n, d, want_sub=True):
 
 
 def random_spd(rng, batch, n, d):
-    ld = np.tril(0.3 * rng.normal(size=batch + (n, d, d))) + np.eye(d)
+    ld = np.tril(0.3 * rng.normal(size=batch + (n, d, d)), k=-1) + (1.0 + np.abs(0.3 * rng.normal(size=batch + (n, d))))[..., None] * np.eye(d)
     ls = 0.3 * rng.normal(size=batch + (n - 1, d, d))
     ldt, lst = torch.tensor(ld, dtype=F64), torch.tensor(ls, dtype=F64)
     full = dense_of(ldt, lst, False)

@@ -55,7 +55,7 @@ def test_cholesky_solve_inverse_blocks_and_products_vs_dense_autograd(batch, n, 
         dg, sb, r = (dev(t).clone().requires_grad_(True) for t in (diag, sub, rhs))
         val = loss(dg, sb, r, native)
         val.backward()
-        grads.append((float(val), dg.grad, sb.grad, r.grad))
+        grads.append((float(val.detach()), dg.grad, sb.grad, r.grad))
     assert grads[0][0] == pytest.approx(grads[1][0], rel=1e-9)
     for g1, g2 in zip(grads[0][1:], grads[1][1:]):
         scale = float(g2.abs().max())
