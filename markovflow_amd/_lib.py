@@ -386,6 +386,22 @@ def checked(t: torch.Tensor) -> torch.Tensor:
     return t.as_subclass(CheckedTensor)
 
 
+def checked_cholesky(mat: torch.Tensor, what: str) -> torch.Tensor:
+    """``torch.linalg.cholesky_ex`` whose failure goes through the same channel as the kernels' (the d > 9 routes
+    used to return silent NaNs where the d <= 9 kernels raise): its `info` is folded into the stream's device flag by one
+    asynchronous device-side operation, no synchronisation."""
+    chol, info = torch.linalg.cholesky_ex(mat, check_errors=False)
+    if mat.is_cuda:
+        pivot_info(mat.device)                                   # makes sure the (device, stream) flag exists
+        idx = mat.device.index if mat.device.index is not None else torch.cuda.current_device()
+        flag = _flags[(idx, torch.cuda.current_stream(idx).cuda_stream)]
+        flag.dev.copy_(torch.maximum(flag.dev, (info != 0).any().to(torch.int32).reshape(1)))
+        raise_on_info(flag.ptr, what, mat.device)
+    elif bool((info != 0).any()):
+        raise MarkovflowAmdError(f"{what}: matrix is not positive definite")
+    return chol
+
+
 def raise_on_info(info, what: str, device=None):
     """Called right after a factorising launch: queues the copy of the flag into its pinned mirror behind the kernel.
     Synchronous mode: wait and raise now; default: remember the name."""

@@ -190,7 +190,7 @@ class SDEKernel(abc.ABC):
         return StateSpaceModel(
             initial_mean=self.initial_mean(batch).to(dtype=a_s.dtype, device=a_s.device).expand(batch + (self.state_dim,)).contiguous(),
             # (P-infinity + jitter is positive definite by construction: no info check, hence no host synchronisation)
-            chol_initial_covariance=torch.linalg.cholesky_ex(p0, check_errors=False)[0],
+            chol_initial_covariance=_lib.checked_cholesky(p0, "SDEKernel.state_space_model (initial covariance)"),
             state_transitions=a_s,
             state_offsets=self.state_offsets(time_points[..., :-1], deltas).to(dtype=a_s.dtype),
             chol_process_covariances=chol_q,

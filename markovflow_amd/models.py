@@ -73,6 +73,13 @@ class GaussianProcessRegression:
     _prof_events = (None, None)
     fused = True    # set False to force the materialised route (kernel tensors -> KalmanFilter)
 
+    def invalidate_hyperparameter_cache(self) -> None:
+        """Forget the hyper-parameter tensors the fused route keeps between calls.  They are re-derived automatically when a
+        source tensor (a lengthscale, a variance, the noise factor) is REPLACED or written in place through torch (tensor identity
+        + autograd version counter); a write that bypasses the version counter - ``lengthscale.data.clamp_()``, ``set_()`` - is
+        invisible to that check: call this after such a write."""
+        self._fused_cache = None
+
     def _fused_log_likelihood_per_series(self) -> Optional[torch.Tensor]:
         """Per-series log-likelihood through ``mf_gpr_matern_loglik_*`` (kernel -> SSM generation fused into the Kalman
         sweep: 16 bytes per step instead of the materialised tensors); ``None`` when the kernel / shapes are not covered."""

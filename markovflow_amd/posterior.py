@@ -143,7 +143,7 @@ def _predict_state_dense(idx, a_mt, q_mt, a_tp, q_tp, means, covs, sub, m0, p0):
     tri = torch.linalg.solve_triangular
     n = means.shape[1]
     g = a_tp @ q_mt
-    chol = torch.linalg.cholesky_ex(q_tp + g @ tr(a_tp), check_errors=False)[0]
+    chol = _lib.checked_cholesky(q_tp + g @ tr(a_tp), "ConditionalProcess.predict_state")
     v = tri(chol, g, upper=False)                                         # L^-1 A_tp Q_mt
     t_m = q_mt - tr(v) @ v
     e = tr(tri(tr(chol), v, upper=True))                                  # E = (L^-T V)^T

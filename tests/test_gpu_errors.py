@@ -93,3 +93,37 @@ def test_flags_are_per_stream(rng):
             mfa.SymmetricBlockTriDiagonal(g, s).cholesky
         _lib.check_errors()
         assert reports == 1
+
+
+def test_torch_factorisations_on_the_path_report_through_the_same_channel(rng):
+    """the d > 9 prediction route and the kernels' initial covariance factor with torch; a matrix that is not positive
+    definite must raise there as it does in the HIP kernels (d <= 9), not return silent NaNs."""
+    _lib.check_errors()
+    good = tt(np.tile(np.eye(3), (4, 1, 1)))
+    bad = good.clone()
+    bad[2] = -bad[2]
+    assert bool(torch.isfinite(_lib.checked_cholesky(good, "stand-in")).all())
+    _lib.check_errors()
+    _lib.checked_cholesky(bad, "ConditionalProcess.predict_state")
+    with pytest.raises(mfa.MarkovflowAmdError, match="predict_state"):
+        _lib.check_errors()
+    _lib.check_errors()
+
+
+def test_fused_gpr_cache_and_writes_that_bypass_the_version_counter():
+    """The fused GPR route keeps its derived hyper-parameter tensors until a source is replaced or written in place through torch;
+    a `.data` write is invisible to that check and needs invalidate_hyperparameter_cache() (documented)."""
+    t = torch.cumsum(0.1 + 0.1 * torch.rand(3, 50, dtype=torch.float64, device=DEV), dim=-1)
+    y = torch.randn(3, 50, 1, dtype=torch.float64, device=DEV)
+    ls = torch.full((3,), 0.8, dtype=torch.float64, device=DEV)
+    noise = 0.3 * torch.eye(1, dtype=torch.float64, device=DEV)
+    gpr = mfa.GaussianProcessRegression((t, y), mfa.Matern52(ls, 1.1, jitter=1e-9), chol_obs_covariance=noise)
+    v0 = float(gpr.log_likelihood())
+    ls.mul_(1.5)                                               # through torch: seen (version counter)
+    v1 = float(gpr.log_likelihood())
+    fresh = mfa.GaussianProcessRegression((t, y), mfa.Matern52(ls.clone(), 1.1, jitter=1e-9), chol_obs_covariance=noise)
+    assert v1 != v0 and v1 == pytest.approx(float(fresh.log_likelihood()), rel=1e-12)
+    ls.data.mul_(0.5)                                          # bypasses the counter
+    gpr.invalidate_hyperparameter_cache()
+    fresh = mfa.GaussianProcessRegression((t, y), mfa.Matern52(ls.clone(), 1.1, jitter=1e-9), chol_obs_covariance=noise)
+    assert float(gpr.log_likelihood()) == pytest.approx(float(fresh.log_likelihood()), rel=1e-12)
