@@ -50,19 +50,51 @@ typedef int mf_v4i __attribute__((ext_vector_type(4)));
 #endif
 #define MF_POLICY_WIDE MF_POLICY_OF(MF_POLW)
 #define MF_POLICY_NARROW MF_POLICY_OF(MF_POLN)
-template <bool WIDE> MF_DEV void dma_b128(mf_v4i srd, unsigned lds_addr, unsigned voff) {
+// Up to four consecutive DMA instructions of one stream in ONE asm statement (round 4): the leading `s_nop 4`, the save /
+// restore of m0 are paid once per group instead of once per instruction (6 -> 3.5 instructions per DMA, 56 DMAs per step at
+// d = 6 fp64), and m0 walks from one 1-KB (dwordx4) or 256-B (dword) slice of the LDS image to the next by `s_add_u32` (SCC is
+// declared clobbered; one wait state between a write of m0 and the LDS-DMA that reads it, as before).
+#define MF_DMA_HEAD "s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+#define MF_DMA_TAIL "s_mov_b32 m0, %0"
+#define MF_DMA_X4(v, pol) "buffer_load_dwordx4 " v ", %1, 0 offen" pol " lds\n\t"
+#define MF_DMA_X1(v, pol) "buffer_load_dword " v ", %1, 0 offen" pol " lds\n\t"
+#define MF_DMA_STEP4 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+#define MF_DMA_STEP1 "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\t"
+template <bool WIDE, int N> MF_DEV void dma_b128_group(mf_v4i srd, unsigned lds_addr, const unsigned* v) {
     unsigned keep;
-    if (WIDE)
-        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen" MF_POLICY_WIDE " lds\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(srd), "s"(lds_addr) : "memory");
-    else
-        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen" MF_POLICY_NARROW " lds\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(srd), "s"(lds_addr) : "memory");
+    static_assert(N >= 1 && N <= 4, "group size");
+#define MF_DMA_B128_BODY(POL)                                                                                                       \
+    if constexpr (N == 1)                                                                                                           \
+        asm volatile(MF_DMA_HEAD MF_DMA_X4("%3", POL) MF_DMA_TAIL : "=&s"(keep) : "s"(srd), "s"(lds_addr), "v"(v[0]) : "memory", "scc"); \
+    else if constexpr (N == 2)                                                                                                      \
+        asm volatile(MF_DMA_HEAD MF_DMA_X4("%3", POL) MF_DMA_STEP4 MF_DMA_X4("%4", POL) MF_DMA_TAIL                                 \
+                     : "=&s"(keep) : "s"(srd), "s"(lds_addr), "v"(v[0]), "v"(v[1]) : "memory", "scc");                              \
+    else if constexpr (N == 3)                                                                                                      \
+        asm volatile(MF_DMA_HEAD MF_DMA_X4("%3", POL) MF_DMA_STEP4 MF_DMA_X4("%4", POL) MF_DMA_STEP4 MF_DMA_X4("%5", POL) MF_DMA_TAIL \
+                     : "=&s"(keep) : "s"(srd), "s"(lds_addr), "v"(v[0]), "v"(v[1]), "v"(v[2]) : "memory", "scc");                   \
+    else                                                                                                                            \
+        asm volatile(MF_DMA_HEAD MF_DMA_X4("%3", POL) MF_DMA_STEP4 MF_DMA_X4("%4", POL) MF_DMA_STEP4 MF_DMA_X4("%5", POL)           \
+                     MF_DMA_STEP4 MF_DMA_X4("%6", POL) MF_DMA_TAIL                                                                  \
+                     : "=&s"(keep) : "s"(srd), "s"(lds_addr), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "memory", "scc");
+    if (WIDE) { MF_DMA_B128_BODY(MF_POLICY_WIDE) } else { MF_DMA_B128_BODY(MF_POLICY_NARROW) }
+#undef MF_DMA_B128_BODY
 }
-MF_DEV void dma_b32(mf_v4i srd, unsigned lds_addr, unsigned voff) {
+template <int N> MF_DEV void dma_b32_group(mf_v4i srd, unsigned lds_addr, const unsigned* v) {
     unsigned keep;
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen" MF_POLICY_NARROW " lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(srd), "s"(lds_addr) : "memory");
+    static_assert(N >= 1 && N <= 4, "group size");
+    if constexpr (N == 1)
+        asm volatile(MF_DMA_HEAD MF_DMA_X1("%3", MF_POLICY_NARROW) MF_DMA_TAIL : "=&s"(keep) : "s"(srd), "s"(lds_addr), "v"(v[0]) : "memory", "scc");
+    else if constexpr (N == 2)
+        asm volatile(MF_DMA_HEAD MF_DMA_X1("%3", MF_POLICY_NARROW) MF_DMA_STEP1 MF_DMA_X1("%4", MF_POLICY_NARROW) MF_DMA_TAIL
+                     : "=&s"(keep) : "s"(srd), "s"(lds_addr), "v"(v[0]), "v"(v[1]) : "memory", "scc");
+    else if constexpr (N == 3)
+        asm volatile(MF_DMA_HEAD MF_DMA_X1("%3", MF_POLICY_NARROW) MF_DMA_STEP1 MF_DMA_X1("%4", MF_POLICY_NARROW) MF_DMA_STEP1
+                     MF_DMA_X1("%5", MF_POLICY_NARROW) MF_DMA_TAIL
+                     : "=&s"(keep) : "s"(srd), "s"(lds_addr), "v"(v[0]), "v"(v[1]), "v"(v[2]) : "memory", "scc");
+    else
+        asm volatile(MF_DMA_HEAD MF_DMA_X1("%3", MF_POLICY_NARROW) MF_DMA_STEP1 MF_DMA_X1("%4", MF_POLICY_NARROW) MF_DMA_STEP1
+                     MF_DMA_X1("%5", MF_POLICY_NARROW) MF_DMA_STEP1 MF_DMA_X1("%6", MF_POLICY_NARROW) MF_DMA_TAIL
+                     : "=&s"(keep) : "s"(srd), "s"(lds_addr), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "memory", "scc");
 }
 
 // One streamed array: ROWB bytes per (row, step), of which only the units flagged by Keep are fetched.
@@ -157,18 +189,22 @@ template <typename St> struct DmaStream {
         return carried ? MF_DMA_INVALID : off;
     }
 #endif
-    // issue DMA instructions [i0, i1) of this stream
+    // issue DMA instructions [i0, i1) of this stream, up to four per asm statement
     template <int I0, int I1> MF_DEV void issue(mf_v4i srd, unsigned lds_base) const {
-        MF_UNROLL for (int i = I0; i < I1; ++i) {
-            if (i < St::NI) {
+        constexpr int HI = I1 < St::NI ? I1 : St::NI;
+        if constexpr (I0 < HI) {
+            constexpr int N = (HI - I0) < 4 ? (HI - I0) : 4;
+            unsigned voff[N];
+            MF_UNROLL for (int k = 0; k < N; ++k) {
 #ifdef MF_EXPERIMENT
-                const unsigned voff = exp_offset(vo[i]);
+                voff[k] = exp_offset(vo[I0 + k]);
 #else
-                const unsigned voff = vo[i];
+                voff[k] = vo[I0 + k];
 #endif
-                if (St::UNIT == 16) dma_b128<(St::UG >= 8)>(srd, lds_base + i * 1024, voff);
-                else dma_b32(srd, lds_base + i * 256, voff);
             }
+            if (St::UNIT == 16) dma_b128_group<(St::UG >= 8), N>(srd, lds_base + I0 * 1024, voff);
+            else dma_b32_group<N>(srd, lds_base + I0 * 256, voff);
+            issue<I0 + N, I1>(srd, lds_base);
         }
     }
 };

@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))));
 import markovflow_amd as mfa
 from oracle import numpy_oracle as O
 from test_gpu_kalman import random_ssm, loglik_with_chunks, build_kf
+from test_gpu_posterior_streamed import posterior_chain_abi
 
 tt = lambda x: torch.tensor(np.ascontiguousarray(x), dtype=torch.float64, device="cuda:0")   # noqa: E731
 nn = lambda x: x.detach().cpu().numpy()                                                          # noqa: E731
@@ -14,7 +15,7 @@ nn = lambda x: x.detach().cpu().numpy()                                         
 
 def run(n_cases: int, seed: int, dmin: int = 1, dmax: int = 9) -> dict:
   rng = np.random.default_rng(seed)
-  worst = dict(ll=0.0, post=0.0, chol=0.0, solve=0.0, covs=0.0, kl=0.0)
+  worst = dict(ll=0.0, post=0.0, post_chain=0.0, chol=0.0, solve=0.0, covs=0.0, kl=0.0)
   for case in range(n_cases):
       d = int(rng.integers(dmin, dmax + 1)); m = int(rng.integers(1, 5 if dmax > 9 else 4)); bsz = int(rng.integers(1, 5))
       t = int(rng.choice([2, 3, 5, 8, 9, 17, 63, 64, 65, 71, 127, 128, 130, 200, 257, 400]))
@@ -33,6 +34,15 @@ def run(n_cases: int, seed: int, dmin: int = 1, dmax: int = 9) -> dict:
           om = O.ssm_marginal_means(o[0], o[2], o[3]); oc = O.ssm_marginal_covariances(o[1], o[2], o[4])
           worst["post"] = max(worst["post"], float(np.max(np.abs(nn(means)[s] - om)) / (1 + np.max(np.abs(om)))),
                               float(np.max(np.abs(nn(covs)[s] - oc)) / (1 + np.max(np.abs(oc)))))
+      if d <= 6 and m <= 3 and t >= 2:
+          # the streamed, time-partitioned posterior chain (csrc/mf_post_lds.hpp) through the C ABI: automatic and a random
+          # explicit partition, all five tensors of every series
+          for chunks in (0, int(rng.integers(1, max(2, t)))):
+              got5 = posterior_chain_abi(kw, r_inv, chunks)
+              for s in range(bsz):
+                  o = O.kf_posterior_ssm(**{k: v[s] for k, v in kw.items()}, r_inv=r_inv)
+                  for g, w in zip(got5, o):
+                      worst["post_chain"] = max(worst["post_chain"], float(np.max(np.abs(g[s] - w)) / (1 + np.max(np.abs(w)))))
       prior = kf.prior_ssm
       pc, ps = prior.covariance_blocks()
       for s in range(bsz):                                   # every series, not only the first
