@@ -359,6 +359,31 @@ int mf_kf_loglik_grad_f32(int64_t B, int64_t T, int d, int m, const float* mu0, 
                           float* g_omega, const float* weights, int* info, void* stream);
 
 /*
+ * The same gradients for FEW, LONG series WITHOUT the smoothed marginals in memory (csrc/mf_grad_lds.hpp): five streamed passes,
+ * all partitioned in time - the three of the streamed posterior chain above: chunk summaries, scan, emit (only chol(Q') and b' of
+ * the chain are read back), a scan that meets the two sides of every chunk boundary in the smoothed marginal of the chunk's first block,
+ * and a forward pass per (series, chunk) that carries (m_k, S_k, Cov(x_{k+1}, x_k)) in registers and writes every gradient once.
+ * Replaces mf_kf_posterior_chain -> mf_ssm_marginal_means / _covariances -> mf_kf_loglik_grad for state dimensions 1..6,
+ * m <= 3 (per-step precision: m = 1) and 16-byte aligned A, cholQ, g_A, g_cholQ; -101: not this route's call (the caller keeps
+ * the three-call route).  Outputs and weights as for mf_kf_loglik_grad; the upper triangles of g_cholP0, g_cholQ are zeros.
+ * ws: mf_kf_loglik_grad_streamed_workspace_bytes (0: not this route's call); it holds the posterior chain, (4 d^2 + 3 d) s bytes
+ * per step.  chunks: time partitions per series, 0 = automatic (>= 2).  prof_start / prof_stop: optional hipEvent_t recorded
+ * around the kernels.  Reference: TensorFlow reverse mode through markovflow/kalman_filter.py:184-255.
+ */
+size_t mf_kf_loglik_grad_streamed_workspace_bytes(int64_t B, int64_t T, int d, int m, int rinv_per_step, int elem_size,
+                                                  int64_t chunks);
+int mf_kf_loglik_grad_streamed_f64(int64_t B, int64_t T, int d, int m, const double* mu0, const double* cholP0, const double* A,
+                                   const double* b, const double* cholQ, const double* H, const double* y, const double* Rinv,
+                                   int rinv_per_step, const double* weights, double* g_mu0, double* g_cholP0, double* g_A,
+                                   double* g_b, double* g_cholQ, double* g_H, double* g_y, double* g_omega, void* ws,
+                                   size_t ws_bytes, int* info, int64_t chunks, void* prof_start, void* prof_stop, void* stream);
+int mf_kf_loglik_grad_streamed_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const float* cholP0, const float* A,
+                                   const float* b, const float* cholQ, const float* H, const float* y, const float* Rinv,
+                                   int rinv_per_step, const float* weights, float* g_mu0, float* g_cholP0, float* g_A,
+                                   float* g_b, float* g_cholQ, float* g_H, float* g_y, float* g_omega, void* ws,
+                                   size_t ws_bytes, int* info, int64_t chunks, void* prof_start, void* prof_stop, void* stream);
+
+/*
  * Gradient of  KL(q1 || q2)  between two state space models (markovflow/state_space_model.py:528-593; differentiated by
  * TensorFlow in the reference, pinned by tests/integration/models/test_variational.py:123-132) with respect to the parameters
  * of q1: the adjoints of q1's marginal mean and covariance, lam_k = n_k + A^T lam_{k+1}, M_k = N_k + A^T M_{k+1} A, in three

@@ -44,6 +44,24 @@ template <> const mf::PostOps<double>* post_table_for<double>(int d) {
 }
 #undef MF_CASE
 
+template <typename T> const mf::GradOps<T>* grad_table_for(int d);
+#define MF_CASE(D) case D: return mf::grad_ops_f32_d##D();
+template <> const mf::GradOps<float>* grad_table_for<float>(int d) {
+    switch (d) {
+        MF_CASE(1) MF_CASE(2) MF_CASE(3) MF_CASE(4) MF_CASE(5) MF_CASE(6)
+        default: return nullptr;
+    }
+}
+#undef MF_CASE
+#define MF_CASE(D) case D: return mf::grad_ops_f64_d##D();
+template <> const mf::GradOps<double>* grad_table_for<double>(int d) {
+    switch (d) {
+        MF_CASE(1) MF_CASE(2) MF_CASE(3) MF_CASE(4) MF_CASE(5) MF_CASE(6)
+        default: return nullptr;
+    }
+}
+#undef MF_CASE
+
 inline hipStream_t S(void* s) { return static_cast<hipStream_t>(s); }
 
 template <typename T>
@@ -443,6 +461,24 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
                                               g_cholQ, g_H, g_y, g_omega, S(stream));                                  \
         return -100;    \
     }                                                                                                                  \
+    int mf_kf_loglik_grad_streamed_##SUF(int64_t B, int64_t Tn, int d, int m, const T* mu0, const T* cholP0,           \
+                                         const T* A, const T* b, const T* cholQ, const T* H, const T* y, const T* Rinv, \
+                                         int rinv_per_step, const T* weights, T* g_mu0, T* g_cholP0, T* g_A, T* g_b,    \
+                                         T* g_cholQ, T* g_H, T* g_y, T* g_omega, void* ws, size_t ws_bytes, int* info,  \
+                                         int64_t chunks, void* prof_start, void* prof_stop, void* stream) {             \
+        if (B < 1) return -1;                                                                                          \
+        if (Tn < 2) return -2;                                                                                         \
+        if (d < 1) return -3;                                                                                          \
+        if (m < 1) return -4;                                                                                          \
+        if (!mu0 || !cholP0 || !A || !b || !cholQ) return -5;                                                          \
+        if (!H || !y || !Rinv) return -10;                                                                             \
+        if (!g_mu0 || !g_cholP0 || !g_A || !g_b || !g_cholQ || !g_H || !g_y || !g_omega) return -15;                   \
+        const auto* gt = grad_table_for<T>(d);                                                                         \
+        if (!gt) return -101;                                                                                          \
+        return gt->run(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, weights, g_mu0, g_cholP0, g_A,    \
+                       g_b, g_cholQ, g_H, g_y, g_omega, ws, ws_bytes, info, chunks,                                     \
+                       static_cast<hipEvent_t>(prof_start), static_cast<hipEvent_t>(prof_stop), S(stream));            \
+    }                                                                                                                  \
     int mf_ssm_kl_grad_##SUF(int64_t B, int64_t Tn, int d, const T* mu0_1, const T* cholP0_1, const T* A_1,            \
                              const T* b_1, const T* cholQ_1, const T* mu0_2, const T* cholP0_2, const T* A_2,          \
                              const T* b_2, const T* cholQ_2, const T* means_1, const T* covs_1, const T* weights,      \
@@ -590,6 +626,14 @@ size_t mf_kf_posterior_chain_workspace_bytes(int64_t B, int64_t T, int d, int m,
     if (B < 1 || T < 2 || d < 1 || m < 1) return 0;
     if (elem_size == 4) { const auto* t = post_table_for<float>(d); return t ? t->ws(B, T, m, rinv_per_step, chunks) : 0; }
     const auto* t = post_table_for<double>(d);
+    return t ? t->ws(B, T, m, rinv_per_step, chunks) : 0;
+}
+
+size_t mf_kf_loglik_grad_streamed_workspace_bytes(int64_t B, int64_t T, int d, int m, int rinv_per_step, int elem_size,
+                                                  int64_t chunks) {
+    if (B < 1 || T < 2 || d < 1 || m < 1) return 0;
+    if (elem_size == 4) { const auto* t = grad_table_for<float>(d); return t ? t->ws(B, T, m, rinv_per_step, chunks) : 0; }
+    const auto* t = grad_table_for<double>(d);
     return t ? t->ws(B, T, m, rinv_per_step, chunks) : 0;
 }
 

@@ -1,0 +1,140 @@
+// Instantiates the streamed backward of KalmanFilter.log_likelihood (mf_grad_lds.hpp) for ONE state dimension (compile with
+// -DMF_D=<d>) and both scalar types, and exports its launch table (mf_launch.hpp: GradOps).  The posterior chain it starts from
+// is the one of mf_post_inst.hip (PostOps of the same state dimension), run on the partition chosen here.
+#ifndef MF_D
+#error "compile with -DMF_D=<state dimension>"
+#endif
+#include "mf_grad_lds.hpp"
+#include "mf_launch.hpp"
+
+#include <type_traits>
+
+namespace mf {
+
+#define MF_CAT2(a, b) a##b
+#define MF_CAT(a, b) MF_CAT2(a, b)
+
+namespace {
+
+constexpr int D = MF_D;
+inline long cdiv(long a, long b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
+
+template <typename T> const PostOps<T>* post_ops();
+template <> const PostOps<float>* post_ops<float>() { return MF_CAT(post_ops_f32_d, MF_D)(); }
+template <> const PostOps<double>* post_ops<double>() { return MF_CAT(post_ops_f64_d, MF_D)(); }
+
+template <typename T, int M, bool RS> constexpr bool grad_supported() { return GradLds<T, D, M, RS>::SUPPORTED; }
+template <typename T> bool grad_covers(int m, int per_step) {
+    if (per_step) return m == 1 && grad_supported<T, 1, true>();
+    switch (m) {
+        case 1: return grad_supported<T, 1, false>();
+        case 2: return grad_supported<T, 2, false>();
+        case 3: return grad_supported<T, 3, false>();
+        default: return false;
+    }
+}
+template <typename T> int grad_lds_bytes(int m, int per_step) {
+    if (per_step) return GradLds<T, D, 1, true>::TOTAL;
+    return m == 1 ? GradLds<T, D, 1, false>::TOTAL : (m == 2 ? GradLds<T, D, 2, false>::TOTAL : GradLds<T, D, 3, false>::TOTAL);
+}
+
+// chunks per series: one wavefront on every SIMD the LDS image of pass 5 leaves room for; all five passes share the partition
+// (the posterior chain is asked for exactly this many chunks and reports the partition it made of them)
+template <typename T> bool grad_plan(long B, long Tn, int m, int per_step, long chunks, long& P, long& L) {
+    int w = (160 * 1024) / grad_lds_bytes<T>(m, per_step);
+    w = w > 4 ? 4 : (w < 1 ? 1 : w);
+    const long nt = Tn - 1;
+    long want = chunks > 0 ? chunks : cdiv(256L * 64 * w, B);
+    if (chunks <= 0) {
+        const long maxP = nt / 4 > 0 ? nt / 4 : 1;
+        if (want > maxP) want = maxP;
+    }
+    if (want > nt) want = nt;
+    if (want < 2) want = 2;            // pass 4 needs the summaries of passes 1-2, which a single chunk skips
+    return post_ops<T>()->plan(B, Tn, m, per_step, want, &P, &L) == 0 && P >= 2;
+}
+
+template <typename T> struct GradWs {
+    size_t post, chainA, chainb, start_m, start_S, total;
+    GradWs(long B, long Tn, int m, int per_step, long P) {
+        const size_t nt = size_t(Tn - 1);
+        post = align_up(post_ops<T>()->ws(B, Tn, m, per_step, P));
+        chainA = align_up(size_t(B) * nt * D * D * sizeof(T));
+        chainb = align_up(size_t(B) * nt * D * sizeof(T));
+        start_m = align_up(size_t(B) * P * D * sizeof(T));
+        start_S = align_up(size_t(B) * P * D * D * sizeof(T));
+        total = post + 2 * chainA + chainb + align_up(size_t(B) * D * sizeof(T)) + align_up(size_t(B) * D * D * sizeof(T)) + start_m + start_S;
+    }
+};
+
+template <typename T> size_t grad_ws(long B, long Tn, int m, int per_step, long chunks) {
+    if (B < 1 || Tn < 2 || !grad_covers<T>(m, per_step)) return 0;
+    long P, L;
+    if (!grad_plan<T>(B, Tn, m, per_step, chunks, P, L)) return 0;
+    if (post_ops<T>()->ws(B, Tn, m, per_step, P) == 0) return 0;
+    return GradWs<T>(B, Tn, m, per_step, P).total + 256;
+}
+
+template <typename T>
+int grad_run(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H, const T* y,
+             const T* Rinv, int rinv_per_step, const T* weights, T* g_mu0, T* g_cholP0, T* g_A, T* g_b, T* g_cholQ, T* g_H, T* g_y,
+             T* g_Om, void* ws, size_t ws_bytes, int* info, long chunks, hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
+    if (B < 1 || Tn < 2 || !grad_covers<T>(m, rinv_per_step)) return -101;
+    if (((reinterpret_cast<size_t>(A) | reinterpret_cast<size_t>(cholQ) | reinterpret_cast<size_t>(g_A) |
+          reinterpret_cast<size_t>(g_cholQ)) & 15) != 0) return -101;
+    long P, L;
+    if (!grad_plan<T>(B, Tn, m, rinv_per_step, chunks, P, L)) return -101;
+    const GradWs<T> lay(B, Tn, m, rinv_per_step, P);
+    if (ws == nullptr || ws_bytes < lay.total) return -21;
+    char* p = static_cast<char*>(ws);
+    void* post_ws = p; p += lay.post;
+    T* a_post = reinterpret_cast<T*>(p); p += lay.chainA;
+    T* cq_post = reinterpret_cast<T*>(p); p += lay.chainA;
+    T* b_post = reinterpret_cast<T*>(p); p += lay.chainb;
+    T* mu0_post = reinterpret_cast<T*>(p); p += align_up(size_t(B) * D * sizeof(T));
+    T* cp0_post = reinterpret_cast<T*>(p); p += align_up(size_t(B) * D * D * sizeof(T));
+    T* start_m = reinterpret_cast<T*>(p); p += lay.start_m;
+    T* start_S = reinterpret_cast<T*>(p);
+    if (ev0) (void)hipEventRecord(ev0, st);
+    // passes 1-3: the posterior chain on P chunks (a single chunk: the emit pass alone, and pass 4 finds P = 1)
+    const int rc = post_ops<T>()->chain(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, a_post, mu0_post, b_post,
+                                        cp0_post, cq_post, post_ws, lay.post, info, P, nullptr, nullptr, st);
+    if (rc != 0) return rc;
+    const PostWs<T, D> w = PostWs<T, D>::carve(post_ws, B, P);
+    KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, info, 0, weights};
+    const GradIo<T> io{cq_post, b_post, w.bPsi, w.bpsi, start_m, start_S, g_mu0, g_cholP0, g_A, g_b, g_cholQ, g_H, g_y, g_Om};
+    const dim3 grid((unsigned)cdiv(B * P, 64)), block(64);
+    auto launch = [&](auto mtag, auto rtag) {
+        constexpr int M = decltype(mtag)::value;
+        constexpr bool RS = decltype(rtag)::value;
+        if constexpr (GradLds<T, D, M, RS>::SUPPORTED) {
+            constexpr int lds = GradLds<T, D, M, RS>::TOTAL;
+            constexpr int scan_lds = PostScanLds<T, D>::BYTES;
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&grad_lds_kernel<T, D, M, RS>),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (attr != hipSuccess) return;
+            hipLaunchKernelGGL((grad_start_kernel<T, D, M>), dim3((unsigned)B), block, scan_lds, st, a, w.sum, io);
+            hipLaunchKernelGGL((grad_lds_kernel<T, D, M, RS>), grid, block, lds, st, a, L, io);
+        }
+    };
+    using std::integral_constant;
+    if (rinv_per_step) launch(integral_constant<int, 1>{}, integral_constant<bool, true>{});
+    else if (m == 1) launch(integral_constant<int, 1>{}, integral_constant<bool, false>{});
+    else if (m == 2) launch(integral_constant<int, 2>{}, integral_constant<bool, false>{});
+    else launch(integral_constant<int, 3>{}, integral_constant<bool, false>{});
+    if (ev1) (void)hipEventRecord(ev1, st);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+template <typename T> const GradOps<T>* table() {
+    static const GradOps<T> t = {&grad_ws<T>, &grad_run<T>};
+    return &t;
+}
+
+}  // namespace
+
+const GradOps<float>* MF_CAT(grad_ops_f32_d, MF_D)() { return table<float>(); }
+const GradOps<double>* MF_CAT(grad_ops_f64_d, MF_D)() { return table<double>(); }
+
+}  // namespace mf

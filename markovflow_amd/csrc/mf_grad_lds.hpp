@@ -1,0 +1,401 @@
+// The backward of KalmanFilter.log_likelihood for FEW, LONG series, streamed and partitioned in time (arithmetic and derivation:
+// mf_grad_math.hpp).  After the three passes of the posterior chain (mf_post_lds.hpp: chunk summaries, scan, emit) two more:
+//
+//   4. grad_start_kernel   a wavefront per series composes the SAME chunk summaries in time order (Kogge-Stone over the lanes),
+//      closes every prefix with the prior, and meets the state (Psi, psi) pass 2 left at the chunk boundary: the smoothed
+//      marginal (m, S) of the first block of every chunk.
+//   5. grad_lds_kernel     a lane per (series, chunk) walks its transitions FORWARD from that marginal; per transition it reads
+//      the model (A, cholQ, b, H, y: the LDS-DMA streams of the log-likelihood kernel) and chol(Q'), b' of the posterior chain,
+//      carries (m_k, S_k) in registers and writes every gradient of the transition once, through the LDS staging buffer of
+//      the emit pass (consecutive lanes store consecutive 16-B units of a row).
+//
+// Against the route it replaces (posterior chain -> marginal means and covariances by two scans in time -> one lane per (series,
+// time point) reading them back) the moments (2 d^2 + d values per step, written and read) never exist in HBM, and the
+// transitions A' of the posterior chain are not read: A' = Q' Q^-1 A costs two triangular products.
+// LDS: the image of one step (~55 KB at d = 6 fp64) + staging -> two wavefronts per CU.
+#pragma once
+#include "mf_grad_math.hpp"
+#include "mf_post_lds.hpp"
+
+namespace mf {
+
+template <typename T> struct GradIo {
+    const T* cq_post; const T* b_post;                // the posterior chain (pass 3)
+    const T* bPsi; const T* bpsi;                     // boundary states per consumer chunk (pass 2)
+    T* start_m; T* start_S;                           // [B, P, D], [B, P, D, D] (pass 4 -> pass 5)
+    T* gmu0; T* gC0; T* gA; T* gb; T* gC; T* gH; T* gy; T* gOm;
+};
+
+// ---- pass 4 -------------------------------------------------------------------------------------------------------------------
+// Summary j of the mirrored array stems from chunk P-1-j (pass 1 wrote them for the scan that runs from the last chunk); here
+// chunk i is read at P-1-i.  The inclusive scan leaves in i the composition of chunks 0 .. i, whose remaining block is block 0
+// and whose separator is the first block of chunk i+1.
+template <typename T, int D, int M>
+__global__ void __launch_bounds__(64) grad_start_kernel(KfArgs<T> a, RedSys<T> in, GradIo<T> io) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    const long s = blockIdx.x;
+    const long P = in.n;
+    const long q = (P + 63) / 64;
+    const long i0 = lane * q;
+    long i1 = i0 + q;
+    if (i1 > P) i1 = P;
+    const bool has = i0 < P;
+    bool bad = false;
+    const PostScanLds<T, D> lds{reinterpret_cast<T*>(smem), lane};
+    // what block 0 owns
+    T C0[D][D], mu0[D], Lam0[D][D], lam0[D], Rsh[M * M];
+    MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) { C0[i][j] = T(0); Lam0[i][j] = T(0); }
+    load_lower<T, D>(a.cholP0 + s * D * D, C0);
+    load_vec<T, D>(a.mu0 + s * D, mu0);
+    MF_UNROLL for (int i = 0; i < M * M; ++i) Rsh[i] = a.Rinv[(a.rinv_per_step ? (s * a.Tn) * M * M : 0) + i];
+    grad_prior_terms<T, D, M>(C0, mu0, a.H + (s * a.Tn) * M * D, a.y + (s * a.Tn) * M, Rsh, Lam0, lam0, bad);
+    // the marginal of the first block of chunk i+1 from the composition `run` of chunks 0 .. i; the composition of ALL chunks
+    // gives block 0 its right-hand side (Psi_0, psi_0)
+    auto emit = [&](long i, const PostSummary<T, D>& run) {
+        T Lam[D][D], lam[D], Psi[D][D], psi[D], m[D], S[D][D];
+        MF_UNROLL for (int r = 0; r < D; ++r) MF_UNROLL for (int c = 0; c < D; ++c) { Lam[r][c] = T(0); Psi[r][c] = T(0); S[r][c] = T(0); }
+        if (i + 1 < P) {
+            grad_close_prefix<T, D>(run, Lam0, lam0, Lam, lam, bad);
+            load_lower<T, D>(io.bPsi + (s * P + i) * D * D, Psi);
+            load_vec<T, D>(io.bpsi + (s * P + i) * D, psi);
+            grad_marginal<T, D>(Lam, lam, Psi, psi, m, S, bad);
+            store_vec<T, D>(io.start_m + (s * P + i + 1) * D, m);
+            store_sym<T, D>(io.start_S + (s * P + i + 1) * D * D, S);
+        } else {
+            MF_UNROLL for (int r = 0; r < D; ++r) {
+                lam[r] = lam0[r];
+                psi[r] = run.tv[r];
+                MF_UNROLL for (int c = 0; c <= r; ++c) { Lam[r][c] = Lam0[r][c]; Psi[r][c] = run.Dv[r][c]; }
+            }
+            grad_marginal<T, D>(Lam, lam, Psi, psi, m, S, bad);
+            store_vec<T, D>(io.start_m + (s * P) * D, m);
+            store_sym<T, D>(io.start_S + (s * P) * D * D, S);
+        }
+    };
+    PostSummary<T, D> acc;
+    if (has) {
+        post_summary_load<T, D>(in, s * P + (P - 1 - i0), acc);
+        for (long i = i0 + 1; i < i1; ++i) {
+            PostSummary<T, D> nx;
+            post_summary_load<T, D>(in, s * P + (P - 1 - i), nx);
+            post_combine<T, D>(nx, acc, bad);                   // nx on the right: the result stays in acc
+        }
+    }
+    const int nl = (int)((P + q - 1) / q);                      // lanes that hold a run
+    for (int off = 1; off < nl; off <<= 1) {
+        if (has) lds.put(acc);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // one wave per workgroup: LDS operations execute in order
+        __builtin_amdgcn_wave_barrier();
+        if (has && lane >= off) {
+            PostSummary<T, D> prev;
+            lds.get(lane - off, prev);                          // the run on the left
+            post_combine<T, D>(acc, prev, bad);
+            acc = prev;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (q == 1) {
+        if (has) emit(i0, acc);
+    } else {
+        if (has) lds.put(acc);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (has) {
+            PostSummary<T, D> run;
+            if (lane > 0) lds.get(lane - 1, run);
+            for (long i = i0; i < i1; ++i) {
+                PostSummary<T, D> nx;
+                post_summary_load<T, D>(in, s * P + (P - 1 - i), nx);
+                if (lane > 0 || i > i0) post_combine<T, D>(nx, run, bad);
+                else run = nx;
+                emit(i, run);
+            }
+        }
+    }
+    if (bad && a.info) raise_info(a.info);
+}
+
+// ---- pass 5 -------------------------------------------------------------------------------------------------------------------
+template <typename T, int D, int M, bool RSTEP> struct GradLds {
+    using Cfg = KfLdsCfg<T, D, M, RSTEP>;
+    using PL = PostLds<T, D, M, RSTEP>;
+    static constexpr int S = (int)sizeof(T);
+    static constexpr int H0 = PL::H0, B0 = PL::B0, B1 = PL::B1, Bv = PL::Bv, UNIT = PL::UNIT, U0 = PL::U0, U1 = PL::U1, Uv = PL::Uv;
+    static constexpr int BH = M * D * S;                                           // a row of d/dH
+    static constexpr int unit_h() { for (int u = 16; u > 4; u /= 2) if (BH % u == 0) return u; return 4; }
+    static constexpr int UNITH = unit_h(), UH = BH / UNITH;
+    static constexpr int OFF_G = ((Cfg::LDS_TOTAL + 15) / 16) * 16;               // chol(Q') of the step: the units of cholQ's stream
+    static constexpr int OFF_bp = OFF_G + Cfg::StC::LDS_BYTES;
+    static constexpr int OFF_stageM = OFF_bp + Cfg::Stb::LDS_BYTES;
+    static constexpr int OFF_stagev = OFF_stageM + 64 * B0;
+    static constexpr int OFF_len = OFF_stagev + ((64 * (Bv > BH ? Bv : BH) + 15) / 16) * 16;
+    static constexpr int TOTAL = OFF_len + 256;
+    static constexpr int N_DMA = Cfg::StA::NI + 2 * Cfg::StC::NI + 2 * Cfg::Stb::NI + Cfg::StH::NI + Cfg::Sty::NI + (RSTEP ? Cfg::StR::NI : 0);
+    static constexpr bool SUPPORTED = Cfg::SUPPORTED && N_DMA < 64 && TOTAL <= 80 * 1024;
+};
+
+// The next step's LDS-DMA, issued at the sites of grad_step: a stream's image is single-buffered, so its batch goes out after the
+// last read of the current rows (C, G, the vectors: in registers from the top of the step; A: read three times from the image).
+template <typename T, int D, int M, bool RSTEP> struct GradPump {
+    using GL = GradLds<T, D, M, RSTEP>;
+    using Cfg = typename GL::Cfg;
+    const DmaStream<typename Cfg::StA>& dA; const DmaStream<typename Cfg::StC>& dC;
+    const DmaStream<typename Cfg::Stb>& db; const DmaStream<typename Cfg::StH>& dH;
+    const DmaStream<typename Cfg::Sty>& dy; const DmaStream<typename Cfg::StR>& dR;
+    mf_v4i sA, sC, sb, sH, sy, sR, sG, sbp;
+    unsigned lds0;
+    bool more, yfetch;
+    MF_DEV void all() const {
+        dC.template issue<0, 64>(sC, lds0 + Cfg::OFF_C);
+        dC.template issue<0, 64>(sG, lds0 + GL::OFF_G);
+        db.template issue<0, 64>(sb, lds0 + Cfg::OFF_b);
+        db.template issue<0, 64>(sbp, lds0 + GL::OFF_bp);
+        dH.template issue<0, 64>(sH, lds0 + Cfg::OFF_H);
+        dy.template issue<0, 64>(sy, lds0 + Cfg::OFF_y);
+        if (RSTEP) dR.template issue<0, 64>(sR, lds0 + Cfg::OFF_R);
+        dA.template issue<0, 64>(sA, lds0 + Cfg::OFF_A);
+    }
+    template <int K> MF_DEV void site() const {
+        asm volatile("" ::: "memory");                  // the image changes behind the compiler's back: no LDS value survives a site
+        if (!more) return;
+        if constexpr (K == 0) dC.template issue<0, 64>(sC, lds0 + Cfg::OFF_C);
+        if constexpr (K == 1) dC.template issue<0, 64>(sG, lds0 + GL::OFF_G);
+        if constexpr (K == 2) {
+            db.template issue<0, 64>(sb, lds0 + Cfg::OFF_b);
+            db.template issue<0, 64>(sbp, lds0 + GL::OFF_bp);
+            dH.template issue<0, 64>(sH, lds0 + Cfg::OFF_H);
+            if (yfetch) dy.template issue<0, 64>(sy, lds0 + Cfg::OFF_y);
+            if (RSTEP) dR.template issue<0, 64>(sR, lds0 + Cfg::OFF_R);
+        }
+        if constexpr (K >= 3 && K <= 6) {
+            constexpr int Q = (Cfg::StA::NI + 3) / 4;
+            if constexpr (K == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the last read of A has its data
+            dA.template issue<(K - 3) * Q, (K - 2) * Q>(sA, lds0 + Cfg::OFF_A);
+        }
+    }
+};
+
+// The gradient rows of one step: matrix rows in two halves and d-vectors through the staging buffer (StagedPiece, mf_post_lds.hpp),
+// stored in a burst as soon as they are staged; d/dy and Omega (M and M^2 values) straight from the lane.
+template <typename T, int D, int M, bool RSTEP> struct GradSink {
+    using GL = GradLds<T, D, M, RSTEP>;
+    static constexpr int H0 = GL::H0, U0 = GL::U0, U1 = GL::U1, Uv = GL::Uv, UNIT = GL::UNIT, UH = GL::UH, UNITH = GL::UNITH;
+    using W = typename OutWord<UNIT>::type;
+    using WH = typename OutWord<UNITH>::type;
+    using P0 = StagedPiece<T, U0, UNIT>;
+    using P1 = StagedPiece<T, U1, UNIT>;
+    using Pv = StagedPiece<T, Uv, UNIT>;
+    using PH = StagedPiece<T, UH, UNITH>;
+    char* smem; int lane;
+    DmaStream<OutPiece<U0, UNIT>> d0;
+    DmaStream<OutPiece<(U1 > 0 ? U1 : 1), UNIT>> d1;
+    DmaStream<OutPiece<Uv, UNIT>> dv;
+    DmaStream<OutPiece<UH, UNITH>> dh;
+    unsigned long long qA, qC, qb, qH, fA, fC, fb, fH;     // the wave's rows at this position; the tensors' ends
+    T* gy; T* gOm;                                        // this lane's time point
+    long e, minlen;
+    W ma, mb;
+    WH ha, hb;
+
+    MF_DEV void init(char* smem_, int lane_, int rel_mat, int rel_vec, int rel_h) {
+        smem = smem_; lane = lane_;
+        d0.init(smem, lane, rel_mat, 0);
+        if constexpr (U1 > 0) d1.init(smem, lane, rel_mat, 0);
+        dv.init(smem, lane, rel_vec, 0);
+        dh.init(smem, lane, rel_h, 0);
+    }
+    template <typename P, int NU, typename WW, typename DS>
+    MF_DEV void burst(int off_stage, const DS& ds, unsigned long long q, unsigned long long f, const T* row, WW& wa, WW& wb) {
+        const mf_v4i srd = make_srd(q, f);
+        P::stage(smem, off_stage, lane, row, wa);
+        static_for<0, NU>([&](auto ic) {
+            P::template unit<decltype(ic)::value>(smem, off_stage, GL::OFF_len, lane, ds.vo, srd, e < minlen, e, wa, wb);
+        });
+    }
+    template <int HALF, int R> MF_DEV void put_mat(unsigned long long q, unsigned long long f, const T (&rows)[R][D]) {
+        T row[R * D];
+        MF_UNROLL for (int i = 0; i < R; ++i) MF_UNROLL for (int j = 0; j < D; ++j) row[i * D + j] = rows[i][j];
+        if constexpr (HALF == 0) burst<P0, U0>(GL::OFF_stageM, d0, q, f, row, ma, mb);
+        else burst<P1, U1>(GL::OFF_stageM, d1, q + GL::B0, f, row, ma, mb);
+    }
+    template <int HALF, int R> MF_DEV void put_gA(const T (&rows)[R][D], bool) { put_mat<HALF, R>(qA, fA, rows); }
+    template <int HALF, int R> MF_DEV void put_gC(const T (&rows)[R][D], bool) { put_mat<HALF, R>(qC, fC, rows); }
+    MF_DEV void put_gb(const T (&v)[D], bool) { burst<Pv, Uv>(GL::OFF_stagev, dv, qb, fb, v, ma, mb); }
+    MF_DEV void put_obs(const T (&gH)[M * D], const T (&gyv)[M], const T (&gOmv)[M * M], bool active) {
+        burst<PH, UH>(GL::OFF_stagev, dh, qH, fH, gH, ha, hb);
+        if (active) {
+            MF_UNROLL for (int i = 0; i < M; ++i) gy[i] = gyv[i];
+            MF_UNROLL for (int i = 0; i < M * M; ++i) gOm[i] = gOmv[i];
+        }
+    }
+};
+
+// One wavefront per workgroup = 64 (series, chunk) lanes; KfArgs::P = chunks per series, L = transitions per chunk.  Position j of
+// a chunk = transition tau0 + j; a chunk shorter than the wave's longest idles LAST (its rows are then dropped by the range check).
+template <typename T, int D, int M, bool RSTEP>
+__global__ void __launch_bounds__(64) grad_lds_kernel(KfArgs<T> a, long L, GradIo<T> io) {
+    using GL = GradLds<T, D, M, RSTEP>;
+    using Cfg = typename GL::Cfg;
+    using Sink = GradSink<T, D, M, RSTEP>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    const long total = a.B * a.P;
+    const long id_raw = (long)blockIdx.x * 64 + lane;
+    const bool valid = id_raw < total;
+    const long id = valid ? id_raw : total - 1;
+    const long s = id / a.P, c = id % a.P;
+    const long nt = a.Tn - 1;
+    const long tau0 = c * L;
+    long len = nt - tau0;
+    if (len > L) len = L;
+    if (len < 0 || !valid) len = 0;
+    constexpr int S = sizeof(T);
+    long nsteps = len, minlen = len;
+    MF_UNROLL for (int off = 32; off > 0; off >>= 1) {
+        const long o = __shfl_xor((long long)nsteps, off);
+        nsteps = o > nsteps ? o : nsteps;
+        const long u = __shfl_xor((long long)minlen, off);
+        minlen = u < minlen ? u : minlen;
+    }
+    nsteps = __builtin_amdgcn_readfirstlane((int)nsteps);
+    minlen = __builtin_amdgcn_readfirstlane((int)minlen);
+
+    // ---- row offsets (LDS tables) and wave-uniform stream pointers, as in kf_chunk_lds_kernel -------------------------------
+    const unsigned long long offA = (unsigned long long)(s * nt + tau0) * (D * D * S);
+    const unsigned long long offb = (unsigned long long)(s * nt + tau0) * (D * S);
+    const unsigned long long offH = (unsigned long long)(s * a.Tn + tau0 + 1) * (M * D * S);
+    const unsigned long long offy = (unsigned long long)(s * a.Tn + tau0 + 1) * (M * S);
+    const unsigned long long offR = (unsigned long long)(s * a.Tn + tau0 + 1) * (M * M * S);
+    const unsigned long long offA0 = uniform64(offA), offb0 = uniform64(offb);
+    const unsigned long long offH0 = uniform64(offH), offy0 = uniform64(offy), offR0 = uniform64(offR);
+    const bool rowok = valid && len > 0;
+    {
+        unsigned* tab = reinterpret_cast<unsigned*>(smem);
+        tab[Cfg::OFF_relA / 4 + lane] = rowok ? (unsigned)(offA - offA0) : MF_DMA_INVALID;
+        tab[Cfg::OFF_relb / 4 + lane] = rowok ? (unsigned)(offb - offb0) : MF_DMA_INVALID;
+        tab[Cfg::OFF_relH / 4 + lane] = rowok ? (unsigned)(offH - offH0) : MF_DMA_INVALID;
+        tab[Cfg::OFF_rely / 4 + lane] = rowok ? (unsigned)(offy - offy0) : MF_DMA_INVALID;
+        tab[Cfg::OFF_relR / 4 + lane] = rowok ? (unsigned)(offR - offR0) : MF_DMA_INVALID;
+        reinterpret_cast<int*>(smem)[GL::OFF_len / 4 + lane] = rowok ? (int)len : 0;
+        if (lane < Cfg::StC::U) {
+            unsigned g = 0;
+            MF_UNROLL for (int cc = 0; cc < Cfg::StC::U; ++cc) if (lane == cc) g = (unsigned)Cfg::StC::global_unit(cc);
+            tab[Cfg::OFF_gtabC / 4 + lane] = g * Cfg::StC::UNIT;
+        }
+    }
+    DmaStream<typename Cfg::StA> dA;
+    DmaStream<typename Cfg::StC> dC;
+    DmaStream<typename Cfg::Stb> db;
+    DmaStream<typename Cfg::StH> dH;
+    DmaStream<typename Cfg::Sty> dy;
+    DmaStream<typename Cfg::StR> dR;
+    const unsigned long long nA = (unsigned long long)a.B * nt * (D * D * S), nb = (unsigned long long)a.B * nt * (D * S);
+    const unsigned long long nH = (unsigned long long)a.B * a.Tn * (M * D * S), ny = (unsigned long long)a.B * a.Tn * (M * S);
+    const unsigned long long nR = (unsigned long long)a.B * a.Tn * (M * M * S);
+    unsigned long long pA = (unsigned long long)a.A + offA0, pC = (unsigned long long)a.cholQ + offA0;
+    unsigned long long pG = (unsigned long long)io.cq_post + offA0, pbp = (unsigned long long)io.b_post + offb0;
+    unsigned long long pb = (unsigned long long)a.b + offb0, pH = (unsigned long long)a.H + offH0;
+    unsigned long long py = (unsigned long long)a.y + offy0;
+    unsigned long long pR = (unsigned long long)a.Rinv + (RSTEP ? offR0 : 0ull);
+    const unsigned long long eA = (unsigned long long)a.A + nA, eC = (unsigned long long)a.cholQ + nA;
+    const unsigned long long eG = (unsigned long long)io.cq_post + nA, ebp = (unsigned long long)io.b_post + nb;
+    const unsigned long long eb = (unsigned long long)a.b + nb, eH = (unsigned long long)a.H + nH, ey = (unsigned long long)a.y + ny;
+    const unsigned long long eR = (unsigned long long)a.Rinv + (RSTEP ? nR : 0ull);
+    const unsigned lds0 = (unsigned)(size_t)smem;
+
+    // ---- the chunk's first block: its smoothed marginal; block 0 also owns the prior and the observation of time point 0 -----
+    const T wgt = a.weights ? a.weights[s] : T(1);
+    bool bad = false;
+    T mk[D], Sk[D][D], Rsh[M * M];
+    MF_UNROLL for (int i = 0; i < M * M; ++i) Rsh[i] = RSTEP ? (valid ? a.Rinv[(s * a.Tn) * M * M + i] : T(0)) : a.Rinv[i];
+    MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Sk[i][j] = T(0);
+    load_vec<T, D>(io.start_m + id * D, mk);
+    load_lower<T, D>(io.start_S + id * D * D, Sk);
+    if (valid && c == 0) {
+        T C0[D][D], mu0[D], gmu0[D], gC0[D][D], gH[M * D], gyv[M], gOmv[M * M];
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) C0[i][j] = T(0);
+        load_lower<T, D>(a.cholP0 + s * D * D, C0);
+        load_vec<T, D>(a.mu0 + s * D, mu0);
+        grad_prior<T, D>(C0, mu0, mk, Sk, wgt, gmu0, gC0, bad);
+        store_vec<T, D>(io.gmu0 + s * D, gmu0);
+        store_mat<T, D, D>(io.gC0 + s * D * D, gC0);
+        grad_obs<T, D, M>(a.H + (s * a.Tn) * M * D, a.y + (s * a.Tn) * M, Rsh, mk, Sk, wgt, gH, gyv, gOmv);
+        MF_UNROLL for (int i = 0; i < M * D; ++i) io.gH[(s * a.Tn) * M * D + i] = gH[i];
+        MF_UNROLL for (int i = 0; i < M; ++i) io.gy[(s * a.Tn) * M + i] = gyv[i];
+        MF_UNROLL for (int i = 0; i < M * M; ++i) io.gOm[(s * a.Tn) * M * M + i] = gOmv[i];
+    }
+    // the LDS tables must be visible before the first DMA address is formed, and the plain loads / stores above must be done before
+    // DMAs are counted; touching the carried values keeps hipcc's wait-count pass from draining the DMA queue inside the loop
+    // (mf_post_lds.hpp has the story)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    MF_UNROLL for (int i = 0; i < D; ++i) {
+        asm volatile("" : "+v"(mk[i]));
+        MF_UNROLL for (int j = 0; j <= i; ++j) asm volatile("" : "+v"(Sk[i][j]));
+    }
+    {
+        T w_ = wgt;
+        asm volatile("" : "+v"(w_));
+    }
+    dA.init(smem, lane, Cfg::OFF_relA, 0);
+    dC.init(smem, lane, Cfg::OFF_relA, Cfg::OFF_gtabC);
+    db.init(smem, lane, Cfg::OFF_relb, 0);
+    dH.init(smem, lane, Cfg::OFF_relH, 0);
+    dy.init(smem, lane, Cfg::OFF_rely, 0);
+    if (RSTEP) dR.init(smem, lane, Cfg::OFF_relR, 0);
+    Sink sink;
+    sink.init(smem, lane, Cfg::OFF_relA, Cfg::OFF_relb, Cfg::OFF_relH);
+    sink.fA = (unsigned long long)io.gA + nA; sink.fC = (unsigned long long)io.gC + nA;
+    sink.fb = (unsigned long long)io.gb + nb; sink.fH = (unsigned long long)io.gH + nH;
+    sink.minlen = minlen;
+    unsigned long long qA = (unsigned long long)io.gA + offA0, qC = (unsigned long long)io.gC + offA0;
+    unsigned long long qb = (unsigned long long)io.gb + offb0, qH = (unsigned long long)io.gH + offH0;
+    T* gy_lane = io.gy + (s * a.Tn + tau0 + 1) * M;
+    T* gOm_lane = io.gOm + (s * a.Tn + tau0 + 1) * M * M;
+
+    const RowReader<T, typename Cfg::StA> rA(smem, Cfg::OFF_A, lane);
+    const RowReader<T, typename Cfg::StC> rC(smem, Cfg::OFF_C, lane);
+    const RowReader<T, typename Cfg::StC> rG(smem, GL::OFF_G, lane);
+    const RowReader<T, typename Cfg::Stb> rb(smem, Cfg::OFF_b, lane);
+    const RowReader<T, typename Cfg::Stb> rbp(smem, GL::OFF_bp, lane);
+    const RowReader<T, typename Cfg::StH> rH(smem, Cfg::OFF_H, lane);
+    const RowReader<T, typename Cfg::Sty> ry(smem, Cfg::OFF_y, lane);
+    const RowReader<T, typename Cfg::StR> rR(smem, Cfg::OFF_R, lane);
+    using Pump = GradPump<T, D, M, RSTEP>;
+    if (nsteps > 0) {
+        const Pump p0{dA, dC, db, dH, dy, dR, make_srd(pA, eA), make_srd(pC, eC), make_srd(pb, eb), make_srd(pH, eH),
+                      make_srd(py, ey), make_srd(pR, eR), make_srd(pG, eG), make_srd(pbp, ebp), lds0, true, true};
+        p0.all();
+    }
+    for (long j = 0; j < nsteps; ++j) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const bool more = (j + 1 < nsteps);
+        const bool yfetch = ((j + 1) % Cfg::YG) == 0;
+        pA += D * D * S; pC += D * D * S; pG += D * D * S; pb += D * S; pbp += D * S; pH += M * D * S;
+        if (RSTEP) pR += M * M * S;
+        if (yfetch) py += Cfg::YG * M * S;
+        T C[D][D], G[D][D], bq[D], bp[D], hk[M * D], yk[M];
+        MF_UNROLL for (int i = 0; i < D; ++i)
+            MF_UNROLL for (int jj = 0; jj <= i; ++jj) { C[i][jj] = rC.at(i * D + jj); G[i][jj] = rG.at(i * D + jj); }
+        MF_UNROLL for (int i = 0; i < D; ++i) { bq[i] = rb.at(i); bp[i] = rbp.at(i); }
+        MF_UNROLL for (int i = 0; i < M * D; ++i) hk[i] = rH.at(i);
+        MF_UNROLL for (int i = 0; i < M; ++i)
+            yk[i] = *reinterpret_cast<const T*>(ry.row + ((int)(j % Cfg::YG) * M + i) * (int)sizeof(T));
+        if (RSTEP) { MF_UNROLL for (int i = 0; i < M * M; ++i) Rsh[i] = rR.at(i); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const Pump pump{dA, dC, db, dH, dy, dR, make_srd(pA, eA), make_srd(pC, eC), make_srd(pb, eb), make_srd(pH, eH),
+                        make_srd(py, ey), make_srd(pR, eR), make_srd(pG, eG), make_srd(pbp, ebp), lds0, more, yfetch};
+        const bool active = j < len;
+        sink.qA = qA; sink.qC = qC; sink.qb = qb; sink.qH = qH; sink.e = j;
+        sink.gy = gy_lane; sink.gOm = gOm_lane;
+        auto Aat = [&](int i, int jj) { return rA.at(i * D + jj); };
+        grad_step<T, D, M>(mk, Sk, bad, C, bq, G, bp, hk, yk, Rsh, wgt, Aat, pump, sink, active);
+        qA += D * D * S; qC += D * D * S; qb += D * S; qH += M * D * S;
+        gy_lane += M; gOm_lane += M * M;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (valid && bad && a.info) raise_info(a.info);
+}
+
+}  // namespace mf

@@ -74,8 +74,18 @@ template <typename T> struct PostOps {
     int (*chain)(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H,
                  const T* y, const T* Rinv, int rinv_per_step, T* a_post, T* mu0_post, T* b_post, T* cp0_post, T* cq_post,
                  void* ws, size_t ws_bytes, int* info, long chunks, hipEvent_t ev0, hipEvent_t ev1, hipStream_t st);
+    int (*plan)(long B, long Tn, int m, int rinv_per_step, long chunks, long* P, long* L);   // the partition `chain` makes of `chunks`
 };
 constexpr int MF_MAX_D_POST = 6;
+
+// streamed backward of KalmanFilter.log_likelihood (mf_grad_lds.hpp, mf_grad_inst.hip; the same state dimensions)
+template <typename T> struct GradOps {
+    size_t (*ws)(long B, long Tn, int m, int rinv_per_step, long chunks);      // 0: not this route's call
+    int (*run)(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H,
+               const T* y, const T* Rinv, int rinv_per_step, const T* weights, T* g_mu0, T* g_cholP0, T* g_A, T* g_b, T* g_cholQ,
+               T* g_H, T* g_y, T* g_Om, void* ws, size_t ws_bytes, int* info, long chunks, hipEvent_t ev0, hipEvent_t ev1,
+               hipStream_t st);
+};
 
 constexpr int MF_MAX_D = 9;        // largest state dimension with a register-resident (lane per chunk) instantiation
 constexpr int MF_MAX_D_ROW = 15;   // largest state dimension of the row kernels (one 16-lane row per chunk; 10 ... 15: only those)
@@ -134,7 +144,9 @@ MF_DECLARE_TABLES(10) MF_DECLARE_TABLES(11) MF_DECLARE_TABLES(12) MF_DECLARE_TAB
 #undef MF_DECLARE_TABLES
 #define MF_DECLARE_POST(D)                            \
     const PostOps<float>* post_ops_f32_d##D();        \
-    const PostOps<double>* post_ops_f64_d##D();
+    const PostOps<double>* post_ops_f64_d##D();       \
+    const GradOps<float>* grad_ops_f32_d##D();        \
+    const GradOps<double>* grad_ops_f64_d##D();
 MF_DECLARE_POST(1) MF_DECLARE_POST(2) MF_DECLARE_POST(3) MF_DECLARE_POST(4) MF_DECLARE_POST(5) MF_DECLARE_POST(6)
 #undef MF_DECLARE_POST
 

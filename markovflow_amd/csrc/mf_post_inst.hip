@@ -14,7 +14,6 @@ namespace {
 
 constexpr int D = MF_D;
 inline long cdiv(long a, long b) { return (a + b - 1) / b; }
-inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
 
 // outputs / observation-precision forms with a streaming instantiation (the LDS image and the per-step DMA count of
 // KfLdsCfg must fit, as for the log-likelihood kernel)
@@ -53,11 +52,7 @@ template <typename T> PostPlan post_plan(long B, long Tn, int m, int per_step, l
     return pl;
 }
 
-// summaries (Dv, GU, F: D*D each; tv, gU: D each; sc) + boundary states (Psi: D*D, psi: D) per (series, chunk)
-template <typename T> size_t post_ws_for(long B, long P) {
-    const size_t nb = size_t(B) * P;
-    return align_up(nb * (3 * D * D + 2 * D + 1) * sizeof(T)) + align_up(nb * D * D * sizeof(T)) + align_up(nb * D * sizeof(T));
-}
+template <typename T> size_t post_ws_for(long B, long P) { return PostWs<T, D>::bytes(B, P); }
 // 0 = this call is not the streamed kernels' (the caller keeps its other routes)
 template <typename T> size_t post_ws(long B, long Tn, int m, int per_step, long chunks) {
     if (B < 1 || Tn < 2 || !post_covers<T>(m, per_step)) return 0;
@@ -75,18 +70,10 @@ int post_chain(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A
     const PostPlan pl = post_plan<T>(B, Tn, m, rinv_per_step, chunks);
     if (ws == nullptr || ws_bytes < post_ws_for<T>(B, pl.P)) return -21;
     const long P = pl.P, L = pl.L;
-    char* p = static_cast<char*>(ws);
-    RedSys<T> sum;
-    {
-        T* base = reinterpret_cast<T*>(p);
-        const long nb = B * P;
-        sum.Dv = base; sum.GU = sum.Dv + nb * D * D; sum.F = sum.GU + nb * D * D; sum.tv = sum.F + nb * D * D;
-        sum.gU = sum.tv + nb * D; sum.sc = sum.gU + nb * D;
-        sum.n = P; sum.f_stride = P; sum.f_off = 0;
-        p += align_up(size_t(nb) * (3 * D * D + 2 * D + 1) * sizeof(T));
-    }
-    T* bPsi = reinterpret_cast<T*>(p); p += align_up(size_t(B) * P * D * D * sizeof(T));
-    T* bpsi = reinterpret_cast<T*>(p);
+    const PostWs<T, D> w = PostWs<T, D>::carve(ws, B, P);
+    const RedSys<T> sum = w.sum;
+    T* bPsi = w.bPsi;
+    T* bpsi = w.bpsi;
     KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, info, 0, nullptr};
     const PostOut<T> po{a_post, mu0_post, b_post, cp0_post, cq_post, bPsi, bpsi};
     const dim3 grid((unsigned)cdiv(B * P, 64)), block(64);
@@ -115,8 +102,16 @@ int post_chain(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
+template <typename T> int post_plan_of(long B, long Tn, int m, int per_step, long chunks, long* P, long* L) {
+    if (B < 1 || Tn < 2 || !post_covers<T>(m, per_step)) return -101;
+    const PostPlan pl = post_plan<T>(B, Tn, m, per_step, chunks);
+    *P = pl.P;
+    *L = pl.L;
+    return 0;
+}
+
 template <typename T> const PostOps<T>* table() {
-    static const PostOps<T> t = {&post_ws<T>, &post_chain<T>};
+    static const PostOps<T> t = {&post_ws<T>, &post_chain<T>, &post_plan_of<T>};
     return &t;
 }
 

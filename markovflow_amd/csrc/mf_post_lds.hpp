@@ -25,6 +25,30 @@ template <typename T> struct PostOut {
     const T* bPsi; const T* bpsi;                                 // boundary state per consumer chunk [B, P, D, D] / [B, P, D] (EMIT)
 };
 
+// Workspace of the three passes: chunk summaries (Dv, GU, F: D*D each; tv, gU: D each; sc) and the boundary states (Psi: D*D,
+// psi: D) per (series, chunk).  (mf_grad_lds.hpp reads both after the passes have run.)
+template <typename T, int D> struct PostWs {
+    RedSys<T> sum; T* bPsi; T* bpsi;
+    static size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
+    static size_t bytes(long B, long P) {
+        const size_t nb = size_t(B) * P;
+        return align_up(nb * (3 * D * D + 2 * D + 1) * sizeof(T)) + align_up(nb * D * D * sizeof(T)) + align_up(nb * D * sizeof(T));
+    }
+    static PostWs carve(void* ws, long B, long P) {
+        PostWs w;
+        char* p = static_cast<char*>(ws);
+        T* base = reinterpret_cast<T*>(p);
+        const long nb = B * P;
+        w.sum.Dv = base; w.sum.GU = w.sum.Dv + nb * D * D; w.sum.F = w.sum.GU + nb * D * D; w.sum.tv = w.sum.F + nb * D * D;
+        w.sum.gU = w.sum.tv + nb * D; w.sum.sc = w.sum.gU + nb * D;
+        w.sum.n = P; w.sum.f_stride = P; w.sum.f_off = 0;
+        p += align_up(size_t(nb) * (3 * D * D + 2 * D + 1) * sizeof(T));
+        w.bPsi = reinterpret_cast<T*>(p); p += align_up(size_t(B) * P * D * D * sizeof(T));
+        w.bpsi = reinterpret_cast<T*>(p);
+        return w;
+    }
+};
+
 // ---- coalesced output rows, one store at a time ---------------------------------------------------------------------------
 // A lane produces whole rows of the posterior chain (A'_t: d x d, cholQ'_t: d x d, b'_t: d) for ITS chunk; stored directly,
 // one store instruction of the wave touches 64 different 128-B lines.  Instead the rows go through an LDS staging buffer:

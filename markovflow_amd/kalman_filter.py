@@ -48,6 +48,9 @@ class _LogLikelihoodPerSeries(torch.autograd.Function):
     def backward(ctx, grad_out):
         mu0, cp0, a_s, b_s, cq, h, y, r_inv = ctx.saved_tensors
         with torch.no_grad():
+            streamed = _streamed_backward(mu0, cp0, a_s, b_s, cq, h, y, r_inv, grad_out)
+            if streamed is not None:
+                return streamed + (None,)
             kf = _RawFilter(StateSpaceModel(mu0, cp0, a_s, b_s, cq), EmissionModel(h), y, r_inv)
             post = kf.posterior_state_space_model()
             means, covs, cross = post._moments(want_sub=True)  # one forward sweep (or two scans) of the posterior chain
@@ -75,6 +78,44 @@ class _LogLikelihoodPerSeries(torch.autograd.Function):
             # The log-determinant of the precision lives in the constants, which torch differentiates outside this function.
             g_r_inv = -0.5 * g_om if per_step else -0.5 * torch.sum(g_om, dim=(0, 1))
         return g_mu0, g_cp0, g_a, g_b, g_cq, g_h, g_y, g_r_inv, None
+
+
+# few, long series (the condition under which posterior_state_space_model streams, below): the backward as five streamed passes
+_GRAD_STREAMED = True
+_grad_prof_events = (None, None)     # optional hipEvent_t pair recorded around the kernels of the streamed backward (bench.py)
+
+
+def _streamed_backward(mu0, cp0, a_s, b_s, cq, h, y, r_inv, grad_out, chunks=0):
+    """``mf_kf_loglik_grad_streamed_*`` (csrc/mf_grad_lds.hpp): the smoothed marginals stay in registers.  ``None`` when the call
+    is not that route's (many series, short chains, d > 6, m > 3, unaligned views): the caller keeps the three-kernel route."""
+    bsz, n, m, d = h.shape
+    if not _GRAD_STREAMED or bsz < 1 or bsz >= BaseKalmanFilter._POST_FUSED_MIN_SERIES or n <= 64:
+        return None
+    per_step = r_inv.dim() > 2
+    lib = _lib.load()
+    ws_bytes = int(lib.mf_kf_loglik_grad_streamed_workspace_bytes(bsz, n, d, m, int(per_step), h.element_size(), chunks))
+    if ws_bytes == 0:
+        return None
+    tensors = [t.contiguous() for t in (mu0, cp0, a_s, b_s, cq, h, y, r_inv)]
+    g_mu0, g_cp0 = torch.empty_like(tensors[0]), torch.empty_like(tensors[1])
+    g_a, g_b, g_cq = torch.empty_like(tensors[2]), torch.empty_like(tensors[3]), torch.empty_like(tensors[4])
+    g_h, g_y = torch.empty_like(tensors[5]), torch.empty_like(tensors[6])
+    g_om = torch.empty((bsz, n, m, m), dtype=h.dtype, device=h.device)
+    if any(t.data_ptr() % 16 for t in (tensors[2], tensors[4], g_a, g_cq)):
+        return None
+    ws = _lib.workspace(ws_bytes, h.device)
+    info = _lib.pivot_info(h.device)
+    w = grad_out.reshape(bsz).contiguous()
+    ev0, ev1 = _grad_prof_events
+    rc = _lib.call_rc("mf_kf_loglik_grad_streamed", h.dtype, bsz, n, d, m, *[_lib.ptr(t) for t in tensors], int(per_step),
+                      _lib.ptr(w), _lib.ptr(g_mu0), _lib.ptr(g_cp0), _lib.ptr(g_a), _lib.ptr(g_b), _lib.ptr(g_cq), _lib.ptr(g_h),
+                      _lib.ptr(g_y), _lib.ptr(g_om), _lib.ptr(ws), ws_bytes, info, chunks, ev0, ev1, _lib.stream_ptr(h.device))
+    if rc == -101:
+        return None
+    _lib.check(rc, "mf_kf_loglik_grad_streamed")
+    _lib.raise_on_info(info, "log_likelihood (backward)", h.device)
+    g_r_inv = -0.5 * g_om if per_step else -0.5 * torch.sum(g_om, dim=(0, 1))
+    return g_mu0, g_cp0, g_a, g_b, g_cq, g_h, g_y, g_r_inv
 
 
 def _local_gradients_dense(mu0, cp0, a_s, b_s, cq, h, y, r_inv, means, covs, cross, w):
