@@ -137,7 +137,7 @@ template <typename T, int D, int M, bool RSTEP> struct GradLds {
 };
 
 // The next step's LDS-DMA, issued at the sites of grad_step: a stream's image is single-buffered, so its batch goes out after the
-// last read of the current rows (C, G, the vectors: in registers from the top of the step; A: read three times from the image).
+// last read of the current rows (C, H, y: in registers from the top of the step; A, G, b, b': read from the image where used).
 template <typename T, int D, int M, bool RSTEP> struct GradPump {
     using GL = GradLds<T, D, M, RSTEP>;
     using Cfg = typename GL::Cfg;
@@ -160,20 +160,26 @@ template <typename T, int D, int M, bool RSTEP> struct GradPump {
     template <int K> MF_DEV void site() const {
         asm volatile("" ::: "memory");                  // the image changes behind the compiler's back: no LDS value survives a site
         if (!more) return;
+        constexpr int Q = (Cfg::StA::NI + 3) / 4;
         if constexpr (K == 0) dC.template issue<0, 64>(sC, lds0 + Cfg::OFF_C);
-        if constexpr (K == 1) dC.template issue<0, 64>(sG, lds0 + GL::OFF_G);
-        if constexpr (K == 2) {
-            db.template issue<0, 64>(sb, lds0 + Cfg::OFF_b);
-            db.template issue<0, 64>(sbp, lds0 + GL::OFF_bp);
+        if constexpr (K == 1) {
             dH.template issue<0, 64>(sH, lds0 + Cfg::OFF_H);
             if (yfetch) dy.template issue<0, 64>(sy, lds0 + Cfg::OFF_y);
             if (RSTEP) dR.template issue<0, 64>(sR, lds0 + Cfg::OFF_R);
         }
-        if constexpr (K >= 3 && K <= 6) {
-            constexpr int Q = (Cfg::StA::NI + 3) / 4;
-            if constexpr (K == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the last read of A has its data
-            dA.template issue<(K - 3) * Q, (K - 2) * Q>(sA, lds0 + Cfg::OFF_A);
+        if constexpr (K == 3) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the last reads of A, b, b' have their data
+            db.template issue<0, 64>(sb, lds0 + Cfg::OFF_b);
+            db.template issue<0, 64>(sbp, lds0 + GL::OFF_bp);
+            dA.template issue<0, Q>(sA, lds0 + Cfg::OFF_A);
         }
+        if constexpr (K == 4) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // ... and the last read of G
+            dC.template issue<0, 64>(sG, lds0 + GL::OFF_G);
+            dA.template issue<Q, 2 * Q>(sA, lds0 + Cfg::OFF_A);
+        }
+        if constexpr (K == 5) dA.template issue<2 * Q, 3 * Q>(sA, lds0 + Cfg::OFF_A);
+        if constexpr (K == 6) dA.template issue<3 * Q, 4 * Q>(sA, lds0 + Cfg::OFF_A);
     }
 };
 
@@ -189,8 +195,9 @@ template <typename T, int D, int M, bool RSTEP> struct GradSink {
     using Pv = StagedPiece<T, Uv, UNIT>;
     using PH = StagedPiece<T, UH, UNITH>;
     char* smem; int lane;
+    static constexpr bool SAME_HALVES = (U1 == U0);  // even d: the second half of a matrix row has the offsets of the first
     DmaStream<OutPiece<U0, UNIT>> d0;
-    DmaStream<OutPiece<(U1 > 0 ? U1 : 1), UNIT>> d1;
+    DmaStream<OutPiece<(U1 > 0 && !SAME_HALVES ? U1 : 1), UNIT>> d1;
     DmaStream<OutPiece<Uv, UNIT>> dv;
     DmaStream<OutPiece<UH, UNITH>> dh;
     unsigned long long qA, qC, qb, qH, fA, fC, fb, fH;     // the wave's rows at this position; the tensors' ends
@@ -202,7 +209,7 @@ template <typename T, int D, int M, bool RSTEP> struct GradSink {
     MF_DEV void init(char* smem_, int lane_, int rel_mat, int rel_vec, int rel_h) {
         smem = smem_; lane = lane_;
         d0.init(smem, lane, rel_mat, 0);
-        if constexpr (U1 > 0) d1.init(smem, lane, rel_mat, 0);
+        if constexpr (U1 > 0 && !SAME_HALVES) d1.init(smem, lane, rel_mat, 0);
         dv.init(smem, lane, rel_vec, 0);
         dh.init(smem, lane, rel_h, 0);
     }
@@ -218,6 +225,7 @@ template <typename T, int D, int M, bool RSTEP> struct GradSink {
         T row[R * D];
         MF_UNROLL for (int i = 0; i < R; ++i) MF_UNROLL for (int j = 0; j < D; ++j) row[i * D + j] = rows[i][j];
         if constexpr (HALF == 0) burst<P0, U0>(GL::OFF_stageM, d0, q, f, row, ma, mb);
+        else if constexpr (SAME_HALVES) burst<P1, U1>(GL::OFF_stageM, d0, q + GL::B0, f, row, ma, mb);
         else burst<P1, U1>(GL::OFF_stageM, d1, q + GL::B0, f, row, ma, mb);
     }
     template <int HALF, int R> MF_DEV void put_gA(const T (&rows)[R][D], bool) { put_mat<HALF, R>(qA, fA, rows); }
@@ -265,9 +273,10 @@ __global__ void __launch_bounds__(64) grad_lds_kernel(KfArgs<T> a, long L, GradI
     // ---- row offsets (LDS tables) and wave-uniform stream pointers, as in kf_chunk_lds_kernel -------------------------------
     const unsigned long long offA = (unsigned long long)(s * nt + tau0) * (D * D * S);
     const unsigned long long offb = (unsigned long long)(s * nt + tau0) * (D * S);
-    const unsigned long long offH = (unsigned long long)(s * a.Tn + tau0 + 1) * (M * D * S);
-    const unsigned long long offy = (unsigned long long)(s * a.Tn + tau0 + 1) * (M * S);
-    const unsigned long long offR = (unsigned long long)(s * a.Tn + tau0 + 1) * (M * M * S);
+    // (the observation a step handles is that of the block its transition LEAVES: time point tau0 + j)
+    const unsigned long long offH = (unsigned long long)(s * a.Tn + tau0) * (M * D * S);
+    const unsigned long long offy = (unsigned long long)(s * a.Tn + tau0) * (M * S);
+    const unsigned long long offR = (unsigned long long)(s * a.Tn + tau0) * (M * M * S);
     const unsigned long long offA0 = uniform64(offA), offb0 = uniform64(offb);
     const unsigned long long offH0 = uniform64(offH), offy0 = uniform64(offy), offR0 = uniform64(offR);
     const bool rowok = valid && len > 0;
@@ -305,26 +314,22 @@ __global__ void __launch_bounds__(64) grad_lds_kernel(KfArgs<T> a, long L, GradI
     const unsigned long long eR = (unsigned long long)a.Rinv + (RSTEP ? nR : 0ull);
     const unsigned lds0 = (unsigned)(size_t)smem;
 
-    // ---- the chunk's first block: its smoothed marginal; block 0 also owns the prior and the observation of time point 0 -----
+    // ---- the chunk's first block: its smoothed marginal; block 0 also owns the prior -----------------------------------------
     const T wgt = a.weights ? a.weights[s] : T(1);
     bool bad = false;
     T mk[D], Sk[D][D], Rsh[M * M];
-    MF_UNROLL for (int i = 0; i < M * M; ++i) Rsh[i] = RSTEP ? (valid ? a.Rinv[(s * a.Tn) * M * M + i] : T(0)) : a.Rinv[i];
+    MF_UNROLL for (int i = 0; i < M * M; ++i) Rsh[i] = RSTEP ? T(0) : a.Rinv[i];
     MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Sk[i][j] = T(0);
     load_vec<T, D>(io.start_m + id * D, mk);
     load_lower<T, D>(io.start_S + id * D * D, Sk);
     if (valid && c == 0) {
-        T C0[D][D], mu0[D], gmu0[D], gC0[D][D], gH[M * D], gyv[M], gOmv[M * M];
+        T C0[D][D], mu0[D], gmu0[D], gC0[D][D];
         MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) C0[i][j] = T(0);
         load_lower<T, D>(a.cholP0 + s * D * D, C0);
         load_vec<T, D>(a.mu0 + s * D, mu0);
         grad_prior<T, D>(C0, mu0, mk, Sk, wgt, gmu0, gC0, bad);
         store_vec<T, D>(io.gmu0 + s * D, gmu0);
         store_mat<T, D, D>(io.gC0 + s * D * D, gC0);
-        grad_obs<T, D, M>(a.H + (s * a.Tn) * M * D, a.y + (s * a.Tn) * M, Rsh, mk, Sk, wgt, gH, gyv, gOmv);
-        MF_UNROLL for (int i = 0; i < M * D; ++i) io.gH[(s * a.Tn) * M * D + i] = gH[i];
-        MF_UNROLL for (int i = 0; i < M; ++i) io.gy[(s * a.Tn) * M + i] = gyv[i];
-        MF_UNROLL for (int i = 0; i < M * M; ++i) io.gOm[(s * a.Tn) * M * M + i] = gOmv[i];
     }
     // the LDS tables must be visible before the first DMA address is formed, and the plain loads / stores above must be done before
     // DMAs are counted; touching the carried values keeps hipcc's wait-count pass from draining the DMA queue inside the loop
@@ -351,8 +356,8 @@ __global__ void __launch_bounds__(64) grad_lds_kernel(KfArgs<T> a, long L, GradI
     sink.minlen = minlen;
     unsigned long long qA = (unsigned long long)io.gA + offA0, qC = (unsigned long long)io.gC + offA0;
     unsigned long long qb = (unsigned long long)io.gb + offb0, qH = (unsigned long long)io.gH + offH0;
-    T* gy_lane = io.gy + (s * a.Tn + tau0 + 1) * M;
-    T* gOm_lane = io.gOm + (s * a.Tn + tau0 + 1) * M * M;
+    T* gy_lane = io.gy + (s * a.Tn + tau0) * M;
+    T* gOm_lane = io.gOm + (s * a.Tn + tau0) * M * M;
 
     const RowReader<T, typename Cfg::StA> rA(smem, Cfg::OFF_A, lane);
     const RowReader<T, typename Cfg::StC> rC(smem, Cfg::OFF_C, lane);
@@ -375,10 +380,8 @@ __global__ void __launch_bounds__(64) grad_lds_kernel(KfArgs<T> a, long L, GradI
         pA += D * D * S; pC += D * D * S; pG += D * D * S; pb += D * S; pbp += D * S; pH += M * D * S;
         if (RSTEP) pR += M * M * S;
         if (yfetch) py += Cfg::YG * M * S;
-        T C[D][D], G[D][D], bq[D], bp[D], hk[M * D], yk[M];
-        MF_UNROLL for (int i = 0; i < D; ++i)
-            MF_UNROLL for (int jj = 0; jj <= i; ++jj) { C[i][jj] = rC.at(i * D + jj); G[i][jj] = rG.at(i * D + jj); }
-        MF_UNROLL for (int i = 0; i < D; ++i) { bq[i] = rb.at(i); bp[i] = rbp.at(i); }
+        T C[D][D], hk[M * D], yk[M];
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int jj = 0; jj <= i; ++jj) C[i][jj] = rC.at(i * D + jj);
         MF_UNROLL for (int i = 0; i < M * D; ++i) hk[i] = rH.at(i);
         MF_UNROLL for (int i = 0; i < M; ++i)
             yk[i] = *reinterpret_cast<const T*>(ry.row + ((int)(j % Cfg::YG) * M + i) * (int)sizeof(T));
@@ -390,11 +393,23 @@ __global__ void __launch_bounds__(64) grad_lds_kernel(KfArgs<T> a, long L, GradI
         sink.qA = qA; sink.qC = qC; sink.qb = qb; sink.qH = qH; sink.e = j;
         sink.gy = gy_lane; sink.gOm = gOm_lane;
         auto Aat = [&](int i, int jj) { return rA.at(i * D + jj); };
-        grad_step<T, D, M>(mk, Sk, bad, C, bq, G, bp, hk, yk, Rsh, wgt, Aat, pump, sink, active);
+        auto Gat = [&](int i, int jj) { return rG.at(i * D + jj); };
+        auto bqat = [&](int i) { return rb.at(i); };
+        auto bpat = [&](int i) { return rbp.at(i); };
+        grad_step<T, D, M>(mk, Sk, bad, C, hk, yk, Rsh, wgt, Aat, Gat, bqat, bpat, pump, sink, active);
         qA += D * D * S; qC += D * D * S; qb += D * S; qH += M * D * S;
         gy_lane += M; gOm_lane += M * M;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (valid && len > 0 && tau0 + len == nt) {       // the last block of the series: its observation
+        T gH[M * D], gyv[M], gOmv[M * M];
+        const long k = s * a.Tn + nt;
+        if (RSTEP) { MF_UNROLL for (int i = 0; i < M * M; ++i) Rsh[i] = a.Rinv[k * M * M + i]; }
+        grad_obs<T, D, M>(a.H + k * M * D, a.y + k * M, Rsh, mk, Sk, wgt, gH, gyv, gOmv);
+        MF_UNROLL for (int i = 0; i < M * D; ++i) io.gH[k * M * D + i] = gH[i];
+        MF_UNROLL for (int i = 0; i < M; ++i) io.gy[k * M + i] = gyv[i];
+        MF_UNROLL for (int i = 0; i < M * M; ++i) io.gOm[k * M * M + i] = gOmv[i];
+    }
     if (valid && bad && a.info) raise_info(a.info);
 }
 

@@ -10,7 +10,7 @@
 //                  e = x_{k+1} - A x_k - b = (A' - A) x_k + (b' - b) + eps':  E[e] = m_{k+1} - A m_k - b,
 //                  E[e x_k^T] = (A' - A) S_k + E[e] m_k^T,  Psi = (A' - A) S_k (A' - A)^T + Q' + E[e] E[e]^T  and
 //                  d/dA = Q^-1 E[e x^T],  d/db = Q^-1 E[e],  d/dC = tril(C^-T (C^-1 Psi C^-T - I)),
-//                  r = y - H x_{k+1}:  d/dH = R^-1 (E[r] m^T - H S),  d/dy = -R^-1 E[r],  Omega = E[r] E[r]^T + H S H^T
+//                  r = y - H x_k:  d/dH = R^-1 (E[r] m^T - H S),  d/dy = -R^-1 E[r],  Omega = E[r] E[r]^T + H S H^T
 // (the same closed forms as kf_grad_kernel, mf_kernels.hpp, which reads the moments from HBM).  Everything is
 // `__host__ __device__`: tests/host_sim runs these steps on the CPU against the oracle.
 // Reference: TensorFlow reverse mode through kalman_filter.py:184-255 (banded_matrices' registered gradients); pinned by
@@ -150,15 +150,24 @@ struct NoGradPump {
 constexpr int GRAD_PUMP_SITES = 8;
 
 // ---- one transition k -> k+1, forward in time -----------------------------------------------------------------------------
-// (mk, Sk): smoothed moments of block k on entry, of block k+1 on exit (S in the lower triangle).  C = cholQ_k (lower), bq = b_k,
-// G = cholQ'_k (lower), bp = b'_k; A_k is read through `Aat(i, j)` THREE times (on the device from the LDS image, so that it never
-// occupies registers between its uses; pump site 3 is the first place after the last read).  (hk, yk, Rsh): observation of block
-// k+1.  Outputs go to `sink` as soon as they exist: put_gA<HALF>(rows), put_gb(v), put_gC<HALF>(rows), put_obs(gH, gy, gOm).
-// Pump sites: 0 after C is consumed, 1 after G, 2 after the vectors, 3..6 spread behind the last read of A, 7 at the end.
-template <typename T, int D, int M, typename AReader, typename Pump, typename Sink>
-MF_HD void grad_step(T (&mk)[D], T (&Sk)[D][D], bool& bad, const T (&C)[D][D], const T (&bq)[D], const T (&G)[D][D],
-                     const T (&bp)[D], const T (&hk)[M * D], const T (&yk)[M], const T (&Rsh)[M * M], T wgt,
-                     const AReader& Aat, const Pump& pump, Sink& sink, bool active) {
+// (mk, Sk): smoothed moments of block k on entry, of block k+1 on exit (S in the lower triangle).  (hk, yk, Rsh): the observation
+// of block k - its gradient is formed FIRST, from the moments on entry, so that H and y are dead for the rest of the step (the
+// last block of a series is left to the caller).  C = cholQ_k (lower); A_k, G = cholQ'_k (lower), b_k and b'_k are read through
+// `Aat(i, j)`, `Gat(i, j)`, `bqat(i)`, `bpat(i)` - on the device from the LDS image, A and G twice, so that none of them occupies
+// registers between its uses (the step's live set is what limits the kernel: Ci, A', X, S_k and S_{k+1} at the peak).
+// Outputs go to `sink` as soon as they exist: put_obs(gH, gy, gOm), put_gA<HALF>(rows), put_gb(v), put_gC<HALF>(rows).
+// Pump sites (a stream's next rows may be fetched after the last read of the current ones): 0 after C, H, y; 3 after the last
+// read of A, b, b'; 4 after the last read of G; 1, 2, 5, 6, 7 are free places to spread batches over.
+template <typename T, int D, int M, typename AReader, typename GReader, typename BqReader, typename BpReader, typename Pump,
+          typename Sink>
+MF_HD void grad_step(T (&mk)[D], T (&Sk)[D][D], bool& bad, const T (&C)[D][D], const T (&hk)[M * D], const T (&yk)[M],
+                     const T (&Rsh)[M * M], T wgt, const AReader& Aat, const GReader& Gat, const BqReader& bqat,
+                     const BpReader& bpat, const Pump& pump, Sink& sink, bool active) {
+    {
+        T gH[M * D], gy[M], gOm[M * M];
+        if (active) grad_obs<T, D, M>(hk, yk, Rsh, mk, Sk, wgt, gH, gy, gOm);
+        sink.put_obs(gH, gy, gOm, active);
+    }
     constexpr int H0 = (D + 1) / 2;
     T Ci[D][D];
     if (active) {
@@ -167,76 +176,96 @@ MF_HD void grad_step(T (&mk)[D], T (&Sk)[D][D], bool& bad, const T (&C)[D][D], c
         tri_inv_lower<T, D>(C, Ci, unused, bad);
     }
     pump.template site<0>();
-    T Ap[D][D];
+    T Ap[D][D], Sn[D][D];
     if (active) {
         MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Ap[i][j] = Aat(i, j);
         trimul_lower_inplace<T, D, D>(Ci, Ap);                       // C^-1 A
         trimulT_lower_inplace<T, D, D>(Ci, Ap);                      // Q^-1 A
-        trimulT_lower_inplace<T, D, D>(G, Ap);                       // G^T Q^-1 A
-        trimul_lower_inplace<T, D, D>(G, Ap);                        // A' = Q' Q^-1 A
+        MF_UNROLL for (int i = 0; i < D; ++i) {                      // G^T Q^-1 A (top-down)
+            const T gii = Gat(i, i);
+            MF_UNROLL for (int j = 0; j < D; ++j) Ap[i][j] *= gii;
+            MF_UNROLL for (int k = i + 1; k < D; ++k) {
+                const T gki = Gat(k, i);
+                MF_UNROLL for (int j = 0; j < D; ++j) Ap[i][j] += gki * Ap[k][j];
+            }
+        }
+        MF_UNROLL for (int i = D - 1; i >= 0; --i) {                 // A' = G G^T Q^-1 A (bottom-up)
+            const T gii = Gat(i, i);
+            MF_UNROLL for (int j = 0; j < D; ++j) Ap[i][j] *= gii;
+            MF_UNROLL for (int k = 0; k < i; ++k) {
+                const T gik = Gat(i, k);
+                MF_UNROLL for (int j = 0; j < D; ++j) Ap[i][j] += gik * Ap[k][j];
+            }
+        }
+        // Q' = G G^T, the start of S_{k+1}
+        MF_UNROLL for (int i = 0; i < D; ++i)
+            MF_UNROLL for (int j = 0; j <= i; ++j) {
+                T acc = Gat(i, 0) * Gat(j, 0);
+                MF_UNROLL for (int l = 1; l <= j; ++l) acc += Gat(i, l) * Gat(j, l);
+                Sn[i][j] = acc;
+            }
     }
     pump.template site<1>();
-    T X[D][D], T1[D][D], mn[D], eb[D], GG[D][D], Sn[D][D];
+    T X[D][D], mn[D], eb[D];
     if (active) {
+        // X = Cov(x_{k+1}, x_k) = A' S_k,  m_{k+1} = A' m_k + b',  S_{k+1} = X A'^T + Q'
         MF_UNROLL for (int i = 0; i < D; ++i) {
-            mn[i] = bp[i];
+            mn[i] = bpat(i);
             MF_UNROLL for (int j = 0; j < D; ++j) X[i][j] = Ap[i][0] * (0 >= j ? Sk[0][j] : Sk[j][0]);
         }
         MF_UNROLL for (int l = 1; l < D; ++l)
             MF_UNROLL for (int i = 0; i < D; ++i)
                 MF_UNROLL for (int j = 0; j < D; ++j) X[i][j] += Ap[i][l] * (l >= j ? Sk[l][j] : Sk[j][l]);
         MF_UNROLL for (int l = 0; l < D; ++l) MF_UNROLL for (int i = 0; i < D; ++i) mn[i] += Ap[i][l] * mk[l];
+        MF_UNROLL for (int l = 0; l < D; ++l)
+            MF_UNROLL for (int i = 0; i < D; ++i)
+                MF_UNROLL for (int j = 0; j <= i; ++j) Sn[i][j] += X[i][l] * Ap[j][l];
     }
     pump.template site<2>();
     if (active) {
-        // T1 = (A' - A) S_k,  E[e] = m_{k+1} - A m_k - b
-        MF_UNROLL for (int i = 0; i < D; ++i) {
-            eb[i] = mn[i] - bq[i];
-            MF_UNROLL for (int j = 0; j < D; ++j) T1[i][j] = X[i][j];
-        }
+        // X <- (A' - A) S_k,  E[e] = m_{k+1} - A m_k - b;  then A' <- A' - A
+        MF_UNROLL for (int i = 0; i < D; ++i) eb[i] = mn[i] - bqat(i);
         MF_UNROLL for (int l = 0; l < D; ++l)
             MF_UNROLL for (int i = 0; i < D; ++i) {
                 const T ail = Aat(i, l);
                 eb[i] -= ail * mk[l];
-                MF_UNROLL for (int j = 0; j < D; ++j) T1[i][j] -= ail * (l >= j ? Sk[l][j] : Sk[j][l]);
+                MF_UNROLL for (int j = 0; j < D; ++j) X[i][j] -= ail * (l >= j ? Sk[l][j] : Sk[j][l]);
+                Ap[i][l] -= ail;
             }
-        // Q' = G G^T,  S_{k+1} = X A'^T + Q'
-        MF_UNROLL for (int i = 0; i < D; ++i)
-            MF_UNROLL for (int j = 0; j <= i; ++j) {
-                T acc = G[i][0] * G[j][0];
-                MF_UNROLL for (int l = 1; l <= j; ++l) acc += G[i][l] * G[j][l];
-                GG[i][j] = acc;
-                Sn[i][j] = acc;
-            }
-        MF_UNROLL for (int l = 0; l < D; ++l)
-            MF_UNROLL for (int i = 0; i < D; ++i)
-                MF_UNROLL for (int j = 0; j <= i; ++j) Sn[i][j] += X[i][l] * Ap[j][l];
-        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Ap[i][j] -= Aat(i, j);     // A' - A
+        // the moments of block k+1 (block k's are not needed any more)
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) Sk[i][j] = Sn[i][j];
     }
     pump.template site<3>();
+    T Psi[D][D];
     if (active) {
-        // Psi = T1 (A' - A)^T + Q' + E[e] E[e]^T  (lower, into GG)
-        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) GG[i][j] += eb[i] * eb[j];
+        // Psi = (A' - A) S_k (A' - A)^T + Q' + E[e] E[e]^T  (lower)
+        MF_UNROLL for (int i = 0; i < D; ++i)
+            MF_UNROLL for (int j = 0; j <= i; ++j) {
+                T acc = eb[i] * eb[j];
+                MF_UNROLL for (int l = 0; l <= j; ++l) acc += Gat(i, l) * Gat(j, l);
+                Psi[i][j] = acc;
+            }
         MF_UNROLL for (int l = 0; l < D; ++l)
             MF_UNROLL for (int i = 0; i < D; ++i)
-                MF_UNROLL for (int j = 0; j <= i; ++j) GG[i][j] += T1[i][l] * Ap[j][l];
-        // E[e x_k^T] = T1 + E[e] m_k^T;  d/dA = Q^-1 E[e x^T]
-        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) T1[i][j] += eb[i] * mk[j];
-        trimul_lower_inplace<T, D, D>(Ci, T1);
+                MF_UNROLL for (int j = 0; j <= i; ++j) Psi[i][j] += X[i][l] * Ap[j][l];
+        // E[e x_k^T] = (A' - A) S_k + E[e] m_k^T;  d/dA = Q^-1 E[e x^T]
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) X[i][j] += eb[i] * mk[j];
+        MF_UNROLL for (int i = 0; i < D; ++i) mk[i] = mn[i];
+        trimul_lower_inplace<T, D, D>(Ci, X);
     }
     pump.template site<4>();
     if (active) {
-        trimulT_lower_inplace<T, D, D>(Ci, T1);
-        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) T1[i][j] *= wgt;
+        trimulT_lower_inplace<T, D, D>(Ci, X);
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) X[i][j] *= wgt;
     }
     {
         T rows[H0][D];
-        MF_UNROLL for (int i = 0; i < H0; ++i) MF_UNROLL for (int j = 0; j < D; ++j) rows[i][j] = T1[i][j];
+        MF_UNROLL for (int i = 0; i < H0; ++i) MF_UNROLL for (int j = 0; j < D; ++j) rows[i][j] = X[i][j];
         sink.template put_gA<0>(rows, active);
     }
     if constexpr (D - H0 > 0) {
         T rows[D - H0][D];
-        MF_UNROLL for (int i = H0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) rows[i - H0][j] = T1[i][j];
+        MF_UNROLL for (int i = H0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) rows[i - H0][j] = X[i][j];
         sink.template put_gA<1>(rows, active);
     }
     pump.template site<5>();
@@ -255,8 +284,8 @@ MF_HD void grad_step(T (&mk)[D], T (&Sk)[D][D], bool& bad, const T (&C)[D][D], c
         T N1[D][D];
         MF_UNROLL for (int i = 0; i < D; ++i)
             MF_UNROLL for (int l = 0; l <= i; ++l) {
-                T acc = Ci[i][0] * (0 >= l ? GG[0][l] : GG[l][0]);
-                MF_UNROLL for (int k = 1; k <= i; ++k) acc += Ci[i][k] * (k >= l ? GG[k][l] : GG[l][k]);
+                T acc = Ci[i][0] * (0 >= l ? Psi[0][l] : Psi[l][0]);
+                MF_UNROLL for (int k = 1; k <= i; ++k) acc += Ci[i][k] * (k >= l ? Psi[k][l] : Psi[l][k]);
                 N1[i][l] = acc;
             }
         MF_UNROLL for (int i = 0; i < D; ++i)
@@ -290,18 +319,6 @@ MF_HD void grad_step(T (&mk)[D], T (&Sk)[D][D], bool& bad, const T (&C)[D][D], c
                 }
         }
         sink.template put_gC<1>(rows, active);
-    }
-    // the moments of block k+1 and its observation
-    if (active) {
-        MF_UNROLL for (int i = 0; i < D; ++i) {
-            mk[i] = mn[i];
-            MF_UNROLL for (int j = 0; j <= i; ++j) Sk[i][j] = Sn[i][j];
-        }
-    }
-    {
-        T gH[M * D], gy[M], gOm[M * M];
-        if (active) grad_obs<T, D, M>(hk, yk, Rsh, mk, Sk, wgt, gH, gy, gOm);
-        sink.put_obs(gH, gy, gOm, active);
     }
     pump.template site<7>();
 }

@@ -1,10 +1,12 @@
 #!/bin/bash
-# Kernel-level breakdown of log_likelihood forward + backward (scripts/bench_grad.py) at two shapes -> gpurun_out/grad_prof/
-R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/grad_prof; mkdir -p $OUT
+# Per-kernel times of log_likelihood().backward() at the headline shape (streamed route), and of the route it replaces.
 cd /tmp && export TMPDIR=/tmp
-for SH in "1024 10000" "16384 500"; do
-  set -- $SH; tag=B$1_T$2
-  rm -rf /tmp/pg_$tag
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pg_$tag -- python3 $R/scripts/bench_grad.py --batch $1 --T $2 --iters 3 > $OUT/$tag.log 2>&1
-  python3 $R/scripts/kstats.py /tmp/pg_$tag 30 > $OUT/${tag}_kstats.txt
-done
+R=$GRAFT_REPO_ROOT
+python3 $R/scripts/bench_grad.py --iters 5 2>&1 | tail -5
+rm -rf /tmp/pg && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pg -- python3 $R/scripts/bench_grad.py --iters 5 > /dev/null 2>&1
+python3 - <<'PY'
+import csv, glob
+f = glob.glob('/tmp/pg/**/*kernel_stats.csv', recursive=True)[0]
+for r in list(csv.DictReader(open(f)))[:14]:
+    print(f"{r['Name'][:100]:100s} calls {r['Calls']:>4s} avg {float(r['AverageNs'])/1e6:8.3f} ms  {r['Percentage']}%")
+PY

@@ -160,23 +160,36 @@ int run(long B, long Tn, const T* mu0, const T* cholP0, const T* A, const T* b, 
             }
             grad_marginal<T, D>(Lam, lam, Psi, psi, mk, Sk, bad);
             if (c == 0) {
-                T gmu0[D], gC0[D][D], gH[M * D], gy[M], gOm[M * M];
+                T gmu0[D], gC0[D][D];
                 grad_prior<T, D>(C0, m0v, mk, Sk, wgt, gmu0, gC0, bad);
                 store_vec<T, D>(go->gmu0 + s * D, gmu0);
                 store_mat<T, D, D>(go->gC0 + s * D * D, gC0);
-                grad_obs<T, D, M>(h0, y0, R0, mk, Sk, wgt, gH, gy, gOm);
-                HostGradSink<T, D, M> sink{*go, 0, s * Tn};
-                sink.put_obs(gH, gy, gOm, true);
             }
             for (long e = 0; e < len; ++e) {
                 const long t = tau0 + e;
-                T C[D][D] = {}, mv[D], hk[M * D], yk[M], Rsh[M * M], Bm[D][D], G[D][D] = {}, bp[D];
-                load_step(t, C, mv, hk, yk, Rsh, Bm);
+                T C[D][D] = {}, mv[D], hk1[M * D], yk1[M], Rsh[M * M], hk[M * D], yk[M], Bm[D][D], G[D][D] = {}, bp[D];
+                load_step(t, C, mv, hk1, yk1, Rsh, Bm);
+                // the observation of the block the transition leaves
+                for (int q = 0; q < M * D; ++q) hk[q] = H[(s * Tn + t) * M * D + q];
+                for (int q = 0; q < M; ++q) yk[q] = y[(s * Tn + t) * M + q];
+                for (int q = 0; q < M * M; ++q) Rsh[q] = per_step ? Rinv[(s * Tn + t) * M * M + q] : Rinv[q];
                 load_lower<T, D>(cq_post + (s * nt + t) * D * D, G);
                 load_vec<T, D>(b_post + (s * nt + t) * D, bp);
-                HostGradSink<T, D, M> sink{*go, s * nt + t, s * Tn + t + 1};
+                HostGradSink<T, D, M> sink{*go, s * nt + t, s * Tn + t};
                 auto Aat = [&](int i, int j) { return Bm[i][j]; };
-                grad_step<T, D, M>(mk, Sk, bad, C, mv, G, bp, hk, yk, Rsh, wgt, Aat, NoGradPump{}, sink, true);
+                auto Gat = [&](int i, int j) { return G[i][j]; };
+                auto bqat = [&](int i) { return mv[i]; };
+                auto bpat = [&](int i) { return bp[i]; };
+                grad_step<T, D, M>(mk, Sk, bad, C, hk, yk, Rsh, wgt, Aat, Gat, bqat, bpat, NoGradPump{}, sink, true);
+            }
+            if (c == P - 1) {                                                  // the last block of the series: its observation
+                T hk[M * D], yk[M], Rsh[M * M], gH[M * D], gy[M], gOm[M * M];
+                for (int q = 0; q < M * D; ++q) hk[q] = H[(s * Tn + nt) * M * D + q];
+                for (int q = 0; q < M; ++q) yk[q] = y[(s * Tn + nt) * M + q];
+                for (int q = 0; q < M * M; ++q) Rsh[q] = per_step ? Rinv[(s * Tn + nt) * M * M + q] : Rinv[q];
+                grad_obs<T, D, M>(hk, yk, Rsh, mk, Sk, wgt, gH, gy, gOm);
+                HostGradSink<T, D, M> sink{*go, 0, s * Tn + nt};
+                sink.put_obs(gH, gy, gOm, true);
             }
         }
     }
