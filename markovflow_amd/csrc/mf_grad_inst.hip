@@ -64,7 +64,7 @@ template <typename T> struct GradWs {
         chainb = align_up(size_t(B) * nt * D * sizeof(T));
         start_m = align_up(size_t(B) * P * D * sizeof(T));
         start_S = align_up(size_t(B) * P * D * D * sizeof(T));
-        total = post + 2 * chainA + chainb + align_up(size_t(B) * D * sizeof(T)) + align_up(size_t(B) * D * D * sizeof(T)) + start_m + start_S;
+        total = post + chainA + chainb + align_up(size_t(B) * D * sizeof(T)) + align_up(size_t(B) * D * D * sizeof(T)) + start_m + start_S;
     }
 };
 
@@ -89,7 +89,6 @@ int grad_run(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, 
     if (ws == nullptr || ws_bytes < lay.total) return -21;
     char* p = static_cast<char*>(ws);
     void* post_ws = p; p += lay.post;
-    T* a_post = reinterpret_cast<T*>(p); p += lay.chainA;
     T* cq_post = reinterpret_cast<T*>(p); p += lay.chainA;
     T* b_post = reinterpret_cast<T*>(p); p += lay.chainb;
     T* mu0_post = reinterpret_cast<T*>(p); p += align_up(size_t(B) * D * sizeof(T));
@@ -98,7 +97,7 @@ int grad_run(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, 
     T* start_S = reinterpret_cast<T*>(p);
     if (ev0) (void)hipEventRecord(ev0, st);
     // passes 1-3: the posterior chain on P chunks (a single chunk: the emit pass alone, and pass 4 finds P = 1)
-    const int rc = post_ops<T>()->chain(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, a_post, mu0_post, b_post,
+    const int rc = post_ops<T>()->chain(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, nullptr, mu0_post, b_post,
                                         cp0_post, cq_post, post_ws, lay.post, info, P, nullptr, nullptr, st);
     if (rc != 0) return rc;
     const PostWs<T, D> w = PostWs<T, D>::carve(post_ws, B, P);

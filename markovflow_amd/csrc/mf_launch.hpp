@@ -71,6 +71,7 @@ template <typename T> struct OpsTable {
 // streamed, time-partitioned posterior chain (mf_post_lds.hpp, instantiated by mf_post_inst.hip for d = 1 ... MF_MAX_D_POST)
 template <typename T> struct PostOps {
     size_t (*ws)(long B, long Tn, int m, int rinv_per_step, long chunks);      // 0: not this route's call
+    // a_post = NULL: the chain without its transitions (the streamed backward of log_likelihood does not read them)
     int (*chain)(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H,
                  const T* y, const T* Rinv, int rinv_per_step, T* a_post, T* mu0_post, T* b_post, T* cp0_post, T* cq_post,
                  void* ws, size_t ws_bytes, int* info, long chunks, hipEvent_t ev0, hipEvent_t ev1, hipStream_t st);

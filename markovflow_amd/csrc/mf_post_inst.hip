@@ -86,11 +86,12 @@ int post_chain(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A
             constexpr int scan_lds = PostScanLds<T, D>::BYTES;
             if (ev0) (void)hipEventRecord(ev0, st);
             if (P > 1) {
-                hipLaunchKernelGGL((post_lds_kernel<T, D, M, RS, false>), grid, block, lds, st, a, L, sum, po);
+                hipLaunchKernelGGL((post_lds_kernel<T, D, M, RS, 0>), grid, block, lds, st, a, L, sum, po);
                 hipLaunchKernelGGL((post_scan_kernel<T, D>), dim3((unsigned)B), block, scan_lds, st, sum, B, bPsi, bpsi,
                                    info);
             }
-            hipLaunchKernelGGL((post_lds_kernel<T, D, M, RS, true>), grid, block, lds_emit, st, a, L, sum, po);
+            if (a_post) hipLaunchKernelGGL((post_lds_kernel<T, D, M, RS, 1>), grid, block, lds_emit, st, a, L, sum, po);
+            else hipLaunchKernelGGL((post_lds_kernel<T, D, M, RS, 2>), grid, block, lds_emit, st, a, L, sum, po);
             if (ev1) (void)hipEventRecord(ev1, st);
         }
     };

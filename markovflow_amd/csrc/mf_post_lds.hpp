@@ -2,13 +2,13 @@
 // memory side of the log-likelihood kernel (mf_kf_lds.hpp: every lane's next transition brought in by LDS-DMA, consecutive
 // lanes reading consecutive 16-B pieces of a row).  Three passes, arithmetic in mf_post_math.hpp:
 //
-//   1. post_lds_kernel<EMIT = false>  a lane per (series, chunk) walks its transitions from the last to the first, assembles
+//   1. post_lds_kernel<MODE = 0>      a lane per (series, chunk) walks its transitions from the last to the first, assembles
 //      the posterior precision on the way (state_space_model.py:431-483, kalman_filter.py:86-101,149-156) and eliminates
 //      with the fill-in carried towards the block on the chunk's right: one summary per chunk.  Reads (2 d^2 + d + m d + m) s
 //      bytes per step, writes nothing but the summaries.
 //   2. post_scan_kernel               a wavefront per series composes the summaries (Kogge-Stone over the lanes): the state of
 //      the backward recursion (Psi, psi) at every chunk boundary.
-//   3. post_lds_kernel<EMIT = true>   every chunk restarts the textbook backward recursion (block_tri_diag.py:438-545) from
+//   3. post_lds_kernel<MODE = 1>      every chunk restarts the textbook backward recursion (block_tri_diag.py:438-545) from
 //      its boundary and writes the posterior chain: reads the same bytes again, writes (2 d^2 + d) s per step.
 //
 // Against the route it replaces for B < 2048 (mf_ssm_precision -> parallel-in-time U D U^T -> affine scan -> emit kernels:
@@ -148,7 +148,8 @@ template <typename T, int NU, int UNIT> struct StagedPiece {
 
 // The emit step's sink (mf_post_math.hpp: post_emit_step) on the device.  It lives across the steps of the loop: the second half
 // of A' of step j is stored during step j + 1.
-template <typename T, int D, int M, bool RSTEP> struct PostSink {
+// TRANS = false: the step hands over no transitions (post_emit_step<TRANS = false>), their store windows stay empty.
+template <typename T, int D, int M, bool RSTEP, bool TRANS = true> struct PostSink {
     using PL = PostLds<T, D, M, RSTEP>;
     static constexpr int H0 = PL::H0, U0 = PL::U0, U1 = PL::U1, Uv = PL::Uv, UNIT = PL::UNIT;
     using W = typename OutWord<UNIT>::type;
@@ -182,7 +183,7 @@ template <typename T, int D, int M, bool RSTEP> struct PostSink {
     template <int SITE> MF_DEV void tick(bool) {
         constexpr int C0a = 9, C0b = 10 + D, Cva = C0b, Cvb = 10 + 2 * D, C1a = Cvb, C1b = 10 + 4 * D, A0a = 34, A0b = 34 + (D - H0) + D + 1;
         // the second half of the PREVIOUS step's A' (position e + 1; its descriptor was built when it was staged)
-        if (have_prev)
+        if (TRANS && have_prev)
             window<SITE, 0, 9, U1>([&](auto ic) {
                 P1::template unit<decltype(ic)::value>(smem, PL::OFF_stageM, PL::OFF_len, lane, d1.vo, sM, e + 1 < minlen, e + 1, ma, mb);
             });
@@ -195,9 +196,10 @@ template <typename T, int D, int M, bool RSTEP> struct PostSink {
         window<SITE, C1a, C1b, U1>([&](auto ic) {
             P1::template unit<decltype(ic)::value>(smem, PL::OFF_stageM, PL::OFF_len, lane, d1.vo, sM, e < minlen, e, ma, mb);
         });
-        window<SITE, A0a, A0b, U0>([&](auto ic) {
-            P0::template unit<decltype(ic)::value>(smem, PL::OFF_stageM, PL::OFF_len, lane, d0.vo, sM, e < minlen, e, ma, mb);
-        });
+        if constexpr (TRANS)
+            window<SITE, A0a, A0b, U0>([&](auto ic) {
+                P0::template unit<decltype(ic)::value>(smem, PL::OFF_stageM, PL::OFF_len, lane, d0.vo, sM, e < minlen, e, ma, mb);
+            });
     }
     MF_DEV void stage_factor(const T (&Gi)[D][D], const T (&mean)[D], bool) {
         T row[H0 * D];
@@ -242,11 +244,13 @@ template <typename T, int D, int M, bool RSTEP> struct PostSink {
 // Passes 1 and 3: one wavefront per workgroup = 64 (series, chunk) lanes.  KfArgs::P = chunks per series, L = transitions per
 // chunk.  Position e of a chunk = transition tau0 + e; the wave walks e = nsteps-1 ... 0 (a chunk shorter than the wave's
 // longest idles FIRST, so that all lanes end on their chunk's first transition and every DMA address is >= the tensor's start).
-template <typename T, int D, int M, bool RSTEP, bool EMIT>
+// MODE: 0 = pass 1, 1 = pass 3, 2 = pass 3 without the transitions A' (po.a_post is not touched).
+template <typename T, int D, int M, bool RSTEP, int MODE>
 __global__ void __launch_bounds__(64) post_lds_kernel(KfArgs<T> a, long L, RedSys<T> out, PostOut<T> po) {
+    constexpr bool EMIT = MODE != 0;
     using Cfg = KfLdsCfg<T, D, M, RSTEP>;
     using PL = PostLds<T, D, M, RSTEP>;
-    using Sink = PostSink<T, D, M, RSTEP>;
+    using Sink = PostSink<T, D, M, RSTEP, MODE != 2>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const long total = a.B * a.P;
@@ -400,7 +404,7 @@ __global__ void __launch_bounds__(64) post_lds_kernel(KfArgs<T> a, long L, RedSy
         if constexpr (EMIT) {                                                                                         \
             sink.qA = qA; sink.qC = qC; sink.qb = qb; sink.e = e;                                                     \
             qA -= D * D * S; qC -= D * D * S; qb -= D * S;                                                            \
-            post_emit_step<T, D, M>(E.Phi, E.t, E.bad, C, mvec, hk, yk, Rsh, Bm, pump, sink, active);                 \
+            post_emit_step<T, D, M, MODE == 1>(E.Phi, E.t, E.bad, C, mvec, hk, yk, Rsh, Bm, pump, sink, active);                 \
         } else {                                                                                                      \
             post_up_step<T, D, M, FIRST>(E, C, mvec, hk, yk, Rsh, Bm, pump, active, c + 1 < a.P);                     \
         }                                                                                                             \

@@ -207,8 +207,10 @@ template <int I0, int I1, typename F> MF_HD void static_for(F&& f) {
 // back cost ~13 k cycles per step).  Site map: [0, 9) while (Delta, x) is completed and factored - the previous step's last
 // piece drains there -, [9, 34) the products up to A' (the factor's pieces drain), [34, 44) the rest.
 // Sinks are called by ALL lanes (a device sink moves other lanes' rows); `active` is theirs to use.
+// TRANS = false: the transitions A' are neither formed nor handed over (the streamed backward of log_likelihood rebuilds them from
+// chol(Q'), mf_grad_math.hpp) - two triangular products and a third of the stores less.
 constexpr int EMIT_SITES = 44;
-template <typename T, int D, int M, typename Pump, typename Sink>
+template <typename T, int D, int M, bool TRANS = true, typename Pump, typename Sink>
 MF_HD void post_emit_step(T (&Phi)[D][D], T (&t)[D], bool& bad, const T (&C)[D][D], const T (&mvec)[D],
                           const T (&hk)[M * D], const T (&yk)[M], const T (&Rsh)[M * M], T (&Bm)[D][D], const Pump& pump,
                           Sink& sink, bool active) {
@@ -319,20 +321,20 @@ MF_HD void post_emit_step(T (&Phi)[D][D], T (&t)[D], bool& bad, const T (&C)[D][
     // A'_{t+1} = -Delta^-1 S = G^-1 Vn, the first rows
     {
         T Ap[H0][D];
-        if (active) {
+        if (TRANS && active) {
             MF_UNROLL for (int i = 0; i < H0; ++i) {
                 MF_UNROLL for (int j = 0; j < D; ++j) Ap[i][j] = Gi[i][0] * Bm[0][j];
                 MF_UNROLL for (int k = 1; k <= i; ++k)
                     MF_UNROLL for (int j = 0; j < D; ++j) Ap[i][j] += Gi[i][k] * Bm[k][j];
             }
         }
-        sink.template stage_transition<0>(Ap, active);
+        if constexpr (TRANS) sink.template stage_transition<0>(Ap, active);
     }
     {
         T Ap[D - H0 > 0 ? D - H0 : 1][D];
         static_for<H0, D>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            if (active) {
+            if (TRANS && active) {
                 MF_UNROLL for (int j = 0; j < D; ++j) Ap[i - H0][j] = Gi[i][0] * Bm[0][j];
                 MF_UNROLL for (int k = 1; k <= i; ++k)
                     MF_UNROLL for (int j = 0; j < D; ++j) Ap[i - H0][j] += Gi[i][k] * Bm[k][j];
@@ -358,7 +360,7 @@ MF_HD void post_emit_step(T (&Phi)[D][D], T (&t)[D], bool& bad, const T (&C)[D][
         }
         sink.template tick<34 + (D - H0) + D>(active);
         static_assert(34 + (D - H0) + D < EMIT_SITES, "site map of post_emit_step");
-        if constexpr (D - H0 > 0) sink.template stage_transition<1>(Ap, active);
+        if constexpr (TRANS && D - H0 > 0) sink.template stage_transition<1>(Ap, active);
     }
 }
 
