@@ -368,7 +368,12 @@ int mf_kf_loglik_grad_f32(int64_t B, int64_t T, int d, int m, const float* mu0, 
  * the three-call route).  Outputs and weights as for mf_kf_loglik_grad; the upper triangles of g_cholP0, g_cholQ are zeros.
  * ws: mf_kf_loglik_grad_streamed_workspace_bytes (0: not this route's call); it holds the posterior chain, (4 d^2 + 3 d) s bytes
  * per step.  chunks: time partitions per series, 0 = automatic (>= 2).  prof_start / prof_stop: optional hipEvent_t recorded
- * around the kernels.  Reference: TensorFlow reverse mode through markovflow/kalman_filter.py:184-255.
+ * around the kernels.
+ * fwd_ws (nullable): the workspace of the mf_kf_loglik call that evaluated the SAME inputs, untouched since, together with the
+ * partition mf_kf_loglik_plan reports for that call (path 2: the streaming level-0 kernel, whose per-chunk summaries are the
+ * first thing in its workspace).  The Schur complement of a chunk's interior does not depend on the direction of the
+ * elimination, so those summaries replace the first two passes and the boundary scan: three passes instead of five.
+ * Reference: TensorFlow reverse mode through markovflow/kalman_filter.py:184-255.
  */
 size_t mf_kf_loglik_grad_streamed_workspace_bytes(int64_t B, int64_t T, int d, int m, int rinv_per_step, int elem_size,
                                                   int64_t chunks);
@@ -376,12 +381,18 @@ int mf_kf_loglik_grad_streamed_f64(int64_t B, int64_t T, int d, int m, const dou
                                    const double* b, const double* cholQ, const double* H, const double* y, const double* Rinv,
                                    int rinv_per_step, const double* weights, double* g_mu0, double* g_cholP0, double* g_A,
                                    double* g_b, double* g_cholQ, double* g_H, double* g_y, double* g_omega, void* ws,
-                                   size_t ws_bytes, int* info, int64_t chunks, void* prof_start, void* prof_stop, void* stream);
+                                   size_t ws_bytes, int* info, int64_t chunks, const void* fwd_ws, int64_t fwd_chunks_per_series,
+                                   int64_t fwd_chunk_length, void* prof_start, void* prof_stop, void* stream);
 int mf_kf_loglik_grad_streamed_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const float* cholP0, const float* A,
                                    const float* b, const float* cholQ, const float* H, const float* y, const float* Rinv,
                                    int rinv_per_step, const float* weights, float* g_mu0, float* g_cholP0, float* g_A,
                                    float* g_b, float* g_cholQ, float* g_H, float* g_y, float* g_omega, void* ws,
-                                   size_t ws_bytes, int* info, int64_t chunks, void* prof_start, void* prof_stop, void* stream);
+                                   size_t ws_bytes, int* info, int64_t chunks, const void* fwd_ws, int64_t fwd_chunks_per_series,
+                                   int64_t fwd_chunk_length, void* prof_start, void* prof_stop, void* stream);
+/* The level-0 kernel (path: 0 row kernels, 1 spike-in-LDS, 2 streaming, 3 direct loads) and time partition mf_kf_loglik chooses
+ * for a call; aligned16: A and cholQ are 16-byte aligned. */
+int mf_kf_loglik_plan(int64_t B, int64_t T, int d, int m, int rinv_per_step, int elem_size, int64_t chunks, int aligned16,
+                      int* path, int64_t* chunks_per_series, int64_t* chunk_length);
 
 /*
  * Gradient of  KL(q1 || q2)  between two state space models (markovflow/state_space_model.py:528-593; differentiated by

@@ -465,7 +465,8 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
                                          const T* A, const T* b, const T* cholQ, const T* H, const T* y, const T* Rinv, \
                                          int rinv_per_step, const T* weights, T* g_mu0, T* g_cholP0, T* g_A, T* g_b,    \
                                          T* g_cholQ, T* g_H, T* g_y, T* g_omega, void* ws, size_t ws_bytes, int* info,  \
-                                         int64_t chunks, void* prof_start, void* prof_stop, void* stream) {             \
+                                         int64_t chunks, const void* fwd_ws, int64_t fwd_chunks_per_series,             \
+                                         int64_t fwd_chunk_length, void* prof_start, void* prof_stop, void* stream) {   \
         if (B < 1) return -1;                                                                                          \
         if (Tn < 2) return -2;                                                                                         \
         if (d < 1) return -3;                                                                                          \
@@ -476,8 +477,9 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         const auto* gt = grad_table_for<T>(d);                                                                         \
         if (!gt) return -101;                                                                                          \
         return gt->run(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, weights, g_mu0, g_cholP0, g_A,    \
-                       g_b, g_cholQ, g_H, g_y, g_omega, ws, ws_bytes, info, chunks,                                     \
-                       static_cast<hipEvent_t>(prof_start), static_cast<hipEvent_t>(prof_stop), S(stream));            \
+                       g_b, g_cholQ, g_H, g_y, g_omega, ws, ws_bytes, info, chunks, fwd_ws, fwd_chunks_per_series,      \
+                       fwd_chunk_length, static_cast<hipEvent_t>(prof_start), static_cast<hipEvent_t>(prof_stop),      \
+                       S(stream));                                                                                    \
     }                                                                                                                  \
     int mf_ssm_kl_grad_##SUF(int64_t B, int64_t Tn, int d, const T* mu0_1, const T* cholP0_1, const T* A_1,            \
                              const T* b_1, const T* cholQ_1, const T* mu0_2, const T* cholP0_2, const T* A_2,          \
@@ -627,6 +629,18 @@ size_t mf_kf_posterior_chain_workspace_bytes(int64_t B, int64_t T, int d, int m,
     if (elem_size == 4) { const auto* t = post_table_for<float>(d); return t ? t->ws(B, T, m, rinv_per_step, chunks) : 0; }
     const auto* t = post_table_for<double>(d);
     return t ? t->ws(B, T, m, rinv_per_step, chunks) : 0;
+}
+
+int mf_kf_loglik_plan(int64_t B, int64_t T, int d, int m, int rinv_per_step, int elem_size, int64_t chunks, int aligned16,
+                      int* path, int64_t* chunks_per_series, int64_t* chunk_length) {
+    if (B < 1 || T < 1 || d < 1 || !path || !chunks_per_series || !chunk_length) return -1;
+    long P = 0, L = 0;
+    int rc = -100;
+    if (elem_size == 4) { if (const auto* t = table_for<float>(d)) rc = t->kf_loglik_plan(B, T, m, rinv_per_step, chunks, aligned16, path, &P, &L); }
+    else if (const auto* t = table_for<double>(d)) rc = t->kf_loglik_plan(B, T, m, rinv_per_step, chunks, aligned16, path, &P, &L);
+    *chunks_per_series = P;
+    *chunk_length = L;
+    return rc;
 }
 
 size_t mf_kf_loglik_grad_streamed_workspace_bytes(int64_t B, int64_t T, int d, int m, int rinv_per_step, int elem_size,

@@ -55,11 +55,25 @@ template <typename T> bool grad_plan(long B, long Tn, int m, int per_step, long 
     return post_ops<T>()->plan(B, Tn, m, per_step, want, &P, &L) == 0 && P >= 2;
 }
 
+// the partition when the forward evaluation's summaries are given: groups of k of its chunks
+inline bool grad_plan_from(long B, long Tn, long chunks, int w, long fwd_P, long fwd_L, long& P, long& L, long& k) {
+    const long nt = Tn - 1;
+    if (fwd_P < 2 || fwd_L < 1 || (fwd_P - 1) * fwd_L >= nt || fwd_P * fwd_L < nt) return false;
+    long want = chunks > 0 ? chunks : cdiv(256L * 64 * w, B);
+    if (want < 2) want = 2;
+    k = cdiv(fwd_P, want);
+    if (k > fwd_P / 2) k = fwd_P / 2;
+    if (k < 1) k = 1;
+    L = k * fwd_L;
+    P = cdiv(nt, L);
+    return P >= 2;
+}
+
 template <typename T> struct GradWs {
     size_t post, chainA, chainb, start_m, start_S, total;
-    GradWs(long B, long Tn, int m, int per_step, long P) {
+    GradWs(long B, long Tn, long P) {
         const size_t nt = size_t(Tn - 1);
-        post = align_up(post_ops<T>()->ws(B, Tn, m, per_step, P));
+        post = align_up(PostWs<T, D>::bytes(B, P) + 256);
         chainA = align_up(size_t(B) * nt * D * D * sizeof(T));
         chainb = align_up(size_t(B) * nt * D * sizeof(T));
         start_m = align_up(size_t(B) * P * D * sizeof(T));
@@ -68,24 +82,34 @@ template <typename T> struct GradWs {
     }
 };
 
+// (sized for the finest partition either route makes: at most the chunks of grad_plan, or of the forward evaluation's groups)
 template <typename T> size_t grad_ws(long B, long Tn, int m, int per_step, long chunks) {
     if (B < 1 || Tn < 2 || !grad_covers<T>(m, per_step)) return 0;
     long P, L;
     if (!grad_plan<T>(B, Tn, m, per_step, chunks, P, L)) return 0;
     if (post_ops<T>()->ws(B, Tn, m, per_step, P) == 0) return 0;
-    return GradWs<T>(B, Tn, m, per_step, P).total + 256;
+    return GradWs<T>(B, Tn, 2 * P + 2).total + 256;
 }
 
 template <typename T>
 int grad_run(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H, const T* y,
              const T* Rinv, int rinv_per_step, const T* weights, T* g_mu0, T* g_cholP0, T* g_A, T* g_b, T* g_cholQ, T* g_H, T* g_y,
-             T* g_Om, void* ws, size_t ws_bytes, int* info, long chunks, hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
+             T* g_Om, void* ws, size_t ws_bytes, int* info, long chunks, const void* fwd_ws, long fwd_P, long fwd_L,
+             hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
     if (B < 1 || Tn < 2 || !grad_covers<T>(m, rinv_per_step)) return -101;
     if (((reinterpret_cast<size_t>(A) | reinterpret_cast<size_t>(cholQ) | reinterpret_cast<size_t>(g_A) |
           reinterpret_cast<size_t>(g_cholQ)) & 15) != 0) return -101;
-    long P, L;
+    long P, L, k = 0;
     if (!grad_plan<T>(B, Tn, m, rinv_per_step, chunks, P, L)) return -101;
-    const GradWs<T> lay(B, Tn, m, rinv_per_step, P);
+    const long Pmax = 2 * P + 2;                     // what the workspace query promised
+    bool from_fwd = false;
+    if (fwd_ws != nullptr) {
+        int w = (160 * 1024) / grad_lds_bytes<T>(m, rinv_per_step);
+        w = w > 4 ? 4 : (w < 1 ? 1 : w);
+        long P2, L2;
+        if (grad_plan_from(B, Tn, chunks, w, fwd_P, fwd_L, P2, L2, k) && P2 <= Pmax) { from_fwd = true; P = P2; L = L2; }
+    }
+    const GradWs<T> lay(B, Tn, P);
     if (ws == nullptr || ws_bytes < lay.total) return -21;
     char* p = static_cast<char*>(ws);
     void* post_ws = p; p += lay.post;
@@ -95,25 +119,45 @@ int grad_run(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, 
     T* cp0_post = reinterpret_cast<T*>(p); p += align_up(size_t(B) * D * D * sizeof(T));
     T* start_m = reinterpret_cast<T*>(p); p += lay.start_m;
     T* start_S = reinterpret_cast<T*>(p);
-    if (ev0) (void)hipEventRecord(ev0, st);
-    // passes 1-3: the posterior chain on P chunks (a single chunk: the emit pass alone, and pass 4 finds P = 1)
-    const int rc = post_ops<T>()->chain(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, nullptr, mu0_post, b_post,
-                                        cp0_post, cq_post, post_ws, lay.post, info, P, nullptr, nullptr, st);
-    if (rc != 0) return rc;
     const PostWs<T, D> w = PostWs<T, D>::carve(post_ws, B, P);
     KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, info, 0, weights};
-    const GradIo<T> io{cq_post, b_post, w.bPsi, w.bpsi, start_m, start_S, g_mu0, g_cholP0, g_A, g_b, g_cholQ, g_H, g_y, g_Om};
+    const GradIo<T> io{cq_post, b_post, w.bPsi, w.bpsi, start_m, start_S, from_fwd ? mu0_post : nullptr,
+                       from_fwd ? cp0_post : nullptr, g_mu0, g_cholP0, g_A, g_b, g_cholQ, g_H, g_y, g_Om};
     const dim3 grid((unsigned)cdiv(B * P, 64)), block(64);
+    constexpr int scan_lds = PostScanLds<T, D>::BYTES;
+    if (ev0) (void)hipEventRecord(ev0, st);
+    if (from_fwd) {
+        // the summaries of the forward evaluation (level 0 of mf_kf_loglik: the first fwd_P blocks per series of its workspace)
+        // stand in for passes 1, 2 and 4: boundary states and start moments at every k-th of its chunk boundaries
+        char* fp = const_cast<char*>(static_cast<const char*>(fwd_ws));
+        RedSys<T> k0;
+        {
+            T* base = reinterpret_cast<T*>(fp);
+            const long nb = B * fwd_P;
+            k0.Dv = base; k0.GU = k0.Dv + nb * D * D; k0.F = k0.GU + nb * D * D; k0.tv = k0.F + nb * D * D;
+            k0.gU = k0.tv + nb * D; k0.sc = k0.gU + nb * D;
+            k0.n = fwd_P; k0.f_stride = fwd_P; k0.f_off = 0;
+        }
+        hipLaunchKernelGGL((k0_scan_kernel<T, D, false>), dim3((unsigned)B), block, scan_lds, st, k0, k, P, io, info);
+        hipLaunchKernelGGL((k0_scan_kernel<T, D, true>), dim3((unsigned)B), block, scan_lds, st, k0, k, P, io, info);
+        const int rc = post_ops<T>()->emit(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, nullptr, mu0_post, b_post,
+                                           cp0_post, cq_post, post_ws, lay.post, info, P, L, st);
+        if (rc != 0) return rc;
+    } else {
+        // passes 1-3: the posterior chain (without its transitions) on P chunks
+        const int rc = post_ops<T>()->chain(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, nullptr, mu0_post, b_post,
+                                            cp0_post, cq_post, post_ws, lay.post, info, P, nullptr, nullptr, st);
+        if (rc != 0) return rc;
+    }
     auto launch = [&](auto mtag, auto rtag) {
         constexpr int M = decltype(mtag)::value;
         constexpr bool RS = decltype(rtag)::value;
         if constexpr (GradLds<T, D, M, RS>::SUPPORTED) {
             constexpr int lds = GradLds<T, D, M, RS>::TOTAL;
-            constexpr int scan_lds = PostScanLds<T, D>::BYTES;
             static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&grad_lds_kernel<T, D, M, RS>),
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (attr != hipSuccess) return;
-            hipLaunchKernelGGL((grad_start_kernel<T, D, M>), dim3((unsigned)B), block, scan_lds, st, a, w.sum, io);
+            if (!from_fwd) hipLaunchKernelGGL((grad_start_kernel<T, D, M>), dim3((unsigned)B), block, scan_lds, st, a, w.sum, io);
             hipLaunchKernelGGL((grad_lds_kernel<T, D, M, RS>), grid, block, lds, st, a, L, io);
         }
     };

@@ -21,8 +21,9 @@ namespace mf {
 
 template <typename T> struct GradIo {
     const T* cq_post; const T* b_post;                // the posterior chain (pass 3)
-    const T* bPsi; const T* bpsi;                     // boundary states per consumer chunk (pass 2)
+    T* bPsi; T* bpsi;                                 // boundary states per consumer chunk (pass 2, or k0_scan_kernel)
     T* start_m; T* start_S;                           // [B, P, D], [B, P, D, D] (pass 4 -> pass 5)
+    const T* mu0_post; const T* cp0_post;             // non-NULL: block 0's marginal is the chain's (mu0', cholP0' cholP0'^T)
     T* gmu0; T* gC0; T* gA; T* gb; T* gC; T* gH; T* gy; T* gOm;
 };
 
@@ -115,6 +116,110 @@ __global__ void __launch_bounds__(64) grad_start_kernel(KfArgs<T> a, RedSys<T> i
         }
     }
     if (bad && a.info) raise_info(a.info);
+}
+
+// ---- passes 1, 2 and 4 from the summaries the FORWARD evaluation left behind ---------------------------------------------------
+// kf_chunk_lds_kernel (mf_kf_lds.hpp), the level-0 kernel of mf_kf_loglik, writes one summary per (series, chunk) in the same
+// five-field form, for the forward elimination: (Dv, tv) the partial pivot / right-hand side of the chunk's LAST block including
+// that block's own terms, (GU, gU) what the chunk's interior adds to its FIRST block (the separator on its left, own terms
+// excluded), F the coupling of the two; chunk 0 has the prior eliminated into it.  The Schur complement of a chunk's interior
+// does not depend on the direction it was eliminated in, so these summaries hold everything passes 1 and 2 compute again:
+//   prefix compositions (chunks 0 .. j):  (Dv, tv) = everything on the LEFT of block (j+1) L, own terms included = (Lam, lam);
+//   suffix compositions (chunks j .. P-1), their last block eliminated too:  (GU, gU) = everything on the RIGHT of block j L,
+//   own terms excluded = (Psi, psi), the state the emit pass restarts from.
+// post_combine composes two runs in either convention: its first argument is the run whose remaining block is the other's
+// separator - here the run on the LEFT.  One wavefront per series, two launches (prefix, then suffix, which finishes the
+// marginals); the backward's chunks are groups of k forward chunks.
+template <typename T, int D, bool SUFFIX>
+__global__ void __launch_bounds__(64) k0_scan_kernel(RedSys<T> in, long k, long Pg, GradIo<T> io, int* info) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    const long s = blockIdx.x;
+    const long P = in.n;
+    const long q = (P + 63) / 64;
+    const long p0 = lane * q;                 // positions in scan order: position p is chunk p (prefix) or chunk P-1-p (suffix)
+    long p1 = p0 + q;
+    if (p1 > P) p1 = P;
+    const bool has = p0 < P;
+    bool bad = false;
+    const PostScanLds<T, D> lds{reinterpret_cast<T*>(smem), lane};
+    auto chunk_of = [&](long p) { return SUFFIX ? P - 1 - p : p; };
+    // acc <- composition of `acc` (earlier positions) and `nx` (the next position)
+    auto fold = [&](PostSummary<T, D>& acc, PostSummary<T, D>& nx) {
+        if constexpr (SUFFIX) post_combine<T, D>(nx, acc, bad);            // nx is on the left: the result stays in acc
+        else { post_combine<T, D>(acc, nx, bad); acc = nx; }               // acc is on the left: the result lands in nx
+    };
+    auto emit = [&](long p, const PostSummary<T, D>& run) {
+        const long j = chunk_of(p);
+        if constexpr (!SUFFIX) {
+            if ((j + 1) % k == 0 && (j + 1) / k < Pg) {
+                const long c = (j + 1) / k;
+                store_sym<T, D>(io.start_S + (s * Pg + c) * D * D, run.Dv);
+                store_vec<T, D>(io.start_m + (s * Pg + c) * D, run.tv);
+            }
+        } else {
+            if (j % k == 0 && j >= 1) {
+                const long c = j / k;
+                PostSummary<T, D> z;
+                MF_UNROLL for (int r = 0; r < D; ++r) {
+                    z.tv[r] = T(0); z.gU[r] = T(0);
+                    MF_UNROLL for (int cc = 0; cc < D; ++cc) { z.Dv[r][cc] = T(0); z.GU[r][cc] = T(0); z.F[r][cc] = T(0); }
+                }
+                post_combine<T, D>(run, z, bad);                            // the run's last block (block T-1) eliminated
+                store_sym<T, D>(io.bPsi + (s * Pg + c - 1) * D * D, z.GU);
+                store_vec<T, D>(io.bpsi + (s * Pg + c - 1) * D, z.gU);
+                T Lam[D][D], lam[D], Psi[D][D], m[D], S[D][D];
+                MF_UNROLL for (int r = 0; r < D; ++r) MF_UNROLL for (int cc = 0; cc < D; ++cc) { Lam[r][cc] = T(0); S[r][cc] = T(0); Psi[r][cc] = z.GU[r][cc]; }
+                load_lower<T, D>(io.start_S + (s * Pg + c) * D * D, Lam);
+                load_vec<T, D>(io.start_m + (s * Pg + c) * D, lam);
+                grad_marginal<T, D>(Lam, lam, Psi, z.gU, m, S, bad);
+                store_vec<T, D>(io.start_m + (s * Pg + c) * D, m);
+                store_sym<T, D>(io.start_S + (s * Pg + c) * D * D, S);
+            }
+        }
+    };
+    PostSummary<T, D> acc;
+    if (has) {
+        post_summary_load<T, D>(in, s * P + chunk_of(p0), acc);
+        for (long p = p0 + 1; p < p1; ++p) {
+            PostSummary<T, D> nx;
+            post_summary_load<T, D>(in, s * P + chunk_of(p), nx);
+            fold(acc, nx);
+        }
+    }
+    const int nl = (int)((P + q - 1) / q);
+    for (int off = 1; off < nl; off <<= 1) {
+        if (has) lds.put(acc);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (has && lane >= off) {
+            PostSummary<T, D> prev;
+            lds.get(lane - off, prev);
+            fold(prev, acc);                                              // prev: the earlier positions
+            if constexpr (SUFFIX) acc = prev;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (q == 1) {
+        if (has) emit(p0, acc);
+    } else {
+        if (has) lds.put(acc);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (has) {
+            PostSummary<T, D> run;
+            if (lane > 0) lds.get(lane - 1, run);
+            for (long p = p0; p < p1; ++p) {
+                PostSummary<T, D> nx;
+                post_summary_load<T, D>(in, s * P + chunk_of(p), nx);
+                if (lane > 0 || p > p0) fold(run, nx);
+                else run = nx;
+                emit(p, run);
+            }
+        }
+    }
+    if (bad && info) raise_info(info);
 }
 
 // ---- pass 5 -------------------------------------------------------------------------------------------------------------------
@@ -320,8 +425,21 @@ __global__ void __launch_bounds__(64) grad_lds_kernel(KfArgs<T> a, long L, GradI
     T mk[D], Sk[D][D], Rsh[M * M];
     MF_UNROLL for (int i = 0; i < M * M; ++i) Rsh[i] = RSTEP ? T(0) : a.Rinv[i];
     MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Sk[i][j] = T(0);
-    load_vec<T, D>(io.start_m + id * D, mk);
-    load_lower<T, D>(io.start_S + id * D * D, Sk);
+    if (io.mu0_post != nullptr && c == 0) {          // block 0: the posterior chain starts from its marginal
+        T G0[D][D];
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) G0[i][j] = T(0);
+        load_lower<T, D>(io.cp0_post + s * D * D, G0);
+        load_vec<T, D>(io.mu0_post + s * D, mk);
+        MF_UNROLL for (int i = 0; i < D; ++i)
+            MF_UNROLL for (int j = 0; j <= i; ++j) {
+                T acc = T(0);
+                MF_UNROLL for (int l = 0; l <= j; ++l) acc += G0[i][l] * G0[j][l];
+                Sk[i][j] = acc;
+            }
+    } else {
+        load_vec<T, D>(io.start_m + id * D, mk);
+        load_lower<T, D>(io.start_S + id * D * D, Sk);
+    }
     if (valid && c == 0) {
         T C0[D][D], mu0[D], gmu0[D], gC0[D][D];
         MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) C0[i][j] = T(0);

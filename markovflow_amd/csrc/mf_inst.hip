@@ -393,6 +393,16 @@ int kf_loglik(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A,
     return reduce_levels<T>(lvl0, B, p, add_const, out, info, st);
 }
 
+template <typename T>
+int kf_loglik_plan(long B, long Tn, int m, int rinv_per_step, long chunks, int aligned16, int* path, long* P, long* L) {
+    if (B < 1 || Tn < 1 || m < 1 || m > ROW_MAXM) return -1;
+    const KfPlan pl = kf_plan<T>(B, Tn, m, rinv_per_step, chunks, aligned16 != 0);
+    *path = (int)pl.path;
+    *P = pl.P;
+    *L = pl.L;
+    return 0;
+}
+
 template <typename T> size_t btd_logdet_quad_ws(long B, long n, long chunks) {
     (void)chunks;
     long nn = n;
@@ -1413,6 +1423,7 @@ template <typename T> const OpsTable<T>* table() {
         &kf_loglik_ws<T>, &kf_loglik<T>, &btd_logdet_quad_ws<T>, &btd_logdet_quad<T>, &btd_cholesky_ws<T>, &btd_cholesky<T>,
         &btd_solve_ws<T>, &btd_solve<T>,    &btd_matvec<T>, &btd_logdet<T>,        &btd_diag_of_inverse_ws<T>, &btd_diag_of_inverse<T>, &ssm_marginal_covs<T>, &btd_udl_ws<T>, &btd_udl<T>,
         &ssm_precision<T>, &ssm_means_entry<T>, &block_matmul<T>, &gpr_loglik<T>, &sde_predict<T>, &kf_grad<T>, &kl_grad<T>, &posterior_chain<T>, &kl_value<T>, &marginals_grad<T>, &adjoint_ws<T>, &ssm_marginals_entry<T>, &kl_ws<T>, &marginals_ws<T>,
+        &kf_loglik_plan<T>,
     };
     return &t;
 }

@@ -66,6 +66,9 @@ template <typename T> struct OpsTable {
                          T* ocov, T* osub, void* ws, size_t ws_bytes, hipStream_t st);
     size_t (*kl_ws)(long B, long Tn);
     size_t (*marginals_ws)(long B, long n);
+    // the level-0 kernel and time partition kf_loglik chooses: path 2 = the streaming kernel (mf_kf_lds.hpp), whose summaries
+    // (P per series, L transitions each) sit at the start of the workspace
+    int (*kf_loglik_plan)(long B, long Tn, int m, int rinv_per_step, long chunks, int aligned16, int* path, long* P, long* L);
 };
 
 // streamed, time-partitioned posterior chain (mf_post_lds.hpp, instantiated by mf_post_inst.hip for d = 1 ... MF_MAX_D_POST)
@@ -76,6 +79,10 @@ template <typename T> struct PostOps {
                  const T* y, const T* Rinv, int rinv_per_step, T* a_post, T* mu0_post, T* b_post, T* cp0_post, T* cq_post,
                  void* ws, size_t ws_bytes, int* info, long chunks, hipEvent_t ev0, hipEvent_t ev1, hipStream_t st);
     int (*plan)(long B, long Tn, int m, int rinv_per_step, long chunks, long* P, long* L);   // the partition `chain` makes of `chunks`
+    // pass 3 alone on the partition (P, L), from boundary states the caller has put into the workspace (PostWs: bPsi, bpsi)
+    int (*emit)(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H,
+                const T* y, const T* Rinv, int rinv_per_step, T* a_post, T* mu0_post, T* b_post, T* cp0_post, T* cq_post,
+                void* ws, size_t ws_bytes, int* info, long P, long L, hipStream_t st);
 };
 constexpr int MF_MAX_D_POST = 6;
 
@@ -84,8 +91,8 @@ template <typename T> struct GradOps {
     size_t (*ws)(long B, long Tn, int m, int rinv_per_step, long chunks);      // 0: not this route's call
     int (*run)(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H,
                const T* y, const T* Rinv, int rinv_per_step, const T* weights, T* g_mu0, T* g_cholP0, T* g_A, T* g_b, T* g_cholQ,
-               T* g_H, T* g_y, T* g_Om, void* ws, size_t ws_bytes, int* info, long chunks, hipEvent_t ev0, hipEvent_t ev1,
-               hipStream_t st);
+               T* g_H, T* g_y, T* g_Om, void* ws, size_t ws_bytes, int* info, long chunks, const void* fwd_ws, long fwd_P,
+               long fwd_L, hipEvent_t ev0, hipEvent_t ev1, hipStream_t st);
 };
 
 constexpr int MF_MAX_D = 9;        // largest state dimension with a register-resident (lane per chunk) instantiation

@@ -60,16 +60,13 @@ template <typename T> size_t post_ws(long B, long Tn, int m, int per_step, long 
     return post_ws_for<T>(B, pl.P) + 256;
 }
 
+// passes 1-3 on the partition (P, L); from_bounds: the caller has filled the boundary states, pass 3 alone
 template <typename T>
-int post_chain(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H,
-               const T* y, const T* Rinv, int rinv_per_step, T* a_post, T* mu0_post, T* b_post, T* cp0_post, T* cq_post,
-               void* ws, size_t ws_bytes, int* info, long chunks, hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
-    if (B < 1 || Tn < 2 || !post_covers<T>(m, rinv_per_step)) return -101;
-    // LDS-DMA moves 16-byte units: the streamed tensors must be 16-byte aligned (torch allocations are)
-    if (((reinterpret_cast<size_t>(A) | reinterpret_cast<size_t>(cholQ)) & 15) != 0) return -101;
-    const PostPlan pl = post_plan<T>(B, Tn, m, rinv_per_step, chunks);
-    if (ws == nullptr || ws_bytes < post_ws_for<T>(B, pl.P)) return -21;
-    const long P = pl.P, L = pl.L;
+int post_launch(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H,
+                const T* y, const T* Rinv, int rinv_per_step, T* a_post, T* mu0_post, T* b_post, T* cp0_post, T* cq_post,
+                void* ws, size_t ws_bytes, int* info, long P, long L, bool from_bounds, hipEvent_t ev0, hipEvent_t ev1,
+                hipStream_t st) {
+    if (ws == nullptr || ws_bytes < post_ws_for<T>(B, P)) return -21;
     const PostWs<T, D> w = PostWs<T, D>::carve(ws, B, P);
     const RedSys<T> sum = w.sum;
     T* bPsi = w.bPsi;
@@ -85,7 +82,7 @@ int post_chain(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A
             static_assert(lds_emit <= 64 * 1024, "emit pass: LDS image + staging beyond the default dynamic-LDS limit");
             constexpr int scan_lds = PostScanLds<T, D>::BYTES;
             if (ev0) (void)hipEventRecord(ev0, st);
-            if (P > 1) {
+            if (P > 1 && !from_bounds) {
                 hipLaunchKernelGGL((post_lds_kernel<T, D, M, RS, 0>), grid, block, lds, st, a, L, sum, po);
                 hipLaunchKernelGGL((post_scan_kernel<T, D>), dim3((unsigned)B), block, scan_lds, st, sum, B, bPsi, bpsi,
                                    info);
@@ -103,6 +100,28 @@ int post_chain(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
+template <typename T>
+int post_chain(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H,
+               const T* y, const T* Rinv, int rinv_per_step, T* a_post, T* mu0_post, T* b_post, T* cp0_post, T* cq_post,
+               void* ws, size_t ws_bytes, int* info, long chunks, hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
+    if (B < 1 || Tn < 2 || !post_covers<T>(m, rinv_per_step)) return -101;
+    // LDS-DMA moves 16-byte units: the streamed tensors must be 16-byte aligned (torch allocations are)
+    if (((reinterpret_cast<size_t>(A) | reinterpret_cast<size_t>(cholQ)) & 15) != 0) return -101;
+    const PostPlan pl = post_plan<T>(B, Tn, m, rinv_per_step, chunks);
+    return post_launch<T>(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, a_post, mu0_post, b_post, cp0_post,
+                          cq_post, ws, ws_bytes, info, pl.P, pl.L, false, ev0, ev1, st);
+}
+
+template <typename T>
+int post_emit(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H,
+              const T* y, const T* Rinv, int rinv_per_step, T* a_post, T* mu0_post, T* b_post, T* cp0_post, T* cq_post, void* ws,
+              size_t ws_bytes, int* info, long P, long L, hipStream_t st) {
+    if (B < 1 || Tn < 2 || P < 1 || L < 1 || (P - 1) * L >= Tn - 1 || P * L < Tn - 1 || !post_covers<T>(m, rinv_per_step)) return -101;
+    if (((reinterpret_cast<size_t>(A) | reinterpret_cast<size_t>(cholQ)) & 15) != 0) return -101;
+    return post_launch<T>(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, a_post, mu0_post, b_post, cp0_post,
+                          cq_post, ws, ws_bytes, info, P, L, true, nullptr, nullptr, st);
+}
+
 template <typename T> int post_plan_of(long B, long Tn, int m, int per_step, long chunks, long* P, long* L) {
     if (B < 1 || Tn < 2 || !post_covers<T>(m, per_step)) return -101;
     const PostPlan pl = post_plan<T>(B, Tn, m, per_step, chunks);
@@ -112,7 +131,7 @@ template <typename T> int post_plan_of(long B, long Tn, int m, int per_step, lon
 }
 
 template <typename T> const PostOps<T>* table() {
-    static const PostOps<T> t = {&post_ws<T>, &post_chain<T>, &post_plan_of<T>};
+    static const PostOps<T> t = {&post_ws<T>, &post_chain<T>, &post_plan_of<T>, &post_emit<T>};
     return &t;
 }
 

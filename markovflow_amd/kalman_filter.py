@@ -12,6 +12,7 @@ over time is partitioned so that every SIMD of the chip has work
 information vector, and one backward UDUᵀ sweep that emits the posterior chain.
 """
 import abc
+import ctypes
 import math
 from typing import Optional
 
@@ -40,15 +41,19 @@ class _LogLikelihoodPerSeries(torch.autograd.Function):
         with torch.no_grad():
             kf = _RawFilter(StateSpaceModel(mu0, cp0, a_s, b_s, cq), EmissionModel(h), y, r_inv)
             kf._chunks = chunks
+            kf._keep_summaries = True
             out = kf._log_likelihood_per_series()
         ctx.save_for_backward(mu0, cp0, a_s, b_s, cq, h, y, r_inv)
+        # the chunk summaries the forward elimination left in its workspace: the streamed backward starts from them
+        ctx.fwd_summaries = kf._summaries
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         mu0, cp0, a_s, b_s, cq, h, y, r_inv = ctx.saved_tensors
         with torch.no_grad():
-            streamed = _streamed_backward(mu0, cp0, a_s, b_s, cq, h, y, r_inv, grad_out)
+            streamed = _streamed_backward(mu0, cp0, a_s, b_s, cq, h, y, r_inv, grad_out, fwd=ctx.fwd_summaries)
+            ctx.fwd_summaries = None
             if streamed is not None:
                 return streamed + (None,)
             kf = _RawFilter(StateSpaceModel(mu0, cp0, a_s, b_s, cq), EmissionModel(h), y, r_inv)
@@ -82,14 +87,20 @@ class _LogLikelihoodPerSeries(torch.autograd.Function):
 
 # few, long series (the condition under which posterior_state_space_model streams, below): the backward as five streamed passes
 _GRAD_STREAMED = True
+_GRAD_STREAMED_MAX_SERIES = int(__import__("os").environ.get("MF_GRAD_STREAMED_MAX_SERIES", "2048"))   # (experiment knob)
 _grad_prof_events = (None, None)     # optional hipEvent_t pair recorded around the kernels of the streamed backward (bench.py)
 
 
-def _streamed_backward(mu0, cp0, a_s, b_s, cq, h, y, r_inv, grad_out, chunks=0):
+_GRAD_FROM_FORWARD = True            # start the streamed backward from the forward evaluation's chunk summaries when it left any
+
+
+def _streamed_backward(mu0, cp0, a_s, b_s, cq, h, y, r_inv, grad_out, chunks=0, fwd=None):
     """``mf_kf_loglik_grad_streamed_*`` (csrc/mf_grad_lds.hpp): the smoothed marginals stay in registers.  ``None`` when the call
-    is not that route's (many series, short chains, d > 6, m > 3, unaligned views): the caller keeps the three-kernel route."""
+    is not that route's (short chains, d > 6, m > 3, unaligned views): the caller keeps the three-kernel route.
+    ``fwd = (workspace, chunks per series, chunk length)`` of the forward ``mf_kf_loglik`` call on the same tensors, if its
+    level-0 kernel was the streaming one: its chunk summaries replace the backward's own first two passes."""
     bsz, n, m, d = h.shape
-    if not _GRAD_STREAMED or bsz < 1 or bsz >= BaseKalmanFilter._POST_FUSED_MIN_SERIES or n <= 64:
+    if not _GRAD_STREAMED or bsz < 1 or bsz >= _GRAD_STREAMED_MAX_SERIES or n <= 64:
         return None
     per_step = r_inv.dim() > 2
     lib = _lib.load()
@@ -107,9 +118,11 @@ def _streamed_backward(mu0, cp0, a_s, b_s, cq, h, y, r_inv, grad_out, chunks=0):
     info = _lib.pivot_info(h.device)
     w = grad_out.reshape(bsz).contiguous()
     ev0, ev1 = _grad_prof_events
+    fwd_ws, fwd_p, fwd_l = fwd if (fwd is not None and _GRAD_FROM_FORWARD) else (None, 0, 0)
     rc = _lib.call_rc("mf_kf_loglik_grad_streamed", h.dtype, bsz, n, d, m, *[_lib.ptr(t) for t in tensors], int(per_step),
                       _lib.ptr(w), _lib.ptr(g_mu0), _lib.ptr(g_cp0), _lib.ptr(g_a), _lib.ptr(g_b), _lib.ptr(g_cq), _lib.ptr(g_h),
-                      _lib.ptr(g_y), _lib.ptr(g_om), _lib.ptr(ws), ws_bytes, info, chunks, ev0, ev1, _lib.stream_ptr(h.device))
+                      _lib.ptr(g_y), _lib.ptr(g_om), _lib.ptr(ws), ws_bytes, info, chunks, _lib.ptr(fwd_ws), fwd_p, fwd_l,
+                      ev0, ev1, _lib.stream_ptr(h.device))
     if rc == -101:
         return None
     _lib.check(rc, "mf_kf_loglik_grad_streamed")
@@ -186,6 +199,8 @@ class BaseKalmanFilter(abc.ABC):
     # tuning / measurement hooks (not part of the reference API): time partitions per series (0 = automatic) and
     # an optional pair of hipEvent_t handles recorded around the dominant kernel (used by bench.py)
     _chunks = 0
+    _keep_summaries = False
+    _summaries = None
     _prof_events = (None, None)
     _post_prof_events = (None, None)     # hipEvent_t pair around the kernels of posterior_state_space_model (bench.py)
 
@@ -324,6 +339,14 @@ class BaseKalmanFilter(abc.ABC):
                   0.0, _lib.ptr(out), _lib.ptr(ws), ws_bytes, info, self._chunks, self._prof_events[0],
                   self._prof_events[1], _lib.stream_ptr(a_s.device))
         _lib.raise_on_info(info, "KalmanFilter.log_likelihood", a_s.device)
+        if self._keep_summaries:
+            # (asked for by the autograd function: which level-0 kernel ran, on which time partition; its summaries are the first
+            # thing in the workspace, which therefore stays alive until the backward)
+            path, p_f, l_f = ctypes.c_int(0), ctypes.c_int64(0), ctypes.c_int64(0)
+            aligned = int((a_s.data_ptr() | cq.data_ptr()) % 16 == 0)
+            rc = lib.mf_kf_loglik_plan(bsz, n, d, m, int(per_step), esz, self._chunks, aligned, ctypes.byref(path),
+                                       ctypes.byref(p_f), ctypes.byref(l_f))
+            self._summaries = (ws, int(p_f.value), int(l_f.value)) if (rc == 0 and path.value == 2 and p_f.value >= 2) else None
         return out
 
     def _per_series(self):

@@ -19,18 +19,34 @@ pytestmark = pytest.mark.gpu
 NAMES = ("mu0", "cholP0", "A", "b", "cholQ", "H", "y", "Omega")
 
 
-def grad_streamed_abi(kw, r_inv, w, chunks, dtype=torch.float64, per_step=False):
-    """Call mf_kf_loglik_grad_streamed directly; the eight gradient tensors as numpy arrays."""
+def grad_streamed_abi(kw, r_inv, w, chunks, dtype=torch.float64, per_step=False, fwd_chunks=None):
+    """Call mf_kf_loglik_grad_streamed directly; the eight gradient tensors as numpy arrays.  fwd_chunks (0 = automatic): evaluate
+    mf_kf_loglik first, on that many chunks per series, and hand its workspace (the chunk summaries) to the backward."""
+    import ctypes
     ins = [tt(kw[k], dtype) for k in ("mu0", "chol_p0", "a_s", "b_s", "chol_q", "h", "y")] + [tt(r_inv, dtype)]
     bsz, t, m, d = ins[5].shape
     lib = _lib.load()
+    fwd = (None, 0, 0)
+    if fwd_chunks is not None:
+        esz = ins[0].element_size()
+        fws = torch.empty(int(lib.mf_kf_loglik_workspace_bytes(bsz, t, d, esz, fwd_chunks)), dtype=torch.uint8, device=DEV)
+        val = torch.empty(bsz, dtype=dtype, device=DEV)
+        finfo = _lib.new_info(torch.device(DEV))
+        _lib.call("mf_kf_loglik", dtype, bsz, t, d, m, *[_lib.ptr(x) for x in ins], int(per_step), 0.0, _lib.ptr(val), _lib.ptr(fws),
+                  fws.numel(), _lib.ptr(finfo), fwd_chunks, None, None, _lib.stream_ptr(torch.device(DEV)))
+        path, p_f, l_f = ctypes.c_int(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        assert lib.mf_kf_loglik_plan(bsz, t, d, m, int(per_step), esz, fwd_chunks, 1, ctypes.byref(path), ctypes.byref(p_f),
+                                     ctypes.byref(l_f)) == 0
+        assert path.value == 2 and p_f.value >= 2, "the forward should have taken the streaming kernel on several chunks"
+        fwd = (fws, int(p_f.value), int(l_f.value))
     wsb = int(lib.mf_kf_loglik_grad_streamed_workspace_bytes(bsz, t, d, m, int(per_step), ins[0].element_size(), chunks))
     assert wsb > 0, "the streamed kernels should cover this call"
     ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
     outs = [torch.full_like(x, float("nan")) for x in ins[:7]] + [torch.full((bsz, t, m, m), float("nan"), dtype=dtype, device=DEV)]
     info = _lib.new_info(torch.device(DEV))
     _lib.call("mf_kf_loglik_grad_streamed", dtype, bsz, t, d, m, *[_lib.ptr(x) for x in ins], int(per_step), _lib.ptr(tt(w, dtype)),
-              *[_lib.ptr(x) for x in outs], _lib.ptr(ws), wsb, _lib.ptr(info), chunks, None, None, _lib.stream_ptr(torch.device(DEV)))
+              *[_lib.ptr(x) for x in outs], _lib.ptr(ws), wsb, _lib.ptr(info), chunks, _lib.ptr(fwd[0]), fwd[1], fwd[2], None, None,
+              _lib.stream_ptr(torch.device(DEV)))
     torch.cuda.synchronize()
     assert int(info.item()) == 0
     return [nn(x) for x in outs]
@@ -72,6 +88,31 @@ def test_streamed_backward_against_dense_autograd(rng, d, m, t, bsz, chunks, per
         r_inv = np.linalg.inv(r @ r.T + np.eye(m))
     w = rng.uniform(0.5, 1.5, size=bsz)
     got = grad_streamed_abi(kw, r_inv, w, chunks, per_step=per_step)
+    want, want_r = dense_autograd(kw, r_inv, w, per_step)
+    for name, g, ref in zip(NAMES[:7], got[:7], want):
+        assert np.all(np.isfinite(g)), name
+        np.testing.assert_allclose(g, ref, rtol=1e-6, atol=1e-8 * (1 + np.abs(ref).max()), err_msg=name)
+    got_r = precision_gradient(got[7], r_inv, w, t, per_step)
+    np.testing.assert_allclose(got_r, want_r, rtol=1e-6, atol=1e-8 * (1 + np.abs(want_r).max()), err_msg="R^-1")
+
+
+# the same gradients from the FORWARD evaluation's chunk summaries (three passes instead of five): the backward's chunks are groups
+# of the forward's - one group per chunk, several, ragged last groups, more than 64 forward chunks per series
+@pytest.mark.parametrize("d,m,t,bsz,chunks,fwd_chunks,per_step", [
+    (6, 1, 100, 3, 0, 0, False), (6, 1, 101, 2, 5, 12, False), (6, 1, 64, 2, 2, 2, False), (6, 1, 150, 1, 7, 70, False),
+    (6, 2, 90, 2, 4, 9, False), (6, 3, 70, 2, 5, 5, False), (6, 1, 57, 3, 4, 11, True), (4, 1, 120, 3, 0, 0, False),
+    (4, 2, 37, 2, 3, 7, False), (2, 1, 50, 70, 0, 0, False), (1, 1, 40, 3, 5, 10, False), (3, 1, 130, 2, 3, 100, False),
+    (5, 1, 129, 2, 11, 33, False), (5, 3, 45, 2, 2, 6, False), (6, 1, 3, 70, 2, 2, False),
+])
+def test_streamed_backward_from_the_forward_summaries(rng, d, m, t, bsz, chunks, fwd_chunks, per_step):
+    kw = random_ssm(rng, (bsz,), t, d, m, well=True)
+    if per_step:
+        r_inv = rng.uniform(0.5, 2.0, size=(bsz, t, m, m))
+    else:
+        r = rng.normal(size=(m, m))
+        r_inv = np.linalg.inv(r @ r.T + np.eye(m))
+    w = rng.uniform(0.5, 1.5, size=bsz)
+    got = grad_streamed_abi(kw, r_inv, w, chunks, per_step=per_step, fwd_chunks=fwd_chunks)
     want, want_r = dense_autograd(kw, r_inv, w, per_step)
     for name, g, ref in zip(NAMES[:7], got[:7], want):
         assert np.all(np.isfinite(g)), name
