@@ -342,8 +342,8 @@ def smoother_and_backward(kf, inputs, bsz, tn, d, m, esz):
     out["posterior_TGT"] = {
         "ms": ms, "kernels_ms": sum(kern) / len(kern), "algorithmic_GBps": b_post / ms / 1e6,
         "frac_of_hbm_peak": b_post / ms / 1e6 / HBM_PEAK_GBS,
-        "kernels": "mf::post_lds_kernel<EMIT=false> (reversed elimination per chunk) + mf::post_scan_kernel + "
-                   "mf::post_lds_kernel<EMIT=true>; round 3: mf_ssm_precision + parallel-in-time U D U^T + affine scan, 11.2 ms",
+        "kernels": "mf::post_lds_kernel<MODE=0> (reversed elimination per chunk) + mf::post_scan_kernel + "
+                   "mf::post_lds_kernel<MODE=1>; round 3: mf_ssm_precision + parallel-in-time U D U^T + affine scan, 11.2 ms",
         "note": f"KalmanFilter.posterior_state_space_model B={bsz} T={tn} d={d} m={m}: all five tensors of the posterior chain"}
     p = kf.prior_ssm
     leaves = [t.detach().clone().requires_grad_(True) for t in (p.initial_mean, p.cholesky_initial_covariance, p.state_transitions,
@@ -361,11 +361,24 @@ def smoother_and_backward(kf, inputs, bsz, tn, d, m, esz):
             fwd.append(e0.elapsed_time(e1)); bwd.append(e1.elapsed_time(e2))
     b_bwd = bsz * tn * (4 * d * d + 2 * d + 2 * m * d + 2 * m) * esz
     f_ms, b_ms = sorted(fwd)[len(fwd) // 2], sorted(bwd)[len(bwd) // 2]
+    # the kernels of the backward alone (hipEvents recorded by the library around them)
+    from markovflow_amd import kalman_filter as kfm
+    evg = HipEvents()
+    kfm._grad_prof_events = (evg.start, evg.stop)
+    kern = []
+    for _ in range(3):
+        for x in leaves:
+            x.grad = None
+        kfg.log_likelihood().backward()
+        kern.append(evg.elapsed_ms())
+    kfm._grad_prof_events = (None, None)
     out["loglik_backward_TGT"] = {
-        "forward_ms": f_ms, "backward_ms": b_ms, "backward_over_forward": b_ms / f_ms,
+        "forward_ms": f_ms, "backward_ms": b_ms, "backward_kernels_ms": sum(kern) / len(kern), "backward_over_forward": b_ms / f_ms,
         "backward_algorithmic_GBps": b_bwd / b_ms / 1e6, "backward_frac_of_hbm_peak": b_bwd / b_ms / 1e6 / HBM_PEAK_GBS,
-        "note": "KalmanFilter.log_likelihood().backward() w.r.t. mu0, cholP0, A, b, cholQ (Fisher's identity: streamed posterior "
-                "chain -> smoothed moments -> local closed forms); round 3: 21.8 ms"}
+        "kernels": "mf::k0_scan_kernel x2 (compositions of the forward evaluation's chunk summaries) + mf::post_lds_kernel<MODE=2> "
+                   "(emit pass: chol(Q'), b') + mf::grad_lds_kernel (forward pass, smoothed marginals in registers)",
+        "note": "KalmanFilter.log_likelihood().backward() w.r.t. mu0, cholP0, A, b, cholQ (Fisher's identity, streamed: "
+                "csrc/mf_grad_lds.hpp); round 3: 21.8 ms, start of round 4: 17.1 ms"}
     return out
 
 
