@@ -74,8 +74,8 @@ template <typename T> struct GradWs {
     GradWs(long B, long Tn, long P) {
         const size_t nt = size_t(Tn - 1);
         post = align_up(PostWs<T, D>::bytes(B, P) + 256);
-        chainA = align_up(size_t(B) * nt * D * D * sizeof(T));
-        chainb = align_up(size_t(B) * nt * D * sizeof(T));
+        chainA = align_up(size_t(B) * nt * PostLds<T, D, 1, false>::REC);      // the chain as packed records
+        chainb = 0;
         start_m = align_up(size_t(B) * P * D * sizeof(T));
         start_S = align_up(size_t(B) * P * D * D * sizeof(T));
         total = post + chainA + chainb + align_up(size_t(B) * D * sizeof(T)) + align_up(size_t(B) * D * D * sizeof(T)) + start_m + start_S;
@@ -113,15 +113,14 @@ int grad_run(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, 
     if (ws == nullptr || ws_bytes < lay.total) return -21;
     char* p = static_cast<char*>(ws);
     void* post_ws = p; p += lay.post;
-    T* cq_post = reinterpret_cast<T*>(p); p += lay.chainA;
-    T* b_post = reinterpret_cast<T*>(p); p += lay.chainb;
+    T* rec_post = reinterpret_cast<T*>(p); p += lay.chainA;
     T* mu0_post = reinterpret_cast<T*>(p); p += align_up(size_t(B) * D * sizeof(T));
     T* cp0_post = reinterpret_cast<T*>(p); p += align_up(size_t(B) * D * D * sizeof(T));
     T* start_m = reinterpret_cast<T*>(p); p += lay.start_m;
     T* start_S = reinterpret_cast<T*>(p);
     const PostWs<T, D> w = PostWs<T, D>::carve(post_ws, B, P);
     KfArgs<T> a{B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, info, 0, weights};
-    const GradIo<T> io{cq_post, b_post, w.bPsi, w.bpsi, start_m, start_S, from_fwd ? mu0_post : nullptr,
+    const GradIo<T> io{rec_post, w.bPsi, w.bpsi, start_m, start_S, from_fwd ? mu0_post : nullptr,
                        from_fwd ? cp0_post : nullptr, g_mu0, g_cholP0, g_A, g_b, g_cholQ, g_H, g_y, g_Om};
     const dim3 grid((unsigned)cdiv(B * P, 64)), block(64);
     constexpr int scan_lds = PostScanLds<T, D>::BYTES;
@@ -140,13 +139,13 @@ int grad_run(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, 
         }
         hipLaunchKernelGGL((k0_scan_kernel<T, D, false>), dim3((unsigned)B), block, scan_lds, st, k0, k, P, io, info);
         hipLaunchKernelGGL((k0_scan_kernel<T, D, true>), dim3((unsigned)B), block, scan_lds, st, k0, k, P, io, info);
-        const int rc = post_ops<T>()->emit(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, nullptr, mu0_post, b_post,
-                                           cp0_post, cq_post, post_ws, lay.post, info, P, L, st);
+        const int rc = post_ops<T>()->emit(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, nullptr, mu0_post, nullptr,
+                                           cp0_post, rec_post, post_ws, lay.post, info, P, L, st);
         if (rc != 0) return rc;
     } else {
         // passes 1-3: the posterior chain (without its transitions) on P chunks
-        const int rc = post_ops<T>()->chain(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, nullptr, mu0_post, b_post,
-                                            cp0_post, cq_post, post_ws, lay.post, info, P, nullptr, nullptr, st);
+        const int rc = post_ops<T>()->chain(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, nullptr, mu0_post, nullptr,
+                                            cp0_post, rec_post, post_ws, lay.post, info, P, nullptr, nullptr, st);
         if (rc != 0) return rc;
     }
     auto launch = [&](auto mtag, auto rtag) {

@@ -12,7 +12,7 @@
 // Against the route it replaces (posterior chain -> marginal means and covariances by two scans in time -> one lane per (series,
 // time point) reading them back) the moments (2 d^2 + d values per step, written and read) never exist in HBM, and the
 // transitions A' of the posterior chain are not read: A' = Q' Q^-1 A costs two triangular products.
-// LDS: the image of one step (~55 KB at d = 6 fp64) + staging -> two wavefronts per CU.
+// LDS: the image of one step (~54 KB at d = 6 fp64) + the record's offset table + staging -> two wavefronts per CU.
 #pragma once
 #include "mf_grad_math.hpp"
 #include "mf_post_lds.hpp"
@@ -20,7 +20,7 @@
 namespace mf {
 
 template <typename T> struct GradIo {
-    const T* cq_post; const T* b_post;                // the posterior chain (pass 3)
+    const void* rec_post;                             // the posterior chain (pass 3): packed records [chol(Q') | b'], PostLds::REC bytes each
     T* bPsi; T* bpsi;                                 // boundary states per consumer chunk (pass 2, or k0_scan_kernel)
     T* start_m; T* start_S;                           // [B, P, D], [B, P, D, D] (pass 4 -> pass 5)
     const T* mu0_post; const T* cp0_post;             // non-NULL: block 0's marginal is the chain's (mu0', cholP0' cholP0'^T)
@@ -231,13 +231,21 @@ template <typename T, int D, int M, bool RSTEP> struct GradLds {
     static constexpr int BH = M * D * S;                                           // a row of d/dH
     static constexpr int unit_h() { for (int u = 16; u > 4; u /= 2) if (BH % u == 0) return u; return 4; }
     static constexpr int UNITH = unit_h(), UH = BH / UNITH;
-    static constexpr int OFF_G = ((Cfg::LDS_TOTAL + 15) / 16) * 16;               // chol(Q') of the step: the units of cholQ's stream
-    static constexpr int OFF_bp = OFF_G + Cfg::StC::LDS_BYTES;
-    static constexpr int OFF_stageM = OFF_bp + Cfg::Stb::LDS_BYTES;
-    static constexpr int OFF_stagev = OFF_stageM + 64 * B0;
-    static constexpr int OFF_len = OFF_stagev + ((64 * (Bv > BH ? Bv : BH) + 15) / 16) * 16;
+    // the chain's record of the step (PostLds: REC bytes = [chol(Q') lower, row-major | b' | pad]) and, per lane, the source offsets
+    // of its DMA instructions - in LDS, not in registers (the step has none to spare): 16 slots of 4 B
+    using StP = Stream<PL::REC, KeepAll>;
+    static constexpr int NG = PL::NG;
+    static_assert(StP::NI <= 16, "record: at most 16 DMA instructions per step");
+    static constexpr int OFF_P = ((Cfg::LDS_TOTAL + 15) / 16) * 16;
+    static constexpr int OFF_voP = OFF_P + StP::LDS_BYTES;
+    static constexpr int OFF_relP = OFF_voP + 64 * 64;
+    static constexpr int OFF_stageM = OFF_relP + 256;
+    // (ONE staging buffer: the pieces are staged and stored in bursts, one after the other)
+    static constexpr int OFF_stagev = OFF_stageM;
+    static constexpr int STAGE = 64 * (B0 > BH ? (B0 > Bv ? B0 : Bv) : (BH > Bv ? BH : Bv));
+    static constexpr int OFF_len = OFF_stageM + ((STAGE + 15) / 16) * 16;
     static constexpr int TOTAL = OFF_len + 256;
-    static constexpr int N_DMA = Cfg::StA::NI + 2 * Cfg::StC::NI + 2 * Cfg::Stb::NI + Cfg::StH::NI + Cfg::Sty::NI + (RSTEP ? Cfg::StR::NI : 0);
+    static constexpr int N_DMA = Cfg::StA::NI + Cfg::StC::NI + StP::NI + Cfg::Stb::NI + Cfg::StH::NI + Cfg::Sty::NI + (RSTEP ? Cfg::StR::NI : 0);
     static constexpr bool SUPPORTED = Cfg::SUPPORTED && N_DMA < 64 && TOTAL <= 80 * 1024;
 };
 
@@ -249,18 +257,30 @@ template <typename T, int D, int M, bool RSTEP> struct GradPump {
     const DmaStream<typename Cfg::StA>& dA; const DmaStream<typename Cfg::StC>& dC;
     const DmaStream<typename Cfg::Stb>& db; const DmaStream<typename Cfg::StH>& dH;
     const DmaStream<typename Cfg::Sty>& dy; const DmaStream<typename Cfg::StR>& dR;
-    mf_v4i sA, sC, sb, sH, sy, sR, sG, sbp;
+    mf_v4i sA, sC, sb, sH, sy, sR, sP;
     unsigned lds0;
     bool more, yfetch;
+    const char* votab;                                  // this lane's 16 record offsets (LDS)
     MF_DEV void all() const {
         dC.template issue<0, 64>(sC, lds0 + Cfg::OFF_C);
-        dC.template issue<0, 64>(sG, lds0 + GL::OFF_G);
+        issue_record<0>();
         db.template issue<0, 64>(sb, lds0 + Cfg::OFF_b);
-        db.template issue<0, 64>(sbp, lds0 + GL::OFF_bp);
         dH.template issue<0, 64>(sH, lds0 + Cfg::OFF_H);
         dy.template issue<0, 64>(sy, lds0 + Cfg::OFF_y);
         if (RSTEP) dR.template issue<0, 64>(sR, lds0 + Cfg::OFF_R);
         dA.template issue<0, 64>(sA, lds0 + Cfg::OFF_A);
+    }
+    // the record's DMA instructions, four per group; their source offsets come from the lane's LDS table
+    template <int I0> MF_DEV void issue_record() const {
+        constexpr int NI = GL::StP::NI;
+        if constexpr (I0 < NI) {
+            constexpr int N = (NI - I0) < 4 ? (NI - I0) : 4;
+            const mf_v4i o = *reinterpret_cast<const mf_v4i*>(votab + I0 * 4);
+            unsigned voff[N];
+            MF_UNROLL for (int k = 0; k < N; ++k) voff[k] = (unsigned)o[k];
+            dma_b128_group<(GL::StP::UG >= 8), N>(sP, lds0 + GL::OFF_P + I0 * 1024, voff);
+            issue_record<I0 + N>();
+        }
     }
     template <int K> MF_DEV void site() const {
         asm volatile("" ::: "memory");                  // the image changes behind the compiler's back: no LDS value survives a site
@@ -275,12 +295,11 @@ template <typename T, int D, int M, bool RSTEP> struct GradPump {
         if constexpr (K == 3) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the last reads of A, b, b' have their data
             db.template issue<0, 64>(sb, lds0 + Cfg::OFF_b);
-            db.template issue<0, 64>(sbp, lds0 + GL::OFF_bp);
             dA.template issue<0, Q>(sA, lds0 + Cfg::OFF_A);
         }
         if constexpr (K == 4) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // ... and the last read of G
-            dC.template issue<0, 64>(sG, lds0 + GL::OFF_G);
+            issue_record<0>();
             dA.template issue<Q, 2 * Q>(sA, lds0 + Cfg::OFF_A);
         }
         if constexpr (K == 5) dA.template issue<2 * Q, 3 * Q>(sA, lds0 + Cfg::OFF_A);
@@ -384,6 +403,8 @@ __global__ void __launch_bounds__(64) grad_lds_kernel(KfArgs<T> a, long L, GradI
     const unsigned long long offR = (unsigned long long)(s * a.Tn + tau0) * (M * M * S);
     const unsigned long long offA0 = uniform64(offA), offb0 = uniform64(offb);
     const unsigned long long offH0 = uniform64(offH), offy0 = uniform64(offy), offR0 = uniform64(offR);
+    constexpr int REC = GL::PL::REC;
+    const unsigned long long offP = (unsigned long long)(s * nt + tau0) * REC, offP0 = uniform64(offP);
     const bool rowok = valid && len > 0;
     {
         unsigned* tab = reinterpret_cast<unsigned*>(smem);
@@ -393,6 +414,7 @@ __global__ void __launch_bounds__(64) grad_lds_kernel(KfArgs<T> a, long L, GradI
         tab[Cfg::OFF_rely / 4 + lane] = rowok ? (unsigned)(offy - offy0) : MF_DMA_INVALID;
         tab[Cfg::OFF_relR / 4 + lane] = rowok ? (unsigned)(offR - offR0) : MF_DMA_INVALID;
         reinterpret_cast<int*>(smem)[GL::OFF_len / 4 + lane] = rowok ? (int)len : 0;
+        tab[GL::OFF_relP / 4 + lane] = rowok ? (unsigned)(offP - offP0) : MF_DMA_INVALID;
         if (lane < Cfg::StC::U) {
             unsigned g = 0;
             MF_UNROLL for (int cc = 0; cc < Cfg::StC::U; ++cc) if (lane == cc) g = (unsigned)Cfg::StC::global_unit(cc);
@@ -409,12 +431,12 @@ __global__ void __launch_bounds__(64) grad_lds_kernel(KfArgs<T> a, long L, GradI
     const unsigned long long nH = (unsigned long long)a.B * a.Tn * (M * D * S), ny = (unsigned long long)a.B * a.Tn * (M * S);
     const unsigned long long nR = (unsigned long long)a.B * a.Tn * (M * M * S);
     unsigned long long pA = (unsigned long long)a.A + offA0, pC = (unsigned long long)a.cholQ + offA0;
-    unsigned long long pG = (unsigned long long)io.cq_post + offA0, pbp = (unsigned long long)io.b_post + offb0;
+    unsigned long long pP = (unsigned long long)io.rec_post + offP0;
     unsigned long long pb = (unsigned long long)a.b + offb0, pH = (unsigned long long)a.H + offH0;
     unsigned long long py = (unsigned long long)a.y + offy0;
     unsigned long long pR = (unsigned long long)a.Rinv + (RSTEP ? offR0 : 0ull);
     const unsigned long long eA = (unsigned long long)a.A + nA, eC = (unsigned long long)a.cholQ + nA;
-    const unsigned long long eG = (unsigned long long)io.cq_post + nA, ebp = (unsigned long long)io.b_post + nb;
+    const unsigned long long eP = (unsigned long long)io.rec_post + (unsigned long long)a.B * nt * REC;
     const unsigned long long eb = (unsigned long long)a.b + nb, eH = (unsigned long long)a.H + nH, ey = (unsigned long long)a.y + ny;
     const unsigned long long eR = (unsigned long long)a.Rinv + (RSTEP ? nR : 0ull);
     const unsigned lds0 = (unsigned)(size_t)smem;
@@ -467,6 +489,14 @@ __global__ void __launch_bounds__(64) grad_lds_kernel(KfArgs<T> a, long L, GradI
     dH.init(smem, lane, Cfg::OFF_relH, 0);
     dy.init(smem, lane, Cfg::OFF_rely, 0);
     if (RSTEP) dR.init(smem, lane, Cfg::OFF_relR, 0);
+    const char* votab = smem + GL::OFF_voP + lane * 64;
+    {
+        DmaStream<typename GL::StP> dP;
+        dP.init(smem, lane, GL::OFF_relP, 0);
+        unsigned* vt = reinterpret_cast<unsigned*>(smem + GL::OFF_voP + lane * 64);
+        MF_UNROLL for (int i = 0; i < 16; ++i) vt[i] = i < GL::StP::NI ? dP.vo[i] : MF_DMA_INVALID;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     Sink sink;
     sink.init(smem, lane, Cfg::OFF_relA, Cfg::OFF_relb, Cfg::OFF_relH);
     sink.fA = (unsigned long long)io.gA + nA; sink.fC = (unsigned long long)io.gC + nA;
@@ -479,23 +509,22 @@ __global__ void __launch_bounds__(64) grad_lds_kernel(KfArgs<T> a, long L, GradI
 
     const RowReader<T, typename Cfg::StA> rA(smem, Cfg::OFF_A, lane);
     const RowReader<T, typename Cfg::StC> rC(smem, Cfg::OFF_C, lane);
-    const RowReader<T, typename Cfg::StC> rG(smem, GL::OFF_G, lane);
+    const RowReader<T, typename GL::StP> rP(smem, GL::OFF_P, lane);
     const RowReader<T, typename Cfg::Stb> rb(smem, Cfg::OFF_b, lane);
-    const RowReader<T, typename Cfg::Stb> rbp(smem, GL::OFF_bp, lane);
     const RowReader<T, typename Cfg::StH> rH(smem, Cfg::OFF_H, lane);
     const RowReader<T, typename Cfg::Sty> ry(smem, Cfg::OFF_y, lane);
     const RowReader<T, typename Cfg::StR> rR(smem, Cfg::OFF_R, lane);
     using Pump = GradPump<T, D, M, RSTEP>;
     if (nsteps > 0) {
         const Pump p0{dA, dC, db, dH, dy, dR, make_srd(pA, eA), make_srd(pC, eC), make_srd(pb, eb), make_srd(pH, eH),
-                      make_srd(py, ey), make_srd(pR, eR), make_srd(pG, eG), make_srd(pbp, ebp), lds0, true, true};
+                      make_srd(py, ey), make_srd(pR, eR), make_srd(pP, eP), lds0, true, true, votab};
         p0.all();
     }
     for (long j = 0; j < nsteps; ++j) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const bool more = (j + 1 < nsteps);
         const bool yfetch = ((j + 1) % Cfg::YG) == 0;
-        pA += D * D * S; pC += D * D * S; pG += D * D * S; pb += D * S; pbp += D * S; pH += M * D * S;
+        pA += D * D * S; pC += D * D * S; pP += REC; pb += D * S; pH += M * D * S;
         if (RSTEP) pR += M * M * S;
         if (yfetch) py += Cfg::YG * M * S;
         T C[D][D], hk[M * D], yk[M];
@@ -506,14 +535,14 @@ __global__ void __launch_bounds__(64) grad_lds_kernel(KfArgs<T> a, long L, GradI
         if (RSTEP) { MF_UNROLL for (int i = 0; i < M * M; ++i) Rsh[i] = rR.at(i); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const Pump pump{dA, dC, db, dH, dy, dR, make_srd(pA, eA), make_srd(pC, eC), make_srd(pb, eb), make_srd(pH, eH),
-                        make_srd(py, ey), make_srd(pR, eR), make_srd(pG, eG), make_srd(pbp, ebp), lds0, more, yfetch};
+                        make_srd(py, ey), make_srd(pR, eR), make_srd(pP, eP), lds0, more, yfetch, votab};
         const bool active = j < len;
         sink.qA = qA; sink.qC = qC; sink.qb = qb; sink.qH = qH; sink.e = j;
         sink.gy = gy_lane; sink.gOm = gOm_lane;
         auto Aat = [&](int i, int jj) { return rA.at(i * D + jj); };
-        auto Gat = [&](int i, int jj) { return rG.at(i * D + jj); };
+        auto Gat = [&](int i, int jj) { return rP.at(i * (i + 1) / 2 + jj); };
         auto bqat = [&](int i) { return rb.at(i); };
-        auto bpat = [&](int i) { return rbp.at(i); };
+        auto bpat = [&](int i) { return rP.at(GL::NG + i); };
         grad_step<T, D, M>(mk, Sk, bad, C, hk, yk, Rsh, wgt, Aat, Gat, bqat, bpat, pump, sink, active);
         qA += D * D * S; qC += D * D * S; qb += D * S; qH += M * D * S;
         gy_lane += M; gOm_lane += M * M;

@@ -15,6 +15,8 @@
 // precision and factor written and re-read, ~6x the algorithmic traffic through per-lane row loads) the inputs are read
 // twice, coalesced, and every output once.
 #pragma once
+#include <type_traits>
+
 #include "mf_kf_lds.hpp"
 #include "mf_post_math.hpp"
 
@@ -105,10 +107,18 @@ template <typename T, int D, int M, bool RSTEP> struct PostLds {
     static constexpr int unit() { for (int u = 16; u > 4; u /= 2) if (B0 % u == 0 && B1 % u == 0 && Bv % u == 0) return u; return 4; }
     static constexpr int UNIT = unit();
     static constexpr int U0 = B0 / UNIT, U1 = B1 / UNIT, Uv = Bv / UNIT;          // store instructions per piece
+    // The chain as the streamed backward of log_likelihood reads it (MODE 2 of post_lds_kernel, mf_grad_lds.hpp): ONE record per
+    // transition, [chol(Q') lower triangle, row-major | b' | zeros up to a 16-B unit] - 224 B at d = 6 fp64 instead of rows of 288 + 48 B
+    // in two tensors: two or three lines touched per step instead of four or five.  Staged and stored in two pieces.
+    static constexpr int NG = D * (D + 1) / 2, NR = NG + D;                        // elements of the factor, of the record
+    static constexpr int REC = ((NR * S + 15) / 16) * 16, RU = REC / 16;           // bytes, 16-B units per record
+    static constexpr int RUa = (RU + 1) / 2, RUb = RU / 2, REa = RUa * 16 / S, REb = RUb * 16 / S;
     static constexpr int OFF_stageM = ((Cfg::LDS_TOTAL + 15) / 16) * 16;
     static constexpr int OFF_stagev = OFF_stageM + 64 * B0;
-    static constexpr int OFF_len = OFF_stagev + ((64 * Bv + 15) / 16) * 16;
-    static constexpr int TOTAL = OFF_len + 256;                     // one wavefront's image + staging
+    static constexpr int STAGE = (64 * B0 + ((64 * Bv + 15) / 16) * 16) > 64 * RUa * 16 ? (64 * B0 + ((64 * Bv + 15) / 16) * 16) : 64 * RUa * 16;
+    static constexpr int OFF_len = OFF_stageM + STAGE;
+    static constexpr int OFF_relP = OFF_len + 256;                   // row offsets of the records
+    static constexpr int TOTAL = OFF_relP + 256;                    // one wavefront's image + staging
 };
 
 // One staged piece: 64 rows x NU units in an LDS buffer; unit u of the image (u = 64 i + lane for store instruction i) is read
@@ -209,7 +219,7 @@ template <typename T, int D, int M, bool RSTEP, bool TRANS = true> struct PostSi
         sv = make_srd(qb, fb);
         Pv::stage(smem, PL::OFF_stagev, lane, mean, va);
     }
-    MF_DEV void stage_factor_rest(const T (&Gi)[D][D], bool) {
+    MF_DEV void stage_factor_rest(const T (&Gi)[D][D], const T (&)[D], bool) {
         if constexpr (U1 > 0) {
             T row[(D - H0) * D];
             MF_UNROLL for (int i = H0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) row[(i - H0) * D + j] = (j <= i) ? Gi[i][j] : T(0);
@@ -241,16 +251,84 @@ template <typename T, int D, int M, bool RSTEP, bool TRANS = true> struct PostSi
     }
 };
 
+// The sink of MODE 2: the packed records (PostLds: REC).  Piece A (the record's first RUa units) is staged when the factor
+// exists and stored during the window of the factor's first half, piece B with the rest of the factor; no transitions.
+template <typename T, int D, int M, bool RSTEP> struct PackedSink {
+    using PL = PostLds<T, D, M, RSTEP>;
+    static constexpr int RUa = PL::RUa, RUb = PL::RUb, REa = PL::REa, REb = PL::REb, NG = PL::NG, NR = PL::NR;
+    using W = typename OutWord<16>::type;
+    using PA = StagedPiece<T, RUa, 16>;
+    using PB = StagedPiece<T, (RUb > 0 ? RUb : 1), 16>;
+    char* smem; int lane;
+    DmaStream<OutPiece<RUa, 16>> da;
+    DmaStream<OutPiece<(RUb > 0 ? RUb : 1), 16>> db;
+    unsigned long long qR, fR;                     // this position's records; the end of the record array
+    unsigned long long qA, qC, qb, fA, fC, fb;     // (the members the kernel sets for either sink)
+    long e, minlen;
+    bool have_prev;
+    W ma, mb;
+    mf_v4i sM;
+
+    MF_DEV void init(char* smem_, int lane_, int, int) {
+        smem = smem_; lane = lane_;
+        da.init(smem, lane, PL::OFF_relP, 0);
+        if constexpr (RUb > 0) db.init(smem, lane, PL::OFF_relP, 0);
+        have_prev = false;
+    }
+    template <int SITE, int S0, int S1, int U, typename F> MF_DEV void window(F&& f) {
+        if constexpr (SITE >= S0 && SITE < S1 && U > 0) {
+            constexpr int i = SITE - S0, Wd = S1 - S0;
+            static_for<(i * U) / Wd, ((i + 1) * U) / Wd>(f);
+        }
+    }
+    template <int SITE> MF_DEV void tick(bool) {
+        constexpr int C0a = 9, C0b = 10 + 2 * D, C1a = C0b, C1b = 10 + 4 * D;
+        window<SITE, C0a, C0b, RUa>([&](auto ic) {
+            PA::template unit<decltype(ic)::value>(smem, PL::OFF_stageM, PL::OFF_len, lane, da.vo, sM, e < minlen, e, ma, mb);
+        });
+        if constexpr (RUb > 0)
+            window<SITE, C1a, C1b, RUb>([&](auto ic) {
+                PB::template unit<decltype(ic)::value>(smem, PL::OFF_stageM, PL::OFF_len, lane, db.vo, sM, e < minlen, e, ma, mb);
+            });
+    }
+    // element q of the record
+    static MF_DEV T element(int q, const T (&Gi)[D][D], const T (&mean)[D]) {
+        T v = T(0);
+        MF_UNROLL for (int i = 0; i < D; ++i) {
+            MF_UNROLL for (int j = 0; j <= i; ++j) if (q == i * (i + 1) / 2 + j) v = Gi[i][j];
+            if (q == NG + i) v = mean[i];
+        }
+        return v;
+    }
+    MF_DEV void stage_factor(const T (&Gi)[D][D], const T (&mean)[D], bool) {
+        T row[REa];
+        MF_UNROLL for (int q = 0; q < REa; ++q) row[q] = element(q, Gi, mean);
+        sM = make_srd(qR, fR);
+        PA::stage(smem, PL::OFF_stageM, lane, row, ma);
+    }
+    MF_DEV void stage_factor_rest(const T (&Gi)[D][D], const T (&mean)[D], bool) {
+        if constexpr (RUb > 0) {
+            T row[REb];
+            MF_UNROLL for (int q = 0; q < REb; ++q) row[q] = element(REa + q, Gi, mean);
+            sM = make_srd(qR + RUa * 16, fR);
+            PB::stage(smem, PL::OFF_stageM, lane, row, ma);
+        }
+    }
+    template <int HALF, int R> MF_DEV void stage_transition(const T (&)[R][D], bool) {}
+    MF_DEV void flush() {}
+};
+
 // Passes 1 and 3: one wavefront per workgroup = 64 (series, chunk) lanes.  KfArgs::P = chunks per series, L = transitions per
 // chunk.  Position e of a chunk = transition tau0 + e; the wave walks e = nsteps-1 ... 0 (a chunk shorter than the wave's
 // longest idles FIRST, so that all lanes end on their chunk's first transition and every DMA address is >= the tensor's start).
-// MODE: 0 = pass 1, 1 = pass 3, 2 = pass 3 without the transitions A' (po.a_post is not touched).
+// MODE: 0 = pass 1, 1 = pass 3, 2 = pass 3 for the streamed backward: no transitions, chol(Q') and b' as packed records
+// (PostLds::REC bytes per transition) at po.cq_post; po.a_post, po.b_post are not touched.
 template <typename T, int D, int M, bool RSTEP, int MODE>
 __global__ void __launch_bounds__(64) post_lds_kernel(KfArgs<T> a, long L, RedSys<T> out, PostOut<T> po) {
     constexpr bool EMIT = MODE != 0;
     using Cfg = KfLdsCfg<T, D, M, RSTEP>;
     using PL = PostLds<T, D, M, RSTEP>;
-    using Sink = PostSink<T, D, M, RSTEP, MODE != 2>;
+    using Sink = std::conditional_t<MODE == 2, PackedSink<T, D, M, RSTEP>, PostSink<T, D, M, RSTEP, true>>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const long total = a.B * a.P;
@@ -297,6 +375,7 @@ __global__ void __launch_bounds__(64) post_lds_kernel(KfArgs<T> a, long L, RedSy
         tab[Cfg::OFF_rely / 4 + lane] = rowok ? (unsigned)(offy - offy0) : MF_DMA_INVALID;
         tab[Cfg::OFF_relR / 4 + lane] = rowok ? (unsigned)(offR - offR0) : MF_DMA_INVALID;
         if (EMIT) reinterpret_cast<int*>(smem)[PL::OFF_len / 4 + lane] = rowok ? (int)len : 0;
+        if (MODE == 2) tab[PL::OFF_relP / 4 + lane] = rowok ? (unsigned)((offA - offA0) / (D * D * S) * PL::REC) : MF_DMA_INVALID;
         if (lane < Cfg::StC::U) {
             unsigned g = 0;
             MF_UNROLL for (int cc = 0; cc < Cfg::StC::U; ++cc) if (lane == cc) g = (unsigned)Cfg::StC::global_unit(cc);
@@ -378,6 +457,9 @@ __global__ void __launch_bounds__(64) post_lds_kernel(KfArgs<T> a, long L, RedSy
     const unsigned long long fC = (unsigned long long)po.cq_post + (unsigned long long)a.B * nt * (D * D * S);
     const unsigned long long fb = (unsigned long long)po.b_post + (unsigned long long)a.B * nt * (D * S);
     if (EMIT) { sink.fA = fA; sink.fC = fC; sink.fb = fb; sink.minlen = minlen; sink.e = 0; }
+    // MODE 2: po.cq_post is the record array [B, T-1, REC bytes]
+    unsigned long long qR = (unsigned long long)po.cq_post + offA0 / (D * D * S) * PL::REC + (unsigned long long)e_top * PL::REC;
+    if constexpr (MODE == 2) sink.fR = (unsigned long long)po.cq_post + (unsigned long long)a.B * nt * PL::REC;
 
 #define MF_POST_LDS_STEP(FIRST)                                                                                       \
     {                                                                                                                 \
@@ -403,6 +485,7 @@ __global__ void __launch_bounds__(64) post_lds_kernel(KfArgs<T> a, long L, RedSy
         const bool active = e < len;                                                                                  \
         if constexpr (EMIT) {                                                                                         \
             sink.qA = qA; sink.qC = qC; sink.qb = qb; sink.e = e;                                                     \
+            if constexpr (MODE == 2) { sink.qR = qR; qR -= PL::REC; }                                                 \
             qA -= D * D * S; qC -= D * D * S; qb -= D * S;                                                            \
             post_emit_step<T, D, M, MODE == 1>(E.Phi, E.t, E.bad, C, mvec, hk, yk, Rsh, Bm, pump, sink, active);                 \
         } else {                                                                                                      \

@@ -199,7 +199,7 @@ template <int I0, int I1, typename F> MF_HD void static_for(F&& f) {
 // chain at index t are handed to `sink` in pieces, as soon as they exist:
 //   sink.stage_factor(Gi, mean)      Gi = chol(Delta_{t+1}^-1) (-> cholQ'_t; the sink takes rows 0 .. D/2-1 now),
 //                                    mean = Delta_{t+1}^-1 x_{t+1} (-> b'_t)
-//   sink.stage_factor_rest(Gi)       rows D/2 .. D-1 of the same factor
+//   sink.stage_factor_rest(Gi, mean) rows D/2 .. D-1 of the same factor (a sink that packs factor and mean takes its second part)
 //   sink.stage_transition<HALF>(Ap)  rows [HALF D/2, ...) of A'_{t+1} = -Delta_{t+1}^-1 S_t (Ap holds these rows only)
 // Between the arithmetic the step calls sink.tick<SITE>() at EMIT_SITES places spaced ~25-35 multiply-adds apart: a device
 // sink issues ONE store instruction per tick (mf_post_lds.hpp: a SIMD's store path takes a 1-KB store per ~350 cycles under
@@ -295,7 +295,7 @@ MF_HD void post_emit_step(T (&Phi)[D][D], T (&t)[D], bool& bad, const T (&C)[D][
         }
         sink.template tick<10 + D + k>(active);
     });
-    sink.stage_factor_rest(Gi, active);
+    sink.stage_factor_rest(Gi, mean, active);
     // -S_t = Q^-1 A = C^-T B in place, top-down
     static_for<0, D>([&](auto ic) {
         constexpr int i = decltype(ic)::value;

@@ -19,7 +19,7 @@ template <typename T, int D> struct HostSink {
         for (int i = 0; i < H0; ++i) for (int j = 0; j < D; ++j) cq_post[k * D * D + i * D + j] = j <= i ? Gi[i][j] : T(0);
         store_vec<T, D>(b_post + k * D, mean);
     }
-    void stage_factor_rest(const T (&Gi)[D][D], bool) {
+    void stage_factor_rest(const T (&Gi)[D][D], const T (&)[D], bool) {
         for (int i = H0; i < D; ++i) for (int j = 0; j < D; ++j) cq_post[k * D * D + i * D + j] = j <= i ? Gi[i][j] : T(0);
     }
     template <int HALF, int R> void stage_transition(const T (&Ap)[R][D], bool) {
