@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 NAMES = ("mu0", "cholP0", "A", "b", "cholQ", "H", "y", "Omega")
 
 
-def grad_streamed_abi(kw, r_inv, w, chunks, dtype=torch.float64, per_step=False, fwd_chunks=None):
+def grad_streamed_abi(kw, r_inv, w, chunks, dtype=torch.float64, per_step=False, fwd_chunks=None, strict=True):
     """Call mf_kf_loglik_grad_streamed directly; the eight gradient tensors as numpy arrays.  fwd_chunks (0 = automatic): evaluate
     mf_kf_loglik first, on that many chunks per series, and hand its workspace (the chunk summaries) to the backward."""
     import ctypes
@@ -37,8 +37,10 @@ def grad_streamed_abi(kw, r_inv, w, chunks, dtype=torch.float64, per_step=False,
         path, p_f, l_f = ctypes.c_int(0), ctypes.c_int64(0), ctypes.c_int64(0)
         assert lib.mf_kf_loglik_plan(bsz, t, d, m, int(per_step), esz, fwd_chunks, 1, ctypes.byref(path), ctypes.byref(p_f),
                                      ctypes.byref(l_f)) == 0
-        assert path.value == 2 and p_f.value >= 2, "the forward should have taken the streaming kernel on several chunks"
-        fwd = (fws, int(p_f.value), int(l_f.value))
+        if strict:
+            assert path.value == 2 and p_f.value >= 2, "the forward should have taken the streaming kernel on several chunks"
+        if path.value == 2 and p_f.value >= 2:
+            fwd = (fws, int(p_f.value), int(l_f.value))
     wsb = int(lib.mf_kf_loglik_grad_streamed_workspace_bytes(bsz, t, d, m, int(per_step), ins[0].element_size(), chunks))
     assert wsb > 0, "the streamed kernels should cover this call"
     ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
