@@ -182,7 +182,7 @@ int mf_kf_loglik_total_f32(int64_t B, const float* per_series, int m, const floa
     return loglik_total<float>(B, per_series, m, chol_obs, num_points, extra_const, host_const, out, stream);
 }
 
-int mf_version(void) { return 6; }
+int mf_version(void) { return 7; }
 int mf_max_state_dim(void) { return mf::MF_MAX_D; }
 
 size_t mf_kf_loglik_workspace_bytes(int64_t B, int64_t T, int d, int elem_size, int64_t chunks) {
