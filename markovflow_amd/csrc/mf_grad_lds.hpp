@@ -224,8 +224,9 @@ __global__ void __launch_bounds__(64) k0_scan_kernel(RedSys<T> in, long k, long 
 
 // ---- pass 5 -------------------------------------------------------------------------------------------------------------------
 template <typename T, int D, int M, bool RSTEP> struct GradLds {
-    using Cfg = KfLdsCfg<T, D, M, RSTEP>;
-    using PL = PostLds<T, D, M, RSTEP>;
+    static constexpr int BG = backward_row_group(M);  // b and H rows are fetched in pairs (two wavefronts per CU: the LDS is there)
+    using Cfg = KfLdsCfg<T, D, M, RSTEP, BG>;
+    using PL = PostLds<T, D, M, RSTEP, BG>;
     static constexpr int S = (int)sizeof(T);
     static constexpr int H0 = PL::H0, B0 = PL::B0, B1 = PL::B1, Bv = PL::Bv, UNIT = PL::UNIT, U0 = PL::U0, U1 = PL::U1, Uv = PL::Uv;
     static constexpr int BH = M * D * S;                                           // a row of d/dH
@@ -259,7 +260,7 @@ template <typename T, int D, int M, bool RSTEP> struct GradPump {
     const DmaStream<typename Cfg::Sty>& dy; const DmaStream<typename Cfg::StR>& dR;
     mf_v4i sA, sC, sb, sH, sy, sR, sP;
     unsigned lds0;
-    bool more, yfetch;
+    bool more, yfetch, bfetch;
     const char* votab;                                  // this lane's 16 record offsets (LDS)
     MF_DEV void all() const {
         dC.template issue<0, 64>(sC, lds0 + Cfg::OFF_C);
@@ -288,13 +289,13 @@ template <typename T, int D, int M, bool RSTEP> struct GradPump {
         constexpr int Q = (Cfg::StA::NI + 3) / 4;
         if constexpr (K == 0) dC.template issue<0, 64>(sC, lds0 + Cfg::OFF_C);
         if constexpr (K == 1) {
-            dH.template issue<0, 64>(sH, lds0 + Cfg::OFF_H);
+            if (bfetch) dH.template issue<0, 64>(sH, lds0 + Cfg::OFF_H);
             if (yfetch) dy.template issue<0, 64>(sy, lds0 + Cfg::OFF_y);
             if (RSTEP) dR.template issue<0, 64>(sR, lds0 + Cfg::OFF_R);
         }
         if constexpr (K == 3) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the last reads of A, b, b' have their data
-            db.template issue<0, 64>(sb, lds0 + Cfg::OFF_b);
+            if (bfetch) db.template issue<0, 64>(sb, lds0 + Cfg::OFF_b);
             dA.template issue<0, Q>(sA, lds0 + Cfg::OFF_A);
         }
         if constexpr (K == 4) {
@@ -517,31 +518,35 @@ __global__ void __launch_bounds__(64) grad_lds_kernel(KfArgs<T> a, long L, GradI
     using Pump = GradPump<T, D, M, RSTEP>;
     if (nsteps > 0) {
         const Pump p0{dA, dC, db, dH, dy, dR, make_srd(pA, eA), make_srd(pC, eC), make_srd(pb, eb), make_srd(pH, eH),
-                      make_srd(py, ey), make_srd(pR, eR), make_srd(pP, eP), lds0, true, true, votab};
+                      make_srd(py, ey), make_srd(pR, eR), make_srd(pP, eP), lds0, true, true, true, votab};
         p0.all();
     }
     for (long j = 0; j < nsteps; ++j) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const bool more = (j + 1 < nsteps);
         const bool yfetch = ((j + 1) % Cfg::YG) == 0;
-        pA += D * D * S; pC += D * D * S; pP += REC; pb += D * S; pH += M * D * S;
+        constexpr int BG = GL::BG;
+        const bool bfetch = ((j + 1) % BG) == 0;
+        const int gb = (int)(j % BG);
+        pA += D * D * S; pC += D * D * S; pP += REC;
+        if (bfetch) { pb += BG * D * S; pH += BG * M * D * S; }
         if (RSTEP) pR += M * M * S;
         if (yfetch) py += Cfg::YG * M * S;
         T C[D][D], hk[M * D], yk[M];
         MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int jj = 0; jj <= i; ++jj) C[i][jj] = rC.at(i * D + jj);
-        MF_UNROLL for (int i = 0; i < M * D; ++i) hk[i] = rH.at(i);
+        MF_UNROLL for (int i = 0; i < M * D; ++i) hk[i] = *reinterpret_cast<const T*>(rH.row + (gb * M * D + i) * (int)sizeof(T));
         MF_UNROLL for (int i = 0; i < M; ++i)
             yk[i] = *reinterpret_cast<const T*>(ry.row + ((int)(j % Cfg::YG) * M + i) * (int)sizeof(T));
         if (RSTEP) { MF_UNROLL for (int i = 0; i < M * M; ++i) Rsh[i] = rR.at(i); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const Pump pump{dA, dC, db, dH, dy, dR, make_srd(pA, eA), make_srd(pC, eC), make_srd(pb, eb), make_srd(pH, eH),
-                        make_srd(py, ey), make_srd(pR, eR), make_srd(pP, eP), lds0, more, yfetch, votab};
+                        make_srd(py, ey), make_srd(pR, eR), make_srd(pP, eP), lds0, more, yfetch, bfetch, votab};
         const bool active = j < len;
         sink.qA = qA; sink.qC = qC; sink.qb = qb; sink.qH = qH; sink.e = j;
         sink.gy = gy_lane; sink.gOm = gOm_lane;
         auto Aat = [&](int i, int jj) { return rA.at(i * D + jj); };
         auto Gat = [&](int i, int jj) { return rP.at(i * (i + 1) / 2 + jj); };
-        auto bqat = [&](int i) { return rb.at(i); };
+        auto bqat = [&](int i) { return *reinterpret_cast<const T*>(rb.row + (gb * D + i) * (int)sizeof(T)); };
         auto bpat = [&](int i) { return rP.at(GL::NG + i); };
         grad_step<T, D, M>(mk, Sk, bad, C, hk, yk, Rsh, wgt, Aat, Gat, bqat, bpat, pump, sink, active);
         qA += D * D * S; qC += D * D * S; qb += D * S; qH += M * D * S;

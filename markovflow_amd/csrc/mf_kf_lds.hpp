@@ -244,12 +244,16 @@ template <typename T, typename St> struct RowReader {
 
 // RSTEP: the observation precision is a per-step stream [B, T, M, M] (KalmanFilterWithSites / WithSparseSites) instead of
 // one shared [M, M] matrix held in registers.
-template <typename T, int D, int M, bool RSTEP = false> struct KfLdsCfg {
+// BG: rows of b and H fetched per DMA batch (the same remedy as YG below, for kernels that have the LDS: the passes of the streamed
+// backward, mf_post_lds.hpp MODE 2 and mf_grad_lds.hpp, run two wavefronts per CU and take pairs - a 48-B row touches 1.375 lines,
+// a 96-B pair 1.5).
+template <typename T, int D, int M, bool RSTEP = false, int BG = 1> struct KfLdsCfg {
     static constexpr int S = sizeof(T);
+    static constexpr int BGRP = BG;
     using StA = Stream<D * D * S, KeepAll>;
     using StC = Stream<D * D * S, KeepLower<D, S>>;
-    using Stb = Stream<D * S, KeepAll>;
-    using StH = Stream<M * D * S, KeepAll>;
+    using Stb = Stream<BG * D * S, KeepAll>;
+    using StH = Stream<BG * M * D * S, KeepAll>;
     // y rows are tiny (M S bytes): with one output they are fetched YG steps at a time, so a 128-B line of y is
     // touched every YG-th step instead of every step (the memory side moves whole lines whatever part is used)
     static constexpr int YG = (M == 1) ? 4 : 1;

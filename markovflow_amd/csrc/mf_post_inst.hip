@@ -88,7 +88,15 @@ int post_launch(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* 
                                    info);
             }
             if (a_post) hipLaunchKernelGGL((post_lds_kernel<T, D, M, RS, 1>), grid, block, lds_emit, st, a, L, sum, po);
-            else hipLaunchKernelGGL((post_lds_kernel<T, D, M, RS, 2>), grid, block, lds_emit, st, a, L, sum, po);
+            else {
+                constexpr int lds2 = PostLds<T, D, M, RS, backward_row_group(M)>::TOTAL;
+                if constexpr (lds2 > 64 * 1024) {
+                    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&post_lds_kernel<T, D, M, RS, 2>),
+                                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+                    if (attr != hipSuccess) return;
+                }
+                hipLaunchKernelGGL((post_lds_kernel<T, D, M, RS, 2>), grid, block, lds2, st, a, L, sum, po);
+            }
             if (ev1) (void)hipEventRecord(ev1, st);
         }
     };

@@ -99,8 +99,8 @@ MF_DEV void buf_store(OutWord<4>::type v, mf_v4i srd, unsigned voff) {
 }
 
 // Geometry of the outputs of one step: a d x d row is handled as two halves of H0 and D - H0 matrix rows, a d row whole.
-template <typename T, int D, int M, bool RSTEP> struct PostLds {
-    using Cfg = KfLdsCfg<T, D, M, RSTEP>;
+template <typename T, int D, int M, bool RSTEP, int BG = 1> struct PostLds {
+    using Cfg = KfLdsCfg<T, D, M, RSTEP, BG>;
     static constexpr int S = (int)sizeof(T);
     static constexpr int H0 = (D + 1) / 2;
     static constexpr int B0 = H0 * D * S, B1 = (D - H0) * D * S, Bv = D * S;      // bytes of the two halves and of a vector row
@@ -159,8 +159,8 @@ template <typename T, int NU, int UNIT> struct StagedPiece {
 // The emit step's sink (mf_post_math.hpp: post_emit_step) on the device.  It lives across the steps of the loop: the second half
 // of A' of step j is stored during step j + 1.
 // TRANS = false: the step hands over no transitions (post_emit_step<TRANS = false>), their store windows stay empty.
-template <typename T, int D, int M, bool RSTEP, bool TRANS = true> struct PostSink {
-    using PL = PostLds<T, D, M, RSTEP>;
+template <typename T, int D, int M, bool RSTEP, bool TRANS = true, int BG = 1> struct PostSink {
+    using PL = PostLds<T, D, M, RSTEP, BG>;
     static constexpr int H0 = PL::H0, U0 = PL::U0, U1 = PL::U1, Uv = PL::Uv, UNIT = PL::UNIT;
     using W = typename OutWord<UNIT>::type;
     using P0 = StagedPiece<T, U0, UNIT>;
@@ -253,8 +253,8 @@ template <typename T, int D, int M, bool RSTEP, bool TRANS = true> struct PostSi
 
 // The sink of MODE 2: the packed records (PostLds: REC).  Piece A (the record's first RUa units) is staged when the factor
 // exists and stored during the window of the factor's first half, piece B with the rest of the factor; no transitions.
-template <typename T, int D, int M, bool RSTEP> struct PackedSink {
-    using PL = PostLds<T, D, M, RSTEP>;
+template <typename T, int D, int M, bool RSTEP, int BG = 1> struct PackedSink {
+    using PL = PostLds<T, D, M, RSTEP, BG>;
     static constexpr int RUa = PL::RUa, RUb = PL::RUb, REa = PL::REa, REb = PL::REb, NG = PL::NG, NR = PL::NR;
     using W = typename OutWord<16>::type;
     using PA = StagedPiece<T, RUa, 16>;
@@ -318,6 +318,50 @@ template <typename T, int D, int M, bool RSTEP> struct PackedSink {
     MF_DEV void flush() {}
 };
 
+// rows of b and H per DMA batch in the passes of the streamed backward (three outputs: the image of one row is as much as fits)
+constexpr int backward_row_group(int m) { return m <= 2 ? 2 : 1; }
+
+// KfPump (mf_kf_lds.hpp) with the rows of b and H fetched Cfg::BGRP steps at a time: their batch goes out only on the steps
+// that leave a group (bfetch), like the y rows.
+template <typename Cfg> struct PostPump {
+    const DmaStream<typename Cfg::StA>& dA; const DmaStream<typename Cfg::StC>& dC;
+    const DmaStream<typename Cfg::Stb>& db; const DmaStream<typename Cfg::StH>& dH;
+    const DmaStream<typename Cfg::Sty>& dy; const DmaStream<typename Cfg::StR>& dR;
+    mf_v4i sA, sC, sb, sH, sy, sR;
+    unsigned lds0;
+    bool more;
+    bool yfetch = true;
+    bool bfetch = true;
+    template <int K> MF_DEV void small() const {
+        if (!more) return;
+        constexpr int HC = (Cfg::StC::NI + 1) / 2;
+        if (K == 0) dC.template issue<0, HC>(sC, lds0 + Cfg::OFF_C);
+        else {
+            dC.template issue<HC, 64>(sC, lds0 + Cfg::OFF_C);
+            if (bfetch) {
+                db.template issue<0, 64>(sb, lds0 + Cfg::OFF_b);
+                dH.template issue<0, 64>(sH, lds0 + Cfg::OFF_H);
+            }
+            if (yfetch) dy.template issue<0, 64>(sy, lds0 + Cfg::OFF_y);
+            if (Cfg::RS) dR.template issue<0, 64>(sR, lds0 + Cfg::OFF_R);
+        }
+    }
+    template <int K> MF_DEV void all() const {
+        dC.template issue<0, 64>(sC, lds0 + Cfg::OFF_C);
+        db.template issue<0, 64>(sb, lds0 + Cfg::OFF_b);
+        dH.template issue<0, 64>(sH, lds0 + Cfg::OFF_H);
+        dy.template issue<0, 64>(sy, lds0 + Cfg::OFF_y);
+        if (Cfg::RS) dR.template issue<0, 64>(sR, lds0 + Cfg::OFF_R);
+        dA.template issue<0, 64>(sA, lds0 + Cfg::OFF_A);
+    }
+    template <int K> MF_DEV void big() const {
+        if (!more) return;
+        constexpr int Q = (Cfg::StA::NI + 3) / 4;
+        dA.template issue<K * Q, (K + 1) * Q>(sA, lds0 + Cfg::OFF_A);
+    }
+    MF_DEV void unpumped() const {}
+};
+
 // Passes 1 and 3: one wavefront per workgroup = 64 (series, chunk) lanes.  KfArgs::P = chunks per series, L = transitions per
 // chunk.  Position e of a chunk = transition tau0 + e; the wave walks e = nsteps-1 ... 0 (a chunk shorter than the wave's
 // longest idles FIRST, so that all lanes end on their chunk's first transition and every DMA address is >= the tensor's start).
@@ -326,9 +370,10 @@ template <typename T, int D, int M, bool RSTEP> struct PackedSink {
 template <typename T, int D, int M, bool RSTEP, int MODE>
 __global__ void __launch_bounds__(64) post_lds_kernel(KfArgs<T> a, long L, RedSys<T> out, PostOut<T> po) {
     constexpr bool EMIT = MODE != 0;
-    using Cfg = KfLdsCfg<T, D, M, RSTEP>;
-    using PL = PostLds<T, D, M, RSTEP>;
-    using Sink = std::conditional_t<MODE == 2, PackedSink<T, D, M, RSTEP>, PostSink<T, D, M, RSTEP, true>>;
+    constexpr int BG = (MODE == 2) ? backward_row_group(M) : 1;       // MODE 2 runs two wavefronts per CU: LDS for pairs of b and H rows
+    using Cfg = KfLdsCfg<T, D, M, RSTEP, BG>;
+    using PL = PostLds<T, D, M, RSTEP, BG>;
+    using Sink = std::conditional_t<MODE == 2, PackedSink<T, D, M, RSTEP, BG>, PostSink<T, D, M, RSTEP, true, BG>>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const long total = a.B * a.P;
@@ -392,8 +437,8 @@ __global__ void __launch_bounds__(64) post_lds_kernel(KfArgs<T> a, long L, RedSy
     const long e_top = nsteps > 0 ? nsteps - 1 : 0;
     unsigned long long pA = (unsigned long long)a.A + offA0 + (unsigned long long)e_top * (D * D * S);
     unsigned long long pC = (unsigned long long)a.cholQ + offA0 + (unsigned long long)e_top * (D * D * S);
-    unsigned long long pb = (unsigned long long)a.b + offb0 + (unsigned long long)e_top * (D * S);
-    unsigned long long pH = (unsigned long long)a.H + offH0 + (unsigned long long)e_top * (M * D * S);
+    unsigned long long pb = (unsigned long long)a.b + offb0 + (unsigned long long)(e_top / BG) * (BG * D * S);
+    unsigned long long pH = (unsigned long long)a.H + offH0 + (unsigned long long)(e_top / BG) * (BG * M * D * S);
     unsigned long long py = (unsigned long long)a.y + offy0 + (unsigned long long)(e_top / Cfg::YG) * (Cfg::YG * M * S);
     unsigned long long pR = (unsigned long long)a.Rinv + (RSTEP ? offR0 + (unsigned long long)e_top * (M * M * S) : 0ull);
     const unsigned long long eA = (unsigned long long)a.A + (unsigned long long)a.B * nt * (D * D * S);
@@ -443,7 +488,7 @@ __global__ void __launch_bounds__(64) post_lds_kernel(KfArgs<T> a, long L, RedSy
     const RowReader<T, typename Cfg::Sty> ry(smem, Cfg::OFF_y, lane);
     const RowReader<T, typename Cfg::StR> rR(smem, Cfg::OFF_R, lane);
 
-    using Pump = KfPump<Cfg>;
+    using Pump = PostPump<Cfg>;
     if (nsteps > 0) {   // prologue: fetch the last position
         Pump p0{dA, dC, db, dH, dy, dR, make_srd(pA, eA), make_srd(pC, eC), make_srd(pb, eb), make_srd(pH, eH),
                 make_srd(py, ey), make_srd(pR, eR), lds0, true};
@@ -467,12 +512,22 @@ __global__ void __launch_bounds__(64) post_lds_kernel(KfArgs<T> a, long L, RedSy
         const long e = nsteps - 1 - j;                                                                                \
         const bool more = e > 0;                                                                                      \
         const bool yfetch = (e % Cfg::YG) == 0;        /* position e-1 lies in the previous group of y rows */        \
-        pA -= D * D * S; pC -= D * D * S; pb -= D * S; pH -= M * D * S; if (RSTEP) pR -= M * M * S;                   \
+        const bool bfetch = (e % BG) == 0;             /* ... of b and H rows */                                      \
+        pA -= D * D * S; pC -= D * D * S; if (RSTEP) pR -= M * M * S;                                                 \
+        if (bfetch) { pb -= BG * D * S; pH -= BG * M * D * S; }                                                       \
         if (yfetch) py -= Cfg::YG * M * S;                                                                            \
         T C[D][D], mvec[D], hk[M * D], yk[M];                                                                         \
         MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int jj = 0; jj <= i; ++jj) C[i][jj] = rC.at(i * D + jj); \
-        MF_UNROLL for (int i = 0; i < D; ++i) mvec[i] = rb.at(i);                                                     \
-        MF_UNROLL for (int i = 0; i < M * D; ++i) hk[i] = rH.at(i);                                                   \
+        if constexpr (BG == 1) {                                                                                      \
+            MF_UNROLL for (int i = 0; i < D; ++i) mvec[i] = rb.at(i);                                                 \
+            MF_UNROLL for (int i = 0; i < M * D; ++i) hk[i] = rH.at(i);                                               \
+        } else {                                                                                                      \
+            const int gb = (int)(e % BG);                                                                             \
+            MF_UNROLL for (int i = 0; i < D; ++i)                                                                     \
+                mvec[i] = *reinterpret_cast<const T*>(rb.row + (gb * D + i) * (int)sizeof(T));                        \
+            MF_UNROLL for (int i = 0; i < M * D; ++i)                                                                 \
+                hk[i] = *reinterpret_cast<const T*>(rH.row + (gb * M * D + i) * (int)sizeof(T));                      \
+        }                                                                                                             \
         MF_UNROLL for (int i = 0; i < M; ++i)                                                                         \
             yk[i] = *reinterpret_cast<const T*>(ry.row + ((int)(e % Cfg::YG) * M + i) * (int)sizeof(T));              \
         if (RSTEP) { MF_UNROLL for (int i = 0; i < M * M; ++i) Rsh[i] = rR.at(i); }                                    \
@@ -480,8 +535,7 @@ __global__ void __launch_bounds__(64) post_lds_kernel(KfArgs<T> a, long L, RedSy
         MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int jj = 0; jj < D; ++jj) Bm[i][jj] = rA.at(i * D + jj); \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                            \
         const Pump pump{dA, dC, db, dH, dy, dR, make_srd(pA, eA), make_srd(pC, eC), make_srd(pb, eb),                 \
-                        make_srd(pH, eH), make_srd(py, ey), make_srd(pR, eR), lds0, more, yfetch};                    \
-        pump.unpumped();                                                                                              \
+                        make_srd(pH, eH), make_srd(py, ey), make_srd(pR, eR), lds0, more, yfetch, bfetch};            \
         const bool active = e < len;                                                                                  \
         if constexpr (EMIT) {                                                                                         \
             sink.qA = qA; sink.qC = qC; sink.qb = qb; sink.e = e;                                                     \

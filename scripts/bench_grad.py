@@ -7,9 +7,12 @@ from markovflow_amd import synthetic
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1024); ap.add_argument("--T", type=int, default=10000); ap.add_argument("--iters", type=int, default=3)
+ap.add_argument("--orders", default="5,5"); ap.add_argument("--dtype", default="float64")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
-inp = synthetic.make_ssm(a.batch, a.T, (5, 5), dtype=torch.float64, device=dev)
+orders = tuple(int(x) for x in a.orders.split(","))
+dt = getattr(torch, a.dtype)
+inp = synthetic.make_ssm(a.batch, a.T, orders, dtype=dt, device=dev)
 kf0 = synthetic.kalman_filter_from(inp)
 p = kf0.prior_ssm
 leaves = [t.detach().clone().requires_grad_(True) for t in (p.initial_mean, p.cholesky_initial_covariance, p.state_transitions,
@@ -23,4 +26,4 @@ for i in range(a.iters + 1):
     for l in leaves: l.grad = None
     tf, ll = timed(kf.log_likelihood)
     tb, _ = timed(ll.backward)
-    if i: print(f"B={a.batch} T={a.T} d=6 fp64: forward {tf:.2f} ms, backward {tb:.2f} ms")
+    if i: print(f"B={a.batch} T={a.T} Matern orders {orders} {a.dtype}: forward {tf:.2f} ms, backward {tb:.2f} ms")
