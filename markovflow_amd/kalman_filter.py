@@ -330,7 +330,20 @@ class BaseKalmanFilter(abc.ABC):
         esz = a_s.element_size()
         if bsz == 0:                                   # empty batch: nothing to launch
             return torch.empty(0, dtype=a_s.dtype, device=a_s.device)
-        ws_bytes = int(lib.mf_kf_loglik_workspace_bytes(bsz, n, d, esz, self._chunks))
+        chunks = self._chunks
+        aligned = int((a_s.data_ptr() | cq.data_ptr()) % 16 == 0)
+        path, p_f, l_f = ctypes.c_int(-1), ctypes.c_int64(0), ctypes.c_int64(0)
+        if self._keep_summaries:
+            # (asked for by the autograd function: which level-0 kernel runs, on which time partition.  Its chunk summaries are the
+            # first thing in the workspace, which therefore stays alive until the backward.  So many series that one chunk each
+            # fills the chip: two chunks cost the forward 6 % and save the backward its first two passes - measured at B = 65536,
+            # T = 128: forward 1.52 -> 1.61 ms, backward 10.3 -> 8.6 ms)
+            plan = lambda c: lib.mf_kf_loglik_plan(bsz, n, d, m, int(per_step), esz, c, aligned, ctypes.byref(path),   # noqa: E731
+                                                   ctypes.byref(p_f), ctypes.byref(l_f))
+            if plan(chunks) == 0 and chunks == 0 and path.value == 2 and p_f.value == 1 and n > 64:
+                chunks = 2
+                plan(chunks)
+        ws_bytes = int(lib.mf_kf_loglik_workspace_bytes(bsz, n, d, esz, chunks))
         if ws_bytes == 0:
             _lib.check(-100, "mf_kf_loglik")
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a_s.device)
@@ -338,17 +351,11 @@ class BaseKalmanFilter(abc.ABC):
         info = _lib.pivot_info(a_s.device)
         _lib.call("mf_kf_loglik", a_s.dtype, bsz, n, d, m, _lib.ptr(mu0), _lib.ptr(cp0), _lib.ptr(a_s),
                   _lib.ptr(b_s), _lib.ptr(cq), _lib.ptr(h), _lib.ptr(y), _lib.ptr(r_inv), int(per_step),
-                  0.0, _lib.ptr(out), _lib.ptr(ws), ws_bytes, info, self._chunks, self._prof_events[0],
+                  0.0, _lib.ptr(out), _lib.ptr(ws), ws_bytes, info, chunks, self._prof_events[0],
                   self._prof_events[1], _lib.stream_ptr(a_s.device))
         _lib.raise_on_info(info, "KalmanFilter.log_likelihood", a_s.device)
         if self._keep_summaries:
-            # (asked for by the autograd function: which level-0 kernel ran, on which time partition; its summaries are the first
-            # thing in the workspace, which therefore stays alive until the backward)
-            path, p_f, l_f = ctypes.c_int(0), ctypes.c_int64(0), ctypes.c_int64(0)
-            aligned = int((a_s.data_ptr() | cq.data_ptr()) % 16 == 0)
-            rc = lib.mf_kf_loglik_plan(bsz, n, d, m, int(per_step), esz, self._chunks, aligned, ctypes.byref(path),
-                                       ctypes.byref(p_f), ctypes.byref(l_f))
-            self._summaries = (ws, int(p_f.value), int(l_f.value)) if (rc == 0 and path.value == 2 and p_f.value >= 2) else None
+            self._summaries = (ws, int(p_f.value), int(l_f.value)) if (path.value == 2 and p_f.value >= 2) else None
         return out
 
     def _per_series(self):

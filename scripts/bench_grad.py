@@ -7,7 +7,7 @@ from markovflow_amd import synthetic
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1024); ap.add_argument("--T", type=int, default=10000); ap.add_argument("--iters", type=int, default=3)
-ap.add_argument("--orders", default="5,5"); ap.add_argument("--dtype", default="float64")
+ap.add_argument("--chunks", type=int, default=0); ap.add_argument("--orders", default="5,5"); ap.add_argument("--dtype", default="float64")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 orders = tuple(int(x) for x in a.orders.split(","))
@@ -19,6 +19,7 @@ leaves = [t.detach().clone().requires_grad_(True) for t in (p.initial_mean, p.ch
                                                             p.state_offsets, p.cholesky_process_covariances)]
 ssm = mfa.StateSpaceModel(*leaves)
 kf = mfa.KalmanFilter(ssm, kf0.emission, kf0.observations, kf0._chol_obs_covariance)
+kf._chunks = a.chunks
 def timed(fn):
     torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); out = fn(); e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1), out
