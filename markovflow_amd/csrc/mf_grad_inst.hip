@@ -137,8 +137,11 @@ int grad_run(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, 
             k0.gU = k0.tv + nb * D; k0.sc = k0.gU + nb * D;
             k0.n = fwd_P; k0.f_stride = fwd_P; k0.f_off = 0;
         }
-        hipLaunchKernelGGL((k0_scan_kernel<T, D, false>), dim3((unsigned)B), block, scan_lds, st, k0, k, P, io, info);
-        hipLaunchKernelGGL((k0_scan_kernel<T, D, true>), dim3((unsigned)B), block, scan_lds, st, k0, k, P, io, info);
+        int G = 64;                                    // lanes per series: a power of two that holds the forward's chunks
+        if (fwd_P <= 32) { G = 1; while (G < fwd_P) G <<= 1; }
+        const dim3 sgrid((unsigned)cdiv(B, 64 / G));
+        hipLaunchKernelGGL((k0_scan_kernel<T, D, false>), sgrid, block, scan_lds, st, k0, B, G, k, P, io, info);
+        hipLaunchKernelGGL((k0_scan_kernel<T, D, true>), sgrid, block, scan_lds, st, k0, B, G, k, P, io, info);
         const int rc = post_ops<T>()->emit(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, nullptr, mu0_post, nullptr,
                                            cp0_post, rec_post, post_ws, lay.post, info, P, L, st);
         if (rc != 0) return rc;

@@ -131,16 +131,19 @@ __global__ void __launch_bounds__(64) grad_start_kernel(KfArgs<T> a, RedSys<T> i
 // separator - here the run on the LEFT.  One wavefront per series, two launches (prefix, then suffix, which finishes the
 // marginals); the backward's chunks are groups of k forward chunks.
 template <typename T, int D, bool SUFFIX>
-__global__ void __launch_bounds__(64) k0_scan_kernel(RedSys<T> in, long k, long Pg, GradIo<T> io, int* info) {
+__global__ void __launch_bounds__(64) k0_scan_kernel(RedSys<T> in, long B, int G, long k, long Pg, GradIo<T> io, int* info) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x;
-    const long s = blockIdx.x;
+    // G lanes per series (a power of two >= the lanes that hold a run; 64 when a series has more than 32 chunks): with few chunks
+    // per series a wavefront scans 64 / G series side by side
+    const int lane = threadIdx.x, lp = lane & (G - 1);
+    const long s_raw = (long)blockIdx.x * (64 / G) + lane / G;
+    const long s = s_raw < B ? s_raw : B - 1;
     const long P = in.n;
     const long q = (P + 63) / 64;
-    const long p0 = lane * q;                 // positions in scan order: position p is chunk p (prefix) or chunk P-1-p (suffix)
+    const long p0 = lp * q;                   // positions in scan order: position p is chunk p (prefix) or chunk P-1-p (suffix)
     long p1 = p0 + q;
     if (p1 > P) p1 = P;
-    const bool has = p0 < P;
+    const bool has = p0 < P && s_raw < B;
     bool bad = false;
     const PostScanLds<T, D> lds{reinterpret_cast<T*>(smem), lane};
     auto chunk_of = [&](long p) { return SUFFIX ? P - 1 - p : p; };
@@ -192,7 +195,7 @@ __global__ void __launch_bounds__(64) k0_scan_kernel(RedSys<T> in, long k, long 
         if (has) lds.put(acc);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        if (has && lane >= off) {
+        if (has && lp >= off) {
             PostSummary<T, D> prev;
             lds.get(lane - off, prev);
             fold(prev, acc);                                              // prev: the earlier positions
@@ -209,11 +212,11 @@ __global__ void __launch_bounds__(64) k0_scan_kernel(RedSys<T> in, long k, long 
         __builtin_amdgcn_wave_barrier();
         if (has) {
             PostSummary<T, D> run;
-            if (lane > 0) lds.get(lane - 1, run);
+            if (lp > 0) lds.get(lane - 1, run);
             for (long p = p0; p < p1; ++p) {
                 PostSummary<T, D> nx;
                 post_summary_load<T, D>(in, s * P + chunk_of(p), nx);
-                if (lane > 0 || p > p0) fold(run, nx);
+                if (lp > 0 || p > p0) fold(run, nx);
                 else run = nx;
                 emit(p, run);
             }
