@@ -136,16 +136,23 @@ def test_streamed_backward_is_the_route_of_few_long_series_and_agrees_with_the_r
         kf.log_likelihood().sum().backward()
         return {k: nn(v.grad) for k, v in leaves.items()}
 
-    seen = []
+    seen, from_forward = [], []
     real = _lib.call_rc
 
     def spy(name, *args):
         seen.append(name)
+        if name == "mf_kf_loglik_grad_streamed":
+            from_forward.append(args[-6] is not None and args[-5] >= 2)      # fwd_ws, chunks per series of the forward evaluation
         return real(name, *args)
 
     monkeypatch.setattr(_lib, "call_rc", spy)
     streamed = run()
-    assert "mf_kf_loglik_grad_streamed" in seen
+    assert "mf_kf_loglik_grad_streamed" in seen and from_forward == [True]   # three passes, from the forward's summaries
+    monkeypatch.setattr(kfm, "_GRAD_FROM_FORWARD", False)
+    own = run()                                                            # five passes
+    assert from_forward[-1] is False
+    for k in streamed:
+        np.testing.assert_allclose(streamed[k], own[k], rtol=1e-9, atol=1e-11 * (1 + np.abs(own[k]).max()), err_msg=k)
     monkeypatch.setattr(kfm, "_GRAD_STREAMED", False)
     seen.clear()
     other = run()
@@ -155,12 +162,13 @@ def test_streamed_backward_is_the_route_of_few_long_series_and_agrees_with_the_r
         np.testing.assert_allclose(streamed[k], other[k], rtol=1e-7, atol=1e-9 * (1 + scale), err_msg=k)
 
 
-def test_streamed_backward_fp32(rng):
+@pytest.mark.parametrize("fwd_chunks", [None, 0, 9])
+def test_streamed_backward_fp32(rng, fwd_chunks):
     kw = random_ssm(rng, (3,), 120, 6, 1, well=True)
     kw = {k: v.astype(np.float32).astype(np.float64) for k, v in kw.items()}
     r_inv = np.eye(1) * 2.0
     w = np.ones(3)
-    got = grad_streamed_abi(kw, r_inv, w, 0, dtype=torch.float32)
+    got = grad_streamed_abi(kw, r_inv, w, 0, dtype=torch.float32, fwd_chunks=fwd_chunks)
     want, _ = dense_autograd(kw, r_inv, w, False)
     for name, g, ref in zip(NAMES[:7], got[:7], want):
         np.testing.assert_allclose(g, ref, rtol=5e-3, atol=5e-3 * (1 + np.abs(ref).max()), err_msg=name)
