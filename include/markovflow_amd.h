@@ -365,7 +365,8 @@ int mf_kf_loglik_grad_f32(int64_t B, int64_t T, int d, int m, const float* mu0, 
  * and a forward pass per (series, chunk) that carries (m_k, S_k, Cov(x_{k+1}, x_k)) in registers and writes every gradient once.
  * Replaces mf_kf_posterior_chain -> mf_ssm_marginal_means / _covariances -> mf_kf_loglik_grad for state dimensions 1..6,
  * m <= 3 (per-step precision: m = 1) and 16-byte aligned A, cholQ, g_A, g_cholQ; -101: not this route's call (the caller keeps
- * the three-call route).  Outputs and weights as for mf_kf_loglik_grad; the upper triangles of g_cholP0, g_cholQ are zeros.
+ * the three-call route).  Outputs and weights as for mf_kf_loglik_grad; the upper triangles of g_cholP0, g_cholQ are zeros;
+ * g_b, g_H, g_y, g_omega may be NULL (not wanted: not computed into memory - a tenth of the pass's traffic).
  * ws: mf_kf_loglik_grad_streamed_workspace_bytes (0: not this route's call); it holds the posterior chain, (4 d^2 + 3 d) s bytes
  * per step.  chunks: time partitions per series, 0 = automatic (>= 2).  prof_start / prof_stop: optional hipEvent_t recorded
  * around the kernels.

@@ -473,7 +473,7 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (m < 1) return -4;                                                                                          \
         if (!mu0 || !cholP0 || !A || !b || !cholQ) return -5;                                                          \
         if (!H || !y || !Rinv) return -10;                                                                             \
-        if (!g_mu0 || !g_cholP0 || !g_A || !g_b || !g_cholQ || !g_H || !g_y || !g_omega) return -15;                   \
+        if (!g_mu0 || !g_cholP0 || !g_A || !g_cholQ) return -15;   /* g_b, g_H, g_y, g_omega: NULL = not wanted */        \
         const auto* gt = grad_table_for<T>(d);                                                                         \
         if (!gt) return -101;                                                                                          \
         return gt->run(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, weights, g_mu0, g_cholP0, g_A,    \

@@ -358,13 +358,15 @@ template <typename T, int D, int M, bool RSTEP> struct GradSink {
     }
     template <int HALF, int R> MF_DEV void put_gA(const T (&rows)[R][D], bool) { put_mat<HALF, R>(qA, fA, rows); }
     template <int HALF, int R> MF_DEV void put_gC(const T (&rows)[R][D], bool) { put_mat<HALF, R>(qC, fC, rows); }
-    MF_DEV void put_gb(const T (&v)[D], bool) { burst<Pv, Uv>(GL::OFF_stagev, dv, qb, fb, v, ma, mb); }
+    // (a gradient the caller did not ask for - NULL - is not stored: wave-uniform branches)
+    bool want_b, want_H, want_y, want_Om;
+    MF_DEV void put_gb(const T (&v)[D], bool) {
+        if (want_b) burst<Pv, Uv>(GL::OFF_stagev, dv, qb, fb, v, ma, mb);
+    }
     MF_DEV void put_obs(const T (&gH)[M * D], const T (&gyv)[M], const T (&gOmv)[M * M], bool active) {
-        burst<PH, UH>(GL::OFF_stagev, dh, qH, fH, gH, ha, hb);
-        if (active) {
-            MF_UNROLL for (int i = 0; i < M; ++i) gy[i] = gyv[i];
-            MF_UNROLL for (int i = 0; i < M * M; ++i) gOm[i] = gOmv[i];
-        }
+        if (want_H) burst<PH, UH>(GL::OFF_stagev, dh, qH, fH, gH, ha, hb);
+        if (active && want_y) { MF_UNROLL for (int i = 0; i < M; ++i) gy[i] = gyv[i]; }
+        if (active && want_Om) { MF_UNROLL for (int i = 0; i < M * M; ++i) gOm[i] = gOmv[i]; }
     }
 };
 
@@ -506,6 +508,7 @@ __global__ void __launch_bounds__(64) grad_lds_kernel(KfArgs<T> a, long L, GradI
     sink.fA = (unsigned long long)io.gA + nA; sink.fC = (unsigned long long)io.gC + nA;
     sink.fb = (unsigned long long)io.gb + nb; sink.fH = (unsigned long long)io.gH + nH;
     sink.minlen = minlen;
+    sink.want_b = io.gb != nullptr; sink.want_H = io.gH != nullptr; sink.want_y = io.gy != nullptr; sink.want_Om = io.gOm != nullptr;
     unsigned long long qA = (unsigned long long)io.gA + offA0, qC = (unsigned long long)io.gC + offA0;
     unsigned long long qb = (unsigned long long)io.gb + offb0, qH = (unsigned long long)io.gH + offH0;
     T* gy_lane = io.gy + (s * a.Tn + tau0) * M;
@@ -561,9 +564,9 @@ __global__ void __launch_bounds__(64) grad_lds_kernel(KfArgs<T> a, long L, GradI
         const long k = s * a.Tn + nt;
         if (RSTEP) { MF_UNROLL for (int i = 0; i < M * M; ++i) Rsh[i] = a.Rinv[k * M * M + i]; }
         grad_obs<T, D, M>(a.H + k * M * D, a.y + k * M, Rsh, mk, Sk, wgt, gH, gyv, gOmv);
-        MF_UNROLL for (int i = 0; i < M * D; ++i) io.gH[k * M * D + i] = gH[i];
-        MF_UNROLL for (int i = 0; i < M; ++i) io.gy[k * M + i] = gyv[i];
-        MF_UNROLL for (int i = 0; i < M * M; ++i) io.gOm[k * M * M + i] = gOmv[i];
+        if (io.gH) { MF_UNROLL for (int i = 0; i < M * D; ++i) io.gH[k * M * D + i] = gH[i]; }
+        if (io.gy) { MF_UNROLL for (int i = 0; i < M; ++i) io.gy[k * M + i] = gyv[i]; }
+        if (io.gOm) { MF_UNROLL for (int i = 0; i < M * M; ++i) io.gOm[k * M * M + i] = gOmv[i]; }
     }
     if (valid && bad && a.info) raise_info(a.info);
 }

@@ -52,7 +52,8 @@ class _LogLikelihoodPerSeries(torch.autograd.Function):
     def backward(ctx, grad_out):
         mu0, cp0, a_s, b_s, cq, h, y, r_inv = ctx.saved_tensors
         with torch.no_grad():
-            streamed = _streamed_backward(mu0, cp0, a_s, b_s, cq, h, y, r_inv, grad_out, fwd=ctx.fwd_summaries)
+            streamed = _streamed_backward(mu0, cp0, a_s, b_s, cq, h, y, r_inv, grad_out, fwd=ctx.fwd_summaries,
+                                          want=tuple(ctx.needs_input_grad[:8]))
             ctx.fwd_summaries = None
             if streamed is not None:
                 return streamed + (None,)
@@ -96,11 +97,13 @@ _grad_prof_events = (None, None)     # optional hipEvent_t pair recorded around 
 _GRAD_FROM_FORWARD = True            # start the streamed backward from the forward evaluation's chunk summaries when it left any
 
 
-def _streamed_backward(mu0, cp0, a_s, b_s, cq, h, y, r_inv, grad_out, chunks=0, fwd=None):
+def _streamed_backward(mu0, cp0, a_s, b_s, cq, h, y, r_inv, grad_out, chunks=0, fwd=None, want=(True,) * 8):
     """``mf_kf_loglik_grad_streamed_*`` (csrc/mf_grad_lds.hpp): the smoothed marginals stay in registers.  ``None`` when the call
     is not that route's (short chains, d > 6, m > 3, unaligned views): the caller keeps the three-kernel route.
     ``fwd = (workspace, chunks per series, chunk length)`` of the forward ``mf_kf_loglik`` call on the same tensors, if its
-    level-0 kernel was the streaming one: its chunk summaries replace the backward's own first two passes."""
+    level-0 kernel was the streaming one: its chunk summaries replace the backward's own first two passes.
+    ``want``: which of the eight inputs need a gradient (``ctx.needs_input_grad``) - those of b, H, y and the precision are not
+    stored when nobody asked (their slots come back as ``None``)."""
     bsz, n, m, d = h.shape
     if not _GRAD_STREAMED or bsz < 1 or bsz >= _GRAD_STREAMED_MAX_SERIES or n <= 64:
         return None
@@ -111,9 +114,11 @@ def _streamed_backward(mu0, cp0, a_s, b_s, cq, h, y, r_inv, grad_out, chunks=0, 
         return None
     tensors = [t.contiguous() for t in (mu0, cp0, a_s, b_s, cq, h, y, r_inv)]
     g_mu0, g_cp0 = torch.empty_like(tensors[0]), torch.empty_like(tensors[1])
-    g_a, g_b, g_cq = torch.empty_like(tensors[2]), torch.empty_like(tensors[3]), torch.empty_like(tensors[4])
-    g_h, g_y = torch.empty_like(tensors[5]), torch.empty_like(tensors[6])
-    g_om = torch.empty((bsz, n, m, m), dtype=h.dtype, device=h.device)
+    g_a, g_cq = torch.empty_like(tensors[2]), torch.empty_like(tensors[4])
+    g_b = torch.empty_like(tensors[3]) if want[3] else None
+    g_h = torch.empty_like(tensors[5]) if want[5] else None
+    g_y = torch.empty_like(tensors[6]) if want[6] else None
+    g_om = torch.empty((bsz, n, m, m), dtype=h.dtype, device=h.device) if want[7] else None
     if any(t.data_ptr() % 16 for t in (tensors[2], tensors[4], g_a, g_cq)):
         return None
     ws = _lib.workspace(ws_bytes, h.device)
@@ -129,7 +134,7 @@ def _streamed_backward(mu0, cp0, a_s, b_s, cq, h, y, r_inv, grad_out, chunks=0, 
         return None
     _lib.check(rc, "mf_kf_loglik_grad_streamed")
     _lib.raise_on_info(info, "log_likelihood (backward)", h.device)
-    g_r_inv = -0.5 * g_om if per_step else -0.5 * torch.sum(g_om, dim=(0, 1))
+    g_r_inv = None if g_om is None else (-0.5 * g_om if per_step else -0.5 * torch.sum(g_om, dim=(0, 1)))
     return g_mu0, g_cp0, g_a, g_b, g_cq, g_h, g_y, g_r_inv
 
 

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 NAMES = ("mu0", "cholP0", "A", "b", "cholQ", "H", "y", "Omega")
 
 
-def grad_streamed_abi(kw, r_inv, w, chunks, dtype=torch.float64, per_step=False, fwd_chunks=None, strict=True):
+def grad_streamed_abi(kw, r_inv, w, chunks, dtype=torch.float64, per_step=False, fwd_chunks=None, strict=True, skip=()):
     """Call mf_kf_loglik_grad_streamed directly; the eight gradient tensors as numpy arrays.  fwd_chunks (0 = automatic): evaluate
     mf_kf_loglik first, on that many chunks per series, and hand its workspace (the chunk summaries) to the backward."""
     import ctypes
@@ -47,7 +47,7 @@ def grad_streamed_abi(kw, r_inv, w, chunks, dtype=torch.float64, per_step=False,
     outs = [torch.full_like(x, float("nan")) for x in ins[:7]] + [torch.full((bsz, t, m, m), float("nan"), dtype=dtype, device=DEV)]
     info = _lib.new_info(torch.device(DEV))
     _lib.call("mf_kf_loglik_grad_streamed", dtype, bsz, t, d, m, *[_lib.ptr(x) for x in ins], int(per_step), _lib.ptr(tt(w, dtype)),
-              *[_lib.ptr(x) for x in outs], _lib.ptr(ws), wsb, _lib.ptr(info), chunks, _lib.ptr(fwd[0]), fwd[1], fwd[2], None, None,
+              *[None if i in skip else _lib.ptr(x) for i, x in enumerate(outs)], _lib.ptr(ws), wsb, _lib.ptr(info), chunks, _lib.ptr(fwd[0]), fwd[1], fwd[2], None, None,
               _lib.stream_ptr(torch.device(DEV)))
     torch.cuda.synchronize()
     assert int(info.item()) == 0
@@ -121,6 +121,20 @@ def test_streamed_backward_from_the_forward_summaries(rng, d, m, t, bsz, chunks,
         np.testing.assert_allclose(g, ref, rtol=1e-6, atol=1e-8 * (1 + np.abs(ref).max()), err_msg=name)
     got_r = precision_gradient(got[7], r_inv, w, t, per_step)
     np.testing.assert_allclose(got_r, want_r, rtol=1e-6, atol=1e-8 * (1 + np.abs(want_r).max()), err_msg="R^-1")
+
+
+def test_gradients_nobody_asked_for_are_not_stored(rng):
+    """g_b, g_H, g_y, g_omega = NULL: their buffers stay untouched and the others do not change."""
+    kw = random_ssm(rng, (3,), 90, 6, 2, well=True)
+    r_inv = np.linalg.inv(np.array([[1.0, 0.2], [0.2, 0.7]]))
+    w = rng.uniform(0.5, 1.5, size=3)
+    full = grad_streamed_abi(kw, r_inv, w, 5, fwd_chunks=0)
+    part = grad_streamed_abi(kw, r_inv, w, 5, fwd_chunks=0, skip=(3, 5, 6, 7))
+    for i, name in enumerate(NAMES):
+        if i in (3, 5, 6, 7):
+            assert np.all(np.isnan(part[i])), name
+        else:
+            np.testing.assert_array_equal(part[i], full[i], err_msg=name)
 
 
 def test_streamed_backward_is_the_route_of_few_long_series_and_agrees_with_the_route_it_replaces(rng, monkeypatch):
