@@ -481,6 +481,24 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
                        fwd_chunk_length, static_cast<hipEvent_t>(prof_start), static_cast<hipEvent_t>(prof_stop),      \
                        S(stream));                                                                                    \
     }                                                                                                                  \
+    int mf_gpr_matern_loglik_grad_##SUF(int64_t B, int64_t Tn, int ncomp, const int* orders, const T* lam, const T* var, \
+                                        int per_series, const T* t, const T* y, const T* rinv, T jitter,                \
+                                        const T* weights, T* g_A, T* g_cholQ, T* g_cholP0, T* g_omega, void* ws,        \
+                                        size_t ws_bytes, int* info, const void* fwd_ws,                                \
+                                        int64_t fwd_chunks_per_series, int64_t fwd_chunk_length, void* stream) {       \
+        if (B < 1) return -1;                                                                                          \
+        if (Tn < 2) return -2;                                                                                         \
+        if (ncomp < 1 || !orders) return -3;                                                                           \
+        if (!lam || !var || !t || !y || !rinv) return -5;                                                              \
+        if (!g_A || !g_cholQ || !g_cholP0) return -13;                                                                 \
+        int d = 0;                                                                                                     \
+        for (int c = 0; c < ncomp; ++c) d += (orders[c] + 1) / 2;                                                      \
+        const auto* gt = grad_table_for<T>(d);                                                                         \
+        if (!gt) return -101;                                                                                          \
+        return gt->gpr_run(B, Tn, ncomp, orders, lam, var, per_series, t, y, rinv, jitter, weights, g_A, g_cholQ,       \
+                           g_cholP0, g_omega, ws, ws_bytes, info, fwd_ws, fwd_chunks_per_series, fwd_chunk_length,      \
+                           S(stream));                                                                                 \
+    }                                                                                                                  \
     int mf_ssm_kl_grad_##SUF(int64_t B, int64_t Tn, int d, const T* mu0_1, const T* cholP0_1, const T* A_1,            \
                              const T* b_1, const T* cholQ_1, const T* mu0_2, const T* cholP0_2, const T* A_2,          \
                              const T* b_2, const T* cholQ_2, const T* means_1, const T* covs_1, const T* weights,      \
@@ -641,6 +659,13 @@ int mf_kf_loglik_plan(int64_t B, int64_t T, int d, int m, int rinv_per_step, int
     *chunks_per_series = P;
     *chunk_length = L;
     return rc;
+}
+
+size_t mf_gpr_matern_loglik_grad_workspace_bytes(int64_t B, int64_t T, int d, int elem_size, int64_t fwd_chunks_per_series) {
+    if (B < 1 || T < 2 || d < 1) return 0;
+    if (elem_size == 4) { const auto* t = grad_table_for<float>(d); return t ? t->gpr_ws(B, T, fwd_chunks_per_series) : 0; }
+    const auto* t = grad_table_for<double>(d);
+    return t ? t->gpr_ws(B, T, fwd_chunks_per_series) : 0;
 }
 
 size_t mf_kf_loglik_grad_streamed_workspace_bytes(int64_t B, int64_t T, int d, int m, int rinv_per_step, int elem_size,

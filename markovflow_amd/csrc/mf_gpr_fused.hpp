@@ -92,10 +92,13 @@ template <typename T, int O0, int O1> struct GprGen {
     }
 };
 
-struct NoPump {
-    template <int K> MF_DEV void small() const {}
-    template <int K> MF_DEV void big() const {}
+#ifndef MF_NOPUMP_DEFINED
+#define MF_NOPUMP_DEFINED
+struct NoPump {        // (mf_post_math.hpp has the same stand-in for the host simulation)
+    template <int K> MF_HD void small() const {}
+    template <int K> MF_HD void big() const {}
 };
+#endif
 
 template <typename T> struct GprArgs {
     long B, Tn;

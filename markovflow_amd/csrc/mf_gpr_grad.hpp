@@ -1,0 +1,304 @@
+// The backward of GaussianProcessRegression.log_likelihood with the kernel -> state-space-model step FUSED into its passes
+// (the training step of models/gaussian_process_regression.py:150-160 under a GradientTape; kernels/matern.py, sde_kernel.py:421-446
+// for the closed forms): the emit pass and the gradient pass of the streamed backward (mf_post_lds.hpp MODE 2, mf_grad_lds.hpp)
+// with A_k = exp(F dt_k) and chol Q_k generated in registers from (dt_k, hyper-parameters) as the fused forward does
+// (mf_gpr_fused.hpp) - a step reads 16 bytes of the model instead of (2 d^2 + 3 d + 1) s, and the model tensors are never
+// materialised.  Sum of one or two Matern components, one output, zero state offsets, H = [1 0 0 | 1 0 0].
+//
+//   forward (mf_gpr_matern_loglik)    leaves one summary per (series, chunk) in its workspace, in the form of mf_kf_loglik's
+//   k0_scan_kernel x 2                 boundary states and start moments from those summaries (mf_grad_lds.hpp)
+//   gpr_emit_kernel                    the posterior chain's chol(Q'), b' as packed records, backward in time
+//   gpr_grad_kernel                    forward in time: smoothed marginals in registers; writes g_A, g_cholQ (what the generator's
+//                                      backward, mf_sde_matern_transitions_grad, contracts with its forward-mode duals), g_cholP0
+//                                      and Omega (the noise's gradient)
+// No input image in LDS: both kernels run one wavefront per SIMD on the forward's own partition.
+#pragma once
+#include "mf_gpr_fused.hpp"
+#include "mf_grad_lds.hpp"
+
+namespace mf {
+
+// LDS of the two kernels: [record image | A_k per lane (its NA non-zero entries: the diagonal blocks) | staging | tables]
+template <typename T, int D, int NA> struct GprBwdLds {
+    using PL = PostLds<T, D, 1, false, 1>;            // record and piece geometry only (its offsets are not used)
+    static constexpr int S = (int)sizeof(T), M = 1;
+    static constexpr int NG = PL::NG, NR = PL::NR, REC = PL::REC, RU = PL::RU, RUa = PL::RUa, RUb = PL::RUb, REa = PL::REa, REb = PL::REb;
+    static constexpr int H0 = PL::H0, B0 = PL::B0, B1 = PL::B1, Bv = PL::Bv, UNIT = PL::UNIT, U0 = PL::U0, U1 = PL::U1, Uv = PL::Uv;
+    static constexpr int BH = D * S, UNITH = UNIT, UH = Uv;         // (d/dH is not produced; the piece exists for the sink's types)
+    using StP = Stream<REC, KeepAll>;
+    static constexpr int OFF_P = 0;
+    static constexpr int OFF_Amat = OFF_P + StP::LDS_BYTES;        // this step's A_k, NA entries per lane
+    static constexpr int OFF_stageM = OFF_Amat + ((64 * NA * S + 15) / 16) * 16;
+    static constexpr int OFF_stagev = OFF_stageM;
+    static constexpr int STAGE0 = 64 * (B0 > Bv ? B0 : Bv), STAGE1 = 64 * RUa * 16;
+    static constexpr int OFF_len = OFF_stageM + (((STAGE0 > STAGE1 ? STAGE0 : STAGE1) + 15) / 16) * 16;
+    static constexpr int OFF_relP = OFF_len + 256;
+    static constexpr int OFF_relA = OFF_relP + 256;
+    static constexpr int OFF_relv = OFF_relA + 256;
+    static constexpr int OFF_hyp = OFF_relv + 256;                 // lam0, var0, lam1, var1, R^-1 per lane
+    static constexpr int TOTAL = OFF_hyp + 5 * 64 * S;
+};
+
+template <typename T> struct GprBwdIo {
+    void* rec; T* bPsi; T* bpsi; T* mu0_post; T* cp0_post;        // emit: records out; boundary states in; block 0's marginal out
+};
+
+template <typename T, int O0, int O1> MF_DEV GprGen<T, O0, O1> gpr_load_gen(const char* smem, int off_hyp, int lane, T jitter) {
+    const T* h = reinterpret_cast<const T*>(smem + off_hyp);
+    GprGen<T, O0, O1> g;
+    g.lam[0] = h[0 * 64 + lane]; g.var[0] = h[1 * 64 + lane];
+    g.lam[1] = h[2 * 64 + lane]; g.var[1] = h[3 * 64 + lane];
+    g.jitter = jitter;
+    return g;
+}
+template <typename T, int O1> MF_DEV void gpr_store_hyp(char* smem, int off_hyp, int lane, const GprArgs<T>& a, long s) {
+    T* h = reinterpret_cast<T*>(smem + off_hyp);
+    h[0 * 64 + lane] = a.lam[s * a.hstride];
+    h[1 * 64 + lane] = a.var[s * a.hstride];
+    h[2 * 64 + lane] = O1 ? a.lam[s * a.hstride + 1] : T(0);
+    h[3 * 64 + lane] = O1 ? a.var[s * a.hstride + 1] : T(0);
+    h[4 * 64 + lane] = a.rinv[0];
+}
+
+// ---- emit: position e of a chunk = transition tau0 + e; the wave walks e = nsteps-1 ... 0 (a shorter chunk idles FIRST) -----------
+template <typename T, int O0, int O1>
+__global__ void __launch_bounds__(64) gpr_emit_kernel(GprArgs<T> a, GprBwdIo<T> io) {
+    using Gen = GprGen<T, O0, O1>;
+    constexpr int D = Gen::D;
+    using GB = GprBwdLds<T, D, Gen::K0 * Gen::K0 + Gen::K1 * Gen::K1>;
+    using Sink = PackedSinkT<T, D, GB>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    const long total = a.B * a.P;
+    const long id_raw = (long)blockIdx.x * 64 + lane;
+    const bool valid = id_raw < total;
+    const long id = valid ? id_raw : total - 1;
+    const long s = id / a.P, c = id % a.P;
+    const long nt = a.Tn - 1, tau0 = c * a.L;
+    long len = nt - tau0;
+    if (len > a.L) len = a.L;
+    if (len < 0 || !valid) len = 0;
+    long nsteps = len, minlen = len;
+    MF_UNROLL for (int off = 32; off > 0; off >>= 1) {
+        const long o = __shfl_xor((long long)nsteps, off);
+        nsteps = o > nsteps ? o : nsteps;
+        const long u = __shfl_xor((long long)minlen, off);
+        minlen = u < minlen ? u : minlen;
+    }
+    nsteps = __builtin_amdgcn_readfirstlane((int)nsteps);
+    minlen = __builtin_amdgcn_readfirstlane((int)minlen);
+    const unsigned long long offP = (unsigned long long)(s * nt + tau0) * GB::REC, offP0 = uniform64(offP);
+    const bool rowok = valid && len > 0;
+    {
+        unsigned* tab = reinterpret_cast<unsigned*>(smem);
+        tab[GB::OFF_relP / 4 + lane] = rowok ? (unsigned)(offP - offP0) : MF_DMA_INVALID;
+        reinterpret_cast<int*>(smem)[GB::OFF_len / 4 + lane] = rowok ? (int)len : 0;
+    }
+    gpr_store_hyp<T, O1>(smem, GB::OFF_hyp, lane, a, s);
+    T hk[D], zero[D];
+    MF_UNROLL for (int i = 0; i < D; ++i) { hk[i] = (i == 0 || (O1 && i == Gen::K0)) ? T(1) : T(0); zero[i] = T(0); }
+    const T* ts = a.t + s * a.Tn;
+    const T* ys = a.y + s * a.Tn;
+    T Phi[D][D], tv[D];
+    bool bad = false;
+    MF_UNROLL for (int i = 0; i < D; ++i) { tv[i] = T(0); MF_UNROLL for (int j = 0; j < D; ++j) Phi[i][j] = T(0); }
+    if (valid && c + 1 < a.P) {
+        load_lower<T, D>(io.bPsi + id * D * D, Phi);
+        load_vec<T, D>(io.bpsi + id * D, tv);
+    }
+    // time points and observations one position ahead of their use; a chunk that is not active yet holds its LAST position's
+    const long e_top = nsteps > 0 ? nsteps - 1 : 0;
+    const long e0 = len > 0 ? (e_top < len ? e_top : len - 1) : 0;
+    T t_hi = len > 0 ? ts[tau0 + e0 + 1] : T(0), t_lo = len > 0 ? ts[tau0 + e0] : T(0), y_cur = len > 0 ? ys[tau0 + e0 + 1] : T(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    MF_UNROLL for (int i = 0; i < D; ++i) {
+        asm volatile("" : "+v"(tv[i]));
+        MF_UNROLL for (int j = 0; j <= i; ++j) asm volatile("" : "+v"(Phi[i][j]));
+    }
+    Sink sink;
+    sink.init(smem, lane, 0, 0);
+    sink.fR = (unsigned long long)io.rec + (unsigned long long)a.B * nt * GB::REC;
+    sink.minlen = minlen;
+    unsigned long long qR = (unsigned long long)io.rec + offP0 + (unsigned long long)e_top * GB::REC;
+    const NoPump pump;
+    for (long j = 0; j < nsteps; ++j) {
+        const long e = nsteps - 1 - j;
+        const bool active = e < len;
+        const T dt = t_hi - t_lo;
+        T yk[1] = {y_cur}, Rk[1] = {reinterpret_cast<const T*>(smem + GB::OFF_hyp)[4 * 64 + lane]};
+        // the next position this lane will be ACTIVE at: e-1 once it is active, still len-1 before
+        const long en = e - 1 < len ? e - 1 : len - 1;
+        if (en >= 0 && en != (e < len ? e : len - 1)) { t_hi = t_lo; t_lo = ts[tau0 + en]; y_cur = ys[tau0 + en + 1]; }
+        T C[D][D], Bm[D][D];
+        gpr_load_gen<T, O0, O1>(smem, GB::OFF_hyp, lane, a.jitter).make(dt, false, Bm, C);
+        sink.qR = qR; sink.e = e;
+        qR -= GB::REC;
+        post_emit_step<T, D, 1, false>(Phi, tv, bad, C, zero, hk, yk, Rk, Bm, pump, sink, active);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (valid && c == 0) {          // block 0: the stationary prior closes the chain
+        T C0[D][D], dummy[D][D], mean[D], Gi[D][D];
+        gpr_load_gen<T, O0, O1>(smem, GB::OFF_hyp, lane, a.jitter).make(T(0), true, dummy, C0);
+        T y0[1] = {ys[0]}, Rk[1] = {a.rinv[0]};
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Gi[i][j] = T(0);
+        post_emit_prior<T, D, 1>(Phi, tv, bad, C0, zero, hk, y0, Rk, mean, Gi);
+        store_vec<T, D>(io.mu0_post + s * D, mean);
+        store_lower<T, D>(io.cp0_post + s * D * D, Gi);
+    }
+    if (valid && bad && a.info) raise_info(a.info);
+}
+
+// ---- gradient pass: position j of a chunk = transition tau0 + j, forward in time (a shorter chunk idles LAST) ----------------------
+template <typename T, typename GB> struct GprGradPump {
+    const DmaStream<typename GB::StP>& dP;
+    mf_v4i sP;
+    unsigned lds0;
+    bool more;
+    MF_DEV void issue_record() const { dP.template issue<0, 64>(sP, lds0 + GB::OFF_P); }
+    template <int K> MF_DEV void site() const {
+        asm volatile("" ::: "memory");
+        if constexpr (K == 4) {
+            if (!more) return;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the last read of the record's factor has its data
+            issue_record();
+        }
+    }
+};
+
+template <typename T, int O0, int O1>
+__global__ void __launch_bounds__(64) gpr_grad_kernel(GprArgs<T> a, GradIo<T> io, const T* __restrict__ weights) {
+    using Gen = GprGen<T, O0, O1>;
+    constexpr int D = Gen::D, S = sizeof(T);
+    constexpr int K0 = Gen::K0, K1 = Gen::K1, NA = K0 * K0 + K1 * K1;
+    using GB = GprBwdLds<T, D, NA>;
+    using Sink = GradSinkT<T, D, 1, GB>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    const long total = a.B * a.P;
+    const long id_raw = (long)blockIdx.x * 64 + lane;
+    const bool valid = id_raw < total;
+    const long id = valid ? id_raw : total - 1;
+    const long s = id / a.P, c = id % a.P;
+    const long nt = a.Tn - 1, tau0 = c * a.L;
+    long len = nt - tau0;
+    if (len > a.L) len = a.L;
+    if (len < 0 || !valid) len = 0;
+    long nsteps = len, minlen = len;
+    MF_UNROLL for (int off = 32; off > 0; off >>= 1) {
+        const long o = __shfl_xor((long long)nsteps, off);
+        nsteps = o > nsteps ? o : nsteps;
+        const long u = __shfl_xor((long long)minlen, off);
+        minlen = u < minlen ? u : minlen;
+    }
+    nsteps = __builtin_amdgcn_readfirstlane((int)nsteps);
+    minlen = __builtin_amdgcn_readfirstlane((int)minlen);
+    const unsigned long long offA = (unsigned long long)(s * nt + tau0) * (D * D * S), offA0 = uniform64(offA);
+    const unsigned long long offP = (unsigned long long)(s * nt + tau0) * GB::REC, offP0 = uniform64(offP);
+    const bool rowok = valid && len > 0;
+    {
+        unsigned* tab = reinterpret_cast<unsigned*>(smem);
+        tab[GB::OFF_relA / 4 + lane] = rowok ? (unsigned)(offA - offA0) : MF_DMA_INVALID;
+        tab[GB::OFF_relv / 4 + lane] = MF_DMA_INVALID;              // (no vector rows are stored)
+        tab[GB::OFF_relP / 4 + lane] = rowok ? (unsigned)(offP - offP0) : MF_DMA_INVALID;
+        reinterpret_cast<int*>(smem)[GB::OFF_len / 4 + lane] = rowok ? (int)len : 0;
+    }
+    gpr_store_hyp<T, O1>(smem, GB::OFF_hyp, lane, a, s);
+    T hk[D];
+    MF_UNROLL for (int i = 0; i < D; ++i) hk[i] = (i == 0 || (O1 && i == Gen::K0)) ? T(1) : T(0);
+    const T* ts = a.t + s * a.Tn;
+    const T* ys = a.y + s * a.Tn;
+    const T wgt = weights ? weights[s] : T(1);
+    bool bad = false;
+    T mk[D], Sk[D][D];
+    MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) Sk[i][j] = T(0);
+    if (c == 0) {                    // block 0: the posterior chain starts from its marginal
+        T G0[D][D];
+        MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) G0[i][j] = T(0);
+        load_lower<T, D>(io.cp0_post + s * D * D, G0);
+        load_vec<T, D>(io.mu0_post + s * D, mk);
+        MF_UNROLL for (int i = 0; i < D; ++i)
+            MF_UNROLL for (int j = 0; j <= i; ++j) {
+                T acc = T(0);
+                MF_UNROLL for (int l = 0; l <= j; ++l) acc += G0[i][l] * G0[j][l];
+                Sk[i][j] = acc;
+            }
+    } else {
+        load_vec<T, D>(io.start_m + id * D, mk);
+        load_lower<T, D>(io.start_S + id * D * D, Sk);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (valid && c == 0) {          // the prior's gradient: mu0 = 0, cholP0 = chol(Pinf + jitter)
+        T C0[D][D], dummy[D][D], mu0[D], gmu0[D], gC0[D][D];
+        gpr_load_gen<T, O0, O1>(smem, GB::OFF_hyp, lane, a.jitter).make(T(0), true, dummy, C0);
+        MF_UNROLL for (int i = 0; i < D; ++i) mu0[i] = T(0);
+        grad_prior<T, D>(C0, mu0, mk, Sk, wgt, gmu0, gC0, bad);
+        store_mat<T, D, D>(io.gC0 + s * D * D, gC0);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    MF_UNROLL for (int i = 0; i < D; ++i) {
+        asm volatile("" : "+v"(mk[i]));
+        MF_UNROLL for (int j = 0; j <= i; ++j) asm volatile("" : "+v"(Sk[i][j]));
+    }
+    DmaStream<typename GB::StP> dP;
+    dP.init(smem, lane, GB::OFF_relP, 0);
+    Sink sink;
+    sink.init(smem, lane, GB::OFF_relA, GB::OFF_relv, GB::OFF_relv);
+    const unsigned long long nA = (unsigned long long)a.B * nt * (D * D * S);
+    sink.fA = (unsigned long long)io.gA + nA; sink.fC = (unsigned long long)io.gC + nA; sink.fb = 0; sink.fH = 0;
+    sink.minlen = minlen;
+    sink.want_b = false; sink.want_H = false; sink.want_y = false; sink.want_Om = io.gOm != nullptr;
+    unsigned long long qA = (unsigned long long)io.gA + offA0, qC = (unsigned long long)io.gC + offA0;
+    T* gOm_lane = io.gOm + (s * a.Tn + tau0);
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    unsigned long long pP = (unsigned long long)io.rec_post + offP0;
+    const unsigned long long eP = (unsigned long long)io.rec_post + (unsigned long long)a.B * nt * GB::REC;
+    const RowReader<T, typename GB::StP> rP(smem, GB::OFF_P, lane);
+    T* Amat = reinterpret_cast<T*>(smem + GB::OFF_Amat + lane * (NA * S));
+    using Pump = GprGradPump<T, GB>;
+    if (nsteps > 0) {
+        const Pump p0{dP, make_srd(pP, eP), lds0, true};
+        p0.issue_record();
+    }
+    // time points and observations one position ahead of their use (an idle lane keeps reading its last position)
+    T t_lo = len > 0 ? ts[tau0] : T(0), t_hi = len > 0 ? ts[tau0 + 1] : T(0), y_cur = len > 0 ? ys[tau0] : T(0);
+    for (long j = 0; j < nsteps; ++j) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const bool more = (j + 1 < nsteps);
+        const bool active = j < len;
+        pP += GB::REC;
+        const T dt = t_hi - t_lo;
+        T yk[1] = {y_cur}, Rk[1] = {reinterpret_cast<const T*>(smem + GB::OFF_hyp)[4 * 64 + lane]};
+        if (j + 1 < len) { t_lo = t_hi; t_hi = ts[tau0 + j + 2]; y_cur = ys[tau0 + j + 1]; }
+        T C[D][D];
+        {
+            T Am[D][D];
+            gpr_load_gen<T, O0, O1>(smem, GB::OFF_hyp, lane, a.jitter).make(dt, false, Am, C);
+            MF_UNROLL for (int i = 0; i < K0; ++i) MF_UNROLL for (int jj = 0; jj < K0; ++jj) Amat[i * K0 + jj] = Am[i][jj];
+            MF_UNROLL for (int i = 0; i < K1; ++i) MF_UNROLL for (int jj = 0; jj < K1; ++jj) Amat[K0 * K0 + i * K1 + jj] = Am[K0 + i][K0 + jj];
+        }
+        const Pump pump{dP, make_srd(pP, eP), lds0, more};
+        sink.qA = qA; sink.qC = qC; sink.qb = 0; sink.qH = 0; sink.e = j;
+        sink.gy = nullptr; sink.gOm = gOm_lane;
+        // (A_k is block diagonal: its zeros are known at compile time)
+        auto Aat = [&](int i, int jj) {
+            if (i < K0 && jj < K0) return Amat[i * K0 + jj];
+            if (i >= K0 && jj >= K0) return Amat[K0 * K0 + (i - K0) * K1 + (jj - K0)];
+            return T(0);
+        };
+        auto Gat = [&](int i, int jj) { return rP.at(i * (i + 1) / 2 + jj); };
+        auto bqat = [&](int) { return T(0); };
+        auto bpat = [&](int i) { return rP.at(GB::NG + i); };
+        grad_step<T, D, 1>(mk, Sk, bad, C, hk, yk, Rk, wgt, Aat, Gat, bqat, bpat, pump, sink, active);
+        qA += D * D * S; qC += D * D * S;
+        gOm_lane += 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (valid && len > 0 && tau0 + len == nt && io.gOm) {       // the last block of the series: its observation
+        T gH[D], gyv[1], gOmv[1], y1[1] = {ys[nt]}, Rk[1] = {a.rinv[0]};
+        grad_obs<T, D, 1>(hk, y1, Rk, mk, Sk, wgt, gH, gyv, gOmv);
+        io.gOm[s * a.Tn + nt] = gOmv[0];
+    }
+    if (valid && bad && a.info) raise_info(a.info);
+}
+
+}  // namespace mf

@@ -4,7 +4,7 @@
 #ifndef MF_D
 #error "compile with -DMF_D=<state dimension>"
 #endif
-#include "mf_grad_lds.hpp"
+#include "mf_gpr_grad.hpp"
 #include "mf_launch.hpp"
 
 #include <type_traits>
@@ -172,8 +172,93 @@ int grad_run(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, 
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
+// ---- GaussianProcessRegression.log_likelihood: the backward with the kernel -> state-space-model step fused (mf_gpr_grad.hpp) ------
+// Needs the summaries of the fused forward (mf_gpr_matern_loglik on fwd_P chunks of fwd_L transitions): the backward runs on
+// the same partition.  Workspace: boundary states, start moments, the chain's packed records, block 0's marginal.
+template <typename T> struct GprGradWs {
+    size_t post, rec, start_m, start_S, m0, c0, total;
+    GprGradWs(long B, long Tn, long P) {
+        const size_t nt = size_t(Tn - 1);
+        post = align_up(PostWs<T, D>::bytes(B, P) + 256);
+        rec = align_up(size_t(B) * nt * PostLds<T, D, 1, false>::REC);
+        start_m = align_up(size_t(B) * P * D * sizeof(T));
+        start_S = align_up(size_t(B) * P * D * D * sizeof(T));
+        m0 = align_up(size_t(B) * D * sizeof(T));
+        c0 = align_up(size_t(B) * D * D * sizeof(T));
+        total = post + rec + start_m + start_S + m0 + c0;
+    }
+};
+template <typename T> size_t gpr_grad_ws(long B, long Tn, long fwd_P) {
+    if (B < 1 || Tn < 2 || fwd_P < 2) return 0;
+    return GprGradWs<T>(B, Tn, fwd_P).total + 256;
+}
+
+template <typename T, int O0, int O1>
+int gpr_grad_launch(const GprArgs<T>& a, const GprBwdIo<T>& eio, const GradIo<T>& gio, const T* weights, hipStream_t st) {
+    using Gen = GprGen<T, O0, O1>;
+    using GB = GprBwdLds<T, Gen::D, Gen::K0 * Gen::K0 + Gen::K1 * Gen::K1>;
+    static_assert(Gen::D == D, "signature of another state dimension");
+    constexpr int lds = GB::TOTAL;
+    static_assert(lds <= 64 * 1024, "GPR backward: LDS beyond the default dynamic-LDS limit");
+    const dim3 grid((unsigned)cdiv(a.B * a.P, 64)), block(64);
+    hipLaunchKernelGGL((gpr_emit_kernel<T, O0, O1>), grid, block, lds, st, a, eio);
+    hipLaunchKernelGGL((gpr_grad_kernel<T, O0, O1>), grid, block, lds, st, a, gio, weights);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+template <typename T>
+int gpr_grad_run(long B, long Tn, int ncomp, const int* orders, const T* lam, const T* var, int per_series, const T* t, const T* y,
+                 const T* rinv, T jitter, const T* weights, T* g_A, T* g_cholQ, T* g_cholP0, T* g_Om, void* ws, size_t ws_bytes,
+                 int* info, const void* fwd_ws, long fwd_P, long fwd_L, hipStream_t st) {
+    if (B < 1 || Tn < 2 || ncomp < 1 || ncomp > 2) return -101;
+    const long nt = Tn - 1;
+    if (fwd_ws == nullptr || fwd_P < 2 || fwd_L < 1 || (fwd_P - 1) * fwd_L >= nt || fwd_P * fwd_L < nt) return -101;
+    if ((reinterpret_cast<size_t>(g_A) | reinterpret_cast<size_t>(g_cholQ)) & 15) return -101;
+    const long P = fwd_P, L = fwd_L;
+    const GprGradWs<T> lay(B, Tn, P);
+    if (ws == nullptr || ws_bytes < lay.total) return -21;
+    char* p = static_cast<char*>(ws);
+    void* post_ws = p; p += lay.post;
+    void* rec = p; p += lay.rec;
+    T* start_m = reinterpret_cast<T*>(p); p += lay.start_m;
+    T* start_S = reinterpret_cast<T*>(p); p += lay.start_S;
+    T* mu0_post = reinterpret_cast<T*>(p); p += lay.m0;
+    T* cp0_post = reinterpret_cast<T*>(p);
+    const PostWs<T, D> w = PostWs<T, D>::carve(post_ws, B, P);
+    const GradIo<T> gio{rec, w.bPsi, w.bpsi, start_m, start_S, mu0_post, cp0_post, nullptr, g_cholP0, g_A, nullptr, g_cholQ,
+                        nullptr, nullptr, g_Om};
+    const GprBwdIo<T> eio{rec, w.bPsi, w.bpsi, mu0_post, cp0_post};
+    RedSys<T> k0;
+    {
+        T* base = reinterpret_cast<T*>(const_cast<char*>(static_cast<const char*>(fwd_ws)));
+        const long nb = B * P;
+        k0.Dv = base; k0.GU = k0.Dv + nb * D * D; k0.F = k0.GU + nb * D * D; k0.tv = k0.F + nb * D * D;
+        k0.gU = k0.tv + nb * D; k0.sc = k0.gU + nb * D;
+        k0.n = P; k0.f_stride = P; k0.f_off = 0;
+    }
+    int G = 64;
+    if (P <= 32) { G = 1; while (G < P) G <<= 1; }
+    const dim3 sgrid((unsigned)cdiv(B, 64 / G)), block(64);
+    constexpr int scan_lds = PostScanLds<T, D>::BYTES;
+    hipLaunchKernelGGL((k0_scan_kernel<T, D, false>), sgrid, block, scan_lds, st, k0, B, G, 1L, P, gio, info);
+    hipLaunchKernelGGL((k0_scan_kernel<T, D, true>), sgrid, block, scan_lds, st, k0, B, G, 1L, P, gio, info);
+    const GprArgs<T> a{B, Tn, lam, var, per_series ? (long)ncomp : 0L, t, y, rinv, jitter, P, L, info};
+    const int o0 = orders[0], o1 = ncomp > 1 ? orders[1] : 0;
+    int rc = -101;
+    if constexpr (D == 1) { if (o0 == 1 && o1 == 0) rc = gpr_grad_launch<T, 1, 0>(a, eio, gio, weights, st); }
+    if constexpr (D == 2) { if (o0 == 3 && o1 == 0) rc = gpr_grad_launch<T, 3, 0>(a, eio, gio, weights, st); }
+    if constexpr (D == 3) { if (o0 == 5 && o1 == 0) rc = gpr_grad_launch<T, 5, 0>(a, eio, gio, weights, st); }
+    if constexpr (D == 4) { if (o0 == 3 && o1 == 3) rc = gpr_grad_launch<T, 3, 3>(a, eio, gio, weights, st); }
+    if constexpr (D == 5) {
+        if (o0 == 5 && o1 == 3) rc = gpr_grad_launch<T, 5, 3>(a, eio, gio, weights, st);
+        else if (o0 == 3 && o1 == 5) rc = gpr_grad_launch<T, 3, 5>(a, eio, gio, weights, st);
+    }
+    if constexpr (D == 6) { if (o0 == 5 && o1 == 5) rc = gpr_grad_launch<T, 5, 5>(a, eio, gio, weights, st); }
+    return rc;
+}
+
 template <typename T> const GradOps<T>* table() {
-    static const GradOps<T> t = {&grad_ws<T>, &grad_run<T>};
+    static const GradOps<T> t = {&grad_ws<T>, &grad_run<T>, &gpr_grad_ws<T>, &gpr_grad_run<T>};
     return &t;
 }
 

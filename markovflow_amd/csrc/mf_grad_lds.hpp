@@ -313,8 +313,9 @@ template <typename T, int D, int M, bool RSTEP> struct GradPump {
 
 // The gradient rows of one step: matrix rows in two halves and d-vectors through the staging buffer (StagedPiece, mf_post_lds.hpp),
 // stored in a burst as soon as they are staged; d/dy and Omega (M and M^2 values) straight from the lane.
-template <typename T, int D, int M, bool RSTEP> struct GradSink {
-    using GL = GradLds<T, D, M, RSTEP>;
+// (GL: any layout with the piece geometry H0 ... UNITH, B0 and the offsets OFF_stageM, OFF_stagev, OFF_len - GradLds here, GprBwdLds
+// in mf_gpr_grad.hpp)
+template <typename T, int D, int M, typename GL> struct GradSinkT {
     static constexpr int H0 = GL::H0, U0 = GL::U0, U1 = GL::U1, Uv = GL::Uv, UNIT = GL::UNIT, UH = GL::UH, UNITH = GL::UNITH;
     using W = typename OutWord<UNIT>::type;
     using WH = typename OutWord<UNITH>::type;
@@ -376,7 +377,7 @@ template <typename T, int D, int M, bool RSTEP>
 __global__ void __launch_bounds__(64) grad_lds_kernel(KfArgs<T> a, long L, GradIo<T> io) {
     using GL = GradLds<T, D, M, RSTEP>;
     using Cfg = typename GL::Cfg;
-    using Sink = GradSink<T, D, M, RSTEP>;
+    using Sink = GradSinkT<T, D, M, GL>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const long total = a.B * a.P;

@@ -93,6 +93,11 @@ template <typename T> struct GradOps {
                const T* y, const T* Rinv, int rinv_per_step, const T* weights, T* g_mu0, T* g_cholP0, T* g_A, T* g_b, T* g_cholQ,
                T* g_H, T* g_y, T* g_Om, void* ws, size_t ws_bytes, int* info, long chunks, const void* fwd_ws, long fwd_P,
                long fwd_L, hipEvent_t ev0, hipEvent_t ev1, hipStream_t st);
+    // GPR with the kernel -> state-space-model step fused (mf_gpr_grad.hpp); -101: signature / partition not covered
+    size_t (*gpr_ws)(long B, long Tn, long fwd_P);
+    int (*gpr_run)(long B, long Tn, int ncomp, const int* orders, const T* lam, const T* var, int per_series, const T* t,
+                   const T* y, const T* rinv, T jitter, const T* weights, T* g_A, T* g_cholQ, T* g_cholP0, T* g_Om, void* ws,
+                   size_t ws_bytes, int* info, const void* fwd_ws, long fwd_P, long fwd_L, hipStream_t st);
 };
 
 constexpr int MF_MAX_D = 9;        // largest state dimension with a register-resident (lane per chunk) instantiation

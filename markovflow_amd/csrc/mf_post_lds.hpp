@@ -253,8 +253,9 @@ template <typename T, int D, int M, bool RSTEP, bool TRANS = true, int BG = 1> s
 
 // The sink of MODE 2: the packed records (PostLds: REC).  Piece A (the record's first RUa units) is staged when the factor
 // exists and stored during the window of the factor's first half, piece B with the rest of the factor; no transitions.
-template <typename T, int D, int M, bool RSTEP, int BG = 1> struct PackedSink {
-    using PL = PostLds<T, D, M, RSTEP, BG>;
+// (PL: any layout with the record geometry RUa ... NR and the offsets OFF_stageM, OFF_len, OFF_relP - PostLds here, GprBwdLds in
+// mf_gpr_grad.hpp)
+template <typename T, int D, typename PL> struct PackedSinkT {
     static constexpr int RUa = PL::RUa, RUb = PL::RUb, REa = PL::REa, REb = PL::REb, NG = PL::NG, NR = PL::NR;
     using W = typename OutWord<16>::type;
     using PA = StagedPiece<T, RUa, 16>;
@@ -373,7 +374,7 @@ __global__ void __launch_bounds__(64) post_lds_kernel(KfArgs<T> a, long L, RedSy
     constexpr int BG = (MODE == 2) ? backward_row_group(M) : 1;       // MODE 2 runs two wavefronts per CU: LDS for pairs of b and H rows
     using Cfg = KfLdsCfg<T, D, M, RSTEP, BG>;
     using PL = PostLds<T, D, M, RSTEP, BG>;
-    using Sink = std::conditional_t<MODE == 2, PackedSink<T, D, M, RSTEP, BG>, PostSink<T, D, M, RSTEP, true, BG>>;
+    using Sink = std::conditional_t<MODE == 2, PackedSinkT<T, D, PL>, PostSink<T, D, M, RSTEP, true, BG>>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const long total = a.B * a.P;

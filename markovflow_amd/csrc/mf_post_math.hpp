@@ -78,10 +78,13 @@ template <typename T, int D> MF_HD void tri_inv_lower_d(const T (&C)[D][D], cons
 }
 
 // no-op stand-in for the LDS-DMA pump of the device kernels (host simulation, and kernels that load directly)
+#ifndef MF_NOPUMP_DEFINED
+#define MF_NOPUMP_DEFINED
 struct NoPump {
     template <int K> MF_HD void small() const {}
     template <int K> MF_HD void big() const {}
 };
+#endif
 
 // ---- pass 1 ("up"): one transition of the REVERSED partitioned elimination ------------------------------------------------
 // Chunk c owns transitions [c L, min((c+1) L, T-1)) and walks them from the last to the first.  The block its last

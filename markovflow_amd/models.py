@@ -19,6 +19,80 @@ from .posterior import AnalyticPosteriorProcess
 from .state_space_model import StateSpaceModel
 
 
+
+class _GprFusedLogLik(torch.autograd.Function):
+    """Per-series log-likelihood of GP regression (without the chain-independent constants) as a differentiable function of the
+    stacked hyper-parameters ``lam`` (= sqrt(order) / lengthscale), ``var`` and the noise precision, with the kernel -> state space
+    model step fused into BOTH directions: forward ``mf_gpr_matern_loglik_*`` on an explicit time partition (its chunk summaries
+    stay in the workspace), backward ``mf_gpr_matern_loglik_grad_*`` (csrc/mf_gpr_grad.hpp: boundary scans on those summaries, an
+    emit pass and a gradient pass that generate the transitions in registers) followed by the generator's backward
+    (``mf_sde_matern_transitions_grad_*``), which reduces ``g_A``, ``g_cholQ`` to the hyper-parameters.  ``chol_p0`` (the stationary
+    prior's factor as a differentiable torch function of the hyper-parameters) is an input only so that its gradient has a graph to
+    flow into; the kernels generate their own.  Reference: TensorFlow reverse mode through
+    models/gaussian_process_regression.py:150-160, kernels/matern.py, sde_kernel.py:421-446."""
+
+    @staticmethod
+    def forward(ctx, lam_t, var_t, chol_p0, rinv, t, y, orders, per_series, jitter, chunks):
+        bsz, n = t.shape
+        d = sum((o + 1) // 2 for o in orders)
+        nt = n - 1
+        lib = _lib.load()
+        want = chunks if chunks > 0 else max(1, min(-(-65536 // bsz), max(nt // 4, 1)))
+        want = max(1, min(want, nt))
+        length = -(-nt // want)
+        parts = -(-nt // length)
+        ws_bytes = int(lib.mf_kf_loglik_workspace_bytes(bsz, n, d, t.element_size(), want))
+        ws = _lib.workspace(ws_bytes, t.device)
+        out = torch.empty(bsz, dtype=t.dtype, device=t.device)
+        info = _lib.pivot_info(t.device)
+        c_orders = (ctypes.c_int * len(orders))(*orders)
+        lam_c, var_c, rinv_c = lam_t.detach().contiguous(), var_t.detach().contiguous(), rinv.detach().contiguous()
+        rc = _lib.call_rc("mf_gpr_matern_loglik", t.dtype, bsz, n, len(orders), c_orders, _lib.ptr(lam_c), _lib.ptr(var_c),
+                          int(per_series), _lib.ptr(t), _lib.ptr(y), _lib.ptr(rinv_c), jitter, 0.0, _lib.ptr(out), _lib.ptr(ws),
+                          ws_bytes, info, want, None, None, _lib.stream_ptr(t.device))
+        _lib.check(rc, "mf_gpr_matern_loglik")
+        _lib.raise_on_info(info, "GaussianProcessRegression.log_likelihood", t.device)
+        ctx.save_for_backward(lam_c, var_c, rinv_c, t, y)
+        ctx.meta = (orders, per_series, jitter, d, tuple(chol_p0.shape))
+        ctx.fwd = (ws, parts, length)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lam_c, var_c, rinv_c, t, y = ctx.saved_tensors
+        orders, per_series, jitter, d, p0_shape = ctx.meta
+        ws_f, parts, length = ctx.fwd
+        ctx.fwd = None
+        bsz, n = t.shape
+        lib = _lib.load()
+        c_orders = (ctypes.c_int * len(orders))(*orders)
+        with torch.no_grad():
+            g_a = torch.empty((bsz, n - 1, d, d), dtype=t.dtype, device=t.device)
+            g_cq = torch.empty_like(g_a)
+            g_cp0 = torch.empty((bsz, d, d), dtype=t.dtype, device=t.device)
+            g_om = torch.empty((bsz, n), dtype=t.dtype, device=t.device)
+            ws_bytes = int(lib.mf_gpr_matern_loglik_grad_workspace_bytes(bsz, n, d, t.element_size(), parts))
+            ws = _lib.workspace(ws_bytes, t.device)
+            info = _lib.pivot_info(t.device)
+            w = grad_out.reshape(bsz).contiguous()
+            rc = _lib.call_rc("mf_gpr_matern_loglik_grad", t.dtype, bsz, n, len(orders), c_orders, _lib.ptr(lam_c), _lib.ptr(var_c),
+                              int(per_series), _lib.ptr(t), _lib.ptr(y), _lib.ptr(rinv_c), jitter, _lib.ptr(w), _lib.ptr(g_a),
+                              _lib.ptr(g_cq), _lib.ptr(g_cp0), _lib.ptr(g_om), _lib.ptr(ws), ws_bytes, info, _lib.ptr(ws_f), parts,
+                              length, _lib.stream_ptr(t.device))
+            _lib.check(rc, "mf_gpr_matern_loglik_grad")
+            _lib.raise_on_info(info, "GaussianProcessRegression.log_likelihood (backward)", t.device)
+            dt = (t[:, 1:] - t[:, :-1]).contiguous()
+            part = torch.empty((bsz, n - 1, len(orders), 2), dtype=t.dtype, device=t.device)
+            _lib.call("mf_sde_matern_transitions_grad", t.dtype, bsz, n - 1, len(orders), c_orders, _lib.ptr(lam_c), _lib.ptr(var_c),
+                      int(per_series), _lib.ptr(dt), jitter, _lib.ptr(g_a), _lib.ptr(g_cq), _lib.ptr(part), _lib.stream_ptr(t.device))
+            g = torch.sum(part, dim=1)                                   # [B, ncomp, 2]
+            if not per_series:
+                g = torch.sum(g, dim=0)
+            g_p0 = g_cp0 if len(p0_shape) == 3 else torch.sum(g_cp0, dim=0)
+            g_rinv = (-0.5 * torch.sum(g_om)).reshape(1, 1)
+        return g[..., 0].contiguous(), g[..., 1].contiguous(), g_p0.reshape(p0_shape), g_rinv, None, None, None, None, None, None
+
+
 class GaussianProcessRegression:
     """GP regression as a Kalman filter on the kernel's state space model (gaussian_process_regression.py:29-160)."""
 
@@ -80,6 +154,47 @@ class GaussianProcessRegression:
         invisible to that check: call this after such a write."""
         self._fused_cache = None
 
+    fused_backward = True    # set False to force the materialised route whenever a gradient is required
+
+    def _fused_differentiable(self, comps, multi, rows, m, d) -> Optional[torch.Tensor]:
+        """The fused route when a hyper-parameter or the noise requires a gradient: ``_GprFusedLogLik`` (forward AND backward with the
+        kernel -> state space model step fused; d <= 6: one or two components, one output, chains of more than 64 points).  ``None``:
+        the materialised, differentiable route runs (row signatures, observations that require a gradient, short chains)."""
+        n = self._time_points.shape[-1]
+        if (not self.fused_backward or rows or multi or m != 1 or d > 6 or n <= 64 or self._observations.requires_grad
+                or self._time_points.requires_grad):
+            return None
+        dtype, dev = self._observations.dtype, self._observations.device
+        batch = tuple(self._time_points.shape[:-1])
+        t = self._time_points.reshape(-1, n).to(dtype).contiguous()
+        y = self._observations.reshape(-1, n).contiguous()
+        bsz = t.shape[0]
+        nt = n - 1
+        want = self._chunks if self._chunks > 0 else max(1, min(-(-65536 // max(bsz, 1)), max(nt // 4, 1)))
+        if bsz == 0 or -(-nt // (-(-nt // max(1, min(want, nt))))) < 2:
+            return None                     # a single chunk per series leaves no summaries to start the backward from
+        lam = [c._lambda.to(dtype=dtype, device=dev) for c in comps]
+        var = [c._variance_t.to(dtype=dtype, device=dev) for c in comps]
+        per_series = any(x.dim() > 0 for x in lam + var)
+        if per_series:
+            lam_t = torch.stack([x.expand(batch).reshape(-1) for x in lam], dim=-1)
+            var_t = torch.stack([x.expand(batch).reshape(-1) for x in var], dim=-1)
+        else:
+            lam_t, var_t = torch.stack(lam), torch.stack(var)
+        chol = self._chol_obs_covariance.to(dtype=dtype, device=dev)
+        rinv = (1.0 / (chol * chol)).reshape(1, 1)
+        log_det_rinv = torch.log(rinv[0, 0])
+        # the stationary prior's factor as a differentiable function of the hyper-parameters ([d, d], or [B, d, d] per series)
+        p0 = self._kernel.initial_covariance(self._time_points[..., :1])
+        chol_p0 = _lib.checked_cholesky(p0.to(dtype), "GaussianProcessRegression.log_likelihood")
+        chol_p0 = chol_p0.reshape((-1,) + tuple(chol_p0.shape[-2:])) if chol_p0.dim() > 2 else chol_p0
+        if chol_p0.dim() == 3 and chol_p0.shape[0] != bsz:
+            chol_p0 = chol_p0.expand(bsz, d, d)
+        orders = tuple(c.order for c in comps)
+        out = _GprFusedLogLik.apply(lam_t, var_t, chol_p0, rinv, t, y, orders, per_series, self._kernel._jitter, self._chunks)
+        const = -0.5 * math.log(2 * math.pi) * n * m + 0.5 * n * log_det_rinv
+        return (out + const).reshape(batch)
+
     def _fused_log_likelihood_per_series(self) -> Optional[torch.Tensor]:
         """Per-series log-likelihood through ``mf_gpr_matern_loglik_*`` (kernel -> SSM generation fused into the Kalman
         sweep: 16 bytes per step instead of the materialised tensors); ``None`` when the kernel / shapes are not covered."""
@@ -94,7 +209,7 @@ class GaussianProcessRegression:
             return None
         if torch.is_grad_enabled() and (self._kernel._needs_grad() or self._chol_obs_covariance.requires_grad
                                         or self._observations.requires_grad):
-            return None                     # the fused kernel has no backward: the differentiable materialised route runs
+            return self._fused_differentiable(comps, multi, rows, m, d)
         batch = tuple(self._time_points.shape[:-1])
         n, dtype, dev = self._time_points.shape[-1], self._observations.dtype, self._observations.device
         t = self._time_points.reshape(-1, n).to(dtype).contiguous()

@@ -1,0 +1,91 @@
+"""
+GPU parity tests of the fused backward of GaussianProcessRegression.log_likelihood (csrc/mf_gpr_grad.hpp:
+`mf_gpr_matern_loglik_grad_*` + `mf_sde_matern_transitions_grad_*`) - the training step of
+/root/reference/markovflow/models/gaussian_process_regression.py:150-160 under a GradientTape (the reference checks it in
+tests/integration/models/test_gaussian_process_regression.py:117-130).  Gradients with respect to lengthscales, variances and the
+noise against torch autograd through the DENSE GP marginal likelihood (rtol 1e-6), and against the materialised route
+(kernel tensors -> KalmanFilter -> streamed backward -> generator backward) at sizes beyond it.
+"""
+import numpy as np
+import pytest
+import torch
+
+import markovflow_amd as mfa
+from markovflow_amd import _lib
+from test_gpu_kalman import DEV
+
+pytestmark = pytest.mark.gpu
+ORD = {1: mfa.Matern12, 3: mfa.Matern32, 5: mfa.Matern52}
+
+
+def _dense_kernel(order, l, v, r):
+    lam = np.sqrt(float(order)) / l
+    if order == 1:
+        return v * torch.exp(-lam * r)
+    if order == 3:
+        return v * (1 + lam * r) * torch.exp(-lam * r)
+    return v * (1 + lam * r + (lam * r) ** 2 / 3) * torch.exp(-lam * r)
+
+
+def _run(orders, t, y, vals, per_series, fused_backward, chunks=0):
+    names = list(vals)
+    leaves = {k: torch.tensor(v, dtype=torch.float64, device=DEV, requires_grad=True) for k, v in vals.items()}
+    comps = [ORD[o](leaves[f"l{i}"], leaves[f"v{i}"]) for i, o in enumerate(orders)]
+    kern = mfa.Sum(comps) if len(comps) > 1 else comps[0]
+    gpr = mfa.GaussianProcessRegression((torch.tensor(t, device=DEV), torch.tensor(y[..., None], device=DEV)), kern,
+                                        chol_obs_covariance=leaves["s"].reshape(1, 1))
+    gpr.fused_backward = fused_backward
+    gpr._chunks = chunks
+    ll = gpr.log_likelihood()
+    ll.backward()
+    return float(ll.detach()), {k: leaves[k].grad.detach().cpu().numpy() for k in names}
+
+
+@pytest.mark.parametrize("orders,n,bsz,per_series,chunks", [
+    ((5, 5), 90, 2, False, 0), ((5, 5), 101, 3, True, 7), ((5,), 80, 2, False, 0), ((3, 3), 120, 2, True, 0),
+    ((5, 3), 70, 2, False, 5), ((3, 5), 66, 2, True, 3), ((3,), 150, 2, False, 40), ((1,), 100, 3, True, 0),
+])
+def test_fused_backward_vs_dense_gp(rng, monkeypatch, orders, n, bsz, per_series, chunks):
+    t = np.cumsum(0.1 + rng.exponential(0.2, size=(bsz, n)), axis=-1)
+    y = rng.normal(size=(bsz, n))
+    shape = (bsz,) if per_series else ()
+    vals = {"s": np.array(0.3)}
+    for i in range(len(orders)):
+        vals[f"l{i}"] = rng.uniform(0.6, 1.6, size=shape)
+        vals[f"v{i}"] = rng.uniform(0.5, 1.5, size=shape)
+    cpu = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in vals.items()}
+    tt_, yt = torch.tensor(t), torch.tensor(y)
+    total = 0.0
+    for s in range(bsz):
+        r = (tt_[s][:, None] - tt_[s][None, :]).abs()
+        pick = (lambda x: x[s]) if per_series else (lambda x: x)
+        kmat = sum(_dense_kernel(o, pick(cpu[f"l{i}"]), pick(cpu[f"v{i}"]), r) for i, o in enumerate(orders))
+        kn = kmat + cpu["s"] ** 2 * torch.eye(n, dtype=torch.float64)
+        total = total - 0.5 * (yt[s] @ torch.linalg.solve(kn, yt[s]) + torch.linalg.slogdet(kn)[1] + n * np.log(2 * np.pi))
+    total.backward()
+    seen = []
+    real = _lib.call_rc
+
+    def spy(name, *args):
+        seen.append(name)
+        return real(name, *args)
+
+    monkeypatch.setattr(_lib, "call_rc", spy)
+    ll, grads = _run(orders, t, y, vals, per_series, True, chunks)
+    assert "mf_gpr_matern_loglik_grad" in seen, "the fused backward should have run"
+    assert ll == pytest.approx(float(total.detach()), rel=1e-9)
+    for k in vals:
+        np.testing.assert_allclose(grads[k], cpu[k].grad.numpy(), rtol=1e-6, atol=1e-9, err_msg=k)
+
+
+def test_fused_backward_agrees_with_the_materialised_route_on_long_chains(rng):
+    bsz, n = 6, 1500
+    t = np.cumsum(0.05 + rng.exponential(0.05, size=(bsz, n)), axis=-1)
+    y = rng.normal(size=(bsz, n))
+    vals = {"s": np.array(0.4), "l0": rng.uniform(0.6, 1.6, size=(bsz,)), "v0": rng.uniform(0.5, 1.5, size=(bsz,)),
+            "l1": rng.uniform(0.6, 1.6, size=(bsz,)), "v1": rng.uniform(0.5, 1.5, size=(bsz,))}
+    ll_f, g_f = _run((5, 5), t, y, vals, True, True)
+    ll_m, g_m = _run((5, 5), t, y, vals, True, False)
+    assert ll_f == pytest.approx(ll_m, rel=1e-11)
+    for k in vals:
+        np.testing.assert_allclose(g_f[k], g_m[k], rtol=1e-7, atol=1e-9 * (1 + np.abs(g_m[k]).max()), err_msg=k)
