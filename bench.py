@@ -261,10 +261,29 @@ def other_configs(dev):
     gpr = mfa.GaussianProcessRegression((t_pts, y_obs), mfa.Sum(parts, jitter=1e-9),
                                         chol_obs_covariance=(0.1 ** 0.5) * torch.eye(1, dtype=torch.float64, device=dev))
     ms = _time_gpu(gpr.log_likelihood, iters=10)
+    # the training step of the same model: forward + backward w.r.t. lengthscales, variances and the noise factor - both
+    # directions with the kernel -> SSM step fused since round 4 (csrc/mf_gpr_grad.hpp)
+    ls_t = [(0.5 + 1.5 * torch.rand(bsz, dtype=torch.float64, device=dev, generator=g)).requires_grad_(True) for _ in range(2)]
+    var_t = [(0.5 + 1.5 * torch.rand(bsz, dtype=torch.float64, device=dev, generator=g)).requires_grad_(True) for _ in range(2)]
+    chol_t = ((0.1 ** 0.5) * torch.eye(1, dtype=torch.float64, device=dev)).requires_grad_(True)
+
+    def train_step_tgt(fused_backward=True):
+        for x in ls_t + var_t + [chol_t]:
+            x.grad = None
+        kern = mfa.Sum([mfa.Matern52(l, v, jitter=1e-9) for l, v in zip(ls_t, var_t)], jitter=1e-9)
+        model = mfa.GaussianProcessRegression((t_pts, y_obs), kern, chol_obs_covariance=chol_t)
+        model.fused_backward = fused_backward
+        model.log_likelihood().backward()
+
+    ms_train = _time_gpu(train_step_tgt, iters=5, warm=2)
+    ms_train_mat = _time_gpu(lambda: train_step_tgt(False), iters=3, warm=1)
     out["gpr_fused_matern52x2_B1024_T10000_d6_f64"] = {
-        "ms": ms, "steps_per_s": bsz * tn / ms * 1e3,
+        "ms": ms, "steps_per_s": bsz * tn / ms * 1e3, "training_step_ms": ms_train, "training_step_materialised_ms": ms_train_mat,
         "note": "GaussianProcessRegression.log_likelihood through mf_gpr_matern_loglik (A_k, chol Q_k generated in registers); "
-                "NOT the headline metric: the boundary differs (time points + hyper-parameters instead of SSM tensors)"}
+                "NOT the headline metric: the boundary differs (time points + hyper-parameters instead of SSM tensors).  "
+                "training_step_ms: forward + backward w.r.t. every hyper-parameter, both directions fused "
+                "(mf_gpr_matern_loglik_grad + mf_sde_matern_transitions_grad; round 3: 28.1 ms); training_step_materialised_ms: "
+                "kernel tensors -> KalmanFilter -> streamed backward -> generator backward"}
     del t_pts, y_obs, gpr
     # config 4's MODEL: IndependentMultiOutput of three Matern-5/2 kernels (d = 9, 3 outputs), 512 series x 1000 points, from
     # (t, y, hyper-parameters): fused into the row kernel since round 3 (csrc/mf_row_gpr.hpp) against the materialised route
