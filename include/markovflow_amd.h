@@ -266,6 +266,13 @@ int mf_sde_matern_transitions_grad_f64(int64_t B, int64_t n, int ncomp, const in
 int mf_sde_matern_transitions_grad_f32(int64_t B, int64_t n, int ncomp, const int* orders, const float* lam, const float* var,
                                        int per_series, const float* dt, float jitter, const float* g_A, const float* g_cholQ,
                                        float* out, void* stream);
+/* The same with the incoming gradients as packed records (see mf_gpr_matern_loglik_grad): only the entries the generator reads. */
+int mf_sde_matern_transitions_grad_packed_f64(int64_t B, int64_t n, int ncomp, const int* orders, const double* lam,
+                                              const double* var, int per_series, const double* dt, double jitter,
+                                              const double* g_packed, double* out, void* stream);
+int mf_sde_matern_transitions_grad_packed_f32(int64_t B, int64_t n, int ncomp, const int* orders, const float* lam,
+                                              const float* var, int per_series, const float* dt, float jitter,
+                                              const float* g_packed, float* out, void* stream);
 
 /*
  * GaussianProcessRegression.log_likelihood (markovflow/models/gaussian_process_regression.py:150-160) for a Matern kernel or
@@ -398,21 +405,23 @@ int mf_kf_loglik_grad_streamed_f32(int64_t B, int64_t T, int d, int m, const flo
  * emit pass and the gradient pass of the streamed backward, 16 bytes of model per step; the model tensors never exist.
  * fwd_ws: the workspace of the mf_gpr_matern_loglik call on the SAME inputs with an EXPLICIT chunk count C, untouched since;
  * its partition is fwd_chunk_length = ceil((T-1) / C), fwd_chunks_per_series = ceil((T-1) / fwd_chunk_length) >= 2.
- * Outputs: g_A, g_cholQ [B,T-1,d,d] - the derivative of sum_s weights[s] log p(y_s) with respect to the transitions and the
- * Cholesky factors of the process covariances, the inputs of mf_sde_matern_transitions_grad, which reduces them to the
- * hyper-parameters -, g_cholP0 [B,d,d] (the stationary prior's factor), g_omega [B,T] (nullable; E[r^2] per time point: the
+ * Outputs: g_packed [B,T-1,rec] - the derivative of sum_s weights[s] log p(y_s) with respect to the transitions and the Cholesky
+ * factors of the process covariances, ONE record per transition: [the k x k diagonal block of g_A of every component, row-major |
+ * the lower triangle of the diagonal block of g_cholQ of every component, row-major], each part padded to 16 bytes (30 values at
+ * d = 3 + 3 in fp64 instead of 72) - the input of mf_sde_matern_transitions_grad_packed, which reduces it to the hyper-parameters -,
+ * g_cholP0 [B,d,d] (the stationary prior's factor), g_omega [B,T] (nullable; E[r^2] per time point: the
  * derivative with respect to the noise PRECISION is -1/2 of it, + 1/2 R from the log-determinant, which the caller owns).
  * ws: mf_gpr_matern_loglik_grad_workspace_bytes.  -101: signature or partition not covered (materialise instead).
  */
 size_t mf_gpr_matern_loglik_grad_workspace_bytes(int64_t B, int64_t T, int d, int elem_size, int64_t fwd_chunks_per_series);
 int mf_gpr_matern_loglik_grad_f64(int64_t B, int64_t T, int ncomp, const int* orders, const double* lam, const double* var,
                                   int per_series, const double* t, const double* y, const double* rinv, double jitter,
-                                  const double* weights, double* g_A, double* g_cholQ, double* g_cholP0, double* g_omega,
+                                  const double* weights, double* g_packed, double* g_cholP0, double* g_omega,
                                   void* ws, size_t ws_bytes, int* info, const void* fwd_ws, int64_t fwd_chunks_per_series,
                                   int64_t fwd_chunk_length, void* stream);
 int mf_gpr_matern_loglik_grad_f32(int64_t B, int64_t T, int ncomp, const int* orders, const float* lam, const float* var,
                                   int per_series, const float* t, const float* y, const float* rinv, float jitter,
-                                  const float* weights, float* g_A, float* g_cholQ, float* g_cholP0, float* g_omega,
+                                  const float* weights, float* g_packed, float* g_cholP0, float* g_omega,
                                   void* ws, size_t ws_bytes, int* info, const void* fwd_ws, int64_t fwd_chunks_per_series,
                                   int64_t fwd_chunk_length, void* stream);
 /* The level-0 kernel (path: 0 row kernels, 1 spike-in-LDS, 2 streaming, 3 direct loads) and time partition mf_kf_loglik chooses

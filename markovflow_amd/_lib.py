@@ -33,7 +33,9 @@ _SIGS = {
     "mf_ssm_marginals": (_int, [_i64, _i64, _int] + ["Tp"] * 8 + [_vp, _sz, _vp]),
     "mf_block_matmul": (_int, [_i64, _i64, _int, "Tp", _i64, "Tp", _i64, "Tp", _vp]),
     "mf_gpr_matern_loglik_grad": (_int, [_i64, _i64, _int, ctypes.POINTER(ctypes.c_int), "Tp", "Tp", _int, "Tp", "Tp", "Tp", "T",
-                                  "Tp", "Tp", "Tp", "Tp", "Tp", _vp, _sz, _vp, _vp, _i64, _i64, _vp]),
+                                  "Tp", "Tp", "Tp", "Tp", _vp, _sz, _vp, _vp, _i64, _i64, _vp]),
+    "mf_sde_matern_transitions_grad_packed": (_int, [_i64, _i64, _int, ctypes.POINTER(ctypes.c_int), "Tp", "Tp", _int, "Tp", "T", "Tp",
+                                              "Tp", _vp]),
     "mf_gpr_matern_loglik": (_int, [_i64, _i64, _int, ctypes.POINTER(ctypes.c_int), "Tp", "Tp", _int, "Tp", "Tp", "Tp", "T", "T",
                                     "Tp", _vp, _sz, _vp, _i64, _vp, _vp, _vp]),
     "mf_gpr_matern_multi_loglik": (_int, [_i64, _i64, _int, ctypes.POINTER(ctypes.c_int), "Tp", "Tp", _int, "Tp", "Tp", _int, "Tp",

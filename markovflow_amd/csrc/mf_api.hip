@@ -483,19 +483,19 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
     }                                                                                                                  \
     int mf_gpr_matern_loglik_grad_##SUF(int64_t B, int64_t Tn, int ncomp, const int* orders, const T* lam, const T* var, \
                                         int per_series, const T* t, const T* y, const T* rinv, T jitter,                \
-                                        const T* weights, T* g_A, T* g_cholQ, T* g_cholP0, T* g_omega, void* ws,        \
+                                        const T* weights, T* g_packed, T* g_cholP0, T* g_omega, void* ws,              \
                                         size_t ws_bytes, int* info, const void* fwd_ws,                                \
                                         int64_t fwd_chunks_per_series, int64_t fwd_chunk_length, void* stream) {       \
         if (B < 1) return -1;                                                                                          \
         if (Tn < 2) return -2;                                                                                         \
         if (ncomp < 1 || !orders) return -3;                                                                           \
         if (!lam || !var || !t || !y || !rinv) return -5;                                                              \
-        if (!g_A || !g_cholQ || !g_cholP0) return -13;                                                                 \
+        if (!g_packed || !g_cholP0) return -13;                                                                        \
         int d = 0;                                                                                                     \
         for (int c = 0; c < ncomp; ++c) d += (orders[c] + 1) / 2;                                                      \
         const auto* gt = grad_table_for<T>(d);                                                                         \
         if (!gt) return -101;                                                                                          \
-        return gt->gpr_run(B, Tn, ncomp, orders, lam, var, per_series, t, y, rinv, jitter, weights, g_A, g_cholQ,       \
+        return gt->gpr_run(B, Tn, ncomp, orders, lam, var, per_series, t, y, rinv, jitter, weights, g_packed,           \
                            g_cholP0, g_omega, ws, ws_bytes, info, fwd_ws, fwd_chunks_per_series, fwd_chunk_length,      \
                            S(stream));                                                                                 \
     }                                                                                                                  \

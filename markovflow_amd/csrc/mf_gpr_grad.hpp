@@ -8,9 +8,9 @@
 //   forward (mf_gpr_matern_loglik)    leaves one summary per (series, chunk) in its workspace, in the form of mf_kf_loglik's
 //   k0_scan_kernel x 2                 boundary states and start moments from those summaries (mf_grad_lds.hpp)
 //   gpr_emit_kernel                    the posterior chain's chol(Q'), b' as packed records, backward in time
-//   gpr_grad_kernel                    forward in time: smoothed marginals in registers; writes g_A, g_cholQ (what the generator's
-//                                      backward, mf_sde_matern_transitions_grad, contracts with its forward-mode duals), g_cholP0
-//                                      and Omega (the noise's gradient)
+//   gpr_grad_kernel                    forward in time: smoothed marginals in registers; writes the diagonal blocks of g_A and of
+//                                      g_cholQ as packed records (what the generator's backward, mf_sde_matern_transitions_grad_packed,
+//                                      contracts with its forward-mode duals), g_cholP0 and Omega (the noise's gradient)
 // No input image in LDS: both kernels run one wavefront per SIMD on the forward's own partition.
 #pragma once
 #include "mf_gpr_fused.hpp"
@@ -30,13 +30,77 @@ template <typename T, int D, int NA> struct GprBwdLds {
     static constexpr int OFF_Amat = OFF_P + StP::LDS_BYTES;        // this step's A_k, NA entries per lane
     static constexpr int OFF_stageM = OFF_Amat + ((64 * NA * S + 15) / 16) * 16;
     static constexpr int OFF_stagev = OFF_stageM;
-    static constexpr int STAGE0 = 64 * (B0 > Bv ? B0 : Bv), STAGE1 = 64 * RUa * 16;
+    // (one staging buffer for every piece: halves of the chain's record, the two parts of the gradient record)
+    static constexpr int STAGE0 = 64 * (((NA * S + 15) / 16) * 16), STAGE1 = 64 * RUa * 16;
     static constexpr int OFF_len = OFF_stageM + (((STAGE0 > STAGE1 ? STAGE0 : STAGE1) + 15) / 16) * 16;
     static constexpr int OFF_relP = OFF_len + 256;
     static constexpr int OFF_relA = OFF_relP + 256;
     static constexpr int OFF_relv = OFF_relA + 256;
     static constexpr int OFF_hyp = OFF_relv + 256;                 // lam0, var0, lam1, var1, R^-1 per lane
     static constexpr int TOTAL = OFF_hyp + 5 * 64 * S;
+    // the gradients as the generator's backward reads them (mf_sde_matern_transitions_grad_packed): one record per transition,
+    // [the diagonal blocks of g_A, row-major | the lower triangles of the diagonal blocks of g_cholQ], each part padded to 16 bytes
+    // - 240 B at d = 6 (3 + 3) fp64 instead of two d x d rows of 288 B, of which the generator ignores 58 %
+    template <int K0, int K1> struct Grec {
+        static constexpr int NGA = K0 * K0 + K1 * K1, NGC = K0 * (K0 + 1) / 2 + K1 * (K1 + 1) / 2;
+        static constexpr int RGA = ((NGA * S + 15) / 16) * 16, RGC = ((NGC * S + 15) / 16) * 16, RECG = RGA + RGC;
+        static constexpr int NUA = RGA / 16, NUC = RGC / 16, EA = RGA / S, EC = RGC / S;
+        static_assert(64 * RGA <= (STAGE0 > STAGE1 ? STAGE0 : STAGE1) && 64 * RGC <= (STAGE0 > STAGE1 ? STAGE0 : STAGE1), "staging buffer");
+    };
+};
+
+// The sink of the gradient pass: the packed record in two pieces (the blocks of g_A when its second half exists, the factor's
+// when its second half exists), Omega straight from the lane; nothing else is wanted.
+template <typename T, int D, int K0, int K1, typename GB> struct GprGradSink {
+    using GR = typename GB::template Grec<K0, K1>;
+    static constexpr int H0 = (D + 1) / 2, NUA = GR::NUA, NUC = GR::NUC;
+    using W = typename OutWord<16>::type;
+    using PA = StagedPiece<T, NUA, 16>;
+    using PC = StagedPiece<T, NUC, 16>;
+    char* smem; int lane;
+    DmaStream<OutPiece<NUA, 16>> da;
+    DmaStream<OutPiece<NUC, 16>> dc;
+    unsigned long long qG, fG;
+    T* gOm;
+    long e, minlen;
+    bool want_Om;
+    W ma, mb;
+    T recA[GR::EA], recC[GR::EC];
+    MF_DEV void init(char* smem_, int lane_, int rel_g) {
+        smem = smem_; lane = lane_;
+        da.init(smem, lane, rel_g, 0);
+        dc.init(smem, lane, rel_g, 0);
+        MF_UNROLL for (int i = 0; i < GR::EA; ++i) recA[i] = T(0);
+        MF_UNROLL for (int i = 0; i < GR::EC; ++i) recC[i] = T(0);
+    }
+    static constexpr bool same_block(int i, int j) { return (i < K0) == (j < K0); }
+    static constexpr int idx_a(int i, int j) { return i < K0 ? i * K0 + j : K0 * K0 + (i - K0) * K1 + (j - K0); }
+    static constexpr int idx_c(int i, int j) {
+        return i < K0 ? i * (i + 1) / 2 + j : K0 * (K0 + 1) / 2 + (i - K0) * (i - K0 + 1) / 2 + (j - K0);
+    }
+    template <typename P, int NU, typename DS> MF_DEV void burst(const DS& ds, unsigned long long q, const T* row) {
+        const mf_v4i srd = make_srd(q, fG);
+        P::stage(smem, GB::OFF_stageM, lane, row, ma);
+        static_for<0, NU>([&](auto ic) {
+            P::template unit<decltype(ic)::value>(smem, GB::OFF_stageM, GB::OFF_len, lane, ds.vo, srd, e < minlen, e, ma, mb);
+        });
+    }
+    template <int HALF, int R> MF_DEV void put_gA(const T (&rows)[R][D], bool) {
+        MF_UNROLL for (int r = 0; r < R; ++r)
+            MF_UNROLL for (int j = 0; j < D; ++j)
+                if (same_block(HALF * H0 + r, j)) recA[idx_a(HALF * H0 + r, j)] = rows[r][j];
+        if constexpr (HALF == 1 || D - H0 == 0) burst<PA, NUA>(da, qG, recA);
+    }
+    template <int HALF, int R> MF_DEV void put_gC(const T (&rows)[R][D], bool) {
+        MF_UNROLL for (int r = 0; r < R; ++r)
+            MF_UNROLL for (int j = 0; j < D; ++j)
+                if (j <= HALF * H0 + r && same_block(HALF * H0 + r, j)) recC[idx_c(HALF * H0 + r, j)] = rows[r][j];
+        if constexpr (HALF == 1 || D - H0 == 0) burst<PC, NUC>(dc, qG + GR::RGA, recC);
+    }
+    MF_DEV void put_gb(const T (&)[D], bool) {}
+    MF_DEV void put_obs(const T (&)[D], const T (&)[1], const T (&gOmv)[1], bool active) {
+        if (active && want_Om) gOm[0] = gOmv[0];
+    }
 };
 
 template <typename T> struct GprBwdIo {
@@ -171,7 +235,8 @@ __global__ void __launch_bounds__(64) gpr_grad_kernel(GprArgs<T> a, GradIo<T> io
     constexpr int D = Gen::D, S = sizeof(T);
     constexpr int K0 = Gen::K0, K1 = Gen::K1, NA = K0 * K0 + K1 * K1;
     using GB = GprBwdLds<T, D, NA>;
-    using Sink = GradSinkT<T, D, 1, GB>;
+    using GR = typename GB::template Grec<K0, K1>;
+    using Sink = GprGradSink<T, D, K0, K1, GB>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const long total = a.B * a.P;
@@ -192,13 +257,12 @@ __global__ void __launch_bounds__(64) gpr_grad_kernel(GprArgs<T> a, GradIo<T> io
     }
     nsteps = __builtin_amdgcn_readfirstlane((int)nsteps);
     minlen = __builtin_amdgcn_readfirstlane((int)minlen);
-    const unsigned long long offA = (unsigned long long)(s * nt + tau0) * (D * D * S), offA0 = uniform64(offA);
+    const unsigned long long offG = (unsigned long long)(s * nt + tau0) * GR::RECG, offG0 = uniform64(offG);
     const unsigned long long offP = (unsigned long long)(s * nt + tau0) * GB::REC, offP0 = uniform64(offP);
     const bool rowok = valid && len > 0;
     {
         unsigned* tab = reinterpret_cast<unsigned*>(smem);
-        tab[GB::OFF_relA / 4 + lane] = rowok ? (unsigned)(offA - offA0) : MF_DMA_INVALID;
-        tab[GB::OFF_relv / 4 + lane] = MF_DMA_INVALID;              // (no vector rows are stored)
+        tab[GB::OFF_relA / 4 + lane] = rowok ? (unsigned)(offG - offG0) : MF_DMA_INVALID;        // rows of the gradient records
         tab[GB::OFF_relP / 4 + lane] = rowok ? (unsigned)(offP - offP0) : MF_DMA_INVALID;
         reinterpret_cast<int*>(smem)[GB::OFF_len / 4 + lane] = rowok ? (int)len : 0;
     }
@@ -242,12 +306,11 @@ __global__ void __launch_bounds__(64) gpr_grad_kernel(GprArgs<T> a, GradIo<T> io
     DmaStream<typename GB::StP> dP;
     dP.init(smem, lane, GB::OFF_relP, 0);
     Sink sink;
-    sink.init(smem, lane, GB::OFF_relA, GB::OFF_relv, GB::OFF_relv);
-    const unsigned long long nA = (unsigned long long)a.B * nt * (D * D * S);
-    sink.fA = (unsigned long long)io.gA + nA; sink.fC = (unsigned long long)io.gC + nA; sink.fb = 0; sink.fH = 0;
+    sink.init(smem, lane, GB::OFF_relA);
+    sink.fG = (unsigned long long)io.gA + (unsigned long long)a.B * nt * GR::RECG;      // io.gA: the packed gradient records
     sink.minlen = minlen;
-    sink.want_b = false; sink.want_H = false; sink.want_y = false; sink.want_Om = io.gOm != nullptr;
-    unsigned long long qA = (unsigned long long)io.gA + offA0, qC = (unsigned long long)io.gC + offA0;
+    sink.want_Om = io.gOm != nullptr;
+    unsigned long long qG = (unsigned long long)io.gA + offG0;
     T* gOm_lane = io.gOm + (s * a.Tn + tau0);
     const unsigned lds0 = (unsigned)(size_t)smem;
     unsigned long long pP = (unsigned long long)io.rec_post + offP0;
@@ -277,8 +340,8 @@ __global__ void __launch_bounds__(64) gpr_grad_kernel(GprArgs<T> a, GradIo<T> io
             MF_UNROLL for (int i = 0; i < K1; ++i) MF_UNROLL for (int jj = 0; jj < K1; ++jj) Amat[K0 * K0 + i * K1 + jj] = Am[K0 + i][K0 + jj];
         }
         const Pump pump{dP, make_srd(pP, eP), lds0, more};
-        sink.qA = qA; sink.qC = qC; sink.qb = 0; sink.qH = 0; sink.e = j;
-        sink.gy = nullptr; sink.gOm = gOm_lane;
+        sink.qG = qG; sink.e = j;
+        sink.gOm = gOm_lane;
         // (A_k is block diagonal: its zeros are known at compile time)
         auto Aat = [&](int i, int jj) {
             if (i < K0 && jj < K0) return Amat[i * K0 + jj];
@@ -289,7 +352,7 @@ __global__ void __launch_bounds__(64) gpr_grad_kernel(GprArgs<T> a, GradIo<T> io
         auto bqat = [&](int) { return T(0); };
         auto bpat = [&](int i) { return rP.at(GB::NG + i); };
         grad_step<T, D, 1>(mk, Sk, bad, C, hk, yk, Rk, wgt, Aat, Gat, bqat, bpat, pump, sink, active);
-        qA += D * D * S; qC += D * D * S;
+        qG += GR::RECG;
         gOm_lane += 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -208,12 +208,12 @@ int gpr_grad_launch(const GprArgs<T>& a, const GprBwdIo<T>& eio, const GradIo<T>
 
 template <typename T>
 int gpr_grad_run(long B, long Tn, int ncomp, const int* orders, const T* lam, const T* var, int per_series, const T* t, const T* y,
-                 const T* rinv, T jitter, const T* weights, T* g_A, T* g_cholQ, T* g_cholP0, T* g_Om, void* ws, size_t ws_bytes,
+                 const T* rinv, T jitter, const T* weights, T* g_packed, T* g_cholP0, T* g_Om, void* ws, size_t ws_bytes,
                  int* info, const void* fwd_ws, long fwd_P, long fwd_L, hipStream_t st) {
     if (B < 1 || Tn < 2 || ncomp < 1 || ncomp > 2) return -101;
     const long nt = Tn - 1;
     if (fwd_ws == nullptr || fwd_P < 2 || fwd_L < 1 || (fwd_P - 1) * fwd_L >= nt || fwd_P * fwd_L < nt) return -101;
-    if ((reinterpret_cast<size_t>(g_A) | reinterpret_cast<size_t>(g_cholQ)) & 15) return -101;
+    if (reinterpret_cast<size_t>(g_packed) & 15) return -101;
     const long P = fwd_P, L = fwd_L;
     const GprGradWs<T> lay(B, Tn, P);
     if (ws == nullptr || ws_bytes < lay.total) return -21;
@@ -225,7 +225,7 @@ int gpr_grad_run(long B, long Tn, int ncomp, const int* orders, const T* lam, co
     T* mu0_post = reinterpret_cast<T*>(p); p += lay.m0;
     T* cp0_post = reinterpret_cast<T*>(p);
     const PostWs<T, D> w = PostWs<T, D>::carve(post_ws, B, P);
-    const GradIo<T> gio{rec, w.bPsi, w.bpsi, start_m, start_S, mu0_post, cp0_post, nullptr, g_cholP0, g_A, nullptr, g_cholQ,
+    const GradIo<T> gio{rec, w.bPsi, w.bpsi, start_m, start_S, mu0_post, cp0_post, nullptr, g_cholP0, g_packed, nullptr, nullptr,
                         nullptr, nullptr, g_Om};
     const GprBwdIo<T> eio{rec, w.bPsi, w.bpsi, mu0_post, cp0_post};
     RedSys<T> k0;

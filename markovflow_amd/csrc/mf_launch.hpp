@@ -96,7 +96,7 @@ template <typename T> struct GradOps {
     // GPR with the kernel -> state-space-model step fused (mf_gpr_grad.hpp); -101: signature / partition not covered
     size_t (*gpr_ws)(long B, long Tn, long fwd_P);
     int (*gpr_run)(long B, long Tn, int ncomp, const int* orders, const T* lam, const T* var, int per_series, const T* t,
-                   const T* y, const T* rinv, T jitter, const T* weights, T* g_A, T* g_cholQ, T* g_cholP0, T* g_Om, void* ws,
+                   const T* y, const T* rinv, T jitter, const T* weights, T* g_packed, T* g_cholP0, T* g_Om, void* ws,
                    size_t ws_bytes, int* info, const void* fwd_ws, long fwd_P, long fwd_L, hipStream_t st);
 };
 

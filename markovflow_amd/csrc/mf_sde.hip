@@ -232,8 +232,10 @@ int run(int64_t B, int64_t n, int ncomp, const int* orders, const T* lam, const 
 // :421-446 and the banded Cholesky through TensorFlow; here gA, gC come from the Fisher-identity backward of the log-likelihood.)
 // One lane per (series, transition): the component's closed forms in forward mode (Dual2: tangents d/d lam, d/d var), contracted
 // with the incoming gradients' diagonal blocks; out [B, n, ncomp, 2] - summed over the transitions by the caller (deterministic).
+// (gA / gC point at the component's own block: dense tensors with row stride ld, or - packed - the K x K block row-major and the
+// lower triangle of the factor's block row-major)
 template <typename T, int K>
-__device__ __forceinline__ void grad_component(T lam, T var, T dt, T jitter, int d, int off, const T* __restrict__ gA,
+__device__ __forceinline__ void grad_component(T lam, T var, T dt, T jitter, int ld, bool packed, const T* __restrict__ gA,
                                                const T* __restrict__ gC, T& g_lam, T& g_var) {
     using Du = Dual2<T>;
     Comp<Du, K> c;
@@ -243,7 +245,7 @@ __device__ __forceinline__ void grad_component(T lam, T var, T dt, T jitter, int
     if (gA) {
         for (int i = 0; i < K; ++i)
             for (int j = 0; j < K; ++j) {
-                const T g = gA[(off + i) * d + off + j];
+                const T g = gA[i * (packed ? K : ld) + j];
                 g_lam += g * c.A[i][j].a;
                 g_var += g * c.A[i][j].b;
             }
@@ -255,31 +257,41 @@ __device__ __forceinline__ void grad_component(T lam, T var, T dt, T jitter, int
         if (!zero) {
             for (int i = 0; i < K; ++i)
                 for (int j = 0; j <= i; ++j) {
-                    const T g = gC[(off + i) * d + off + j];
+                    const T g = packed ? gC[i * (i + 1) / 2 + j] : gC[i * ld + j];
                     g_lam += g * L[i][j].a;
                     g_var += g * L[i][j].b;
                 }
         }
     }
 }
+// packed = 0: gA, gC are the dense [B, n, d, d] tensors.  packed = 1: gA is ONE record per transition of `rec` elements -
+// [the K x K block of g_A of every component | the lower triangle of the block of g_cholQ of every component], what
+// mf_gpr_matern_loglik_grad writes (csrc/mf_gpr_grad.hpp) - and gC is ignored.
 template <typename T>
 __global__ void __launch_bounds__(64) matern_transitions_grad_kernel(long B, long n, Spec sp, const T* __restrict__ lam,
                                                                      const T* __restrict__ var, long hstride,
                                                                      const T* __restrict__ dt, T jitter, const T* __restrict__ gA,
-                                                                     const T* __restrict__ gC, T* __restrict__ out) {
+                                                                     const T* __restrict__ gC, int packed, int rec,
+                                                                     T* __restrict__ out) {
     const long id = (long)blockIdx.x * 64 + threadIdx.x;
     if (id >= B * n) return;
     const long s = id / n;
     const int d = sp.d;
     const T delta = dt[id];
-    const T* ga = gA ? gA + id * d * d : nullptr;
-    const T* gc = gC ? gC + id * d * d : nullptr;
+    int na = 0;
+    for (int c = 0; c < sp.ncomp; ++c) { const int k = (sp.order[c] + 1) / 2; na += k * k; }
+    int pa = 0, pc = (int)(((na * sizeof(T) + 15) / 16) * 16 / sizeof(T));      // the factor's part starts on a 16-byte unit
     for (int c = 0; c < sp.ncomp; ++c) {
         const T l = lam[s * hstride + c], v = var[s * hstride + c];
+        const int k = (sp.order[c] + 1) / 2, off = sp.off[c];
+        const T* ga = packed ? gA + id * rec + pa : (gA ? gA + id * d * d + off * d + off : nullptr);
+        const T* gc = packed ? gA + id * rec + pc : (gC ? gC + id * d * d + off * d + off : nullptr);
+        pa += k * k;
+        pc += k * (k + 1) / 2;
         T gl, gv;
-        if (sp.order[c] == 1) grad_component<T, 1>(l, v, delta, jitter, d, sp.off[c], ga, gc, gl, gv);
-        else if (sp.order[c] == 3) grad_component<T, 2>(l, v, delta, jitter, d, sp.off[c], ga, gc, gl, gv);
-        else grad_component<T, 3>(l, v, delta, jitter, d, sp.off[c], ga, gc, gl, gv);
+        if (sp.order[c] == 1) grad_component<T, 1>(l, v, delta, jitter, d, packed != 0, ga, gc, gl, gv);
+        else if (sp.order[c] == 3) grad_component<T, 2>(l, v, delta, jitter, d, packed != 0, ga, gc, gl, gv);
+        else grad_component<T, 3>(l, v, delta, jitter, d, packed != 0, ga, gc, gl, gv);
         out[(id * sp.ncomp + c) * 2] = gl;
         out[(id * sp.ncomp + c) * 2 + 1] = gv;
     }
@@ -287,7 +299,7 @@ __global__ void __launch_bounds__(64) matern_transitions_grad_kernel(long B, lon
 
 template <typename T>
 int run_grad(int64_t B, int64_t n, int ncomp, const int* orders, const T* lam, const T* var, int per_series, const T* dt, T jitter,
-             const T* gA, const T* gC, T* out, void* stream) {
+             const T* gA, const T* gC, int packed, T* out, void* stream) {
     if (B < 0) return -1;
     if (n < 0) return -2;
     if (ncomp < 1 || ncomp > MAXC) return -3;
@@ -307,10 +319,14 @@ int run_grad(int64_t B, int64_t n, int ncomp, const int* orders, const T* lam, c
     if (!var) return -6;
     if (!dt) return -8;
     if (!out) return -12;
+    if (packed && !gA) return -10;
+    int ra = 0, rc = 0;               // elements of a packed record: blocks of g_A | lower triangles of g_cholQ, each padded to 16 bytes
+    for (int c = 0; c < ncomp; ++c) { const int k = (orders[c] + 1) / 2; ra += k * k; rc += k * (k + 1) / 2; }
+    const int rec = (int)((((ra * sizeof(T) + 15) / 16) * 16 + ((rc * sizeof(T) + 15) / 16) * 16) / sizeof(T));
     const long total = B * n;
     hipLaunchKernelGGL((matern_transitions_grad_kernel<T>), dim3((unsigned)((total + 63) / 64)), dim3(64), 0,
                        static_cast<hipStream_t>(stream), (long)B, (long)n, sp, lam, var, per_series ? (long)ncomp : 0L, dt, jitter,
-                       gA, gC, out);
+                       gA, gC, packed, rec, out);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
@@ -375,12 +391,22 @@ int mf_sde_matern_transitions_f32(int64_t B, int64_t n, int ncomp, const int* or
 int mf_sde_matern_transitions_grad_f64(int64_t B, int64_t n, int ncomp, const int* orders, const double* lam, const double* var,
                                        int per_series, const double* dt, double jitter, const double* g_A, const double* g_cholQ,
                                        double* out, void* stream) {
-    return run_grad<double>(B, n, ncomp, orders, lam, var, per_series, dt, jitter, g_A, g_cholQ, out, stream);
+    return run_grad<double>(B, n, ncomp, orders, lam, var, per_series, dt, jitter, g_A, g_cholQ, 0, out, stream);
 }
 int mf_sde_matern_transitions_grad_f32(int64_t B, int64_t n, int ncomp, const int* orders, const float* lam, const float* var,
                                        int per_series, const float* dt, float jitter, const float* g_A, const float* g_cholQ,
                                        float* out, void* stream) {
-    return run_grad<float>(B, n, ncomp, orders, lam, var, per_series, dt, jitter, g_A, g_cholQ, out, stream);
+    return run_grad<float>(B, n, ncomp, orders, lam, var, per_series, dt, jitter, g_A, g_cholQ, 0, out, stream);
+}
+int mf_sde_matern_transitions_grad_packed_f64(int64_t B, int64_t n, int ncomp, const int* orders, const double* lam,
+                                              const double* var, int per_series, const double* dt, double jitter,
+                                              const double* g_packed, double* out, void* stream) {
+    return run_grad<double>(B, n, ncomp, orders, lam, var, per_series, dt, jitter, g_packed, nullptr, 1, out, stream);
+}
+int mf_sde_matern_transitions_grad_packed_f32(int64_t B, int64_t n, int ncomp, const int* orders, const float* lam,
+                                              const float* var, int per_series, const float* dt, float jitter,
+                                              const float* g_packed, float* out, void* stream) {
+    return run_grad<float>(B, n, ncomp, orders, lam, var, per_series, dt, jitter, g_packed, nullptr, 1, out, stream);
 }
 
 }  // extern "C"

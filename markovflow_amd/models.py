@@ -67,8 +67,12 @@ class _GprFusedLogLik(torch.autograd.Function):
         lib = _lib.load()
         c_orders = (ctypes.c_int * len(orders))(*orders)
         with torch.no_grad():
-            g_a = torch.empty((bsz, n - 1, d, d), dtype=t.dtype, device=t.device)
-            g_cq = torch.empty_like(g_a)
+            # one packed record per transition: the diagonal blocks of g_A | the lower triangles of those of g_cholQ (16-B padded parts)
+            esz = t.element_size()
+            sizes = [(o + 1) // 2 for o in orders]
+            pad = lambda nel: -(-nel * esz // 16) * 16 // esz                                         # noqa: E731
+            rec = pad(sum(k * k for k in sizes)) + pad(sum(k * (k + 1) // 2 for k in sizes))
+            g_packed = torch.empty((bsz, n - 1, rec), dtype=t.dtype, device=t.device)
             g_cp0 = torch.empty((bsz, d, d), dtype=t.dtype, device=t.device)
             g_om = torch.empty((bsz, n), dtype=t.dtype, device=t.device)
             ws_bytes = int(lib.mf_gpr_matern_loglik_grad_workspace_bytes(bsz, n, d, t.element_size(), parts))
@@ -76,15 +80,16 @@ class _GprFusedLogLik(torch.autograd.Function):
             info = _lib.pivot_info(t.device)
             w = grad_out.reshape(bsz).contiguous()
             rc = _lib.call_rc("mf_gpr_matern_loglik_grad", t.dtype, bsz, n, len(orders), c_orders, _lib.ptr(lam_c), _lib.ptr(var_c),
-                              int(per_series), _lib.ptr(t), _lib.ptr(y), _lib.ptr(rinv_c), jitter, _lib.ptr(w), _lib.ptr(g_a),
-                              _lib.ptr(g_cq), _lib.ptr(g_cp0), _lib.ptr(g_om), _lib.ptr(ws), ws_bytes, info, _lib.ptr(ws_f), parts,
-                              length, _lib.stream_ptr(t.device))
+                              int(per_series), _lib.ptr(t), _lib.ptr(y), _lib.ptr(rinv_c), jitter, _lib.ptr(w), _lib.ptr(g_packed),
+                              _lib.ptr(g_cp0), _lib.ptr(g_om), _lib.ptr(ws), ws_bytes, info, _lib.ptr(ws_f), parts, length,
+                              _lib.stream_ptr(t.device))
             _lib.check(rc, "mf_gpr_matern_loglik_grad")
             _lib.raise_on_info(info, "GaussianProcessRegression.log_likelihood (backward)", t.device)
             dt = (t[:, 1:] - t[:, :-1]).contiguous()
             part = torch.empty((bsz, n - 1, len(orders), 2), dtype=t.dtype, device=t.device)
-            _lib.call("mf_sde_matern_transitions_grad", t.dtype, bsz, n - 1, len(orders), c_orders, _lib.ptr(lam_c), _lib.ptr(var_c),
-                      int(per_series), _lib.ptr(dt), jitter, _lib.ptr(g_a), _lib.ptr(g_cq), _lib.ptr(part), _lib.stream_ptr(t.device))
+            _lib.call("mf_sde_matern_transitions_grad_packed", t.dtype, bsz, n - 1, len(orders), c_orders, _lib.ptr(lam_c),
+                      _lib.ptr(var_c), int(per_series), _lib.ptr(dt), jitter, _lib.ptr(g_packed), _lib.ptr(part),
+                      _lib.stream_ptr(t.device))
             g = torch.sum(part, dim=1)                                   # [B, ncomp, 2]
             if not per_series:
                 g = torch.sum(g, dim=0)
