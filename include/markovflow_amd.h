@@ -273,6 +273,13 @@ int mf_sde_matern_transitions_grad_packed_f64(int64_t B, int64_t n, int ncomp, c
 int mf_sde_matern_transitions_grad_packed_f32(int64_t B, int64_t n, int ncomp, const int* orders, const float* lam,
                                               const float* var, int per_series, const float* dt, float jitter,
                                               const float* g_packed, float* out, void* stream);
+/* The stationary prior of the same kernels, chol(Pinf + jitter) (markovflow/kernels/sde_kernel.py:402-419): out [B,ncomp,2] =
+ * the contraction of g_cholP0 [B,d,d] (only the lower triangles of its diagonal blocks are read) with d chol / d (lam, var) of
+ * every component - per series; a caller with shared hyper-parameters (per_series = 0) sums over the batch. */
+int mf_sde_matern_prior_chol_grad_f64(int64_t B, int ncomp, const int* orders, const double* lam, const double* var, int per_series,
+                                      double jitter, const double* g_cholP0, double* out, void* stream);
+int mf_sde_matern_prior_chol_grad_f32(int64_t B, int ncomp, const int* orders, const float* lam, const float* var, int per_series,
+                                      float jitter, const float* g_cholP0, float* out, void* stream);
 
 /*
  * GaussianProcessRegression.log_likelihood (markovflow/models/gaussian_process_regression.py:150-160) for a Matern kernel or

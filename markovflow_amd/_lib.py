@@ -34,6 +34,7 @@ _SIGS = {
     "mf_block_matmul": (_int, [_i64, _i64, _int, "Tp", _i64, "Tp", _i64, "Tp", _vp]),
     "mf_gpr_matern_loglik_grad": (_int, [_i64, _i64, _int, ctypes.POINTER(ctypes.c_int), "Tp", "Tp", _int, "Tp", "Tp", "Tp", "T",
                                   "Tp", "Tp", "Tp", "Tp", _vp, _sz, _vp, _vp, _i64, _i64, _vp]),
+    "mf_sde_matern_prior_chol_grad": (_int, [_i64, _int, ctypes.POINTER(ctypes.c_int), "Tp", "Tp", _int, "T", "Tp", "Tp", _vp]),
     "mf_sde_matern_transitions_grad_packed": (_int, [_i64, _i64, _int, ctypes.POINTER(ctypes.c_int), "Tp", "Tp", _int, "Tp", "T", "Tp",
                                               "Tp", _vp]),
     "mf_gpr_matern_loglik": (_int, [_i64, _i64, _int, ctypes.POINTER(ctypes.c_int), "Tp", "Tp", _int, "Tp", "Tp", "Tp", "T", "T",

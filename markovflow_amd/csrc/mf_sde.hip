@@ -297,6 +297,71 @@ __global__ void __launch_bounds__(64) matern_transitions_grad_kernel(long B, lon
     }
 }
 
+// The stationary prior's factor chol(Pinf + jitter), block by block: out[s, c, :] = <g_cholP0 block c, d chol / d (lam, var)>.
+// (Comp::build with the transition zeroed: Q = Pinf + jitter.)
+template <typename T, int K>
+__device__ __forceinline__ void prior_component(T lam, T var, T jitter, int ld, const T* __restrict__ gC, T& g_lam, T& g_var) {
+    using Du = Dual2<T>;
+    Comp<Du, K> c;
+    c.build(Du(lam, T(1), T(0)), Du(var, T(0), T(1)), Du(T(1)));
+    for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) c.A[i][j] = Du(T(0));
+    Du Q[K][K], L[K][K];
+    bool zero;
+    comp_chol<Du, K>(c, Du(jitter), Q, L, zero, true);
+    g_lam = T(0);
+    g_var = T(0);
+    if (zero) return;
+    for (int i = 0; i < K; ++i)
+        for (int j = 0; j <= i; ++j) {
+            const T g = gC[i * ld + j];
+            g_lam += g * L[i][j].a;
+            g_var += g * L[i][j].b;
+        }
+}
+template <typename T>
+__global__ void __launch_bounds__(64) matern_prior_grad_kernel(long B, Spec sp, const T* __restrict__ lam, const T* __restrict__ var,
+                                                               long hstride, T jitter, const T* __restrict__ gC0, T* __restrict__ out) {
+    const long s = (long)blockIdx.x * 64 + threadIdx.x;
+    if (s >= B) return;
+    const int d = sp.d;
+    for (int c = 0; c < sp.ncomp; ++c) {
+        const T l = lam[s * hstride + c], v = var[s * hstride + c];
+        const int off = sp.off[c];
+        const T* gc = gC0 + s * d * d + off * d + off;
+        T gl, gv;
+        if (sp.order[c] == 1) prior_component<T, 1>(l, v, jitter, d, gc, gl, gv);
+        else if (sp.order[c] == 3) prior_component<T, 2>(l, v, jitter, d, gc, gl, gv);
+        else prior_component<T, 3>(l, v, jitter, d, gc, gl, gv);
+        out[(s * sp.ncomp + c) * 2] = gl;
+        out[(s * sp.ncomp + c) * 2 + 1] = gv;
+    }
+}
+template <typename T>
+int run_prior_grad(int64_t B, int ncomp, const int* orders, const T* lam, const T* var, int per_series, T jitter, const T* gC0, T* out,
+                   void* stream) {
+    if (B < 0) return -1;
+    if (ncomp < 1 || ncomp > MAXC) return -2;
+    if (!orders) return -3;
+    Spec sp;
+    sp.ncomp = ncomp;
+    int off = 0;
+    for (int c = 0; c < ncomp; ++c) {
+        if (orders[c] != 1 && orders[c] != 3 && orders[c] != 5) return -3;
+        sp.order[c] = orders[c];
+        sp.off[c] = off;
+        off += (orders[c] + 1) / 2;
+    }
+    sp.d = off;
+    if (B == 0) return 0;
+    if (!lam) return -4;
+    if (!var) return -5;
+    if (!gC0) return -8;
+    if (!out) return -9;
+    hipLaunchKernelGGL((matern_prior_grad_kernel<T>), dim3((unsigned)((B + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       (long)B, sp, lam, var, per_series ? (long)ncomp : 0L, jitter, gC0, out);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
 template <typename T>
 int run_grad(int64_t B, int64_t n, int ncomp, const int* orders, const T* lam, const T* var, int per_series, const T* dt, T jitter,
              const T* gA, const T* gC, int packed, T* out, void* stream) {
@@ -407,6 +472,14 @@ int mf_sde_matern_transitions_grad_packed_f32(int64_t B, int64_t n, int ncomp, c
                                               const float* var, int per_series, const float* dt, float jitter,
                                               const float* g_packed, float* out, void* stream) {
     return run_grad<float>(B, n, ncomp, orders, lam, var, per_series, dt, jitter, g_packed, nullptr, 1, out, stream);
+}
+int mf_sde_matern_prior_chol_grad_f64(int64_t B, int ncomp, const int* orders, const double* lam, const double* var, int per_series,
+                                      double jitter, const double* g_cholP0, double* out, void* stream) {
+    return run_prior_grad<double>(B, ncomp, orders, lam, var, per_series, jitter, g_cholP0, out, stream);
+}
+int mf_sde_matern_prior_chol_grad_f32(int64_t B, int ncomp, const int* orders, const float* lam, const float* var, int per_series,
+                                      float jitter, const float* g_cholP0, float* out, void* stream) {
+    return run_prior_grad<float>(B, ncomp, orders, lam, var, per_series, jitter, g_cholP0, out, stream);
 }
 
 }  // extern "C"

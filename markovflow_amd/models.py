@@ -26,13 +26,12 @@ class _GprFusedLogLik(torch.autograd.Function):
     model step fused into BOTH directions: forward ``mf_gpr_matern_loglik_*`` on an explicit time partition (its chunk summaries
     stay in the workspace), backward ``mf_gpr_matern_loglik_grad_*`` (csrc/mf_gpr_grad.hpp: boundary scans on those summaries, an
     emit pass and a gradient pass that generate the transitions in registers) followed by the generator's backward
-    (``mf_sde_matern_transitions_grad_*``), which reduces ``g_A``, ``g_cholQ`` to the hyper-parameters.  ``chol_p0`` (the stationary
-    prior's factor as a differentiable torch function of the hyper-parameters) is an input only so that its gradient has a graph to
-    flow into; the kernels generate their own.  Reference: TensorFlow reverse mode through
+    (``mf_sde_matern_transitions_grad_packed_*``, and ``mf_sde_matern_prior_chol_grad_*`` for the stationary prior's factor, which
+    the kernels generate themselves), which reduces the gradients of the transitions to the hyper-parameters.  Reference: TensorFlow reverse mode through
     models/gaussian_process_regression.py:150-160, kernels/matern.py, sde_kernel.py:421-446."""
 
     @staticmethod
-    def forward(ctx, lam_t, var_t, chol_p0, rinv, t, y, orders, per_series, jitter, chunks):
+    def forward(ctx, lam_t, var_t, rinv, t, y, orders, per_series, jitter, chunks):
         bsz, n = t.shape
         d = sum((o + 1) // 2 for o in orders)
         nt = n - 1
@@ -53,14 +52,14 @@ class _GprFusedLogLik(torch.autograd.Function):
         _lib.check(rc, "mf_gpr_matern_loglik")
         _lib.raise_on_info(info, "GaussianProcessRegression.log_likelihood", t.device)
         ctx.save_for_backward(lam_c, var_c, rinv_c, t, y)
-        ctx.meta = (orders, per_series, jitter, d, tuple(chol_p0.shape))
+        ctx.meta = (orders, per_series, jitter, d)
         ctx.fwd = (ws, parts, length)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         lam_c, var_c, rinv_c, t, y = ctx.saved_tensors
-        orders, per_series, jitter, d, p0_shape = ctx.meta
+        orders, per_series, jitter, d = ctx.meta
         ws_f, parts, length = ctx.fwd
         ctx.fwd = None
         bsz, n = t.shape
@@ -90,12 +89,14 @@ class _GprFusedLogLik(torch.autograd.Function):
             _lib.call("mf_sde_matern_transitions_grad_packed", t.dtype, bsz, n - 1, len(orders), c_orders, _lib.ptr(lam_c),
                       _lib.ptr(var_c), int(per_series), _lib.ptr(dt), jitter, _lib.ptr(g_packed), _lib.ptr(part),
                       _lib.stream_ptr(t.device))
-            g = torch.sum(part, dim=1)                                   # [B, ncomp, 2]
+            prior = torch.empty((bsz, len(orders), 2), dtype=t.dtype, device=t.device)
+            _lib.call("mf_sde_matern_prior_chol_grad", t.dtype, bsz, len(orders), c_orders, _lib.ptr(lam_c), _lib.ptr(var_c),
+                      int(per_series), jitter, _lib.ptr(g_cp0), _lib.ptr(prior), _lib.stream_ptr(t.device))
+            g = torch.sum(part, dim=1) + prior                           # [B, ncomp, 2]
             if not per_series:
                 g = torch.sum(g, dim=0)
-            g_p0 = g_cp0 if len(p0_shape) == 3 else torch.sum(g_cp0, dim=0)
             g_rinv = (-0.5 * torch.sum(g_om)).reshape(1, 1)
-        return g[..., 0].contiguous(), g[..., 1].contiguous(), g_p0.reshape(p0_shape), g_rinv, None, None, None, None, None, None
+        return g[..., 0].contiguous(), g[..., 1].contiguous(), g_rinv, None, None, None, None, None, None
 
 
 class GaussianProcessRegression:
@@ -189,14 +190,8 @@ class GaussianProcessRegression:
         chol = self._chol_obs_covariance.to(dtype=dtype, device=dev)
         rinv = (1.0 / (chol * chol)).reshape(1, 1)
         log_det_rinv = torch.log(rinv[0, 0])
-        # the stationary prior's factor as a differentiable function of the hyper-parameters ([d, d], or [B, d, d] per series)
-        p0 = self._kernel.initial_covariance(self._time_points[..., :1])
-        chol_p0 = _lib.checked_cholesky(p0.to(dtype), "GaussianProcessRegression.log_likelihood")
-        chol_p0 = chol_p0.reshape((-1,) + tuple(chol_p0.shape[-2:])) if chol_p0.dim() > 2 else chol_p0
-        if chol_p0.dim() == 3 and chol_p0.shape[0] != bsz:
-            chol_p0 = chol_p0.expand(bsz, d, d)
         orders = tuple(c.order for c in comps)
-        out = _GprFusedLogLik.apply(lam_t, var_t, chol_p0, rinv, t, y, orders, per_series, self._kernel._jitter, self._chunks)
+        out = _GprFusedLogLik.apply(lam_t, var_t, rinv, t, y, orders, per_series, self._kernel._jitter, self._chunks)
         const = -0.5 * math.log(2 * math.pi) * n * m + 0.5 * n * log_det_rinv
         return (out + const).reshape(batch)
 
