@@ -27,13 +27,14 @@ def _dense_kernel(order, l, v, r):
     return v * (1 + lam * r + (lam * r) ** 2 / 3) * torch.exp(-lam * r)
 
 
-def _run(orders, t, y, vals, per_series, fused_backward, chunks=0):
+def _run(orders, t, y, vals, per_series, fused_backward, chunks=0, dtype=torch.float64, jitter=None):
     names = list(vals)
-    leaves = {k: torch.tensor(v, dtype=torch.float64, device=DEV, requires_grad=True) for k, v in vals.items()}
-    comps = [ORD[o](leaves[f"l{i}"], leaves[f"v{i}"]) for i, o in enumerate(orders)]
-    kern = mfa.Sum(comps) if len(comps) > 1 else comps[0]
-    gpr = mfa.GaussianProcessRegression((torch.tensor(t, device=DEV), torch.tensor(y[..., None], device=DEV)), kern,
-                                        chol_obs_covariance=leaves["s"].reshape(1, 1))
+    leaves = {k: torch.tensor(v, dtype=dtype, device=DEV, requires_grad=True) for k, v in vals.items()}
+    kw = {} if jitter is None else {"jitter": jitter}
+    comps = [ORD[o](leaves[f"l{i}"], leaves[f"v{i}"], **kw) for i, o in enumerate(orders)]
+    kern = mfa.Sum(comps, **kw) if len(comps) > 1 else comps[0]
+    gpr = mfa.GaussianProcessRegression((torch.tensor(t, dtype=dtype, device=DEV), torch.tensor(y[..., None], dtype=dtype, device=DEV)),
+                                        kern, chol_obs_covariance=leaves["s"].reshape(1, 1))
     gpr.fused_backward = fused_backward
     gpr._chunks = chunks
     ll = gpr.log_likelihood()
@@ -89,3 +90,20 @@ def test_fused_backward_agrees_with_the_materialised_route_on_long_chains(rng):
     assert ll_f == pytest.approx(ll_m, rel=1e-11)
     for k in vals:
         np.testing.assert_allclose(g_f[k], g_m[k], rtol=1e-7, atol=1e-9 * (1 + np.abs(g_m[k]).max()), err_msg=k)
+
+
+@pytest.mark.parametrize("orders", [(5, 5), (3,), (5, 3)])
+def test_fused_backward_fp32(rng, orders):
+    """fp32 instantiations: against the fp64 run of the same fused route (well-separated time points, jitter fp32 can carry)."""
+    bsz, n = 3, 200
+    t = np.cumsum(0.3 + rng.exponential(0.3, size=(bsz, n)), axis=-1).astype(np.float32).astype(np.float64)
+    y = rng.normal(size=(bsz, n)).astype(np.float32).astype(np.float64)
+    vals = {"s": np.array(0.5)}
+    for i in range(len(orders)):
+        vals[f"l{i}"] = rng.uniform(0.8, 1.6, size=(bsz,)).astype(np.float32).astype(np.float64)
+        vals[f"v{i}"] = rng.uniform(0.5, 1.5, size=(bsz,)).astype(np.float32).astype(np.float64)
+    ll64, g64 = _run(orders, t, y, vals, True, True, jitter=1e-4)
+    ll32, g32 = _run(orders, t, y, vals, True, True, dtype=torch.float32, jitter=1e-4)
+    assert ll32 == pytest.approx(ll64, rel=2e-4)
+    for k in vals:
+        np.testing.assert_allclose(g32[k], g64[k], rtol=2e-2, atol=2e-2 * (1 + np.abs(g64[k]).max()), err_msg=k)

@@ -176,6 +176,19 @@ def test_streamed_backward_is_the_route_of_few_long_series_and_agrees_with_the_r
         np.testing.assert_allclose(streamed[k], other[k], rtol=1e-7, atol=1e-9 * (1 + scale), err_msg=k)
 
 
+@pytest.mark.parametrize("d,m", [(1, 1), (2, 2), (3, 1), (4, 3), (5, 1)])
+def test_streamed_backward_fp32_other_state_dimensions(rng, d, m):
+    kw = random_ssm(rng, (3,), 90, d, m, well=True)
+    kw = {k: v.astype(np.float32).astype(np.float64) for k, v in kw.items()}
+    r_inv = np.eye(m) * 2.0
+    w = np.ones(3)
+    want, _ = dense_autograd(kw, r_inv, w, False)
+    for fwd_chunks in (None, 5):
+        got = grad_streamed_abi(kw, r_inv, w, 4, dtype=torch.float32, fwd_chunks=fwd_chunks)
+        for name, g, ref in zip(NAMES[:7], got[:7], want):
+            np.testing.assert_allclose(g, ref, rtol=5e-3, atol=5e-3 * (1 + np.abs(ref).max()), err_msg=name)
+
+
 @pytest.mark.parametrize("fwd_chunks", [None, 0, 9])
 def test_streamed_backward_fp32(rng, fwd_chunks):
     kw = random_ssm(rng, (3,), 120, 6, 1, well=True)
