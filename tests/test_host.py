@@ -356,3 +356,29 @@ def test_dense_prediction_closed_forms_against_joint_gaussian_conditioning():
             want_cov = tm + dm @ pm @ dm.T + e @ pp @ e.T + e @ c @ dm.T + dm @ c.T @ e.T
             np.testing.assert_allclose(mean[s, j].numpy(), want_mean, rtol=1e-10, atol=1e-12)
             np.testing.assert_allclose(cov[s, j].numpy(), want_cov, rtol=1e-9, atol=1e-11)
+
+
+def test_plans_and_workspace_queries_of_the_streamed_backward_need_no_gpu():
+    """mf_kf_loglik_plan (which level-0 kernel, which time partition), the workspace queries of the streamed backward and of the
+    fused GPR backward are host code: the headline shape takes the streaming kernel on 64 chunks of 157 transitions, and the
+    partition the fused GPR route computes in Python (models._GprFusedLogLik) is the one mf_gpr_matern_loglik makes of an
+    explicit chunk count."""
+    import ctypes
+    lib = _lib.load()
+    path, p, length = ctypes.c_int(-1), ctypes.c_int64(0), ctypes.c_int64(0)
+    assert lib.mf_kf_loglik_plan(1024, 10000, 6, 1, 0, 8, 0, 1, ctypes.byref(path), ctypes.byref(p), ctypes.byref(length)) == 0
+    assert (path.value, p.value, length.value) == (2, 64, 157)
+    # unaligned tensors cannot take the LDS-DMA kernel
+    assert lib.mf_kf_loglik_plan(1024, 10000, 6, 1, 0, 8, 0, 0, ctypes.byref(path), ctypes.byref(p), ctypes.byref(length)) == 0
+    assert path.value != 2
+    # so many series that one chunk each fills the chip: a single chunk (the autograd forward then asks for two)
+    assert lib.mf_kf_loglik_plan(100000, 128, 6, 1, 0, 8, 0, 1, ctypes.byref(path), ctypes.byref(p), ctypes.byref(length)) == 0
+    assert (path.value, p.value) == (2, 1)
+    assert lib.mf_kf_loglik_plan(100000, 128, 6, 1, 0, 8, 2, 1, ctypes.byref(path), ctypes.byref(p), ctypes.byref(length)) == 0
+    assert (path.value, p.value, length.value) == (2, 2, 64)
+    assert lib.mf_kf_loglik_grad_streamed_workspace_bytes(1024, 10000, 6, 1, 0, 8, 0) > 1024 * 9999 * 224
+    assert lib.mf_kf_loglik_grad_streamed_workspace_bytes(1024, 10000, 7, 1, 0, 8, 0) == 0        # d = 7: not this route's
+    assert lib.mf_kf_loglik_grad_streamed_workspace_bytes(1024, 10000, 6, 4, 0, 8, 0) == 0        # four outputs neither
+    assert lib.mf_gpr_matern_loglik_grad_workspace_bytes(1024, 10000, 6, 8, 64) > 1024 * 9999 * 224
+    assert lib.mf_gpr_matern_loglik_grad_workspace_bytes(1024, 10000, 6, 8, 1) == 0               # no summaries to start from
+    assert lib.mf_version() == 7
