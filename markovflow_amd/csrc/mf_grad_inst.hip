@@ -172,6 +172,56 @@ int grad_run(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, 
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
+// ---- posterior_state_space_model from the filter's summaries ------------------------------------------------------------------------
+// groups of k forward chunks, k chosen so that the emit pass runs on about the partition it would choose itself
+template <typename T> bool post_from_fwd_plan(long B, long Tn, int m, int per_step, long fwd_P, long fwd_L, long& P, long& L, long& k) {
+    const long nt = Tn - 1;
+    if (fwd_P < 2 || fwd_L < 1 || (fwd_P - 1) * fwd_L >= nt || fwd_P * fwd_L < nt) return false;
+    long Pw = 0, Lw = 0;
+    if (post_ops<T>()->plan(B, Tn, m, per_step, 0, &Pw, &Lw) != 0 || Pw < 1) return false;
+    k = cdiv(fwd_P, Pw);
+    if (k < 1) k = 1;
+    L = k * fwd_L;
+    P = cdiv(nt, L);
+    return P >= 1;
+}
+template <typename T> size_t post_from_fwd_ws(long B, long Tn, int m, int per_step, long fwd_P) {
+    if (B < 1 || Tn < 2 || fwd_P < 2) return 0;
+    if (post_ops<T>()->ws(B, Tn, m, per_step, 0) == 0) return 0;
+    return align_up(PostWs<T, D>::bytes(B, fwd_P) + 256);           // (no group has more chunks than the forward evaluation)
+}
+template <typename T>
+int post_from_fwd(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H, const T* y,
+                  const T* Rinv, int rinv_per_step, T* a_post, T* mu0_post, T* b_post, T* cp0_post, T* cq_post, void* ws,
+                  size_t ws_bytes, int* info, const void* fwd_ws, long fwd_P, long fwd_L, hipEvent_t ev0, hipEvent_t ev1,
+                  hipStream_t st) {
+    if (B < 1 || Tn < 2 || fwd_ws == nullptr || a_post == nullptr) return -101;
+    long P, L, k;
+    if (!post_from_fwd_plan<T>(B, Tn, m, rinv_per_step, fwd_P, fwd_L, P, L, k)) return -101;
+    if (ws == nullptr || ws_bytes < PostWs<T, D>::bytes(B, P)) return -21;
+    const PostWs<T, D> w = PostWs<T, D>::carve(ws, B, P);
+    if (ev0) (void)hipEventRecord(ev0, st);
+    if (P > 1) {
+        RedSys<T> k0;
+        T* base = reinterpret_cast<T*>(const_cast<char*>(static_cast<const char*>(fwd_ws)));
+        const long nb = B * fwd_P;
+        k0.Dv = base; k0.GU = k0.Dv + nb * D * D; k0.F = k0.GU + nb * D * D; k0.tv = k0.F + nb * D * D;
+        k0.gU = k0.tv + nb * D; k0.sc = k0.gU + nb * D;
+        k0.n = fwd_P; k0.f_stride = fwd_P; k0.f_off = 0;
+        const GradIo<T> io{nullptr, w.bPsi, w.bpsi, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, nullptr};
+        int G = 64;
+        if (fwd_P <= 32) { G = 1; while (G < fwd_P) G <<= 1; }
+        constexpr int scan_lds = PostScanLds<T, D>::BYTES;
+        hipLaunchKernelGGL((k0_scan_kernel<T, D, true>), dim3((unsigned)cdiv(B, 64 / G)), dim3(64), scan_lds, st, k0, B, G, k, P, io,
+                           info);
+    }
+    const int rc = post_ops<T>()->emit(B, Tn, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, a_post, mu0_post, b_post, cp0_post,
+                                       cq_post, ws, ws_bytes, info, P, L, st);
+    if (ev1) (void)hipEventRecord(ev1, st);
+    return rc;
+}
+
 // ---- GaussianProcessRegression.log_likelihood: the backward with the kernel -> state-space-model step fused (mf_gpr_grad.hpp) ------
 // Needs the summaries of the fused forward (mf_gpr_matern_loglik on fwd_P chunks of fwd_L transitions): the backward runs on
 // the same partition.  Workspace: boundary states, start moments, the chain's packed records, block 0's marginal.
@@ -258,7 +308,7 @@ int gpr_grad_run(long B, long Tn, int ncomp, const int* orders, const T* lam, co
 }
 
 template <typename T> const GradOps<T>* table() {
-    static const GradOps<T> t = {&grad_ws<T>, &grad_run<T>, &gpr_grad_ws<T>, &gpr_grad_run<T>};
+    static const GradOps<T> t = {&grad_ws<T>, &grad_run<T>, &post_from_fwd_ws<T>, &post_from_fwd<T>, &gpr_grad_ws<T>, &gpr_grad_run<T>};
     return &t;
 }
 

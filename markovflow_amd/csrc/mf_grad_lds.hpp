@@ -171,13 +171,15 @@ __global__ void __launch_bounds__(64) k0_scan_kernel(RedSys<T> in, long B, int G
                 post_combine<T, D>(run, z, bad);                            // the run's last block (block T-1) eliminated
                 store_sym<T, D>(io.bPsi + (s * Pg + c - 1) * D * D, z.GU);
                 store_vec<T, D>(io.bpsi + (s * Pg + c - 1) * D, z.gU);
-                T Lam[D][D], lam[D], Psi[D][D], m[D], S[D][D];
-                MF_UNROLL for (int r = 0; r < D; ++r) MF_UNROLL for (int cc = 0; cc < D; ++cc) { Lam[r][cc] = T(0); S[r][cc] = T(0); Psi[r][cc] = z.GU[r][cc]; }
-                load_lower<T, D>(io.start_S + (s * Pg + c) * D * D, Lam);
-                load_vec<T, D>(io.start_m + (s * Pg + c) * D, lam);
-                grad_marginal<T, D>(Lam, lam, Psi, z.gU, m, S, bad);
-                store_vec<T, D>(io.start_m + (s * Pg + c) * D, m);
-                store_sym<T, D>(io.start_S + (s * Pg + c) * D * D, S);
+                if (io.start_m != nullptr) {          // (NULL: the boundary states alone - the posterior chain from the filter's summaries)
+                    T Lam[D][D], lam[D], Psi[D][D], m[D], S[D][D];
+                    MF_UNROLL for (int r = 0; r < D; ++r) MF_UNROLL for (int cc = 0; cc < D; ++cc) { Lam[r][cc] = T(0); S[r][cc] = T(0); Psi[r][cc] = z.GU[r][cc]; }
+                    load_lower<T, D>(io.start_S + (s * Pg + c) * D * D, Lam);
+                    load_vec<T, D>(io.start_m + (s * Pg + c) * D, lam);
+                    grad_marginal<T, D>(Lam, lam, Psi, z.gU, m, S, bad);
+                    store_vec<T, D>(io.start_m + (s * Pg + c) * D, m);
+                    store_sym<T, D>(io.start_S + (s * Pg + c) * D * D, S);
+                }
             }
         }
     };

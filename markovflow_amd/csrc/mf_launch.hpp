@@ -93,6 +93,13 @@ template <typename T> struct GradOps {
                const T* y, const T* Rinv, int rinv_per_step, const T* weights, T* g_mu0, T* g_cholP0, T* g_A, T* g_b, T* g_cholQ,
                T* g_H, T* g_y, T* g_Om, void* ws, size_t ws_bytes, int* info, long chunks, const void* fwd_ws, long fwd_P,
                long fwd_L, hipEvent_t ev0, hipEvent_t ev1, hipStream_t st);
+    // posterior_state_space_model from the summaries a preceding mf_kf_loglik call on the same inputs left in its workspace (the
+    // smoother reuses the filter's pass): boundary states by a scan over those summaries, then the emit pass alone
+    size_t (*post_from_fwd_ws)(long B, long Tn, int m, int rinv_per_step, long fwd_P);
+    int (*post_from_fwd)(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H,
+                         const T* y, const T* Rinv, int rinv_per_step, T* a_post, T* mu0_post, T* b_post, T* cp0_post, T* cq_post,
+                         void* ws, size_t ws_bytes, int* info, const void* fwd_ws, long fwd_P, long fwd_L, hipEvent_t ev0,
+                         hipEvent_t ev1, hipStream_t st);
     // GPR with the kernel -> state-space-model step fused (mf_gpr_grad.hpp); -101: signature / partition not covered
     size_t (*gpr_ws)(long B, long Tn, long fwd_P);
     int (*gpr_run)(long B, long Tn, int ncomp, const int* orders, const T* lam, const T* var, int per_series, const T* t,

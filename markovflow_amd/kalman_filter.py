@@ -208,6 +208,25 @@ class BaseKalmanFilter(abc.ABC):
     _chunks = 0
     _keep_summaries = False
     _summaries = None
+    # the smoother after the filter: log_likelihood() leaves the chunk summaries of its level-0 kernel in its workspace; a
+    # posterior_state_space_model() on the SAME tensors (storage, shape and autograd version of every input) starts from them
+    # (mf_kf_posterior_chain_from_filter).  A write that bypasses torch's version counter (`x.data.mul_()`, `set_()`) is invisible to
+    # that check: call invalidate_filter_cache() after one.
+    _POST_FROM_FILTER = True
+    _filter_cache = None
+
+    def invalidate_filter_cache(self) -> None:
+        self._filter_cache = None
+
+    def _r_inv_key(self):
+        """What identifies the observation precision between two calls (None: unknown - nothing is cached)."""
+        return None
+
+    def _cache_key(self, tensors):
+        rk = self._r_inv_key()
+        if rk is None:
+            return None
+        return tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype) for t in tensors) + (rk,)
     _prof_events = (None, None)
     _post_prof_events = (None, None)     # hipEvent_t pair around the kernels of posterior_state_space_model (bench.py)
 
@@ -275,6 +294,28 @@ class BaseKalmanFilter(abc.ABC):
         if d > lib.mf_max_state_dim() or m > 4 or bsz == 0:
             return None
         serial = bsz >= self._POST_FUSED_MIN_SERIES or n <= self._POST_FUSED_MAX_SERIAL_BLOCKS
+        cache = self._filter_cache
+        if (not serial and self._POST_STREAMED and self._POST_FROM_FILTER and cache is not None and m <= 3
+                and (a_s.data_ptr() | cq.data_ptr()) % 16 == 0 and cache[0] == self._cache_key((mu0, cp0, a_s, b_s, cq, h, y))):
+            # the smoother after the filter: start from the summaries log_likelihood() left behind
+            wsb = int(lib.mf_kf_posterior_chain_from_filter_workspace_bytes(bsz, n, d, m, int(per_step), a_s.element_size(), cache[2]))
+            if wsb:
+                ws2 = torch.empty(wsb, dtype=torch.uint8, device=a_s.device)
+                outs = [torch.empty_like(x) for x in (a_s, mu0, b_s, cp0, cq)]
+                info = _lib.pivot_info(a_s.device)
+                rc = _lib.call_rc("mf_kf_posterior_chain_from_filter", a_s.dtype, bsz, n, d, m, _lib.ptr(mu0), _lib.ptr(cp0),
+                                  _lib.ptr(a_s), _lib.ptr(b_s), _lib.ptr(cq), _lib.ptr(h), _lib.ptr(y), _lib.ptr(r_inv), int(per_step),
+                                  *[_lib.ptr(x) for x in outs], _lib.ptr(ws2), wsb, info, _lib.ptr(cache[1]), cache[2], cache[3],
+                                  self._post_prof_events[0], self._post_prof_events[1], _lib.stream_ptr(a_s.device))
+                if rc != -101:
+                    _lib.check(rc, "mf_kf_posterior_chain_from_filter")
+                    _lib.raise_on_info(info, "posterior_state_space_model", a_s.device)
+                    a_p, mu0_p, b_p, cp0_p, cq_p = outs
+                    batch = tuple(self.prior_ssm.batch_shape)
+                    return StateSpaceModel(initial_mean=mu0_p.reshape(batch + (d,)), chol_initial_covariance=cp0_p.reshape(batch + (d, d)),
+                                           state_transitions=a_p.reshape(batch + (n - 1, d, d)),
+                                           state_offsets=b_p.reshape(batch + (n - 1, d)),
+                                           chol_process_covariances=cq_p.reshape(batch + (n - 1, d, d)))
         ws, ws_bytes = None, 0
         if not serial and self._POST_STREAMED and (a_s.data_ptr() | cq.data_ptr()) % 16 == 0:
             ws_bytes = int(lib.mf_kf_posterior_chain_workspace_bytes(bsz, n, d, m, int(per_step), a_s.element_size(),
@@ -338,16 +379,16 @@ class BaseKalmanFilter(abc.ABC):
         chunks = self._chunks
         aligned = int((a_s.data_ptr() | cq.data_ptr()) % 16 == 0)
         path, p_f, l_f = ctypes.c_int(-1), ctypes.c_int64(0), ctypes.c_int64(0)
-        if self._keep_summaries:
-            # (asked for by the autograd function: which level-0 kernel runs, on which time partition.  Its chunk summaries are the
-            # first thing in the workspace, which therefore stays alive until the backward.  So many series that one chunk each
-            # fills the chip: two chunks cost the forward 6 % and save the backward its first two passes - measured at B = 65536,
-            # T = 128: forward 1.52 -> 1.61 ms, backward 10.3 -> 8.6 ms)
-            plan = lambda c: lib.mf_kf_loglik_plan(bsz, n, d, m, int(per_step), esz, c, aligned, ctypes.byref(path),   # noqa: E731
-                                                   ctypes.byref(p_f), ctypes.byref(l_f))
-            if plan(chunks) == 0 and chunks == 0 and path.value == 2 and p_f.value == 1 and n > 64:
-                chunks = 2
-                plan(chunks)
+        # which level-0 kernel runs, on which time partition: its chunk summaries are the first thing in the workspace, which stays
+        # alive for whoever starts from them (the autograd function's backward; posterior_state_space_model, see _POST_FROM_FILTER)
+        plan = lambda c: lib.mf_kf_loglik_plan(bsz, n, d, m, int(per_step), esz, c, aligned, ctypes.byref(path),       # noqa: E731
+                                               ctypes.byref(p_f), ctypes.byref(l_f))
+        planned = plan(chunks) == 0
+        if self._keep_summaries and planned and chunks == 0 and path.value == 2 and p_f.value == 1 and n > 64:
+            # (so many series that one chunk each fills the chip: two chunks cost the forward 6 % and save the backward its
+            # first two passes - measured at B = 65536, T = 128: forward 1.52 -> 1.61 ms, backward 10.3 -> 8.6 ms)
+            chunks = 2
+            plan(chunks)
         ws_bytes = int(lib.mf_kf_loglik_workspace_bytes(bsz, n, d, esz, chunks))
         if ws_bytes == 0:
             _lib.check(-100, "mf_kf_loglik")
@@ -359,8 +400,11 @@ class BaseKalmanFilter(abc.ABC):
                   0.0, _lib.ptr(out), _lib.ptr(ws), ws_bytes, info, chunks, self._prof_events[0],
                   self._prof_events[1], _lib.stream_ptr(a_s.device))
         _lib.raise_on_info(info, "KalmanFilter.log_likelihood", a_s.device)
+        usable = planned and path.value == 2 and p_f.value >= 2
         if self._keep_summaries:
-            self._summaries = (ws, int(p_f.value), int(l_f.value)) if (path.value == 2 and p_f.value >= 2) else None
+            self._summaries = (ws, int(p_f.value), int(l_f.value)) if usable else None
+        key = self._cache_key((mu0, cp0, a_s, b_s, cq, h, y)) if (usable and self._POST_FROM_FILTER) else None
+        self._filter_cache = (key, ws, int(p_f.value), int(l_f.value)) if key is not None else None
         return out
 
     def _per_series(self):
@@ -438,6 +482,10 @@ class KalmanFilter(BaseKalmanFilter):
                                chol_obs_covariance=chol_obs_covariance, emission_matrix=emission_model.emission_matrix)
         self._chol_obs_covariance = chol_obs_covariance
         self._observations = observations
+
+    def _r_inv_key(self):
+        c = self._chol_obs_covariance
+        return (c.data_ptr(), c._version, tuple(c.shape))
 
     @property
     def _r_inv(self) -> torch.Tensor:

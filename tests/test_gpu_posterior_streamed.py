@@ -147,3 +147,54 @@ def test_full_size_streamed_posterior_chain():
     for name, g, w in zip(("mu0", "cholP0", "A", "b", "cholQ"), got, ref):
         gg = nn(g[pick])
         assert np.abs(gg - w).max() <= 1e-8 * np.abs(w).max(), name
+
+
+# ---- the smoother after the filter: posterior_state_space_model() from the summaries log_likelihood() left behind -----------------
+@pytest.mark.parametrize("d,m,t,bsz,chunks", [(6, 1, 500, 4, 0), (6, 1, 301, 3, 13), (4, 2, 200, 5, 0), (2, 1, 150, 70, 0),
+                                              (6, 3, 90, 2, 6), (5, 1, 1000, 1, 0), (3, 1, 70, 3, 2)])
+def test_posterior_from_the_filters_summaries(rng, monkeypatch, d, m, t, bsz, chunks):
+    kw = random_ssm(rng, (bsz,), t, d, m, well=True)
+    r = rng.normal(size=(m, m))
+    chol_r = np.linalg.cholesky(r @ r.T + np.eye(m))
+    kf = build_kf(kw, chol_r)
+    kf._chunks = chunks
+    seen = []
+    real = _lib.call_rc
+
+    def spy(name, *args):
+        seen.append(name)
+        return real(name, *args)
+
+    monkeypatch.setattr(_lib, "call_rc", spy)
+    kf.log_likelihood()
+    post = kf.posterior_state_space_model()
+    assert "mf_kf_posterior_chain_from_filter" in seen
+    want = O.kf_posterior_ssm(**kw, r_inv=np.linalg.inv(chol_r @ chol_r.T))
+    got = (post.initial_mean, post.cholesky_initial_covariance, post.state_transitions, post.state_offsets,
+           post.cholesky_process_covariances)
+    assert_chain(tuple(nn(g) for g in got), want, rtol=1e-8, atol=1e-10)
+
+
+def test_filter_cache_is_dropped_when_an_input_changes(rng, monkeypatch):
+    """An in-place write to any input (torch bumps its version counter) invalidates the summaries: the next posterior runs its own
+    passes and is the posterior of the NEW inputs."""
+    kw = random_ssm(rng, (3,), 400, 6, 1, well=True)
+    kf = build_kf(kw, np.array([[0.7]]))
+    kf.log_likelihood()
+    kf.observations.mul_(1.5)
+    seen = []
+    real = _lib.call_rc
+
+    def spy(name, *args):
+        seen.append(name)
+        return real(name, *args)
+
+    monkeypatch.setattr(_lib, "call_rc", spy)
+    post = kf.posterior_state_space_model()
+    assert "mf_kf_posterior_chain_from_filter" not in seen
+    kw2 = dict(kw)
+    kw2["y"] = kw["y"] * 1.5
+    want = O.kf_posterior_ssm(**kw2, r_inv=np.array([[1.0 / 0.49]]))
+    got = (post.initial_mean, post.cholesky_initial_covariance, post.state_transitions, post.state_offsets,
+           post.cholesky_process_covariances)
+    assert_chain(tuple(nn(g) for g in got), want, rtol=1e-8, atol=1e-10)
