@@ -351,18 +351,29 @@ def smoother_and_backward(kf, inputs, bsz, tn, d, m, esz):
     out = {}
     ev = HipEvents()
     kf._post_prof_events = (ev.start, ev.stop)
+    # on its own: no filter pass to start from
+    kf._POST_FROM_FILTER = False
+    kf.invalidate_filter_cache()
     ms = _time_gpu(kf.posterior_state_space_model, iters=5)
     kern = []
     for _ in range(3):
         kf.posterior_state_space_model()
         kern.append(ev.elapsed_ms())
+    # the smoother after the filter: log_likelihood() on the same tensors left its chunk summaries behind
+    kf._POST_FROM_FILTER = True
+    kf.log_likelihood()
+    ms_after = _time_gpu(kf.posterior_state_space_model, iters=5)
     kf._post_prof_events = (None, None)
     b_post = bsz * tn * (4 * d * d + 3 * d + m * d + m) * esz
     out["posterior_TGT"] = {
         "ms": ms, "kernels_ms": sum(kern) / len(kern), "algorithmic_GBps": b_post / ms / 1e6,
         "frac_of_hbm_peak": b_post / ms / 1e6 / HBM_PEAK_GBS,
+        "ms_after_log_likelihood": ms_after, "algorithmic_GBps_after_log_likelihood": b_post / ms_after / 1e6,
+        "frac_of_hbm_peak_after_log_likelihood": b_post / ms_after / 1e6 / HBM_PEAK_GBS,
         "kernels": "mf::post_lds_kernel<MODE=0> (reversed elimination per chunk) + mf::post_scan_kernel + "
-                   "mf::post_lds_kernel<MODE=1>; round 3: mf_ssm_precision + parallel-in-time U D U^T + affine scan, 11.2 ms",
+                   "mf::post_lds_kernel<MODE=1>; round 3: mf_ssm_precision + parallel-in-time U D U^T + affine scan, 11.2 ms.  "
+                   "ms_after_log_likelihood: mf::k0_scan_kernel over the summaries the log-likelihood left + the emit pass alone "
+                   "(mf_kf_posterior_chain_from_filter)",
         "note": f"KalmanFilter.posterior_state_space_model B={bsz} T={tn} d={d} m={m}: all five tensors of the posterior chain"}
     p = kf.prior_ssm
     leaves = [t.detach().clone().requires_grad_(True) for t in (p.initial_mean, p.cholesky_initial_covariance, p.state_transitions,
