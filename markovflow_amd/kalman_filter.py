@@ -89,8 +89,8 @@ class _LogLikelihoodPerSeries(torch.autograd.Function):
 # few, long series (the condition under which posterior_state_space_model streams, below): the backward as five streamed passes
 _GRAD_STREAMED = True
 # (no upper limit on the batch: measured at B = 16384, T = 500 and B = 4096, T = 2000 the streamed passes beat one lane per
-# series too - 10.6 -> 9.4 ms, 21.9 -> 9.2 ms before the forward's summaries were used; the knob is for A/B timing)
-_GRAD_STREAMED_MAX_SERIES = int(__import__("os").environ.get("MF_GRAD_STREAMED_MAX_SERIES", str(1 << 40)))
+# series too - 10.6 -> 9.4 ms, 21.9 -> 9.2 ms before the forward's summaries were used; the constant is there for A/B timing)
+_GRAD_STREAMED_MAX_SERIES = 1 << 40
 _grad_prof_events = (None, None)     # optional hipEvent_t pair recorded around the kernels of the streamed backward (bench.py)
 
 
@@ -403,7 +403,9 @@ class BaseKalmanFilter(abc.ABC):
         usable = planned and path.value == 2 and p_f.value >= 2
         if self._keep_summaries:
             self._summaries = (ws, int(p_f.value), int(l_f.value)) if usable else None
-        key = self._cache_key((mu0, cp0, a_s, b_s, cq, h, y)) if (usable and self._POST_FROM_FILTER) else None
+        # (kept only where posterior_state_space_model would take the streamed kernels: the workspace stays alive with the filter)
+        streamed_post = bsz < self._POST_FUSED_MIN_SERIES and n > self._POST_FUSED_MAX_SERIAL_BLOCKS and m <= 3
+        key = self._cache_key((mu0, cp0, a_s, b_s, cq, h, y)) if (usable and self._POST_FROM_FILTER and streamed_post) else None
         self._filter_cache = (key, ws, int(p_f.value), int(l_f.value)) if key is not None else None
         return out
 
