@@ -427,6 +427,25 @@ int mf_kf_posterior_chain_from_filter_f32(int64_t B, int64_t T, int d, int m, co
                                           void* prof_start, void* prof_stop, void* stream);
 
 /*
+ * The posterior of the same GP-regression models as a state space model (markovflow/models/gaussian_process_regression.py:130-148
+ * builds its posterior process from it) without materialising the prior's tensors: boundary states from the summaries the fused
+ * forward mf_gpr_matern_loglik left in its workspace (explicit chunk count, partition as for mf_gpr_matern_loglik_grad), then the
+ * emit pass of the streamed posterior chain with the transitions generated in registers (csrc/mf_gpr_grad.hpp).  Outputs as
+ * mf_kf_posterior_chain.  ws: mf_gpr_matern_posterior_chain_workspace_bytes.  -101: signature or partition not covered.
+ */
+size_t mf_gpr_matern_posterior_chain_workspace_bytes(int64_t B, int64_t T, int d, int elem_size, int64_t fwd_chunks_per_series);
+int mf_gpr_matern_posterior_chain_f64(int64_t B, int64_t T, int ncomp, const int* orders, const double* lam, const double* var,
+                                      int per_series, const double* t, const double* y, const double* rinv, double jitter,
+                                      double* a_post, double* mu0_post, double* b_post, double* cholP0_post, double* cholQ_post,
+                                      void* ws, size_t ws_bytes, int* info, const void* fwd_ws, int64_t fwd_chunks_per_series,
+                                      int64_t fwd_chunk_length, void* stream);
+int mf_gpr_matern_posterior_chain_f32(int64_t B, int64_t T, int ncomp, const int* orders, const float* lam, const float* var,
+                                      int per_series, const float* t, const float* y, const float* rinv, float jitter,
+                                      float* a_post, float* mu0_post, float* b_post, float* cholP0_post, float* cholQ_post,
+                                      void* ws, size_t ws_bytes, int* info, const void* fwd_ws, int64_t fwd_chunks_per_series,
+                                      int64_t fwd_chunk_length, void* stream);
+
+/*
  * The backward of the fused GP-regression log-likelihood mf_gpr_matern_loglik: a Sum of one or two Matern components, one output - the
  * training step
  * of markovflow/models/gaussian_process_regression.py:150-160 under a GradientTape - with the kernel -> state-space-model step

@@ -32,6 +32,8 @@ _SIGS = {
     "mf_ssm_marginal_means": (_int, [_i64, _i64, _i64, _int, "Tp", "Tp", "Tp", _vp, _sz, _vp]),
     "mf_ssm_marginals": (_int, [_i64, _i64, _int] + ["Tp"] * 8 + [_vp, _sz, _vp]),
     "mf_block_matmul": (_int, [_i64, _i64, _int, "Tp", _i64, "Tp", _i64, "Tp", _vp]),
+    "mf_gpr_matern_posterior_chain": (_int, [_i64, _i64, _int, ctypes.POINTER(ctypes.c_int), "Tp", "Tp", _int, "Tp", "Tp", "Tp", "T",
+                                      "Tp", "Tp", "Tp", "Tp", "Tp", _vp, _sz, _vp, _vp, _i64, _i64, _vp]),
     "mf_gpr_matern_loglik_grad": (_int, [_i64, _i64, _int, ctypes.POINTER(ctypes.c_int), "Tp", "Tp", _int, "Tp", "Tp", "Tp", "T",
                                   "Tp", "Tp", "Tp", "Tp", _vp, _sz, _vp, _vp, _i64, _i64, _vp]),
     "mf_sde_matern_prior_chol_grad": (_int, [_i64, _int, ctypes.POINTER(ctypes.c_int), "Tp", "Tp", _int, "T", "Tp", "Tp", _vp]),
@@ -70,6 +72,7 @@ _PLAIN = {
     "mf_kf_posterior_chain_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _int, _int, _i64]),
     "mf_kf_loglik_grad_streamed_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _int, _int, _i64]),
     "mf_gpr_matern_loglik_grad_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _i64]),
+    "mf_gpr_matern_posterior_chain_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _i64]),
     "mf_kf_posterior_chain_from_filter_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _int, _int, _i64]),
     "mf_kf_loglik_plan": (_int, [_i64, _i64, _int, _int, _int, _int, _i64, _int, ctypes.POINTER(_int), ctypes.POINTER(_i64),
                                  ctypes.POINTER(_i64)]),

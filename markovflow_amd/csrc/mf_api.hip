@@ -502,6 +502,24 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
                                  fwd_chunk_length, static_cast<hipEvent_t>(prof_start),                                \
                                  static_cast<hipEvent_t>(prof_stop), S(stream));                                       \
     }                                                                                                                  \
+    int mf_gpr_matern_posterior_chain_##SUF(int64_t B, int64_t Tn, int ncomp, const int* orders, const T* lam,          \
+                                            const T* var, int per_series, const T* t, const T* y, const T* rinv,        \
+                                            T jitter, T* a_post, T* mu0_post, T* b_post, T* cholP0_post,                \
+                                            T* cholQ_post, void* ws, size_t ws_bytes, int* info, const void* fwd_ws,    \
+                                            int64_t fwd_chunks_per_series, int64_t fwd_chunk_length, void* stream) {    \
+        if (B < 1) return -1;                                                                                          \
+        if (Tn < 2) return -2;                                                                                         \
+        if (ncomp < 1 || !orders) return -3;                                                                           \
+        if (!lam || !var || !t || !y || !rinv) return -5;                                                              \
+        if (!a_post || !mu0_post || !b_post || !cholP0_post || !cholQ_post) return -12;                                \
+        int d = 0;                                                                                                     \
+        for (int c = 0; c < ncomp; ++c) d += (orders[c] + 1) / 2;                                                      \
+        const auto* gt = grad_table_for<T>(d);                                                                         \
+        if (!gt) return -101;                                                                                          \
+        return gt->gpr_post_run(B, Tn, ncomp, orders, lam, var, per_series, t, y, rinv, jitter, a_post, mu0_post,       \
+                                b_post, cholP0_post, cholQ_post, ws, ws_bytes, info, fwd_ws, fwd_chunks_per_series,     \
+                                fwd_chunk_length, S(stream));                                                          \
+    }                                                                                                                  \
     int mf_gpr_matern_loglik_grad_##SUF(int64_t B, int64_t Tn, int ncomp, const int* orders, const T* lam, const T* var, \
                                         int per_series, const T* t, const T* y, const T* rinv, T jitter,                \
                                         const T* weights, T* g_packed, T* g_cholP0, T* g_omega, void* ws,              \
@@ -688,6 +706,13 @@ size_t mf_kf_posterior_chain_from_filter_workspace_bytes(int64_t B, int64_t T, i
     if (elem_size == 4) { const auto* t = grad_table_for<float>(d); return t ? t->post_from_fwd_ws(B, T, m, rinv_per_step, fwd_chunks_per_series) : 0; }
     const auto* t = grad_table_for<double>(d);
     return t ? t->post_from_fwd_ws(B, T, m, rinv_per_step, fwd_chunks_per_series) : 0;
+}
+
+size_t mf_gpr_matern_posterior_chain_workspace_bytes(int64_t B, int64_t T, int d, int elem_size, int64_t fwd_chunks_per_series) {
+    if (B < 1 || T < 2 || d < 1) return 0;
+    if (elem_size == 4) { const auto* t = grad_table_for<float>(d); return t ? t->gpr_post_ws(B, T, fwd_chunks_per_series) : 0; }
+    const auto* t = grad_table_for<double>(d);
+    return t ? t->gpr_post_ws(B, T, fwd_chunks_per_series) : 0;
 }
 
 size_t mf_gpr_matern_loglik_grad_workspace_bytes(int64_t B, int64_t T, int d, int elem_size, int64_t fwd_chunks_per_series) {

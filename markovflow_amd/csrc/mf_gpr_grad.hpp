@@ -105,6 +105,17 @@ template <typename T, int D, int K0, int K1, typename GB> struct GprGradSink {
 
 template <typename T> struct GprBwdIo {
     void* rec; T* bPsi; T* bpsi; T* mu0_post; T* cp0_post;        // emit: records out; boundary states in; block 0's marginal out
+    T* a_post; T* b_post; T* cq_post;                             // FULL: the posterior chain itself instead of the records
+};
+
+// Layout of the FULL emit (the posterior chain as a state space model, mf_gpr_matern_posterior_chain): the staging buffers and
+// tables of the streamed emit pass (PostLds) - its input image region is unused and holds the hyper-parameters
+template <typename T, int D> struct GprPostLds {
+    using PL = PostLds<T, D, 1, false, 1>;
+    static constexpr int OFF_hyp = 0, OFF_len = PL::OFF_len, OFF_relA = PL::Cfg::OFF_relA, OFF_relb = PL::Cfg::OFF_relb;
+    static constexpr int OFF_relP = OFF_relA, REC = PL::REC;          // (names the record variant of the kernel refers to; unused)
+    static constexpr int TOTAL = PL::TOTAL;
+    static_assert(5 * 64 * (int)sizeof(T) <= PL::Cfg::OFF_relA, "hyper-parameters inside the unused image region");
 };
 
 template <typename T, int O0, int O1> MF_DEV GprGen<T, O0, O1> gpr_load_gen(const char* smem, int off_hyp, int lane, T jitter) {
@@ -125,12 +136,16 @@ template <typename T, int O1> MF_DEV void gpr_store_hyp(char* smem, int off_hyp,
 }
 
 // ---- emit: position e of a chunk = transition tau0 + e; the wave walks e = nsteps-1 ... 0 (a shorter chunk idles FIRST) -----------
-template <typename T, int O0, int O1>
+// FULL: all five tensors of the posterior chain through the sink of the streamed emit pass (three wavefronts per CU); else the
+// packed records for the gradient pass.
+template <typename T, int O0, int O1, bool FULL = false>
 __global__ void __launch_bounds__(64) gpr_emit_kernel(GprArgs<T> a, GprBwdIo<T> io) {
     using Gen = GprGen<T, O0, O1>;
-    constexpr int D = Gen::D;
-    using GB = GprBwdLds<T, D, Gen::K0 * Gen::K0 + Gen::K1 * Gen::K1>;
-    using Sink = PackedSinkT<T, D, GB>;
+    constexpr int D = Gen::D, S = sizeof(T);
+    using GBR = GprBwdLds<T, D, Gen::K0 * Gen::K0 + Gen::K1 * Gen::K1>;
+    using GPL = GprPostLds<T, D>;
+    using GB = std::conditional_t<FULL, GPL, GBR>;
+    using Sink = std::conditional_t<FULL, PostSink<T, D, 1, false, true, 1>, PackedSinkT<T, D, GBR>>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const long total = a.B * a.P;
@@ -152,10 +167,17 @@ __global__ void __launch_bounds__(64) gpr_emit_kernel(GprArgs<T> a, GprBwdIo<T> 
     nsteps = __builtin_amdgcn_readfirstlane((int)nsteps);
     minlen = __builtin_amdgcn_readfirstlane((int)minlen);
     const unsigned long long offP = (unsigned long long)(s * nt + tau0) * GB::REC, offP0 = uniform64(offP);
+    const unsigned long long offA = (unsigned long long)(s * nt + tau0) * (D * D * S), offA0 = uniform64(offA);
+    const unsigned long long offb = (unsigned long long)(s * nt + tau0) * (D * S), offb0 = uniform64(offb);
     const bool rowok = valid && len > 0;
     {
         unsigned* tab = reinterpret_cast<unsigned*>(smem);
-        tab[GB::OFF_relP / 4 + lane] = rowok ? (unsigned)(offP - offP0) : MF_DMA_INVALID;
+        if constexpr (FULL) {
+            tab[GPL::OFF_relA / 4 + lane] = rowok ? (unsigned)(offA - offA0) : MF_DMA_INVALID;
+            tab[GPL::OFF_relb / 4 + lane] = rowok ? (unsigned)(offb - offb0) : MF_DMA_INVALID;
+        } else {
+            tab[GB::OFF_relP / 4 + lane] = rowok ? (unsigned)(offP - offP0) : MF_DMA_INVALID;
+        }
         reinterpret_cast<int*>(smem)[GB::OFF_len / 4 + lane] = rowok ? (int)len : 0;
     }
     gpr_store_hyp<T, O1>(smem, GB::OFF_hyp, lane, a, s);
@@ -180,10 +202,22 @@ __global__ void __launch_bounds__(64) gpr_emit_kernel(GprArgs<T> a, GprBwdIo<T> 
         MF_UNROLL for (int j = 0; j <= i; ++j) asm volatile("" : "+v"(Phi[i][j]));
     }
     Sink sink;
-    sink.init(smem, lane, 0, 0);
-    sink.fR = (unsigned long long)io.rec + (unsigned long long)a.B * nt * GB::REC;
+    unsigned long long qR = 0, qA = 0, qC = 0, qb = 0;
+    if constexpr (FULL) {
+        sink.init(smem, lane, GPL::OFF_relA, GPL::OFF_relb);
+        const unsigned long long nA = (unsigned long long)a.B * nt * (D * D * S), nb = (unsigned long long)a.B * nt * (D * S);
+        sink.fA = (unsigned long long)io.a_post + nA; sink.fC = (unsigned long long)io.cq_post + nA;
+        sink.fb = (unsigned long long)io.b_post + nb;
+        qA = (unsigned long long)io.a_post + offA0 + (unsigned long long)e_top * (D * D * S);
+        qC = (unsigned long long)io.cq_post + offA0 + (unsigned long long)e_top * (D * D * S);
+        qb = (unsigned long long)io.b_post + offb0 + (unsigned long long)e_top * (D * S);
+    } else {
+        sink.init(smem, lane, 0, 0);
+        sink.fR = (unsigned long long)io.rec + (unsigned long long)a.B * nt * GB::REC;
+        qR = (unsigned long long)io.rec + offP0 + (unsigned long long)e_top * GB::REC;
+    }
     sink.minlen = minlen;
-    unsigned long long qR = (unsigned long long)io.rec + offP0 + (unsigned long long)e_top * GB::REC;
+    sink.e = 0;
     const NoPump pump;
     for (long j = 0; j < nsteps; ++j) {
         const long e = nsteps - 1 - j;
@@ -195,10 +229,17 @@ __global__ void __launch_bounds__(64) gpr_emit_kernel(GprArgs<T> a, GprBwdIo<T> 
         if (en >= 0 && en != (e < len ? e : len - 1)) { t_hi = t_lo; t_lo = ts[tau0 + en]; y_cur = ys[tau0 + en + 1]; }
         T C[D][D], Bm[D][D];
         gpr_load_gen<T, O0, O1>(smem, GB::OFF_hyp, lane, a.jitter).make(dt, false, Bm, C);
-        sink.qR = qR; sink.e = e;
-        qR -= GB::REC;
-        post_emit_step<T, D, 1, false>(Phi, tv, bad, C, zero, hk, yk, Rk, Bm, pump, sink, active);
+        sink.e = e;
+        if constexpr (FULL) {
+            sink.qA = qA; sink.qC = qC; sink.qb = qb;
+            qA -= D * D * S; qC -= D * D * S; qb -= D * S;
+        } else {
+            sink.qR = qR;
+            qR -= GB::REC;
+        }
+        post_emit_step<T, D, 1, FULL>(Phi, tv, bad, C, zero, hk, yk, Rk, Bm, pump, sink, active);
     }
+    if constexpr (FULL) sink.flush();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (valid && c == 0) {          // block 0: the stationary prior closes the chain
         T C0[D][D], dummy[D][D], mean[D], Gi[D][D];

@@ -277,7 +277,7 @@ int gpr_grad_run(long B, long Tn, int ncomp, const int* orders, const T* lam, co
     const PostWs<T, D> w = PostWs<T, D>::carve(post_ws, B, P);
     const GradIo<T> gio{rec, w.bPsi, w.bpsi, start_m, start_S, mu0_post, cp0_post, nullptr, g_cholP0, g_packed, nullptr, nullptr,
                         nullptr, nullptr, g_Om};
-    const GprBwdIo<T> eio{rec, w.bPsi, w.bpsi, mu0_post, cp0_post};
+    const GprBwdIo<T> eio{rec, w.bPsi, w.bpsi, mu0_post, cp0_post, nullptr, nullptr, nullptr};
     RedSys<T> k0;
     {
         T* base = reinterpret_cast<T*>(const_cast<char*>(static_cast<const char*>(fwd_ws)));
@@ -307,8 +307,63 @@ int gpr_grad_run(long B, long Tn, int ncomp, const int* orders, const T* lam, co
     return rc;
 }
 
+// ---- GaussianProcessRegression: posterior_state_space_model with the kernel -> state-space-model step fused --------------------------
+template <typename T, int O0, int O1>
+int gpr_post_launch(const GprArgs<T>& a, const GprBwdIo<T>& eio, hipStream_t st) {
+    static_assert(GprGen<T, O0, O1>::D == D, "signature of another state dimension");
+    constexpr int lds = GprPostLds<T, D>::TOTAL;
+    static_assert(lds <= 64 * 1024, "GPR posterior: LDS beyond the default dynamic-LDS limit");
+    hipLaunchKernelGGL((gpr_emit_kernel<T, O0, O1, true>), dim3((unsigned)cdiv(a.B * a.P, 64)), dim3(64), lds, st, a, eio);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+template <typename T> size_t gpr_post_ws(long B, long Tn, long fwd_P) {
+    if (B < 1 || Tn < 2 || fwd_P < 2) return 0;
+    return align_up(PostWs<T, D>::bytes(B, fwd_P) + 256);
+}
+template <typename T>
+int gpr_post_run(long B, long Tn, int ncomp, const int* orders, const T* lam, const T* var, int per_series, const T* t, const T* y,
+                 const T* rinv, T jitter, T* a_post, T* mu0_post, T* b_post, T* cp0_post, T* cq_post, void* ws, size_t ws_bytes,
+                 int* info, const void* fwd_ws, long fwd_P, long fwd_L, hipStream_t st) {
+    if (B < 1 || Tn < 2 || ncomp < 1 || ncomp > 2) return -101;
+    const long nt = Tn - 1;
+    if (fwd_ws == nullptr || fwd_P < 2 || fwd_L < 1 || (fwd_P - 1) * fwd_L >= nt || fwd_P * fwd_L < nt) return -101;
+    if ((reinterpret_cast<size_t>(a_post) | reinterpret_cast<size_t>(cq_post)) & 15) return -101;
+    const long P = fwd_P, L = fwd_L;
+    if (ws == nullptr || ws_bytes < PostWs<T, D>::bytes(B, P)) return -21;
+    const PostWs<T, D> w = PostWs<T, D>::carve(ws, B, P);
+    RedSys<T> k0;
+    {
+        T* base = reinterpret_cast<T*>(const_cast<char*>(static_cast<const char*>(fwd_ws)));
+        const long nb = B * P;
+        k0.Dv = base; k0.GU = k0.Dv + nb * D * D; k0.F = k0.GU + nb * D * D; k0.tv = k0.F + nb * D * D;
+        k0.gU = k0.tv + nb * D; k0.sc = k0.gU + nb * D;
+        k0.n = P; k0.f_stride = P; k0.f_off = 0;
+    }
+    const GradIo<T> io{nullptr, w.bPsi, w.bpsi, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, nullptr};
+    int G = 64;
+    if (P <= 32) { G = 1; while (G < P) G <<= 1; }
+    constexpr int scan_lds = PostScanLds<T, D>::BYTES;
+    hipLaunchKernelGGL((k0_scan_kernel<T, D, true>), dim3((unsigned)cdiv(B, 64 / G)), dim3(64), scan_lds, st, k0, B, G, 1L, P, io, info);
+    const GprArgs<T> a{B, Tn, lam, var, per_series ? (long)ncomp : 0L, t, y, rinv, jitter, P, L, info};
+    const GprBwdIo<T> eio{nullptr, w.bPsi, w.bpsi, mu0_post, cp0_post, a_post, b_post, cq_post};
+    const int o0 = orders[0], o1 = ncomp > 1 ? orders[1] : 0;
+    int rc = -101;
+    if constexpr (D == 1) { if (o0 == 1 && o1 == 0) rc = gpr_post_launch<T, 1, 0>(a, eio, st); }
+    if constexpr (D == 2) { if (o0 == 3 && o1 == 0) rc = gpr_post_launch<T, 3, 0>(a, eio, st); }
+    if constexpr (D == 3) { if (o0 == 5 && o1 == 0) rc = gpr_post_launch<T, 5, 0>(a, eio, st); }
+    if constexpr (D == 4) { if (o0 == 3 && o1 == 3) rc = gpr_post_launch<T, 3, 3>(a, eio, st); }
+    if constexpr (D == 5) {
+        if (o0 == 5 && o1 == 3) rc = gpr_post_launch<T, 5, 3>(a, eio, st);
+        else if (o0 == 3 && o1 == 5) rc = gpr_post_launch<T, 3, 5>(a, eio, st);
+    }
+    if constexpr (D == 6) { if (o0 == 5 && o1 == 5) rc = gpr_post_launch<T, 5, 5>(a, eio, st); }
+    return rc;
+}
+
 template <typename T> const GradOps<T>* table() {
-    static const GradOps<T> t = {&grad_ws<T>, &grad_run<T>, &post_from_fwd_ws<T>, &post_from_fwd<T>, &gpr_grad_ws<T>, &gpr_grad_run<T>};
+    static const GradOps<T> t = {&grad_ws<T>, &grad_run<T>, &post_from_fwd_ws<T>, &post_from_fwd<T>, &gpr_grad_ws<T>, &gpr_grad_run<T>,
+                                 &gpr_post_ws<T>, &gpr_post_run<T>};
     return &t;
 }
 

@@ -105,6 +105,11 @@ template <typename T> struct GradOps {
     int (*gpr_run)(long B, long Tn, int ncomp, const int* orders, const T* lam, const T* var, int per_series, const T* t,
                    const T* y, const T* rinv, T jitter, const T* weights, T* g_packed, T* g_cholP0, T* g_Om, void* ws,
                    size_t ws_bytes, int* info, const void* fwd_ws, long fwd_P, long fwd_L, hipStream_t st);
+    // ... and its posterior_state_space_model from the fused forward's summaries
+    size_t (*gpr_post_ws)(long B, long Tn, long fwd_P);
+    int (*gpr_post_run)(long B, long Tn, int ncomp, const int* orders, const T* lam, const T* var, int per_series, const T* t,
+                        const T* y, const T* rinv, T jitter, T* a_post, T* mu0_post, T* b_post, T* cp0_post, T* cq_post, void* ws,
+                        size_t ws_bytes, int* info, const void* fwd_ws, long fwd_P, long fwd_L, hipStream_t st);
 };
 
 constexpr int MF_MAX_D = 9;        // largest state dimension with a register-resident (lane per chunk) instantiation

@@ -95,7 +95,12 @@ MF_DEV void buf_store(OutWord<8>::type v, mf_v4i srd, unsigned voff) {
     asm volatile("s_nop 4\n\tbuffer_store_dwordx2 %0, %1, %2, 0 offen\n\ts_nop 0" :: "a"(v), "v"(voff), "s"(srd) : "memory");
 }
 MF_DEV void buf_store(OutWord<4>::type v, mf_v4i srd, unsigned voff) {
-    asm volatile("s_nop 4\n\tbuffer_store_dword %0, %1, %2, 0 offen\n\ts_nop 0" :: "a"(v), "v"(voff), "s"(srd) : "memory");
+    // (the dword form serves the odd fp32 cases; in the fused GPR emit at d = 5 the compiler carried the descriptor in VGPRs across the
+    // step and handed them to the "s" operand as they were: made scalar again here)
+    mf_v4i u;
+    u.x = __builtin_amdgcn_readfirstlane(srd.x); u.y = __builtin_amdgcn_readfirstlane(srd.y);
+    u.z = __builtin_amdgcn_readfirstlane(srd.z); u.w = __builtin_amdgcn_readfirstlane(srd.w);
+    asm volatile("s_nop 4\n\tbuffer_store_dword %0, %1, %2, 0 offen\n\ts_nop 0" :: "a"(v), "v"(voff), "s"(u) : "memory");
 }
 
 // Geometry of the outputs of one step: a d x d row is handled as two halves of H0 and D - H0 matrix rows, a d row whole.

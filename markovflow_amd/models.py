@@ -279,12 +279,81 @@ class GaussianProcessRegression:
     def posterior(self) -> AnalyticPosteriorProcess:
         """Posterior process for inference at new time points (gaussian_process_regression.py:130-148)."""
         return AnalyticPosteriorProcess(
-            posterior_dist=self._kalman.posterior_state_space_model(),
+            posterior_dist=self.posterior_state_space_model(),
             kernel=self._kernel,
             conditioning_time_points=self._time_points,
             chol_obs_covariance=self._chol_obs_covariance,
         )
 
+    def _fused_posterior_chain(self) -> Optional[StateSpaceModel]:
+        """The posterior chain with the kernel -> state space model step fused (``mf_gpr_matern_loglik_*`` on an explicit partition
+        for its chunk summaries, then ``mf_gpr_matern_posterior_chain_*``): no prior tensors in memory.  ``None`` where the fused
+        kernels do not apply (row signatures, several outputs, d > 6, short chains, gradients required)."""
+        comps = self._kernel._components()
+        d, m, n = self._kernel.state_dim, self._observations.shape[-1], self._time_points.shape[-1]
+        if (not self.fused or not self.fused_backward or not self._observations.is_cuda or isinstance(self._kernel, IndependentMultiOutput)
+                or len(comps) > 2 or m != 1 or d > 6 or n <= 64):
+            return None
+        if torch.is_grad_enabled() and (self._kernel._needs_grad() or self._chol_obs_covariance.requires_grad):
+            return None
+        dtype, dev = self._observations.dtype, self._observations.device
+        batch = tuple(self._time_points.shape[:-1])
+        t = self._time_points.reshape(-1, n).to(dtype).contiguous()
+        y = self._observations.reshape(-1, n).contiguous()
+        bsz, nt = t.shape[0], n - 1
+        if bsz == 0 or bsz >= 2048:
+            return None
+        want = self._chunks if self._chunks > 0 else max(1, min(-(-49152 // bsz), max(nt // 4, 1)))   # three wavefronts per CU
+        want = max(1, min(want, nt))
+        length = -(-nt // want)
+        parts = -(-nt // length)
+        if parts < 2:
+            return None
+        with torch.no_grad():
+            lam = [c._lambda.to(dtype=dtype, device=dev) for c in comps]
+            var = [c._variance_t.to(dtype=dtype, device=dev) for c in comps]
+            per_series = any(x.dim() > 0 for x in lam + var)
+            if per_series:
+                lam_t = torch.stack([x.expand(batch).reshape(-1) for x in lam], dim=-1).contiguous()
+                var_t = torch.stack([x.expand(batch).reshape(-1) for x in var], dim=-1).contiguous()
+            else:
+                lam_t, var_t = torch.stack(lam).contiguous(), torch.stack(var).contiguous()
+            chol = self._chol_obs_covariance.to(dtype=dtype, device=dev)
+            rinv = (1.0 / (chol * chol)).reshape(1, 1).contiguous()
+            lib = _lib.load()
+            esz = t.element_size()
+            orders = (ctypes.c_int * len(comps))(*[c.order for c in comps])
+            ws_f = _lib.workspace(int(lib.mf_kf_loglik_workspace_bytes(bsz, n, d, esz, want)), dev)
+            val = torch.empty(bsz, dtype=dtype, device=dev)
+            info = _lib.pivot_info(dev)
+            rc = _lib.call_rc("mf_gpr_matern_loglik", dtype, bsz, n, len(comps), orders, _lib.ptr(lam_t), _lib.ptr(var_t),
+                              int(per_series), _lib.ptr(t), _lib.ptr(y), _lib.ptr(rinv), self._kernel._jitter, 0.0, _lib.ptr(val),
+                              _lib.ptr(ws_f), ws_f.numel(), info, want, None, None, _lib.stream_ptr(dev))
+            if rc == -101:
+                return None
+            _lib.check(rc, "mf_gpr_matern_loglik")
+            wsb = int(lib.mf_gpr_matern_posterior_chain_workspace_bytes(bsz, n, d, esz, parts))
+            if wsb == 0:
+                return None
+            ws = _lib.workspace(wsb, dev)
+            a_p = torch.empty((bsz, nt, d, d), dtype=dtype, device=dev)
+            cq_p = torch.empty_like(a_p)
+            b_p = torch.empty((bsz, nt, d), dtype=dtype, device=dev)
+            mu0_p = torch.empty((bsz, d), dtype=dtype, device=dev)
+            cp0_p = torch.empty((bsz, d, d), dtype=dtype, device=dev)
+            rc = _lib.call_rc("mf_gpr_matern_posterior_chain", dtype, bsz, n, len(comps), orders, _lib.ptr(lam_t), _lib.ptr(var_t),
+                              int(per_series), _lib.ptr(t), _lib.ptr(y), _lib.ptr(rinv), self._kernel._jitter, _lib.ptr(a_p),
+                              _lib.ptr(mu0_p), _lib.ptr(b_p), _lib.ptr(cp0_p), _lib.ptr(cq_p), _lib.ptr(ws), wsb, info, _lib.ptr(ws_f),
+                              parts, length, _lib.stream_ptr(dev))
+            if rc == -101:
+                return None
+            _lib.check(rc, "mf_gpr_matern_posterior_chain")
+            _lib.raise_on_info(info, "GaussianProcessRegression.posterior_state_space_model", dev)
+        return StateSpaceModel(initial_mean=mu0_p.reshape(batch + (d,)), chol_initial_covariance=cp0_p.reshape(batch + (d, d)),
+                               state_transitions=a_p.reshape(batch + (nt, d, d)), state_offsets=b_p.reshape(batch + (nt, d)),
+                               chol_process_covariances=cq_p.reshape(batch + (nt, d, d)))
+
     def posterior_state_space_model(self) -> StateSpaceModel:
         """The smoothed chain on the training time points (what the reference's ``posterior`` is built from, :138-144)."""
-        return self._kalman.posterior_state_space_model()
+        fused = self._fused_posterior_chain()
+        return fused if fused is not None else self._kalman.posterior_state_space_model()

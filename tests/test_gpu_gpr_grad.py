@@ -107,3 +107,42 @@ def test_fused_backward_fp32(rng, orders):
     assert ll32 == pytest.approx(ll64, rel=2e-4)
     for k in vals:
         np.testing.assert_allclose(g32[k], g64[k], rtol=2e-2, atol=2e-2 * (1 + np.abs(g64[k]).max()), err_msg=k)
+
+
+# ---- posterior_state_space_model of the GPR model with the kernel -> state space model step fused ---------------------------------
+@pytest.mark.parametrize("orders,n,bsz,per_series,chunks", [
+    ((5, 5), 300, 3, True, 0), ((5, 5), 101, 2, False, 7), ((5,), 90, 2, True, 0), ((3, 3), 200, 3, False, 0),
+    ((5, 3), 150, 2, True, 5), ((3, 5), 66, 2, True, 3), ((3,), 400, 1, False, 0), ((1,), 100, 3, True, 4),
+])
+def test_fused_posterior_chain_agrees_with_the_materialised_route(rng, monkeypatch, orders, n, bsz, per_series, chunks):
+    t = np.cumsum(0.1 + rng.exponential(0.2, size=(bsz, n)), axis=-1)
+    y = rng.normal(size=(bsz, n))
+    shape = (bsz,) if per_series else ()
+
+    def build():
+        comps = [ORD[o](torch.tensor(rng2.uniform(0.6, 1.6, size=shape), device=DEV), torch.tensor(rng2.uniform(0.5, 1.5, size=shape), device=DEV))
+                 for o in orders]
+        kern = mfa.Sum(comps) if len(comps) > 1 else comps[0]
+        return mfa.GaussianProcessRegression((torch.tensor(t, device=DEV), torch.tensor(y[..., None], device=DEV)), kern,
+                                             chol_obs_covariance=torch.tensor([[0.4]], dtype=torch.float64, device=DEV))
+
+    seen = []
+    real = _lib.call_rc
+
+    def spy(name, *args):
+        seen.append(name)
+        return real(name, *args)
+
+    monkeypatch.setattr(_lib, "call_rc", spy)
+    rng2 = np.random.default_rng(5)
+    gpr = build()
+    gpr._chunks = chunks
+    fused = gpr.posterior_state_space_model()
+    assert "mf_gpr_matern_posterior_chain" in seen
+    rng2 = np.random.default_rng(5)
+    ref_model = build()
+    ref_model.fused_backward = False
+    ref = ref_model.posterior_state_space_model()
+    for name in ("initial_mean", "cholesky_initial_covariance", "state_transitions", "state_offsets", "cholesky_process_covariances"):
+        g, w = getattr(fused, name).cpu().numpy(), getattr(ref, name).cpu().numpy()
+        np.testing.assert_allclose(g, w, rtol=1e-8, atol=1e-10 * (1 + np.abs(w).max()), err_msg=name)
