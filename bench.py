@@ -277,13 +277,21 @@ def other_configs(dev):
 
     ms_train = _time_gpu(train_step_tgt, iters=5, warm=2)
     ms_train_mat = _time_gpu(lambda: train_step_tgt(False), iters=3, warm=1)
+    # the smoother of the same model: posterior chain with the kernel -> SSM step fused, against the materialised route
+    ms_gpost = _time_gpu(gpr.posterior_state_space_model, iters=5, warm=2)
+    gpr.fused_backward = False
+    ms_gpost_mat = _time_gpu(gpr.posterior_state_space_model, iters=3, warm=1)
+    gpr.fused_backward = True
     out["gpr_fused_matern52x2_B1024_T10000_d6_f64"] = {
         "ms": ms, "steps_per_s": bsz * tn / ms * 1e3, "training_step_ms": ms_train, "training_step_materialised_ms": ms_train_mat,
+        "posterior_ms": ms_gpost, "posterior_materialised_ms": ms_gpost_mat,
         "note": "GaussianProcessRegression.log_likelihood through mf_gpr_matern_loglik (A_k, chol Q_k generated in registers); "
                 "NOT the headline metric: the boundary differs (time points + hyper-parameters instead of SSM tensors).  "
                 "training_step_ms: forward + backward w.r.t. every hyper-parameter, both directions fused "
                 "(mf_gpr_matern_loglik_grad + mf_sde_matern_transitions_grad; round 3: 28.1 ms); training_step_materialised_ms: "
-                "kernel tensors -> KalmanFilter -> streamed backward -> generator backward"}
+                "kernel tensors -> KalmanFilter -> streamed backward -> generator backward; posterior_ms: "
+                "posterior_state_space_model through mf_gpr_matern_posterior_chain (fused forward for its summaries + emit pass "
+                "generating the transitions) against kernel tensors -> KalmanFilter.posterior_state_space_model"}
     del t_pts, y_obs, gpr
     # config 4's MODEL: IndependentMultiOutput of three Matern-5/2 kernels (d = 9, 3 outputs), 512 series x 1000 points, from
     # (t, y, hyper-parameters): fused into the row kernel since round 3 (csrc/mf_row_gpr.hpp) against the materialised route
