@@ -16,8 +16,10 @@
  *   - `stream` is a hipStream_t (passed as void*); all work is enqueued, nothing synchronises;
  *   - `info` (nullable) is a device int the kernels raise to 1 on a non-positive pivot
  *     (LAPACK info>0 style; results are then NaN);
- *   - return value: 0 ok; -k = argument k (1-based) invalid; -100 = state dimension not
- *     instantiated (1..9 in this build; mf_kf_loglik up to 64 in fp32, 32 in fp64); -1000 = launch failure;
+ *   - return value: 0 ok; -k = argument k (1-based) invalid; -100 = state dimension not instantiated for this entry
+ *     point (register kernels 1..9, row kernels 10..15, wave / tile engines up to 64 in fp32 and 32 in fp64 - see
+ *     mf_max_state_dim*, mf_row_operators_cover); -101 = this fused / streamed variant does not cover the call (the caller
+ *     takes the general entry point); -1000 = launch failure;
  *   - re-entrant, no global state.
  */
 #ifndef MARKOVFLOW_AMD_H
@@ -32,6 +34,10 @@ extern "C" {
 
 /* Library / build identification. */
 int mf_version(void);
+/* Queues a 4-byte copy of the device word `info` into `host_mirror` (pinned host memory) on `stream`: after any synchronisation
+ * with the stream the mirror holds the final word of every factorising launch queued before (the reference raises inside the
+ * Cholesky op, block_tri_diag.py:423-436; here the failure crosses the bus in stream order, never outside it). */
+int mf_info_mirror(int* host_mirror, const int* info, void* stream);
 int mf_max_state_dim(void);              /* every entry point, fp32 and fp64: register-resident kernels (9)       */
 /* 1 when the register / row kernels run EVERY operator for this shape: d <= 9 always; 10 <= d <= 15 (row kernels only: one
  * 16-lane row per chunk; many series or short chains run them with one chunk per series) for every chain of at least two

@@ -63,6 +63,7 @@ _SIGS = {
 }
 _PLAIN = {
     "mf_version": (_int, []),
+    "mf_info_mirror": (_int, [_vp, _vp, _vp]),
     "mf_max_state_dim": (_int, []),
     "mf_row_operators_cover": (_int, [_i64, _i64, _int, _int]),
     "mf_max_state_dim_f32_loglik": (_int, []),
@@ -266,11 +267,23 @@ class _Flag:
         self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.view = ctypes.c_int.from_address(self.host.data_ptr())
         self.ptr = ctypes.c_void_p(self.dev.data_ptr())
+        self.host_ptr = ctypes.c_void_p(self.host.data_ptr())
+        self.stream_ptr = ctypes.c_void_p(stream.cuda_stream)
+        self.device_index = device_index
+        self.pending = False          # a factorising launch since the last queued copy
 
     def mirror(self):
-        """Queue the copy of the device word behind whatever the stream holds."""
-        with torch.cuda.stream(self.stream):
-            self.host.copy_(self.dev, non_blocking=True)
+        """Queue the copy of the device word behind whatever the stream holds: one hipMemcpyAsync through the library
+        (``mf_info_mirror``; through torch - stream context + ``copy_`` - the same copy cost ~20 us of host time per factorising
+        call, a fifth of a BASELINE config 2 evaluation: VERDICT r04 weak 4)."""
+        self.pending = False
+        if torch.cuda.current_device() != self.device_index:
+            with torch.cuda.device(self.device_index):
+                rc = load().mf_info_mirror(self.host_ptr, self.ptr, self.stream_ptr)
+        else:
+            rc = load().mf_info_mirror(self.host_ptr, self.ptr, self.stream_ptr)
+        if rc != 0:
+            raise MarkovflowAmdError("mf_info_mirror failed")
 
     def clear(self):
         """After a SYNCHRONISED look that found the flag raised: every copy queued so far has landed."""
@@ -330,6 +343,11 @@ def _take_failures(synced: bool = False, synchronise: bool = False):
     with the names issued so far.  A clean look only forgets the names when it was a synchronised one: without that a kernel
     issued earlier may still be running and raise the flag later, and its name has to survive this look."""
     final = synced or synchronise
+    if final:
+        for f in _flags.values():
+            if getattr(f, "pending", False):   # a copy left to a later launch that never came: queue it now and wait for it
+                f.mirror()
+                f.stream.synchronize()
     if synchronise:
         for f in _flags.values():
             f.stream.synchronize()
@@ -419,9 +437,11 @@ def checked_cholesky(mat: torch.Tensor, what: str) -> torch.Tensor:
     return chol
 
 
-def raise_on_info(info, what: str, device=None):
+def raise_on_info(info, what: str, device=None, more_follow: bool = False):
     """Called right after a factorising launch: queues the copy of the flag into its pinned mirror behind the kernel.
-    Synchronous mode: wait and raise now; default: remember the name."""
+    Synchronous mode: wait and raise now; default: remember the name.  ``more_follow``: the SAME evaluation issues another
+    factorising launch on this stream before anything can reach the host (the observation precision in front of the
+    log-likelihood kernel): the copy is left to that one."""
     _issued.append(what)
     if len(_issued) > 64:
         del _issued[:-64]
@@ -432,7 +452,10 @@ def raise_on_info(info, what: str, device=None):
     stream = torch.cuda.current_stream(idx)
     flag = _flags.get((idx, stream.cuda_stream))
     if flag is not None:
-        flag.mirror()
+        if more_follow and not CHECK_PIVOTS:
+            flag.pending = True
+        else:
+            flag.mirror()
     if CHECK_PIVOTS and not _suppress:
         stream.synchronize()
         ops = _take_failures(synced=True)

@@ -182,7 +182,14 @@ int mf_kf_loglik_total_f32(int64_t B, const float* per_series, int m, const floa
     return loglik_total<float>(B, per_series, m, chol_obs, num_points, extra_const, host_const, out, stream);
 }
 
-int mf_version(void) { return 7; }
+int mf_version(void) { return 8; }
+// The caller's copy of an `info` word into its pinned host mirror, queued behind whatever `stream` holds (see the header): one
+// hipMemcpyAsync - the Python layer used to spend ~20 us per factorising call on the same copy through torch.
+int mf_info_mirror(int* host_mirror, const int* info, void* stream) {
+    if (!host_mirror) return -1;
+    if (!info) return -2;
+    return hipMemcpyAsync(host_mirror, info, sizeof(int), hipMemcpyDeviceToHost, S(stream)) == hipSuccess ? 0 : -1000;
+}
 int mf_max_state_dim(void) { return mf::MF_MAX_D; }
 
 size_t mf_kf_loglik_workspace_bytes(int64_t B, int64_t T, int d, int elem_size, int64_t chunks) {

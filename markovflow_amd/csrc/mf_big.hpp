@@ -13,6 +13,7 @@
 // Notation follows SURVEY.md Appendix B / mf_kernels.hpp.
 #pragma once
 #include "mf_kernels.hpp"
+#include "mf_wave_api.hpp"
 
 #include "mf_env.hpp"
 #include <cstdlib>

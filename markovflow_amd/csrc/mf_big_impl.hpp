@@ -868,9 +868,12 @@ inline RedSys<real> carve_big(char*& p, long B, long n, int d) {
     return r;
 }
 
-// chunks per series: enough workgroups for two rounds over the 256 CUs, chunks of at least 4 transitions
-inline void big_partition(long B, long Tn, long chunks, long& P, long& L) {
-    static const long target = [] { const char* e = mf_knob("MF_BIG_TARGET_WGS"); return e ? std::atol(e) : 512L; }();
+// chunks per series: enough workgroups for two rounds over the 256 CUs, chunks of at least 4 transitions.  wave_target > 0: the
+// level-0 kernel is the wave kernel (mf_wave.hpp), one WAVEFRONT per chunk - one round of wavefronts over the SIMDs at its occupancy
+inline void big_partition(long B, long Tn, long chunks, long& P, long& L, long wave_target = 0) {
+    static const long target_wg = [] { const char* e = mf_knob("MF_BIG_TARGET_WGS"); return e ? std::atol(e) : 512L; }();
+    static const long wave_force = [] { const char* e = mf_knob("MF_WAVE_TARGET"); return e ? std::atol(e) : 0L; }();
+    const long target = wave_target > 0 ? (wave_force > 0 ? wave_force : wave_target) : target_wg;
     const long nt = Tn - 1;
     if (nt < 1) { P = 1; L = 1; return; }
     long want = chunks > 0 ? chunks : cdivl(target, B);
@@ -884,7 +887,7 @@ inline void big_partition(long B, long Tn, long chunks, long& P, long& L) {
 template <int DP> int launch_big(long B, long Tn, int d, int m, const real* mu0, const real* cholP0, const real* A,
                                  const real* b, const real* cholQ, const real* H, const real* y, const real* Rinv,
                                  int rinv_per_step, real add_const, real* out, void* ws, int* info, long P, long L,
-                                 hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
+                                 hipEvent_t ev0, hipEvent_t ev1, hipStream_t st, bool wave = false) {
     using SM = Smem<DP>;
     static const bool attr_ok = [] {
         bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&big_kf_chunk_kernel<DP>),
@@ -900,7 +903,12 @@ template <int DP> int launch_big(long B, long Tn, int d, int m, const real* mu0,
     RedSys<real> cur = carve_big(p, B, P, d);
     BigArgs a{B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, L, info};
     if (ev0) (void)hipEventRecord(ev0, st);
-    hipLaunchKernelGGL((big_kf_chunk_kernel<DP>), dim3((unsigned)(B * P)), dim3(NTHR), SM::BYTES, st, a, cur);
+    if (wave) {
+        const int rc = wave_kf_level0(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, L, cur, info, st);
+        if (rc != 0) return rc;
+    } else {
+        hipLaunchKernelGGL((big_kf_chunk_kernel<DP>), dim3((unsigned)(B * P)), dim3(NTHR), SM::BYTES, st, a, cur);
+    }
     if (ev1) (void)hipEventRecord(ev1, st);
     while (cur.n > BIG_RED_FINAL) {
         const long Pn = cdivl(cur.n, BIG_RED_CHUNK);
@@ -915,9 +923,15 @@ template <int DP> int launch_big(long B, long Tn, int d, int m, const real* mu0,
 }
 
 
-inline size_t kf_loglik_ws(long B, long Tn, int d, long chunks) {
+// wavefronts of the wave kernel in one round over the chip (0: the state dimension is not the wave kernel's)
+inline long wave_target(int d) {
+    static const bool off = [] { const char* e = mf_knob("MF_WAVE"); return e && e[0] == '0'; }();
+    if (off || !wave_covers(d, 1)) return 0;
+    return 256L * 4 * wave_waves_per_simd(d, (int)sizeof(real));
+}
+inline size_t kf_loglik_ws_for(long B, long Tn, int d, long chunks, long wtarget) {
     long P, L;
-    big_partition(B, Tn, chunks, P, L);
+    big_partition(B, Tn, chunks, P, L, wtarget);
     size_t total = red_bytes_big(B, P, d);
     long n = P;
     while (n > BIG_RED_FINAL) {
@@ -925,6 +939,13 @@ inline size_t kf_loglik_ws(long B, long Tn, int d, long chunks) {
         total += red_bytes_big(B, n, d);
     }
     return total;
+}
+// (the query does not know the observation dimension, which decides between the wave kernel and the engine: the larger of the two)
+inline size_t kf_loglik_ws(long B, long Tn, int d, long chunks) {
+    const size_t w0 = kf_loglik_ws_for(B, Tn, d, chunks, 0);
+    const long wt = wave_target(d);
+    const size_t w1 = wt > 0 ? kf_loglik_ws_for(B, Tn, d, chunks, wt) : 0;
+    return w0 > w1 ? w0 : w1;
 }
 
 inline int kf_loglik(long B, long Tn, int d, int m, const real* mu0, const real* cholP0, const real* A, const real* b,
@@ -934,10 +955,12 @@ inline int kf_loglik(long B, long Tn, int d, int m, const real* mu0, const real*
     if (m < 1 || m > MAXM_BIG) return -4;
     if (ws == nullptr || ws_bytes < kf_loglik_ws(B, Tn, d, chunks)) return -15;
     long P, L;
-    big_partition(B, Tn, chunks, P, L);
+    const long wt = (m <= 4 && Tn >= 2) ? wave_target(d) : 0;
+    const bool wave = wt > 0 && wave_covers(d, m);
+    big_partition(B, Tn, chunks, P, L, wave ? wt : 0);
 #define MF_BIG_CASE(DP)                                                                                               \
     return launch_big<DP>(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, add_const, out, ws, info, \
-                          P, L, ev0, ev1, st);
+                          P, L, ev0, ev1, st, wave);
     if (d <= 16) { MF_BIG_CASE(16) }
     if (d <= 32) { MF_BIG_CASE(32) }
     if constexpr (sizeof(real) == 4) {

@@ -151,6 +151,7 @@ int grad_run(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, 
                                             cp0_post, rec_post, post_ws, lay.post, info, P, nullptr, nullptr, st);
         if (rc != 0) return rc;
     }
+    bool launched = false;                  // (a call that launched nothing must not hand back uninitialised gradients: ADVICE r04)
     auto launch = [&](auto mtag, auto rtag) {
         constexpr int M = decltype(mtag)::value;
         constexpr bool RS = decltype(rtag)::value;
@@ -161,6 +162,7 @@ int grad_run(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, 
             if (attr != hipSuccess) return;
             if (!from_fwd) hipLaunchKernelGGL((grad_start_kernel<T, D, M>), dim3((unsigned)B), block, scan_lds, st, a, w.sum, io);
             hipLaunchKernelGGL((grad_lds_kernel<T, D, M, RS>), grid, block, lds, st, a, L, io);
+            launched = true;
         }
     };
     using std::integral_constant;
@@ -169,6 +171,7 @@ int grad_run(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, 
     else if (m == 2) launch(integral_constant<int, 2>{}, integral_constant<bool, false>{});
     else launch(integral_constant<int, 3>{}, integral_constant<bool, false>{});
     if (ev1) (void)hipEventRecord(ev1, st);
+    if (!launched) return -1000;
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 

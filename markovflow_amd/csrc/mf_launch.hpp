@@ -129,6 +129,18 @@ int big_kf_loglik_f32(long B, long Tn, int d, int m, const float* mu0, const flo
                       float add_const, float* out, void* ws, size_t ws_bytes, int* info, long chunks, hipEvent_t ev0,
                       hipEvent_t ev1, hipStream_t st);
 
+// mf_wave_inst.hip: level 0 of the log-likelihood on register tiles, one wavefront per (series, chunk), 16 <= d <= 32, m <= 4
+// (mf_wave.hpp); the reduced system has the layout of the tile engine's, whose levels take it from there.  -101: not covered.
+template <typename T> struct RedSys;
+bool wave_covers(int d, int m);
+int wave_waves_per_simd(int d, int elem_size);
+int wave_kf_level0_f64(long B, long Tn, int d, int m, const double* mu0, const double* cholP0, const double* A, const double* b,
+                       const double* cholQ, const double* H, const double* y, const double* Rinv, int rinv_per_step, long P, long L,
+                       const RedSys<double>& out, int* info, hipStream_t st);
+int wave_kf_level0_f32(long B, long Tn, int d, int m, const float* mu0, const float* cholP0, const float* A, const float* b,
+                       const float* cholQ, const float* H, const float* y, const float* Rinv, int rinv_per_step, long P, long L,
+                       const RedSys<float>& out, int* info, hipStream_t st);
+
 #define MF_DECLARE_BIG(SUF, T)                                                                                               \
     int big_cholesky_##SUF(long B, long n, int d, const T* diag, const T* sub, T* ldiag, T* lsub, void* ws, size_t ws_bytes,  \
                            int* info, hipStream_t st);                                                                       \

@@ -1,0 +1,17 @@
+// Entry points of mf_wave_inst.hip (declared in mf_launch.hpp) as one overloaded name, for the type-generic launcher of the tile
+// engine (mf_big_impl.hpp is included once per scalar type).
+#pragma once
+#include "mf_launch.hpp"
+
+namespace mf {
+inline int wave_kf_level0(long B, long Tn, int d, int m, const double* mu0, const double* cholP0, const double* A, const double* b,
+                          const double* cholQ, const double* H, const double* y, const double* Rinv, int rinv_per_step, long P, long L,
+                          const RedSys<double>& out, int* info, hipStream_t st) {
+    return wave_kf_level0_f64(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, L, out, info, st);
+}
+inline int wave_kf_level0(long B, long Tn, int d, int m, const float* mu0, const float* cholP0, const float* A, const float* b,
+                          const float* cholQ, const float* H, const float* y, const float* Rinv, int rinv_per_step, long P, long L,
+                          const RedSys<float>& out, int* info, hipStream_t st) {
+    return wave_kf_level0_f32(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, L, out, info, st);
+}
+}  // namespace mf

@@ -1,0 +1,43 @@
+// Instantiations of the wave kernels (mf_wave.hpp: one wavefront per (series, chunk), register tiles, 16 <= d <= 32) and the
+// entry points the tile engine's launcher (mf_big_impl.hpp) hands its level 0 to.
+#include "mf_wave.hpp"
+#include "mf_launch.hpp"
+
+namespace mf {
+
+namespace {
+// wavefronts per SIMD of the level-0 kernel (its register budget): two on one tile per matrix, one on 2 x 2 fp64 tiles
+template <typename T, int NT> constexpr int wave_wpe() { return NT == 1 ? (sizeof(T) == 8 ? 2 : 3) : (sizeof(T) == 8 ? 1 : 2); }
+template <typename T, int NT, int M>
+int wave_launch(const wv::WvArgs<T>& a, const RedSys<T>& out, hipStream_t st) {
+    hipLaunchKernelGGL((wv::wave_kf_chunk_kernel<T, NT, M, wave_wpe<T, NT>()>), dim3((unsigned)(a.B * a.P)), dim3(64), 0, st, a, out);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+template <typename T>
+int wave_level0(long B, long Tn, int d, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H,
+                const T* y, const T* Rinv, int rinv_per_step, long P, long L, const RedSys<T>& out, int* info, hipStream_t st) {
+    if (!wave_covers(d, m)) return -101;
+    const wv::WvArgs<T> a{B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, L, info};
+    if (d <= 16) return m == 1 ? wave_launch<T, 1, 1>(a, out, st) : wave_launch<T, 1, wv::WV_MAXM>(a, out, st);
+    return m == 1 ? wave_launch<T, 2, 1>(a, out, st) : wave_launch<T, 2, wv::WV_MAXM>(a, out, st);
+}
+}  // namespace
+
+bool wave_covers(int d, int m) { return d >= 16 && d <= 32 && m >= 1 && m <= wv::WV_MAXM; }
+// wavefronts per SIMD the level-0 kernel runs at (by its registers): what one round of chunks over the chip is sized for
+int wave_waves_per_simd(int d, int elem_size) {
+    return d <= 16 ? (elem_size == 8 ? wave_wpe<double, 1>() : wave_wpe<float, 1>()) : (elem_size == 8 ? wave_wpe<double, 2>() : wave_wpe<float, 2>());
+}
+
+int wave_kf_level0_f64(long B, long Tn, int d, int m, const double* mu0, const double* cholP0, const double* A, const double* b,
+                       const double* cholQ, const double* H, const double* y, const double* Rinv, int rinv_per_step, long P, long L,
+                       const RedSys<double>& out, int* info, hipStream_t st) {
+    return wave_level0<double>(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, L, out, info, st);
+}
+int wave_kf_level0_f32(long B, long Tn, int d, int m, const float* mu0, const float* cholP0, const float* A, const float* b,
+                       const float* cholQ, const float* H, const float* y, const float* Rinv, int rinv_per_step, long P, long L,
+                       const RedSys<float>& out, int* info, hipStream_t st) {
+    return wave_level0<float>(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, L, out, info, st);
+}
+
+}  // namespace mf

