@@ -344,6 +344,58 @@ def other_configs(dev):
         "cholesky_ms": t_chol, "posterior_state_space_model_ms": t_post,
         "note": "SymmetricBlockTriDiagonal.cholesky of the prior precision and KalmanFilter.posterior_state_space_model (precision "
                 "assembly + U D U^T + chain means), time-partitioned (round 2: 54 ms / 81 ms with one workgroup per series)"}
+    del kf, prec
+    # between the row kernels (d <= 15) and the tile engine: the wave kernels (csrc/mf_wave.hpp, round 5) at the shape VERDICT r04
+    # names - B = 512, T = 1000, fp64, m = 1.  Flop model 15 d^3 (executed by the partitioned elimination); the fp64 matrix rate
+    # this chip sustains is 63.8 TFLOP/s (scripts/micro/mfma_rate.hip: v_mfma_f64_16x16x4_f64 at 4 wavefronts per SIMD)
+    wave = {}
+    for dd in (15, 16, 24, 32):
+        kfw = synthetic.kalman_filter_from(synthetic.make_dense_ssm(512, 1000, dd, 1, dtype=torch.float64, device=dev))
+        msw = _time_gpu(kfw.log_likelihood, iters=5, warm=2)
+        wave[f"d{dd}"] = {"ms": msw, "steps_per_s": 512 * 1000 / msw * 1e3, "executed_TFLOPs_15d3": 512 * 1000 * 15.0 * dd ** 3 / msw / 1e9,
+                          "algorithmic_GBps": 512 * 1000 * synthetic.loglik_bytes_per_step(dd, 1, 8) / msw / 1e6}
+        del kfw
+    wave["note"] = ("KalmanFilter.log_likelihood B=512 T=1000 m=1 fp64: d = 15 row kernels (mf_row.hpp), d >= 16 wave kernels "
+                    "(one wavefront per chunk, register tiles in the MFMA accumulator layout); round 4: d=16 18.1 ms, d=32 57.9 ms")
+    out["wave_kernels_B512_T1000_m1_f64"] = wave
+    # reverse mode through the OPERATORS: the chain the reference's CVI models differentiate,
+    # dist_p.precision -> naturals_to_ssm_params -> kl_divergence (models/variational_cvi.py:105-136), few long series
+    from markovflow_amd import ssm_gaussian_transformations as G
+
+    bsz, tn = 64, 10000
+    t_pts = torch.cumsum(0.05 + 0.05 * torch.empty(bsz, tn, dtype=torch.float64, device=dev).exponential_(1.0, generator=g), dim=-1)
+    nat1 = torch.randn(bsz, tn, 1, dtype=torch.float64, device=dev, generator=g).requires_grad_(True)
+    nat2 = (-0.5 * (0.5 + torch.rand(bsz, tn, 1, 1, dtype=torch.float64, device=dev, generator=g))).requires_grad_(True)
+    ls_c = [(0.5 + 1.5 * torch.rand(bsz, dtype=torch.float64, device=dev, generator=g)).requires_grad_(True) for _ in range(2)]
+    var_c = [(0.5 + 1.5 * torch.rand(bsz, dtype=torch.float64, device=dev, generator=g)).requires_grad_(True) for _ in range(2)]
+
+    def cvi_kl():
+        kern = mfa.Sum([mfa.Matern52(l, v, jitter=1e-9) for l, v in zip(ls_c, var_c)], jitter=1e-9)
+        dist_p = kern.state_space_model(t_pts)
+        prec = dist_p.precision
+        h = kern.generate_emission_model(t_pts).emission_matrix
+        theta_lin = (h.transpose(-1, -2) @ nat1[..., None])[..., 0]
+        theta_diag = -0.5 * prec.block_diagonal + h.transpose(-1, -2) @ nat2 @ h
+        a_s, offsets, chol_p0, chol_q, mu0 = G.naturals_to_ssm_params(theta_lin, theta_diag, -prec.block_sub_diagonal)
+        return torch.sum(mfa.StateSpaceModel(mu0, chol_p0, a_s, offsets, chol_q).kl_divergence(dist_p))
+
+    fwd, bwd = [], []
+    for i in range(4):
+        for x in ls_c + var_c + [nat1, nat2]:
+            x.grad = None
+        torch.cuda.synchronize()
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record(); kl = cvi_kl(); e1.record(); kl.backward(); e2.record()
+        torch.cuda.synchronize()
+        if i:
+            fwd.append(e0.elapsed_time(e1)); bwd.append(e1.elapsed_time(e2))
+    f_ms, b_ms = sorted(fwd)[len(fwd) // 2], sorted(bwd)[len(bwd) // 2]
+    out["cvi_chain_precision_naturals_kl_B64_T10000_d6_f64"] = {
+        "forward_ms": f_ms, "backward_ms": b_ms, "backward_over_forward": b_ms / f_ms,
+        "note": "KL(q || p) with q built as variational_cvi.py:105-136 builds it (dist_p.precision -> naturals_to_ssm_params), "
+                "gradients w.r.t. lengthscales, variances and sites.  The adjoints of cholesky and block_diagonal_of_inverse are HIP "
+                "(mf_btd_cholesky_grad / mf_btd_diag_of_inverse_grad: local kernels + the congruence scan, parallel in time); round 4: a "
+                "Python loop over the T blocks"}
     return out
 
 

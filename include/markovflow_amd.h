@@ -352,6 +352,44 @@ int mf_sde_conditional_predict_f32(int64_t B, int64_t N, int64_t Np, int d, cons
                                    const float* prior_cov, float* out_mean, float* out_cov, int* info, void* stream);
 
 /*
+ * conditional_statistics of markovflow/conditionals.py:87-120 (_conditional_statistics_from_transitions, :122-203): for every
+ * new time point the statistics of p(x_t | x_-, x_+) = N(P_t [x_-, x_+], T_t) from the transitions x_- -> x_t (A_mt, Q_mt) and
+ * x_t -> x_+ (A_tp, Q_tp), each [n, d, d]:  E = Q_mt A_tp^T (Q_tp + A_tp Q_mt A_tp^T)^-1,  D = A_mt - E A_tp A_mt,
+ * projections = [D | E] ([n, d, 2d]),  covariances = T = Q_mt - Q_mt A_tp^T (...)^-1 A_tp Q_mt ([n, d, d]).  One lane per point,
+ * d <= 9 (-100 beyond).  `info`: raised when Q_tp + A_tp Q_mt A_tp^T is not positive definite.
+ */
+int mf_sde_conditional_statistics_f64(int64_t n, int d, const double* A_mt, const double* Q_mt, const double* A_tp,
+                                      const double* Q_tp, double* projections, double* covariances, int* info, void* stream);
+int mf_sde_conditional_statistics_f32(int64_t n, int d, const float* A_mt, const float* Q_mt, const float* A_tp, const float* Q_tp,
+                                      float* projections, float* covariances, int* info, void* stream);
+
+/*
+ * Reverse mode through the operators: banded_matrices registers a gradient for cholesky_band and inverse_from_cholesky_band
+ * (markovflow/block_tri_diag.py:22-31), which is how the CVI models differentiate dist_p.precision -> naturals_to_ssm_params
+ * (models/variational_cvi.py:105-136).
+ *   mf_btd_cholesky_grad: (g_ldiag [B,T,d,d] lower | NULL, g_lsub [B,T-1,d,d] | NULL) = gradients w.r.t. the factor's blocks ->
+ *     (g_diag [B,T,d,d] symmetric, g_sub [B,T-1,d,d]) = gradients w.r.t. the symmetric matrix' blocks.  Local adjoint of the
+ *     dense Cholesky per block + the congruence recursion Z_k = C_k + G_k^T Z_{k+1} G_k, G_k = W_k L_k^-1 (parallel in time for
+ *     few series) + an axpy.
+ *   mf_btd_diag_of_inverse_grad: sigma = the forward's diagonal blocks of (L L^T)^-1; (g_diag | NULL, g_sub | NULL) = gradients
+ *     w.r.t. the diagonal / sub-diagonal blocks of the inverse -> (g_ldiag lower, g_lsub).  The block Takahashi recursion run
+ *     forward in reverse mode, A_{k+1} = Qbar_{k+1} + G_k A_k G_k^T, between two local kernels.
+ * lsub == NULL: block-diagonal factor.  Workspace: mf_btd_grad_workspace_bytes (0: state dimension without these kernels,
+ * the entry points then return -100).  d <= 9 (register kernels) and 10 <= d <= 15 where the row scan takes the recursion.
+ */
+size_t mf_btd_grad_workspace_bytes(int64_t B, int64_t T, int d, int elem_size);
+int mf_btd_cholesky_grad_f64(int64_t B, int64_t T, int d, const double* ldiag, const double* lsub, const double* g_ldiag,
+                             const double* g_lsub, double* g_diag, double* g_sub, void* ws, size_t ws_bytes, void* stream);
+int mf_btd_cholesky_grad_f32(int64_t B, int64_t T, int d, const float* ldiag, const float* lsub, const float* g_ldiag,
+                             const float* g_lsub, float* g_diag, float* g_sub, void* ws, size_t ws_bytes, void* stream);
+int mf_btd_diag_of_inverse_grad_f64(int64_t B, int64_t T, int d, const double* ldiag, const double* lsub, const double* sigma,
+                                    const double* g_diag, const double* g_sub, double* g_ldiag, double* g_lsub, void* ws,
+                                    size_t ws_bytes, void* stream);
+int mf_btd_diag_of_inverse_grad_f32(int64_t B, int64_t T, int d, const float* ldiag, const float* lsub, const float* sigma,
+                                    const float* g_diag, const float* g_sub, float* g_ldiag, float* g_lsub, void* ws,
+                                    size_t ws_bytes, void* stream);
+
+/*
  * Gradient of the Kalman log-likelihood with respect to every tensor of the model (the reference
  * gets it from TensorFlow's reverse mode over the banded ops: tests/integration/models/test_gaussian_process_regression.py:117-130,
  * markovflow/models/variational_cvi.py:138-161 for the sites variants).  Fisher's identity,

@@ -17,7 +17,7 @@ from .kalman_filter import (
     UnivariateGaussianSitesNat,
 )
 from .state_space_model import StateSpaceModel, state_space_model_from_covariances
-from . import distributed, kernels, models, ssm_gaussian_transformations
+from . import conditionals, distributed, kernels, models, ssm_gaussian_transformations
 from .kernels import IndependentMultiOutput, Matern12, Matern32, Matern52, SDEKernel, StationaryKernel, Sum
 from .models import GaussianProcessRegression
 from .posterior import AnalyticPosteriorProcess, ConditionalProcess
@@ -27,7 +27,7 @@ __all__ = [
     "BlockTriDiagonal", "LowerTriangularBlockTriDiagonal", "SymmetricBlockTriDiagonal", "EmissionModel",
     "GaussMarkovDistribution", "check_compatible", "BaseKalmanFilter", "GaussianSites", "KalmanFilter",
     "KalmanFilterWithSites", "KalmanFilterWithSparseSites", "UnivariateGaussianSitesNat", "StateSpaceModel",
-    "state_space_model_from_covariances", "distributed", "kernels", "models", "ssm_gaussian_transformations", "SDEKernel", "StationaryKernel", "Matern12", "Matern32",
+    "state_space_model_from_covariances", "conditionals", "distributed", "kernels", "models", "ssm_gaussian_transformations", "SDEKernel", "StationaryKernel", "Matern12", "Matern32",
     "Matern52", "Sum", "IndependentMultiOutput", "GaussianProcessRegression", "AnalyticPosteriorProcess", "ConditionalProcess",
     "MarkovflowAmdError", "check_errors", "errors_as_nan", "set_synchronous_checks",
 ]

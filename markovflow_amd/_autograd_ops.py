@@ -9,16 +9,36 @@ FORWARD is the HIP kernel behind the operator and whose backward is
 
 * ``solve`` / ``dense_mult`` / ``abs_log_det``: closed forms on the operator's own kernels (one transposed solve / product +
   outer products that are local in time) - as fast as the forward;
-* ``cholesky``: the block recurrence ``L_k = chol(D_k - W_{k-1} W_{k-1}^T)``, ``W_k = S_k L_k^-T`` run backwards (the classic
-  ``L^-T Phi(L^T Lbar) L^-1`` adjoint per pivot, chained through ``W``): a loop over the blocks of batched d x d torch
-  products - sequential in time, O(T) small launches: the functional closure of the gap, not a fast path;
-* ``block_diagonal_of_inverse`` (+ sub-diagonal blocks): the block Takahashi recursion re-evaluated in differentiable torch ops.
+* ``cholesky``: HIP (``mf_btd_cholesky_grad_*``, csrc/mf_btd_par.hpp).  The block Cholesky is a LOCAL map ``(P_k, S_k) -> (L_k, W_k)``
+  behind the recursion ``P_k = D_k - S_{k-1} P_{k-1}^-1 S_{k-1}^T``, so its adjoint is a kernel that is local in time (the classic
+  ``L^-T Phi(L^T Lbar) L^-1`` per pivot), the congruence recursion ``Z_k = C_k + G_k^T Z_{k+1} G_k`` with the block Takahashi coupling
+  ``G_k = W_k L_k^-1`` (the scan of the marginals' adjoint: parallel in time for few series, a lane per series for many) and an axpy;
+* ``block_diagonal_of_inverse`` (+ sub-diagonal blocks): HIP (``mf_btd_diag_of_inverse_grad_*``): the same recursion run forward
+  (``A_{k+1} = Qbar_{k+1} + G_k A_k G_k^T``) between two local kernels.
+  Beyond the state dimensions of those kernels (d > 9) both fall back to a block-by-block loop of batched torch products
+  (``_cholesky_backward_torch`` / ``_inverse_blocks_backward_torch``), which is also what the CPU tests compare them against.
 
-Values always come from the HIP kernels; only the adjoints above are torch.
+Values always come from the HIP kernels.
 """
 from typing import Optional
 
 import torch
+
+from . import _lib
+
+
+def _hip_grad_ws(ldiag: torch.Tensor):
+    """``(B, n, d, workspace bytes)`` when the operator-adjoint kernels cover these blocks (HIP tensor, d <= 9), else None."""
+    if not ldiag.is_cuda:
+        return None
+    n, d = ldiag.shape[-3], ldiag.shape[-1]
+    bsz = 1
+    for x in ldiag.shape[:-3]:
+        bsz *= int(x)
+    if bsz == 0 or d > _lib.load().mf_max_state_dim():
+        return None
+    wsb = int(_lib.load().mf_btd_grad_workspace_bytes(bsz, n, d, ldiag.element_size()))
+    return (bsz, n, d, wsb) if wsb else None
 
 
 def _tr(x):
@@ -50,22 +70,41 @@ class BtdCholesky(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_ldiag, g_lsub):
         ldiag, lsub = ctx.saved_tensors
-        n = ldiag.shape[-3]
-        lbar = torch.tril(g_ldiag).clone() if g_ldiag is not None else torch.zeros_like(ldiag)
-        if not ctx.has_sub:
-            return None, _chol_adjoint(ldiag, lbar), None               # independent blocks: one batched adjoint
-        wbar_in = g_lsub if g_lsub is not None else torch.zeros_like(lsub)
-        dbar, sbar = torch.empty_like(ldiag), torch.empty_like(lsub)
-        for k in range(n - 1, -1, -1):
-            pbar = _chol_adjoint(ldiag[..., k, :, :], lbar[..., k, :, :])
-            dbar[..., k, :, :] = pbar
-            if k > 0:
-                w = lsub[..., k - 1, :, :]
-                wbar = wbar_in[..., k - 1, :, :] - 2.0 * pbar @ w                            # P_k = D_k - W W^T
-                sb = torch.linalg.solve_triangular(ldiag[..., k - 1, :, :], wbar, upper=False, left=False)   # W = S L^-T
-                sbar[..., k - 1, :, :] = sb
-                lbar[..., k - 1, :, :] -= torch.tril(_tr(sb) @ w)
-        return None, dbar, sbar
+        lsub = lsub if ctx.has_sub else None
+        plan = _hip_grad_ws(ldiag)
+        if plan is None:
+            return (None,) + _cholesky_backward_torch(ldiag, lsub, g_ldiag, g_lsub)
+        bsz, n, d, wsb = plan
+        flat = lambda t: None if t is None else t.reshape((bsz, -1, d, d)).contiguous()           # noqa: E731
+        g_diag = torch.empty_like(ldiag, memory_format=torch.contiguous_format)
+        g_sub = torch.empty_like(lsub, memory_format=torch.contiguous_format) if lsub is not None else None
+        ws = _lib.workspace(wsb, ldiag.device)
+        with torch.no_grad():
+            _lib.call("mf_btd_cholesky_grad", ldiag.dtype, bsz, n, d, _lib.ptr(flat(ldiag)), _lib.ptr(flat(lsub)),
+                      _lib.ptr(flat(g_ldiag)), _lib.ptr(flat(g_lsub) if lsub is not None else None), _lib.ptr(g_diag),
+                      _lib.ptr(g_sub), _lib.ptr(ws), wsb, _lib.stream_ptr(ldiag.device))
+        return None, g_diag, g_sub
+
+
+def _cholesky_backward_torch(ldiag, lsub, g_ldiag, g_lsub):
+    """The adjoint of the block Cholesky as a backward sweep of batched torch products (d > 9, CPU tensors; the reference the HIP
+    kernels are tested against)."""
+    n = ldiag.shape[-3]
+    lbar = torch.tril(g_ldiag).clone() if g_ldiag is not None else torch.zeros_like(ldiag)
+    if lsub is None:
+        return _chol_adjoint(ldiag, lbar), None                     # independent blocks: one batched adjoint
+    wbar_in = g_lsub if g_lsub is not None else torch.zeros_like(lsub)
+    dbar, sbar = torch.empty_like(ldiag), torch.empty_like(lsub)
+    for k in range(n - 1, -1, -1):
+        pbar = _chol_adjoint(ldiag[..., k, :, :], lbar[..., k, :, :])
+        dbar[..., k, :, :] = pbar
+        if k > 0:
+            w = lsub[..., k - 1, :, :]
+            wbar = wbar_in[..., k - 1, :, :] - 2.0 * pbar @ w                            # P_k = D_k - W W^T
+            sb = torch.linalg.solve_triangular(ldiag[..., k - 1, :, :], wbar, upper=False, left=False)   # W = S L^-T
+            sbar[..., k - 1, :, :] = sb
+            lbar[..., k - 1, :, :] -= torch.tril(_tr(sb) @ w)
+    return dbar, sbar
 
 
 class BtdSolve(torch.autograd.Function):
@@ -150,40 +189,62 @@ class BtdInverseBlocks(torch.autograd.Function):
     def forward(ctx, run, ldiag, lsub, want_sub):
         odiag, osub = run(ldiag.detach(), None if lsub is None else lsub.detach(), want_sub)
         ctx.has_sub, ctx.want_sub = lsub is not None, want_sub and lsub is not None
-        ctx.save_for_backward(ldiag, lsub if lsub is not None else ldiag.new_zeros(0))
+        ctx.save_for_backward(ldiag, lsub if lsub is not None else ldiag.new_zeros(0), odiag)
         return odiag, osub
 
     @staticmethod
     def backward(ctx, g_diag, g_sub):
-        ldiag, lsub = ctx.saved_tensors
-        with torch.enable_grad():
-            chol = ldiag.detach().requires_grad_(True)
-            w = lsub.detach().requires_grad_(True) if ctx.has_sub else None
-            eye = torch.eye(chol.shape[-1], dtype=chol.dtype, device=chol.device).expand(chol.shape)
-            linv = torch.linalg.solve_triangular(torch.tril(chol), eye, upper=False)
-            base = _tr(linv) @ linv
-            n = chol.shape[-3]
-            if w is None:
-                sig, subs = base, None
-            else:
-                gk = w @ linv[..., :-1, :, :]                               # G_k = W_k L_k^-1
-                blocks, sblocks = [None] * n, [None] * (n - 1)
-                blocks[n - 1] = base[..., n - 1, :, :]
-                for k in range(n - 2, -1, -1):
-                    g = gk[..., k, :, :]
-                    blocks[k] = base[..., k, :, :] + _tr(g) @ blocks[k + 1] @ g
-                    sblocks[k] = -blocks[k + 1] @ g
-                sig = torch.stack(blocks, dim=-3)
-                subs = torch.stack(sblocks, dim=-3) if n > 1 else None
-            outs, gouts = [sig], [g_diag if g_diag is not None else torch.zeros_like(sig)]
-            if ctx.want_sub and subs is not None and g_sub is not None:
-                outs.append(subs)
-                gouts.append(g_sub)
-            ins = [chol] + ([w] if w is not None else [])
-            grads = torch.autograd.grad(outs, ins, gouts, allow_unused=True)
-        g_chol = torch.tril(grads[0]) if grads[0] is not None else None
-        g_w = grads[1] if w is not None else None
-        return None, g_chol, g_w, None
+        ldiag, lsub, odiag = ctx.saved_tensors
+        lsub = lsub if ctx.has_sub else None
+        if not ctx.want_sub:
+            g_sub = None
+        plan = _hip_grad_ws(ldiag)
+        if plan is None:
+            g_chol, g_w = _inverse_blocks_backward_torch(ldiag, lsub, g_diag, g_sub)
+            return None, g_chol, g_w, None
+        bsz, n, d, wsb = plan
+        flat = lambda t: None if t is None else t.reshape((bsz, -1, d, d)).contiguous()           # noqa: E731
+        g_ldiag = torch.empty_like(ldiag, memory_format=torch.contiguous_format)
+        g_lsub = torch.empty_like(lsub, memory_format=torch.contiguous_format) if lsub is not None else None
+        ws = _lib.workspace(wsb, ldiag.device)
+        with torch.no_grad():
+            _lib.call("mf_btd_diag_of_inverse_grad", ldiag.dtype, bsz, n, d, _lib.ptr(flat(ldiag)), _lib.ptr(flat(lsub)),
+                      _lib.ptr(flat(odiag)), _lib.ptr(flat(g_diag)), _lib.ptr(flat(g_sub) if lsub is not None else None),
+                      _lib.ptr(g_ldiag), _lib.ptr(g_lsub), _lib.ptr(ws), wsb, _lib.stream_ptr(ldiag.device))
+        return None, g_ldiag, g_lsub, None
+
+
+def _inverse_blocks_backward_torch(ldiag, lsub, g_diag, g_sub):
+    """The block Takahashi recursion re-evaluated in differentiable torch ops and differentiated by torch (d > 9, CPU tensors; the
+    reference the HIP kernels are tested against)."""
+    with torch.enable_grad():
+        chol = ldiag.detach().requires_grad_(True)
+        w = lsub.detach().requires_grad_(True) if lsub is not None else None
+        eye = torch.eye(chol.shape[-1], dtype=chol.dtype, device=chol.device).expand(chol.shape)
+        linv = torch.linalg.solve_triangular(torch.tril(chol), eye, upper=False)
+        base = _tr(linv) @ linv
+        n = chol.shape[-3]
+        if w is None:
+            sig, subs = base, None
+        else:
+            gk = w @ linv[..., :-1, :, :]                               # G_k = W_k L_k^-1
+            blocks, sblocks = [None] * n, [None] * (n - 1)
+            blocks[n - 1] = base[..., n - 1, :, :]
+            for k in range(n - 2, -1, -1):
+                g = gk[..., k, :, :]
+                blocks[k] = base[..., k, :, :] + _tr(g) @ blocks[k + 1] @ g
+                sblocks[k] = -blocks[k + 1] @ g
+            sig = torch.stack(blocks, dim=-3)
+            subs = torch.stack(sblocks, dim=-3) if n > 1 else None
+        outs, gouts = [sig], [g_diag if g_diag is not None else torch.zeros_like(sig)]
+        if subs is not None and g_sub is not None:
+            outs.append(subs)
+            gouts.append(g_sub)
+        ins = [chol] + ([w] if w is not None else [])
+        grads = torch.autograd.grad(outs, ins, gouts, allow_unused=True)
+    g_chol = torch.tril(grads[0]) if grads[0] is not None else None
+    g_w = grads[1] if w is not None else None
+    return g_chol, g_w
 
 
 def needs_grad(*tensors: Optional[torch.Tensor]) -> bool:

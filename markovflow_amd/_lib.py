@@ -56,6 +56,9 @@ _SIGS = {
     "mf_ssm_marginals_grad": (_int, [_i64, _i64, _int] + ["Tp"] * 12 + [_vp, _sz, _vp]),
     "mf_sde_conditional_predict": (_int, [_i64, _i64, _i64, _int, _vp, "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", "Tp",
                                           "Tp", "Tp", _vp, _vp]),
+    "mf_sde_conditional_statistics": (_int, [_i64, _int, "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", _vp, _vp]),
+    "mf_btd_cholesky_grad": (_int, [_i64, _i64, _int, "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", _vp, _sz, _vp]),
+    "mf_btd_diag_of_inverse_grad": (_int, [_i64, _i64, _int, "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", _vp, _sz, _vp]),
     "mf_sde_matern_transitions": (_int, [_i64, _i64, _int, ctypes.POINTER(ctypes.c_int), "Tp", "Tp", _int, "Tp", "T",
                                          "Tp", "Tp", "Tp", _vp]),
     "mf_sde_matern_transitions_grad": (_int, [_i64, _i64, _int, ctypes.POINTER(ctypes.c_int), "Tp", "Tp", _int, "Tp", "T",
@@ -84,6 +87,7 @@ _PLAIN = {
     "mf_btd_solve_workspace_bytes": (_sz, [_i64, _i64, _i64, _int, _int]),
     "mf_btd_diag_of_inverse_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
     "mf_btd_udl_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
+    "mf_btd_grad_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
 }
 
 _lib = None

@@ -444,6 +444,49 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
                               subsequent_covs, prior_mean, prior_cov, out_mean, out_cov, info, S(stream));             \
     }
 
+#define MF_DEFINE4B(SUF, T)                                                                                            \
+    int mf_sde_conditional_statistics_##SUF(int64_t n, int d, const T* A_mt, const T* Q_mt, const T* A_tp, const T* Q_tp, \
+                                            T* projections, T* covariances, int* info, void* stream) {                \
+        if (n < 0) return -1;                                                                                          \
+        if (d < 1) return -2;                                                                                          \
+        const auto* t = table_for<T>(d);                                                                               \
+        if (!t) return -100;                                                                                           \
+        if (n == 0) return 0;                                                                                          \
+        if (!A_mt || !Q_mt || !A_tp || !Q_tp) return -3;                                                               \
+        if (!projections) return -7;                                                                                   \
+        if (!covariances) return -8;                                                                                   \
+        return t->sde_cond_stats(n, A_mt, Q_mt, A_tp, Q_tp, projections, covariances, info, S(stream));                \
+    }                                                                                                                  \
+    int mf_btd_cholesky_grad_##SUF(int64_t B, int64_t n, int d, const T* ldiag, const T* lsub, const T* g_ldiag,       \
+                                   const T* g_lsub, T* g_diag, T* g_sub, void* ws, size_t ws_bytes, void* stream) {    \
+        if (B < 0) return -1;                                                                                          \
+        if (n < 1) return -2;                                                                                          \
+        if (d < 1) return -3;                                                                                          \
+        const auto* t = table_for<T>(d);                                                                               \
+        if (!t) return -100;                                                                                           \
+        if (B == 0) return 0;                                                                                          \
+        if (!ldiag) return -4;                                                                                         \
+        if (!g_diag) return -8;                                                                                        \
+        if (lsub && n > 1 && !g_sub) return -9;                                                                        \
+        return t->btd_cholesky_grad(B, n, ldiag, lsub, g_ldiag, g_lsub, g_diag, g_sub, ws, ws_bytes, S(stream));       \
+    }                                                                                                                  \
+    int mf_btd_diag_of_inverse_grad_##SUF(int64_t B, int64_t n, int d, const T* ldiag, const T* lsub, const T* sigma,  \
+                                          const T* g_diag, const T* g_sub, T* g_ldiag, T* g_lsub, void* ws,            \
+                                          size_t ws_bytes, void* stream) {                                             \
+        if (B < 0) return -1;                                                                                          \
+        if (n < 1) return -2;                                                                                          \
+        if (d < 1) return -3;                                                                                          \
+        const auto* t = table_for<T>(d);                                                                               \
+        if (!t) return -100;                                                                                           \
+        if (B == 0) return 0;                                                                                          \
+        if (!ldiag) return -4;                                                                                         \
+        if (lsub && n > 1 && !sigma) return -6;                                                                        \
+        if (!g_ldiag) return -9;                                                                                       \
+        if (lsub && n > 1 && !g_lsub) return -10;                                                                      \
+        return t->btd_diag_of_inverse_grad(B, n, ldiag, lsub, sigma, g_diag, g_sub, g_ldiag, g_lsub, ws, ws_bytes,     \
+                                           S(stream));                                                                 \
+    }
+
 #define MF_DEFINE5(SUF, T)                                                                                             \
     int mf_kf_loglik_grad_##SUF(int64_t B, int64_t Tn, int d, int m, const T* mu0, const T* cholP0, const T* A,        \
                                 const T* b, const T* cholQ, const T* H, const T* y, const T* Rinv, int rinv_per_step,  \
@@ -616,6 +659,8 @@ MF_DEFINE3(f64, double)
 MF_DEFINE3(f32, float)
 MF_DEFINE4(f64, double)
 MF_DEFINE4(f32, float)
+MF_DEFINE4B(f64, double)
+MF_DEFINE4B(f32, float)
 MF_DEFINE5(f64, double)
 MF_DEFINE5(f32, float)
 
@@ -651,6 +696,15 @@ size_t mf_btd_diag_of_inverse_workspace_bytes(int64_t B, int64_t T, int d, int e
     // 10 <= d <= 15: sized for whichever engine takes the call (row kernels when the plan is theirs, else the tile engine)
     const size_t large = big_dim(d, elem_size) ? big_max(mf::big_marginal_covs_ws(B, T, d, elem_size), mf::big_btd_tak_ws(B, T, d, elem_size)) : 0;
     return small > large ? small : large;
+}
+
+// reverse mode of cholesky / block_diagonal_of_inverse: register and row kernels only (-> 0 beyond: the Python layer keeps its
+// differentiable torch route there)
+size_t mf_btd_grad_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {
+    if (B < 1 || T < 1) return 0;
+    if (elem_size == 4) { if (const auto* t = table_for<float>(d)) return t->btd_grad_ws(B, T); }
+    else if (const auto* t = table_for<double>(d)) return t->btd_grad_ws(B, T);
+    return 0;
 }
 
 size_t mf_btd_udl_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {

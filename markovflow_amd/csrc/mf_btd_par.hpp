@@ -711,6 +711,9 @@ MF_DEV void takahashi_from(const T (&L)[D][D], const T (&W)[D][D], bool has_g, T
 //   SRC 2  adjoint of those marginal covariances, M_k = N_k + A_k^T M_{k+1} A_k (the reverse-mode sweep of `marginals` and of
 //          kl_divergence, mf_kl_grad.hpp): position p = block n-1-p, N read from a buffer of symmetric blocks, G = A_k;
 //          a = N [B,n,D,D], b = A.
+//   SRC 3  the FORWARD recursion with explicit terms, Sigma_{p} = N_p + M_{p-1} Sigma_{p-1} M_{p-1}^T (the adjoint sweep of the block
+//          Takahashi recursion, mf_btd_diag_of_inverse_grad): position p = block p, N read from a buffer of symmetric blocks,
+//          G = M_{p-1}^T;  a = N [B,n,D,D], b = M [B,n-1,D,D].
 template <typename T> struct TakSrc {
     const T* a;
     const T* b;
@@ -726,6 +729,9 @@ MF_DEV void tak_load(const TakSrc<T>& src, long s, long n, long p, T (&L)[D][D],
         const long k = n - 1 - p;                        // block n-1 (position 0) has no transition: clamped, not used
         load_lower<T, D>(src.a + (s * n + k) * D * D, L);
         if (n > 1) load_mat<T, D, D>(src.b + (s * (n - 1) + (k < n - 1 ? k : n - 2)) * D * D, W);
+    } else if (SRC == 3) {
+        load_lower<T, D>(src.a + (s * n + p) * D * D, L);
+        if (n > 1) load_mat<T, D, D>(src.b + (s * (n - 1) + (p > 0 ? p - 1 : 0)) * D * D, W);
     } else {
         const T* lp = p > 0 ? src.a + (s * (n - 1) + p - 1) * D * D : src.c0 + s * D * D;
         load_lower<T, D>(lp, L);
@@ -740,6 +746,11 @@ MF_DEV void tak_terms(const T (&L)[D][D], const T (&W)[D][D], bool has_g, T (&N)
         MF_UNROLL for (int i = 0; i < D; ++i) {
             MF_UNROLL for (int j = 0; j <= i; ++j) N[i][j] = L[i][j];
             MF_UNROLL for (int j = 0; j < D; ++j) G[i][j] = W[i][j];
+        }
+    } else if (SRC == 3) {
+        MF_UNROLL for (int i = 0; i < D; ++i) {
+            MF_UNROLL for (int j = 0; j <= i; ++j) N[i][j] = L[i][j];
+            MF_UNROLL for (int j = 0; j < D; ++j) G[i][j] = W[j][i];
         }
     } else {
         MF_UNROLL for (int i = 0; i < D; ++i)
@@ -994,7 +1005,7 @@ __global__ void __launch_bounds__(64) par_tak_emit_kernel(long B, long n, long l
         if (c > 0) load_vec<T, D>(mean.up + (s * P + c - 1) * D, mu);
     }
     for (long p = p0; p < p1; ++p) {
-        const long k = SRC == 1 ? p : n - 1 - p;
+        const long k = (SRC == 1 || SRC == 3) ? p : n - 1 - p;
         if (PF) load(p + 1 < p1 ? p + 1 : p, nxt);
         else load(p, cur);
         __builtin_amdgcn_sched_barrier(0);
@@ -1034,6 +1045,219 @@ __global__ void __launch_bounds__(64) par_tak_emit_kernel(long B, long n, long l
     }
 }
 
+
+// ---- reverse mode through the operators (banded_matrices registers a gradient for every op, block_tri_diag.py:22-31) -----------
+// The block Cholesky  P_k = D_k - S_{k-1} P_{k-1}^-1 S_{k-1}^T,  L_k = chol(P_k),  W_k = S_k L_k^-T  is a LOCAL map (P_k, S_k) ->
+// (L_k, W_k) behind a Riccati-type recursion in P_k.  Its adjoint therefore splits into a part that is local in time - the only
+// place where the projection Phi of the dense Cholesky adjoint acts - and the adjoint of the recursion, which is a congruence
+// recursion with the coupling of the block Takahashi recursion, G_k = W_k L_k^-1:
+//     Sbar_k(loc) = Wbar_k L_k^-1,   Lbar_k(eff) = Lbar_k - tril(Sbar_k(loc)^T W_k),   C_k = sym(L_k^-T Phi(L_k^T Lbar_k(eff)) L_k^-1)
+//     Dbar_k = Z_k,  Z_k = C_k + G_k^T Z_{k+1} G_k,   Sbar_k = Sbar_k(loc) - 2 Z_{k+1} G_k
+// so the backward pass is one fully parallel kernel (below), the congruence scan of the marginals' adjoint (SRC 2: parallel in time
+// for few series, a lane per series for many) and an axpy - no sequential sweep of its own.
+template <typename T, int D>
+__global__ void __launch_bounds__(64) btd_chol_grad_local_kernel(long B, long n, const T* __restrict__ ldiag, const T* __restrict__ lsub,
+                                                                 const T* __restrict__ gl, const T* __restrict__ gw,
+                                                                 T* __restrict__ oC, T* __restrict__ oG, T* __restrict__ oS) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= B * n) return;
+    const long s = id / n, k = id % n;
+    T L[D][D], Li[D][D], Lb[D][D];
+    load_lower<T, D>(ldiag + id * D * D, L);
+    LogAcc<T> la;
+    la.init();
+    bool bad = false;
+    tri_inv_lower<T, D>(L, Li, la, bad);
+    MF_UNROLL for (int i = 0; i < D; ++i)
+        MF_UNROLL for (int j = 0; j < D; ++j) Lb[i][j] = (gl && j <= i) ? gl[id * D * D + i * D + j] : T(0);
+    if (lsub && k < n - 1) {
+        const long ks = s * (n - 1) + k;
+        T W[D][D], X[D][D];
+        load_mat<T, D, D>(lsub + ks * D * D, W);
+        // G = W Li (lower-triangular Li: columns j use rows l >= j)
+        MF_UNROLL for (int i = 0; i < D; ++i)
+            MF_UNROLL for (int j = 0; j < D; ++j) {
+                T a = T(0);
+                MF_UNROLL for (int l = j; l < D; ++l) a += W[i][l] * Li[l][j];
+                X[i][j] = a;
+            }
+        store_mat<T, D, D>(oG + ks * D * D, X);
+        if (gw) {
+            T Wb[D][D];
+            load_mat<T, D, D>(gw + ks * D * D, Wb);
+            MF_UNROLL for (int i = 0; i < D; ++i)
+                MF_UNROLL for (int j = 0; j < D; ++j) {
+                    T a = T(0);
+                    MF_UNROLL for (int l = j; l < D; ++l) a += Wb[i][l] * Li[l][j];
+                    X[i][j] = a;                                         // Sbar(loc) = Wbar Li
+                }
+            MF_UNROLL for (int i = 0; i < D; ++i)
+                MF_UNROLL for (int j = 0; j <= i; ++j) {
+                    T a = T(0);
+                    MF_UNROLL for (int l = 0; l < D; ++l) a += X[l][i] * W[l][j];
+                    Lb[i][j] -= a;                                       // - tril(Sbar(loc)^T W)
+                }
+        } else {
+            MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) X[i][j] = T(0);
+        }
+        store_mat<T, D, D>(oS + ks * D * D, X);
+    }
+    // Phi = tril(L^T Lbar), diagonal halved;  Y = Phi Li (lower);  X = Li^T Y;  C = (X + X^T) / 2
+    T Phi[D][D];
+    MF_UNROLL for (int i = 0; i < D; ++i)
+        MF_UNROLL for (int j = 0; j <= i; ++j) {
+            T a = T(0);
+            MF_UNROLL for (int l = i; l < D; ++l) a += L[l][i] * Lb[l][j];
+            Phi[i][j] = (i == j) ? T(0.5) * a : a;
+        }
+    T Y[D][D];
+    MF_UNROLL for (int i = 0; i < D; ++i)
+        MF_UNROLL for (int j = 0; j <= i; ++j) {
+            T a = T(0);
+            MF_UNROLL for (int l = j; l <= i; ++l) a += Phi[i][l] * Li[l][j];
+            Y[i][j] = a;
+        }
+    T* o = oC + id * D * D;
+    MF_UNROLL for (int i = 0; i < D; ++i)
+        MF_UNROLL for (int j = 0; j <= i; ++j) {
+            T a = T(0), b = T(0);                                        // X[i][j], X[j][i]
+            MF_UNROLL for (int l = i; l < D; ++l) a += Li[l][i] * Y[l][j];
+            MF_UNROLL for (int l = i; l < D; ++l) b += Li[l][j] * Y[l][i];       // (Y[l][i] = 0 for l < i)
+            const T c = T(0.5) * (a + b);
+            o[i * D + j] = c;
+            o[j * D + i] = c;
+        }
+}
+// out[i] += alpha * x[i]
+template <typename T> __global__ void __launch_bounds__(256) axpy_kernel(long n, T alpha, const T* __restrict__ x, T* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] += alpha * x[i];
+}
+
+// The block Takahashi recursion  Sigma_k = B_k + G_k^T Sigma_{k+1} G_k,  sub_k = -Sigma_{k+1} G_k  (B_k = L_k^-T L_k^-1, G_k = W_k L_k^-1)
+// run backwards in reverse mode is the same congruence recursion run FORWARD with G instead of G^T:
+//     A_0 = sym(Sigmabar_0),   A_{k+1} = sym(Sigmabar_{k+1}) - sym(subbar_k G_k^T) + G_k A_k G_k^T            (SRC 3)
+// between two kernels that are local in time: `pre` forms G_k and the explicit terms, `post` turns the totals A_k into
+//     Lbar_k = -2 tril(L_k^-T (L_k^-1 A_k L_k^-T)) - tril(G_k^T Wbar_k),   Wbar_k = (2 Sigma_{k+1} G_k A_k - Sigma_{k+1} subbar_k) L_k^-T.
+template <typename T, int D>
+__global__ void __launch_bounds__(64) btd_inv_grad_pre_kernel(long B, long n, const T* __restrict__ ldiag, const T* __restrict__ lsub,
+                                                              const T* __restrict__ gd, const T* __restrict__ gs,
+                                                              T* __restrict__ oQ, T* __restrict__ oG) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= B * n) return;
+    const long s = id / n, k = id % n;
+    auto sym_in = [&](long blk, T (&Q)[D][D]) {
+        MF_UNROLL for (int i = 0; i < D; ++i)
+            MF_UNROLL for (int j = 0; j <= i; ++j) {
+                const T v = gd ? T(0.5) * (gd[blk * D * D + i * D + j] + gd[blk * D * D + j * D + i]) : T(0);
+                Q[i][j] = v;
+            }
+    };
+    T Q[D][D];
+    if (k == 0 || !lsub) {                        // (no coupling: every block is its own chain and its total is its own term)
+        sym_in(id, Q);
+        store_sym<T, D>(oQ + id * D * D, Q);
+    }
+    if (!(lsub && k < n - 1)) return;
+    const long ks = s * (n - 1) + k;
+    T L[D][D], Li[D][D], W[D][D], G[D][D];
+    load_lower<T, D>(ldiag + id * D * D, L);
+    LogAcc<T> la;
+    la.init();
+    bool bad = false;
+    tri_inv_lower<T, D>(L, Li, la, bad);
+    load_mat<T, D, D>(lsub + ks * D * D, W);
+    MF_UNROLL for (int i = 0; i < D; ++i)
+        MF_UNROLL for (int j = 0; j < D; ++j) {
+            T a = T(0);
+            MF_UNROLL for (int l = j; l < D; ++l) a += W[i][l] * Li[l][j];
+            G[i][j] = a;
+        }
+    store_mat<T, D, D>(oG + ks * D * D, G);
+    sym_in(id + 1, Q);
+    if (gs) {
+        T Sb[D][D];
+        load_mat<T, D, D>(gs + ks * D * D, Sb);
+        MF_UNROLL for (int i = 0; i < D; ++i)
+            MF_UNROLL for (int j = 0; j <= i; ++j) {
+                T a = T(0);
+                MF_UNROLL for (int l = 0; l < D; ++l) a += Sb[i][l] * G[j][l] + Sb[j][l] * G[i][l];
+                Q[i][j] -= T(0.5) * a;                                   // - sym(subbar G^T)
+            }
+    }
+    store_sym<T, D>(oQ + (id + 1) * D * D, Q);
+}
+template <typename T, int D>
+__global__ void __launch_bounds__(64) btd_inv_grad_post_kernel(long B, long n, const T* __restrict__ ldiag, const T* __restrict__ lsub,
+                                                               const T* __restrict__ sig, const T* __restrict__ tot,
+                                                               const T* __restrict__ gs, const T* __restrict__ Gk,
+                                                               T* __restrict__ g_ldiag, T* __restrict__ g_lsub) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= B * n) return;
+    const long s = id / n, k = id % n;
+    T L[D][D], Li[D][D], A[D][D];
+    load_lower<T, D>(ldiag + id * D * D, L);
+    LogAcc<T> la;
+    la.init();
+    bool bad = false;
+    tri_inv_lower<T, D>(L, Li, la, bad);
+    load_mat<T, D, D>(tot + id * D * D, A);                              // symmetric, stored full
+    // M1 = Li A Li^T (symmetric);  Lbar = -2 tril(Li^T M1)
+    T X[D][D], M1[D][D], Lb[D][D];
+    MF_UNROLL for (int i = 0; i < D; ++i)
+        MF_UNROLL for (int j = 0; j < D; ++j) {
+            T a = T(0);
+            MF_UNROLL for (int l = 0; l <= i; ++l) a += Li[i][l] * A[l][j];
+            X[i][j] = a;
+        }
+    MF_UNROLL for (int i = 0; i < D; ++i)
+        MF_UNROLL for (int j = 0; j < D; ++j) {
+            T a = T(0);
+            MF_UNROLL for (int l = 0; l <= j; ++l) a += X[i][l] * Li[j][l];
+            M1[i][j] = a;
+        }
+    MF_UNROLL for (int i = 0; i < D; ++i)
+        MF_UNROLL for (int j = 0; j <= i; ++j) {
+            T a = T(0);
+            MF_UNROLL for (int l = i; l < D; ++l) a += Li[l][i] * M1[l][j];
+            Lb[i][j] = T(-2) * a;
+        }
+    if (lsub && k < n - 1) {
+        const long ks = s * (n - 1) + k;
+        T G[D][D], Sg[D][D], Gb[D][D];
+        load_mat<T, D, D>(Gk + ks * D * D, G);
+        load_mat<T, D, D>(sig + (id + 1) * D * D, Sg);                   // Sigma_{k+1}
+        // X = 2 G A - subbar;  Gbar = Sigma_{k+1} X
+        MF_UNROLL for (int i = 0; i < D; ++i)
+            MF_UNROLL for (int j = 0; j < D; ++j) {
+                T a = T(0);
+                MF_UNROLL for (int l = 0; l < D; ++l) a += G[i][l] * A[l][j];
+                X[i][j] = T(2) * a - (gs ? gs[ks * D * D + i * D + j] : T(0));
+            }
+        MF_UNROLL for (int i = 0; i < D; ++i)
+            MF_UNROLL for (int j = 0; j < D; ++j) {
+                T a = T(0);
+                MF_UNROLL for (int l = 0; l < D; ++l) a += Sg[i][l] * X[l][j];
+                Gb[i][j] = a;
+            }
+        // Wbar = Gbar Li^T;  Lbar -= tril(G^T Wbar)
+        MF_UNROLL for (int i = 0; i < D; ++i)
+            MF_UNROLL for (int j = 0; j < D; ++j) {
+                T a = T(0);
+                MF_UNROLL for (int l = 0; l <= j; ++l) a += Gb[i][l] * Li[j][l];
+                X[i][j] = a;
+            }
+        store_mat<T, D, D>(g_lsub + ks * D * D, X);
+        MF_UNROLL for (int i = 0; i < D; ++i)
+            MF_UNROLL for (int j = 0; j <= i; ++j) {
+                T a = T(0);
+                MF_UNROLL for (int l = 0; l < D; ++l) a += G[l][i] * X[l][j];
+                Lb[i][j] -= a;
+            }
+    }
+    T* o = g_ldiag + id * D * D;
+    MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) o[i * D + j] = (j <= i) ? Lb[i][j] : T(0);
+}
 
 // ---- upper_diagonal_lower (U D U^T) and the posterior chain in parallel in time -------------------------------------------------
 // Level-0 emit of the reversed factorisation: chunk c covers positions [c len, ...) (position p = block n-1-p) and restarts

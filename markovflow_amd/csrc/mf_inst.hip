@@ -827,6 +827,57 @@ int btd_diag_of_inverse(long B, long n, const T* ldiag, const T* lsub, T* odiag,
     return tak_scan<T, 0>(B, n, TakSrc<T>{ldiag, lsub, nullptr}, odiag, osub, ws, ws_bytes, st);
 }
 
+// Reverse mode of SymmetricBlockTriDiagonal.cholesky / LowerTriangularBlockTriDiagonal.block_diagonal_of_inverse (mf_btd_par.hpp:
+// a local kernel, a congruence scan, a local kernel).  Workspace: the scan's + three / two tensors of blocks.
+template <typename T> size_t btd_grad_ws(long B, long n) {
+    return align_up(btd_diag_of_inverse_ws<T>(B, n)) + 3 * align_up(size_t(B) * n * D * D * sizeof(T));
+}
+template <typename T>
+int btd_cholesky_grad(long B, long n, const T* ldiag, const T* lsub, const T* g_ldiag, const T* g_lsub, T* g_diag, T* g_sub, void* ws,
+                      size_t ws_bytes, hipStream_t st) {
+    if (ws == nullptr || ws_bytes < btd_grad_ws<T>(B, n)) return -9;
+    const size_t blk = align_up(size_t(B) * n * D * D * sizeof(T));
+    char* p = static_cast<char*>(ws);
+    T* C = reinterpret_cast<T*>(p); p += blk;
+    T* G = reinterpret_cast<T*>(p); p += blk;
+    T* Zs = reinterpret_cast<T*>(p); p += blk;            // -Z_{k+1} G_k of the scan
+    const size_t scan_bytes = ws_bytes - 3 * blk;
+    const bool chain = lsub != nullptr && n > 1;
+    // (no coupling: the local kernel's C IS the answer, written straight into g_diag)
+    MF_LANE_LAUNCH((btd_chol_grad_local_kernel<T, D>), dim3((unsigned)cdiv(B * n, 64)), dim3(64), 0, st, B, n, ldiag,
+                   chain ? lsub : static_cast<const T*>(nullptr), g_ldiag, chain ? g_lsub : static_cast<const T*>(nullptr),
+                   chain ? C : g_diag, G, g_sub);
+    if (!chain) return hipGetLastError() == hipSuccess ? 0 : -1000;
+    const int rc = tak_scan<T, 2>(B, n, TakSrc<T>{C, G, nullptr}, g_diag, Zs, p, scan_bytes, st);
+    if (rc != 0) return rc;
+    const long cnt = B * (n - 1) * D * D;
+    hipLaunchKernelGGL((axpy_kernel<T>), dim3((unsigned)cdiv(cnt, 256)), dim3(256), 0, st, cnt, T(2), static_cast<const T*>(Zs), g_sub);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+template <typename T>
+int btd_diag_of_inverse_grad(long B, long n, const T* ldiag, const T* lsub, const T* sigma, const T* g_diag, const T* g_sub,
+                             T* g_ldiag, T* g_lsub, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (ws == nullptr || ws_bytes < btd_grad_ws<T>(B, n)) return -11;
+    const size_t blk = align_up(size_t(B) * n * D * D * sizeof(T));
+    char* p = static_cast<char*>(ws);
+    T* Q = reinterpret_cast<T*>(p); p += blk;
+    T* G = reinterpret_cast<T*>(p); p += blk;
+    T* A = reinterpret_cast<T*>(p); p += blk;
+    const size_t scan_bytes = ws_bytes - 3 * blk;
+    const bool chain = lsub != nullptr && n > 1;
+    const T* ls = chain ? lsub : static_cast<const T*>(nullptr);
+    const T* gs = chain ? g_sub : static_cast<const T*>(nullptr);
+    MF_LANE_LAUNCH((btd_inv_grad_pre_kernel<T, D>), dim3((unsigned)cdiv(B * n, 64)), dim3(64), 0, st, B, n, ldiag, ls, g_diag, gs,
+                   chain ? Q : A, G);
+    if (chain) {
+        const int rc = tak_scan<T, 3>(B, n, TakSrc<T>{Q, G, nullptr}, A, static_cast<T*>(nullptr), p, scan_bytes, st);
+        if (rc != 0) return rc;
+    }
+    MF_LANE_LAUNCH((btd_inv_grad_post_kernel<T, D>), dim3((unsigned)cdiv(B * n, 64)), dim3(64), 0, st, B, n, ldiag, ls, sigma,
+                   static_cast<const T*>(A), gs, static_cast<const T*>(G), g_ldiag, g_lsub);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
 // StateSpaceModel.marginal_covariances (+ subsequent_covariances) by the forward recursion; n = T >= 2 blocks
 template <typename T>
 int ssm_marginal_covs(long B, long n, const T* cholP0, const T* A, const T* cholQ, T* ocov, T* osub, void* ws, size_t ws_bytes,
@@ -1234,6 +1285,12 @@ int sde_predict(long B, long N, long Np, const long long* idx, const T* Amt, con
 }
 
 template <typename T>
+int sde_cond_stats(long n, const T* Amt, const T* Qmt, const T* Atp, const T* Qtp, T* proj, T* cov, int* info, hipStream_t st) {
+    MF_LANE_LAUNCH((sde_cond_stats_kernel<T, D>), dim3((unsigned)cdiv(n, 64)), dim3(64), 0, st, n, Amt, Qmt, Atp, Qtp, proj, cov, info);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+template <typename T>
 int kf_grad(long B, long Tn, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H,
             const T* y, const T* Rinv, const T* pm, const T* pS, const T* pX, T* gmu0, T* gC0, T* gA, T* gb, T* gC, T* gH,
             T* gy, T* gOm, const T* weights, int rinv_per_step, int* info, hipStream_t st) {
@@ -1423,7 +1480,7 @@ template <typename T> const OpsTable<T>* table() {
         &kf_loglik_ws<T>, &kf_loglik<T>, &btd_logdet_quad_ws<T>, &btd_logdet_quad<T>, &btd_cholesky_ws<T>, &btd_cholesky<T>,
         &btd_solve_ws<T>, &btd_solve<T>,    &btd_matvec<T>, &btd_logdet<T>,        &btd_diag_of_inverse_ws<T>, &btd_diag_of_inverse<T>, &ssm_marginal_covs<T>, &btd_udl_ws<T>, &btd_udl<T>,
         &ssm_precision<T>, &ssm_means_entry<T>, &block_matmul<T>, &gpr_loglik<T>, &sde_predict<T>, &kf_grad<T>, &kl_grad<T>, &posterior_chain<T>, &kl_value<T>, &marginals_grad<T>, &adjoint_ws<T>, &ssm_marginals_entry<T>, &kl_ws<T>, &marginals_ws<T>,
-        &kf_loglik_plan<T>,
+        &kf_loglik_plan<T>, &sde_cond_stats<T>, &btd_grad_ws<T>, &btd_cholesky_grad<T>, &btd_diag_of_inverse_grad<T>,
     };
     return &t;
 }

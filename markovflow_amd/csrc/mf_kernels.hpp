@@ -889,6 +889,62 @@ __global__ void __launch_bounds__(64) sde_predict_kernel(long B, long N, long Np
     if (bad && info) raise_info(info);
 }
 
+// conditional_statistics (markovflow/conditionals.py:87-203) alone: the statistics of p(x_t | x_-, x_+) = N(P_t [x_-, x_+], T_t) for
+// every new point from the transitions x_- -> x_t (A_mt, Q_mt) and x_t -> x_+ (A_tp, Q_tp) - the first half of sde_predict_kernel
+// with P_t = [D | E] (d x 2d) and T_t (d x d, symmetric) written out.  One lane per point.
+template <typename T, int D>
+__global__ void __launch_bounds__(64) sde_cond_stats_kernel(long n, const T* __restrict__ Amt, const T* __restrict__ Qmt,
+                                                            const T* __restrict__ Atp, const T* __restrict__ Qtp,
+                                                            T* __restrict__ proj, T* __restrict__ cov, int* info) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n) return;
+    T Am[D][D], Qm[D][D], Ap[D][D], Qp[D][D];
+    load_mat<T, D, D>(Amt + id * D * D, Am);
+    load_mat<T, D, D>(Qmt + id * D * D, Qm);
+    load_mat<T, D, D>(Atp + id * D * D, Ap);
+    load_lower<T, D>(Qtp + id * D * D, Qp);
+    T G[D][D];
+    MF_UNROLL for (int r = 0; r < D; ++r)
+        MF_UNROLL for (int c = 0; c < D; ++c) {
+            T a = T(0);
+            MF_UNROLL for (int l = 0; l < D; ++l) a += Ap[r][l] * Qm[l][c];
+            G[r][c] = a;                                 // A_tp Q_mt
+        }
+    MF_UNROLL for (int r = 0; r < D; ++r)
+        MF_UNROLL for (int c = 0; c <= r; ++c) {
+            T a = Qp[r][c];
+            MF_UNROLL for (int l = 0; l < D; ++l) a += G[r][l] * Ap[c][l];
+            Qp[r][c] = a;                                // Q-+ (lower)
+        }
+    T Li[D];
+    LogAcc<T> la;
+    la.init();
+    bool bad = false;
+    chol_lower<T, D>(Qp, Li, la, bad);
+    trsm_left_lower<T, D, D>(Qp, Li, G);                 // V = L^-1 A_tp Q_mt
+    T Tm[D][D];
+    MF_UNROLL for (int r = 0; r < D; ++r) MF_UNROLL for (int c = 0; c <= r; ++c) Tm[r][c] = Qm[r][c];
+    syrk_tn_lower<T, D, D>(G, Tm, T(-1));                // T = Q_mt - V^T V (lower)
+    trsm_left_lower_t<T, D, D>(Qp, Li, G);               // E^T = L^-T V
+    T* pr = proj + id * D * 2 * D;
+    MF_UNROLL for (int r = 0; r < D; ++r) {
+        T ea[D];                                         // row r of E A_tp
+        MF_UNROLL for (int c = 0; c < D; ++c) {
+            T a = T(0);
+            MF_UNROLL for (int l = 0; l < D; ++l) a += G[l][r] * Ap[l][c];
+            ea[c] = a;
+        }
+        MF_UNROLL for (int c = 0; c < D; ++c) {
+            T a = Am[r][c];
+            MF_UNROLL for (int l = 0; l < D; ++l) a -= ea[l] * Am[l][c];
+            pr[r * 2 * D + c] = a;                       // D = A_mt - E A_tp A_mt
+            pr[r * 2 * D + D + c] = G[c][r];             // E
+        }
+    }
+    store_sym<T, D>(cov + id * D * D, Tm);
+    if (bad && info) raise_info(info);
+}
+
 // Gradient of KalmanFilter.log_likelihood with respect to every tensor of the model, by Fisher's
 // identity: grad log p(y) = E_{x|y}[grad log p(x, y)], evaluated from the SMOOTHED pairwise marginals (means m_k, covariances
 // S_k, cross-covariances S_{k+1,k} = Cov(x_{k+1}, x_k)) - exact, and local in time: one lane per (series, time point).

@@ -69,6 +69,14 @@ template <typename T> struct OpsTable {
     // the level-0 kernel and time partition kf_loglik chooses: path 2 = the streaming kernel (mf_kf_lds.hpp), whose summaries
     // (P per series, L transitions each) sit at the start of the workspace
     int (*kf_loglik_plan)(long B, long Tn, int m, int rinv_per_step, long chunks, int aligned16, int* path, long* P, long* L);
+    // conditional_statistics (conditionals.py:87-203): P_t [n, d, 2d], T_t [n, d, d] from the transitions around every new point
+    int (*sde_cond_stats)(long n, const T* Amt, const T* Qmt, const T* Atp, const T* Qtp, T* proj, T* cov, int* info, hipStream_t st);
+    // reverse mode of cholesky / block_diagonal_of_inverse (block_tri_diag.py:22-31: banded_matrices' registered gradients)
+    size_t (*btd_grad_ws)(long B, long n);
+    int (*btd_cholesky_grad)(long B, long n, const T* ldiag, const T* lsub, const T* g_ldiag, const T* g_lsub, T* g_diag, T* g_sub,
+                             void* ws, size_t ws_bytes, hipStream_t st);
+    int (*btd_diag_of_inverse_grad)(long B, long n, const T* ldiag, const T* lsub, const T* sigma, const T* g_diag, const T* g_sub,
+                                    T* g_ldiag, T* g_lsub, void* ws, size_t ws_bytes, hipStream_t st);
 };
 
 // streamed, time-partitioned posterior chain (mf_post_lds.hpp, instantiated by mf_post_inst.hip for d = 1 ... MF_MAX_D_POST)

@@ -105,6 +105,11 @@ MF_DEV void load_cov_step(const TakSrc<T>& src, const T* mu0, const T* b, long s
         else d.o = T(0);
         fence(Crow);
         row_cct<T, D>(Crow, d.Nn);
+    } else if constexpr (SRC == 3) {       // forward, explicit terms: Mp = M_{p-1} (its own row), N_p from a buffer of symmetric blocks
+        load_row<T, D>(src.a + (s * n + p) * D * D, rc, d.Nn);
+        if (n > 1) load_row<T, D>(src.b + (s * (n - 1) + (p > 0 ? p - 1 : 0)) * D * D, rc, d.Arow);
+        else sfor<D>([&](auto j) { d.Arow[decltype(j)::value] = T(0); });
+        d.o = T(0);
     } else {
         const long k = n - 1 - p;
         load_row<T, D>(src.a + (s * n + k) * D * D, rc, d.Nn);
@@ -246,7 +251,7 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, false)) row_co
         RowCovStep<T, D> d;
         load_cov_step<T, D, SRC, MEAN>(src, mean.mu0, mean.b, q.s, n, p, q.rc, d);
         T (&Nn)[D] = d.Nn;
-        const long k = SRC == 1 ? p : n - 1 - p;                      // block this position writes
+        const long k = (SRC == 1 || SRC == 3) ? p : n - 1 - p;        // block this position writes
         if (p > 0) {
             T T2[D];
             sfor<D>([&](auto j) { T2[decltype(j)::value] = T(0); });
@@ -254,7 +259,7 @@ __global__ void __launch_bounds__(64, row_par_waves(sizeof(T), D, false)) row_co
             row_mul<T, D, D>(d.Arow, Sr, T2);                          // A Sigma_{p-1}
             if constexpr (SRC == 1) {
                 if (osub && st) sfor<D>([&](auto j) { osub[(q.s * (n - 1) + p - 1) * D * D + q.r * D + decltype(j)::value] = T2[decltype(j)::value]; });
-            } else if constexpr (SRC == 0) {       // sub-diagonal block of the inverse: -Sigma_{k+1} G_k = -(G^T Sigma)^T
+            } else if constexpr (SRC == 0 || SRC == 2) {       // sub-diagonal block of the inverse: -Sigma_{k+1} G_k = -(G^T Sigma)^T
                 if (osub && st) sfor<D>([&](auto j) { osub[(q.s * (n - 1) + k) * D * D + decltype(j)::value * D + q.r] = -T2[decltype(j)::value]; });
             }
             fence(d.Arow);

@@ -270,16 +270,17 @@ template <typename T, int NT> MF_DEV T dot_cv(const CV<T, NT>& a, const CV<T, NT
 
 // ---- global memory <-> the accumulator layout ----------------------------------------------------------------------------------
 // g: d x d row-major.  lower: the strict upper triangle reads as zero; idpad: ones on the padded diagonal.
-template <typename T, int NT, int S>
+// EX: d == 16 NT exactly - no padding, every bound check folds away.
+template <typename T, int NT, int S, bool EX = false>
 MF_DEV void load_mat(Mat<T, NT>& m, const T* __restrict__ g, int d, bool lower, bool idpad, const Lane& ln) {
     MF_UNROLL for (int ti = 0; ti < NT; ++ti)
         MF_UNROLL for (int tj = 0; tj < NT; ++tj) {
             if (!nz<S>(ti, tj)) { m.t[ti][tj] = typename Tr<T>::v4{0, 0, 0, 0}; continue; }
             MF_UNROLL for (int e = 0; e < 4; ++e) {
                 const int i = 16 * ti + Tr<T>::row(ln.q, e), j = 16 * tj + ln.r;
-                const bool in = i < d && j < d && (!lower || j <= i);
+                const bool in = (EX || (i < d && j < d)) && (!lower || j <= i);
                 const T v = g[in ? i * d + j : 0];
-                m.t[ti][tj][e] = in ? v : ((idpad && i == j && i >= d) ? T(1) : T(0));
+                m.t[ti][tj][e] = in ? v : ((!EX && idpad && i == j && i >= d) ? T(1) : T(0));
             }
         }
 }
@@ -296,23 +297,24 @@ MF_DEV void load_mat_t(Mat<T, NT>& m, const T* __restrict__ g, int d, const Lane
             }
 }
 // tile (ti, tj) of a d x d row-major matrix, TRANSPOSED (t = g[16 ti ..][16 tj ..]^T)
-template <typename T> MF_DEV void load_tile_t(typename Tr<T>::v4& t, const T* __restrict__ g, int d, int ti, int tj, const Lane& ln) {
+template <typename T, bool EX = false>
+MF_DEV void load_tile_t(typename Tr<T>::v4& t, const T* __restrict__ g, int d, int ti, int tj, const Lane& ln) {
     MF_UNROLL for (int e = 0; e < 4; ++e) {
         const int i = 16 * ti + ln.r, j = 16 * tj + Tr<T>::row(ln.q, e);          // element (j', i') of the transposed tile
-        const bool in = i < d && j < d;
+        const bool in = EX || (i < d && j < d);
         const T v = g[in ? i * d + j : 0];
         t[e] = in ? v : T(0);
     }
 }
 // the d x d corner of a matrix; SYM: tiles ti <= tj hold a symmetric matrix, the lower off-diagonal tile comes through LDS
-template <typename T, int NT, bool SYM>
+template <typename T, int NT, bool SYM, bool EX = false>
 MF_DEV void store_mat(T* __restrict__ g, Mat<T, NT>& m, int d, T* lds, const Lane& ln) {
     if constexpr (SYM && NT == 2) transpose_tile<T>(m.t[1][0], m.t[0][1], lds, ln);
     MF_UNROLL for (int ti = 0; ti < NT; ++ti)
         MF_UNROLL for (int tj = 0; tj < NT; ++tj)
             MF_UNROLL for (int e = 0; e < 4; ++e) {
                 const int i = 16 * ti + Tr<T>::row(ln.q, e), j = 16 * tj + ln.r;
-                if (i < d && j < d) g[i * d + j] = m.t[ti][tj][e];
+                if (EX || (i < d && j < d)) g[i * d + j] = m.t[ti][tj][e];
             }
 }
 template <typename T, int NT> MF_DEV void load_cv(CV<T, NT>& v, const T* __restrict__ g, int d, const Lane& ln) {
@@ -460,12 +462,13 @@ template <typename T, int M> MF_DEV void load_rinv(T (&Ri)[M][M], const T* __res
 // of big_kf_chunk_kernel, mf_big_impl.hpp: the levels behind it do not know which kernel produced their input).
 // WPE: wavefronts per SIMD the register allocation is held to (the diagonal-tile chains are fp64 / fp32 VALU work that one
 // wavefront alone issues at a third of the rate two or more reach together: scripts/micro/dpp_f64_rate.hip)
-template <typename T, int NT, int M, int WPE>
+template <typename T, int NT, int M, int WPE, bool EX>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) wave_kf_chunk_kernel(WvArgs<T> a, RedSys<T> out) {
     __shared__ __attribute__((aligned(16))) T lds[NT * NT * 16 * Tr<T>::LD];
-    const Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
+    Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
     const long id = blockIdx.x, s = id / a.P, c = id % a.P;
-    const int d = a.d, m = a.m;
+    int d = EX ? 16 * NT : a.d;          // EX: the state dimension fills its tiles exactly (d = 16, 32): no padding, no bound checks
+    const int m = a.m;
     const long nt = a.Tn - 1, tau0 = c * a.L;
     long len = nt - tau0;
     if (len > a.L) len = a.L;
@@ -506,8 +509,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     };
 
     if (c == 0) {   // block 0: the prior
-        load_mat<T, NT, S_LOWER>(C, a.cholP0 + s * dd, d, true, true, ln);
-        if constexpr (NT == 2) load_tile_t<T>(c10t, a.cholP0 + s * dd, d, 1, 0, ln);
+        load_mat<T, NT, S_LOWER, EX>(C, a.cholP0 + s * dd, d, true, true, ln);
+        if constexpr (NT == 2) load_tile_t<T, EX>(c10t, a.cholP0 + s * dd, d, 1, 0, ln);
         load_rv<T, NT>(mv_rv, a.mu0 + s * d, d, ln);
         load_cv<T, NT>(mv_cv, a.mu0 + s * d, d, ln);
         ob.load(a.H + (s * a.Tn) * m * d, a.y + (s * a.Tn) * m, d, m, ln);
@@ -516,11 +519,28 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
         MF_UNROLL for (int i = 0; i < NT; ++i) MF_UNROLL for (int j = i; j < NT; ++j) E.Phi.t[i][j] = Dn.t[i][j];
         E.t = rn;
     }
+    Mat<T, NT> Cn;
+    typename Tr<T>::v4 c10tn = {0, 0, 0, 0};
+    if (len > 0) {
+        load_mat<T, NT, S_LOWER, EX>(Cn, a.cholQ + (s * nt + tau0) * dd, d, true, true, ln);
+        if constexpr (NT == 2) load_tile_t<T, EX>(c10tn, a.cholQ + (s * nt + tau0) * dd, d, 1, 0, ln);
+    }
     for (long j = 0; j < len; ++j) {
         const long tau = tau0 + j, blk = tau + 1;
-        load_mat<T, NT, S_LOWER>(C, a.cholQ + (s * nt + tau) * dd, d, true, true, ln);
-        if constexpr (NT == 2) load_tile_t<T>(c10t, a.cholQ + (s * nt + tau) * dd, d, 1, 0, ln);
-        load_mat<T, NT, S_FULL>(Am, a.A + (s * nt + tau) * dd, d, false, false, ln);
+        // (the lane coordinates and d are made opaque once per step: everything derived from them - load offsets, padding masks,
+        // the unit vectors of the substitutions - would otherwise be hoisted out of the loop and live, or spill, across it)
+        asm volatile("" : "+v"(ln.r), "+v"(ln.q));
+        if constexpr (!EX) asm volatile("" : "+s"(d));
+        // the step opens with the inversion of chol(Q): its factor was fetched one step ahead (everything else is first used a few
+        // microseconds into the step, behind that inversion, and is simply loaded here)
+        C = Cn;
+        c10t = c10tn;
+        {
+            const long tn = (j + 1 < len) ? tau + 1 : tau;
+            load_mat<T, NT, S_LOWER, EX>(Cn, a.cholQ + (s * nt + tn) * dd, d, true, true, ln);
+            if constexpr (NT == 2) load_tile_t<T, EX>(c10tn, a.cholQ + (s * nt + tn) * dd, d, 1, 0, ln);
+        }
+        load_mat<T, NT, S_FULL, EX>(Am, a.A + (s * nt + tau) * dd, d, false, false, ln);
         load_rv<T, NT>(mv_rv, a.b + (s * nt + tau) * d, d, ln);
         load_cv<T, NT>(mv_cv, a.b + (s * nt + tau) * d, d, ln);
         ob.load(a.H + (s * a.Tn + blk) * m * d, a.y + (s * a.Tn + blk) * m, d, m, ln);

@@ -6,11 +6,17 @@
 namespace mf {
 
 namespace {
-// wavefronts per SIMD of the level-0 kernel (its register budget): two on one tile per matrix, one on 2 x 2 fp64 tiles
-template <typename T, int NT> constexpr int wave_wpe() { return NT == 1 ? (sizeof(T) == 8 ? 2 : 3) : (sizeof(T) == 8 ? 1 : 2); }
+// wavefronts per SIMD the level-0 kernel is compiled for (its register budget; none of these spills, `make` prints the usage):
+// one tile per matrix - fp64 two, fp32 four; 2 x 2 tiles - fp64 one (502 registers), fp32 two.  With two to four outputs the
+// observation rows cost up to forty more registers: one wavefront fewer in fp32
+template <typename T, int NT, int M> constexpr int wave_wpe() {
+    return NT == 1 ? (sizeof(T) == 8 ? 2 : (M == 1 ? 4 : 3)) : (sizeof(T) == 8 ? 1 : 2);
+}
 template <typename T, int NT, int M>
 int wave_launch(const wv::WvArgs<T>& a, const RedSys<T>& out, hipStream_t st) {
-    hipLaunchKernelGGL((wv::wave_kf_chunk_kernel<T, NT, M, wave_wpe<T, NT>()>), dim3((unsigned)(a.B * a.P)), dim3(64), 0, st, a, out);
+    const dim3 grid((unsigned)(a.B * a.P)), block(64);
+    if (a.d == 16 * NT) hipLaunchKernelGGL((wv::wave_kf_chunk_kernel<T, NT, M, wave_wpe<T, NT, M>(), true>), grid, block, 0, st, a, out);
+    else hipLaunchKernelGGL((wv::wave_kf_chunk_kernel<T, NT, M, wave_wpe<T, NT, M>(), false>), grid, block, 0, st, a, out);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 template <typename T>
@@ -26,7 +32,8 @@ int wave_level0(long B, long Tn, int d, int m, const T* mu0, const T* cholP0, co
 bool wave_covers(int d, int m) { return d >= 16 && d <= 32 && m >= 1 && m <= wv::WV_MAXM; }
 // wavefronts per SIMD the level-0 kernel runs at (by its registers): what one round of chunks over the chip is sized for
 int wave_waves_per_simd(int d, int elem_size) {
-    return d <= 16 ? (elem_size == 8 ? wave_wpe<double, 1>() : wave_wpe<float, 1>()) : (elem_size == 8 ? wave_wpe<double, 2>() : wave_wpe<float, 2>());
+    return d <= 16 ? (elem_size == 8 ? wave_wpe<double, 1, 1>() : wave_wpe<float, 1, 1>())
+                   : (elem_size == 8 ? wave_wpe<double, 2, 1>() : wave_wpe<float, 2, 1>());
 }
 
 int wave_kf_level0_f64(long B, long Tn, int d, int m, const double* mu0, const double* cholP0, const double* A, const double* b,

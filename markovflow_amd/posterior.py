@@ -57,11 +57,12 @@ class ConditionalProcess:
         flat = lambda t, k: t.reshape((-1,) + tuple(t.shape[-k:])).contiguous()  # noqa: E731
         bsz = max(1, int(torch.tensor(batch).prod())) if batch else 1
         if d > _lib.load().mf_max_state_dim():
-            # beyond the lane-per-point kernel (d <= 9): the same closed forms as batched products (the posterior chain and its
-            # moments above come from the row kernels / the tile engine)
-            mean, cov = _predict_state_dense(flat(idx, 1), flat(a_mt, 3), flat(q_mt, 3), flat(a_tp, 3), flat(q_tp, 3), flat(means, 2),
-                                             flat(covs, 3), None if sub is None else flat(sub, 3), flat(m0, 1), flat(p0, 2))
-            return mean.reshape(batch + (n_new, d)), cov.reshape(batch + (n_new, d, d))
+            # beyond the lane-per-point kernel (d <= 9): the reference's own composition (posterior.py:217-221) of the functions of
+            # conditionals.py - pairwise_marginals -> conditional_predict - as batched products (the posterior chain and its moments
+            # come from the row kernels / the tile engine)
+            from . import conditionals
+            pair_mean, pair_cov = conditionals.pairwise_marginals(dist, m0, p0)
+            return conditionals.conditional_predict(new, train, kern, pair_mean, pair_cov)
         out_mean = torch.empty((bsz, n_new, d), dtype=dtype, device=dev)
         out_cov = torch.empty((bsz, n_new, d, d), dtype=dtype, device=dev)
         info = _lib.pivot_info(dev)

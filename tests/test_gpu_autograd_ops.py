@@ -115,3 +115,79 @@ def test_cvi_shaped_gradient_through_precision_and_naturals(rng):
         fd = (float(_cvi_kl(ls0, var0, t_pts, nat1 + hstep * d1, nat2)) - float(_cvi_kl(ls0, var0, t_pts, nat1 - hstep * d1, nat2))) / (2 * hstep)
         assert float(torch.sum(n1.grad * d1)) == pytest.approx(fd, rel=2e-5, abs=1e-7)
         assert bool(torch.isfinite(n2.grad).all())
+
+
+# ---- the HIP adjoints of cholesky / block_diagonal_of_inverse (mf_btd_cholesky_grad_*, mf_btd_diag_of_inverse_grad_*) -------------
+def _random_factor(rng, batch, n, d, dtype=F64):
+    ld = np.tril(0.3 * rng.normal(size=batch + (n, d, d)), k=-1) + (1.0 + np.abs(0.3 * rng.normal(size=batch + (n, d))))[..., None] * np.eye(d)
+    ls = 0.3 * rng.normal(size=batch + (n - 1, d, d))
+    return torch.tensor(ld, dtype=dtype, device=DEV), torch.tensor(ls, dtype=dtype, device=DEV)
+
+
+@pytest.mark.parametrize("batch,n,d,with_sub,which", [
+    ((3,), 300, 6, True, "both"), ((2,), 1000, 4, True, "both"), ((4100,), 12, 4, True, "both"), ((2, 3), 40, 2, True, "both"),
+    ((5,), 64, 9, True, "both"), ((3,), 50, 7, True, "both"), ((2,), 30, 5, False, "both"), ((3,), 1, 3, False, "both"),
+    ((2,), 2, 6, True, "both"), ((2,), 200, 6, True, "diag"), ((2,), 200, 6, True, "sub"), ((1,), 3000, 1, True, "both"),
+])
+def test_hip_operator_adjoints_against_the_torch_recursions(batch, n, d, with_sub, which):
+    """The kernels against the block-by-block torch recursions (which tests/test_autograd_ops.py pins on dense autograd): few long
+    series (recursion parallel in time), many short ones (a lane per series), no coupling, a single block, only one of the two
+    output gradients given."""
+    from markovflow_amd import _autograd_ops as ag
+    rng = np.random.default_rng(11)
+    ldiag, lsub = _random_factor(rng, batch, n, d)
+    if not with_sub or n == 1:
+        lsub = None
+    g1 = torch.tensor(rng.normal(size=tuple(ldiag.shape)), dtype=F64, device=DEV) if which in ("both", "diag") else None
+    g2 = (torch.tensor(rng.normal(size=tuple(lsub.shape)), dtype=F64, device=DEV)
+          if (lsub is not None and which in ("both", "sub")) else None)
+    assert ag._hip_grad_ws(ldiag) is not None
+    # cholesky: gradients w.r.t. the factor's blocks -> gradients w.r.t. the matrix' blocks
+
+    class Ctx:
+        pass
+
+    ctx = Ctx()
+    ctx.has_sub = lsub is not None
+    ctx.saved_tensors = (ldiag, lsub if lsub is not None else ldiag.new_zeros(0))
+    _, gd, gs = ag.BtdCholesky.backward(ctx, g1, g2)
+    want_d, want_s = ag._cholesky_backward_torch(ldiag, lsub, g1, g2)
+    scale = float(want_d.abs().max())
+    assert float((gd - want_d).abs().max()) <= 1e-9 * scale
+    if lsub is not None:
+        assert float((gs - want_s).abs().max()) <= 1e-9 * max(float(want_s.abs().max()), scale)
+    # block_diagonal_of_inverse: gradients w.r.t. the blocks of the inverse -> gradients w.r.t. the factor's blocks
+    chol = mfa.LowerTriangularBlockTriDiagonal(ldiag, lsub)
+    odiag, _ = chol._diag_and_sub_of_inverse(want_sub=lsub is not None)
+    ctx = Ctx()
+    ctx.has_sub, ctx.want_sub = lsub is not None, lsub is not None
+    ctx.saved_tensors = (ldiag, lsub if lsub is not None else ldiag.new_zeros(0), odiag.contiguous())
+    _, gl, gw, _ = ag.BtdInverseBlocks.backward(ctx, g1, g2)
+    want_l, want_w = ag._inverse_blocks_backward_torch(ldiag, lsub, g1, g2)
+    if want_l is None:
+        want_l = torch.zeros_like(ldiag)
+    scale = max(float(want_l.abs().max()), 1e-30)
+    assert float((gl - want_l).abs().max()) <= 1e-9 * scale
+    if lsub is not None:
+        if want_w is None:
+            want_w = torch.zeros_like(lsub)
+        assert float((gw - want_w).abs().max()) <= 1e-9 * max(float(want_w.abs().max()), scale)
+
+
+def test_hip_operator_adjoints_fp32():
+    from markovflow_amd import _autograd_ops as ag
+    rng = np.random.default_rng(12)
+    ldiag, lsub = _random_factor(rng, (3,), 120, 5, dtype=torch.float32)
+    g1 = torch.tensor(rng.normal(size=tuple(ldiag.shape)), dtype=torch.float32, device=DEV)
+    g2 = torch.tensor(rng.normal(size=tuple(lsub.shape)), dtype=torch.float32, device=DEV)
+
+    class Ctx:
+        pass
+
+    ctx = Ctx()
+    ctx.has_sub = True
+    ctx.saved_tensors = (ldiag, lsub)
+    _, gd, gs = ag.BtdCholesky.backward(ctx, g1, g2)
+    want_d, want_s = ag._cholesky_backward_torch(ldiag.double(), lsub.double(), g1.double(), g2.double())
+    assert float((gd.double() - want_d).abs().max()) <= 2e-4 * float(want_d.abs().max())
+    assert float((gs.double() - want_s).abs().max()) <= 2e-4 * float(want_s.abs().max())
