@@ -164,7 +164,8 @@ def ptr(t: Optional[torch.Tensor]):
 
 
 def stream_ptr(device) -> ctypes.c_void_p:
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    idx = device.index if isinstance(device, torch.device) else torch.device(device).index
+    return ctypes.c_void_p(_raw_stream(torch.cuda.current_device() if idx is None else idx))
 
 
 class MarkovflowAmdError(RuntimeError):
@@ -194,22 +195,39 @@ def check(rc: int, what: str):
     raise ValueError(f"{what}: invalid argument #{-rc} (see include/markovflow_amd.h)")
 
 
+_PTR_ARGS = {}     # entry point -> positions of its device-pointer arguments (every "Tp" and void* of the signature)
+_FN = {}           # (entry point, dtype) -> the ctypes function
+
+
+def _raw_stream(device_index: int) -> int:
+    """The current stream of a device as a raw handle - ``torch.cuda.current_stream()`` builds a Stream object (3 us, and every
+    launch needs the handle two or three times)."""
+    return torch._C._cuda_getCurrentRawStream(device_index)
+
+
 def call_rc(base: str, dtype: torch.dtype, *args) -> int:
     """Dispatch ``base_f32`` / ``base_f64`` and return the ABI's return code.  Every floating-point tensor argument must have
     the dispatch dtype and all tensors must live on one device (a float32 buffer read as doubles would run past its end); the
-    launch happens with that device current."""
-    fn = getattr(load(), base + suffix(dtype))
+    launch happens with that device current.  (The checks walk the pointer positions of the signature only, and the device is
+    switched only when it is not the current one: the Python layer's per-call cost is what an evaluation of ~0.1 ms of kernels -
+    BASELINE config 2 - is made of, scripts/prof_host.py.)"""
+    fn = _FN.get((base, dtype))
+    if fn is None:
+        fn = _FN[(base, dtype)] = getattr(load(), base + suffix(dtype))
+        _PTR_ARGS[base] = tuple(i for i, a in enumerate(_SIGS[base][1]) if a == "Tp" or a is _vp)
     device = None
-    for a in args:
-        if isinstance(a, DevPtr):
-            if a.dtype.is_floating_point and a.dtype != dtype:
+    for i in _PTR_ARGS[base]:
+        a = args[i]
+        if type(a) is DevPtr:
+            if a.dtype != dtype and a.dtype.is_floating_point:
                 raise TypeError(f"{base}: got a {a.dtype} tensor in a {dtype} call; all tensors of one model must share a dtype")
             if device is None:
                 device = a.device
             elif a.device != device:
                 raise ValueError(f"{base}: tensors on different devices ({device} and {a.device})")
-    raise_pending()
-    if device is None:
+    if _flags and not _suppress:
+        raise_pending()
+    if device is None or device.index is None or device.index == torch.cuda.current_device():
         return fn(*args)
     with torch.cuda.device(device):
         return fn(*args)
@@ -327,17 +345,18 @@ _suppress = 0
 
 def pivot_info(device):
     """The `info` argument of a factorising entry point: pointer to the device int of (this device, its current stream)."""
-    device = torch.device(device)
+    if not isinstance(device, torch.device):
+        device = torch.device(device)
     if device.type != "cuda":
         raise RuntimeError("markovflow_amd kernels run on an MI355X only: got a CPU tensor and there is no CPU fallback. "
                            "Move the inputs to device 'cuda'.")
     idx = device.index
     idx = torch.cuda.current_device() if idx is None else idx
-    stream = torch.cuda.current_stream(idx)
-    key = (idx, stream.cuda_stream)
-    if key not in _flags:
-        _flags[key] = _Flag(idx, stream)
-    return _flags[key].ptr
+    key = (idx, _raw_stream(idx))
+    flag = _flags.get(key)
+    if flag is None:
+        flag = _flags[key] = _Flag(idx, torch.cuda.current_stream(idx))
+    return flag.ptr
 
 
 def _take_failures(synced: bool = False, synchronise: bool = False):
@@ -451,17 +470,18 @@ def raise_on_info(info, what: str, device=None, more_follow: bool = False):
         del _issued[:-64]
     if info is None:
         return
-    idx = torch.device(device).index if device is not None else None
+    if device is not None and not isinstance(device, torch.device):
+        device = torch.device(device)
+    idx = device.index if device is not None else None
     idx = torch.cuda.current_device() if idx is None else idx
-    stream = torch.cuda.current_stream(idx)
-    flag = _flags.get((idx, stream.cuda_stream))
+    flag = _flags.get((idx, _raw_stream(idx)))
     if flag is not None:
         if more_follow and not CHECK_PIVOTS:
             flag.pending = True
         else:
             flag.mirror()
     if CHECK_PIVOTS and not _suppress:
-        stream.synchronize()
+        torch.cuda.current_stream(idx).synchronize()
         ops = _take_failures(synced=True)
         if ops is not None:
             raise MarkovflowAmdError(f"{what}: matrix is not positive definite")

@@ -529,6 +529,11 @@ int btd_cholesky(long B, long n, const T* diag, const T* sub, T* ldiag, T* lsub,
         if (sub && n >= 2)
             MF_LANE_LAUNCH((par_chol_emit_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, n, 1L, diag,
                                sub, static_cast<const T*>(nullptr), ldiag, lsub, info);
+        else if (!sub)
+            // block-diagonal matrix: every block is a chain of its own - a lane per BLOCK, not per series (naturals_to_ssm_params
+            // factors three of these at [64, 10^4]: 19 ms each with 64 lanes walking 10^4 blocks, profiles/r05_cvi_chain.txt)
+            MF_LANE_LAUNCH((btd_cholesky_kernel<T, D>), dim3((unsigned)cdiv(B * n, 64)), dim3(64), 0, st, B * n, 1L, diag, sub,
+                               ldiag, lsub, info);
         else
             MF_LANE_LAUNCH((btd_cholesky_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, diag, sub,
                                ldiag, lsub, info);
@@ -624,6 +629,9 @@ int btd_solve(long Bl, long Br, long n, const T* ldiag, const T* lsub, const T* 
         if (lsub && n >= 2)     // one lane per right-hand side: the level-0 emit kernel as ONE chunk (prefetched loads)
             MF_LANE_LAUNCH((par_solve_emit_kernel<T, D>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Bl, Br, n, n, 1L,
                                ldiag, lsub, rhs, static_cast<const T*>(nullptr), transpose, out);
+        else if (!lsub)         // block-diagonal factor: a lane per (right-hand side, block); flat (r n + k) mod (Bl n) is the factor's block
+            MF_LANE_LAUNCH((btd_solve_kernel<T, D>), dim3((unsigned)cdiv(Br * n, 64)), dim3(64), 0, st, Bl * n, Br * n, 1L, ldiag,
+                               lsub, rhs, out, transpose);
         else
             MF_LANE_LAUNCH((btd_solve_kernel<T, D>), dim3((unsigned)cdiv(Br, 64)), dim3(64), 0, st, Bl, Br, n, ldiag,
                                lsub, rhs, out, transpose);
@@ -819,8 +827,9 @@ int tak_scan(long B, long n, TakSrc<T> src, T* odiag, T* osub, void* ws, size_t 
 template <typename T>
 int btd_diag_of_inverse(long B, long n, const T* ldiag, const T* lsub, T* odiag, T* osub, void* ws, size_t ws_bytes,
                         hipStream_t st) {
-    if (!lsub || n < 2) {       // block-diagonal factor: nothing to scan
-        MF_LANE_LAUNCH((btd_diag_of_inverse_kernel<T, D>), dim3((unsigned)cdiv(B, 64)), dim3(64), 0, st, B, n, ldiag,
+    if (!lsub || n < 2) {       // block-diagonal factor: nothing to scan - a lane per block
+        const long nb = lsub ? B : B * n, nn = lsub ? n : 1L;
+        MF_LANE_LAUNCH((btd_diag_of_inverse_kernel<T, D>), dim3((unsigned)cdiv(nb, 64)), dim3(64), 0, st, nb, nn, ldiag,
                            lsub, odiag, osub);
         return hipGetLastError() == hipSuccess ? 0 : -1000;
     }

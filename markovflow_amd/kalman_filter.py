@@ -424,7 +424,7 @@ class BaseKalmanFilter(abc.ABC):
         # (kept only where posterior_state_space_model would take the streamed kernels: the workspace stays alive with the filter)
         streamed_post = bsz < self._POST_FUSED_MIN_SERIES and n > self._POST_FUSED_MAX_SERIAL_BLOCKS and m <= 3
         key, sources = self._cache_key() if (usable and self._POST_FROM_FILTER and streamed_post) else (None, None)
-        stream = torch.cuda.current_stream(a_s.device) if a_s.is_cuda else None
+        stream = torch.cuda.current_stream(a_s.device) if (key is not None and a_s.is_cuda) else None
         self._filter_cache = (key, ws, int(p_f.value), int(l_f.value), sources, stream) if key is not None else None
         return out
 
