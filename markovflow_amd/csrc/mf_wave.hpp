@@ -197,36 +197,155 @@ MF_DEV void tri_inv_tile(const typename Tr<T>::v4& C, typename Tr<T>::v4& Ci, T*
     cols_to_tile<T>(x, Ci, ln);
 }
 
-// C (lower, tiles 00 [10 11]) -> Ci = C^-1 (S_LOWER).  NT = 2: c10t = (C10)^T, which the caller reads transposed from memory.
+// ---- several diagonal tiles at once: the four 16-lane rows of the wavefront work on NTL = 1, 2 or 4 DIFFERENT tiles --------------
+// (tile i in rows [i * 4 / NTL, (i + 1) * 4 / NTL)): the same instruction stream, a quarter / half of the per-tile cost.  In: the
+// tiles in the accumulator layout -> NTL images -> each lane reads its row of ITS tile.  Out: the first row of lanes of every
+// tile writes the columns of the inverse into the tile's image, from where every lane reads the inverse - or its transpose,
+// whichever the caller multiplies with - back in the accumulator layout.  la / bad: per LANE (the lane's own tile); the caller
+// extracts a tile's values from a lane of its rows.
+template <int NTL> MF_DEV int tile_of_row(int q) { return NTL == 4 ? q : (NTL == 2 ? (q >> 1) : 0); }
+template <typename T, int NTL> MF_DEV void rows_in(const typename Tr<T>::v4 (&t)[NTL], T* img, T (&a)[16], const Lane& ln) {
+    using v2 = typename Tr<T>::v2;
+    constexpr int TS = 16 * Tr<T>::LD;
+    lds_fence();
+    MF_UNROLL for (int i = 0; i < NTL; ++i) tile_to_image<T>(t[i], img + i * TS, ln);
+    lds_fence();
+    const T* mine = img + tile_of_row<NTL>(ln.q) * TS + ln.r * Tr<T>::LD;
+    MF_UNROLL for (int k = 0; k < 8; ++k) {
+        const v2 p = *reinterpret_cast<const v2*>(mine + 2 * k);
+        a[2 * k] = p[0];
+        a[2 * k + 1] = p[1];
+    }
+    lds_fence();
+}
+// TR: read the transposes
+template <typename T, int NTL, bool TR> MF_DEV void cols_out(const T (&x)[16], typename Tr<T>::v4 (&t)[NTL], T* img, const Lane& ln) {
+    constexpr int TS = 16 * Tr<T>::LD;
+    if ((ln.q & (4 / NTL - 1)) == 0) {                      // the first row of lanes of every tile
+        T* mine = img + tile_of_row<NTL>(ln.q) * TS + ln.r;
+        MF_UNROLL for (int row = 0; row < 16; ++row) mine[row * Tr<T>::LD] = x[row];
+    }
+    lds_fence();
+    MF_UNROLL for (int i = 0; i < NTL; ++i) {
+        if (TR) image_to_tile_t<T>(t[i], img + i * TS, ln);
+        else {
+            MF_UNROLL for (int e = 0; e < 4; ++e) t[i][e] = img[i * TS + Tr<T>::row(ln.q, e) * Tr<T>::LD + ln.r];
+        }
+    }
+    lds_fence();
+}
+// P[i] (symmetric positive definite, lower triangle used) -> out[i] = chol(P[i])^-1 (TR: its transpose)
+template <typename T, int NTL, bool TR>
+MF_DEV void chol_inv_tiles(const typename Tr<T>::v4 (&P)[NTL], typename Tr<T>::v4 (&out)[NTL], T* img, const Lane& ln, LogAcc<T>& la,
+                           bool& bad) {
+    using D = Dpp<T>;
+    T a[16], x[16];
+    rows_in<T, NTL>(P, img, a, ln);
+    sfor<16>([&](auto i) { x[decltype(i)::value] = (ln.r == decltype(i)::value) ? T(1) : T(0); });
+    sfor<16>([&](auto j) {
+        constexpr int jj = decltype(j)::value;
+        fence1(a[jj]);
+        const T s = D::template bcast<jj>(a[jj]);
+        bad |= !(s > T(0));
+        const T inv = row::row_rsqrt(s);
+        la.mul(s);
+        if constexpr (jj == 7) la.renorm();
+        a[jj] *= inv;
+        x[jj] *= inv;
+        fence1(a[jj]);
+        sfor2<jj + 1, 16>([&](auto k) {
+            constexpr int kk = decltype(k)::value;
+            D::template fnmac<kk>(a[kk], a[jj], a[jj]);
+            D::template fnmac<kk>(x[kk], a[jj], x[jj]);
+        });
+    });
+    la.renorm();
+    cols_out<T, NTL, TR>(x, out, img, ln);
+}
+// C[i] (lower triangular) -> out[i] = C[i]^-1 (TR: its transpose)
+template <typename T, int NTL, bool TR>
+MF_DEV void tri_inv_tiles(const typename Tr<T>::v4 (&C)[NTL], typename Tr<T>::v4 (&out)[NTL], T* img, const Lane& ln, LogAcc<T>& la,
+                          bool& bad) {
+    using D = Dpp<T>;
+    T a[16], x[16], dinv[16];
+    rows_in<T, NTL>(C, img, a, ln);
+    fence(a);
+    sfor<16>([&](auto k) {
+        constexpr int kk = decltype(k)::value;
+        const T c = D::template bcast<kk>(a[kk]);
+        bad |= !(c != T(0));
+        dinv[kk] = t_rcp<T>(c);
+        la.mul(c);
+        if constexpr (kk == 7) la.renorm();
+    });
+    la.renorm();
+    sfor<16>([&](auto i) { x[decltype(i)::value] = (ln.r == decltype(i)::value) ? T(1) : T(0); });
+    sfor<16>([&](auto k) {
+        constexpr int kk = decltype(k)::value;
+        x[kk] *= dinv[kk];
+        sfor2<kk + 1, 16>([&](auto i) { D::template fnmac<decltype(i)::value>(x[decltype(i)::value], a[kk], x[kk]); });
+    });
+    cols_out<T, NTL, TR>(x, out, img, ln);
+}
+// the value a per-lane accumulator holds for tile i of NTL (a lane of the tile's first row)
+template <typename T, int NTL> MF_DEV T of_tile(T v, int i) { return __shfl(v, 16 * (i * (4 / NTL)), 64); }
+
+// C (lower, tiles 00 [10 11]) -> Ci = C^-1 (S_LOWER).  NT = 2: c10t = (C10)^T, which the caller reads transposed from memory; the
+// two diagonal tiles are inverted side by side (two 16-lane rows each).  la: per lane, the diagonal of the lane's own tile.
 template <typename T, int NT>
 MF_DEV void tri_inv_mat(const Mat<T, NT>& C, const typename Tr<T>::v4& c10t, Mat<T, NT>& Ci, T* lds, const Lane& ln, LogAcc<T>& la,
                         bool& bad) {
-    MF_UNROLL for (int i = 0; i < NT; ++i) tri_inv_tile<T>(C.t[i][i], Ci.t[i][i], lds, ln, la, bad);
-    if constexpr (NT == 2) {
-        using v4 = typename Tr<T>::v4;
+    using v4 = typename Tr<T>::v4;
+    if constexpr (NT == 1) {
+        const v4 in[1] = {C.t[0][0]};
+        v4 out[1];
+        tri_inv_tiles<T, 1, false>(in, out, lds, ln, la, bad);
+        Ci.t[0][0] = out[0];
+    } else {
+        const v4 in[2] = {C.t[0][0], C.t[1][1]};
+        v4 out[2], cit11;
+        tri_inv_tiles<T, 2, false>(in, out, lds, ln, la, bad);
+        image_to_tile_t<T>(cit11, lds + 16 * Tr<T>::LD, ln);                                    // Ci11^T: the image is still there
+        lds_fence();
+        Ci.t[0][0] = out[0];
+        Ci.t[1][1] = out[1];
         // Ci10 = -Ci11 (C10 Ci00): both products in the P^T Q form
-        v4 g = {0, 0, 0, 0}, h = {0, 0, 0, 0}, cit11;
+        v4 g = {0, 0, 0, 0}, h = {0, 0, 0, 0};
         MF_UNROLL for (int e = 0; e < 4; ++e) g = Tr<T>::mfma(c10t[e], Ci.t[0][0][e], g);           // C10 Ci00
-        transpose_tile<T>(cit11, Ci.t[1][1], lds, ln);
         MF_UNROLL for (int e = 0; e < 4; ++e) h = Tr<T>::mfma(cit11[e], g[e], h);                   // Ci11 (C10 Ci00)
         Ci.t[1][0] = -h;
         Ci.t[0][1] = v4{0, 0, 0, 0};
     }
 }
+// log of the product a per-lane accumulator of tri_inv_mat holds, over all NT diagonal tiles
+template <typename T, int NT> MF_DEV T tri_logdet(const LogAcc<T>& la) {
+    const T v = la.value();
+    if constexpr (NT == 1) return v;
+    else return of_tile<T, 2>(v, 0) + of_tile<T, 2>(v, 1);
+}
 // Phi (symmetric, tiles ti <= tj valid) -> LiT = (chol(Phi)^-1)^T (S_UPPER); Phi's tile (1,1) is consumed
 template <typename T, int NT>
 MF_DEV void chol_inv_mat(Mat<T, NT>& Phi, Mat<T, NT>& LiT, T* lds, const Lane& ln, LogAcc<T>& la, bool& bad) {
     using v4 = typename Tr<T>::v4;
-    v4 li00;
-    chol_inv_tile<T>(Phi.t[0][0], li00, lds, ln, la, bad);
-    transpose_tile<T>(LiT.t[0][0], li00, lds, ln);
+    {
+        const v4 in[1] = {Phi.t[0][0]};
+        v4 out[1];
+        chol_inv_tiles<T, 1, true>(in, out, lds, ln, la, bad);
+        LiT.t[0][0] = out[0];
+    }
     if constexpr (NT == 2) {
-        v4 lt01 = {0, 0, 0, 0}, acc = {0, 0, 0, 0}, z = {0, 0, 0, 0}, h = {0, 0, 0, 0}, li11;
+        v4 li00, lt01 = {0, 0, 0, 0}, acc = {0, 0, 0, 0}, z = {0, 0, 0, 0}, h = {0, 0, 0, 0};
+        MF_UNROLL for (int e = 0; e < 4; ++e) li00[e] = lds[Tr<T>::row(ln.q, e) * Tr<T>::LD + ln.r];            // L00^-1: the image is still there
+        lds_fence();
         MF_UNROLL for (int e = 0; e < 4; ++e) lt01 = Tr<T>::mfma(LiT.t[0][0][e], Phi.t[0][1][e], lt01);      // (L10)^T = Li00 Phi01
         MF_UNROLL for (int e = 0; e < 4; ++e) acc = Tr<T>::mfma(lt01[e], lt01[e], acc);                      // L10 L10^T
         Phi.t[1][1] -= acc;
-        chol_inv_tile<T>(Phi.t[1][1], li11, lds, ln, la, bad);
-        transpose_tile<T>(LiT.t[1][1], li11, lds, ln);
+        {
+            const v4 in[1] = {Phi.t[1][1]};
+            v4 out[1];
+            chol_inv_tiles<T, 1, true>(in, out, lds, ln, la, bad);
+            LiT.t[1][1] = out[0];
+        }
         MF_UNROLL for (int e = 0; e < 4; ++e) z = Tr<T>::mfma(lt01[e], li00[e], z);                          // Z = L10 Li00
         MF_UNROLL for (int e = 0; e < 4; ++e) h = Tr<T>::mfma(z[e], LiT.t[1][1][e], h);                      // Z^T Li11^T
         LiT.t[0][1] = -h;
@@ -363,6 +482,10 @@ template <typename T, int NT> struct WaveElim {
     template <bool SPIKE> MF_DEV void eliminate(T* lds, const Lane& ln) {
         chol_inv_mat<T, NT>(Phi, LiT, lds, ln, laL, bad);
         phase();
+        after_factor<SPIKE>(ln);
+    }
+    // ... with LiT already in place (the multi-chunk kernel factors the pivots of its chunks side by side)
+    template <bool SPIKE> MF_DEV void after_factor(const Lane& ln) {
         RV<T, NT> t_rv;
         cv_to_rv<T, NT>(t_rv, t, ln);
         CV<T, NT> z;
@@ -573,9 +696,184 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
         }
     }
     const T ww = sum16<T>(acc_ww), quad = sum16<T>(E.quad);
-    const T scalar = T(-0.5) * (acc_yry + ww) + T(0.5) * quad - laC.value() - T(0.5) * E.laL.value();
+    const T scalar = T(-0.5) * (acc_yry + ww) + T(0.5) * quad - tri_logdet<T, NT>(laC) - T(0.5) * E.laL.value();
     store_chunk_wave<T, NT>(out, id, d, E, scalar, lds, ln);
     if (__any(E.bad) && threadIdx.x == 0 && a.info) raise_info(a.info);
+}
+
+// ---- NC chunks per wavefront (one tile per matrix) --------------------------------------------------------------------------
+// At d <= 16 a step is bound by vector-instruction issue, and two thirds of its ~1 050 vector instructions are the two diagonal-tile
+// factorisations, which all four 16-lane rows of the wavefront run redundantly.  Here a wavefront carries NC = 2 or 4
+// chunks: their matrix products, vector operations and loads run one chunk after the other on the whole wavefront, but the
+// factorisations of all NC chunks run SIDE BY SIDE in the rows (chol_inv_tiles / tri_inv_tiles with NTL = NC) - the same instruction
+// stream as for one chunk.  Chunks that have nothing to factor in a step (seed step of a spike, chunk already finished) hand in an
+// identity tile.  Same arithmetic per chunk, same reduced system, as wave_kf_chunk_kernel.
+template <typename T> MF_DEV typename Tr<T>::v4 identity_tile(const Lane& ln) {
+    typename Tr<T>::v4 t;
+    MF_UNROLL for (int e = 0; e < 4; ++e) t[e] = (Tr<T>::row(ln.q, e) == ln.r) ? T(1) : T(0);
+    return t;
+}
+template <typename T, int M, int WPE, bool EX, int NC>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) wave_kf_multi_kernel(WvArgs<T> a, RedSys<T> out) {
+    constexpr int NT = 1;
+    using v4 = typename Tr<T>::v4;
+    __shared__ __attribute__((aligned(16))) T lds[NC * 16 * Tr<T>::LD];
+    Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
+    int d = EX ? 16 : a.d;
+    const int m = a.m;
+    const long nt = a.Tn - 1, total = a.B * a.P, dd = long(d) * d;
+    long id[NC], sr[NC], tau0[NC], len[NC];
+    bool valid[NC], spike[NC];
+    long maxlen = 0;
+    MF_UNROLL for (int ci = 0; ci < NC; ++ci) {
+        const long raw = (long)blockIdx.x * NC + ci;
+        valid[ci] = raw < total;
+        id[ci] = valid[ci] ? raw : total - 1;
+        sr[ci] = id[ci] / a.P;
+        const long c = id[ci] % a.P;
+        tau0[ci] = c * a.L;
+        long l = nt - tau0[ci];
+        if (l > a.L) l = a.L;
+        if (l < 0 || !valid[ci]) l = 0;
+        len[ci] = l;
+        spike[ci] = c > 0;
+        if (l > maxlen) maxlen = l;
+    }
+    WaveElim<T, NT> E[NC];
+    LogAcc<T> laC, laL;                       // per LANE: the lane's own chunk (rows [ci * 4 / NC, (ci + 1) * 4 / NC))
+    laC.init();
+    laL.init();
+    bool bad = false;
+    T acc_ww[NC], acc_yry[NC];
+    T Ri[M][M];
+    if (!a.rinv_per_step) load_rinv<T, M>(Ri, a.Rinv, m);
+    Mat<T, NT> Cn[NC];
+    MF_UNROLL for (int ci = 0; ci < NC; ++ci) { E[ci].init(); acc_ww[ci] = T(0); acc_yry[ci] = T(0); }
+
+    // (everything a step computes per chunk is declared INSIDE the step: values assigned and used under `this chunk is active`
+    // would otherwise be carried around the loop on the other path - ~60 registers per chunk)
+    {   // block 0 of the chunks that start their series: the prior
+        Mat<T, NT> Dn[NC];
+        CV<T, NT> rn[NC], mv_cv[NC];
+        RV<T, NT> mv_rv[NC];
+        ObsRows<T, NT, M> ob[NC];
+        v4 cin[NC], cout[NC];
+        bool any0 = false;
+        MF_UNROLL for (int ci = 0; ci < NC; ++ci) {
+            cin[ci] = identity_tile<T>(ln);
+            if (valid[ci] && !spike[ci]) {
+                any0 = true;
+                Mat<T, NT> C0;
+                load_mat<T, NT, S_LOWER, EX>(C0, a.cholP0 + sr[ci] * dd, d, true, true, ln);
+                cin[ci] = C0.t[0][0];
+                load_rv<T, NT>(mv_rv[ci], a.mu0 + sr[ci] * d, d, ln);
+                load_cv<T, NT>(mv_cv[ci], a.mu0 + sr[ci] * d, d, ln);
+                ob[ci].load(a.H + (sr[ci] * a.Tn) * m * d, a.y + (sr[ci] * a.Tn) * m, d, m, ln);
+            }
+        }
+        if (any0) {
+            tri_inv_tiles<T, NC, false>(cin, cout, lds, ln, laC, bad);
+            MF_UNROLL for (int ci = 0; ci < NC; ++ci)
+                if (valid[ci] && !spike[ci]) {
+                    Mat<T, NT> Ci;
+                    Ci.t[0][0] = cout[ci];
+                    tn<T, NT, S_LOWER, S_LOWER, S_UPPER, OP_SET>(Dn[ci], Ci, Ci);
+                    tn_mv<T, NT, S_FULL>(rn[ci], Dn[ci], mv_rv[ci]);
+                    acc_ww[ci] += dot_cv<T, NT>(rn[ci], mv_cv[ci]);
+                    if (a.rinv_per_step) load_rinv<T, M>(Ri, a.Rinv + (sr[ci] * a.Tn) * m * m, m);
+                    acc_yry[ci] += obs_apply<T, NT, M>(ob[ci], Ri, Dn[ci], rn[ci]);
+                    E[ci].Phi.t[0][0] = Dn[ci].t[0][0];
+                    E[ci].t = rn[ci];
+                }
+        }
+    }
+    MF_UNROLL for (int ci = 0; ci < NC; ++ci) {
+        Cn[ci].t[0][0] = identity_tile<T>(ln);
+        if (len[ci] > 0) load_mat<T, NT, S_LOWER, EX>(Cn[ci], a.cholQ + (sr[ci] * nt + tau0[ci]) * dd, d, true, true, ln);
+    }
+    for (long j = 0; j < maxlen; ++j) {
+        asm volatile("" : "+v"(ln.r), "+v"(ln.q));
+        if constexpr (!EX) asm volatile("" : "+s"(d));
+        v4 cin[NC], cit[NC], pin[NC], lit[NC];
+        Mat<T, NT> Am[NC], Dn[NC], S[NC];
+        CV<T, NT> rn[NC], mv_cv[NC], btw[NC];
+        RV<T, NT> mv_rv[NC], rn0_rv[NC];
+        ObsRows<T, NT, M> ob[NC];
+        // the transition and the observation rows of chunk ci: issued one chunk ahead of their use (all of them up front would sit in
+        // registers across the factorisation of the chol(Q) tiles: scratch)
+        auto fetch = [&](int ci) {
+            if (j < len[ci]) {
+                const long tau = tau0[ci] + j, blk = tau + 1;
+                load_mat<T, NT, S_FULL, EX>(Am[ci], a.A + (sr[ci] * nt + tau) * dd, d, false, false, ln);
+                load_rv<T, NT>(mv_rv[ci], a.b + (sr[ci] * nt + tau) * d, d, ln);
+                load_cv<T, NT>(mv_cv[ci], a.b + (sr[ci] * nt + tau) * d, d, ln);
+                ob[ci].load(a.H + (sr[ci] * a.Tn + blk) * m * d, a.y + (sr[ci] * a.Tn + blk) * m, d, m, ln);
+            }
+        };
+        MF_UNROLL for (int ci = 0; ci < NC; ++ci) {
+            const bool act = j < len[ci];
+            cin[ci] = act ? Cn[ci].t[0][0] : identity_tile<T>(ln);
+            if (act) {
+                const long tau = tau0[ci] + j;
+                const long tn1 = (j + 1 < len[ci]) ? tau + 1 : tau;
+                load_mat<T, NT, S_LOWER, EX>(Cn[ci], a.cholQ + (sr[ci] * nt + tn1) * dd, d, true, true, ln);
+            }
+        }
+        fetch(0);
+        tri_inv_tiles<T, NC, false>(cin, cit, lds, ln, laC, bad);
+        phase();
+        MF_UNROLL for (int ci = 0; ci < NC; ++ci) {
+            pin[ci] = identity_tile<T>(ln);
+            if (ci + 1 < NC) fetch(ci + 1);
+            if (j < len[ci]) {
+                const long blk = tau0[ci] + j + 1;
+                {
+                    Mat<T, NT> Ci;
+                    Ci.t[0][0] = cit[ci];
+                    tn<T, NT, S_LOWER, S_LOWER, S_UPPER, OP_SET>(Dn[ci], Ci, Ci);
+                }
+                tn_mv<T, NT, S_FULL>(rn[ci], Dn[ci], mv_rv[ci]);
+                acc_ww[ci] += dot_cv<T, NT>(rn[ci], mv_cv[ci]);
+                cv_to_rv<T, NT>(rn0_rv[ci], rn[ci], ln);
+                tn<T, NT, S_FULL, S_FULL, S_FULL, OP_NEG>(S[ci], Dn[ci], Am[ci]);
+                tn_mv<T, NT, S_FULL>(btw[ci], Am[ci], rn0_rv[ci]);
+                if (a.rinv_per_step) load_rinv<T, M>(Ri, a.Rinv + (sr[ci] * a.Tn + blk) * m * m, m);
+                acc_yry[ci] += obs_apply<T, NT, M>(ob[ci], Ri, Dn[ci], rn[ci]);
+                if (j == 0 && spike[ci]) {
+                    tn<T, NT, S_FULL, S_FULL, S_UPPER, OP_NEG>(E[ci].GU, Am[ci], S[ci]);
+                    E[ci].X = S[ci];
+                    E[ci].gU.v[0] = -btw[ci].v[0];
+                    E[ci].Phi.t[0][0] = Dn[ci].t[0][0];
+                    E[ci].t = rn[ci];
+                } else {
+                    tn<T, NT, S_FULL, S_FULL, S_UPPER, OP_SUB>(E[ci].Phi, Am[ci], S[ci]);
+                    E[ci].t.v[0] -= btw[ci].v[0];
+                    pin[ci] = E[ci].Phi.t[0][0];
+                }
+            }
+            phase();
+        }
+        chol_inv_tiles<T, NC, true>(pin, lit, lds, ln, laL, bad);
+        phase();
+        MF_UNROLL for (int ci = 0; ci < NC; ++ci) {
+            if (j < len[ci] && !(j == 0 && spike[ci])) {
+                E[ci].LiT.t[0][0] = lit[ci];
+                if (spike[ci]) E[ci].template after_factor<true>(ln); else E[ci].template after_factor<false>(ln);
+                Mat<T, NT> ST, WT;
+                transpose<T, NT, S_FULL>(ST, S[ci], lds, ln);
+                tn<T, NT, S_UPPER, S_FULL, S_FULL, OP_SET>(WT, E[ci].LiT, ST);
+                if (spike[ci]) E[ci].template advance<true>(WT, Dn[ci], rn[ci]); else E[ci].template advance<false>(WT, Dn[ci], rn[ci]);
+            }
+            phase();
+        }
+    }
+    const T logC = laC.value(), logL = laL.value();
+    MF_UNROLL for (int ci = 0; ci < NC; ++ci) {
+        const T ww = sum16<T>(acc_ww[ci]), quad = sum16<T>(E[ci].quad);
+        const T scalar = T(-0.5) * (acc_yry[ci] + ww) + T(0.5) * quad - of_tile<T, NC>(logC, ci) - T(0.5) * of_tile<T, NC>(logL, ci);
+        if (valid[ci]) store_chunk_wave<T, NT>(out, id[ci], d, E[ci], scalar, lds, ln);
+    }
+    if (__any(bad) && threadIdx.x == 0 && a.info) raise_info(a.info);
 }
 
 }  // namespace wv

@@ -1,5 +1,6 @@
 // Instantiations of the wave kernels (mf_wave.hpp: one wavefront per (series, chunk), register tiles, 16 <= d <= 32) and the
 // entry points the tile engine's launcher (mf_big_impl.hpp) hands its level 0 to.
+#include <cstdlib>
 #include "mf_wave.hpp"
 #include "mf_launch.hpp"
 
@@ -11,6 +12,17 @@ namespace {
 // observation rows cost up to forty more registers: one wavefront fewer in fp32
 template <typename T, int NT, int M> constexpr int wave_wpe() {
     return NT == 1 ? (sizeof(T) == 8 ? 2 : (M == 1 ? 4 : 3)) : (sizeof(T) == 8 ? 1 : 2);
+}
+// chunks per wavefront at one tile per matrix (d <= 16; wave_kf_multi_kernel): two in fp64 at two wavefronts per SIMD, four in fp32
+template <typename T> constexpr int wave_nc() { return sizeof(T) == 8 ? 2 : 4; }
+template <typename T, int M> constexpr int wave_multi_wpe() { return 2; }
+template <typename T, int M>
+int wave_launch_multi(const wv::WvArgs<T>& a, const RedSys<T>& out, hipStream_t st) {
+    constexpr int NC = wave_nc<T>();
+    const dim3 grid((unsigned)((a.B * a.P + NC - 1) / NC)), block(64);
+    if (a.d == 16) hipLaunchKernelGGL((wv::wave_kf_multi_kernel<T, M, wave_multi_wpe<T, M>(), true, NC>), grid, block, 0, st, a, out);
+    else hipLaunchKernelGGL((wv::wave_kf_multi_kernel<T, M, wave_multi_wpe<T, M>(), false, NC>), grid, block, 0, st, a, out);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 template <typename T, int NT, int M>
 int wave_launch(const wv::WvArgs<T>& a, const RedSys<T>& out, hipStream_t st) {
@@ -24,6 +36,8 @@ int wave_level0(long B, long Tn, int d, int m, const T* mu0, const T* cholP0, co
                 const T* y, const T* Rinv, int rinv_per_step, long P, long L, const RedSys<T>& out, int* info, hipStream_t st) {
     if (!wave_covers(d, m)) return -101;
     const wv::WvArgs<T> a{B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, L, info};
+    static const bool multi = [] { const char* e = getenv("MF_WAVE_MULTI"); return !(e && e[0] == (char)48); }();  /* EXPERIMENT: revert to mf_knob */
+    if (d <= 16 && multi) return m == 1 ? wave_launch_multi<T, 1>(a, out, st) : wave_launch_multi<T, wv::WV_MAXM>(a, out, st);
     if (d <= 16) return m == 1 ? wave_launch<T, 1, 1>(a, out, st) : wave_launch<T, 1, wv::WV_MAXM>(a, out, st);
     return m == 1 ? wave_launch<T, 2, 1>(a, out, st) : wave_launch<T, 2, wv::WV_MAXM>(a, out, st);
 }
@@ -31,8 +45,9 @@ int wave_level0(long B, long Tn, int d, int m, const T* mu0, const T* cholP0, co
 
 bool wave_covers(int d, int m) { return d >= 16 && d <= 32 && m >= 1 && m <= wv::WV_MAXM; }
 // wavefronts per SIMD the level-0 kernel runs at (by its registers): what one round of chunks over the chip is sized for
+// (d <= 16: chunks in flight per SIMD = wavefronts x chunks per wavefront of the multi-chunk kernel)
 int wave_waves_per_simd(int d, int elem_size) {
-    return d <= 16 ? (elem_size == 8 ? wave_wpe<double, 1, 1>() : wave_wpe<float, 1, 1>())
+    return d <= 16 ? (elem_size == 8 ? wave_multi_wpe<double, 1>() * wave_nc<double>() : wave_multi_wpe<float, 1>() * wave_nc<float>())
                    : (elem_size == 8 ? wave_wpe<double, 2, 1>() : wave_wpe<float, 2, 1>());
 }
 

@@ -29,19 +29,8 @@ def _outer(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 
 def _chol_solve(chol: torch.Tensor, rhs: torch.Tensor) -> torch.Tensor:
-    """``(chol chol^T)^-1 rhs`` for stacks of blocks ``[..., d, d]`` against ``[..., d, k]``.  On the device (d <= 9): the blocks
-    as ONE block-diagonal factor and the k columns as leading right-hand-side dimensions of ``LowerTriangularBlockTriDiagonal.solve``
-    (a lane per (column, block); differentiable through its own adjoint) - rocBLAS' batched trsm takes 0.7 ms per call on
-    640 000 blocks of 6 x 6, twelve calls per evaluation of the CVI chain (profiles/r05_cvi_chain.txt)."""
-    d = chol.shape[-1]
-    if not (chol.is_cuda and chol.dim() >= 3 and d <= _lib.load().mf_max_state_dim() and chol.shape[:-2] == rhs.shape[:-2]
-            and chol.numel() > 0):
-        return _lib.chol_solve(chol, rhs)
-    k = rhs.shape[-1]
-    fac = LowerTriangularBlockTriDiagonal(chol.reshape(1, -1, d, d).contiguous())
-    cols = rhs.reshape(-1, d, k).permute(2, 0, 1).reshape(k, 1, -1, d).contiguous()          # [k, 1, blocks, d]
-    sol = fac.solve(fac.solve(cols), transpose_left=True)
-    return sol.reshape(k, -1, d).permute(1, 2, 0).reshape(rhs.shape)
+    """``(chol chol^T)^-1 rhs`` per block: the HIP route of ``_autograd_ops.chol_solve_blocks`` (d <= 9), torch beyond."""
+    return _ag.chol_solve_blocks(chol, rhs)
 
 
 def _mm(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:

@@ -11,6 +11,7 @@ from typing import Tuple
 
 import torch
 
+from . import _autograd_ops as _ag
 from . import _lib
 from .block_tri_diag import LowerTriangularBlockTriDiagonal, SymmetricBlockTriDiagonal, _flat
 from .gauss_markov import GaussMarkovDistribution, SampleShape, check_compatible
@@ -307,12 +308,12 @@ class StateSpaceModel(GaussMarkovDistribution):
         if torch.is_grad_enabled() and any(t.requires_grad for t in (self._chol_P_0, self._A_s, self._chol_Q_s)):
             chols = self.concatenated_cholesky_process_covariance                       # [cholP0, cholQ_1 ...]
             eye = torch.eye(self.state_dim, dtype=chols.dtype, device=chols.device).expand(chols.shape)
-            q_inv = _lib.chol_solve(chols, eye)
+            q_inv = _ag.chol_solve_blocks(chols, eye)                                   # (HIP per-block solves and products, d <= 9)
             q_inv = 0.5 * (q_inv + q_inv.transpose(-1, -2))
             if self.num_transitions == 0:
                 return SymmetricBlockTriDiagonal(q_inv)
-            j = q_inv[..., 1:, :, :] @ self._A_s                                        # Q_{k+1}^-1 A_{k+1}
-            ata = self._A_s.transpose(-1, -2) @ j
+            j = _ag.block_matmul(q_inv[..., 1:, :, :].contiguous(), self._A_s)           # Q_{k+1}^-1 A_{k+1}
+            ata = _ag.block_matmul(self._A_s.transpose(-1, -2).contiguous(), j)
             diag = q_inv + torch.cat([ata, torch.zeros_like(ata[..., :1, :, :])], dim=-3)
             return SymmetricBlockTriDiagonal(diag, -j)
         diag, sub, _ = self._precision_and_eta(None, None, None, False, want_eta=False)
