@@ -572,12 +572,18 @@ def dry_rank(args) -> int:
         dist.init_process_group(backend="gloo")
     ones = torch.ones(1, dtype=torch.float64)
     dist.all_reduce(ones)
-    lo, hi = mfd.shard_bounds(args.batch * world, rank, world)          # weak scaling: every rank owns args.batch series
+    per_gpu = 512 if args.workload == "config4" else args.batch        # (config 4: 4096 series over 8 GPUs = 512 per shard)
+    lo, hi = mfd.shard_bounds(per_gpu * world, rank, world)             # weak scaling: every rank owns per_gpu series
     owned = torch.tensor([float(hi - lo)], dtype=torch.float64)
     dist.all_reduce(owned)
+    # the sharded reductions the timed step ends in, on the rank's share of a known total (gloo instead of RCCL)
+    share = torch.full((), float(hi - lo), dtype=torch.float64)
+    total = (mfd.sharded_elbo(share, torch.zeros((), dtype=torch.float64)) if args.workload == "config4"
+             else mfd.all_reduce_sum(share.clone()))
     if rank == 0:
         print(json.dumps({"dry_launch": True, "n_gpus": dist.get_world_size(), "ranks_seen": int(ones.item()),
-                          "series_total": int(owned.item()), "series_per_gpu": args.batch,
+                          "workload": args.workload, "sharded_total": float(total),
+                          "series_total": int(owned.item()), "series_per_gpu": per_gpu,
                           "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}))
     dist.destroy_process_group()
     return 0

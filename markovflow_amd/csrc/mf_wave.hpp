@@ -459,6 +459,12 @@ template <typename T, int NT> MF_DEV void store_cv(T* __restrict__ g, const CV<T
 }
 
 // ---- the elimination state of one chunk (Elim of mf_kernels.hpp on register tiles) ----------------------------------------------
+// what an elimination leaves for the step that follows it (declared per step by the caller: as members of the chunk's state these
+// values - written and read under "this step eliminates" - would be carried around the step loop on the other path, 24 registers)
+template <typename T, int NT> struct WaveFact {
+    Mat<T, NT> LiT, V;
+    RV<T, NT> z_rv;
+};
 template <typename T, int NT> struct WaveElim {
     Mat<T, NT> Phi;      // symmetric (tiles ti <= tj): pivot of the current block
     Mat<T, NT> X;        // coupling current block <-> the chunk's left separator
@@ -467,9 +473,6 @@ template <typename T, int NT> struct WaveElim {
     T quad;              // per lane: sum over its columns of z^2 (summed over the lanes of a row at the end)
     LogAcc<T> laL;       // pivots of the eliminated blocks
     bool bad;
-    // products of the current elimination, kept for advance()
-    Mat<T, NT> LiT, V;
-    RV<T, NT> z_rv;
 
     MF_DEV void init() {
         Phi.zero(); X.zero(); GU.zero();
@@ -479,35 +482,35 @@ template <typename T, int NT> struct WaveElim {
         bad = false;
     }
     // Factor the complete pivot in Phi, z = L^-1 t, spike V = L^-1 X folded into the separator.
-    template <bool SPIKE> MF_DEV void eliminate(T* lds, const Lane& ln) {
-        chol_inv_mat<T, NT>(Phi, LiT, lds, ln, laL, bad);
+    template <bool SPIKE> MF_DEV void eliminate(WaveFact<T, NT>& f, T* lds, const Lane& ln) {
+        chol_inv_mat<T, NT>(Phi, f.LiT, lds, ln, laL, bad);
         phase();
-        after_factor<SPIKE>(ln);
+        after_factor<SPIKE>(f, ln);
     }
-    // ... with LiT already in place (the multi-chunk kernel factors the pivots of its chunks side by side)
-    template <bool SPIKE> MF_DEV void after_factor(const Lane& ln) {
+    // ... with f.LiT already in place (the multi-chunk kernel factors the pivots of its chunks side by side)
+    template <bool SPIKE> MF_DEV void after_factor(WaveFact<T, NT>& f, const Lane& ln) {
         RV<T, NT> t_rv;
         cv_to_rv<T, NT>(t_rv, t, ln);
         CV<T, NT> z;
-        tn_mv<T, NT, S_UPPER>(z, LiT, t_rv);                      // z = Li t
+        tn_mv<T, NT, S_UPPER>(z, f.LiT, t_rv);                    // z = Li t
         quad += dot_cv<T, NT>(z, z);
-        cv_to_rv<T, NT>(z_rv, z, ln);
+        cv_to_rv<T, NT>(f.z_rv, z, ln);
         if constexpr (SPIKE) {
-            tn<T, NT, S_UPPER, S_FULL, S_FULL, OP_SET>(V, LiT, X);            // V = Li X
-            tn<T, NT, S_FULL, S_FULL, S_UPPER, OP_SUB>(GU, V, V);             // GU -= V^T V
+            tn<T, NT, S_UPPER, S_FULL, S_FULL, OP_SET>(f.V, f.LiT, X);        // V = Li X
+            tn<T, NT, S_FULL, S_FULL, S_UPPER, OP_SUB>(GU, f.V, f.V);         // GU -= V^T V
             CV<T, NT> vz;
-            tn_mv<T, NT, S_FULL>(vz, V, z_rv);
+            tn_mv<T, NT, S_FULL>(vz, f.V, f.z_rv);
             MF_UNROLL for (int j = 0; j < NT; ++j) gU.v[j] -= vz.v[j];
         }
     }
     // After eliminate(): the next block couples to the eliminated one through W with WT = W^T given; Dn / rn are its own parts.
-    template <bool SPIKE> MF_DEV void advance(const Mat<T, NT>& WT, const Mat<T, NT>& Dn, const CV<T, NT>& rn) {
+    template <bool SPIKE> MF_DEV void advance(const WaveFact<T, NT>& f, const Mat<T, NT>& WT, const Mat<T, NT>& Dn, const CV<T, NT>& rn) {
         CV<T, NT> wz;
-        tn_mv<T, NT, S_FULL>(wz, WT, z_rv);                                   // W z
+        tn_mv<T, NT, S_FULL>(wz, WT, f.z_rv);                                 // W z
         MF_UNROLL for (int j = 0; j < NT; ++j) t.v[j] = rn.v[j] - wz.v[j];
         MF_UNROLL for (int i = 0; i < NT; ++i) MF_UNROLL for (int j = i; j < NT; ++j) Phi.t[i][j] = Dn.t[i][j];
         tn<T, NT, S_FULL, S_FULL, S_UPPER, OP_SUB>(Phi, WT, WT);              // Phi = Dn - W W^T
-        if constexpr (SPIKE) tn<T, NT, S_FULL, S_FULL, S_FULL, OP_NEG>(X, WT, V);   // X = -W V
+        if constexpr (SPIKE) tn<T, NT, S_FULL, S_FULL, S_FULL, OP_NEG>(X, WT, f.V);   // X = -W V
     }
 };
 
@@ -686,13 +689,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
             tn<T, NT, S_FULL, S_FULL, S_UPPER, OP_SUB>(E.Phi, Am, S);           // D_{k-1} += A^T Q^-1 A: complete
             MF_UNROLL for (int k = 0; k < NT; ++k) E.t.v[k] -= btw.v[k];
             phase();
-            if (spike) E.template eliminate<true>(lds, ln); else E.template eliminate<false>(lds, ln);
+            WaveFact<T, NT> f;
+            if (spike) E.template eliminate<true>(f, lds, ln); else E.template eliminate<false>(f, lds, ln);
             phase();
             Mat<T, NT> ST, WT;
             transpose<T, NT, S_FULL>(ST, S, lds, ln);
-            tn<T, NT, S_UPPER, S_FULL, S_FULL, OP_SET>(WT, E.LiT, ST);          // W^T = Li S^T
+            tn<T, NT, S_UPPER, S_FULL, S_FULL, OP_SET>(WT, f.LiT, ST);          // W^T = Li S^T
             phase();
-            if (spike) E.template advance<true>(WT, Dn, rn); else E.template advance<false>(WT, Dn, rn);
+            if (spike) E.template advance<true>(f, WT, Dn, rn); else E.template advance<false>(f, WT, Dn, rn);
         }
     }
     const T ww = sum16<T>(acc_ww), quad = sum16<T>(E.quad);
@@ -857,12 +861,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
         phase();
         MF_UNROLL for (int ci = 0; ci < NC; ++ci) {
             if (j < len[ci] && !(j == 0 && spike[ci])) {
-                E[ci].LiT.t[0][0] = lit[ci];
-                if (spike[ci]) E[ci].template after_factor<true>(ln); else E[ci].template after_factor<false>(ln);
+                WaveFact<T, NT> f;
+                f.LiT.t[0][0] = lit[ci];
+                if (spike[ci]) E[ci].template after_factor<true>(f, ln); else E[ci].template after_factor<false>(f, ln);
                 Mat<T, NT> ST, WT;
                 transpose<T, NT, S_FULL>(ST, S[ci], lds, ln);
-                tn<T, NT, S_UPPER, S_FULL, S_FULL, OP_SET>(WT, E[ci].LiT, ST);
-                if (spike[ci]) E[ci].template advance<true>(WT, Dn[ci], rn[ci]); else E[ci].template advance<false>(WT, Dn[ci], rn[ci]);
+                tn<T, NT, S_UPPER, S_FULL, S_FULL, OP_SET>(WT, f.LiT, ST);
+                if (spike[ci]) E[ci].template advance<true>(f, WT, Dn[ci], rn[ci]); else E[ci].template advance<false>(f, WT, Dn[ci], rn[ci]);
             }
             phase();
         }

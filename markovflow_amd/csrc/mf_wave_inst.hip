@@ -1,6 +1,5 @@
 // Instantiations of the wave kernels (mf_wave.hpp: one wavefront per (series, chunk), register tiles, 16 <= d <= 32) and the
 // entry points the tile engine's launcher (mf_big_impl.hpp) hands its level 0 to.
-#include <cstdlib>
 #include "mf_wave.hpp"
 #include "mf_launch.hpp"
 
@@ -36,7 +35,11 @@ int wave_level0(long B, long Tn, int d, int m, const T* mu0, const T* cholP0, co
                 const T* y, const T* Rinv, int rinv_per_step, long P, long L, const RedSys<T>& out, int* info, hipStream_t st) {
     if (!wave_covers(d, m)) return -101;
     const wv::WvArgs<T> a{B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, L, info};
-    static const bool multi = [] { const char* e = getenv("MF_WAVE_MULTI"); return !(e && e[0] == (char)48); }();  /* EXPERIMENT: revert to mf_knob */
+    // the multi-chunk kernel (two / four chunks per wavefront, their diagonal tiles factored side by side) is correct (the parity
+    // tests pass on it) but needs ~430 registers per lane in fp64: held to the 256 of two wavefronts per SIMD it spills 700 bytes
+    // per lane and runs 2.4 x SLOWER (4.43 against 1.85 ms at d = 16, B = 512, T = 1000: profiles/r05_wave_multi_ab.txt) - built,
+    // measured, off; MF_WAVE_MULTI=1 selects it in experiment builds
+    static const bool multi = [] { const char* e = mf_knob("MF_WAVE_MULTI"); return e && e[0] == '1'; }();
     if (d <= 16 && multi) return m == 1 ? wave_launch_multi<T, 1>(a, out, st) : wave_launch_multi<T, wv::WV_MAXM>(a, out, st);
     if (d <= 16) return m == 1 ? wave_launch<T, 1, 1>(a, out, st) : wave_launch<T, 1, wv::WV_MAXM>(a, out, st);
     return m == 1 ? wave_launch<T, 2, 1>(a, out, st) : wave_launch<T, 2, wv::WV_MAXM>(a, out, st);
@@ -45,9 +48,8 @@ int wave_level0(long B, long Tn, int d, int m, const T* mu0, const T* cholP0, co
 
 bool wave_covers(int d, int m) { return d >= 16 && d <= 32 && m >= 1 && m <= wv::WV_MAXM; }
 // wavefronts per SIMD the level-0 kernel runs at (by its registers): what one round of chunks over the chip is sized for
-// (d <= 16: chunks in flight per SIMD = wavefronts x chunks per wavefront of the multi-chunk kernel)
 int wave_waves_per_simd(int d, int elem_size) {
-    return d <= 16 ? (elem_size == 8 ? wave_multi_wpe<double, 1>() * wave_nc<double>() : wave_multi_wpe<float, 1>() * wave_nc<float>())
+    return d <= 16 ? (elem_size == 8 ? wave_wpe<double, 1, 1>() : wave_wpe<float, 1, 1>())
                    : (elem_size == 8 ? wave_wpe<double, 2, 1>() : wave_wpe<float, 2, 1>());
 }
 

@@ -194,6 +194,24 @@ def test_bench_dry_launch_runs_the_rank_plumbing_without_a_gpu(gpus):
     assert out["series_total"] == 1000 * gpus and out["ipc_mode_legacy"] == "0"
 
 
+def test_bench_dry_launch_of_the_config4_workload_at_world_8():
+    """BASELINE config 4 (4096 series over 8 GPUs, log-likelihood + KL combined by ONE scalar all-reduce): the same launch path
+    with `--workload config4`, eight ranks, the shard size of the real run and the sharded ELBO reduction on gloo (VERDICT r04
+    next 10)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-launch", "--workload", "config4"],
+                          capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, proc.stdout
+    out = json.loads(lines[0])
+    assert out["dry_launch"] and out["n_gpus"] == 8 and out["ranks_seen"] == 8 and out["workload"] == "config4"
+    assert out["series_total"] == 4096 and out["series_per_gpu"] == 512 and out["sharded_total"] == 4096.0
+
+
 def test_visible_gpus_opens_no_runtime():
     """The launcher counts GPUs from sysfs: no torch, no HIP library in the process afterwards."""
     import subprocess
