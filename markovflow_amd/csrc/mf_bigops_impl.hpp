@@ -480,6 +480,13 @@ inline int op_ssm_precision(long B, long Tn, int d, int m, const real* mu0, cons
                             const real* cholQ, const real* H, const real* y, const real* Rinv, int rinv_per_step, real* diag,
                             real* sub, real* eta, hipStream_t st) {
     if (H && (m < 1 || m > MAXM_BIG)) return -4;
+    {   // 16 <= d <= 32, at most four outputs: a wavefront per block on register tiles (mf_wave.hpp)
+        static const bool off = [] { const char* e = mf_knob("MF_WAVE"); return e && e[0] == '0'; }();
+        if (!off && B * Tn > 0) {
+            const int rc = wave_ssm_precision(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, diag, sub, eta, st);
+            if (rc != -101) return rc;
+        }
+    }
     BigArgs a{B, Tn, d, H ? m : 1, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, 1, 1, nullptr};
 #define MF_C(DP)                                                                                                       \
     { static const bool ok = big_attr(&bigop_ssm_precision_kernel<DP>, Smem<DP>::BYTES); if (!ok) return -1000;          \

@@ -73,6 +73,12 @@ template <typename T, int NT> struct Mat {
 template <typename T, int NT> struct CV { T v[NT]; };        // lane (r, q): v[tj] = vec[16 tj + r]
 template <typename T, int NT> struct RV { T v[NT][4]; };     // lane (r, q): v[ti][e] = vec[16 ti + row(q, e)]
 
+template <typename T> MF_DEV typename Tr<T>::v4 identity_tile(const Lane& ln) {
+    typename Tr<T>::v4 t;
+    MF_UNROLL for (int e = 0; e < 4; ++e) t[e] = (Tr<T>::row(ln.q, e) == ln.r) ? T(1) : T(0);
+    return t;
+}
+
 enum { OP_SET = 0, OP_ADD = 1, OP_SUB = 2, OP_NEG = 3 };
 // out (OP) P^T Q.  PS / QS: tile structure of P / Q (all-zero tiles are skipped); OS = S_UPPER: the result is symmetric and only
 // its tiles ti <= tj are formed.
@@ -705,6 +711,100 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     if (__any(E.bad) && threadIdx.x == 0 && a.info) raise_info(a.info);
 }
 
+// ---- StateSpaceModel._build_precision (+ H^T R^-1 H, + information vector) for 16 <= d <= 32 -------------------------------------
+// (state_space_model.py:431-483, kalman_filter.py:86-101,149-156).  One wavefront per (series, block k): block k's diagonal block
+// needs Q_k^-1 and - when a transition leaves it - A_{k+1}^T Q_{k+1}^-1 A_{k+1}; its sub-diagonal block is -Q_{k+1}^-1 A_{k+1}.
+// The two Cholesky factors (four diagonal tiles at d > 16) are inverted SIDE BY SIDE in the rows of the wavefront (one pass).
+// Every Q^-1 is formed twice over the launch (by the blocks on both sides of its transition): fully parallel, no second pass.
+// The tile engine's version is a 256-thread workgroup per block: 10.9 ms at B = 512, T = 1000, d = 16 (profiles/r05_bigops_d16.txt).
+template <typename T, int NT, int M, bool EX>
+__global__ void __launch_bounds__(64) wave_ssm_precision_kernel(WvArgs<T> a, T* __restrict__ diag, T* __restrict__ sub,
+                                                               T* __restrict__ eta) {
+    using v4 = typename Tr<T>::v4;
+    constexpr int NTL = 2 * NT, TS = 16 * Tr<T>::LD;
+    __shared__ __attribute__((aligned(16))) T lds[NTL * TS];
+    const Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
+    const long id = blockIdx.x, s = id / a.Tn, k = id % a.Tn;
+    const int d = EX ? 16 * NT : a.d, m = a.m;
+    const long nt = a.Tn - 1, dd = long(d) * d;
+    const bool has_next = k + 1 < a.Tn;
+    LogAcc<T> la;
+    la.init();
+    bool bad = false;
+    Mat<T, NT> C0, C1, Am;
+    v4 c10t[2] = {v4{0, 0, 0, 0}, v4{0, 0, 0, 0}};
+    const T* c0p = k == 0 ? a.cholP0 + s * dd : a.cholQ + (s * nt + k - 1) * dd;
+    load_mat<T, NT, S_LOWER, EX>(C0, c0p, d, true, true, ln);
+    if constexpr (NT == 2) load_tile_t<T, EX>(c10t[0], c0p, d, 1, 0, ln);
+    MF_UNROLL for (int i = 0; i < NT; ++i) MF_UNROLL for (int j = 0; j < NT; ++j) C1.t[i][j] = (i == j) ? identity_tile<T>(ln) : v4{0, 0, 0, 0};
+    Am.zero();
+    if (has_next) {
+        load_mat<T, NT, S_LOWER, EX>(C1, a.cholQ + (s * nt + k) * dd, d, true, true, ln);
+        if constexpr (NT == 2) load_tile_t<T, EX>(c10t[1], a.cholQ + (s * nt + k) * dd, d, 1, 0, ln);
+        load_mat<T, NT, S_FULL, EX>(Am, a.A + (s * nt + k) * dd, d, false, false, ln);
+    }
+    // both factors' inverses: Ci[0], Ci[1] (S_LOWER)
+    Mat<T, NT> Ci[2];
+    {
+        v4 in[NTL], out[NTL];
+        MF_UNROLL for (int f = 0; f < 2; ++f) MF_UNROLL for (int i = 0; i < NT; ++i) in[f * NT + i] = (f == 0 ? C0 : C1).t[i][i];
+        tri_inv_tiles<T, NTL, false>(in, out, lds, ln, la, bad);
+        MF_UNROLL for (int f = 0; f < 2; ++f) {
+            Ci[f].zero();
+            MF_UNROLL for (int i = 0; i < NT; ++i) Ci[f].t[i][i] = out[f * NT + i];
+        }
+        if constexpr (NT == 2) {
+            v4 cit11[2];
+            MF_UNROLL for (int f = 0; f < 2; ++f) image_to_tile_t<T>(cit11[f], lds + (f * NT + 1) * TS, ln);
+            lds_fence();
+            MF_UNROLL for (int f = 0; f < 2; ++f) {
+                v4 g = {0, 0, 0, 0}, h = {0, 0, 0, 0};
+                MF_UNROLL for (int e = 0; e < 4; ++e) g = Tr<T>::mfma(c10t[f][e], Ci[f].t[0][0][e], g);
+                MF_UNROLL for (int e = 0; e < 4; ++e) h = Tr<T>::mfma(cit11[f][e], g[e], h);
+                Ci[f].t[1][0] = -h;
+            }
+        }
+    }
+    Mat<T, NT> Dn, Q1;
+    CV<T, NT> rn;
+    MF_UNROLL for (int j = 0; j < NT; ++j) rn.v[j] = T(0);
+    tn<T, NT, S_LOWER, S_LOWER, S_UPPER, OP_SET>(Dn, Ci[0], Ci[0]);                 // Q_k^-1
+    if constexpr (NT == 2) transpose_tile<T>(Dn.t[1][0], Dn.t[0][1], lds, ln);
+    if (eta) {
+        RV<T, NT> mv;
+        load_rv<T, NT>(mv, k == 0 ? a.mu0 + s * d : a.b + (s * nt + k - 1) * d, d, ln);
+        tn_mv<T, NT, S_FULL>(rn, Dn, mv);                                           // Q_k^-1 m_k
+    }
+    if (a.H) {
+        ObsRows<T, NT, M> ob;
+        T Ri[M][M];
+        load_rinv<T, M>(Ri, a.rinv_per_step ? a.Rinv + (s * a.Tn + k) * m * m : a.Rinv, m);
+        ob.load(a.H + (s * a.Tn + k) * m * d, a.y ? a.y + (s * a.Tn + k) * m : a.H, d, m, ln);
+        if (!a.y) { MF_UNROLL for (int o = 0; o < M; ++o) ob.y[o] = T(0); }         // no observation term in eta
+        (void)obs_apply<T, NT, M>(ob, Ri, Dn, rn);
+    }
+    if (has_next) {
+        tn<T, NT, S_LOWER, S_LOWER, S_UPPER, OP_SET>(Q1, Ci[1], Ci[1]);             // Q_{k+1}^-1
+        if constexpr (NT == 2) transpose_tile<T>(Q1.t[1][0], Q1.t[0][1], lds, ln);
+        Mat<T, NT> S;
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_NEG>(S, Q1, Am);                       // S_k = -Q_{k+1}^-1 A_{k+1}
+        tn<T, NT, S_FULL, S_FULL, S_UPPER, OP_SUB>(Dn, Am, S);                      // + A^T Q^-1 A
+        if (eta) {
+            RV<T, NT> mv1, r1_rv;
+            CV<T, NT> r1, btw;
+            load_rv<T, NT>(mv1, a.b + (s * nt + k) * d, d, ln);
+            tn_mv<T, NT, S_FULL>(r1, Q1, mv1);
+            cv_to_rv<T, NT>(r1_rv, r1, ln);
+            tn_mv<T, NT, S_FULL>(btw, Am, r1_rv);
+            MF_UNROLL for (int j = 0; j < NT; ++j) rn.v[j] -= btw.v[j];            // - A^T Q^-1 b
+        }
+        store_mat<T, NT, false, EX>(sub + (s * nt + k) * dd, S, d, lds, ln);
+    }
+    store_mat<T, NT, true, EX>(diag + id * dd, Dn, d, lds, ln);
+    if (eta) store_cv<T, NT>(eta + id * d, rn, d, ln);
+    (void)bad;
+}
+
 // ---- NC chunks per wavefront (one tile per matrix) --------------------------------------------------------------------------
 // At d <= 16 a step is bound by vector-instruction issue, and two thirds of its ~1 050 vector instructions are the two diagonal-tile
 // factorisations, which all four 16-lane rows of the wavefront run redundantly.  Here a wavefront carries NC = 2 or 4
@@ -712,11 +812,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
 // factorisations of all NC chunks run SIDE BY SIDE in the rows (chol_inv_tiles / tri_inv_tiles with NTL = NC) - the same instruction
 // stream as for one chunk.  Chunks that have nothing to factor in a step (seed step of a spike, chunk already finished) hand in an
 // identity tile.  Same arithmetic per chunk, same reduced system, as wave_kf_chunk_kernel.
-template <typename T> MF_DEV typename Tr<T>::v4 identity_tile(const Lane& ln) {
-    typename Tr<T>::v4 t;
-    MF_UNROLL for (int e = 0; e < 4; ++e) t[e] = (Tr<T>::row(ln.q, e) == ln.r) ? T(1) : T(0);
-    return t;
-}
 template <typename T, int M, int WPE, bool EX, int NC>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) wave_kf_multi_kernel(WvArgs<T> a, RedSys<T> out) {
     constexpr int NT = 1;

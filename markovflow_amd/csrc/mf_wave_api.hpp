@@ -14,4 +14,21 @@ inline int wave_kf_level0(long B, long Tn, int d, int m, const float* mu0, const
                           const RedSys<float>& out, int* info, hipStream_t st) {
     return wave_kf_level0_f32(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, L, out, info, st);
 }
+// mf_wave_inst.hip: precision assembly on register tiles (wave_ssm_precision_kernel); -101: not covered
+int wave_ssm_precision_f64(long B, long Tn, int d, int m, const double* mu0, const double* cholP0, const double* A, const double* b,
+                           const double* cholQ, const double* H, const double* y, const double* Rinv, int rinv_per_step, double* diag,
+                           double* sub, double* eta, hipStream_t st);
+int wave_ssm_precision_f32(long B, long Tn, int d, int m, const float* mu0, const float* cholP0, const float* A, const float* b,
+                           const float* cholQ, const float* H, const float* y, const float* Rinv, int rinv_per_step, float* diag,
+                           float* sub, float* eta, hipStream_t st);
+inline int wave_ssm_precision(long B, long Tn, int d, int m, const double* mu0, const double* cholP0, const double* A, const double* b,
+                              const double* cholQ, const double* H, const double* y, const double* Rinv, int rinv_per_step, double* diag,
+                              double* sub, double* eta, hipStream_t st) {
+    return wave_ssm_precision_f64(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, diag, sub, eta, st);
+}
+inline int wave_ssm_precision(long B, long Tn, int d, int m, const float* mu0, const float* cholP0, const float* A, const float* b,
+                              const float* cholQ, const float* H, const float* y, const float* Rinv, int rinv_per_step, float* diag,
+                              float* sub, float* eta, hipStream_t st) {
+    return wave_ssm_precision_f32(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, diag, sub, eta, st);
+}
 }  // namespace mf

@@ -1,5 +1,7 @@
 // Instantiations of the wave kernels (mf_wave.hpp: one wavefront per (series, chunk), register tiles, 16 <= d <= 32) and the
 // entry points the tile engine's launcher (mf_big_impl.hpp) hands its level 0 to.
+#include <type_traits>
+
 #include "mf_wave.hpp"
 #include "mf_launch.hpp"
 
@@ -62,6 +64,46 @@ int wave_kf_level0_f32(long B, long Tn, int d, int m, const float* mu0, const fl
                        const float* cholQ, const float* H, const float* y, const float* Rinv, int rinv_per_step, long P, long L,
                        const RedSys<float>& out, int* info, hipStream_t st) {
     return wave_level0<float>(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, L, out, info, st);
+}
+
+// ---- StateSpaceModel._build_precision / BaseKalmanFilter._k_inv_post for 16 <= d <= 32 (wave_ssm_precision_kernel) -----------------
+namespace {
+template <typename T>
+int wave_precision(long B, long Tn, int d, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H,
+                   const T* y, const T* Rinv, int rinv_per_step, T* diag, T* sub, T* eta, hipStream_t st) {
+    if (!wave_covers(d, H ? m : 1)) return -101;
+    const wv::WvArgs<T> a{B, Tn, d, H ? m : 1, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, 1, 1, nullptr};
+    const dim3 grid((unsigned)(B * Tn)), block(64);
+    const bool m1 = !H || m == 1;
+    auto go = [&](auto nt, auto mm, auto ex) {
+        hipLaunchKernelGGL((wv::wave_ssm_precision_kernel<T, decltype(nt)::value, decltype(mm)::value, decltype(ex)::value>), grid, block, 0,
+                           st, a, diag, sub, eta);
+    };
+    using std::integral_constant;
+    using I1 = integral_constant<int, 1>;
+    using I2 = integral_constant<int, 2>;
+    using IM = integral_constant<int, wv::WV_MAXM>;
+    using Tt = integral_constant<bool, true>;
+    using Ff = integral_constant<bool, false>;
+    if (d <= 16) {
+        if (d == 16) { if (m1) go(I1{}, I1{}, Tt{}); else go(I1{}, IM{}, Tt{}); }
+        else { if (m1) go(I1{}, I1{}, Ff{}); else go(I1{}, IM{}, Ff{}); }
+    } else {
+        if (d == 32) { if (m1) go(I2{}, I1{}, Tt{}); else go(I2{}, IM{}, Tt{}); }
+        else { if (m1) go(I2{}, I1{}, Ff{}); else go(I2{}, IM{}, Ff{}); }
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+}  // namespace
+int wave_ssm_precision_f64(long B, long Tn, int d, int m, const double* mu0, const double* cholP0, const double* A, const double* b,
+                           const double* cholQ, const double* H, const double* y, const double* Rinv, int rinv_per_step, double* diag,
+                           double* sub, double* eta, hipStream_t st) {
+    return wave_precision<double>(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, diag, sub, eta, st);
+}
+int wave_ssm_precision_f32(long B, long Tn, int d, int m, const float* mu0, const float* cholP0, const float* A, const float* b,
+                           const float* cholQ, const float* H, const float* y, const float* Rinv, int rinv_per_step, float* diag,
+                           float* sub, float* eta, hipStream_t st) {
+    return wave_precision<float>(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, diag, sub, eta, st);
 }
 
 }  // namespace mf

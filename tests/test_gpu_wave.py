@@ -110,3 +110,30 @@ def test_wave_every_series_against_the_c_oracle_at_the_verdict_shape(rng, d):
     ref = c_oracle.kf_loglik(kw["mu0"], kw["chol_p0"], kw["a_s"], kw["b_s"], kw["chol_q"], kw["h"], kw["y"], r_inv, generic=True)
     got = loglik_with_chunks(kw, r_inv, 0) + _const(m, t, r_inv)            # (the C oracle returns the complete per-series value)
     np.testing.assert_allclose(got, ref, rtol=1e-9)
+
+
+# ---- precision assembly on register tiles (wave_ssm_precision_kernel): StateSpaceModel.precision, BaseKalmanFilter._k_inv_post --------
+@pytest.mark.parametrize("dtype,d,m,t,bsz", [(torch.float64, 16, 1, 9, 3), (torch.float64, 16, 3, 2, 2), (torch.float64, 17, 1, 12, 2),
+                                             (torch.float64, 24, 2, 30, 2), (torch.float64, 32, 4, 17, 2), (torch.float64, 30, 1, 40, 1),
+                                             (torch.float32, 16, 1, 20, 2), (torch.float32, 32, 2, 11, 2)])
+def test_wave_precision_prior_and_posterior(rng, dtype, d, m, t, bsz):
+    """`ssm.precision` (state_space_model.py:431-483) and `kf._k_inv_post` (kalman_filter.py:86-101) for 16 <= d <= 32 against the
+    numpy oracle, block by block; the information vector through the posterior's initial mean / offsets is covered by
+    tests/test_gpu_large_d_ops.py::test_large_d_posterior_marginals_and_kl."""
+    kw = random_ssm(rng, (bsz,), t, d, m, well=True)
+    if dtype == F32:
+        kw = rounded(kw)
+    tol = dict(rtol=1e-9, atol=1e-10) if dtype == torch.float64 else dict(rtol=2e-4, atol=2e-4)
+    cov = 0.5 * np.eye(m) + 0.1 * np.ones((m, m))
+    chol_r = np.linalg.cholesky(cov)
+    if dtype == F32:
+        chol_r = chol_r.astype(np.float32).astype(np.float64)
+    kf = build_kf(kw, chol_r, dtype=dtype)
+    prec = kf.prior_ssm.precision
+    want_d, want_s = O.ssm_precision(kw["chol_p0"], kw["a_s"], kw["chol_q"])
+    np.testing.assert_allclose(nn(prec.block_diagonal), want_d, **tol)
+    np.testing.assert_allclose(nn(prec.block_sub_diagonal), want_s, **tol)
+    post = kf._k_inv_post
+    want_d, want_s = O.kf_posterior_precision(kw["chol_p0"], kw["a_s"], kw["chol_q"], kw["h"], np.linalg.inv(chol_r @ chol_r.T))
+    np.testing.assert_allclose(nn(post.block_diagonal), want_d, **tol)
+    np.testing.assert_allclose(nn(post.block_sub_diagonal), want_s, **tol)
