@@ -602,6 +602,13 @@ inline size_t bigpar_solve_ws(long Bl, long Br, long n, int d) {
 }
 inline int op_solve_par(long Bl, long Br, long n, int d, const real* ldiag, const real* lsub, const real* rhs, real* out, int transpose,
                         void* ws, size_t ws_bytes, hipStream_t st) {
+    {   // 16 <= d <= 32: the time axis serially inside a wavefront, the batch over the chip (mf_wave_ops.hpp)
+        static const bool off = [] { const char* e = mf_knob("MF_WAVE"); return e && e[0] == '0'; }();
+        if (!off && Br > 0 && n > 0) {
+            const int rc = wave_btd_solve(Bl, Br, n, d, ldiag, lsub, rhs, out, transpose, st);
+            if (rc != -101) return rc;
+        }
+    }
     long P, L;
     bigpar_partition(Br, n, d, P, L);
     if (P == 1 || !lsub || !ws || ws_bytes < bigpar_solve_ws(Bl, Br, n, d)) return op_solve(Bl, Br, n, d, ldiag, lsub, rhs, out, transpose, st);

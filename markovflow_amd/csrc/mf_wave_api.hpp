@@ -31,4 +31,17 @@ inline int wave_ssm_precision(long B, long Tn, int d, int m, const float* mu0, c
                               float* sub, float* eta, hipStream_t st) {
     return wave_ssm_precision_f32(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, diag, sub, eta, st);
 }
+// mf_wave_inst.hip: solve with the time axis walked serially inside a wavefront (mf_wave_ops.hpp); -101: not covered
+int wave_btd_solve_f64(long Bl, long Br, long n, int d, const double* ldiag, const double* lsub, const double* rhs, double* out,
+                       int transpose, hipStream_t st);
+int wave_btd_solve_f32(long Bl, long Br, long n, int d, const float* ldiag, const float* lsub, const float* rhs, float* out, int transpose,
+                       hipStream_t st);
+inline int wave_btd_solve(long Bl, long Br, long n, int d, const double* ldiag, const double* lsub, const double* rhs, double* out,
+                          int transpose, hipStream_t st) {
+    return wave_btd_solve_f64(Bl, Br, n, d, ldiag, lsub, rhs, out, transpose, st);
+}
+inline int wave_btd_solve(long Bl, long Br, long n, int d, const float* ldiag, const float* lsub, const float* rhs, float* out, int transpose,
+                          hipStream_t st) {
+    return wave_btd_solve_f32(Bl, Br, n, d, ldiag, lsub, rhs, out, transpose, st);
+}
 }  // namespace mf

@@ -3,6 +3,7 @@
 #include <type_traits>
 
 #include "mf_wave.hpp"
+#include "mf_wave_ops.hpp"
 #include "mf_launch.hpp"
 
 namespace mf {
@@ -104,6 +105,36 @@ int wave_ssm_precision_f32(long B, long Tn, int d, int m, const float* mu0, cons
                            const float* cholQ, const float* H, const float* y, const float* Rinv, int rinv_per_step, float* diag,
                            float* sub, float* eta, hipStream_t st) {
     return wave_precision<float>(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, diag, sub, eta, st);
+}
+
+// ---- LowerTriangularBlockTriDiagonal.solve for 16 <= d <= 32: the time axis serially inside a wavefront (wave_solve_kernel) -----------
+namespace {
+template <typename T>
+int wave_solve(long Bl, long Br, long n, int d, const T* ldiag, const T* lsub, const T* rhs, T* out, int transpose, hipStream_t st) {
+    if (!wave_covers(d, 1)) return -101;
+    // the walk is n dependent block steps of ~0.4 us: a long chain of few series belongs to the time-partitioned engine
+    if (n > 2000 && Br < 64) return -101;
+    const wv::SolveArgs<T> a{Bl, Br, n, d, ldiag, lsub, rhs, out};
+    const dim3 block(64);
+    if (d <= 16) {
+        const dim3 grid((unsigned)((Br + 3) / 4));
+        if (transpose) hipLaunchKernelGGL((wv::wave_solve_kernel<T, 1, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((wv::wave_solve_kernel<T, 1, false>), grid, block, 0, st, a);
+    } else {
+        const dim3 grid((unsigned)((Br + 1) / 2));
+        if (transpose) hipLaunchKernelGGL((wv::wave_solve_kernel<T, 2, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((wv::wave_solve_kernel<T, 2, false>), grid, block, 0, st, a);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+}  // namespace
+int wave_btd_solve_f64(long Bl, long Br, long n, int d, const double* ldiag, const double* lsub, const double* rhs, double* out,
+                       int transpose, hipStream_t st) {
+    return wave_solve<double>(Bl, Br, n, d, ldiag, lsub, rhs, out, transpose, st);
+}
+int wave_btd_solve_f32(long Bl, long Br, long n, int d, const float* ldiag, const float* lsub, const float* rhs, float* out, int transpose,
+                       hipStream_t st) {
+    return wave_solve<float>(Bl, Br, n, d, ldiag, lsub, rhs, out, transpose, st);
 }
 
 }  // namespace mf

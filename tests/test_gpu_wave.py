@@ -137,3 +137,41 @@ def test_wave_precision_prior_and_posterior(rng, dtype, d, m, t, bsz):
     want_d, want_s = O.kf_posterior_precision(kw["chol_p0"], kw["a_s"], kw["chol_q"], kw["h"], np.linalg.inv(chol_r @ chol_r.T))
     np.testing.assert_allclose(nn(post.block_diagonal), want_d, **tol)
     np.testing.assert_allclose(nn(post.block_sub_diagonal), want_s, **tol)
+
+
+# ---- LowerTriangularBlockTriDiagonal.solve on the wave solve kernel (csrc/mf_wave_ops.hpp) -----------------------------------------
+@pytest.mark.parametrize("dtype,d", [(torch.float64, 16), (torch.float64, 17), (torch.float64, 24), (torch.float64, 31),
+                                     (torch.float64, 32), (torch.float32, 16), (torch.float32, 21), (torch.float32, 32)])
+@pytest.mark.parametrize("bl,lead,n,has_sub", [(1, (), 1, False), (3, (), 2, True), (5, (2,), 37, True), (2, (3,), 11, False),
+                                               (9, (), 200, True)])
+def test_wave_solve_both_orientations(rng, dtype, d, bl, lead, n, has_sub):
+    """block_tri_diag.py:339-351: L z = r and L^T z = r, right-hand sides with leading dimensions broadcast over the factor
+    (series r uses factor r % Bl), ragged wavefronts (Br not a multiple of the 4 or 2 series a wavefront walks), a block-diagonal
+    factor (no coupling), one block."""
+    from test_gpu_large_d_ops import TOL, scaled_spd_btd
+    diag, sub = scaled_spd_btd(rng, (bl,), n, d, has_sub)
+    ld, ls = O.btd_cholesky(diag, sub)
+    if dtype == torch.float32:
+        ld = ld.astype(np.float32).astype(np.float64)
+        ls = None if ls is None else ls.astype(np.float32).astype(np.float64)
+    rhs = rng.normal(size=lead + (bl, n, d))
+    exact = mfa.LowerTriangularBlockTriDiagonal(tt(np.tril(ld), dtype), tt(ls, dtype))
+    r = tt(rhs, dtype)
+    tol = TOL[dtype]
+    np.testing.assert_allclose(nn(exact.solve(r)), O.btd_solve(ld, ls, rhs), **tol)
+    np.testing.assert_allclose(nn(exact.solve(r, transpose_left=True)), O.btd_solve(ld, ls, rhs, transpose_left=True), **tol)
+
+
+def test_wave_solve_round_trip_at_the_operator_bench_shape(rng):
+    """B = 512, T = 1000, d = 16 and 32: L (L^-1 r) = r and L^T (L^-T r) = r through dense_mult - a size-independent property at
+    the shape scripts/bench_bigops.py times."""
+    from test_gpu_large_d_ops import scaled_spd_btd
+    for d, bsz in ((16, 512), (32, 130)):
+        diag, sub = scaled_spd_btd(rng, (bsz,), 1000, d, True)
+        ld, ls = tt(np.tril(diag), torch.float64), tt(sub, torch.float64)      # any lower factor with a safe diagonal will do
+        low = mfa.LowerTriangularBlockTriDiagonal(ld, ls)
+        r = torch.randn(bsz, 1000, d, dtype=torch.float64, device=DEV)
+        z = low.solve(r)
+        torch.testing.assert_close(low.dense_mult(z), r, rtol=1e-9, atol=1e-9)
+        zt = low.solve(r, transpose_left=True)
+        torch.testing.assert_close(low.dense_mult(zt, transpose_left=True), r, rtol=1e-9, atol=1e-9)
