@@ -555,8 +555,17 @@ inline bool bigpar_pivots(long B, long n, int d, long P, long L, const real* dia
     return true;
 }
 
+// MF_WAVE=0 (experiment builds only, mf_env.hpp): the operators of 16 <= d <= 32 stay on the tile engine
+inline bool wave_off() {
+    static const bool off = [] { const char* e = mf_knob("MF_WAVE"); return e && e[0] == '0'; }();
+    return off;
+}
 inline int op_cholesky_par(long B, long n, int d, const real* diag, const real* sub, real* ldiag, real* lsub, void* ws, size_t ws_bytes,
                            int* info, hipStream_t st) {
+    if (!wave_off()) {   // 16 <= d <= 32, many series: one wavefront per series on register tiles (mf_wave_ops.hpp)
+        const int rc = wave_btd_cholesky<real>(B, n, d, diag, sub, ldiag, lsub, info, st);
+        if (rc != -101) return rc;
+    }
     long P, L;
     bigpar_partition(B, n, d, P, L);
     if (P == 1 || !sub || !ws || ws_bytes < bigpar_ws(B, n, d, false)) return op_cholesky(B, n, d, diag, sub, ldiag, lsub, info, st);
@@ -573,6 +582,10 @@ inline int op_cholesky_par(long B, long n, int d, const real* diag, const real* 
 
 inline int op_udl_par(long B, long n, int d, const real* diag, const real* sub, real* ut, real* chol_d, const real* eta, real* m_post,
                       real* chol_dinv, void* ws, size_t ws_bytes, int* info, hipStream_t st) {
+    if (!wave_off()) {
+        const int rc = wave_btd_udl<real>(B, n, d, diag, sub, ut, chol_d, eta, m_post, chol_dinv, info, st);
+        if (rc != -101) return rc;
+    }
     long P, L;
     bigpar_partition(B, n, d, P, L);
     if (P == 1 || !sub || !ws || ws_bytes < bigpar_ws(B, n, d, eta != nullptr))
@@ -603,8 +616,7 @@ inline size_t bigpar_solve_ws(long Bl, long Br, long n, int d) {
 inline int op_solve_par(long Bl, long Br, long n, int d, const real* ldiag, const real* lsub, const real* rhs, real* out, int transpose,
                         void* ws, size_t ws_bytes, hipStream_t st) {
     {   // 16 <= d <= 32: the time axis serially inside a wavefront, the batch over the chip (mf_wave_ops.hpp)
-        static const bool off = [] { const char* e = mf_knob("MF_WAVE"); return e && e[0] == '0'; }();
-        if (!off && Br > 0 && n > 0) {
+        if (!wave_off() && Br > 0 && n > 0) {
             const int rc = wave_btd_solve(Bl, Br, n, d, ldiag, lsub, rhs, out, transpose, st);
             if (rc != -101) return rc;
         }
@@ -658,6 +670,10 @@ inline size_t bigpar_tak_ws(long B, long n, int d) {
 }
 inline int op_diag_of_inverse_par(long B, long n, int d, const real* ldiag, const real* lsub, real* odiag, real* osub, void* ws,
                                   size_t ws_bytes, hipStream_t st) {
+    if (!wave_off()) {
+        const int rc = wave_btd_diag_of_inverse<real>(B, n, d, ldiag, lsub, odiag, osub, st);
+        if (rc != -101) return rc;
+    }
     long P, L;
     bigpar_partition(B, n, d, P, L);
     if (P == 1 || !lsub || !ws || ws_bytes < bigpar_tak_ws(B, n, d)) return op_diag_of_inverse(B, n, d, ldiag, lsub, odiag, osub, st);

@@ -44,4 +44,10 @@ inline int wave_btd_solve(long Bl, long Br, long n, int d, const float* ldiag, c
                           hipStream_t st) {
     return wave_btd_solve_f32(Bl, Br, n, d, ldiag, lsub, rhs, out, transpose, st);
 }
+// mf_wave_inst.hip: the factorisations with one wavefront per series walking the time axis (mf_wave_ops.hpp); -101: not covered.
+// Overloaded on the scalar type; defined for double and float.
+template <typename T> int wave_btd_cholesky(long B, long n, int d, const T* diag, const T* sub, T* ldiag, T* lsub, int* info, hipStream_t st);
+template <typename T> int wave_btd_udl(long B, long n, int d, const T* diag, const T* sub, T* ut, T* chol_d, const T* eta, T* m_post,
+                                       T* chol_dinv, int* info, hipStream_t st);
+template <typename T> int wave_btd_diag_of_inverse(long B, long n, int d, const T* ldiag, const T* lsub, T* odiag, T* osub, hipStream_t st);
 }  // namespace mf

@@ -5,6 +5,7 @@
 #include "mf_wave.hpp"
 #include "mf_wave_ops.hpp"
 #include "mf_launch.hpp"
+#include "mf_wave_api.hpp"
 
 namespace mf {
 
@@ -136,5 +137,52 @@ int wave_btd_solve_f32(long Bl, long Br, long n, int d, const float* ldiag, cons
                        hipStream_t st) {
     return wave_solve<float>(Bl, Br, n, d, ldiag, lsub, rhs, out, transpose, st);
 }
+
+
+// ---- cholesky / upper_diagonal_lower (+ posterior chain) / block_diagonal_of_inverse: one wavefront per series ---------------------
+namespace {
+// the walk is n dependent block steps of 2 - 5 us; few long series belong to the time-partitioned engine
+inline bool wave_serial_pays(long B, long n) { return B >= 64 || n <= 256; }
+}  // namespace
+#define MF_WAVE_FACT(KERNEL, ARGS, WAVES)                                                                              \
+    do {                                                                                                               \
+        if (d <= 16) hipLaunchKernelGGL((wv::KERNEL<T, 1>), dim3((unsigned)(WAVES)), dim3(64), 0, st, ARGS);             \
+        else hipLaunchKernelGGL((wv::KERNEL<T, 2>), dim3((unsigned)(WAVES)), dim3(64), 0, st, ARGS);                     \
+        return hipGetLastError() == hipSuccess ? 0 : -1000;                                                            \
+    } while (0)
+template <typename T> int wave_btd_cholesky(long B, long n, int d, const T* diag, const T* sub, T* ldiag, T* lsub, int* info, hipStream_t st) {
+    if (!wave_covers(d, 1) || B <= 0 || n <= 0) return -101;
+    if (!sub) {   // block diagonal: every block is its own series
+        const wv::FactArgs<T> a{B * n, 1, d, diag, nullptr, ldiag, nullptr, nullptr, nullptr, nullptr, info};
+        MF_WAVE_FACT(wave_cholesky_kernel, a, B * n);
+    }
+    if (!wave_serial_pays(B, n)) return -101;
+    const wv::FactArgs<T> a{B, n, d, diag, sub, ldiag, lsub, nullptr, nullptr, nullptr, info};
+    MF_WAVE_FACT(wave_cholesky_kernel, a, B);
+}
+template <typename T> int wave_btd_udl(long B, long n, int d, const T* diag, const T* sub, T* ut, T* chol_d, const T* eta, T* m_post,
+                                       T* chol_dinv, int* info, hipStream_t st) {
+    if (!wave_covers(d, 1) || B <= 0 || n <= 0 || !wave_serial_pays(B, n)) return -101;
+    const wv::FactArgs<T> a{B, n, d, diag, sub, ut, chol_d, eta, m_post, chol_dinv, info};
+    MF_WAVE_FACT(wave_udl_kernel, a, B);
+}
+template <typename T> int wave_btd_diag_of_inverse(long B, long n, int d, const T* ldiag, const T* lsub, T* odiag, T* osub, hipStream_t st) {
+    if (!wave_covers(d, 1) || B <= 0 || n <= 0) return -101;
+    if (!lsub) {
+        const wv::FactArgs<T> a{B * n, 1, d, ldiag, nullptr, odiag, nullptr, nullptr, nullptr, nullptr, nullptr};
+        MF_WAVE_FACT(wave_inverse_blocks_kernel, a, B * n);
+    }
+    if (!wave_serial_pays(B, n)) return -101;
+    const wv::FactArgs<T> a{B, n, d, ldiag, lsub, odiag, osub, nullptr, nullptr, nullptr, nullptr};
+    MF_WAVE_FACT(wave_inverse_blocks_kernel, a, B);
+}
+#undef MF_WAVE_FACT
+template int wave_btd_cholesky<double>(long, long, int, const double*, const double*, double*, double*, int*, hipStream_t);
+template int wave_btd_cholesky<float>(long, long, int, const float*, const float*, float*, float*, int*, hipStream_t);
+template int wave_btd_udl<double>(long, long, int, const double*, const double*, double*, double*, const double*, double*, double*, int*,
+                                  hipStream_t);
+template int wave_btd_udl<float>(long, long, int, const float*, const float*, float*, float*, const float*, float*, float*, int*, hipStream_t);
+template int wave_btd_diag_of_inverse<double>(long, long, int, const double*, const double*, double*, double*, hipStream_t);
+template int wave_btd_diag_of_inverse<float>(long, long, int, const float*, const float*, float*, float*, hipStream_t);
 
 }  // namespace mf

@@ -131,3 +131,275 @@ __global__ void __launch_bounds__(64) wave_solve_kernel(SolveArgs<T> a) {
 
 }  // namespace wv
 }  // namespace mf
+
+// =====================================================================================================================================
+// The factorisations with the time axis walked serially by ONE WAVEFRONT PER SERIES on mf_wave.hpp's register tiles: every product in
+// the P^T Q form on the matrix cores, the 16 x 16 diagonal tiles factored inside the wave, the next block's operands in flight while
+// the current one is worked.  For hundreds of series of 16 <= d <= 32 (the tile engine partitions these in time with one 256-thread
+// workgroup per chunk: cholesky 5.4 / 26.7 ms, block_diagonal_of_inverse 8.2 / 25.4 ms at B = 512, T = 1000, d = 16 / 32 in fp64 -
+// profiles/r05_bigops_d16.txt).
+namespace mf {
+namespace wv {
+
+// P (symmetric positive definite tile, lower triangle used) -> L = chol(P) and LiT = L^-T as tiles; the image holds L^-1 afterwards
+template <typename T>
+MF_DEV void chol_fact_tile(const typename Tr<T>::v4& P, typename Tr<T>::v4& L, typename Tr<T>::v4& LiT, T* img, const Lane& ln,
+                           bool& bad) {
+    using D = Dpp<T>;
+    using v4 = typename Tr<T>::v4;
+    T a[16], x[16];
+    const v4 in[1] = {P};
+    rows_in<T, 1>(in, img, a, ln);
+    sfor<16>([&](auto i) { x[decltype(i)::value] = (ln.r == decltype(i)::value) ? T(1) : T(0); });
+    sfor<16>([&](auto j) {
+        constexpr int jj = decltype(j)::value;
+        fence1(a[jj]);
+        const T s = D::template bcast<jj>(a[jj]);
+        bad |= !(s > T(0));
+        const T inv = row::row_rsqrt(s);
+        a[jj] *= inv;                  // L[r][j]
+        x[jj] *= inv;                  // Li[j][r]
+        fence1(a[jj]);
+        sfor2<jj + 1, 16>([&](auto k) {
+            constexpr int kk = decltype(k)::value;
+            D::template fnmac<kk>(a[kk], a[jj], a[jj]);
+            D::template fnmac<kk>(x[kk], a[jj], x[jj]);
+        });
+    });
+    if (ln.q == 0) {                   // the rows of L (the lane's entries right of the diagonal are rounding residue: zero)
+        MF_UNROLL for (int j = 0; j < 16; ++j) img[ln.r * Tr<T>::LD + j] = (j <= ln.r) ? a[j] : T(0);
+    }
+    lds_fence();
+    MF_UNROLL for (int e = 0; e < 4; ++e) L[e] = img[Tr<T>::row(ln.q, e) * Tr<T>::LD + ln.r];
+    lds_fence();
+    v4 out[1];
+    cols_out<T, 1, true>(x, out, img, ln);
+    LiT = out[0];
+}
+// Phi (symmetric, tiles ti <= tj valid; consumed) -> L = chol(Phi) (S_LOWER) and LiT = L^-T (S_UPPER)
+template <typename T, int NT>
+MF_DEV void chol_fact_mat(Mat<T, NT>& Phi, Mat<T, NT>& L, Mat<T, NT>& LiT, T* lds, const Lane& ln, bool& bad) {
+    using v4 = typename Tr<T>::v4;
+    chol_fact_tile<T>(Phi.t[0][0], L.t[0][0], LiT.t[0][0], lds, ln, bad);
+    if constexpr (NT == 2) {
+        v4 li00, lt01 = {0, 0, 0, 0}, acc = {0, 0, 0, 0}, z = {0, 0, 0, 0}, h = {0, 0, 0, 0};
+        MF_UNROLL for (int e = 0; e < 4; ++e) li00[e] = lds[Tr<T>::row(ln.q, e) * Tr<T>::LD + ln.r];            // L00^-1 from the image
+        lds_fence();
+        MF_UNROLL for (int e = 0; e < 4; ++e) lt01 = Tr<T>::mfma(LiT.t[0][0][e], Phi.t[0][1][e], lt01);      // (L10)^T = Li00 Phi01
+        MF_UNROLL for (int e = 0; e < 4; ++e) acc = Tr<T>::mfma(lt01[e], lt01[e], acc);                      // L10 L10^T
+        Phi.t[1][1] -= acc;
+        chol_fact_tile<T>(Phi.t[1][1], L.t[1][1], LiT.t[1][1], lds, ln, bad);
+        MF_UNROLL for (int e = 0; e < 4; ++e) z = Tr<T>::mfma(lt01[e], li00[e], z);                          // Z = L10 Li00
+        MF_UNROLL for (int e = 0; e < 4; ++e) h = Tr<T>::mfma(z[e], LiT.t[1][1][e], h);                      // Z^T Li11^T
+        LiT.t[0][1] = -h;
+        LiT.t[1][0] = v4{0, 0, 0, 0};
+        transpose_tile<T>(L.t[1][0], lt01, lds, ln);
+        L.t[0][1] = v4{0, 0, 0, 0};
+    }
+}
+// a symmetric block from its LOWER triangle (what the reference's banded Cholesky reads): tiles ti <= tj
+template <typename T, int NT> MF_DEV void load_sym_lower(Mat<T, NT>& m, const T* __restrict__ g, int d, const Lane& ln) {
+    MF_UNROLL for (int ti = 0; ti < NT; ++ti)
+        MF_UNROLL for (int e = 0; e < 4; ++e) {
+            const int i = 16 * ti + Tr<T>::row(ln.q, e), j = 16 * ti + ln.r;
+            const bool in = i < d && j < d;
+            const T v = g[in ? i * d + j : 0];
+            m.t[ti][ti][e] = in ? v : ((i == j) ? T(1) : T(0));
+        }
+    if constexpr (NT == 2) {
+        load_tile_t<T>(m.t[0][1], g, d, 1, 0, ln);
+        m.t[1][0] = typename Tr<T>::v4{0, 0, 0, 0};
+    }
+}
+template <typename T, int NT> MF_DEV void copy_cv(CV<T, NT>& o, const CV<T, NT>& i) {
+    MF_UNROLL for (int j = 0; j < NT; ++j) o.v[j] = i.v[j];
+}
+
+template <typename T> struct FactArgs {
+    long B, n;
+    int d;
+    const T *diag, *sub;     // the symmetric matrix (cholesky, udl) or the factor (inverse blocks)
+    T *o1, *o2;              // cholesky: L diag, L sub; udl: U^T sub, chol(Delta); inverse blocks: diagonal, sub-diagonal blocks
+    const T* eta;            // udl: information vector (posterior chain) or NULL
+    T *m_post, *chol_dinv;   // udl with eta: Delta_k^-1 x_k and chol(Delta_k^-1)
+    int* info;
+};
+
+// SymmetricBlockTriDiagonal.cholesky (block_tri_diag.py:423-436): L_k = chol(D_k - W_{k-1} W_{k-1}^T), W_k = S_k L_k^-T.
+// The wave keeps W^T: D_k - (W^T)^T (W^T) and W_k^T = (LiT)^T S_k^T are both P^T Q products.
+template <typename T, int NT>
+__global__ void __launch_bounds__(64) wave_cholesky_kernel(FactArgs<T> a) {
+    constexpr int TS = 16 * Tr<T>::LD;
+    __shared__ __attribute__((aligned(16))) T lds[NT * NT * TS];
+    Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
+    const long s = blockIdx.x, n = a.n;
+    int d = a.d;
+    const long dd = long(d) * d;
+    const T* Dg = a.diag + s * n * dd;
+    const T* Sg = a.sub ? a.sub + s * (n - 1) * dd : nullptr;
+    bool bad = false;
+    Mat<T, NT> Dk, WT;
+    load_sym_lower<T, NT>(Dk, Dg, d, ln);
+    WT.zero();
+    for (long k = 0; k < n; ++k) {
+        asm volatile("" : "+v"(ln.r), "+v"(ln.q));
+        asm volatile("" : "+s"(d));
+        const bool more = k + 1 < n, coupled = more && Sg != nullptr;
+        Mat<T, NT> Dn, ST;
+        if (coupled) load_mat_t<T, NT>(ST, Sg + k * dd, d, ln);
+        if (more) load_sym_lower<T, NT>(Dn, Dg + (k + 1) * dd, d, ln);
+        phase();
+        if (k > 0 && Sg) tn<T, NT, S_FULL, S_FULL, S_UPPER, OP_SUB>(Dk, WT, WT);
+        Mat<T, NT> L, LiT;
+        chol_fact_mat<T, NT>(Dk, L, LiT, lds, ln, bad);
+        store_mat<T, NT, false>(a.o1 + (s * n + k) * dd, L, d, lds, ln);
+        phase();
+        if (coupled) {
+            tn<T, NT, S_UPPER, S_FULL, S_FULL, OP_SET>(WT, LiT, ST);                  // W_k^T = L_k^-1 S_k^T
+            Mat<T, NT> W;
+            transpose<T, NT, S_FULL>(W, WT, lds, ln);
+            store_mat<T, NT, false>(a.o2 + (s * (n - 1) + k) * dd, W, d, lds, ln);
+        }
+        if (more) Dk = Dn;
+    }
+    if (__any(bad) && threadIdx.x == 0 && a.info) raise_info(a.info);
+}
+
+// upper_diagonal_lower (block_tri_diag.py:438-545) + the posterior chain's means and factors (kalman_filter.py:159-174), backwards:
+// Delta_k = D_k - S_k^T Delta_{k+1}^-1 S_k, U_k^T = Delta_{k+1}^-1 S_k, x_k = eta_k - U_k x_{k+1}, m_k = Delta_k^-1 x_k.
+template <typename T, int NT>
+__global__ void __launch_bounds__(64) wave_udl_kernel(FactArgs<T> a) {
+    constexpr int TS = 16 * Tr<T>::LD;
+    __shared__ __attribute__((aligned(16))) T lds[NT * NT * TS];
+    Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
+    const long s = blockIdx.x, n = a.n;
+    int d = a.d;
+    const long dd = long(d) * d;
+    const T* Dg = a.diag + s * n * dd;
+    const T* Sg = a.sub ? a.sub + s * (n - 1) * dd : nullptr;
+    const T* Eg = a.eta ? a.eta + s * n * d : nullptr;
+    bool bad = false;
+    Mat<T, NT> Dk, Sk, LiT, Li;
+    CV<T, NT> xk, xp;
+    load_sym_lower<T, NT>(Dk, Dg + (n - 1) * dd, d, ln);
+    Sk.zero();
+    LiT.zero();
+    Li.zero();
+    MF_UNROLL for (int j = 0; j < NT; ++j) xk.v[j] = xp.v[j] = T(0);
+    if (Eg) load_cv<T, NT>(xk, Eg + (n - 1) * d, d, ln);
+    for (long k = n - 1; k >= 0; --k) {
+        asm volatile("" : "+v"(ln.r), "+v"(ln.q));
+        asm volatile("" : "+s"(d));
+        const bool more = k > 0, coupled = k + 1 < n && Sg != nullptr;
+        Mat<T, NT> Dn, Sn;
+        CV<T, NT> xn;
+        if (more) {
+            load_sym_lower<T, NT>(Dn, Dg + (k - 1) * dd, d, ln);
+            if (Sg) load_mat<T, NT, S_FULL>(Sn, Sg + (k - 1) * dd, d, false, false, ln);
+            if (Eg) load_cv<T, NT>(xn, Eg + (k - 1) * d, d, ln);
+        }
+        phase();
+        if (coupled) {
+            Mat<T, NT> U, Ut;
+            tn<T, NT, S_UPPER, S_FULL, S_FULL, OP_SET>(U, LiT, Sk);                    // L^-1 S_k       (L = chol Delta_{k+1})
+            tn<T, NT, S_FULL, S_FULL, S_UPPER, OP_SUB>(Dk, U, U);                      // Delta_k
+            tn<T, NT, S_LOWER, S_FULL, S_FULL, OP_SET>(Ut, Li, U);                     // U_k^T = Delta_{k+1}^-1 S_k
+            store_mat<T, NT, false>(a.o1 + (s * (n - 1) + k) * dd, Ut, d, lds, ln);
+            if (Eg) {
+                RV<T, NT> xr;
+                CV<T, NT> t;
+                cv_to_rv<T, NT>(xr, xp, ln);
+                tn_mv<T, NT, S_FULL>(t, Ut, xr);
+                MF_UNROLL for (int j = 0; j < NT; ++j) xk.v[j] -= t.v[j];
+            }
+        }
+        phase();
+        {
+            Mat<T, NT> L;
+            chol_fact_mat<T, NT>(Dk, L, LiT, lds, ln, bad);
+            store_mat<T, NT, false>(a.o2 + (s * n + k) * dd, L, d, lds, ln);
+        }
+        transpose<T, NT, S_UPPER>(Li, LiT, lds, ln);
+        if constexpr (NT == 2) Li.t[0][1] = typename Tr<T>::v4{0, 0, 0, 0};
+        phase();
+        if (Eg) {
+            RV<T, NT> r;
+            CV<T, NT> w, mk;
+            cv_to_rv<T, NT>(r, xk, ln);
+            tn_mv<T, NT, S_UPPER>(w, LiT, r);                                          // L^-1 x_k
+            cv_to_rv<T, NT>(r, w, ln);
+            tn_mv<T, NT, S_LOWER>(mk, Li, r);                                          // L^-T (L^-1 x_k)
+            store_cv<T, NT>(a.m_post + (s * n + k) * d, mk, d, ln);
+            Mat<T, NT> Qm, Lq, LqiT;
+            tn<T, NT, S_LOWER, S_LOWER, S_UPPER, OP_SET>(Qm, Li, Li);                  // Delta_k^-1
+            chol_fact_mat<T, NT>(Qm, Lq, LqiT, lds, ln, bad);
+            store_mat<T, NT, false>(a.chol_dinv + (s * n + k) * dd, Lq, d, lds, ln);
+            copy_cv<T, NT>(xp, xk);
+        }
+        if (more) {
+            Dk = Dn;
+            if (Sg) Sk = Sn;
+            if (Eg) copy_cv<T, NT>(xk, xn);
+        }
+    }
+    if (__any(bad) && threadIdx.x == 0 && a.info) raise_info(a.info);
+}
+
+// block_diagonal_of_inverse (block_tri_diag.py:318-337), block Takahashi backwards: with G_k = W_k L_k^-1,
+// Sigma_kk = L_k^-T L_k^-1 + G_k^T Sigma_{k+1,k+1} G_k and Sigma_{k+1,k} = -Sigma_{k+1,k+1} G_k.
+template <typename T, int NT>
+__global__ void __launch_bounds__(64) wave_inverse_blocks_kernel(FactArgs<T> a) {
+    using v4 = typename Tr<T>::v4;
+    constexpr int TS = 16 * Tr<T>::LD;
+    __shared__ __attribute__((aligned(16))) T lds[NT * NT * TS];
+    Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
+    const long s = blockIdx.x, n = a.n;
+    int d = a.d;
+    const long dd = long(d) * d;
+    const T* Lg = a.diag + s * n * dd;
+    const T* Wg = a.sub ? a.sub + s * (n - 1) * dd : nullptr;
+    bool bad = false;
+    LogAcc<T> la;
+    la.init();
+    Mat<T, NT> Lk, WTk, Sig;
+    v4 c10t = {0, 0, 0, 0};
+    load_mat<T, NT, S_LOWER>(Lk, Lg + (n - 1) * dd, d, true, true, ln);
+    if constexpr (NT == 2) load_tile_t<T>(c10t, Lg + (n - 1) * dd, d, 1, 0, ln);
+    WTk.zero();
+    Sig.zero();
+    for (long k = n - 1; k >= 0; --k) {
+        asm volatile("" : "+v"(ln.r), "+v"(ln.q));
+        asm volatile("" : "+s"(d));
+        const bool more = k > 0, coupled = k + 1 < n && Wg != nullptr;
+        Mat<T, NT> Ln, WTn;
+        v4 c10tn = {0, 0, 0, 0};
+        if (more) {
+            load_mat<T, NT, S_LOWER>(Ln, Lg + (k - 1) * dd, d, true, true, ln);
+            if constexpr (NT == 2) load_tile_t<T>(c10tn, Lg + (k - 1) * dd, d, 1, 0, ln);
+            if (Wg) load_mat_t<T, NT>(WTn, Wg + (k - 1) * dd, d, ln);
+        }
+        phase();
+        Mat<T, NT> Li, Out;
+        tri_inv_mat<T, NT>(Lk, c10t, Li, lds, ln, la, bad);
+        tn<T, NT, S_LOWER, S_LOWER, S_FULL, OP_SET>(Out, Li, Li);                      // L^-T L^-1
+        phase();
+        if (coupled) {
+            Mat<T, NT> G, NSG;
+            tn<T, NT, S_FULL, S_LOWER, S_FULL, OP_SET>(G, WTk, Li);                    // G = W_k L_k^-1
+            tn<T, NT, S_FULL, S_FULL, S_FULL, OP_NEG>(NSG, Sig, G);                    // -Sigma_{k+1,k+1} G   (Sigma symmetric)
+            if (a.o2) store_mat<T, NT, false>(a.o2 + (s * (n - 1) + k) * dd, NSG, d, lds, ln);
+            tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SUB>(Out, G, NSG);                    // + G^T Sigma G
+        }
+        store_mat<T, NT, false>(a.o1 + (s * n + k) * dd, Out, d, lds, ln);
+        Sig = Out;
+        if (more) {
+            Lk = Ln;
+            c10t = c10tn;
+            if (Wg) WTk = WTn;
+        }
+    }
+    (void)bad;
+}
+
+}  // namespace wv
+}  // namespace mf

@@ -175,3 +175,71 @@ def test_wave_solve_round_trip_at_the_operator_bench_shape(rng):
         torch.testing.assert_close(low.dense_mult(z), r, rtol=1e-9, atol=1e-9)
         zt = low.solve(r, transpose_left=True)
         torch.testing.assert_close(low.dense_mult(zt, transpose_left=True), r, rtol=1e-9, atol=1e-9)
+
+
+# ---- cholesky / upper_diagonal_lower / block_diagonal_of_inverse, one wavefront per series (csrc/mf_wave_ops.hpp) ------------------
+@pytest.mark.parametrize("dtype,d", [(torch.float64, 16), (torch.float64, 17), (torch.float64, 24), (torch.float64, 31),
+                                     (torch.float64, 32), (torch.float32, 16), (torch.float32, 21), (torch.float32, 32)])
+@pytest.mark.parametrize("bsz,n,has_sub", [(1, 1, False), (3, 2, True), (2, 37, True), (70, 9, True), (2, 5, False)])
+def test_wave_factorisations_against_the_oracle(rng, dtype, d, bsz, n, has_sub):
+    """block_tri_diag.py:423-436 (cholesky), :438-545 (upper_diagonal_lower), :318-337 (block diagonal and sub-diagonal of the
+    inverse): every block of every series against the oracle's serial recursions; one block, a block-diagonal matrix, more series
+    than one wavefront round would need."""
+    from test_gpu_large_d_ops import TOL, scaled_spd_btd
+    diag, sub = scaled_spd_btd(rng, (bsz,), n, d, has_sub)
+    if dtype == torch.float32:
+        diag = diag.astype(np.float32).astype(np.float64)
+        sub = None if sub is None else sub.astype(np.float32).astype(np.float64)
+    tol = TOL[dtype]
+    # the strict upper triangle of the diagonal blocks must not be read (block_tri_diag.py:423-436 factors the lower band)
+    junk = np.triu(rng.normal(size=diag.shape), 1)
+    sym = mfa.SymmetricBlockTriDiagonal(tt(np.tril(diag) + junk, dtype), tt(sub, dtype))
+    chol = sym.cholesky
+    ld, ls = O.btd_cholesky(diag, sub)
+    np.testing.assert_allclose(nn(chol.block_diagonal), np.tril(ld), **tol)
+    if has_sub:
+        np.testing.assert_allclose(nn(chol.block_sub_diagonal), ls, **tol)
+    exact = mfa.LowerTriangularBlockTriDiagonal(tt(np.tril(ld), dtype), tt(ls, dtype))
+    inv_d, inv_s = O.btd_block_diagonal_of_inverse(ld, ls, return_sub=True) if has_sub else (O.btd_block_diagonal_of_inverse(ld, ls), None)
+    if has_sub:
+        got_d, got_s = exact._diag_and_sub_of_inverse(want_sub=True)
+        np.testing.assert_allclose(nn(got_s), inv_s, **tol)
+    else:
+        got_d = exact.block_diagonal_of_inverse()
+    np.testing.assert_allclose(nn(got_d), inv_d, **tol)
+    if has_sub:
+        sym2 = mfa.SymmetricBlockTriDiagonal(tt(diag, dtype), tt(sub, dtype))
+        u_t, chol_d = sym2.upper_diagonal_lower()
+        want_u, want_c = O.btd_upper_diagonal_lower(diag, sub)
+        np.testing.assert_allclose(nn(u_t.block_sub_diagonal), want_u, **tol)
+        np.testing.assert_allclose(nn(chol_d.block_diagonal), np.tril(want_c), **tol)
+
+
+def test_wave_cholesky_reports_a_matrix_that_is_not_positive_definite(rng):
+    from test_gpu_large_d_ops import scaled_spd_btd
+    diag, sub = scaled_spd_btd(rng, (70,), 6, 20, True)
+    diag[33, 4, 17, 17] = -1.0
+    with pytest.raises(mfa.MarkovflowAmdError):
+        c = mfa.SymmetricBlockTriDiagonal(tt(diag, torch.float64), tt(sub, torch.float64)).cholesky
+        _ = c.block_diagonal
+        mfa.check_errors()
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("d,m,bsz,t", [(16, 1, 70, 12), (24, 2, 3, 40), (32, 1, 2, 25)])
+def test_wave_posterior_chain_against_the_oracle(rng, dtype, d, m, bsz, t):
+    """kalman_filter.py:159-174: the posterior state space model through precision -> upper_diagonal_lower with the information
+    vector riding along (means, Cholesky factors of the conditional covariances)."""
+    kw = random_ssm(rng, (bsz,), t, d, m, well=True)
+    if dtype == torch.float32:
+        kw = rounded(kw)
+    chol_r = (0.6 * np.eye(m)).astype(np.float32).astype(np.float64)
+    r_inv = np.linalg.inv(chol_r @ chol_r.T)
+    kf = build_kf(kw, chol_r, dtype=dtype)
+    post = kf.posterior_state_space_model()
+    want = O.kf_posterior_ssm(**kw, r_inv=r_inv)
+    got = (post.initial_mean, post.cholesky_initial_covariance, post.state_transitions, post.state_offsets,
+           post.cholesky_process_covariances)
+    tol = dict(rtol=1e-7, atol=1e-9) if dtype == torch.float64 else dict(rtol=5e-3, atol=5e-4)
+    for g, w in zip(got, want):
+        np.testing.assert_allclose(nn(g), w, **tol)
