@@ -284,6 +284,35 @@ class StationaryKernel(SDEKernel, abc.ABC):
         return p.expand(torch.broadcast_shapes(batch + p.shape[-2:], p.shape)) + self.jitter_matrix
 
 
+# (tensor, version) pairs whose positivity has been read back from the device: the check of matern.py:52-56 is a host
+# synchronisation, and a training loop builds the kernel objects anew around the SAME leaf tensors every step (six synchronisations
+# per step at config 4's model).  The entry holds the tensor, so its id cannot be reused; an in-place update (an optimiser step)
+# changes the version and is checked again.
+_POSITIVE = {}
+
+
+def _known_positive(*tensors: torch.Tensor) -> bool:
+    fresh = []
+    for t in tensors:
+        hit = _POSITIVE.get(id(t))
+        if hit is None or hit[0] is not t or hit[1] != t._version:
+            fresh.append(t)
+    if not fresh:
+        return True
+    with torch.no_grad():
+        bad = [(t.detach() <= 0).any() for t in fresh]
+        if len({t.device for t in fresh}) == 1:
+            ok = not bool(torch.stack(bad).any())           # one read-back for all of them
+        else:
+            ok = not any(bool(b) for b in bad)
+    if ok:
+        if len(_POSITIVE) > 256:
+            _POSITIVE.clear()
+        for t in fresh:
+            _POSITIVE[id(t)] = (t, t._version)
+    return ok
+
+
 class _MaternBase(StationaryKernel):
     order = 0   # Matérn-order/2
 
@@ -293,8 +322,9 @@ class _MaternBase(StationaryKernel):
         dev = device if device is not None else (lengthscale.device if isinstance(lengthscale, torch.Tensor) else "cpu")
         self._lengthscale_t = torch.as_tensor(lengthscale, dtype=dtype, device=dev)
         self._variance_t = torch.as_tensor(variance, dtype=dtype, device=dev)
-        if bool(torch.any(self._lengthscale_t <= 0)) or bool(torch.any(self._variance_t <= 0)):
+        if not _known_positive(self._lengthscale_t, self._variance_t):
             raise ValueError("lengthscale and variance must be positive.")   # matern.py:52-56
+        self._lambda_cached = None
 
     @property
     def state_dim(self) -> int:
@@ -310,7 +340,12 @@ class _MaternBase(StationaryKernel):
 
     @property
     def _lambda(self) -> torch.Tensor:
-        return math.sqrt(self.order) / self._lengthscale_t
+        if torch.is_grad_enabled() and self._lengthscale_t.requires_grad:
+            return math.sqrt(self.order) / self._lengthscale_t       # a node of its own per use: graphs built from it stay independent
+        key = self._lengthscale_t._version                         # otherwise one division per kernel object, not one per use
+        if self._lambda_cached is None or self._lambda_cached[0] != key:
+            self._lambda_cached = (key, math.sqrt(self.order) / self._lengthscale_t.detach())
+        return self._lambda_cached[1]
 
     def _components(self):
         return [self]
