@@ -278,10 +278,27 @@ class SymmetricBlockTriDiagonal(BlockTriDiagonal):
     def upper_diagonal_lower(self) -> Tuple[LowerTriangularBlockTriDiagonal, LowerTriangularBlockTriDiagonal]:
         """``U D Uᵀ`` factorisation; returns ``(Uᵀ, chol_D)`` (block_tri_diag.py:438-545)."""
         assert self._sub_diag is not None  # block_tri_diag.py:486
-        u_t, chol_d, _, _ = self._udl(None)
+        if _ag.needs_grad(self._diag, self._sub_diag):
+            u_t, chol_d = self._udl_differentiable()
+        else:
+            u_t, chol_d, _, _ = self._udl(None)
         identities = torch.eye(self.inner_dim, dtype=self._diag.dtype, device=self._diag.device).expand(
             self._diag.shape).contiguous()
         return LowerTriangularBlockTriDiagonal(identities, u_t), LowerTriangularBlockTriDiagonal(chol_d)
+
+    def _udl_differentiable(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """``(U^T sub-diagonal blocks, chol_D)`` as differentiable functions of the blocks.  ``P = U D U^T`` with ``D = C C^T`` is
+        ``P = (U C)(U C)^T``, an UPPER block-bidiagonal factor with lower-triangular diagonal blocks - the Cholesky factor ``L`` of
+        the TIME-REVERSED matrix read backwards: ``C_k = L_{n-1-k, n-1-k}`` and ``U_{k,k+1} C_{k+1} = L_{n-1-k, n-2-k}``.  The
+        reference differentiates its banded UDL through TensorFlow (block_tri_diag.py:438-545 under a tape); here the adjoint of
+        ``cholesky`` (``mf_btd_cholesky_grad_*``) does the work."""
+        diag_r = torch.flip(self._diag, dims=(-3,)).contiguous()
+        sub_r = torch.flip(self._sub_diag, dims=(-3,)).transpose(-1, -2).contiguous()
+        chol = SymmetricBlockTriDiagonal(diag_r, sub_r).cholesky
+        chol_d = torch.flip(chol.block_diagonal, dims=(-3,))
+        coupled = torch.flip(chol.block_sub_diagonal, dims=(-3,))                        # U_{k,k+1} C_{k+1}
+        u_t = torch.linalg.solve_triangular(chol_d[..., 1:, :, :].transpose(-1, -2), coupled.transpose(-1, -2), upper=True)
+        return u_t, chol_d
 
     def _udl(self, eta: Optional[torch.Tensor], chain: bool = False):
         """``chain=True`` (needs ``eta``): the outputs come in the layout of a posterior ``StateSpaceModel`` - returns

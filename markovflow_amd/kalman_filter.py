@@ -18,8 +18,9 @@ from typing import Optional
 
 import torch
 
+from . import _autograd_ops as _ag
 from . import _lib
-from .block_tri_diag import SymmetricBlockTriDiagonal, _flat
+from .block_tri_diag import LowerTriangularBlockTriDiagonal, SymmetricBlockTriDiagonal, _flat
 from .emission_model import EmissionModel
 from .state_space_model import StateSpaceModel
 
@@ -366,6 +367,8 @@ class BaseKalmanFilter(abc.ABC):
     def posterior_state_space_model(self) -> StateSpaceModel:
         """Posterior as a state space model (kalman_filter.py:109-182)."""
         h, y, r_inv, per_step = self._expanded()
+        if _ag.needs_grad(*self._chain_sources(), h, y, r_inv):
+            return self._posterior_differentiable(h, y, r_inv, per_step)
         fused = self._posterior_chain_fused(h, y, r_inv, per_step)
         if fused is not None:
             return fused
@@ -387,6 +390,35 @@ class BaseKalmanFilter(abc.ABC):
             state_offsets=m_post[..., 1:, :],
             chol_process_covariances=chol_dinv[..., 1:, :, :],
         )
+
+    def _posterior_differentiable(self, h, y, r_inv, per_step) -> StateSpaceModel:
+        """The same chain (kalman_filter.py:109-182) as a composition of the DIFFERENTIABLE operators - the reference differentiates
+        through this method under a tape: precision (state_space_model.py:431-483), ``U D U^T`` as the Cholesky factorisation of the
+        time-reversed posterior precision (``SymmetricBlockTriDiagonal._udl_differentiable``; adjoint: ``mf_btd_cholesky_grad_*``),
+        the two solves of kalman_filter.py:159-166 (``mf_btd_solve_*`` and its adjoint) and per-block Cholesky factors."""
+        ssm = self.prior_ssm
+        batch, n, d = tuple(ssm.batch_shape), ssm.num_transitions + 1, ssm.state_dim
+        m = h.shape[-2]
+        hb, yb = h.reshape(batch + (n, m, d)), y.reshape(batch + (n, m))
+        rb = r_inv.reshape(batch + (n, m, m)) if per_step else r_inv
+        prec = ssm.precision
+        rh = rb @ hb                                                                       # R^-1 H
+        diag = prec.block_diagonal + hb.transpose(-1, -2) @ rh                             # kalman_filter.py:86-101
+        obs_proj = (rh.transpose(-1, -2) @ yb[..., None])[..., 0]                          # H^T R^-1 y
+        # K^-1 mu = A^-T Q^-1 [mu0, b_0, ...]  (mu = A^-1 [mu0, b]; kalman_filter.py:153-156 without forming mu)
+        qm = _ag.chol_solve_blocks(ssm.concatenated_cholesky_process_covariance, ssm.concatenated_state_offsets[..., None])[..., 0]
+        eta = obs_proj + qm
+        eye = torch.eye(d, dtype=diag.dtype, device=diag.device).expand(diag.shape).contiguous()
+        back = (ssm.state_transitions.transpose(-1, -2) @ qm[..., 1:, :, None])[..., 0]
+        eta = eta - torch.cat([back, torch.zeros_like(back[..., :1, :])], dim=-2)
+        u_t, chol_d = SymmetricBlockTriDiagonal(diag, prec.block_sub_diagonal)._udl_differentiable()
+        x = LowerTriangularBlockTriDiagonal(eye, u_t).solve(eta, transpose_left=True)      # kalman_filter.py:159-162
+        m_post = _ag.chol_solve_blocks(chol_d, x[..., None])[..., 0]                       # kalman_filter.py:164-166
+        d_inv = _ag.chol_solve_blocks(chol_d, eye)
+        chol_dinv = _lib.checked_cholesky(0.5 * (d_inv + d_inv.transpose(-1, -2)), "posterior_state_space_model")
+        return StateSpaceModel(initial_mean=m_post[..., 0, :], chol_initial_covariance=chol_dinv[..., 0, :, :],
+                               state_transitions=-u_t, state_offsets=m_post[..., 1:, :],
+                               chol_process_covariances=chol_dinv[..., 1:, :, :])
 
     def _constant_terms(self, num_points: int) -> torch.Tensor:
         """``cst + ½ log|Σ⁻¹|`` (kalman_filter.py:229-231,249-253), shape [] or batch_shape."""

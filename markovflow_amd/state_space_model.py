@@ -174,7 +174,11 @@ class StateSpaceModel(GaussMarkovDistribution):
         return self._moments(want_sub=False)[:2]
 
     def covariance_blocks(self) -> Tuple[torch.Tensor, torch.Tensor]:
-        """Marginal covariances and ``Cov(x_{k+1}, x_k)`` from ONE scan."""
+        """Marginal covariances and ``Cov(x_{k+1}, x_k)`` from ONE scan; with parameters that require a gradient the marginals'
+        adjoint (``_Marginals``) and a differentiable block product ``A_k P_k`` (state_space_model.py:254-262,326-341 under a tape)."""
+        if self._needs_grad():
+            covs = self._differentiable_marginals()[1]
+            return covs, _ag.block_matmul(self._A_s.contiguous(), covs[..., :-1, :, :].contiguous())
         return self._covariance_scan(want_sub=True)
 
     def _moments(self, want_sub: bool):
@@ -257,6 +261,8 @@ class StateSpaceModel(GaussMarkovDistribution):
         n, d = self.num_transitions, self.state_dim
         if tuple(marginal_covariances.shape) != tuple(self.batch_shape) + (n + 1, d, d):
             raise ValueError(f"marginal_covariances has shape {tuple(marginal_covariances.shape)}")
+        if _ag.needs_grad(self._A_s, marginal_covariances):
+            return _ag.block_matmul(self._A_s.contiguous(), marginal_covariances[..., :-1, :, :].contiguous())
         a_f, cov_f = _flat(self._A_s, 3), _flat(marginal_covariances, 3)
         out = torch.empty_like(a_f)
         # blocks 0..n-1 of the [n+1]-long covariance chain are read in place (series stride n+1): no slice copy

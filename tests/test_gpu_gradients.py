@@ -441,11 +441,13 @@ def test_operations_without_a_backward_fail_loudly(rng):
     leaves = _leaves(kw, CHAIN, DEV)
     ssm = mfa.StateSpaceModel(*(leaves[k] for k in CHAIN))
     kf = mfa.KalmanFilter(ssm, mfa.EmissionModel(tt(kw["h"])), tt(kw["y"]), tt(np.array([[0.5]])))
-    for op in (lambda: kf.posterior_state_space_model(), lambda: ssm.covariance_blocks()):
+    for op in (lambda: kf._k_inv_post, lambda: ssm._covariance_scan(want_sub=True), lambda: ssm._moments(want_sub=True)):
         with pytest.raises(NotImplementedError, match="not differentiable"):
             op()
-    # round 4: the operator level is differentiable (tests/test_gpu_autograd_ops.py) - precision and the reparameterised sample
+    # round 4: the operator level is differentiable (tests/test_gpu_autograd_ops.py) - precision and the reparameterised sample;
+    # round 5: the posterior chain and the covariance blocks too (test_posterior_state_space_model_gradients_vs_dense_autograd)
     assert ssm.precision.block_diagonal.requires_grad and ssm.sample(2).requires_grad and ssm.normalizer().requires_grad
+    assert kf.posterior_state_space_model().state_transitions.requires_grad and ssm.covariance_blocks()[1].requires_grad
     with torch.no_grad():
         assert torch.isfinite(kf.posterior_state_space_model().marginal_means).all()
     assert torch.isfinite(ssm.create_non_trainable_copy().precision.cholesky.block_diagonal).all()
@@ -519,3 +521,87 @@ def test_trainable_copy_follows_optimiser_steps(rng):
     assert float(torch.triu(leaves[1].detach(), diagonal=1).abs().max()) == 0.0
     fresh = mfa.StateSpaceModel(*(t.detach() for t in leaves)).kl_divergence(prior).sum()
     assert float(q.kl_divergence(prior).sum().detach()) == pytest.approx(float(fresh), rel=1e-12)
+
+
+# ---- posterior_state_space_model / covariance_blocks under a gradient (VERDICT r04 missing 4) --------------------------------------
+def dense_posterior_moments(mu0, cp0, a_s, b_s, cq, h, y, chol_r):
+    """(means [n, d], covariance blocks [n, d, d], Cov(x_{k+1}, x_k) [n-1, d, d]) of x | y for ONE series by dense Gaussian
+    conditioning in differentiable torch (kalman_filter.py:109-182 states the same posterior as a chain)."""
+    n, d = a_s.shape[0] + 1, mu0.shape[0]
+    mean, prec = dense_chain(mu0, cp0, a_s, b_s, cq)
+    hm = torch.block_diag(*[h[i] for i in range(n)])
+    r_inv = torch.block_diag(*[torch.cholesky_inverse(chol_r)] * n)
+    cov = torch.linalg.inv(prec + hm.T @ r_inv @ hm)
+    cov = 0.5 * (cov + cov.T)
+    m_post = cov @ (hm.T @ r_inv @ y.reshape(-1) + prec @ mean)
+    blocks = torch.stack([cov[k * d:(k + 1) * d, k * d:(k + 1) * d] for k in range(n)])
+    cross = torch.stack([cov[(k + 1) * d:(k + 2) * d, k * d:(k + 1) * d] for k in range(n - 1)]) if n > 1 else cov.new_zeros(0, d, d)
+    return m_post.reshape(n, d), blocks, cross
+
+
+@pytest.mark.parametrize("d,m,t,bsz", [(2, 1, 6, 2), (3, 2, 9, 1), (9, 3, 5, 2), (4, 1, 70, 1), (12, 2, 5, 1), (3, 1, 2, 2)])
+def test_posterior_state_space_model_gradients_vs_dense_autograd(rng, d, m, t, bsz):
+    """The reference differentiates THROUGH posterior_state_space_model (kalman_filter.py:109-182 under a tape; conditionals.py:453
+    reads the posterior chain's covariance blocks): weighted sums of the posterior chain's marginal means, covariance blocks and
+    subsequent covariances, value and gradient with respect to every tensor of the model, against dense conditioning."""
+    kw = random_ssm(rng, (bsz,), t, d, m, well=True)
+    chol_r = np.linalg.cholesky(0.4 * np.eye(m) + 0.1 * np.ones((m, m)))
+    names = ["mu0", "chol_p0", "a_s", "b_s", "chol_q", "h", "y"]
+    w_m, w_c, w_x = rng.normal(size=(bsz, t, d)), rng.normal(size=(bsz, t, d, d)), rng.normal(size=(bsz, max(t - 1, 0), d, d))
+    cpu = {k: torch.tensor(kw[k], dtype=torch.float64, requires_grad=True) for k in names}
+    cpu_r = torch.tensor(chol_r, dtype=torch.float64, requires_grad=True)
+    total = 0.0
+    for s in range(bsz):
+        mm, cc, xx = dense_posterior_moments(*(cpu[k][s] for k in names), cpu_r)
+        total = total + (torch.tensor(w_m[s]) * mm).sum() + (torch.tensor(w_c[s]) * cc).sum() + (torch.tensor(w_x[s]) * xx).sum()
+    total.backward()
+    gpu = {k: torch.tensor(kw[k], dtype=torch.float64, device=DEV, requires_grad=True) for k in names}
+    gpu_r = torch.tensor(chol_r, dtype=torch.float64, device=DEV, requires_grad=True)
+    ssm = mfa.StateSpaceModel(gpu["mu0"], gpu["chol_p0"], gpu["a_s"], gpu["b_s"], gpu["chol_q"])
+    post = mfa.KalmanFilter(ssm, mfa.EmissionModel(gpu["h"]), gpu["y"], gpu_r).posterior_state_space_model()
+    means = post.marginal_means
+    covs, cross = post.covariance_blocks()
+    got = (tt(w_m) * means).sum() + (tt(w_c) * covs).sum() + (tt(w_x) * cross).sum()
+    assert float(got.detach()) == pytest.approx(float(total.detach()), rel=1e-8, abs=1e-9)
+    got.backward()
+    for k in names:
+        want = cpu[k].grad.numpy()
+        if k in ("chol_p0", "chol_q"):
+            want = np.tril(want)
+        np.testing.assert_allclose(gpu[k].grad.cpu().numpy(), want, rtol=2e-6, atol=1e-7, err_msg=k)
+    np.testing.assert_allclose(gpu_r.grad.cpu().numpy(), np.tril(cpu_r.grad.numpy()), rtol=2e-6, atol=1e-7)
+    # the value without a gradient is the kernels' chain: both routes describe the same model
+    with torch.no_grad():
+        plain = mfa.KalmanFilter(ssm, mfa.EmissionModel(gpu["h"]), gpu["y"], gpu_r).posterior_state_space_model()
+    for a, b in zip(post._flat_params(), plain._flat_params()):
+        torch.testing.assert_close(a.detach(), b, rtol=1e-7, atol=1e-9)
+
+
+def test_upper_diagonal_lower_gradients_vs_finite_differences(rng):
+    """block_tri_diag.py:438-545 under a tape: U^T and chol_D as differentiable functions of the blocks (the Cholesky factor of the
+    time-reversed matrix), against central differences of the kernel's own factorisation."""
+    from test_gpu_large_d_ops import scaled_spd_btd
+    diag, sub = scaled_spd_btd(rng, (2,), 7, 3, True)
+    dg, sb = tt(diag).requires_grad_(True), tt(sub).requires_grad_(True)
+    w_u, w_c = tt(rng.normal(size=sub.shape)), tt(rng.normal(size=diag.shape))
+
+    def value(dv, sv):
+        u_t, chol_d = mfa.SymmetricBlockTriDiagonal(dv, sv).upper_diagonal_lower()
+        return (w_u * u_t.block_sub_diagonal).sum() + (w_c * chol_d.block_diagonal).sum()
+
+    value(dg, sb).backward()
+    with torch.no_grad():
+        eps = 1e-6
+        for leaf, grad in ((dg, dg.grad), (sb, sb.grad)):
+            for _ in range(6):
+                idx = tuple(int(rng.integers(0, s)) for s in leaf.shape)
+                pert = torch.zeros_like(leaf)
+                pert[idx] = eps
+                if leaf is dg:                        # a symmetric perturbation of a symmetric block: d/dD_ij + d/dD_ji
+                    pert[idx[:-2] + (idx[-1], idx[-2])] = eps
+                    want = grad[idx] + (grad[idx[:-2] + (idx[-1], idx[-2])] if idx[-1] != idx[-2] else 0.0)
+                    up, dn = value(dg + pert, sb), value(dg - pert, sb)
+                else:
+                    want = grad[idx]
+                    up, dn = value(dg, sb + pert), value(dg, sb - pert)
+                assert float((up - dn) / (2 * eps)) == pytest.approx(float(want), rel=2e-5, abs=1e-6)
