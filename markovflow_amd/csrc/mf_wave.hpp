@@ -711,6 +711,173 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     if (__any(E.bad) && threadIdx.x == 0 && a.info) raise_info(a.info);
 }
 
+// ---- d <= 16: the step's two factorisations in ONE pass ------------------------------------------------------------------------
+// A step of wave_kf_chunk_kernel factors two diagonal tiles one after the other - chol(Q_k)^-1 when it opens and the pivot's Cholesky
+// factor half way through - and each pass runs redundantly on all four 16-lane rows: two thirds of the step's ~1 050 vector
+// instructions.  The inverse of the NEXT transition's chol(Q) depends on nothing of this step, so here the rows [0, 2) of the
+// wavefront factor the pivot while the rows [2, 4) invert chol(Q_{k+1}): one instruction stream, the roles told apart by three
+// per-lane constants (the tri rows see a pivot of 1 - rsq gives 1 - and their reciprocal diagonal as the scale of the inverse's row;
+// the Cholesky update of the remaining columns is multiplied by 0 there).
+// P (SPD tile, lower triangle used) -> LiT = chol(P)^-T;  C (lower-triangular tile) -> Ci = C^-1.  la (per lane): the pivots of P in
+// the rows [0, 2), the diagonal of C in the rows [2, 4).  img: two tile images.
+template <typename T>
+MF_DEV void chol_tri_pair(const typename Tr<T>::v4& P, const typename Tr<T>::v4& C, typename Tr<T>::v4& LiT, typename Tr<T>::v4& Ci,
+                          T* img, const Lane& ln, LogAcc<T>& la, bool& bad) {
+    using D = Dpp<T>;
+    using v4 = typename Tr<T>::v4;
+    constexpr int TS = 16 * Tr<T>::LD;
+    T a[16], x[16];
+    const v4 in[2] = {P, C};
+    rows_in<T, 2>(in, img, a, ln);
+    const bool chol = ln.q < 2;
+    const T dg = img[(chol ? 0 : TS) + ln.r * Tr<T>::LD + ln.r];          // the lane's diagonal element (the images are still there)
+    lds_fence();
+    bad |= !chol && !(dg != T(0));
+    const T dinv = chol ? T(1) : t_rcp<T>(dg);
+    const T cm = chol ? T(1) : T(0);
+    sfor<16>([&](auto i) { x[decltype(i)::value] = (ln.r == decltype(i)::value) ? T(1) : T(0); });
+    sfor<16>([&](auto j) {
+        constexpr int jj = decltype(j)::value;
+        fence1(a[jj]);
+        const T s = D::template bcast<jj>(a[jj]);
+        bad |= chol && !(s > T(0));
+        la.mul(s);
+        if constexpr (jj == 7) la.renorm();
+        const T inv = row::row_rsqrt(chol ? s : T(1));
+        T dj = dinv;
+        fence1(dj);
+        const T xs = inv * D::template bcast<jj>(dj);
+        a[jj] *= inv;                  // L[r][j]  |  C[r][j]
+        x[jj] *= xs;                   // Li[j][r] |  Ci[j][r]
+        T am = a[jj] * cm;
+        fence1(a[jj]);
+        fence1(am);
+        sfor2<jj + 1, 16>([&](auto k) {
+            constexpr int kk = decltype(k)::value;
+            D::template fnmac<kk>(a[kk], a[jj], am);             // P[r][k] -= L[k][j] L[r][j]   (nothing in the tri rows)
+            D::template fnmac<kk>(x[kk], a[jj], x[jj]);          // x[k]   -= L[k][j] x[j]       (C[k][j] there)
+        });
+    });
+    la.renorm();
+    if ((ln.q & 1) == 0) {                                       // the first row of lanes of either tile: the columns of the inverse
+        T* mine = img + (chol ? 0 : TS) + ln.r;
+        MF_UNROLL for (int row = 0; row < 16; ++row) mine[row * Tr<T>::LD] = x[row];
+    }
+    lds_fence();
+    image_to_tile_t<T>(LiT, img, ln);
+    MF_UNROLL for (int e = 0; e < 4; ++e) Ci[e] = img[TS + Tr<T>::row(ln.q, e) * Tr<T>::LD + ln.r];
+    lds_fence();
+}
+
+// wave_kf_chunk_kernel for one tile per matrix (d <= 16) with the paired pass: same arithmetic per block, same reduced system.
+template <typename T, int M, int WPE, bool EX>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) wave_kf_pair_kernel(WvArgs<T> a, RedSys<T> out) {
+    constexpr int NT = 1;
+    using v4 = typename Tr<T>::v4;
+    __shared__ __attribute__((aligned(16))) T lds[2 * 16 * Tr<T>::LD];
+    Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
+    const long id = blockIdx.x, s = id / a.P, c = id % a.P;
+    int d = EX ? 16 : a.d;
+    const int m = a.m;
+    const long nt = a.Tn - 1, tau0 = c * a.L;
+    long len = nt - tau0;
+    if (len > a.L) len = a.L;
+    if (len < 0) len = 0;
+    const bool spike = c > 0;
+    const long dd = long(d) * d;
+
+    WaveElim<T, NT> E;
+    E.init();
+    LogAcc<T> la;                               // rows [0, 2): pivots of the eliminated blocks; rows [2, 4): diagonals of the chol(Q)s
+    la.init();
+    T acc_ww = T(0), acc_yry = T(0);
+    T Ri[M][M];
+    if (!a.rinv_per_step) load_rinv<T, M>(Ri, a.Rinv, m);
+
+    Mat<T, NT> Am, Dn, Ci;
+    CV<T, NT> rn, mv_cv;
+    RV<T, NT> mv_rv, rn0_rv;
+    ObsRows<T, NT, M> ob;
+    v4 unused;
+
+    auto own_terms = [&]() {                    // from Ci = chol(Q)^-1 of the block: Dn = Q^-1, rn = Q^-1 mvec
+        tn<T, NT, S_LOWER, S_LOWER, S_UPPER, OP_SET>(Dn, Ci, Ci);
+        tn_mv<T, NT, S_FULL>(rn, Dn, mv_rv);
+        acc_ww += dot_cv<T, NT>(rn, mv_cv);
+        cv_to_rv<T, NT>(rn0_rv, rn, ln);
+    };
+    auto obs_terms = [&](long blk) {
+        if (a.rinv_per_step) load_rinv<T, M>(Ri, a.Rinv + (s * a.Tn + blk) * m * m, m);
+        acc_yry += obs_apply<T, NT, M>(ob, Ri, Dn, rn);
+    };
+
+    if (c == 0) {   // block 0: the prior
+        Mat<T, NT> C0;
+        load_mat<T, NT, S_LOWER, EX>(C0, a.cholP0 + s * dd, d, true, true, ln);
+        load_rv<T, NT>(mv_rv, a.mu0 + s * d, d, ln);
+        load_cv<T, NT>(mv_cv, a.mu0 + s * d, d, ln);
+        ob.load(a.H + (s * a.Tn) * m * d, a.y + (s * a.Tn) * m, d, m, ln);
+        chol_tri_pair<T>(identity_tile<T>(ln), C0.t[0][0], unused, Ci.t[0][0], lds, ln, la, E.bad);
+        own_terms();
+        obs_terms(0);
+        E.Phi.t[0][0] = Dn.t[0][0];
+        E.t = rn;
+    }
+    Mat<T, NT> Cn;
+    if (len > 0) {
+        load_mat<T, NT, S_LOWER, EX>(Cn, a.cholQ + (s * nt + tau0) * dd, d, true, true, ln);
+        chol_tri_pair<T>(identity_tile<T>(ln), Cn.t[0][0], unused, Ci.t[0][0], lds, ln, la, E.bad);
+    }
+    for (long j = 0; j < len; ++j) {
+        const long tau = tau0 + j, blk = tau + 1;
+        asm volatile("" : "+v"(ln.r), "+v"(ln.q));
+        if constexpr (!EX) asm volatile("" : "+s"(d));
+        const bool more = j + 1 < len;
+        load_mat<T, NT, S_LOWER, EX>(Cn, a.cholQ + (s * nt + (more ? tau + 1 : tau)) * dd, d, true, true, ln);
+        load_mat<T, NT, S_FULL, EX>(Am, a.A + (s * nt + tau) * dd, d, false, false, ln);
+        load_rv<T, NT>(mv_rv, a.b + (s * nt + tau) * d, d, ln);
+        load_cv<T, NT>(mv_cv, a.b + (s * nt + tau) * d, d, ln);
+        ob.load(a.H + (s * a.Tn + blk) * m * d, a.y + (s * a.Tn + blk) * m, d, m, ln);
+        own_terms();
+        phase();
+        Mat<T, NT> S;
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_NEG>(S, Dn, Am);                   // S = -Q^-1 A
+        CV<T, NT> btw;
+        tn_mv<T, NT, S_FULL>(btw, Am, rn0_rv);                                  // A^T Q^-1 mvec
+        obs_terms(blk);
+        phase();
+        const v4 cnext = more ? Cn.t[0][0] : identity_tile<T>(ln);              // (the last step has no successor: an identity)
+        if (j == 0 && spike) {
+            tn<T, NT, S_FULL, S_FULL, S_UPPER, OP_NEG>(E.GU, Am, S);            // GU = A^T Q^-1 A
+            E.X = S;
+            E.gU.v[0] = -btw.v[0];
+            E.Phi.t[0][0] = Dn.t[0][0];
+            E.t = rn;
+            chol_tri_pair<T>(identity_tile<T>(ln), cnext, unused, Ci.t[0][0], lds, ln, la, E.bad);
+        } else {
+            tn<T, NT, S_FULL, S_FULL, S_UPPER, OP_SUB>(E.Phi, Am, S);           // D_{k-1} += A^T Q^-1 A: complete
+            E.t.v[0] -= btw.v[0];
+            phase();
+            WaveFact<T, NT> f;
+            chol_tri_pair<T>(E.Phi.t[0][0], cnext, f.LiT.t[0][0], Ci.t[0][0], lds, ln, la, E.bad);
+            phase();
+            if (spike) E.template after_factor<true>(f, ln); else E.template after_factor<false>(f, ln);
+            phase();
+            Mat<T, NT> ST, WT;
+            transpose<T, NT, S_FULL>(ST, S, lds, ln);
+            tn<T, NT, S_UPPER, S_FULL, S_FULL, OP_SET>(WT, f.LiT, ST);          // W^T = Li S^T
+            phase();
+            if (spike) E.template advance<true>(f, WT, Dn, rn); else E.template advance<false>(f, WT, Dn, rn);
+        }
+    }
+    const T ww = sum16<T>(acc_ww), quad = sum16<T>(E.quad);
+    const T lv = la.value();
+    const T log_l2 = of_tile<T, 2>(lv, 0), log_c = of_tile<T, 2>(lv, 1);
+    const T scalar = T(-0.5) * (acc_yry + ww) + T(0.5) * quad - log_c - T(0.5) * log_l2;
+    store_chunk_wave<T, NT>(out, id, d, E, scalar, lds, ln);
+    if (__any(E.bad) && threadIdx.x == 0 && a.info) raise_info(a.info);
+}
+
 // ---- StateSpaceModel._build_precision (+ H^T R^-1 H, + information vector) for 16 <= d <= 32 -------------------------------------
 // (state_space_model.py:431-483, kalman_filter.py:86-101,149-156).  One wavefront per (series, block k): block k's diagonal block
 // needs Q_k^-1 and - when a transition leaves it - A_{k+1}^T Q_{k+1}^-1 A_{k+1}; its sub-diagonal block is -Q_{k+1}^-1 A_{k+1}.
