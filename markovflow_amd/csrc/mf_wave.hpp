@@ -769,15 +769,137 @@ MF_DEV void chol_tri_pair(const typename Tr<T>::v4& P, const typename Tr<T>::v4&
     lds_fence();
 }
 
-// wave_kf_chunk_kernel for one tile per matrix (d <= 16) with the paired pass: same arithmetic per block, same reduced system.
-template <typename T, int M, int WPE, bool EX>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) wave_kf_pair_kernel(WvArgs<T> a, RedSys<T> out) {
-    constexpr int NT = 1;
+// The same for 2 x 2 tiles (16 < d <= 32), where a step has THREE passes (both diagonal tiles of chol(Q) side by side, then the
+// pivot's two diagonal tiles one after the other): the first pass takes the pivot's tile (0, 0) in the first row of lanes and the two
+// tiles of the next chol(Q) in the second and third.  NTL tiles, 4 / NTL rows of lanes each; `chol`: the lane's tile is factored
+// (SPD, lower triangle used), else inverted (lower triangular).  The inverses are left in the NTL images, row-major.
+template <typename T, int NTL>
+MF_DEV void chol_tri_pass(const typename Tr<T>::v4 (&in)[NTL], bool chol, T* img, const Lane& ln, LogAcc<T>& la, bool& bad) {
+    using D = Dpp<T>;
+    constexpr int TS = 16 * Tr<T>::LD;
+    T a[16], x[16];
+    rows_in<T, NTL>(in, img, a, ln);
+    const int tile = tile_of_row<NTL>(ln.q);
+    const T dg = img[tile * TS + ln.r * Tr<T>::LD + ln.r];
+    lds_fence();
+    bad |= !chol && !(dg != T(0));
+    const T dinv = chol ? T(1) : t_rcp<T>(dg);
+    const T cm = chol ? T(1) : T(0);
+    sfor<16>([&](auto i) { x[decltype(i)::value] = (ln.r == decltype(i)::value) ? T(1) : T(0); });
+    sfor<16>([&](auto j) {
+        constexpr int jj = decltype(j)::value;
+        fence1(a[jj]);
+        const T s = D::template bcast<jj>(a[jj]);
+        bad |= chol && !(s > T(0));
+        la.mul(s);
+        if constexpr (jj == 7) la.renorm();
+        const T inv = row::row_rsqrt(chol ? s : T(1));
+        T dj = dinv;
+        fence1(dj);
+        const T xs = inv * D::template bcast<jj>(dj);
+        a[jj] *= inv;
+        x[jj] *= xs;
+        T am = a[jj] * cm;
+        fence1(a[jj]);
+        fence1(am);
+        sfor2<jj + 1, 16>([&](auto k) {
+            constexpr int kk = decltype(k)::value;
+            D::template fnmac<kk>(a[kk], a[jj], am);
+            D::template fnmac<kk>(x[kk], a[jj], x[jj]);
+        });
+    });
+    la.renorm();
+    if ((ln.q & (4 / NTL - 1)) == 0) {
+        T* mine = img + tile * TS + ln.r;
+        MF_UNROLL for (int row = 0; row < 16; ++row) mine[row * Tr<T>::LD] = x[row];
+    }
+    lds_fence();
+}
+template <typename T> MF_DEV void image_to_tile(typename Tr<T>::v4& t, const T* img, const Lane& ln) {
+    MF_UNROLL for (int e = 0; e < 4; ++e) t[e] = img[Tr<T>::row(ln.q, e) * Tr<T>::LD + ln.r];
+}
+// the log-determinants the paired passes collect: `la` by role of the lane's row (first pass), `lb` the pivot's second diagonal tile
+// (all rows alike), `lp` the passes that only invert a chol(Q) (chunk prologue, seed step of a spike; tri_inv_mat's layout)
+template <typename T, int NT> struct PairLogs {
+    LogAcc<T> la, lb, lp;
+    MF_DEV void init() { la.init(); lb.init(); lp.init(); }
+    MF_DEV T pivots() const {                    // log prod of the pivots = 2 log|L|
+        if constexpr (NT == 1) return of_tile<T, 2>(la.value(), 0);
+        else return of_tile<T, 4>(la.value(), 0) + lb.value();
+    }
+    MF_DEV T chol_q() const {                    // log prod diag chol(Q) over the blocks
+        if constexpr (NT == 1) return of_tile<T, 2>(la.value(), 1);
+        else {
+            const T v = la.value();
+            return of_tile<T, 4>(v, 1) + of_tile<T, 4>(v, 2) + tri_logdet<T, 2>(lp);
+        }
+    }
+};
+// C (S_LOWER; c10t = C10^T) -> Ci = C^-1, nothing to factor beside it
+template <typename T, int NT>
+MF_DEV void pair_tri_only(const Mat<T, NT>& C, const typename Tr<T>::v4& c10t, Mat<T, NT>& Ci, T* lds, const Lane& ln, PairLogs<T, NT>& lg,
+                          bool& bad) {
+    if constexpr (NT == 1) {
+        typename Tr<T>::v4 unused;
+        chol_tri_pair<T>(identity_tile<T>(ln), C.t[0][0], unused, Ci.t[0][0], lds, ln, lg.la, bad);
+    } else {
+        tri_inv_mat<T, NT>(C, c10t, Ci, lds, ln, lg.lp, bad);
+    }
+}
+// Phi (symmetric, tiles ti <= tj; consumed) -> LiT = chol(Phi)^-T (S_UPPER);  C (S_LOWER; c10t = C10^T) -> Ci = C^-1 (S_LOWER)
+template <typename T, int NT>
+MF_DEV void pair_both(Mat<T, NT>& Phi, const Mat<T, NT>& C, const typename Tr<T>::v4& c10t, Mat<T, NT>& LiT, Mat<T, NT>& Ci, T* lds,
+                      const Lane& ln, PairLogs<T, NT>& lg, bool& bad) {
     using v4 = typename Tr<T>::v4;
-    __shared__ __attribute__((aligned(16))) T lds[2 * 16 * Tr<T>::LD];
+    if constexpr (NT == 1) {
+        chol_tri_pair<T>(Phi.t[0][0], C.t[0][0], LiT.t[0][0], Ci.t[0][0], lds, ln, lg.la, bad);
+    } else {
+        constexpr int TS = 16 * Tr<T>::LD;
+        const v4 in[4] = {Phi.t[0][0], C.t[0][0], C.t[1][1], identity_tile<T>(ln)};
+        chol_tri_pass<T, 4>(in, ln.q == 0, lds, ln, lg.la, bad);
+        v4 li00, cit11;
+        image_to_tile_t<T>(LiT.t[0][0], lds, ln);
+        image_to_tile<T>(li00, lds, ln);
+        image_to_tile<T>(Ci.t[0][0], lds + TS, ln);
+        image_to_tile<T>(Ci.t[1][1], lds + 2 * TS, ln);
+        image_to_tile_t<T>(cit11, lds + 2 * TS, ln);
+        lds_fence();
+        // the pivot's second block column (chol_inv_mat)
+        v4 lt01 = {0, 0, 0, 0}, acc = {0, 0, 0, 0}, z = {0, 0, 0, 0}, h = {0, 0, 0, 0};
+        MF_UNROLL for (int e = 0; e < 4; ++e) lt01 = Tr<T>::mfma(LiT.t[0][0][e], Phi.t[0][1][e], lt01);      // (L10)^T = Li00 Phi01
+        MF_UNROLL for (int e = 0; e < 4; ++e) acc = Tr<T>::mfma(lt01[e], lt01[e], acc);                      // L10 L10^T
+        Phi.t[1][1] -= acc;
+        {
+            const v4 p11[1] = {Phi.t[1][1]};
+            v4 out[1];
+            chol_inv_tiles<T, 1, true>(p11, out, lds, ln, lg.lb, bad);
+            LiT.t[1][1] = out[0];
+        }
+        MF_UNROLL for (int e = 0; e < 4; ++e) z = Tr<T>::mfma(lt01[e], li00[e], z);                          // Z = L10 Li00
+        MF_UNROLL for (int e = 0; e < 4; ++e) h = Tr<T>::mfma(z[e], LiT.t[1][1][e], h);                      // Z^T Li11^T
+        LiT.t[0][1] = -h;
+        LiT.t[1][0] = v4{0, 0, 0, 0};
+        // the off-diagonal tile of chol(Q)^-1 (tri_inv_mat)
+        v4 g = {0, 0, 0, 0}, h2 = {0, 0, 0, 0};
+        MF_UNROLL for (int e = 0; e < 4; ++e) g = Tr<T>::mfma(c10t[e], Ci.t[0][0][e], g);                    // C10 Ci00
+        MF_UNROLL for (int e = 0; e < 4; ++e) h2 = Tr<T>::mfma(cit11[e], g[e], h2);                          // Ci11 (C10 Ci00)
+        Ci.t[1][0] = -h2;
+        Ci.t[0][1] = v4{0, 0, 0, 0};
+    }
+}
+template <typename T, int NT> MF_DEV void identity_mat(Mat<T, NT>& m, const Lane& ln) {
+    MF_UNROLL for (int i = 0; i < NT; ++i)
+        MF_UNROLL for (int j = 0; j < NT; ++j) m.t[i][j] = (i == j) ? identity_tile<T>(ln) : typename Tr<T>::v4{0, 0, 0, 0};
+}
+
+// wave_kf_chunk_kernel with the paired passes: same arithmetic per block, same reduced system.
+template <typename T, int NT, int M, int WPE, bool EX>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) wave_kf_pair_kernel(WvArgs<T> a, RedSys<T> out) {
+    using v4 = typename Tr<T>::v4;
+    __shared__ __attribute__((aligned(16))) T lds[(NT == 1 ? 2 : 4) * 16 * Tr<T>::LD];
     Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
     const long id = blockIdx.x, s = id / a.P, c = id % a.P;
-    int d = EX ? 16 : a.d;
+    int d = EX ? 16 * NT : a.d;
     const int m = a.m;
     const long nt = a.Tn - 1, tau0 = c * a.L;
     long len = nt - tau0;
@@ -788,8 +910,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
 
     WaveElim<T, NT> E;
     E.init();
-    LogAcc<T> la;                               // rows [0, 2): pivots of the eliminated blocks; rows [2, 4): diagonals of the chol(Q)s
-    la.init();
+    PairLogs<T, NT> lg;
+    lg.init();
     T acc_ww = T(0), acc_yry = T(0);
     T Ri[M][M];
     if (!a.rinv_per_step) load_rinv<T, M>(Ri, a.Rinv, m);
@@ -798,10 +920,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     CV<T, NT> rn, mv_cv;
     RV<T, NT> mv_rv, rn0_rv;
     ObsRows<T, NT, M> ob;
-    v4 unused;
 
-    auto own_terms = [&]() {                    // from Ci = chol(Q)^-1 of the block: Dn = Q^-1, rn = Q^-1 mvec
+    auto own_terms = [&]() {                    // from Ci = chol(Q)^-1 of the block: Dn = Q^-1 (both off-diagonal tiles), rn = Q^-1 mvec
         tn<T, NT, S_LOWER, S_LOWER, S_UPPER, OP_SET>(Dn, Ci, Ci);
+        if constexpr (NT == 2) transpose_tile<T>(Dn.t[1][0], Dn.t[0][1], lds, ln);
         tn_mv<T, NT, S_FULL>(rn, Dn, mv_rv);
         acc_ww += dot_cv<T, NT>(rn, mv_cv);
         cv_to_rv<T, NT>(rn0_rv, rn, ln);
@@ -811,29 +933,35 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
         acc_yry += obs_apply<T, NT, M>(ob, Ri, Dn, rn);
     };
 
+    Mat<T, NT> Cn;
+    v4 c10tn = {0, 0, 0, 0};
     if (c == 0) {   // block 0: the prior
-        Mat<T, NT> C0;
-        load_mat<T, NT, S_LOWER, EX>(C0, a.cholP0 + s * dd, d, true, true, ln);
+        load_mat<T, NT, S_LOWER, EX>(Cn, a.cholP0 + s * dd, d, true, true, ln);
+        if constexpr (NT == 2) load_tile_t<T, EX>(c10tn, a.cholP0 + s * dd, d, 1, 0, ln);
         load_rv<T, NT>(mv_rv, a.mu0 + s * d, d, ln);
         load_cv<T, NT>(mv_cv, a.mu0 + s * d, d, ln);
         ob.load(a.H + (s * a.Tn) * m * d, a.y + (s * a.Tn) * m, d, m, ln);
-        chol_tri_pair<T>(identity_tile<T>(ln), C0.t[0][0], unused, Ci.t[0][0], lds, ln, la, E.bad);
+        pair_tri_only<T, NT>(Cn, c10tn, Ci, lds, ln, lg, E.bad);
         own_terms();
         obs_terms(0);
-        E.Phi.t[0][0] = Dn.t[0][0];
+        MF_UNROLL for (int i = 0; i < NT; ++i) MF_UNROLL for (int j = i; j < NT; ++j) E.Phi.t[i][j] = Dn.t[i][j];
         E.t = rn;
     }
-    Mat<T, NT> Cn;
     if (len > 0) {
         load_mat<T, NT, S_LOWER, EX>(Cn, a.cholQ + (s * nt + tau0) * dd, d, true, true, ln);
-        chol_tri_pair<T>(identity_tile<T>(ln), Cn.t[0][0], unused, Ci.t[0][0], lds, ln, la, E.bad);
+        if constexpr (NT == 2) load_tile_t<T, EX>(c10tn, a.cholQ + (s * nt + tau0) * dd, d, 1, 0, ln);
+        pair_tri_only<T, NT>(Cn, c10tn, Ci, lds, ln, lg, E.bad);
     }
     for (long j = 0; j < len; ++j) {
         const long tau = tau0 + j, blk = tau + 1;
         asm volatile("" : "+v"(ln.r), "+v"(ln.q));
         if constexpr (!EX) asm volatile("" : "+s"(d));
         const bool more = j + 1 < len;
-        load_mat<T, NT, S_LOWER, EX>(Cn, a.cholQ + (s * nt + (more ? tau + 1 : tau)) * dd, d, true, true, ln);
+        {
+            const T* cq = a.cholQ + (s * nt + (more ? tau + 1 : tau)) * dd;
+            load_mat<T, NT, S_LOWER, EX>(Cn, cq, d, true, true, ln);
+            if constexpr (NT == 2) load_tile_t<T, EX>(c10tn, cq, d, 1, 0, ln);
+        }
         load_mat<T, NT, S_FULL, EX>(Am, a.A + (s * nt + tau) * dd, d, false, false, ln);
         load_rv<T, NT>(mv_rv, a.b + (s * nt + tau) * d, d, ln);
         load_cv<T, NT>(mv_cv, a.b + (s * nt + tau) * d, d, ln);
@@ -846,20 +974,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
         tn_mv<T, NT, S_FULL>(btw, Am, rn0_rv);                                  // A^T Q^-1 mvec
         obs_terms(blk);
         phase();
-        const v4 cnext = more ? Cn.t[0][0] : identity_tile<T>(ln);              // (the last step has no successor: an identity)
+        if (!more) {                                                            // the last step has no successor: an identity
+            identity_mat<T, NT>(Cn, ln);
+            c10tn = v4{0, 0, 0, 0};
+        }
         if (j == 0 && spike) {
             tn<T, NT, S_FULL, S_FULL, S_UPPER, OP_NEG>(E.GU, Am, S);            // GU = A^T Q^-1 A
             E.X = S;
-            E.gU.v[0] = -btw.v[0];
-            E.Phi.t[0][0] = Dn.t[0][0];
+            MF_UNROLL for (int k = 0; k < NT; ++k) E.gU.v[k] = -btw.v[k];
+            MF_UNROLL for (int i = 0; i < NT; ++i) MF_UNROLL for (int k = i; k < NT; ++k) E.Phi.t[i][k] = Dn.t[i][k];
             E.t = rn;
-            chol_tri_pair<T>(identity_tile<T>(ln), cnext, unused, Ci.t[0][0], lds, ln, la, E.bad);
+            pair_tri_only<T, NT>(Cn, c10tn, Ci, lds, ln, lg, E.bad);
         } else {
             tn<T, NT, S_FULL, S_FULL, S_UPPER, OP_SUB>(E.Phi, Am, S);           // D_{k-1} += A^T Q^-1 A: complete
-            E.t.v[0] -= btw.v[0];
+            MF_UNROLL for (int k = 0; k < NT; ++k) E.t.v[k] -= btw.v[k];
             phase();
             WaveFact<T, NT> f;
-            chol_tri_pair<T>(E.Phi.t[0][0], cnext, f.LiT.t[0][0], Ci.t[0][0], lds, ln, la, E.bad);
+            pair_both<T, NT>(E.Phi, Cn, c10tn, f.LiT, Ci, lds, ln, lg, E.bad);
             phase();
             if (spike) E.template after_factor<true>(f, ln); else E.template after_factor<false>(f, ln);
             phase();
@@ -871,9 +1002,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
         }
     }
     const T ww = sum16<T>(acc_ww), quad = sum16<T>(E.quad);
-    const T lv = la.value();
-    const T log_l2 = of_tile<T, 2>(lv, 0), log_c = of_tile<T, 2>(lv, 1);
-    const T scalar = T(-0.5) * (acc_yry + ww) + T(0.5) * quad - log_c - T(0.5) * log_l2;
+    const T scalar = T(-0.5) * (acc_yry + ww) + T(0.5) * quad - lg.chol_q() - T(0.5) * lg.pivots();
     store_chunk_wave<T, NT>(out, id, d, E, scalar, lds, ln);
     if (__any(E.bad) && threadIdx.x == 0 && a.info) raise_info(a.info);
 }

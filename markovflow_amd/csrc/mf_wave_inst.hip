@@ -34,12 +34,12 @@ int wave_launch(const wv::WvArgs<T>& a, const RedSys<T>& out, hipStream_t st) {
     else hipLaunchKernelGGL((wv::wave_kf_chunk_kernel<T, NT, M, wave_wpe<T, NT, M>(), false>), grid, block, 0, st, a, out);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
-// d = 16: the pivot's Cholesky factor and the next chol(Q)'s inverse in one pass (wave_kf_pair_kernel); MF_WAVE_PAIR=0: off
-template <typename T, int M>
+// the pivot's Cholesky factor and the next chol(Q)'s inverse in one pass (wave_kf_pair_kernel); MF_WAVE_PAIR=0: the plain kernel
+template <typename T, int NT, int M>
 int wave_launch_pair(const wv::WvArgs<T>& a, const RedSys<T>& out, hipStream_t st) {
     const dim3 grid((unsigned)(a.B * a.P)), block(64);
-    if (a.d == 16) hipLaunchKernelGGL((wv::wave_kf_pair_kernel<T, M, wave_wpe<T, 1, M>(), true>), grid, block, 0, st, a, out);
-    else hipLaunchKernelGGL((wv::wave_kf_pair_kernel<T, M, wave_wpe<T, 1, M>(), false>), grid, block, 0, st, a, out);
+    if (a.d == 16 * NT) hipLaunchKernelGGL((wv::wave_kf_pair_kernel<T, NT, M, wave_wpe<T, NT, M>(), true>), grid, block, 0, st, a, out);
+    else hipLaunchKernelGGL((wv::wave_kf_pair_kernel<T, NT, M, wave_wpe<T, NT, M>(), false>), grid, block, 0, st, a, out);
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 template <typename T>
@@ -54,7 +54,10 @@ int wave_level0(long B, long Tn, int d, int m, const T* mu0, const T* cholP0, co
     static const bool multi = [] { const char* e = mf_knob("MF_WAVE_MULTI"); return e && e[0] == '1'; }();
     if (d <= 16 && multi) return m == 1 ? wave_launch_multi<T, 1>(a, out, st) : wave_launch_multi<T, wv::WV_MAXM>(a, out, st);
     static const bool pair = [] { const char* e = mf_knob("MF_WAVE_PAIR"); return !(e && e[0] == '0'); }();
-    if (d <= 16 && pair) return m == 1 ? wave_launch_pair<T, 1>(a, out, st) : wave_launch_pair<T, wv::WV_MAXM>(a, out, st);
+    if (pair) {
+        if (d <= 16) return m == 1 ? wave_launch_pair<T, 1, 1>(a, out, st) : wave_launch_pair<T, 1, wv::WV_MAXM>(a, out, st);
+        return m == 1 ? wave_launch_pair<T, 2, 1>(a, out, st) : wave_launch_pair<T, 2, wv::WV_MAXM>(a, out, st);
+    }
     if (d <= 16) return m == 1 ? wave_launch<T, 1, 1>(a, out, st) : wave_launch<T, 1, wv::WV_MAXM>(a, out, st);
     return m == 1 ? wave_launch<T, 2, 1>(a, out, st) : wave_launch<T, 2, wv::WV_MAXM>(a, out, st);
 }
