@@ -354,9 +354,25 @@ def other_configs(dev):
         msw = _time_gpu(kfw.log_likelihood, iters=5, warm=2)
         wave[f"d{dd}"] = {"ms": msw, "steps_per_s": 512 * 1000 / msw * 1e3, "executed_TFLOPs_15d3": 512 * 1000 * 15.0 * dd ** 3 / msw / 1e9,
                           "algorithmic_GBps": 512 * 1000 * synthetic.loglik_bytes_per_step(dd, 1, 8) / msw / 1e6}
+        if dd in (16, 32):
+            # the operators of the same dimensions (csrc/mf_wave_ops.hpp: one wavefront per series walks the chain)
+            precw = kfw.prior_ssm.precision
+            symw = mfa.SymmetricBlockTriDiagonal(precw.block_diagonal, precw.block_sub_diagonal)
+            loww = symw.cholesky
+            rhsw = torch.randn(512, 1000, dd, dtype=torch.float64, device=dev, generator=g)
+            wave[f"d{dd}"]["operators_ms"] = {
+                "precision": _time_gpu(lambda: kfw.prior_ssm.precision, iters=3, warm=1),
+                "cholesky": _time_gpu(lambda: mfa.SymmetricBlockTriDiagonal(precw.block_diagonal, precw.block_sub_diagonal).cholesky, iters=3, warm=1),
+                "solve": _time_gpu(lambda: loww.solve(rhsw), iters=3, warm=1),
+                "block_diagonal_of_inverse": _time_gpu(loww.block_diagonal_of_inverse, iters=3, warm=1),
+                "posterior_state_space_model": _time_gpu(kfw.posterior_state_space_model, iters=3, warm=1)}
+            del precw, symw, loww, rhsw
         del kfw
     wave["note"] = ("KalmanFilter.log_likelihood B=512 T=1000 m=1 fp64: d = 15 row kernels (mf_row.hpp), d >= 16 wave kernels "
-                    "(one wavefront per chunk, register tiles in the MFMA accumulator layout); round 4: d=16 18.1 ms, d=32 57.9 ms")
+                    "(one wavefront per chunk, register tiles in the MFMA accumulator layout; the pivot's Cholesky factor and the next "
+                    "chol(Q)'s inverse share one DPP pass); round 4: d=16 18.1 ms, d=32 57.9 ms.  operators_ms: one wavefront per series "
+                    "(round 4 at d=16 / d=32: precision 10.9 / 43.9, cholesky 5.4 / 26.6, solve 8.1 / 22.9, inverse blocks 8.3 / 25.4, "
+                    "posterior_state_space_model 25.4 / 102.8 ms)")
     out["wave_kernels_B512_T1000_m1_f64"] = wave
     # reverse mode through the OPERATORS: the chain the reference's CVI models differentiate,
     # dist_p.precision -> naturals_to_ssm_params -> kl_divergence (models/variational_cvi.py:105-136), few long series

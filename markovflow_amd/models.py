@@ -168,6 +168,8 @@ class GaussianProcessRegression:
         + autograd version counter); a write that bypasses the version counter - ``lengthscale.data.clamp_()``, ``set_()`` - is
         invisible to that check: call this after such a write."""
         self._fused_cache = None
+        for comp in self._kernel._components():
+            comp._lambda_cached = None          # (the components keep sqrt(order) / lengthscale per lengthscale version)
 
     fused_backward = True    # set False to force the materialised route whenever a gradient is required
 
