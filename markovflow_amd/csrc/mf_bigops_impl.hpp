@@ -435,6 +435,11 @@ template <typename K> inline bool big_attr(K kernel, int bytes) {
 }
 inline int big_ok() { return hipGetLastError() == hipSuccess ? 0 : -1000; }
 
+// MF_WAVE=0 (experiment builds only, mf_env.hpp): the operators of 16 <= d <= 32 stay on the tile engine
+inline bool wave_off() {
+    static const bool off = [] { const char* e = mf_knob("MF_WAVE"); return e && e[0] == '0'; }();
+    return off;
+}
 inline int op_cholesky(long B, long n, int d, const real* diag, const real* sub, real* ldiag, real* lsub, int* info, hipStream_t st) {
 #define MF_C(DP)                                                                                                       \
     { static const bool ok = big_attr(&bigop_cholesky_kernel<DP>, Smem<DP>::BYTES); if (!ok) return -1000;               \
@@ -513,6 +518,10 @@ inline size_t marginal_covs_ws(long B, long n, int d) {
 // mu0, b, omean all NULL: covariances only
 inline int op_marginal_covs(long B, long n, int d, const real* mu0, const real* cholP0, const real* A, const real* b,
                             const real* cholQ, real* omean, real* ocov, real* osub, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!wave_off()) {   // 16 <= d <= 32, many series: one wavefront per series walks the forward recursion (mf_wave_ops.hpp)
+        const int rc = wave_ssm_marginals<real>(B, n, d, omean ? mu0 : nullptr, cholP0, A, omean ? b : nullptr, cholQ, omean, ocov, osub, st);
+        if (rc != -101) return rc;
+    }
     long P = cov_chunks(B, n);
     if (P > 1 && (ws == nullptr || ws_bytes < marginal_covs_ws(B, n, d))) P = 1;
     const long L = (n - 1 + P - 1) / P;

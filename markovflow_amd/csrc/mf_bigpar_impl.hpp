@@ -555,11 +555,6 @@ inline bool bigpar_pivots(long B, long n, int d, long P, long L, const real* dia
     return true;
 }
 
-// MF_WAVE=0 (experiment builds only, mf_env.hpp): the operators of 16 <= d <= 32 stay on the tile engine
-inline bool wave_off() {
-    static const bool off = [] { const char* e = mf_knob("MF_WAVE"); return e && e[0] == '0'; }();
-    return off;
-}
 inline int op_cholesky_par(long B, long n, int d, const real* diag, const real* sub, real* ldiag, real* lsub, void* ws, size_t ws_bytes,
                            int* info, hipStream_t st) {
     if (!wave_off()) {   // 16 <= d <= 32, many series: one wavefront per series on register tiles (mf_wave_ops.hpp)

@@ -50,4 +50,7 @@ template <typename T> int wave_btd_cholesky(long B, long n, int d, const T* diag
 template <typename T> int wave_btd_udl(long B, long n, int d, const T* diag, const T* sub, T* ut, T* chol_d, const T* eta, T* m_post,
                                        T* chol_dinv, int* info, hipStream_t st);
 template <typename T> int wave_btd_diag_of_inverse(long B, long n, int d, const T* ldiag, const T* lsub, T* odiag, T* osub, hipStream_t st);
+// marginal means (omean | NULL), covariances and subsequent covariances (osub | NULL) of a chain of n time points
+template <typename T> int wave_ssm_marginals(long B, long n, int d, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ,
+                                             T* omean, T* ocov, T* osub, hipStream_t st);
 }  // namespace mf

@@ -189,7 +189,17 @@ template <typename T> int wave_btd_diag_of_inverse(long B, long n, int d, const 
     const wv::FactArgs<T> a{B, n, d, ldiag, lsub, odiag, osub, nullptr, nullptr, nullptr, nullptr};
     MF_WAVE_FACT(wave_inverse_blocks_kernel, a, B);
 }
+template <typename T> int wave_ssm_marginals(long B, long n, int d, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ,
+                                             T* omean, T* ocov, T* osub, hipStream_t st) {
+    if (!wave_covers(d, 1) || B <= 0 || n <= 0 || !wave_serial_pays(B, n)) return -101;
+    const wv::MargArgs<T> a{B, n, d, mu0, cholP0, A, b, cholQ, omean, ocov, osub};
+    MF_WAVE_FACT(wave_marginals_kernel, a, B);
+}
 #undef MF_WAVE_FACT
+template int wave_ssm_marginals<double>(long, long, int, const double*, const double*, const double*, const double*, const double*, double*,
+                                        double*, double*, hipStream_t);
+template int wave_ssm_marginals<float>(long, long, int, const float*, const float*, const float*, const float*, const float*, float*, float*,
+                                       float*, hipStream_t);
 template int wave_btd_cholesky<double>(long, long, int, const double*, const double*, double*, double*, int*, hipStream_t);
 template int wave_btd_cholesky<float>(long, long, int, const float*, const float*, float*, float*, int*, hipStream_t);
 template int wave_btd_udl<double>(long, long, int, const double*, const double*, double*, double*, const double*, double*, double*, int*,

@@ -401,5 +401,93 @@ __global__ void __launch_bounds__(64) wave_inverse_blocks_kernel(FactArgs<T> a) 
     (void)bad;
 }
 
+// m = g^T with g lower triangular (its strict upper triangle, whatever it holds, reads as zero): the transposed Cholesky factor
+template <typename T, int NT> MF_DEV void load_lower_t(Mat<T, NT>& m, const T* __restrict__ g, int d, const Lane& ln) {
+    MF_UNROLL for (int ti = 0; ti < NT; ++ti)
+        MF_UNROLL for (int tj = 0; tj < NT; ++tj) {
+            if (ti > tj) { m.t[ti][tj] = typename Tr<T>::v4{0, 0, 0, 0}; continue; }
+            MF_UNROLL for (int e = 0; e < 4; ++e) {
+                const int i = 16 * ti + Tr<T>::row(ln.q, e), j = 16 * tj + ln.r;
+                const bool in = i < d && j < d && i <= j;
+                const T v = g[in ? j * d + i : 0];
+                m.t[ti][tj][e] = in ? v : T(0);
+            }
+        }
+}
+
+template <typename T> struct MargArgs {
+    long B, n;               // series, time points
+    int d;
+    const T *mu0, *cholP0, *A, *b, *cholQ;
+    T *omean, *ocov, *osub;  // [B, n, d] | NULL, [B, n, d, d], [B, n - 1, d, d] | NULL
+};
+
+// marginal means / covariances / subsequent covariances (state_space_model.py:232-262,326-341; gauss_markov.py:107-117) by the forward
+// recursion mu' = A mu + b, P' = A P A^T + C C^T, Cov(x', x) = A P - one wavefront per series; with A^T and C^T read transposed
+// every product is P^T Q: P A^T = tn(P, A^T) (P symmetric), A (P A^T) = tn(A^T, .), C C^T = tn(C^T, C^T), A P = tn(A^T, P).
+template <typename T, int NT>
+__global__ void __launch_bounds__(64) wave_marginals_kernel(MargArgs<T> a) {
+    constexpr int TS = 16 * Tr<T>::LD;
+    __shared__ __attribute__((aligned(16))) T lds[NT * NT * TS];
+    Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
+    const long s = blockIdx.x, n = a.n, nt = n - 1;
+    int d = a.d;
+    const long dd = long(d) * d;
+    const T* Ag = a.A + s * nt * dd;
+    const T* Cg = a.cholQ + s * nt * dd;
+    const T* bg = a.b ? a.b + s * nt * d : nullptr;
+    T* om = a.omean ? a.omean + s * n * d : nullptr;
+    T* oc = a.ocov + s * n * dd;
+    T* os = a.osub ? a.osub + s * nt * dd : nullptr;
+    Mat<T, NT> P, AT, CT;
+    CV<T, NT> m, bk;
+    MF_UNROLL for (int j = 0; j < NT; ++j) m.v[j] = bk.v[j] = T(0);
+    load_lower_t<T, NT>(CT, a.cholP0 + s * dd, d, ln);
+    tn<T, NT, S_UPPER, S_UPPER, S_FULL, OP_SET>(P, CT, CT);
+    if (om) {
+        load_cv<T, NT>(m, a.mu0 + s * d, d, ln);
+        store_cv<T, NT>(om, m, d, ln);
+    }
+    store_mat<T, NT, false>(oc, P, d, lds, ln);
+    if (nt > 0) {
+        load_mat_t<T, NT>(AT, Ag, d, ln);
+        load_lower_t<T, NT>(CT, Cg, d, ln);
+        if (om && bg) load_cv<T, NT>(bk, bg, d, ln);
+    }
+    for (long k = 0; k < nt; ++k) {
+        asm volatile("" : "+v"(ln.r), "+v"(ln.q));
+        asm volatile("" : "+s"(d));
+        Mat<T, NT> ATn, CTn;
+        CV<T, NT> bn;
+        MF_UNROLL for (int j = 0; j < NT; ++j) bn.v[j] = T(0);
+        const long kn = k + 1 < nt ? k + 1 : k;
+        load_mat_t<T, NT>(ATn, Ag + kn * dd, d, ln);
+        load_lower_t<T, NT>(CTn, Cg + kn * dd, d, ln);
+        if (om && bg) load_cv<T, NT>(bn, bg + kn * d, d, ln);
+        phase();
+        if (os) {
+            Mat<T, NT> AP;
+            tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(AP, AT, P);                      // A P
+            store_mat<T, NT, false>(os + k * dd, AP, d, lds, ln);
+        }
+        Mat<T, NT> X;
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(X, P, AT);                           // P A^T
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(P, AT, X);                           // A P A^T
+        tn<T, NT, S_UPPER, S_UPPER, S_FULL, OP_ADD>(P, CT, CT);                        // + C C^T
+        if (om) {
+            RV<T, NT> mr;
+            CV<T, NT> am;
+            cv_to_rv<T, NT>(mr, m, ln);
+            tn_mv<T, NT, S_FULL>(am, AT, mr);                                          // A m
+            MF_UNROLL for (int j = 0; j < NT; ++j) m.v[j] = am.v[j] + bk.v[j];
+            store_cv<T, NT>(om + (k + 1) * d, m, d, ln);
+        }
+        store_mat<T, NT, false>(oc + (k + 1) * dd, P, d, lds, ln);
+        AT = ATn;
+        CT = CTn;
+        MF_UNROLL for (int j = 0; j < NT; ++j) bk.v[j] = bn.v[j];
+    }
+}
+
 }  // namespace wv
 }  // namespace mf

@@ -530,7 +530,8 @@ def dense_posterior_moments(mu0, cp0, a_s, b_s, cq, h, y, chol_r):
     n, d = a_s.shape[0] + 1, mu0.shape[0]
     mean, prec = dense_chain(mu0, cp0, a_s, b_s, cq)
     hm = torch.block_diag(*[h[i] for i in range(n)])
-    r_inv = torch.block_diag(*[torch.cholesky_inverse(chol_r)] * n)
+    # chol_r: the Cholesky factor of the shared observation covariance [m, m], or per-point PRECISIONS [n, m, m] (sites)
+    r_inv = torch.block_diag(*([torch.cholesky_inverse(chol_r)] * n if chol_r.dim() == 2 else [chol_r[i] for i in range(n)]))
     cov = torch.linalg.inv(prec + hm.T @ r_inv @ hm)
     cov = 0.5 * (cov + cov.T)
     m_post = cov @ (hm.T @ r_inv @ y.reshape(-1) + prec @ mean)
@@ -605,3 +606,35 @@ def test_upper_diagonal_lower_gradients_vs_finite_differences(rng):
                     want = grad[idx]
                     up, dn = value(dg, sb + pert), value(dg, sb - pert)
                 assert float((up - dn) / (2 * eps)) == pytest.approx(float(want), rel=2e-5, abs=1e-6)
+
+
+def test_sites_filter_posterior_gradients_vs_dense_autograd(rng):
+    """KalmanFilterWithSites.posterior_state_space_model under a tape (kalman_filter.py:437-497 with :109-182): per-point precisions
+    and pseudo-observations that are functions of the sites' natural parameters; gradients with respect to nat1, nat2 and the chain."""
+    d, t = 3, 9
+    kw = random_ssm(rng, (), t, d, 1, well=True)
+    nat1_np, nat2_np = rng.normal(size=(t, 1)), -0.5 * (0.5 + rng.random(size=(t, 1, 1)))
+    w_m, w_c = rng.normal(size=(t, d)), rng.normal(size=(t, d, d))
+
+    def value(dev):
+        leaves = {k: torch.tensor(kw[k], dtype=torch.float64, device=dev, requires_grad=True) for k in CHAIN}
+        nat1 = torch.tensor(nat1_np, dtype=torch.float64, device=dev, requires_grad=True)
+        nat2 = torch.tensor(nat2_np, dtype=torch.float64, device=dev, requires_grad=True)
+        h = torch.tensor(kw["h"], dtype=torch.float64, device=dev)
+        wm, wc = torch.tensor(w_m, dtype=torch.float64, device=dev), torch.tensor(w_c, dtype=torch.float64, device=dev)
+        if dev == "cpu":
+            means, covs, _ = dense_posterior_moments(*(leaves[k] for k in CHAIN), h, -0.5 * nat1 / nat2[..., 0], -2.0 * nat2)
+        else:
+            sites = mfa.UnivariateGaussianSitesNat(nat1, nat2)
+            post = mfa.KalmanFilterWithSites(mfa.StateSpaceModel(*(leaves[k] for k in CHAIN)), mfa.EmissionModel(h), sites).posterior_state_space_model()
+            means, covs = post.marginals
+        total = (wm * means).sum() + (wc * covs).sum()
+        total.backward()
+        return total, leaves, nat1, nat2
+
+    want, cl, c1, c2 = value("cpu")
+    got, gl, g1, g2 = value(DEV)
+    assert float(got.detach()) == pytest.approx(float(want.detach()), rel=1e-9, abs=1e-10)
+    _assert_grads(gl, cl, CHAIN, rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(g1.grad.cpu().numpy(), c1.grad.numpy(), rtol=2e-6, atol=1e-8)
+    np.testing.assert_allclose(g2.grad.cpu().numpy(), c2.grad.numpy(), rtol=2e-6, atol=1e-8)

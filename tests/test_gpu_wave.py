@@ -243,3 +243,36 @@ def test_wave_posterior_chain_against_the_oracle(rng, dtype, d, m, bsz, t):
     tol = dict(rtol=1e-7, atol=1e-9) if dtype == torch.float64 else dict(rtol=5e-3, atol=5e-4)
     for g, w in zip(got, want):
         np.testing.assert_allclose(nn(g), w, **tol)
+
+
+# ---- marginals / covariance blocks / KL on the register tiles (csrc/mf_wave_ops.hpp: wave_marginals_kernel) ------------------------
+@pytest.mark.parametrize("dtype,d", [(torch.float64, 16), (torch.float64, 23), (torch.float64, 32), (torch.float32, 16),
+                                     (torch.float32, 27), (torch.float32, 32)])
+@pytest.mark.parametrize("bsz,t", [(1, 2), (70, 9), (3, 130)])
+def test_wave_marginals_and_covariance_blocks(rng, dtype, d, bsz, t):
+    """state_space_model.py:232-262,326-341 / gauss_markov.py:107-117: means, covariances and Cov(x_{k+1}, x_k) of every series
+    against the explicit forward recursion; the KL divergence to a second chain (state_space_model.py:528-593) against the oracle."""
+    from test_gpu_large_d_ops import TOL
+    kw = random_ssm(rng, (bsz,), t, d, 1, well=True)
+    kw2 = random_ssm(rng, (bsz,), t, d, 1, well=True)
+    if dtype == torch.float32:
+        kw, kw2 = rounded(kw), rounded(kw2)
+    names = ("mu0", "chol_p0", "a_s", "b_s", "chol_q")
+    ssm = mfa.StateSpaceModel(*(tt(kw[k], dtype) for k in names))
+    means, covs = ssm.marginals
+    covs2, sub = ssm.covariance_blocks()
+    em = O.ssm_marginal_means(kw["mu0"], kw["a_s"], kw["b_s"])
+    ec = [kw["chol_p0"] @ np.swapaxes(kw["chol_p0"], -1, -2)]
+    for k in range(t - 1):
+        a, c = kw["a_s"][:, k], kw["chol_q"][:, k]
+        ec.append(a @ ec[-1] @ np.swapaxes(a, -1, -2) + c @ np.swapaxes(c, -1, -2))
+    ec = np.stack(ec, axis=1)
+    tol = TOL[dtype]
+    np.testing.assert_allclose(nn(means), em, **tol)
+    np.testing.assert_allclose(nn(covs), ec, **tol)
+    np.testing.assert_allclose(nn(covs2), ec, **tol)
+    np.testing.assert_allclose(nn(sub), O.ssm_subsequent_covariances(kw["a_s"], ec), **tol)
+    if dtype == torch.float64:
+        other = mfa.StateSpaceModel(*(tt(kw2[k], dtype) for k in names))
+        want = O.ssm_kl_divergence(tuple(kw[k] for k in names), tuple(kw2[k] for k in names))
+        np.testing.assert_allclose(nn(ssm.kl_divergence(other)), want, rtol=1e-8)
