@@ -137,6 +137,11 @@ __global__ void __launch_bounds__(NTHR) biggrad_local_kernel(BigGradArgs a) {
 
 inline int op_kf_grad(const BigGradArgs& a, hipStream_t st) {
     const int d = a.d;
+    if (!wave_off()) {   // 16 <= d <= 32, up to four outputs: one wavefront per (series, time point) on register tiles (mf_wave_grad.hpp)
+        const int rc = wave_kf_grad<real>(a.B, a.Tn, a.d, a.m, a.mu0, a.cholP0, a.A, a.b, a.cholQ, a.H, a.y, a.Rinv, a.rinv_per_step, a.mean,
+                                          a.cov, a.cross, a.w, a.g_mu0, a.g_cholP0, a.g_A, a.g_b, a.g_cholQ, a.g_H, a.g_y, a.g_om, st);
+        if (rc != -101) return rc;
+    }
 #define MF_C(DP)                                                                                                        \
     { if (a.H && a.m > DP) return -4;                                                                                   \
       static const bool ok = big_attr(&biggrad_local_kernel<DP>, Smem<DP>::BYTES);                                       \

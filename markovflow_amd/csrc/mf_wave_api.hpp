@@ -53,4 +53,9 @@ template <typename T> int wave_btd_diag_of_inverse(long B, long n, int d, const 
 // marginal means (omean | NULL), covariances and subsequent covariances (osub | NULL) of a chain of n time points
 template <typename T> int wave_ssm_marginals(long B, long n, int d, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ,
                                              T* omean, T* ocov, T* osub, hipStream_t st);
+// the local step of the log-likelihood's gradient from the smoothed moments (mf_wave_grad.hpp); H == NULL: no observation terms
+template <typename T>
+int wave_kf_grad(long B, long Tn, int d, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H, const T* y,
+                 const T* Rinv, int rinv_per_step, const T* mean, const T* cov, const T* cross, const T* w, T* g_mu0, T* g_cholP0, T* g_A,
+                 T* g_b, T* g_cholQ, T* g_H, T* g_y, T* g_om, hipStream_t st);
 }  // namespace mf

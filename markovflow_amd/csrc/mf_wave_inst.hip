@@ -4,6 +4,7 @@
 
 #include "mf_wave.hpp"
 #include "mf_wave_ops.hpp"
+#include "mf_wave_grad.hpp"
 #include "mf_launch.hpp"
 #include "mf_wave_api.hpp"
 
@@ -196,6 +197,31 @@ template <typename T> int wave_ssm_marginals(long B, long n, int d, const T* mu0
     MF_WAVE_FACT(wave_marginals_kernel, a, B);
 }
 #undef MF_WAVE_FACT
+// the local step of the log-likelihood's gradient (mf_wave_grad.hpp): one wavefront per (series, time point)
+template <typename T>
+int wave_kf_grad(long B, long Tn, int d, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H, const T* y,
+                 const T* Rinv, int rinv_per_step, const T* mean, const T* cov, const T* cross, const T* w, T* g_mu0, T* g_cholP0, T* g_A,
+                 T* g_b, T* g_cholQ, T* g_H, T* g_y, T* g_om, hipStream_t st) {
+    if (!wave_covers(d, H ? m : 1) || B <= 0 || Tn <= 0) return -101;
+    const wv::WvGradArgs<T> a{B, Tn, d, H ? m : 1, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, mean, cov, cross, w,
+                              g_mu0, g_cholP0, g_A, g_b, g_cholQ, g_H, g_y, g_om};
+    const dim3 grid((unsigned)(B * Tn)), block(64);
+    const bool m1 = !H || m == 1;
+    if (d <= 16) {
+        if (m1) hipLaunchKernelGGL((wv::wave_kf_grad_kernel<T, 1, 1>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((wv::wave_kf_grad_kernel<T, 1, wv::WV_MAXM>), grid, block, 0, st, a);
+    } else {
+        if (m1) hipLaunchKernelGGL((wv::wave_kf_grad_kernel<T, 2, 1>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((wv::wave_kf_grad_kernel<T, 2, wv::WV_MAXM>), grid, block, 0, st, a);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+template int wave_kf_grad<double>(long, long, int, int, const double*, const double*, const double*, const double*, const double*, const double*,
+                                  const double*, const double*, int, const double*, const double*, const double*, const double*, double*, double*,
+                                  double*, double*, double*, double*, double*, double*, hipStream_t);
+template int wave_kf_grad<float>(long, long, int, int, const float*, const float*, const float*, const float*, const float*, const float*,
+                                 const float*, const float*, int, const float*, const float*, const float*, const float*, float*, float*, float*,
+                                 float*, float*, float*, float*, float*, hipStream_t);
 template int wave_ssm_marginals<double>(long, long, int, const double*, const double*, const double*, const double*, const double*, double*,
                                         double*, double*, hipStream_t);
 template int wave_ssm_marginals<float>(long, long, int, const float*, const float*, const float*, const float*, const float*, float*, float*,

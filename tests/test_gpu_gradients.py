@@ -46,7 +46,10 @@ def dense_log_likelihood(mu0, cp0, a_s, b_s, cq, h, y, chol_r):
 
 
 @pytest.mark.parametrize("dtype,d,m,t,bsz", [(torch.float32, 64, 32, 40, 2), (torch.float32, 33, 7, 70, 1), (torch.float64, 20, 3, 50, 2),
-                                             (torch.float64, 12, 20, 9, 2)])
+                                             (torch.float64, 12, 20, 9, 2),
+                                             # 16 <= d <= 32 with up to four outputs: the wave kernel of the local step (csrc/mf_wave_grad.hpp)
+                                             (torch.float64, 16, 1, 30, 3), (torch.float64, 32, 4, 12, 2), (torch.float64, 27, 2, 9, 70),
+                                             (torch.float32, 16, 4, 40, 2), (torch.float32, 32, 1, 25, 2)])
 def test_large_d_local_gradient_kernel_vs_closed_forms(rng, dtype, d, m, t, bsz):
     """The tile kernel of the local gradient step (csrc/mf_biggrad_impl.hpp; BASELINE config 5's d = 64, m = 32 in fp32) against
     the same closed forms as batched fp64 products on the SAME smoothed moments (kalman_filter._local_gradients_dense) - every
@@ -81,6 +84,8 @@ def test_large_d_local_gradient_kernel_vs_closed_forms(rng, dtype, d, m, t, bsz)
                                        # beyond the register-resident local kernel (VERDICT r02 missing 4): smoothed moments from the
                                        # LDS-tile / MFMA kernels, local closed forms as batched products (kalman_filter._local_gradients_dense)
                                        (12, 2, 6, 2), (17, 5, 5, 1), (32, 6, 4, 2),
+                                       # 16 <= d <= 32, m <= 4: posterior chain, moments and the local step on the wave kernels
+                                       (16, 1, 6, 2), (24, 3, 5, 2), (32, 4, 4, 1),
                                        # 10 <= d <= 15 on chains long enough for the time partition: posterior chain, moments and the
                                        # local step all in row form (csrc/mf_row_*.hpp compiled for these d)
                                        (12, 3, 70, 1), (15, 4, 66, 2), (10, 1, 130, 1),
