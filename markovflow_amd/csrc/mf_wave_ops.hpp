@@ -197,6 +197,86 @@ MF_DEV void chol_fact_mat(Mat<T, NT>& Phi, Mat<T, NT>& L, Mat<T, NT>& LiT, T* ld
         L.t[0][1] = v4{0, 0, 0, 0};
     }
 }
+// Two SPD tiles factored side by side (rows [0, 2) of the wavefront: PA, rows [2, 4): PB): one instruction stream.  Out: the factors
+// and the transposed inverses of both; the images hold LA^-1 and LB^-1 (row-major) afterwards.  img: two tile images.
+template <typename T>
+MF_DEV void chol_fact_tiles2(const typename Tr<T>::v4& PA, const typename Tr<T>::v4& PB, typename Tr<T>::v4& LA, typename Tr<T>::v4& LiTA,
+                             typename Tr<T>::v4& LB, typename Tr<T>::v4& LiTB, T* img, const Lane& ln, bool& bad) {
+    using D = Dpp<T>;
+    using v4 = typename Tr<T>::v4;
+    constexpr int TS = 16 * Tr<T>::LD;
+    T a[16], x[16];
+    const v4 in[2] = {PA, PB};
+    rows_in<T, 2>(in, img, a, ln);
+    sfor<16>([&](auto i) { x[decltype(i)::value] = (ln.r == decltype(i)::value) ? T(1) : T(0); });
+    sfor<16>([&](auto j) {
+        constexpr int jj = decltype(j)::value;
+        fence1(a[jj]);
+        const T s = D::template bcast<jj>(a[jj]);
+        bad |= !(s > T(0));
+        const T inv = row::row_rsqrt(s);
+        a[jj] *= inv;
+        x[jj] *= inv;
+        fence1(a[jj]);
+        sfor2<jj + 1, 16>([&](auto k) {
+            constexpr int kk = decltype(k)::value;
+            D::template fnmac<kk>(a[kk], a[jj], a[jj]);
+            D::template fnmac<kk>(x[kk], a[jj], x[jj]);
+        });
+    });
+    T* mine = img + (ln.q >> 1) * TS;
+    if ((ln.q & 1) == 0) {
+        MF_UNROLL for (int j = 0; j < 16; ++j) mine[ln.r * Tr<T>::LD + j] = (j <= ln.r) ? a[j] : T(0);
+    }
+    lds_fence();
+    MF_UNROLL for (int e = 0; e < 4; ++e) {
+        LA[e] = img[Tr<T>::row(ln.q, e) * Tr<T>::LD + ln.r];
+        LB[e] = img[TS + Tr<T>::row(ln.q, e) * Tr<T>::LD + ln.r];
+    }
+    lds_fence();
+    if ((ln.q & 1) == 0) {
+        MF_UNROLL for (int row = 0; row < 16; ++row) mine[row * Tr<T>::LD + ln.r] = x[row];
+    }
+    lds_fence();
+    image_to_tile_t<T>(LiTA, img, ln);
+    image_to_tile_t<T>(LiTB, img + TS, ln);
+    lds_fence();
+}
+// A (symmetric, tiles ti <= tj valid; consumed) -> LA = chol(A) (S_LOWER), LiTA = LA^-T (S_UPPER);  B likewise -> LB only.
+// The diagonal tiles of the two matrices share their passes (two instead of four at 2 x 2 tiles, one instead of two at one tile).
+template <typename T, int NT>
+MF_DEV void chol_fact_mat2(Mat<T, NT>& A, Mat<T, NT>& B, Mat<T, NT>& LA, Mat<T, NT>& LiTA, Mat<T, NT>& LB, T* lds, const Lane& ln, bool& bad) {
+    using v4 = typename Tr<T>::v4;
+    v4 litb00;
+    chol_fact_tiles2<T>(A.t[0][0], B.t[0][0], LA.t[0][0], LiTA.t[0][0], LB.t[0][0], litb00, lds, ln, bad);
+    if constexpr (NT == 2) {
+        constexpr int TS = 16 * Tr<T>::LD;
+        v4 lia00, lta = {0, 0, 0, 0}, ltb = {0, 0, 0, 0}, acc = {0, 0, 0, 0}, z = {0, 0, 0, 0}, h = {0, 0, 0, 0}, unused;
+        MF_UNROLL for (int e = 0; e < 4; ++e) lia00[e] = lds[Tr<T>::row(ln.q, e) * Tr<T>::LD + ln.r];          // LA00^-1 from the image
+        lds_fence();
+        MF_UNROLL for (int e = 0; e < 4; ++e) lta = Tr<T>::mfma(LiTA.t[0][0][e], A.t[0][1][e], lta);         // (LA10)^T
+        MF_UNROLL for (int e = 0; e < 4; ++e) acc = Tr<T>::mfma(lta[e], lta[e], acc);
+        A.t[1][1] -= acc;
+        acc = v4{0, 0, 0, 0};
+        MF_UNROLL for (int e = 0; e < 4; ++e) ltb = Tr<T>::mfma(litb00[e], B.t[0][1][e], ltb);               // (LB10)^T
+        MF_UNROLL for (int e = 0; e < 4; ++e) acc = Tr<T>::mfma(ltb[e], ltb[e], acc);
+        B.t[1][1] -= acc;
+        chol_fact_tiles2<T>(A.t[1][1], B.t[1][1], LA.t[1][1], LiTA.t[1][1], LB.t[1][1], unused, lds, ln, bad);
+        MF_UNROLL for (int e = 0; e < 4; ++e) z = Tr<T>::mfma(lta[e], lia00[e], z);                          // Z = LA10 LA00^-1
+        MF_UNROLL for (int e = 0; e < 4; ++e) h = Tr<T>::mfma(z[e], LiTA.t[1][1][e], h);                     // Z^T LA11^-T
+        LiTA.t[0][1] = -h;
+        LiTA.t[1][0] = v4{0, 0, 0, 0};
+        lds_fence();                                                                                         // both transposes in one round trip
+        tile_to_image<T>(lta, lds, ln);
+        tile_to_image<T>(ltb, lds + TS, ln);
+        lds_fence();
+        image_to_tile_t<T>(LA.t[1][0], lds, ln);
+        image_to_tile_t<T>(LB.t[1][0], lds + TS, ln);
+        lds_fence();
+        LA.t[0][1] = v4{0, 0, 0, 0};
+        LB.t[0][1] = v4{0, 0, 0, 0};
+    }
+}
 // a symmetric block from its LOWER triangle (what the reference's banded Cholesky reads): tiles ti <= tj
 template <typename T, int NT> MF_DEV void load_sym_lower(Mat<T, NT>& m, const T* __restrict__ g, int d, const Lane& ln) {
     MF_UNROLL for (int ti = 0; ti < NT; ++ti)
@@ -270,7 +350,7 @@ __global__ void __launch_bounds__(64) wave_cholesky_kernel(FactArgs<T> a) {
 template <typename T, int NT>
 __global__ void __launch_bounds__(64) wave_udl_kernel(FactArgs<T> a) {
     constexpr int TS = 16 * Tr<T>::LD;
-    __shared__ __attribute__((aligned(16))) T lds[NT * NT * TS];
+    __shared__ __attribute__((aligned(16))) T lds[(NT == 1 ? 2 : NT * NT) * TS];
     Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
     const long s = blockIdx.x, n = a.n;
     int d = a.d;
@@ -279,9 +359,10 @@ __global__ void __launch_bounds__(64) wave_udl_kernel(FactArgs<T> a) {
     const T* Sg = a.sub ? a.sub + s * (n - 1) * dd : nullptr;
     const T* Eg = a.eta ? a.eta + s * n * d : nullptr;
     bool bad = false;
-    Mat<T, NT> Dk, Sk, LiT, Li;
+    Mat<T, NT> Dk, Sk, LiT, Li, Qm;
     CV<T, NT> xk, xp;
     load_sym_lower<T, NT>(Dk, Dg + (n - 1) * dd, d, ln);
+    identity_mat<T, NT>(Qm, ln);
     Sk.zero();
     LiT.zero();
     Li.zero();
@@ -316,7 +397,14 @@ __global__ void __launch_bounds__(64) wave_udl_kernel(FactArgs<T> a) {
         phase();
         {
             Mat<T, NT> L;
-            chol_fact_mat<T, NT>(Dk, L, LiT, lds, ln, bad);
+            if (Eg) {
+                // the factor of Delta_{k+1}^-1 (the previous step's, an identity at the first) rides along in the other rows
+                Mat<T, NT> Lq;
+                chol_fact_mat2<T, NT>(Dk, Qm, L, LiT, Lq, lds, ln, bad);
+                if (k + 1 < n) store_mat<T, NT, false>(a.chol_dinv + (s * n + k + 1) * dd, Lq, d, lds, ln);
+            } else {
+                chol_fact_mat<T, NT>(Dk, L, LiT, lds, ln, bad);
+            }
             store_mat<T, NT, false>(a.o2 + (s * n + k) * dd, L, d, lds, ln);
         }
         transpose<T, NT, S_UPPER>(Li, LiT, lds, ln);
@@ -330,10 +418,7 @@ __global__ void __launch_bounds__(64) wave_udl_kernel(FactArgs<T> a) {
             cv_to_rv<T, NT>(r, w, ln);
             tn_mv<T, NT, S_LOWER>(mk, Li, r);                                          // L^-T (L^-1 x_k)
             store_cv<T, NT>(a.m_post + (s * n + k) * d, mk, d, ln);
-            Mat<T, NT> Qm, Lq, LqiT;
-            tn<T, NT, S_LOWER, S_LOWER, S_UPPER, OP_SET>(Qm, Li, Li);                  // Delta_k^-1
-            chol_fact_mat<T, NT>(Qm, Lq, LqiT, lds, ln, bad);
-            store_mat<T, NT, false>(a.chol_dinv + (s * n + k) * dd, Lq, d, lds, ln);
+            tn<T, NT, S_LOWER, S_LOWER, S_UPPER, OP_SET>(Qm, Li, Li);                  // Delta_k^-1: factored beside Delta_{k-1}
             copy_cv<T, NT>(xp, xk);
         }
         if (more) {
@@ -341,6 +426,11 @@ __global__ void __launch_bounds__(64) wave_udl_kernel(FactArgs<T> a) {
             if (Sg) Sk = Sn;
             if (Eg) copy_cv<T, NT>(xk, xn);
         }
+    }
+    if (Eg) {   // the last one has nothing left to ride beside
+        Mat<T, NT> Lq, LqiT;
+        chol_fact_mat<T, NT>(Qm, Lq, LqiT, lds, ln, bad);
+        store_mat<T, NT, false>(a.chol_dinv + s * n * dd, Lq, d, lds, ln);
     }
     if (__any(bad) && threadIdx.x == 0 && a.info) raise_info(a.info);
 }
