@@ -178,7 +178,15 @@ template <typename T> int wave_btd_udl(long B, long n, int d, const T* diag, con
                                        T* chol_dinv, int* info, hipStream_t st) {
     if (!wave_covers(d, 1) || B <= 0 || n <= 0 || !wave_serial_pays(B, n)) return -101;
     const wv::FactArgs<T> a{B, n, d, diag, sub, ut, chol_d, eta, m_post, chol_dinv, info};
-    MF_WAVE_FACT(wave_udl_kernel, a, B);
+    const dim3 grid((unsigned)B), block(64);
+    if (eta) {
+        if (d <= 16) hipLaunchKernelGGL((wv::wave_udl_kernel<T, 1, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((wv::wave_udl_kernel<T, 2, true>), grid, block, 0, st, a);
+    } else {
+        if (d <= 16) hipLaunchKernelGGL((wv::wave_udl_kernel<T, 1, false>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((wv::wave_udl_kernel<T, 2, false>), grid, block, 0, st, a);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 template <typename T> int wave_btd_diag_of_inverse(long B, long n, int d, const T* ldiag, const T* lsub, T* odiag, T* osub, hipStream_t st) {
     if (!wave_covers(d, 1) || B <= 0 || n <= 0) return -101;

@@ -1,5 +1,6 @@
-// Operators of the block-tridiagonal factor for 16 <= d <= 32 with the time axis walked SERIALLY inside a wavefront and the batch
-// spread over the chip (mf_wave.hpp's regime: hundreds of series).  The tile engine partitions these operators in time with one
+// Operators for 16 <= d <= 32 with the time axis walked SERIALLY inside a wavefront and the batch spread over the chip (mf_wave.hpp's
+// regime: hundreds of series).  In this file: solve (below; a row per lane, DPP products), then - on mf_wave.hpp's register tiles and
+// the matrix cores - cholesky, upper_diagonal_lower + the posterior chain, block_diagonal_of_inverse, marginals / covariance blocks.  The tile engine partitions these operators in time with one
 // 256-thread workgroup per chunk - built for config 5's eight series of d = 64; at d = 16, B = 512, T = 1000 its `solve` takes 8.1 ms
 // (profiles/r05_bigops_d16.txt) although a block step is two 16 x 16 matrix-vector products.
 //
@@ -347,7 +348,9 @@ __global__ void __launch_bounds__(64) wave_cholesky_kernel(FactArgs<T> a) {
 
 // upper_diagonal_lower (block_tri_diag.py:438-545) + the posterior chain's means and factors (kalman_filter.py:159-174), backwards:
 // Delta_k = D_k - S_k^T Delta_{k+1}^-1 S_k, U_k^T = Delta_{k+1}^-1 S_k, x_k = eta_k - U_k x_{k+1}, m_k = Delta_k^-1 x_k.
-template <typename T, int NT>
+// ETA: the information vector rides along (posterior chain); without it the kernel is the plain factorisation - two instantiations,
+// not one loop body with both (the longer body cost the plain one 12 %: instruction fetch)
+template <typename T, int NT, bool ETA>
 __global__ void __launch_bounds__(64) wave_udl_kernel(FactArgs<T> a) {
     constexpr int TS = 16 * Tr<T>::LD;
     __shared__ __attribute__((aligned(16))) T lds[(NT == 1 ? 2 : NT * NT) * TS];
@@ -357,7 +360,7 @@ __global__ void __launch_bounds__(64) wave_udl_kernel(FactArgs<T> a) {
     const long dd = long(d) * d;
     const T* Dg = a.diag + s * n * dd;
     const T* Sg = a.sub ? a.sub + s * (n - 1) * dd : nullptr;
-    const T* Eg = a.eta ? a.eta + s * n * d : nullptr;
+    const T* Eg = ETA ? a.eta + s * n * d : nullptr;
     bool bad = false;
     Mat<T, NT> Dk, Sk, LiT, Li, Qm;
     CV<T, NT> xk, xp;
@@ -367,7 +370,7 @@ __global__ void __launch_bounds__(64) wave_udl_kernel(FactArgs<T> a) {
     LiT.zero();
     Li.zero();
     MF_UNROLL for (int j = 0; j < NT; ++j) xk.v[j] = xp.v[j] = T(0);
-    if (Eg) load_cv<T, NT>(xk, Eg + (n - 1) * d, d, ln);
+    if constexpr (ETA) load_cv<T, NT>(xk, Eg + (n - 1) * d, d, ln);
     for (long k = n - 1; k >= 0; --k) {
         asm volatile("" : "+v"(ln.r), "+v"(ln.q));
         asm volatile("" : "+s"(d));
@@ -377,7 +380,7 @@ __global__ void __launch_bounds__(64) wave_udl_kernel(FactArgs<T> a) {
         if (more) {
             load_sym_lower<T, NT>(Dn, Dg + (k - 1) * dd, d, ln);
             if (Sg) load_mat<T, NT, S_FULL>(Sn, Sg + (k - 1) * dd, d, false, false, ln);
-            if (Eg) load_cv<T, NT>(xn, Eg + (k - 1) * d, d, ln);
+            if constexpr (ETA) load_cv<T, NT>(xn, Eg + (k - 1) * d, d, ln);
         }
         phase();
         if (coupled) {
@@ -386,7 +389,7 @@ __global__ void __launch_bounds__(64) wave_udl_kernel(FactArgs<T> a) {
             tn<T, NT, S_FULL, S_FULL, S_UPPER, OP_SUB>(Dk, U, U);                      // Delta_k
             tn<T, NT, S_LOWER, S_FULL, S_FULL, OP_SET>(Ut, Li, U);                     // U_k^T = Delta_{k+1}^-1 S_k
             store_mat<T, NT, false>(a.o1 + (s * (n - 1) + k) * dd, Ut, d, lds, ln);
-            if (Eg) {
+            if constexpr (ETA) {
                 RV<T, NT> xr;
                 CV<T, NT> t;
                 cv_to_rv<T, NT>(xr, xp, ln);
@@ -397,7 +400,7 @@ __global__ void __launch_bounds__(64) wave_udl_kernel(FactArgs<T> a) {
         phase();
         {
             Mat<T, NT> L;
-            if (Eg) {
+            if constexpr (ETA) {
                 // the factor of Delta_{k+1}^-1 (the previous step's, an identity at the first) rides along in the other rows
                 Mat<T, NT> Lq;
                 chol_fact_mat2<T, NT>(Dk, Qm, L, LiT, Lq, lds, ln, bad);
@@ -410,7 +413,7 @@ __global__ void __launch_bounds__(64) wave_udl_kernel(FactArgs<T> a) {
         transpose<T, NT, S_UPPER>(Li, LiT, lds, ln);
         if constexpr (NT == 2) Li.t[0][1] = typename Tr<T>::v4{0, 0, 0, 0};
         phase();
-        if (Eg) {
+        if constexpr (ETA) {
             RV<T, NT> r;
             CV<T, NT> w, mk;
             cv_to_rv<T, NT>(r, xk, ln);
@@ -424,10 +427,10 @@ __global__ void __launch_bounds__(64) wave_udl_kernel(FactArgs<T> a) {
         if (more) {
             Dk = Dn;
             if (Sg) Sk = Sn;
-            if (Eg) copy_cv<T, NT>(xk, xn);
+            if constexpr (ETA) copy_cv<T, NT>(xk, xn);
         }
     }
-    if (Eg) {   // the last one has nothing left to ride beside
+    if constexpr (ETA) {   // the last one has nothing left to ride beside
         Mat<T, NT> Lq, LqiT;
         chol_fact_mat<T, NT>(Qm, Lq, LqiT, lds, ln, bad);
         store_mat<T, NT, false>(a.chol_dinv + s * n * dd, Lq, d, lds, ln);
