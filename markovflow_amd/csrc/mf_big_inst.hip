@@ -78,7 +78,7 @@ size_t big_marginal_covs_ws(long B, long n, int d, int elem_size) {
 }
 // workspace of the time-partitioned factorisations (mf_bigpar_impl.hpp); chain: the posterior chain's right-hand-side maps too
 size_t big_btd_par_ws(long B, long n, int d, int chain, int elem_size) {
-    return elem_size == 4 ? big::bigpar_ws(B, n, d, chain != 0) : bigd::bigpar_ws(B, n, d, chain != 0);
+    return elem_size == 4 ? big::bigpar_ws_any(B, n, d, chain != 0) : bigd::bigpar_ws_any(B, n, d, chain != 0);
 }
 size_t big_btd_solve_ws(long Bl, long Br, long n, int d, int elem_size) {
     return elem_size == 4 ? big::bigpar_solve_ws(Bl, Br, n, d) : bigd::bigpar_solve_ws(Bl, Br, n, d);

@@ -537,6 +537,11 @@ inline size_t bigpar_ws(long B, long n, int d, bool chain) {
     const size_t blk = size_t(B) * P * d * d * sizeof(real);
     return 4 * blk + (chain ? blk + align_up_big(size_t(B) * P * d * sizeof(real)) : 0);
 }
+// (the query does not know which engine takes the call: the larger of the tile engine's and the wave kernels' partition)
+inline size_t bigpar_ws_any(long B, long n, int d, bool chain) {
+    const size_t e = bigpar_ws(B, n, d, chain), w = chain ? wave_udl_ws(B, n, d, (int)sizeof(real)) : 0;
+    return e > w ? e : w;
+}
 struct BigParWs { real *Dv, *GU, *F, *piv, *N, *a; };
 inline BigParWs bigpar_carve(void* ws, long B, long P, int d) {
     const size_t blk = size_t(B) * P * d * d;
@@ -578,7 +583,7 @@ inline int op_cholesky_par(long B, long n, int d, const real* diag, const real* 
 inline int op_udl_par(long B, long n, int d, const real* diag, const real* sub, real* ut, real* chol_d, const real* eta, real* m_post,
                       real* chol_dinv, void* ws, size_t ws_bytes, int* info, hipStream_t st) {
     if (!wave_off()) {
-        const int rc = wave_btd_udl<real>(B, n, d, diag, sub, ut, chol_d, eta, m_post, chol_dinv, info, st);
+        const int rc = wave_btd_udl<real>(B, n, d, diag, sub, ut, chol_d, eta, m_post, chol_dinv, ws, ws_bytes, info, st);
         if (rc != -101) return rc;
     }
     long P, L;

@@ -48,7 +48,9 @@ inline int wave_btd_solve(long Bl, long Br, long n, int d, const float* ldiag, c
 // Overloaded on the scalar type; defined for double and float.
 template <typename T> int wave_btd_cholesky(long B, long n, int d, const T* diag, const T* sub, T* ldiag, T* lsub, int* info, hipStream_t st);
 template <typename T> int wave_btd_udl(long B, long n, int d, const T* diag, const T* sub, T* ut, T* chol_d, const T* eta, T* m_post,
-                                       T* chol_dinv, int* info, hipStream_t st);
+                                       T* chol_dinv, void* ws, size_t ws_bytes, int* info, hipStream_t st);
+// workspace of the time-partitioned posterior chain on the wave kernels (0: not partitioned / not covered)
+size_t wave_udl_ws(long B, long n, int d, int elem_size);
 template <typename T> int wave_btd_diag_of_inverse(long B, long n, int d, const T* ldiag, const T* lsub, T* odiag, T* osub, hipStream_t st);
 // marginal means (omean | NULL), covariances and subsequent covariances (osub | NULL) of a chain of n time points
 template <typename T> int wave_ssm_marginals(long B, long n, int d, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ,

@@ -174,11 +174,52 @@ template <typename T> int wave_btd_cholesky(long B, long n, int d, const T* diag
     const wv::FactArgs<T> a{B, n, d, diag, sub, ldiag, lsub, nullptr, nullptr, nullptr, info};
     MF_WAVE_FACT(wave_cholesky_kernel, a, B);
 }
+// time partition of the posterior chain (wave_udl_up_kernel / _boundary_ / wave_udl_kernel<.., PART>): enough chunks for ~2 wavefronts
+// per SIMD over the chip, chunks of at least 16 blocks, at most 256 per series (the boundary pass walks them serially)
+void wave_udl_partition(long B, long n, int d, int elem_size, long& P, long& L) {
+    static const long force = [] { const char* e = mf_knob("MF_WAVE_UDL_CHUNKS"); return e ? std::atol(e) : 0L; }();
+    // wavefronts the chip holds at once at these kernels' registers: one tile per matrix 3 per SIMD (fp64) / 4 (fp32), 2 x 2 tiles 1 / 2
+    const long target = 1024L * (d <= 16 ? (elem_size == 8 ? 3 : 4) : (elem_size == 8 ? 1 : 2));
+    long want = force > 0 ? force : (target + B - 1) / B;
+    if (want > 256) want = 256;
+    if (want > n / 16) want = n / 16;
+    if (want < 1) want = 1;
+    L = (n + want - 1) / want;
+    P = (n + L - 1) / L;
+}
+size_t wave_udl_ws(long B, long n, int d, int elem_size) {
+    if (!wave_covers(d, 1) || B <= 0 || n <= 0) return 0;
+    long P, L;
+    wave_udl_partition(B, n, d, elem_size, P, L);
+    return P > 1 ? size_t(B) * P * (4 * size_t(d) * d + 3 * size_t(d)) * elem_size + 256 : 0;
+}
 template <typename T> int wave_btd_udl(long B, long n, int d, const T* diag, const T* sub, T* ut, T* chol_d, const T* eta, T* m_post,
-                                       T* chol_dinv, int* info, hipStream_t st) {
-    if (!wave_covers(d, 1) || B <= 0 || n <= 0 || !wave_serial_pays(B, n)) return -101;
-    const wv::FactArgs<T> a{B, n, d, diag, sub, ut, chol_d, eta, m_post, chol_dinv, info};
-    const dim3 grid((unsigned)B), block(64);
+                                       T* chol_dinv, void* ws, size_t ws_bytes, int* info, hipStream_t st) {
+    if (!wave_covers(d, 1) || B <= 0 || n <= 0) return -101;
+    wv::FactArgs<T> a{B, n, d, diag, sub, ut, chol_d, eta, m_post, chol_dinv, info};
+    const dim3 block(64);
+    long P = 1, L = n;
+    if (eta && sub) wave_udl_partition(B, n, d, (int)sizeof(T), P, L);
+    if (P > 1 && ws && ws_bytes >= wave_udl_ws(B, n, d, (int)sizeof(T))) {
+        const size_t blk = size_t(B) * P * d * d, vec = size_t(B) * P * d;
+        T* p = static_cast<T*>(ws);
+        a.P = P; a.L = L;
+        a.rDv = p; a.rGU = p + blk; a.rF = p + 2 * blk; a.bSig = p + 3 * blk;
+        a.rtv = p + 4 * blk; a.rgU = a.rtv + vec; a.bx = a.rgU + vec;
+        const dim3 chunks((unsigned)(B * P)), series((unsigned)B);
+        if (d <= 16) {
+            hipLaunchKernelGGL((wv::wave_udl_up_kernel<T, 1>), chunks, block, 0, st, a);
+            hipLaunchKernelGGL((wv::wave_udl_boundary_kernel<T, 1>), series, block, 0, st, a);
+            hipLaunchKernelGGL((wv::wave_udl_kernel<T, 1, true, true>), chunks, block, 0, st, a);
+        } else {
+            hipLaunchKernelGGL((wv::wave_udl_up_kernel<T, 2>), chunks, block, 0, st, a);
+            hipLaunchKernelGGL((wv::wave_udl_boundary_kernel<T, 2>), series, block, 0, st, a);
+            hipLaunchKernelGGL((wv::wave_udl_kernel<T, 2, true, true>), chunks, block, 0, st, a);
+        }
+        return hipGetLastError() == hipSuccess ? 0 : -1000;
+    }
+    if (!wave_serial_pays(B, n)) return -101;
+    const dim3 grid((unsigned)B);
     if (eta) {
         if (d <= 16) hipLaunchKernelGGL((wv::wave_udl_kernel<T, 1, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((wv::wave_udl_kernel<T, 2, true>), grid, block, 0, st, a);
@@ -236,9 +277,10 @@ template int wave_ssm_marginals<float>(long, long, int, const float*, const floa
                                        float*, hipStream_t);
 template int wave_btd_cholesky<double>(long, long, int, const double*, const double*, double*, double*, int*, hipStream_t);
 template int wave_btd_cholesky<float>(long, long, int, const float*, const float*, float*, float*, int*, hipStream_t);
-template int wave_btd_udl<double>(long, long, int, const double*, const double*, double*, double*, const double*, double*, double*, int*,
-                                  hipStream_t);
-template int wave_btd_udl<float>(long, long, int, const float*, const float*, float*, float*, const float*, float*, float*, int*, hipStream_t);
+template int wave_btd_udl<double>(long, long, int, const double*, const double*, double*, double*, const double*, double*, double*, void*,
+                                  size_t, int*, hipStream_t);
+template int wave_btd_udl<float>(long, long, int, const float*, const float*, float*, float*, const float*, float*, float*, void*, size_t, int*,
+                                 hipStream_t);
 template int wave_btd_diag_of_inverse<double>(long, long, int, const double*, const double*, double*, double*, hipStream_t);
 template int wave_btd_diag_of_inverse<float>(long, long, int, const float*, const float*, float*, float*, hipStream_t);
 

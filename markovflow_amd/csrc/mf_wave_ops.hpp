@@ -304,6 +304,12 @@ template <typename T> struct FactArgs {
     const T* eta;            // udl: information vector (posterior chain) or NULL
     T *m_post, *chol_dinv;   // udl with eta: Delta_k^-1 x_k and chol(Delta_k^-1)
     int* info;
+    // the posterior chain partitioned in time (wave_udl_up_kernel / wave_udl_boundary_kernel / wave_udl_kernel<.., PART>): P chunks of
+    // L blocks per series, counted from the LAST block; per (series, chunk): the reduced system the up-sweep leaves and the boundary
+    // values the emit pass starts from
+    long P, L;
+    T *rDv, *rGU, *rF, *rtv, *rgU;   // [B, P, d, d] x 3, [B, P, d] x 2
+    T *bSig, *bx;                     // [B, P, d, d], [B, P, d]: natural-order pivot Delta and x at the chunk's last (lowest) block
 };
 
 // SymmetricBlockTriDiagonal.cholesky (block_tri_diag.py:423-436): L_k = chol(D_k - W_{k-1} W_{k-1}^T), W_k = S_k L_k^-T.
@@ -350,12 +356,16 @@ __global__ void __launch_bounds__(64) wave_cholesky_kernel(FactArgs<T> a) {
 // Delta_k = D_k - S_k^T Delta_{k+1}^-1 S_k, U_k^T = Delta_{k+1}^-1 S_k, x_k = eta_k - U_k x_{k+1}, m_k = Delta_k^-1 x_k.
 // ETA: the information vector rides along (posterior chain); without it the kernel is the plain factorisation - two instantiations,
 // not one loop body with both (the longer body cost the plain one 12 %: instruction fetch)
-template <typename T, int NT, bool ETA>
+// PART: the emit pass of the time-partitioned form - wavefront (s, c) walks the blocks [k_lo, k_hi] of its chunk (chunks count from the
+// last block) and, for c > 0, starts from the boundary pivot and x of the chunk above it (wave_udl_boundary_kernel).
+template <typename T, int NT, bool ETA, bool PART = false>
 __global__ void __launch_bounds__(64) wave_udl_kernel(FactArgs<T> a) {
     constexpr int TS = 16 * Tr<T>::LD;
     __shared__ __attribute__((aligned(16))) T lds[(NT == 1 ? 2 : NT * NT) * TS];
     Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
-    const long s = blockIdx.x, n = a.n;
+    const long s = PART ? blockIdx.x / a.P : blockIdx.x, c = PART ? blockIdx.x % a.P : 0, n = a.n;
+    const long k_hi = PART ? n - 1 - c * a.L : n - 1;
+    const long k_lo = PART ? (n - (c + 1) * a.L > 0 ? n - (c + 1) * a.L : 0) : 0;
     int d = a.d;
     const long dd = long(d) * d;
     const T* Dg = a.diag + s * n * dd;
@@ -364,17 +374,28 @@ __global__ void __launch_bounds__(64) wave_udl_kernel(FactArgs<T> a) {
     bool bad = false;
     Mat<T, NT> Dk, Sk, LiT, Li, Qm;
     CV<T, NT> xk, xp;
-    load_sym_lower<T, NT>(Dk, Dg + (n - 1) * dd, d, ln);
+    load_sym_lower<T, NT>(Dk, Dg + k_hi * dd, d, ln);
     identity_mat<T, NT>(Qm, ln);
     Sk.zero();
     LiT.zero();
     Li.zero();
     MF_UNROLL for (int j = 0; j < NT; ++j) xk.v[j] = xp.v[j] = T(0);
-    if constexpr (ETA) load_cv<T, NT>(xk, Eg + (n - 1) * d, d, ln);
-    for (long k = n - 1; k >= 0; --k) {
+    if constexpr (ETA) load_cv<T, NT>(xk, Eg + k_hi * d, d, ln);
+    if constexpr (PART) {
+        if (c > 0) {   // the state the serial walk would have reached above this chunk: factor of Delta_{k_hi + 1}, x_{k_hi + 1}
+            Mat<T, NT> Sg0, L0;
+            load_sym_lower<T, NT>(Sg0, a.bSig + (s * a.P + c - 1) * dd, d, ln);
+            chol_fact_mat<T, NT>(Sg0, L0, LiT, lds, ln, bad);
+            transpose<T, NT, S_UPPER>(Li, LiT, lds, ln);
+            if constexpr (NT == 2) Li.t[0][1] = typename Tr<T>::v4{0, 0, 0, 0};
+            load_mat<T, NT, S_FULL>(Sk, Sg + k_hi * dd, d, false, false, ln);
+            if constexpr (ETA) load_cv<T, NT>(xp, a.bx + (s * a.P + c - 1) * d, d, ln);
+        }
+    }
+    for (long k = k_hi; k >= k_lo; --k) {
         asm volatile("" : "+v"(ln.r), "+v"(ln.q));
         asm volatile("" : "+s"(d));
-        const bool more = k > 0, coupled = k + 1 < n && Sg != nullptr;
+        const bool more = k > k_lo, coupled = k + 1 < n && Sg != nullptr;
         Mat<T, NT> Dn, Sn;
         CV<T, NT> xn;
         if (more) {
@@ -404,7 +425,7 @@ __global__ void __launch_bounds__(64) wave_udl_kernel(FactArgs<T> a) {
                 // the factor of Delta_{k+1}^-1 (the previous step's, an identity at the first) rides along in the other rows
                 Mat<T, NT> Lq;
                 chol_fact_mat2<T, NT>(Dk, Qm, L, LiT, Lq, lds, ln, bad);
-                if (k + 1 < n) store_mat<T, NT, false>(a.chol_dinv + (s * n + k + 1) * dd, Lq, d, lds, ln);
+                if (k < k_hi) store_mat<T, NT, false>(a.chol_dinv + (s * n + k + 1) * dd, Lq, d, lds, ln);
             } else {
                 chol_fact_mat<T, NT>(Dk, L, LiT, lds, ln, bad);
             }
@@ -433,7 +454,111 @@ __global__ void __launch_bounds__(64) wave_udl_kernel(FactArgs<T> a) {
     if constexpr (ETA) {   // the last one has nothing left to ride beside
         Mat<T, NT> Lq, LqiT;
         chol_fact_mat<T, NT>(Qm, Lq, LqiT, lds, ln, bad);
-        store_mat<T, NT, false>(a.chol_dinv + s * n * dd, Lq, d, lds, ln);
+        store_mat<T, NT, false>(a.chol_dinv + (s * n + k_lo) * dd, Lq, d, lds, ln);
+    }
+    if (__any(bad) && threadIdx.x == 0 && a.info) raise_info(a.info);
+}
+
+// ---- the posterior chain partitioned in time (hundreds of series leave half the SIMDs without a wavefront and every step's latency
+// exposed: cutting each series into P chunks multiplies the wavefronts) -------------------------------------------------------------
+// In the order the U D U^T sweep visits the blocks (from the last one down) the matrix is an ordinary block tridiagonal one whose
+// coupling of block k with its predecessor k + 1 is S_k^T.  Up-sweep: chunk c eliminates its blocks in that order with the fill-in
+// towards the block above it (the separator) carried as a spike - WaveElim, the log-likelihood's elimination state - and leaves, for
+// its LOWEST block e: Dv (pivot given the chunk's interior), F (coupling e <-> separator), GU / gU (what the interior adds to the
+// separator's pivot / right-hand side), tv (its right-hand side).  Boundary: Delta_e = Dv - F (Delta_sep + GU)^-1 F^T and
+// x_e = tv - F (Delta_sep + GU)^-1 (x_sep + gU) chunk after chunk (the quotient property of Schur complements: GU and gU are the parts
+// of the separator that the natural order does NOT have yet).  Emit: wave_udl_kernel<.., PART> from those boundary values.
+template <typename T, int NT>
+__global__ void __launch_bounds__(64) wave_udl_up_kernel(FactArgs<T> a) {
+    constexpr int TS = 16 * Tr<T>::LD;
+    __shared__ __attribute__((aligned(16))) T lds[NT * NT * TS];
+    Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
+    const long s = blockIdx.x / a.P, c = blockIdx.x % a.P, n = a.n;
+    const long k_hi = n - 1 - c * a.L, k_lo = n - (c + 1) * a.L > 0 ? n - (c + 1) * a.L : 0;
+    int d = a.d;
+    const long dd = long(d) * d;
+    const T* Dg = a.diag + s * n * dd;
+    const T* Sg = a.sub + s * (n - 1) * dd;
+    const T* Eg = a.eta + s * n * d;
+    const bool spike = c > 0;
+    WaveElim<T, NT> E;
+    E.init();
+    Mat<T, NT> Dk, Sk;
+    CV<T, NT> ek;
+    load_sym_lower<T, NT>(Dk, Dg + k_hi * dd, d, ln);
+    load_cv<T, NT>(ek, Eg + k_hi * d, d, ln);
+    if (spike) load_mat_t<T, NT>(E.X, Sg + k_hi * dd, d, ln);                       // block (k_hi, k_hi + 1) = S_{k_hi}^T
+    MF_UNROLL for (int i = 0; i < NT; ++i) MF_UNROLL for (int j = i; j < NT; ++j) E.Phi.t[i][j] = Dk.t[i][j];
+    E.t = ek;
+    for (long k = k_hi - 1; k >= k_lo; --k) {
+        asm volatile("" : "+v"(ln.r), "+v"(ln.q));
+        asm volatile("" : "+s"(d));
+        load_sym_lower<T, NT>(Dk, Dg + k * dd, d, ln);
+        load_mat<T, NT, S_FULL>(Sk, Sg + k * dd, d, false, false, ln);              // S_k: block (k + 1, k)
+        load_cv<T, NT>(ek, Eg + k * d, d, ln);
+        phase();
+        WaveFact<T, NT> f;
+        if (spike) E.template eliminate<true>(f, lds, ln); else E.template eliminate<false>(f, lds, ln);
+        phase();
+        Mat<T, NT> WT;
+        tn<T, NT, S_UPPER, S_FULL, S_FULL, OP_SET>(WT, f.LiT, Sk);                  // W^T = L^-1 S_k   (W = S_k^T L^-T)
+        phase();
+        if (spike) E.template advance<true>(f, WT, Dk, ek); else E.template advance<false>(f, WT, Dk, ek);
+    }
+    const long id = s * a.P + c;
+    store_mat<T, NT, true>(a.rDv + id * dd, E.Phi, d, lds, ln);
+    store_mat<T, NT, true>(a.rGU + id * dd, E.GU, d, lds, ln);
+    store_mat<T, NT, false>(a.rF + id * dd, E.X, d, lds, ln);
+    store_cv<T, NT>(a.rtv + id * d, E.t, d, ln);
+    store_cv<T, NT>(a.rgU + id * d, E.gU, d, ln);
+    if (__any(E.bad) && threadIdx.x == 0 && a.info) raise_info(a.info);
+}
+template <typename T, int NT>
+__global__ void __launch_bounds__(64) wave_udl_boundary_kernel(FactArgs<T> a) {
+    constexpr int TS = 16 * Tr<T>::LD;
+    __shared__ __attribute__((aligned(16))) T lds[NT * NT * TS];
+    Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
+    const long s = blockIdx.x;
+    int d = a.d;
+    const long dd = long(d) * d;
+    bool bad = false;
+    LogAcc<T> la;
+    la.init();
+    Mat<T, NT> Sig;
+    CV<T, NT> x;
+    load_sym_lower<T, NT>(Sig, a.rDv + (s * a.P) * dd, d, ln);
+    load_cv<T, NT>(x, a.rtv + (s * a.P) * d, d, ln);
+    store_mat<T, NT, true>(a.bSig + (s * a.P) * dd, Sig, d, lds, ln);
+    store_cv<T, NT>(a.bx + (s * a.P) * d, x, d, ln);
+    for (long c = 1; c < a.P; ++c) {
+        const long id = s * a.P + c;
+        Mat<T, NT> G, Dv, FT, LiT, Y;
+        CV<T, NT> g, tv, u, t;
+        load_sym_lower<T, NT>(G, a.rGU + id * dd, d, ln);
+        load_sym_lower<T, NT>(Dv, a.rDv + id * dd, d, ln);
+        load_mat_t<T, NT>(FT, a.rF + id * dd, d, ln);
+        load_cv<T, NT>(g, a.rgU + id * d, d, ln);
+        load_cv<T, NT>(tv, a.rtv + id * d, d, ln);
+        // (the padded diagonal of both summands is one: take it once)
+        MF_UNROLL for (int i = 0; i < NT; ++i)
+            MF_UNROLL for (int j = i; j < NT; ++j)
+                MF_UNROLL for (int e = 0; e < 4; ++e) {
+                    const int row = 16 * i + Tr<T>::row(ln.q, e), col = 16 * j + ln.r;
+                    Sig.t[i][j][e] += (row >= d && row == col) ? T(0) : G.t[i][j][e];
+                }
+        chol_inv_mat<T, NT>(Sig, LiT, lds, ln, la, bad);                              // (Delta_sep + GU)^-1 = LiT Li
+        tn<T, NT, S_UPPER, S_FULL, S_FULL, OP_SET>(Y, LiT, FT);                       // Li F^T
+        MF_UNROLL for (int i = 0; i < NT; ++i) MF_UNROLL for (int j = i; j < NT; ++j) Sig.t[i][j] = Dv.t[i][j];
+        tn<T, NT, S_FULL, S_FULL, S_UPPER, OP_SUB>(Sig, Y, Y);                        // Delta_e = Dv - F (.)^-1 F^T
+        MF_UNROLL for (int j = 0; j < NT; ++j) x.v[j] += g.v[j];
+        RV<T, NT> r;
+        cv_to_rv<T, NT>(r, x, ln);
+        tn_mv<T, NT, S_UPPER>(u, LiT, r);                                             // Li (x_sep + gU)
+        cv_to_rv<T, NT>(r, u, ln);
+        tn_mv<T, NT, S_FULL>(t, Y, r);                                                // F Li^T (.)
+        MF_UNROLL for (int j = 0; j < NT; ++j) x.v[j] = tv.v[j] - t.v[j];
+        store_mat<T, NT, true>(a.bSig + id * dd, Sig, d, lds, ln);
+        store_cv<T, NT>(a.bx + id * d, x, d, ln);
     }
     if (__any(bad) && threadIdx.x == 0 && a.info) raise_info(a.info);
 }

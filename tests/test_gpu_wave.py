@@ -226,7 +226,10 @@ def test_wave_cholesky_reports_a_matrix_that_is_not_positive_definite(rng):
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
-@pytest.mark.parametrize("d,m,bsz,t", [(16, 1, 70, 12), (24, 2, 3, 40), (32, 1, 2, 25)])
+@pytest.mark.parametrize("d,m,bsz,t", [(16, 1, 70, 12), (24, 2, 3, 40), (32, 1, 2, 25),
+                                       # chains long enough for the time partition of the sweep (chunks of >= 16 blocks: up-sweep with
+                                       # a spike, boundary pass, emit - csrc/mf_wave_ops.hpp), ragged last chunks
+                                       (16, 1, 3, 100), (17, 3, 70, 67), (32, 2, 2, 131), (16, 4, 1, 700)])
 def test_wave_posterior_chain_against_the_oracle(rng, dtype, d, m, bsz, t):
     """kalman_filter.py:159-174: the posterior state space model through precision -> upper_diagonal_lower with the information
     vector riding along (means, Cholesky factors of the conditional covariances)."""
