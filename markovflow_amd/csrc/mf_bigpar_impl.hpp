@@ -539,7 +539,7 @@ inline size_t bigpar_ws(long B, long n, int d, bool chain) {
 }
 // (the query does not know which engine takes the call: the larger of the tile engine's and the wave kernels' partition)
 inline size_t bigpar_ws_any(long B, long n, int d, bool chain) {
-    const size_t e = bigpar_ws(B, n, d, chain), w = chain ? wave_udl_ws(B, n, d, (int)sizeof(real)) : 0;
+    const size_t e = bigpar_ws(B, n, d, chain), w = wave_udl_ws(B, n, d, (int)sizeof(real));
     return e > w ? e : w;
 }
 struct BigParWs { real *Dv, *GU, *F, *piv, *N, *a; };
@@ -563,7 +563,7 @@ inline bool bigpar_pivots(long B, long n, int d, long P, long L, const real* dia
 inline int op_cholesky_par(long B, long n, int d, const real* diag, const real* sub, real* ldiag, real* lsub, void* ws, size_t ws_bytes,
                            int* info, hipStream_t st) {
     if (!wave_off()) {   // 16 <= d <= 32, many series: one wavefront per series on register tiles (mf_wave_ops.hpp)
-        const int rc = wave_btd_cholesky<real>(B, n, d, diag, sub, ldiag, lsub, info, st);
+        const int rc = wave_btd_cholesky<real>(B, n, d, diag, sub, ldiag, lsub, ws, ws_bytes, info, st);
         if (rc != -101) return rc;
     }
     long P, L;

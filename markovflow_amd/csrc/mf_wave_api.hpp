@@ -46,7 +46,8 @@ inline int wave_btd_solve(long Bl, long Br, long n, int d, const float* ldiag, c
 }
 // mf_wave_inst.hip: the factorisations with one wavefront per series walking the time axis (mf_wave_ops.hpp); -101: not covered.
 // Overloaded on the scalar type; defined for double and float.
-template <typename T> int wave_btd_cholesky(long B, long n, int d, const T* diag, const T* sub, T* ldiag, T* lsub, int* info, hipStream_t st);
+template <typename T> int wave_btd_cholesky(long B, long n, int d, const T* diag, const T* sub, T* ldiag, T* lsub, void* ws, size_t ws_bytes,
+                                            int* info, hipStream_t st);
 template <typename T> int wave_btd_udl(long B, long n, int d, const T* diag, const T* sub, T* ut, T* chol_d, const T* eta, T* m_post,
                                        T* chol_dinv, void* ws, size_t ws_bytes, int* info, hipStream_t st);
 // workspace of the time-partitioned posterior chain on the wave kernels (0: not partitioned / not covered)

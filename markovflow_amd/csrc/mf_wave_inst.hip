@@ -164,11 +164,35 @@ inline bool wave_serial_pays(long B, long n) { return B >= 64 || n <= 256; }
         else hipLaunchKernelGGL((wv::KERNEL<T, 2>), dim3((unsigned)(WAVES)), dim3(64), 0, st, ARGS);                     \
         return hipGetLastError() == hipSuccess ? 0 : -1000;                                                            \
     } while (0)
-template <typename T> int wave_btd_cholesky(long B, long n, int d, const T* diag, const T* sub, T* ldiag, T* lsub, int* info, hipStream_t st) {
+void wave_udl_partition(long B, long n, int d, int elem_size, long& P, long& L);
+size_t wave_udl_ws(long B, long n, int d, int elem_size);
+template <typename T> int wave_btd_cholesky(long B, long n, int d, const T* diag, const T* sub, T* ldiag, T* lsub, void* ws, size_t ws_bytes,
+                                            int* info, hipStream_t st) {
     if (!wave_covers(d, 1) || B <= 0 || n <= 0) return -101;
     if (!sub) {   // block diagonal: every block is its own series
         const wv::FactArgs<T> a{B * n, 1, d, diag, nullptr, ldiag, nullptr, nullptr, nullptr, nullptr, info};
         MF_WAVE_FACT(wave_cholesky_kernel, a, B * n);
+    }
+    long P = 1, L = n;
+    wave_udl_partition(B, n, d, (int)sizeof(T), P, L);
+    if (P > 1 && ws && ws_bytes >= wave_udl_ws(B, n, d, (int)sizeof(T))) {
+        // partitioned in time: up-sweep with a spike, boundary pivots, emit (the scheme of the posterior chain below)
+        wv::FactArgs<T> a{B, n, d, diag, sub, ldiag, lsub, nullptr, nullptr, nullptr, info};
+        const size_t blk = size_t(B) * P * d * d;
+        T* p = static_cast<T*>(ws);
+        a.P = P; a.L = L;
+        a.rDv = p; a.rGU = p + blk; a.rF = p + 2 * blk; a.bSig = p + 3 * blk;
+        const dim3 chunks((unsigned)(B * P)), series((unsigned)B), block(64);
+        if (d <= 16) {
+            hipLaunchKernelGGL((wv::wave_chol_up_kernel<T, 1>), chunks, block, 0, st, a);
+            hipLaunchKernelGGL((wv::wave_udl_boundary_kernel<T, 1>), series, block, 0, st, a);
+            hipLaunchKernelGGL((wv::wave_cholesky_kernel<T, 1, true>), chunks, block, 0, st, a);
+        } else {
+            hipLaunchKernelGGL((wv::wave_chol_up_kernel<T, 2>), chunks, block, 0, st, a);
+            hipLaunchKernelGGL((wv::wave_udl_boundary_kernel<T, 2>), series, block, 0, st, a);
+            hipLaunchKernelGGL((wv::wave_cholesky_kernel<T, 2, true>), chunks, block, 0, st, a);
+        }
+        return hipGetLastError() == hipSuccess ? 0 : -1000;
     }
     if (!wave_serial_pays(B, n)) return -101;
     const wv::FactArgs<T> a{B, n, d, diag, sub, ldiag, lsub, nullptr, nullptr, nullptr, info};
@@ -275,8 +299,8 @@ template int wave_ssm_marginals<double>(long, long, int, const double*, const do
                                         double*, double*, hipStream_t);
 template int wave_ssm_marginals<float>(long, long, int, const float*, const float*, const float*, const float*, const float*, float*, float*,
                                        float*, hipStream_t);
-template int wave_btd_cholesky<double>(long, long, int, const double*, const double*, double*, double*, int*, hipStream_t);
-template int wave_btd_cholesky<float>(long, long, int, const float*, const float*, float*, float*, int*, hipStream_t);
+template int wave_btd_cholesky<double>(long, long, int, const double*, const double*, double*, double*, void*, size_t, int*, hipStream_t);
+template int wave_btd_cholesky<float>(long, long, int, const float*, const float*, float*, float*, void*, size_t, int*, hipStream_t);
 template int wave_btd_udl<double>(long, long, int, const double*, const double*, double*, double*, const double*, double*, double*, void*,
                                   size_t, int*, hipStream_t);
 template int wave_btd_udl<float>(long, long, int, const float*, const float*, float*, float*, const float*, float*, float*, void*, size_t, int*,

@@ -314,24 +314,36 @@ template <typename T> struct FactArgs {
 
 // SymmetricBlockTriDiagonal.cholesky (block_tri_diag.py:423-436): L_k = chol(D_k - W_{k-1} W_{k-1}^T), W_k = S_k L_k^-T.
 // The wave keeps W^T: D_k - (W^T)^T (W^T) and W_k^T = (LiT)^T S_k^T are both P^T Q products.
-template <typename T, int NT>
+// PART: the emit pass of the time-partitioned form (wave_chol_up_kernel, wave_udl_boundary_kernel): wavefront (s, c) walks the blocks
+// [c L, (c + 1) L) and, for c > 0, starts from the natural-order pivot of the block in front of its chunk.
+template <typename T, int NT, bool PART = false>
 __global__ void __launch_bounds__(64) wave_cholesky_kernel(FactArgs<T> a) {
     constexpr int TS = 16 * Tr<T>::LD;
     __shared__ __attribute__((aligned(16))) T lds[NT * NT * TS];
     Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
-    const long s = blockIdx.x, n = a.n;
+    const long s = PART ? blockIdx.x / a.P : blockIdx.x, c = PART ? blockIdx.x % a.P : 0, n = a.n;
+    const long k_lo = PART ? c * a.L : 0, k_hi = PART ? ((c + 1) * a.L < n ? (c + 1) * a.L : n) - 1 : n - 1;
     int d = a.d;
     const long dd = long(d) * d;
     const T* Dg = a.diag + s * n * dd;
     const T* Sg = a.sub ? a.sub + s * (n - 1) * dd : nullptr;
     bool bad = false;
     Mat<T, NT> Dk, WT;
-    load_sym_lower<T, NT>(Dk, Dg, d, ln);
+    load_sym_lower<T, NT>(Dk, Dg + k_lo * dd, d, ln);
     WT.zero();
-    for (long k = 0; k < n; ++k) {
+    if constexpr (PART) {
+        if (c > 0) {   // W^T of the block in front of the chunk, from its natural-order pivot
+            Mat<T, NT> Sg0, L0, LiT0, ST0;
+            load_sym_lower<T, NT>(Sg0, a.bSig + (s * a.P + c - 1) * dd, d, ln);
+            load_mat_t<T, NT>(ST0, Sg + (k_lo - 1) * dd, d, ln);
+            chol_fact_mat<T, NT>(Sg0, L0, LiT0, lds, ln, bad);
+            tn<T, NT, S_UPPER, S_FULL, S_FULL, OP_SET>(WT, LiT0, ST0);
+        }
+    }
+    for (long k = k_lo; k <= k_hi; ++k) {
         asm volatile("" : "+v"(ln.r), "+v"(ln.q));
         asm volatile("" : "+s"(d));
-        const bool more = k + 1 < n, coupled = more && Sg != nullptr;
+        const bool more = k < k_hi, coupled = k + 1 < n && Sg != nullptr;
         Mat<T, NT> Dn, ST;
         if (coupled) load_mat_t<T, NT>(ST, Sg + k * dd, d, ln);
         if (more) load_sym_lower<T, NT>(Dn, Dg + (k + 1) * dd, d, ln);
@@ -350,6 +362,48 @@ __global__ void __launch_bounds__(64) wave_cholesky_kernel(FactArgs<T> a) {
         if (more) Dk = Dn;
     }
     if (__any(bad) && threadIdx.x == 0 && a.info) raise_info(a.info);
+}
+// up-sweep of the time-partitioned Cholesky factorisation (natural order: chunk c = blocks [c L, (c + 1) L), the block in front of it
+// is its separator; the scheme of wave_udl_up_kernel below, no right-hand side): Dv, GU, F per chunk
+template <typename T, int NT>
+__global__ void __launch_bounds__(64) wave_chol_up_kernel(FactArgs<T> a) {
+    constexpr int TS = 16 * Tr<T>::LD;
+    __shared__ __attribute__((aligned(16))) T lds[NT * NT * TS];
+    Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
+    const long s = blockIdx.x / a.P, c = blockIdx.x % a.P, n = a.n;
+    const long k_lo = c * a.L, k_hi = ((c + 1) * a.L < n ? (c + 1) * a.L : n) - 1;
+    int d = a.d;
+    const long dd = long(d) * d;
+    const T* Dg = a.diag + s * n * dd;
+    const T* Sg = a.sub + s * (n - 1) * dd;
+    const bool spike = c > 0;
+    WaveElim<T, NT> E;
+    E.init();
+    Mat<T, NT> Dk, ST;
+    CV<T, NT> zero;
+    MF_UNROLL for (int j = 0; j < NT; ++j) zero.v[j] = T(0);
+    load_sym_lower<T, NT>(Dk, Dg + k_lo * dd, d, ln);
+    if (spike) load_mat<T, NT, S_FULL>(E.X, Sg + (k_lo - 1) * dd, d, false, false, ln);   // block (k_lo, k_lo - 1)
+    MF_UNROLL for (int i = 0; i < NT; ++i) MF_UNROLL for (int j = i; j < NT; ++j) E.Phi.t[i][j] = Dk.t[i][j];
+    for (long k = k_lo + 1; k <= k_hi; ++k) {
+        asm volatile("" : "+v"(ln.r), "+v"(ln.q));
+        asm volatile("" : "+s"(d));
+        load_sym_lower<T, NT>(Dk, Dg + k * dd, d, ln);
+        load_mat_t<T, NT>(ST, Sg + (k - 1) * dd, d, ln);                               // S_{k-1}^T: block (k - 1, k)
+        phase();
+        WaveFact<T, NT> f;
+        if (spike) E.template eliminate<true>(f, lds, ln); else E.template eliminate<false>(f, lds, ln);
+        phase();
+        Mat<T, NT> WT;
+        tn<T, NT, S_UPPER, S_FULL, S_FULL, OP_SET>(WT, f.LiT, ST);                     // W^T = L^-1 S_{k-1}^T
+        phase();
+        if (spike) E.template advance<true>(f, WT, Dk, zero); else E.template advance<false>(f, WT, Dk, zero);
+    }
+    const long id = s * a.P + c;
+    store_mat<T, NT, true>(a.rDv + id * dd, E.Phi, d, lds, ln);
+    store_mat<T, NT, true>(a.rGU + id * dd, E.GU, d, lds, ln);
+    store_mat<T, NT, false>(a.rF + id * dd, E.X, d, lds, ln);
+    if (__any(E.bad) && threadIdx.x == 0 && a.info) raise_info(a.info);
 }
 
 // upper_diagonal_lower (block_tri_diag.py:438-545) + the posterior chain's means and factors (kalman_filter.py:159-174), backwards:
@@ -526,10 +580,12 @@ __global__ void __launch_bounds__(64) wave_udl_boundary_kernel(FactArgs<T> a) {
     la.init();
     Mat<T, NT> Sig;
     CV<T, NT> x;
+    const bool rhs = a.eta != nullptr;                     // (the Cholesky factorisation has no right-hand side)
     load_sym_lower<T, NT>(Sig, a.rDv + (s * a.P) * dd, d, ln);
-    load_cv<T, NT>(x, a.rtv + (s * a.P) * d, d, ln);
+    MF_UNROLL for (int j = 0; j < NT; ++j) x.v[j] = T(0);
+    if (rhs) load_cv<T, NT>(x, a.rtv + (s * a.P) * d, d, ln);
     store_mat<T, NT, true>(a.bSig + (s * a.P) * dd, Sig, d, lds, ln);
-    store_cv<T, NT>(a.bx + (s * a.P) * d, x, d, ln);
+    if (rhs) store_cv<T, NT>(a.bx + (s * a.P) * d, x, d, ln);
     for (long c = 1; c < a.P; ++c) {
         const long id = s * a.P + c;
         Mat<T, NT> G, Dv, FT, LiT, Y;
@@ -537,8 +593,11 @@ __global__ void __launch_bounds__(64) wave_udl_boundary_kernel(FactArgs<T> a) {
         load_sym_lower<T, NT>(G, a.rGU + id * dd, d, ln);
         load_sym_lower<T, NT>(Dv, a.rDv + id * dd, d, ln);
         load_mat_t<T, NT>(FT, a.rF + id * dd, d, ln);
-        load_cv<T, NT>(g, a.rgU + id * d, d, ln);
-        load_cv<T, NT>(tv, a.rtv + id * d, d, ln);
+        MF_UNROLL for (int j = 0; j < NT; ++j) g.v[j] = tv.v[j] = T(0);
+        if (rhs) {
+            load_cv<T, NT>(g, a.rgU + id * d, d, ln);
+            load_cv<T, NT>(tv, a.rtv + id * d, d, ln);
+        }
         // (the padded diagonal of both summands is one: take it once)
         MF_UNROLL for (int i = 0; i < NT; ++i)
             MF_UNROLL for (int j = i; j < NT; ++j)
@@ -558,7 +617,7 @@ __global__ void __launch_bounds__(64) wave_udl_boundary_kernel(FactArgs<T> a) {
         tn_mv<T, NT, S_FULL>(t, Y, r);                                                // F Li^T (.)
         MF_UNROLL for (int j = 0; j < NT; ++j) x.v[j] = tv.v[j] - t.v[j];
         store_mat<T, NT, true>(a.bSig + id * dd, Sig, d, lds, ln);
-        store_cv<T, NT>(a.bx + id * d, x, d, ln);
+        if (rhs) store_cv<T, NT>(a.bx + id * d, x, d, ln);
     }
     if (__any(bad) && threadIdx.x == 0 && a.info) raise_info(a.info);
 }

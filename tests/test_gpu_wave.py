@@ -180,7 +180,9 @@ def test_wave_solve_round_trip_at_the_operator_bench_shape(rng):
 # ---- cholesky / upper_diagonal_lower / block_diagonal_of_inverse, one wavefront per series (csrc/mf_wave_ops.hpp) ------------------
 @pytest.mark.parametrize("dtype,d", [(torch.float64, 16), (torch.float64, 17), (torch.float64, 24), (torch.float64, 31),
                                      (torch.float64, 32), (torch.float32, 16), (torch.float32, 21), (torch.float32, 32)])
-@pytest.mark.parametrize("bsz,n,has_sub", [(1, 1, False), (3, 2, True), (2, 37, True), (70, 9, True), (2, 5, False)])
+@pytest.mark.parametrize("bsz,n,has_sub", [(1, 1, False), (3, 2, True), (2, 37, True), (70, 9, True), (2, 5, False),
+                                           # long enough for the time partition of the Cholesky factorisation (chunks of >= 16 blocks)
+                                           (3, 100, True), (70, 67, True), (1, 500, True)])
 def test_wave_factorisations_against_the_oracle(rng, dtype, d, bsz, n, has_sub):
     """block_tri_diag.py:423-436 (cholesky), :438-545 (upper_diagonal_lower), :318-337 (block diagonal and sub-diagonal of the
     inverse): every block of every series against the oracle's serial recursions; one block, a block-diagonal matrix, more series
