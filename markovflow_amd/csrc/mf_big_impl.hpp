@@ -927,9 +927,10 @@ template <int DP> int launch_big(long B, long Tn, int d, int m, const real* mu0,
 inline long wave_target(int d) {
     static const bool off = [] { const char* e = mf_knob("MF_WAVE"); return e && e[0] == '0'; }();
     if (off || !wave_covers(d, 1)) return 0;
-    // (one tile per matrix: two rounds of wavefronts - the first chunk of a series carries no spike and finishes early, a second
-    // round evens that out: 1.85 -> 1.75 ms at d = 16, B = 512, T = 1000; 2 x 2 tiles: one round, more chunks only add spikes)
-    return 256L * 4 * wave_waves_per_simd(d, (int)sizeof(real)) * (d <= 16 ? 2 : 1);
+    // (one tile per matrix in fp32: two rounds of wavefronts - the first chunk of a series carries no spike and finishes early, a
+    // second round evens that out: 1.10 -> 1.05 ms at d = 16, B = 512, T = 1000; in fp64, since the paired pass, one round is as
+    // good or better: 1.555 against 1.58 ms; 2 x 2 tiles: one round, more chunks only add spikes)
+    return 256L * 4 * wave_waves_per_simd(d, (int)sizeof(real)) * (d <= 16 && sizeof(real) == 4 ? 2 : 1);
 }
 inline size_t kf_loglik_ws_for(long B, long Tn, int d, long chunks, long wtarget) {
     long P, L;
