@@ -511,19 +511,25 @@ inline long cov_chunks(long B, long n) {
     while (P > 1 && (n - 1) / P < 8) --P;
     return P;
 }
-inline size_t marginal_covs_ws(long B, long n, int d) {
+inline size_t marginal_covs_ws_engine(long B, long n, int d) {
     const long P = cov_chunks(B, n);
     return P > 1 ? (3 * size_t(B) * P * d * d + 2 * size_t(B) * P * d) * sizeof(real) : 0;
+}
+// (the query does not know which engine takes the call: the larger of the tile engine's and the wave kernels' partition)
+inline size_t marginal_covs_ws(long B, long n, int d) {
+    const size_t e = marginal_covs_ws_engine(B, n, d), w = wave_marg_ws(B, n, d, (int)sizeof(real));
+    return e > w ? e : w;
 }
 // mu0, b, omean all NULL: covariances only
 inline int op_marginal_covs(long B, long n, int d, const real* mu0, const real* cholP0, const real* A, const real* b,
                             const real* cholQ, real* omean, real* ocov, real* osub, void* ws, size_t ws_bytes, hipStream_t st) {
     if (!wave_off()) {   // 16 <= d <= 32, many series: one wavefront per series walks the forward recursion (mf_wave_ops.hpp)
-        const int rc = wave_ssm_marginals<real>(B, n, d, omean ? mu0 : nullptr, cholP0, A, omean ? b : nullptr, cholQ, omean, ocov, osub, st);
+        const int rc = wave_ssm_marginals<real>(B, n, d, omean ? mu0 : nullptr, cholP0, A, omean ? b : nullptr, cholQ, omean, ocov, osub, ws,
+                                                ws_bytes, st);
         if (rc != -101) return rc;
     }
     long P = cov_chunks(B, n);
-    if (P > 1 && (ws == nullptr || ws_bytes < marginal_covs_ws(B, n, d))) P = 1;
+    if (P > 1 && (ws == nullptr || ws_bytes < marginal_covs_ws_engine(B, n, d))) P = 1;
     const long L = (n - 1 + P - 1) / P;
     P = (n - 1 + L - 1) / L;                                   // no empty chunks
     real* wsM = static_cast<real*>(ws);

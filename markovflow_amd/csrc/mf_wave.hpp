@@ -493,7 +493,7 @@ template <typename T, int NT> struct WaveElim {
         phase();
         after_factor<SPIKE>(f, ln);
     }
-    // ... with f.LiT already in place (the multi-chunk kernel factors the pivots of its chunks side by side)
+    // ... with f.LiT already in place (the paired pass of wave_kf_pair_kernel factors the pivot beside the next chol(Q))
     template <bool SPIKE> MF_DEV void after_factor(WaveFact<T, NT>& f, const Lane& ln) {
         RV<T, NT> t_rv;
         cv_to_rv<T, NT>(t_rv, t, ln);
@@ -1099,177 +1099,6 @@ __global__ void __launch_bounds__(64) wave_ssm_precision_kernel(WvArgs<T> a, T* 
     store_mat<T, NT, true, EX>(diag + id * dd, Dn, d, lds, ln);
     if (eta) store_cv<T, NT>(eta + id * d, rn, d, ln);
     (void)bad;
-}
-
-// ---- NC chunks per wavefront (one tile per matrix) --------------------------------------------------------------------------
-// At d <= 16 a step is bound by vector-instruction issue, and two thirds of its ~1 050 vector instructions are the two diagonal-tile
-// factorisations, which all four 16-lane rows of the wavefront run redundantly.  Here a wavefront carries NC = 2 or 4
-// chunks: their matrix products, vector operations and loads run one chunk after the other on the whole wavefront, but the
-// factorisations of all NC chunks run SIDE BY SIDE in the rows (chol_inv_tiles / tri_inv_tiles with NTL = NC) - the same instruction
-// stream as for one chunk.  Chunks that have nothing to factor in a step (seed step of a spike, chunk already finished) hand in an
-// identity tile.  Same arithmetic per chunk, same reduced system, as wave_kf_chunk_kernel.
-template <typename T, int M, int WPE, bool EX, int NC>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) wave_kf_multi_kernel(WvArgs<T> a, RedSys<T> out) {
-    constexpr int NT = 1;
-    using v4 = typename Tr<T>::v4;
-    __shared__ __attribute__((aligned(16))) T lds[NC * 16 * Tr<T>::LD];
-    Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
-    int d = EX ? 16 : a.d;
-    const int m = a.m;
-    const long nt = a.Tn - 1, total = a.B * a.P, dd = long(d) * d;
-    long id[NC], sr[NC], tau0[NC], len[NC];
-    bool valid[NC], spike[NC];
-    long maxlen = 0;
-    MF_UNROLL for (int ci = 0; ci < NC; ++ci) {
-        const long raw = (long)blockIdx.x * NC + ci;
-        valid[ci] = raw < total;
-        id[ci] = valid[ci] ? raw : total - 1;
-        sr[ci] = id[ci] / a.P;
-        const long c = id[ci] % a.P;
-        tau0[ci] = c * a.L;
-        long l = nt - tau0[ci];
-        if (l > a.L) l = a.L;
-        if (l < 0 || !valid[ci]) l = 0;
-        len[ci] = l;
-        spike[ci] = c > 0;
-        if (l > maxlen) maxlen = l;
-    }
-    WaveElim<T, NT> E[NC];
-    LogAcc<T> laC, laL;                       // per LANE: the lane's own chunk (rows [ci * 4 / NC, (ci + 1) * 4 / NC))
-    laC.init();
-    laL.init();
-    bool bad = false;
-    T acc_ww[NC], acc_yry[NC];
-    T Ri[M][M];
-    if (!a.rinv_per_step) load_rinv<T, M>(Ri, a.Rinv, m);
-    Mat<T, NT> Cn[NC];
-    MF_UNROLL for (int ci = 0; ci < NC; ++ci) { E[ci].init(); acc_ww[ci] = T(0); acc_yry[ci] = T(0); }
-
-    // (everything a step computes per chunk is declared INSIDE the step: values assigned and used under `this chunk is active`
-    // would otherwise be carried around the loop on the other path - ~60 registers per chunk)
-    {   // block 0 of the chunks that start their series: the prior
-        Mat<T, NT> Dn[NC];
-        CV<T, NT> rn[NC], mv_cv[NC];
-        RV<T, NT> mv_rv[NC];
-        ObsRows<T, NT, M> ob[NC];
-        v4 cin[NC], cout[NC];
-        bool any0 = false;
-        MF_UNROLL for (int ci = 0; ci < NC; ++ci) {
-            cin[ci] = identity_tile<T>(ln);
-            if (valid[ci] && !spike[ci]) {
-                any0 = true;
-                Mat<T, NT> C0;
-                load_mat<T, NT, S_LOWER, EX>(C0, a.cholP0 + sr[ci] * dd, d, true, true, ln);
-                cin[ci] = C0.t[0][0];
-                load_rv<T, NT>(mv_rv[ci], a.mu0 + sr[ci] * d, d, ln);
-                load_cv<T, NT>(mv_cv[ci], a.mu0 + sr[ci] * d, d, ln);
-                ob[ci].load(a.H + (sr[ci] * a.Tn) * m * d, a.y + (sr[ci] * a.Tn) * m, d, m, ln);
-            }
-        }
-        if (any0) {
-            tri_inv_tiles<T, NC, false>(cin, cout, lds, ln, laC, bad);
-            MF_UNROLL for (int ci = 0; ci < NC; ++ci)
-                if (valid[ci] && !spike[ci]) {
-                    Mat<T, NT> Ci;
-                    Ci.t[0][0] = cout[ci];
-                    tn<T, NT, S_LOWER, S_LOWER, S_UPPER, OP_SET>(Dn[ci], Ci, Ci);
-                    tn_mv<T, NT, S_FULL>(rn[ci], Dn[ci], mv_rv[ci]);
-                    acc_ww[ci] += dot_cv<T, NT>(rn[ci], mv_cv[ci]);
-                    if (a.rinv_per_step) load_rinv<T, M>(Ri, a.Rinv + (sr[ci] * a.Tn) * m * m, m);
-                    acc_yry[ci] += obs_apply<T, NT, M>(ob[ci], Ri, Dn[ci], rn[ci]);
-                    E[ci].Phi.t[0][0] = Dn[ci].t[0][0];
-                    E[ci].t = rn[ci];
-                }
-        }
-    }
-    MF_UNROLL for (int ci = 0; ci < NC; ++ci) {
-        Cn[ci].t[0][0] = identity_tile<T>(ln);
-        if (len[ci] > 0) load_mat<T, NT, S_LOWER, EX>(Cn[ci], a.cholQ + (sr[ci] * nt + tau0[ci]) * dd, d, true, true, ln);
-    }
-    for (long j = 0; j < maxlen; ++j) {
-        asm volatile("" : "+v"(ln.r), "+v"(ln.q));
-        if constexpr (!EX) asm volatile("" : "+s"(d));
-        v4 cin[NC], cit[NC], pin[NC], lit[NC];
-        Mat<T, NT> Am[NC], Dn[NC], S[NC];
-        CV<T, NT> rn[NC], mv_cv[NC], btw[NC];
-        RV<T, NT> mv_rv[NC], rn0_rv[NC];
-        ObsRows<T, NT, M> ob[NC];
-        // the transition and the observation rows of chunk ci: issued one chunk ahead of their use (all of them up front would sit in
-        // registers across the factorisation of the chol(Q) tiles: scratch)
-        auto fetch = [&](int ci) {
-            if (j < len[ci]) {
-                const long tau = tau0[ci] + j, blk = tau + 1;
-                load_mat<T, NT, S_FULL, EX>(Am[ci], a.A + (sr[ci] * nt + tau) * dd, d, false, false, ln);
-                load_rv<T, NT>(mv_rv[ci], a.b + (sr[ci] * nt + tau) * d, d, ln);
-                load_cv<T, NT>(mv_cv[ci], a.b + (sr[ci] * nt + tau) * d, d, ln);
-                ob[ci].load(a.H + (sr[ci] * a.Tn + blk) * m * d, a.y + (sr[ci] * a.Tn + blk) * m, d, m, ln);
-            }
-        };
-        MF_UNROLL for (int ci = 0; ci < NC; ++ci) {
-            const bool act = j < len[ci];
-            cin[ci] = act ? Cn[ci].t[0][0] : identity_tile<T>(ln);
-            if (act) {
-                const long tau = tau0[ci] + j;
-                const long tn1 = (j + 1 < len[ci]) ? tau + 1 : tau;
-                load_mat<T, NT, S_LOWER, EX>(Cn[ci], a.cholQ + (sr[ci] * nt + tn1) * dd, d, true, true, ln);
-            }
-        }
-        fetch(0);
-        tri_inv_tiles<T, NC, false>(cin, cit, lds, ln, laC, bad);
-        phase();
-        MF_UNROLL for (int ci = 0; ci < NC; ++ci) {
-            pin[ci] = identity_tile<T>(ln);
-            if (ci + 1 < NC) fetch(ci + 1);
-            if (j < len[ci]) {
-                const long blk = tau0[ci] + j + 1;
-                {
-                    Mat<T, NT> Ci;
-                    Ci.t[0][0] = cit[ci];
-                    tn<T, NT, S_LOWER, S_LOWER, S_UPPER, OP_SET>(Dn[ci], Ci, Ci);
-                }
-                tn_mv<T, NT, S_FULL>(rn[ci], Dn[ci], mv_rv[ci]);
-                acc_ww[ci] += dot_cv<T, NT>(rn[ci], mv_cv[ci]);
-                cv_to_rv<T, NT>(rn0_rv[ci], rn[ci], ln);
-                tn<T, NT, S_FULL, S_FULL, S_FULL, OP_NEG>(S[ci], Dn[ci], Am[ci]);
-                tn_mv<T, NT, S_FULL>(btw[ci], Am[ci], rn0_rv[ci]);
-                if (a.rinv_per_step) load_rinv<T, M>(Ri, a.Rinv + (sr[ci] * a.Tn + blk) * m * m, m);
-                acc_yry[ci] += obs_apply<T, NT, M>(ob[ci], Ri, Dn[ci], rn[ci]);
-                if (j == 0 && spike[ci]) {
-                    tn<T, NT, S_FULL, S_FULL, S_UPPER, OP_NEG>(E[ci].GU, Am[ci], S[ci]);
-                    E[ci].X = S[ci];
-                    E[ci].gU.v[0] = -btw[ci].v[0];
-                    E[ci].Phi.t[0][0] = Dn[ci].t[0][0];
-                    E[ci].t = rn[ci];
-                } else {
-                    tn<T, NT, S_FULL, S_FULL, S_UPPER, OP_SUB>(E[ci].Phi, Am[ci], S[ci]);
-                    E[ci].t.v[0] -= btw[ci].v[0];
-                    pin[ci] = E[ci].Phi.t[0][0];
-                }
-            }
-            phase();
-        }
-        chol_inv_tiles<T, NC, true>(pin, lit, lds, ln, laL, bad);
-        phase();
-        MF_UNROLL for (int ci = 0; ci < NC; ++ci) {
-            if (j < len[ci] && !(j == 0 && spike[ci])) {
-                WaveFact<T, NT> f;
-                f.LiT.t[0][0] = lit[ci];
-                if (spike[ci]) E[ci].template after_factor<true>(f, ln); else E[ci].template after_factor<false>(f, ln);
-                Mat<T, NT> ST, WT;
-                transpose<T, NT, S_FULL>(ST, S[ci], lds, ln);
-                tn<T, NT, S_UPPER, S_FULL, S_FULL, OP_SET>(WT, f.LiT, ST);
-                if (spike[ci]) E[ci].template advance<true>(f, WT, Dn[ci], rn[ci]); else E[ci].template advance<false>(f, WT, Dn[ci], rn[ci]);
-            }
-            phase();
-        }
-    }
-    const T logC = laC.value(), logL = laL.value();
-    MF_UNROLL for (int ci = 0; ci < NC; ++ci) {
-        const T ww = sum16<T>(acc_ww[ci]), quad = sum16<T>(E[ci].quad);
-        const T scalar = T(-0.5) * (acc_yry[ci] + ww) + T(0.5) * quad - of_tile<T, NC>(logC, ci) - T(0.5) * of_tile<T, NC>(logL, ci);
-        if (valid[ci]) store_chunk_wave<T, NT>(out, id[ci], d, E[ci], scalar, lds, ln);
-    }
-    if (__any(bad) && threadIdx.x == 0 && a.info) raise_info(a.info);
 }
 
 }  // namespace wv

@@ -55,7 +55,8 @@ size_t wave_udl_ws(long B, long n, int d, int elem_size);
 template <typename T> int wave_btd_diag_of_inverse(long B, long n, int d, const T* ldiag, const T* lsub, T* odiag, T* osub, hipStream_t st);
 // marginal means (omean | NULL), covariances and subsequent covariances (osub | NULL) of a chain of n time points
 template <typename T> int wave_ssm_marginals(long B, long n, int d, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ,
-                                             T* omean, T* ocov, T* osub, hipStream_t st);
+                                             T* omean, T* ocov, T* osub, void* ws, size_t ws_bytes, hipStream_t st);
+size_t wave_marg_ws(long B, long n, int d, int elem_size);
 // the local step of the log-likelihood's gradient from the smoothed moments (mf_wave_grad.hpp); H == NULL: no observation terms
 template <typename T>
 int wave_kf_grad(long B, long Tn, int d, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H, const T* y,

@@ -17,17 +17,6 @@ namespace {
 template <typename T, int NT, int M> constexpr int wave_wpe() {
     return NT == 1 ? (sizeof(T) == 8 ? 2 : (M == 1 ? 4 : 3)) : (sizeof(T) == 8 ? 1 : 2);
 }
-// chunks per wavefront at one tile per matrix (d <= 16; wave_kf_multi_kernel): two in fp64 at two wavefronts per SIMD, four in fp32
-template <typename T> constexpr int wave_nc() { return sizeof(T) == 8 ? 2 : 4; }
-template <typename T, int M> constexpr int wave_multi_wpe() { return 2; }
-template <typename T, int M>
-int wave_launch_multi(const wv::WvArgs<T>& a, const RedSys<T>& out, hipStream_t st) {
-    constexpr int NC = wave_nc<T>();
-    const dim3 grid((unsigned)((a.B * a.P + NC - 1) / NC)), block(64);
-    if (a.d == 16) hipLaunchKernelGGL((wv::wave_kf_multi_kernel<T, M, wave_multi_wpe<T, M>(), true, NC>), grid, block, 0, st, a, out);
-    else hipLaunchKernelGGL((wv::wave_kf_multi_kernel<T, M, wave_multi_wpe<T, M>(), false, NC>), grid, block, 0, st, a, out);
-    return hipGetLastError() == hipSuccess ? 0 : -1000;
-}
 template <typename T, int NT, int M>
 int wave_launch(const wv::WvArgs<T>& a, const RedSys<T>& out, hipStream_t st) {
     const dim3 grid((unsigned)(a.B * a.P)), block(64);
@@ -48,12 +37,6 @@ int wave_level0(long B, long Tn, int d, int m, const T* mu0, const T* cholP0, co
                 const T* y, const T* Rinv, int rinv_per_step, long P, long L, const RedSys<T>& out, int* info, hipStream_t st) {
     if (!wave_covers(d, m)) return -101;
     const wv::WvArgs<T> a{B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, L, info};
-    // the multi-chunk kernel (two / four chunks per wavefront, their diagonal tiles factored side by side) is correct (the parity
-    // tests pass on it) but needs ~430 registers per lane in fp64: held to the 256 of two wavefronts per SIMD it spills 700 bytes
-    // per lane and runs 2.4 x SLOWER (4.43 against 1.85 ms at d = 16, B = 512, T = 1000: profiles/r05_wave_multi_ab.txt) - built,
-    // measured, off; MF_WAVE_MULTI=1 selects it in experiment builds
-    static const bool multi = [] { const char* e = mf_knob("MF_WAVE_MULTI"); return e && e[0] == '1'; }();
-    if (d <= 16 && multi) return m == 1 ? wave_launch_multi<T, 1>(a, out, st) : wave_launch_multi<T, wv::WV_MAXM>(a, out, st);
     static const bool pair = [] { const char* e = mf_knob("MF_WAVE_PAIR"); return !(e && e[0] == '0'); }();
     if (pair) {
         if (d <= 16) return m == 1 ? wave_launch_pair<T, 1, 1>(a, out, st) : wave_launch_pair<T, 1, wv::WV_MAXM>(a, out, st);
@@ -223,7 +206,7 @@ template <typename T> int wave_btd_udl(long B, long n, int d, const T* diag, con
     wv::FactArgs<T> a{B, n, d, diag, sub, ut, chol_d, eta, m_post, chol_dinv, info};
     const dim3 block(64);
     long P = 1, L = n;
-    if (eta && sub) wave_udl_partition(B, n, d, (int)sizeof(T), P, L);
+    if (sub) wave_udl_partition(B, n, d, (int)sizeof(T), P, L);
     if (P > 1 && ws && ws_bytes >= wave_udl_ws(B, n, d, (int)sizeof(T))) {
         const size_t blk = size_t(B) * P * d * d, vec = size_t(B) * P * d;
         T* p = static_cast<T*>(ws);
@@ -231,15 +214,14 @@ template <typename T> int wave_btd_udl(long B, long n, int d, const T* diag, con
         a.rDv = p; a.rGU = p + blk; a.rF = p + 2 * blk; a.bSig = p + 3 * blk;
         a.rtv = p + 4 * blk; a.rgU = a.rtv + vec; a.bx = a.rgU + vec;
         const dim3 chunks((unsigned)(B * P)), series((unsigned)B);
-        if (d <= 16) {
-            hipLaunchKernelGGL((wv::wave_udl_up_kernel<T, 1>), chunks, block, 0, st, a);
-            hipLaunchKernelGGL((wv::wave_udl_boundary_kernel<T, 1>), series, block, 0, st, a);
-            hipLaunchKernelGGL((wv::wave_udl_kernel<T, 1, true, true>), chunks, block, 0, st, a);
-        } else {
-            hipLaunchKernelGGL((wv::wave_udl_up_kernel<T, 2>), chunks, block, 0, st, a);
-            hipLaunchKernelGGL((wv::wave_udl_boundary_kernel<T, 2>), series, block, 0, st, a);
-            hipLaunchKernelGGL((wv::wave_udl_kernel<T, 2, true, true>), chunks, block, 0, st, a);
-        }
+        auto go = [&](auto nt) {
+            constexpr int NT = decltype(nt)::value;
+            hipLaunchKernelGGL((wv::wave_udl_up_kernel<T, NT>), chunks, block, 0, st, a);
+            hipLaunchKernelGGL((wv::wave_udl_boundary_kernel<T, NT>), series, block, 0, st, a);
+            if (eta) hipLaunchKernelGGL((wv::wave_udl_kernel<T, NT, true, true>), chunks, block, 0, st, a);
+            else hipLaunchKernelGGL((wv::wave_udl_kernel<T, NT, false, true>), chunks, block, 0, st, a);
+        };
+        if (d <= 16) go(std::integral_constant<int, 1>{}); else go(std::integral_constant<int, 2>{});
         return hipGetLastError() == hipSuccess ? 0 : -1000;
     }
     if (!wave_serial_pays(B, n)) return -101;
@@ -263,10 +245,45 @@ template <typename T> int wave_btd_diag_of_inverse(long B, long n, int d, const 
     const wv::FactArgs<T> a{B, n, d, ldiag, lsub, odiag, osub, nullptr, nullptr, nullptr, nullptr};
     MF_WAVE_FACT(wave_inverse_blocks_kernel, a, B);
 }
+// the forward recursion of the moments needs far fewer registers than the factorisations (58 per lane at one fp64 tile per matrix, 226
+// at 2 x 2): more wavefronts fit, more chunks pay
+void wave_marg_partition(long B, long nt, int d, int elem_size, long& P, long& L) {
+    const long target = 1024L * (d <= 16 ? 6 : (elem_size == 8 ? 2 : 4));
+    long want = (target + B - 1) / B;
+    if (want > 256) want = 256;
+    if (want > nt / 16) want = nt / 16;
+    if (want < 1) want = 1;
+    L = (nt + want - 1) / want;
+    P = (nt + L - 1) / L;
+}
+size_t wave_marg_ws(long B, long n, int d, int elem_size) {
+    if (!wave_covers(d, 1) || B <= 0 || n <= 1) return 0;
+    long P, L;
+    wave_marg_partition(B, n - 1, d, elem_size, P, L);
+    return P > 1 ? size_t(B) * P * (3 * size_t(d) * d + 2 * size_t(d)) * elem_size + 256 : 0;
+}
 template <typename T> int wave_ssm_marginals(long B, long n, int d, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ,
-                                             T* omean, T* ocov, T* osub, hipStream_t st) {
-    if (!wave_covers(d, 1) || B <= 0 || n <= 0 || !wave_serial_pays(B, n)) return -101;
-    const wv::MargArgs<T> a{B, n, d, mu0, cholP0, A, b, cholQ, omean, ocov, osub};
+                                             T* omean, T* ocov, T* osub, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!wave_covers(d, 1) || B <= 0 || n <= 0) return -101;
+    wv::MargArgs<T> a{B, n, d, mu0, cholP0, A, b, cholQ, omean, ocov, osub};
+    long P = 1, L = n;
+    if (n > 1) wave_marg_partition(B, n - 1, d, (int)sizeof(T), P, L);
+    if (P > 1 && ws && ws_bytes >= wave_marg_ws(B, n, d, (int)sizeof(T))) {
+        const size_t blk = size_t(B) * P * d * d, vec = size_t(B) * P * d;
+        T* p = static_cast<T*>(ws);
+        a.P = P; a.L = L;
+        a.wM = p; a.wN = p + blk; a.bP = p + 2 * blk; a.wv = p + 3 * blk; a.bm = a.wv + vec;
+        const dim3 chunks((unsigned)(B * P)), series((unsigned)B), block(64);
+        auto go = [&](auto nt) {
+            constexpr int NT = decltype(nt)::value;
+            hipLaunchKernelGGL((wv::wave_marg_up_kernel<T, NT>), chunks, block, 0, st, a);
+            hipLaunchKernelGGL((wv::wave_marg_boundary_kernel<T, NT>), series, block, 0, st, a);
+            hipLaunchKernelGGL((wv::wave_marginals_kernel<T, NT, true>), chunks, block, 0, st, a);
+        };
+        if (d <= 16) go(std::integral_constant<int, 1>{}); else go(std::integral_constant<int, 2>{});
+        return hipGetLastError() == hipSuccess ? 0 : -1000;
+    }
+    if (!wave_serial_pays(B, n)) return -101;
     MF_WAVE_FACT(wave_marginals_kernel, a, B);
 }
 #undef MF_WAVE_FACT
@@ -296,9 +313,9 @@ template int wave_kf_grad<float>(long, long, int, int, const float*, const float
                                  const float*, const float*, int, const float*, const float*, const float*, const float*, float*, float*, float*,
                                  float*, float*, float*, float*, float*, hipStream_t);
 template int wave_ssm_marginals<double>(long, long, int, const double*, const double*, const double*, const double*, const double*, double*,
-                                        double*, double*, hipStream_t);
+                                        double*, double*, void*, size_t, hipStream_t);
 template int wave_ssm_marginals<float>(long, long, int, const float*, const float*, const float*, const float*, const float*, float*, float*,
-                                       float*, hipStream_t);
+                                       float*, void*, size_t, hipStream_t);
 template int wave_btd_cholesky<double>(long, long, int, const double*, const double*, double*, double*, void*, size_t, int*, hipStream_t);
 template int wave_btd_cholesky<float>(long, long, int, const float*, const float*, float*, float*, void*, size_t, int*, hipStream_t);
 template int wave_btd_udl<double>(long, long, int, const double*, const double*, double*, double*, const double*, double*, double*, void*,

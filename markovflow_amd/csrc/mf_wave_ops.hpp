@@ -533,14 +533,15 @@ __global__ void __launch_bounds__(64) wave_udl_up_kernel(FactArgs<T> a) {
     const long dd = long(d) * d;
     const T* Dg = a.diag + s * n * dd;
     const T* Sg = a.sub + s * (n - 1) * dd;
-    const T* Eg = a.eta + s * n * d;
+    const T* Eg = a.eta ? a.eta + s * n * d : nullptr;              // NULL: the plain factorisation, no right-hand side
     const bool spike = c > 0;
     WaveElim<T, NT> E;
     E.init();
     Mat<T, NT> Dk, Sk;
     CV<T, NT> ek;
     load_sym_lower<T, NT>(Dk, Dg + k_hi * dd, d, ln);
-    load_cv<T, NT>(ek, Eg + k_hi * d, d, ln);
+    MF_UNROLL for (int j = 0; j < NT; ++j) ek.v[j] = T(0);
+    if (Eg) load_cv<T, NT>(ek, Eg + k_hi * d, d, ln);
     if (spike) load_mat_t<T, NT>(E.X, Sg + k_hi * dd, d, ln);                       // block (k_hi, k_hi + 1) = S_{k_hi}^T
     MF_UNROLL for (int i = 0; i < NT; ++i) MF_UNROLL for (int j = i; j < NT; ++j) E.Phi.t[i][j] = Dk.t[i][j];
     E.t = ek;
@@ -549,7 +550,7 @@ __global__ void __launch_bounds__(64) wave_udl_up_kernel(FactArgs<T> a) {
         asm volatile("" : "+s"(d));
         load_sym_lower<T, NT>(Dk, Dg + k * dd, d, ln);
         load_mat<T, NT, S_FULL>(Sk, Sg + k * dd, d, false, false, ln);              // S_k: block (k + 1, k)
-        load_cv<T, NT>(ek, Eg + k * d, d, ln);
+        if (Eg) load_cv<T, NT>(ek, Eg + k * d, d, ln);
         phase();
         WaveFact<T, NT> f;
         if (spike) E.template eliminate<true>(f, lds, ln); else E.template eliminate<false>(f, lds, ln);
@@ -563,8 +564,10 @@ __global__ void __launch_bounds__(64) wave_udl_up_kernel(FactArgs<T> a) {
     store_mat<T, NT, true>(a.rDv + id * dd, E.Phi, d, lds, ln);
     store_mat<T, NT, true>(a.rGU + id * dd, E.GU, d, lds, ln);
     store_mat<T, NT, false>(a.rF + id * dd, E.X, d, lds, ln);
-    store_cv<T, NT>(a.rtv + id * d, E.t, d, ln);
-    store_cv<T, NT>(a.rgU + id * d, E.gU, d, ln);
+    if (Eg) {
+        store_cv<T, NT>(a.rtv + id * d, E.t, d, ln);
+        store_cv<T, NT>(a.rgU + id * d, E.gU, d, ln);
+    }
     if (__any(E.bad) && threadIdx.x == 0 && a.info) raise_info(a.info);
 }
 template <typename T, int NT>
@@ -697,17 +700,23 @@ template <typename T> struct MargArgs {
     int d;
     const T *mu0, *cholP0, *A, *b, *cholQ;
     T *omean, *ocov, *osub;  // [B, n, d] | NULL, [B, n, d, d], [B, n - 1, d, d] | NULL
+    // partitioned in time (wave_marg_up_kernel / wave_marg_boundary_kernel / wave_marginals_kernel<.., PART>): P chunks of L transitions;
+    // per (series, chunk) the composed map (M, N, v): S -> M S M^T + N, m -> M m + v, and the state the chunk starts from
+    long P, L;
+    T *wM, *wN, *wv, *bP, *bm;   // [B, P, d, d] x 2, [B, P, d]; [B, P, d, d], [B, P, d]
 };
 
 // marginal means / covariances / subsequent covariances (state_space_model.py:232-262,326-341; gauss_markov.py:107-117) by the forward
 // recursion mu' = A mu + b, P' = A P A^T + C C^T, Cov(x', x) = A P - one wavefront per series; with A^T and C^T read transposed
 // every product is P^T Q: P A^T = tn(P, A^T) (P symmetric), A (P A^T) = tn(A^T, .), C C^T = tn(C^T, C^T), A P = tn(A^T, P).
-template <typename T, int NT>
+// PART: wavefront (s, c) walks the transitions [c L, (c + 1) L) from the state the boundary pass left for its chunk.
+template <typename T, int NT, bool PART = false>
 __global__ void __launch_bounds__(64) wave_marginals_kernel(MargArgs<T> a) {
     constexpr int TS = 16 * Tr<T>::LD;
     __shared__ __attribute__((aligned(16))) T lds[NT * NT * TS];
     Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
-    const long s = blockIdx.x, n = a.n, nt = n - 1;
+    const long s = PART ? blockIdx.x / a.P : blockIdx.x, c = PART ? blockIdx.x % a.P : 0, n = a.n, nt = n - 1;
+    const long t_lo = PART ? c * a.L : 0, t_hi = PART ? ((c + 1) * a.L < nt ? (c + 1) * a.L : nt) : nt;
     int d = a.d;
     const long dd = long(d) * d;
     const T* Ag = a.A + s * nt * dd;
@@ -719,25 +728,30 @@ __global__ void __launch_bounds__(64) wave_marginals_kernel(MargArgs<T> a) {
     Mat<T, NT> P, AT, CT;
     CV<T, NT> m, bk;
     MF_UNROLL for (int j = 0; j < NT; ++j) m.v[j] = bk.v[j] = T(0);
-    load_lower_t<T, NT>(CT, a.cholP0 + s * dd, d, ln);
-    tn<T, NT, S_UPPER, S_UPPER, S_FULL, OP_SET>(P, CT, CT);
-    if (om) {
-        load_cv<T, NT>(m, a.mu0 + s * d, d, ln);
-        store_cv<T, NT>(om, m, d, ln);
+    if (!PART || c == 0) {
+        load_lower_t<T, NT>(CT, a.cholP0 + s * dd, d, ln);
+        tn<T, NT, S_UPPER, S_UPPER, S_FULL, OP_SET>(P, CT, CT);
+        if (om) {
+            load_cv<T, NT>(m, a.mu0 + s * d, d, ln);
+            store_cv<T, NT>(om, m, d, ln);
+        }
+        store_mat<T, NT, false>(oc, P, d, lds, ln);
+    } else {
+        load_mat<T, NT, S_FULL>(P, a.bP + (s * a.P + c) * dd, d, false, false, ln);
+        if (om) load_cv<T, NT>(m, a.bm + (s * a.P + c) * d, d, ln);
     }
-    store_mat<T, NT, false>(oc, P, d, lds, ln);
-    if (nt > 0) {
-        load_mat_t<T, NT>(AT, Ag, d, ln);
-        load_lower_t<T, NT>(CT, Cg, d, ln);
-        if (om && bg) load_cv<T, NT>(bk, bg, d, ln);
+    if (t_hi > t_lo) {
+        load_mat_t<T, NT>(AT, Ag + t_lo * dd, d, ln);
+        load_lower_t<T, NT>(CT, Cg + t_lo * dd, d, ln);
+        if (om && bg) load_cv<T, NT>(bk, bg + t_lo * d, d, ln);
     }
-    for (long k = 0; k < nt; ++k) {
+    for (long k = t_lo; k < t_hi; ++k) {
         asm volatile("" : "+v"(ln.r), "+v"(ln.q));
         asm volatile("" : "+s"(d));
         Mat<T, NT> ATn, CTn;
         CV<T, NT> bn;
         MF_UNROLL for (int j = 0; j < NT; ++j) bn.v[j] = T(0);
-        const long kn = k + 1 < nt ? k + 1 : k;
+        const long kn = k + 1 < t_hi ? k + 1 : k;
         load_mat_t<T, NT>(ATn, Ag + kn * dd, d, ln);
         load_lower_t<T, NT>(CTn, Cg + kn * dd, d, ln);
         if (om && bg) load_cv<T, NT>(bn, bg + kn * d, d, ln);
@@ -763,6 +777,86 @@ __global__ void __launch_bounds__(64) wave_marginals_kernel(MargArgs<T> a) {
         AT = ATn;
         CT = CTn;
         MF_UNROLL for (int j = 0; j < NT; ++j) bk.v[j] = bn.v[j];
+    }
+}
+// the composed map of a chunk's transitions: M <- A M, N <- A N A^T + C C^T, v <- A v + b (the same three products per step as the walk)
+template <typename T, int NT>
+__global__ void __launch_bounds__(64) wave_marg_up_kernel(MargArgs<T> a) {
+    constexpr int TS = 16 * Tr<T>::LD;
+    __shared__ __attribute__((aligned(16))) T lds[NT * NT * TS];
+    Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
+    const long s = blockIdx.x / a.P, c = blockIdx.x % a.P, nt = a.n - 1;
+    const long t_lo = c * a.L, t_hi = (c + 1) * a.L < nt ? (c + 1) * a.L : nt;
+    int d = a.d;
+    const long dd = long(d) * d;
+    const T* Ag = a.A + s * nt * dd;
+    const T* Cg = a.cholQ + s * nt * dd;
+    const bool means = a.omean && a.b;
+    const T* bg = means ? a.b + s * nt * d : nullptr;
+    Mat<T, NT> M, N;
+    CV<T, NT> v;
+    identity_mat<T, NT>(M, ln);
+    N.zero();
+    MF_UNROLL for (int j = 0; j < NT; ++j) v.v[j] = T(0);
+    for (long k = t_lo; k < t_hi; ++k) {
+        asm volatile("" : "+v"(ln.r), "+v"(ln.q));
+        asm volatile("" : "+s"(d));
+        Mat<T, NT> AT, CT, X;
+        CV<T, NT> bk;
+        MF_UNROLL for (int j = 0; j < NT; ++j) bk.v[j] = T(0);
+        load_mat_t<T, NT>(AT, Ag + k * dd, d, ln);
+        load_lower_t<T, NT>(CT, Cg + k * dd, d, ln);
+        if (means) load_cv<T, NT>(bk, bg + k * d, d, ln);
+        phase();
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(X, AT, M);                           // A M
+        M = X;
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(X, N, AT);                           // N A^T
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(N, AT, X);                           // A N A^T
+        tn<T, NT, S_UPPER, S_UPPER, S_FULL, OP_ADD>(N, CT, CT);                        // + C C^T
+        RV<T, NT> vr;
+        CV<T, NT> av;
+        cv_to_rv<T, NT>(vr, v, ln);
+        tn_mv<T, NT, S_FULL>(av, AT, vr);
+        MF_UNROLL for (int j = 0; j < NT; ++j) v.v[j] = av.v[j] + bk.v[j];
+    }
+    const long id = s * a.P + c;
+    // (the padded diagonal of M is one: only the d x d corner is stored, and read back with zero padding - the padding of the
+    // covariances it multiplies is zero as well)
+    store_mat<T, NT, false>(a.wM + id * dd, M, d, lds, ln);
+    store_mat<T, NT, false>(a.wN + id * dd, N, d, lds, ln);
+    store_cv<T, NT>(a.wv + id * d, v, d, ln);
+}
+// the state every chunk starts from: S_{c+1} = M_c S_c M_c^T + N_c, m_{c+1} = M_c m_c + v_c
+template <typename T, int NT>
+__global__ void __launch_bounds__(64) wave_marg_boundary_kernel(MargArgs<T> a) {
+    constexpr int TS = 16 * Tr<T>::LD;
+    __shared__ __attribute__((aligned(16))) T lds[NT * NT * TS];
+    Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
+    const long s = blockIdx.x;
+    int d = a.d;
+    const long dd = long(d) * d;
+    Mat<T, NT> P, CT;
+    CV<T, NT> m;
+    load_lower_t<T, NT>(CT, a.cholP0 + s * dd, d, ln);
+    tn<T, NT, S_UPPER, S_UPPER, S_FULL, OP_SET>(P, CT, CT);
+    MF_UNROLL for (int j = 0; j < NT; ++j) m.v[j] = T(0);
+    if (a.omean) load_cv<T, NT>(m, a.mu0 + s * d, d, ln);
+    for (long c = 0; c + 1 < a.P; ++c) {
+        const long id = s * a.P + c;
+        Mat<T, NT> MT, N, X;
+        CV<T, NT> v, am;
+        load_mat_t<T, NT>(MT, a.wM + id * dd, d, ln);
+        load_mat<T, NT, S_FULL>(N, a.wN + id * dd, d, false, false, ln);
+        load_cv<T, NT>(v, a.wv + id * d, d, ln);
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(X, P, MT);                           // S M^T
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(P, MT, X);                           // M S M^T
+        MF_UNROLL for (int i = 0; i < NT; ++i) MF_UNROLL for (int j = 0; j < NT; ++j) P.t[i][j] += N.t[i][j];
+        RV<T, NT> mr;
+        cv_to_rv<T, NT>(mr, m, ln);
+        tn_mv<T, NT, S_FULL>(am, MT, mr);
+        MF_UNROLL for (int j = 0; j < NT; ++j) m.v[j] = am.v[j] + v.v[j];
+        store_mat<T, NT, false>(a.bP + (id + 1) * dd, P, d, lds, ln);
+        store_cv<T, NT>(a.bm + (id + 1) * d, m, d, ln);
     }
 }
 
