@@ -15,6 +15,7 @@ carry ``batch_shape`` (one value per series), which the reference expresses with
 import abc
 import ctypes
 import math
+import weakref
 from typing import List, Sequence, Tuple, Union
 
 import torch
@@ -286,7 +287,8 @@ class StationaryKernel(SDEKernel, abc.ABC):
 
 # (tensor, version) pairs whose positivity has been read back from the device: the check of matern.py:52-56 is a host
 # synchronisation, and a training loop builds the kernel objects anew around the SAME leaf tensors every step (six synchronisations
-# per step at config 4's model).  The entry holds the tensor, so its id cannot be reused; an in-place update (an optimiser step)
+# per step at config 4's model).  The entry holds a WEAK reference (a cache must not keep hyper-parameter tensors of a million series
+# alive): a dead reference, or a live one to another object under a recycled id, is a miss; an in-place update (an optimiser step)
 # changes the version and is checked again.
 _POSITIVE = {}
 
@@ -295,7 +297,7 @@ def _known_positive(*tensors: torch.Tensor) -> bool:
     fresh = []
     for t in tensors:
         hit = _POSITIVE.get(id(t))
-        if hit is None or hit[0] is not t or hit[1] != t._version:
+        if hit is None or hit[0]() is not t or hit[1] != t._version:
             fresh.append(t)
     if not fresh:
         return True
@@ -309,7 +311,7 @@ def _known_positive(*tensors: torch.Tensor) -> bool:
         if len(_POSITIVE) > 256:
             _POSITIVE.clear()
         for t in fresh:
-            _POSITIVE[id(t)] = (t, t._version)
+            _POSITIVE[id(t)] = (weakref.ref(t), t._version)
     return ok
 
 
