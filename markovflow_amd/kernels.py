@@ -46,6 +46,9 @@ def _block_diag(blocks: Sequence[torch.Tensor]) -> torch.Tensor:
     return out
 
 
+_CHOL_INDEX = {}    # (component orders, device) -> flat positions of the non-zero entries of chol(P_inf + jitter)
+
+
 class SDEKernel(abc.ABC):
     """Kernel defined by a linear SDE ``dx = F x dt + L dβ`` (sde_kernel.py:43-351)."""
 
@@ -186,16 +189,63 @@ class SDEKernel(abc.ABC):
         batch = tuple(time_points.shape[:-1])
         deltas = to_delta_time(time_points)
         a_s, chol_q, _ = self._device_transitions(deltas, True, False)
-        p0 = self.initial_covariance(time_points[..., 0:1]).to(dtype=a_s.dtype, device=a_s.device)
-        p0 = p0.expand(batch + tuple(p0.shape[-2:])).contiguous()
+        chol_p0 = self._initial_cholesky(batch, a_s.dtype, a_s.device)
+        if chol_p0 is None:
+            p0 = self.initial_covariance(time_points[..., 0:1]).to(dtype=a_s.dtype, device=a_s.device)
+            p0 = p0.expand(batch + tuple(p0.shape[-2:])).contiguous()
+            # (P-infinity + jitter is positive definite by construction: no info check, hence no host synchronisation)
+            chol_p0 = _lib.checked_cholesky(p0, "SDEKernel.state_space_model (initial covariance)")
         return StateSpaceModel(
             initial_mean=self.initial_mean(batch).to(dtype=a_s.dtype, device=a_s.device).expand(batch + (self.state_dim,)).contiguous(),
-            # (P-infinity + jitter is positive definite by construction: no info check, hence no host synchronisation)
-            chol_initial_covariance=_lib.checked_cholesky(p0, "SDEKernel.state_space_model (initial covariance)"),
+            chol_initial_covariance=chol_p0,
             state_transitions=a_s,
             state_offsets=self.state_offsets(time_points[..., :-1], deltas).to(dtype=a_s.dtype),
             chol_process_covariances=chol_q,
         )
+
+    def _initial_cholesky(self, batch, dtype, device):
+        """``chol(P_inf + jitter I)`` of a concatenation of Matern components in closed form, ``batch + [d, d]`` - or None (the generic
+        route: assemble P_inf, batched Cholesky).  The steady-state covariance of every Matern component is a 1 x 1, a diagonal 2 x 2 or
+        an arrow-shaped 3 x 3 block (matern.py:27-518) whose factor is a handful of elementwise operations on the stacked
+        hyper-parameters; assembling P_inf block by block by slice assignment and differentiating a batched Cholesky through torch
+        is ~150 small launches of the ~320 of a training step at config 4's model (profiles/r05_config4_torch_ops.txt)."""
+        comps = self._components()
+        if not comps or not all(isinstance(c, _MaternBase) and c.order in (1, 3, 5) for c in comps):
+            return None
+        d, jit = self.state_dim, self._jitter
+        rows, cols, vals = [], [], []
+        offs, o = [], 0
+        for c in comps:
+            offs.append(o)
+            o += c.state_dim
+        for order in sorted({c.order for c in comps}):
+            grp = [i for i, c in enumerate(comps) if c.order == order]
+            lam = torch.stack([comps[i]._lambda.to(dtype=dtype, device=device).expand(batch) for i in grp], dim=-1)
+            var = torch.stack([comps[i]._variance_t.to(dtype=dtype, device=device).expand(batch) for i in grp], dim=-1)
+            base = [offs[i] for i in grp]
+            l00 = torch.sqrt(var + jit)
+
+            def put(dr, dc, v):
+                rows.extend(b + dr for b in base)
+                cols.extend(b + dc for b in base)
+                vals.append(v)
+
+            put(0, 0, l00)
+            if order == 3:
+                put(1, 1, torch.sqrt(var * lam ** 2 + jit))
+            elif order == 5:
+                kap = lam ** 2 / 3.0
+                l20 = -(kap * var) / l00
+                put(2, 0, l20)
+                put(1, 1, torch.sqrt(kap * var + jit))
+                put(2, 2, torch.sqrt(lam ** 4 * var + jit - l20 ** 2))
+        flat = torch.zeros(tuple(batch) + (d * d,), dtype=dtype, device=device)
+        key = (tuple(c.order for c in comps), str(device))
+        index = _CHOL_INDEX.get(key)
+        if index is None:       # (one small upload per kernel signature and device, not per model build)
+            index = _CHOL_INDEX[key] = torch.tensor([r * d + c for r, c in zip(rows, cols)], dtype=torch.long, device=device)
+        flat = flat.index_copy(-1, index, torch.cat(vals, dim=-1))
+        return flat.reshape(tuple(batch) + (d, d))
 
     def build_finite_distribution(self, time_points: torch.Tensor) -> GaussMarkovDistribution:
         """sde_kernel.py:140-151."""
