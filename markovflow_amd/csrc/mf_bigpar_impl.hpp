@@ -663,20 +663,25 @@ inline int op_means_par(long Bl, long Br, long n, int d, const real* A, const re
 }
 
 // block_diagonal_of_inverse: M, N, start [B, P, d, d]
-inline size_t bigpar_tak_ws(long B, long n, int d) {
+inline size_t bigpar_tak_ws_engine(long B, long n, int d) {
     long P, L;
     bigpar_partition(B, n, d, P, L);
     return P == 1 ? 0 : 3 * size_t(B) * P * d * d * sizeof(real);
 }
+// (the query does not know which engine takes the call: the larger of the tile engine's and the wave kernels' partition)
+inline size_t bigpar_tak_ws(long B, long n, int d) {
+    const size_t e = bigpar_tak_ws_engine(B, n, d), w = wave_udl_ws(B, n, d, (int)sizeof(real));
+    return e > w ? e : w;
+}
 inline int op_diag_of_inverse_par(long B, long n, int d, const real* ldiag, const real* lsub, real* odiag, real* osub, void* ws,
                                   size_t ws_bytes, hipStream_t st) {
     if (!wave_off()) {
-        const int rc = wave_btd_diag_of_inverse<real>(B, n, d, ldiag, lsub, odiag, osub, st);
+        const int rc = wave_btd_diag_of_inverse<real>(B, n, d, ldiag, lsub, odiag, osub, ws, ws_bytes, st);
         if (rc != -101) return rc;
     }
     long P, L;
     bigpar_partition(B, n, d, P, L);
-    if (P == 1 || !lsub || !ws || ws_bytes < bigpar_tak_ws(B, n, d)) return op_diag_of_inverse(B, n, d, ldiag, lsub, odiag, osub, st);
+    if (P == 1 || !lsub || !ws || ws_bytes < bigpar_tak_ws_engine(B, n, d)) return op_diag_of_inverse(B, n, d, ldiag, lsub, odiag, osub, st);
     const size_t blk = size_t(B) * P * d * d;
     real *wM = static_cast<real*>(ws), *wN = wM + blk, *start = wN + blk;
 #define MF_C(DP)                                                                                                        \

@@ -52,7 +52,8 @@ template <typename T> int wave_btd_udl(long B, long n, int d, const T* diag, con
                                        T* chol_dinv, void* ws, size_t ws_bytes, int* info, hipStream_t st);
 // workspace of the time-partitioned posterior chain on the wave kernels (0: not partitioned / not covered)
 size_t wave_udl_ws(long B, long n, int d, int elem_size);
-template <typename T> int wave_btd_diag_of_inverse(long B, long n, int d, const T* ldiag, const T* lsub, T* odiag, T* osub, hipStream_t st);
+template <typename T> int wave_btd_diag_of_inverse(long B, long n, int d, const T* ldiag, const T* lsub, T* odiag, T* osub, void* ws,
+                                                   size_t ws_bytes, hipStream_t st);
 // marginal means (omean | NULL), covariances and subsequent covariances (osub | NULL) of a chain of n time points
 template <typename T> int wave_ssm_marginals(long B, long n, int d, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ,
                                              T* omean, T* ocov, T* osub, void* ws, size_t ws_bytes, hipStream_t st);

@@ -627,13 +627,17 @@ __global__ void __launch_bounds__(64) wave_udl_boundary_kernel(FactArgs<T> a) {
 
 // block_diagonal_of_inverse (block_tri_diag.py:318-337), block Takahashi backwards: with G_k = W_k L_k^-1,
 // Sigma_kk = L_k^-T L_k^-1 + G_k^T Sigma_{k+1,k+1} G_k and Sigma_{k+1,k} = -Sigma_{k+1,k+1} G_k.
-template <typename T, int NT>
+// PART: the emit pass of the time-partitioned form (wave_inv_up_kernel / wave_inv_boundary_kernel): wavefront (s, c) walks the blocks
+// [k_lo, k_hi] of its chunk (chunks count from the last block) from the Sigma the boundary pass left for the block above them.
+template <typename T, int NT, bool PART = false>
 __global__ void __launch_bounds__(64) wave_inverse_blocks_kernel(FactArgs<T> a) {
     using v4 = typename Tr<T>::v4;
     constexpr int TS = 16 * Tr<T>::LD;
     __shared__ __attribute__((aligned(16))) T lds[NT * NT * TS];
     Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
-    const long s = blockIdx.x, n = a.n;
+    const long s = PART ? blockIdx.x / a.P : blockIdx.x, c = PART ? blockIdx.x % a.P : 0, n = a.n;
+    const long k_hi = PART ? n - 1 - c * a.L : n - 1;
+    const long k_lo = PART ? (n - (c + 1) * a.L > 0 ? n - (c + 1) * a.L : 0) : 0;
     int d = a.d;
     const long dd = long(d) * d;
     const T* Lg = a.diag + s * n * dd;
@@ -643,14 +647,20 @@ __global__ void __launch_bounds__(64) wave_inverse_blocks_kernel(FactArgs<T> a) 
     la.init();
     Mat<T, NT> Lk, WTk, Sig;
     v4 c10t = {0, 0, 0, 0};
-    load_mat<T, NT, S_LOWER>(Lk, Lg + (n - 1) * dd, d, true, true, ln);
-    if constexpr (NT == 2) load_tile_t<T>(c10t, Lg + (n - 1) * dd, d, 1, 0, ln);
+    load_mat<T, NT, S_LOWER>(Lk, Lg + k_hi * dd, d, true, true, ln);
+    if constexpr (NT == 2) load_tile_t<T>(c10t, Lg + k_hi * dd, d, 1, 0, ln);
     WTk.zero();
     Sig.zero();
-    for (long k = n - 1; k >= 0; --k) {
+    if constexpr (PART) {
+        if (c > 0) {
+            load_mat<T, NT, S_FULL>(Sig, a.bSig + (s * a.P + c) * dd, d, false, false, ln);
+            load_mat_t<T, NT>(WTk, Wg + k_hi * dd, d, ln);
+        }
+    }
+    for (long k = k_hi; k >= k_lo; --k) {
         asm volatile("" : "+v"(ln.r), "+v"(ln.q));
         asm volatile("" : "+s"(d));
-        const bool more = k > 0, coupled = k + 1 < n && Wg != nullptr;
+        const bool more = k > k_lo, coupled = k + 1 < n && Wg != nullptr;
         Mat<T, NT> Ln, WTn;
         v4 c10tn = {0, 0, 0, 0};
         if (more) {
@@ -679,6 +689,71 @@ __global__ void __launch_bounds__(64) wave_inverse_blocks_kernel(FactArgs<T> a) 
         }
     }
     (void)bad;
+}
+// the composed map of a chunk of the Takahashi recursion: Sigma_{k_lo} = M^T Sigma_in M + N with M <- M G_k, N <- G_k^T N G_k + L_k^-T L_k^-1
+// block after block (rM holds M^T, rGU holds N in FactArgs' reduced-system arrays; the first chunk has no Sigma above it: G = 0 there)
+template <typename T, int NT>
+__global__ void __launch_bounds__(64) wave_inv_up_kernel(FactArgs<T> a) {
+    using v4 = typename Tr<T>::v4;
+    constexpr int TS = 16 * Tr<T>::LD;
+    __shared__ __attribute__((aligned(16))) T lds[NT * NT * TS];
+    Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
+    const long s = blockIdx.x / a.P, c = blockIdx.x % a.P, n = a.n;
+    const long k_hi = n - 1 - c * a.L, k_lo = n - (c + 1) * a.L > 0 ? n - (c + 1) * a.L : 0;
+    int d = a.d;
+    const long dd = long(d) * d;
+    const T* Lg = a.diag + s * n * dd;
+    const T* Wg = a.sub + s * (n - 1) * dd;
+    bool bad = false;
+    LogAcc<T> la;
+    la.init();
+    Mat<T, NT> MT, N;
+    identity_mat<T, NT>(MT, ln);
+    N.zero();
+    for (long k = k_hi; k >= k_lo; --k) {
+        asm volatile("" : "+v"(ln.r), "+v"(ln.q));
+        asm volatile("" : "+s"(d));
+        Mat<T, NT> Lk, WT, Li, G, X;
+        v4 c10t = {0, 0, 0, 0};
+        load_mat<T, NT, S_LOWER>(Lk, Lg + k * dd, d, true, true, ln);
+        if constexpr (NT == 2) load_tile_t<T>(c10t, Lg + k * dd, d, 1, 0, ln);
+        WT.zero();
+        if (k + 1 < n) load_mat_t<T, NT>(WT, Wg + k * dd, d, ln);
+        phase();
+        tri_inv_mat<T, NT>(Lk, c10t, Li, lds, ln, la, bad);
+        tn<T, NT, S_FULL, S_LOWER, S_FULL, OP_SET>(G, WT, Li);                         // G = W_k L_k^-1
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(X, G, MT);                           // (M G)^T = G^T M^T
+        MT = X;
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(X, N, G);                            // N G
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(N, G, X);                            // G^T N G
+        tn<T, NT, S_LOWER, S_LOWER, S_FULL, OP_ADD>(N, Li, Li);                        // + L^-T L^-1
+    }
+    const long id = s * a.P + c;
+    store_mat<T, NT, false>(a.rDv + id * dd, MT, d, lds, ln);
+    store_mat<T, NT, false>(a.rGU + id * dd, N, d, lds, ln);
+    (void)bad;
+}
+// Sigma above every chunk: Sigma_in(c + 1) = M_c^T Sigma_in(c) M_c + N_c  (Sigma_in(0) = 0: nothing above the last block)
+template <typename T, int NT>
+__global__ void __launch_bounds__(64) wave_inv_boundary_kernel(FactArgs<T> a) {
+    constexpr int TS = 16 * Tr<T>::LD;
+    __shared__ __attribute__((aligned(16))) T lds[NT * NT * TS];
+    Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
+    const long s = blockIdx.x;
+    int d = a.d;
+    const long dd = long(d) * d;
+    Mat<T, NT> Sig;
+    Sig.zero();
+    for (long c = 0; c + 1 < a.P; ++c) {
+        const long id = s * a.P + c;
+        Mat<T, NT> M, N, X;
+        load_mat_t<T, NT>(M, a.rDv + id * dd, d, ln);                                  // stored M^T -> M
+        load_mat<T, NT, S_FULL>(N, a.rGU + id * dd, d, false, false, ln);
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(X, Sig, M);                          // Sigma M
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(Sig, M, X);                          // M^T Sigma M
+        MF_UNROLL for (int i = 0; i < NT; ++i) MF_UNROLL for (int j = 0; j < NT; ++j) Sig.t[i][j] += N.t[i][j];
+        store_mat<T, NT, false>(a.bSig + (id + 1) * dd, Sig, d, lds, ln);
+    }
 }
 
 // m = g^T with g lower triangular (its strict upper triangle, whatever it holds, reads as zero): the transposed Cholesky factor
