@@ -46,7 +46,8 @@ int mf_max_state_dim(void);              /* every entry point, fp32 and fp64: re
  * assembly, gradient step) goes to the tile engine at any d. */
 int mf_row_operators_cover(int64_t B, int64_t T, int d, int elem_size);
 int mf_max_state_dim_f32_loglik(void);   /* mf_kf_loglik_f32 only: LDS-tiled MFMA kernels for 10 <= d <= 64       */
-int mf_max_state_dim_f64_loglik(void);   /* mf_kf_loglik_f64 only: the same on f64 MFMA for 10 <= d <= 32         */
+int mf_max_state_dim_f64_loglik(void);   /* mf_kf_loglik_f64 only: f64 MFMA for 10 <= d <= 64 (panel kernels > 32) */
+int mf_max_state_dim_f64_tile_ops(void); /* every other fp64 entry point on the MFMA engines: 10 <= d <= 32          */
 
 /*
  * KalmanFilter.log_likelihood, per series, fully fused

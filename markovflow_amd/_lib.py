@@ -71,6 +71,7 @@ _PLAIN = {
     "mf_row_operators_cover": (_int, [_i64, _i64, _int, _int]),
     "mf_max_state_dim_f32_loglik": (_int, []),
     "mf_max_state_dim_f64_loglik": (_int, []),
+    "mf_max_state_dim_f64_tile_ops": (_int, []),
     "mf_kf_loglik_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _i64]),
     "mf_btd_logdet_quad_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
     "mf_kf_posterior_chain_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _int, _int, _i64]),

@@ -77,7 +77,7 @@ int kf_loglik(int64_t B, int64_t Tn, int d, int m, const T* mu0, const T* cholP0
     static const int big_from = [] { const char* e = mf::mf_knob("MF_BIG_FROM"); return e ? std::atoi(e) : 1000; }();
     // (more than four outputs: the tile engine at ANY state dimension - its tiles pad d to 16 - so that the observation
     // dimension is not capped at the register kernels' four)
-    const bool big = (d > mf::MF_MAX_D || d >= big_from || m > 4) && d <= (sizeof(T) == 4 ? mf::MF_MAX_D_BIG : mf::MF_MAX_D_BIG_F64);
+    const bool big = (d > mf::MF_MAX_D || d >= big_from || m > 4) && d <= (sizeof(T) == 4 ? mf::MF_MAX_D_BIG : mf::MF_MAX_D_LOGLIK_F64);
     if (!t && !big) return -100;
     if (m < 1 || m > (big ? 32 : 4)) return -4;
     if (B == 0) return 0;
@@ -202,7 +202,7 @@ size_t mf_kf_loglik_workspace_bytes(int64_t B, int64_t T, int d, int elem_size, 
     }
     const auto* t = table_for<double>(d);
     const size_t small = t ? t->kf_loglik_ws(B, T, chunks) : 0;
-    size_t large = (d <= mf::MF_MAX_D_BIG_F64) ? mf::big_kf_loglik_ws(B, T, d, chunks, 8) : 0;
+    size_t large = (d <= mf::MF_MAX_D_LOGLIK_F64) ? mf::big_kf_loglik_ws(B, T, d, chunks, 8) : 0;
     return small > large ? small : large;
 }
 int mf_row_operators_cover(int64_t B, int64_t T, int d, int elem_size) {
@@ -215,7 +215,8 @@ int mf_row_operators_cover(int64_t B, int64_t T, int d, int elem_size) {
     return t && t->btd_cholesky_ws(B, T) > 0 ? 1 : 0;
 }
 int mf_max_state_dim_f32_loglik(void) { return mf::MF_MAX_D_BIG; }
-int mf_max_state_dim_f64_loglik(void) { return mf::MF_MAX_D_BIG_F64; }
+int mf_max_state_dim_f64_loglik(void) { return mf::MF_MAX_D_LOGLIK_F64; }
+int mf_max_state_dim_f64_tile_ops(void) { return mf::MF_MAX_D_BIG_F64; }
 
 int mf_kf_loglik_f64(int64_t B, int64_t T, int d, int m, const double* mu0, const double* cholP0, const double* A,
                      const double* b, const double* cholQ, const double* H, const double* y, const double* Rinv,

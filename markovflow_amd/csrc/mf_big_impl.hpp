@@ -923,6 +923,30 @@ template <int DP> int launch_big(long B, long Tn, int d, int m, const real* mu0,
 }
 
 
+// 32 < d <= 64: level 0 and the reduction levels on the panel kernels (mf_panel.hpp); same partition, same workspace layout
+inline bool panel_path(int d, int m) {
+    static const bool off = [] { const char* e = mf_knob("MF_PANEL"); return e && e[0] == '0'; }();
+    return !off && panel_covers(d, m);
+}
+inline int launch_panel(long B, long Tn, int d, int m, const real* mu0, const real* cholP0, const real* A, const real* b,
+                        const real* cholQ, const real* H, const real* y, const real* Rinv, int rinv_per_step, real add_const,
+                        real* out, void* ws, int* info, long P, long L, hipEvent_t ev0, hipEvent_t ev1, hipStream_t st) {
+    char* p = static_cast<char*>(ws);
+    RedSys<real> cur = carve_big(p, B, P, d);
+    if (ev0) (void)hipEventRecord(ev0, st);
+    int rc = panel_kf_level0(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, L, cur, info, st);
+    if (rc != 0) return rc;
+    if (ev1) (void)hipEventRecord(ev1, st);
+    while (cur.n > BIG_RED_FINAL) {
+        const long Pn = cdivl(cur.n, BIG_RED_CHUNK);
+        RedSys<real> nxt = carve_big(p, B, Pn, d);
+        rc = panel_red(cur, nxt, B, Pn, d, real(0), static_cast<real*>(nullptr), info, 0, st);
+        if (rc != 0) return rc;
+        cur = nxt;
+    }
+    return panel_red(cur, cur, B, 1L, d, add_const, out, info, 1, st);
+}
+
 // wavefronts of the wave kernel in one round over the chip (0: the state dimension is not the wave kernel's)
 inline long wave_target(int d) {
     static const bool off = [] { const char* e = mf_knob("MF_WAVE"); return e && e[0] == '0'; }();
@@ -961,6 +985,9 @@ inline int kf_loglik(long B, long Tn, int d, int m, const real* mu0, const real*
     const long wt = (m <= 4 && Tn >= 2) ? wave_target(d) : 0;
     const bool wave = wt > 0 && wave_covers(d, m);
     big_partition(B, Tn, chunks, P, L, wave ? wt : 0);
+    if (panel_path(d, m))
+        return launch_panel(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, add_const, out, ws, info, P, L, ev0, ev1,
+                            st);
 #define MF_BIG_CASE(DP)                                                                                               \
     return launch_big<DP>(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, add_const, out, ws, info, \
                           P, L, ev0, ev1, st, wave);

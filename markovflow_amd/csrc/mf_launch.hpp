@@ -124,6 +124,7 @@ constexpr int MF_MAX_D = 9;        // largest state dimension with a register-re
 constexpr int MF_MAX_D_ROW = 15;   // largest state dimension of the row kernels (one 16-lane row per chunk; 10 ... 15: only those)
 constexpr int MF_MAX_D_BIG = 64;      // largest state dimension of the LDS-tiled MFMA path, fp32 (log-likelihood only)
 constexpr int MF_MAX_D_BIG_F64 = 32;  // the same in fp64 (seven d x d tiles must fit the 160 KB of LDS)
+constexpr int MF_MAX_D_LOGLIK_F64 = 64;   // mf_kf_loglik_f64 alone: the panel kernels (mf_panel.hpp) carry fp64 to d = 64
 
 // mf_big_inst.hip
 size_t big_kf_loglik_ws(long B, long Tn, int d, long chunks, int elem_size);
@@ -148,6 +149,21 @@ int wave_kf_level0_f64(long B, long Tn, int d, int m, const double* mu0, const d
 int wave_kf_level0_f32(long B, long Tn, int d, int m, const float* mu0, const float* cholP0, const float* A, const float* b,
                        const float* cholQ, const float* H, const float* y, const float* Rinv, int rinv_per_step, long P, long L,
                        const RedSys<float>& out, int* info, hipStream_t st);
+
+// mf_panel_inst.hip: the log-likelihood on register PANELS, one workgroup of d / 16 wavefronts per (series, chunk), 32 < d <= 64
+// (mf_panel.hpp): level 0 and the reduction levels behind it (same reduced system as the tile engine's).
+bool panel_covers(int d, int m);
+int panel_kf_level0_f64(long B, long Tn, int d, int m, const double* mu0, const double* cholP0, const double* A, const double* b,
+                        const double* cholQ, const double* H, const double* y, const double* Rinv, int rinv_per_step, long P, long L,
+                        const RedSys<double>& out, int* info, hipStream_t st);
+int panel_kf_level0_f32(long B, long Tn, int d, int m, const float* mu0, const float* cholP0, const float* A, const float* b,
+                        const float* cholQ, const float* H, const float* y, const float* Rinv, int rinv_per_step, long P, long L,
+                        const RedSys<float>& out, int* info, hipStream_t st);
+// one reduction level RedSys(in.n) -> RedSys(P) (final: P = 1, out_scalar[s] = add_const + the series' value)
+int panel_red_f64(const RedSys<double>& in, const RedSys<double>& out, long B, long P, int d, double add_const, double* out_scalar,
+                  int* info, int final_level, hipStream_t st);
+int panel_red_f32(const RedSys<float>& in, const RedSys<float>& out, long B, long P, int d, float add_const, float* out_scalar,
+                  int* info, int final_level, hipStream_t st);
 
 #define MF_DECLARE_BIG(SUF, T)                                                                                               \
     int big_cholesky_##SUF(long B, long n, int d, const T* diag, const T* sub, T* ldiag, T* lsub, void* ws, size_t ws_bytes,  \

@@ -1,0 +1,81 @@
+// Instantiations of the panel kernels (mf_panel.hpp: one workgroup of d / 16 wavefronts per (series, chunk), register panels,
+// 32 < d <= 64) and the entry points the tile engine's launcher (mf_big_impl.hpp) hands the log-likelihood to.
+#include "mf_panel.hpp"
+#include "mf_launch.hpp"
+
+namespace mf {
+
+namespace {
+template <typename K> bool panel_attr(K kernel, int bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+}
+template <typename T, int NT, int MT, bool EX>
+int panel_launch0(const wv::WvArgs<T>& a, const RedSys<T>& out, hipStream_t st) {
+    constexpr int bytes = pn::Lds<T, NT, MT>::BYTES;
+    static const bool ok = panel_attr(&pn::panel_kf_chunk_kernel<T, NT, MT, EX>, bytes);
+    if (!ok) return -1000;
+    hipLaunchKernelGGL((pn::panel_kf_chunk_kernel<T, NT, MT, EX>), dim3((unsigned)(a.B * a.P)), dim3(64 * NT), bytes, st, a, out);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+template <typename T, int NT, int MT>
+int panel_launch0_ex(const wv::WvArgs<T>& a, const RedSys<T>& out, hipStream_t st) {
+    return a.d == 16 * NT ? panel_launch0<T, NT, MT, true>(a, out, st) : panel_launch0<T, NT, MT, false>(a, out, st);
+}
+template <typename T>
+int panel_level0(long B, long Tn, int d, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H,
+                 const T* y, const T* Rinv, int rinv_per_step, long P, long L, const RedSys<T>& out, int* info, hipStream_t st) {
+    if (!panel_covers(d, m)) return -101;
+    const wv::WvArgs<T> a{B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, L, info};
+    if (d <= 48) return m <= 16 ? panel_launch0_ex<T, 3, 1>(a, out, st) : panel_launch0_ex<T, 3, 2>(a, out, st);
+    return m <= 16 ? panel_launch0_ex<T, 4, 1>(a, out, st) : panel_launch0_ex<T, 4, 2>(a, out, st);
+}
+template <typename T, int NT, bool FINAL, bool EX>
+int panel_red_launch(const RedSys<T>& in, const RedSys<T>& out, long B, long P, int d, T add_const, T* out_scalar, int* info,
+                     hipStream_t st) {
+    constexpr int bytes = pn::Lds<T, NT, 1>::BYTES;
+    static const bool ok = panel_attr(&pn::panel_red_kernel<T, NT, FINAL, EX>, bytes);
+    if (!ok) return -1000;
+    hipLaunchKernelGGL((pn::panel_red_kernel<T, NT, FINAL, EX>), dim3((unsigned)(B * P)), dim3(64 * NT), bytes, st, in, out, B, P, d,
+                       add_const, out_scalar, info);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+template <typename T, int NT>
+int panel_red_nt(const RedSys<T>& in, const RedSys<T>& out, long B, long P, int d, T add_const, T* out_scalar, int* info, int fin,
+                 hipStream_t st) {
+    const bool ex = d == 16 * NT;
+    if (fin) return ex ? panel_red_launch<T, NT, true, true>(in, out, B, P, d, add_const, out_scalar, info, st)
+                       : panel_red_launch<T, NT, true, false>(in, out, B, P, d, add_const, out_scalar, info, st);
+    return ex ? panel_red_launch<T, NT, false, true>(in, out, B, P, d, add_const, out_scalar, info, st)
+              : panel_red_launch<T, NT, false, false>(in, out, B, P, d, add_const, out_scalar, info, st);
+}
+template <typename T>
+int panel_red_t(const RedSys<T>& in, const RedSys<T>& out, long B, long P, int d, T add_const, T* out_scalar, int* info, int fin,
+                hipStream_t st) {
+    if (!panel_covers(d, 1)) return -101;
+    return d <= 48 ? panel_red_nt<T, 3>(in, out, B, P, d, add_const, out_scalar, info, fin, st)
+                   : panel_red_nt<T, 4>(in, out, B, P, d, add_const, out_scalar, info, fin, st);
+}
+}  // namespace
+
+bool panel_covers(int d, int m) { return d > 32 && d <= 64 && m >= 1 && m <= 32; }
+
+int panel_kf_level0_f64(long B, long Tn, int d, int m, const double* mu0, const double* cholP0, const double* A, const double* b,
+                        const double* cholQ, const double* H, const double* y, const double* Rinv, int rinv_per_step, long P, long L,
+                        const RedSys<double>& out, int* info, hipStream_t st) {
+    return panel_level0<double>(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, L, out, info, st);
+}
+int panel_kf_level0_f32(long B, long Tn, int d, int m, const float* mu0, const float* cholP0, const float* A, const float* b,
+                        const float* cholQ, const float* H, const float* y, const float* Rinv, int rinv_per_step, long P, long L,
+                        const RedSys<float>& out, int* info, hipStream_t st) {
+    return panel_level0<float>(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, L, out, info, st);
+}
+int panel_red_f64(const RedSys<double>& in, const RedSys<double>& out, long B, long P, int d, double add_const, double* out_scalar,
+                  int* info, int final_level, hipStream_t st) {
+    return panel_red_t<double>(in, out, B, P, d, add_const, out_scalar, info, final_level, st);
+}
+int panel_red_f32(const RedSys<float>& in, const RedSys<float>& out, long B, long P, int d, float add_const, float* out_scalar,
+                  int* info, int final_level, hipStream_t st) {
+    return panel_red_t<float>(in, out, B, P, d, add_const, out_scalar, info, final_level, st);
+}
+
+}  // namespace mf

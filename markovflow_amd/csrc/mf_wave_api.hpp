@@ -14,6 +14,24 @@ inline int wave_kf_level0(long B, long Tn, int d, int m, const float* mu0, const
                           const RedSys<float>& out, int* info, hipStream_t st) {
     return wave_kf_level0_f32(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, L, out, info, st);
 }
+inline int panel_kf_level0(long B, long Tn, int d, int m, const double* mu0, const double* cholP0, const double* A, const double* b,
+                           const double* cholQ, const double* H, const double* y, const double* Rinv, int rinv_per_step, long P, long L,
+                           const RedSys<double>& out, int* info, hipStream_t st) {
+    return panel_kf_level0_f64(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, L, out, info, st);
+}
+inline int panel_kf_level0(long B, long Tn, int d, int m, const float* mu0, const float* cholP0, const float* A, const float* b,
+                           const float* cholQ, const float* H, const float* y, const float* Rinv, int rinv_per_step, long P, long L,
+                           const RedSys<float>& out, int* info, hipStream_t st) {
+    return panel_kf_level0_f32(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, L, out, info, st);
+}
+inline int panel_red(const RedSys<double>& in, const RedSys<double>& out, long B, long P, int d, double add_const, double* out_scalar,
+                     int* info, int final_level, hipStream_t st) {
+    return panel_red_f64(in, out, B, P, d, add_const, out_scalar, info, final_level, st);
+}
+inline int panel_red(const RedSys<float>& in, const RedSys<float>& out, long B, long P, int d, float add_const, float* out_scalar,
+                     int* info, int final_level, hipStream_t st) {
+    return panel_red_f32(in, out, B, P, d, add_const, out_scalar, info, final_level, st);
+}
 // mf_wave_inst.hip: precision assembly on register tiles (wave_ssm_precision_kernel); -101: not covered
 int wave_ssm_precision_f64(long B, long Tn, int d, int m, const double* mu0, const double* cholP0, const double* A, const double* b,
                            const double* cholQ, const double* H, const double* y, const double* Rinv, int rinv_per_step, double* diag,

@@ -189,7 +189,7 @@ class StateSpaceModel(GaussMarkovDistribution):
         mu0, cp0, a_f, b_f, cq = self._flat_params()
         bsz = a_f.shape[0]
         lib = _lib.load()
-        d_max = lib.mf_max_state_dim_f32_loglik() if a_f.dtype == torch.float32 else lib.mf_max_state_dim_f64_loglik()
+        d_max = lib.mf_max_state_dim_f32_loglik() if a_f.dtype == torch.float32 else lib.mf_max_state_dim_f64_tile_ops()
         if bsz > 0 and n > 1 and d <= d_max:
             means = torch.empty((bsz, n, d), dtype=a_f.dtype, device=a_f.device)
             covs = torch.empty((bsz, n, d, d), dtype=a_f.dtype, device=a_f.device)
@@ -217,7 +217,7 @@ class StateSpaceModel(GaussMarkovDistribution):
         dimensions beyond that engine keep the reference's route."""
         d, n = self.state_dim, self.num_transitions + 1
         lib = _lib.load()
-        d_max = lib.mf_max_state_dim_f32_loglik() if self._A_s.dtype == torch.float32 else lib.mf_max_state_dim_f64_loglik()
+        d_max = lib.mf_max_state_dim_f32_loglik() if self._A_s.dtype == torch.float32 else lib.mf_max_state_dim_f64_tile_ops()
         if d > d_max or n < 2:
             covs = self.precision.cholesky.block_diagonal_of_inverse()
             return covs, (self.subsequent_covariances(covs) if want_sub else None)

@@ -98,9 +98,54 @@ def test_large_d_fp64_time_partition_invariance(rng, chunks):
     np.testing.assert_allclose(loglik_with_chunks(kw, r_inv, chunks) + cst, ref, rtol=1e-9)
 
 
+@pytest.mark.parametrize("d,m,t,batch", [(33, 1, 9, (2,)), (40, 3, 21, (1,)), (48, 17, 12, (2,)), (49, 2, 30, ()),
+                                         (64, 1, 40, (3,)), (64, 32, 24, (2,)), (57, 16, 11, (1,))])
+def test_panel_fp64_log_likelihood_vs_oracle(rng, d, m, t, batch):
+    """fp64 for 32 < d <= 64 (the reference's default float at the spatio-temporal model's state dimension,
+    models/spatio_temporal_variational.py:45-85): the panel kernels (csrc/mf_panel.hpp) on v_mfma_f64_16x16x4_f64.  rtol 1e-9 as
+    for every other fp64 log-likelihood."""
+    kw = random_ssm(rng, batch, t, d, m, well=True)
+    cov = 0.5 * np.eye(m) + 0.1 * np.ones((m, m))
+    kf = build_kf(kw, np.linalg.cholesky(cov))
+    ref = O.kf_log_likelihood(**kw, r_inv=np.linalg.inv(cov))
+    np.testing.assert_allclose(float(kf.log_likelihood().cpu()), ref, rtol=1e-9)
+
+
+@pytest.mark.parametrize("dtype", [F32, torch.float64])
+@pytest.mark.parametrize("d,chunks", [(64, 1), (64, 2), (64, 5), (64, 16), (64, 70), (40, 3), (40, 24), (48, 70)])
+def test_panel_time_partition_invariance(rng, dtype, d, chunks):
+    """Panel kernels: any partition of the time axis (chunks without / with a spike, one and two reduction levels: 70 chunks -> 9
+    -> 2) gives the oracle's per-series value; d = 40 exercises the identity padding of a 48 x 48 problem."""
+    m, t = 2, 281
+    kw = random_ssm(rng, (2,), t, d, m, well=True)
+    if dtype == F32:
+        kw = rounded(kw)
+    r_inv = np.array([[2.0, 0.3], [0.3, 1.5]])
+    ref = O.kf_log_likelihood(**kw, r_inv=r_inv, per_series=True)
+    cst = -0.5 * np.log(2 * np.pi) * m * t + 0.5 * t * np.linalg.slogdet(r_inv)[1]
+    got = loglik_with_chunks(kw, r_inv, chunks, dtype=dtype)
+    np.testing.assert_allclose(got + cst, ref, rtol=RTOL if dtype == F32 else 1e-9)
+
+
+@pytest.mark.parametrize("dtype", [F32, torch.float64])
+def test_panel_per_step_precisions(rng, dtype):
+    """KalmanFilterWithSites (per-step R^-1, m = 1; kalman_filter.py:437-497) at d = 50 through the panel kernels."""
+    d, t = 50, 30
+    kw = random_ssm(rng, (), t, d, 1, well=True)
+    prec = 0.5 + rng.random(size=(t, 1, 1))
+    if dtype == F32:
+        kw, prec = rounded(kw), prec.astype(np.float32).astype(np.float64)
+    means = kw["y"]
+    ssm = mfa.StateSpaceModel(*(tt(kw[k], dtype) for k in ("mu0", "chol_p0", "a_s", "b_s", "chol_q")))
+    sites = mfa.UnivariateGaussianSitesNat(nat1=tt(means * prec[..., 0], dtype), nat2=tt(-0.5 * prec, dtype))
+    kf = mfa.KalmanFilterWithSites(ssm, mfa.EmissionModel(tt(kw["h"], dtype)), sites)
+    ref = O.kf_log_likelihood(**kw, r_inv=prec, log_det_obs_precision=np.sum(np.log(prec)))
+    np.testing.assert_allclose(float(kf.log_likelihood().cpu()), ref, rtol=RTOL if dtype == F32 else 1e-9)
+
+
 def test_large_d_unsupported_cases_fail_loudly(rng):
-    kw = random_ssm(rng, (1,), 4, 33, 1, well=True)
-    with pytest.raises(NotImplementedError):          # fp64 beyond the sizes whose seven tiles fit the LDS
+    kw = random_ssm(rng, (1,), 4, 65, 1, well=True)
+    with pytest.raises(NotImplementedError):          # fp64 beyond the panel kernels
         build_kf(kw, np.eye(1)).log_likelihood()
     kw = random_ssm(rng, (1,), 4, 65, 1, well=True)
     with pytest.raises(NotImplementedError):          # beyond the LDS-tiled sizes
