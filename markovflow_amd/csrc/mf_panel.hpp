@@ -70,28 +70,74 @@ template <typename T, int LD> MF_DEV void img_put_t(T* img, int ti, int tj, cons
     MF_UNROLL for (int e = 0; e < 4; ++e) img[(16 * ti + Tr<T>::row(ln.q, e)) * LD + p] = t[e];
 }
 
+MF_DEV float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+MF_DEV double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// Phase timing of a level-0 step (diagnostic builds only: -DMF_PANEL_STAMP; the first wavefront of workgroup 1 prints the table).
+// s_memtime between the phases, accumulated over the chunk.
+#ifdef MF_PANEL_STAMP
+struct Stamp {
+    unsigned long long* acc;          // 12 words of LDS, written by thread 0
+    unsigned long long prev;
+    MF_DEV void init(void* lds) {
+        acc = static_cast<unsigned long long*>(lds);
+        if (threadIdx.x == 0) for (int i = 0; i < 12; ++i) acc[i] = 0;
+        prev = __builtin_readcyclecounter();
+    }
+    MF_DEV void at(int i) {
+        const unsigned long long now = __builtin_readcyclecounter();
+        if (threadIdx.x == 0) acc[i] += now - prev;
+        prev = now;
+    }
+    MF_DEV void print(long steps) {
+        if (blockIdx.x == 1 && threadIdx.x == 0) {
+            printf("panel step phases (memtime ticks per step, %ld steps):", steps);
+            for (int i = 0; i < 12; ++i) printf(" [%d] %.0f", i, (double)acc[i] / (double)(steps > 0 ? steps : 1));
+            printf("\n");
+        }
+    }
+};
+#define MF_PSTAMP(st, i) (st).at(i);
+#else
+struct Stamp {
+    MF_DEV void init(void*) {}
+    MF_DEV void print(long) {}
+};
+#define MF_PSTAMP(st, i)
+#endif
+
 template <typename T> MF_DEV typename Tr<T>::v4 mm(const typename Tr<T>::v4& a, const typename Tr<T>::v4& b, typename Tr<T>::v4 acc) {
     MF_UNROLL for (int e = 0; e < 4; ++e) acc = Tr<T>::mfma(a[e], b[e], acc);
     return acc;
 }
 
 enum { OP_SET = 0, OP_ADD = 1, OP_SUB = 2, OP_NEG = 3 };
-// out[ti] (OP) sum_tk P(tk, ti)^T Q[tk]  for the ti with ti_on(ti) and the tk with tk_on(tk, ti); P from the image.  The four K-values of
-// a tile are consecutive instructions on ONE accumulator; the output tiles are independent chains that the compiler interleaves.
-template <typename T, int NT, int KT, int LD, int OP, typename TiOn, typename TkOn>
-MF_DEV void tn_img(Panel<T, NT>& out, const T* img, const typename Tr<T>::v4 (&Q)[KT], const Lane& ln, TiOn ti_on, TkOn tk_on) {
+enum { P_FULL = 0, P_UPPER = 1, P_LOWER = 2 };      // tile structure of P: all tiles, tk <= ti only, tk >= ti only
+// out[ti] (OP) sum_tk P(tk, ti)^T Q[tk], P from the image.  Straight-line code - NO wavefront-dependent skipping: a symmetric result is
+// formed in full (a branch per tile costs the schedule more than the instructions it would save: every tile product becomes a block of
+// its own - LDS read, wait, four dependent matrix instructions).  The NT output tiles are independent accumulator chains, issued
+// round-robin so that no instruction waits for the one before it on its own chain.
+template <typename T, int NT, int KT, int LD, int OP, int PS>
+MF_DEV void tn_img(Panel<T, NT>& out, const T* img, const typename Tr<T>::v4 (&Q)[KT], const Lane& ln) {
     using v4 = typename Tr<T>::v4;
-    v4 acc[NT];
+    auto on = [](int tk, int ti) { return PS == P_FULL || (PS == P_UPPER ? tk <= ti : tk >= ti); };
+    v4 acc[NT], a[2][NT];
     MF_UNROLL for (int ti = 0; ti < NT; ++ti) acc[ti] = (OP == OP_ADD) ? out.t[ti] : v4{0, 0, 0, 0};
+    MF_UNROLL for (int ti = 0; ti < NT; ++ti)
+        if (on(0, ti)) a[0][ti] = img_tile<T, LD>(img, 0, ti, ln);
+    // the A tiles of K-tile tk + 1 are read while the matrix instructions of K-tile tk issue; the scheduling fence keeps the compiler
+    // from hoisting ALL the reads of a product to its top (4 NT^2 registers of operands in flight)
     MF_UNROLL for (int tk = 0; tk < KT; ++tk) {
-        MF_UNROLL for (int ti = 0; ti < NT; ++ti) {
-            if (!ti_on(ti) || !tk_on(tk, ti)) continue;
-            const v4 a = img_tile<T, LD>(img, tk, ti, ln);
-            acc[ti] = mm<T>(a, Q[tk], acc[ti]);
+        if (tk + 1 < KT) {
+            MF_UNROLL for (int ti = 0; ti < NT; ++ti)
+                if (on(tk + 1, ti)) a[(tk + 1) & 1][ti] = img_tile<T, LD>(img, tk + 1, ti, ln);
         }
+        MF_UNROLL for (int e = 0; e < 4; ++e)
+            MF_UNROLL for (int ti = 0; ti < NT; ++ti)
+                if (on(tk, ti)) acc[ti] = Tr<T>::mfma(a[tk & 1][ti][e], Q[tk][e], acc[ti]);
+        __builtin_amdgcn_sched_barrier(0);
     }
     MF_UNROLL for (int ti = 0; ti < NT; ++ti) {
-        if (!ti_on(ti)) continue;
         if (OP == OP_SUB) out.t[ti] -= acc[ti];
         else if (OP == OP_NEG) out.t[ti] = -acc[ti];
         else out.t[ti] = acc[ti];
@@ -107,32 +153,58 @@ template <typename T, int NT> MF_DEV void vec_rv(RV<T, NT>& v, const T* vec, con
         MF_UNROLL for (int e = 0; e < 4; ++e) v.v[ti][e] = vec[16 * ti + Tr<T>::row(ln.q, e)];
 }
 // own entries of M^T v (M: the wavefront's panel, KT tiles high)
-template <typename T, int KT, typename On> MF_DEV T mv_panel(const typename Tr<T>::v4 (&M)[KT], const T (&v)[KT][4], On on) {
+template <typename T, int KT> MF_DEV T mv_panel(const typename Tr<T>::v4 (&M)[KT], const T (&v)[KT][4]) {
     T acc = T(0);
     MF_UNROLL for (int ti = 0; ti < KT; ++ti) {
-        if (!on(ti)) continue;
-        MF_UNROLL for (int e = 0; e < 4; ++e) acc = __builtin_fma(M[ti][e], v[ti][e], acc);
+        MF_UNROLL for (int e = 0; e < 4; ++e) acc = fma_t(M[ti][e], v[ti][e], acc);
     }
     return wv::xor_rows<T>(acc);
 }
 
 // ---- global memory <-> panels ------------------------------------------------------------------------------------------------------
-// panel w of a d x d row-major matrix.  lower: the strict upper triangle reads as zero; idpad: ones on the padded diagonal
+// The lane coordinates behind an optimisation barrier: the per-lane offsets of a group of loads are then computed where the loads are
+// issued.  Without it the compiler hoists them out of the step loop (they are loop-invariant), keeps 2 x 16 registers of 64-bit offsets
+// alive across the whole step, spills them - and every reload waits (vmcnt is in order) for the global load issued just before it:
+// sixteen loads of a panel went out ONE AT A TIME, each paying the full memory latency (profiles/r06_panel_phases.txt).
+MF_DEV Lane opaque_lane(const Lane& ln) {
+    Lane l = ln;
+    asm volatile("" : "+v"(l.r), "+v"(l.q));
+    return l;
+}
+// panel w of a d x d row-major matrix.  lower: the strict upper triangle reads as zero; idpad: ones on the padded diagonal.
+// EX (d = 16 NT): every address is in range - the loads are unconditional (one base, immediate offsets) and the triangle is masked
+// on the VALUES.
 template <typename T, int NT, bool EX>
-MF_DEV void load_panel(Panel<T, NT>& p, const T* __restrict__ g, int d, int w, bool lower, bool idpad, const Lane& ln) {
+MF_DEV void load_panel(Panel<T, NT>& p, const T* __restrict__ g, int d, int w, bool lower, bool idpad, const Lane& ln_) {
+    const Lane ln = opaque_lane(ln_);
+    if constexpr (EX) {
+        constexpr int D = 16 * NT;
+        const T* __restrict__ base = g + Tr<T>::row(ln.q, 0) * D + 16 * w + ln.r;
+        MF_UNROLL for (int ti = 0; ti < NT; ++ti) {
+            if (lower && ti < w) { p.t[ti] = typename Tr<T>::v4{0, 0, 0, 0}; continue; }
+            MF_UNROLL for (int e = 0; e < 4; ++e) p.t[ti][e] = base[(16 * ti + Tr<T>::row(0, e)) * D];
+        }
+        if (lower) {
+            MF_UNROLL for (int ti = 0; ti < NT; ++ti)
+                MF_UNROLL for (int e = 0; e < 4; ++e)
+                    if (16 * ti + Tr<T>::row(ln.q, e) < 16 * w + ln.r) p.t[ti][e] = T(0);
+        }
+        return;
+    }
     MF_UNROLL for (int ti = 0; ti < NT; ++ti) {
         if (lower && ti < w) { p.t[ti] = typename Tr<T>::v4{0, 0, 0, 0}; continue; }
         MF_UNROLL for (int e = 0; e < 4; ++e) {
             const int i = 16 * ti + Tr<T>::row(ln.q, e), j = 16 * w + ln.r;
-            const bool in = (EX || (i < d && j < d)) && (!lower || j <= i);
+            const bool in = (i < d && j < d) && (!lower || j <= i);
             const T v = g[in ? i * d + j : 0];
-            p.t[ti][e] = in ? v : ((!EX && idpad && i == j && i >= d) ? T(1) : T(0));
+            p.t[ti][e] = in ? v : ((idpad && i == j && i >= d) ? T(1) : T(0));
         }
     }
 }
 // panel w of g^T (g: d x d row-major): 16 contiguous bytes per lane and tile in fp32
 template <typename T, int NT, bool EX>
-MF_DEV void load_panel_t(Panel<T, NT>& p, const T* __restrict__ g, int d, int w, const Lane& ln) {
+MF_DEV void load_panel_t(Panel<T, NT>& p, const T* __restrict__ g, int d, int w, const Lane& ln_) {
+    const Lane ln = opaque_lane(ln_);
     MF_UNROLL for (int ti = 0; ti < NT; ++ti)
         MF_UNROLL for (int e = 0; e < 4; ++e) {
             const int i = 16 * ti + Tr<T>::row(ln.q, e), j = 16 * w + ln.r;          // element (i, j) of g^T = g[j][i]
@@ -143,7 +215,8 @@ MF_DEV void load_panel_t(Panel<T, NT>& p, const T* __restrict__ g, int d, int w,
 }
 // rows of an mo x d matrix (observation matrix), panel w: MT tiles high
 template <typename T, int MT>
-MF_DEV void load_rows_panel(typename Tr<T>::v4 (&p)[MT], const T* __restrict__ g, int mo, int d, int w, const Lane& ln) {
+MF_DEV void load_rows_panel(typename Tr<T>::v4 (&p)[MT], const T* __restrict__ g, int mo, int d, int w, const Lane& ln_) {
+    const Lane ln = opaque_lane(ln_);
     MF_UNROLL for (int to = 0; to < MT; ++to)
         MF_UNROLL for (int e = 0; e < 4; ++e) {
             const int i = 16 * to + Tr<T>::row(ln.q, e), j = 16 * w + ln.r;
@@ -181,23 +254,100 @@ MF_DEV void store_panel(T* __restrict__ g, const Panel<T, NT>& p, int d, int w, 
     }
 }
 
+// ---- LDS-DMA (buffer_load_dword ... lds): global memory -> LDS without a register in between ---------------------------------------
+// One instruction moves 256 consecutive bytes (lane l: 4 bytes at voffset + 4 l) to the 256 LDS bytes at M0 + imm + 4 l.  Used to
+// fetch the NEXT step's inputs while this step's last products run: nothing is loop-carried in registers (a loaded value that
+// crosses the back edge of the step loop is waited for at the back edge).  The instructions sit in asm statements, so the compiler's
+// own s_waitcnt bookkeeping does not know them: memory operations complete in order, its waits are therefore never too short, and the
+// consumers below wait with an explicit s_waitcnt vmcnt(0).  Lanes beyond the descriptor's range write ZEROS (padding for free).
+typedef int pn_v4i __attribute__((ext_vector_type(4)));
+MF_DEV pn_v4i dma_srd(const void* base, unsigned bytes) {
+    const unsigned long long b = (unsigned long long)base;
+    pn_v4i srd;
+    srd.x = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    srd.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(b >> 32) & 0xffffu));
+    srd.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    srd.w = 0x00020000;
+    return srd;
+}
+MF_DEV unsigned lds_addr(const void* p) { return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)p); }
+// sixteen rows of ROWB <= 256 bytes: global row stride ROWB, LDS row stride ROWB + PAD (the immediate offset advances both sides by
+// ROWB, M0 by PAD); the lanes beyond a row are switched off
+template <int ROWB, int PAD> MF_DEV void dma_rows16(pn_v4i srd, unsigned lds, unsigned voff) {
+    unsigned keep;
+#define MF_PN_ROW(i) "buffer_load_dword %3, %1, 0 offen offset:%" #i " lds\n\ts_add_u32 m0, m0, %4\n\ts_nop 0\n\t"
+    if (voff < (unsigned)ROWB)
+        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     MF_PN_ROW(5) MF_PN_ROW(6) MF_PN_ROW(7) MF_PN_ROW(8) MF_PN_ROW(9) MF_PN_ROW(10) MF_PN_ROW(11) MF_PN_ROW(12)
+                     MF_PN_ROW(13) MF_PN_ROW(14) MF_PN_ROW(15) MF_PN_ROW(16) MF_PN_ROW(17) MF_PN_ROW(18) MF_PN_ROW(19) MF_PN_ROW(20)
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(srd), "s"(lds), "v"(voff), "n"(PAD),
+                       "n"(0 * ROWB), "n"(1 * ROWB), "n"(2 * ROWB), "n"(3 * ROWB), "n"(4 * ROWB), "n"(5 * ROWB), "n"(6 * ROWB), "n"(7 * ROWB),
+                       "n"(8 * ROWB), "n"(9 * ROWB), "n"(10 * ROWB), "n"(11 * ROWB), "n"(12 * ROWB), "n"(13 * ROWB), "n"(14 * ROWB), "n"(15 * ROWB)
+                     : "memory", "scc");
+#undef MF_PN_ROW
+}
+// `bytes` (<= 512, a multiple of 4) consecutive bytes, of which the first `valid` come from memory and the rest are zeros
+MF_DEV void dma_vec(const void* g, unsigned valid, void* dst, unsigned bytes) {
+    const pn_v4i srd = dma_srd(g, valid);
+    const unsigned lds = lds_addr(dst), voff = 4u * (threadIdx.x & 63);
+    unsigned keep;
+    if (voff < bytes)
+        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %3, %1, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(srd), "s"(lds), "v"(voff) : "memory");
+    if (voff + 256u < bytes)
+        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %3, %1, 0 offen offset:256 lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(srd), "s"(lds), "v"(voff) : "memory");
+}
+MF_DEV void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// C_ww (lower triangular 16 x 16 tile, given by ROWS: lane r holds a[k] = C_ww[r][k]) -> its inverse: row-major in the slot (for the
+// other wavefronts) and in the accumulator layout (out).  wv::tri_inv_tiles without the accumulator -> image -> rows detour.
+template <typename T>
+MF_DEV void tri_inv_rows(T (&a)[16], typename Tr<T>::v4& out, T* slot, const Lane& ln, LogAcc<T>& la, bool& bad) {
+    using D = wv::Dpp<T>;
+    using wv::sfor;
+    using wv::sfor2;
+    T x[16], dinv[16];
+    wv::fence(a);
+    sfor<16>([&](auto k) {
+        constexpr int kk = decltype(k)::value;
+        const T cc = D::template bcast<kk>(a[kk]);
+        bad |= !(cc != T(0));
+        dinv[kk] = t_rcp<T>(cc);
+        la.mul(cc);
+        if constexpr (kk == 7) la.renorm();
+    });
+    la.renorm();
+    sfor<16>([&](auto i) { x[decltype(i)::value] = (ln.r == decltype(i)::value) ? T(1) : T(0); });
+    sfor<16>([&](auto k) {
+        constexpr int kk = decltype(k)::value;
+        x[kk] *= dinv[kk];
+        sfor2<kk + 1, 16>([&](auto i) { D::template fnmac<decltype(i)::value>(x[decltype(i)::value], a[kk], x[kk]); });
+    });
+    typename Tr<T>::v4 o[1];
+    wv::cols_out<T, 1, false>(x, o, slot, ln);
+    out = o[0];
+}
+
 // ---- the workgroup's LDS ---------------------------------------------------------------------------------------------------------------
 template <typename T, int NT, int MT> struct Lds {
     using G = PG<T, NT>;
     static constexpr int MP = 16 * MT;
     static constexpr int LDH = MP + (sizeof(T) == 4 ? 4 : 2);
-    static constexpr int ELEMS = 3 * G::IMG + G::DP * LDH + MP * LDH + NT * G::SLOT + 3 * G::DP + MP + 64;
+    static constexpr int VECS = 4 * G::DP + MP + 64;      // the vectors come first: low LDS addresses for the DMA destinations
+    static constexpr int ELEMS = VECS + 3 * G::IMG + G::DP * LDH + MP * LDH + NT * G::SLOT;
     static constexpr int BYTES = ELEMS * (int)sizeof(T);
     T* base;
-    MF_DEV T* I(int i) const { return base + i * G::IMG; }
-    MF_DEV T* IH() const { return base + 3 * G::IMG; }                        // holds H (MP x DP)
+    MF_DEV T* vec(int i) const { return base + i * G::DP; }                   // 0: rn, 1: t, 2: z, 3: mvec
+    MF_DEV T* ys() const { return vec(4); }
+    MF_DEV T* red() const { return ys() + MP; }
+    MF_DEV T* I(int i) const { return base + VECS + i * G::IMG; }
+    MF_DEV T* IH() const { return I(3); }                                     // holds H (MP x DP)
     MF_DEV T* IR() const { return IH() + G::DP * LDH; }                       // holds R^-1 (MP x MP, symmetric)
     MF_DEV T* slot(int i) const { return IR() + MP * LDH + i * G::SLOT; }     // inverse of diagonal tile i, row-major (mf_wave.hpp image)
-    MF_DEV T* vec(int i) const { return slot(NT) + i * G::DP; }               // 0: rn, 1: t, 2: z
-    MF_DEV T* ys() const { return vec(3); }
-    MF_DEV T* red() const { return ys() + MP; }
 };
-enum { V_RN = 0, V_T = 1, V_Z = 2 };
+enum { V_RN = 0, V_T = 1, V_Z = 2, V_M = 3 };
 
 template <typename T, int NT, int MT> struct Ctx {
     Lds<T, NT, MT> sm;
@@ -205,18 +355,32 @@ template <typename T, int NT, int MT> struct Ctx {
     int w;               // wavefront = panel index (wave-uniform)
 };
 
-// ---- C (lower triangular panels, tiles ti >= w) -> Ci = C^-1 (lower).  Barriers: 1.  Uses image 0 (holds C^T) and the slots. -----------
-template <typename T, int NT, int MT>
+// ---- C (lower triangular panels, tiles ti >= w) -> Ci = C^-1 (lower).  Barriers: 1.  Uses image 1 (holds C^T) and the slots. -----------
+// FROM_IMG: C^T is already in image 1 - every wavefront fetched its OWN sixteen rows of C there by LDS-DMA (an image row of C^T is a
+// row of C) - and C is not in registers at all; the wavefront's diagonal tile is read by rows straight from the image.
+template <typename T, int NT, int MT, bool FROM_IMG>
 MF_DEV void tri_inv_panel(const Panel<T, NT>& C, Panel<T, NT>& Ci, const Ctx<T, NT, MT>& c, LogAcc<T>& la, bool& bad) {
     using v4 = typename Tr<T>::v4;
     using G = PG<T, NT>;
     const Lane& ln = c.ln;
-    T* I0 = c.sm.I(0);
-    MF_UNROLL for (int ti = 1; ti < NT; ++ti)
-        if (ti > c.w) img_put_t<T, G::LD>(I0, ti, c.w, C.t[ti], ln);
-    v4 in[1] = {C.t[0]}, o[1];
-    MF_UNROLL for (int j = 1; j < NT; ++j) if (is_wave(c.w, j)) in[0] = C.t[j];
-    wv::tri_inv_tiles<T, 1, false>(in, o, c.sm.slot(c.w), ln, la, bad);       // the slot keeps Ci_ww row-major
+    T* I1 = c.sm.I(1);
+    v4 o[1];
+    if constexpr (FROM_IMG) {
+        dma_wait();
+        T a[16];
+        const T* row = I1 + (16 * c.w + ln.r) * G::LD + 16 * c.w;
+        MF_UNROLL for (int k4 = 0; k4 < 4; ++k4) {
+            const v4 t4 = *reinterpret_cast<const typename V4A<T>::type*>(row + 4 * k4);
+            MF_UNROLL for (int e = 0; e < 4; ++e) a[4 * k4 + e] = t4[e];
+        }
+        tri_inv_rows<T>(a, o[0], c.sm.slot(c.w), ln, la, bad);
+    } else {
+        MF_UNROLL for (int ti = 1; ti < NT; ++ti)
+            if (ti > c.w) img_put_t<T, G::LD>(I1, ti, c.w, C.t[ti], ln);
+        v4 in[1] = {C.t[0]};
+        MF_UNROLL for (int j = 1; j < NT; ++j) if (is_wave(c.w, j)) in[0] = C.t[j];
+        wv::tri_inv_tiles<T, 1, false>(in, o, c.sm.slot(c.w), ln, la, bad);       // the slot keeps Ci_ww row-major
+    }
     __syncthreads();
     Ci.zero();
     MF_UNROLL for (int j = 0; j < NT; ++j) if (is_wave(c.w, j)) Ci.t[j] = o[0];
@@ -226,7 +390,7 @@ MF_DEV void tri_inv_panel(const Panel<T, NT>& C, Panel<T, NT>& Ci, const Ctx<T, 
         v4 acc = {0, 0, 0, 0};
         MF_UNROLL for (int k = 0; k < i; ++k) {
             if (k < c.w) continue;
-            acc = mm<T>(img_tile<T, G::LD>(I0, k, i, ln), Ci.t[k], acc);          // tile (k, i) of C^T: the A operand of C(i, k) Q
+            acc = mm<T>(img_tile<T, G::LD>(I1, k, i, ln), Ci.t[k], acc);          // tile (k, i) of C^T: the A operand of C(i, k) Q
         }
         v4 dt;
         wv::image_to_tile_t<T>(dt, c.sm.slot(i), ln);                             // Ci_ii^T: the A operand of Ci_ii Q
@@ -235,9 +399,10 @@ MF_DEV void tri_inv_panel(const Panel<T, NT>& C, Panel<T, NT>& Ci, const Ctx<T, 
 }
 
 // ---- Phi (symmetric, tiles ti <= w valid; consumed) -> LiT = chol(Phi)^-T (upper: tiles ti <= w).  Barriers: 2 NT - 1. ------------------
-// Uses image 1 (holds U = L^T), image 2 (holds U^T) and the slots.
-template <typename T, int NT, int MT>
-MF_DEV void chol_inv_panel(Panel<T, NT>& Phi, Panel<T, NT>& LiT, const Ctx<T, NT, MT>& c, LogAcc<T>& la, bool& bad) {
+// Uses image 1 (holds U = L^T), image 2 (holds U^T) and the slots.  first(): called behind the first barrier (whatever the workgroup
+// read from the images before the call has been read by then).
+template <typename T, int NT, int MT, typename First>
+MF_DEV void chol_inv_panel(Panel<T, NT>& Phi, Panel<T, NT>& LiT, const Ctx<T, NT, MT>& c, LogAcc<T>& la, bool& bad, First first) {
     using v4 = typename Tr<T>::v4;
     using G = PG<T, NT>;
     const Lane& ln = c.ln;
@@ -251,6 +416,7 @@ MF_DEV void chol_inv_panel(Panel<T, NT>& Phi, Panel<T, NT>& LiT, const Ctx<T, NT
             own = o[0];                                                           // Li_jj^T = U_jj^-1 in the accumulator layout
         }
         __syncthreads();
+        if (j == 0) first();
         if (j + 1 < NT) {
             if (c.w > j) {
                 v4 lt;
@@ -287,9 +453,9 @@ MF_DEV void chol_inv_panel(Panel<T, NT>& Phi, Panel<T, NT>& LiT, const Ctx<T, NT
 
 // ---- the elimination state of one chunk ------------------------------------------------------------------------------------------------
 template <typename T, int NT> struct PanelElim {
-    Panel<T, NT> Phi;      // symmetric (tiles ti <= w): pivot of the current block
+    Panel<T, NT> Phi;      // symmetric, all tiles formed (the factorisation reads the tiles ti <= w): pivot of the current block
     Panel<T, NT> X;        // coupling current block <-> the chunk's left separator
-    Panel<T, NT> GU;       // symmetric (tiles ti <= w): accumulated contribution to the separator's pivot
+    Panel<T, NT> GU;       // symmetric, all tiles formed: accumulated contribution to the separator's pivot
     T t, gU;               // own entries of the right-hand sides
     T quad;                // own entries of z, squared and summed
     LogAcc<T> laL;
@@ -304,66 +470,85 @@ template <typename T, int NT> struct PanelElim {
 
 // Eliminate the block whose complete pivot is in E.Phi and whose right-hand side is E.t; then advance to the next block, whose own
 // pivot / right-hand-side parts are Dn (tiles ti <= w) / rn and whose coupling to the eliminated block is W with WT = W^T = Li S^T.
-//   ST_FROM_S: S is the wavefront's panel of the coupling S (level 0: transposed through image 1);
+//   ST_FROM_S: S is the wavefront's panel of the coupling S (level 0: transposed through image 0);
 //   else:      S already holds the panel of S^T (reduction levels: the coupling is read transposed from memory).
-// Images: 0 <- LiT, 1 <- S^T then WT, 2 <- V.  Barriers: 2 NT - 1 + 3.  late(): called at the end, where few panels are
-// live - the place for the next step's first global loads.
-template <typename T, int NT, int MT, bool ST_FROM_S, typename Late>
+// Images: 0 <- S^T, then WT;  1 <- U, then LiT;  2 <- U^T, then V.  A panel that has gone into its image is re-read from there as the B
+// operand of a later product instead of staying in registers (S, V, WT: 48 registers at the step's widest point).
+// Barriers: 2 NT - 1 + 3.  mid(): called behind the last barrier, in front of the last two products: image 1 and the vectors are
+// free from there on - the place where the next step's inputs are requested (LDS-DMA), two products ahead of their use.
+template <typename T, int NT, int MT, bool ST_FROM_S, typename Mid>
 MF_DEV void eliminate_advance(PanelElim<T, NT>& E, Panel<T, NT>& S, const Panel<T, NT>& Dn, T rn, bool spike,
-                              const Ctx<T, NT, MT>& c, Late late) {
+                              const Ctx<T, NT, MT>& c, Mid mid, Stamp& stamp) {
     using G = PG<T, NT>;
     const Lane& ln = c.ln;
     const int w = c.w;
     T *I0 = c.sm.I(0), *I1 = c.sm.I(1), *I2 = c.sm.I(2);
     vec_put<T>(c.sm.vec(V_T), w, E.t, ln);
-    Panel<T, NT> LiT;
-    chol_inv_panel<T, NT, MT>(E.Phi, LiT, c, E.laL, E.bad);
     T z;
     {
+        Panel<T, NT> LiT;
+        chol_inv_panel<T, NT, MT>(E.Phi, LiT, c, E.laL, E.bad, [&]() __attribute__((always_inline)) {
+            if (ST_FROM_S) {
+                MF_UNROLL for (int ti = 0; ti < NT; ++ti) img_put_t<T, G::LD>(I0, ti, w, S.t[ti], ln);
+            }
+        });
+        MF_PSTAMP(stamp, 5)
         RV<T, NT> t_rv;
         vec_rv<T, NT>(t_rv, c.sm.vec(V_T), ln);
-        z = mv_panel<T, NT>(LiT.t, t_rv.v, [&](int ti) { return ti <= w; });            // z = Li t
+        z = mv_panel<T, NT>(LiT.t, t_rv.v);            // z = Li t
+        MF_UNROLL for (int ti = 0; ti < NT; ++ti)
+            if (ti <= w) img_put<T, G::LD>(I1, ti, w, LiT.t[ti], ln);
     }
-    E.quad = __builtin_fma(z, z, E.quad);
+    E.quad = fma_t(z, z, E.quad);
     vec_put<T>(c.sm.vec(V_Z), w, z, ln);
-    MF_UNROLL for (int ti = 0; ti < NT; ++ti)
-        if (ti <= w) img_put<T, G::LD>(I0, ti, w, LiT.t[ti], ln);
-    if (ST_FROM_S) {
-        MF_UNROLL for (int ti = 0; ti < NT; ++ti) img_put_t<T, G::LD>(I1, ti, w, S.t[ti], ln);
-    }
     __syncthreads();
-    Panel<T, NT> V;
-    if (spike) {
-        tn_img<T, NT, NT, G::LD, OP_SET>(V, I0, E.X.t, ln, [](int) { return true; }, [](int tk, int ti) { return tk <= ti; });     // V = Li X
-        RV<T, NT> z_rv;
-        vec_rv<T, NT>(z_rv, c.sm.vec(V_Z), ln);
-        E.gU -= mv_panel<T, NT>(V.t, z_rv.v, [](int) { return true; });                                                            // gU -= V^T z
-        MF_UNROLL for (int ti = 0; ti < NT; ++ti) img_put<T, G::LD>(I2, ti, w, V.t[ti], ln);
-    }
+    MF_PSTAMP(stamp, 6)
     Panel<T, NT> WT;
     {
         Panel<T, NT> ST;
         if (ST_FROM_S) {
-            MF_UNROLL for (int tk = 0; tk < NT; ++tk) ST.t[tk] = img_tile<T, G::LD>(I1, tk, w, ln);
+            MF_UNROLL for (int tk = 0; tk < NT; ++tk) ST.t[tk] = img_tile<T, G::LD>(I0, tk, w, ln);
         } else {
             ST = S;
         }
-        tn_img<T, NT, NT, G::LD, OP_SET>(WT, I0, ST.t, ln, [](int) { return true; }, [](int tk, int ti) { return tk <= ti; });     // W^T = Li S^T
+        tn_img<T, NT, NT, G::LD, OP_SET, P_UPPER>(WT, I1, ST.t, ln);     // W^T = Li S^T
+    }
+    if (spike) {
+        Panel<T, NT> V;
+        tn_img<T, NT, NT, G::LD, OP_SET, P_UPPER>(V, I1, E.X.t, ln);     // V = Li X
+        RV<T, NT> z_rv;
+        vec_rv<T, NT>(z_rv, c.sm.vec(V_Z), ln);
+        E.gU -= mv_panel<T, NT>(V.t, z_rv.v);                                                            // gU -= V^T z
+        MF_UNROLL for (int ti = 0; ti < NT; ++ti) img_put<T, G::LD>(I2, ti, w, V.t[ti], ln);
     }
     __syncthreads();
-    MF_UNROLL for (int ti = 0; ti < NT; ++ti) img_put<T, G::LD>(I1, ti, w, WT.t[ti], ln);
-    if (spike)
-        tn_img<T, NT, NT, G::LD, OP_SUB>(E.GU, I2, V.t, ln, [&](int ti) { return ti <= w; }, [](int, int) { return true; });         // GU -= V^T V
-    __syncthreads();
+    MF_PSTAMP(stamp, 7)
+    MF_UNROLL for (int ti = 0; ti < NT; ++ti) img_put<T, G::LD>(I0, ti, w, WT.t[ti], ln);
     {
-        RV<T, NT> z2;
-        vec_rv<T, NT>(z2, c.sm.vec(V_Z), ln);
-        E.t = rn - mv_panel<T, NT>(WT.t, z2.v, [](int) { return true; });                                                          // t = rn - W z
+        RV<T, NT> z_rv;
+        vec_rv<T, NT>(z_rv, c.sm.vec(V_Z), ln);
+        E.t = rn - mv_panel<T, NT>(WT.t, z_rv.v);                                                        // t = rn - W z
     }
+    if (spike) {
+        Panel<T, NT> Vq;
+        MF_UNROLL for (int tk = 0; tk < NT; ++tk) Vq.t[tk] = img_tile<T, G::LD>(I2, tk, w, ln);
+        tn_img<T, NT, NT, G::LD, OP_SUB, P_FULL>(E.GU, I2, Vq.t, ln);      // GU -= V^T V
+    }
+    __syncthreads();
+    MF_PSTAMP(stamp, 8)
+    mid();
     MF_UNROLL for (int ti = 0; ti < NT; ++ti) E.Phi.t[ti] = Dn.t[ti];
-    tn_img<T, NT, NT, G::LD, OP_SUB>(E.Phi, I1, WT.t, ln, [&](int ti) { return ti <= w; }, [](int, int) { return true; });           // Phi = Dn - W W^T
-    if (spike) tn_img<T, NT, NT, G::LD, OP_NEG>(E.X, I1, V.t, ln, [](int) { return true; }, [](int, int) { return true; });         // X = -W V
-    late();
+    {
+        Panel<T, NT> Wq;
+        MF_UNROLL for (int tk = 0; tk < NT; ++tk) Wq.t[tk] = img_tile<T, G::LD>(I0, tk, w, ln);
+        tn_img<T, NT, NT, G::LD, OP_SUB, P_FULL>(E.Phi, I0, Wq.t, ln);     // Phi = Dn - W W^T
+    }
+    if (spike) {
+        Panel<T, NT> Vq;
+        MF_UNROLL for (int tk = 0; tk < NT; ++tk) Vq.t[tk] = img_tile<T, G::LD>(I2, tk, w, ln);
+        tn_img<T, NT, NT, G::LD, OP_NEG, P_FULL>(E.X, I0, Vq.t, ln);              // X = -W V
+    }
+    MF_PSTAMP(stamp, 9)
 }
 
 // The last block of a final reduction: factor, z, nothing to advance to.
@@ -371,11 +556,11 @@ template <typename T, int NT, int MT> MF_DEV void eliminate_last(PanelElim<T, NT
     const int w = c.w;
     vec_put<T>(c.sm.vec(V_T), w, E.t, c.ln);
     Panel<T, NT> LiT;
-    chol_inv_panel<T, NT, MT>(E.Phi, LiT, c, E.laL, E.bad);
+    chol_inv_panel<T, NT, MT>(E.Phi, LiT, c, E.laL, E.bad, [] {});
     RV<T, NT> t_rv;
     vec_rv<T, NT>(t_rv, c.sm.vec(V_T), c.ln);
-    const T z = mv_panel<T, NT>(LiT.t, t_rv.v, [&](int ti) { return ti <= w; });
-    E.quad = __builtin_fma(z, z, E.quad);
+    const T z = mv_panel<T, NT>(LiT.t, t_rv.v);
+    E.quad = fma_t(z, z, E.quad);
     __syncthreads();
 }
 
@@ -392,8 +577,8 @@ template <typename T, int NT> MF_DEV T wg_sum(T x, T* red, int w) {
 template <typename T, int NT, int MT>
 MF_DEV void store_chunk_panel(const RedSys<T>& out, long idx, int d, const PanelElim<T, NT>& E, T scalar, const Ctx<T, NT, MT>& c) {
     const long dd = long(d) * d;
-    store_panel<T, NT, true>(out.Dv + idx * dd, E.Phi, d, c.w, c.ln);
-    store_panel<T, NT, true>(out.GU + idx * dd, E.GU, d, c.w, c.ln);
+    store_panel<T, NT, false>(out.Dv + idx * dd, E.Phi, d, c.w, c.ln);
+    store_panel<T, NT, false>(out.GU + idx * dd, E.GU, d, c.w, c.ln);
     store_panel<T, NT, false>(out.F + idx * dd, E.X, d, c.w, c.ln);
     const int j = 16 * c.w + c.ln.r;
     if (c.ln.q == 0 && j < d) {
@@ -446,102 +631,136 @@ panel_kf_chunk_kernel(wv::WvArgs<T> a, RedSys<T> out) {
     Panel<T, NT> Dn, Am;
     typename Tr<T>::v4 Hp[MT];
     T rn = T(0);
-    // The block's own terms from its Cholesky factor C: Dn = Q^-1 (all tiles), rn = Q^-1 mvec; image 2 <- Q^-1; the observation rows
+    // The block's own terms from its Cholesky factor C: Dn = Q^-1 (all tiles), rn = Q^-1 mvec; image 1 <- Q^-1; the observation rows
     // (-> Hp) and the transition (Ag != NULL, -> Am) are loaded behind the inversion of C - their latency is covered by the product that
     // follows - and go into their images.  Ends with the barrier that publishes them.
-    auto own_terms = [&](const Panel<T, NT>& C, const T* __restrict__ mvec, long blk, const T* __restrict__ Ag) __attribute__((always_inline)) {
+    // DMA: the next block's chol(Q) goes straight into image 1 (= the image of C^T), fp32 and d = 16 NT only (an image row is then a
+    // row of C, at most 256 bytes; the fp64 image permutes its columns); the offset and observation vectors go by DMA in every case.
+    constexpr bool DMA = EX && sizeof(T) == 4;
+    // request the inputs that open the step of transition tau (block blk = tau + 1; tau < 0: the prior block 0).  Image 1, V_M and ys
+    // must be free.  Wavefront w fetches the rows 16 w ... 16 w + 15 of C; wavefront 0 the offset vector, the last one the observations.
+    auto request = [&](long tau) __attribute__((always_inline)) {
+        const T* Cg = tau < 0 ? a.cholP0 + s * dd : a.cholQ + (s * nt + tau) * dd;
+        const T* mv = tau < 0 ? a.mu0 + s * d : a.b + (s * nt + tau) * d;
+        const long blk = tau + 1;
+        if constexpr (DMA)
+            dma_rows16<G::DP * (int)sizeof(T), (G::LD - G::DP) * (int)sizeof(T)>(dma_srd(Cg + 16 * w * G::DP, 16 * G::DP * sizeof(T)),
+                                                         lds_addr(I1 + 16 * w * G::LD), 4u * (threadIdx.x & 63));
+        if (w == 0) dma_vec(mv, d * sizeof(T), c.sm.vec(V_M), G::DP * sizeof(T));
+        if (w == NT - 1) dma_vec(a.y + (s * a.Tn + blk) * m, m * sizeof(T), c.sm.ys(), L::MP * sizeof(T));
+    };
+    // The block's own terms from its Cholesky factor: Dn = Q^-1 (all tiles), rn = Q^-1 mvec; image 1 <- Q^-1; the observation rows
+    // (-> Hp) and the transition (Ag != NULL, -> Am) are loaded behind the inversion of C - their latency is covered by the product that
+    // follows - and go into their images.  Cg: the factor in memory (read here unless it came by DMA).  Ends with the barrier that
+    // publishes the images.
+    auto own_terms = [&](const T* __restrict__ Cg, long blk, const T* __restrict__ Ag, Stamp& stamp) __attribute__((always_inline)) {
         if (a.rinv_per_step) stage_rinv(a.Rinv + (s * a.Tn + blk) * m * m);
-        if (threadIdx.x < L::MP) c.sm.ys()[threadIdx.x] = (int)threadIdx.x < m ? a.y[(s * a.Tn + blk) * m + threadIdx.x] : T(0);
         Panel<T, NT> Ci;
-        tri_inv_panel<T, NT, MT>(C, Ci, c, laC, E.bad);
+        if constexpr (DMA) {
+            tri_inv_panel<T, NT, MT, true>(Ci, Ci, c, laC, E.bad);
+        } else {
+            Panel<T, NT> C;
+            load_panel<T, NT, EX>(C, Cg, d, w, true, true, ln);
+            dma_wait();                                       // (the vectors; C's loads are the compiler's)
+            tri_inv_panel<T, NT, MT, false>(C, Ci, c, laC, E.bad);
+        }
+        MF_PSTAMP(stamp, 0)
         if (Ag) load_panel<T, NT, EX>(Am, Ag, d, w, false, false, ln);
         load_rows_panel<T, MT>(Hp, a.H + (s * a.Tn + blk) * m * d, m, d, w, ln);
         MF_UNROLL for (int ti = 0; ti < NT; ++ti)
-            if (ti >= w) img_put<T, G::LD>(I1, ti, w, Ci.t[ti], ln);
+            if (ti >= w) img_put<T, G::LD>(I2, ti, w, Ci.t[ti], ln);
         __syncthreads();
-        tn_img<T, NT, NT, G::LD, OP_SET>(Dn, I1, Ci.t, ln, [](int) { return true; },
-                                         [&](int tk, int ti) { return tk >= ti && tk >= w; });                  // Q^-1 = Ci^T Ci
+        MF_PSTAMP(stamp, 1)
+        tn_img<T, NT, NT, G::LD, OP_SET, P_LOWER>(Dn, I2, Ci.t, ln);                                            // Q^-1 = Ci^T Ci
         {
             RV<T, NT> mv;
-            load_rv_g<T, NT>(mv.v, mvec, d, ln);
-            rn = mv_panel<T, NT>(Dn.t, mv.v, [](int) { return true; });                                         // Q^-1 mvec
-            acc_ww = __builtin_fma(rn, load_cv_g<T>(mvec, d, w, ln), acc_ww);                                   // mvec^T Q^-1 mvec
+            vec_rv<T, NT>(mv, c.sm.vec(V_M), ln);
+            rn = mv_panel<T, NT>(Dn.t, mv.v);                                                                   // Q^-1 mvec
+            acc_ww = fma_t(rn, c.sm.vec(V_M)[16 * w + ln.r], acc_ww);                                           // mvec^T Q^-1 mvec
         }
         vec_put<T>(c.sm.vec(V_RN), w, rn, ln);
-        MF_UNROLL for (int ti = 0; ti < NT; ++ti) img_put<T, G::LD>(I2, ti, w, Dn.t[ti], ln);
+        MF_UNROLL for (int ti = 0; ti < NT; ++ti) img_put<T, G::LD>(I1, ti, w, Dn.t[ti], ln);
         MF_UNROLL for (int to = 0; to < MT; ++to) img_put<T, L::LDH>(IH, to, w, Hp[to], ln);
         if (Ag) {
             MF_UNROLL for (int ti = 0; ti < NT; ++ti) img_put<T, G::LD>(I0, ti, w, Am.t[ti], ln);
         }
         __syncthreads();
+        MF_PSTAMP(stamp, 2)
     };
     // the observation terms on top: Dn += H^T R^-1 H, rn += H^T R^-1 y, y^T R^-1 y (kalman_filter.py:86-101)
     auto obs_terms = [&](long blk) __attribute__((always_inline)) {
         v4 Gp[MT];
         {
             Panel<T, MT> Gq;
-            tn_img<T, MT, MT, L::LDH, OP_SET>(Gq, IR, Hp, ln, [](int) { return true; }, [](int, int) { return true; });           // G = R^-1 H
+            tn_img<T, MT, MT, L::LDH, OP_SET, P_FULL>(Gq, IR, Hp, ln);           // G = R^-1 H
             MF_UNROLL for (int to = 0; to < MT; ++to) Gp[to] = Gq.t[to];
         }
-        tn_img<T, NT, MT, L::LDH, OP_ADD>(Dn, IH, Gp, ln, [](int) { return true; }, [](int, int) { return true; });                // += H^T G
+        tn_img<T, NT, MT, L::LDH, OP_ADD, P_FULL>(Dn, IH, Gp, ln);                // += H^T G
         {
             T yv[MT][4];
-            load_rv_g<T, MT>(yv, a.y + (s * a.Tn + blk) * m, m, ln);
-            rn += mv_panel<T, MT>(Gp, yv, [](int) { return true; });                                                              // += G^T y
+            MF_UNROLL for (int to = 0; to < MT; ++to)
+                MF_UNROLL for (int e = 0; e < 4; ++e) yv[to][e] = c.sm.ys()[16 * to + Tr<T>::row(ln.q, e)];
+            rn += mv_panel<T, MT>(Gp, yv);                                                              // += G^T y
         }
         {   // y^T R^-1 y: thread (o, part) takes the terms p = part, part + NPART, ... of row o (R^-1 symmetric: read down a column)
             constexpr int NPART = 64 * NT / L::MP;
             const int o = threadIdx.x % L::MP, part = threadIdx.x / L::MP;
             if (part < NPART) {
                 T acc = T(0);
-                for (int p = part; p < L::MP; p += NPART) acc = __builtin_fma(IR[p * L::LDH + 16 * (o >> 4) + pos16<T>(o & 15)], c.sm.ys()[p], acc);
-                acc_yry = __builtin_fma(acc, c.sm.ys()[o], acc_yry);
+                for (int p = part; p < L::MP; p += NPART) acc = fma_t(IR[p * L::LDH + 16 * (o >> 4) + pos16<T>(o & 15)], c.sm.ys()[p], acc);
+                acc_yry = fma_t(acc, c.sm.ys()[o], acc_yry);
             }
         }
     };
 
-    Panel<T, NT> Cn;
     if (ch == 0) {   // block 0: the prior
-        load_panel<T, NT, EX>(Cn, a.cholP0 + s * dd, d, w, true, true, ln);
-        own_terms(Cn, a.mu0 + s * d, 0, nullptr);
+        Stamp st0;
+        st0.init(c.sm.red() + 16);
+        request(-1);
+        own_terms(a.cholP0 + s * dd, 0, nullptr, st0);
         obs_terms(0);
         MF_UNROLL for (int ti = 0; ti < NT; ++ti) E.Phi.t[ti] = Dn.t[ti];
         E.t = rn;
         __syncthreads();
     }
-    if (len > 0) load_panel<T, NT, EX>(Cn, a.cholQ + (s * nt + tau0) * dd, d, w, true, true, ln);
+    if (len > 0) request(tau0);
+    Stamp stamp;
+    stamp.init(c.sm.red() + 16);
     for (long j = 0; j < len; ++j) {
         const long tau = tau0 + j, blk = tau + 1;
         asm volatile("" : "+v"(ln.r), "+v"(ln.q));
         if constexpr (!EX) asm volatile("" : "+s"(d));
-        own_terms(Cn, a.b + (s * nt + tau) * d, blk, a.A + (s * nt + tau) * dd);
+        MF_PSTAMP(stamp, 11)
+        own_terms(a.cholQ + (s * nt + tau) * dd, blk, a.A + (s * nt + tau) * dd, stamp);
         Panel<T, NT> S;
-        tn_img<T, NT, NT, G::LD, OP_NEG>(S, I2, Am.t, ln, [](int) { return true; }, [](int, int) { return true; });               // S = -Q^-1 A
+        tn_img<T, NT, NT, G::LD, OP_NEG, P_FULL>(S, I1, Am.t, ln);               // S = -Q^-1 A
         T btw;
         {
             RV<T, NT> rn_rv;
             vec_rv<T, NT>(rn_rv, c.sm.vec(V_RN), ln);
-            btw = mv_panel<T, NT>(Am.t, rn_rv.v, [](int) { return true; });                                                       // A^T Q^-1 mvec
+            btw = mv_panel<T, NT>(Am.t, rn_rv.v);                                                       // A^T Q^-1 mvec
         }
+        MF_PSTAMP(stamp, 3)
         obs_terms(blk);
+        MF_PSTAMP(stamp, 4)
         if (j == 0 && spike) {
             // the block on the left is the chunk's separator: its coupling seeds the spike
-            tn_img<T, NT, NT, G::LD, OP_NEG>(E.GU, I0, S.t, ln, [&](int ti) { return ti <= w; }, [](int, int) { return true; });   // GU = A^T Q^-1 A
+            tn_img<T, NT, NT, G::LD, OP_NEG, P_FULL>(E.GU, I0, S.t, ln);   // GU = A^T Q^-1 A
             E.X = S;
             E.gU = -btw;
             MF_UNROLL for (int ti = 0; ti < NT; ++ti) E.Phi.t[ti] = Dn.t[ti];
             E.t = rn;
-            if (j + 1 < len) load_panel<T, NT, EX>(Cn, a.cholQ + (s * nt + tau + 1) * dd, d, w, true, true, ln);
             __syncthreads();
+            if (j + 1 < len) request(tau + 1);
         } else {
-            tn_img<T, NT, NT, G::LD, OP_SUB>(E.Phi, I0, S.t, ln, [&](int ti) { return ti <= w; }, [](int, int) { return true; });  // D_{k-1} += A^T Q^-1 A
+            tn_img<T, NT, NT, G::LD, OP_SUB, P_FULL>(E.Phi, I0, S.t, ln);  // D_{k-1} += A^T Q^-1 A
             E.t -= btw;
-            // the next transition's Cholesky factor opens the next step: its loads are issued behind this step's last barrier
             eliminate_advance<T, NT, MT, true>(E, S, Dn, rn, spike, c, [&]() __attribute__((always_inline)) {
-                if (j + 1 < len) load_panel<T, NT, EX>(Cn, a.cholQ + (s * nt + tau + 1) * dd, d, w, true, true, ln);
-            });
+                if (j + 1 < len) request(tau + 1);
+            }, stamp);
         }
     }
+    stamp.print(len);
     // the chunk's scalar: every wavefront's share, summed
     T part = T(-0.5) * wv::sum16<T>(acc_ww) + T(0.5) * wv::sum16<T>(E.quad) - laC.value() - T(0.5) * E.laL.value();
     part += T(-0.5) * wv::sum16<T>(wv::xor_rows<T>(acc_yry));
@@ -589,7 +808,9 @@ panel_red_kernel(RedSys<T> in, RedSys<T> out, long B, long P, int d_, T add_cons
         if (k > k0) {
             Panel<T, NT> FT;
             load_panel_t<T, NT, EX>(FT, Fk, d, w, ln);
-            eliminate_advance<T, NT, 1, false>(E, FT, Dn, rn, spike, c, [] {});
+            Stamp stamp;
+            stamp.init(c.sm.red() + 16);
+            eliminate_advance<T, NT, 1, false>(E, FT, Dn, rn, spike, c, [] {}, stamp);
         } else {
             if (k > 0 && !FINAL) load_panel<T, NT, EX>(E.X, Fk, d, w, false, false, ln);
             MF_UNROLL for (int ti = 0; ti < NT; ++ti) E.Phi.t[ti] = Dn.t[ti];

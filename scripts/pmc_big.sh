@@ -8,7 +8,7 @@ f=$(find /tmp/pb_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && { he
 cut -c1-160 $OUT/kernel_stats.csv
 for CTRS in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE"; do
   n=$(echo $CTRS | tr ' ' '_' | cut -c1-30); rm -rf /tmp/pb_$n
-  timeout 300 rocprofv3 --pmc $CTRS --kernel-trace --kernel-include-regex "mf::big" --output-format csv -d /tmp/pb_$n -- $CMD > $OUT/pmc_$n.log 2>&1
+  timeout 300 rocprofv3 --pmc $CTRS --kernel-trace --kernel-include-regex "mf::(big|pn)" --output-format csv -d /tmp/pb_$n -- $CMD > $OUT/pmc_$n.log 2>&1
   f=$(find /tmp/pb_$n -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python3 - "$f" <<'PY' | tee -a $OUT/pmc_summary.txt
 import csv, sys, collections
