@@ -16,6 +16,7 @@
 #include "mf_wave_api.hpp"
 
 #include "mf_env.hpp"
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 

@@ -846,6 +846,9 @@ __global__ void __launch_bounds__(NTHR) big_red_kernel(RedSys<real> in, RedSys<r
 
 
 constexpr long BIG_RED_CHUNK = 8, BIG_RED_FINAL = 8;
+// the panel kernels' reduction levels: a block step costs ~10 us whatever the number of workgroups, so the tree is made shallow in
+// SERIAL steps - 64 chunk ends -> 16 -> 4 -> 1 is 3 + 3 + 4 block steps in three launches, radix 8 is 7 + 8 in two
+constexpr long PANEL_RED_CHUNK = 4, PANEL_RED_FINAL = 4;
 inline long cdivl(long a, long b) { return (a + b - 1) / b; }
 inline size_t align_up_big(size_t x) { return (x + 255) & ~size_t(255); }
 inline long red_elems(int d) { return 3L * d * d + 2L * d + 1; }
@@ -937,8 +940,8 @@ inline int launch_panel(long B, long Tn, int d, int m, const real* mu0, const re
     int rc = panel_kf_level0(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, L, cur, info, st);
     if (rc != 0) return rc;
     if (ev1) (void)hipEventRecord(ev1, st);
-    while (cur.n > BIG_RED_FINAL) {
-        const long Pn = cdivl(cur.n, BIG_RED_CHUNK);
+    while (cur.n > PANEL_RED_FINAL) {
+        const long Pn = cdivl(cur.n, PANEL_RED_CHUNK);
         RedSys<real> nxt = carve_big(p, B, Pn, d);
         rc = panel_red(cur, nxt, B, Pn, d, real(0), static_cast<real*>(nullptr), info, 0, st);
         if (rc != 0) return rc;
@@ -956,13 +959,16 @@ inline long wave_target(int d) {
     // good or better: 1.555 against 1.58 ms; 2 x 2 tiles: one round, more chunks only add spikes)
     return 256L * 4 * wave_waves_per_simd(d, (int)sizeof(real)) * (d <= 16 && sizeof(real) == 4 ? 2 : 1);
 }
-inline size_t kf_loglik_ws_for(long B, long Tn, int d, long chunks, long wtarget) {
+inline long panel_target_small() { return sizeof(real) == 4 ? 2048 : 1024; }
+inline size_t kf_loglik_ws_for(long B, long Tn, int d, long chunks, long wtarget, bool panel = false) {
     long P, L;
     big_partition(B, Tn, chunks, P, L, wtarget);
+    // (the panel kernels' levels shrink by PANEL_RED_CHUNK)
+    const long rchunk = panel ? PANEL_RED_CHUNK : BIG_RED_CHUNK, rfinal = panel ? PANEL_RED_FINAL : BIG_RED_FINAL;
     size_t total = red_bytes_big(B, P, d);
     long n = P;
-    while (n > BIG_RED_FINAL) {
-        n = cdivl(n, BIG_RED_CHUNK);
+    while (n > rfinal) {
+        n = cdivl(n, rchunk);
         total += red_bytes_big(B, n, d);
     }
     return total;
@@ -972,7 +978,10 @@ inline size_t kf_loglik_ws(long B, long Tn, int d, long chunks) {
     const size_t w0 = kf_loglik_ws_for(B, Tn, d, chunks, 0);
     const long wt = wave_target(d);
     const size_t w1 = wt > 0 ? kf_loglik_ws_for(B, Tn, d, chunks, wt) : 0;
-    return w0 > w1 ? w0 : w1;
+    size_t w2 = 0;
+    if (d > 32) w2 = kf_loglik_ws_for(B, Tn, d, chunks, 0, true);
+    else if (d > 16) w2 = kf_loglik_ws_for(B, Tn, d, chunks, panel_target_small(), true);
+    return std::max(std::max(w0, w1), w2);
 }
 
 inline int kf_loglik(long B, long Tn, int d, int m, const real* mu0, const real* cholP0, const real* A, const real* b,
@@ -985,6 +994,8 @@ inline int kf_loglik(long B, long Tn, int d, int m, const real* mu0, const real*
     const long wt = (m <= 4 && Tn >= 2) ? wave_target(d) : 0;
     const bool wave = wt > 0 && wave_covers(d, m);
     big_partition(B, Tn, chunks, P, L, wave ? wt : 0);
+    // (two wavefronts per workgroup at d <= 32: four - fp32: eight - workgroups fit a CU)
+    if (panel_path(d, m) && d <= 32) big_partition(B, Tn, chunks, P, L, panel_target_small());
     if (panel_path(d, m))
         return launch_panel(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, add_const, out, ws, info, P, L, ev0, ev1,
                             st);

@@ -588,7 +588,7 @@ MF_DEV void store_chunk_panel(const RedSys<T>& out, long idx, int d, const Panel
     if (threadIdx.x == 0) out.sc[idx] = scalar;
 }
 
-template <typename T, int NT, int MT> constexpr int panel_wpe() { return sizeof(T) == 4 ? 2 : 1; }
+template <typename T, int NT, int MT> constexpr int panel_wpe() { return NT <= 2 ? (sizeof(T) == 4 ? 4 : 2) : (sizeof(T) == 4 ? 2 : 1); }
 
 // Level 0: workgroup (s, c) eliminates the transitions [c L, min((c+1) L, T-1)) of series s.
 template <typename T, int NT, int MT, bool EX>
@@ -788,34 +788,48 @@ panel_red_kernel(RedSys<T> in, RedSys<T> out, long B, long P, int d_, T add_cons
     PanelElim<T, NT> E;
     E.init();
     T acc_sc = T(0);
-    for (long k = k0; k < k1; ++k) {
-        asm volatile("" : "+v"(ln.r), "+v"(ln.q));
-        if constexpr (!EX) asm volatile("" : "+s"(d));
+    // block k's inputs: own pivot / right-hand-side parts (Dv[k] + GU[k + 1]: the next chunk's contribution to its separator) and the
+    // coupling to block k - 1, transposed.  They are requested one block AHEAD, in front of the elimination of block k - 1.
+    struct Blk {
+        Panel<T, NT> Dn, G2, FT;
+        T rn, sc;
+    };
+    auto load_blk = [&](Blk& bk, long k, bool coupling) __attribute__((always_inline)) {
         const long idx = s * in.n + k;
         const bool has_next = in.GU && (k + 1 < in.n);
-        if (in.sc) acc_sc += in.sc[idx];
-        // the block's own pivot / right-hand-side parts (padded diagonal = 1 keeps the padded states harmless)
-        Panel<T, NT> Dn;
-        load_panel<T, NT, EX>(Dn, in.Dv + idx * dd, d, w, false, true, ln);
-        T rn = load_cv_g<T>(in.tv + idx * d, d, w, ln);
+        bk.sc = in.sc ? in.sc[idx] : T(0);
+        load_panel<T, NT, EX>(bk.Dn, in.Dv + idx * dd, d, w, false, true, ln);
+        bk.rn = load_cv_g<T>(in.tv + idx * d, d, w, ln);
         if (has_next) {
-            Panel<T, NT> G2;
-            load_panel<T, NT, EX>(G2, in.GU + (idx + 1) * dd, d, w, false, false, ln);
-            MF_UNROLL for (int ti = 0; ti < NT; ++ti) Dn.t[ti] += G2.t[ti];
-            rn += load_cv_g<T>(in.gU + (idx + 1) * d, d, w, ln);
-        }
-        const T* Fk = in.F + (s * in.f_stride + k + in.f_off) * dd;
-        if (k > k0) {
-            Panel<T, NT> FT;
-            load_panel_t<T, NT, EX>(FT, Fk, d, w, ln);
-            Stamp stamp;
-            stamp.init(c.sm.red() + 16);
-            eliminate_advance<T, NT, 1, false>(E, FT, Dn, rn, spike, c, [] {}, stamp);
+            load_panel<T, NT, EX>(bk.G2, in.GU + (idx + 1) * dd, d, w, false, false, ln);
+            bk.rn += load_cv_g<T>(in.gU + (idx + 1) * d, d, w, ln);
         } else {
-            if (k > 0 && !FINAL) load_panel<T, NT, EX>(E.X, Fk, d, w, false, false, ln);
-            MF_UNROLL for (int ti = 0; ti < NT; ++ti) E.Phi.t[ti] = Dn.t[ti];
-            E.t = rn;
+            bk.G2.zero();
         }
+        if (coupling) load_panel_t<T, NT, EX>(bk.FT, in.F + (s * in.f_stride + k + in.f_off) * dd, d, w, ln);
+    };
+    {
+        // the chunk's first block: nothing to eliminate yet; its coupling (k0 > 0) is the one to the chunk's left separator
+        Blk b0;
+        load_blk(b0, k0, false);
+        if (k0 > 0 && !FINAL) load_panel<T, NT, EX>(E.X, in.F + (s * in.f_stride + k0 + in.f_off) * dd, d, w, false, false, ln);
+        MF_UNROLL for (int ti = 0; ti < NT; ++ti) E.Phi.t[ti] = b0.Dn.t[ti] + b0.G2.t[ti];
+        E.t = b0.rn;
+        acc_sc += b0.sc;
+    }
+    Blk nx;
+    if (k0 + 1 < k1) load_blk(nx, k0 + 1, true);
+    for (long k = k0 + 1; k < k1; ++k) {
+        asm volatile("" : "+v"(ln.r), "+v"(ln.q));
+        if constexpr (!EX) asm volatile("" : "+s"(d));
+        Panel<T, NT> Dn, FT = nx.FT;
+        MF_UNROLL for (int ti = 0; ti < NT; ++ti) Dn.t[ti] = nx.Dn.t[ti] + nx.G2.t[ti];
+        const T rn = nx.rn;
+        acc_sc += nx.sc;
+        if (k + 1 < k1) load_blk(nx, k + 1, true);
+        Stamp stamp;
+        stamp.init(c.sm.red() + 16);
+        eliminate_advance<T, NT, 1, false>(E, FT, Dn, rn, spike, c, [] {}, stamp);
     }
     if (FINAL) eliminate_last<T, NT, 1>(E, c);
     T part = T(0.5) * wv::sum16<T>(E.quad) - T(0.5) * E.laL.value();

@@ -26,6 +26,7 @@ int panel_level0(long B, long Tn, int d, int m, const T* mu0, const T* cholP0, c
                  const T* y, const T* Rinv, int rinv_per_step, long P, long L, const RedSys<T>& out, int* info, hipStream_t st) {
     if (!panel_covers(d, m)) return -101;
     const wv::WvArgs<T> a{B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, L, info};
+    if (d <= 32) return m <= 16 ? panel_launch0_ex<T, 2, 1>(a, out, st) : panel_launch0_ex<T, 2, 2>(a, out, st);
     if (d <= 48) return m <= 16 ? panel_launch0_ex<T, 3, 1>(a, out, st) : panel_launch0_ex<T, 3, 2>(a, out, st);
     return m <= 16 ? panel_launch0_ex<T, 4, 1>(a, out, st) : panel_launch0_ex<T, 4, 2>(a, out, st);
 }
@@ -51,13 +52,18 @@ int panel_red_nt(const RedSys<T>& in, const RedSys<T>& out, long B, long P, int 
 template <typename T>
 int panel_red_t(const RedSys<T>& in, const RedSys<T>& out, long B, long P, int d, T add_const, T* out_scalar, int* info, int fin,
                 hipStream_t st) {
-    if (!panel_covers(d, 1)) return -101;
+    if (d <= 16 || d > 64) return -101;
+    if (d <= 32) return panel_red_nt<T, 2>(in, out, B, P, d, add_const, out_scalar, info, fin, st);
     return d <= 48 ? panel_red_nt<T, 3>(in, out, B, P, d, add_const, out_scalar, info, fin, st)
                    : panel_red_nt<T, 4>(in, out, B, P, d, add_const, out_scalar, info, fin, st);
 }
 }  // namespace
 
-bool panel_covers(int d, int m) { return d > 32 && d <= 64 && m >= 1 && m <= 32; }
+// 32 < d <= 64: every call.  16 < d <= 32: the calls with more than four outputs - up to four the wave kernels (mf_wave.hpp: the whole
+// chunk in one wavefront, no barrier) are 1.5-2.3 x faster than two wavefronts with barriers between them, beyond four they do not
+// exist and the LDS-tile engine took the call: 58 ms against 10 ms here at d = 32, m = 8, B = 512, T = 1000, fp64
+// (profiles/r06_panel_nt2_ab.txt).
+bool panel_covers(int d, int m) { return m >= 1 && m <= 32 && ((d > 32 && d <= 64) || (d > 16 && d <= 32 && m > 4)); }
 
 int panel_kf_level0_f64(long B, long Tn, int d, int m, const double* mu0, const double* cholP0, const double* A, const double* b,
                         const double* cholQ, const double* H, const double* y, const double* Rinv, int rinv_per_step, long P, long L,
