@@ -194,6 +194,20 @@ def other_configs(dev):
     out["config2_loglik_B256_T4096_d4_f64"] = {
         "ms": ms, "steps_per_s": 256 * 4096 / ms * 1e3,
         "algorithmic_GBps": 256 * 4096 * synthetic.loglik_bytes_per_step(4, 1, 8) / ms / 1e6}
+    # the headline shape in FLOAT32: B=1024, T=10000, d=6, m=1 on a chain fp32 can represent (three Matern-3/2
+    # components at gaps 0.2 + Exp(0.3): the headline's Matern-5/2 process covariances are below fp32 resolution at its gaps;
+    # tests/test_gpu_baseline_configs.py::test_headline_shape_fp32_on_a_chain_fp32_can_represent holds its parity)
+    inp = synthetic.make_ssm(1024, 10000, (3, 3, 3), dtype=torch.float32, device=dev, dt_min=0.2, dt_scale=0.3, jitter=1e-6)
+    kf = synthetic.kalman_filter_from(inp)
+    ms = _time_gpu(kf.log_likelihood)
+    b32 = synthetic.loglik_bytes_per_step(6, 1, 4)
+    out["headline_f32"] = {
+        "ms": ms, "steps_per_s": 1024 * 10000 / ms * 1e3, "bytes_per_step": b32,
+        "algorithmic_GBps": 1024 * 10000 * b32 / ms / 1e6, "frac_of_hbm_peak": 1024 * 10000 * b32 / ms / 1e6 / HBM_PEAK_GBS,
+        "note": "KalmanFilter.log_likelihood B=1024 T=10000 d=6 m=1 float32, whole call; 340 B/step algorithmic.  The fp32 rows are "
+                "144 B: three 128-B lines are touched for 2.25 lines of data on the two wide streams, and the step is issue-bound at "
+                "the same instruction count as fp64 with half the bytes (DESIGN.md, K0)"}
+    del inp, kf
     # config 3: SymmetricBlockTriDiagonal.cholesky + solve, T=100000 d=6 fp32, one chain (parallel-in-time path)
     n, d = 100000, 6
     g = torch.Generator(device=dev); g.manual_seed(3)
@@ -323,19 +337,43 @@ def other_configs(dev):
                 "training_step_ms: log_likelihood forward + backward w.r.t. every hyper-parameter (HIP generator backward + "
                 "Fisher-identity backward of the filter)"}
     del t_pts, y_obs, gpr
-    # config 5: state_dim 64, T=2048, fp32, 32 spatial outputs, 8 series (LDS-tiled MFMA path)
+    # config 5: state_dim 64, T=2048, fp32, 32 spatial outputs, 8 series - the panel kernels (csrc/mf_panel.hpp, round 6: a workgroup of
+    # four wavefronts per chunk, register-resident column panels, A operand through LDS, two workgroups per CU)
     bsz, tn, d, m = 8, 2048, 64, 32
     kf = synthetic.kalman_filter_from(synthetic.make_dense_ssm(bsz, tn, d, m, dtype=torch.float32, device=dev))
     ms = _time_gpu(kf.log_likelihood, iters=5)
+    # the level-0 kernel alone: HIP events around its launch, on the stream it is launched on
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    ev = (ctypes.c_void_p(), ctypes.c_void_p())
+    hip.hipEventCreate(ctypes.byref(ev[0])); hip.hipEventCreate(ctypes.byref(ev[1]))
+    kf._prof_events = ev
+    lvl0 = []
+    for _ in range(6):
+        kf.log_likelihood(); torch.cuda.synchronize()
+        f = ctypes.c_float(); hip.hipEventElapsedTime(ctypes.byref(f), ev[0], ev[1]); lvl0.append(f.value)
+    kf._prof_events = (None, None)
+    ms0 = sorted(lvl0[1:])[len(lvl0[1:]) // 2]
     # two flop models, both printed: ALGORITHMIC 9 d^3 per step (what the plain natural-order recursion needs) and
     # EXECUTED 15 d^3 (what the time-partitioned elimination performs, incl. the spike's three extra products)
     alg, exe = 9.0 * d ** 3, 15.0 * d ** 3
     out["config5_loglik_d64_T2048_m32_B8_f32"] = {
-        "ms": ms, "steps_per_s": bsz * tn / ms * 1e3,
+        "ms": ms, "steps_per_s": bsz * tn / ms * 1e3, "level0_kernel_ms": ms0,
         "algorithmic_TFLOPs": bsz * tn * alg / ms / 1e9, "frac_of_f32_mfma_peak_algorithmic": bsz * tn * alg / ms / 1e9 / 157.3,
         "executed_TFLOPs": bsz * tn * exe / ms / 1e9, "frac_of_f32_mfma_peak_executed": bsz * tn * exe / ms / 1e9 / 157.3,
-        "note": "whole log_likelihood() incl. reduction levels; flop models 9 d^3 (algorithmic, SURVEY 8d) and 15 d^3 (executed by "
-                "the partitioned elimination); MFMA busy counters: profiles/"}
+        "level0_algorithmic_TFLOPs": bsz * tn * alg / ms0 / 1e9, "level0_frac_of_f32_mfma_peak_algorithmic": bsz * tn * alg / ms0 / 1e9 / 157.3,
+        "note": "whole log_likelihood() incl. reduction levels, and its level-0 kernel alone (HIP events); flop models 9 d^3 (algorithmic, "
+                "SURVEY 8d) and 15 d^3 (executed by the partitioned elimination); rounds 2-5 (LDS-tile engine): 2.7 ms / level 0 2.25 ms, "
+                "matrix pipe 20.5 % busy; MFMA busy counters of this kernel: profiles/r06_panel_*_pmc_summary.txt"}
+    # the same shape in float64 - the reference's default float (state_space_model.py:294, models/spatio_temporal_variational.py:45-85):
+    # the panel kernels on v_mfma_f64_16x16x4_f64, one workgroup per CU (fp64 beyond d = 32 did not exist before round 6)
+    kf64 = synthetic.kalman_filter_from(synthetic.make_dense_ssm(bsz, tn, d, m, dtype=torch.float64, device=dev))
+    ms64 = _time_gpu(kf64.log_likelihood, iters=5)
+    out["config5_loglik_d64_T2048_m32_B8_f64"] = {
+        "ms": ms64, "steps_per_s": bsz * tn / ms64 * 1e3, "algorithmic_TFLOPs": bsz * tn * alg / ms64 / 1e9,
+        "frac_of_f64_mfma_peak_algorithmic": bsz * tn * alg / ms64 / 1e9 / 78.6,
+        "note": "float64 at config 5's shape; peak 78.6 TFLOP/s (v_mfma_f64_16x16x4_f64, nominal)"}
+    del kf64
     # the operators around it at the same shape: partitioned in time on the same tile engine since round 3 (csrc/mf_bigpar_impl.hpp)
     prec = kf.prior_ssm.precision
     t_chol = _time_gpu(lambda: mfa.SymmetricBlockTriDiagonal(prec.block_diagonal, prec.block_sub_diagonal).cholesky, iters=3, warm=1)

@@ -71,7 +71,9 @@ class BtdCholesky(torch.autograd.Function):
     def backward(ctx, g_ldiag, g_lsub):
         ldiag, lsub = ctx.saved_tensors
         lsub = lsub if ctx.has_sub else None
-        plan = _hip_grad_ws(ldiag)
+        # (under create_graph=True the backward runs with the tape ON: the raw adjoint kernels would drop the second-order terms
+        # silently, so that case takes the torch expressions below, which are recorded)
+        plan = None if torch.is_grad_enabled() else _hip_grad_ws(ldiag)
         if plan is None:
             return (None,) + _cholesky_backward_torch(ldiag, lsub, g_ldiag, g_lsub)
         bsz, n, d, wsb = plan
@@ -198,7 +200,9 @@ class BtdInverseBlocks(torch.autograd.Function):
         lsub = lsub if ctx.has_sub else None
         if not ctx.want_sub:
             g_sub = None
-        plan = _hip_grad_ws(ldiag)
+        # (under create_graph=True the backward runs with the tape ON: the raw adjoint kernels would drop the second-order terms
+        # silently, so that case takes the torch expressions below, which are recorded)
+        plan = None if torch.is_grad_enabled() else _hip_grad_ws(ldiag)
         if plan is None:
             g_chol, g_w = _inverse_blocks_backward_torch(ldiag, lsub, g_diag, g_sub)
             return None, g_chol, g_w, None
@@ -271,9 +275,10 @@ class BlockMatmul(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, y = ctx.saved_tensors
+        # through block_matmul() itself: under create_graph=True the products are nodes again (Hessian-vector products)
         g = g.contiguous()
-        gx = _block_matmul_kernel(g, _tr(y).contiguous()) if ctx.needs_input_grad[0] else None
-        gy = _block_matmul_kernel(_tr(x).contiguous(), g) if ctx.needs_input_grad[1] else None
+        gx = block_matmul(g, _tr(y).contiguous()) if ctx.needs_input_grad[0] else None
+        gy = block_matmul(_tr(x).contiguous(), g) if ctx.needs_input_grad[1] else None
         return gx, gy
 
 

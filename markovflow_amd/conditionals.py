@@ -40,7 +40,10 @@ def _conditional_statistics_from_transitions(state_transitions_to_t: torch.Tenso
     ``T = Q_mt - Q_mt A_tp^T (...)^-1 A_tp Q_mt``."""
     a_mt, q_mt, a_tp, q_tp = state_transitions_to_t, process_covariances_to_t, state_transitions_from_t, process_covariances_from_t
     lead, d = tuple(a_mt.shape[:-2]), a_mt.shape[-1]
-    if a_mt.is_cuda and d <= _lib.load().mf_max_state_dim() and not return_precision and a_mt.numel() > 0 \
+    # (the kernel takes four arrays of ONE shape; broadcastable inputs - which the reference's tf.matmul accepts - take the
+    # torch route below, which broadcasts)
+    same_shape = a_mt.shape == q_mt.shape == a_tp.shape == q_tp.shape
+    if a_mt.is_cuda and same_shape and d <= _lib.load().mf_max_state_dim() and not return_precision and a_mt.numel() > 0 \
             and not (torch.is_grad_enabled() and any(x.requires_grad for x in (a_mt, q_mt, a_tp, q_tp))):
         f = [_flat(x, 2) for x in (a_mt, q_mt, a_tp, q_tp)]
         n = f[0].shape[0]
@@ -129,7 +132,16 @@ def pairwise_marginals(dist: GaussMarkovDistribution, initial_mean: torch.Tensor
     """Mean ``batch + [num_transitions + 2, 2d]`` and covariance ``batch + [num_transitions + 2, 2d, 2d]`` of every pair of
     subsequent states ``(x_k, x_{k+1})``, the chain extended by the prior ``N(initial_mean, initial_covariance)`` before its
     first and after its last state (uncorrelated with the chain: the prior sits infinitely far away) - conditionals.py:424-485."""
-    means, covs, sub = dist._moments(want_sub=dist.num_transitions > 0)
+    needs_grad = getattr(dist, "_needs_grad", None)
+    if needs_grad is not None and needs_grad():
+        # under a tape: the differentiable moments, as the reference builds them (dist.marginals + dist.covariance_blocks(),
+        # conditionals.py:449-450) - `_moments` writes raw kernel outputs into fresh buffers and would drop the gradient silently
+        means = dist.marginal_means
+        covs, sub = dist.covariance_blocks()
+        if dist.num_transitions == 0:
+            sub = None
+    else:
+        means, covs, sub = dist._moments(want_sub=dist.num_transitions > 0)
     batch, d = tuple(dist.batch_shape), dist.state_dim
     m0 = initial_mean.to(means.dtype).expand(batch + (d,))[..., None, :]
     p0 = initial_covariance.to(covs.dtype).expand(batch + (d, d))[..., None, :, :]

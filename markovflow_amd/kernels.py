@@ -343,11 +343,20 @@ class StationaryKernel(SDEKernel, abc.ABC):
 _POSITIVE = {}
 
 
+def _version_key(t: torch.Tensor):
+    """``(data pointer, version counter)``: what the caches below compare.  The pointer catches ``set_()`` / ``.data = `` re-seating
+    (invisible to the version counter); inference tensors track no version at all - ``None``: never cached."""
+    if t.is_inference():
+        return None
+    return (t.data_ptr(), t._version)
+
+
 def _known_positive(*tensors: torch.Tensor) -> bool:
     fresh = []
     for t in tensors:
-        hit = _POSITIVE.get(id(t))
-        if hit is None or hit[0]() is not t or hit[1] != t._version:
+        key = _version_key(t)
+        hit = _POSITIVE.get(id(t)) if key is not None else None
+        if hit is None or hit[0]() is not t or hit[1] != key:
             fresh.append(t)
     if not fresh:
         return True
@@ -361,7 +370,9 @@ def _known_positive(*tensors: torch.Tensor) -> bool:
         if len(_POSITIVE) > 256:
             _POSITIVE.clear()
         for t in fresh:
-            _POSITIVE[id(t)] = (weakref.ref(t), t._version)
+            key = _version_key(t)
+            if key is not None:
+                _POSITIVE[id(t)] = (weakref.ref(t), key)
     return ok
 
 
@@ -394,10 +405,20 @@ class _MaternBase(StationaryKernel):
     def _lambda(self) -> torch.Tensor:
         if torch.is_grad_enabled() and self._lengthscale_t.requires_grad:
             return math.sqrt(self.order) / self._lengthscale_t       # a node of its own per use: graphs built from it stay independent
-        key = self._lengthscale_t._version                         # otherwise one division per kernel object, not one per use
+        key = _version_key(self._lengthscale_t)                    # otherwise one division per kernel object, not one per use
+        if key is None:                                            # (an inference tensor: no version to key a cache on)
+            return math.sqrt(self.order) / self._lengthscale_t
         if self._lambda_cached is None or self._lambda_cached[0] != key:
             self._lambda_cached = (key, math.sqrt(self.order) / self._lengthscale_t.detach())
         return self._lambda_cached[1]
+
+    def invalidate_cache(self) -> None:
+        """Forget what was derived from the hyper-parameters (``√order/ℓ``, the positivity check).  The caches are keyed on the
+        tensors' data pointer and version counter; a write THROUGH ``.data`` (``x.data.mul_()``) changes neither - call this
+        after one (as ``KalmanFilter.invalidate_filter_cache`` / ``GaussianProcessRegression.invalidate_hyperparameter_cache``)."""
+        self._lambda_cached = None
+        for t in (self._lengthscale_t, self._variance_t):
+            _POSITIVE.pop(id(t), None)
 
     def _components(self):
         return [self]

@@ -48,21 +48,22 @@ class ConditionalProcess:
         inf = torch.full(batch + (1,), APPROX_INF, dtype=dtype, device=dev)
         aug = torch.cat([-inf, train, inf], dim=-1)
         minus, plus = torch.gather(aug, -1, idx), torch.gather(aug, -1, idx + 1)
-        a_mt, q_mt = kern.transition_statistics(minus, new - minus)
-        a_tp, q_tp = kern.transition_statistics(new, plus - new)
-        means, covs, sub = dist._moments(want_sub=n > 1)
         m0 = kern.initial_mean(batch).to(dtype=dtype, device=dev).expand(batch + (d,)).contiguous()
         p0 = kern.initial_covariance(new[..., :1]).to(dtype=dtype, device=dev)
         p0 = p0.expand(batch + (d, d)).contiguous()
-        flat = lambda t, k: t.reshape((-1,) + tuple(t.shape[-k:])).contiguous()  # noqa: E731
-        bsz = max(1, int(torch.tensor(batch).prod())) if batch else 1
         if d > _lib.load().mf_max_state_dim():
             # beyond the lane-per-point kernel (d <= 9): the reference's own composition (posterior.py:217-221) of the functions of
             # conditionals.py - pairwise_marginals -> conditional_predict - as batched products (the posterior chain and its moments
-            # come from the row kernels / the tile engine)
+            # come from the row kernels / the tile engine).  Taken BEFORE the transitions and moments below are formed: those
+            # functions form their own
             from . import conditionals
             pair_mean, pair_cov = conditionals.pairwise_marginals(dist, m0, p0)
             return conditionals.conditional_predict(new, train, kern, pair_mean, pair_cov)
+        a_mt, q_mt = kern.transition_statistics(minus, new - minus)
+        a_tp, q_tp = kern.transition_statistics(new, plus - new)
+        means, covs, sub = dist._moments(want_sub=n > 1)
+        flat = lambda t, k: t.reshape((-1,) + tuple(t.shape[-k:])).contiguous()  # noqa: E731
+        bsz = max(1, int(torch.tensor(batch).prod())) if batch else 1
         out_mean = torch.empty((bsz, n_new, d), dtype=dtype, device=dev)
         out_cov = torch.empty((bsz, n_new, d, d), dtype=dtype, device=dev)
         info = _lib.pivot_info(dev)

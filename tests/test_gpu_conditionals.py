@@ -98,3 +98,48 @@ def test_pairwise_marginals_then_conditional_predict_against_the_dense_gp_and_th
     bm, bc = C.base_conditional_predict(proj, t_cov, states)
     np.testing.assert_allclose(nn(bm), nn((proj @ states[..., None])[..., 0]), rtol=1e-12)
     np.testing.assert_allclose(nn(bc), nn(t_cov), rtol=0, atol=0)
+
+
+def test_pairwise_marginals_carries_gradients_to_the_chain(rng):
+    """under a tape ``pairwise_marginals`` is built from the differentiable moments (the reference forms it from
+    ``dist.marginals`` / ``dist.covariance_blocks()`` under its tape, conditionals.py:449-450; its sparse / PEP models differentiate
+    through it).  Gradient of a scalar of both outputs w.r.t. every parameter of the chain against the dense torch composition
+    ``P_{k+1} = A_k P_k A_k^T + Q_k``, ``m_{k+1} = A_k m_k + b_k``, ``Cov(x_{k+1}, x_k) = A_k P_k``; fp64, rtol 1e-8."""
+    bsz, n, d = 2, 7, 3
+    g = torch.Generator(device=DEV); g.manual_seed(11)
+    rnd = lambda *s: torch.randn(*s, dtype=torch.float64, device=DEV, generator=g)                    # noqa: E731
+    eye = torch.eye(d, dtype=torch.float64, device=DEV)
+    leaves = [rnd(bsz, d), torch.tril(0.3 * rnd(bsz, d, d)) + eye, 0.5 * rnd(bsz, n - 1, d, d), 0.3 * rnd(bsz, n - 1, d),
+              torch.tril(0.3 * rnd(bsz, n - 1, d, d)) + eye]
+    m0, p0 = rnd(bsz, d), eye.expand(bsz, d, d) * 2.0
+    wm, wc = rnd(bsz, n + 1, 2 * d), rnd(bsz, n + 1, 2 * d, 2 * d)
+
+    def scalar(pm, pc):
+        return torch.sum(pm * wm) + torch.sum(pc * wc)
+
+    def ours(mu0, cp0, a, b, cq):
+        return scalar(*C.pairwise_marginals(mfa.StateSpaceModel(mu0, cp0, a, b, cq), m0, p0))
+
+    def dense(mu0, cp0, a, b, cq):
+        means, covs, subs = [mu0], [cp0 @ cp0.transpose(-1, -2)], []
+        for k in range(n - 1):
+            subs.append(a[:, k] @ covs[-1])
+            covs.append(a[:, k] @ covs[-1] @ a[:, k].transpose(-1, -2) + cq[:, k] @ cq[:, k].transpose(-1, -2))
+            means.append((a[:, k] @ means[-1][..., None])[..., 0] + b[:, k])
+        ext_m = torch.stack([m0] + means + [m0], dim=1)
+        ext_c = torch.stack([p0] + covs + [p0], dim=1)
+        zero = torch.zeros_like(p0)
+        ext_s = torch.stack([zero] + subs + [zero], dim=1)
+        pm = torch.cat([ext_m[:, :-1], ext_m[:, 1:]], dim=-1)
+        pc = torch.cat([torch.cat([ext_c[:, :-1], ext_s.transpose(-1, -2)], dim=-1), torch.cat([ext_s, ext_c[:, 1:]], dim=-1)], dim=-2)
+        return scalar(pm, pc)
+
+    a_leaves = [t.clone().requires_grad_(True) for t in leaves]
+    b_leaves = [t.clone().requires_grad_(True) for t in leaves]
+    va, vb = ours(*a_leaves), dense(*b_leaves)
+    assert float(va) == pytest.approx(float(vb), rel=1e-10)
+    ga, gb = torch.autograd.grad(va, a_leaves), torch.autograd.grad(vb, b_leaves)
+    for x, y, name in zip(ga, gb, ("mu0", "cholP0", "A", "b", "cholQ")):
+        if name.startswith("chol"):
+            x, y = torch.tril(x), torch.tril(y)
+        np.testing.assert_allclose(nn(x), nn(y), rtol=1e-8, atol=1e-10, err_msg=name)

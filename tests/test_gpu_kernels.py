@@ -293,3 +293,15 @@ def test_generator_backward_equals_autograd_through_the_closed_forms(rng, sig, p
     (torch.sum(w_a * a_t) + torch.sum(w_c * chol_t)).backward()
     for g, x in zip(got, ls + var):
         np.testing.assert_allclose(nn(g), nn(x.grad), rtol=1e-8, atol=1e-10)
+
+
+def test_kernel_under_inference_mode_on_the_device():
+    """kernels are built and evaluated under torch.inference_mode() (a common wrapper for prediction): the version-keyed
+    caches step aside for inference tensors; the transitions equal the ones formed outside it."""
+    t = torch.cumsum(0.1 + torch.rand(2, 50, dtype=torch.float64, device="cuda:0"), dim=-1)
+    ls, var = torch.tensor([0.7, 1.3], dtype=torch.float64, device="cuda:0"), torch.tensor([1.1, 0.6], dtype=torch.float64, device="cuda:0")
+    ref = mfa.Matern52(ls, var).state_space_model(t)
+    with torch.inference_mode():
+        got = mfa.Matern52(ls.clone(), var.clone()).state_space_model(t)
+        assert torch.equal(got.state_transitions, ref.state_transitions)
+        assert torch.equal(got.cholesky_process_covariances, ref.cholesky_process_covariances)

@@ -32,7 +32,9 @@ def test_argument_errors_without_touching_the_gpu():
     assert lib.mf_btd_solve_f32(2, 3, 4, 3, None, None, None, None, 0, None, 0, None) == -1
     assert lib.mf_kf_loglik_workspace_bytes(1024, 10000, 6, 8, 0) > 0
     assert lib.mf_kf_loglik_workspace_bytes(1024, 10000, 12, 8, 0) > 0      # LDS-tiled f64 MFMA path (d <= 32)
-    assert lib.mf_kf_loglik_workspace_bytes(1024, 10000, 40, 8, 0) == 0
+    assert lib.mf_kf_loglik_workspace_bytes(1024, 10000, 40, 8, 0) > 0       # fp64 log-likelihood up to d = 64: the panel kernels
+    assert lib.mf_kf_loglik_workspace_bytes(8, 100, 65, 8, 0) == 0
+    assert lib.mf_max_state_dim_f64_loglik() == 64 and lib.mf_max_state_dim_f64_tile_ops() == 32
     assert lib.mf_kf_loglik_workspace_bytes(1024, 10000, 64, 4, 0) > 0 and lib.mf_kf_loglik_workspace_bytes(8, 100, 65, 4, 0) == 0
     assert lib.mf_btd_cholesky_f64(0, 4, 3, None, None, None, None, None, 0, None, None) == 0   # empty batch is a no-op
 
@@ -444,3 +446,31 @@ def test_filter_cache_key_follows_the_source_tensors_not_their_flattened_copies(
                                torch.eye(d, dtype=torch.float64).expand(t - 1, d, d))
     kfs = mfa.KalmanFilterWithSites(ssm1, mfa.EmissionModel(torch.ones(t, 1, d, dtype=torch.float64)), sites)
     assert kfs._cache_key() == (None, None)
+
+
+def test_kernels_can_be_built_and_evaluated_under_inference_mode():
+    """the positivity / sqrt(order)/lengthscale caches are keyed on the autograd version counter, which inference tensors
+    do not have - building or evaluating a kernel under torch.inference_mode() must not raise."""
+    import markovflow_amd as mfa
+    with torch.inference_mode():
+        k = mfa.Matern32(torch.tensor(1.0, dtype=torch.float64), torch.tensor(2.0, dtype=torch.float64))
+        assert float(k._lambda) == pytest.approx(3 ** 0.5) and k.steady_state_covariance.shape == (2, 2)
+        s = mfa.Sum([k, mfa.Matern12(torch.tensor(0.5, dtype=torch.float64), torch.tensor(1.0, dtype=torch.float64))])
+        assert s.state_dim == 3
+    with pytest.raises(ValueError):
+        with torch.inference_mode():
+            mfa.Matern32(torch.tensor(-1.0, dtype=torch.float64), torch.tensor(2.0, dtype=torch.float64))
+
+
+def test_kernel_cache_follows_reseated_data_and_can_be_invalidated():
+    """a `set_()` re-seats the storage without touching the version counter - the cache key holds the data pointer
+    too; a write through `.data` is invisible to both and is what invalidate_cache() is for."""
+    import markovflow_amd as mfa
+    ls = torch.tensor(2.0, dtype=torch.float64)
+    k = mfa.Matern32(ls, torch.tensor(1.0, dtype=torch.float64))
+    lam0 = float(k._lambda)
+    ls.set_(torch.tensor(4.0, dtype=torch.float64))
+    assert float(k._lambda) == pytest.approx(lam0 / 2)
+    ls.data.mul_(2.0)
+    k.invalidate_cache()
+    assert float(k._lambda) == pytest.approx(lam0 / 4)
