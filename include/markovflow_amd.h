@@ -14,8 +14,11 @@
  *   - suffix _f32 / _f64 selects the scalar type; both are first class;
  *   - nothing is allocated inside: scratch comes from the caller (`*_workspace_bytes` + `ws`);
  *   - `stream` is a hipStream_t (passed as void*); all work is enqueued, nothing synchronises;
- *   - `info` (nullable) is a device int the kernels raise to 1 on a non-positive pivot
- *     (LAPACK info>0 style; results are then NaN);
+ *   - `info` (nullable) is a device int, zeroed by the caller, that the kernels raise on a non-positive pivot (LAPACK info > 0
+ *     style; results are then NaN from the failing block on).  The word NAMES the first failing block where the raising kernel
+ *     knows it - mf_info_flat_index(word) = series * blocks_per_series + block, the smallest such index over everything that
+ *     raised on this word (the Cholesky and log-likelihood kernels of the lane, streamed and panel forms) - and is 1 where it does
+ *     not (reduction levels, composite kernels): LAPACK's `info = 1 + flat index`, SURVEY 8(b), is `1 + mf_info_flat_index(word)`;
  *   - return value: 0 ok; -k = argument k (1-based) invalid; -100 = state dimension not instantiated for this entry
  *     point (register kernels 1..9, row kernels 10..15, wave / tile engines up to 64 in fp32 and 32 in fp64 - see
  *     mf_max_state_dim*, mf_row_operators_cover); -101 = this fused / streamed variant does not cover the call (the caller
@@ -38,6 +41,9 @@ int mf_version(void);
  * with the stream the mirror holds the final word of every factorising launch queued before (the reference raises inside the
  * Cholesky op, block_tri_diag.py:423-436; here the failure crosses the bus in stream order, never outside it). */
 int mf_info_mirror(int* host_mirror, const int* info, void* stream);
+/* Flat index (series * blocks_per_series + block) of the first block whose elimination met a non-positive pivot, decoded from an
+ * `info` word; -1 when the word is 0 (no failure) or 1 (a failure whose block the raising kernel could not name). */
+int64_t mf_info_flat_index(int info_word);
 int mf_max_state_dim(void);              /* every entry point, fp32 and fp64: register-resident kernels (9)       */
 /* 1 when the register / row kernels run EVERY operator for this shape: d <= 9 always; 10 <= d <= 15 (row kernels only: one
  * 16-lane row per chunk; many series or short chains run them with one chunk per series) for every chain of at least two

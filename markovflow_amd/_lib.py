@@ -67,6 +67,7 @@ _SIGS = {
 _PLAIN = {
     "mf_version": (_int, []),
     "mf_info_mirror": (_int, [_vp, _vp, _vp]),
+    "mf_info_flat_index": (_i64, [_int]),
     "mf_max_state_dim": (_int, []),
     "mf_row_operators_cover": (_int, [_i64, _i64, _int, _int]),
     "mf_max_state_dim_f32_loglik": (_int, []),
@@ -170,7 +171,19 @@ def stream_ptr(device) -> ctypes.c_void_p:
 
 
 class MarkovflowAmdError(RuntimeError):
-    pass
+    """A factorisation met a non-positive pivot (TensorFlow's Cholesky raises there, block_tri_diag.py:423-436).  Where the raising
+    kernel names the block: ``flat_index`` = series * blocks_per_series + block of the FIRST failing block (LAPACK's
+    ``info = 1 + flat_index``), and ``series`` / ``block`` when the blocks per series of the raising call are known."""
+
+    def __init__(self, message: str, flat_index=None, blocks_per_series=None):
+        self.flat_index, self.series, self.block = flat_index, None, None
+        if flat_index is not None:
+            message += f" [first non-positive pivot: flat block index {flat_index} (LAPACK info = {flat_index + 1})"
+            if blocks_per_series:
+                self.series, self.block = flat_index // blocks_per_series, flat_index % blocks_per_series
+                message += f" = series {self.series}, block {self.block} of {blocks_per_series}"
+            message += "]"
+        super().__init__(message)
 
 
 def small_state_dim(d: int, bsz: int, n: int, elem_size: int) -> bool:
@@ -317,6 +330,16 @@ class _Flag:
 
 _flags = {}      # (device index, stream handle) -> _Flag
 _issued = []     # names of factorising calls since the last clean look
+_issued_blocks = []   # blocks per series of those that said so (to turn a flat index into (series, block))
+
+
+class _Failure(str):
+    """The names of the operations a raised flag may belong to, with what the `info` word says about the block."""
+
+    def __new__(cls, ops, flat, blocks):
+        self = super().__new__(cls, ops)
+        self.flat, self.blocks = flat, blocks
+        return self
 
 
 def set_synchronous_checks(on: bool):
@@ -375,20 +398,25 @@ def _take_failures(synced: bool = False, synchronise: bool = False):
     if synchronise:
         for f in _flags.values():
             f.stream.synchronize()
-    bad = False
+    bad, word = False, 0
     for f in _flags.values():
         if f.view.value != 0:
             if not final:
                 f.stream.synchronize()
+            word = max(word, int(f.view.value))          # (the kernels combine with an atomic max: smallest flat index wins)
             f.clear()
             bad = True
     if not bad:
         if final:
             _issued.clear()
+            _issued_blocks.clear()
         return None
     ops = ", ".join(dict.fromkeys(_issued)) or "a factorisation"
+    flat = int(load().mf_info_flat_index(word))
+    blocks = _issued_blocks[-1] if _issued_blocks and len(set(_issued_blocks)) == 1 else None    # unambiguous only
     _issued.clear()
-    return ops
+    _issued_blocks.clear()
+    return _Failure(ops, flat if flat >= 0 else None, blocks)
 
 
 def raise_pending(synced: bool = False):
@@ -397,7 +425,7 @@ def raise_pending(synced: bool = False):
     if _flags and not _suppress:
         ops = _take_failures(synced)
         if ops is not None:
-            raise MarkovflowAmdError(f"matrix is not positive definite (non-positive pivot) in one of: {ops}")
+            raise MarkovflowAmdError(f"matrix is not positive definite (non-positive pivot) in one of: {ops}", ops.flat, ops.blocks)
 
 
 def check_errors():
@@ -405,7 +433,7 @@ def check_errors():
     if _flags and not _suppress:
         ops = _take_failures(synchronise=True)
         if ops is not None:
-            raise MarkovflowAmdError(f"matrix is not positive definite (non-positive pivot) in one of: {ops}")
+            raise MarkovflowAmdError(f"matrix is not positive definite (non-positive pivot) in one of: {ops}", ops.flat, ops.blocks)
     elif _flags:
         for f in _flags.values():
             f.stream.synchronize()
@@ -461,7 +489,7 @@ def checked_cholesky(mat: torch.Tensor, what: str) -> torch.Tensor:
     return chol
 
 
-def raise_on_info(info, what: str, device=None, more_follow: bool = False):
+def raise_on_info(info, what: str, device=None, more_follow: bool = False, blocks: Optional[int] = None):
     """Called right after a factorising launch: queues the copy of the flag into its pinned mirror behind the kernel.
     Synchronous mode: wait and raise now; default: remember the name.  ``more_follow``: the SAME evaluation issues another
     factorising launch on this stream before anything can reach the host (the observation precision in front of the
@@ -469,6 +497,10 @@ def raise_on_info(info, what: str, device=None, more_follow: bool = False):
     _issued.append(what)
     if len(_issued) > 64:
         del _issued[:-64]
+    if blocks:
+        _issued_blocks.append(int(blocks))
+        if len(_issued_blocks) > 64:
+            del _issued_blocks[:-64]
     if info is None:
         return
     if device is not None and not isinstance(device, torch.device):
@@ -485,4 +517,4 @@ def raise_on_info(info, what: str, device=None, more_follow: bool = False):
         torch.cuda.current_stream(idx).synchronize()
         ops = _take_failures(synced=True)
         if ops is not None:
-            raise MarkovflowAmdError(f"{what}: matrix is not positive definite")
+            raise MarkovflowAmdError(f"{what}: matrix is not positive definite", ops.flat, blocks or ops.blocks)

@@ -270,7 +270,7 @@ class SymmetricBlockTriDiagonal(BlockTriDiagonal):
         _lib.call("mf_btd_cholesky", diag.dtype, diag.shape[0], self.outer_dim, self.inner_dim, _lib.ptr(diag),
                   _lib.ptr(sub), _lib.ptr(ldiag), _lib.ptr(lsub), _lib.ptr(ws), ws_bytes, info,
                   _lib.stream_ptr(diag.device))
-        _lib.raise_on_info(info, "SymmetricBlockTriDiagonal.cholesky", diag.device)
+        _lib.raise_on_info(info, "SymmetricBlockTriDiagonal.cholesky", diag.device, blocks=diag.shape[-3])
         return LowerTriangularBlockTriDiagonal(
             ldiag.reshape(self._diag.shape), None if lsub is None else lsub.reshape(self._sub_diag.shape)
         )

@@ -190,6 +190,8 @@ int mf_info_mirror(int* host_mirror, const int* info, void* stream) {
     if (!info) return -2;
     return hipMemcpyAsync(host_mirror, info, sizeof(int), hipMemcpyDeviceToHost, S(stream)) == hipSuccess ? 0 : -1000;
 }
+// flat index (series x blocks per series + block) an `info` word names; -1: no failure, or a failure whose block is unknown (word 1)
+int64_t mf_info_flat_index(int info_word) { return info_word >= 2 ? (int64_t)(0x7fffffff - info_word) : -1; }   // (mf_small.hpp: MF_INFO_TOP)
 int mf_max_state_dim(void) { return mf::MF_MAX_D; }
 
 size_t mf_kf_loglik_workspace_bytes(int64_t B, int64_t T, int d, int elem_size, int64_t chunks) {

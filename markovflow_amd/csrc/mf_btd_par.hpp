@@ -307,6 +307,7 @@ __global__ void __launch_bounds__(64) par_chol_emit_kernel(long B, long n, long 
     LogAcc<T> la;
     la.init();
     bool bad = false;
+    long first_bad = -1;
     struct Step { T S[D][D]; T W[D][D]; };
     auto load = [&](long k, Step& d) {
         load_lower<T, D>(diag + (s * n + k) * D * D, d.S);
@@ -338,13 +339,14 @@ __global__ void __launch_bounds__(64) par_chol_emit_kernel(long B, long n, long 
             syrk_nt_lower<T, D, D>(cur.W, cur.S, T(-1));
         }
         chol_lower<T, D>(cur.S, Li, la, bad);
+        if (bad && first_bad < 0) first_bad = k;
         la.init();
         MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) L[i][j] = cur.S[i][j];
         store_lower<T, D>(ldiag + (s * n + k) * D * D, L);
         if (PF) cur = nxt;
         if (PF2) nxt = nx2;
     }
-    if (bad && info) raise_info(info);
+    if (bad && info) raise_pivot(info, s * n + (first_bad < 0 ? k0 : first_bad));
 }
 
 // ---- Solve: affine recursion z_p = M_p z_{p-1} + c_p over positions p (p = k, or n-1-k for the transposed solve) -----

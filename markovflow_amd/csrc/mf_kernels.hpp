@@ -165,6 +165,7 @@ __global__ void __launch_bounds__(64) kf_chunk_kernel(KfArgs<T> a, RedSys<T> out
     LogAcc<T> laC;
     laC.init();
     T acc_yry = T(0), acc_ww = T(0);
+    long first_bad = -1;          // the block whose elimination step first met a non-positive pivot
 
     for (long k = k0; k < k1; ++k) {
         T C[D][D], Ci[D][D], mvec[D], w[D];
@@ -215,6 +216,7 @@ __global__ void __launch_bounds__(64) kf_chunk_kernel(KfArgs<T> a, RedSys<T> out
             syrk_tn_lower<T, D, D>(Bm, E.Phi, T(1));    // D_{k-1} complete
             MF_UNROLL for (int i = 0; i < D; ++i) E.t[i] -= btw[i];
             E.eliminate();
+            if (E.bad && first_bad < 0) first_bad = k - 1;
             trsm_right_lower_t<T, D, D>(E.Phi, E.Li, Bm);   // Y = B L^-T
             trimulT_lower<T, D, D>(Ci, Bm, W);              // -W = C^-T Y
             MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j < D; ++j) W[i][j] = -W[i][j];
@@ -223,7 +225,7 @@ __global__ void __launch_bounds__(64) kf_chunk_kernel(KfArgs<T> a, RedSys<T> out
     }
     const T scalar = T(-0.5) * (acc_yry + acc_ww) + T(0.5) * E.quad - laC.value() - E.laL.value();
     store_chunk<T, D, SPIKE>(out, id, E, scalar);
-    if (E.bad && a.info) raise_info(a.info);
+    if (E.bad && a.info) raise_pivot(a.info, s * a.Tn + (first_bad < 0 ? k0 : first_bad));
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -402,6 +404,7 @@ __global__ void __launch_bounds__(64) btd_cholesky_kernel(long B, long n, const 
     LogAcc<T> la;
     la.init();
     bool bad = false;
+    long first_bad = -1;
     for (long k = 0; k < n; ++k) {
         T S[D][D];
         load_lower<T, D>(diag + (s * n + k) * D * D, S);
@@ -413,11 +416,12 @@ __global__ void __launch_bounds__(64) btd_cholesky_kernel(long B, long n, const 
             syrk_nt_lower<T, D, D>(W, S, T(-1));
         }
         chol_lower<T, D>(S, Li, la, bad);
+        if (bad && first_bad < 0) first_bad = k;
         la.init();
         MF_UNROLL for (int i = 0; i < D; ++i) MF_UNROLL for (int j = 0; j <= i; ++j) L[i][j] = S[i][j];
         store_lower<T, D>(ldiag + (s * n + k) * D * D, L);
     }
-    if (bad && info) raise_info(info);
+    if (bad && info) raise_pivot(info, s * n + first_bad);
 }
 
 // K2  LowerTriangularBlockTriDiagonal.solve (block_tri_diag.py:339-351); rhs series r uses factor r % Bl

@@ -577,9 +577,11 @@ __global__ void __launch_bounds__(64) kf_chunk_lds_kernel(KfArgs<T> a, long L, R
         MF_NOPUMP_ISSUE                                                                                               \
         const bool active = j < len;                                                                                  \
         kf_lds_step<T, D, M, SPIKE, FIRST>(E, laC, acc_yry, acc_ww, C, mvec, hk, yk, Rsh, Bm, pump, active, c > 0);    \
+        if (E.bad && first_bad < 0) first_bad = tau0 + j;                                                             \
         MF_STAMP_ACC                                                                                                  \
     }
     long j = 0;
+    long first_bad = -1;          // the block whose elimination step first met a non-positive pivot
     if (nsteps > 0) MF_KF_LDS_STEP(true)
     for (j = 1; j < nsteps; ++j) MF_KF_LDS_STEP(false)
 #undef MF_KF_LDS_STEP
@@ -587,7 +589,7 @@ __global__ void __launch_bounds__(64) kf_chunk_lds_kernel(KfArgs<T> a, long L, R
     if (valid) {
         const T scalar = T(-0.5) * (acc_yry + acc_ww) + T(0.5) * E.quad - laC.value() - E.laL.value();
         store_chunk<T, D, SPIKE>(out, id, E, scalar);
-        if (E.bad && a.info) raise_info(a.info);
+        if (E.bad && a.info) raise_pivot(a.info, s * a.Tn + (first_bad < 0 ? tau0 : first_bad));
 #ifdef MF_CHECKSUM
         out.GU[id * D * D + 0] = cs_A; out.GU[id * D * D + 1] = cs_C; out.GU[id * D * D + 2] = cs_b;
         out.gU[id * D + 0] = cs_H; out.gU[id * D + 1] = cs_y;

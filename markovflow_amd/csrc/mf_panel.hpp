@@ -726,6 +726,7 @@ panel_kf_chunk_kernel(wv::WvArgs<T> a, RedSys<T> out) {
     if (len > 0) request(tau0);
     Stamp stamp;
     stamp.init(c.sm.red() + 16);
+    long first_bad = -1;          // the block whose elimination step first met a non-positive pivot (per wavefront)
     for (long j = 0; j < len; ++j) {
         const long tau = tau0 + j, blk = tau + 1;
         asm volatile("" : "+v"(ln.r), "+v"(ln.q));
@@ -758,6 +759,7 @@ panel_kf_chunk_kernel(wv::WvArgs<T> a, RedSys<T> out) {
             eliminate_advance<T, NT, MT, true>(E, S, Dn, rn, spike, c, [&]() __attribute__((always_inline)) {
                 if (j + 1 < len) request(tau + 1);
             }, stamp);
+            if (E.bad && first_bad < 0) first_bad = tau;
         }
     }
     stamp.print(len);
@@ -766,7 +768,7 @@ panel_kf_chunk_kernel(wv::WvArgs<T> a, RedSys<T> out) {
     part += T(-0.5) * wv::sum16<T>(wv::xor_rows<T>(acc_yry));
     const T scalar = wg_sum<T, NT>(part, c.sm.red(), w);
     store_chunk_panel<T, NT, MT>(out, id, d, E, scalar, c);
-    if (__any(E.bad) && (threadIdx.x & 63) == 0 && a.info) raise_info(a.info);
+    if (__any(E.bad) && (threadIdx.x & 63) == 0 && a.info) raise_pivot(a.info, s * a.Tn + (first_bad < 0 ? tau0 : first_bad));
 }
 
 // Reduction level: RedSys(n) -> RedSys(P) (FINAL: P = 1, the last block is eliminated too and out_scalar written).  Same block

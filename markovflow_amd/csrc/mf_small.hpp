@@ -13,11 +13,18 @@
 #define MF_HD __host__ __device__ __forceinline__
 
 namespace mf {
-// Raise the caller's `info` flag (non-positive pivot): one int in DEVICE memory; all writers write the same value.  The host
-// learns of it through a stream-ordered copy queued behind the kernel (markovflow_amd/_lib.py), never through a store of
+// The caller's `info` word (non-positive pivot): one int in DEVICE memory, LAPACK-style.  0: every pivot positive.  Otherwise the
+// word is MF_INFO_TOP - f with f the FLAT INDEX (series x blocks per series + block) of a block whose elimination met a
+// non-positive pivot - the kernels combine with an atomic max, so the SMALLEST such index over everything that raised survives -
+// or 1 when the raising kernel cannot name the block (reduction levels, composite kernels).  Decoded by mf_info_flat_index().
+// The host learns of it through a stream-ordered copy queued behind the kernel (markovflow_amd/_lib.py), never through a store of
 // the kernel's own across the bus - that one could land after the stream's synchronisation had returned.
-__device__ __forceinline__ void raise_info(int* info) {
-    __hip_atomic_store(info, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+constexpr int MF_INFO_TOP = 0x7fffffff;
+__device__ __forceinline__ void raise_info(int* info) { atomicMax(info, 1); }
+__device__ __forceinline__ void raise_pivot(int* info, long flat) {
+    long f = flat < 0 ? 0 : flat;
+    if (f > (long)MF_INFO_TOP - 2) f = (long)MF_INFO_TOP - 2;
+    atomicMax(info, MF_INFO_TOP - (int)f);
 }
 }   // namespace mf
 #define MF_UNROLL _Pragma("unroll")

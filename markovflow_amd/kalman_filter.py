@@ -457,7 +457,7 @@ class BaseKalmanFilter(abc.ABC):
                   _lib.ptr(b_s), _lib.ptr(cq), _lib.ptr(h), _lib.ptr(y), _lib.ptr(r_inv), int(per_step),
                   0.0, _lib.ptr(out), _lib.ptr(ws), ws_bytes, info, chunks, self._prof_events[0],
                   self._prof_events[1], _lib.stream_ptr(a_s.device))
-        _lib.raise_on_info(info, "KalmanFilter.log_likelihood", a_s.device)
+        _lib.raise_on_info(info, "KalmanFilter.log_likelihood", a_s.device, blocks=n)
         usable = planned and path.value == 2 and p_f.value >= 2
         if self._keep_summaries:
             self._summaries = (ws, int(p_f.value), int(l_f.value)) if usable else None

@@ -95,7 +95,8 @@ def test_parallel_cholesky_flags_non_positive_definite(rng):
     info = _lib.new_info(dg.device)
     _lib.call("mf_btd_cholesky", torch.float64, 1, n, d, _lib.ptr(dg), _lib.ptr(sb), _lib.ptr(ld), _lib.ptr(ls),
               _lib.ptr(ws), ws_bytes, _lib.ptr(info), _lib.stream_ptr(dg.device))
-    assert int(info.item()) == 1
+    # (the up / down sweeps raise without a location, the emit pass names the block: the smallest flat index survives)
+    assert int(info.item()) > 0 and int(lib.mf_info_flat_index(int(info.item()))) == 137
 
 
 def test_too_small_workspace_falls_back_to_the_serial_kernel(rng):

@@ -11,7 +11,7 @@ import torch
 
 import markovflow_amd as mfa
 from markovflow_amd import _lib, synthetic
-from test_gpu_kalman import DEV, tt
+from test_gpu_kalman import DEV, build_kf, random_ssm, tt
 
 pytestmark = pytest.mark.gpu
 
@@ -127,3 +127,42 @@ def test_fused_gpr_cache_and_writes_that_bypass_the_version_counter():
     gpr.invalidate_hyperparameter_cache()
     fresh = mfa.GaussianProcessRegression((t, y), mfa.Matern52(ls.clone(), 1.1, jitter=1e-9), chol_obs_covariance=noise)
     assert float(gpr.log_likelihood()) == pytest.approx(float(fresh.log_likelihood()), rel=1e-12)
+
+
+def test_non_positive_pivot_is_reported_like_the_reference(rng):
+    """SURVEY 8(b) / VERDICT r05 item 9: the `info` word names the FIRST failing block, LAPACK style (`info = 1 + flat index`,
+    flat index = series * blocks + block).  (a) C ABI: `mf_btd_cholesky_f64` on three series of which series 2 loses positive
+    definiteness at block 4 and series 1 at block 5 -> the SMALLEST flat index wins: 1 * 7 + 5;
+    (b) the Python classes raise MarkovflowAmdError carrying series / block; (c) the fused log-likelihood names the block whose
+    elimination step failed."""
+    from markovflow_amd import _lib
+    bsz, n, d = 3, 7, 4
+    a = rng.normal(size=(bsz, n, d, d))
+    diag = a @ a.transpose(0, 1, 3, 2) + 4 * np.eye(d)
+    sub = 0.1 * rng.normal(size=(bsz, n - 1, d, d))
+    diag[2, 4] -= 50 * np.eye(d)
+    diag[1, 5] -= 50 * np.eye(d)
+    dg, sb = torch.tensor(diag, device=DEV), torch.tensor(sub, device=DEV)
+    lib = _lib.load()
+    info = _lib.new_info(torch.device(DEV))
+    ld, ls = torch.empty_like(dg), torch.empty_like(sb)
+    rc = lib.mf_btd_cholesky_f64(bsz, n, d, _lib.ptr(dg), _lib.ptr(sb), _lib.ptr(ld), _lib.ptr(ls), None, 0, _lib.ptr(info),
+                                 _lib.stream_ptr(torch.device(DEV)))
+    assert rc == 0
+    word = int(info.item())
+    assert word >= 2 and int(lib.mf_info_flat_index(word)) == 1 * n + 5
+    assert int(lib.mf_info_flat_index(0)) == -1 and int(lib.mf_info_flat_index(1)) == -1
+    _lib.set_synchronous_checks(True)
+    try:
+        with pytest.raises(mfa.MarkovflowAmdError) as exc:
+            mfa.SymmetricBlockTriDiagonal(dg, sb).cholesky
+        assert exc.value.flat_index == 1 * n + 5 and exc.value.series == 1 and exc.value.block == 5
+        assert "series 1, block 5" in str(exc.value)
+        # the fused log-likelihood: a process covariance factor with a zero on its diagonal at transition 3 of series 0
+        kw = random_ssm(rng, (2,), 9, 3, 1, well=True)
+        kw["chol_q"][0, 3, 1, 1] = 0.0
+        with pytest.raises(mfa.MarkovflowAmdError) as exc:
+            build_kf(kw, np.eye(1)).log_likelihood()
+        assert exc.value.series == 0 and exc.value.block in (3, 4)
+    finally:
+        _lib.set_synchronous_checks(False)
