@@ -616,6 +616,22 @@ int mf_ssm_kl_divergence_f32(int64_t B, int64_t T, int d, const float* mu0_1, co
                              float* out_cross, float* out_N, float* out_n, void* ws, size_t ws_bytes, int* info, void* stream);
 
 /*
+ * KL(q1 || q2) for 16 <= d <= 32 from q1's MOMENTS (markovflow/state_space_model.py:528-593: the reference assembles q2's precision,
+ * multiplies it block by block with q1's marginal / subsequent covariances and sums, :569-573).  One wavefront per (series, block)
+ * forms block row k of q2's precision on register tiles (as mf_ssm_precision does) and reduces it on the spot against
+ * covs_1 [B,T,d,d], cross_1 [B,T-1,d,d] = Cov(x_{k+1}, x_k) and mean_diff [B,T,d] = mu_2 - mu_1; the two log-determinants ride along
+ * (q1's factors are read on their diagonals only); a second small kernel sums the T terms of a series in a fixed order.  q2's
+ * precision never exists in memory.  ws: mf_ssm_kl_from_moments_workspace_bytes (B T scalars).  -100 outside 16 <= d <= 32.
+ */
+size_t mf_ssm_kl_from_moments_workspace_bytes(int64_t B, int64_t T, int d, int elem_size);
+int mf_ssm_kl_from_moments_f64(int64_t B, int64_t T, int d, const double* cholP0_1, const double* cholQ_1, const double* cholP0_2,
+                               const double* A_2, const double* cholQ_2, const double* covs_1, const double* cross_1,
+                               const double* mean_diff, double* out, void* ws, size_t ws_bytes, void* stream);
+int mf_ssm_kl_from_moments_f32(int64_t B, int64_t T, int d, const float* cholP0_1, const float* cholQ_1, const float* cholP0_2,
+                               const float* A_2, const float* cholQ_2, const float* covs_1, const float* cross_1,
+                               const float* mean_diff, float* out, void* ws, size_t ws_bytes, void* stream);
+
+/*
  * Adjoint of the marginal recursion  m_{k+1} = A_k m_k + b_k,  S_{k+1} = A_k S_k A_k^T + Q_k  (markovflow/state_space_model.py:232-262,
  * differentiated by TensorFlow in the reference: the expected log-likelihood of every variational model goes through
  * `marginals`, models/variational.py:150, models/sparse_variational.py:178-192).  Given the incoming gradients g_means [B,T,d] and

@@ -31,6 +31,7 @@ _SIGS = {
                                 "Tp", "Tp", "Tp", _vp]),
     "mf_ssm_marginal_means": (_int, [_i64, _i64, _i64, _int, "Tp", "Tp", "Tp", _vp, _sz, _vp]),
     "mf_ssm_marginals": (_int, [_i64, _i64, _int] + ["Tp"] * 8 + [_vp, _sz, _vp]),
+    "mf_ssm_kl_from_moments": (_int, [_i64, _i64, _int, "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", "Tp", _vp, _sz, _vp]),
     "mf_block_matmul": (_int, [_i64, _i64, _int, "Tp", _i64, "Tp", _i64, "Tp", _vp]),
     "mf_gpr_matern_posterior_chain": (_int, [_i64, _i64, _int, ctypes.POINTER(ctypes.c_int), "Tp", "Tp", _int, "Tp", "Tp", "Tp", "T",
                                       "Tp", "Tp", "Tp", "Tp", "Tp", _vp, _sz, _vp, _vp, _i64, _i64, _vp]),
@@ -68,6 +69,7 @@ _PLAIN = {
     "mf_version": (_int, []),
     "mf_info_mirror": (_int, [_vp, _vp, _vp]),
     "mf_info_flat_index": (_i64, [_int]),
+    "mf_ssm_kl_from_moments_workspace_bytes": (_sz, [_i64, _i64, _int, _int]),
     "mf_max_state_dim": (_int, []),
     "mf_row_operators_cover": (_int, [_i64, _i64, _int, _int]),
     "mf_max_state_dim_f32_loglik": (_int, []),

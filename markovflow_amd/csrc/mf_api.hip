@@ -1,6 +1,7 @@
 // extern "C" entry points of include/markovflow_amd.h: argument checks + dispatch on the state dimension.
 #include "../../include/markovflow_amd.h"
 #include "mf_launch.hpp"
+#include "mf_wave_api.hpp"
 
 #include <cstdlib>
 
@@ -666,6 +667,31 @@ MF_DEFINE4B(f64, double)
 MF_DEFINE4B(f32, float)
 MF_DEFINE5(f64, double)
 MF_DEFINE5(f32, float)
+
+// KL(q1 || q2) from q1's moments on register tiles, 16 <= d <= 32 (mf_wave.hpp: wave_ssm_kl_terms_kernel); see the header
+size_t mf_ssm_kl_from_moments_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {
+    if (B < 1 || T < 1 || d < 16 || d > 32 || (elem_size != 4 && elem_size != 8)) return 0;
+    return size_t(B) * size_t(T) * size_t(elem_size);
+}
+#define MF_DEFINE_KLM(SUF, T)                                                                                                     \
+    int mf_ssm_kl_from_moments_##SUF(int64_t B, int64_t Tn, int d, const T* cholP0_1, const T* cholQ_1, const T* cholP0_2,         \
+                                     const T* A_2, const T* cholQ_2, const T* covs_1, const T* cross_1, const T* mean_diff, T* out, \
+                                     void* ws, size_t ws_bytes, void* stream) {                                                    \
+        if (B < 0) return -1;                                                                                                      \
+        if (Tn < 1) return -2;                                                                                                     \
+        if (d < 16 || d > 32) return -100;                                                                                         \
+        if (B == 0) return 0;                                                                                                      \
+        if (!cholP0_1 || (Tn > 1 && !cholQ_1)) return -4;                                                                          \
+        if (!cholP0_2 || (Tn > 1 && (!A_2 || !cholQ_2))) return -6;                                                                \
+        if (!covs_1 || (Tn > 1 && !cross_1)) return -9;                                                                            \
+        if (!mean_diff) return -11;                                                                                                \
+        if (!out) return -12;                                                                                                      \
+        return mf::wave_ssm_kl_##SUF(B, Tn, d, cholP0_1, cholQ_1, cholP0_2, A_2, cholQ_2, covs_1, cross_1, mean_diff, out, ws,     \
+                                     ws_bytes, S(stream));                                                                         \
+    }
+MF_DEFINE_KLM(f64, double)
+MF_DEFINE_KLM(f32, float)
+#undef MF_DEFINE_KLM
 
 static size_t big_max(size_t a, size_t b) { return a > b ? a : b; }
 static bool big_dim(int d, int elem_size) {

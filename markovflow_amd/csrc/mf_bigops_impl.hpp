@@ -275,27 +275,52 @@ __global__ void __launch_bounds__(NTHR) bigop_ssm_precision_kernel(BigArgs a, re
     if (eta && threadIdx.x < d) eta[id * d + threadIdx.x] = rn[threadIdx.x];
 }
 
-// StateSpaceModel.marginal_means / sample propagation: one 64-thread workgroup per series, thread = state component
+// StateSpaceModel.marginal_means / sample propagation: one wavefront per series, lane = state component.  The lane holds ITS ROW
+// of the next transition in registers, fetched one step ahead; the current mean reaches the other lanes by v_readlane - no LDS, no
+// barrier (round 6; the first form wrote the mean to LDS behind two workgroup barriers per step and loaded its row element by
+// element after them: 1.2 / 2.1 ms at B = 512, T = 1000, d = 16 / 32 in fp64, a third of StateSpaceModel.kl_divergence there).
 __global__ void __launch_bounds__(64) bigop_means_kernel(long Bl, long Br, long Tn, int d, const real* __restrict__ A,
                                                         const real* __restrict__ offs, real* __restrict__ out) {
-    __shared__ real mu[64];
     const long r = blockIdx.x, s = r % Bl;
     const int i = threadIdx.x;
+    const int ii = i < d ? i : d - 1;             // the idle lanes shadow the last row: every load stays in range
     const long dd = (long)d * d;
-    real cur = i < d ? offs[r * Tn * d + i] : real(0);
+    real cur = offs[r * Tn * d + ii];
     if (i < d) out[r * Tn * d + i] = cur;
-    for (long k = 1; k < Tn; ++k) {
-        mu[i] = cur;
-        __syncthreads();
-        real a = 0;
-        if (i < d) {
-            const real* Am = A + (s * (Tn - 1) + k - 1) * dd + (long)i * d;
-            for (int j = 0; j < d; ++j) a += Am[j] * mu[j];
-            a += offs[(r * Tn + k) * d + i];
-            out[(r * Tn + k) * d + i] = a;
+    real a[64], an[64];
+    auto load_row = [&](long k, real (&dst)[64]) {
+        const real* Am = A + (s * (Tn - 1) + k) * dd + (long)ii * d;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (16 * c >= d) break;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const int j = 16 * c + jj;
+                dst[j] = j < d ? Am[j] : real(0);
+            }
         }
-        __syncthreads();
-        cur = a;
+    };
+    if (Tn > 1) load_row(0, a);
+    for (long k = 1; k < Tn; ++k) {
+        // (the offset is requested BEFORE the prefetch of the next row: loads are waited for in order, and a wait for the offset
+        // must not include the row that was only just requested)
+        const real o = offs[(r * Tn + k) * d + ii];
+        __builtin_amdgcn_sched_barrier(0);
+        if (k + 1 < Tn) load_row(k, an);
+        real acc0 = 0, acc1 = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (16 * c >= d) break;
+#pragma unroll
+            for (int jj = 0; jj < 16; jj += 2) {
+                acc0 += a[16 * c + jj] * bcast(cur, 16 * c + jj);             // (columns beyond d hold zeros)
+                acc1 += a[16 * c + jj + 1] * bcast(cur, 16 * c + jj + 1);
+            }
+        }
+        cur = acc0 + acc1 + o;
+        if (i < d) out[(r * Tn + k) * d + i] = cur;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) a[j] = an[j];
     }
 }
 

@@ -1101,5 +1101,135 @@ __global__ void __launch_bounds__(64) wave_ssm_precision_kernel(WvArgs<T> a, T* 
     (void)bad;
 }
 
+// ---- StateSpaceModel.kl_divergence for 16 <= d <= 32: the per-block terms of KL(chain 1 || chain 2) on register tiles ---------------
+// (state_space_model.py:528-593).  The reference assembles P2 = chain 2's precision, multiplies it block by block with chain 1's
+// marginal / subsequent covariances and sums (:569-573), forms |L2^T (mu2 - mu1)|^2 and two log-determinants.  Here one wavefront per
+// (series, block k) forms block row k of P2 in registers exactly as wave_ssm_precision_kernel does - D_k = Q_k^-1 + A^T Q_{k+1}^-1 A,
+// S_k = -Q_{k+1}^-1 A - and reduces it on the spot against what chain 1 contributes to that block:
+//     term_k = tr(D_k Sigma_kk) + 2 tr(S_k^T C_k) + delta_k^T D_k delta_k + 2 delta_{k+1}^T S_k delta_k
+//              + 2 log|chol2_k| - 2 log|chol1_k| - d                               (C_k = Cov(x_{k+1}, x_k), delta = mu2 - mu1)
+// so that KL = 1/2 sum_k term_k.  P2 never exists in memory (the composition it replaces wrote and re-read 2 x [B, T, d, d] and ran
+// six element-wise / reduction launches of torch over them: 6.8 ms at B = 512, T = 1000, d = 16).
+// a: chain 2 (cholP0, A, cholQ); chol1_0 / chol1_q: chain 1's factors (only their diagonals are read).
+template <typename T, int NT, bool EX>
+__global__ void __launch_bounds__(64) wave_ssm_kl_terms_kernel(WvArgs<T> a, const T* __restrict__ chol1_0, const T* __restrict__ chol1_q,
+                                                              const T* __restrict__ cov, const T* __restrict__ cross,
+                                                              const T* __restrict__ mdiff, T* __restrict__ terms) {
+    using v4 = typename Tr<T>::v4;
+    constexpr int NTL = 2 * NT, TS = 16 * Tr<T>::LD;
+    __shared__ __attribute__((aligned(16))) T lds[NTL * TS];
+    const Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
+    const long id = blockIdx.x, s = id / a.Tn, k = id % a.Tn;
+    const int d = EX ? 16 * NT : a.d;
+    const long nt = a.Tn - 1, dd = long(d) * d;
+    const bool has_next = k + 1 < a.Tn;
+    LogAcc<T> la;
+    la.init();
+    bool bad = false;
+    Mat<T, NT> C0, C1, Am;
+    v4 c10t[2] = {v4{0, 0, 0, 0}, v4{0, 0, 0, 0}};
+    const T* c0p = k == 0 ? a.cholP0 + s * dd : a.cholQ + (s * nt + k - 1) * dd;
+    load_mat<T, NT, S_LOWER, EX>(C0, c0p, d, true, true, ln);
+    if constexpr (NT == 2) load_tile_t<T, EX>(c10t[0], c0p, d, 1, 0, ln);
+    MF_UNROLL for (int i = 0; i < NT; ++i) MF_UNROLL for (int j = 0; j < NT; ++j) C1.t[i][j] = (i == j) ? identity_tile<T>(ln) : v4{0, 0, 0, 0};
+    Am.zero();
+    if (has_next) {
+        load_mat<T, NT, S_LOWER, EX>(C1, a.cholQ + (s * nt + k) * dd, d, true, true, ln);
+        if constexpr (NT == 2) load_tile_t<T, EX>(c10t[1], a.cholQ + (s * nt + k) * dd, d, 1, 0, ln);
+        load_mat<T, NT, S_FULL, EX>(Am, a.A + (s * nt + k) * dd, d, false, false, ln);
+    }
+    Mat<T, NT> Ci[2];
+    T logdet2;
+    {
+        v4 in[NTL], out[NTL];
+        MF_UNROLL for (int f = 0; f < 2; ++f) MF_UNROLL for (int i = 0; i < NT; ++i) in[f * NT + i] = (f == 0 ? C0 : C1).t[i][i];
+        tri_inv_tiles<T, NTL, false>(in, out, lds, ln, la, bad);
+        // la (per lane): the diagonal of the lane's own tile; block k's factor is the tiles [0, NT)
+        const T lv = la.value();
+        logdet2 = of_tile<T, NTL>(lv, 0);
+        if constexpr (NT == 2) logdet2 += of_tile<T, NTL>(lv, 1);
+        MF_UNROLL for (int f = 0; f < 2; ++f) {
+            Ci[f].zero();
+            MF_UNROLL for (int i = 0; i < NT; ++i) Ci[f].t[i][i] = out[f * NT + i];
+        }
+        if constexpr (NT == 2) {
+            v4 cit11[2];
+            MF_UNROLL for (int f = 0; f < 2; ++f) image_to_tile_t<T>(cit11[f], lds + (f * NT + 1) * TS, ln);
+            lds_fence();
+            MF_UNROLL for (int f = 0; f < 2; ++f) {
+                v4 g = {0, 0, 0, 0}, h = {0, 0, 0, 0};
+                MF_UNROLL for (int e = 0; e < 4; ++e) g = Tr<T>::mfma(c10t[f][e], Ci[f].t[0][0][e], g);
+                MF_UNROLL for (int e = 0; e < 4; ++e) h = Tr<T>::mfma(cit11[f][e], g[e], h);
+                Ci[f].t[1][0] = -h;
+            }
+        }
+    }
+    Mat<T, NT> Dn, S;
+    tn<T, NT, S_LOWER, S_LOWER, S_UPPER, OP_SET>(Dn, Ci[0], Ci[0]);                 // Q_k^-1 (tiles ti <= tj)
+    S.zero();
+    if (has_next) {
+        Mat<T, NT> Q1;
+        tn<T, NT, S_LOWER, S_LOWER, S_UPPER, OP_SET>(Q1, Ci[1], Ci[1]);             // Q_{k+1}^-1
+        if constexpr (NT == 2) transpose_tile<T>(Q1.t[1][0], Q1.t[0][1], lds, ln);
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_NEG>(S, Q1, Am);                       // S_k = -Q_{k+1}^-1 A_{k+1}
+        tn<T, NT, S_FULL, S_FULL, S_UPPER, OP_SUB>(Dn, Am, S);                      // + A^T Q^-1 A
+    }
+    if constexpr (NT == 2) transpose_tile<T>(Dn.t[1][0], Dn.t[0][1], lds, ln);     // the full symmetric block
+    // trace terms: element-wise against chain 1's covariance blocks, in the layout the tiles are in
+    T acc = T(0);
+    {
+        Mat<T, NT> Sg;
+        load_mat<T, NT, S_FULL, EX>(Sg, cov + (s * a.Tn + k) * dd, d, false, false, ln);
+        MF_UNROLL for (int i = 0; i < NT; ++i) MF_UNROLL for (int j = 0; j < NT; ++j)
+            MF_UNROLL for (int e = 0; e < 4; ++e) {
+                // (the padded diagonal of D is one, the padding of Sigma zero: nothing to mask)
+                acc = __builtin_fma(Dn.t[i][j][e], Sg.t[i][j][e], acc);
+            }
+        if (has_next) {
+            load_mat<T, NT, S_FULL, EX>(Sg, cross + (s * nt + k) * dd, d, false, false, ln);
+            MF_UNROLL for (int i = 0; i < NT; ++i) MF_UNROLL for (int j = 0; j < NT; ++j)
+                MF_UNROLL for (int e = 0; e < 4; ++e) acc = __builtin_fma(T(2) * S.t[i][j][e], Sg.t[i][j][e], acc);
+        }
+    }
+    T total = xor_rows<T>(sum16<T>(acc));
+    // Mahalanobis terms
+    {
+        RV<T, NT> dk_rv;
+        CV<T, NT> dk_cv, y;
+        load_rv<T, NT>(dk_rv, mdiff + (s * a.Tn + k) * d, d, ln);
+        load_cv<T, NT>(dk_cv, mdiff + (s * a.Tn + k) * d, d, ln);
+        tn_mv<T, NT, S_FULL>(y, Dn, dk_rv);                                         // D_k delta_k (D symmetric)
+        T mh = dot_cv<T, NT>(y, dk_cv);
+        if (has_next) {
+            RV<T, NT> dn_rv;
+            load_rv<T, NT>(dn_rv, mdiff + (s * a.Tn + k + 1) * d, d, ln);
+            tn_mv<T, NT, S_FULL>(y, S, dn_rv);                                      // S_k^T delta_{k+1}
+            mh = __builtin_fma(T(2), dot_cv<T, NT>(y, dk_cv), mh);
+        }
+        total += sum16<T>(mh);
+    }
+    // log-determinants: chain 2's from the inversion above, chain 1's from the diagonal of its factor
+    {
+        const T* c1p = k == 0 ? chol1_0 + s * dd : chol1_q + (s * nt + k - 1) * dd;
+        T l1 = T(0);
+        MF_UNROLL for (int i = 0; i < NT; ++i) {
+            const int j = 16 * i + ln.r;
+            const T v = c1p[j < d ? j * d + j : 0];
+            l1 += (j < d) ? log(v < T(0) ? -v : v) : T(0);
+        }
+        total += T(2) * logdet2 - T(2) * sum16<T>(l1) - T(d);
+    }
+    if (threadIdx.x == 0) terms[id] = total;
+    (void)bad;
+}
+// out[s] = scale * sum_k terms[s][k]: one wavefront per series, a fixed summation order (deterministic)
+template <typename T> __global__ void __launch_bounds__(64) row_sums_kernel(long B, long n, const T* __restrict__ terms, T scale, T* __restrict__ out) {
+    const long s = blockIdx.x;
+    T acc = T(0);
+    for (long k = threadIdx.x; k < n; k += 64) acc += terms[s * n + k];
+    acc = xor_rows<T>(sum16<T>(acc));
+    if (threadIdx.x == 0) out[s] = scale * acc;
+}
+
 }  // namespace wv
 }  // namespace mf

@@ -49,6 +49,13 @@ inline int wave_ssm_precision(long B, long Tn, int d, int m, const float* mu0, c
                               float* sub, float* eta, hipStream_t st) {
     return wave_ssm_precision_f32(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, diag, sub, eta, st);
 }
+// mf_wave_inst.hip: the per-block terms of KL(chain 1 || chain 2) on register tiles + their sum (wave_ssm_kl_terms_kernel); ws: B Tn scalars
+int wave_ssm_kl_f64(long B, long Tn, int d, const double* cp0_1, const double* cq_1, const double* cp0_2, const double* a_2,
+                    const double* cq_2, const double* cov, const double* cross, const double* mdiff, double* out, void* ws,
+                    size_t ws_bytes, hipStream_t st);
+int wave_ssm_kl_f32(long B, long Tn, int d, const float* cp0_1, const float* cq_1, const float* cp0_2, const float* a_2,
+                    const float* cq_2, const float* cov, const float* cross, const float* mdiff, float* out, void* ws, size_t ws_bytes,
+                    hipStream_t st);
 // mf_wave_inst.hip: solve with the time axis walked serially inside a wavefront (mf_wave_ops.hpp); -101: not covered
 int wave_btd_solve_f64(long Bl, long Br, long n, int d, const double* ldiag, const double* lsub, const double* rhs, double* out,
                        int transpose, hipStream_t st);

@@ -105,6 +105,38 @@ int wave_ssm_precision_f32(long B, long Tn, int d, int m, const float* mu0, cons
     return wave_precision<float>(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, diag, sub, eta, st);
 }
 
+// ---- StateSpaceModel.kl_divergence for 16 <= d <= 32 (wave_ssm_kl_terms_kernel + row_sums_kernel); ws: B * Tn scalars --------------
+namespace {
+template <typename T>
+int wave_kl(long B, long Tn, int d, const T* cp0_1, const T* cq_1, const T* cp0_2, const T* a_2, const T* cq_2, const T* cov,
+            const T* cross, const T* mdiff, T* out, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!wave_covers(d, 1) || B <= 0 || Tn <= 0) return -101;
+    if (ws == nullptr || ws_bytes < size_t(B) * Tn * sizeof(T)) return -15;
+    T* terms = static_cast<T*>(ws);
+    const wv::WvArgs<T> a{B, Tn, d, 1, nullptr, cp0_2, a_2, nullptr, cq_2, nullptr, nullptr, nullptr, 0, 1, 1, nullptr};
+    const dim3 grid((unsigned)(B * Tn)), block(64);
+    if (d <= 16) {
+        if (d == 16) hipLaunchKernelGGL((wv::wave_ssm_kl_terms_kernel<T, 1, true>), grid, block, 0, st, a, cp0_1, cq_1, cov, cross, mdiff, terms);
+        else hipLaunchKernelGGL((wv::wave_ssm_kl_terms_kernel<T, 1, false>), grid, block, 0, st, a, cp0_1, cq_1, cov, cross, mdiff, terms);
+    } else {
+        if (d == 32) hipLaunchKernelGGL((wv::wave_ssm_kl_terms_kernel<T, 2, true>), grid, block, 0, st, a, cp0_1, cq_1, cov, cross, mdiff, terms);
+        else hipLaunchKernelGGL((wv::wave_ssm_kl_terms_kernel<T, 2, false>), grid, block, 0, st, a, cp0_1, cq_1, cov, cross, mdiff, terms);
+    }
+    hipLaunchKernelGGL((wv::row_sums_kernel<T>), dim3((unsigned)B), block, 0, st, B, Tn, static_cast<const T*>(terms), T(0.5), out);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+}  // namespace
+int wave_ssm_kl_f64(long B, long Tn, int d, const double* cp0_1, const double* cq_1, const double* cp0_2, const double* a_2,
+                    const double* cq_2, const double* cov, const double* cross, const double* mdiff, double* out, void* ws,
+                    size_t ws_bytes, hipStream_t st) {
+    return wave_kl<double>(B, Tn, d, cp0_1, cq_1, cp0_2, a_2, cq_2, cov, cross, mdiff, out, ws, ws_bytes, st);
+}
+int wave_ssm_kl_f32(long B, long Tn, int d, const float* cp0_1, const float* cq_1, const float* cp0_2, const float* a_2,
+                    const float* cq_2, const float* cov, const float* cross, const float* mdiff, float* out, void* ws, size_t ws_bytes,
+                    hipStream_t st) {
+    return wave_kl<float>(B, Tn, d, cp0_1, cq_1, cp0_2, a_2, cq_2, cov, cross, mdiff, out, ws, ws_bytes, st);
+}
+
 // ---- LowerTriangularBlockTriDiagonal.solve for 16 <= d <= 32: the time axis serially inside a wavefront (wave_solve_kernel) -----------
 namespace {
 template <typename T>

@@ -407,6 +407,22 @@ class StateSpaceModel(GaussMarkovDistribution):
     def _kl_divergence_operators(self, dist: GaussMarkovDistribution) -> torch.Tensor:
         """The reference's route (state_space_model.py:569-593) over the operator kernels."""
         means_1, marginal_covs_1, subsequent_covs_1 = self._moments(want_sub=True)
+        d, n = self.state_dim, self.num_transitions + 1
+        if (isinstance(dist, StateSpaceModel) and self._A_s.is_cuda and 16 <= d <= 32 and n > 1
+                and dist._A_s.dtype == self._A_s.dtype and tuple(dist.batch_shape) == tuple(self.batch_shape)):
+            # 16 <= d <= 32: q2's precision is formed block row by block row on register tiles and reduced on the spot against q1's
+            # moments (mf_ssm_kl_from_moments_*): it never exists in memory and no element-wise / reduction launch of torch runs
+            mean_diff = (dist.marginal_means - means_1).reshape(-1, n, d).contiguous()
+            bsz = mean_diff.shape[0]
+            cp0_1, cq_1 = _flat(self._chol_P_0, 2), _flat(self._chol_Q_s, 3)
+            cp0_2, a_2, cq_2 = _flat(dist._chol_P_0, 2), _flat(dist._A_s, 3), _flat(dist._chol_Q_s, 3)
+            out = torch.empty(bsz, dtype=a_2.dtype, device=a_2.device)
+            ws_bytes = int(_lib.load().mf_ssm_kl_from_moments_workspace_bytes(bsz, n, d, a_2.element_size()))
+            ws = _lib.workspace(ws_bytes, a_2.device)
+            _lib.call("mf_ssm_kl_from_moments", a_2.dtype, bsz, n, d, _lib.ptr(cp0_1), _lib.ptr(cq_1), _lib.ptr(cp0_2), _lib.ptr(a_2),
+                      _lib.ptr(cq_2), _lib.ptr(_flat(marginal_covs_1, 3)), _lib.ptr(_flat(subsequent_covs_1, 3)), _lib.ptr(mean_diff),
+                      _lib.ptr(out), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(a_2.device))
+            return out.reshape(tuple(self.batch_shape))
         precision_2 = dist.precision
         # sums over the blocks first, then over time: a reduction of [.., T, d, d] straight to batch_shape runs on one
         # workgroup per series (0.42 ms each at B = 8, T = 2048, d = 64)
