@@ -450,6 +450,36 @@ def other_configs(dev):
                 "gradients w.r.t. lengthscales, variances and sites.  The adjoints of cholesky and block_diagonal_of_inverse are HIP "
                 "(mf_btd_cholesky_grad / mf_btd_diag_of_inverse_grad: local kernels + the congruence scan, parallel in time); round 4: a "
                 "Python loop over the T blocks"}
+    # reverse mode through the OPERATORS at the reference's largest tested shape (d = 30, T = 1001, one chain;
+    # tests/unit/test_ssm_gaussian_transformations.py:40-46): cholesky -> block_diagonal_of_inverse (+ sub-diagonal blocks) and back.
+    # Round 6: the adjoints are one launch each (csrc/mf_adj.hip, a workgroup per series); rounds 4-5: a Python loop over the blocks
+    n30, d30 = 1001, 30
+    ld = torch.tril((4.0 / d30) * 0.3 * torch.randn(4, n30, d30, d30, dtype=torch.float64, device=dev, generator=g), -1) + torch.diag_embed(
+        1 + torch.rand(4, n30, d30, dtype=torch.float64, device=dev, generator=g))
+    ls = (2.0 / d30) * 0.3 * torch.randn(4, n30 - 1, d30, d30, dtype=torch.float64, device=dev, generator=g)
+    dg = ld @ ld.transpose(-1, -2)
+    dg[:, 1:] += ls @ ls.transpose(-1, -2)
+    sb = ls @ ld[:, :-1].transpose(-1, -2)
+    dg.requires_grad_(True); sb.requires_grad_(True)
+    wd = torch.randn(4, n30, d30, d30, dtype=torch.float64, device=dev, generator=g)
+    fwd30, bwd30 = [], []
+    for i in range(4):
+        dg.grad = sb.grad = None
+        torch.cuda.synchronize()
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        inv_d, inv_s = mfa.SymmetricBlockTriDiagonal(dg, sb).cholesky._diag_and_sub_of_inverse(want_sub=True)
+        loss = torch.sum(inv_d * wd) + torch.sum(inv_s)
+        e1.record(); loss.backward(); e2.record()
+        torch.cuda.synchronize()
+        if i:
+            fwd30.append(e0.elapsed_time(e1)); bwd30.append(e1.elapsed_time(e2))
+    f30, b30 = sorted(fwd30)[len(fwd30) // 2], sorted(bwd30)[len(bwd30) // 2]
+    out["operator_adjoints_d30_T1001_B4_f64"] = {
+        "forward_ms": f30, "backward_ms": b30, "backward_over_forward": b30 / f30,
+        "note": "SymmetricBlockTriDiagonal.cholesky -> block_diagonal_of_inverse (with sub-diagonal blocks), forward and reverse mode, "
+                "four chains of the reference's largest tested operator shape"}
+    del ld, ls, dg, sb, wd
     return out
 
 

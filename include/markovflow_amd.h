@@ -382,7 +382,9 @@ int mf_sde_conditional_statistics_f32(int64_t n, int d, const float* A_mt, const
  *     w.r.t. the diagonal / sub-diagonal blocks of the inverse -> (g_ldiag lower, g_lsub).  The block Takahashi recursion run
  *     forward in reverse mode, A_{k+1} = Qbar_{k+1} + G_k A_k G_k^T, between two local kernels.
  * lsub == NULL: block-diagonal factor.  Workspace: mf_btd_grad_workspace_bytes (0: state dimension without these kernels,
- * the entry points then return -100).  d <= 9 (register kernels) and 10 <= d <= 15 where the row scan takes the recursion.
+ * the entry points then return -100).  d <= 9 (register kernels) and 10 <= d <= 15 where the row scan takes the recursion;
+ * 10 <= d <= 32 otherwise (round 6): one workgroup per series walks the recurrence with the step's matrices in LDS
+ * (csrc/mf_adj.hip; the reference differentiates these operators at d = 30, T = 1001) - a token workspace size, nothing is used.
  */
 size_t mf_btd_grad_workspace_bytes(int64_t B, int64_t T, int d, int elem_size);
 int mf_btd_cholesky_grad_f64(int64_t B, int64_t T, int d, const double* ldiag, const double* lsub, const double* g_ldiag,

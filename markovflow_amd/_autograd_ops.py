@@ -28,14 +28,15 @@ from . import _lib
 
 
 def _hip_grad_ws(ldiag: torch.Tensor):
-    """``(B, n, d, workspace bytes)`` when the operator-adjoint kernels cover these blocks (HIP tensor, d <= 9), else None."""
+    """``(B, n, d, workspace bytes)`` when the operator-adjoint kernels cover these blocks (HIP tensor; d <= 9: local kernels + a
+    scan in time, 10 <= d <= 32: one workgroup per series walks the chain, ``csrc/mf_adj.hip``), else None."""
     if not ldiag.is_cuda:
         return None
     n, d = ldiag.shape[-3], ldiag.shape[-1]
     bsz = 1
     for x in ldiag.shape[:-3]:
         bsz *= int(x)
-    if bsz == 0 or d > _lib.load().mf_max_state_dim():
+    if bsz == 0:
         return None
     wsb = int(_lib.load().mf_btd_grad_workspace_bytes(bsz, n, d, ldiag.element_size()))
     return (bsz, n, d, wsb) if wsb else None

@@ -467,12 +467,17 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (n < 1) return -2;                                                                                          \
         if (d < 1) return -3;                                                                                          \
         const auto* t = table_for<T>(d);                                                                               \
-        if (!t) return -100;                                                                                           \
+        if (!t && !mf::adj_covers(d)) return -100;                                                                     \
         if (B == 0) return 0;                                                                                          \
         if (!ldiag) return -4;                                                                                         \
         if (!g_diag) return -8;                                                                                        \
         if (lsub && n > 1 && !g_sub) return -9;                                                                        \
-        return t->btd_cholesky_grad(B, n, ldiag, lsub, g_ldiag, g_lsub, g_diag, g_sub, ws, ws_bytes, S(stream));       \
+        if (t) {                                                                                                       \
+            const int rc = t->btd_cholesky_grad(B, n, ldiag, lsub, g_ldiag, g_lsub, g_diag, g_sub, ws, ws_bytes, S(stream)); \
+            if (rc != -100 || !mf::adj_covers(d)) return rc;                                                           \
+        }                                                                                                              \
+        /* 10 <= d <= 32: one workgroup per series walks the chain (mf_adj.hip) */                                     \
+        return mf::adj_cholesky_grad<T>(B, n, d, ldiag, lsub, g_ldiag, g_lsub, g_diag, g_sub, S(stream));              \
     }                                                                                                                  \
     int mf_btd_diag_of_inverse_grad_##SUF(int64_t B, int64_t n, int d, const T* ldiag, const T* lsub, const T* sigma,  \
                                           const T* g_diag, const T* g_sub, T* g_ldiag, T* g_lsub, void* ws,            \
@@ -481,14 +486,18 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
         if (n < 1) return -2;                                                                                          \
         if (d < 1) return -3;                                                                                          \
         const auto* t = table_for<T>(d);                                                                               \
-        if (!t) return -100;                                                                                           \
+        if (!t && !mf::adj_covers(d)) return -100;                                                                     \
         if (B == 0) return 0;                                                                                          \
         if (!ldiag) return -4;                                                                                         \
         if (lsub && n > 1 && !sigma) return -6;                                                                        \
         if (!g_ldiag) return -9;                                                                                       \
         if (lsub && n > 1 && !g_lsub) return -10;                                                                      \
-        return t->btd_diag_of_inverse_grad(B, n, ldiag, lsub, sigma, g_diag, g_sub, g_ldiag, g_lsub, ws, ws_bytes,     \
-                                           S(stream));                                                                 \
+        if (t) {                                                                                                       \
+            const int rc = t->btd_diag_of_inverse_grad(B, n, ldiag, lsub, sigma, g_diag, g_sub, g_ldiag, g_lsub, ws, ws_bytes, \
+                                                       S(stream));                                                     \
+            if (rc != -100 || !mf::adj_covers(d)) return rc;                                                           \
+        }                                                                                                              \
+        return mf::adj_diag_of_inverse_grad<T>(B, n, d, ldiag, lsub, sigma, g_diag, g_sub, g_ldiag, g_lsub, S(stream)); \
     }
 
 #define MF_DEFINE5(SUF, T)                                                                                             \
@@ -731,9 +740,12 @@ size_t mf_btd_diag_of_inverse_workspace_bytes(int64_t B, int64_t T, int d, int e
 // differentiable torch route there)
 size_t mf_btd_grad_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {
     if (B < 1 || T < 1) return 0;
-    if (elem_size == 4) { if (const auto* t = table_for<float>(d)) return t->btd_grad_ws(B, T); }
-    else if (const auto* t = table_for<double>(d)) return t->btd_grad_ws(B, T);
-    return 0;
+    size_t ws = 0;
+    if (elem_size == 4) { if (const auto* t = table_for<float>(d)) ws = t->btd_grad_ws(B, T); }
+    else if (const auto* t = table_for<double>(d)) ws = t->btd_grad_ws(B, T);
+    // 10 <= d <= 32: the workgroup-per-series kernels (mf_adj.hip) need no workspace; a token size says "covered"
+    if (ws == 0 && mf::adj_covers(d)) ws = 16;
+    return ws;
 }
 
 size_t mf_btd_udl_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {

@@ -128,6 +128,10 @@ def _random_factor(rng, batch, n, d, dtype=F64):
     ((3,), 300, 6, True, "both"), ((2,), 1000, 4, True, "both"), ((4100,), 12, 4, True, "both"), ((2, 3), 40, 2, True, "both"),
     ((5,), 64, 9, True, "both"), ((3,), 50, 7, True, "both"), ((2,), 30, 5, False, "both"), ((3,), 1, 3, False, "both"),
     ((2,), 2, 6, True, "both"), ((2,), 200, 6, True, "diag"), ((2,), 200, 6, True, "sub"), ((1,), 3000, 1, True, "both"),
+    # 10 <= d <= 32 (round 6, csrc/mf_adj.hip: one workgroup per series walks the recurrence) incl. the reference's largest tested
+    # operator shape, d = 30, T = 1001 (tests/unit/test_ssm_gaussian_transformations.py:40-46)
+    ((3,), 40, 12, True, "both"), ((2,), 25, 16, True, "both"), ((2,), 30, 24, True, "diag"), ((2,), 30, 24, True, "sub"),
+    ((1,), 12, 32, True, "both"), ((2,), 9, 17, False, "both"), ((3,), 1, 20, False, "both"), ((1,), 1001, 30, True, "both"),
 ])
 def test_hip_operator_adjoints_against_the_torch_recursions(batch, n, d, with_sub, which):
     """The kernels against the block-by-block torch recursions (which tests/test_autograd_ops.py pins on dense autograd): few long
@@ -136,6 +140,11 @@ def test_hip_operator_adjoints_against_the_torch_recursions(batch, n, d, with_su
     from markovflow_amd import _autograd_ops as ag
     rng = np.random.default_rng(11)
     ldiag, lsub = _random_factor(rng, batch, n, d)
+    if d >= 10:
+        # (G_k = W_k L_k^-1 has to stay a contraction for the recurrences to be evaluable over a thousand blocks at all - in any
+        # implementation: scale the couplings and the strict lower triangles with the state dimension)
+        lsub = lsub * (2.0 / d)
+        ldiag = torch.tril(ldiag, -1) * (4.0 / d) + torch.diag_embed(torch.diagonal(ldiag, dim1=-2, dim2=-1))
     if not with_sub or n == 1:
         lsub = None
     g1 = torch.tensor(rng.normal(size=tuple(ldiag.shape)), dtype=F64, device=DEV) if which in ("both", "diag") else None
