@@ -81,7 +81,9 @@ size_t big_btd_par_ws(long B, long n, int d, int chain, int elem_size) {
     return elem_size == 4 ? big::bigpar_ws_any(B, n, d, chain != 0) : bigd::bigpar_ws_any(B, n, d, chain != 0);
 }
 size_t big_btd_solve_ws(long Bl, long Br, long n, int d, int elem_size) {
-    return elem_size == 4 ? big::bigpar_solve_ws(Bl, Br, n, d) : bigd::bigpar_solve_ws(Bl, Br, n, d);
+    const size_t tile = elem_size == 4 ? big::bigpar_solve_ws(Bl, Br, n, d) : bigd::bigpar_solve_ws(Bl, Br, n, d);
+    const size_t wave = wave_btd_solve_ws(Bl, Br, n, d, elem_size);
+    return tile > wave ? tile : wave;
 }
 size_t big_btd_tak_ws(long B, long n, int d, int elem_size) {
     return elem_size == 4 ? big::bigpar_tak_ws(B, n, d) : bigd::bigpar_tak_ws(B, n, d);

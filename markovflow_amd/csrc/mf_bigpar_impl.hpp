@@ -617,7 +617,7 @@ inline int op_solve_par(long Bl, long Br, long n, int d, const real* ldiag, cons
                         void* ws, size_t ws_bytes, hipStream_t st) {
     {   // 16 <= d <= 32: the time axis serially inside a wavefront, the batch over the chip (mf_wave_ops.hpp)
         if (!wave_off() && Br > 0 && n > 0) {
-            const int rc = wave_btd_solve(Bl, Br, n, d, ldiag, lsub, rhs, out, transpose, st);
+            const int rc = wave_btd_solve(Bl, Br, n, d, ldiag, lsub, rhs, out, transpose, ws, ws_bytes, st);
             if (rc != -101) return rc;
         }
     }

@@ -58,17 +58,19 @@ int wave_ssm_kl_f32(long B, long Tn, int d, const float* cp0_1, const float* cq_
                     hipStream_t st);
 // mf_wave_inst.hip: solve with the time axis walked serially inside a wavefront (mf_wave_ops.hpp); -101: not covered
 int wave_btd_solve_f64(long Bl, long Br, long n, int d, const double* ldiag, const double* lsub, const double* rhs, double* out,
-                       int transpose, hipStream_t st);
+                       int transpose, void* ws, size_t ws_bytes, hipStream_t st);
 int wave_btd_solve_f32(long Bl, long Br, long n, int d, const float* ldiag, const float* lsub, const float* rhs, float* out, int transpose,
-                       hipStream_t st);
+                       void* ws, size_t ws_bytes, hipStream_t st);
 inline int wave_btd_solve(long Bl, long Br, long n, int d, const double* ldiag, const double* lsub, const double* rhs, double* out,
-                          int transpose, hipStream_t st) {
-    return wave_btd_solve_f64(Bl, Br, n, d, ldiag, lsub, rhs, out, transpose, st);
+                          int transpose, void* ws, size_t ws_bytes, hipStream_t st) {
+    return wave_btd_solve_f64(Bl, Br, n, d, ldiag, lsub, rhs, out, transpose, ws, ws_bytes, st);
 }
 inline int wave_btd_solve(long Bl, long Br, long n, int d, const float* ldiag, const float* lsub, const float* rhs, float* out, int transpose,
-                          hipStream_t st) {
-    return wave_btd_solve_f32(Bl, Br, n, d, ldiag, lsub, rhs, out, transpose, st);
+                          void* ws, size_t ws_bytes, hipStream_t st) {
+    return wave_btd_solve_f32(Bl, Br, n, d, ldiag, lsub, rhs, out, transpose, ws, ws_bytes, st);
 }
+// workspace of the time-partitioned wave solve (0: not partitioned / not covered)
+size_t wave_btd_solve_ws(long Bl, long Br, long n, int d, int elem_size);
 // mf_wave_inst.hip: the factorisations with one wavefront per series walking the time axis (mf_wave_ops.hpp); -101: not covered.
 // Overloaded on the scalar type; defined for double and float.
 template <typename T> int wave_btd_cholesky(long B, long n, int d, const T* diag, const T* sub, T* ldiag, T* lsub, void* ws, size_t ws_bytes,

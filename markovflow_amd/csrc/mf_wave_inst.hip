@@ -139,13 +139,62 @@ int wave_ssm_kl_f32(long B, long Tn, int d, const float* cp0_1, const float* cq_
 
 // ---- LowerTriangularBlockTriDiagonal.solve for 16 <= d <= 32: the time axis serially inside a wavefront (wave_solve_kernel) -----------
 namespace {
+// Chunks of the time-partitioned solve: enough (series, chunk) pairs for ~3 wavefronts of the map pass per SIMD, chunks of at least
+// 32 blocks (the map pass is ~4 x a block of the walk: a triangular inversion and two products against two matrix-vector products).
+// A walk of n dependent ~2 us block steps is what is being cut: B = 512, T = 1000, d = 16: 2.0 ms unpartitioned.
+// Both passes read the factor: at d = 16, B = 512 the partitioned form moves 2 x 2.2 GB in 1.4 ms where the walk moved 2.2 GB in
+// 2.0 ms (latency-bound: 128 wavefronts), with fewer series the gain grows with the number of chunks (B = 64: 8 x).  At d > 16 a
+// block of the map pass costs ~4 x a block of the walk and takes the register file of a SIMD: only where its wavefronts have a SIMD
+// each (B (P - 1) <= 1024) and at least four chunks come out.
+void wave_solve_partition(long Bl, long Br, int d, long n, long& P, long& Lc) {
+    P = 1; Lc = n;
+    if (Bl != Br || n < 128) return;
+    long want = (d <= 16 ? 3072 : 1024) / (Br > 0 ? Br : 1);
+    if (want > n / 32) want = n / 32;
+    if (want > 64) want = 64;
+    if (want < (d <= 16 ? 2 : 4)) return;
+    Lc = (n + want - 1) / want;
+    P = (n + Lc - 1) / Lc;
+    if (P < 2) { P = 1; Lc = n; }
+}
 template <typename T>
-int wave_solve(long Bl, long Br, long n, int d, const T* ldiag, const T* lsub, const T* rhs, T* out, int transpose, hipStream_t st) {
+int wave_solve(long Bl, long Br, long n, int d, const T* ldiag, const T* lsub, const T* rhs, T* out, int transpose, void* ws,
+               size_t ws_bytes, hipStream_t st) {
     if (!wave_covers(d, 1)) return -101;
+    long P, Lc;
+    wave_solve_partition(Bl, Br, d, n, P, Lc);
+    static const bool nopart = getenv("MF_WAVE_SOLVE_NOPART") != nullptr;
+    const size_t need = size_t(Br) * P * (size_t(d) * d + 2 * d) * sizeof(T);
+    if (nopart || !lsub || !ws || ws_bytes < need) P = 1;
     // the walk is n dependent block steps of ~0.4 us: a long chain of few series belongs to the time-partitioned engine
-    if (n > 2000 && Br < 64) return -101;
-    const wv::SolveArgs<T> a{Bl, Br, n, d, ldiag, lsub, rhs, out};
+    if (P == 1 && n > 2000 && Br < 64) return -101;
+    wv::SolveArgs<T> a{Bl, Br, n, d, ldiag, lsub, rhs, out, P, Lc, nullptr, nullptr, nullptr};
     const dim3 block(64);
+    if (P > 1) {
+        a.wM = static_cast<T*>(ws);
+        a.wv = a.wM + size_t(Br) * P * d * d;
+        a.zin = a.wv + size_t(Br) * P * d;
+        const dim3 gup((unsigned)(Br * (P - 1))), gb((unsigned)Br);
+#define MF_UP(NT_)                                                                                                  \
+        {                                                                                                           \
+            if (transpose) hipLaunchKernelGGL((wv::wave_solve_up_kernel<T, NT_, true>), gup, block, 0, st, a);       \
+            else hipLaunchKernelGGL((wv::wave_solve_up_kernel<T, NT_, false>), gup, block, 0, st, a);                \
+            hipLaunchKernelGGL((wv::wave_solve_boundary_kernel<T, NT_>), gb, block, 0, st, a);                       \
+        }
+        if (d <= 16) MF_UP(1) else MF_UP(2)
+#undef MF_UP
+        const long units = Br * P;
+        if (d <= 16) {
+            const dim3 grid((unsigned)((units + 3) / 4));
+            if (transpose) hipLaunchKernelGGL((wv::wave_solve_kernel<T, 1, true, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((wv::wave_solve_kernel<T, 1, false, true>), grid, block, 0, st, a);
+        } else {
+            const dim3 grid((unsigned)((units + 1) / 2));
+            if (transpose) hipLaunchKernelGGL((wv::wave_solve_kernel<T, 2, true, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((wv::wave_solve_kernel<T, 2, false, true>), grid, block, 0, st, a);
+        }
+        return hipGetLastError() == hipSuccess ? 0 : -1000;
+    }
     if (d <= 16) {
         const dim3 grid((unsigned)((Br + 3) / 4));
         if (transpose) hipLaunchKernelGGL((wv::wave_solve_kernel<T, 1, true>), grid, block, 0, st, a);
@@ -158,13 +207,19 @@ int wave_solve(long Bl, long Br, long n, int d, const T* ldiag, const T* lsub, c
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 }  // namespace
+size_t wave_btd_solve_ws(long Bl, long Br, long n, int d, int elem_size) {
+    if (!wave_covers(d, 1)) return 0;
+    long P, Lc;
+    wave_solve_partition(Bl, Br, d, n, P, Lc);
+    return P > 1 ? size_t(Br) * P * (size_t(d) * d + 2 * d) * elem_size : 0;
+}
 int wave_btd_solve_f64(long Bl, long Br, long n, int d, const double* ldiag, const double* lsub, const double* rhs, double* out,
-                       int transpose, hipStream_t st) {
-    return wave_solve<double>(Bl, Br, n, d, ldiag, lsub, rhs, out, transpose, st);
+                       int transpose, void* ws, size_t ws_bytes, hipStream_t st) {
+    return wave_solve<double>(Bl, Br, n, d, ldiag, lsub, rhs, out, transpose, ws, ws_bytes, st);
 }
 int wave_btd_solve_f32(long Bl, long Br, long n, int d, const float* ldiag, const float* lsub, const float* rhs, float* out, int transpose,
-                       hipStream_t st) {
-    return wave_solve<float>(Bl, Br, n, d, ldiag, lsub, rhs, out, transpose, st);
+                       void* ws, size_t ws_bytes, hipStream_t st) {
+    return wave_solve<float>(Bl, Br, n, d, ldiag, lsub, rhs, out, transpose, ws, ws_bytes, st);
 }
 
 

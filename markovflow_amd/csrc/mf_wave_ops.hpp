@@ -22,6 +22,10 @@ template <typename T> struct SolveArgs {
     int d;
     const T *ldiag, *lsub, *rhs;
     T* out;
+    // partitioned in time (wave_solve_up_kernel / wave_solve_boundary_kernel / wave_solve_kernel<.., PART>; Bl == Br): P chunks of Lc
+    // blocks in walking order; per (series, chunk) the composed map z_out = M z_in + v, and the z every chunk starts from
+    long P, Lc;
+    T *wM, *wv, *zin;        // [Br, P, d, d], [Br, P, d], [Br, P, d]
 };
 
 // the lane's row of one step, in the (possibly reversed) coordinates p = 0 .. 16 NR - 1 of its series
@@ -31,14 +35,18 @@ template <typename T, int NR> struct SolveRow {
     T dinv, x;        // 1 / M'[p_i][p_i]; right-hand side element
 };
 
-template <typename T, int NR, bool TRANS>
+// PART: the emit pass of the time-partitioned form - a group of rows is a (series, chunk) pair and starts from the z the boundary pass
+// left for its chunk.
+template <typename T, int NR, bool TRANS, bool PART = false>
 __global__ void __launch_bounds__(64) wave_solve_kernel(SolveArgs<T> a) {
     using D = Dpp<T>;
     constexpr int DP = 16 * NR, NS = 4 / NR;
     const int r = threadIdx.x & 15, q = threadIdx.x >> 4, g = q / NR, h = q % NR;
-    const long sr_raw = (long)blockIdx.x * NS + g;
-    const bool valid = sr_raw < a.Br;
-    const long sr = valid ? sr_raw : a.Br - 1, sl = sr % a.Bl;
+    const long units = PART ? a.Br * a.P : a.Br;
+    const long id_raw = (long)blockIdx.x * NS + g;
+    const bool valid = id_raw < units;
+    const long id = valid ? id_raw : units - 1;
+    const long sr = PART ? id / a.P : id, ch = PART ? id % a.P : 0, sl = sr % a.Bl;
     const int d = a.d;
     const long n = a.n, dd = long(d) * d;
     const int pi = 16 * h + r;                              // the lane's position in its series' (reversed) coordinates
@@ -76,10 +84,15 @@ __global__ void __launch_bounds__(64) wave_solve_kernel(SolveArgs<T> a) {
     T z = T(0);                                             // the previously solved block's element p_i
     SolveRow<T, NR> cur, nxt;
     const long k0 = TRANS ? n - 1 : 0, step = TRANS ? -1 : 1;
-    load(k0, cur);
-    for (long t = 0; t < n; ++t) {
+    const long t_lo = PART ? ch * a.Lc : 0, t_hi = PART ? ((ch + 1) * a.Lc < n ? (ch + 1) * a.Lc : n) : n;
+    if (PART && ch > 0) {
+        const T zv = a.zin[(sr * a.P + ch) * d + (row_in ? i : 0)];
+        z = row_in ? zv : T(0);
+    }
+    load(k0 + step * t_lo, cur);
+    for (long t = t_lo; t < t_hi; ++t) {
         const long k = k0 + step * t;
-        if (t + 1 < n) load(k + step, nxt);
+        if (t + 1 < t_hi) load(k + step, nxt);
         __builtin_amdgcn_sched_barrier(0);
         // ---- y = r_k - C' z_prev --------------------------------------------------------------------------------------------
         T zc[NR];                                           // z_prev's half c, as held by the lanes of THIS row (DPP sources)
@@ -127,6 +140,91 @@ __global__ void __launch_bounds__(64) wave_solve_kernel(SolveArgs<T> a) {
         z = y * cur.dinv;
         if (valid && row_in) zo[k * d + i] = z;
         cur = nxt;
+    }
+}
+
+// The composed map of a chunk of the substitution, on the register tiles: in walking order z_t = B_t z_{t-1} + a_t with
+//   forwards   B = -L_k^-1 W_{k-1},   a = L_k^-1 r_k;        transposed   B = -L_k^-T W_k^T,   a = L_k^-T r_k,
+// so M <- B M, v <- B v + a block after block: one triangular inversion (DPP), two products and two matrix-vector products per
+// block.  Every product is P^T Q: forwards W M = tn(W^T, M) with W^T read transposed and L^-1 X = tn(L^-T, X) with L^-T through the
+// LDS image; transposed W^T M = tn(W, M), L^-T X = tn(L^-1, X) as they are.  The last chunk's map is not needed.
+template <typename T, int NT, bool TRANS>
+__global__ void __launch_bounds__(64) wave_solve_up_kernel(SolveArgs<T> a) {
+    using v4 = typename Tr<T>::v4;
+    constexpr int TS = 16 * Tr<T>::LD;
+    __shared__ __attribute__((aligned(16))) T lds[NT * NT * TS];
+    Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
+    const long s = blockIdx.x / (a.P - 1), c = blockIdx.x % (a.P - 1), n = a.n;
+    const long t_lo = c * a.Lc, t_hi = (c + 1) * a.Lc < n ? (c + 1) * a.Lc : n;
+    int d = a.d;
+    const long dd = long(d) * d;
+    const T* Ld = a.ldiag + s * n * dd;
+    const T* Ls = a.lsub + s * (n - 1) * dd;
+    const T* rh = a.rhs + s * n * d;
+    LogAcc<T> la;
+    la.init();
+    bool bad = false;
+    Mat<T, NT> M;
+    CV<T, NT> v;
+    identity_mat<T, NT>(M, ln);
+    MF_UNROLL for (int j = 0; j < NT; ++j) v.v[j] = T(0);
+    for (long t = t_lo; t < t_hi; ++t) {
+        asm volatile("" : "+v"(ln.r), "+v"(ln.q));
+        asm volatile("" : "+s"(d));
+        const long k = TRANS ? n - 1 - t : t;
+        const bool has_c = t > 0;
+        const long kc = TRANS ? k : k - 1;
+        Mat<T, NT> L, Li, W, X;
+        v4 c10t = {0, 0, 0, 0};
+        CV<T, NT> rk, y;
+        load_mat<T, NT, S_LOWER>(L, Ld + k * dd, d, true, true, ln);
+        if constexpr (NT == 2) load_tile_t<T>(c10t, Ld + k * dd, d, 1, 0, ln);
+        if (!has_c) W.zero();
+        else if (TRANS) load_mat<T, NT, S_FULL>(W, Ls + kc * dd, d, false, false, ln);
+        else load_mat_t<T, NT>(W, Ls + kc * dd, d, ln);                           // W^T
+        load_cv<T, NT>(rk, rh + k * d, d, ln);
+        phase();
+        tri_inv_mat<T, NT>(L, c10t, Li, lds, ln, la, bad);
+        if constexpr (!TRANS) {
+            L.zero();
+            transpose<T, NT, S_LOWER>(L, Li, lds, ln);                            // L^-T (upper) in L
+        }
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(X, W, M);                           // W M | W^T M
+        if constexpr (TRANS) tn<T, NT, S_LOWER, S_FULL, S_FULL, OP_NEG>(M, Li, X);    // -L^-T X
+        else tn<T, NT, S_UPPER, S_FULL, S_FULL, OP_NEG>(M, L, X);                     // -L^-1 X
+        RV<T, NT> vr;
+        cv_to_rv<T, NT>(vr, v, ln);
+        tn_mv<T, NT, S_FULL>(y, W, vr);                                               // W v | W^T v
+        MF_UNROLL for (int j = 0; j < NT; ++j) rk.v[j] -= y.v[j];
+        cv_to_rv<T, NT>(vr, rk, ln);
+        if constexpr (TRANS) tn_mv<T, NT, S_LOWER>(v, Li, vr);
+        else tn_mv<T, NT, S_UPPER>(v, L, vr);
+    }
+    const long id = s * a.P + c;
+    store_mat<T, NT, false>(a.wM + id * dd, M, d, lds, ln);
+    store_cv<T, NT>(a.wv + id * d, v, d, ln);
+    (void)bad;
+}
+// the z every chunk starts from: z_in(c + 1) = M_c z_in(c) + v_c, z_in(0) = 0 - a wavefront per series
+template <typename T, int NT>
+__global__ void __launch_bounds__(64) wave_solve_boundary_kernel(SolveArgs<T> a) {
+    Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
+    const long s = blockIdx.x;
+    const int d = a.d;
+    const long dd = long(d) * d;
+    CV<T, NT> z;
+    MF_UNROLL for (int j = 0; j < NT; ++j) z.v[j] = T(0);
+    for (long c = 0; c + 1 < a.P; ++c) {
+        const long id = s * a.P + c;
+        Mat<T, NT> MT;
+        CV<T, NT> vc, y;
+        RV<T, NT> zr;
+        load_mat_t<T, NT>(MT, a.wM + id * dd, d, ln);
+        load_cv<T, NT>(vc, a.wv + id * d, d, ln);
+        cv_to_rv<T, NT>(zr, z, ln);
+        tn_mv<T, NT, S_FULL>(y, MT, zr);                                               // M z
+        MF_UNROLL for (int j = 0; j < NT; ++j) z.v[j] = y.v[j] + vc.v[j];
+        store_cv<T, NT>(a.zin + (id + 1) * d, z, d, ln);
     }
 }
 

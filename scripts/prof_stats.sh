@@ -9,6 +9,6 @@ python3 - <<PY | tee $R/gpurun_out/${TAG}_stats.txt
 import csv, glob
 f = glob.glob("/tmp/ps_$TAG/**/*kernel_stats.csv", recursive=True)
 print("# $*")
-for r in list(csv.DictReader(open(f[0])))[:12] if f else []:
+for r in list(csv.DictReader(open(f[0])))[:40] if f else []:
     print(f"{r['Name'][:90]:90s} calls {r['Calls']:>6s}  avg {float(r['AverageNs']) / 1e3:10.1f} us  {r['Percentage']}%")
 PY

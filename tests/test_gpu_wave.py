@@ -143,7 +143,9 @@ def test_wave_precision_prior_and_posterior(rng, dtype, d, m, t, bsz):
 @pytest.mark.parametrize("dtype,d", [(torch.float64, 16), (torch.float64, 17), (torch.float64, 24), (torch.float64, 31),
                                      (torch.float64, 32), (torch.float32, 16), (torch.float32, 21), (torch.float32, 32)])
 @pytest.mark.parametrize("bl,lead,n,has_sub", [(1, (), 1, False), (3, (), 2, True), (5, (2,), 37, True), (2, (3,), 11, False),
-                                               (9, (), 200, True)])
+                                               # long enough for the time partition (composed maps on the register tiles, then the
+                                               # walk per chunk): even and ragged last chunks
+                                               (9, (), 200, True), (4, (), 300, True), (3, (), 131, True)])
 def test_wave_solve_both_orientations(rng, dtype, d, bl, lead, n, has_sub):
     """block_tri_diag.py:339-351: L z = r and L^T z = r, right-hand sides with leading dimensions broadcast over the factor
     (series r uses factor r % Bl), ragged wavefronts (Br not a multiple of the 4 or 2 series a wavefront walks), a block-diagonal
