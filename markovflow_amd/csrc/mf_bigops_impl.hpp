@@ -279,42 +279,46 @@ __global__ void __launch_bounds__(NTHR) bigop_ssm_precision_kernel(BigArgs a, re
 // of the next transition in registers, fetched one step ahead; the current mean reaches the other lanes by v_readlane - no LDS, no
 // barrier (round 6; the first form wrote the mean to LDS behind two workgroup barriers per step and loaded its row element by
 // element after them: 1.2 / 2.1 ms at B = 512, T = 1000, d = 16 / 32 in fp64, a third of StateSpaceModel.kl_divergence there).
+// P > 1: workgroup (r, c) walks positions (c Lc, (c + 1) Lc] from the mean m_in[r, c] of position c Lc (wave_means_up_kernel /
+// wave_means_boundary_kernel, mf_wave_ops.hpp: the composed maps of the chunks).
 __global__ void __launch_bounds__(64) bigop_means_kernel(long Bl, long Br, long Tn, int d, const real* __restrict__ A,
-                                                        const real* __restrict__ offs, real* __restrict__ out) {
-    const long r = blockIdx.x, s = r % Bl;
+                                                        const real* __restrict__ offs, real* __restrict__ out, long P, long Lc,
+                                                        const real* __restrict__ m_in) {
+    const long r = P > 1 ? blockIdx.x / P : blockIdx.x, c = P > 1 ? blockIdx.x % P : 0, s = r % Bl;
+    const long k_lo = P > 1 ? c * Lc + 1 : 1, k_hi = P > 1 ? ((c + 1) * Lc + 1 < Tn ? (c + 1) * Lc + 1 : Tn) : Tn;
     const int i = threadIdx.x;
     const int ii = i < d ? i : d - 1;             // the idle lanes shadow the last row: every load stays in range
     const long dd = (long)d * d;
-    real cur = offs[r * Tn * d + ii];
-    if (i < d) out[r * Tn * d + i] = cur;
+    real cur = c == 0 ? offs[r * Tn * d + ii] : m_in[(r * P + c) * d + ii];
+    if (c == 0 && i < d) out[r * Tn * d + i] = cur;
     real a[64], an[64];
     auto load_row = [&](long k, real (&dst)[64]) {
         const real* Am = A + (s * (Tn - 1) + k) * dd + (long)ii * d;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (16 * c >= d) break;
+        for (int cc = 0; cc < 4; ++cc) {
+            if (16 * cc >= d) break;
 #pragma unroll
             for (int jj = 0; jj < 16; ++jj) {
-                const int j = 16 * c + jj;
+                const int j = 16 * cc + jj;
                 dst[j] = j < d ? Am[j] : real(0);
             }
         }
     };
-    if (Tn > 1) load_row(0, a);
-    for (long k = 1; k < Tn; ++k) {
+    if (k_hi > k_lo) load_row(k_lo - 1, a);
+    for (long k = k_lo; k < k_hi; ++k) {
         // (the offset is requested BEFORE the prefetch of the next row: loads are waited for in order, and a wait for the offset
         // must not include the row that was only just requested)
         const real o = offs[(r * Tn + k) * d + ii];
         __builtin_amdgcn_sched_barrier(0);
-        if (k + 1 < Tn) load_row(k, an);
+        if (k + 1 < k_hi) load_row(k, an);
         real acc0 = 0, acc1 = 0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (16 * c >= d) break;
+        for (int cc = 0; cc < 4; ++cc) {
+            if (16 * cc >= d) break;
 #pragma unroll
             for (int jj = 0; jj < 16; jj += 2) {
-                acc0 += a[16 * c + jj] * bcast(cur, 16 * c + jj);             // (columns beyond d hold zeros)
-                acc1 += a[16 * c + jj + 1] * bcast(cur, 16 * c + jj + 1);
+                acc0 += a[16 * cc + jj] * bcast(cur, 16 * cc + jj);             // (columns beyond d hold zeros)
+                acc1 += a[16 * cc + jj + 1] * bcast(cur, 16 * cc + jj + 1);
             }
         }
         cur = acc0 + acc1 + o;
@@ -536,8 +540,9 @@ inline int op_ssm_precision(long B, long Tn, int d, int m, const real* mu0, cons
 #undef MF_C
     return big_ok();
 }
-inline int op_means(long Bl, long Br, long Tn, int d, const real* A, const real* offs, real* out, hipStream_t st) {
-    hipLaunchKernelGGL(bigop_means_kernel, dim3((unsigned)Br), dim3(64), 0, st, Bl, Br, Tn, d, A, offs, out);
+inline int op_means(long Bl, long Br, long Tn, int d, const real* A, const real* offs, real* out, hipStream_t st, long P = 1,
+                    long Lc = 0, const real* m_in = nullptr) {
+    hipLaunchKernelGGL(bigop_means_kernel, dim3((unsigned)(Br * P)), dim3(64), 0, st, Bl, Br, Tn, d, A, offs, out, P, Lc, m_in);
     return big_ok();
 }
 // chunks per series of the covariance recursion: about two workgroups per CU, chunks of at least eight transitions

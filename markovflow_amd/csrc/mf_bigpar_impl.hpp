@@ -644,6 +644,12 @@ inline int op_solve_par(long Bl, long Br, long n, int d, const real* ldiag, cons
 // marginal means: the workspace of the solve (N [Br, P, d, d], a [Br, P, d])
 inline int op_means_par(long Bl, long Br, long n, int d, const real* A, const real* offs, real* out, void* ws, size_t ws_bytes,
                         hipStream_t st) {
+    if (!wave_off()) {   // 16 <= d <= 32: the chunk maps on the register tiles, then the readlane walk per chunk
+        long Pw = 1, Lw = 0;
+        const real* m_in = nullptr;
+        if (wave_means_boundaries(Bl, Br, n, d, A, offs, ws, ws_bytes, &Pw, &Lw, &m_in, st) != 0) return -1000;
+        if (Pw > 1) return op_means(Bl, Br, n, d, A, offs, out, st, Pw, Lw, m_in);
+    }
     long P, L;
     bigpar_partition(Br, n, d, P, L);
     if (P == 1 || !ws || ws_bytes < bigpar_solve_ws(Bl, Br, n, d)) return op_means(Bl, Br, n, d, A, offs, out, st);

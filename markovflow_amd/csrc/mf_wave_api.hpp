@@ -69,6 +69,20 @@ inline int wave_btd_solve(long Bl, long Br, long n, int d, const float* ldiag, c
                           void* ws, size_t ws_bytes, hipStream_t st) {
     return wave_btd_solve_f32(Bl, Br, n, d, ldiag, lsub, rhs, out, transpose, ws, ws_bytes, st);
 }
+// marginal_means at 16 <= d <= 32 partitioned in time: the chunk maps and the mean every chunk starts from (mf_wave_ops.hpp), in the
+// solve's workspace; *P = 1: not partitioned (nothing launched).  The walk per chunk is the caller's (bigop_means_kernel).
+int wave_means_boundaries_f64(long Bl, long Br, long n, int d, const double* A, const double* offs, void* ws, size_t ws_bytes, long* P,
+                              long* Lc, const double** m_in, hipStream_t st);
+int wave_means_boundaries_f32(long Bl, long Br, long n, int d, const float* A, const float* offs, void* ws, size_t ws_bytes, long* P,
+                              long* Lc, const float** m_in, hipStream_t st);
+inline int wave_means_boundaries(long Bl, long Br, long n, int d, const double* A, const double* offs, void* ws, size_t ws_bytes, long* P,
+                                 long* Lc, const double** m_in, hipStream_t st) {
+    return wave_means_boundaries_f64(Bl, Br, n, d, A, offs, ws, ws_bytes, P, Lc, m_in, st);
+}
+inline int wave_means_boundaries(long Bl, long Br, long n, int d, const float* A, const float* offs, void* ws, size_t ws_bytes, long* P,
+                                 long* Lc, const float** m_in, hipStream_t st) {
+    return wave_means_boundaries_f32(Bl, Br, n, d, A, offs, ws, ws_bytes, P, Lc, m_in, st);
+}
 // workspace of the time-partitioned wave solve (0: not partitioned / not covered)
 size_t wave_btd_solve_ws(long Bl, long Br, long n, int d, int elem_size);
 // mf_wave_inst.hip: the factorisations with one wavefront per series walking the time axis (mf_wave_ops.hpp); -101: not covered.

@@ -207,10 +207,47 @@ int wave_solve(long Bl, long Br, long n, int d, const T* ldiag, const T* lsub, c
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 }  // namespace
+namespace {
+template <typename T>
+int wave_means_bnd(long Bl, long Br, long n, int d, const T* A, const T* offs, void* ws, size_t ws_bytes, long* Pout, long* Lout,
+                   const T** m_in, hipStream_t st) {
+    *Pout = 1; *Lout = n; *m_in = nullptr;
+    if (!wave_covers(d, 1) || n < 2) return 0;
+    long P, Lc;
+    // the solve's rule over the n - 1 transitions (the walk is one dependent ~1.1 us block step after another: 1.15 ms at T = 1000)
+    wave_solve_partition(Bl, Br, d, n - 1, P, Lc);
+    static const bool nopart = getenv("MF_WAVE_SOLVE_NOPART") != nullptr;
+    if (nopart || P < 2 || !ws || ws_bytes < size_t(Br) * P * (size_t(d) * d + 2 * d) * sizeof(T)) return 0;
+    wv::MeansArgs<T> a{Br, n, d, A, offs, P, Lc, static_cast<T*>(ws), nullptr, nullptr};
+    a.wv = a.wM + size_t(Br) * P * d * d;
+    a.m_in = a.wv + size_t(Br) * P * d;
+    const dim3 block(64), gup((unsigned)(Br * (P - 1))), gb((unsigned)Br);
+    if (d <= 16) {
+        hipLaunchKernelGGL((wv::wave_means_up_kernel<T, 1>), gup, block, 0, st, a);
+        hipLaunchKernelGGL((wv::wave_means_boundary_kernel<T, 1>), gb, block, 0, st, a);
+    } else {
+        hipLaunchKernelGGL((wv::wave_means_up_kernel<T, 2>), gup, block, 0, st, a);
+        hipLaunchKernelGGL((wv::wave_means_boundary_kernel<T, 2>), gb, block, 0, st, a);
+    }
+    if (hipGetLastError() != hipSuccess) return -1000;
+    *Pout = P; *Lout = Lc; *m_in = a.m_in;
+    return 0;
+}
+}  // namespace
+int wave_means_boundaries_f64(long Bl, long Br, long n, int d, const double* A, const double* offs, void* ws, size_t ws_bytes, long* P,
+                              long* Lc, const double** m_in, hipStream_t st) {
+    return wave_means_bnd<double>(Bl, Br, n, d, A, offs, ws, ws_bytes, P, Lc, m_in, st);
+}
+int wave_means_boundaries_f32(long Bl, long Br, long n, int d, const float* A, const float* offs, void* ws, size_t ws_bytes, long* P,
+                              long* Lc, const float** m_in, hipStream_t st) {
+    return wave_means_bnd<float>(Bl, Br, n, d, A, offs, ws, ws_bytes, P, Lc, m_in, st);
+}
 size_t wave_btd_solve_ws(long Bl, long Br, long n, int d, int elem_size) {
     if (!wave_covers(d, 1)) return 0;
-    long P, Lc;
+    long P, Lc, Pm, Lm;
     wave_solve_partition(Bl, Br, d, n, P, Lc);
+    wave_solve_partition(Bl, Br, d, n > 1 ? n - 1 : 1, Pm, Lm);                   // marginal_means (wave_means_bnd) shares the workspace
+    if (Pm > P) P = Pm;
     return P > 1 ? size_t(Br) * P * (size_t(d) * d + 2 * d) * elem_size : 0;
 }
 int wave_btd_solve_f64(long Bl, long Br, long n, int d, const double* ldiag, const double* lsub, const double* rhs, double* out,

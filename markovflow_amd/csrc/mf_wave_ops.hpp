@@ -205,6 +205,81 @@ __global__ void __launch_bounds__(64) wave_solve_up_kernel(SolveArgs<T> a) {
     store_cv<T, NT>(a.wv + id * d, v, d, ln);
     (void)bad;
 }
+// ---- StateSpaceModel.marginal_means partitioned in time: the maps of the chunks on the register tiles -----------------------------
+// m_t = A_{t-1} m_{t-1} + o_t (m_0 = o_0).  Chunk c carries position c Lc to (c + 1) Lc: M <- A M, v <- A v + o (one product and one
+// matrix-vector product per block, A read transposed: A M = tn(A^T, M)); then m_in(c + 1) = M_c m_in(c) + v_c, a wavefront per series.
+// The walk per chunk from m_in(c) is bigop_means_kernel (mf_bigops_impl.hpp: a row of A per lane, the mean by v_readlane).
+template <typename T> struct MeansArgs {
+    long B, n;
+    int d;
+    const T *A, *offs;
+    long P, Lc;
+    T *wM, *wv, *m_in;       // [B, P, d, d], [B, P, d], [B, P, d]
+};
+template <typename T, int NT>
+__global__ void __launch_bounds__(64) wave_means_up_kernel(MeansArgs<T> a) {
+    constexpr int TS = 16 * Tr<T>::LD;
+    __shared__ __attribute__((aligned(16))) T lds[NT * NT * TS];
+    Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
+    const long s = blockIdx.x / (a.P - 1), c = blockIdx.x % (a.P - 1), n = a.n;
+    const long t_lo = c * a.Lc + 1, t_hi = (c + 1) * a.Lc + 1 < n ? (c + 1) * a.Lc + 1 : n;
+    int d = a.d;
+    const long dd = long(d) * d;
+    const T* Ag = a.A + s * (n - 1) * dd;
+    const T* og = a.offs + s * n * d;
+    Mat<T, NT> M, AT;
+    CV<T, NT> v, ok;
+    identity_mat<T, NT>(M, ln);
+    MF_UNROLL for (int j = 0; j < NT; ++j) v.v[j] = T(0);
+    if (t_hi > t_lo) {
+        load_mat_t<T, NT>(AT, Ag + (t_lo - 1) * dd, d, ln);
+        load_cv<T, NT>(ok, og + t_lo * d, d, ln);
+    }
+    for (long t = t_lo; t < t_hi; ++t) {
+        asm volatile("" : "+v"(ln.r), "+v"(ln.q));
+        asm volatile("" : "+s"(d));
+        Mat<T, NT> ATn, X;
+        CV<T, NT> on, y;
+        const long tn_ = t + 1 < t_hi ? t + 1 : t;
+        load_mat_t<T, NT>(ATn, Ag + (tn_ - 1) * dd, d, ln);
+        load_cv<T, NT>(on, og + tn_ * d, d, ln);
+        phase();
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(X, AT, M);                           // A M
+        M = X;
+        RV<T, NT> vr;
+        cv_to_rv<T, NT>(vr, v, ln);
+        tn_mv<T, NT, S_FULL>(y, AT, vr);                                               // A v
+        MF_UNROLL for (int j = 0; j < NT; ++j) v.v[j] = y.v[j] + ok.v[j];
+        AT = ATn;
+        MF_UNROLL for (int j = 0; j < NT; ++j) ok.v[j] = on.v[j];
+    }
+    const long id = s * a.P + c;
+    store_mat<T, NT, false>(a.wM + id * dd, M, d, lds, ln);
+    store_cv<T, NT>(a.wv + id * d, v, d, ln);
+}
+template <typename T, int NT>
+__global__ void __launch_bounds__(64) wave_means_boundary_kernel(MeansArgs<T> a) {
+    Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
+    const long s = blockIdx.x;
+    const int d = a.d;
+    const long dd = long(d) * d;
+    CV<T, NT> m;
+    load_cv<T, NT>(m, a.offs + s * a.n * d, d, ln);
+    store_cv<T, NT>(a.m_in + (s * a.P) * d, m, d, ln);
+    for (long c = 0; c + 1 < a.P; ++c) {
+        const long id = s * a.P + c;
+        Mat<T, NT> MT;
+        CV<T, NT> vc, y;
+        RV<T, NT> mr;
+        load_mat_t<T, NT>(MT, a.wM + id * dd, d, ln);
+        load_cv<T, NT>(vc, a.wv + id * d, d, ln);
+        cv_to_rv<T, NT>(mr, m, ln);
+        tn_mv<T, NT, S_FULL>(y, MT, mr);                                               // M m
+        MF_UNROLL for (int j = 0; j < NT; ++j) m.v[j] = y.v[j] + vc.v[j];
+        store_cv<T, NT>(a.m_in + (id + 1) * d, m, d, ln);
+    }
+}
+
 // the z every chunk starts from: z_in(c + 1) = M_c z_in(c) + v_c, z_in(0) = 0 - a wavefront per series
 template <typename T, int NT>
 __global__ void __launch_bounds__(64) wave_solve_boundary_kernel(SolveArgs<T> a) {

@@ -255,7 +255,7 @@ def test_wave_posterior_chain_against_the_oracle(rng, dtype, d, m, bsz, t):
 # ---- marginals / covariance blocks / KL on the register tiles (csrc/mf_wave_ops.hpp: wave_marginals_kernel) ------------------------
 @pytest.mark.parametrize("dtype,d", [(torch.float64, 16), (torch.float64, 23), (torch.float64, 32), (torch.float32, 16),
                                      (torch.float32, 27), (torch.float32, 32)])
-@pytest.mark.parametrize("bsz,t", [(1, 2), (70, 9), (3, 130), (70, 67), (1, 700)])
+@pytest.mark.parametrize("bsz,t", [(1, 2), (70, 9), (3, 130), (70, 67), (1, 700), (5, 331)])
 def test_wave_marginals_and_covariance_blocks(rng, dtype, d, bsz, t):
     """state_space_model.py:232-262,326-341 / gauss_markov.py:107-117: means, covariances and Cov(x_{k+1}, x_k) of every series
     against the explicit forward recursion; the KL divergence to a second chain (state_space_model.py:528-593) against the oracle."""
@@ -276,6 +276,8 @@ def test_wave_marginals_and_covariance_blocks(rng, dtype, d, bsz, t):
     ec = np.stack(ec, axis=1)
     tol = TOL[dtype]
     np.testing.assert_allclose(nn(means), em, **tol)
+    # the means alone: from 129 transitions on the chunk maps on the register tiles, then the walk per chunk (mf_wave_ops.hpp)
+    np.testing.assert_allclose(nn(ssm.marginal_means), em, **tol)
     np.testing.assert_allclose(nn(covs), ec, **tol)
     np.testing.assert_allclose(nn(covs2), ec, **tol)
     np.testing.assert_allclose(nn(sub), O.ssm_subsequent_covariances(kw["a_s"], ec), **tol)
