@@ -10,6 +10,7 @@ from markovflow_amd import _lib
 ap = argparse.ArgumentParser()
 ap.add_argument("--T", type=int, default=100000); ap.add_argument("--d", type=int, default=6)
 ap.add_argument("--batch", type=int, default=1); ap.add_argument("--dtype", default="f32"); ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--op", default="all", help="all | chol (the factorisation only: for kernel timelines)")
 a = ap.parse_args()
 dev = torch.device("cuda:0"); dt = torch.float32 if a.dtype == "f32" else torch.float64
 B, n, d = a.batch, a.T, a.d
@@ -40,7 +41,10 @@ def timeit(fn):
     for _ in range(a.iters): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / a.iters
-tc, ts, tst = timeit(chol), timeit(solve), timeit(lambda: solve(1))
+tc = timeit(chol)
+if a.op == "chol":
+    print(f"B={B} T={n} d={d} {a.dtype}: cholesky {tc*1e3:.1f} us"); sys.exit(0)
+ts, tst = timeit(solve), timeit(lambda: solve(1))
 err = float((ld.double() - ldiag).abs().max())
 bc, bs = B * n * 4 * d * d * esz, B * n * (2 * d * d + 2 * d) * esz
 print(f"B={B} T={n} d={d} {a.dtype} parallel_ws={wsb>0}: cholesky {tc*1e3:.1f} us = {bc/tc/1e6:.1f} GB/s | solve {ts*1e3:.1f} us = {bs/ts/1e6:.1f} GB/s | "
