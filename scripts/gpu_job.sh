@@ -28,7 +28,12 @@ panel)
 wave)
   { timeout 1200 python -m pytest tests/test_gpu_wave.py tests/test_gpu_large_d_ops.py -q 2>&1 | tail -3
     for dt in f64 f32; do python scripts/bench_wave.py --dims 15,16,17,24,30,32 --dtype $dt 2>&1 | noids; done
-    for dt in f64 f32; do python scripts/bench_wave.py --dims 24,32 --dtype $dt --m 8 2>&1 | noids; done; } | tee gpurun_out/${TAG}_wave.txt ;;
+    for dt in f64 f32; do python scripts/bench_wave.py --dims 24,32 --dtype $dt --m 8 2>&1 | noids; done
+    echo "== operators, B = 512 / 64, T = 1000, f64 (scripts/bench_bigops.py)"
+    for d in 16 32; do for b in 512 64; do echo "-- d=$d B=$b"; python scripts/bench_bigops.py --batch $b --T 1000 --d $d --m 1 --dtype f64 --iters 5 2>&1 | noids | grep -v "^$"; done; done
+    echo "== kl_divergence pieces (scripts/prof_kl_wave.py)"; python scripts/prof_kl_wave.py 2>&1 | noids | tail -8
+    echo "== operator adjoints (scripts/bench_adjoints.py)"; python scripts/bench_adjoints.py 2>&1 | noids
+    python scripts/bench_adjoints.py --dtype f32 --dims 16,32 2>&1 | noids; } | tee gpurun_out/${TAG}_wave.txt ;;
 fuzz)
   { echo "== fuzz_parity.py 300 17"; timeout 1200 python3 scripts/fuzz_parity.py 300 17 2>&1 | noids | tail -3
     echo "== fuzz_large_d.py 200 19"; timeout 900 python3 scripts/fuzz_large_d.py 200 19 2>&1 | noids | tail -2
