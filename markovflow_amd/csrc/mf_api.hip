@@ -645,10 +645,17 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
                                    T* out_cross, T* out_N, T* out_n, void* ws, size_t ws_bytes, int* info,             \
                                    void* stream) {                                                                     \
         MF_HEAD(T, B, Tn, d)                                                                                           \
-        if (!t) return -100;                                                                                            \
         if (!mu0_1 || !cholP0_1 || (Tn > 1 && (!A_1 || !b_1 || !cholQ_1))) return -4;                                  \
         if (!mu0_2 || !cholP0_2 || (Tn > 1 && (!A_2 || !b_2 || !cholQ_2))) return -9;                                  \
         if (!out) return -14;                                                                                          \
+        if (!t) {   /* 16 <= d <= 32, the value alone: the moment recursion and the block terms in one walk (mf_wave_ops.hpp) */ \
+            if (Tn > 1 && !out_means && !out_covs && !out_cross && !out_N && !out_n) {                                  \
+                const int rc_ = mf::wave_ssm_kl_fused_##SUF(B, Tn, d, mu0_1, cholP0_1, A_1, b_1, cholQ_1, mu0_2, cholP0_2, A_2, \
+                                                            b_2, cholQ_2, out, ws, ws_bytes, S(stream));                \
+                if (rc_ != -101) return rc_;                                                                           \
+            }                                                                                                          \
+            return -100;                                                                                               \
+        }                                                                                                              \
         return t->kl(B, Tn, mu0_1, cholP0_1, A_1, b_1, cholQ_1, mu0_2, cholP0_2, A_2, b_2, cholQ_2, out, out_means,    \
                      out_covs, out_cross, out_N, out_n, ws, ws_bytes, info, S(stream));                                \
     }                                                                                                                  \
@@ -770,9 +777,9 @@ size_t mf_ssm_marginals_workspace_bytes(int64_t B, int64_t T, int d, int elem_si
 
 size_t mf_ssm_kl_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {
     if (B < 1 || T < 1) return 0;
-    if (elem_size == 4) { const auto* t = table_for<float>(d); return t ? t->kl_ws(B, T) : 0; }
+    if (elem_size == 4) { const auto* t = table_for<float>(d); return t ? t->kl_ws(B, T) : mf::wave_ssm_kl_fused_ws(B, T, d, 4); }
     const auto* t = table_for<double>(d);
-    return t ? t->kl_ws(B, T) : 0;
+    return t ? t->kl_ws(B, T) : mf::wave_ssm_kl_fused_ws(B, T, d, 8);
 }
 
 size_t mf_ssm_adjoint_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {

@@ -56,6 +56,14 @@ int wave_ssm_kl_f64(long B, long Tn, int d, const double* cp0_1, const double* c
 int wave_ssm_kl_f32(long B, long Tn, int d, const float* cp0_1, const float* cq_1, const float* cp0_2, const float* a_2,
                     const float* cq_2, const float* cov, const float* cross, const float* mdiff, float* out, void* ws, size_t ws_bytes,
                     hipStream_t st);
+// mf_wave_inst.hip: StateSpaceModel.kl_divergence in one walk per (series, chunk) (wave_kl_walk_kernel); -101: not covered, -15: workspace
+size_t wave_ssm_kl_fused_ws(long B, long n, int d, int elem_size);
+int wave_ssm_kl_fused_f64(long B, long n, int d, const double* mu0_1, const double* cp0_1, const double* a_1, const double* b_1,
+                          const double* cq_1, const double* mu0_2, const double* cp0_2, const double* a_2, const double* b_2,
+                          const double* cq_2, double* out, void* ws, size_t ws_bytes, hipStream_t st);
+int wave_ssm_kl_fused_f32(long B, long n, int d, const float* mu0_1, const float* cp0_1, const float* a_1, const float* b_1,
+                          const float* cq_1, const float* mu0_2, const float* cp0_2, const float* a_2, const float* b_2,
+                          const float* cq_2, float* out, void* ws, size_t ws_bytes, hipStream_t st);
 // mf_wave_inst.hip: solve with the time axis walked serially inside a wavefront (mf_wave_ops.hpp); -101: not covered
 int wave_btd_solve_f64(long Bl, long Br, long n, int d, const double* ldiag, const double* lsub, const double* rhs, double* out,
                        int transpose, void* ws, size_t ws_bytes, hipStream_t st);

@@ -137,6 +137,62 @@ int wave_ssm_kl_f32(long B, long Tn, int d, const float* cp0_1, const float* cq_
     return wave_kl<float>(B, Tn, d, cp0_1, cq_1, cp0_2, a_2, cq_2, cov, cross, mdiff, out, ws, ws_bytes, st);
 }
 
+// ---- kl_divergence at 16 <= d <= 32 in one walk per (series, chunk): wave_kl_walk_kernel (mf_wave_ops.hpp) -----------------------
+void wave_marg_partition(long B, long nt, int d, int elem_size, long& P, long& L);
+namespace {
+template <typename T> size_t wave_kl_fused_need(long B, long n, int d, long P) {
+    // q1: wM, wN, bP [B, P, d, d], wv, bm [B, P, d]; q2: wM [B, P, d, d], wv, m_in [B, P, d]; terms [B, n]
+    return (size_t(B) * P * (4 * size_t(d) * d + 4 * size_t(d)) + size_t(B) * n) * sizeof(T) + 256;
+}
+template <typename T>
+int wave_kl_fused(long B, long n, int d, const T* mu0_1, const T* cp0_1, const T* a_1, const T* b_1, const T* cq_1, const T* mu0_2,
+                  const T* cp0_2, const T* a_2, const T* b_2, const T* cq_2, T* out, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!wave_covers(d, 1) || B <= 0 || n < 2) return -101;
+    long P = 1, L = n - 1;
+    wave_marg_partition(B, n - 1, d, (int)sizeof(T), P, L);
+    if (!ws || ws_bytes < wave_kl_fused_need<T>(B, n, d, P)) return -15;
+    const size_t blk = size_t(B) * P * d * d, vec = size_t(B) * P * d;
+    T* p = static_cast<T*>(ws);
+    wv::MargArgs<T> m1{B, n, d, mu0_1, cp0_1, a_1, b_1, cq_1, /*omean (non-NULL: the means are wanted)*/ p, nullptr, nullptr};
+    m1.P = P; m1.L = L;
+    m1.wM = p; m1.wN = p + blk; m1.bP = p + 2 * blk; m1.wv = p + 3 * blk; m1.bm = m1.wv + vec;
+    T* q = m1.bm + vec;
+    wv::MeansArgs<T> m2{B, n, d, a_2, nullptr, P, L, q, q + blk, q + blk + vec, mu0_2, b_2};
+    T* terms = q + blk + 2 * vec;
+    const wv::KlWalkArgs<T> ka{B, n, d, mu0_1, cp0_1, a_1, b_1, cq_1, mu0_2, cp0_2, a_2, b_2, cq_2, P, L, m1.bP, m1.bm, m2.m_in, terms};
+    const dim3 chunks((unsigned)(B * P)), series((unsigned)B), block(64);
+    auto go = [&](auto ntag) {
+        constexpr int NT = decltype(ntag)::value;
+        if (P > 1) {
+            hipLaunchKernelGGL((wv::wave_marg_up_kernel<T, NT>), chunks, block, 0, st, m1);
+            hipLaunchKernelGGL((wv::wave_marg_boundary_kernel<T, NT>), series, block, 0, st, m1);
+            hipLaunchKernelGGL((wv::wave_means_up_kernel<T, NT>), dim3((unsigned)(B * (P - 1))), block, 0, st, m2);
+            hipLaunchKernelGGL((wv::wave_means_boundary_kernel<T, NT>), series, block, 0, st, m2);
+        }
+        hipLaunchKernelGGL((wv::wave_kl_walk_kernel<T, NT>), chunks, block, 0, st, ka);
+    };
+    if (d <= 16) go(std::integral_constant<int, 1>{}); else go(std::integral_constant<int, 2>{});
+    hipLaunchKernelGGL((wv::row_sums_kernel<T>), series, block, 0, st, B, n, static_cast<const T*>(terms), T(0.5), out);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+}  // namespace
+size_t wave_ssm_kl_fused_ws(long B, long n, int d, int elem_size) {
+    if (!wave_covers(d, 1) || B <= 0 || n < 2) return 0;
+    long P = 1, L = n - 1;
+    wave_marg_partition(B, n - 1, d, elem_size, P, L);
+    return elem_size == 8 ? wave_kl_fused_need<double>(B, n, d, P) : wave_kl_fused_need<float>(B, n, d, P);
+}
+int wave_ssm_kl_fused_f64(long B, long n, int d, const double* mu0_1, const double* cp0_1, const double* a_1, const double* b_1,
+                          const double* cq_1, const double* mu0_2, const double* cp0_2, const double* a_2, const double* b_2,
+                          const double* cq_2, double* out, void* ws, size_t ws_bytes, hipStream_t st) {
+    return wave_kl_fused<double>(B, n, d, mu0_1, cp0_1, a_1, b_1, cq_1, mu0_2, cp0_2, a_2, b_2, cq_2, out, ws, ws_bytes, st);
+}
+int wave_ssm_kl_fused_f32(long B, long n, int d, const float* mu0_1, const float* cp0_1, const float* a_1, const float* b_1,
+                          const float* cq_1, const float* mu0_2, const float* cp0_2, const float* a_2, const float* b_2,
+                          const float* cq_2, float* out, void* ws, size_t ws_bytes, hipStream_t st) {
+    return wave_kl_fused<float>(B, n, d, mu0_1, cp0_1, a_1, b_1, cq_1, mu0_2, cp0_2, a_2, b_2, cq_2, out, ws, ws_bytes, st);
+}
+
 // ---- LowerTriangularBlockTriDiagonal.solve for 16 <= d <= 32: the time axis serially inside a wavefront (wave_solve_kernel) -----------
 namespace {
 // Chunks of the time-partitioned solve: enough (series, chunk) pairs for ~3 wavefronts of the map pass per SIMD, chunks of at least

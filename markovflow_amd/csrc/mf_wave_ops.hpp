@@ -212,9 +212,13 @@ __global__ void __launch_bounds__(64) wave_solve_up_kernel(SolveArgs<T> a) {
 template <typename T> struct MeansArgs {
     long B, n;
     int d;
-    const T *A, *offs;
+    const T *A, *offs;       // offs [B, n, d]: o_0 = mu0, o_t = b_{t-1}; or NULL and (mu0 [B, d], b [B, n - 1, d]) below
     long P, Lc;
     T *wM, *wv, *m_in;       // [B, P, d, d], [B, P, d], [B, P, d]
+    const T *mu0, *b;
+    MF_DEV const T* off(long s, long t) const {
+        return offs ? offs + (s * n + t) * d : (t == 0 ? mu0 + s * d : b + (s * (n - 1) + t - 1) * d);
+    }
 };
 template <typename T, int NT>
 __global__ void __launch_bounds__(64) wave_means_up_kernel(MeansArgs<T> a) {
@@ -226,14 +230,13 @@ __global__ void __launch_bounds__(64) wave_means_up_kernel(MeansArgs<T> a) {
     int d = a.d;
     const long dd = long(d) * d;
     const T* Ag = a.A + s * (n - 1) * dd;
-    const T* og = a.offs + s * n * d;
     Mat<T, NT> M, AT;
     CV<T, NT> v, ok;
     identity_mat<T, NT>(M, ln);
     MF_UNROLL for (int j = 0; j < NT; ++j) v.v[j] = T(0);
     if (t_hi > t_lo) {
         load_mat_t<T, NT>(AT, Ag + (t_lo - 1) * dd, d, ln);
-        load_cv<T, NT>(ok, og + t_lo * d, d, ln);
+        load_cv<T, NT>(ok, a.off(s, t_lo), d, ln);
     }
     for (long t = t_lo; t < t_hi; ++t) {
         asm volatile("" : "+v"(ln.r), "+v"(ln.q));
@@ -242,7 +245,7 @@ __global__ void __launch_bounds__(64) wave_means_up_kernel(MeansArgs<T> a) {
         CV<T, NT> on, y;
         const long tn_ = t + 1 < t_hi ? t + 1 : t;
         load_mat_t<T, NT>(ATn, Ag + (tn_ - 1) * dd, d, ln);
-        load_cv<T, NT>(on, og + tn_ * d, d, ln);
+        load_cv<T, NT>(on, a.off(s, tn_), d, ln);
         phase();
         tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(X, AT, M);                           // A M
         M = X;
@@ -264,7 +267,7 @@ __global__ void __launch_bounds__(64) wave_means_boundary_kernel(MeansArgs<T> a)
     const int d = a.d;
     const long dd = long(d) * d;
     CV<T, NT> m;
-    load_cv<T, NT>(m, a.offs + s * a.n * d, d, ln);
+    load_cv<T, NT>(m, a.off(s, 0), d, ln);
     store_cv<T, NT>(a.m_in + (s * a.P) * d, m, d, ln);
     for (long c = 0; c + 1 < a.P; ++c) {
         const long id = s * a.P + c;
@@ -1106,6 +1109,192 @@ __global__ void __launch_bounds__(64) wave_marg_boundary_kernel(MargArgs<T> a) {
         store_mat<T, NT, false>(a.bP + (id + 1) * dd, P, d, lds, ln);
         store_cv<T, NT>(a.bm + (id + 1) * d, m, d, ln);
     }
+}
+
+// ---- StateSpaceModel.kl_divergence at 16 <= d <= 32 in ONE walk (state_space_model.py:528-593) ---------------------------------
+// KL(q1 || q2) = 1/2 sum_k [ tr(D_k Sigma_k) + 2 tr(S_k Cov(x_{k+1}, x_k)) + delta_k^T D_k delta_k + 2 delta_k^T S_k^T delta_{k+1}
+//                            + 2 log|C2_k| - 2 log|C1_k| - d ],   D_k = Q2_k^-1 + A2_{k+1}^T Q2_{k+1}^-1 A2_{k+1},  S_k = -Q2_{k+1}^-1 A2_{k+1}
+// (the block rows of q2's precision against q1's moments; wave_ssm_kl_terms_kernel, mf_wave.hpp, evaluates a block from moments in
+// memory).  Here the moments never exist in memory: wavefront (series, chunk) walks q1's moment recursion (wave_marginals_kernel:
+// P' = A1 P A1^T + C1 C1^T, Cov(x', x) = A1 P, m' = A1 m + b1) from the state wave_marg_boundary_kernel left for its chunk, q2's
+// means alongside (from wave_means_boundary_kernel), and reduces every block against q2's block row on the spot; the inverse of
+// q2's next factor is carried to the next block (one triangular inversion per block).  Per block terms go to `terms` [B, n] and
+// are summed in a fixed order by row_sums_kernel.  Round 6, first form: moments 1.37 ms (2 GB written) + terms 1.34 ms (2 GB read back)
+// at B = 512, T = 1000, d = 16.
+template <typename T> struct KlWalkArgs {
+    long B, n;
+    int d;
+    const T *mu0_1, *cp0_1, *A_1, *b_1, *cq_1;
+    const T *mu0_2, *cp0_2, *A_2, *b_2, *cq_2;
+    long P, L;                       // chunks of L transitions (P = 1: the whole chain)
+    const T *bP, *bm, *m2_in;        // [B, P, d, d], [B, P, d], [B, P, d]: q1's covariance / mean and q2's mean at position c L
+    T* terms;                        // [B, n]
+};
+template <typename T, int NT> MF_DEV void sym_complete(Mat<T, NT>& m, T* lds, const Lane& ln) {
+    if constexpr (NT == 2) transpose_tile<T>(m.t[1][0], m.t[0][1], lds, ln);
+}
+template <typename T, int NT> MF_DEV T frob(const Mat<T, NT>& x, const Mat<T, NT>& y, T acc) {
+    MF_UNROLL for (int i = 0; i < NT; ++i) MF_UNROLL for (int j = 0; j < NT; ++j)
+        MF_UNROLL for (int e = 0; e < 4; ++e) acc = __builtin_fma(x.t[i][j][e], y.t[i][j][e], acc);
+    return acc;
+}
+// sum_j log|C[j][j]| over the d x d lower factor at g (per 16-lane row: the caller takes sum16)
+template <typename T, int NT> MF_DEV T log_diag(const T* __restrict__ g, int d, const Lane& ln) {
+    T l = T(0);
+    MF_UNROLL for (int i = 0; i < NT; ++i) {
+        const int j = 16 * i + ln.r;
+        const T v = g[j < d ? j * d + j : 0];
+        l += (j < d) ? log(v < T(0) ? -v : v) : T(0);
+    }
+    return l;
+}
+template <typename T, int NT>
+__global__ void __launch_bounds__(64) wave_kl_walk_kernel(KlWalkArgs<T> a) {
+    constexpr bool EARLY = !(sizeof(T) == 8 && NT == 2);
+    using v4 = typename Tr<T>::v4;
+    constexpr int TS = 16 * Tr<T>::LD;
+    __shared__ __attribute__((aligned(16))) T lds[NT * NT * TS];
+    Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
+    const long s = blockIdx.x / a.P, c = blockIdx.x % a.P, n = a.n, nt = n - 1;
+    const long t_lo = c * a.L, t_hi = (c + 1) * a.L < nt ? (c + 1) * a.L : nt;
+    int d = a.d;
+    const long dd = long(d) * d;
+    LogAcc<T> la;
+    bool bad = false;
+    // q1 at position t_lo, q2's mean there
+    Mat<T, NT> P;
+    CV<T, NT> m1, m2;
+    if (c == 0) {
+        Mat<T, NT> CT;
+        load_lower_t<T, NT>(CT, a.cp0_1 + s * dd, d, ln);
+        tn<T, NT, S_UPPER, S_UPPER, S_FULL, OP_SET>(P, CT, CT);
+        load_cv<T, NT>(m1, a.mu0_1 + s * d, d, ln);
+        load_cv<T, NT>(m2, a.mu0_2 + s * d, d, ln);
+    } else {
+        load_mat<T, NT, S_FULL>(P, a.bP + (s * a.P + c) * dd, d, false, false, ln);
+        load_cv<T, NT>(m1, a.bm + (s * a.P + c) * d, d, ln);
+        load_cv<T, NT>(m2, a.m2_in + (s * a.P + c) * d, d, ln);
+    }
+    // Q2^-1 of block t_lo and log|C2| of it
+    Mat<T, NT> Q0;
+    T logdet0;
+    {
+        Mat<T, NT> C0, Ci;
+        v4 c10t = {0, 0, 0, 0};
+        const T* c0p = t_lo == 0 ? a.cp0_2 + s * dd : a.cq_2 + (s * nt + t_lo - 1) * dd;
+        load_mat<T, NT, S_LOWER>(C0, c0p, d, true, true, ln);
+        if constexpr (NT == 2) load_tile_t<T>(c10t, c0p, d, 1, 0, ln);
+        la.init();
+        tri_inv_mat<T, NT>(C0, c10t, Ci, lds, ln, la, bad);
+        logdet0 = tri_logdet<T, NT>(la);
+        tn<T, NT, S_LOWER, S_LOWER, S_UPPER, OP_SET>(Q0, Ci, Ci);
+        sym_complete<T, NT>(Q0, lds, ln);
+    }
+    // one block's terms from (D, S | none), q1's covariance and cross covariance, the mean differences
+    auto emit = [&](long k, Mat<T, NT>& Dn, const Mat<T, NT>* S, const Mat<T, NT>* cross, const CV<T, NT>& dk, const CV<T, NT>* dnext, T l1) {
+        T acc = frob<T, NT>(Dn, P, T(0));
+        if (S) acc = __builtin_fma(T(2), frob<T, NT>(*S, *cross, T(0)), acc);                 // + 2 sum(S o Cov(x_{k+1}, x_k))
+        T total = xor_rows<T>(sum16<T>(acc));
+        RV<T, NT> dr;
+        CV<T, NT> y;
+        cv_to_rv<T, NT>(dr, dk, ln);
+        tn_mv<T, NT, S_FULL>(y, Dn, dr);                                                      // D delta_k (D symmetric)
+        T mh = dot_cv<T, NT>(y, dk);
+        if (S) {
+            cv_to_rv<T, NT>(dr, *dnext, ln);
+            tn_mv<T, NT, S_FULL>(y, *S, dr);                                                  // S^T delta_{k+1}
+            mh = __builtin_fma(T(2), dot_cv<T, NT>(y, dk), mh);
+        }
+        total += sum16<T>(mh);
+        total += T(2) * logdet0 - T(2) * sum16<T>(l1) - T(d);
+        if (threadIdx.x == 0) a.terms[s * n + k] = total;
+    };
+    for (long k = t_lo; k < t_hi; ++k) {
+        asm volatile("" : "+v"(ln.r), "+v"(ln.q));
+        asm volatile("" : "+s"(d));
+        // EARLY (every instantiation but f64 at NT = 2, which has no registers for it): everything the block needs from memory is
+        // asked for here, one exposed round trip per block instead of five; the wavefronts sharing the SIMD cover that one
+        Mat<T, NT> C1, Am, A2T, A1T, CT1;
+        v4 c10t = {0, 0, 0, 0};
+        CV<T, NT> b1v, b2v;
+        const T* c1 = a.cq_2 + (s * nt + k) * dd;
+        const T* c1p = k == 0 ? a.cp0_1 + s * dd : a.cq_1 + (s * nt + k - 1) * dd;
+        T l1 = T(0);
+        load_mat<T, NT, S_LOWER>(C1, c1, d, true, true, ln);
+        if constexpr (NT == 2) load_tile_t<T>(c10t, c1, d, 1, 0, ln);
+        load_mat<T, NT, S_FULL>(Am, a.A_2 + (s * nt + k) * dd, d, false, false, ln);
+        if constexpr (EARLY) {
+            load_mat_t<T, NT>(A2T, a.A_2 + (s * nt + k) * dd, d, ln);
+            load_mat_t<T, NT>(A1T, a.A_1 + (s * nt + k) * dd, d, ln);
+            load_lower_t<T, NT>(CT1, a.cq_1 + (s * nt + k) * dd, d, ln);
+            load_cv<T, NT>(b1v, a.b_1 + (s * nt + k) * d, d, ln);
+            load_cv<T, NT>(b2v, a.b_2 + (s * nt + k) * d, d, ln);
+            l1 = log_diag<T, NT>(c1p, d, ln);
+        }
+        // ---- q2's block row k: D = Q_k^-1 + A^T Q_{k+1}^-1 A, S = -Q_{k+1}^-1 A ------------------------------------------------
+        Mat<T, NT> Q1, S, Dn;
+        T logdet1;
+        {
+            Mat<T, NT> Ci;
+            la.init();
+            tri_inv_mat<T, NT>(C1, c10t, Ci, lds, ln, la, bad);
+            logdet1 = tri_logdet<T, NT>(la);
+            tn<T, NT, S_LOWER, S_LOWER, S_UPPER, OP_SET>(Q1, Ci, Ci);
+            sym_complete<T, NT>(Q1, lds, ln);
+        }
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_NEG>(S, Q1, Am);
+        Dn = Q0;
+        tn<T, NT, S_FULL, S_FULL, S_UPPER, OP_SUB>(Dn, Am, S);
+        sym_complete<T, NT>(Dn, lds, ln);
+        if constexpr (!EARLY) phase();
+        // ---- the means of both chains at k + 1 --------------------------------------------------------------------------------
+        CV<T, NT> m1n, m2n, dk, dn;
+        {
+            RV<T, NT> r;
+            CV<T, NT> y;
+            if constexpr (!EARLY) {
+                load_mat_t<T, NT>(A2T, a.A_2 + (s * nt + k) * dd, d, ln);                 // (the lines Am came from)
+                load_cv<T, NT>(b2v, a.b_2 + (s * nt + k) * d, d, ln);
+            }
+            cv_to_rv<T, NT>(r, m2, ln);
+            tn_mv<T, NT, S_FULL>(y, A2T, r);
+            MF_UNROLL for (int j = 0; j < NT; ++j) m2n.v[j] = y.v[j] + b2v.v[j];
+            if constexpr (!EARLY) {
+                load_mat_t<T, NT>(A1T, a.A_1 + (s * nt + k) * dd, d, ln);
+                load_cv<T, NT>(b1v, a.b_1 + (s * nt + k) * d, d, ln);
+            }
+            cv_to_rv<T, NT>(r, m1, ln);
+            tn_mv<T, NT, S_FULL>(y, A1T, r);
+            MF_UNROLL for (int j = 0; j < NT; ++j) m1n.v[j] = y.v[j] + b1v.v[j];
+            MF_UNROLL for (int j = 0; j < NT; ++j) { dk.v[j] = m2.v[j] - m1.v[j]; dn.v[j] = m2n.v[j] - m1n.v[j]; }
+        }
+        // ---- q1's cross covariance, the block's terms, then q1's next covariance ---------------------------------------------------
+        {
+            Mat<T, NT> AP;
+            tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(AP, A1T, P);                         // Cov(x_{k+1}, x_k) = A1 P
+            if constexpr (!EARLY) l1 = log_diag<T, NT>(c1p, d, ln);
+            emit(k, Dn, &S, &AP, dk, &dn, l1);
+        }
+        if constexpr (!EARLY) phase();
+        {
+            Mat<T, NT> X;
+            tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(X, P, A1T);                          // P A1^T
+            tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(P, A1T, X);                          // A1 P A1^T
+            if constexpr (!EARLY) load_lower_t<T, NT>(CT1, a.cq_1 + (s * nt + k) * dd, d, ln);
+            tn<T, NT, S_UPPER, S_UPPER, S_FULL, OP_ADD>(P, CT1, CT1);                      // + C1 C1^T
+        }
+        Q0 = Q1;
+        logdet0 = logdet1;
+        MF_UNROLL for (int j = 0; j < NT; ++j) { m1.v[j] = m1n.v[j]; m2.v[j] = m2n.v[j]; }
+        if constexpr (!EARLY) phase();
+    }
+    if (t_hi == nt) {                                                                     // the last block: no transition out of it
+        CV<T, NT> dk;
+        MF_UNROLL for (int j = 0; j < NT; ++j) dk.v[j] = m2.v[j] - m1.v[j];
+        const T* c1p = nt == 0 ? a.cp0_1 + s * dd : a.cq_1 + (s * nt + nt - 1) * dd;
+        emit(nt, Q0, nullptr, nullptr, dk, nullptr, log_diag<T, NT>(c1p, d, ln));
+    }
+    (void)bad;
 }
 
 }  // namespace wv

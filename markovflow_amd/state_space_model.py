@@ -381,6 +381,23 @@ class StateSpaceModel(GaussMarkovDistribution):
         Other distributions and state dimensions beyond the register kernels take the reference's operator route."""
         bsz = int(math.prod(self.batch_shape))
         n, d = self.num_transitions + 1, self.state_dim
+        if (isinstance(dist, StateSpaceModel) and bsz > 0 and 16 <= d <= 32 and n > 1 and self._A_s.is_cuda
+                and dist._A_s.dtype == self._A_s.dtype and tuple(dist.batch_shape) == tuple(self.batch_shape)):
+            # 16 <= d <= 32: q1's moment recursion, q2's means and the block terms in ONE walk per (series, chunk) on register
+            # tiles (wave_kl_walk_kernel): neither the moments nor q2's precision exist in memory.  (No by-products for the
+            # backward: above d = 9 it re-evaluates, `_dense_kl`.)
+            dtype, dev = self._A_s.dtype, self._A_s.device
+            out = torch.empty(bsz, dtype=dtype, device=dev)
+            ws_bytes = int(_lib.load().mf_ssm_kl_workspace_bytes(bsz, n, d, out.element_size()))
+            ws = _lib.workspace(ws_bytes, dev)
+            info = _lib.pivot_info(dev)
+            rc = _lib.call_rc("mf_ssm_kl_divergence", dtype, bsz, n, d, *[_lib.ptr(t) for t in self._flat_params()],
+                              *[_lib.ptr(t) for t in dist._flat_params()], _lib.ptr(out), None, None, None, None, None, _lib.ptr(ws),
+                              ws_bytes, info, _lib.stream_ptr(dev))
+            if rc != -100:
+                _lib.check(rc, "mf_ssm_kl_divergence")
+                out = out.reshape(tuple(self.batch_shape))
+                return (out, None, None) if keep_moments else out
         if isinstance(dist, StateSpaceModel) and bsz > 0 and _lib.small_state_dim(d, bsz, n, self._A_s.element_size()):
             dtype, dev = self._A_s.dtype, self._A_s.device
             out = torch.empty(bsz, dtype=dtype, device=dev)
