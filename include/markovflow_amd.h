@@ -604,7 +604,13 @@ int mf_kf_posterior_chain_f32(int64_t B, int64_t T, int d, int m, const float* m
  * mf_kf_loglik_grad need; the sweep per series carries the same quantities in registers and writes them on request.
  * out_N [B,T,d,d], out_n [B,T,d] (both or neither; either route): N_k = dA_k^T Q2_k^-1 dA_k, n_k = dA_k^T Q2_k^-1 eps_k, the
  * inputs of the adjoint recursion of mf_ssm_kl_grad - by-products of the forward sweep that save the backward a kernel.
- * State dimension 1..9.
+ * State dimension 1..15 (10..15: where mf_row_operators_cover holds).
+ * State dimension 16..32, T > 1, every by-product pointer NULL and a workspace of mf_ssm_kl_workspace_bytes: the value alone, in
+ * the reference's operator form (the block rows of q2's precision against q1's marginal / subsequent covariances,
+ * state_space_model.py:569-593) evaluated in ONE walk per (series, chunk of the time axis) on 16 x 16 MFMA register tiles
+ * (csrc/mf_wave_ops.hpp, wave_kl_walk_kernel): q1's moment recursion, q2's means and the block terms together, neither the moments
+ * nor the precision in memory; -100 with by-products requested (their consumers, mf_ssm_kl_grad_*, stop at d = 9), -15 without
+ * the workspace.  `info` is not written on this route (a non-positive diagonal of a factor yields NaN in `out`).
  */
 size_t mf_ssm_kl_workspace_bytes(int64_t B, int64_t T, int d, int elem_size);
 int mf_ssm_kl_divergence_f64(int64_t B, int64_t T, int d, const double* mu0_1, const double* cholP0_1, const double* A_1,
