@@ -404,13 +404,19 @@ def other_configs(dev):
                 "solve": _time_gpu(lambda: loww.solve(rhsw), iters=3, warm=1),
                 "block_diagonal_of_inverse": _time_gpu(loww.block_diagonal_of_inverse, iters=3, warm=1),
                 "posterior_state_space_model": _time_gpu(kfw.posterior_state_space_model, iters=3, warm=1)}
-            del precw, symw, loww, rhsw
+            # round 6: solve^T, the prior's marginal means and KL(posterior || prior) (one walk per (series, chunk) on the tiles)
+            postw = kfw.posterior_state_space_model()
+            wave[f"d{dd}"]["operators_ms"].update({
+                "solve_transposed": _time_gpu(lambda: loww.solve(rhsw, transpose_left=True), iters=3, warm=1),
+                "marginal_means": _time_gpu(lambda: kfw.prior_ssm.marginal_means, iters=3, warm=1),
+                "kl_divergence": _time_gpu(lambda: postw.kl_divergence(kfw.prior_ssm), iters=3, warm=1)})
+            del precw, symw, loww, rhsw, postw
         del kfw
     wave["note"] = ("KalmanFilter.log_likelihood B=512 T=1000 m=1 fp64: d = 15 row kernels (mf_row.hpp), d >= 16 wave kernels "
                     "(one wavefront per chunk, register tiles in the MFMA accumulator layout; the pivot's Cholesky factor and the next "
                     "chol(Q)'s inverse share one DPP pass); round 4: d=16 18.1 ms, d=32 57.9 ms.  operators_ms: one wavefront per series "
                     "(round 4 at d=16 / d=32: precision 10.9 / 43.9, cholesky 5.4 / 26.6, solve 8.1 / 22.9, inverse blocks 8.3 / 25.4, "
-                    "posterior_state_space_model 25.4 / 102.8 ms)")
+                    "posterior_state_space_model 25.4 / 102.8 ms; round 5: solve 2.0 / 3.4, kl_divergence 6.8 / 12.0)")
     out["wave_kernels_B512_T1000_m1_f64"] = wave
     # reverse mode through the OPERATORS: the chain the reference's CVI models differentiate,
     # dist_p.precision -> naturals_to_ssm_params -> kl_divergence (models/variational_cvi.py:105-136), few long series
