@@ -532,6 +532,13 @@ inline int op_ssm_precision(long B, long Tn, int d, int m, const real* mu0, cons
             if (rc != -101) return rc;
         }
     }
+    {   // 32 < d <= 64: the panel kernels' per-block terms without the elimination (mf_panel.hpp, PREC), chunks of 16 blocks
+        static const bool poff = std::getenv("MF_PANEL_PREC_OFF") != nullptr;      // (A/B switch)
+        if (!poff && B * Tn > 0) {
+            const int rc = panel_ssm_precision(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, diag, sub, eta, st);
+            if (rc != -101) return rc;
+        }
+    }
     BigArgs a{B, Tn, d, H ? m : 1, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, 1, 1, nullptr};
 #define MF_C(DP)                                                                                                       \
     { static const bool ok = big_attr(&bigop_ssm_precision_kernel<DP>, Smem<DP>::BYTES); if (!ok) return -1000;          \

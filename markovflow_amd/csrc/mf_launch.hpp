@@ -159,6 +159,13 @@ int panel_kf_level0_f64(long B, long Tn, int d, int m, const double* mu0, const 
 int panel_kf_level0_f32(long B, long Tn, int d, int m, const float* mu0, const float* cholP0, const float* A, const float* b,
                         const float* cholQ, const float* H, const float* y, const float* Rinv, int rinv_per_step, long P, long L,
                         const RedSys<float>& out, int* info, hipStream_t st);
+// StateSpaceModel._build_precision (+ H^T R^-1 H, + information vector) for 32 < d <= 64 on the panel kernels; -101: not covered
+int panel_ssm_precision_f64(long B, long Tn, int d, int m, const double* mu0, const double* cholP0, const double* A, const double* b,
+                            const double* cholQ, const double* H, const double* y, const double* Rinv, int rinv_per_step, double* diag,
+                            double* sub, double* eta, hipStream_t st);
+int panel_ssm_precision_f32(long B, long Tn, int d, int m, const float* mu0, const float* cholP0, const float* A, const float* b,
+                            const float* cholQ, const float* H, const float* y, const float* Rinv, int rinv_per_step, float* diag,
+                            float* sub, float* eta, hipStream_t st);
 // one reduction level RedSys(in.n) -> RedSys(P) (final: P = 1, out_scalar[s] = add_const + the series' value)
 int panel_red_f64(const RedSys<double>& in, const RedSys<double>& out, long B, long P, int d, double add_const, double* out_scalar,
                   int* info, int final_level, hipStream_t st);

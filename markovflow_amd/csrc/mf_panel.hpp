@@ -591,9 +591,18 @@ MF_DEV void store_chunk_panel(const RedSys<T>& out, long idx, int d, const Panel
 template <typename T, int NT, int MT> constexpr int panel_wpe() { return NT <= 2 ? (sizeof(T) == 4 ? 4 : 2) : (sizeof(T) == 4 ? 2 : 1); }
 
 // Level 0: workgroup (s, c) eliminates the transitions [c L, min((c+1) L, T-1)) of series s.
-template <typename T, int NT, int MT, bool EX>
+// PREC: the same per-block terms WITHOUT the elimination - StateSpaceModel._build_precision (+ H^T R^-1 H, + the information vector;
+// state_space_model.py:431-483, kalman_filter.py:86-101,153-156) for a chunk of blocks: diag_k = Q_k^-1 + A_{k+1}^T Q_{k+1}^-1 A_{k+1}
+// (+ H^T R^-1 H), sub_k = -Q_{k+1}^-1 A_{k+1}, eta_k = Q_k^-1 m_k - A_{k+1}^T Q_{k+1}^-1 m_{k+1} (+ H^T R^-1 y).  The chunk inverts the
+// factor of its first block itself (one inversion more per chunk); a.H == NULL: the prior precision, po.eta == NULL: no vector,
+// a.y == NULL: no observation term in it.  (Rounds 2-5: a workgroup per block on LDS tiles, two inversions per block: 2.3 ms at
+// config 5's shape.)
+template <typename T> struct PrecOut {
+    T *diag, *sub, *eta;
+};
+template <typename T, int NT, int MT, bool EX, bool PREC = false>
 __global__ void __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(panel_wpe<T, NT, MT>(), panel_wpe<T, NT, MT>())))
-panel_kf_chunk_kernel(wv::WvArgs<T> a, RedSys<T> out) {
+panel_kf_chunk_kernel(wv::WvArgs<T> a, RedSys<T> out, PrecOut<T> po = PrecOut<T>{nullptr, nullptr, nullptr}) {
     using v4 = typename Tr<T>::v4;
     using G = PG<T, NT>;
     using L = Lds<T, NT, MT>;
@@ -626,10 +635,11 @@ panel_kf_chunk_kernel(wv::WvArgs<T> a, RedSys<T> out) {
             IR[cc * L::LDH + 16 * (k >> 4) + pos16<T>(k & 15)] = (k < m && cc < m) ? R[k * m + cc] : T(0);
         }
     };
-    if (!a.rinv_per_step) stage_rinv(a.Rinv);
+    if (!a.rinv_per_step && (!PREC || a.H)) stage_rinv(a.Rinv);
 
     Panel<T, NT> Dn, Am;
     typename Tr<T>::v4 Hp[MT];
+    if constexpr (PREC) { MF_UNROLL for (int to = 0; to < MT; ++to) Hp[to] = typename Tr<T>::v4{0, 0, 0, 0}; }
     T rn = T(0);
     // The block's own terms from its Cholesky factor C: Dn = Q^-1 (all tiles), rn = Q^-1 mvec; image 1 <- Q^-1; the observation rows
     // (-> Hp) and the transition (Ag != NULL, -> Am) are loaded behind the inversion of C - their latency is covered by the product that
@@ -646,15 +656,15 @@ panel_kf_chunk_kernel(wv::WvArgs<T> a, RedSys<T> out) {
         if constexpr (DMA)
             dma_rows16<G::DP * (int)sizeof(T), (G::LD - G::DP) * (int)sizeof(T)>(dma_srd(Cg + 16 * w * G::DP, 16 * G::DP * sizeof(T)),
                                                          lds_addr(I1 + 16 * w * G::LD), 4u * (threadIdx.x & 63));
-        if (w == 0) dma_vec(mv, d * sizeof(T), c.sm.vec(V_M), G::DP * sizeof(T));
-        if (w == NT - 1) dma_vec(a.y + (s * a.Tn + blk) * m, m * sizeof(T), c.sm.ys(), L::MP * sizeof(T));
+        if (w == 0 && (!PREC || po.eta)) dma_vec(mv, d * sizeof(T), c.sm.vec(V_M), G::DP * sizeof(T));
+        if (w == NT - 1 && (!PREC || (a.H && a.y))) dma_vec(a.y + (s * a.Tn + blk) * m, m * sizeof(T), c.sm.ys(), L::MP * sizeof(T));
     };
     // The block's own terms from its Cholesky factor: Dn = Q^-1 (all tiles), rn = Q^-1 mvec; image 1 <- Q^-1; the observation rows
     // (-> Hp) and the transition (Ag != NULL, -> Am) are loaded behind the inversion of C - their latency is covered by the product that
     // follows - and go into their images.  Cg: the factor in memory (read here unless it came by DMA).  Ends with the barrier that
     // publishes the images.
     auto own_terms = [&](const T* __restrict__ Cg, long blk, const T* __restrict__ Ag, Stamp& stamp) __attribute__((always_inline)) {
-        if (a.rinv_per_step) stage_rinv(a.Rinv + (s * a.Tn + blk) * m * m);
+        if (a.rinv_per_step && (!PREC || a.H)) stage_rinv(a.Rinv + (s * a.Tn + blk) * m * m);
         Panel<T, NT> Ci;
         if constexpr (DMA) {
             tri_inv_panel<T, NT, MT, true>(Ci, Ci, c, laC, E.bad);
@@ -666,7 +676,7 @@ panel_kf_chunk_kernel(wv::WvArgs<T> a, RedSys<T> out) {
         }
         MF_PSTAMP(stamp, 0)
         if (Ag) load_panel<T, NT, EX>(Am, Ag, d, w, false, false, ln);
-        load_rows_panel<T, MT>(Hp, a.H + (s * a.Tn + blk) * m * d, m, d, w, ln);
+        if (!PREC || a.H) load_rows_panel<T, MT>(Hp, a.H + (s * a.Tn + blk) * m * d, m, d, w, ln);
         MF_UNROLL for (int ti = 0; ti < NT; ++ti)
             if (ti >= w) img_put<T, G::LD>(I2, ti, w, Ci.t[ti], ln);
         __syncthreads();
@@ -700,7 +710,7 @@ panel_kf_chunk_kernel(wv::WvArgs<T> a, RedSys<T> out) {
             T yv[MT][4];
             MF_UNROLL for (int to = 0; to < MT; ++to)
                 MF_UNROLL for (int e = 0; e < 4; ++e) yv[to][e] = c.sm.ys()[16 * to + Tr<T>::row(ln.q, e)];
-            rn += mv_panel<T, MT>(Gp, yv);                                                              // += G^T y
+            if (!PREC || a.y) rn += mv_panel<T, MT>(Gp, yv);                                            // += G^T y
         }
         {   // y^T R^-1 y: thread (o, part) takes the terms p = part, part + NPART, ... of row o (R^-1 symmetric: read down a column)
             constexpr int NPART = 64 * NT / L::MP;
@@ -713,6 +723,52 @@ panel_kf_chunk_kernel(wv::WvArgs<T> a, RedSys<T> out) {
         }
     };
 
+    if constexpr (PREC) {
+        Stamp st0;
+        st0.init(c.sm.red() + 16);
+        const int jv = 16 * w + ln.r;
+        if (ch == 0) {
+            request(-1);
+            own_terms(a.cholP0 + s * dd, 0, nullptr, st0);
+        } else {
+            request(tau0 - 1);
+            own_terms(a.cholQ + (s * nt + tau0 - 1) * dd, tau0, nullptr, st0);
+        }
+        if (a.H) obs_terms(tau0);
+        Panel<T, NT> Dp = Dn;                      // the diagonal block in the making and its share of the vector
+        T ep = rn;
+        __syncthreads();
+        if (len > 0) request(tau0);
+        for (long j = 0; j < len; ++j) {
+            const long tau = tau0 + j, blk = tau + 1;
+            asm volatile("" : "+v"(ln.r), "+v"(ln.q));
+            if constexpr (!EX) asm volatile("" : "+s"(d));
+            own_terms(a.cholQ + (s * nt + tau) * dd, blk, a.A + (s * nt + tau) * dd, st0);
+            Panel<T, NT> S;
+            tn_img<T, NT, NT, G::LD, OP_NEG, P_FULL>(S, I1, Am.t, ln);           // S = -Q^-1 A
+            T btw;
+            {
+                RV<T, NT> rn_rv;
+                vec_rv<T, NT>(rn_rv, c.sm.vec(V_RN), ln);
+                btw = mv_panel<T, NT>(Am.t, rn_rv.v);                            // A^T Q^-1 m
+            }
+            if (a.H) obs_terms(blk);
+            tn_img<T, NT, NT, G::LD, OP_SUB, P_FULL>(Dp, I0, S.t, ln);           // + A^T Q^-1 A
+            ep -= btw;
+            store_panel<T, NT, false>(po.diag + (s * a.Tn + tau) * dd, Dp, d, w, ln);
+            store_panel<T, NT, false>(po.sub + (s * nt + tau) * dd, S, d, w, ln);
+            if (po.eta && ln.q == 0 && jv < d) po.eta[(s * a.Tn + tau) * d + jv] = ep;
+            Dp = Dn;
+            ep = rn;
+            __syncthreads();
+            if (j + 1 < len) request(tau + 1);
+        }
+        if (tau0 + len == nt) {                    // the last block of the series: its own terms are all it has
+            store_panel<T, NT, false>(po.diag + (s * a.Tn + nt) * dd, Dp, d, w, ln);
+            if (po.eta && ln.q == 0 && jv < d) po.eta[(s * a.Tn + nt) * d + jv] = ep;
+        }
+        return;
+    }
     if (ch == 0) {   // block 0: the prior
         Stamp st0;
         st0.init(c.sm.red() + 16);

@@ -30,6 +30,31 @@ int panel_level0(long B, long Tn, int d, int m, const T* mu0, const T* cholP0, c
     if (d <= 48) return m <= 16 ? panel_launch0_ex<T, 3, 1>(a, out, st) : panel_launch0_ex<T, 3, 2>(a, out, st);
     return m <= 16 ? panel_launch0_ex<T, 4, 1>(a, out, st) : panel_launch0_ex<T, 4, 2>(a, out, st);
 }
+// StateSpaceModel._build_precision (+ observation terms, + information vector) on the panel kernels: chunks of 16 blocks
+template <typename T, int NT, int MT, bool EX>
+int panel_prec_launch(const wv::WvArgs<T>& a, const pn::PrecOut<T>& po, hipStream_t st) {
+    constexpr int bytes = pn::Lds<T, NT, MT>::BYTES;
+    static const bool ok = panel_attr(&pn::panel_kf_chunk_kernel<T, NT, MT, EX, true>, bytes);
+    if (!ok) return -1000;
+    hipLaunchKernelGGL((pn::panel_kf_chunk_kernel<T, NT, MT, EX, true>), dim3((unsigned)(a.B * a.P)), dim3(64 * NT), bytes, st, a,
+                       RedSys<T>{}, po);
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+template <typename T, int NT, int MT>
+int panel_prec_ex(const wv::WvArgs<T>& a, const pn::PrecOut<T>& po, hipStream_t st) {
+    return a.d == 16 * NT ? panel_prec_launch<T, NT, MT, true>(a, po, st) : panel_prec_launch<T, NT, MT, false>(a, po, st);
+}
+template <typename T>
+int panel_prec(long B, long Tn, int d, int m, const T* mu0, const T* cholP0, const T* A, const T* b, const T* cholQ, const T* H,
+               const T* y, const T* Rinv, int rinv_per_step, T* diag, T* sub, T* eta, hipStream_t st) {
+    const int mm = H ? m : 1;
+    if (!(d > 32 && d <= 64) || mm < 1 || mm > 32 || B <= 0 || Tn <= 0) return -101;
+    const long nt = Tn - 1, L = 16, P = nt > 0 ? (nt + L - 1) / L : 1;
+    const wv::WvArgs<T> a{B, Tn, d, mm, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, L, nullptr};
+    const pn::PrecOut<T> po{diag, sub, eta};
+    if (d <= 48) return mm <= 16 ? panel_prec_ex<T, 3, 1>(a, po, st) : panel_prec_ex<T, 3, 2>(a, po, st);
+    return mm <= 16 ? panel_prec_ex<T, 4, 1>(a, po, st) : panel_prec_ex<T, 4, 2>(a, po, st);
+}
 template <typename T, int NT, bool FINAL, bool EX>
 int panel_red_launch(const RedSys<T>& in, const RedSys<T>& out, long B, long P, int d, T add_const, T* out_scalar, int* info,
                      hipStream_t st) {
@@ -74,6 +99,16 @@ int panel_kf_level0_f32(long B, long Tn, int d, int m, const float* mu0, const f
                         const float* cholQ, const float* H, const float* y, const float* Rinv, int rinv_per_step, long P, long L,
                         const RedSys<float>& out, int* info, hipStream_t st) {
     return panel_level0<float>(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, P, L, out, info, st);
+}
+int panel_ssm_precision_f64(long B, long Tn, int d, int m, const double* mu0, const double* cholP0, const double* A, const double* b,
+                            const double* cholQ, const double* H, const double* y, const double* Rinv, int rinv_per_step, double* diag,
+                            double* sub, double* eta, hipStream_t st) {
+    return panel_prec<double>(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, diag, sub, eta, st);
+}
+int panel_ssm_precision_f32(long B, long Tn, int d, int m, const float* mu0, const float* cholP0, const float* A, const float* b,
+                            const float* cholQ, const float* H, const float* y, const float* Rinv, int rinv_per_step, float* diag,
+                            float* sub, float* eta, hipStream_t st) {
+    return panel_prec<float>(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, diag, sub, eta, st);
 }
 int panel_red_f64(const RedSys<double>& in, const RedSys<double>& out, long B, long P, int d, double add_const, double* out_scalar,
                   int* info, int final_level, hipStream_t st) {

@@ -56,6 +56,16 @@ int wave_ssm_kl_f64(long B, long Tn, int d, const double* cp0_1, const double* c
 int wave_ssm_kl_f32(long B, long Tn, int d, const float* cp0_1, const float* cq_1, const float* cp0_2, const float* a_2,
                     const float* cq_2, const float* cov, const float* cross, const float* mdiff, float* out, void* ws, size_t ws_bytes,
                     hipStream_t st);
+inline int panel_ssm_precision(long B, long Tn, int d, int m, const double* mu0, const double* cholP0, const double* A, const double* b,
+                               const double* cholQ, const double* H, const double* y, const double* Rinv, int rinv_per_step, double* diag,
+                               double* sub, double* eta, hipStream_t st) {
+    return panel_ssm_precision_f64(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, diag, sub, eta, st);
+}
+inline int panel_ssm_precision(long B, long Tn, int d, int m, const float* mu0, const float* cholP0, const float* A, const float* b,
+                               const float* cholQ, const float* H, const float* y, const float* Rinv, int rinv_per_step, float* diag,
+                               float* sub, float* eta, hipStream_t st) {
+    return panel_ssm_precision_f32(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, diag, sub, eta, st);
+}
 // mf_wave_inst.hip: StateSpaceModel.kl_divergence in one walk per (series, chunk) (wave_kl_walk_kernel); -101: not covered, -15: workspace
 size_t wave_ssm_kl_fused_ws(long B, long n, int d, int elem_size);
 int wave_ssm_kl_fused_f64(long B, long n, int d, const double* mu0_1, const double* cp0_1, const double* a_1, const double* b_1,

@@ -197,3 +197,28 @@ def test_large_d_posterior_chain_partitioned_in_time(rng, dtype, d, m, t):
     np.testing.assert_allclose(nn(kf.prior_ssm.marginal_means), O.ssm_marginal_means(kw["mu0"], kw["a_s"], kw["b_s"]), **tol)
     kl = O.ssm_kl_divergence(want, (kw["mu0"], kw["chol_p0"], kw["a_s"], kw["b_s"], kw["chol_q"]))
     np.testing.assert_allclose(nn(post.kl_divergence(kf.prior_ssm)), kl, rtol=1e-6 if dtype == torch.float64 else 2e-2)
+
+
+# ---- precision assembly at 32 < d <= 64 on the panel kernels (csrc/mf_panel.hpp, PREC): chunks of 16 blocks -----------------------
+@pytest.mark.parametrize("d,m,t,bsz", [(33, 1, 3, 2), (40, 3, 2, 2), (48, 17, 16, 1), (49, 2, 17, 2), (64, 32, 18, 2), (64, 5, 50, 1),
+                                       (56, 20, 33, 3)])
+def test_panel_precision_prior_and_posterior(rng, d, m, t, bsz):
+    """`ssm.precision` (state_space_model.py:431-483) and `kf._k_inv_post` (kalman_filter.py:86-101) for 32 < d <= 64 (fp32) against
+    the numpy oracle, block by block: chains shorter / one longer / several times longer than a chunk, m up to 32; the
+    information vector through the posterior chain's means is covered by test_large_d_posterior_marginals_and_kl."""
+    kw = random_ssm(rng, (bsz,), t, d, m, well=True)
+    kw = {k: v.astype(np.float32).astype(np.float64) for k, v in kw.items()}
+    cov = 0.5 * np.eye(m) + 0.1 * np.ones((m, m)) / m
+    chol_r = np.linalg.cholesky(cov).astype(np.float32).astype(np.float64)
+    kf = build_kf(kw, chol_r, dtype=torch.float32)
+    tol = dict(rtol=2e-3, atol=2e-3)
+    prec = kf.prior_ssm.precision
+    want_d, want_s = O.ssm_precision(kw["chol_p0"], kw["a_s"], kw["chol_q"])
+    np.testing.assert_allclose(nn(prec.block_diagonal), want_d, **tol)
+    if t > 1:
+        np.testing.assert_allclose(nn(prec.block_sub_diagonal), want_s, **tol)
+    post = kf._k_inv_post
+    want_d, want_s = O.kf_posterior_precision(kw["chol_p0"], kw["a_s"], kw["chol_q"], kw["h"], np.linalg.inv(chol_r @ chol_r.T))
+    np.testing.assert_allclose(nn(post.block_diagonal), want_d, **tol)
+    if t > 1:
+        np.testing.assert_allclose(nn(post.block_sub_diagonal), want_s, **tol)
