@@ -553,6 +553,13 @@ template <int DP, bool REV>
 inline bool bigpar_pivots(long B, long n, int d, long P, long L, const real* diag, const real* sub, const BigParWs& w, int* info, hipStream_t st) {
     static const bool ok = big_attr(&bigpar_chol_up_kernel<DP, REV>, Smem<DP>::BYTES) && big_attr(&bigpar_chol_boundary_kernel<DP>, Smem<DP>::BYTES);
     if (!ok) return false;
+    // 32 < d <= 64: the up-sweep on the panel kernels (mf_panel.hpp, panel_red_kernel in operator mode: 1.64 -> 0.5 ms at config 5's shape)
+    static const bool poff = std::getenv("MF_PANEL_UP_OFF") != nullptr;       // (A/B switch)
+    static const bool boff = std::getenv("MF_PANEL_BOUNDARY_OFF") != nullptr;
+    const int prc = poff ? -101 : panel_chol_up(B, n, d, P, L, diag, sub, w.Dv, w.GU, w.F, boff ? nullptr : w.piv, REV ? 1 : 0, info, st);
+    if (prc != 0 && prc != -101) return false;
+    if (prc == 0 && !boff) return true;              // (up-sweep and chunk ends both on the panel kernels)
+    if (prc == -101)
     hipLaunchKernelGGL((bigpar_chol_up_kernel<DP, REV>), dim3((unsigned)(B * (P - 1))), dim3(NTHR), Smem<DP>::BYTES, st, B, n, d, P, L,
                        diag, sub, w.Dv, w.GU, w.F, info);
     hipLaunchKernelGGL((bigpar_chol_boundary_kernel<DP>), dim3((unsigned)B), dim3(NTHR), Smem<DP>::BYTES, st, B, d, P,

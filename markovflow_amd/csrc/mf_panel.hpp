@@ -581,11 +581,11 @@ MF_DEV void store_chunk_panel(const RedSys<T>& out, long idx, int d, const Panel
     store_panel<T, NT, false>(out.GU + idx * dd, E.GU, d, c.w, c.ln);
     store_panel<T, NT, false>(out.F + idx * dd, E.X, d, c.w, c.ln);
     const int j = 16 * c.w + c.ln.r;
-    if (c.ln.q == 0 && j < d) {
+    if (out.tv && c.ln.q == 0 && j < d) {
         out.tv[idx * d + j] = E.t;
         out.gU[idx * d + j] = E.gU;
     }
-    if (threadIdx.x == 0) out.sc[idx] = scalar;
+    if (out.sc && threadIdx.x == 0) out.sc[idx] = scalar;
 }
 
 template <typename T, int NT, int MT> constexpr int panel_wpe() { return NT <= 2 ? (sizeof(T) == 4 ? 4 : 2) : (sizeof(T) == 4 ? 2 : 1); }
@@ -831,7 +831,8 @@ panel_kf_chunk_kernel(wv::WvArgs<T> a, RedSys<T> out, PrecOut<T> po = PrecOut<T>
 // sequence as big_red_kernel (mf_big_impl.hpp).
 template <typename T, int NT, bool FINAL, bool EX>
 __global__ void __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(panel_wpe<T, NT, 1>(), panel_wpe<T, NT, 1>())))
-panel_red_kernel(RedSys<T> in, RedSys<T> out, long B, long P, int d_, T add_const, T* __restrict__ out_scalar, int* info) {
+panel_red_kernel(RedSys<T> in, RedSys<T> out, long B, long P, int d_, T add_const, T* __restrict__ out_scalar, int* info,
+                 long Lc = 0, int rev = 0, T* __restrict__ pivs = nullptr) {
     using L = Lds<T, NT, 1>;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Ctx<T, NT, 1> c{L{reinterpret_cast<T*>(smem_raw)}, Lane{(int)(threadIdx.x & 15), (int)((threadIdx.x >> 4) & 3)},
@@ -840,8 +841,13 @@ panel_red_kernel(RedSys<T> in, RedSys<T> out, long B, long P, int d_, T add_cons
     const int w = c.w;
     int d = EX ? 16 * NT : d_;
     const long id = blockIdx.x, s = id / P, ch = id % P;
-    const long k0 = (ch * in.n) / P, k1 = ((ch + 1) * in.n) / P;
+    // Lc > 0: OPERATOR mode - the up-sweep of the time-partitioned Cholesky / U D U^T factorisation of a user matrix (in.Dv = diag,
+    // in.F = sub with f_stride = n - 1, f_off = -1, no vectors): chunks of Lc blocks as the tile engine's boundary and emit passes
+    // expect them (mf_bigpar_impl.hpp), rev: the blocks in reversed order with the couplings transposed (upper_diagonal_lower)
+    const long k0 = Lc > 0 ? ch * Lc : (ch * in.n) / P;
+    const long k1 = Lc > 0 ? (k0 + Lc < in.n ? k0 + Lc : in.n) : ((ch + 1) * in.n) / P;
     const bool spike = !FINAL && k0 > 0;
+    if (Lc > 0 && k0 >= in.n) return;             // (an empty last chunk of the operator partition: the whole workgroup leaves)
     const long dd = long(d) * d;
     PanelElim<T, NT> E;
     E.init();
@@ -853,34 +859,43 @@ panel_red_kernel(RedSys<T> in, RedSys<T> out, long B, long P, int d_, T add_cons
         T rn, sc;
     };
     auto load_blk = [&](Blk& bk, long k, bool coupling) __attribute__((always_inline)) {
-        const long idx = s * in.n + k;
+        const long idx = s * in.n + (rev ? in.n - 1 - k : k);
         const bool has_next = in.GU && (k + 1 < in.n);
         bk.sc = in.sc ? in.sc[idx] : T(0);
         load_panel<T, NT, EX>(bk.Dn, in.Dv + idx * dd, d, w, false, true, ln);
-        bk.rn = load_cv_g<T>(in.tv + idx * d, d, w, ln);
+        bk.rn = in.tv ? load_cv_g<T>(in.tv + idx * d, d, w, ln) : T(0);
         if (has_next) {
             load_panel<T, NT, EX>(bk.G2, in.GU + (idx + 1) * dd, d, w, false, false, ln);
-            bk.rn += load_cv_g<T>(in.gU + (idx + 1) * d, d, w, ln);
+            if (in.gU) bk.rn += load_cv_g<T>(in.gU + (idx + 1) * d, d, w, ln);
         } else {
             bk.G2.zero();
         }
-        if (coupling) load_panel_t<T, NT, EX>(bk.FT, in.F + (s * in.f_stride + k + in.f_off) * dd, d, w, ln);
+        if (coupling) {
+            if (rev) load_panel<T, NT, EX>(bk.FT, in.F + (s * in.f_stride + in.n - 1 - k) * dd, d, w, false, false, ln);
+            else load_panel_t<T, NT, EX>(bk.FT, in.F + (s * in.f_stride + k + in.f_off) * dd, d, w, ln);
+        }
     };
     {
         // the chunk's first block: nothing to eliminate yet; its coupling (k0 > 0) is the one to the chunk's left separator
         Blk b0;
         load_blk(b0, k0, false);
-        if (k0 > 0 && !FINAL) load_panel<T, NT, EX>(E.X, in.F + (s * in.f_stride + k0 + in.f_off) * dd, d, w, false, false, ln);
+        if (k0 > 0 && !FINAL) {
+            if (rev) load_panel_t<T, NT, EX>(E.X, in.F + (s * in.f_stride + in.n - 1 - k0) * dd, d, w, ln);
+            else load_panel<T, NT, EX>(E.X, in.F + (s * in.f_stride + k0 + in.f_off) * dd, d, w, false, false, ln);
+        }
         MF_UNROLL for (int ti = 0; ti < NT; ++ti) E.Phi.t[ti] = b0.Dn.t[ti] + b0.G2.t[ti];
         E.t = b0.rn;
         acc_sc += b0.sc;
+        // pivs (operator mode, one workgroup per series over the chunk ends): the pivot of every block WITHOUT the next block's
+        // contribution - the natural-order pivots the emit passes restart from (bigpar_chol_boundary_kernel's output)
+        if (pivs) store_panel<T, NT, false>(pivs + (s * in.n + k0) * dd, b0.Dn, d, w, ln);
     }
     Blk nx;
     if (k0 + 1 < k1) load_blk(nx, k0 + 1, true);
     for (long k = k0 + 1; k < k1; ++k) {
         asm volatile("" : "+v"(ln.r), "+v"(ln.q));
         if constexpr (!EX) asm volatile("" : "+s"(d));
-        Panel<T, NT> Dn, FT = nx.FT;
+        Panel<T, NT> Dn, FT = nx.FT, G2k = nx.G2;
         MF_UNROLL for (int ti = 0; ti < NT; ++ti) Dn.t[ti] = nx.Dn.t[ti] + nx.G2.t[ti];
         const T rn = nx.rn;
         acc_sc += nx.sc;
@@ -888,13 +903,17 @@ panel_red_kernel(RedSys<T> in, RedSys<T> out, long B, long P, int d_, T add_cons
         Stamp stamp;
         stamp.init(c.sm.red() + 16);
         eliminate_advance<T, NT, 1, false>(E, FT, Dn, rn, spike, c, [] {}, stamp);
+        if (pivs) {
+            MF_UNROLL for (int ti = 0; ti < NT; ++ti) G2k.t[ti] = E.Phi.t[ti] - G2k.t[ti];
+            store_panel<T, NT, false>(pivs + (s * in.n + k) * dd, G2k, d, w, ln);
+        }
     }
     if (FINAL) eliminate_last<T, NT, 1>(E, c);
     T part = T(0.5) * wv::sum16<T>(E.quad) - T(0.5) * E.laL.value();
     const T tot = wg_sum<T, NT>(part, c.sm.red(), w);
     if (FINAL) {
         if (threadIdx.x == 0) out_scalar[s] = add_const + acc_sc + tot;
-    } else {
+    } else if (out.Dv) {
         store_chunk_panel<T, NT, 1>(out, id, d, E, acc_sc + tot, c);
     }
     if (__any(E.bad) && (threadIdx.x & 63) == 0 && info) raise_info(info);

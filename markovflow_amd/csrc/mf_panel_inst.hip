@@ -110,6 +110,52 @@ int panel_ssm_precision_f32(long B, long Tn, int d, int m, const float* mu0, con
                             float* sub, float* eta, hipStream_t st) {
     return panel_prec<float>(B, Tn, d, m, mu0, cholP0, A, b, cholQ, H, y, Rinv, rinv_per_step, diag, sub, eta, st);
 }
+namespace {
+template <typename T, int NT>
+int panel_chol_up_nt(const RedSys<T>& in, const RedSys<T>& out, long B, long P, long L, int d, int rev, T* pivs, int* info,
+                     hipStream_t st) {
+    constexpr int bytes = pn::Lds<T, NT, 1>::BYTES;
+    const dim3 grid((unsigned)(B * P)), block(64 * NT);
+    if (d == 16 * NT) {
+        static const bool ok = panel_attr(&pn::panel_red_kernel<T, NT, false, true>, bytes);
+        if (!ok) return -1000;
+        hipLaunchKernelGGL((pn::panel_red_kernel<T, NT, false, true>), grid, block, bytes, st, in, out, B, P, d, T(0),
+                           static_cast<T*>(nullptr), info, L, rev, pivs);
+    } else {
+        static const bool ok = panel_attr(&pn::panel_red_kernel<T, NT, false, false>, bytes);
+        if (!ok) return -1000;
+        hipLaunchKernelGGL((pn::panel_red_kernel<T, NT, false, false>), grid, block, bytes, st, in, out, B, P, d, T(0),
+                           static_cast<T*>(nullptr), info, L, rev, pivs);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+// the up-sweep of the time-partitioned Cholesky / U D U^T factorisation for 32 < d <= 64 on the panel reduction kernel (operator
+// mode): per chunk of L blocks the pivot of its last block, the contribution to the separator in front of it and the coupling to it,
+// in the arrays the tile engine's boundary and emit passes read
+template <typename T>
+int panel_chol_up_t(long B, long n, int d, long P, long L, const T* diag, const T* sub, T* oDv, T* oGU, T* oF, T* piv, int rev,
+                    int* info, hipStream_t st) {
+    if (d <= 32 || d > 64 || !sub || P < 2) return -101;
+    const RedSys<T> in{const_cast<T*>(diag), nullptr, const_cast<T*>(sub), nullptr, nullptr, nullptr, n, n - 1, -1};
+    const RedSys<T> out{oDv, oGU, oF, nullptr, nullptr, nullptr, P, P, 0};
+    const int rc = d <= 48 ? panel_chol_up_nt<T, 3>(in, out, B, P, L, d, rev, nullptr, info, st)
+                           : panel_chol_up_nt<T, 4>(in, out, B, P, L, d, rev, nullptr, info, st);
+    if (rc != 0 || !piv) return rc;
+    // the chunk ends of every series: one workgroup walks the P - 1 reduced blocks and leaves the natural-order pivot of each
+    const RedSys<T> red{oDv, oGU, oF, nullptr, nullptr, nullptr, P, P, 0};
+    const RedSys<T> none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1, 0};
+    return d <= 48 ? panel_chol_up_nt<T, 3>(red, none, B, 1, P - 1, d, 0, piv, info, st)
+                   : panel_chol_up_nt<T, 4>(red, none, B, 1, P - 1, d, 0, piv, info, st);
+}
+}  // namespace
+int panel_chol_up_f64(long B, long n, int d, long P, long L, const double* diag, const double* sub, double* oDv, double* oGU, double* oF,
+                      double* piv, int rev, int* info, hipStream_t st) {
+    return panel_chol_up_t<double>(B, n, d, P, L, diag, sub, oDv, oGU, oF, piv, rev, info, st);
+}
+int panel_chol_up_f32(long B, long n, int d, long P, long L, const float* diag, const float* sub, float* oDv, float* oGU, float* oF,
+                      float* piv, int rev, int* info, hipStream_t st) {
+    return panel_chol_up_t<float>(B, n, d, P, L, diag, sub, oDv, oGU, oF, piv, rev, info, st);
+}
 int panel_red_f64(const RedSys<double>& in, const RedSys<double>& out, long B, long P, int d, double add_const, double* out_scalar,
                   int* info, int final_level, hipStream_t st) {
     return panel_red_t<double>(in, out, B, P, d, add_const, out_scalar, info, final_level, st);

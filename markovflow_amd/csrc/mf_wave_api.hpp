@@ -56,6 +56,20 @@ int wave_ssm_kl_f64(long B, long Tn, int d, const double* cp0_1, const double* c
 int wave_ssm_kl_f32(long B, long Tn, int d, const float* cp0_1, const float* cq_1, const float* cp0_2, const float* a_2,
                     const float* cq_2, const float* cov, const float* cross, const float* mdiff, float* out, void* ws, size_t ws_bytes,
                     hipStream_t st);
+// mf_panel_inst.hip: the up-sweep of the time-partitioned factorisations for 32 < d <= 64 (panel_red_kernel in operator mode); -101: not covered
+// (piv != NULL: the pass over the chunk ends as well - the natural-order pivot of the last block of every chunk, [B, P, d, d])
+int panel_chol_up_f64(long B, long n, int d, long P, long L, const double* diag, const double* sub, double* oDv, double* oGU, double* oF,
+                      double* piv, int rev, int* info, hipStream_t st);
+int panel_chol_up_f32(long B, long n, int d, long P, long L, const float* diag, const float* sub, float* oDv, float* oGU, float* oF,
+                      float* piv, int rev, int* info, hipStream_t st);
+inline int panel_chol_up(long B, long n, int d, long P, long L, const double* diag, const double* sub, double* oDv, double* oGU, double* oF,
+                         double* piv, int rev, int* info, hipStream_t st) {
+    return panel_chol_up_f64(B, n, d, P, L, diag, sub, oDv, oGU, oF, piv, rev, info, st);
+}
+inline int panel_chol_up(long B, long n, int d, long P, long L, const float* diag, const float* sub, float* oDv, float* oGU, float* oF,
+                         float* piv, int rev, int* info, hipStream_t st) {
+    return panel_chol_up_f32(B, n, d, P, L, diag, sub, oDv, oGU, oF, piv, rev, info, st);
+}
 inline int panel_ssm_precision(long B, long Tn, int d, int m, const double* mu0, const double* cholP0, const double* A, const double* b,
                                const double* cholQ, const double* H, const double* y, const double* Rinv, int rinv_per_step, double* diag,
                                double* sub, double* eta, hipStream_t st) {
