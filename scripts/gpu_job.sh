@@ -23,7 +23,8 @@ panel)
   { timeout 900 python -m pytest tests/test_gpu_kalman_large_d.py -q 2>&1 | tail -3
     timeout 600 python -m pytest tests/test_gpu_baseline_configs.py -x -q -k config5 2>&1 | tail -2
     for d in 64 48 40; do python scripts/bench_big.py --iters 10 --d $d 2>&1 | noids; done
-    python scripts/bench_big.py --iters 10 --batch 64 2>&1 | noids; } | tee gpurun_out/${TAG}_panel.txt
+    python scripts/bench_big.py --iters 10 --batch 64 2>&1 | noids
+    echo "== operators at config 5's shape (scripts/bench_bigops.py)"; python scripts/bench_bigops.py 2>&1 | noids; } | tee gpurun_out/${TAG}_panel.txt
   bash scripts/pmc_big.sh ${TAG}_panel > gpurun_out/${TAG}_panel_pmc.log 2>&1; cat gpurun_out/${TAG}_panel/pmc_summary.txt | cut -c1-500 ;;
 wave)
   { timeout 1200 python -m pytest tests/test_gpu_wave.py tests/test_gpu_large_d_ops.py -q 2>&1 | tail -3
