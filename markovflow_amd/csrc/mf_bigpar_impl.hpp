@@ -580,6 +580,10 @@ inline int op_cholesky_par(long B, long n, int d, const real* diag, const real* 
 #define MF_C(DP)                                                                                                        \
     { static const bool ok = big_attr(&bigpar_chol_emit_kernel<DP>, Smem<DP>::BYTES);                                    \
       if (!ok || !bigpar_pivots<DP, false>(B, n, d, P, L, diag, sub, w, info, st)) return -1000;                         \
+      static const bool eoff = std::getenv("MF_PANEL_EMIT_OFF") != nullptr;                                             \
+      const int erc = eoff ? -101 : panel_chol_emit(B, n, d, P, L, diag, sub, static_cast<const real*>(w.piv), ldiag, lsub, info, st); \
+      if (erc != 0 && erc != -101) return -1000;                                                                        \
+      if (erc == -101)                                                                                                  \
       hipLaunchKernelGGL((bigpar_chol_emit_kernel<DP>), dim3((unsigned)(B * P)), dim3(NTHR), Smem<DP>::BYTES, st, B, n, d, P, L, \
                          diag, sub, static_cast<const real*>(w.piv), ldiag, lsub, info); }
     MF_BIGOP_DISPATCH(MF_C)

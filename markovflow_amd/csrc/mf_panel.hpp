@@ -22,6 +22,7 @@
 // of the wavefronts w >= j), followed by a back-substitution for U^-1 = L^-T that every wavefront runs on its own panel.
 #pragma once
 #include "mf_wave.hpp"
+#include "mf_wave_ops.hpp"   // chol_fact_tile (a diagonal tile factored with the factor itself kept: the emit pass)
 
 namespace mf {
 namespace pn {
@@ -401,8 +402,11 @@ MF_DEV void tri_inv_panel(const Panel<T, NT>& C, Panel<T, NT>& Ci, const Ctx<T, 
 // ---- Phi (symmetric, tiles ti <= w valid; consumed) -> LiT = chol(Phi)^-T (upper: tiles ti <= w).  Barriers: 2 NT - 1. ------------------
 // Uses image 1 (holds U = L^T), image 2 (holds U^T) and the slots.  first(): called behind the first barrier (whatever the workgroup
 // read from the images before the call has been read by then).
+// want_l (the emit pass of the factorisation): also the wavefront's diagonal tile of the factor itself, L_ww in the
+// accumulator layout; with it and Phi.t[j] = U(j, w) = L(w, j)^T, j < w, the wavefront holds block row w of L on return.
 template <typename T, int NT, int MT, typename First>
-MF_DEV void chol_inv_panel(Panel<T, NT>& Phi, Panel<T, NT>& LiT, const Ctx<T, NT, MT>& c, LogAcc<T>& la, bool& bad, First first) {
+MF_DEV void chol_inv_panel(Panel<T, NT>& Phi, Panel<T, NT>& LiT, const Ctx<T, NT, MT>& c, LogAcc<T>& la, bool& bad, First first,
+                           bool want_l, typename Tr<T>::v4& Ldiag) {
     using v4 = typename Tr<T>::v4;
     using G = PG<T, NT>;
     const Lane& ln = c.ln;
@@ -410,10 +414,14 @@ MF_DEV void chol_inv_panel(Panel<T, NT>& Phi, Panel<T, NT>& LiT, const Ctx<T, NT
     v4 own = {0, 0, 0, 0};
     MF_UNROLL for (int j = 0; j < NT; ++j) {
         if (is_wave(c.w, j)) {
+            if (want_l) {
+                wv::chol_fact_tile<T>(Phi.t[j], Ldiag, own, c.sm.slot(j), ln, bad);   // (same image afterwards; no log-determinant)
+            } else {
             const v4 in[1] = {Phi.t[j]};
             v4 o[1];
             wv::chol_inv_tiles<T, 1, true>(in, o, c.sm.slot(j), ln, la, bad);     // the slot keeps Li_jj = L_jj^-1 row-major
             own = o[0];                                                           // Li_jj^T = U_jj^-1 in the accumulator layout
+            }
         }
         __syncthreads();
         if (j == 0) first();
@@ -476,9 +484,23 @@ template <typename T, int NT> struct PanelElim {
 // operand of a later product instead of staying in registers (S, V, WT: 48 registers at the step's widest point).
 // Barriers: 2 NT - 1 + 3.  mid(): called behind the last barrier, in front of the last two products: image 1 and the vectors are
 // free from there on - the place where the next step's inputs are requested (LDS-DMA), two products ahead of their use.
+// block row w of a matrix whose TRANSPOSED column panel w the wavefront holds (tiles t[tj] = M^T[16 tj ..][16 w ..]): M[16 w + r][16 tj + row]
+template <typename T, int NT>
+MF_DEV void store_panel_rows_t(T* __restrict__ g, const typename Tr<T>::v4 (&t)[NT], int d, int w, const Lane& ln, int skip = -1) {
+    MF_UNROLL for (int tj = 0; tj < NT; ++tj) {
+        if (tj == skip) continue;
+        MF_UNROLL for (int e = 0; e < 4; ++e) {
+            const int i = 16 * w + ln.r, j = 16 * tj + Tr<T>::row(ln.q, e);
+            if (i < d && j < d) g[i * d + j] = t[tj][e];
+        }
+    }
+}
+// gl / gw (the emit pass of SymmetricBlockTriDiagonal.cholesky, block_tri_diag.py:423-436): the factor of the pivot that is
+// eliminated goes to gl (lower triangular, zeros above), W = S L^-T to gw; either may be NULL.
 template <typename T, int NT, int MT, bool ST_FROM_S, typename Mid>
 MF_DEV void eliminate_advance(PanelElim<T, NT>& E, Panel<T, NT>& S, const Panel<T, NT>& Dn, T rn, bool spike,
-                              const Ctx<T, NT, MT>& c, Mid mid, Stamp& stamp) {
+                              const Ctx<T, NT, MT>& c, Mid mid, Stamp& stamp, T* __restrict__ gl = nullptr, T* __restrict__ gw = nullptr,
+                              int d_emit = 0) {
     using G = PG<T, NT>;
     const Lane& ln = c.ln;
     const int w = c.w;
@@ -487,11 +509,21 @@ MF_DEV void eliminate_advance(PanelElim<T, NT>& E, Panel<T, NT>& S, const Panel<
     T z;
     {
         Panel<T, NT> LiT;
+        typename Tr<T>::v4 Ld = {0, 0, 0, 0};
         chol_inv_panel<T, NT, MT>(E.Phi, LiT, c, E.laL, E.bad, [&]() __attribute__((always_inline)) {
             if (ST_FROM_S) {
                 MF_UNROLL for (int ti = 0; ti < NT; ++ti) img_put_t<T, G::LD>(I0, ti, w, S.t[ti], ln);
             }
-        });
+        }, gl != nullptr, Ld);
+        if (gl) {   // block row w of L: U(j, w)^T for j < w, the diagonal tile, zeros to the right
+            typename Tr<T>::v4 rowt[NT];
+            MF_UNROLL for (int tj = 0; tj < NT; ++tj) rowt[tj] = tj < w ? E.Phi.t[tj] : typename Tr<T>::v4{0, 0, 0, 0};
+            store_panel_rows_t<T, NT>(gl, rowt, d_emit, w, ln, w);
+            MF_UNROLL for (int e = 0; e < 4; ++e) {
+                const int i = 16 * w + Tr<T>::row(ln.q, e), j = 16 * w + ln.r;
+                if (i < d_emit && j < d_emit) gl[i * d_emit + j] = Ld[e];
+            }
+        }
         MF_PSTAMP(stamp, 5)
         RV<T, NT> t_rv;
         vec_rv<T, NT>(t_rv, c.sm.vec(V_T), ln);
@@ -513,6 +545,7 @@ MF_DEV void eliminate_advance(PanelElim<T, NT>& E, Panel<T, NT>& S, const Panel<
         }
         tn_img<T, NT, NT, G::LD, OP_SET, P_UPPER>(WT, I1, ST.t, ln);     // W^T = Li S^T
     }
+    if (gw) store_panel_rows_t<T, NT>(gw, WT.t, d_emit, w, ln);
     if (spike) {
         Panel<T, NT> V;
         tn_img<T, NT, NT, G::LD, OP_SET, P_UPPER>(V, I1, E.X.t, ln);     // V = Li X
@@ -556,7 +589,8 @@ template <typename T, int NT, int MT> MF_DEV void eliminate_last(PanelElim<T, NT
     const int w = c.w;
     vec_put<T>(c.sm.vec(V_T), w, E.t, c.ln);
     Panel<T, NT> LiT;
-    chol_inv_panel<T, NT, MT>(E.Phi, LiT, c, E.laL, E.bad, [] {});
+    typename Tr<T>::v4 unused = {0, 0, 0, 0};
+    chol_inv_panel<T, NT, MT>(E.Phi, LiT, c, E.laL, E.bad, [] {}, false, unused);
     RV<T, NT> t_rv;
     vec_rv<T, NT>(t_rv, c.sm.vec(V_T), c.ln);
     const T z = mv_panel<T, NT>(LiT.t, t_rv.v);
@@ -915,6 +949,63 @@ panel_red_kernel(RedSys<T> in, RedSys<T> out, long B, long P, int d_, T add_cons
         if (threadIdx.x == 0) out_scalar[s] = add_const + acc_sc + tot;
     } else if (out.Dv) {
         store_chunk_panel<T, NT, 1>(out, id, d, E, acc_sc + tot, c);
+    }
+    if (__any(E.bad) && (threadIdx.x & 63) == 0 && info) raise_info(info);
+}
+
+// The emit pass of the time-partitioned SymmetricBlockTriDiagonal.cholesky (block_tri_diag.py:423-436) for 32 < d <= 64: workgroup
+// (series, chunk) restarts the textbook recursion from the natural-order pivot of the block in front of its chunk (piv, the pass
+// over the chunk ends) and writes L_k and W_{k-1} = S_{k-1} L_{k-1}^-T for its blocks - eliminate_advance without a spike, with the
+// factor and W taken out of it on the way (rounds 2-5: bigpar_chol_emit_kernel on LDS tiles, 1.66 ms at config 5's shape).
+template <typename T, int NT, bool EX>
+__global__ void __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(panel_wpe<T, NT, 1>(), panel_wpe<T, NT, 1>())))
+panel_chol_emit_kernel(long B, long n, int d_, long P, long Lc, const T* __restrict__ diag, const T* __restrict__ sub,
+                       const T* __restrict__ piv, T* __restrict__ ldiag, T* __restrict__ lsub, int* info) {
+    using L = Lds<T, NT, 1>;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    Ctx<T, NT, 1> c{L{reinterpret_cast<T*>(smem_raw)}, Lane{(int)(threadIdx.x & 15), (int)((threadIdx.x >> 4) & 3)},
+                    __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))};
+    Lane& ln = c.ln;
+    const int w = c.w;
+    int d = EX ? 16 * NT : d_;
+    const long s = blockIdx.x / P, ch = blockIdx.x % P;
+    const long k0 = ch * Lc, k1 = k0 + Lc < n ? k0 + Lc : n, dd = long(d) * d;
+    if (k0 >= n) return;
+    PanelElim<T, NT> E;
+    E.init();
+    Stamp stamp;
+    stamp.init(c.sm.red() + 16);
+    // step j = k0 - 1 (ch > 0: the pivot in front of the chunk, only W is written), then k0 ... k1 - 2 (factor and W); block k1 - 1: factor
+    const long j0 = ch > 0 ? k0 - 1 : k0;
+    if (ch > 0) load_panel<T, NT, EX>(E.Phi, piv + (s * P + ch - 1) * dd, d, w, false, true, ln);
+    else load_panel<T, NT, EX>(E.Phi, diag + (s * n) * dd, d, w, false, true, ln);
+    Panel<T, NT> Dn, FT;
+    auto load_step = [&](long j) __attribute__((always_inline)) {     // the inputs of eliminating block j: D_{j+1} and S_j^T
+        load_panel<T, NT, EX>(Dn, diag + (s * n + j + 1) * dd, d, w, false, true, ln);
+        load_panel_t<T, NT, EX>(FT, sub + (s * (n - 1) + j) * dd, d, w, ln);
+    };
+    if (j0 < k1 - 1) load_step(j0);
+    for (long j = j0; j < k1 - 1; ++j) {
+        asm volatile("" : "+v"(ln.r), "+v"(ln.q));
+        if constexpr (!EX) asm volatile("" : "+s"(d));
+        Panel<T, NT> Dc = Dn, Fc = FT;
+        if (j + 1 < k1 - 1) load_step(j + 1);
+        const bool own = j >= k0;                    // (the factor of the pivot in front of the chunk belongs to the chunk before)
+        eliminate_advance<T, NT, 1, false>(E, Fc, Dc, T(0), false, c, [] {}, stamp, own ? ldiag + (s * n + j) * dd : nullptr,
+                                           lsub + (s * (n - 1) + j) * dd, d);
+    }
+    {   // the chunk's last block: its factor alone
+        Panel<T, NT> LiT;
+        typename Tr<T>::v4 Ld = {0, 0, 0, 0};
+        chol_inv_panel<T, NT, 1>(E.Phi, LiT, c, E.laL, E.bad, [] {}, true, Ld);
+        T* gl = ldiag + (s * n + k1 - 1) * dd;
+        typename Tr<T>::v4 rowt[NT];
+        MF_UNROLL for (int tj = 0; tj < NT; ++tj) rowt[tj] = tj < w ? E.Phi.t[tj] : typename Tr<T>::v4{0, 0, 0, 0};
+        store_panel_rows_t<T, NT>(gl, rowt, d, w, ln, w);
+        MF_UNROLL for (int e = 0; e < 4; ++e) {
+            const int i = 16 * w + Tr<T>::row(ln.q, e), jj = 16 * w + ln.r;
+            if (i < d && jj < d) gl[i * d + jj] = Ld[e];
+        }
     }
     if (__any(E.bad) && (threadIdx.x & 63) == 0 && info) raise_info(info);
 }

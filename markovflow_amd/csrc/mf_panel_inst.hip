@@ -156,6 +156,39 @@ int panel_chol_up_f32(long B, long n, int d, long P, long L, const float* diag, 
                       float* piv, int rev, int* info, hipStream_t st) {
     return panel_chol_up_t<float>(B, n, d, P, L, diag, sub, oDv, oGU, oF, piv, rev, info, st);
 }
+namespace {
+template <typename T, int NT>
+int panel_chol_emit_nt(long B, long n, int d, long P, long L, const T* diag, const T* sub, const T* piv, T* ldiag, T* lsub, int* info,
+                       hipStream_t st) {
+    constexpr int bytes = pn::Lds<T, NT, 1>::BYTES;
+    const dim3 grid((unsigned)(B * P)), block(64 * NT);
+    if (d == 16 * NT) {
+        static const bool ok = panel_attr(&pn::panel_chol_emit_kernel<T, NT, true>, bytes);
+        if (!ok) return -1000;
+        hipLaunchKernelGGL((pn::panel_chol_emit_kernel<T, NT, true>), grid, block, bytes, st, B, n, d, P, L, diag, sub, piv, ldiag, lsub, info);
+    } else {
+        static const bool ok = panel_attr(&pn::panel_chol_emit_kernel<T, NT, false>, bytes);
+        if (!ok) return -1000;
+        hipLaunchKernelGGL((pn::panel_chol_emit_kernel<T, NT, false>), grid, block, bytes, st, B, n, d, P, L, diag, sub, piv, ldiag, lsub, info);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+template <typename T>
+int panel_chol_emit_t(long B, long n, int d, long P, long L, const T* diag, const T* sub, const T* piv, T* ldiag, T* lsub, int* info,
+                      hipStream_t st) {
+    if (d <= 32 || d > 64 || !sub || P < 2) return -101;
+    return d <= 48 ? panel_chol_emit_nt<T, 3>(B, n, d, P, L, diag, sub, piv, ldiag, lsub, info, st)
+                   : panel_chol_emit_nt<T, 4>(B, n, d, P, L, diag, sub, piv, ldiag, lsub, info, st);
+}
+}  // namespace
+int panel_chol_emit_f64(long B, long n, int d, long P, long L, const double* diag, const double* sub, const double* piv, double* ldiag,
+                        double* lsub, int* info, hipStream_t st) {
+    return panel_chol_emit_t<double>(B, n, d, P, L, diag, sub, piv, ldiag, lsub, info, st);
+}
+int panel_chol_emit_f32(long B, long n, int d, long P, long L, const float* diag, const float* sub, const float* piv, float* ldiag,
+                        float* lsub, int* info, hipStream_t st) {
+    return panel_chol_emit_t<float>(B, n, d, P, L, diag, sub, piv, ldiag, lsub, info, st);
+}
 int panel_red_f64(const RedSys<double>& in, const RedSys<double>& out, long B, long P, int d, double add_const, double* out_scalar,
                   int* info, int final_level, hipStream_t st) {
     return panel_red_t<double>(in, out, B, P, d, add_const, out_scalar, info, final_level, st);

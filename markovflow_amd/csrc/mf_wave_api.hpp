@@ -70,6 +70,19 @@ inline int panel_chol_up(long B, long n, int d, long P, long L, const float* dia
                          float* piv, int rev, int* info, hipStream_t st) {
     return panel_chol_up_f32(B, n, d, P, L, diag, sub, oDv, oGU, oF, piv, rev, info, st);
 }
+// mf_panel_inst.hip: the emit pass of the time-partitioned cholesky for 32 < d <= 64 (panel_chol_emit_kernel); -101: not covered
+int panel_chol_emit_f64(long B, long n, int d, long P, long L, const double* diag, const double* sub, const double* piv, double* ldiag,
+                        double* lsub, int* info, hipStream_t st);
+int panel_chol_emit_f32(long B, long n, int d, long P, long L, const float* diag, const float* sub, const float* piv, float* ldiag,
+                        float* lsub, int* info, hipStream_t st);
+inline int panel_chol_emit(long B, long n, int d, long P, long L, const double* diag, const double* sub, const double* piv, double* ldiag,
+                           double* lsub, int* info, hipStream_t st) {
+    return panel_chol_emit_f64(B, n, d, P, L, diag, sub, piv, ldiag, lsub, info, st);
+}
+inline int panel_chol_emit(long B, long n, int d, long P, long L, const float* diag, const float* sub, const float* piv, float* ldiag,
+                           float* lsub, int* info, hipStream_t st) {
+    return panel_chol_emit_f32(B, n, d, P, L, diag, sub, piv, ldiag, lsub, info, st);
+}
 inline int panel_ssm_precision(long B, long Tn, int d, int m, const double* mu0, const double* cholP0, const double* A, const double* b,
                                const double* cholQ, const double* H, const double* y, const double* Rinv, int rinv_per_step, double* diag,
                                double* sub, double* eta, hipStream_t st) {
