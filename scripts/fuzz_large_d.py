@@ -1,8 +1,10 @@
 """Randomised log-likelihood parity for 10 <= d <= 64 in both dtypes (row, wave, panel and LDS-tile kernels; m up to 32; explicit
-time partitions) against the numpy oracle."""
+time partitions) against the numpy oracle; in fp32 at d > 32 (every third such case) also the operators that run on the panel
+kernels since round 6: the precision assembly (prior and posterior), cholesky of the posterior precision, the posterior chain."""
 import os, sys, time
 import numpy as np
 import torch
+import markovflow_amd as mfa
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 from oracle import numpy_oracle as O
@@ -27,6 +29,30 @@ for case in range(n_cases):
     got = float(kf.log_likelihood())
     key = "f64" if f64 else "f32"
     worst[key] = max(worst[key], abs(got - ref) / abs(ref))
+    if not f64 and d > 32 and case % 3 == 0:
+        rel = lambda a, b: float(np.max(np.abs(np.asarray(a) - b)) / (np.max(np.abs(b)) + 1e-300))   # noqa: E731
+        r32 = {k: v.astype(np.float32).astype(np.float64) for k, v in kw.items()}
+        chol_r = np.linalg.cholesky(cov).astype(np.float32).astype(np.float64)
+        r_inv = np.linalg.inv(chol_r @ chol_r.T)
+        kf32 = build_kf(r32, chol_r, dtype=torch.float32)
+        errs = []
+        pd, ps = O.ssm_precision(r32["chol_p0"], r32["a_s"], r32["chol_q"])
+        prec = kf32.prior_ssm.precision
+        errs += [rel(prec.block_diagonal.cpu().numpy(), pd), rel(prec.block_sub_diagonal.cpu().numpy(), ps)]
+        qd, qs = O.kf_posterior_precision(r32["chol_p0"], r32["a_s"], r32["chol_q"], r32["h"], r_inv)
+        post = kf32._k_inv_post
+        errs += [rel(post.block_diagonal.cpu().numpy(), qd), rel(post.block_sub_diagonal.cpu().numpy(), qs)]
+        ld, ls = O.btd_cholesky(qd, qs)
+        tt = lambda x: torch.tensor(x, dtype=torch.float32, device="cuda:0")                           # noqa: E731
+        chol = mfa.SymmetricBlockTriDiagonal(tt(qd), tt(qs)).cholesky
+        errs += [rel(chol.block_diagonal.cpu().numpy(), np.tril(ld)), rel(chol.block_sub_diagonal.cpu().numpy(), ls)]
+        chain = kf32.posterior_state_space_model()
+        want = O.kf_posterior_ssm(**r32, r_inv=r_inv)
+        for g_, w_ in zip((chain.initial_mean, chain.cholesky_initial_covariance, chain.state_transitions, chain.state_offsets,
+                           chain.cholesky_process_covariances), want):
+            errs.append(rel(g_.cpu().numpy(), w_))
+        assert max(errs) < 2e-2, (case, dict(d=d, m=m, bsz=bsz, t=t), errs)
+        worst["ops f32"] = max(worst.get("ops f32", 0.0), max(errs))
 print(f"{n_cases} cases in {time.time() - t0:.0f} s; worst relative deviation:", {k: f"{v:.2e}" for k, v in worst.items()})
 assert worst["f64"] < 1e-9 and worst["f32"] < 5e-3, worst
 print("fuzz ok")
