@@ -4,9 +4,9 @@ kernels since round 6: the precision assembly (prior and posterior), cholesky of
 import os, sys, time
 import numpy as np
 import torch
-import markovflow_amd as mfa
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import markovflow_amd as mfa
 from oracle import numpy_oracle as O
 from test_gpu_kalman import build_kf
 
