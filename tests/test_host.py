@@ -51,6 +51,22 @@ def test_workspace_queries_accept_degenerate_sizes():
     assert lib.mf_kf_loglik_workspace_bytes(3, 1, 6, 8, 0) > 0          # a chain of one block is legal
 
 
+def test_workspace_queries_of_the_round_6_paths():
+    """The time-partitioned wave solve / marginal_means and the one-walk kl_divergence at 16 <= d <= 32 size their own workspaces
+    (csrc/mf_wave_inst.hip); no GPU needed for the queries."""
+    lib = _lib.load()
+    for esz in (4, 8):
+        # B = 512, T = 1000, d = 16: six chunks of (M, v, z_in) per series at least
+        assert lib.mf_btd_solve_workspace_bytes(512, 512, 1000, 16, esz) >= 512 * 6 * (16 * 16 + 2 * 16) * esz
+        assert lib.mf_btd_solve_workspace_bytes(64, 64, 1000, 32, esz) > 0
+        assert lib.mf_ssm_kl_workspace_bytes(512, 1000, 16, esz) > 512 * 1000 * esz          # per-block terms + the chunk states
+        assert lib.mf_ssm_kl_workspace_bytes(512, 1000, 32, esz) > 0
+        assert lib.mf_ssm_kl_workspace_bytes(8, 1, 16, esz) == 0                              # one block: the operator route
+    assert lib.mf_ssm_kl_workspace_bytes(8, 100, 40, 4) == 0                                   # d > 32: the operator route
+    assert lib.mf_info_flat_index(0) == -1 and lib.mf_info_flat_index(1) == -1                 # no error / block unknown
+    assert lib.mf_info_flat_index(0x7fffffff - 137) == 137
+
+
 def test_cpu_tensors_fail_loudly():
     d = torch.eye(3, dtype=torch.float64).expand(2, 4, 3, 3).contiguous()
     with pytest.raises(RuntimeError, match="no CPU fallback"):
