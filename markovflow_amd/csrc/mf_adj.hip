@@ -21,6 +21,7 @@
 
 #include "mf_launch.hpp"
 #include "mf_wave.hpp"
+#include "mf_wave_ops.hpp"
 
 namespace mf {
 namespace wv {
@@ -271,15 +272,431 @@ wave_inv_grad_kernel(long n, int d, const T* __restrict__ ldiag, const T* __rest
     (void)bad;
 }
 
+
+// =====================================================================================================================================
+// Parallel in time.  The block Cholesky  P_k = D_k - S_{k-1} P_{k-1}^-1 S_{k-1}^T, L_k = chol(P_k), W_k = S_k L_k^-T  is a LOCAL map
+// (P_k, S_k) -> (L_k, W_k) behind a Riccati-type recursion in P_k: its adjoint splits into a part that is local in time - the only
+// place where the projection Phi of the dense Cholesky adjoint acts - and the adjoint of the recursion, a CONGRUENCE recursion with
+// the coupling of the block Takahashi recursion, G_k = W_k L_k^-1 (mf_btd_par.hpp has the derivation and the d <= 9 kernels):
+//     Sbar_k(loc) = Wbar_k L_k^-1,   Lbar_k(eff) = Lbar_k - tril(Sbar_k(loc)^T W_k),   C_k = sym(L_k^-T Phi(L_k^T Lbar_k(eff)) L_k^-1)
+//     Dbar_k = Z_k,   Z_k = C_k + G_k^T Z_{k+1} G_k,   Sbar_k = Sbar_k(loc) - 2 Z_{k+1} G_k.
+// So: one wavefront per (series, block) for the local terms, the congruence recursion as composed maps per chunk + a pass over the
+// chunk ends + a walk per chunk (the scheme of wave_inv_up_kernel / wave_inv_boundary_kernel / wave_inverse_blocks_kernel,
+// mf_wave_ops.hpp, with C and G read instead of formed from a factor), an axpy.  (The sequential kernels above: 10.7 ms per launch
+// for ONE series of 1001 blocks at d = 30 - a wavefront walking the chain; they stay for short chains and without a workspace.)
+template <typename T, int NT>
+__global__ void __launch_bounds__(64) wave_chol_grad_local_kernel(long B, long n, int d, const T* __restrict__ ldiag,
+                                                                 const T* __restrict__ lsub, const T* __restrict__ gl,
+                                                                 const T* __restrict__ gw, T* __restrict__ oC, T* __restrict__ oG,
+                                                                 T* __restrict__ oS) {
+    using v4 = typename Tr<T>::v4;
+    constexpr int TS = 16 * Tr<T>::LD;
+    __shared__ __attribute__((aligned(16))) T lds[NT * NT * TS];
+    const Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
+    const long id = blockIdx.x, s = id / n, k = id % n, dd = (long)d * d;
+    LogAcc<T> la;
+    la.init();
+    bool bad = false;
+    Mat<T, NT> L, Li, Lb;
+    v4 c10t;
+    load_factor<T, NT>(L, c10t, ldiag + id * dd, d, ln);
+    load_or_zero<T, NT>(Lb, gl ? gl + id * dd : nullptr, d, false, ln);
+    Mat<T, NT> Wt, W, Wbt;
+    const bool has_w = lsub && k + 1 < n;
+    const long ks = s * (n - 1) + k;
+    if (has_w) {
+        load_or_zero<T, NT>(Wt, lsub + ks * dd, d, true, ln);
+        if (gw) {
+            load_or_zero<T, NT>(W, lsub + ks * dd, d, false, ln);
+            load_or_zero<T, NT>(Wbt, gw + ks * dd, d, true, ln);
+        }
+    }
+    tri_inv_mat<T, NT>(L, c10t, Li, lds, ln, la, bad);
+    mask_lower<T, NT>(Lb, T(1), ln);
+    if (has_w) {
+        Mat<T, NT> X;
+        tn<T, NT, S_FULL, S_LOWER, S_FULL, OP_SET>(X, Wt, Li);                  // G = W L^-1
+        store_mat<T, NT, false>(oG + ks * dd, X, d, lds, ln);
+        if (gw) {
+            tn<T, NT, S_FULL, S_LOWER, S_FULL, OP_SET>(X, Wbt, Li);             // Sbar(loc) = Wbar L^-1
+            store_mat<T, NT, false>(oS + ks * dd, X, d, lds, ln);
+            Mat<T, NT> Tm;
+            tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(Tm, X, W);                // Sbar(loc)^T W
+            mask_lower<T, NT>(Tm, T(1), ln);
+            axpy<T, NT>(Lb, T(-1), Tm);
+        } else {
+            X.zero();
+            store_mat<T, NT, false>(oS + ks * dd, X, d, lds, ln);
+        }
+    }
+    Mat<T, NT> M, Y;
+    tn<T, NT, S_LOWER, S_LOWER, S_FULL, OP_SET>(M, L, Lb);                      // L^T Lbar(eff)
+    mask_lower<T, NT>(M, T(0.5), ln);                                           // Phi
+    {
+        Mat<T, NT> Ft;
+        tn<T, NT, S_LOWER, S_LOWER, S_FULL, OP_SET>(Ft, M, Li);
+        tn<T, NT, S_FULL, S_LOWER, S_FULL, OP_SET>(Y, Ft, Li);                  // L^-T Phi L^-1
+    }
+    transpose<T, NT, S_FULL>(M, Y, lds, ln);
+    MF_UNROLL for (int i = 0; i < NT; ++i) MF_UNROLL for (int j = 0; j < NT; ++j) Y.t[i][j] = T(0.5) * (Y.t[i][j] + M.t[i][j]);
+    store_mat<T, NT, false>(oC + id * dd, Y, d, lds, ln);
+    (void)bad;
+}
+
+// The congruence recursion run backwards, X_k = N_k + G_k^T X_{k+1} G_k (X symmetric), with N [B, n, d, d] and G [B, n - 1, d, d] read
+// from memory (a.diag, a.sub); a.o1 <- X_k, a.o2 <- -X_{k+1} G_k (or NULL).  Chunks count from the LAST block, as in the kernels these
+// are modelled on; the pass over the chunk ends IS wave_inv_boundary_kernel.
+template <typename T, int NT>
+__global__ void __launch_bounds__(64) wave_cong_up_kernel(FactArgs<T> a) {
+    constexpr int TS = 16 * Tr<T>::LD;
+    __shared__ __attribute__((aligned(16))) T lds[NT * NT * TS];
+    Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
+    const long s = blockIdx.x / a.P, c = blockIdx.x % a.P, n = a.n;
+    const long k_hi = n - 1 - c * a.L, k_lo = n - (c + 1) * a.L > 0 ? n - (c + 1) * a.L : 0;
+    int d = a.d;
+    const long dd = long(d) * d;
+    Mat<T, NT> MT, N;
+    identity_mat<T, NT>(MT, ln);
+    N.zero();
+    for (long k = k_hi; k >= k_lo; --k) {
+        asm volatile("" : "+v"(ln.r), "+v"(ln.q));
+        asm volatile("" : "+s"(d));
+        Mat<T, NT> G, C, X;
+        G.zero();
+        if (k + 1 < n) load_mat<T, NT, S_FULL>(G, a.sub + (s * (n - 1) + k) * dd, d, false, false, ln);
+        load_mat<T, NT, S_FULL>(C, a.diag + (s * n + k) * dd, d, false, false, ln);
+        phase();
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(X, G, MT);                           // (M G)^T = G^T M^T
+        MT = X;
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(X, N, G);                            // N G
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(N, G, X);                            // G^T N G
+        axpy<T, NT>(N, T(1), C);
+    }
+    const long id = s * a.P + c;
+    store_mat<T, NT, false>(a.rDv + id * dd, MT, d, lds, ln);
+    store_mat<T, NT, false>(a.rGU + id * dd, N, d, lds, ln);
+}
+template <typename T, int NT, bool PART>
+__global__ void __launch_bounds__(64) wave_cong_walk_kernel(FactArgs<T> a) {
+    constexpr int TS = 16 * Tr<T>::LD;
+    __shared__ __attribute__((aligned(16))) T lds[NT * NT * TS];
+    Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
+    const long s = PART ? blockIdx.x / a.P : blockIdx.x, c = PART ? blockIdx.x % a.P : 0, n = a.n;
+    const long k_hi = PART ? n - 1 - c * a.L : n - 1;
+    const long k_lo = PART ? (n - (c + 1) * a.L > 0 ? n - (c + 1) * a.L : 0) : 0;
+    int d = a.d;
+    const long dd = long(d) * d;
+    Mat<T, NT> Sig, Gk, Ck;
+    Sig.zero();
+    if (PART && c > 0) load_mat<T, NT, S_FULL>(Sig, a.bSig + (s * a.P + c) * dd, d, false, false, ln);
+    Gk.zero();
+    if (k_hi + 1 < n) load_mat<T, NT, S_FULL>(Gk, a.sub + (s * (n - 1) + k_hi) * dd, d, false, false, ln);
+    load_mat<T, NT, S_FULL>(Ck, a.diag + (s * n + k_hi) * dd, d, false, false, ln);
+    for (long k = k_hi; k >= k_lo; --k) {
+        asm volatile("" : "+v"(ln.r), "+v"(ln.q));
+        asm volatile("" : "+s"(d));
+        const bool more = k > k_lo, coupled = k + 1 < n;
+        Mat<T, NT> Gn, Cn;
+        if (more) {
+            load_mat<T, NT, S_FULL>(Gn, a.sub + (s * (n - 1) + k - 1) * dd, d, false, false, ln);
+            load_mat<T, NT, S_FULL>(Cn, a.diag + (s * n + k - 1) * dd, d, false, false, ln);
+        }
+        phase();
+        Mat<T, NT> Out = Ck;
+        if (coupled) {
+            Mat<T, NT> NSG;
+            tn<T, NT, S_FULL, S_FULL, S_FULL, OP_NEG>(NSG, Sig, Gk);                   // -X_{k+1} G   (X symmetric)
+            if (a.o2) store_mat<T, NT, false>(a.o2 + (s * (n - 1) + k) * dd, NSG, d, lds, ln);
+            tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SUB>(Out, Gk, NSG);                   // + G^T X G
+        }
+        store_mat<T, NT, false>(a.o1 + (s * n + k) * dd, Out, d, lds, ln);
+        Sig = Out;
+        if (more) {
+            Gk = Gn;
+            Ck = Cn;
+        }
+    }
+}
+// ---- block_diagonal_of_inverse, reverse mode, parallel in time --------------------------------------------------------------------
+// The block Takahashi recursion run backwards in reverse mode is the same congruence recursion run FORWARD with G instead of G^T:
+//     A_0 = sym(Sigmabar_0),   A_{k+1} = sym(Sigmabar_{k+1}) - sym(subbar_k G_k^T) + G_k A_k G_k^T
+// between two kernels that are local in time: `pre` forms G_k and the explicit terms Q, `post` turns the totals A_k into
+//     Lbar_k = -2 tril(L_k^-T (L_k^-1 A_k L_k^-T)) - tril(G_k^T Wbar_k),   Wbar_k = (2 Sigma_{k+1} G_k A_k - Sigma_{k+1} subbar_k) L_k^-T
+// (mf_btd_par.hpp: btd_inv_grad_pre_kernel / _post_kernel, d <= 9).
+template <typename T, int NT>
+__global__ void __launch_bounds__(64) wave_inv_grad_pre_kernel(long B, long n, int d, const T* __restrict__ ldiag, const T* __restrict__ lsub,
+                                                              const T* __restrict__ gd, const T* __restrict__ gs, T* __restrict__ oQ,
+                                                              T* __restrict__ oG) {
+    using v4 = typename Tr<T>::v4;
+    constexpr int TS = 16 * Tr<T>::LD;
+    __shared__ __attribute__((aligned(16))) T lds[NT * NT * TS];
+    const Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
+    const long id = blockIdx.x, s = id / n, k = id % n, dd = (long)d * d;
+    auto sym_in = [&](long blk, Mat<T, NT>& Q) {
+        Mat<T, NT> Qt;
+        load_or_zero<T, NT>(Q, gd ? gd + blk * dd : nullptr, d, false, ln);
+        load_or_zero<T, NT>(Qt, gd ? gd + blk * dd : nullptr, d, true, ln);
+        MF_UNROLL for (int i = 0; i < NT; ++i) MF_UNROLL for (int j = 0; j < NT; ++j) Q.t[i][j] = T(0.5) * (Q.t[i][j] + Qt.t[i][j]);
+    };
+    if (k == 0 || !lsub) {
+        Mat<T, NT> Q;
+        sym_in(id, Q);
+        store_mat<T, NT, false>(oQ + id * dd, Q, d, lds, ln);
+    }
+    if (!(lsub && k + 1 < n)) return;
+    const long ks = s * (n - 1) + k;
+    LogAcc<T> la;
+    la.init();
+    bool bad = false;
+    Mat<T, NT> L, Li, Wt, G, Gt, Q;
+    v4 c10t;
+    load_factor<T, NT>(L, c10t, ldiag + id * dd, d, ln);
+    load_or_zero<T, NT>(Wt, lsub + ks * dd, d, true, ln);
+    tri_inv_mat<T, NT>(L, c10t, Li, lds, ln, la, bad);
+    tn<T, NT, S_FULL, S_LOWER, S_FULL, OP_SET>(G, Wt, Li);                      // G = W L^-1
+    store_mat<T, NT, false>(oG + ks * dd, G, d, lds, ln);
+    sym_in(id + 1, Q);
+    if (gs) {
+        Mat<T, NT> Sbt, X, Xt;
+        tn<T, NT, S_LOWER, S_FULL, S_FULL, OP_SET>(Gt, Li, Wt);                 // G^T
+        load_or_zero<T, NT>(Sbt, gs + ks * dd, d, true, ln);
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(X, Sbt, Gt);                  // subbar G^T
+        transpose<T, NT, S_FULL>(Xt, X, lds, ln);
+        MF_UNROLL for (int i = 0; i < NT; ++i) MF_UNROLL for (int j = 0; j < NT; ++j) Q.t[i][j] -= T(0.5) * (X.t[i][j] + Xt.t[i][j]);
+    }
+    store_mat<T, NT, false>(oQ + (id + 1) * dd, Q, d, lds, ln);
+    (void)bad;
+}
+// The congruence recursion run forwards, X_{k+1} = N_{k+1} + G_k X_k G_k^T, X_0 = N_0 (X symmetric), N [B, n, d, d] = a.diag and
+// G [B, n - 1, d, d] = a.sub read from memory; a.o1 <- X_k.  Chunk c carries position c L to (c + 1) L (a.rDv: the chunk's M = prod G,
+// a.rGU: its N, a.bSig: X at position c L) - the scheme of wave_marg_up_kernel / _boundary_kernel / wave_marginals_kernel.
+template <typename T, int NT>
+__global__ void __launch_bounds__(64) wave_cong_fwd_up_kernel(FactArgs<T> a) {
+    constexpr int TS = 16 * Tr<T>::LD;
+    __shared__ __attribute__((aligned(16))) T lds[NT * NT * TS];
+    Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
+    const long s = blockIdx.x / a.P, c = blockIdx.x % a.P, nt = a.n - 1;
+    const long t_lo = c * a.L, t_hi = (c + 1) * a.L < nt ? (c + 1) * a.L : nt;
+    int d = a.d;
+    const long dd = long(d) * d;
+    Mat<T, NT> M, N;
+    identity_mat<T, NT>(M, ln);
+    N.zero();
+    for (long k = t_lo; k < t_hi; ++k) {
+        asm volatile("" : "+v"(ln.r), "+v"(ln.q));
+        asm volatile("" : "+s"(d));
+        Mat<T, NT> GT, Qn, X;
+        load_mat_t<T, NT>(GT, a.sub + (s * nt + k) * dd, d, ln);
+        load_mat<T, NT, S_FULL>(Qn, a.diag + (s * a.n + k + 1) * dd, d, false, false, ln);
+        phase();
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(X, GT, M);                           // G M
+        M = X;
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(X, N, GT);                           // N G^T
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(N, GT, X);                           // G N G^T
+        axpy<T, NT>(N, T(1), Qn);
+    }
+    const long id = s * a.P + c;
+    store_mat<T, NT, false>(a.rDv + id * dd, M, d, lds, ln);
+    store_mat<T, NT, false>(a.rGU + id * dd, N, d, lds, ln);
+}
+template <typename T, int NT>
+__global__ void __launch_bounds__(64) wave_cong_fwd_boundary_kernel(FactArgs<T> a) {
+    constexpr int TS = 16 * Tr<T>::LD;
+    __shared__ __attribute__((aligned(16))) T lds[NT * NT * TS];
+    Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
+    const long s = blockIdx.x;
+    int d = a.d;
+    const long dd = long(d) * d;
+    Mat<T, NT> X;
+    load_mat<T, NT, S_FULL>(X, a.diag + (s * a.n) * dd, d, false, false, ln);           // X_0 = N_0
+    for (long c = 0; c + 1 < a.P; ++c) {
+        const long id = s * a.P + c;
+        Mat<T, NT> MT, N, Y;
+        load_mat_t<T, NT>(MT, a.rDv + id * dd, d, ln);
+        load_mat<T, NT, S_FULL>(N, a.rGU + id * dd, d, false, false, ln);
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(Y, X, MT);                           // X M^T
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(X, MT, Y);                           // M X M^T
+        axpy<T, NT>(X, T(1), N);
+        store_mat<T, NT, false>(a.bSig + (id + 1) * dd, X, d, lds, ln);
+    }
+}
+template <typename T, int NT, bool PART>
+__global__ void __launch_bounds__(64) wave_cong_fwd_walk_kernel(FactArgs<T> a) {
+    constexpr int TS = 16 * Tr<T>::LD;
+    __shared__ __attribute__((aligned(16))) T lds[NT * NT * TS];
+    Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
+    const long s = PART ? blockIdx.x / a.P : blockIdx.x, c = PART ? blockIdx.x % a.P : 0, nt = a.n - 1;
+    const long t_lo = PART ? c * a.L : 0, t_hi = PART ? ((c + 1) * a.L < nt ? (c + 1) * a.L : nt) : nt;
+    int d = a.d;
+    const long dd = long(d) * d;
+    Mat<T, NT> X, GT, Qn;
+    if (!PART || c == 0) {
+        load_mat<T, NT, S_FULL>(X, a.diag + (s * a.n) * dd, d, false, false, ln);
+        store_mat<T, NT, false>(a.o1 + (s * a.n) * dd, X, d, lds, ln);
+    } else {
+        load_mat<T, NT, S_FULL>(X, a.bSig + (s * a.P + c) * dd, d, false, false, ln);
+    }
+    if (t_hi > t_lo) {
+        load_mat_t<T, NT>(GT, a.sub + (s * nt + t_lo) * dd, d, ln);
+        load_mat<T, NT, S_FULL>(Qn, a.diag + (s * a.n + t_lo + 1) * dd, d, false, false, ln);
+    }
+    for (long k = t_lo; k < t_hi; ++k) {
+        asm volatile("" : "+v"(ln.r), "+v"(ln.q));
+        asm volatile("" : "+s"(d));
+        Mat<T, NT> GTn, Qnn, Y;
+        const long kn = k + 1 < t_hi ? k + 1 : k;
+        load_mat_t<T, NT>(GTn, a.sub + (s * nt + kn) * dd, d, ln);
+        load_mat<T, NT, S_FULL>(Qnn, a.diag + (s * a.n + kn + 1) * dd, d, false, false, ln);
+        phase();
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(Y, X, GT);                           // X G^T
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(X, GT, Y);                           // G X G^T
+        axpy<T, NT>(X, T(1), Qn);
+        store_mat<T, NT, false>(a.o1 + (s * a.n + k + 1) * dd, X, d, lds, ln);
+        GT = GTn;
+        Qn = Qnn;
+    }
+}
+template <typename T, int NT>
+__global__ void __launch_bounds__(64) wave_inv_grad_post_kernel(long B, long n, int d, const T* __restrict__ ldiag, const T* __restrict__ lsub,
+                                                               const T* __restrict__ sig, const T* __restrict__ tot,
+                                                               const T* __restrict__ gs, const T* __restrict__ Gk, T* __restrict__ g_ldiag,
+                                                               T* __restrict__ g_lsub) {
+    using v4 = typename Tr<T>::v4;
+    constexpr int TS = 16 * Tr<T>::LD;
+    __shared__ __attribute__((aligned(16))) T lds[NT * NT * TS];
+    const Lane ln{(int)(threadIdx.x & 15), (int)(threadIdx.x >> 4)};
+    const long id = blockIdx.x, s = id / n, k = id % n, dd = (long)d * d;
+    LogAcc<T> la;
+    la.init();
+    bool bad = false;
+    Mat<T, NT> L, Li, LiT, A, Lb;
+    v4 c10t;
+    load_factor<T, NT>(L, c10t, ldiag + id * dd, d, ln);
+    load_or_zero<T, NT>(A, tot + id * dd, d, false, ln);                        // symmetric, stored full
+    tri_inv_mat<T, NT>(L, c10t, Li, lds, ln, la, bad);
+    LiT.zero();
+    transpose<T, NT, S_LOWER>(LiT, Li, lds, ln);
+    {
+        Mat<T, NT> U, M1;
+        tn<T, NT, S_FULL, S_UPPER, S_FULL, OP_SET>(U, A, LiT);                  // A L^-T   (A symmetric)
+        tn<T, NT, S_UPPER, S_FULL, S_FULL, OP_SET>(M1, LiT, U);                 // L^-1 A L^-T
+        tn<T, NT, S_LOWER, S_FULL, S_FULL, OP_SET>(Lb, Li, M1);                 // L^-T (.)
+        MF_UNROLL for (int i = 0; i < NT; ++i) MF_UNROLL for (int j = 0; j < NT; ++j) Lb.t[i][j] = T(-2) * Lb.t[i][j];
+    }
+    if (lsub && k + 1 < n) {
+        const long ks = s * (n - 1) + k;
+        Mat<T, NT> G, Gt, Sg, X, Kt, Wb;
+        load_or_zero<T, NT>(G, Gk + ks * dd, d, false, ln);
+        load_or_zero<T, NT>(Gt, Gk + ks * dd, d, true, ln);
+        load_or_zero<T, NT>(Sg, sig + (id + 1) * dd, d, false, ln);             // Sigma_{k+1} (symmetric)
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(X, Gt, A);                    // G A
+        {
+            Mat<T, NT> Sb;
+            load_or_zero<T, NT>(Sb, gs ? gs + ks * dd : nullptr, d, false, ln);
+            MF_UNROLL for (int i = 0; i < NT; ++i) MF_UNROLL for (int j = 0; j < NT; ++j) X.t[i][j] = T(2) * X.t[i][j] - Sb.t[i][j];
+        }
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SET>(Kt, X, Sg);                   // (Sigma X)^T = X^T Sigma
+        tn<T, NT, S_FULL, S_UPPER, S_FULL, OP_SET>(Wb, Kt, LiT);                // Wbar = Sigma X L^-T
+        store_mat<T, NT, false>(g_lsub + ks * dd, Wb, d, lds, ln);
+        tn<T, NT, S_FULL, S_FULL, S_FULL, OP_SUB>(Lb, G, Wb);                   // - G^T Wbar
+    }
+    mask_lower<T, NT>(Lb, T(1), ln);
+    store_mat<T, NT, false>(g_ldiag + id * dd, Lb, d, lds, ln);
+    (void)bad;
+}
+
+template <typename T> __global__ void __launch_bounds__(256) adj_axpy_kernel(long cnt, T alpha, const T* __restrict__ x, T* __restrict__ y) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < cnt) y[i] += alpha * x[i];
+}
+
 }  // namespace wv
 
 bool adj_covers(int d) { return d >= 10 && d <= 32; }
 
+void wave_udl_partition(long B, long n, int d, int elem_size, long& P, long& L);      // mf_wave_inst.hip
+
+// workspace of the parallel-in-time forms: three [B, n, d, d] arrays (local terms, couplings, scan by-products) + the chunk maps and
+// the states at the chunk ends of the congruence scans
+size_t adj_grad_ws(long B, long n, int d, int elem_size) {
+    if (!adj_covers(d) || B < 1 || n < 1) return 0;
+    long P = 1, L = n;
+    wave_udl_partition(B, n, d < 16 ? 16 : d, elem_size, P, L);
+    return (3 * size_t(B) * n + 3 * size_t(B) * P) * size_t(d) * d * elem_size + 256;
+}
+namespace {
+constexpr long ADJ_PAR_MIN_BLOCKS = 32;          // shorter chains: the sequential kernels
+template <typename T> struct AdjWs {
+    T *C, *G, *Zs, *rM, *rN, *bS;
+    long P, L;
+};
+template <typename T> bool adj_carve(void* ws, size_t ws_bytes, long B, long n, int d, AdjWs<T>& w) {
+    static const bool seq = getenv("MF_ADJ_SEQUENTIAL") != nullptr;       // (A/B switch)
+    if (seq || !ws || n < ADJ_PAR_MIN_BLOCKS || ws_bytes < adj_grad_ws(B, n, d, (int)sizeof(T))) return false;
+    wave_udl_partition(B, n, d < 16 ? 16 : d, (int)sizeof(T), w.P, w.L);
+    const size_t blk = size_t(B) * n * d * d, red = size_t(B) * w.P * d * d;
+    T* p = static_cast<T*>(ws);
+    w.C = p; w.G = p + blk; w.Zs = p + 2 * blk;
+    w.rM = p + 3 * blk; w.rN = w.rM + red; w.bS = w.rN + red;
+    return true;
+}
+// X_k = N_k + G_k^T X_{k+1} G_k for every block (N = w.C, G = w.G), X -> o1, -X_{k+1} G_k -> o2
+template <typename T, int NT> void cong_back(long B, long n, int d, const AdjWs<T>& w, T* o1, T* o2, hipStream_t st) {
+    wv::FactArgs<T> a{B, n, d, w.C, w.G, o1, o2, nullptr, nullptr, nullptr, nullptr};
+    a.P = w.P; a.L = w.L; a.rDv = w.rM; a.rGU = w.rN; a.bSig = w.bS;
+    const dim3 chunks((unsigned)(B * w.P)), series((unsigned)B), block(64);
+    if (w.P > 1) {
+        hipLaunchKernelGGL((wv::wave_cong_up_kernel<T, NT>), chunks, block, 0, st, a);
+        hipLaunchKernelGGL((wv::wave_inv_boundary_kernel<T, NT>), series, block, 0, st, a);
+        hipLaunchKernelGGL((wv::wave_cong_walk_kernel<T, NT, true>), chunks, block, 0, st, a);
+    } else {
+        hipLaunchKernelGGL((wv::wave_cong_walk_kernel<T, NT, false>), series, block, 0, st, a);
+    }
+}
+template <typename T, int NT>
+void inv_grad_par(long B, long n, int d, const T* ldiag, const T* lsub, const T* sigma, const T* g_diag, const T* g_sub, T* g_ldiag,
+                  T* g_lsub, const AdjWs<T>& w, hipStream_t st) {
+    const dim3 blocks((unsigned)(B * n)), chunks((unsigned)(B * w.P)), series((unsigned)B), block(64);
+    T *Q = w.C, *G = w.G, *A = w.Zs;
+    hipLaunchKernelGGL((wv::wave_inv_grad_pre_kernel<T, NT>), blocks, block, 0, st, B, n, d, ldiag, lsub, g_diag, g_sub, Q, G);
+    wv::FactArgs<T> a{B, n, d, Q, G, A, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // (the forward recursion runs over the n - 1 transitions: the chunks of the partition are chunks of transitions)
+    a.P = w.P; a.L = w.L; a.rDv = w.rM; a.rGU = w.rN; a.bSig = w.bS;
+    if (w.P > 1) {
+        hipLaunchKernelGGL((wv::wave_cong_fwd_up_kernel<T, NT>), chunks, block, 0, st, a);
+        hipLaunchKernelGGL((wv::wave_cong_fwd_boundary_kernel<T, NT>), series, block, 0, st, a);
+        hipLaunchKernelGGL((wv::wave_cong_fwd_walk_kernel<T, NT, true>), chunks, block, 0, st, a);
+    } else {
+        hipLaunchKernelGGL((wv::wave_cong_fwd_walk_kernel<T, NT, false>), series, block, 0, st, a);
+    }
+    hipLaunchKernelGGL((wv::wave_inv_grad_post_kernel<T, NT>), blocks, block, 0, st, B, n, d, ldiag, lsub, sigma, static_cast<const T*>(A),
+                       g_sub, static_cast<const T*>(G), g_ldiag, g_lsub);
+}
+template <typename T, int NT>
+void chol_grad_par(long B, long n, int d, const T* ldiag, const T* lsub, const T* g_ldiag, const T* g_lsub, T* g_diag, T* g_sub,
+                   const AdjWs<T>& w, hipStream_t st) {
+    hipLaunchKernelGGL((wv::wave_chol_grad_local_kernel<T, NT>), dim3((unsigned)(B * n)), dim3(64), 0, st, B, n, d, ldiag, lsub, g_ldiag,
+                       g_lsub, w.C, w.G, g_sub);
+    cong_back<T, NT>(B, n, d, w, g_diag, w.Zs, st);
+    const long cnt = B * (n - 1) * (long)d * d;
+    hipLaunchKernelGGL((wv::adj_axpy_kernel<T>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, cnt, T(2), static_cast<const T*>(w.Zs),
+                       g_sub);
+}
+}  // namespace
+
 template <typename T>
 int adj_cholesky_grad(long B, long n, int d, const T* ldiag, const T* lsub, const T* g_ldiag, const T* g_lsub, T* g_diag, T* g_sub,
-                      hipStream_t st) {
+                      void* ws, size_t ws_bytes, hipStream_t st) {
     if (!adj_covers(d)) return -100;
     if (n > 1 && !lsub) return -100;
+    {
+        AdjWs<T> w;
+        if (n > 1 && adj_carve<T>(ws, ws_bytes, B, n, d, w)) {
+            if (d <= 16) chol_grad_par<T, 1>(B, n, d, ldiag, lsub, g_ldiag, g_lsub, g_diag, g_sub, w, st);
+            else chol_grad_par<T, 2>(B, n, d, ldiag, lsub, g_ldiag, g_lsub, g_diag, g_sub, w, st);
+            return hipGetLastError() == hipSuccess ? 0 : -1000;
+        }
+    }
     const bool ph = getenv("MF_ADJ_PREFETCH") ? atoi(getenv("MF_ADJ_PREFETCH")) != 0 : !(sizeof(T) == 8 && d > 16);   // (the variable: A/B only)
 #define MF_ADJ_LAUNCH(NT_, PH_)                                                                                                        \
     hipLaunchKernelGGL((wv::wave_chol_grad_kernel<T, NT_, PH_>), dim3((unsigned)B), dim3(64), 0, st, n, d, ldiag, lsub, g_ldiag, g_lsub, \
@@ -291,9 +708,17 @@ int adj_cholesky_grad(long B, long n, int d, const T* ldiag, const T* lsub, cons
 }
 template <typename T>
 int adj_diag_of_inverse_grad(long B, long n, int d, const T* ldiag, const T* lsub, const T* sigma, const T* g_diag, const T* g_sub,
-                             T* g_ldiag, T* g_lsub, hipStream_t st) {
+                             T* g_ldiag, T* g_lsub, void* ws, size_t ws_bytes, hipStream_t st) {
     if (!adj_covers(d)) return -100;
     if (n > 1 && !lsub) return -100;
+    {
+        AdjWs<T> w;
+        if (n > 1 && adj_carve<T>(ws, ws_bytes, B, n, d, w)) {
+            if (d <= 16) inv_grad_par<T, 1>(B, n, d, ldiag, lsub, sigma, g_diag, g_sub, g_ldiag, g_lsub, w, st);
+            else inv_grad_par<T, 2>(B, n, d, ldiag, lsub, sigma, g_diag, g_sub, g_ldiag, g_lsub, w, st);
+            return hipGetLastError() == hipSuccess ? 0 : -1000;
+        }
+    }
     const bool ph = getenv("MF_ADJ_PREFETCH") ? atoi(getenv("MF_ADJ_PREFETCH")) != 0 : !(sizeof(T) == 8 && d > 16);
 #define MF_ADJ_LAUNCH(NT_, PH_)                                                                                                         \
     hipLaunchKernelGGL((wv::wave_inv_grad_kernel<T, NT_, PH_>), dim3((unsigned)B), dim3(64), 0, st, n, d, ldiag, lsub, sigma, g_diag, g_sub, \
@@ -304,12 +729,12 @@ int adj_diag_of_inverse_grad(long B, long n, int d, const T* ldiag, const T* lsu
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 template int adj_cholesky_grad<double>(long, long, int, const double*, const double*, const double*, const double*, double*, double*,
-                                       hipStream_t);
-template int adj_cholesky_grad<float>(long, long, int, const float*, const float*, const float*, const float*, float*, float*,
-                                      hipStream_t);
+                                       void*, size_t, hipStream_t);
+template int adj_cholesky_grad<float>(long, long, int, const float*, const float*, const float*, const float*, float*, float*, void*,
+                                      size_t, hipStream_t);
 template int adj_diag_of_inverse_grad<double>(long, long, int, const double*, const double*, const double*, const double*,
-                                              const double*, double*, double*, hipStream_t);
+                                              const double*, double*, double*, void*, size_t, hipStream_t);
 template int adj_diag_of_inverse_grad<float>(long, long, int, const float*, const float*, const float*, const float*, const float*,
-                                             float*, float*, hipStream_t);
+                                             float*, float*, void*, size_t, hipStream_t);
 
 }  // namespace mf

@@ -477,7 +477,7 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
             if (rc != -100 || !mf::adj_covers(d)) return rc;                                                           \
         }                                                                                                              \
         /* 10 <= d <= 32: one workgroup per series walks the chain (mf_adj.hip) */                                     \
-        return mf::adj_cholesky_grad<T>(B, n, d, ldiag, lsub, g_ldiag, g_lsub, g_diag, g_sub, S(stream));              \
+        return mf::adj_cholesky_grad<T>(B, n, d, ldiag, lsub, g_ldiag, g_lsub, g_diag, g_sub, ws, ws_bytes, S(stream)); \
     }                                                                                                                  \
     int mf_btd_diag_of_inverse_grad_##SUF(int64_t B, int64_t n, int d, const T* ldiag, const T* lsub, const T* sigma,  \
                                           const T* g_diag, const T* g_sub, T* g_ldiag, T* g_lsub, void* ws,            \
@@ -497,7 +497,7 @@ int mf_kf_loglik_f32(int64_t B, int64_t T, int d, int m, const float* mu0, const
                                                        S(stream));                                                     \
             if (rc != -100 || !mf::adj_covers(d)) return rc;                                                           \
         }                                                                                                              \
-        return mf::adj_diag_of_inverse_grad<T>(B, n, d, ldiag, lsub, sigma, g_diag, g_sub, g_ldiag, g_lsub, S(stream)); \
+        return mf::adj_diag_of_inverse_grad<T>(B, n, d, ldiag, lsub, sigma, g_diag, g_sub, g_ldiag, g_lsub, ws, ws_bytes, S(stream)); \
     }
 
 #define MF_DEFINE5(SUF, T)                                                                                             \
@@ -750,8 +750,8 @@ size_t mf_btd_grad_workspace_bytes(int64_t B, int64_t T, int d, int elem_size) {
     size_t ws = 0;
     if (elem_size == 4) { if (const auto* t = table_for<float>(d)) ws = t->btd_grad_ws(B, T); }
     else if (const auto* t = table_for<double>(d)) ws = t->btd_grad_ws(B, T);
-    // 10 <= d <= 32: the workgroup-per-series kernels (mf_adj.hip) need no workspace; a token size says "covered"
-    if (ws == 0 && mf::adj_covers(d)) ws = 16;
+    // 10 <= d <= 32: the parallel-in-time adjoints on register tiles (mf_adj.hip)
+    if (ws == 0 && mf::adj_covers(d)) ws = mf::adj_grad_ws(B, T, d, elem_size);
     return ws;
 }
 

@@ -172,14 +172,16 @@ int panel_red_f64(const RedSys<double>& in, const RedSys<double>& out, long B, l
 int panel_red_f32(const RedSys<float>& in, const RedSys<float>& out, long B, long P, int d, float add_const, float* out_scalar,
                   int* info, int final_level, hipStream_t st);
 
-// mf_adj.hip: reverse mode through cholesky / block_diagonal_of_inverse for 10 <= d <= 32, one workgroup per series (no workspace)
+// mf_adj.hip: reverse mode through cholesky / block_diagonal_of_inverse for 10 <= d <= 32 on register MFMA tiles: parallel in time
+// (local terms + congruence scans; needs adj_grad_ws bytes) or, without a workspace / for short chains, a wavefront per series
 bool adj_covers(int d);
+size_t adj_grad_ws(long B, long n, int d, int elem_size);
 template <typename T>
 int adj_cholesky_grad(long B, long n, int d, const T* ldiag, const T* lsub, const T* g_ldiag, const T* g_lsub, T* g_diag, T* g_sub,
-                      hipStream_t st);
+                      void* ws, size_t ws_bytes, hipStream_t st);
 template <typename T>
 int adj_diag_of_inverse_grad(long B, long n, int d, const T* ldiag, const T* lsub, const T* sigma, const T* g_diag, const T* g_sub,
-                             T* g_ldiag, T* g_lsub, hipStream_t st);
+                             T* g_ldiag, T* g_lsub, void* ws, size_t ws_bytes, hipStream_t st);
 
 #define MF_DECLARE_BIG(SUF, T)                                                                                               \
     int big_cholesky_##SUF(long B, long n, int d, const T* diag, const T* sub, T* ldiag, T* lsub, void* ws, size_t ws_bytes,  \
