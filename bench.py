@@ -458,7 +458,7 @@ def other_configs(dev):
                 "Python loop over the T blocks"}
     # reverse mode through the OPERATORS at the reference's largest tested shape (d = 30, T = 1001, one chain;
     # tests/unit/test_ssm_gaussian_transformations.py:40-46): cholesky -> block_diagonal_of_inverse (+ sub-diagonal blocks) and back.
-    # Round 6: the adjoints are one launch each (csrc/mf_adj.hip, a wavefront per series on register MFMA tiles); rounds 4-5: a Python
+    # Round 6 (csrc/mf_adj.hip, register MFMA tiles): local terms per block + congruence scans, parallel in time; rounds 4-5: a Python
     # loop over the blocks
     n30, d30 = 1001, 30
     ld = torch.tril((4.0 / d30) * 0.3 * torch.randn(4, n30, d30, d30, dtype=torch.float64, device=dev, generator=g), -1) + torch.diag_embed(

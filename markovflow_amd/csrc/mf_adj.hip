@@ -2,19 +2,20 @@
 // 10 <= d <= 32 (banded_matrices registers gradients for cholesky_band / inverse_from_cholesky_band, block_tri_diag.py:22-31; the
 // reference differentiates them at d = 30, T = 1001, tests/unit/test_ssm_gaussian_transformations.py:40-46).
 //
-// Both adjoints are recurrences along the chain whose step is a dozen d x d products and one triangular inversion - sequential in
-// time whatever the formulation (the local adjoint of a dense Cholesky is a general linear map on d^2 numbers: it does not compose
-// as a scan of d x d matrices).  Rounds 4-5 ran them for d > 9 as a Python loop over the T blocks, ~10 torch launches per block
-// (10^4 launches at the reference's shape).  Here: ONE launch per adjoint, one WAVEFRONT per series walking its chain with every
-// matrix of the step in registers as 16 x 16 MFMA tiles (mf_wave.hpp's toolkit: products in the P^T Q form, the triangular
-// inversion on DPP, transposes through a wave-private LDS image, no barrier).  Every product below is arranged so that the left
-// factor is available transposed - either loaded transposed from memory (load_mat_t: the same cache lines) or formed transposed by
-// a second product - because a register tile can only enter a product as P in P^T Q.  The first version of this file kept the
-// matrices in LDS with scalar multiply-adds in a 256-thread workgroup: 42 us per block per adjoint at d = 30 (LDS latency and
-// bandwidth, ~15 barriers per block) against 14 us here, 3.7 us at d <= 16; profiles/r06_adjoints.txt has the sequence.  What is
-// left at f64, d > 16 is half matrix-core time (~310 v_mfma_f64_16x16x4 of 64 cycles per block on ONE SIMD - the series are the only
-// parallelism) and half the dependent chain of a step (inversion, transposes, loads).
-// (d <= 9 has the register kernels with a scan in time, mf_btd_par.hpp.)
+// Two forms, both on 16 x 16 MFMA register tiles (mf_wave.hpp's toolkit: products as P^T Q, the triangular inversion on DPP, transposes
+// through a wave-private LDS image, no workgroup barrier):
+//   * PARALLEL IN TIME (second half of this file; needs adj_grad_ws bytes): each adjoint = terms that are local in time, one
+//     wavefront per (series, block), around ONE congruence recursion X_k = N_k + G_k^T X_{k+1} G_k (cholesky; backwards) or
+//     X_{k+1} = N_{k+1} + G_k X_k G_k^T (inverse blocks; forwards) with G_k = W_k L_k^-1, which runs as composed maps per chunk, a pass
+//     over the chunk ends and a walk per chunk - the derivation and the d <= 9 kernels are mf_btd_par.hpp's.  d = 30, T = 1001, fp64:
+//     backward 0.83 ms at B = 4 (0.7 x the forward), 16 ms at B = 256 (1.5 x).
+//   * SEQUENTIAL (first half; no workspace, short chains): one wavefront per series walks the block recurrences - a dozen products
+//     and one inversion per block: 13.7 us per block per adjoint at d = 30 in fp64 (27 ms for one chain of 1001 blocks), 3.7 us at
+//     d <= 16.  Every product is arranged so that the left factor is available transposed - loaded transposed (load_mat_t: the same
+//     cache lines) or formed transposed by a second product - because a register tile can only enter a product as P in P^T Q.
+// Rounds 4-5 ran both adjoints for d > 9 as a Python loop over the T blocks, ~10 torch launches per block (10^4 launches at the
+// reference's shape); the first kernel form of round 6 kept the matrices in LDS with scalar multiply-adds (42 us per block);
+// profiles/r06_adjoints.txt has the sequence.  (d <= 9: the register kernels with the same scans, mf_btd_par.hpp.)
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>

@@ -128,10 +128,14 @@ def _random_factor(rng, batch, n, d, dtype=F64):
     ((3,), 300, 6, True, "both"), ((2,), 1000, 4, True, "both"), ((4100,), 12, 4, True, "both"), ((2, 3), 40, 2, True, "both"),
     ((5,), 64, 9, True, "both"), ((3,), 50, 7, True, "both"), ((2,), 30, 5, False, "both"), ((3,), 1, 3, False, "both"),
     ((2,), 2, 6, True, "both"), ((2,), 200, 6, True, "diag"), ((2,), 200, 6, True, "sub"), ((1,), 3000, 1, True, "both"),
-    # 10 <= d <= 32 (round 6, csrc/mf_adj.hip: one workgroup per series walks the recurrence) incl. the reference's largest tested
-    # operator shape, d = 30, T = 1001 (tests/unit/test_ssm_gaussian_transformations.py:40-46)
+    # 10 <= d <= 32 (round 6, csrc/mf_adj.hip, register MFMA tiles): chains shorter than 32 blocks - one wavefront per series walks
+    # the recurrence - and longer ones - local terms + congruence scans, parallel in time (ragged chunk partitions, one of the two
+    # incoming gradients missing) - incl. the reference's largest tested operator shape, d = 30, T = 1001
+    # (tests/unit/test_ssm_gaussian_transformations.py:40-46)
     ((3,), 40, 12, True, "both"), ((2,), 25, 16, True, "both"), ((2,), 30, 24, True, "diag"), ((2,), 30, 24, True, "sub"),
     ((1,), 12, 32, True, "both"), ((2,), 9, 17, False, "both"), ((3,), 1, 20, False, "both"), ((1,), 1001, 30, True, "both"),
+    ((2,), 77, 16, True, "both"), ((3,), 100, 20, True, "diag"), ((2,), 64, 32, True, "sub"), ((5,), 33, 10, True, "both"),
+    ((2,), 130, 24, True, "both"), ((70,), 45, 15, True, "both"),
 ])
 def test_hip_operator_adjoints_against_the_torch_recursions(batch, n, d, with_sub, which):
     """The kernels against the block-by-block torch recursions (which tests/test_autograd_ops.py pins on dense autograd): few long
