@@ -383,8 +383,10 @@ int mf_sde_conditional_statistics_f32(int64_t n, int d, const float* A_mt, const
  *     forward in reverse mode, A_{k+1} = Qbar_{k+1} + G_k A_k G_k^T, between two local kernels.
  * lsub == NULL: block-diagonal factor.  Workspace: mf_btd_grad_workspace_bytes (0: state dimension without these kernels,
  * the entry points then return -100).  d <= 9 (register kernels) and 10 <= d <= 15 where the row scan takes the recursion;
- * 10 <= d <= 32 otherwise (round 6): one workgroup per series walks the recurrence with the step's matrices in LDS
- * (csrc/mf_adj.hip; the reference differentiates these operators at d = 30, T = 1001) - a token workspace size, nothing is used.
+ * 10 <= d <= 32 otherwise (round 6, csrc/mf_adj.hip, 16 x 16 MFMA register tiles; the reference differentiates these operators at
+ * d = 30, T = 1001): with a workspace of mf_btd_grad_workspace_bytes and at least 32 blocks, terms local in time (a wavefront per
+ * block) around one congruence recursion per adjoint, partitioned in time; otherwise (shorter chains, ws == NULL) one wavefront
+ * per series walks the block recurrences.
  */
 size_t mf_btd_grad_workspace_bytes(int64_t B, int64_t T, int d, int elem_size);
 int mf_btd_cholesky_grad_f64(int64_t B, int64_t T, int d, const double* ldiag, const double* lsub, const double* g_ldiag,
