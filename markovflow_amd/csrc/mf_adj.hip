@@ -623,7 +623,10 @@ size_t adj_grad_ws(long B, long n, int d, int elem_size) {
     if (!adj_covers(d) || B < 1 || n < 1) return 0;
     long P = 1, L = n;
     wave_udl_partition(B, n, d < 16 ? 16 : d, elem_size, P, L);
-    return (3 * size_t(B) * n + 3 * size_t(B) * P) * size_t(d) * d * elem_size + 256;
+    const size_t need = (3 * size_t(B) * n + 3 * size_t(B) * P) * size_t(d) * d * elem_size + 256;
+    // (three arrays of the size of the factor: beyond 8 GiB - thousands of series, which fill the chip with a wavefront each - the
+    // sequential form, which needs none, takes the call; the token says "covered")
+    return need <= (size_t(8) << 30) ? need : 16;
 }
 namespace {
 constexpr long ADJ_PAR_MIN_BLOCKS = 32;          // shorter chains: the sequential kernels
@@ -633,7 +636,8 @@ template <typename T> struct AdjWs {
 };
 template <typename T> bool adj_carve(void* ws, size_t ws_bytes, long B, long n, int d, AdjWs<T>& w) {
     static const bool seq = getenv("MF_ADJ_SEQUENTIAL") != nullptr;       // (A/B switch)
-    if (seq || !ws || n < ADJ_PAR_MIN_BLOCKS || ws_bytes < adj_grad_ws(B, n, d, (int)sizeof(T))) return false;
+    const size_t need = adj_grad_ws(B, n, d, (int)sizeof(T));
+    if (seq || !ws || n < ADJ_PAR_MIN_BLOCKS || need <= 16 || ws_bytes < need) return false;
     wave_udl_partition(B, n, d < 16 ? 16 : d, (int)sizeof(T), w.P, w.L);
     const size_t blk = size_t(B) * n * d * d, red = size_t(B) * w.P * d * d;
     T* p = static_cast<T*>(ws);

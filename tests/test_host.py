@@ -63,6 +63,9 @@ def test_workspace_queries_of_the_round_6_paths():
         assert lib.mf_ssm_kl_workspace_bytes(512, 1000, 32, esz) > 0
         assert lib.mf_ssm_kl_workspace_bytes(8, 1, 16, esz) == 0                              # one block: the operator route
     assert lib.mf_ssm_kl_workspace_bytes(8, 100, 40, 4) == 0                                   # d > 32: the operator route
+    # operator adjoints at 10 <= d <= 32: three arrays of the factor's size + the chunk states; a token beyond 8 GiB (sequential form)
+    assert lib.mf_btd_grad_workspace_bytes(4, 1001, 30, 8) >= 3 * 4 * 1001 * 30 * 30 * 8
+    assert lib.mf_btd_grad_workspace_bytes(8192, 1001, 32, 8) == 16
     assert lib.mf_info_flat_index(0) == -1 and lib.mf_info_flat_index(1) == -1                 # no error / block unknown
     assert lib.mf_info_flat_index(0x7fffffff - 137) == 137
 
