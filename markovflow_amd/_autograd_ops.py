@@ -15,8 +15,11 @@ FORWARD is the HIP kernel behind the operator and whose backward is
   ``G_k = W_k L_k^-1`` (the scan of the marginals' adjoint: parallel in time for few series, a lane per series for many) and an axpy;
 * ``block_diagonal_of_inverse`` (+ sub-diagonal blocks): HIP (``mf_btd_diag_of_inverse_grad_*``): the same recursion run forward
   (``A_{k+1} = Qbar_{k+1} + G_k A_k G_k^T``) between two local kernels.
-  Beyond the state dimensions of those kernels (d > 9) both fall back to a block-by-block loop of batched torch products
-  (``_cholesky_backward_torch`` / ``_inverse_blocks_backward_torch``), which is also what the CPU tests compare them against.
+  10 <= d <= 32: the same split on register MFMA tiles (csrc/mf_adj.hip).  Beyond the kernels (d > 32, or under ``create_graph``)
+  a GPU tensor takes the same split in batched torch products with the congruence recursion as a Hillis-Steele scan in time
+  (``_cholesky_backward_scan`` / ``_inverse_blocks_backward_scan``: log2 T rounds, no Python loop over the blocks); the
+  block-by-block loops (``_cholesky_backward_torch`` / ``_inverse_blocks_backward_torch``) remain for CPU tensors and are what the
+  tests compare everything against.
 
 Values always come from the HIP kernels.
 """
@@ -28,8 +31,8 @@ from . import _lib
 
 
 def _hip_grad_ws(ldiag: torch.Tensor):
-    """``(B, n, d, workspace bytes)`` when the operator-adjoint kernels cover these blocks (HIP tensor; d <= 9: local kernels + a
-    scan in time, 10 <= d <= 32: one workgroup per series walks the chain, ``csrc/mf_adj.hip``), else None."""
+    """``(B, n, d, workspace bytes)`` when the operator-adjoint kernels cover these blocks (HIP tensor; d <= 9 and 10 <= d <= 32,
+    ``csrc/mf_adj.hip``: local kernels + a congruence scan in time), else None."""
     if not ldiag.is_cuda:
         return None
     n, d = ldiag.shape[-3], ldiag.shape[-1]
@@ -56,6 +59,81 @@ def _chol_adjoint(chol: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
     return 0.5 * (x + _tr(x))
 
 
+def _scan_pays(t: torch.Tensor) -> bool:
+    """A GPU tensor with more than a handful of blocks: the scan forms below instead of a Python loop over the blocks."""
+    return t.is_cuda and t.shape[-3] > 8
+
+
+def _congruence_scan(g: torch.Tensor, c: torch.Tensor, backward: bool) -> torch.Tensor:
+    """``backward``: ``X_k = C_k + G_k^T X_{k+1} G_k`` (``X_{n-1} = C_{n-1}``); else ``X_{k+1} = C_{k+1} + G_k X_k G_k^T`` (``X_0 = C_0``).
+    ``g [.., n-1, d, d]``, ``c [.., n, d, d]``.  Hillis-Steele over the maps ``X -> M^T X M + N`` (``M X M^T + N`` forwards): element k
+    absorbs the composite ``off`` blocks further along; log2(n) rounds of batched products, differentiable."""
+    n = c.shape[-3]
+    if n == 1:
+        return c
+    if not backward:                                   # the forward recursion is the backward one on the reversed chain with G^T
+        return torch.flip(_congruence_scan(torch.flip(_tr(g), dims=(-3,)), torch.flip(c, dims=(-3,)), True), dims=(-3,))
+    m = torch.cat([g, torch.zeros_like(g[..., :1, :, :])], dim=-3)      # block n - 1 has nothing beyond it
+    acc = c
+    off = 1
+    while off < n:
+        m_far, n_far = m[..., off:, :, :], acc[..., off:, :, :]
+        m_near = m[..., :-off, :, :]
+        acc = torch.cat([acc[..., :-off, :, :] + _tr(m_near) @ n_far @ m_near, acc[..., -off:, :, :]], dim=-3)
+        m = torch.cat([m_far @ m_near, torch.zeros_like(m[..., -off:, :, :])], dim=-3)
+        off *= 2
+    return acc
+
+
+def _cholesky_backward_scan(ldiag, lsub, g_ldiag, g_lsub):
+    """The adjoint of the block Cholesky as terms local in time + ONE congruence recursion (the split of csrc/mf_btd_par.hpp /
+    mf_adj.hip): ``Sbar(loc) = Wbar L^-1``, ``Lbar(eff) = Lbar - tril(Sbar(loc)^T W)``, ``C = sym(L^-T Phi(L^T Lbar(eff)) L^-1)``,
+    ``Z_k = C_k + G_k^T Z_{k+1} G_k`` with ``G = W L^-1``; ``Dbar = Z``, ``Sbar_k = Sbar_k(loc) - 2 Z_{k+1} G_k``."""
+    lbar = torch.tril(g_ldiag) if g_ldiag is not None else torch.zeros_like(ldiag)
+    if lsub is None:
+        return _chol_adjoint(ldiag, lbar), None
+    low = torch.tril(ldiag)
+    eye = torch.eye(ldiag.shape[-1], dtype=ldiag.dtype, device=ldiag.device).expand(ldiag.shape)
+    linv = torch.linalg.solve_triangular(low, eye, upper=False)
+    g = lsub @ linv[..., :-1, :, :]
+    if g_lsub is not None:
+        s_loc = g_lsub @ linv[..., :-1, :, :]
+        corr = torch.tril(_tr(s_loc) @ lsub)
+        lbar = torch.cat([lbar[..., :-1, :, :] - corr, lbar[..., -1:, :, :]], dim=-3)
+    else:
+        s_loc = torch.zeros_like(lsub)
+    z = _congruence_scan(g, _chol_adjoint(ldiag, lbar), True)
+    return z, s_loc - 2.0 * z[..., 1:, :, :] @ g
+
+
+def _inverse_blocks_backward_scan(ldiag, lsub, sigma, g_diag, g_sub):
+    """The adjoint of the block Takahashi recursion in the same split (``sigma``: the diagonal blocks of the inverse, the forward's
+    output): ``A_0 = sym(Sbar_0)``, ``A_{k+1} = sym(Sbar_{k+1}) - sym(subbar_k G_k^T) + G_k A_k G_k^T``;
+    ``Lbar_k = -2 tril(L^-T (L^-1 A_k L^-T)) - tril(G_k^T Wbar_k)``, ``Wbar_k = (2 Sigma_{k+1} G_k A_k - Sigma_{k+1} subbar_k) L_k^-T``."""
+    low = torch.tril(ldiag)
+    eye = torch.eye(ldiag.shape[-1], dtype=ldiag.dtype, device=ldiag.device).expand(ldiag.shape)
+    linv = torch.linalg.solve_triangular(low, eye, upper=False)
+    q = 0.5 * (g_diag + _tr(g_diag)) if g_diag is not None else torch.zeros_like(ldiag)
+    if lsub is None:
+        a = q
+        g = None
+    else:
+        g = lsub @ linv[..., :-1, :, :]
+        if g_sub is not None:
+            x = g_sub @ _tr(g)
+            q = torch.cat([q[..., :1, :, :], q[..., 1:, :, :] - 0.5 * (x + _tr(x))], dim=-3)
+        a = _congruence_scan(g, q, False)
+    lbar = -2.0 * torch.tril(_tr(linv) @ (linv @ a @ _tr(linv)))
+    if lsub is None:
+        return lbar, None
+    x = 2.0 * g @ a[..., :-1, :, :]
+    if g_sub is not None:
+        x = x - g_sub
+    wbar = sigma[..., 1:, :, :] @ x @ _tr(linv[..., :-1, :, :])
+    lbar = torch.cat([lbar[..., :-1, :, :] - torch.tril(_tr(g) @ wbar), lbar[..., -1:, :, :]], dim=-3)
+    return lbar, wbar
+
+
 class BtdCholesky(torch.autograd.Function):
     """``SymmetricBlockTriDiagonal.cholesky`` (block_tri_diag.py:423-436).  ``run(diag, sub) -> (ldiag, lsub)`` is the kernel."""
 
@@ -76,6 +154,8 @@ class BtdCholesky(torch.autograd.Function):
         # silently, so that case takes the torch expressions below, which are recorded)
         plan = None if torch.is_grad_enabled() else _hip_grad_ws(ldiag)
         if plan is None:
+            if _scan_pays(ldiag):
+                return (None,) + _cholesky_backward_scan(ldiag, lsub, g_ldiag, g_lsub)
             return (None,) + _cholesky_backward_torch(ldiag, lsub, g_ldiag, g_lsub)
         bsz, n, d, wsb = plan
         flat = lambda t: None if t is None else t.reshape((bsz, -1, d, d)).contiguous()           # noqa: E731
@@ -205,7 +285,10 @@ class BtdInverseBlocks(torch.autograd.Function):
         # silently, so that case takes the torch expressions below, which are recorded)
         plan = None if torch.is_grad_enabled() else _hip_grad_ws(ldiag)
         if plan is None:
-            g_chol, g_w = _inverse_blocks_backward_torch(ldiag, lsub, g_diag, g_sub)
+            if _scan_pays(ldiag):
+                g_chol, g_w = _inverse_blocks_backward_scan(ldiag, lsub, odiag, g_diag, g_sub)
+            else:
+                g_chol, g_w = _inverse_blocks_backward_torch(ldiag, lsub, g_diag, g_sub)
             return None, g_chol, g_w, None
         bsz, n, d, wsb = plan
         flat = lambda t: None if t is None else t.reshape((bsz, -1, d, d)).contiguous()           # noqa: E731

@@ -157,3 +157,36 @@ def test_inverse_blocks_adjoint(batch, n, d, with_sub):
     for x1, x2 in zip(*outs):
         if x1 is not None:
             np.testing.assert_allclose(x1.numpy(), x2.numpy(), rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize("batch,n,d", [((), 1, 3), ((2,), 2, 4), ((3,), 9, 3), ((2,), 17, 5), ((1,), 64, 2), ((2,), 33, 6)])
+@pytest.mark.parametrize("which", ["both", "diag", "sub"])
+def test_scan_forms_of_the_operator_adjoints_against_the_block_loops(batch, n, d, which):
+    """``_cholesky_backward_scan`` / ``_inverse_blocks_backward_scan`` (terms local in time + one congruence recursion as a
+    Hillis-Steele scan: what a GPU tensor beyond the adjoint kernels takes instead of a Python loop over the blocks) against the
+    block-by-block recursions the tests above pin on dense autograd."""
+    gen = torch.Generator().manual_seed(7)
+    f64 = torch.float64
+    ld = torch.tril(0.3 * torch.randn(*batch, n, d, d, dtype=f64, generator=gen), -1) + torch.diag_embed(
+        1 + torch.rand(*batch, n, d, dtype=f64, generator=gen))
+    ls = 0.3 * torch.randn(*batch, n - 1, d, d, dtype=f64, generator=gen) if n > 1 else None
+    g1 = torch.randn(ld.shape, dtype=f64, generator=gen) if which in ("both", "diag") else None
+    g2 = torch.randn(ls.shape, dtype=f64, generator=gen) if (ls is not None and which in ("both", "sub")) else None
+    a, b = ag._cholesky_backward_torch(ld, ls, g1, g2), ag._cholesky_backward_scan(ld, ls, g1, g2)
+    torch.testing.assert_close(b[0], a[0], rtol=1e-11, atol=1e-12)
+    if ls is not None:
+        torch.testing.assert_close(b[1], a[1], rtol=1e-11, atol=1e-12)
+    # the diagonal blocks of the inverse (the forward's output the scan form reuses): block Takahashi
+    eye = torch.eye(d, dtype=f64).expand(ld.shape)
+    linv = torch.linalg.solve_triangular(torch.tril(ld), eye, upper=False)
+    base = linv.transpose(-1, -2) @ linv
+    sig = [None] * n
+    sig[n - 1] = base[..., n - 1, :, :]
+    for k in range(n - 2, -1, -1):
+        g = ls[..., k, :, :] @ linv[..., k, :, :]
+        sig[k] = base[..., k, :, :] + g.transpose(-1, -2) @ sig[k + 1] @ g
+    sigma = torch.stack(sig, dim=-3)
+    c, e = ag._inverse_blocks_backward_torch(ld, ls, g1, g2), ag._inverse_blocks_backward_scan(ld, ls, sigma, g1, g2)
+    torch.testing.assert_close(e[0], c[0], rtol=1e-11, atol=1e-12)
+    if ls is not None:
+        torch.testing.assert_close(e[1], c[1], rtol=1e-11, atol=1e-12)

@@ -204,3 +204,34 @@ def test_hip_operator_adjoints_fp32():
     want_d, want_s = ag._cholesky_backward_torch(ldiag.double(), lsub.double(), g1.double(), g2.double())
     assert float((gd.double() - want_d).abs().max()) <= 2e-4 * float(want_d.abs().max())
     assert float((gs.double() - want_s).abs().max()) <= 2e-4 * float(want_s.abs().max())
+
+
+@pytest.mark.parametrize("d,n,bsz", [(40, 50, 2), (64, 130, 1), (33, 9, 3)])
+def test_operator_adjoints_beyond_the_kernels_take_the_scan_forms(d, n, bsz):
+    """d > 32 (fp32 operators on the panel / tile engine): no adjoint kernel; a GPU tensor takes the scan forms of
+    markovflow_amd/_autograd_ops.py (local terms + a Hillis-Steele congruence scan, no Python loop over the blocks) - checked
+    against the block loops in float32 arithmetic on the same device."""
+    from markovflow_amd import _autograd_ops as ag
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    f32 = torch.float32
+    ld = torch.tril((4.0 / d) * 0.3 * torch.randn(bsz, n, d, d, dtype=f32, device=DEV, generator=gen), -1) + torch.diag_embed(
+        1 + torch.rand(bsz, n, d, dtype=f32, device=DEV, generator=gen))
+    ls = (2.0 / d) * 0.3 * torch.randn(bsz, n - 1, d, d, dtype=f32, device=DEV, generator=gen)
+    assert ag._hip_grad_ws(ld) is None and ag._scan_pays(ld)
+    dg = ld @ ld.transpose(-1, -2)
+    dg[:, 1:] += ls @ ls.transpose(-1, -2)
+    sb = ls @ ld[:, :-1].transpose(-1, -2)
+    dg.requires_grad_(True); sb.requires_grad_(True)
+    w = torch.randn(bsz, n, d, d, dtype=f32, device=DEV, generator=gen)
+    inv_d, inv_s = mfa.SymmetricBlockTriDiagonal(dg, sb).cholesky._diag_and_sub_of_inverse(want_sub=True)
+    (torch.sum(inv_d * w) + torch.sum(inv_s)).backward()
+    got_d, got_s = dg.grad.clone(), sb.grad.clone()
+    # the same chain with the block loops
+    chol = mfa.SymmetricBlockTriDiagonal(dg.detach(), sb.detach()).cholesky
+    cd, cs = chol.block_diagonal, chol.block_sub_diagonal
+    gl, gw = ag._inverse_blocks_backward_torch(cd, cs, w, torch.ones_like(sb))
+    want_d, want_s = ag._cholesky_backward_torch(cd, cs, gl, gw)
+    scale = float(want_d.abs().max())
+    assert float((got_d - want_d).abs().max()) <= 2e-3 * scale
+    assert float((got_s - want_s).abs().max()) <= 2e-3 * max(float(want_s.abs().max()), scale)
+
